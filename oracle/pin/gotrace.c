@@ -1,0 +1,478 @@
+/*
+ * gotrace — ptrace harness that pins the oracle against the reference's own prebuilt binary.
+ *
+ * TEST INFRASTRUCTURE ONLY. Runs only in the build container (needs /root/reference/test_run);
+ * its output (tests/golden/ref_trace_*.json: seeds + SHA-256 digests, no reference text) is what travels.
+ *
+ * Why: the reference (Go 1.16.6 + Lattigo fork test_lattigo@eb33b0555aaa) draws keys and encryption noise
+ * from crypto-random, serialises nothing and has no tests, so nothing in its tree pins ciphertext
+ * coefficients. The binary itself, however, runs here. This tool starts it under
+ * ptrace, and at the entry of main.conv_then_pack (conv.go:522) OVERWRITES every input of the hot path —
+ * ct_in (conv.go:527), pl_ker[i] (conv.go:527) and, at the first use of each Galois key inside
+ * rlwe.(*KeySwitcher).SwitchKeysInPlace, the level-0 slices of that switching key (conv.go:291) — with
+ * residues derived from a counter-based splitmix64 stream. It then records SHA-256 digests of
+ *   - every plain_idx[s] (conv.go:241-261; pins Lattigo's psi choice + NTT ordering),
+ *   - the ciphertext after each MulNew / SetScale (conv.go:527-528),
+ *   - per pack-tree node: MulNew, SubNew, Add, SwitchKeysInPlace(p0,p1), RotateGal, Add (conv.go:288-292),
+ *   - the ciphertext returned by conv_then_pack (conv.go:545) and its Scale.
+ * The oracle replays the same seeds and must reproduce every digest (tests/test_oracle_pin.py).
+ *
+ * Go 1.16 uses the stack ABI0: at a function's first instruction [rsp] = return address and the
+ * arguments (receiver first) start at [rsp+8]; results follow the arguments.
+ */
+#define _GNU_SOURCE
+#include <errno.h>
+#include <fcntl.h>
+#include <inttypes.h>
+#include <signal.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/ptrace.h>
+#include <sys/types.h>
+#include <sys/user.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+/* ---------- sha256 (FIPS 180-4) ---------- */
+typedef struct { uint32_t h[8]; uint8_t buf[64]; uint64_t len; size_t fill; } sha256_t;
+static const uint32_t K256[64] = {
+0x428a2f98,0x71374491,0xb5c0fbcf,0xe9b5dba5,0x3956c25b,0x59f111f1,0x923f82a4,0xab1c5ed5,0xd807aa98,0x12835b01,0x243185be,0x550c7dc3,
+0x72be5d74,0x80deb1fe,0x9bdc06a7,0xc19bf174,0xe49b69c1,0xefbe4786,0x0fc19dc6,0x240ca1cc,0x2de92c6f,0x4a7484aa,0x5cb0a9dc,0x76f988da,
+0x983e5152,0xa831c66d,0xb00327c8,0xbf597fc7,0xc6e00bf3,0xd5a79147,0x06ca6351,0x14292967,0x27b70a85,0x2e1b2138,0x4d2c6dfc,0x53380d13,
+0x650a7354,0x766a0abb,0x81c2c92e,0x92722c85,0xa2bfe8a1,0xa81a664b,0xc24b8b70,0xc76c51a3,0xd192e819,0xd6990624,0xf40e3585,0x106aa070,
+0x19a4c116,0x1e376c08,0x2748774c,0x34b0bcb5,0x391c0cb3,0x4ed8aa4a,0x5b9cca4f,0x682e6ff3,0x748f82ee,0x78a5636f,0x84c87814,0x8cc70208,
+0x90befffa,0xa4506ceb,0xbef9a3f7,0xc67178f2};
+#define ROR(x,n) (((x)>>(n))|((x)<<(32-(n))))
+static void sha_block(sha256_t *s, const uint8_t *p) {
+    uint32_t w[64], a,b,c,d,e,f,g,h;
+    for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4*i]<<24 | (uint32_t)p[4*i+1]<<16 | (uint32_t)p[4*i+2]<<8 | p[4*i+3];
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = ROR(w[i-15],7)^ROR(w[i-15],18)^(w[i-15]>>3), s1 = ROR(w[i-2],17)^ROR(w[i-2],19)^(w[i-2]>>10);
+        w[i] = w[i-16]+s0+w[i-7]+s1;
+    }
+    a=s->h[0];b=s->h[1];c=s->h[2];d=s->h[3];e=s->h[4];f=s->h[5];g=s->h[6];h=s->h[7];
+    for (int i = 0; i < 64; i++) {
+        uint32_t S1=ROR(e,6)^ROR(e,11)^ROR(e,25), ch=(e&f)^(~e&g), t1=h+S1+ch+K256[i]+w[i];
+        uint32_t S0=ROR(a,2)^ROR(a,13)^ROR(a,22), mj=(a&b)^(a&c)^(b&c), t2=S0+mj;
+        h=g;g=f;f=e;e=d+t1;d=c;c=b;b=a;a=t1+t2;
+    }
+    s->h[0]+=a;s->h[1]+=b;s->h[2]+=c;s->h[3]+=d;s->h[4]+=e;s->h[5]+=f;s->h[6]+=g;s->h[7]+=h;
+}
+static void sha_init(sha256_t *s) {
+    static const uint32_t iv[8]={0x6a09e667,0xbb67ae85,0x3c6ef372,0xa54ff53a,0x510e527f,0x9b05688c,0x1f83d9ab,0x5be0cd19};
+    memcpy(s->h, iv, sizeof iv); s->len = 0; s->fill = 0;
+}
+static void sha_update(sha256_t *s, const void *data, size_t n) {
+    const uint8_t *p = data; s->len += n;
+    while (n) {
+        size_t k = 64 - s->fill; if (k > n) k = n;
+        memcpy(s->buf + s->fill, p, k); s->fill += k; p += k; n -= k;
+        if (s->fill == 64) { sha_block(s, s->buf); s->fill = 0; }
+    }
+}
+static void sha_final(sha256_t *s, char hex[65]) {
+    uint64_t bits = s->len * 8; uint8_t pad = 0x80; sha_update(s, &pad, 1);
+    uint8_t z = 0; while (s->fill != 56) sha_update(s, &z, 1);
+    uint8_t l[8]; for (int i = 0; i < 8; i++) l[i] = (uint8_t)(bits >> (56 - 8*i));
+    sha_update(s, l, 8);
+    for (int i = 0; i < 8; i++) sprintf(hex + 8*i, "%08x", s->h[i]);
+}
+
+/* ---------- counter-based splitmix64 stream (same function in tests/seedgen.py and oracle) ---------- */
+static inline uint64_t splitmix64_at(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* ---------- tracee memory ---------- */
+static pid_t g_pid; static int g_mem = -1;
+static void rd(uint64_t addr, void *buf, size_t n) {
+    if (pread(g_mem, buf, n, (off_t)addr) != (ssize_t)n) { fprintf(stderr, "rd %#lx+%zu failed: %s\n", addr, n, strerror(errno)); exit(3); }
+}
+static void wr(uint64_t addr, const void *buf, size_t n) {
+    if (pwrite(g_mem, buf, n, (off_t)addr) != (ssize_t)n) { fprintf(stderr, "wr %#lx+%zu failed: %s\n", addr, n, strerror(errno)); exit(3); }
+}
+static uint64_t rd64(uint64_t a) { uint64_t v; rd(a, &v, 8); return v; }
+static double rdf64(uint64_t a) { double v; rd(a, &v, 8); return v; }
+
+/* ---------- breakpoints ---------- */
+typedef void (*handler_t)(pid_t tid, struct user_regs_struct *r, void *ud);
+typedef struct { uint64_t addr; uint8_t orig; int armed; handler_t fn; void *ud; int refs; } bp_t;
+#define MAXBP 256
+static bp_t g_bp[MAXBP]; static int g_nbp;
+static bp_t *bp_find(uint64_t a) { for (int i = 0; i < g_nbp; i++) if (g_bp[i].addr == a && g_bp[i].refs > 0) return &g_bp[i]; return NULL; }
+static void bp_arm(bp_t *b) { uint8_t cc = 0xcc; rd(b->addr, &b->orig, 1); wr(b->addr, &cc, 1); b->armed = 1; }
+static void bp_disarm(bp_t *b) { if (b->armed) { wr(b->addr, &b->orig, 1); b->armed = 0; } }
+static bp_t *bp_add(uint64_t a, handler_t fn, void *ud) {
+    bp_t *b = bp_find(a);
+    if (b) { b->refs++; return b; }
+    for (int i = 0; i < g_nbp; i++) if (g_bp[i].refs == 0) { b = &g_bp[i]; break; }
+    if (!b) { if (g_nbp == MAXBP) { fprintf(stderr, "too many bps\n"); exit(3); } b = &g_bp[g_nbp++]; }
+    b->addr = a; b->fn = fn; b->ud = ud; b->refs = 1; bp_arm(b); return b;
+}
+static void bp_release(bp_t *b) { if (--b->refs == 0) bp_disarm(b); }
+
+/* pending function returns: LIFO per return address (Go may relocate the goroutine stack between
+ * entry and return, so the stack pointer cannot be used to match them). */
+typedef struct { uint64_t ret_addr; handler_t fn; void *ud; } pend_t;
+#define MAXPEND 64
+static pend_t g_pend[MAXPEND]; static int g_npend;
+static void on_return_bp(pid_t tid, struct user_regs_struct *r, void *ud);
+static void hook_return(struct user_regs_struct *r, handler_t fn, void *ud) {
+    uint64_t ra = rd64(r->rsp);
+    if (g_npend == MAXPEND) { fprintf(stderr, "pend overflow\n"); exit(3); }
+    g_pend[g_npend++] = (pend_t){ra, fn, ud};
+    bp_add(ra, on_return_bp, NULL);
+}
+static void on_return_bp(pid_t tid, struct user_regs_struct *r, void *ud) {
+    (void)ud;
+    uint64_t a = r->rip;
+    for (int i = g_npend - 1; i >= 0; i--) if (g_pend[i].ret_addr == a) {
+        pend_t p = g_pend[i];
+        memmove(&g_pend[i], &g_pend[i+1], (size_t)(g_npend - i - 1) * sizeof(pend_t)); g_npend--;
+        bp_t *b = bp_find(a); p.fn(tid, r, p.ud); if (b) bp_release(b);
+        return;
+    }
+}
+
+/* ---------- Go object walkers (layouts verified at run time by `probe`) ---------- */
+/* ring.Poly{Coeffs [][]uint64, ...}: word0 = ptr to slice headers, word1 = len (limbs) */
+static int poly_limbs(uint64_t poly) { return (int)rd64(poly + 8); }
+static uint64_t poly_row(uint64_t poly, int limb, uint64_t *len) {
+    uint64_t hdr = rd64(poly) + 24ull * (uint64_t)limb;
+    if (len) *len = rd64(hdr + 8);
+    return rd64(hdr);
+}
+/* ckks.Ciphertext{*rlwe.Ciphertext, Scale}; rlwe.Ciphertext{Value []*ring.Poly} */
+static int ct_degree1(uint64_t ct) { return (int)rd64(rd64(ct) + 8); }
+static uint64_t ct_poly(uint64_t ct, int k) { return rd64(rd64(rd64(ct)) + 8ull * (uint64_t)k); }
+static double ct_scale(uint64_t ct) { return rdf64(ct + 8); }
+/* ckks.Plaintext{*rlwe.Plaintext, Scale}; rlwe.Plaintext{Value *ring.Poly} */
+static uint64_t pt_poly(uint64_t pt) { return rd64(rd64(pt)); }
+static double pt_scale(uint64_t pt) { return rdf64(pt + 8); }
+
+static FILE *g_out; static int g_first_event = 1;
+static uint64_t g_N = 65536;
+static uint64_t *g_tmp;
+
+static void hash_rows(sha256_t *s, uint64_t poly, int nlimbs) {
+    for (int l = 0; l < nlimbs; l++) {
+        uint64_t len, p = poly_row(poly, l, &len);
+        if (len != g_N) { fprintf(stderr, "row len %lu != N\n", len); exit(3); }
+        rd(p, g_tmp, g_N * 8); sha_update(s, g_tmp, g_N * 8);
+    }
+}
+static void emit_begin(const char *op) {
+    fprintf(g_out, "%s\n  {\"op\": \"%s\"", g_first_event ? "" : ",", op); g_first_event = 0;
+}
+static void emit_poly(const char *key, uint64_t poly, int nlimbs) {
+    sha256_t s; char hex[65]; sha_init(&s); hash_rows(&s, poly, nlimbs); sha_final(&s, hex);
+    uint64_t first[4]; rd(poly_row(poly, 0, NULL), first, 32);
+    fprintf(g_out, ", \"%s\": {\"limbs\": %d, \"sha256\": \"%s\", \"head\": [%lu, %lu, %lu, %lu]}", key, nlimbs, hex,
+            first[0], first[1], first[2], first[3]);
+}
+static void emit_ct(const char *key, uint64_t ct) {
+    int deg1 = ct_degree1(ct); int limbs = poly_limbs(ct_poly(ct, 0));
+    fprintf(g_out, ", \"%s\": {\"scale\": %.17g, \"level\": %d, \"polys\": [", key, ct_scale(ct), limbs - 1);
+    for (int k = 0; k < deg1; k++) {
+        sha256_t s; char hex[65]; sha_init(&s); hash_rows(&s, ct_poly(ct, k), limbs); sha_final(&s, hex);
+        uint64_t first[2]; rd(poly_row(ct_poly(ct, k), 0, NULL), first, 16);
+        fprintf(g_out, "%s{\"sha256\": \"%s\", \"head\": [%lu, %lu]}", k ? ", " : "", hex, first[0], first[1]);
+    }
+    fprintf(g_out, "]}");
+}
+static void emit_end(void) { fprintf(g_out, "}"); fflush(g_out); }
+
+static void plant_row(uint64_t rowptr, uint64_t seed, uint64_t q) {
+    for (uint64_t j = 0; j < g_N; j++) g_tmp[j] = splitmix64_at(seed, j) % q;
+    wr(rowptr, g_tmp, g_N * 8);
+}
+
+/* ---------- addresses (nm /root/reference/test_run); each hook sits on the first instruction AFTER the
+ * goroutine stack-growth check (the `sub $frame,%rsp`), where rsp still equals the entry rsp and the
+ * function cannot be restarted by runtime.morestack any more ---------- */
+#define A_CALL_BL            0x548544ull  /* call main.testConv_BL_in in main.main (main.go:640) */
+#define A_CONV_THEN_PACK     0x53b17bull
+#define A_MULNEW             0x5227dbull
+#define A_SETSCALE           0x521b98ull
+#define A_SUBNEW             0x51b9b3ull
+#define A_ADD                0x51aef3ull
+#define A_ROTATEGAL          0x5245b3ull
+#define A_SWITCHKEYS         0x4fdd53ull
+#define A_MULTBYCONST        0x51ee98ull
+#define A_DIVROUND           0x4f3ab3ull
+#define A_ENCODECOEFFS       0x518bb8ull
+#define A_TYPE_FLOAT64       0x570a20ull  /* runtime type descriptor of float64 (seen in the interface word) */
+
+static const uint64_t Q0 = 0x80000000080001ull, Q1 = 0x1ffffffea0001ull, P0 = 0x1fffffffffe00001ull;
+static uint64_t g_seed = 0xC0FFEE;
+static int g_mode_probe, g_in_ctp, g_verbose, g_lean, g_after_ctp, g_encode_calls;
+static int g_skip_bl = 1;
+
+/* seed lanes: tag<<32 | index */
+#define SEED_CT(p,l)      (g_seed + ((1ull<<32) | (uint64_t)((p)*8+(l))))
+#define SEED_KER(i,l)     (g_seed + ((2ull<<32) | (uint64_t)((i)*8+(l))))
+#define SEED_EVK(k,c,w)   (g_seed + ((3ull<<32) | (uint64_t)((k)*8+(c)*2+(w))))
+
+static void dump_words(const char *what, uint64_t a, int n) {
+    fprintf(stderr, "%s @%#lx:", what, a);
+    for (int i = 0; i < n; i++) fprintf(stderr, " %#lx", rd64(a + 8ull*(uint64_t)i));
+    fprintf(stderr, "\n");
+}
+
+/* --- evaluator-op hooks, active only inside conv_then_pack --- */
+typedef struct { uint64_t a, b, c; } ud3_t;
+static ud3_t g_udpool[MAXPEND]; static int g_udi;
+static ud3_t *ud_new(uint64_t a, uint64_t b, uint64_t c) { ud3_t *u = &g_udpool[g_udi++ % MAXPEND]; u->a = a; u->b = b; u->c = c; return u; }
+
+static void ret_mulnew(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    uint64_t ct = rd64(r->rsp - 8 + 0x30); emit_begin("MulNew"); emit_ct("out", ct); emit_end(); }
+static void on_mulnew(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (g_in_ctp && !g_lean) hook_return(r, ret_mulnew, NULL); }
+
+static void ret_setscale(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
+    emit_begin("SetScale"); emit_ct("out", ((ud3_t*)ud)->a); emit_end(); }
+static void on_setscale(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_ctp) return;
+    hook_return(r, ret_setscale, ud_new(rd64(r->rsp + 0x10), 0, 0)); }
+
+static void ret_subnew(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    uint64_t ct = rd64(r->rsp - 8 + 0x30); emit_begin("SubNew"); emit_ct("out", ct); emit_end(); }
+static void on_subnew(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (g_in_ctp && !g_lean) hook_return(r, ret_subnew, NULL); }
+
+static void ret_add(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
+    emit_begin(((ud3_t*)ud)->b ? "Add.bias" : "Add"); emit_ct("out", ((ud3_t*)ud)->a); emit_end(); }
+static int g_add_calls;
+static void on_add(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    /* Add(recv, op0 (itab,ptr), op1 (itab,ptr), ctOut) */
+    if (g_after_ctp) {           /* eval.go:258  Add(ct_res, pl_bn_b, ct_res) */
+        g_after_ctp = 0;
+        uint64_t pt = rd64(r->rsp + 0x28);
+        emit_begin("bias_plaintext"); fprintf(g_out, ", \"scale\": %.17g", pt_scale(pt));
+        emit_poly("pt", pt_poly(pt), poly_limbs(pt_poly(pt))); emit_end();
+        hook_return(r, ret_add, ud_new(rd64(r->rsp + 0x30), 1, 0)); return;
+    }
+    if (!g_in_ctp) return;
+    int nth = g_add_calls++;     /* conv.go:290 (even) and conv.go:292 (odd, the node result) */
+    if (g_lean && !(nth & 1)) return;
+    hook_return(r, ret_add, ud_new(rd64(r->rsp + 0x30), 0, 0)); }
+
+static void ret_rotgal(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
+    emit_begin("RotateGal"); fprintf(g_out, ", \"galEl\": %lu", ((ud3_t*)ud)->b); emit_ct("out", ((ud3_t*)ud)->a); emit_end(); }
+static void on_rotgal(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_ctp || g_lean) return;
+    hook_return(r, ret_rotgal, ud_new(rd64(r->rsp + 0x20), rd64(r->rsp + 0x18), 0)); }
+
+static void ret_multbyconst(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
+    ud3_t *u = ud; double c; memcpy(&c, &u->b, 8);
+    emit_begin("MultByConst"); fprintf(g_out, ", \"const_is_f64\": %d, \"const\": %.17g", (int)u->c, c);
+    emit_ct("out", u->a); emit_end(); }
+static void on_multbyconst(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_ctp || g_lean) return;
+    /* MultByConst(recv, ct0 *Ciphertext, constant interface{} (2 words), ctOut *Ciphertext) */
+    if (g_mode_probe) dump_words("MultByConst args", r->rsp + 8, 6);
+    uint64_t ty = rd64(r->rsp + 0x18), data = rd64(r->rsp + 0x20);
+    int is_f64 = (ty == A_TYPE_FLOAT64);
+    hook_return(r, ret_multbyconst, ud_new(rd64(r->rsp + 0x28), is_f64 ? rd64(data) : 0, (uint64_t)is_f64)); }
+
+/* SwitchKeysInPlace(recv, levelQ int, cx *ring.Poly, evakey *rlwe.SwitchingKey, p0, p1 *ring.Poly) */
+static uint64_t g_evk_seen[64]; static int g_nevk;
+static void ret_switchkeys(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
+    ud3_t *u = ud; emit_begin("SwitchKeysInPlace"); fprintf(g_out, ", \"evk\": %lu", u->c);
+    emit_poly("p0", u->a, 1); emit_poly("p1", u->b, 1); emit_end(); }
+static void on_switchkeys(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_ctp) return;
+    uint64_t level = rd64(r->rsp + 0x10), cx = rd64(r->rsp + 0x18), evk = rd64(r->rsp + 0x20);
+    uint64_t p0 = rd64(r->rsp + 0x28), p1 = rd64(r->rsp + 0x30);
+    int k = -1; for (int i = 0; i < g_nevk; i++) if (g_evk_seen[i] == evk) k = i;
+    if (g_mode_probe) {
+        fprintf(stderr, "SwitchKeysInPlace level=%lu cx=%#lx evk=%#lx p0=%#lx p1=%#lx\n", level, cx, evk, p0, p1);
+        dump_words(" evk", evk, 4); uint64_t v = rd64(evk); dump_words(" evk.Value[0]", v, 4);
+        dump_words("  poly b", rd64(v), 6); fprintf(stderr, "  limbs b=%d p0 limbs=%d cx limbs=%d\n", poly_limbs(rd64(v)), poly_limbs(p0), poly_limbs(cx));
+    }
+    if (level != 0) { fprintf(stderr, "unexpected level %lu in SwitchKeysInPlace\n", level); exit(3); }
+    if (k < 0) {
+        k = g_nevk; g_evk_seen[g_nevk++] = evk;
+        uint64_t digits = rd64(evk + 8), v = rd64(evk);               /* Value [][2]*ring.Poly */
+        (void)digits;
+        for (int c = 0; c < 2; c++) {
+            uint64_t poly = rd64(v + 8ull*(uint64_t)c); int limbs = poly_limbs(poly);
+            plant_row(poly_row(poly, 0, NULL), SEED_EVK(k, c, 0), Q0);
+            plant_row(poly_row(poly, limbs - 1, NULL), SEED_EVK(k, c, 1), P0);   /* single P prime = last limb */
+        }
+    }
+    if (!g_lean) hook_return(r, ret_switchkeys, ud_new(p0, p1, (uint64_t)k));
+}
+
+/* (*encoderComplex128).EncodeCoeffs(coeffs []float64, pt *ckks.Plaintext): digest of the encoded plaintext
+ * (coefficient domain, before ToNTT). Call order in `conv k i n` with BL skipped: 16 x gen_idxNlogs
+ * (conv.go:251), 1 x input (test.go:46), B x prep_Ker (conv.go:513), 1 x bias (eval.go:242). */
+static void ret_encode(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
+    ud3_t *u = ud; uint64_t pt = u->a;
+    emit_begin("EncodeCoeffs"); fprintf(g_out, ", \"call\": %lu, \"ncoeffs\": %lu, \"scale\": %.17g", u->b, u->c, pt_scale(pt));
+    emit_poly("pt", pt_poly(pt), poly_limbs(pt_poly(pt))); emit_end(); }
+static void on_encode(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (g_lean && g_encode_calls >= 24) { g_encode_calls++; return; }
+    hook_return(r, ret_encode, ud_new(rd64(r->rsp + 0x28), (uint64_t)g_encode_calls++, rd64(r->rsp + 0x18))); }
+
+/* conv_then_pack(params (0x68 bytes by value), pack_evaluator (itab,ptr), ctxt_in, pl_ker (ptr,len,cap),
+ *                plain_idx (ptr,len,cap), max_ob, norm, ECD_LV int, out_scale float64) *Ciphertext
+ * entry-rsp offsets (from the frame layout of test_run:main.conv_then_pack, sub $0x150 / args at 0x158):
+ *   ctxt_in +0x80, pl_ker +0x88/+0x90, plain_idx +0xa0/+0xa8, max_ob +0xb8, norm +0xc0, ECD_LV +0xc8,
+ *   out_scale +0xd0, result +0xd8 */
+static void ret_ctp(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    uint64_t ct = rd64(r->rsp - 8 + 0xd8);
+    emit_begin("conv_then_pack.return"); emit_ct("out", ct); emit_end();
+    g_in_ctp = 0; g_after_ctp = 1;
+}
+static int g_ctp_calls;
+static void on_ctp(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    uint64_t E = r->rsp;
+    uint64_t ct_in = rd64(E + 0x80), ker = rd64(E + 0x88), nker = rd64(E + 0x90), idx = rd64(E + 0xa0), nidx = rd64(E + 0xa8);
+    uint64_t max_ob = rd64(E + 0xb8), norm = rd64(E + 0xc0), ecd = rd64(E + 0xc8); double out_scale = rdf64(E + 0xd0);
+    fprintf(stderr, "conv_then_pack: ct_in=%#lx pl_ker=%#lx(%lu) idx=%#lx(%lu) max_ob=%lu norm=%lu ECD_LV=%lu out_scale=%g\n",
+            ct_in, ker, nker, idx, nidx, max_ob, norm, ecd, out_scale);
+    if (g_mode_probe) {
+        dump_words("ct_in", ct_in, 4); dump_words(" *ct_in[0] (rlwe.Ciphertext)", rd64(ct_in), 4);
+        uint64_t p0 = ct_poly(ct_in, 0); dump_words("  poly0", p0, 6); dump_words("   hdrs", rd64(p0), 6);
+        uint64_t pt0 = rd64(ker); dump_words("pl_ker[0]", pt0, 4); dump_words(" *pl_ker[0][0] (rlwe.Plaintext)", rd64(pt0), 4);
+        dump_words("  poly", pt_poly(pt0), 6);
+        fprintf(stderr, "ct_in scale=%g deg+1=%d limbs=%d; pt scale=%g limbs=%d\n", ct_scale(ct_in), ct_degree1(ct_in),
+                poly_limbs(ct_poly(ct_in, 0)), pt_scale(pt0), poly_limbs(pt_poly(pt0)));
+        uint64_t i0 = rd64(idx); fprintf(stderr, "idx[0] scale=%g limbs=%d\n", pt_scale(i0), poly_limbs(pt_poly(i0)));
+    }
+    if (g_ctp_calls++ > 0) return;          /* first call only */
+    g_in_ctp = 1;
+    emit_begin("conv_then_pack.entry");
+    fprintf(g_out, ", \"max_ob\": %lu, \"norm\": %lu, \"ECD_LV\": %lu, \"out_scale\": %.17g, \"ct_in_scale\": %.17g, \"pl_ker_scale\": %.17g",
+            max_ob, norm, ecd, out_scale, ct_scale(ct_in), pt_scale(rd64(ker)));
+    emit_end();
+    /* digests of the reference's own pl_ker[i] (prep_Ker output, conv.go:510-515) before they are overwritten */
+    for (uint64_t i = 0; i < nker && !(g_lean && i >= 4); i++) {
+        uint64_t pt = rd64(ker + 8*i);
+        emit_begin("pl_ker_orig"); fprintf(g_out, ", \"i\": %lu, \"scale\": %.17g", i, pt_scale(pt));
+        emit_poly("pt", pt_poly(pt), poly_limbs(pt_poly(pt))); emit_end();
+    }
+    /* plant ct_in and pl_ker */
+    for (int p = 0; p < 2; p++) {
+        uint64_t poly = ct_poly(ct_in, p);
+        plant_row(poly_row(poly, 0, NULL), SEED_CT(p, 0), Q0);
+        plant_row(poly_row(poly, 1, NULL), SEED_CT(p, 1), Q1);
+    }
+    for (uint64_t i = 0; i < nker; i++) {
+        uint64_t poly = pt_poly(rd64(ker + 8*i));
+        plant_row(poly_row(poly, 0, NULL), SEED_KER(i, 0), Q0);
+        plant_row(poly_row(poly, 1, NULL), SEED_KER(i, 1), Q1);
+    }
+    for (uint64_t s = 0; s < nidx; s++) {
+        uint64_t pt = rd64(idx + 8*s);
+        emit_begin("plain_idx"); fprintf(g_out, ", \"s\": %lu, \"scale\": %.17g", s, pt_scale(pt));
+        emit_poly("pt", pt_poly(pt), poly_limbs(pt_poly(pt))); emit_end();
+    }
+    hook_return(r, ret_ctp, NULL);
+}
+
+static void usage(void) {
+    fprintf(stderr, "usage: gotrace [-probe] [-seed S] [-o out.json] [-keep-bl] -- /root/reference/test_run conv K I N\n"); exit(2);
+}
+
+int main(int argc, char **argv) {
+    const char *outpath = NULL; int ai = 1;
+    for (; ai < argc; ai++) {
+        if (!strcmp(argv[ai], "--")) { ai++; break; }
+        else if (!strcmp(argv[ai], "-probe")) g_mode_probe = 1;
+        else if (!strcmp(argv[ai], "-v")) g_verbose = 1;
+        else if (!strcmp(argv[ai], "-lean")) g_lean = 1;
+        else if (!strcmp(argv[ai], "-keep-bl")) g_skip_bl = 0;
+        else if (!strcmp(argv[ai], "-seed") && ai + 1 < argc) g_seed = strtoull(argv[++ai], NULL, 0);
+        else if (!strcmp(argv[ai], "-o") && ai + 1 < argc) outpath = argv[++ai];
+        else usage();
+    }
+    if (ai >= argc) usage();
+    g_out = outpath ? fopen(outpath, "w") : stdout;
+    if (!g_out) { perror("fopen"); return 2; }
+    g_tmp = malloc(g_N * 8);
+
+    pid_t pid = fork();
+    if (pid == 0) {
+        ptrace(PTRACE_TRACEME, 0, 0, 0);
+        execv(argv[ai], argv + ai);
+        perror("execv"); _exit(127);
+    }
+    g_pid = pid; int st;
+    waitpid(pid, &st, 0);
+    if (!WIFSTOPPED(st)) { fprintf(stderr, "tracee did not stop\n"); return 3; }
+    ptrace(PTRACE_SETOPTIONS, pid, 0, PTRACE_O_TRACECLONE | PTRACE_O_EXITKILL);
+    char path[64]; snprintf(path, sizeof path, "/proc/%d/mem", pid);
+    g_mem = open(path, O_RDWR);
+    if (g_mem < 0) { perror("open mem"); return 3; }
+
+    if (g_skip_bl) {   /* skip the BL baseline run (main.go:640); in tracee memory only */
+        uint8_t cur[5], nop5[5] = {0x0f, 0x1f, 0x44, 0x00, 0x00};
+        rd(A_CALL_BL, cur, 5);
+        if (cur[0] != 0xe8) { fprintf(stderr, "unexpected byte at call site: %#x\n", cur[0]); return 3; }
+        wr(A_CALL_BL, nop5, 5);
+    }
+    fprintf(g_out, "{\"seed\": %lu, \"N\": %lu, \"lean\": %d, \"moduli\": {\"Q0\": %lu, \"Q1\": %lu, \"P\": %lu},\n \"argv\": [", g_seed, g_N, g_lean, Q0, Q1, P0);
+    for (int i = ai + 1; i < argc; i++) fprintf(g_out, "%s\"%s\"", i > ai + 1 ? ", " : "", argv[i]);
+    fprintf(g_out, "],\n \"events\": [");
+    bp_add(A_CONV_THEN_PACK, on_ctp, NULL);
+    bp_add(A_ENCODECOEFFS, on_encode, NULL);
+    bp_add(A_MULNEW, on_mulnew, NULL);
+    bp_add(A_SETSCALE, on_setscale, NULL);
+    bp_add(A_SUBNEW, on_subnew, NULL);
+    bp_add(A_ADD, on_add, NULL);
+    bp_add(A_ROTATEGAL, on_rotgal, NULL);
+    bp_add(A_SWITCHKEYS, on_switchkeys, NULL);
+    bp_add(A_MULTBYCONST, on_multbyconst, NULL);
+
+    ptrace(PTRACE_CONT, pid, 0, 0);
+    int exit_code = -1; uint64_t refire_addr = 0, refire_rsp = 0;
+    for (;;) {
+        pid_t t = waitpid(-1, &st, __WALL);
+        if (t < 0) { if (errno == ECHILD) break; if (errno == EINTR) continue; perror("waitpid"); break; }
+        if (WIFEXITED(st) || WIFSIGNALED(st)) {
+            if (t == pid) { exit_code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st); }
+            continue;
+        }
+        if (!WIFSTOPPED(st)) continue;
+        int sig = WSTOPSIG(st);
+        if (sig == SIGTRAP) {
+            int ev = st >> 16;
+            if (ev == PTRACE_EVENT_CLONE) { ptrace(PTRACE_CONT, t, 0, 0); continue; }
+            struct user_regs_struct r; ptrace(PTRACE_GETREGS, t, 0, &r);
+            bp_t *b = bp_find(r.rip - 1);
+            if (b && b->armed) {
+                r.rip -= 1;
+                uint64_t addr = b->addr;
+                handler_t fn = b->fn; void *ud = b->ud;
+                if (refire_addr == addr && refire_rsp == r.rsp) refire_addr = 0;   /* same hit, handler already ran */
+                else fn(t, &r, ud);                  /* may add/release breakpoints (including this one) */
+                b = bp_find(addr);
+                ptrace(PTRACE_SETREGS, t, 0, &r);
+                if (b && b->armed) {                 /* step over, then re-arm */
+                    bp_disarm(b);
+                    ptrace(PTRACE_SINGLESTEP, t, 0, 0);
+                    int st2; waitpid(t, &st2, __WALL);
+                    if (WIFSTOPPED(st2) && WSTOPSIG(st2) != SIGTRAP) {
+                        /* a signal (Go's SIGURG preemption) raced the step: re-arm and deliver it; if the
+                         * instruction has not executed yet the breakpoint fires again for the SAME hit */
+                        struct user_regs_struct r2; ptrace(PTRACE_GETREGS, t, 0, &r2);
+                        if (r2.rip == addr) { refire_addr = addr; refire_rsp = r2.rsp; }
+                        bp_arm(b); ptrace(PTRACE_CONT, t, 0, WSTOPSIG(st2)); continue;
+                    }
+                    bp_arm(b);
+                }
+                ptrace(PTRACE_CONT, t, 0, 0);
+                continue;
+            }
+            ptrace(PTRACE_CONT, t, 0, 0);             /* exec/new-thread trap */
+            continue;
+        }
+        if (sig == SIGSTOP) { ptrace(PTRACE_CONT, t, 0, 0); continue; }   /* new thread's initial stop */
+        ptrace(PTRACE_CONT, t, 0, sig);               /* forward (Go uses SIGURG for preemption) */
+    }
+    fprintf(g_out, "\n ],\n \"exit_code\": %d}\n", exit_code);
+    fflush(g_out);
+    fprintf(stderr, "tracee exit code %d\n", exit_code);
+    return exit_code == 0 ? 0 : 1;
+}
