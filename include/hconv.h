@@ -1,0 +1,123 @@
+/*
+ * hconv.h — C ABI of libhconv.so: the MI355X (gfx950) engine behind the reference's `conv` hot path.
+ *
+ * The reference (github.com/dwkim606/optimal_conv, pure Go) has no FFI layer; the seam this library plugs into
+ * is the `ckks.Evaluator` interface value every hot-path function receives:
+ *     conv.go:522  conv_then_pack(params, pack_evaluator ckks.Evaluator, ...)
+ *     conv.go:266  pack_ctxts(pack_eval ckks.Evaluator, ...)
+ *     eval.go:224  evalConv_BN(cont *context, ...)      (uses cont.pack_evaluator / cont.evaluator, main.go:39-40)
+ * A Go `gpuEvaluator` implements the methods those functions call and forwards each to one
+ * entry point below over cgo. All signatures are plain C: opaque handles, raw pointers, sizes; no torch types.
+ *
+ * Conventions
+ *  - Every function returns 0 on success, non-zero on error (hc_last_error gives the text). Nothing throws or
+ *    aborts across the ABI; the Go shim turns non-zero into panic() to keep the reference's behaviour.
+ *  - "dptr" arguments are DEVICE pointers obtained from hc_malloc. A "row" is N = 2^logN uint64 residues of one
+ *    RNS limb, contiguous; a level-l polynomial is (l+1) consecutive rows; a ciphertext is [poly][limb][N].
+ *    This is Lattigo's Poly.Coeffs[limb][N] layout made contiguous.
+ *  - Moduli are addressed by index: 0..nq-1 = the Q chain (level order), nq..nq+np-1 = special primes P.
+ *  - Values cross the ABI in Lattigo's public representation: ciphertext/plaintext rows are canonical residues
+ *    in [0,q) in the NTT domain (bit-reversed order, psi chosen as ring.genNTTParams does); switching keys are
+ *    handed over exactly as stored in rlwe.SwitchingKey.Value[d][k].Coeffs[limb] (NTT + Montgomery form).
+ *  - The library never retains host pointers after a call returns (cgo rule); long-lived data is loaded through
+ *    the *_load calls. Calls on one hc_ctx must be serialised by the caller; each call sets the device.
+ *  - All work is queued on the context's own HIP stream; hc_sync waits for it. hc_download syncs implicitly.
+ */
+#ifndef HCONV_H
+#define HCONV_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hc_ctx hc_ctx;
+typedef struct hc_ker hc_ker; /* device-resident kernel plaintexts pl_ker[0..max_ob) (conv.go:510-515) */
+
+#define HC_OK 0
+#define HC_ERR_ARG 1
+#define HC_ERR_HIP 2
+#define HC_ERR_STATE 3
+#define HC_ERR_UNSUPPORTED 4
+
+/* ---- context: replaces ckks.NewEvaluator(params, evk) for the pack evaluator (conv.go:258, main.go:446-461) ----
+ * q[0..nq): ciphertext moduli in level order; p[0..np): special primes. NTT tables are derived as
+ * ring.genNTTParams does (psi = g^((q-1)/2N), g from ring.primitiveRoot). device = HIP device ordinal. */
+int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, const uint64_t *p, int np, int device);
+void hc_ctx_destroy(hc_ctx *ctx);
+const char *hc_last_error(const hc_ctx *ctx); /* ctx may be NULL: error of the last failed hc_ctx_create */
+int hc_version(void);
+
+/* ---- device memory ---- */
+int hc_malloc(hc_ctx *ctx, size_t bytes, void **dptr);
+int hc_free(hc_ctx *ctx, void *dptr);
+int hc_upload(hc_ctx *ctx, void *dst_dptr, const void *src_host, size_t bytes);
+int hc_download(hc_ctx *ctx, void *dst_host, const void *src_dptr, size_t bytes);
+int hc_sync(hc_ctx *ctx);
+
+/* ---- L0: one call per ring / evaluator primitive (rows are device pointers; `count` consecutive rows) ---- */
+/* ring.NTTLvl / ring.InvNTTLvl on limb `mod` (encoder.ToNTT conv.go:514; inside Rescale and key switching) */
+int hc_ntt(hc_ctx *ctx, int mod, const uint64_t *in, uint64_t *out, int count);
+int hc_intt(hc_ctx *ctx, int mod, const uint64_t *in, uint64_t *out, int count);
+/* evaluator.MulNew(ct, pt) per limb (conv.go:527, conv.go:288): out = a*b mod q (= MForm + MulCoeffsMontgomery) */
+int hc_mul(hc_ctx *ctx, int mod, const uint64_t *a, const uint64_t *b, uint64_t *out, int count);
+/* evaluator.Add / SubNew per limb (conv.go:289,290,292; eval.go:258) */
+int hc_add(hc_ctx *ctx, int mod, const uint64_t *a, const uint64_t *b, uint64_t *out, int count);
+int hc_sub(hc_ctx *ctx, int mod, const uint64_t *a, const uint64_t *b, uint64_t *out, int count);
+/* evaluator.MultByConst's coefficient loop for an integer constant c (inside SetScale, conv.go:528) */
+int hc_mul_const(hc_ctx *ctx, int mod, const uint64_t *a, uint64_t c, uint64_t *out, int count);
+/* the integer constant and scale factor MultByConst derives from a float64 (getConstAndScale + scaleUpExact) */
+uint64_t hc_const_for(double constant, double q_level_as_f64, uint64_t q, double *scale_mult);
+/* ring.DivRoundByLastModulusNTT, one drop: x = (level+1) rows, out = level rows (inside Rescale/SetScale) */
+int hc_div_round_last(hc_ctx *ctx, int level, const uint64_t *x, uint64_t *out);
+/* ring.PermuteNTTWithIndexLvl with ring.PermuteNTTIndex(galEl) (inside RotateGal, conv.go:291) */
+int hc_permute(hc_ctx *ctx, uint64_t galEl, const uint64_t *in, uint64_t *out, int count);
+
+/* rlwe.SwitchingKey for galEl, digit 0, the rows level-0 key switching reads: limb Q0 and the single P limb of
+ * Value[0][0] (b) and Value[0][1] (a), HOST pointers, stored form. Replaces GenRotationKeys' output being handed
+ * to NewEvaluator (conv.go:258). */
+int hc_evk_load(hc_ctx *ctx, uint64_t galEl, const uint64_t *b_q, const uint64_t *a_q, const uint64_t *b_p,
+                const uint64_t *a_p);
+/* rlwe.KeySwitcher.SwitchKeysInPlace at level 0 (c1 -> d0,d1) and evaluator.RotateGal at level 0 (conv.go:291).
+ * in/out may alias for hc_rotate_gal_l0 (conv.go:291 rotates in place). */
+int hc_keyswitch_l0(hc_ctx *ctx, uint64_t galEl, const uint64_t *c1, uint64_t *d0, uint64_t *d1);
+int hc_rotate_gal_l0(hc_ctx *ctx, uint64_t galEl, const uint64_t *c0, const uint64_t *c1, uint64_t *o0, uint64_t *o1);
+
+/* ---- L1: the fused hot path ---- */
+/* pl_ker as prep_Ker leaves it (conv.go:510-515): HOST array [max_ob][2][N], level 1, NTT domain. */
+int hc_ker_load(hc_ctx *ctx, const uint64_t *pl_ker_host, int max_ob, hc_ker **out);
+/* same from a DEVICE array (e.g. produced by hc_ntt); the input buffer is not retained */
+int hc_ker_load_device(hc_ctx *ctx, const uint64_t *pl_ker_dptr, int max_ob, hc_ker **out);
+void hc_ker_free(hc_ctx *ctx, hc_ker *ker);
+/* plain_idx (conv.go:241-261): NULL => derive idx[s] = NTT(X^(2^s)) on the device; else HOST array [logN][N] */
+int hc_idx_load(hc_ctx *ctx, const uint64_t *idx_host);
+
+/* conv_then_pack (conv.go:522-546) followed by eval.go:258's bias add when bias != NULL.
+ *   ct_in : device, [2][2][N] level-1 ciphertext, Scale = ct_scale
+ *   ker   : kernel plaintexts with Scale = ker_scale; max_ob, norm as in conv.go:522
+ *   bias  : device row mod Q0 (pl_bn_b, level 0, NTT) or NULL
+ *   ct_out: device, [2][N] level-0 ciphertext; *scale_out = its Scale
+ * Fails with HC_ERR_STATE when the resulting level/scale would trip the reference's panic (conv.go:541-543). */
+int hc_conv_then_pack(hc_ctx *ctx, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
+                      int max_ob, int norm, double out_scale, const uint64_t *bias, uint64_t *ct_out,
+                      double *scale_out);
+/* loop A only (conv.go:525-531): cts_out = device [max_ob][2][N]; and loop B only (pack_ctxts, conv.go:266-300),
+ * in place on cts (result in slot 0). Exposed for parity tests and profiling. */
+int hc_conv_mult_phase(hc_ctx *ctx, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
+                       int max_ob, int norm, double out_scale, uint64_t *cts_out);
+int hc_pack_ctxts(hc_ctx *ctx, uint64_t *cts, int max_cnum, int real_cnum);
+
+/* ---- tuning / measurement ---- */
+int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes", "profile" */
+/* HIP-event timing on the context's stream */
+int hc_timer_start(hc_ctx *ctx);
+int hc_timer_stop(hc_ctx *ctx, float *ms);
+/* per-kernel accumulated HIP-event time while option "profile" is 1; name==NULL resets */
+int hc_profile_get(hc_ctx *ctx, const char *kernel_name, double *total_ms, long *launches);
+int hc_profile_names(hc_ctx *ctx, char *buf, size_t buflen); /* comma separated */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

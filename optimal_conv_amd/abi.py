@@ -1,0 +1,299 @@
+"""ctypes view of include/hconv.h (libhconv.so). Plumbing for tests and bench.py, not the product.
+
+The library is HIP-only: `load()` raises if libhconv.so has not been built (see __graft_entry__.build) and
+`Context()` raises if no GPU is visible. There is no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libhconv.so")
+
+u64p = C.POINTER(C.c_uint64)
+
+# every symbol include/hconv.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "hc_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, u64p, C.c_int, u64p, C.c_int, C.c_int]),
+    "hc_ctx_destroy": (None, [C.c_void_p]),
+    "hc_last_error": (C.c_char_p, [C.c_void_p]),
+    "hc_version": (C.c_int, []),
+    "hc_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "hc_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hc_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "hc_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "hc_sync": (C.c_int, [C.c_void_p]),
+    "hc_ntt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "hc_intt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "hc_mul": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "hc_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "hc_sub": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "hc_mul_const": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]),
+    "hc_const_for": (C.c_uint64, [C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_double)]),
+    "hc_div_round_last": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "hc_permute": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]),
+    "hc_evk_load": (C.c_int, [C.c_void_p, C.c_uint64, u64p, u64p, u64p, u64p]),
+    "hc_keyswitch_l0": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_rotate_gal_l0": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_ker_load": (C.c_int, [C.c_void_p, u64p, C.c_int, C.POINTER(C.c_void_p)]),
+    "hc_ker_load_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "hc_ker_free": (None, [C.c_void_p, C.c_void_p]),
+    "hc_idx_load": (C.c_int, [C.c_void_p, u64p]),
+    "hc_conv_then_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double,
+                                    C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "hc_conv_mult_phase": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double,
+                                     C.c_void_p]),
+    "hc_pack_ctxts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "hc_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
+    "hc_timer_start": (C.c_int, [C.c_void_p]),
+    "hc_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "hc_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "hc_profile_names": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+}
+
+
+class HconvError(RuntimeError):
+    pass
+
+
+_libs = {}
+
+
+def load(path=None):
+    """dlopen libhconv.so and type every entry point. Raises if the HIP library is missing."""
+    path = path or DEFAULT_LIB
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise HconvError(f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                         "optimal_conv_amd has no CPU fallback.")
+    L = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)     # AttributeError here = header/library drift
+        fn.restype, fn.argtypes = res, args
+    _libs[path] = L
+    return L
+
+
+def _hp(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+class DevBuf:
+    """A device allocation of `rows` x N uint64."""
+
+    def __init__(self, ctx, nwords):
+        self.ctx, self.nwords = ctx, int(nwords)
+        p = C.c_void_p()
+        ctx._ck(ctx.L.hc_malloc(ctx.h, self.nwords * 8, C.byref(p)))
+        self.ptr = p
+
+    def at(self, word_off):
+        return C.c_void_p(self.ptr.value + int(word_off) * 8)
+
+    def upload(self, arr, word_off=0):
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        assert word_off + arr.size <= self.nwords
+        self.ctx._ck(self.ctx.L.hc_upload(self.ctx.h, self.at(word_off), arr.ctypes.data_as(C.c_void_p), arr.size * 8))
+        return self
+
+    def download(self, shape=None, word_off=0, nwords=None):
+        n = self.nwords - word_off if nwords is None else nwords
+        out = np.empty(n, dtype=np.uint64)
+        self.ctx._ck(self.ctx.L.hc_download(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.at(word_off), n * 8))
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            self.ctx.L.hc_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """hc_ctx over (Q chain, P chain) on one device."""
+
+    def __init__(self, q, p, logN=16, device=0, lib_path=None):
+        self.L = load(lib_path)
+        self.q, self.p, self.logN, self.N = list(q), list(p), logN, 1 << logN
+        qa = (C.c_uint64 * len(q))(*q)
+        pa = (C.c_uint64 * max(1, len(p)))(*(list(p) or [0]))
+        h = C.c_void_p()
+        rc = self.L.hc_ctx_create(C.byref(h), logN, qa, len(q), pa, len(p), device)
+        if rc != 0:
+            raise HconvError(f"hc_ctx_create failed ({rc}): {self.L.hc_last_error(None).decode()}")
+        self.h = h
+        self.nq = len(q)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.L.hc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise HconvError(f"libhconv error {rc}: {self.L.hc_last_error(self.h).decode()}")
+
+    def buf(self, arr=None, nwords=None):
+        if arr is not None:
+            arr = np.ascontiguousarray(arr, dtype=np.uint64)
+            return DevBuf(self, arr.size).upload(arr)
+        return DevBuf(self, nwords)
+
+    def sync(self):
+        self._ck(self.L.hc_sync(self.h))
+
+    def set_option(self, name, value):
+        self._ck(self.L.hc_set_option(self.h, name.encode(), int(value)))
+
+    # ---- L0, numpy in / numpy out convenience (each call uploads, runs, downloads) ----
+    def _rows_op(self, fn, mod, *arrays, extra=()):
+        arrays = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, self.N) for a in arrays]
+        count = arrays[0].shape[0]
+        bufs = [self.buf(a) for a in arrays]
+        out = self.buf(nwords=count * self.N)
+        self._ck(fn(self.h, mod, *[b.ptr for b in bufs], *extra, out.ptr, count))
+        res = out.download((count, self.N))
+        for b in bufs + [out]:
+            b.free()
+        return res
+
+    def ntt(self, mod, a):
+        return self._rows_op(self.L.hc_ntt, mod, a)
+
+    def intt(self, mod, a):
+        return self._rows_op(self.L.hc_intt, mod, a)
+
+    def mul(self, mod, a, b):
+        return self._rows_op(self.L.hc_mul, mod, a, b)
+
+    def add(self, mod, a, b):
+        return self._rows_op(self.L.hc_add, mod, a, b)
+
+    def sub(self, mod, a, b):
+        return self._rows_op(self.L.hc_sub, mod, a, b)
+
+    def mul_const(self, mod, a, c):
+        return self._rows_op(self.L.hc_mul_const, mod, a, extra=(C.c_uint64(int(c)),))
+
+    def permute(self, gal, a):
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, self.N)
+        src, dst = self.buf(a), self.buf(nwords=a.size)
+        self._ck(self.L.hc_permute(self.h, C.c_uint64(gal), src.ptr, dst.ptr, a.shape[0]))
+        out = dst.download(a.shape)
+        src.free(); dst.free()
+        return out
+
+    def const_for(self, constant, q_level, q):
+        sm = C.c_double(0)
+        v = self.L.hc_const_for(constant, float(q_level), C.c_uint64(q), C.byref(sm))
+        return int(v), sm.value
+
+    def div_round_last(self, level, x):
+        x = np.ascontiguousarray(x, dtype=np.uint64).reshape(level + 1, self.N)
+        src, dst = self.buf(x), self.buf(nwords=level * self.N)
+        self._ck(self.L.hc_div_round_last(self.h, level, src.ptr, dst.ptr))
+        out = dst.download((level, self.N))
+        src.free(); dst.free()
+        return out
+
+    def evk_load(self, gal, evk4):
+        e = [np.ascontiguousarray(r, dtype=np.uint64) for r in evk4]
+        self._ck(self.L.hc_evk_load(self.h, C.c_uint64(gal), _hp(e[0]), _hp(e[1]), _hp(e[2]), _hp(e[3])))
+
+    def idx_load(self, idx=None):
+        if idx is None:
+            self._ck(self.L.hc_idx_load(self.h, None))
+        else:
+            idx = np.ascontiguousarray(idx, dtype=np.uint64)
+            self._ck(self.L.hc_idx_load(self.h, _hp(idx)))
+
+    def keyswitch_l0(self, gal, c1):
+        src = self.buf(c1)
+        d = self.buf(nwords=2 * self.N)
+        self._ck(self.L.hc_keyswitch_l0(self.h, C.c_uint64(gal), src.ptr, d.at(0), d.at(self.N)))
+        out = d.download((2, self.N))
+        src.free(); d.free()
+        return out[0], out[1]
+
+    def rotate_gal_l0(self, gal, ct):
+        src = self.buf(np.ascontiguousarray(ct, dtype=np.uint64).reshape(2, self.N))
+        d = self.buf(nwords=2 * self.N)
+        self._ck(self.L.hc_rotate_gal_l0(self.h, C.c_uint64(gal), src.at(0), src.at(self.N), d.at(0), d.at(self.N)))
+        out = d.download((2, self.N))
+        src.free(); d.free()
+        return out
+
+    # ---- L1 ----
+    def ker_load(self, pl_ker):
+        pl_ker = np.ascontiguousarray(pl_ker, dtype=np.uint64)
+        max_ob = pl_ker.size // (2 * self.N)
+        k = C.c_void_p()
+        self._ck(self.L.hc_ker_load(self.h, _hp(pl_ker.reshape(-1)), max_ob, C.byref(k)))
+        return k
+
+    def ker_free(self, k):
+        self.L.hc_ker_free(self.h, k)
+
+    def conv_then_pack_dev(self, ct_in_buf, ct_scale, ker, ker_scale, max_ob, norm, out_scale, bias_buf, out_buf):
+        sc = C.c_double(0)
+        self._ck(self.L.hc_conv_then_pack(self.h, ct_in_buf.ptr, ct_scale, ker, ker_scale, max_ob, norm, out_scale,
+                                          bias_buf.ptr if bias_buf is not None else None, out_buf.ptr, C.byref(sc)))
+        return sc.value
+
+    def conv_then_pack(self, ct_in, ct_scale, pl_ker, ker_scale, max_ob, norm, out_scale, bias=None):
+        ker = self.ker_load(pl_ker)
+        cin = self.buf(ct_in)
+        b = self.buf(bias) if bias is not None else None
+        out = self.buf(nwords=2 * self.N)
+        sc = self.conv_then_pack_dev(cin, ct_scale, ker, ker_scale, max_ob, norm, out_scale, b, out)
+        res = out.download((2, self.N))
+        for x in (cin, out) + ((b,) if b is not None else ()):
+            x.free()
+        self.ker_free(ker)
+        return res, sc
+
+    def conv_mult_phase(self, ct_in, ct_scale, pl_ker, ker_scale, max_ob, norm, out_scale):
+        ker = self.ker_load(pl_ker)
+        cin = self.buf(ct_in)
+        out = self.buf(nwords=max_ob * 2 * self.N)
+        self._ck(self.L.hc_conv_mult_phase(self.h, cin.ptr, ct_scale, ker, ker_scale, max_ob, norm, out_scale, out.ptr))
+        res = out.download((max_ob, 2, self.N))
+        cin.free(); out.free(); self.ker_free(ker)
+        return res
+
+    def pack_ctxts(self, cts, max_cnum, real_cnum):
+        d = self.buf(cts)
+        self._ck(self.L.hc_pack_ctxts(self.h, d.ptr, max_cnum, real_cnum))
+        res = d.download(nwords=2 * self.N).reshape(2, self.N)
+        d.free()
+        return res
+
+    # ---- measurement ----
+    def timer_start(self):
+        self._ck(self.L.hc_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        self._ck(self.L.hc_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile(self):
+        buf = C.create_string_buffer(4096)
+        self._ck(self.L.hc_profile_names(self.h, buf, 4096))
+        out = {}
+        for name in filter(None, buf.value.decode().split(",")):
+            t, n = C.c_double(0), C.c_long(0)
+            self._ck(self.L.hc_profile_get(self.h, name.encode(), C.byref(t), C.byref(n)))
+            out[name] = (t.value, n.value)
+        return out
+
+    def profile_reset(self):
+        self._ck(self.L.hc_profile_get(self.h, None, None, None))

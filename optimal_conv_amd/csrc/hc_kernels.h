@@ -1,0 +1,490 @@
+// hc_kernels.h — gfx950 kernels of the homomorphic-convolution hot path.
+//
+// Data model: a limb-polynomial ("row") is N = 2^16 uint64 residues = a 256 x 256 matrix [R][C] (R = index>>8).
+// Lattigo's negacyclic NTT (Cooley-Tukey, natural in -> bit-reversed out, twiddle psi[m + j/2t]; SURVEY.md
+// 8(a)-R) splits exactly into
+//     stages 1..8  (t >= 256): 256 independent 256-point transforms down the COLUMNS, twiddles psi[1..255]
+//     stages 9..16 (t <  256): 256 independent 256-point transforms along the ROWS, twiddles psi[m'(256+R)+..]
+// and the Gentleman-Sande inverse is the mirror image (rows first, then columns). One workgroup (256 threads)
+// owns a 16-row x 256 ("rows" kernels) or 256 x 16-column ("cols" kernels) tile = 4096 residues; each thread
+// keeps 16 residues in VGPRs and runs two radix-16 rounds (4 butterfly stages each) with ONE exchange through
+// LDS between them. Adjacent passes of consecutive transforms work on the same tile shape, so the whole chain
+//     iNTT -> (pointwise / basis change) -> NTT
+// is fused pairwise: [rows-inv] [cols-inv + middle op + cols-fwd] [rows-fwd + epilogue], and the row-local
+// Galois permutation of the pack tree is applied inside the last rows kernel through LDS.
+// Global accesses are always 128-byte segments (16 consecutive residues) or fully linear.
+//
+// Twiddles are (w, floor(w*2^64/q)) pairs (Shoup/Harvey); butterflies keep values lazily in [0,4q) (forward) or
+// [0,2q) (inverse); every value stored to a ciphertext is the canonical residue, so results equal the
+// reference's bit for bit.
+#pragma once
+#include "hc_arith.h"
+
+#define HC_TPB 256
+#define HC_ROWS_LDS (16 * 272)          // u64 words: 16 rows x (16 groups x 17)
+#define HC_COLS_LDS (272 * 16)          // u64 words: (256 + 16 pad) row slots x 16 columns
+
+struct __attribute__((aligned(16))) HcTw { u64 w, ws; };
+
+// Twiddle tables of one (modulus, direction), device pointers.
+struct HcTwTab {
+    const HcTw *rowsA;   // [256 rows][16 slots]          round on the high column bits (uniform per row)
+    const HcTw *rowsB;   // [256 rows][16 slots][16 tid]  round on the low column bits (per thread)
+    const HcTw *colsA;   // [16 slots]                    round on the high row bits (uniform)
+    const HcTw *colsB;   // [16 slots][16 tid]            round on the low row bits
+    HcTw ninv;           // N^-1 (inverse tables only)
+    HcTw w_last_ninv;    // inverse colsA slot 0 multiplied by N^-1
+};
+
+// ---------------------------------------------------------------- radix-16 rounds
+// Slot numbering: a 4-stage round has 1+2+4+8 twiddles; the stage with 2^s twiddles uses slots (2^s - 1 + g).
+// Forward rounds walk s = 0..3 (distance 8,4,2,1); inverse rounds walk distance 1,2,4,8 (s = 3..0).
+template <class TW>
+__device__ __forceinline__ void hc_ct_round(u64 (&e)[16], const TW &tw, u64 q) {
+    const u64 twoq = 2 * q;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int g = 0; g < (1 << s); g++) {
+            const HcTw w = tw((1 << s) - 1 + g);
+#pragma unroll
+            for (int k = 0; k < half; k++) {
+                const int a = g * 2 * half + k, b = a + half;
+                u64 X = hc_csub(e[a], twoq);
+                u64 T = hc_mul_shoup_lazy(e[b], w.w, w.ws, q);
+                e[a] = X + T;
+                e[b] = X - T + twoq;
+            }
+        }
+    }
+}
+// LAST: the final stage also multiplies by N^-1 (folded into the twiddle for the "-" output).
+template <bool LAST, class TW>
+__device__ __forceinline__ void hc_gs_round(u64 (&e)[16], const TW &tw, u64 q, HcTw ninv, HcTw w_last) {
+    const u64 twoq = 2 * q;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int dist = 1 << s;
+#pragma unroll
+        for (int g = 0; g < (8 >> s); g++) {
+            HcTw w = tw((8 >> s) - 1 + g);
+            if (LAST && s == 3) w = w_last;
+#pragma unroll
+            for (int k = 0; k < dist; k++) {
+                const int a = g * 2 * dist + k, b = a + dist;
+                u64 X = e[a], Y = e[b];
+                if (LAST && s == 3) e[a] = hc_mul_shoup_lazy(X + Y, ninv.w, ninv.ws, q);
+                else e[a] = hc_csub(X + Y, twoq);
+                e[b] = hc_mul_shoup_lazy(X - Y + twoq, w.w, w.ws, q);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- tile geometry
+// rows kernels: thread t -> (rloc = t>>4, tid = t&15); LDS word of (rloc, col)
+__device__ __forceinline__ int hc_rows_lds(int rloc, int col) { return rloc * 272 + (col >> 4) * 17 + (col & 15); }
+// cols kernels: thread t -> (c = t&15, tid = t>>4); LDS word of (row, c)
+__device__ __forceinline__ int hc_cols_lds(int row, int c) { return ((row >> 4) * 17 + (row & 15)) * 16 + c; }
+
+struct HcRowsTwA { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return p[slot]; } };
+struct HcRowsTwB { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return p[slot * 16]; } };
+
+// forward rows pass on registers: in  e[hi] = element (row, hi*16+tid)  [lazy < 4q]
+//                                 out e[lo] = element (row, tid*16+lo)  [lazy < 4q]
+__device__ __forceinline__ void hc_rows_fwd(u64 (&e)[16], u64 *lds, const HcTwTab &T, int row, int rloc, int tid, u64 q) {
+    hc_ct_round(e, HcRowsTwA{T.rowsA + row * 16}, q);
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) lds[hc_rows_lds(rloc, hi * 16 + tid)] = e[hi];
+    __syncthreads();
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) e[lo] = lds[hc_rows_lds(rloc, tid * 16 + lo)];
+    hc_ct_round(e, HcRowsTwB{T.rowsB + row * 256 + tid}, q);
+}
+// inverse rows pass: in e[lo] = (row, tid*16+lo) [lazy < 2q]; out e[hi] = (row, hi*16+tid) [lazy < 2q]
+__device__ __forceinline__ void hc_rows_inv(u64 (&e)[16], u64 *lds, const HcTwTab &T, int row, int rloc, int tid, u64 q) {
+    hc_gs_round<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, q, T.ninv, T.ninv);
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) lds[hc_rows_lds(rloc, tid * 16 + lo)] = e[lo];
+    __syncthreads();
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) e[hi] = lds[hc_rows_lds(rloc, hi * 16 + tid)];
+    hc_gs_round<false>(e, HcRowsTwA{T.rowsA + row * 16}, q, T.ninv, T.ninv);
+}
+// forward cols pass: in e[hi] = (hi*16+tid, c) [lazy < 4q]; out e[lo] = (tid*16+lo, c) [lazy < 4q]
+__device__ __forceinline__ void hc_cols_fwd(u64 (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, u64 q) {
+    hc_ct_round(e, HcRowsTwA{T.colsA}, q);
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) lds[hc_cols_lds(hi * 16 + tid, c)] = e[hi];
+    __syncthreads();
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) e[lo] = lds[hc_cols_lds(tid * 16 + lo, c)];
+    hc_ct_round(e, HcRowsTwB{T.colsB + tid}, q);
+}
+// inverse cols pass incl. N^-1: in e[lo] = (tid*16+lo, c) [lazy < 2q]; out e[hi] = (hi*16+tid, c) [lazy < 2q]
+__device__ __forceinline__ void hc_cols_inv(u64 (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, u64 q) {
+    hc_gs_round<false>(e, HcRowsTwB{T.colsB + tid}, q, T.ninv, T.ninv);
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) lds[hc_cols_lds(tid * 16 + lo, c)] = e[lo];
+    __syncthreads();
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) e[hi] = lds[hc_cols_lds(hi * 16 + tid, c)];
+    hc_gs_round<true>(e, HcRowsTwA{T.colsA}, q, T.ninv, T.w_last_ninv);
+}
+
+// rows tile <-> "linear" order (thread t holds column t of the 16 rows; k = local row) through LDS
+__device__ __forceinline__ void hc_rows_lin_to_lo(u64 (&e)[16], u64 *lds, int t, int rloc, int tid) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[hc_rows_lds(k, t)] = e[k];
+    __syncthreads();
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) e[lo] = lds[hc_rows_lds(rloc, tid * 16 + lo)];
+}
+__device__ __forceinline__ void hc_rows_lo_to_lin(u64 (&e)[16], u64 *lds, int t, int rloc, int tid) {
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) lds[hc_rows_lds(rloc, tid * 16 + lo)] = e[lo];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) e[k] = lds[hc_rows_lds(k, t)];
+}
+
+// x mod q for x < 2^64 with mu = floor(2^64/q): result canonical
+__device__ __forceinline__ u64 hc_barrett64(u64 x, u64 q, u64 mu) {
+    u64 r = x - hc_mulhi(x, mu) * q;   // in [0, 2q)
+    return hc_csub(r, q);
+}
+
+// ================================================================ standalone transforms (L0 API)
+// grid = (16, count): blockIdx.x = tile, blockIdx.y = row (limb-polynomial) index
+__global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd(const u64 *in, u64 *out, HcTwTab T, u64 q) {
+    __shared__ u64 lds[HC_COLS_LDS];
+    const int t = threadIdx.x, c = t & 15, tid = t >> 4;
+    const size_t base = (size_t)blockIdx.y * 65536 + blockIdx.x * 16 + c;
+    u64 e[16];
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) e[hi] = in[base + (size_t)(hi * 16 + tid) * 256];
+    hc_cols_fwd(e, lds, T, c, tid, q);
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) out[base + (size_t)(tid * 16 + lo) * 256] = e[lo];
+}
+__global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon(const u64 *in, u64 *out, HcTwTab T, u64 q) {
+    __shared__ u64 lds[HC_ROWS_LDS];
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
+    const size_t pbase = (size_t)blockIdx.y * 65536;
+    u64 e[16];
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) e[hi] = in[pbase + (size_t)row * 256 + hi * 16 + tid];
+    hc_rows_fwd(e, lds, T, row, rloc, tid, q);
+    __syncthreads();
+    hc_rows_lo_to_lin(e, lds, t, rloc, tid);
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t] = hc_csub(hc_csub(e[k], 2 * q), q);
+}
+__global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv(const u64 *in, u64 *out, HcTwTab T, u64 q) {
+    __shared__ u64 lds[HC_ROWS_LDS];
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
+    const size_t pbase = (size_t)blockIdx.y * 65536;
+    u64 e[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) e[k] = in[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t];
+    hc_rows_lin_to_lo(e, lds, t, rloc, tid);
+    __syncthreads();
+    hc_rows_inv(e, lds, T, row, rloc, tid, q);
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) out[pbase + (size_t)row * 256 + hi * 16 + tid] = e[hi];
+}
+__global__ __launch_bounds__(HC_TPB) void hc_k_cols_inv_canon(const u64 *in, u64 *out, HcTwTab T, u64 q) {
+    __shared__ u64 lds[HC_COLS_LDS];
+    const int t = threadIdx.x, c = t & 15, tid = t >> 4;
+    const size_t base = (size_t)blockIdx.y * 65536 + blockIdx.x * 16 + c;
+    u64 e[16];
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) e[lo] = in[base + (size_t)(tid * 16 + lo) * 256];
+    hc_cols_inv(e, lds, T, c, tid, q);
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_csub(e[hi], q);
+}
+
+// ================================================================ pointwise kernels (L0 API + load-time conversions)
+enum { HC_PW_MUL = 0, HC_PW_ADD = 1, HC_PW_SUB = 2, HC_PW_MULC = 3, HC_PW_TO_MONT = 4, HC_PW_FROM_MONT = 5 };
+template <int OP>
+__global__ __launch_bounds__(HC_TPB) void hc_k_pointwise(const u64 *a, const u64 *b, u64 *out, size_t n, HcMod m, HcTw cst) {
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * HC_TPB) {
+        u64 x = a[i], r;
+        if (OP == HC_PW_MUL) r = hc_mont(x, hc_mont(b[i], m.r2, m.q, m.qinv), m.q, m.qinv);
+        else if (OP == HC_PW_ADD) r = hc_addmod(x, b[i], m.q);
+        else if (OP == HC_PW_SUB) r = hc_submod(x, b[i], m.q);
+        else if (OP == HC_PW_MULC) r = hc_mul_shoup(x, cst.w, cst.ws, m.q);
+        else if (OP == HC_PW_TO_MONT) r = hc_mont(x, m.r2, m.q, m.qinv);
+        else r = hc_mont(x, 1, m.q, m.qinv);
+        out[i] = r;
+    }
+}
+// Shoup companion of a row of fixed multiplicands: ws = floor(w * 2^64 / q)
+__global__ __launch_bounds__(HC_TPB) void hc_k_shoup_companion(const u64 *w, u64 *ws, size_t n, u64 q) {
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * HC_TPB)
+        ws[i] = hc_shoup_companion(w[i], q);
+}
+// interleave (w, ws) into HcTw pairs, optionally into the rows-kernel "lo-local coalesced" order:
+//   natural index (R, C = tid*16+lo)  ->  pair slot ((R>>4)*16 + lo) * 256 + (R&15)*16 + tid
+__global__ __launch_bounds__(HC_TPB) void hc_k_make_pairs(const u64 *w, HcTw *out, size_t n, u64 q, int lo_local_order) {
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * HC_TPB) {
+        u64 x = w[i];
+        HcTw p; p.w = x; p.ws = hc_shoup_companion(x, q);
+        size_t j = i;
+        if (lo_local_order) {
+            size_t poly = i >> 16; int R = (int)((i >> 8) & 255), C = (int)(i & 255);
+            j = (poly << 16) + (size_t)(((R >> 4) * 16 + (C & 15)) * 256 + (R & 15) * 16 + (C >> 4));
+        }
+        out[j] = p;
+    }
+}
+
+// ring.PermuteNTTIndex on the fly: source index of destination i for Galois element g (N = 2^16)
+__device__ __forceinline__ u32 hc_perm_src(u32 i, u32 g) {
+    u32 r = __brev(i) >> 16;
+    u32 t = ((g * (2 * r + 1)) & 0x1FFFFu) >> 1;     // ((g*(2r+1) mod 2N) - 1) / 2 ; the product is odd
+    return __brev(t) >> 16;
+}
+__global__ __launch_bounds__(HC_TPB) void hc_k_permute(const u64 *in, u64 *out, u32 g, int count) {
+    const size_t n = (size_t)count << 16;
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * HC_TPB)
+        out[i] = in[(i & ~(size_t)0xFFFF) + hc_perm_src((u32)(i & 0xFFFF), g)];
+}
+
+// ================================================================ loop A (conv.go:525-531), fused
+// Per output channel i and ciphertext polynomial p:
+//   a_l = c'_p[l] (*) k_i[l]  (l = 0,1; c' = ct_in * MultByConst constant, k in Montgomery form)
+//   rescale by Q1: t = INTT_Q1(a_1); t = [t + h]_{Q1}; u = NTT_Q0(t - h); out = (a_0 - u) * Q1^-1 mod Q0
+struct HcLoopA {
+    const u64 *ctc;   // [2 polys][2 limbs][N]   ct_in times the integer constant, canonical
+    const u64 *ker;   // [max_ob][2 limbs][N]    Montgomery form
+    u64 *tmp;         // [chunk][2 polys][N]
+    u64 *cts;         // [max_ob][2 polys][N]    level-0 outputs
+    int i0, norm;     // first channel of this chunk; channel of job j is i0 + (j>>1)*norm, poly = j&1
+    HcMod m0, m1;
+    HcTw q1inv;       // Q1^-1 mod Q0
+    u64 h, negh0;     // (Q1-1)>>1 ; Q0 - (h mod Q0)
+};
+// KA1: rows-inverse of a_1 (mod Q1). grid = (16, jobs)
+__global__ __launch_bounds__(HC_TPB) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
+    __shared__ u64 lds[HC_ROWS_LDS];
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
+    const int job = blockIdx.y, p = job & 1, i = A.i0 + (job >> 1) * A.norm;
+    const u64 *c = A.ctc + ((size_t)p * 2 + 1) * 65536, *k = A.ker + ((size_t)i * 2 + 1) * 65536;
+    u64 e[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+        const size_t off = (size_t)(blockIdx.x * 16 + kk) * 256 + t;
+        e[kk] = hc_mont(c[off], k[off], A.m1.q, A.m1.qinv);
+    }
+    hc_rows_lin_to_lo(e, lds, t, rloc, tid);
+    __syncthreads();
+    hc_rows_inv(e, lds, T1inv, row, rloc, tid, A.m1.q);
+    u64 *o = A.tmp + (size_t)job * 65536 + (size_t)row * 256;
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
+}
+// KA2: cols-inverse mod Q1, centred lift to Q0, cols-forward mod Q0, in place on tmp. grid = (16, jobs)
+__global__ __launch_bounds__(HC_TPB) void hc_k_a2(HcLoopA A, HcTwTab T1inv, HcTwTab T0fwd) {
+    __shared__ u64 lds[HC_COLS_LDS];
+    const int t = threadIdx.x, c = t & 15, tid = t >> 4;
+    u64 *base = A.tmp + (size_t)blockIdx.y * 65536 + blockIdx.x * 16 + c;
+    u64 e[16];
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) e[lo] = base[(size_t)(tid * 16 + lo) * 256];
+    hc_cols_inv(e, lds, T1inv, c, tid, A.m1.q);
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) {
+        u64 v = hc_csub(hc_csub(e[hi], A.m1.q) + A.h, A.m1.q);   // [t + h]_{Q1}
+        e[hi] = v + A.negh0;                                      // (.. - h) mod Q0, lazy < 2*Q0
+    }
+    __syncthreads();
+    hc_cols_fwd(e, lds, T0fwd, c, tid, A.m0.q);
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
+}
+// KA3: rows-forward mod Q0, then out = (a_0 - u) * Q1^-1. grid = (16, jobs)
+__global__ __launch_bounds__(HC_TPB) void hc_k_a3(HcLoopA A, HcTwTab T0fwd) {
+    __shared__ u64 lds[HC_ROWS_LDS];
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
+    const int job = blockIdx.y, p = job & 1, i = A.i0 + (job >> 1) * A.norm;
+    const u64 *in = A.tmp + (size_t)job * 65536 + (size_t)row * 256;
+    u64 e[16];
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
+    hc_rows_fwd(e, lds, T0fwd, row, rloc, tid, A.m0.q);
+    __syncthreads();
+    hc_rows_lo_to_lin(e, lds, t, rloc, tid);
+    const u64 *c = A.ctc + ((size_t)p * 2) * 65536, *k = A.ker + ((size_t)i * 2) * 65536;
+    u64 *o = A.cts + ((size_t)i * 2 + p) * 65536;
+    const u64 q = A.m0.q;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+        const size_t off = (size_t)(blockIdx.x * 16 + kk) * 256 + t;
+        u64 a0 = hc_mont(c[off], k[off], q, A.m0.qinv);
+        u64 u = hc_csub(hc_csub(e[kk], 2 * q), q);
+        o[off] = hc_mul_shoup(hc_submod(a0, u, q), A.q1inv.w, A.q1inv.ws, q);
+    }
+}
+
+// ================================================================ loop B node (conv.go:288-292), fused
+// Node n of a tree level: y = cts[i], x = cts[i+step], i = n*norm.
+struct HcLoopB {
+    u64 *cts;            // [max_cnum][2][N]
+    u64 *tmpC;           // [chunk][N]      c1 of t2 through iNTT_Q0 / NTT_P
+    u64 *tmpF;           // [chunk][2][N]   F0 = t2.c0*P + b_Q (*) t2.c1 ; F1 = a_Q (*) t2.c1   (mod Q0)
+    u64 *tmpE;           // [chunk][2][N]   P-part accumulators through iNTT_P / NTT_Q0
+    const HcTw *idx;     // [N]             idx[s] plaintext, natural order
+    const HcTw *evkQ;    // [2][N]          b_Q, a_Q natural order (plain form + companion)
+    const HcTw *evkP;    // [2][N]          b_P, a_P in lo-local-coalesced order
+    int n0, step, norm;  // first node of this chunk
+    HcMod m0, mp;
+    HcTw pmodq;          // P mod Q0
+    HcTw pinv;           // P^-1 mod Q0
+    u64 mu0;             // floor(2^64/Q0)
+    double pf;           // (double)P
+    u32 gal;             // Galois element of this level
+};
+// KB1: t1/t2, Q-part of the key switch, rows-inverse (mod Q0) of t2.c1. grid = (16, nodes)
+__global__ __launch_bounds__(HC_TPB) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
+    __shared__ u64 lds[HC_ROWS_LDS];
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
+    const int node = blockIdx.y, i = (B.n0 + node) * B.norm;
+    u64 *y = B.cts + (size_t)i * 2 * 65536, *x = B.cts + (size_t)(i + B.step) * 2 * 65536;
+    u64 *F = B.tmpF + (size_t)node * 2 * 65536;
+    const u64 q = B.m0.q;
+    u64 e[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+        const size_t off = (size_t)(blockIdx.x * 16 + kk) * 256 + t;
+        const HcTw I = B.idx[off];
+        // polynomial 1 first: its t2 feeds the key switch
+        u64 m1 = hc_mul_shoup(x[65536 + off], I.w, I.ws, q);
+        u64 y1 = y[65536 + off];
+        u64 t2c1 = hc_submod(y1, m1, q);
+        y[65536 + off] = hc_addmod(y1, m1, q);                       // t1.c1 (conv.go:290)
+        const HcTw bq = B.evkQ[off], aq = B.evkQ[65536 + off];
+        F[65536 + off] = hc_mul_shoup(t2c1, aq.w, aq.ws, q);
+        u64 G = hc_mul_shoup(t2c1, bq.w, bq.ws, q);
+        u64 m0 = hc_mul_shoup(x[off], I.w, I.ws, q);
+        u64 y0 = y[off];
+        u64 t2c0 = hc_submod(y0, m0, q);
+        y[off] = hc_addmod(y0, m0, q);                               // t1.c0
+        F[off] = hc_addmod(hc_mul_shoup(t2c0, B.pmodq.w, B.pmodq.ws, q), G, q);
+        e[kk] = t2c1;
+    }
+    hc_rows_lin_to_lo(e, lds, t, rloc, tid);
+    __syncthreads();
+    hc_rows_inv(e, lds, T0inv, row, rloc, tid, q);
+    u64 *o = B.tmpC + (size_t)node * 65536 + (size_t)row * 256;
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
+}
+// KB2: cols-inverse mod Q0 (-> canonical c < Q0 < P), cols-forward mod P, in place on tmpC. grid = (16, nodes)
+__global__ __launch_bounds__(HC_TPB) void hc_k_b2(HcLoopB B, HcTwTab T0inv, HcTwTab TPfwd) {
+    __shared__ u64 lds[HC_COLS_LDS];
+    const int t = threadIdx.x, c = t & 15, tid = t >> 4;
+    u64 *base = B.tmpC + (size_t)blockIdx.y * 65536 + blockIdx.x * 16 + c;
+    u64 e[16];
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) e[lo] = base[(size_t)(tid * 16 + lo) * 256];
+    hc_cols_inv(e, lds, T0inv, c, tid, B.m0.q);
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) e[hi] = hc_csub(e[hi], B.m0.q);
+    __syncthreads();
+    hc_cols_fwd(e, lds, TPfwd, c, tid, B.mp.q);
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
+}
+// KB3: rows-forward mod P, multiply by b_P and a_P, rows-inverse mod P of both. grid = (16, nodes)
+__global__ __launch_bounds__(HC_TPB) void hc_k_b3(HcLoopB B, HcTwTab TPfwd, HcTwTab TPinv) {
+    __shared__ u64 lds[HC_ROWS_LDS];
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
+    const int node = blockIdx.y;
+    const u64 *in = B.tmpC + (size_t)node * 65536 + (size_t)row * 256;
+    const u64 q = B.mp.q;
+    u64 cp[16], e[16];
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) cp[hi] = in[hi * 16 + tid];
+    hc_rows_fwd(cp, lds, TPfwd, row, rloc, tid, q);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const HcTw *ev = B.evkP + (size_t)k * 65536 + (size_t)blockIdx.x * 4096 + t;
+#pragma unroll
+        for (int lo = 0; lo < 16; lo++) {
+            const HcTw w = ev[lo * 256];
+            e[lo] = hc_mul_shoup_lazy(cp[lo], w.w, w.ws, q);
+        }
+        __syncthreads();
+        hc_rows_inv(e, lds, TPinv, row, rloc, tid, q);
+        u64 *o = B.tmpE + ((size_t)node * 2 + k) * 65536 + (size_t)row * 256;
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
+    }
+}
+// KB4: cols-inverse mod P, exact basis extension P -> Q0 (ring.modUpExact, one P prime), cols-forward mod Q0.
+// grid = (16, 2*nodes), in place on tmpE
+__global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTwTab T0fwd) {
+    __shared__ u64 lds[HC_COLS_LDS];
+    const int t = threadIdx.x, c = t & 15, tid = t >> 4;
+    u64 *base = B.tmpE + (size_t)blockIdx.y * 65536 + blockIdx.x * 16 + c;
+    const u64 P = B.mp.q, q = B.m0.q;
+    u64 e[16];
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) e[lo] = base[(size_t)(tid * 16 + lo) * 256];
+    hc_cols_inv(e, lds, TPinv, c, tid, P);
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) {
+        const u64 yv = hc_csub(e[hi], P);                        // [d]_P in [0,P)
+        const u64 v = (u64)((double)yv / B.pf);                   // fp64 overflow count, as reconstructRNS
+        u64 r = hc_barrett64(yv, q, B.mu0);
+        if (v) r = hc_submod(r, B.pmodq.w, q);                    // v is 0 or 1 for a single P prime
+        e[hi] = r;
+    }
+    __syncthreads();
+    hc_cols_fwd(e, lds, T0fwd, c, tid, q);
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
+}
+// KB5: rows-forward mod Q0 of both extensions, d = (F - n) * P^-1, row-local Galois permutation through LDS,
+// ct[i] = t1 + perm(d). grid = (16, nodes). Requires the permutation to stay inside 256-blocks (galEl = 2^j+1, j >= 9).
+__global__ __launch_bounds__(HC_TPB) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, const u64 *bias) {
+    __shared__ u64 lds[HC_ROWS_LDS];
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
+    const int node = blockIdx.y, i = (B.n0 + node) * B.norm;
+    const u64 q = B.m0.q;
+    u64 e[16];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const u64 *in = B.tmpE + ((size_t)node * 2 + k) * 65536 + (size_t)row * 256;
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
+        if (k) __syncthreads();
+        hc_rows_fwd(e, lds, T0fwd, row, rloc, tid, q);
+        __syncthreads();
+        hc_rows_lo_to_lin(e, lds, t, rloc, tid);
+        const u64 *F = B.tmpF + ((size_t)node * 2 + k) * 65536;
+        u64 *y = B.cts + ((size_t)i * 2 + k) * 65536;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            const size_t off = (size_t)(blockIdx.x * 16 + kk) * 256 + t;
+            u64 n = hc_csub(hc_csub(e[kk], 2 * q), q);
+            e[kk] = hc_mul_shoup(hc_submod(F[off], n, q), B.pinv.w, B.pinv.ws, q);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) lds[hc_rows_lds(kk, t)] = e[kk];
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            const u32 dst = (u32)((blockIdx.x * 16 + kk) * 256 + t);
+            const u32 src = hc_perm_src(dst, B.gal);
+            const size_t off = dst;
+            u64 r = hc_addmod(y[off], lds[hc_rows_lds(kk, (int)(src & 255))], q);
+            if (bias != nullptr && k == 0) r = hc_addmod(r, bias[off], q);
+            y[off] = r;
+        }
+    }
+}

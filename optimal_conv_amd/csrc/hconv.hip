@@ -1,0 +1,674 @@
+// hconv.hip — C ABI (include/hconv.h) + host orchestration of the gfx950 kernels in hc_kernels.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o optimal_conv_amd/libhconv.so csrc/hconv.hip
+// There is deliberately no CPU path in this library: every entry point that computes launches HIP kernels.
+#ifdef HC_EMU
+#include "hip_emu.h"   // tests/kernel_emu: CPU fiber stand-in used only by -m "not gpu" tests
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hconv.h"
+#include "hc_kernels.h"
+
+#define HC_N 65536
+#define HC_LOGN 16
+
+// ------------------------------------------------------------------ host number theory (table construction)
+static u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+static u64 h_powmod(u64 b, u64 e, u64 q) {
+    u64 r = 1; b %= q;
+    while (e) { if (e & 1) r = h_mulmod(r, b, q); b = h_mulmod(b, b, q); e >>= 1; }
+    return r;
+}
+static u64 h_inv(u64 a, u64 q) { return h_powmod(a % q, q - 2, q); }
+static u64 h_shoup(u64 w, u64 q) { return (u64)((((u128)w) << 64) / q); }
+static HcTw h_pair(u64 w, u64 q) { HcTw p; p.w = w; p.ws = h_shoup(w, q); return p; }
+static bool h_is_prime(u64 n) {
+    if (n < 2) return false;
+    for (u64 p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) { if (n % p == 0) return n == p; }
+    u64 d = n - 1; int s = 0; while ((d & 1) == 0) { d >>= 1; s++; }
+    for (u64 a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+        u64 x = h_powmod(a, d, n); if (x == 1 || x == n - 1) continue;
+        bool comp = true;
+        for (int i = 1; i < s; i++) { x = h_mulmod(x, x, n); if (x == n - 1) { comp = false; break; } }
+        if (comp) return false;
+    }
+    return true;
+}
+// Same rule as the reference's dependency (ring.primitiveRoot): candidates 3,4,5,... and the
+// first g with g^((q-1)/f) != 1 for every prime factor f of q-1 wins. psi = g^((q-1)/2N).
+static u64 h_primitive_root(u64 q) {
+    std::vector<u64> fac; u64 n = q - 1;
+    for (u64 p = 2; p * p <= n; p += (p == 2 ? 1 : 2)) if (n % p == 0) { fac.push_back(p); while (n % p == 0) n /= p; }
+    if (n > 1) fac.push_back(n);
+    for (u64 g = 3;; g++) {
+        bool ok = true;
+        for (u64 f : fac) if (h_powmod(g, (q - 1) / f, q) == 1) { ok = false; break; }
+        if (ok) return g;
+    }
+}
+static u32 h_bitrev16(u32 x) { u32 r = 0; for (int i = 0; i < 16; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
+
+// ------------------------------------------------------------------ context
+struct HcModHost {
+    HcMod m;
+    u64 psi, psi_inv;
+    HcTwTab fwd, inv;            // device tables
+    std::vector<void *> allocs;
+};
+struct HcEvk { HcTw *q_pairs; HcTw *p_pairs; bool row_local; };   // [2][N] each
+struct HcProfRec { std::string name; hipEvent_t a, b; };
+
+struct hc_ctx {
+    int device = 0, nq = 0, np = 0;
+    hipStream_t stream = nullptr;
+    std::vector<HcModHost> mods;
+    std::map<u64, HcEvk> evk;
+    HcTw *idx_pairs = nullptr;   // [logN][N]
+    // workspace
+    u64 *ws_cts = nullptr; size_t ws_cts_rows = 0;
+    u64 *ws_ctc = nullptr;
+    u64 *ws_tmp = nullptr; size_t ws_tmp_rows = 0;
+    long chunk_nodes = 32;
+    long profile = 0;
+    std::vector<HcProfRec> prof;
+    std::map<std::string, std::pair<double, long>> prof_acc;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    std::string err;
+};
+struct hc_ker { u64 *d = nullptr; int max_ob = 0; };
+
+static std::string g_create_err;
+static int hc_fail(hc_ctx *c, int code, const char *fmt, ...) {
+    char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+#define HC_HIP(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hc_fail(c, HC_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+#define HC_ENTER(c) do { if (!(c)) return HC_ERR_ARG; HC_HIP(c, hipSetDevice((c)->device)); } while (0)
+
+template <class K, class... Args>
+static int hc_launch(hc_ctx *c, const char *name, K kernel, dim3 grid, Args... args) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (c->profile) { HC_HIP(c, hipEventCreate(&a)); HC_HIP(c, hipEventCreate(&b)); HC_HIP(c, hipEventRecord(a, c->stream)); }
+    hipLaunchKernelGGL(kernel, grid, dim3(HC_TPB), 0, c->stream, args...);
+    HC_HIP(c, hipGetLastError());
+    if (c->profile) { HC_HIP(c, hipEventRecord(b, c->stream)); c->prof.push_back({name, a, b}); }
+    return HC_OK;
+}
+#define HC_TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
+
+static int hc_prof_flush(hc_ctx *c) {
+    if (c->prof.empty()) return HC_OK;
+    HC_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto &r : c->prof) {
+        float ms = 0; HC_HIP(c, hipEventElapsedTime(&ms, r.a, r.b));
+        auto &acc = c->prof_acc[r.name]; acc.first += ms; acc.second += 1;
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    c->prof.clear();
+    return HC_OK;
+}
+
+template <class T>
+static int hc_dev_upload(hc_ctx *c, HcModHost *owner, const std::vector<T> &v, const T **out) {
+    void *d = nullptr;
+    HC_HIP(c, hipMalloc(&d, v.size() * sizeof(T)));
+    HC_HIP(c, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    owner->allocs.push_back(d);
+    *out = (const T *)d;
+    return HC_OK;
+}
+
+// Twiddle tables (layouts documented at HcTwTab). pw[idx] = psi^{bitrev16(idx)} as Lattigo's NttPsi (without
+// the Montgomery factor).
+static int hc_build_tables(hc_ctx *c, HcModHost *mh, bool inverse) {
+    const u64 q = mh->m.q, base = inverse ? mh->psi_inv : mh->psi;
+    std::vector<u64> pw(HC_N);
+    {
+        std::vector<u64> nat(HC_N); nat[0] = 1;
+        for (int j = 1; j < HC_N; j++) nat[j] = h_mulmod(nat[j - 1], base, q);
+        for (int j = 0; j < HC_N; j++) pw[h_bitrev16((u32)j)] = nat[j];
+    }
+    std::vector<HcTw> rowsA(256 * 16), rowsB((size_t)256 * 16 * 16), colsA(16), colsB(16 * 16);
+    HcTw zero; zero.w = 0; zero.ws = 0;
+    for (auto &x : rowsA) x = zero;
+    for (auto &x : rowsB) x = zero;
+    for (auto &x : colsA) x = zero;
+    for (auto &x : colsB) x = zero;
+    for (int s = 0; s < 4; s++) for (int g = 0; g < (1 << s); g++) {
+        const int slot = (1 << s) - 1 + g;
+        colsA[slot] = h_pair(pw[(1 << s) + g], q);
+        for (int tid = 0; tid < 16; tid++) colsB[slot * 16 + tid] = h_pair(pw[(16 << s) + tid * (1 << s) + g], q);
+        for (int row = 0; row < 256; row++) {
+            rowsA[row * 16 + slot] = h_pair(pw[(size_t)(1 << s) * (256 + row) + g], q);
+            for (int tid = 0; tid < 16; tid++)
+                rowsB[((size_t)row * 16 + slot) * 16 + tid] = h_pair(pw[(size_t)(16 << s) * (256 + row) + tid * (1 << s) + g], q);
+        }
+    }
+    HcTwTab T; memset(&T, 0, sizeof T);
+    HC_TRY(hc_dev_upload(c, mh, rowsA, &T.rowsA)); HC_TRY(hc_dev_upload(c, mh, rowsB, &T.rowsB));
+    HC_TRY(hc_dev_upload(c, mh, colsA, &T.colsA)); HC_TRY(hc_dev_upload(c, mh, colsB, &T.colsB));
+    T.ninv = h_pair(mh->m.ninv, q);
+    T.w_last_ninv = h_pair(h_mulmod(pw[1], mh->m.ninv, q), q);
+    if (inverse) mh->inv = T; else mh->fwd = T;
+    return HC_OK;
+}
+
+extern "C" int hc_version(void) { return 1; }
+extern "C" const char *hc_last_error(const hc_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, const uint64_t *p, int np, int device) {
+    if (!out || !q || nq < 1 || np < 0 || (np > 0 && !p)) return hc_fail(nullptr, HC_ERR_ARG, "hc_ctx_create: bad arguments");
+    if (logN != HC_LOGN) return hc_fail(nullptr, HC_ERR_UNSUPPORTED, "hc_ctx_create: logN=%d (this build is specialised for logN=16, the only ring degree the reference CLI uses: main.go:578-579)", logN);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0)
+        return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: HIP device %d not available (%d devices) - this library has no CPU path", device, ndev);
+    hc_ctx *c = new hc_ctx();
+    c->device = device; c->nq = nq; c->np = np;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: cannot create stream on device %d", device); }
+    hipEventCreate(&c->t0); hipEventCreate(&c->t1);
+    c->mods.resize((size_t)(nq + np));
+    for (int i = 0; i < nq + np; i++) {
+        const u64 qi = i < nq ? q[i] : p[i - nq];
+        if (qi >> 62 || !h_is_prime(qi) || (qi - 1) % (2ull * HC_N)) {
+            std::string e = "hc_ctx_create: modulus is not an NTT-friendly prime below 2^62";
+            hc_ctx_destroy(c); g_create_err = e; return HC_ERR_ARG;
+        }
+        HcModHost &mh = c->mods[(size_t)i];
+        mh.m.q = qi;
+        u64 inv = 1; for (int k = 0; k < 6; k++) inv *= 2 - qi * inv;
+        mh.m.qinv = inv;
+        u64 r = (u64)((((u128)1) << 64) % qi);
+        mh.m.r2 = h_mulmod(r, r, qi);
+        mh.m.ninv = h_inv(HC_N, qi); mh.m.ninv_s = h_shoup(mh.m.ninv, qi);
+        u64 g = h_primitive_root(qi), power = (qi - 1) / (2ull * HC_N);
+        mh.psi = h_powmod(g, power, qi); mh.psi_inv = h_powmod(g, (qi - 1) - power, qi);
+        int rc = hc_build_tables(c, &mh, false); if (!rc) rc = hc_build_tables(c, &mh, true);
+        if (rc) { g_create_err = c->err; hc_ctx_destroy(c); return rc; }
+    }
+    *out = c;
+    return HC_OK;
+}
+
+extern "C" void hc_ctx_destroy(hc_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto &mh : c->mods) for (void *d : mh.allocs) hipFree(d);
+    for (auto &kv : c->evk) { hipFree(kv.second.q_pairs); hipFree(kv.second.p_pairs); }
+    if (c->idx_pairs) hipFree(c->idx_pairs);
+    if (c->ws_cts) hipFree(c->ws_cts);
+    if (c->ws_ctc) hipFree(c->ws_ctc);
+    if (c->ws_tmp) hipFree(c->ws_tmp);
+    if (c->t0) hipEventDestroy(c->t0);
+    if (c->t1) hipEventDestroy(c->t1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ------------------------------------------------------------------ memory
+extern "C" int hc_malloc(hc_ctx *c, size_t bytes, void **dptr) { HC_ENTER(c); if (!dptr) return hc_fail(c, HC_ERR_ARG, "hc_malloc: null"); HC_HIP(c, hipMalloc(dptr, bytes)); return HC_OK; }
+extern "C" int hc_free(hc_ctx *c, void *dptr) { HC_ENTER(c); HC_HIP(c, hipStreamSynchronize(c->stream)); HC_HIP(c, hipFree(dptr)); return HC_OK; }
+extern "C" int hc_upload(hc_ctx *c, void *dst, const void *src, size_t bytes) {
+    HC_ENTER(c); if (!dst || !src) return hc_fail(c, HC_ERR_ARG, "hc_upload: null pointer");
+    HC_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hipStreamSynchronize(c->stream));   // the host buffer may be released right after return (cgo rule)
+    return HC_OK;
+}
+extern "C" int hc_download(hc_ctx *c, void *dst, const void *src, size_t bytes) {
+    HC_ENTER(c); if (!dst || !src) return hc_fail(c, HC_ERR_ARG, "hc_download: null pointer");
+    HC_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(c, hipStreamSynchronize(c->stream));
+    return HC_OK;
+}
+extern "C" int hc_sync(hc_ctx *c) { HC_ENTER(c); HC_HIP(c, hipStreamSynchronize(c->stream)); return hc_prof_flush(c); }
+
+// ------------------------------------------------------------------ L0
+static int hc_check_mod(hc_ctx *c, int mod, const char *fn) {
+    if (mod < 0 || mod >= c->nq + c->np) return hc_fail(c, HC_ERR_ARG, "%s: modulus index %d out of range", fn, mod);
+    return HC_OK;
+}
+static dim3 hc_pw_grid(size_t n) { size_t b = (n + HC_TPB - 1) / HC_TPB; if (b > 4096) b = 4096; return dim3((unsigned)b); }
+
+static int hc_ensure_tmp(hc_ctx *c, size_t rows) {
+    if (c->ws_tmp_rows >= rows) return HC_OK;
+    HC_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->ws_tmp) HC_HIP(c, hipFree(c->ws_tmp));
+    c->ws_tmp = nullptr; c->ws_tmp_rows = 0;
+    HC_HIP(c, hipMalloc((void **)&c->ws_tmp, rows * HC_N * sizeof(u64)));
+    c->ws_tmp_rows = rows;
+    return HC_OK;
+}
+
+extern "C" int hc_ntt(hc_ctx *c, int mod, const uint64_t *in, uint64_t *out, int count) {
+    HC_ENTER(c); HC_TRY(hc_check_mod(c, mod, "hc_ntt"));
+    if (!in || !out || count < 1) return hc_fail(c, HC_ERR_ARG, "hc_ntt: bad arguments");
+    HcModHost &mh = c->mods[(size_t)mod];
+    HC_TRY(hc_ensure_tmp(c, (size_t)count));
+    HC_TRY(hc_launch(c, "cols_fwd", hc_k_cols_fwd, dim3(16, (unsigned)count), (const u64 *)in, c->ws_tmp, mh.fwd, mh.m.q));
+    HC_TRY(hc_launch(c, "rows_fwd_canon", hc_k_rows_fwd_canon, dim3(16, (unsigned)count), (const u64 *)c->ws_tmp, (u64 *)out, mh.fwd, mh.m.q));
+    return HC_OK;
+}
+extern "C" int hc_intt(hc_ctx *c, int mod, const uint64_t *in, uint64_t *out, int count) {
+    HC_ENTER(c); HC_TRY(hc_check_mod(c, mod, "hc_intt"));
+    if (!in || !out || count < 1) return hc_fail(c, HC_ERR_ARG, "hc_intt: bad arguments");
+    HcModHost &mh = c->mods[(size_t)mod];
+    HC_TRY(hc_ensure_tmp(c, (size_t)count));
+    HC_TRY(hc_launch(c, "rows_inv", hc_k_rows_inv, dim3(16, (unsigned)count), (const u64 *)in, c->ws_tmp, mh.inv, mh.m.q));
+    HC_TRY(hc_launch(c, "cols_inv_canon", hc_k_cols_inv_canon, dim3(16, (unsigned)count), (const u64 *)c->ws_tmp, (u64 *)out, mh.inv, mh.m.q));
+    return HC_OK;
+}
+template <int OP>
+static int hc_pw(hc_ctx *c, const char *fn, int mod, const uint64_t *a, const uint64_t *b, uint64_t *out, int count, HcTw cst) {
+    HC_ENTER(c); HC_TRY(hc_check_mod(c, mod, fn));
+    if (!a || !out || count < 1) return hc_fail(c, HC_ERR_ARG, "%s: bad arguments", fn);
+    size_t n = (size_t)count * HC_N;
+    return hc_launch(c, fn, hc_k_pointwise<OP>, hc_pw_grid(n), (const u64 *)a, (const u64 *)b, (u64 *)out, n, c->mods[(size_t)mod].m, cst);
+}
+extern "C" int hc_mul(hc_ctx *c, int mod, const uint64_t *a, const uint64_t *b, uint64_t *out, int count) { HcTw z; z.w = z.ws = 0; if (!b) return HC_ERR_ARG; return hc_pw<HC_PW_MUL>(c, "hc_mul", mod, a, b, out, count, z); }
+extern "C" int hc_add(hc_ctx *c, int mod, const uint64_t *a, const uint64_t *b, uint64_t *out, int count) { HcTw z; z.w = z.ws = 0; if (!b) return HC_ERR_ARG; return hc_pw<HC_PW_ADD>(c, "hc_add", mod, a, b, out, count, z); }
+extern "C" int hc_sub(hc_ctx *c, int mod, const uint64_t *a, const uint64_t *b, uint64_t *out, int count) { HcTw z; z.w = z.ws = 0; if (!b) return HC_ERR_ARG; return hc_pw<HC_PW_SUB>(c, "hc_sub", mod, a, b, out, count, z); }
+extern "C" int hc_mul_const(hc_ctx *c, int mod, const uint64_t *a, uint64_t k, uint64_t *out, int count) {
+    if (!c) return HC_ERR_ARG; HC_TRY(hc_check_mod(c, mod, "hc_mul_const"));
+    u64 q = c->mods[(size_t)mod].m.q;
+    return hc_pw<HC_PW_MULC>(c, "hc_mul_const", mod, a, a, out, count, h_pair(k % q, q));
+}
+extern "C" int hc_permute(hc_ctx *c, uint64_t galEl, const uint64_t *in, uint64_t *out, int count) {
+    HC_ENTER(c);
+    if (!in || !out || in == out || count < 1 || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_permute: bad arguments (in/out must differ, galEl odd)");
+    return hc_launch(c, "permute", hc_k_permute, hc_pw_grid((size_t)count * HC_N), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), count);
+}
+
+// getConstAndScale + scaleUpExact of the reference's dependency: a float64 constant with a
+// fractional part is scaled by float64(Q[level]); the integer is trunc(fl(fl(c*s) + 0.5)) mod q, q - r if negative.
+extern "C" uint64_t hc_const_for(double constant, double q_level_f, uint64_t q, double *scale_mult) {
+    double scale = 1.0;
+    if (constant != 0) { double frac = constant - (double)(int64_t)constant; if (frac != 0) scale = q_level_f; }
+    if (scale_mult) *scale_mult = scale;
+    const bool neg = constant < 0;
+    double x = (neg ? -scale * constant : scale * constant) + 0.5;
+    u64 res;
+    if (x < 18446744073709551616.0) res = (u64)x % q;
+    else {
+        int e; double mant = frexp(x, &e);
+        u64 mi = (u64)ldexp(mant, 53); int sh = e - 53;
+        u64 r = mi % q; for (int i = 0; i < sh; i++) { r += r; if (r >= q) r -= q; }
+        res = r;
+    }
+    return neg ? q - res : res;
+}
+
+// ------------------------------------------------------------------ loop A plumbing
+static int hc_fill_loopA(hc_ctx *c, HcLoopA *A, const u64 *ker, u64 *cts, int norm) {
+    const HcModHost &m0 = c->mods[0], &m1 = c->mods[1];
+    A->ctc = c->ws_ctc; A->ker = ker; A->tmp = c->ws_tmp; A->cts = cts; A->i0 = 0; A->norm = norm;
+    A->m0 = m0.m; A->m1 = m1.m;
+    A->q1inv = h_pair(h_inv(m1.m.q % m0.m.q, m0.m.q), m0.m.q);
+    A->h = (m1.m.q - 1) >> 1; A->negh0 = m0.m.q - (A->h % m0.m.q);
+    return HC_OK;
+}
+
+// ct_in (2x2 rows) times per-limb constants -> ws_ctc
+static int hc_prepare_ctc(hc_ctx *c, const u64 *ct_in, const u64 cst[2]) {
+    if (!c->ws_ctc) HC_HIP(c, hipMalloc((void **)&c->ws_ctc, 4 * HC_N * sizeof(u64)));
+    for (int p = 0; p < 2; p++) for (int l = 0; l < 2; l++) {
+        const HcMod &m = c->mods[(size_t)l].m;
+        size_t off = ((size_t)p * 2 + (size_t)l) * HC_N;
+        HC_TRY(hc_launch(c, "ctc", hc_k_pointwise<HC_PW_MULC>, hc_pw_grid(HC_N), ct_in + off, ct_in + off, c->ws_ctc + off, (size_t)HC_N, m, h_pair(cst[l] % m.q, m.q)));
+    }
+    return HC_OK;
+}
+
+static int hc_loopA_run(hc_ctx *c, const u64 *ker_mont, int max_ob, int norm, u64 *cts) {
+    const int nch = max_ob / norm;                 // channels actually computed (i % norm == 0)
+    const long chunk = c->chunk_nodes < 1 ? 1 : c->chunk_nodes;
+    HC_TRY(hc_ensure_tmp(c, (size_t)(chunk < nch ? chunk : nch) * 5));
+    HcLoopA A; HC_TRY(hc_fill_loopA(c, &A, ker_mont, cts, norm));
+    const HcModHost &m0 = c->mods[0], &m1 = c->mods[1];
+    for (int j0 = 0; j0 < nch; j0 += (int)chunk) {
+        const int nj = (int)((nch - j0) < chunk ? (nch - j0) : chunk);
+        A.i0 = j0 * norm;
+        dim3 grid(16, (unsigned)(2 * nj));
+        HC_TRY(hc_launch(c, "a1_mul_rowsinv", hc_k_a1, grid, A, m1.inv));
+        HC_TRY(hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2, grid, A, m1.inv, m0.fwd));
+        HC_TRY(hc_launch(c, "a3_rowsfwd_rescale", hc_k_a3, grid, A, m0.fwd));
+    }
+    return HC_OK;
+}
+
+// hc_div_round_last (level 1 only on this path): reuse loop A with ker = Montgomery one (c' (*) R = c')
+extern "C" int hc_div_round_last(hc_ctx *c, int level, const uint64_t *x, uint64_t *out) {
+    HC_ENTER(c);
+    if (level != 1 || c->nq < 2) return hc_fail(c, HC_ERR_UNSUPPORTED, "hc_div_round_last: only level 1 -> 0 (the conv path's rescale) is implemented");
+    if (!x || !out) return hc_fail(c, HC_ERR_ARG, "hc_div_round_last: null");
+    // Build a "ciphertext" whose polynomial 0 is x and a kernel equal to R mod q (Montgomery form of 1).
+    HC_TRY(hc_ensure_tmp(c, 16));
+    if (!c->ws_ctc) HC_HIP(c, hipMalloc((void **)&c->ws_ctc, 4 * HC_N * sizeof(u64)));
+    u64 *scratch = nullptr; HC_HIP(c, hipMalloc((void **)&scratch, (size_t)(2 + 4) * HC_N * sizeof(u64)));
+    u64 *one = scratch, *cts = scratch + 2 * HC_N;
+    std::vector<u64> h((size_t)2 * HC_N);
+    for (int l = 0; l < 2; l++) { u64 q = c->mods[(size_t)l].m.q; u64 r = (u64)((((u128)1) << 64) % q); for (int j = 0; j < HC_N; j++) h[(size_t)l * HC_N + (size_t)j] = r; }
+    HC_HIP(c, hipMemcpyAsync(one, h.data(), h.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hipMemcpyAsync(c->ws_ctc, x, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    HC_HIP(c, hipMemcpyAsync(c->ws_ctc + 2 * HC_N, x, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    int rc = hc_loopA_run(c, one, 1, 1, cts);
+    if (!rc) { hipMemcpyAsync(out, cts, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); hipStreamSynchronize(c->stream); }
+    hipFree(scratch);
+    return rc;
+}
+
+// ------------------------------------------------------------------ evk / idx / ker loading
+static int hc_make_pairs(hc_ctx *c, const u64 *d_rows, int rows, u64 q, bool lo_local, HcTw **out) {
+    HcTw *d = nullptr;
+    HC_HIP(c, hipMalloc((void **)&d, (size_t)rows * HC_N * sizeof(HcTw)));
+    int rc = hc_launch(c, "make_pairs", hc_k_make_pairs, hc_pw_grid((size_t)rows * HC_N), d_rows, d, (size_t)rows * HC_N, q, lo_local ? 1 : 0);
+    if (rc) { hipFree(d); return rc; }
+    *out = d;
+    return HC_OK;
+}
+static bool hc_perm_row_local(u64 galEl) {
+    // ring.PermuteNTTIndex stays inside 256-element blocks iff it fixes the top 8 bits of the destination index
+    for (u32 i = 0; i < HC_N; i += 97) {
+        u32 r = h_bitrev16(i), t = (u32)(((galEl * (2ull * r + 1)) & 0x1FFFF) >> 1), s = h_bitrev16(t);
+        if ((s >> 8) != (i >> 8)) return false;
+    }
+    for (u32 i = 0; i < HC_N; i++) {
+        u32 r = h_bitrev16(i), t = (u32)(((galEl * (2ull * r + 1)) & 0x1FFFF) >> 1), s = h_bitrev16(t);
+        if ((s >> 8) != (i >> 8)) return false;
+    }
+    return true;
+}
+extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const uint64_t *a_q, const uint64_t *b_p, const uint64_t *a_p) {
+    HC_ENTER(c);
+    if (!b_q || !a_q || !b_p || !a_p || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_evk_load: bad arguments");
+    if (c->np != 1) return hc_fail(c, HC_ERR_UNSUPPORTED, "hc_evk_load: level-0 key switching with one special prime (the pack evaluator of main.go:446-456) is what is implemented; np=%d", c->np);
+    const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
+    u64 *stage = nullptr; HC_HIP(c, hipMalloc((void **)&stage, 4 * HC_N * sizeof(u64)));
+    const uint64_t *src[4] = {b_q, a_q, b_p, a_p};
+    for (int k = 0; k < 4; k++) HC_HIP(c, hipMemcpyAsync(stage + (size_t)k * HC_N, src[k], HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    // stored form is Montgomery: bring to plain residues, then attach Shoup companions
+    HcTw z; z.w = z.ws = 0;
+    int rc = hc_launch(c, "evk_from_mont", hc_k_pointwise<HC_PW_FROM_MONT>, hc_pw_grid(2 * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)2 * HC_N, m0.m, z);
+    if (!rc) rc = hc_launch(c, "evk_from_mont", hc_k_pointwise<HC_PW_FROM_MONT>, hc_pw_grid(2 * HC_N), (const u64 *)(stage + 2 * HC_N), (const u64 *)(stage + 2 * HC_N), stage + 2 * HC_N, (size_t)2 * HC_N, mp.m, z);
+    HcEvk e; e.q_pairs = e.p_pairs = nullptr; e.row_local = hc_perm_row_local(galEl);
+    if (!rc) rc = hc_make_pairs(c, stage, 2, m0.m.q, false, &e.q_pairs);
+    if (!rc) rc = hc_make_pairs(c, stage + 2 * HC_N, 2, mp.m.q, true, &e.p_pairs);
+    hipStreamSynchronize(c->stream);
+    hipFree(stage);
+    if (rc) { if (e.q_pairs) hipFree(e.q_pairs); if (e.p_pairs) hipFree(e.p_pairs); return rc; }
+    auto it = c->evk.find(galEl);
+    if (it != c->evk.end()) { hipFree(it->second.q_pairs); hipFree(it->second.p_pairs); }
+    c->evk[galEl] = e;
+    return HC_OK;
+}
+
+extern "C" int hc_idx_load(hc_ctx *c, const uint64_t *idx_host) {
+    HC_ENTER(c);
+    const HcModHost &m0 = c->mods[0];
+    u64 *stage = nullptr; HC_HIP(c, hipMalloc((void **)&stage, (size_t)HC_LOGN * HC_N * sizeof(u64)));
+    int rc = HC_OK;
+    if (idx_host) {
+        HC_HIP(c, hipMemcpyAsync(stage, idx_host, (size_t)HC_LOGN * HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    } else {   // conv.go:248-253: coeffs[1<<i] = 1 -> EncodeCoeffs(scale 1) -> ToNTT, on the device
+        HC_HIP(c, hipMemsetAsync(stage, 0, (size_t)HC_LOGN * HC_N * sizeof(u64), c->stream));
+        u64 one = 1;
+        for (int i = 0; i < HC_LOGN; i++) HC_HIP(c, hipMemcpyAsync(stage + (size_t)i * HC_N + ((size_t)1 << i), &one, sizeof one, hipMemcpyHostToDevice, c->stream));
+        HC_HIP(c, hipStreamSynchronize(c->stream));
+        u64 *tmp = nullptr; HC_HIP(c, hipMalloc((void **)&tmp, (size_t)HC_LOGN * HC_N * sizeof(u64)));
+        rc = hc_launch(c, "cols_fwd", hc_k_cols_fwd, dim3(16, HC_LOGN), (const u64 *)stage, tmp, m0.fwd, m0.m.q);
+        if (!rc) rc = hc_launch(c, "rows_fwd_canon", hc_k_rows_fwd_canon, dim3(16, HC_LOGN), (const u64 *)tmp, stage, m0.fwd, m0.m.q);
+        hipStreamSynchronize(c->stream); hipFree(tmp);
+    }
+    HcTw *pairs = nullptr;
+    if (!rc) rc = hc_make_pairs(c, stage, HC_LOGN, m0.m.q, false, &pairs);
+    hipStreamSynchronize(c->stream); hipFree(stage);
+    if (rc) return rc;
+    if (c->idx_pairs) hipFree(c->idx_pairs);
+    c->idx_pairs = pairs;
+    return HC_OK;
+}
+
+static int hc_ker_from_device(hc_ctx *c, u64 *d, int max_ob, bool take, hc_ker **out) {
+    // to Montgomery form, limb by limb: rows alternate Q0, Q1
+    u64 *dst = d;
+    if (!take) { HC_HIP(c, hipMalloc((void **)&dst, (size_t)max_ob * 2 * HC_N * sizeof(u64))); }
+    HcTw z; z.w = z.ws = 0;
+    for (int i = 0; i < max_ob; i++) for (int l = 0; l < 2; l++) {
+        size_t off = ((size_t)i * 2 + (size_t)l) * HC_N;
+        int rc = hc_launch(c, "ker_to_mont", hc_k_pointwise<HC_PW_TO_MONT>, hc_pw_grid(HC_N), (const u64 *)(d + off), (const u64 *)(d + off), dst + off, (size_t)HC_N, c->mods[(size_t)l].m, z);
+        if (rc) { hipFree(dst); return rc; }
+    }
+    HC_HIP(c, hipStreamSynchronize(c->stream));
+    hc_ker *k = new hc_ker(); k->d = dst; k->max_ob = max_ob; *out = k;
+    return HC_OK;
+}
+extern "C" int hc_ker_load(hc_ctx *c, const uint64_t *host, int max_ob, hc_ker **out) {
+    HC_ENTER(c);
+    if (!host || !out || max_ob < 1 || c->nq < 2) return hc_fail(c, HC_ERR_ARG, "hc_ker_load: bad arguments");
+    u64 *d = nullptr; HC_HIP(c, hipMalloc((void **)&d, (size_t)max_ob * 2 * HC_N * sizeof(u64)));
+    HC_HIP(c, hipMemcpyAsync(d, host, (size_t)max_ob * 2 * HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    return hc_ker_from_device(c, d, max_ob, true, out);
+}
+extern "C" int hc_ker_load_device(hc_ctx *c, const uint64_t *dptr, int max_ob, hc_ker **out) {
+    HC_ENTER(c);
+    if (!dptr || !out || max_ob < 1 || c->nq < 2) return hc_fail(c, HC_ERR_ARG, "hc_ker_load_device: bad arguments");
+    return hc_ker_from_device(c, (u64 *)dptr, max_ob, false, out);
+}
+extern "C" void hc_ker_free(hc_ctx *c, hc_ker *k) { if (!k) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } hipFree(k->d); delete k; }
+
+// ------------------------------------------------------------------ loop B plumbing
+static int hc_fill_loopB(hc_ctx *c, HcLoopB *B, u64 *cts, const HcEvk &e, int logStep, int step, int norm, u64 galEl, int chunk) {
+    const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
+    B->cts = cts;
+    B->tmpC = c->ws_tmp; B->tmpF = c->ws_tmp + (size_t)chunk * HC_N; B->tmpE = c->ws_tmp + (size_t)chunk * 3 * HC_N;
+    B->idx = c->idx_pairs + (size_t)logStep * HC_N;
+    B->evkQ = e.q_pairs; B->evkP = e.p_pairs;
+    B->n0 = 0; B->step = step; B->norm = norm;
+    B->m0 = m0.m; B->mp = mp.m;
+    B->pmodq = h_pair(mp.m.q % m0.m.q, m0.m.q);
+    B->pinv = h_pair(h_inv(mp.m.q % m0.m.q, m0.m.q), m0.m.q);
+    B->mu0 = (u64)((((u128)1) << 64) / m0.m.q);
+    B->pf = (double)mp.m.q;
+    B->gal = (u32)(galEl & 0x1FFFF);
+    return HC_OK;
+}
+// one tree level: nodes i = 0, norm, 2*norm, ... < step
+static int hc_pack_level(hc_ctx *c, u64 *cts, int step, int logStep, int norm, u64 galEl, const u64 *bias_last) {
+    auto it = c->evk.find(galEl);
+    if (it == c->evk.end()) return hc_fail(c, HC_ERR_STATE, "pack: no switching key loaded for galEl=%llu (the reference panics in permuteNTT)", (unsigned long long)galEl);
+    if (!it->second.row_local) return hc_fail(c, HC_ERR_UNSUPPORTED, "pack: galEl=%llu does not permute inside 256-blocks (needs max_cnum <= 256)", (unsigned long long)galEl);
+    if (!c->idx_pairs) HC_TRY(hc_idx_load(c, nullptr));
+    const int nodes = (step + norm - 1) / norm;
+    const int chunk = (int)(c->chunk_nodes < nodes ? (c->chunk_nodes < 1 ? 1 : c->chunk_nodes) : nodes);
+    HC_TRY(hc_ensure_tmp(c, (size_t)chunk * 5));
+    HcLoopB B; HC_TRY(hc_fill_loopB(c, &B, cts, it->second, logStep, step, norm, galEl, chunk));
+    const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
+    for (int n0 = 0; n0 < nodes; n0 += chunk) {
+        const int nn = (nodes - n0) < chunk ? (nodes - n0) : chunk;
+        B.n0 = n0;
+        HC_TRY(hc_launch(c, "b1_node_rowsinv", hc_k_b1, dim3(16, (unsigned)nn), B, m0.inv));
+        HC_TRY(hc_launch(c, "b2_colsinv_colsfwdP", hc_k_b2, dim3(16, (unsigned)nn), B, m0.inv, mp.fwd));
+        HC_TRY(hc_launch(c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, dim3(16, (unsigned)nn), B, mp.fwd, mp.inv));
+        HC_TRY(hc_launch(c, "b4_colsinvP_modup_colsfwd", hc_k_b4, dim3(16, (unsigned)(2 * nn)), B, mp.inv, m0.fwd));
+        HC_TRY(hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, (unsigned)nn), B, m0.fwd, bias_last));
+    }
+    return HC_OK;
+}
+// conv.go:266-300 on device-resident level-0 ciphertexts, in place (result in slot 0)
+static int hc_pack_run(hc_ctx *c, u64 *cts, int max_cnum, int real_cnum, const u64 *bias) {
+    if (max_cnum < 1 || real_cnum < 1 || max_cnum % real_cnum || (max_cnum & (max_cnum - 1)) || (real_cnum & (real_cnum - 1)))
+        return hc_fail(c, HC_ERR_ARG, "pack: max_cnum=%d real_cnum=%d must be powers of two", max_cnum, real_cnum);
+    const int norm = max_cnum / real_cnum;
+    int step = max_cnum / 2, logStep = 0;
+    for (int i = step; i > 1; i /= 2) logStep++;
+    int j = HC_LOGN - logStep;
+    bool bias_done = false;
+    while (step >= norm && step >= 1) {
+        const bool last = (step / 2 < norm) || step == 1;
+        HC_TRY(hc_pack_level(c, cts, step, logStep, norm, (1ull << j) + 1, last ? bias : nullptr));
+        if (last) bias_done = true;
+        step /= 2; logStep--; j++;
+    }
+    if (bias && !bias_done) {   // max_cnum == real_cnum == 1: no tree level ran
+        HcTw z; z.w = z.ws = 0;
+        HC_TRY(hc_launch(c, "bias_add", hc_k_pointwise<HC_PW_ADD>, hc_pw_grid(HC_N), (const u64 *)cts, bias, cts, (size_t)HC_N, c->mods[0].m, z));
+    }
+    return HC_OK;
+}
+extern "C" int hc_pack_ctxts(hc_ctx *c, uint64_t *cts, int max_cnum, int real_cnum) {
+    HC_ENTER(c); if (!cts) return hc_fail(c, HC_ERR_ARG, "hc_pack_ctxts: null");
+    return hc_pack_run(c, (u64 *)cts, max_cnum, real_cnum, nullptr);
+}
+
+// ------------------------------------------------------------------ key switch / rotate at level 0 (L0 API)
+extern "C" int hc_rotate_gal_l0(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uint64_t *c1, uint64_t *o0, uint64_t *o1);
+static int hc_ks_common(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uint64_t *c1, uint64_t *o0, uint64_t *o1, bool rotate) {
+    // Expressed through one pack-tree node: with x = 0 (so t1 = y, t2 = y) and y = (c0, c1) the node computes
+    // y + RotateGal(y); RotateGal(y) is recovered by subtracting y. Used only by the L0 parity API; the hot path
+    // never takes this detour.
+    auto it = c->evk.find(galEl);
+    if (it == c->evk.end()) return hc_fail(c, HC_ERR_STATE, "no switching key loaded for galEl=%llu", (unsigned long long)galEl);
+    u64 *buf = nullptr; HC_HIP(c, hipMalloc((void **)&buf, (size_t)6 * HC_N * sizeof(u64)));
+    u64 *y = buf, *x = buf + 2 * HC_N, *keep = buf + 4 * HC_N;
+    int rc = HC_OK;
+    hipMemsetAsync(x, 0, 2 * HC_N * sizeof(u64), c->stream);
+    if (c0) hipMemcpyAsync(y, c0, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); else hipMemsetAsync(y, 0, HC_N * sizeof(u64), c->stream);
+    hipMemcpyAsync(y + HC_N, c1, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream);
+    hipMemcpyAsync(keep, y, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream);
+    if (!c->idx_pairs) rc = hc_idx_load(c, nullptr);
+    const bool local = it->second.row_local;
+    u64 g_used = galEl;
+    if (!rc) {
+        if (rotate && local) {
+            // slots: y at 0, x at 1 => step = 1 in a 2-slot array, idx row irrelevant because x = 0
+            const int chunk = 1;
+            rc = hc_ensure_tmp(c, 5);
+            HcLoopB B; if (!rc) rc = hc_fill_loopB(c, &B, y, it->second, 0, 1, 1, g_used, chunk);
+            const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
+            if (!rc) rc = hc_launch(c, "b1_node_rowsinv", hc_k_b1, dim3(16, 1), B, m0.inv);
+            if (!rc) rc = hc_launch(c, "b2_colsinv_colsfwdP", hc_k_b2, dim3(16, 1), B, m0.inv, mp.fwd);
+            if (!rc) rc = hc_launch(c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, dim3(16, 1), B, mp.fwd, mp.inv);
+            if (!rc) rc = hc_launch(c, "b4_colsinvP_modup_colsfwd", hc_k_b4, dim3(16, 2), B, mp.inv, m0.fwd);
+            if (!rc) rc = hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, 1), B, m0.fwd, (const u64 *)nullptr);
+            HcTw z; z.w = z.ws = 0;
+            if (!rc) rc = hc_launch(c, "ks_sub", hc_k_pointwise<HC_PW_SUB>, hc_pw_grid(2 * HC_N), (const u64 *)y, (const u64 *)keep, y, (size_t)2 * HC_N, c->mods[0].m, z);
+            if (!rc) { hipMemcpyAsync(o0, y, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); hipMemcpyAsync(o1, y + HC_N, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); }
+        } else {
+            rc = hc_fail(c, HC_ERR_UNSUPPORTED, "level-0 key switch is exposed for Galois elements that permute inside 256-blocks (2^j+1, j>=9), the ones pack_ctxts uses");
+        }
+    }
+    hipStreamSynchronize(c->stream);
+    hipFree(buf);
+    return rc;
+}
+extern "C" int hc_rotate_gal_l0(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uint64_t *c1, uint64_t *o0, uint64_t *o1) {
+    HC_ENTER(c); if (!c0 || !c1 || !o0 || !o1) return hc_fail(c, HC_ERR_ARG, "hc_rotate_gal_l0: null");
+    return hc_ks_common(c, galEl, c0, c1, o0, o1, true);
+}
+extern "C" int hc_keyswitch_l0(hc_ctx *c, uint64_t galEl, const uint64_t *c1, uint64_t *d0, uint64_t *d1) {
+    // SwitchKeysInPlace(c1) = Permute_{g^-1}( RotateGal((0, c1)) ): undo the permutation with the inverse element
+    HC_ENTER(c); if (!c1 || !d0 || !d1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_l0: null");
+    u64 *buf = nullptr; HC_HIP(c, hipMalloc((void **)&buf, (size_t)2 * HC_N * sizeof(u64)));
+    int rc = hc_ks_common(c, galEl, nullptr, c1, buf, buf + HC_N, true);
+    if (!rc) {
+        u64 twoN = 2ull * HC_N, ginv = 1, b = galEl % twoN;
+        for (u64 e = twoN - 1; e; e >>= 1, b = (b * b) % twoN) if (e & 1) ginv = (ginv * b) % twoN;
+        rc = hc_permute(c, ginv, buf, d0, 1);
+        if (!rc) rc = hc_permute(c, ginv, buf + HC_N, d1, 1);
+    }
+    hipStreamSynchronize(c->stream); hipFree(buf);
+    return rc;
+}
+
+// ------------------------------------------------------------------ L1
+static int hc_ensure_cts(hc_ctx *c, size_t rows) {
+    if (c->ws_cts_rows >= rows) return HC_OK;
+    HC_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->ws_cts) HC_HIP(c, hipFree(c->ws_cts));
+    c->ws_cts = nullptr; c->ws_cts_rows = 0;
+    HC_HIP(c, hipMalloc((void **)&c->ws_cts, rows * HC_N * sizeof(u64)));
+    c->ws_cts_rows = rows;
+    return HC_OK;
+}
+// scale bookkeeping of conv.go:527-528 (MulNew, SetScale = MultByConst + Rescale) -> per-limb constants
+static int hc_loopA_consts(hc_ctx *c, double ct_scale, double ker_scale, int max_ob, int norm, double out_scale, u64 cst[2], double *target) {
+    if (c->nq < 2) return hc_fail(c, HC_ERR_STATE, "conv: needs the level-1 modulus chain (nq >= 2)");
+    if (max_ob < 1 || norm < 1 || max_ob % norm) return hc_fail(c, HC_ERR_ARG, "conv: max_ob=%d norm=%d", max_ob, norm);
+    const double tgt = out_scale / (double)(max_ob / norm);
+    const double prod = ct_scale * ker_scale, constant = tgt / prod;
+    double smul = 1;
+    for (int l = 0; l < 2; l++) cst[l] = hc_const_for(constant, (double)c->mods[1].m.q, c->mods[(size_t)l].m.q, &smul);
+    // Rescale's drop loop (upstream Rescale): exactly one limb must go (level 1 -> 0)
+    double sc = prod * smul; int drops = 0, level = 1;
+    while (level - drops > 0 && sc / (double)c->mods[(size_t)(level - drops)].m.q >= tgt / 2) { sc /= (double)c->mods[(size_t)(level - drops)].m.q; drops++; }
+    if (drops != 1) return hc_fail(c, HC_ERR_STATE, "conv: SetScale would drop %d limbs instead of 1 (scales ct=%g ker=%g out=%g)", drops, ct_scale, ker_scale, out_scale);
+    *target = tgt;
+    return HC_OK;
+}
+extern "C" int hc_conv_mult_phase(hc_ctx *c, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
+                                  int max_ob, int norm, double out_scale, uint64_t *cts_out) {
+    HC_ENTER(c);
+    if (!ct_in || !ker || !cts_out || ker->max_ob < max_ob) return hc_fail(c, HC_ERR_ARG, "hc_conv_mult_phase: bad arguments");
+    u64 cst[2]; double target;
+    HC_TRY(hc_loopA_consts(c, ct_scale, ker_scale, max_ob, norm, out_scale, cst, &target));
+    HC_TRY(hc_prepare_ctc(c, (const u64 *)ct_in, cst));
+    return hc_loopA_run(c, ker->d, max_ob, norm, (u64 *)cts_out);
+}
+extern "C" int hc_conv_then_pack(hc_ctx *c, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
+                                 int max_ob, int norm, double out_scale, const uint64_t *bias, uint64_t *ct_out, double *scale_out) {
+    HC_ENTER(c);
+    if (!ct_in || !ker || !ct_out || ker->max_ob < max_ob) return hc_fail(c, HC_ERR_ARG, "hc_conv_then_pack: bad arguments");
+    u64 cst[2]; double target;
+    HC_TRY(hc_loopA_consts(c, ct_scale, ker_scale, max_ob, norm, out_scale, cst, &target));
+    HC_TRY(hc_ensure_cts(c, (size_t)max_ob * 2));
+    HC_TRY(hc_prepare_ctc(c, (const u64 *)ct_in, cst));
+    HC_TRY(hc_loopA_run(c, ker->d, max_ob, norm, c->ws_cts));
+    HC_TRY(hc_pack_run(c, c->ws_cts, max_ob, max_ob / norm, (const u64 *)bias));
+    HC_HIP(c, hipMemcpyAsync(ct_out, c->ws_cts, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    // conv.go:274 multiplies the scale by real_cnum; conv.go:541 then demands out_scale and level 0
+    const double final_scale = target * (double)(max_ob / norm);
+    if (final_scale != out_scale) return hc_fail(c, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
+    if (scale_out) *scale_out = final_scale;
+    return HC_OK;
+}
+
+// ------------------------------------------------------------------ options / timing
+extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
+    if (!c || !name) return HC_ERR_ARG;
+    if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
+    if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
+    return hc_fail(c, HC_ERR_ARG, "unknown option %s", name);
+}
+extern "C" int hc_timer_start(hc_ctx *c) { HC_ENTER(c); HC_HIP(c, hipEventRecord(c->t0, c->stream)); return HC_OK; }
+extern "C" int hc_timer_stop(hc_ctx *c, float *ms) {
+    HC_ENTER(c); HC_HIP(c, hipEventRecord(c->t1, c->stream)); HC_HIP(c, hipEventSynchronize(c->t1));
+    if (ms) HC_HIP(c, hipEventElapsedTime(ms, c->t0, c->t1));
+    return HC_OK;
+}
+extern "C" int hc_profile_get(hc_ctx *c, const char *name, double *total_ms, long *launches) {
+    HC_ENTER(c); HC_TRY(hc_prof_flush(c));
+    if (!name) { c->prof_acc.clear(); return HC_OK; }
+    auto it = c->prof_acc.find(name);
+    if (total_ms) *total_ms = it == c->prof_acc.end() ? 0 : it->second.first;
+    if (launches) *launches = it == c->prof_acc.end() ? 0 : it->second.second;
+    return HC_OK;
+}
+extern "C" int hc_profile_names(hc_ctx *c, char *buf, size_t buflen) {
+    HC_ENTER(c); HC_TRY(hc_prof_flush(c));
+    std::string s;
+    for (auto &kv : c->prof_acc) { if (!s.empty()) s += ","; s += kv.first; }
+    if (!buf || buflen < s.size() + 1) return hc_fail(c, HC_ERR_ARG, "hc_profile_names: buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return HC_OK;
+}

@@ -1,0 +1,170 @@
+"""Parity cases shared by the GPU tests (libhconv.so on a real MI355X) and the CPU kernel-emulation tests
+(the same kernel sources run under tests/kernel_emu). Every case compares the C-ABI result with the oracle,
+bit for bit, on seeded inputs; `ctx` is an optimal_conv_amd.Context, `O` an oracle_lib.Oracle."""
+import numpy as np
+
+from oracle_lib import P0, Q0, Q1, splitmix_rows
+
+N = 65536
+MODS = ((0, Q0), (1, Q1), (2, P0))
+
+
+def rows(seed, q, count=1):
+    return np.stack([splitmix_rows(seed + 1000 * i, q, N) for i in range(count)])
+
+
+def eq(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    bad = np.flatnonzero(a.reshape(-1) != b.reshape(-1))
+    assert bad.size == 0, f"{what}: {bad.size} of {a.size} residues differ, first at {bad[:4]}: got {a.reshape(-1)[bad[:4]]} want {b.reshape(-1)[bad[:4]]}"
+
+
+def edge_rows(q):
+    """all-zero, all q-1, a single 1, alternating extremes"""
+    z = np.zeros(N, dtype=np.uint64)
+    m = np.full(N, q - 1, dtype=np.uint64)
+    one = z.copy(); one[N - 1] = 1
+    alt = z.copy(); alt[::2] = q - 1
+    return np.stack([z, m, one, alt])
+
+
+def case_ntt(ctx, O):
+    for mod, q in MODS:
+        a = np.concatenate([rows(11 + mod, q, 2), edge_rows(q)])
+        eq(ctx.ntt(mod, a), np.stack([O.ntt(mod, r) for r in a]), f"ntt mod{mod}")
+        eq(ctx.intt(mod, a), np.stack([O.intt(mod, r) for r in a]), f"intt mod{mod}")
+        eq(ctx.intt(mod, ctx.ntt(mod, a)), a, f"intt(ntt) mod{mod}")
+
+
+def case_pointwise(ctx, O):
+    for mod, q in MODS:
+        a = np.concatenate([rows(21 + mod, q, 1), edge_rows(q)])
+        b = np.concatenate([rows(31 + mod, q, 1), edge_rows(q)[::-1]])
+        eq(ctx.mul(mod, a, b), np.stack([O.mul(mod, x, y) for x, y in zip(a, b)]), f"mul mod{mod}")
+        eq(ctx.add(mod, a, b), np.stack([O.add(mod, x, y) for x, y in zip(a, b)]), f"add mod{mod}")
+        eq(ctx.sub(mod, a, b), np.stack([O.sub(mod, x, y) for x, y in zip(a, b)]), f"sub mod{mod}")
+        for c in (0, 1, 2048, q - 1, 0xDEADBEEFCAFE):
+            eq(ctx.mul_const(mod, a, c), np.stack([O.mul_scalar(mod, x, c) for x in a]), f"mul_const {c} mod{mod}")
+
+
+def case_permute(ctx, O):
+    a = rows(41, Q0, 2)
+    for gal in (513, 1025, 32769, 65537, 5, 3, 2 * N - 1):
+        idx = O.permute_index(gal)
+        eq(ctx.permute(gal, a), np.stack([O.permute(idx, r) for r in a]), f"permute gal={gal}")
+
+
+def case_const_for(ctx, O):
+    for B in (1, 4, 16, 64, 256, 1024):
+        constant = (2.0 ** 30 / B) / 2.0 ** 60
+        for l, q in ((0, Q0), (1, Q1)):
+            assert ctx.const_for(constant, Q1, q) == O.const_for(constant, 1, l), (B, l)
+    for constant in (3.0, -2.0, 0.5, -0.25, 1e-3, 0.0, 123456.789, -7.5e-9):
+        assert ctx.const_for(constant, Q1, Q0) == O.const_for(constant, 1, 0), constant
+
+
+def case_rescale(ctx, O):
+    x = np.stack([splitmix_rows(51, Q0, N), splitmix_rows(52, Q1, N)])
+    eq(ctx.div_round_last(1, x), O.div_round_last(1, x), "div_round_last")
+    # rounding boundary: x_1 = h, h+1 (centre of the interval) in the coefficient domain
+    h = (Q1 - 1) >> 1
+    t = np.zeros(N, dtype=np.uint64); t[0] = h; t[1] = h + 1; t[2] = Q1 - 1; t[3] = 1
+    x2 = np.stack([splitmix_rows(53, Q0, N), O.ntt(1, t)])
+    eq(ctx.div_round_last(1, x2), O.div_round_last(1, x2), "div_round_last boundary")
+
+
+def seeded_evk(seed):
+    return np.stack([splitmix_rows(seed, Q0, N), splitmix_rows(seed + 1, Q0, N), splitmix_rows(seed + 2, P0, N), splitmix_rows(seed + 3, P0, N)])
+
+
+def case_keyswitch(ctx, O, gals=(513, 65537)):
+    for gal in gals:
+        evk4 = seeded_evk(600 + gal)
+        ctx.evk_load(gal, evk4)
+        ct = np.stack([splitmix_rows(61 + gal, Q0, N), splitmix_rows(62 + gal, Q0, N)])
+        eq(ctx.rotate_gal_l0(gal, ct), O.rotate_gal_l0(ct, gal, evk4), f"rotate_gal gal={gal}")
+        d0, d1 = ctx.keyswitch_l0(gal, ct[1])
+        w0, w1 = O.keyswitch_l0(ct[1], evk4)
+        eq(d0, w0, f"keyswitch d0 gal={gal}"); eq(d1, w1, f"keyswitch d1 gal={gal}")
+
+
+def case_modup_overflow(ctx, O):
+    """Force the fp64 overflow count v = 1 of ring.modUpExact: make [d]_P land within 2^7 of P.
+    With evk_P = Montgomery form of 1 (so b_P = a_P = 1) the P accumulator is NTT_P(INTT_Q0(c1)) itself, i.e.
+    [d]_P = the coefficient vector of c1; coefficients cannot reach P (c < Q0), so instead plant evk_P = -1:
+    [d]_P = P - c for small c > 0 -> float64(P - c)/float64(P) rounds to 1.0 for c < ~2^7."""
+    gal = 65537
+    R_P = (1 << 64) % P0
+    neg1_mont = (P0 - 1) * R_P % P0
+    evk4 = np.stack([splitmix_rows(71, Q0, N), splitmix_rows(72, Q0, N),
+                     np.full(N, neg1_mont, dtype=np.uint64), np.full(N, neg1_mont, dtype=np.uint64)])
+    coeffs = np.zeros(N, dtype=np.uint64)
+    coeffs[:64] = np.arange(1, 65, dtype=np.uint64)          # [d]_P = P-1 ... P-64  -> v = 1
+    coeffs[64:128] = np.arange(200, 264, dtype=np.uint64) * np.uint64(1 << 20)   # far from P -> v = 0
+    c1 = O.ntt(0, coeffs)
+    assert O.L.or_modup_1p(P0 - 1, P0, Q0) != (P0 - 1) % Q0, "the oracle must take the v=1 branch here"
+    ctx.evk_load(gal, evk4)
+    d0, d1 = ctx.keyswitch_l0(gal, c1)
+    w0, w1 = O.keyswitch_l0(c1, evk4)
+    eq(d0, w0, "modup overflow d0"); eq(d1, w1, "modup overflow d1")
+    ctx.evk_load(gal, seeded_evk(600 + gal))
+
+
+def planted_conv_inputs(seed, max_ob):
+    ct_in = np.empty((2, 2, N), dtype=np.uint64)
+    for p in range(2):
+        ct_in[p, 0] = splitmix_rows(seed + 10 + p, Q0, N)
+        ct_in[p, 1] = splitmix_rows(seed + 20 + p, Q1, N)
+    ker = np.empty((max_ob, 2, N), dtype=np.uint64)
+    for i in range(max_ob):
+        ker[i, 0] = splitmix_rows(seed + 100 + 2 * i, Q0, N)
+        ker[i, 1] = splitmix_rows(seed + 101 + 2 * i, Q1, N)
+    return ct_in, ker
+
+
+def load_tree_keys(ctx, seed, max_ob, norm=1):
+    """switching keys for the Galois elements pack_ctxts touches (conv.go:284-296); returns oracle evk array"""
+    evk_all = np.zeros((16, 4, N), dtype=np.uint64)
+    step = max_ob // 2
+    j = 16 - (step.bit_length() - 1 if step > 0 else 0)
+    while step >= norm and step >= 1:
+        gal = (1 << j) + 1
+        evk4 = seeded_evk(seed + 7000 + 10 * j)
+        ctx.evk_load(gal, evk4)
+        evk_all[j - 1] = evk4
+        step //= 2
+        j += 1
+    return evk_all
+
+
+def case_conv(ctx, O, max_ob, seed=0xBEEF, with_bias=True, chunk=None):
+    ct_in, ker = planted_conv_inputs(seed, max_ob)
+    evk_all = load_tree_keys(ctx, seed, max_ob)
+    idx = O.idx_plaintexts()
+    ctx.idx_load(None)                      # derived on the device; must equal the oracle's (checked via the result)
+    bias = splitmix_rows(seed + 5, Q0, N) if with_bias else None
+    if chunk is not None:
+        ctx.set_option("chunk_nodes", chunk)
+    out_scale = 2.0 ** 30
+    got, sc = ctx.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, max_ob, 1, out_scale, bias)
+    want, wsc = O.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, idx, evk_all, max_ob, 1, out_scale, bias)
+    assert sc == wsc == out_scale
+    eq(got, want, f"conv_then_pack B={max_ob}")
+    return got
+
+
+def case_conv_phases(ctx, O, max_ob=4, seed=0xF00D):
+    """loop A and loop B separately (hc_conv_mult_phase / hc_pack_ctxts)"""
+    ct_in, ker = planted_conv_inputs(seed, max_ob)
+    evk_all = load_tree_keys(ctx, seed, max_ob)
+    ctx.idx_load(O.idx_plaintexts())        # host-supplied idx table this time
+    target = 2.0 ** 30 / max_ob
+    cst = [O.const_for(target / 2.0 ** 60, 1, l)[0] for l in range(2)]
+    cts = ctx.conv_mult_phase(ct_in, 2.0 ** 30, ker, 2.0 ** 30, max_ob, 1, 2.0 ** 30)
+    want = np.stack([O.mul_setscale(ct_in, ker[i], cst) for i in range(max_ob)])
+    eq(cts, want, "conv_mult_phase")
+    got = ctx.pack_ctxts(cts, max_ob, max_ob)
+    # oracle: same tree through or_conv_then_pack on the same inputs (no bias)
+    ref, _ = O.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, O.idx_plaintexts(), evk_all, max_ob, 1, 2.0 ** 30, None)
+    eq(got, ref, "pack_ctxts")

@@ -1,0 +1,61 @@
+"""CPU-side check of the HIP kernel SOURCES: optimal_conv_amd/csrc is compiled with g++ against the fiber emulator
+in tests/kernel_emu (threads = ucontext fibers, __syncthreads = yield) and driven through the same C ABI and the
+same parity cases as the GPU tests. This validates indexing, LDS exchanges, barrier placement and the host
+orchestration without a GPU; it says nothing about gfx950 code generation - tests/test_gpu_parity.py does that.
+The emulated library is test infrastructure and is never loaded by the package itself."""
+import os
+import subprocess
+
+import pytest
+
+import parity_cases as pc
+from optimal_conv_amd import Context
+from oracle_lib import Oracle, P0, Q0, Q1
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_emu")
+EMU_LIB = os.path.join(EMU_DIR, "_build", "libhconv_emu.so")
+
+
+@pytest.fixture(scope="module")
+def env():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    ctx = Context([Q0, Q1], [P0], lib_path=EMU_LIB)
+    yield ctx, Oracle()
+    ctx.close()
+
+
+def test_ntt(env):
+    pc.case_ntt(*env)
+
+
+def test_pointwise(env):
+    pc.case_pointwise(*env)
+
+
+def test_permute(env):
+    pc.case_permute(*env)
+
+
+def test_const_for(env):
+    pc.case_const_for(*env)
+
+
+def test_rescale(env):
+    pc.case_rescale(*env)
+
+
+def test_keyswitch(env):
+    pc.case_keyswitch(*env)
+
+
+def test_modup_overflow_branch(env):
+    pc.case_modup_overflow(*env)
+
+
+def test_conv_phases(env):
+    pc.case_conv_phases(*env)
+
+
+@pytest.mark.parametrize("max_ob,chunk", [(1, None), (2, None), (4, 1), (8, 3), (16, 32)])
+def test_conv_then_pack(env, max_ob, chunk):
+    pc.case_conv(*env, max_ob, chunk=chunk)
