@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py — homomorphic convs/sec of the `conv 3 3` hot path (evalConv_BN: conv_then_pack + bias add,
+eval.go:250-260) on N MI355X GPUs.
+
+A "step" is one homomorphic convolution: one N=2^16 level-1 ciphertext in, B=256 kernel plaintexts, one level-0
+ciphertext out (conv.go:522-546 + eval.go:258), kernel plaintexts pre-encoded and excluded exactly as the reference
+excludes prep_Ker from its "Conv (with BN)" timer (eval.go:244). Inputs are synthetic uniform residues, resident in
+HBM before the timed region. Multi-GPU: ciphertexts (images) are independent, so rank r runs its own convolutions
+on GPU r with no data-path collective (weak scaling); torch.distributed only provides the barriers and the
+max-over-ranks reduction of the elapsed time.
+
+Prints ONE JSON line (rank 0). `roofline.achieved` = algorithmic bytes per conv ((5B-1+2.5*log2B+0.5)
+MiB) / average conv duration measured with HIP events on the library's own stream; `cpu_baseline` = the CPU
+oracle (a port of the reference's Go/Lattigo path, one thread) timed on this host on one full `conv 3 3`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+Q0, Q1, P0 = 0x80000000080001, 0x1FFFFFFEA0001, 0x1FFFFFFFFFE00001
+N = 65536
+BATCHS = [4, 16, 64, 256]          # main.go:578
+WIDTHS = [128, 64, 32, 16]         # main.go:579
+
+
+def algorithmic_mib(B):
+    """compulsory HBM traffic of one conv with every phase fused, in MiB."""
+    return 5 * B - 1 + 2.5 * np.log2(B) + 0.5
+
+
+def synth_rows(rng, q, shape):
+    return (rng.integers(0, 1 << 62, size=shape, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
+
+
+def cpu_baseline(B):
+    """Time the CPU oracle (test infrastructure, used here only as the baseline being reported, never as the
+    product) on one full conv_then_pack at the bench workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    O = Oracle()
+    rng = np.random.default_rng(0xC0FFEE)
+    ct_in = np.stack([np.stack([synth_rows(rng, Q0, N), synth_rows(rng, Q1, N)]) for _ in range(2)])
+    ker = np.empty((B, 2, N), dtype=np.uint64)
+    ker[:, 0] = synth_rows(rng, Q0, (B, N)); ker[:, 1] = synth_rows(rng, Q1, (B, N))
+    evk = np.zeros((16, 4, N), dtype=np.uint64)
+    evk[:, 0] = synth_rows(rng, Q0, (16, N)); evk[:, 1] = synth_rows(rng, Q0, (16, N))
+    evk[:, 2] = synth_rows(rng, P0, (16, N)); evk[:, 3] = synth_rows(rng, P0, (16, N))
+    idx = O.idx_plaintexts()
+    bias = synth_rows(rng, Q0, N)
+    t0 = time.perf_counter()
+    O.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, idx, evk, B, 1, 2.0 ** 30, bias)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "conv/s", "cores": 1, "kind": "port",
+            "sample": f"1 full conv_then_pack+bias at B={B} (N=2^16) on the C oracle, {dt:.2f} s, host has {os.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--i-batch", type=int, default=3, help="reference batch index (main.go:578): 3 => B=256, W=16 = `conv 3 3`")
+    ap.add_argument("--ker-wid", type=int, default=3)
+    ap.add_argument("--chunk", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank) if backend == "nccl" else None)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from optimal_conv_amd import Context
+    B, W = BATCHS[args.i_batch], WIDTHS[args.i_batch]
+    ctx = Context([Q0, Q1], [P0], device=local_rank)        # raises if no GPU / no libhconv.so
+    ctx.set_option("chunk_nodes", args.chunk)
+    rng = np.random.default_rng(0xC0FFEE + args.i_batch + 1000 * rank)
+    ct_in = np.stack([np.stack([synth_rows(rng, Q0, N), synth_rows(rng, Q1, N)]) for _ in range(2)])
+    pl_ker = np.empty((B, 2, N), dtype=np.uint64)
+    pl_ker[:, 0] = synth_rows(rng, Q0, (B, N)); pl_ker[:, 1] = synth_rows(rng, Q1, (B, N))
+    step = B // 2
+    j = 16 - (step.bit_length() - 1)
+    while step >= 1:
+        ctx.evk_load((1 << j) + 1, [synth_rows(rng, Q0, N), synth_rows(rng, Q0, N), synth_rows(rng, P0, N), synth_rows(rng, P0, N)])
+        step //= 2; j += 1
+    ctx.idx_load(None)
+    ker = ctx.ker_load(pl_ker)
+    d_in, d_bias, d_out = ctx.buf(ct_in), ctx.buf(synth_rows(rng, Q0, N)), ctx.buf(nwords=2 * N)
+
+    def one_step():
+        ctx.conv_then_pack_dev(d_in, 2.0 ** 30, ker, 2.0 ** 30, B, 1, 2.0 ** 30, d_bias, d_out)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        ctx.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        one_step()
+    ev_ms = ctx.timer_stop()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel HIP-event profile (separate untimed pass: event records between launches perturb the stream)
+    ctx.set_option("profile", 1)
+    ctx.profile_reset()
+    nprof = max(1, min(3, args.steps))
+    for _ in range(nprof):
+        one_step()
+    prof = ctx.profile()
+    ctx.set_option("profile", 0)
+    kern = {k: {"ms_per_conv": v[0] / nprof, "launches_per_conv": v[1] // nprof} for k, v in prof.items()}
+    dom = max(kern, key=lambda k: kern[k]["ms_per_conv"]) if kern else None
+
+    if rank == 0:
+        conv_ms_events = ev_ms / args.steps
+        alg_bytes = algorithmic_mib(B) * 2 ** 20
+        achieved = alg_bytes / (conv_ms_events * 1e-3) / 1e9
+        out = {
+            "metric": "homomorphic convs/sec (conv_then_pack + BN bias, k x k, batch B, N=2^16)",
+            "value": world * args.steps / elapsed, "unit": "conv/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"conv {args.ker_wid} {args.i_batch}", "ker_wid": args.ker_wid, "batch": B, "in_wid": W,
+                       "logN": 16, "moduli": "ckks.DefaultBootstrapParams[6] Q0,Q1 + P=0x1fffffffffe00001",
+                       "convs_per_step_per_gpu": 1, "chunk_nodes": args.chunk},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None,
+                         "unit_of_launch": "one conv_then_pack (all of its kernel launches on one stream)",
+                         "algorithmic_bytes_per_conv": alg_bytes, "conv_ms_hip_events": conv_ms_events,
+                         "dominant_kernel": dom, "kernels": kern},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B)
+        print(json.dumps(out), flush=True)
+    ctx.ker_free(ker)
+    ctx.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
