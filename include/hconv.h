@@ -54,6 +54,7 @@ int hc_malloc(hc_ctx *ctx, size_t bytes, void **dptr);
 int hc_free(hc_ctx *ctx, void *dptr);
 int hc_upload(hc_ctx *ctx, void *dst_dptr, const void *src_host, size_t bytes);
 int hc_download(hc_ctx *ctx, void *dst_host, const void *src_dptr, size_t bytes);
+int hc_copy(hc_ctx *ctx, void *dst_dptr, const void *src_dptr, size_t bytes); /* device to device, on the stream */
 int hc_sync(hc_ctx *ctx);
 
 /* ---- L0: one call per ring / evaluator primitive (rows are device pointers; `count` consecutive rows) ---- */

@@ -23,6 +23,7 @@ SYMBOLS = {
     "hc_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hc_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "hc_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "hc_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "hc_sync": (C.c_int, [C.c_void_p]),
     "hc_ntt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "hc_intt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

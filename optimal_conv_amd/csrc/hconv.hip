@@ -232,6 +232,11 @@ extern "C" int hc_download(hc_ctx *c, void *dst, const void *src, size_t bytes) 
     HC_HIP(c, hipStreamSynchronize(c->stream));
     return HC_OK;
 }
+extern "C" int hc_copy(hc_ctx *c, void *dst, const void *src, size_t bytes) {
+    HC_ENTER(c); if (!dst || !src) return hc_fail(c, HC_ERR_ARG, "hc_copy: null pointer");
+    HC_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return HC_OK;
+}
 extern "C" int hc_sync(hc_ctx *c) { HC_ENTER(c); HC_HIP(c, hipStreamSynchronize(c->stream)); return hc_prof_flush(c); }
 
 // ------------------------------------------------------------------ L0

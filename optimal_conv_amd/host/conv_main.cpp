@@ -1,0 +1,39 @@
+// conv_main.cpp — the reference's CLI surface (main.go:578-645) over the MI355X engine:
+//     conv <ker_wid 3|5|7> <i_batch 0..3> <num_tests <= 10>
+// prints the same line shapes as the reference's `conv` run (SURVEY.md 8(a)-S "CLI output contract").
+// `convReLU` and `resnet` are next-rows of the scope table and exit with a clear message;
+// the "Base Line" (BL) comparison run is likewise a next-row (8f-2) and is reported as skipped.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string>
+
+#include "hconv_host.hpp"
+
+int main(int argc, char **argv) {
+    const int batchs[5] = {4, 16, 64, 256, 1024}, widths[5] = {128, 64, 32, 16, 8};   // main.go:578-579
+    if (argc < 5) hconv::panic("runtime error: index out of range (usage: conv|convReLU <ker_wid> <i_batch> <num_tests>)");
+    const std::string test_name = argv[1];
+    const int ker_wid = atoi(argv[2]), i_batch = atoi(argv[3]), num_tests = atoi(argv[4]);
+    if (!(ker_wid == 3 || ker_wid == 5 || ker_wid == 7)) hconv::panic("Wrong kernel wid (not in 3,5,7)");
+    bool boot = false;
+    if (test_name == "conv") {
+        if (num_tests > 10 || i_batch > 3) hconv::panic("Too many tests (>10) or too many batch index (>3)");
+    } else if (test_name == "convReLU") {
+        boot = true;
+        if (num_tests > 10 || i_batch > 3) hconv::panic("Too many tests (>10) or too many batch index (>3)");
+    } else if (test_name == "resnet") {
+        hconv::panic("resnet: not built in this engine (scope table next-row 8f-3)");
+    } else hconv::panic("wrong test type");
+    if (i_batch < 0) hconv::panic("runtime error: index out of range");
+    if (boot) {
+        printf("Convolution followed by ReLU (& Bootstrapping) test start!\n");
+        hconv::panic("convReLU: bootstrapping chain is a next-row of the scope table (8f-1) and is not built in this engine");
+    }
+    printf("Convolution test start! (No Bootstrapping)\n");
+    printf("Ker:  %d batches:  %d widths:  %d\n", ker_wid, batchs[i_batch], widths[i_batch]);
+    printf("Base Line start.\n");
+    printf("(BL slot-packed baseline: next-row 8f-2, not built in this engine - skipped)\n");
+    printf("Ours start.\n");
+    hconv::testConv_in(batchs[i_batch], widths[i_batch], ker_wid, num_tests, boot);
+    return 0;
+}

@@ -1,0 +1,110 @@
+// hconv_host.hpp — C++ host side above the C ABI (include/hconv.h), mirroring the reference's operator interface
+// for the `conv` path with the same names, argument meaning and error behaviour (errors are fatal, like Go's panic).
+//
+// The reference's host code is Go; no Go toolchain exists in this image or on the GPU box,
+// so per the build contract the host side is C++. Mapping (reference -> here):
+//   main.go:22-42   type context              -> struct Context
+//   main.go:44-462  newContext("Conv")        -> newContext()
+//   conv.go:241-261 gen_idxNlogs              -> inside newContext (idx on the device, Galois keys 2^(i+1)+1)
+//   main.go:1007    prep_Input                -> prep_Input
+//   conv.go:184     reshape_ker               -> reshape_ker
+//   conv.go:206     encode_ker_final          -> encode_ker_final
+//   conv.go:487     prep_Ker                  -> prep_Ker      (EncodeCoeffs on the host, ToNTT on the GPU)
+//   conv.go:522     conv_then_pack            -> conv_then_pack (fused: hc_conv_then_pack; or op-by-op through
+//   conv.go:266     pack_ctxts                -> pack_ctxts      GpuEvaluator with HCONV_OPWISE=1)
+//   eval.go:224     evalConv_BN               -> evalConv_BN
+//   main.go:1057    post_process              -> post_process
+//   main.go:971     readTxt                   -> readTxt
+//   main.go:694     printDebugCfsPlain        -> printDebugCfsPlain
+//   test.go:15      testConv_in               -> testConv_in
+// ckks.Evaluator methods the path calls -> class GpuEvaluator {MulNew, SetScale, SubNew, Add, RotateGal}.
+// Keys/encryption/decryption are harness-only (the reference draws them from crypto-random; nothing to match):
+// implemented here on the host with every NTT done on the GPU through the ABI.
+#pragma once
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hconv.h"
+
+namespace hconv {
+
+typedef unsigned __int128 u128;
+static const int LOGN = 16;
+static const int N = 1 << LOGN;
+
+// ckks.DefaultBootstrapParams[6] of the fork, level order; only Q[0], Q[1] carry the conv path
+extern const std::vector<uint64_t> PARAMS6_Q;
+extern const std::vector<uint64_t> PARAMS6_P;      // bootstrapping key-switch primes (logQP print only)
+static const uint64_t PACK_P = 0x1fffffffffe00001ull;   // main.go:449
+
+[[noreturn]] void panic(const std::string &msg);        // Go's panic(): message to stderr, exit status 2
+
+// Device-resident ciphertext / plaintext (ckks.Ciphertext{Value []*ring.Poly; Scale}, ckks.Plaintext)
+struct Ciphertext {
+    uint64_t *d = nullptr;   // device [2][level+1][N]
+    int level = 0;
+    double Scale = 0;
+};
+struct Plaintext {
+    uint64_t *d = nullptr;   // device [level+1][N], NTT domain
+    int level = 0;
+    double Scale = 0;
+};
+
+struct Context {
+    int logN = LOGN, Nn = N, ECD_LV = 1;       // main.go:46
+    hc_ctx *hc = nullptr;                     // pack_evaluator + evaluator (both run on the same device context)
+    std::vector<int64_t> sk;                  // sparse ternary secret, h = 192 (main.go:410)
+    std::vector<uint64_t> sk_ntt[3];          // NTT rows mod Q0, Q1, P (host)
+    double scale = (double)(1 << 30);
+    int num_rotations = 0;
+    uint64_t seed = 0;
+};
+
+// ---- harness / reference-shaped API ----
+Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, const std::vector<int> &kp_wids, bool boot, const std::string &kind);
+void freeContext(Context *);
+std::vector<double> readTxt(const std::string &name_file, int size);
+std::vector<double> prep_Input(const std::vector<double> &input, int raw_in_wid, int in_wid, int Nn, int norm, bool trans, bool printResult);
+std::vector<std::vector<double>> reshape_ker(const std::vector<double> &ker_in, int k_sz, int out_batch, bool trans);
+std::vector<double> encode_ker_final(const std::vector<std::vector<double>> &ker_in, int pos, int i, int in_wid, int in_batch, int ker_wid);
+std::vector<double> post_process(const std::vector<double> &in_cfs, int raw_in_wid, int in_wid);
+void printDebugCfsPlain(const std::vector<double> &valuesTest, const std::vector<double> &valuesWant);
+void set_Variables(int batch, int raw_in_wid, int in_wid, int ker_wid, const std::string &kind, int *kp_wid, int *out_batch, int *logN, bool *trans);
+
+// encoder / encryptor / decryptor (ckks.Encoder.EncodeCoeffs, Encryptor.EncryptNew, Decryptor.Decrypt + DecodeCoeffs)
+std::vector<uint64_t> EncodeCoeffs(const std::vector<double> &coeffs, int level, double scale);   // host rows, coefficient domain
+Ciphertext EncryptNew(Context *cont, const std::vector<uint64_t> &pt_rows, int level, double scale);
+std::vector<double> DecryptDecodeCoeffs(Context *cont, const Ciphertext &ct);
+void freeCt(Context *cont, Ciphertext &ct);
+
+// kernel plaintexts: handle to the B device-resident plaintexts
+struct KerPlain { hc_ker *h = nullptr; int max_bat = 0; double Scale = 0; };
+KerPlain prep_Ker(Context *cont, const std::vector<double> &ker_in, const std::vector<double> &BN_a, int in_wid, int ker_wid,
+                  int real_ib, int real_ob, int norm, int ECD_LV, int pos, bool trans);
+
+Ciphertext conv_then_pack(Context *cont, const Ciphertext &ctxt_in, const KerPlain &pl_ker, int max_ob, int norm, int ECD_LV,
+                          double out_scale, const Plaintext *pl_bn_b);
+Ciphertext evalConv_BN(Context *cont, const Ciphertext &ct_input, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
+                       const std::vector<double> &bn_b, int in_wid, int ker_wid, int real_ib, int real_ob, int norm, double out_scale, bool trans);
+void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool boot);
+
+// ckks.Evaluator subset used by conv.go, one C-ABI call per limb row
+class GpuEvaluator {
+public:
+    explicit GpuEvaluator(Context *c) : cont(c) {}
+    Ciphertext MulNew(const Ciphertext &ct, const Plaintext &pt);            // conv.go:527, 288
+    void SetScale(Ciphertext &ct, double scale);                             // conv.go:528
+    Ciphertext SubNew(const Ciphertext &a, const Ciphertext &b);             // conv.go:289
+    void Add(const Ciphertext &a, const Ciphertext &b, Ciphertext &out);     // conv.go:290, 292
+    void AddPlain(const Ciphertext &a, const Plaintext &b, Ciphertext &out); // eval.go:258
+    void RotateGal(const Ciphertext &ct, uint64_t galEl, Ciphertext &out);   // conv.go:291
+private:
+    Context *cont;
+    Ciphertext alloc(int level, double scale);
+};
+
+}  // namespace hconv
