@@ -68,7 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--i-batch", type=int, default=3, help="reference batch index (main.go:578): 3 => B=256, W=16 = `conv 3 3`")
     ap.add_argument("--ker-wid", type=int, default=3)
-    ap.add_argument("--chunk", type=int, default=32)
+    ap.add_argument("--chunk", type=int, default=64)
+    ap.add_argument("--streams", type=int, default=1, help="independent ciphertexts in flight per GPU (one hc_ctx = one HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -88,28 +89,41 @@ def main():
 
     from optimal_conv_amd import Context
     B, W = BATCHS[args.i_batch], WIDTHS[args.i_batch]
-    ctx = Context([Q0, Q1], [P0], device=local_rank)        # raises if no GPU / no libhconv.so
-    ctx.set_option("chunk_nodes", args.chunk)
+    S = max(1, args.streams)
     rng = np.random.default_rng(0xC0FFEE + args.i_batch + 1000 * rank)
     ct_in = np.stack([np.stack([synth_rows(rng, Q0, N), synth_rows(rng, Q1, N)]) for _ in range(2)])
     pl_ker = np.empty((B, 2, N), dtype=np.uint64)
     pl_ker[:, 0] = synth_rows(rng, Q0, (B, N)); pl_ker[:, 1] = synth_rows(rng, Q1, (B, N))
+    keys = []
     step = B // 2
     j = 16 - (step.bit_length() - 1)
     while step >= 1:
-        ctx.evk_load((1 << j) + 1, [synth_rows(rng, Q0, N), synth_rows(rng, Q0, N), synth_rows(rng, P0, N), synth_rows(rng, P0, N)])
+        keys.append(((1 << j) + 1, [synth_rows(rng, Q0, N), synth_rows(rng, Q0, N), synth_rows(rng, P0, N), synth_rows(rng, P0, N)]))
         step //= 2; j += 1
-    ctx.idx_load(None)
-    ker = ctx.ker_load(pl_ker)
-    d_in, d_bias, d_out = ctx.buf(ct_in), ctx.buf(synth_rows(rng, Q0, N)), ctx.buf(nwords=2 * N)
+    bias = synth_rows(rng, Q0, N)
+    lanes = []                      # one lane = one context/stream with its own resident ciphertext, keys and kernel plaintexts
+    for s_ in range(S):
+        ctx = Context([Q0, Q1], [P0], device=local_rank)        # raises if no GPU / no libhconv.so
+        ctx.set_option("chunk_nodes", args.chunk)
+        for gal, k4 in keys:
+            ctx.evk_load(gal, k4)
+        ctx.idx_load(None)
+        lanes.append({"ctx": ctx, "ker": ctx.ker_load(pl_ker), "in": ctx.buf(ct_in), "bias": ctx.buf(bias), "out": ctx.buf(nwords=2 * N)})
+    ctx = lanes[0]["ctx"]
+    counter = [0]
 
     def one_step():
-        ctx.conv_then_pack_dev(d_in, 2.0 ** 30, ker, 2.0 ** 30, B, 1, 2.0 ** 30, d_bias, d_out)
+        L = lanes[counter[0] % S]; counter[0] += 1
+        L["ctx"].conv_then_pack_dev(L["in"], 2.0 ** 30, L["ker"], 2.0 ** 30, B, 1, 2.0 ** 30, L["bias"], L["out"])
+
+    def sync_all():
+        for L in lanes:
+            L["ctx"].sync()
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        ctx.sync()
+        sync_all()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
 
@@ -120,6 +134,7 @@ def main():
     ctx.timer_start()
     for _ in range(args.steps):
         one_step()
+    sync_all()
     ev_ms = ctx.timer_stop()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -129,11 +144,12 @@ def main():
         elapsed = float(t.item())
 
     # per-kernel HIP-event profile (separate untimed pass: event records between launches perturb the stream)
+    counter[0] = 0
     ctx.set_option("profile", 1)
     ctx.profile_reset()
     nprof = max(1, min(3, args.steps))
     for _ in range(nprof):
-        one_step()
+        lanes[0]["ctx"].conv_then_pack_dev(lanes[0]["in"], 2.0 ** 30, lanes[0]["ker"], 2.0 ** 30, B, 1, 2.0 ** 30, lanes[0]["bias"], lanes[0]["out"])
     prof = ctx.profile()
     ctx.set_option("profile", 0)
     kern = {k: {"ms_per_conv": v[0] / nprof, "launches_per_conv": v[1] // nprof} for k, v in prof.items()}
@@ -152,7 +168,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"conv {args.ker_wid} {args.i_batch}", "ker_wid": args.ker_wid, "batch": B, "in_wid": W,
                        "logN": 16, "moduli": "ckks.DefaultBootstrapParams[6] Q0,Q1 + P=0x1fffffffffe00001",
-                       "convs_per_step_per_gpu": 1, "chunk_nodes": args.chunk},
+                       "convs_per_step_per_gpu": 1, "ciphertexts_in_flight_per_gpu": S, "chunk_nodes": args.chunk},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None,
                          "unit_of_launch": "one conv_then_pack (all of its kernel launches on one stream)",
@@ -162,8 +178,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out), flush=True)
-    ctx.ker_free(ker)
-    ctx.close()
+    for L in lanes:
+        L["ctx"].ker_free(L["ker"])
+        L["ctx"].close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

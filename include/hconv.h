@@ -108,6 +108,11 @@ int hc_conv_then_pack(hc_ctx *ctx, const uint64_t *ct_in, double ct_scale, const
 int hc_conv_mult_phase(hc_ctx *ctx, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
                        int max_ob, int norm, double out_scale, uint64_t *cts_out);
 int hc_pack_ctxts(hc_ctx *ctx, uint64_t *cts, int max_cnum, int real_cnum);
+/* The same tree over `count` level-0 ciphertexts whose indices in the full pack are m << stride_log2 (m = slot):
+ * what one GPU holds when conv.go:286-297's tree is sharded by i mod G (stride_log2 = log2 G: the levels with
+ * step >= G), and, with stride_log2 = 0, the last log2 G levels over the G gathered partial results. bias (device
+ * row mod Q0 or NULL) is added to the result as eval.go:258 does. */
+int hc_pack_ctxts_strided(hc_ctx *ctx, uint64_t *cts, int count, int stride_log2, const uint64_t *bias);
 
 /* ---- tuning / measurement ---- */
 int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes", "profile" */

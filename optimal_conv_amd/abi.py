@@ -46,6 +46,7 @@ SYMBOLS = {
     "hc_conv_mult_phase": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double,
                                      C.c_void_p]),
     "hc_pack_ctxts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "hc_pack_ctxts_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hc_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
     "hc_timer_start": (C.c_int, [C.c_void_p]),
     "hc_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

@@ -21,8 +21,11 @@
 #include "hc_arith.h"
 
 #define HC_TPB 256
-#define HC_ROWS_LDS (16 * 272)          // u64 words: 16 rows x (16 groups x 17)
-#define HC_COLS_LDS (272 * 16)          // u64 words: (256 + 16 pad) row slots x 16 columns
+#ifndef HC_MIN_WAVES
+#define HC_MIN_WAVES 4               // waves per SIMD the register allocator must leave room for in the IO-heavy rows kernels
+#endif
+#define HC_ROWS_LDS 4096                // u64 words: 16 rows x 256 columns, XOR-swizzled (exactly 32 KiB => 5 workgroups per CU)
+#define HC_COLS_LDS 4096                // u64 words: 256 rows x 16 columns, XOR-swizzled
 
 struct __attribute__((aligned(16))) HcTw { u64 w, ws; };
 
@@ -83,10 +86,19 @@ __device__ __forceinline__ void hc_gs_round(u64 (&e)[16], const TW &tw, u64 q, H
 }
 
 // ---------------------------------------------------------------- tile geometry
-// rows kernels: thread t -> (rloc = t>>4, tid = t&15); LDS word of (rloc, col)
-__device__ __forceinline__ int hc_rows_lds(int rloc, int col) { return rloc * 272 + (col >> 4) * 17 + (col & 15); }
-// cols kernels: thread t -> (c = t&15, tid = t>>4); LDS word of (row, c)
-__device__ __forceinline__ int hc_cols_lds(int row, int c) { return ((row >> 4) * 17 + (row & 15)) * 16 + c; }
+// LDS holds 8-byte words; a ds_read/write_b64 is serviced per half-wave over 32 word slots (64 banks x 4 B), so a
+// layout is conflict-free when the 32 lanes of a half-wave hit 32 distinct values of (word index mod 32).
+// rows kernels: thread t -> (rloc = t>>4, tid = t&15); a half-wave = 2 rows x 16 tids. Three access patterns:
+//   hi-local (col = hi*16+tid), lo-local (col = tid*16+lo), linear (row k, col = t). The swizzle XORs the low
+//   4 column bits with bits 5..7 of the column and flips bits 3 and 4 on odd rows: bijective per row, and each of
+//   the three patterns spreads its 32 lanes over all 32 slots (derivation in DESIGN.md).
+__device__ __forceinline__ int hc_rows_lds(int rloc, int col) {
+    return rloc * 256 + ((col & 0xF0) ^ ((rloc & 1) << 4)) + ((col & 15) ^ ((col >> 5) & 7) ^ ((rloc & 1) << 3));
+}
+// cols kernels: thread t -> (c = t&15, tid = t>>4); a half-wave = 2 tids x 16 columns. Patterns: hi-local
+//   (row = hi*16+tid) and lo-local (row = tid*16+lo). Row bit 0 is XORed with row bit 4 so that the two tids of
+//   a half-wave land in different 16-word halves in both patterns.
+__device__ __forceinline__ int hc_cols_lds(int row, int c) { return ((row ^ ((row >> 4) & 1)) << 4) + c; }
 
 struct HcRowsTwA { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return p[slot]; } };
 struct HcRowsTwB { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return p[slot * 16]; } };
@@ -306,26 +318,31 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_a2(HcLoopA A, HcTwTab T1inv, HcTw
     for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
 }
 // KA3: rows-forward mod Q0, then out = (a_0 - u) * Q1^-1. grid = (16, jobs)
-__global__ __launch_bounds__(HC_TPB) void hc_k_a3(HcLoopA A, HcTwTab T0fwd) {
+// a_0 = c'_p[0] (*) k_i[0] is formed first, in the linear layout the epilogue uses, so that every global load of
+// the kernel is issued before the transform starts and nothing stalls behind the stores at the end.
+__global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_a3(HcLoopA A, HcTwTab T0fwd) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
     const int job = blockIdx.y, p = job & 1, i = A.i0 + (job >> 1) * A.norm;
-    const u64 *in = A.tmp + (size_t)job * 65536 + (size_t)row * 256;
-    u64 e[16];
+    const u64 *__restrict__ in = A.tmp + (size_t)job * 65536 + (size_t)row * 256;
+    const u64 *__restrict__ c = A.ctc + ((size_t)p * 2) * 65536 + (size_t)blockIdx.x * 4096 + t;
+    const u64 *__restrict__ k = A.ker + ((size_t)i * 2) * 65536 + (size_t)blockIdx.x * 4096 + t;
+    u64 *__restrict__ o = A.cts + ((size_t)i * 2 + p) * 65536 + (size_t)blockIdx.x * 4096 + t;
+    const u64 q = A.m0.q;
+    u64 e[16], a0[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
-    hc_rows_fwd(e, lds, T0fwd, row, rloc, tid, A.m0.q);
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) a0[kk] = c[kk * 256];
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) a0[kk] = hc_mont(a0[kk], k[kk * 256], q, A.m0.qinv);
+    hc_rows_fwd(e, lds, T0fwd, row, rloc, tid, q);
     __syncthreads();
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
-    const u64 *c = A.ctc + ((size_t)p * 2) * 65536, *k = A.ker + ((size_t)i * 2) * 65536;
-    u64 *o = A.cts + ((size_t)i * 2 + p) * 65536;
-    const u64 q = A.m0.q;
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
-        const size_t off = (size_t)(blockIdx.x * 16 + kk) * 256 + t;
-        u64 a0 = hc_mont(c[off], k[off], q, A.m0.qinv);
         u64 u = hc_csub(hc_csub(e[kk], 2 * q), q);
-        o[off] = hc_mul_shoup(hc_submod(a0, u, q), A.q1inv.w, A.q1inv.ws, q);
+        o[kk * 256] = hc_mul_shoup(hc_submod(a0[kk], u, q), A.q1inv.w, A.q1inv.ws, q);
     }
 }
 
@@ -344,41 +361,54 @@ struct HcLoopB {
     HcTw pmodq;          // P mod Q0
     HcTw pinv;           // P^-1 mod Q0
     u64 mu0;             // floor(2^64/Q0)
-    double pf;           // (double)P
+    u64 vthresh;         // smallest y with uint64(float64(y)/float64(P)) >= 1 (P if none): the fp64 overflow count as a compare
     u32 gal;             // Galois element of this level
 };
 // KB1: t1/t2, Q-part of the key switch, rows-inverse (mod Q0) of t2.c1. grid = (16, nodes)
-__global__ __launch_bounds__(HC_TPB) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
+// The pointwise front end works on batches of 4 residues per thread: all 28 loads of a batch are issued before
+// its arithmetic, and the streams are restrict-qualified (x is read-only, y/F are written at the offsets just
+// read) so the next batch's loads are not ordered behind this batch's stores.
+__global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
     const int node = blockIdx.y, i = (B.n0 + node) * B.norm;
-    u64 *y = B.cts + (size_t)i * 2 * 65536, *x = B.cts + (size_t)(i + B.step) * 2 * 65536;
-    u64 *F = B.tmpF + (size_t)node * 2 * 65536;
+    const size_t tile = (size_t)blockIdx.x * 4096 + t;
+    u64 *__restrict__ y = B.cts + (size_t)i * 2 * 65536 + tile;
+    const u64 *__restrict__ x = B.cts + (size_t)(i + B.step) * 2 * 65536 + tile;
+    u64 *__restrict__ F = B.tmpF + (size_t)node * 2 * 65536 + tile;
+    const HcTw *__restrict__ idx = B.idx + tile;
+    const HcTw *__restrict__ evk = B.evkQ + tile;
     const u64 q = B.m0.q;
     u64 e[16];
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
-        const size_t off = (size_t)(blockIdx.x * 16 + kk) * 256 + t;
-        const HcTw I = B.idx[off];
-        // polynomial 1 first: its t2 feeds the key switch
-        u64 m1 = hc_mul_shoup(x[65536 + off], I.w, I.ws, q);
-        u64 y1 = y[65536 + off];
-        u64 t2c1 = hc_submod(y1, m1, q);
-        y[65536 + off] = hc_addmod(y1, m1, q);                       // t1.c1 (conv.go:290)
-        const HcTw bq = B.evkQ[off], aq = B.evkQ[65536 + off];
-        F[65536 + off] = hc_mul_shoup(t2c1, aq.w, aq.ws, q);
-        u64 G = hc_mul_shoup(t2c1, bq.w, bq.ws, q);
-        u64 m0 = hc_mul_shoup(x[off], I.w, I.ws, q);
-        u64 y0 = y[off];
-        u64 t2c0 = hc_submod(y0, m0, q);
-        y[off] = hc_addmod(y0, m0, q);                               // t1.c0
-        F[off] = hc_addmod(hc_mul_shoup(t2c0, B.pmodq.w, B.pmodq.ws, q), G, q);
-        e[kk] = t2c1;
+    for (int b = 0; b < 4; b++) {
+        u64 x1[4], y1[4], x0[4], y0[4]; HcTw I[4], bq[4], aq[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int o = (b * 4 + j) * 256;
+            x1[j] = x[65536 + o]; y1[j] = y[65536 + o]; I[j] = idx[o]; bq[j] = evk[o]; aq[j] = evk[65536 + o];
+            x0[j] = x[o]; y0[j] = y[o];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int o = (b * 4 + j) * 256;
+            // polynomial 1 first: its t2 feeds the key switch
+            const u64 m1 = hc_mul_shoup(x1[j], I[j].w, I[j].ws, q);
+            const u64 t2c1 = hc_submod(y1[j], m1, q);
+            y[65536 + o] = hc_addmod(y1[j], m1, q);                           // t1.c1 (conv.go:290)
+            F[65536 + o] = hc_mul_shoup(t2c1, aq[j].w, aq[j].ws, q);
+            const u64 G = hc_mul_shoup(t2c1, bq[j].w, bq[j].ws, q);
+            const u64 m0 = hc_mul_shoup(x0[j], I[j].w, I[j].ws, q);
+            const u64 t2c0 = hc_submod(y0[j], m0, q);
+            y[o] = hc_addmod(y0[j], m0, q);                                    // t1.c0
+            F[o] = hc_addmod(hc_mul_shoup(t2c0, B.pmodq.w, B.pmodq.ws, q), G, q);
+            e[b * 4 + j] = t2c1;
+        }
     }
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     __syncthreads();
     hc_rows_inv(e, lds, T0inv, row, rloc, tid, q);
-    u64 *o = B.tmpC + (size_t)node * 65536 + (size_t)row * 256;
+    u64 *__restrict__ o = B.tmpC + (size_t)node * 65536 + (size_t)row * 256;
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
 }
@@ -399,7 +429,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b2(HcLoopB B, HcTwTab T0inv, HcTw
     for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
 }
 // KB3: rows-forward mod P, multiply by b_P and a_P, rows-inverse mod P of both. grid = (16, nodes)
-__global__ __launch_bounds__(HC_TPB) void hc_k_b3(HcLoopB B, HcTwTab TPfwd, HcTwTab TPinv) {
+__global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b3(HcLoopB B, HcTwTab TPfwd, HcTwTab TPinv) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
     const int node = blockIdx.y;
@@ -438,9 +468,10 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTw
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) {
         const u64 yv = hc_csub(e[hi], P);                        // [d]_P in [0,P)
-        const u64 v = (u64)((double)yv / B.pf);                   // fp64 overflow count, as reconstructRNS
+        // ring.reconstructRNS: v = uint64(float64(y)/float64(P)) (0 or 1 for one P prime). y -> v is monotone, so
+        // the host finds the switch point with the very same fp64 expression and the kernel only compares.
         u64 r = hc_barrett64(yv, q, B.mu0);
-        if (v) r = hc_submod(r, B.pmodq.w, q);                    // v is 0 or 1 for a single P prime
+        if (yv >= B.vthresh) r = hc_submod(r, B.pmodq.w, q);
         e[hi] = r;
     }
     __syncthreads();
@@ -448,43 +479,47 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTw
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
 }
-// KB5: rows-forward mod Q0 of both extensions, d = (F - n) * P^-1, row-local Galois permutation through LDS,
-// ct[i] = t1 + perm(d). grid = (16, nodes). Requires the permutation to stay inside 256-blocks (galEl = 2^j+1, j >= 9).
-__global__ __launch_bounds__(HC_TPB) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, const u64 *bias) {
+// KB5: rows-forward mod Q0 of one extension, d = (F - n) * P^-1, row-local Galois permutation through LDS,
+// ct[i][k] = t1 + perm(d). grid = (16, 2*nodes): job = node*2 + k. Requires the permutation to stay inside
+// 256-blocks (galEl = 2^j+1, j >= 9). F and t1 are fetched up front, so the epilogue issues no loads.
+__global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, const u64 *bias) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
-    const int node = blockIdx.y, i = (B.n0 + node) * B.norm;
+    const int job = blockIdx.y, node = job >> 1, k = job & 1, i = (B.n0 + node) * B.norm;
     const u64 q = B.m0.q;
-    u64 e[16];
+    const size_t tile = (size_t)blockIdx.x * 4096 + t;
+    const u64 *__restrict__ in = B.tmpE + (size_t)job * 65536 + (size_t)row * 256;
+    const u64 *__restrict__ F = B.tmpF + (size_t)job * 65536 + tile;
+    u64 *__restrict__ y = B.cts + ((size_t)i * 2 + k) * 65536 + tile;
+    u64 e[16], f[16];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const u64 *in = B.tmpE + ((size_t)node * 2 + k) * 65536 + (size_t)row * 256;
+    for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
 #pragma unroll
-        for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
-        if (k) __syncthreads();
-        hc_rows_fwd(e, lds, T0fwd, row, rloc, tid, q);
-        __syncthreads();
-        hc_rows_lo_to_lin(e, lds, t, rloc, tid);
-        const u64 *F = B.tmpF + ((size_t)node * 2 + k) * 65536;
-        u64 *y = B.cts + ((size_t)i * 2 + k) * 65536;
+    for (int kk = 0; kk < 16; kk++) f[kk] = F[kk * 256];
+    hc_rows_fwd(e, lds, T0fwd, row, rloc, tid, q);
+    __syncthreads();
+    hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) {
-            const size_t off = (size_t)(blockIdx.x * 16 + kk) * 256 + t;
-            u64 n = hc_csub(hc_csub(e[kk], 2 * q), q);
-            e[kk] = hc_mul_shoup(hc_submod(F[off], n, q), B.pinv.w, B.pinv.ws, q);
-        }
-        __syncthreads();
+    for (int kk = 0; kk < 16; kk++) {
+        u64 n = hc_csub(hc_csub(e[kk], 2 * q), q);
+        e[kk] = hc_mul_shoup(hc_submod(f[kk], n, q), B.pinv.w, B.pinv.ws, q);
+    }
+    // t1 (and the bias row) are fetched only now: f is dead, so the register footprint stays at two tiles
+    asm volatile("" ::: "memory");     // keep the compiler from hoisting these loads above the transform
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) lds[hc_rows_lds(kk, t)] = e[kk];
-        __syncthreads();
+    for (int kk = 0; kk < 16; kk++) f[kk] = y[kk * 256];
+    if (bias != nullptr && k == 0) {
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) {
-            const u32 dst = (u32)((blockIdx.x * 16 + kk) * 256 + t);
-            const u32 src = hc_perm_src(dst, B.gal);
-            const size_t off = dst;
-            u64 r = hc_addmod(y[off], lds[hc_rows_lds(kk, (int)(src & 255))], q);
-            if (bias != nullptr && k == 0) r = hc_addmod(r, bias[off], q);
-            y[off] = r;
-        }
+        for (int kk = 0; kk < 16; kk++) f[kk] = hc_addmod(f[kk], bias[tile + kk * 256], q);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) lds[hc_rows_lds(kk, t)] = e[kk];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+        const u32 dst = (u32)((blockIdx.x * 16 + kk) * 256 + t);
+        const u32 src = hc_perm_src(dst, B.gal);
+        y[kk * 256] = hc_addmod(f[kk], lds[hc_rows_lds(kk, (int)(src & 255))], q);
     }
 }

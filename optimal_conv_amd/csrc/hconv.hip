@@ -484,7 +484,12 @@ static int hc_fill_loopB(hc_ctx *c, HcLoopB *B, u64 *cts, const HcEvk &e, int lo
     B->pmodq = h_pair(mp.m.q % m0.m.q, m0.m.q);
     B->pinv = h_pair(h_inv(mp.m.q % m0.m.q, m0.m.q), m0.m.q);
     B->mu0 = (u64)((((u128)1) << 64) / m0.m.q);
-    B->pf = (double)mp.m.q;
+    {   // switch point of v = uint64(float64(y)/float64(P)) over y in [0,P): binary search with the reference's expression
+        const double pf = (double)mp.m.q;
+        u64 lo = 0, hi = mp.m.q;              // invariant: v(lo-1) == 0 (or lo == 0), v(hi) >= 1 or hi == P
+        while (lo < hi) { u64 mid = lo + (hi - lo) / 2; if ((u64)((double)mid / pf) >= 1) hi = mid; else lo = mid + 1; }
+        B->vthresh = lo;
+    }
     B->gal = (u32)(galEl & 0x1FFFF);
     return HC_OK;
 }
@@ -506,22 +511,23 @@ static int hc_pack_level(hc_ctx *c, u64 *cts, int step, int logStep, int norm, u
         HC_TRY(hc_launch(c, "b2_colsinv_colsfwdP", hc_k_b2, dim3(16, (unsigned)nn), B, m0.inv, mp.fwd));
         HC_TRY(hc_launch(c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, dim3(16, (unsigned)nn), B, mp.fwd, mp.inv));
         HC_TRY(hc_launch(c, "b4_colsinvP_modup_colsfwd", hc_k_b4, dim3(16, (unsigned)(2 * nn)), B, mp.inv, m0.fwd));
-        HC_TRY(hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, (unsigned)nn), B, m0.fwd, bias_last));
+        HC_TRY(hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, (unsigned)(2 * nn)), B, m0.fwd, bias_last));
     }
     return HC_OK;
 }
 // conv.go:266-300 on device-resident level-0 ciphertexts, in place (result in slot 0)
-static int hc_pack_run(hc_ctx *c, u64 *cts, int max_cnum, int real_cnum, const u64 *bias) {
+static int hc_pack_run(hc_ctx *c, u64 *cts, int max_cnum, int real_cnum, const u64 *bias, int stride_log2 = 0) {
     if (max_cnum < 1 || real_cnum < 1 || max_cnum % real_cnum || (max_cnum & (max_cnum - 1)) || (real_cnum & (real_cnum - 1)))
         return hc_fail(c, HC_ERR_ARG, "pack: max_cnum=%d real_cnum=%d must be powers of two", max_cnum, real_cnum);
     const int norm = max_cnum / real_cnum;
     int step = max_cnum / 2, logStep = 0;
     for (int i = step; i > 1; i /= 2) logStep++;
-    int j = HC_LOGN - logStep;
+    if (stride_log2 < 0 || logStep + stride_log2 >= HC_LOGN) return hc_fail(c, HC_ERR_ARG, "pack: stride_log2=%d out of range", stride_log2);
+    int j = HC_LOGN - logStep - stride_log2;      // slot m stands for global ciphertext index m << stride_log2
     bool bias_done = false;
     while (step >= norm && step >= 1) {
         const bool last = (step / 2 < norm) || step == 1;
-        HC_TRY(hc_pack_level(c, cts, step, logStep, norm, (1ull << j) + 1, last ? bias : nullptr));
+        HC_TRY(hc_pack_level(c, cts, step, logStep + stride_log2, norm, (1ull << j) + 1, last ? bias : nullptr));
         if (last) bias_done = true;
         step /= 2; logStep--; j++;
     }
@@ -534,6 +540,10 @@ static int hc_pack_run(hc_ctx *c, u64 *cts, int max_cnum, int real_cnum, const u
 extern "C" int hc_pack_ctxts(hc_ctx *c, uint64_t *cts, int max_cnum, int real_cnum) {
     HC_ENTER(c); if (!cts) return hc_fail(c, HC_ERR_ARG, "hc_pack_ctxts: null");
     return hc_pack_run(c, (u64 *)cts, max_cnum, real_cnum, nullptr);
+}
+extern "C" int hc_pack_ctxts_strided(hc_ctx *c, uint64_t *cts, int count, int stride_log2, const uint64_t *bias) {
+    HC_ENTER(c); if (!cts) return hc_fail(c, HC_ERR_ARG, "hc_pack_ctxts_strided: null");
+    return hc_pack_run(c, (u64 *)cts, count, count, (const u64 *)bias, stride_log2);
 }
 
 // ------------------------------------------------------------------ key switch / rotate at level 0 (L0 API)
@@ -565,7 +575,7 @@ static int hc_ks_common(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uin
             if (!rc) rc = hc_launch(c, "b2_colsinv_colsfwdP", hc_k_b2, dim3(16, 1), B, m0.inv, mp.fwd);
             if (!rc) rc = hc_launch(c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, dim3(16, 1), B, mp.fwd, mp.inv);
             if (!rc) rc = hc_launch(c, "b4_colsinvP_modup_colsfwd", hc_k_b4, dim3(16, 2), B, mp.inv, m0.fwd);
-            if (!rc) rc = hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, 1), B, m0.fwd, (const u64 *)nullptr);
+            if (!rc) rc = hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, 2), B, m0.fwd, (const u64 *)nullptr);
             HcTw z; z.w = z.ws = 0;
             if (!rc) rc = hc_launch(c, "ks_sub", hc_k_pointwise<HC_PW_SUB>, hc_pw_grid(2 * HC_N), (const u64 *)y, (const u64 *)keep, y, (size_t)2 * HC_N, c->mods[0].m, z);
             if (!rc) { hipMemcpyAsync(o0, y, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); hipMemcpyAsync(o1, y + HC_N, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); }

@@ -44,6 +44,8 @@ def plain_conv(x, ker, a, b):
 def write_case(outdir, k, i_batch, it):
     B, W, raw, x, ker, a, b = make_case(k, i_batch, it)
     out = plain_conv(x, ker, a, b)
+    os.makedirs(outdir, exist_ok=True)
+    os.makedirs(outdir, exist_ok=True)
     pre = os.path.join(outdir, f"test_conv{k}_batch_{B}_")
     for name, arr in (("in", x), ("ker", ker), ("bna", a), ("bnb", b), ("out", out)):
         np.savetxt(f"{pre}{name}_{it}.csv", arr.reshape(-1), fmt="%.17g")

@@ -1,0 +1,53 @@
+"""The C++ host side (optimal_conv_amd/host: newContext, prep_Ker, evalConv_BN, testConv_in, the `conv` CLI) on CPU:
+the CLI is linked against the emulated kernel library and run as `conv 3 0 1` on synthetic CSVs in the reference's
+file layout (test.go:37-40). Checks the reference's CLI contract (line shapes), its argument
+errors (main.go:586-607) and the decrypted precision the reference reaches at B=4 (MED 25.4 bits)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import golden.gen_conv_csv as gen
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "kernel_emu")
+CLI = os.path.join(EMU_DIR, "_build", "conv_emu")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, CLI])
+    return CLI
+
+
+def test_conv_3_0_1(cli, tmp_path):
+    gen.write_case(str(tmp_path / "test_conv_data"), 3, 0, 0)
+    out = subprocess.run([cli, "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=1200,
+                         env=dict(os.environ, HCONV_SEED="12345"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    txt = out.stdout
+    for pat in (r"^Convolution test start! \(No Bootstrapping\)$", r"^Ker:  3 batches:  4 widths:  128$", r"^Base Line start\.$",
+                r"^Ours start\.$", r"^CKKS parameters: logN = 16, logSlots = 15, h = 192, logQP = 1553, levels = 28, scale= 2\^30\.000000, sigma = 3\.200000 $",
+                r"^Num Rotations:  0$", r"^vec size: log2 =  16$", r"^raw input width:  127$", r"^kernel width:  3$",
+                r"^num raw batches in & out:  4 ,  4$", r"^1 -th iter\.\.\.start$", r"^Encryption done in \S+ $",
+                r"^Plaintext \(kernel\) preparation, Done in \S+ $", r"^\t mult time:  \S+$", r"^\t Pack time:  \S+$",
+                r"^Conv \(with BN\) Done in \S+ $", r"^Decryption Done in \S+ $", r"^ValuesTest:", r"^ValuesWant:"):
+        assert re.search(pat, txt, re.M), f"missing line {pat!r} in:\n{txt}"
+    med = float(re.search(r"^MED Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M).group(1))
+    assert med >= 22.0, txt
+
+
+@pytest.mark.parametrize("argv,msg", [(["conv", "4", "0", "1"], "Wrong kernel wid (not in 3,5,7)"),
+                                      (["conv", "3", "4", "1"], "Too many tests (>10) or too many batch index (>3)"),
+                                      (["conv", "3", "0", "11"], "Too many tests (>10) or too many batch index (>3)"),
+                                      (["bogus", "3", "0", "1"], "wrong test type")])
+def test_cli_argument_panics(cli, tmp_path, argv, msg):
+    out = subprocess.run([cli] + argv, cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and f"panic: {msg}" in out.stderr
+
+
+def test_missing_csv_panics(cli, tmp_path):
+    out = subprocess.run([cli, "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HCONV_SEED="1"))
+    assert out.returncode == 2 and "panic:" in out.stderr
