@@ -35,6 +35,17 @@ def algorithmic_mib(B):
     return 5 * B - 1 + 2.5 * np.log2(B) + 0.5
 
 
+def traffic_from_profiles(B, chunk):
+    """HBM bytes per conv from the committed rocprofv3 PMC passes (tools/pmc_traffic.py); PMC counters cannot be
+    read from inside this process, so the figure is the one measured with the same command and committed under
+    profiles/. None when no measurement for this workload exists."""
+    path = os.path.join(ROOT, "profiles", f"traffic_conv_B{B}.json")
+    try:
+        return json.load(open(path))["bytes_per_conv"]
+    except Exception:
+        return None
+
+
 def synth_rows(rng, q, shape):
     return (rng.integers(0, 1 << 62, size=shape, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
 
@@ -64,12 +75,12 @@ def cpu_baseline(B):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--i-batch", type=int, default=3, help="reference batch index (main.go:578): 3 => B=256, W=16 = `conv 3 3`")
     ap.add_argument("--ker-wid", type=int, default=3)
     ap.add_argument("--chunk", type=int, default=64)
-    ap.add_argument("--streams", type=int, default=1, help="independent ciphertexts in flight per GPU (one hc_ctx = one HIP stream each)")
+    ap.add_argument("--streams", type=int, default=3, help="independent ciphertexts in flight per GPU (one hc_ctx = one HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -170,7 +181,7 @@ def main():
                        "logN": 16, "moduli": "ckks.DefaultBootstrapParams[6] Q0,Q1 + P=0x1fffffffffe00001",
                        "convs_per_step_per_gpu": 1, "ciphertexts_in_flight_per_gpu": S, "chunk_nodes": args.chunk},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None,
+                         "traffic": traffic_from_profiles(B, args.chunk),
                          "unit_of_launch": "one conv_then_pack (all of its kernel launches on one stream)",
                          "algorithmic_bytes_per_conv": alg_bytes, "conv_ms_hip_events": conv_ms_events,
                          "dominant_kernel": dom, "kernels": kern},

@@ -1,14 +1,19 @@
 #!/bin/bash
-# One GPU-box session: build check, GPU parity tests, micro-benchmarks, bench, rocprofv3 kernel stats.
+# One full GPU-box session: build, GPU parity tests, smoke, bench (+other CLI configs), rocprofv3 kernel stats and
+# HBM traffic counters (separate --pmc passes). Artefacts land in gpurun_out/round/ ; copy what is judged to profiles/.
 set -u
-mkdir -p gpurun_out
+O=gpurun_out/round; mkdir -p $O
 export TMPDIR=/tmp
-python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || echo "BUILD FAILED"
-rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9" | head -4 > gpurun_out/gpuinfo.txt
-timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
-tail -15 gpurun_out/pytest_gpu.log
-timeout 300 ./tools/ubench > gpurun_out/ubench.log 2>&1; cat gpurun_out/ubench.log
-timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.json
-for ib in 1 2; do timeout 300 python bench.py --steps 20 --warmup 3 --i-batch $ib --no-cpu-baseline > gpurun_out/bench_ib$ib.json 2>> gpurun_out/bench.err; done
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o conv33 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_run.log 2>&1)
-find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
+python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || echo "BUILD FAILED"
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json | cut -c1-400
+for ib in 0 1 2; do timeout 300 python bench.py --i-batch $ib --no-cpu-baseline > $O/bench_ib$ib.json 2>> $O/bench.err; done
+timeout 300 python bench.py --streams 1 --no-cpu-baseline > $O/bench_streams1.json 2>> $O/bench.err
+R=$GRAFT_REPO_ROOT
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o conv33 -- python $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline > $R/$O/prof_run.log 2>&1)
+for pmc in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $R/$O/pmc_$pmc -o run -- python $R/bench.py --steps 3 --warmup 0 --streams 1 --no-cpu-baseline > $R/$O/pmc_$pmc.log 2>&1)
+done
+python tools/pmc_traffic.py $O/pmc_FETCH_SIZE/run_counter_collection.csv $O/pmc_WRITE_SIZE/run_counter_collection.csv 6 $O/traffic_conv_B256.json
+find $O/prof -name "*stats*.csv" | head -3
