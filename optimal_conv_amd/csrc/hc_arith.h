@@ -30,7 +30,10 @@ HC_HD u64 hc_mulhi(u64 a, u64 b) {
 #endif
 }
 
-// x*w mod q, lazy [0,2q); wp = floor(w*2^64/q), w in [0,q), any x < 2^64
+// x*w mod q, lazy [0,2q); wp = floor(w*2^64/q), w in [0,q), any x < 2^64.
+// (Measured on MI355X, tools/ubench2: a carry-chain form of mulhi with no v_mov re-packing and a multiply-accumulate
+// form of x*w - hi*q cut the butterfly from 23.3 to 19.3 VALU instructions but ran 6 % SLOWER - the VCC-serialised
+// v_addc chains cost more than the moves they remove - so the plain form below stays.)
 HC_HD u64 hc_mul_shoup_lazy(u64 x, u64 w, u64 wp, u64 q) {
     u64 hi = hc_mulhi(x, wp);
     return x * w - hi * q;
@@ -64,4 +67,5 @@ struct HcMod {
     u64 qinv;      // q^-1 mod 2^64
     u64 r2;        // 2^128 mod q (to enter Montgomery form)
     u64 ninv, ninv_s;  // N^-1 mod q and its Shoup companion
+    u64 mu;            // floor(2^64/q) (Barrett, 64-bit inputs)
 };

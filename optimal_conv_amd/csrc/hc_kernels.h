@@ -42,9 +42,15 @@ struct HcTwTab {
 // ---------------------------------------------------------------- radix-16 rounds
 // Slot numbering: a 4-stage round has 1+2+4+8 twiddles; the stage with 2^s twiddles uses slots (2^s - 1 + g).
 // Forward rounds walk s = 0..3 (distance 8,4,2,1); inverse rounds walk distance 1,2,4,8 (s = 3..0).
-template <class TW>
+// Forward lazy-reduction modes (Harvey butterflies; T = w*Y is in [0,2q) for ANY 64-bit Y, so only X needs care):
+//   HC_FM_FREE  no conditional subtraction at all: every stage adds at most 2q to the bound, 16 stages of a full
+//               transform turn inputs < 2q into outputs < 34q. Needs 34q < 2^64, i.e. moduli below 2^58 (Q0, Q1).
+//   HC_FM_ALT   X is folded by 4q before stages 0 and 2 of each round: inputs < 8q stay < 8q. Needs 8q < 2^64, which
+//               holds for every modulus this library accepts (q < 2^61 incl. the 61-bit P: 8P = 2^64 - 2^24 + 8).
+enum { HC_FM_FREE = 1, HC_FM_ALT = 2 };
+template <int FM, class TW>
 __device__ __forceinline__ void hc_ct_round(u64 (&e)[16], const TW &tw, u64 q) {
-    const u64 twoq = 2 * q;
+    const u64 twoq = 2 * q, fourq = 4 * q;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int half = 8 >> s;
@@ -54,13 +60,20 @@ __device__ __forceinline__ void hc_ct_round(u64 (&e)[16], const TW &tw, u64 q) {
 #pragma unroll
             for (int k = 0; k < half; k++) {
                 const int a = g * 2 * half + k, b = a + half;
-                u64 X = hc_csub(e[a], twoq);
+                u64 X = e[a];
+                if (FM == HC_FM_ALT && (s == 0 || s == 2)) X = hc_csub(X, fourq);
                 u64 T = hc_mul_shoup_lazy(e[b], w.w, w.ws, q);
                 e[a] = X + T;
                 e[b] = X - T + twoq;
             }
         }
     }
+}
+// canonical residue of a forward-transform output (FREE: < 34q -> Barrett with mu = floor(2^64/q); ALT: < 8q)
+template <int FM>
+__device__ __forceinline__ u64 hc_fwd_canon(u64 x, u64 q, u64 mu) {
+    if (FM == HC_FM_FREE) { u64 r = x - hc_mulhi(x, mu) * q; return hc_csub(r, q); }
+    return hc_csub(hc_csub(hc_csub(x, 4 * q), 2 * q), q);
 }
 // LAST: the final stage also multiplies by N^-1 (folded into the twiddle for the "-" output).
 template <bool LAST, class TW>
@@ -104,15 +117,16 @@ struct HcRowsTwA { const HcTw *p; __device__ __forceinline__ HcTw operator()(int
 struct HcRowsTwB { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return p[slot * 16]; } };
 
 // forward rows pass on registers: in  e[hi] = element (row, hi*16+tid)  [lazy < 4q]
-//                                 out e[lo] = element (row, tid*16+lo)  [lazy < 4q]
+//                                 out e[lo] = element (row, tid*16+lo)  [lazy, bound per forward mode]
+template <int FM>
 __device__ __forceinline__ void hc_rows_fwd(u64 (&e)[16], u64 *lds, const HcTwTab &T, int row, int rloc, int tid, u64 q) {
-    hc_ct_round(e, HcRowsTwA{T.rowsA + row * 16}, q);
+    hc_ct_round<FM>(e, HcRowsTwA{T.rowsA + row * 16}, q);
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) lds[hc_rows_lds(rloc, hi * 16 + tid)] = e[hi];
     __syncthreads();
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = lds[hc_rows_lds(rloc, tid * 16 + lo)];
-    hc_ct_round(e, HcRowsTwB{T.rowsB + row * 256 + tid}, q);
+    hc_ct_round<FM>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, q);
 }
 // inverse rows pass: in e[lo] = (row, tid*16+lo) [lazy < 2q]; out e[hi] = (row, hi*16+tid) [lazy < 2q]
 __device__ __forceinline__ void hc_rows_inv(u64 (&e)[16], u64 *lds, const HcTwTab &T, int row, int rloc, int tid, u64 q) {
@@ -125,14 +139,15 @@ __device__ __forceinline__ void hc_rows_inv(u64 (&e)[16], u64 *lds, const HcTwTa
     hc_gs_round<false>(e, HcRowsTwA{T.rowsA + row * 16}, q, T.ninv, T.ninv);
 }
 // forward cols pass: in e[hi] = (hi*16+tid, c) [lazy < 4q]; out e[lo] = (tid*16+lo, c) [lazy < 4q]
+template <int FM>
 __device__ __forceinline__ void hc_cols_fwd(u64 (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, u64 q) {
-    hc_ct_round(e, HcRowsTwA{T.colsA}, q);
+    hc_ct_round<FM>(e, HcRowsTwA{T.colsA}, q);
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) lds[hc_cols_lds(hi * 16 + tid, c)] = e[hi];
     __syncthreads();
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = lds[hc_cols_lds(tid * 16 + lo, c)];
-    hc_ct_round(e, HcRowsTwB{T.colsB + tid}, q);
+    hc_ct_round<FM>(e, HcRowsTwB{T.colsB + tid}, q);
 }
 // inverse cols pass incl. N^-1: in e[lo] = (tid*16+lo, c) [lazy < 2q]; out e[hi] = (hi*16+tid, c) [lazy < 2q]
 __device__ __forceinline__ void hc_cols_inv(u64 (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, u64 q) {
@@ -169,6 +184,7 @@ __device__ __forceinline__ u64 hc_barrett64(u64 x, u64 q, u64 mu) {
 
 // ================================================================ standalone transforms (L0 API)
 // grid = (16, count): blockIdx.x = tile, blockIdx.y = row (limb-polynomial) index
+template <int FM>
 __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd(const u64 *in, u64 *out, HcTwTab T, u64 q) {
     __shared__ u64 lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
@@ -176,22 +192,23 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd(const u64 *in, u64 *out,
     u64 e[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[base + (size_t)(hi * 16 + tid) * 256];
-    hc_cols_fwd(e, lds, T, c, tid, q);
+    hc_cols_fwd<FM>(e, lds, T, c, tid, q);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) out[base + (size_t)(tid * 16 + lo) * 256] = e[lo];
 }
-__global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon(const u64 *in, u64 *out, HcTwTab T, u64 q) {
+template <int FM>
+__global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon(const u64 *in, u64 *out, HcTwTab T, u64 q, u64 mu) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
     const size_t pbase = (size_t)blockIdx.y * 65536;
     u64 e[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[pbase + (size_t)row * 256 + hi * 16 + tid];
-    hc_rows_fwd(e, lds, T, row, rloc, tid, q);
+    hc_rows_fwd<FM>(e, lds, T, row, rloc, tid, q);
     __syncthreads();
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
-    for (int k = 0; k < 16; k++) out[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t] = hc_csub(hc_csub(e[k], 2 * q), q);
+    for (int k = 0; k < 16; k++) out[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t] = hc_fwd_canon<FM>(e[k], q, mu);
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv(const u64 *in, u64 *out, HcTwTab T, u64 q) {
     __shared__ u64 lds[HC_ROWS_LDS];
@@ -299,6 +316,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
     for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
 }
 // KA2: cols-inverse mod Q1, centred lift to Q0, cols-forward mod Q0, in place on tmp. grid = (16, jobs)
+template <int FM>
 __global__ __launch_bounds__(HC_TPB) void hc_k_a2(HcLoopA A, HcTwTab T1inv, HcTwTab T0fwd) {
     __shared__ u64 lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
@@ -313,13 +331,14 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_a2(HcLoopA A, HcTwTab T1inv, HcTw
         e[hi] = v + A.negh0;                                      // (.. - h) mod Q0, lazy < 2*Q0
     }
     __syncthreads();
-    hc_cols_fwd(e, lds, T0fwd, c, tid, A.m0.q);
+    hc_cols_fwd<FM>(e, lds, T0fwd, c, tid, A.m0.q);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
 }
 // KA3: rows-forward mod Q0, then out = (a_0 - u) * Q1^-1. grid = (16, jobs)
 // a_0 = c'_p[0] (*) k_i[0] is formed first, in the linear layout the epilogue uses, so that every global load of
 // the kernel is issued before the transform starts and nothing stalls behind the stores at the end.
+template <int FM>
 __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_a3(HcLoopA A, HcTwTab T0fwd) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
@@ -336,12 +355,12 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_a3(HcLoopA A, HcTwT
     for (int kk = 0; kk < 16; kk++) a0[kk] = c[kk * 256];
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) a0[kk] = hc_mont(a0[kk], k[kk * 256], q, A.m0.qinv);
-    hc_rows_fwd(e, lds, T0fwd, row, rloc, tid, q);
+    hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, q);
     __syncthreads();
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
-        u64 u = hc_csub(hc_csub(e[kk], 2 * q), q);
+        u64 u = hc_fwd_canon<FM>(e[kk], q, A.m0.mu);
         o[kk * 256] = hc_mul_shoup(hc_submod(a0[kk], u, q), A.q1inv.w, A.q1inv.ws, q);
     }
 }
@@ -413,6 +432,7 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b1(HcLoopB B, HcTwT
     for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
 }
 // KB2: cols-inverse mod Q0 (-> canonical c < Q0 < P), cols-forward mod P, in place on tmpC. grid = (16, nodes)
+template <int FMP>
 __global__ __launch_bounds__(HC_TPB) void hc_k_b2(HcLoopB B, HcTwTab T0inv, HcTwTab TPfwd) {
     __shared__ u64 lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
@@ -424,11 +444,12 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b2(HcLoopB B, HcTwTab T0inv, HcTw
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = hc_csub(e[hi], B.m0.q);
     __syncthreads();
-    hc_cols_fwd(e, lds, TPfwd, c, tid, B.mp.q);
+    hc_cols_fwd<FMP>(e, lds, TPfwd, c, tid, B.mp.q);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
 }
 // KB3: rows-forward mod P, multiply by b_P and a_P, rows-inverse mod P of both. grid = (16, nodes)
+template <int FMP>
 __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b3(HcLoopB B, HcTwTab TPfwd, HcTwTab TPinv) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
@@ -438,7 +459,7 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b3(HcLoopB B, HcTwT
     u64 cp[16], e[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) cp[hi] = in[hi * 16 + tid];
-    hc_rows_fwd(cp, lds, TPfwd, row, rloc, tid, q);
+    hc_rows_fwd<FMP>(cp, lds, TPfwd, row, rloc, tid, q);
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const HcTw *ev = B.evkP + (size_t)k * 65536 + (size_t)blockIdx.x * 4096 + t;
@@ -456,6 +477,7 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b3(HcLoopB B, HcTwT
 }
 // KB4: cols-inverse mod P, exact basis extension P -> Q0 (ring.modUpExact, one P prime), cols-forward mod Q0.
 // grid = (16, 2*nodes), in place on tmpE
+template <int FM>
 __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTwTab T0fwd) {
     __shared__ u64 lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
@@ -475,13 +497,14 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTw
         e[hi] = r;
     }
     __syncthreads();
-    hc_cols_fwd(e, lds, T0fwd, c, tid, q);
+    hc_cols_fwd<FM>(e, lds, T0fwd, c, tid, q);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
 }
 // KB5: rows-forward mod Q0 of one extension, d = (F - n) * P^-1, row-local Galois permutation through LDS,
 // ct[i][k] = t1 + perm(d). grid = (16, 2*nodes): job = node*2 + k. Requires the permutation to stay inside
 // 256-blocks (galEl = 2^j+1, j >= 9). F and t1 are fetched up front, so the epilogue issues no loads.
+template <int FM>
 __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, const u64 *bias) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
@@ -496,12 +519,12 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b5(HcLoopB B, HcTwT
     for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) f[kk] = F[kk * 256];
-    hc_rows_fwd(e, lds, T0fwd, row, rloc, tid, q);
+    hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, q);
     __syncthreads();
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
-        u64 n = hc_csub(hc_csub(e[kk], 2 * q), q);
+        u64 n = hc_fwd_canon<FM>(e[kk], q, B.m0.mu);
         e[kk] = hc_mul_shoup(hc_submod(f[kk], n, q), B.pinv.w, B.pinv.ws, q);
     }
     // t1 (and the bias row) are fetched only now: f is dead, so the register footprint stays at two tiles

@@ -96,6 +96,9 @@ static int hc_fail(hc_ctx *c, int code, const char *fmt, ...) {
 #define HC_HIP(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hc_fail(c, HC_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 #define HC_ENTER(c) do { if (!(c)) return HC_ERR_ARG; HC_HIP(c, hipSetDevice((c)->device)); } while (0)
 
+// forward lazy-reduction mode by modulus size (see HC_FM_* in hc_kernels.h): 34q < 2^64 <=> q < 2^58.9
+static inline bool hc_fm_free(u64 q) { return q < (1ull << 58); }
+
 template <class K, class... Args>
 static int hc_launch(hc_ctx *c, const char *name, K kernel, dim3 grid, Args... args) {
     hipEvent_t a = nullptr, b = nullptr;
@@ -106,6 +109,9 @@ static int hc_launch(hc_ctx *c, const char *name, K kernel, dim3 grid, Args... a
     return HC_OK;
 }
 #define HC_TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
+// pick the kernel instantiation whose forward transform uses the lazy-reduction mode the modulus q allows
+#define HC_LAUNCH_FM(q, c, name, KERNEL, grid, ...) \
+    (hc_fm_free(q) ? hc_launch(c, name, KERNEL<HC_FM_FREE>, grid, __VA_ARGS__) : hc_launch(c, name, KERNEL<HC_FM_ALT>, grid, __VA_ARGS__))
 
 static int hc_prof_flush(hc_ctx *c) {
     if (c->prof.empty()) return HC_OK;
@@ -191,6 +197,7 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
         u64 r = (u64)((((u128)1) << 64) % qi);
         mh.m.r2 = h_mulmod(r, r, qi);
         mh.m.ninv = h_inv(HC_N, qi); mh.m.ninv_s = h_shoup(mh.m.ninv, qi);
+        mh.m.mu = (u64)((((u128)1) << 64) / qi);
         u64 g = h_primitive_root(qi), power = (qi - 1) / (2ull * HC_N);
         mh.psi = h_powmod(g, power, qi); mh.psi_inv = h_powmod(g, (qi - 1) - power, qi);
         int rc = hc_build_tables(c, &mh, false); if (!rc) rc = hc_build_tables(c, &mh, true);
@@ -261,8 +268,8 @@ extern "C" int hc_ntt(hc_ctx *c, int mod, const uint64_t *in, uint64_t *out, int
     if (!in || !out || count < 1) return hc_fail(c, HC_ERR_ARG, "hc_ntt: bad arguments");
     HcModHost &mh = c->mods[(size_t)mod];
     HC_TRY(hc_ensure_tmp(c, (size_t)count));
-    HC_TRY(hc_launch(c, "cols_fwd", hc_k_cols_fwd, dim3(16, (unsigned)count), (const u64 *)in, c->ws_tmp, mh.fwd, mh.m.q));
-    HC_TRY(hc_launch(c, "rows_fwd_canon", hc_k_rows_fwd_canon, dim3(16, (unsigned)count), (const u64 *)c->ws_tmp, (u64 *)out, mh.fwd, mh.m.q));
+    HC_TRY(HC_LAUNCH_FM(mh.m.q, c, "cols_fwd", hc_k_cols_fwd, dim3(16, (unsigned)count), (const u64 *)in, c->ws_tmp, mh.fwd, mh.m.q));
+    HC_TRY(HC_LAUNCH_FM(mh.m.q, c, "rows_fwd_canon", hc_k_rows_fwd_canon, dim3(16, (unsigned)count), (const u64 *)c->ws_tmp, (u64 *)out, mh.fwd, mh.m.q, mh.m.mu));
     return HC_OK;
 }
 extern "C" int hc_intt(hc_ctx *c, int mod, const uint64_t *in, uint64_t *out, int count) {
@@ -346,8 +353,8 @@ static int hc_loopA_run(hc_ctx *c, const u64 *ker_mont, int max_ob, int norm, u6
         A.i0 = j0 * norm;
         dim3 grid(16, (unsigned)(2 * nj));
         HC_TRY(hc_launch(c, "a1_mul_rowsinv", hc_k_a1, grid, A, m1.inv));
-        HC_TRY(hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2, grid, A, m1.inv, m0.fwd));
-        HC_TRY(hc_launch(c, "a3_rowsfwd_rescale", hc_k_a3, grid, A, m0.fwd));
+        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "a2_colsinv_lift_colsfwd", hc_k_a2, grid, A, m1.inv, m0.fwd));
+        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "a3_rowsfwd_rescale", hc_k_a3, grid, A, m0.fwd));
     }
     return HC_OK;
 }
@@ -431,8 +438,8 @@ extern "C" int hc_idx_load(hc_ctx *c, const uint64_t *idx_host) {
         for (int i = 0; i < HC_LOGN; i++) HC_HIP(c, hipMemcpyAsync(stage + (size_t)i * HC_N + ((size_t)1 << i), &one, sizeof one, hipMemcpyHostToDevice, c->stream));
         HC_HIP(c, hipStreamSynchronize(c->stream));
         u64 *tmp = nullptr; HC_HIP(c, hipMalloc((void **)&tmp, (size_t)HC_LOGN * HC_N * sizeof(u64)));
-        rc = hc_launch(c, "cols_fwd", hc_k_cols_fwd, dim3(16, HC_LOGN), (const u64 *)stage, tmp, m0.fwd, m0.m.q);
-        if (!rc) rc = hc_launch(c, "rows_fwd_canon", hc_k_rows_fwd_canon, dim3(16, HC_LOGN), (const u64 *)tmp, stage, m0.fwd, m0.m.q);
+        rc = HC_LAUNCH_FM(m0.m.q, c, "cols_fwd", hc_k_cols_fwd, dim3(16, HC_LOGN), (const u64 *)stage, tmp, m0.fwd, m0.m.q);
+        if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "rows_fwd_canon", hc_k_rows_fwd_canon, dim3(16, HC_LOGN), (const u64 *)tmp, stage, m0.fwd, m0.m.q, m0.m.mu);
         hipStreamSynchronize(c->stream); hipFree(tmp);
     }
     HcTw *pairs = nullptr;
@@ -508,10 +515,10 @@ static int hc_pack_level(hc_ctx *c, u64 *cts, int step, int logStep, int norm, u
         const int nn = (nodes - n0) < chunk ? (nodes - n0) : chunk;
         B.n0 = n0;
         HC_TRY(hc_launch(c, "b1_node_rowsinv", hc_k_b1, dim3(16, (unsigned)nn), B, m0.inv));
-        HC_TRY(hc_launch(c, "b2_colsinv_colsfwdP", hc_k_b2, dim3(16, (unsigned)nn), B, m0.inv, mp.fwd));
-        HC_TRY(hc_launch(c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, dim3(16, (unsigned)nn), B, mp.fwd, mp.inv));
-        HC_TRY(hc_launch(c, "b4_colsinvP_modup_colsfwd", hc_k_b4, dim3(16, (unsigned)(2 * nn)), B, mp.inv, m0.fwd));
-        HC_TRY(hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, (unsigned)(2 * nn)), B, m0.fwd, bias_last));
+        HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b2_colsinv_colsfwdP", hc_k_b2, dim3(16, (unsigned)nn), B, m0.inv, mp.fwd));
+        HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, dim3(16, (unsigned)nn), B, mp.fwd, mp.inv));
+        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, dim3(16, (unsigned)(2 * nn)), B, mp.inv, m0.fwd));
+        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, (unsigned)(2 * nn)), B, m0.fwd, bias_last));
     }
     return HC_OK;
 }
@@ -572,10 +579,10 @@ static int hc_ks_common(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uin
             HcLoopB B; if (!rc) rc = hc_fill_loopB(c, &B, y, it->second, 0, 1, 1, g_used, chunk);
             const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
             if (!rc) rc = hc_launch(c, "b1_node_rowsinv", hc_k_b1, dim3(16, 1), B, m0.inv);
-            if (!rc) rc = hc_launch(c, "b2_colsinv_colsfwdP", hc_k_b2, dim3(16, 1), B, m0.inv, mp.fwd);
-            if (!rc) rc = hc_launch(c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, dim3(16, 1), B, mp.fwd, mp.inv);
-            if (!rc) rc = hc_launch(c, "b4_colsinvP_modup_colsfwd", hc_k_b4, dim3(16, 2), B, mp.inv, m0.fwd);
-            if (!rc) rc = hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, 2), B, m0.fwd, (const u64 *)nullptr);
+            if (!rc) rc = HC_LAUNCH_FM(mp.m.q, c, "b2_colsinv_colsfwdP", hc_k_b2, dim3(16, 1), B, m0.inv, mp.fwd);
+            if (!rc) rc = HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, dim3(16, 1), B, mp.fwd, mp.inv);
+            if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, dim3(16, 2), B, mp.inv, m0.fwd);
+            if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, 2), B, m0.fwd, (const u64 *)nullptr);
             HcTw z; z.w = z.ws = 0;
             if (!rc) rc = hc_launch(c, "ks_sub", hc_k_pointwise<HC_PW_SUB>, hc_pw_grid(2 * HC_N), (const u64 *)y, (const u64 *)keep, y, (size_t)2 * HC_N, c->mods[0].m, z);
             if (!rc) { hipMemcpyAsync(o0, y, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); hipMemcpyAsync(o1, y + HC_N, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); }
