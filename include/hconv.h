@@ -90,6 +90,13 @@ int hc_rotate_gal_l0(hc_ctx *ctx, uint64_t galEl, const uint64_t *c0, const uint
 int hc_ker_load(hc_ctx *ctx, const uint64_t *pl_ker_host, int max_ob, hc_ker **out);
 /* same from a DEVICE array (e.g. produced by hc_ntt); the input buffer is not retained */
 int hc_ker_load_device(hc_ctx *ctx, const uint64_t *pl_ker_dptr, int max_ob, hc_ker **out);
+/* prep_Ker itself (conv.go:487-518; pos = 0, trans = false) on the device: HOST float arrays as the reference's readTxt
+ * returns them (ker_in HWIO flat of length ker_len = k^2*real_ib*real_ob, BN_a of length real_ob) -> reshape_ker, BN
+ * scaling, max_bat embedding with stride norm, encode_ker_final, EncodeCoeffs at `scale` (level 1), ToNTT. */
+int hc_prep_ker(hc_ctx *ctx, const double *ker_in, int ker_len, const double *bn_a, int in_wid, int ker_wid,
+                int real_ib, int real_ob, int norm, double scale, hc_ker **out);
+/* the plaintexts of a handle as Lattigo would hold them: HOST out [max_ob][2][N], canonical NTT residues */
+int hc_ker_download(hc_ctx *ctx, const hc_ker *ker, uint64_t *host_out);
 void hc_ker_free(hc_ctx *ctx, hc_ker *ker);
 /* plain_idx (conv.go:241-261): NULL => derive idx[s] = NTT(X^(2^s)) on the device; else HOST array [logN][N] */
 int hc_idx_load(hc_ctx *ctx, const uint64_t *idx_host);

@@ -39,6 +39,9 @@ SYMBOLS = {
     "hc_rotate_gal_l0": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_ker_load": (C.c_int, [C.c_void_p, u64p, C.c_int, C.POINTER(C.c_void_p)]),
     "hc_ker_load_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "hc_prep_ker": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                            C.c_double, C.POINTER(C.c_void_p)]),
+    "hc_ker_download": (C.c_int, [C.c_void_p, C.c_void_p, u64p]),
     "hc_ker_free": (None, [C.c_void_p, C.c_void_p]),
     "hc_idx_load": (C.c_int, [C.c_void_p, u64p]),
     "hc_conv_then_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double,
@@ -240,6 +243,20 @@ class Context:
         k = C.c_void_p()
         self._ck(self.L.hc_ker_load(self.h, _hp(pl_ker.reshape(-1)), max_ob, C.byref(k)))
         return k
+
+    def prep_ker(self, ker_in, bn_a, in_wid, ker_wid, real_ib, real_ob, norm=1, scale=2.0 ** 30):
+        ker_in = np.ascontiguousarray(ker_in, dtype=np.float64).reshape(-1)
+        bn_a = np.ascontiguousarray(bn_a, dtype=np.float64)
+        k = C.c_void_p()
+        f64p = C.POINTER(C.c_double)
+        self._ck(self.L.hc_prep_ker(self.h, ker_in.ctypes.data_as(f64p), ker_in.size, bn_a.ctypes.data_as(f64p), in_wid, ker_wid, real_ib,
+                                    real_ob, norm, scale, C.byref(k)))
+        return k
+
+    def ker_download(self, k, max_ob):
+        out = np.empty((max_ob, 2, self.N), dtype=np.uint64)
+        self._ck(self.L.hc_ker_download(self.h, k, _hp(out.reshape(-1))))
+        return out
 
     def ker_free(self, k):
         self.L.hc_ker_free(self.h, k)

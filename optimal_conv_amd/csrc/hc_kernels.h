@@ -270,6 +270,64 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_make_pairs(const u64 *w, HcTw *ou
     }
 }
 
+// ================================================================ prep_Ker on the device (conv.go:487-518)
+// One thread per non-zero of the kernel plaintexts: (i = output channel, j = input channel, k = tap). Restates
+// reshape_ker (conv.go:184-202), the BN scaling (492-496), the max_bat embedding (498-508), encode_ker_final
+// (206-237: flipped taps, reversed channels, negacyclic shift by adj) and EncodeCoeffs' rounding (scaleUpVecExact:
+// x = uint64(|v|*scale + 0.5) in plain f64, q - (x mod q) for negative v) and scatters the two residues into a
+// zero-filled limb-major staging buffer stage[limb][i][N] (coefficient domain). IEEE f64 ops, so the integers are
+// the ones the reference's Go code produces.
+struct HcPrepKer {
+    const double *ker_in;   // HWIO flat: ker_in[o + c*real_ob + t*real_ob*real_ib]
+    const double *bn_a;     // [real_ob]
+    u64 *stage;             // [2][max_bat][N]
+    int in_wid, ker_wid, real_ib, real_ob, norm, max_bat;
+    double scale;
+    u64 q0, q1;
+};
+__global__ __launch_bounds__(HC_TPB) void hc_k_prep_ker(HcPrepKer P) {
+    const int k_sz = P.ker_wid * P.ker_wid;
+    const long total = (long)P.real_ob * P.real_ib * k_sz;
+    const int vec_size = P.in_wid * P.in_wid * P.max_bat;
+    const int adj = (P.max_bat - 1) + P.max_bat * (P.in_wid + 1) * (P.ker_wid - 1) / 2;
+    for (long id = (long)blockIdx.x * HC_TPB + threadIdx.x; id < total; id += (long)gridDim.x * HC_TPB) {
+        const int o = (int)(id % P.real_ob), c = (int)((id / P.real_ob) % P.real_ib), t = (int)(id / ((long)P.real_ob * P.real_ib));
+        const double v = P.ker_in[o + c * P.real_ob + (long)t * P.real_ob * P.real_ib] * P.bn_a[o];   // ker_rs[o][c*k_sz+t] * BN_a[o]
+        // max_ker_rs[norm*o][norm*c*k_sz + t]; encode_ker_final reads row i at (in_batch-1-j)*k_sz + (k_sz-1-k)
+        const int i = P.norm * o;
+        const int col = P.norm * c * k_sz + t;              // = (in_batch-1-j)*k_sz + (k_sz-1-k)
+        const int jj = P.max_bat - 1 - col / k_sz, kk = k_sz - 1 - col % k_sz;
+        const int p0 = (P.in_wid * (kk / P.ker_wid) + kk % P.ker_wid) * P.max_bat + jj;
+        const bool wrap = p0 < adj;                          // moved to the top block with a sign flip (conv.go:224-234)
+        const int p = wrap ? vec_size - adj + p0 : p0 - adj;
+        const double val = wrap ? -v : v;
+        const bool neg = val < 0;
+        const double x = neg ? -P.scale * val : P.scale * val;
+        const u64 xi = (u64)(x + 0.5);
+        const u64 r0 = xi % P.q0, r1 = xi % P.q1;
+        P.stage[((size_t)0 * P.max_bat + i) * 65536 + p] = neg ? P.q0 - r0 : r0;
+        P.stage[((size_t)1 * P.max_bat + i) * 65536 + p] = neg ? P.q1 - r1 : r1;
+    }
+}
+// limb-major NTT'd stage[limb][i][N] -> hc_ker layout dst[i][limb][N]; to_mont != 0: Montgomery form (x * 2^64 mod q)
+__global__ __launch_bounds__(HC_TPB) void hc_k_ker_interleave(const u64 *stage, u64 *dst, int max_bat, HcMod m0, HcMod m1, int to_mont) {
+    const size_t n = (size_t)max_bat * 2 * 65536;
+    for (size_t id = (size_t)blockIdx.x * HC_TPB + threadIdx.x; id < n; id += (size_t)gridDim.x * HC_TPB) {
+        const size_t j = id & 65535, row = id >> 16; const int l = (int)(row & 1); const size_t i = row >> 1;
+        const HcMod m = l ? m1 : m0;
+        const u64 x = stage[((size_t)l * max_bat + i) * 65536 + j];
+        dst[id] = to_mont ? hc_mont(x, m.r2, m.q, m.qinv) : x;
+    }
+}
+// inverse of the above for inspection: dst_plain[i][limb][N] = from Montgomery form
+__global__ __launch_bounds__(HC_TPB) void hc_k_ker_from_mont(const u64 *ker, u64 *dst, int max_bat, HcMod m0, HcMod m1) {
+    const size_t n = (size_t)max_bat * 2 * 65536;
+    for (size_t id = (size_t)blockIdx.x * HC_TPB + threadIdx.x; id < n; id += (size_t)gridDim.x * HC_TPB) {
+        const HcMod m = ((id >> 16) & 1) ? m1 : m0;
+        dst[id] = hc_mont(ker[id], 1, m.q, m.qinv);
+    }
+}
+
 // ring.PermuteNTTIndex on the fly: source index of destination i for Galois element g (N = 2^16)
 __device__ __forceinline__ u32 hc_perm_src(u32 i, u32 g) {
     u32 r = __brev(i) >> 16;

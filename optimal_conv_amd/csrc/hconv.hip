@@ -477,6 +477,48 @@ extern "C" int hc_ker_load_device(hc_ctx *c, const uint64_t *dptr, int max_ob, h
     if (!dptr || !out || max_ob < 1 || c->nq < 2) return hc_fail(c, HC_ERR_ARG, "hc_ker_load_device: bad arguments");
     return hc_ker_from_device(c, (u64 *)dptr, max_ob, false, out);
 }
+// prep_Ker (conv.go:487-518) entirely on the device: scatter/round the k^2*B^2 non-zeros, 2 batched NTTs, Montgomery form
+extern "C" int hc_prep_ker(hc_ctx *c, const double *ker_in, int ker_len, const double *bn_a, int in_wid, int ker_wid,
+                           int real_ib, int real_ob, int norm, double scale, hc_ker **out) {
+    HC_ENTER(c);
+    if (!ker_in || !bn_a || !out || c->nq < 2 || in_wid < 1 || ker_wid < 1 || real_ib < 1 || real_ob < 1 || norm < 1)
+        return hc_fail(c, HC_ERR_ARG, "hc_prep_ker: bad arguments");
+    if (HC_N % (in_wid * in_wid)) return hc_fail(c, HC_ERR_ARG, "hc_prep_ker: in_wid^2 must divide N");
+    const int max_bat = HC_N / (in_wid * in_wid), k_sz = ker_wid * ker_wid;
+    if (ker_len != k_sz * real_ib * real_ob) return hc_fail(c, HC_ERR_ARG, "input size inconsistent!");   // readTxt's panic text (main.go:986)
+    if (norm * real_ib > max_bat || norm * real_ob > max_bat) return hc_fail(c, HC_ERR_ARG, "hc_prep_ker: norm*batch exceeds max_bat=%d", max_bat);
+    const int adj = (max_bat - 1) + max_bat * (in_wid + 1) * (ker_wid - 1) / 2;
+    if (2 * adj > HC_N) return hc_fail(c, HC_ERR_ARG, "hc_prep_ker: kernel too wide for this input width");
+    double *dk = nullptr, *da = nullptr; u64 *stage = nullptr, *dst = nullptr, *tmp = nullptr;
+    HC_HIP(c, hipMalloc((void **)&dk, (size_t)ker_len * sizeof(double)));
+    HC_HIP(c, hipMalloc((void **)&da, (size_t)real_ob * sizeof(double)));
+    HC_HIP(c, hipMalloc((void **)&stage, (size_t)max_bat * 2 * HC_N * sizeof(u64)));
+    HC_HIP(c, hipMalloc((void **)&dst, (size_t)max_bat * 2 * HC_N * sizeof(u64)));
+    HC_HIP(c, hipMemcpyAsync(dk, ker_in, (size_t)ker_len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hipMemcpyAsync(da, bn_a, (size_t)real_ob * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hipMemsetAsync(stage, 0, (size_t)max_bat * 2 * HC_N * sizeof(u64), c->stream));
+    HcPrepKer P; P.ker_in = dk; P.bn_a = da; P.stage = stage; P.in_wid = in_wid; P.ker_wid = ker_wid; P.real_ib = real_ib; P.real_ob = real_ob;
+    P.norm = norm; P.max_bat = max_bat; P.scale = scale; P.q0 = c->mods[0].m.q; P.q1 = c->mods[1].m.q;
+    int rc = hc_launch(c, "prep_ker_scatter", hc_k_prep_ker, hc_pw_grid((size_t)ker_len), P);
+    HC_HIP(c, hipStreamSynchronize(c->stream));      // host buffers may go away after return; hc_ntt below may regrow ws_tmp
+    for (int l = 0; l < 2 && !rc; l++) rc = hc_ntt(c, l, stage + (size_t)l * max_bat * HC_N, stage + (size_t)l * max_bat * HC_N, max_bat);
+    if (!rc) rc = hc_launch(c, "ker_interleave", hc_k_ker_interleave, hc_pw_grid((size_t)max_bat * 2 * HC_N), (const u64 *)stage, dst, max_bat, c->mods[0].m, c->mods[1].m, 1);
+    hipStreamSynchronize(c->stream);
+    hipFree(dk); hipFree(da); hipFree(stage); (void)tmp;
+    if (rc) { hipFree(dst); return rc; }
+    hc_ker *k = new hc_ker(); k->d = dst; k->max_ob = max_bat; *out = k;
+    return HC_OK;
+}
+// plain (non-Montgomery) NTT rows of a kernel handle, [max_ob][2][N] to the HOST: what prep_Ker's pl_ker[i].Value.Coeffs hold
+extern "C" int hc_ker_download(hc_ctx *c, const hc_ker *k, uint64_t *host_out) {
+    HC_ENTER(c); if (!k || !host_out) return hc_fail(c, HC_ERR_ARG, "hc_ker_download: null");
+    u64 *tmp = nullptr; const size_t n = (size_t)k->max_ob * 2 * HC_N;
+    HC_HIP(c, hipMalloc((void **)&tmp, n * sizeof(u64)));
+    int rc = hc_launch(c, "ker_from_mont", hc_k_ker_from_mont, hc_pw_grid(n), (const u64 *)k->d, tmp, k->max_ob, c->mods[0].m, c->mods[1].m);
+    if (!rc) { HC_HIP(c, hipMemcpyAsync(host_out, tmp, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream)); }
+    hipStreamSynchronize(c->stream); hipFree(tmp);
+    return rc;
+}
 extern "C" void hc_ker_free(hc_ctx *c, hc_ker *k) { if (!k) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } hipFree(k->d); delete k; }
 
 // ------------------------------------------------------------------ loop B plumbing

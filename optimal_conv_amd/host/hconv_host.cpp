@@ -246,26 +246,12 @@ void freeCt(Context *c, Ciphertext &ct) { if (ct.d) HC(c->hc, hc_free(c->hc, ct.
 // ---------------------------------------------------------------- prep_Ker (conv.go:487-518)
 KerPlain prep_Ker(Context *c, const std::vector<double> &ker_in, const std::vector<double> &BN_a, int in_wid, int ker_wid,
                   int real_ib, int real_ob, int norm, int ECD_LV, int pos, bool trans) {
-    const int max_bat = N / (in_wid * in_wid), ker_size = ker_wid * ker_wid;
-    std::vector<std::vector<double>> ker_rs = reshape_ker(ker_in, ker_size, real_ob, trans);
-    for (int i = 0; i < real_ob; i++) for (auto &x : ker_rs[(size_t)i]) x *= BN_a[(size_t)i];
-    std::vector<std::vector<double>> max_ker_rs((size_t)max_bat, std::vector<double>((size_t)(max_bat * ker_size), 0.0));
-    for (int i = 0; i < real_ob; i++) for (int j = 0; j < real_ib; j++) for (int k = 0; k < ker_size; k++)
-        max_ker_rs[(size_t)(norm * i)][(size_t)(norm * j * ker_size + k)] = ker_rs[(size_t)i][(size_t)(j * ker_size + k)];
-    // EncodeCoeffs on the host (k^2*B non-zeros per plaintext); ToNTT (conv.go:514) for all B plaintexts on the GPU:
-    // stage limb-major [2][B][N] so each limb is ONE batched hc_ntt call, then interleave into pl_ker[i] = [Q0 row, Q1 row]
-    uint64_t *stage = dev_rows(c, (size_t)max_bat * 2), *d = dev_rows(c, (size_t)max_bat * 2);
-    for (int i = 0; i < max_bat; i++) {
-        std::vector<uint64_t> rows = EncodeCoeffs(encode_ker_final(max_ker_rs, pos, i, in_wid, max_bat, ker_wid), ECD_LV, c->scale);
-        for (int l = 0; l < 2; l++) HC(c->hc, hc_upload(c->hc, stage + ((size_t)l * max_bat + i) * N, rows.data() + (size_t)l * N, (size_t)N * 8));
-    }
-    for (int l = 0; l < 2; l++) HC(c->hc, hc_ntt(c->hc, l, stage + (size_t)l * max_bat * N, stage + (size_t)l * max_bat * N, max_bat));
-    for (int i = 0; i < max_bat; i++) for (int l = 0; l < 2; l++)
-        HC(c->hc, hc_copy(c->hc, d + ((size_t)i * 2 + l) * N, stage + ((size_t)l * max_bat + i) * N, (size_t)N * 8));
-    HC(c->hc, hc_free(c->hc, stage));
-    KerPlain k; k.max_bat = max_bat; k.Scale = c->scale;
-    HC(c->hc, hc_ker_load_device(c->hc, d, max_bat, &k.h));
-    HC(c->hc, hc_free(c->hc, d));
+    // The whole of conv.go:487-518 runs on the device (hc_prep_ker: reshape_ker, BN scale, max_bat embedding,
+    // encode_ker_final, EncodeCoeffs rounding, ToNTT); reshape_ker/encode_ker_final above remain as the host-side
+    // statement of the layout (used by tests and by anyone who wants to inspect a kernel plaintext).
+    if (trans || pos != 0 || ECD_LV != 1) panic("prep_Ker: only the conv path's (pos=0, trans=false, ECD_LV=1) form is built");
+    KerPlain k; k.max_bat = N / (in_wid * in_wid); k.Scale = c->scale;
+    HC(c->hc, hc_prep_ker(c->hc, ker_in.data(), (int)ker_in.size(), BN_a.data(), in_wid, ker_wid, real_ib, real_ob, norm, c->scale, &k.h));
     return k;
 }
 

@@ -168,3 +168,23 @@ def case_conv_phases(ctx, O, max_ob=4, seed=0xF00D):
     # oracle: same tree through or_conv_then_pack on the same inputs (no bias)
     ref, _ = O.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, O.idx_plaintexts(), evk_all, max_ob, 1, 2.0 ** 30, None)
     eq(got, ref, "pack_ctxts")
+
+
+def case_prep_ker(ctx, O, k=3, i_batch=1, trace=None):
+    """hc_prep_ker (conv.go:487-518 on the device) vs the oracle's prep_Ker restatement and, when a reference trace
+    is given, vs the digests of the reference binary's own pl_ker[i] (events pl_ker_orig)."""
+    import golden.gen_conv_csv as gen
+    from oracle_lib import sha_rows
+    B, W, raw, x, ker, bna, bnb = gen.make_case(k, i_batch, 0)
+    h = ctx.prep_ker(ker.reshape(-1), bna, W, k, B, B)
+    got = ctx.ker_download(h, B)
+    ctx.ker_free(h)
+    kc = O.prep_ker_coeffs(ker.reshape(-1), bna, W, k, B, B)
+    for i in range(B):
+        enc = O.encode_coeffs(kc[i], 2.0 ** 30, [0, 1])
+        eq(got[i, 0], O.ntt(0, enc[0]), f"prep_ker ch{i} Q0")
+        eq(got[i, 1], O.ntt(1, enc[1]), f"prep_ker ch{i} Q1")
+    if trace is not None:
+        for e in trace["events"]:
+            if e["op"] == "pl_ker_orig":
+                assert sha_rows(got[e["i"], 0], got[e["i"], 1]) == e["pt"]["sha256"], f"pl_ker[{e['i']}] vs reference binary"

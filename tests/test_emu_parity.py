@@ -59,3 +59,10 @@ def test_conv_phases(env):
 @pytest.mark.parametrize("max_ob,chunk", [(1, None), (2, None), (4, 1), (8, 3), (16, 32)])
 def test_conv_then_pack(env, max_ob, chunk):
     pc.case_conv(*env, max_ob, chunk=chunk)
+
+
+@pytest.mark.parametrize("k,i_batch", [(3, 0), (5, 1), (7, 2)])
+def test_prep_ker(env, k, i_batch):
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"ref_trace_conv_{k}_{i_batch}.json")
+    pc.case_prep_ker(*env, k=k, i_batch=i_batch, trace=json.load(open(path)) if os.path.exists(path) else None)

@@ -1,0 +1,28 @@
+"""The reference's command line on the GPU: optimal_conv_amd/host/conv (C++ host side over libhconv.so) run as
+`conv k i 1` on synthetic CSVs laid out as test.go:37-40 expects; decrypted precision must reach what the reference
+binary reaches on the same data (MED 25.4 / 23.7 / 19.9 bits at B = 4 / 16 / 256)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import golden.gen_conv_csv as gen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "optimal_conv_amd", "host", "conv")
+
+
+@pytest.mark.parametrize("k,i_batch,min_med", [(3, 0, 23.0), (5, 1, 21.0), (3, 3, 18.0), (7, 3, 17.5)])
+def test_conv_cli(tmp_path, k, i_batch, min_med):
+    assert os.path.exists(CLI), "host CLI not built (__graft_entry__.build)"
+    gen.write_case(str(tmp_path / "test_conv_data"), k, i_batch, 0)
+    out = subprocess.run([CLI, "conv", str(k), str(i_batch), "1"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HCONV_SEED="2024"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    txt = out.stdout
+    print(txt)
+    assert re.search(r"^Ours start\.$", txt, re.M) and re.search(r"^\t Pack time:  \S+$", txt, re.M)
+    med = float(re.search(r"^MED Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M).group(1))
+    assert med >= min_med, txt

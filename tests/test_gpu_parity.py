@@ -138,3 +138,10 @@ def test_end_to_end_decrypts_to_plain_conv(env):
     err = np.abs(out - want)
     prec = -np.log2(np.maximum(err, 2.0 ** -40))
     assert np.median(prec) >= 18, f"median precision {np.median(prec):.1f} bits"
+
+
+@pytest.mark.parametrize("k,i_batch", [(3, 0), (3, 1), (3, 3), (5, 2), (7, 3)])
+def test_prep_ker_on_device(env, k, i_batch):
+    """8f-4: prep_Ker on the GPU, vs the oracle and vs the reference binary's own pl_ker digests where a trace exists"""
+    path = os.path.join(HERE, "golden", f"ref_trace_conv_{k}_{i_batch}.json")
+    pc.case_prep_ker(*env, k=k, i_batch=i_batch, trace=json.load(open(path)) if os.path.exists(path) else None)
