@@ -563,7 +563,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTw
 // ct[i][k] = t1 + perm(d). grid = (16, 2*nodes): job = node*2 + k. Requires the permutation to stay inside
 // 256-blocks (galEl = 2^j+1, j >= 9). F and t1 are fetched up front, so the epilogue issues no loads.
 template <int FM>
-__global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, const u64 *bias) {
+__global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, const u64 *bias) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
     const int job = blockIdx.y, node = job >> 1, k = job & 1, i = (B.n0 + node) * B.norm;
