@@ -255,6 +255,13 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_shoup_companion(const u64 *w, u64
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * HC_TPB)
         ws[i] = hc_shoup_companion(w[i], q);
 }
+// copy rows into the rows-kernel "lo-local coalesced" order (same index map as hc_k_make_pairs below)
+__global__ __launch_bounds__(HC_TPB) void hc_k_lo_local(const u64 *in, u64 *out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * HC_TPB) {
+        const size_t poly = i >> 16; const int R = (int)((i >> 8) & 255), C = (int)(i & 255);
+        out[(poly << 16) + (size_t)(((R >> 4) * 16 + (C & 15)) * 256 + (R & 15) * 16 + (C >> 4))] = in[i];
+    }
+}
 // interleave (w, ws) into HcTw pairs, optionally into the rows-kernel "lo-local coalesced" order:
 //   natural index (R, C = tid*16+lo)  ->  pair slot ((R>>4)*16 + lo) * 256 + (R&15)*16 + tid
 __global__ __launch_bounds__(HC_TPB) void hc_k_make_pairs(const u64 *w, HcTw *out, size_t n, u64 q, int lo_local_order) {
@@ -426,13 +433,15 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_a3(HcLoopA A, HcTwT
 // ================================================================ loop B node (conv.go:288-292), fused
 // Node n of a tree level: y = cts[i], x = cts[i+step], i = n*norm.
 struct HcLoopB {
-    u64 *cts;            // [max_cnum][2][N]
+    const u64 *src;      // [max_cnum][2][N] level-0 ciphertexts this tree level reads (x = src[i+step], y = src[i])
+    u64 *dst;            // [max_cnum][2][N] where it writes node results (slot i); src != dst: the two ping-pong
     u64 *tmpC;           // [chunk][N]      c1 of t2 through iNTT_Q0 / NTT_P
-    u64 *tmpF;           // [chunk][2][N]   F0 = t2.c0*P + b_Q (*) t2.c1 ; F1 = a_Q (*) t2.c1   (mod Q0)
     u64 *tmpE;           // [chunk][2][N]   P-part accumulators through iNTT_P / NTT_Q0
-    const HcTw *idx;     // [N]             idx[s] plaintext, natural order
-    const HcTw *evkQ;    // [2][N]          b_Q, a_Q natural order (plain form + companion)
-    const HcTw *evkP;    // [2][N]          b_P, a_P in lo-local-coalesced order
+    // fixed multiplicands are kept in Montgomery form (w * 2^64 mod q), 8 bytes each: one hc_mont per use gives the
+    // canonical product for ANY 64-bit other operand. (Lattigo stores switching keys exactly like this.)
+    const u64 *idx;      // [N]             idx[s] plaintext, natural order
+    const u64 *evkQ;     // [2][N]          b_Q, a_Q natural order
+    const u64 *evkP;     // [2][N]          b_P, a_P in lo-local-coalesced order
     int n0, step, norm;  // first node of this chunk
     HcMod m0, mp;
     HcTw pmodq;          // P mod Q0
@@ -441,47 +450,25 @@ struct HcLoopB {
     u64 vthresh;         // smallest y with uint64(float64(y)/float64(P)) >= 1 (P if none): the fp64 overflow count as a compare
     u32 gal;             // Galois element of this level
 };
-// KB1: t1/t2, Q-part of the key switch, rows-inverse (mod Q0) of t2.c1. grid = (16, nodes)
-// The pointwise front end works on batches of 4 residues per thread: all 28 loads of a batch are issued before
-// its arithmetic, and the streams are restrict-qualified (x is read-only, y/F are written at the offsets just
-// read) so the next batch's loads are not ordered behind this batch's stores.
-__global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
+// KB1: t2.c1 = y1 - I*x1 and its rows-inverse (mod Q0). grid = (16, nodes). Everything else a node needs from x and y
+// (t1, t2.c0, the Q-part of the key switch) is formed in KB5 straight from src, so nothing but the 1-row key-switch
+// operand leaves this kernel.
+__global__ __launch_bounds__(HC_TPB) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
     const int node = blockIdx.y, i = (B.n0 + node) * B.norm;
     const size_t tile = (size_t)blockIdx.x * 4096 + t;
-    u64 *__restrict__ y = B.cts + (size_t)i * 2 * 65536 + tile;
-    const u64 *__restrict__ x = B.cts + (size_t)(i + B.step) * 2 * 65536 + tile;
-    u64 *__restrict__ F = B.tmpF + (size_t)node * 2 * 65536 + tile;
-    const HcTw *__restrict__ idx = B.idx + tile;
-    const HcTw *__restrict__ evk = B.evkQ + tile;
-    const u64 q = B.m0.q;
-    u64 e[16];
+    const u64 *__restrict__ y1 = B.src + ((size_t)i * 2 + 1) * 65536 + tile;
+    const u64 *__restrict__ x1 = B.src + ((size_t)(i + B.step) * 2 + 1) * 65536 + tile;
+    const u64 *__restrict__ idx = B.idx + tile;
+    const u64 q = B.m0.q, qinv = B.m0.qinv;
+    u64 e[16], yy[16], I[16];
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        u64 x1[4], y1[4], x0[4], y0[4]; HcTw I[4], bq[4], aq[4];
+    for (int kk = 0; kk < 16; kk++) { e[kk] = x1[kk * 256]; yy[kk] = y1[kk * 256]; }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int o = (b * 4 + j) * 256;
-            x1[j] = x[65536 + o]; y1[j] = y[65536 + o]; I[j] = idx[o]; bq[j] = evk[o]; aq[j] = evk[65536 + o];
-            x0[j] = x[o]; y0[j] = y[o];
-        }
+    for (int kk = 0; kk < 16; kk++) I[kk] = idx[kk * 256];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int o = (b * 4 + j) * 256;
-            // polynomial 1 first: its t2 feeds the key switch
-            const u64 m1 = hc_mul_shoup(x1[j], I[j].w, I[j].ws, q);
-            const u64 t2c1 = hc_submod(y1[j], m1, q);
-            y[65536 + o] = hc_addmod(y1[j], m1, q);                           // t1.c1 (conv.go:290)
-            F[65536 + o] = hc_mul_shoup(t2c1, aq[j].w, aq[j].ws, q);
-            const u64 G = hc_mul_shoup(t2c1, bq[j].w, bq[j].ws, q);
-            const u64 m0 = hc_mul_shoup(x0[j], I[j].w, I[j].ws, q);
-            const u64 t2c0 = hc_submod(y0[j], m0, q);
-            y[o] = hc_addmod(y0[j], m0, q);                                    // t1.c0
-            F[o] = hc_addmod(hc_mul_shoup(t2c0, B.pmodq.w, B.pmodq.ws, q), G, q);
-            e[b * 4 + j] = t2c1;
-        }
-    }
+    for (int kk = 0; kk < 16; kk++) e[kk] = hc_submod(yy[kk], hc_mont(e[kk], I[kk], q, qinv), q);   // t2.c1 (conv.go:288-289)
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     __syncthreads();
     hc_rows_inv(e, lds, T0inv, row, rloc, tid, q);
@@ -520,12 +507,9 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b3(HcLoopB B, HcTwT
     hc_rows_fwd<FMP>(cp, lds, TPfwd, row, rloc, tid, q);
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const HcTw *ev = B.evkP + (size_t)k * 65536 + (size_t)blockIdx.x * 4096 + t;
+        const u64 *__restrict__ ev = B.evkP + (size_t)k * 65536 + (size_t)blockIdx.x * 4096 + t;
 #pragma unroll
-        for (int lo = 0; lo < 16; lo++) {
-            const HcTw w = ev[lo * 256];
-            e[lo] = hc_mul_shoup_lazy(cp[lo], w.w, w.ws, q);
-        }
+        for (int lo = 0; lo < 16; lo++) e[lo] = hc_mont(cp[lo], ev[lo * 256], q, B.mp.qinv);
         __syncthreads();
         hc_rows_inv(e, lds, TPinv, row, rloc, tid, q);
         u64 *o = B.tmpE + ((size_t)node * 2 + k) * 65536 + (size_t)row * 256;
@@ -559,9 +543,13 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTw
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
 }
-// KB5: rows-forward mod Q0 of one extension, d = (F - n) * P^-1, row-local Galois permutation through LDS,
-// ct[i][k] = t1 + perm(d). grid = (16, 2*nodes): job = node*2 + k. Requires the permutation to stay inside
-// 256-blocks (galEl = 2^j+1, j >= 9). F and t1 are fetched up front, so the epilogue issues no loads.
+// KB5: one job per (node, polynomial k): grid = (16, 2*nodes), job = node*2 + k.
+//   front end (linear layout, straight from src):  m_k = I*x_k ; t1_k = y_k + m_k ; t2.c_k = y_k - m_k ;
+//        F_1 = a_Q * t2.c1                      (k = 1)
+//        F_0 = t2.c0 * P + b_Q * t2.c1          (k = 0; also needs x_1, y_1)
+//   rows-forward mod Q0 of the k-th extension n_k ; d_k = (F_k - n_k) * P^-1 = [k==0] t2.c0 + (key switch)_k ;
+//   row-local Galois permutation through LDS ; dst[i][k] = t1_k + perm(d_k) (+ bias on k = 0 of the last node).
+// Requires the permutation to stay inside 256-blocks (galEl = 2^j+1, j >= 9).
 template <int FM>
 __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, const u64 *bias) {
     __shared__ u64 lds[HC_ROWS_LDS];
@@ -570,13 +558,44 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, c
     const u64 q = B.m0.q;
     const size_t tile = (size_t)blockIdx.x * 4096 + t;
     const u64 *__restrict__ in = B.tmpE + (size_t)job * 65536 + (size_t)row * 256;
-    const u64 *__restrict__ F = B.tmpF + (size_t)job * 65536 + tile;
-    u64 *__restrict__ y = B.cts + ((size_t)i * 2 + k) * 65536 + tile;
-    u64 e[16], f[16];
+    const u64 *__restrict__ yk = B.src + ((size_t)i * 2 + k) * 65536 + tile;
+    const u64 *__restrict__ xk = B.src + ((size_t)(i + B.step) * 2 + k) * 65536 + tile;
+    const u64 *__restrict__ y1 = B.src + ((size_t)i * 2 + 1) * 65536 + tile;
+    const u64 *__restrict__ x1 = B.src + ((size_t)(i + B.step) * 2 + 1) * 65536 + tile;
+    const u64 *__restrict__ idx = B.idx + tile;
+    const u64 *__restrict__ evk = B.evkQ + (size_t)k * 65536 + tile;      // b_Q for k = 0, a_Q for k = 1
+    const u64 qinv = B.m0.qinv;
+    u64 *__restrict__ o = B.dst + ((size_t)i * 2 + k) * 65536 + tile;
+    u64 e[16], f[16], t1[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) f[kk] = F[kk * 256];
+    for (int b = 0; b < 4; b++) {               // batches of 4 residues: all loads of a batch before its arithmetic
+        u64 X[4], Y[4], X1[4], Y1[4], I[4], K[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int off = (b * 4 + j) * 256;
+            X[j] = xk[off]; Y[j] = yk[off]; I[j] = idx[off]; K[j] = evk[off];
+            if (k == 0) { X1[j] = x1[off]; Y1[j] = y1[off]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int kk = b * 4 + j;
+            const u64 m = hc_mont(X[j], I[j], q, qinv);
+            const u64 t2 = hc_submod(Y[j], m, q);
+            t1[kk] = hc_addmod(Y[j], m, q);                                                   // conv.go:290
+            if (k == 0) {
+                const u64 t2c1 = hc_submod(Y1[j], hc_mont(X1[j], I[j], q, qinv), q);
+                f[kk] = hc_addmod(hc_mul_shoup(t2, B.pmodq.w, B.pmodq.ws, q), hc_mont(t2c1, K[j], q, qinv), q);
+            } else {
+                f[kk] = hc_mont(t2, K[j], q, qinv);
+            }
+        }
+    }
+    if (bias != nullptr && k == 0) {
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) t1[kk] = hc_addmod(t1[kk], bias[tile + kk * 256], q);
+    }
     hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, q);
     __syncthreads();
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
@@ -585,22 +604,14 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, c
         u64 n = hc_fwd_canon<FM>(e[kk], q, B.m0.mu);
         e[kk] = hc_mul_shoup(hc_submod(f[kk], n, q), B.pinv.w, B.pinv.ws, q);
     }
-    // t1 (and the bias row) are fetched only now: f is dead, so the register footprint stays at two tiles
-    asm volatile("" ::: "memory");     // keep the compiler from hoisting these loads above the transform
-#pragma unroll
-    for (int kk = 0; kk < 16; kk++) f[kk] = y[kk * 256];
-    if (bias != nullptr && k == 0) {
-#pragma unroll
-        for (int kk = 0; kk < 16; kk++) f[kk] = hc_addmod(f[kk], bias[tile + kk * 256], q);
-    }
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) lds[hc_rows_lds(kk, t)] = e[kk];
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
-        const u32 dst = (u32)((blockIdx.x * 16 + kk) * 256 + t);
-        const u32 src = hc_perm_src(dst, B.gal);
-        y[kk * 256] = hc_addmod(f[kk], lds[hc_rows_lds(kk, (int)(src & 255))], q);
+        const u32 dstidx = (u32)((blockIdx.x * 16 + kk) * 256 + t);
+        const u32 srcidx = hc_perm_src(dstidx, B.gal);
+        o[kk * 256] = hc_addmod(t1[kk], lds[hc_rows_lds(kk, (int)(srcidx & 255))], q);
     }
 }

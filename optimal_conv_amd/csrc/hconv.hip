@@ -65,7 +65,7 @@ struct HcModHost {
     HcTwTab fwd, inv;            // device tables
     std::vector<void *> allocs;
 };
-struct HcEvk { HcTw *q_pairs; HcTw *p_pairs; bool row_local; };   // [2][N] each
+struct HcEvk { u64 *q_rows; u64 *p_rows; bool row_local; };   // [2][N] each, Montgomery form; p_rows in lo-local order
 struct HcProfRec { std::string name; hipEvent_t a, b; };
 
 struct hc_ctx {
@@ -73,9 +73,10 @@ struct hc_ctx {
     hipStream_t stream = nullptr;
     std::vector<HcModHost> mods;
     std::map<u64, HcEvk> evk;
-    HcTw *idx_pairs = nullptr;   // [logN][N]
+    u64 *idx_pairs = nullptr;    // [logN][N] idx plaintexts, Montgomery form
     // workspace
-    u64 *ws_cts = nullptr; size_t ws_cts_rows = 0;
+    u64 *ws_cts = nullptr; size_t ws_cts_rows = 0;     // loop A output / tree ping
+    u64 *ws_cts2 = nullptr; size_t ws_cts2_rows = 0;   // tree pong
     u64 *ws_ctc = nullptr;
     u64 *ws_tmp = nullptr; size_t ws_tmp_rows = 0;
     long chunk_nodes = 32;
@@ -213,9 +214,10 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto &mh : c->mods) for (void *d : mh.allocs) hipFree(d);
-    for (auto &kv : c->evk) { hipFree(kv.second.q_pairs); hipFree(kv.second.p_pairs); }
+    for (auto &kv : c->evk) { hipFree(kv.second.q_rows); hipFree(kv.second.p_rows); }
     if (c->idx_pairs) hipFree(c->idx_pairs);
     if (c->ws_cts) hipFree(c->ws_cts);
+    if (c->ws_cts2) hipFree(c->ws_cts2);
     if (c->ws_ctc) hipFree(c->ws_ctc);
     if (c->ws_tmp) hipFree(c->ws_tmp);
     if (c->t0) hipEventDestroy(c->t0);
@@ -381,14 +383,6 @@ extern "C" int hc_div_round_last(hc_ctx *c, int level, const uint64_t *x, uint64
 }
 
 // ------------------------------------------------------------------ evk / idx / ker loading
-static int hc_make_pairs(hc_ctx *c, const u64 *d_rows, int rows, u64 q, bool lo_local, HcTw **out) {
-    HcTw *d = nullptr;
-    HC_HIP(c, hipMalloc((void **)&d, (size_t)rows * HC_N * sizeof(HcTw)));
-    int rc = hc_launch(c, "make_pairs", hc_k_make_pairs, hc_pw_grid((size_t)rows * HC_N), d_rows, d, (size_t)rows * HC_N, q, lo_local ? 1 : 0);
-    if (rc) { hipFree(d); return rc; }
-    *out = d;
-    return HC_OK;
-}
 static bool hc_perm_row_local(u64 galEl) {
     // ring.PermuteNTTIndex stays inside 256-element blocks iff it fixes the top 8 bits of the destination index
     for (u32 i = 0; i < HC_N; i += 97) {
@@ -406,21 +400,23 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
     if (!b_q || !a_q || !b_p || !a_p || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_evk_load: bad arguments");
     if (c->np != 1) return hc_fail(c, HC_ERR_UNSUPPORTED, "hc_evk_load: level-0 key switching with one special prime (the pack evaluator of main.go:446-456) is what is implemented; np=%d", c->np);
     const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
-    u64 *stage = nullptr; HC_HIP(c, hipMalloc((void **)&stage, 4 * HC_N * sizeof(u64)));
-    const uint64_t *src[4] = {b_q, a_q, b_p, a_p};
-    for (int k = 0; k < 4; k++) HC_HIP(c, hipMemcpyAsync(stage + (size_t)k * HC_N, src[k], HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    // stored form is Montgomery: bring to plain residues, then attach Shoup companions
-    HcTw z; z.w = z.ws = 0;
-    int rc = hc_launch(c, "evk_from_mont", hc_k_pointwise<HC_PW_FROM_MONT>, hc_pw_grid(2 * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)2 * HC_N, m0.m, z);
-    if (!rc) rc = hc_launch(c, "evk_from_mont", hc_k_pointwise<HC_PW_FROM_MONT>, hc_pw_grid(2 * HC_N), (const u64 *)(stage + 2 * HC_N), (const u64 *)(stage + 2 * HC_N), stage + 2 * HC_N, (size_t)2 * HC_N, mp.m, z);
-    HcEvk e; e.q_pairs = e.p_pairs = nullptr; e.row_local = hc_perm_row_local(galEl);
-    if (!rc) rc = hc_make_pairs(c, stage, 2, m0.m.q, false, &e.q_pairs);
-    if (!rc) rc = hc_make_pairs(c, stage + 2 * HC_N, 2, mp.m.q, true, &e.p_pairs);
+    // Lattigo's stored form IS the Montgomery form the kernels multiply with: the Q rows are kept as they come,
+    // the P rows are only re-ordered into the lo-local coalesced order hc_k_b3 reads.
+    u64 *stage = nullptr; HC_HIP(c, hipMalloc((void **)&stage, 2 * HC_N * sizeof(u64)));
+    HcEvk e; e.q_rows = e.p_rows = nullptr; e.row_local = hc_perm_row_local(galEl);
+    HC_HIP(c, hipMalloc((void **)&e.q_rows, 2 * HC_N * sizeof(u64)));
+    HC_HIP(c, hipMalloc((void **)&e.p_rows, 2 * HC_N * sizeof(u64)));
+    HC_HIP(c, hipMemcpyAsync(e.q_rows, b_q, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hipMemcpyAsync(e.q_rows + HC_N, a_q, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hipMemcpyAsync(stage, b_p, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hipMemcpyAsync(stage + HC_N, a_p, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    int rc = hc_launch(c, "evk_lo_local", hc_k_lo_local, hc_pw_grid(2 * HC_N), (const u64 *)stage, e.p_rows, (size_t)2 * HC_N);
     hipStreamSynchronize(c->stream);
     hipFree(stage);
-    if (rc) { if (e.q_pairs) hipFree(e.q_pairs); if (e.p_pairs) hipFree(e.p_pairs); return rc; }
+    (void)m0; (void)mp;
+    if (rc) { hipFree(e.q_rows); hipFree(e.p_rows); return rc; }
     auto it = c->evk.find(galEl);
-    if (it != c->evk.end()) { hipFree(it->second.q_pairs); hipFree(it->second.p_pairs); }
+    if (it != c->evk.end()) { hipFree(it->second.q_rows); hipFree(it->second.p_rows); }
     c->evk[galEl] = e;
     return HC_OK;
 }
@@ -442,12 +438,12 @@ extern "C" int hc_idx_load(hc_ctx *c, const uint64_t *idx_host) {
         if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "rows_fwd_canon", hc_k_rows_fwd_canon, dim3(16, HC_LOGN), (const u64 *)tmp, stage, m0.fwd, m0.m.q, m0.m.mu);
         hipStreamSynchronize(c->stream); hipFree(tmp);
     }
-    HcTw *pairs = nullptr;
-    if (!rc) rc = hc_make_pairs(c, stage, HC_LOGN, m0.m.q, false, &pairs);
-    hipStreamSynchronize(c->stream); hipFree(stage);
-    if (rc) return rc;
+    HcTw z; z.w = z.ws = 0;
+    if (!rc) rc = hc_launch(c, "idx_to_mont", hc_k_pointwise<HC_PW_TO_MONT>, hc_pw_grid((size_t)HC_LOGN * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)HC_LOGN * HC_N, m0.m, z);
+    hipStreamSynchronize(c->stream);
+    if (rc) { hipFree(stage); return rc; }
     if (c->idx_pairs) hipFree(c->idx_pairs);
-    c->idx_pairs = pairs;
+    c->idx_pairs = stage;
     return HC_OK;
 }
 
@@ -522,12 +518,12 @@ extern "C" int hc_ker_download(hc_ctx *c, const hc_ker *k, uint64_t *host_out) {
 extern "C" void hc_ker_free(hc_ctx *c, hc_ker *k) { if (!k) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } hipFree(k->d); delete k; }
 
 // ------------------------------------------------------------------ loop B plumbing
-static int hc_fill_loopB(hc_ctx *c, HcLoopB *B, u64 *cts, const HcEvk &e, int logStep, int step, int norm, u64 galEl, int chunk) {
+static int hc_fill_loopB(hc_ctx *c, HcLoopB *B, const u64 *src, u64 *dst, const HcEvk &e, int logStep, int step, int norm, u64 galEl, int chunk) {
     const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
-    B->cts = cts;
-    B->tmpC = c->ws_tmp; B->tmpF = c->ws_tmp + (size_t)chunk * HC_N; B->tmpE = c->ws_tmp + (size_t)chunk * 3 * HC_N;
+    B->src = src; B->dst = dst;
+    B->tmpC = c->ws_tmp; B->tmpE = c->ws_tmp + (size_t)chunk * HC_N;
     B->idx = c->idx_pairs + (size_t)logStep * HC_N;
-    B->evkQ = e.q_pairs; B->evkP = e.p_pairs;
+    B->evkQ = e.q_rows; B->evkP = e.p_rows;
     B->n0 = 0; B->step = step; B->norm = norm;
     B->m0 = m0.m; B->mp = mp.m;
     B->pmodq = h_pair(mp.m.q % m0.m.q, m0.m.q);
@@ -543,15 +539,15 @@ static int hc_fill_loopB(hc_ctx *c, HcLoopB *B, u64 *cts, const HcEvk &e, int lo
     return HC_OK;
 }
 // one tree level: nodes i = 0, norm, 2*norm, ... < step
-static int hc_pack_level(hc_ctx *c, u64 *cts, int step, int logStep, int norm, u64 galEl, const u64 *bias_last) {
+static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, int step, int logStep, int norm, u64 galEl, const u64 *bias_last) {
     auto it = c->evk.find(galEl);
     if (it == c->evk.end()) return hc_fail(c, HC_ERR_STATE, "pack: no switching key loaded for galEl=%llu (the reference panics in permuteNTT)", (unsigned long long)galEl);
     if (!it->second.row_local) return hc_fail(c, HC_ERR_UNSUPPORTED, "pack: galEl=%llu does not permute inside 256-blocks (needs max_cnum <= 256)", (unsigned long long)galEl);
     if (!c->idx_pairs) HC_TRY(hc_idx_load(c, nullptr));
     const int nodes = (step + norm - 1) / norm;
     const int chunk = (int)(c->chunk_nodes < nodes ? (c->chunk_nodes < 1 ? 1 : c->chunk_nodes) : nodes);
-    HC_TRY(hc_ensure_tmp(c, (size_t)chunk * 5));
-    HcLoopB B; HC_TRY(hc_fill_loopB(c, &B, cts, it->second, logStep, step, norm, galEl, chunk));
+    HC_TRY(hc_ensure_tmp(c, (size_t)chunk * 3));
+    HcLoopB B; HC_TRY(hc_fill_loopB(c, &B, src, dst, it->second, logStep, step, norm, galEl, chunk));
     const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
     for (int n0 = 0; n0 < nodes; n0 += chunk) {
         const int nn = (nodes - n0) < chunk ? (nodes - n0) : chunk;
@@ -573,13 +569,26 @@ static int hc_pack_run(hc_ctx *c, u64 *cts, int max_cnum, int real_cnum, const u
     for (int i = step; i > 1; i /= 2) logStep++;
     if (stride_log2 < 0 || logStep + stride_log2 >= HC_LOGN) return hc_fail(c, HC_ERR_ARG, "pack: stride_log2=%d out of range", stride_log2);
     int j = HC_LOGN - logStep - stride_log2;      // slot m stands for global ciphertext index m << stride_log2
+    // Tree levels ping-pong between the caller's array and an internal one: a level reads slots i and i+step of
+    // `src` and writes slot i of `dst` (i < step), so no kernel ever reads a row another workgroup is writing.
+    const size_t pong_rows = (size_t)(max_cnum / 2 > 0 ? max_cnum / 2 : 1) * 2;
+    if (c->ws_cts2_rows < pong_rows) {
+        HC_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->ws_cts2) HC_HIP(c, hipFree(c->ws_cts2));
+        c->ws_cts2 = nullptr; c->ws_cts2_rows = 0;
+        HC_HIP(c, hipMalloc((void **)&c->ws_cts2, pong_rows * HC_N * sizeof(u64)));
+        c->ws_cts2_rows = pong_rows;
+    }
+    u64 *src = cts, *dst = c->ws_cts2;
     bool bias_done = false;
     while (step >= norm && step >= 1) {
         const bool last = (step / 2 < norm) || step == 1;
-        HC_TRY(hc_pack_level(c, cts, step, logStep + stride_log2, norm, (1ull << j) + 1, last ? bias : nullptr));
+        HC_TRY(hc_pack_level(c, src, dst, step, logStep + stride_log2, norm, (1ull << j) + 1, last ? bias : nullptr));
         if (last) bias_done = true;
+        u64 *t = src; src = dst; dst = t;
         step /= 2; logStep--; j++;
     }
+    if (src != cts) HC_HIP(c, hipMemcpyAsync(cts, src, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));   // result -> slot 0
     if (bias && !bias_done) {   // max_cnum == real_cnum == 1: no tree level ran
         HcTw z; z.w = z.ws = 0;
         HC_TRY(hc_launch(c, "bias_add", hc_k_pointwise<HC_PW_ADD>, hc_pw_grid(HC_N), (const u64 *)cts, bias, cts, (size_t)HC_N, c->mods[0].m, z));
@@ -604,30 +613,28 @@ static int hc_ks_common(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uin
     auto it = c->evk.find(galEl);
     if (it == c->evk.end()) return hc_fail(c, HC_ERR_STATE, "no switching key loaded for galEl=%llu", (unsigned long long)galEl);
     u64 *buf = nullptr; HC_HIP(c, hipMalloc((void **)&buf, (size_t)6 * HC_N * sizeof(u64)));
-    u64 *y = buf, *x = buf + 2 * HC_N, *keep = buf + 4 * HC_N;
+    u64 *y = buf, *x = buf + 2 * HC_N, *res = buf + 4 * HC_N;
     int rc = HC_OK;
     hipMemsetAsync(x, 0, 2 * HC_N * sizeof(u64), c->stream);
     if (c0) hipMemcpyAsync(y, c0, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); else hipMemsetAsync(y, 0, HC_N * sizeof(u64), c->stream);
     hipMemcpyAsync(y + HC_N, c1, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream);
-    hipMemcpyAsync(keep, y, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream);
     if (!c->idx_pairs) rc = hc_idx_load(c, nullptr);
     const bool local = it->second.row_local;
-    u64 g_used = galEl;
     if (!rc) {
         if (rotate && local) {
-            // slots: y at 0, x at 1 => step = 1 in a 2-slot array, idx row irrelevant because x = 0
+            // slots: y at 0, x = 0 at 1 => one node with step = 1; the idx row is irrelevant because x = 0
             const int chunk = 1;
-            rc = hc_ensure_tmp(c, 5);
-            HcLoopB B; if (!rc) rc = hc_fill_loopB(c, &B, y, it->second, 0, 1, 1, g_used, chunk);
+            rc = hc_ensure_tmp(c, 3);
+            HcLoopB B; if (!rc) rc = hc_fill_loopB(c, &B, y, res, it->second, 0, 1, 1, galEl, chunk);
             const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
             if (!rc) rc = hc_launch(c, "b1_node_rowsinv", hc_k_b1, dim3(16, 1), B, m0.inv);
             if (!rc) rc = HC_LAUNCH_FM(mp.m.q, c, "b2_colsinv_colsfwdP", hc_k_b2, dim3(16, 1), B, m0.inv, mp.fwd);
             if (!rc) rc = HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, dim3(16, 1), B, mp.fwd, mp.inv);
             if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, dim3(16, 2), B, mp.inv, m0.fwd);
             if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, 2), B, m0.fwd, (const u64 *)nullptr);
-            HcTw z; z.w = z.ws = 0;
-            if (!rc) rc = hc_launch(c, "ks_sub", hc_k_pointwise<HC_PW_SUB>, hc_pw_grid(2 * HC_N), (const u64 *)y, (const u64 *)keep, y, (size_t)2 * HC_N, c->mods[0].m, z);
-            if (!rc) { hipMemcpyAsync(o0, y, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); hipMemcpyAsync(o1, y + HC_N, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); }
+            HcTw z; z.w = z.ws = 0;      // node result = y + RotateGal(y): subtract y again
+            if (!rc) rc = hc_launch(c, "ks_sub", hc_k_pointwise<HC_PW_SUB>, hc_pw_grid(2 * HC_N), (const u64 *)res, (const u64 *)y, res, (size_t)2 * HC_N, c->mods[0].m, z);
+            if (!rc) { hipMemcpyAsync(o0, res, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); hipMemcpyAsync(o1, res + HC_N, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); }
         } else {
             rc = hc_fail(c, HC_ERR_UNSUPPORTED, "level-0 key switch is exposed for Galois elements that permute inside 256-blocks (2^j+1, j>=9), the ones pack_ctxts uses");
         }
