@@ -441,7 +441,9 @@ struct HcLoopB {
     // canonical product for ANY 64-bit other operand. (Lattigo stores switching keys exactly like this.)
     const u64 *idx;      // [N]             idx[s] plaintext, natural order
     const u64 *evkQ;     // [2][N]          b_Q, a_Q natural order
-    const u64 *evkP;     // [2][N]          b_P, a_P in lo-local-coalesced order
+    const HcTw *evkP;    // [2][N]          b_P, a_P as Shoup pairs in lo-local-coalesced order (hc_k_b3 multiplies
+                         //                 lazy transform outputs inside a register-tight kernel: measured faster than
+                         //                 the Montgomery form there)
     int n0, step, norm;  // first node of this chunk
     HcMod m0, mp;
     HcTw pmodq;          // P mod Q0
@@ -507,9 +509,12 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b3(HcLoopB B, HcTwT
     hc_rows_fwd<FMP>(cp, lds, TPfwd, row, rloc, tid, q);
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const u64 *__restrict__ ev = B.evkP + (size_t)k * 65536 + (size_t)blockIdx.x * 4096 + t;
+        const HcTw *__restrict__ ev = B.evkP + (size_t)k * 65536 + (size_t)blockIdx.x * 4096 + t;
 #pragma unroll
-        for (int lo = 0; lo < 16; lo++) e[lo] = hc_mont(cp[lo], ev[lo * 256], q, B.mp.qinv);
+        for (int lo = 0; lo < 16; lo++) {
+            const HcTw w = ev[lo * 256];
+            e[lo] = hc_mul_shoup_lazy(cp[lo], w.w, w.ws, q);
+        }
         __syncthreads();
         hc_rows_inv(e, lds, TPinv, row, rloc, tid, q);
         u64 *o = B.tmpE + ((size_t)node * 2 + k) * 65536 + (size_t)row * 256;

@@ -65,7 +65,7 @@ struct HcModHost {
     HcTwTab fwd, inv;            // device tables
     std::vector<void *> allocs;
 };
-struct HcEvk { u64 *q_rows; u64 *p_rows; bool row_local; };   // [2][N] each, Montgomery form; p_rows in lo-local order
+struct HcEvk { u64 *q_rows; HcTw *p_rows; bool row_local; };   // [2][N] each: q_rows Montgomery form; p_rows Shoup pairs, lo-local order
 struct HcProfRec { std::string name; hipEvent_t a, b; };
 
 struct hc_ctx {
@@ -403,17 +403,19 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
     // Lattigo's stored form IS the Montgomery form the kernels multiply with: the Q rows are kept as they come,
     // the P rows are only re-ordered into the lo-local coalesced order hc_k_b3 reads.
     u64 *stage = nullptr; HC_HIP(c, hipMalloc((void **)&stage, 2 * HC_N * sizeof(u64)));
-    HcEvk e; e.q_rows = e.p_rows = nullptr; e.row_local = hc_perm_row_local(galEl);
+    HcEvk e; e.q_rows = nullptr; e.p_rows = nullptr; e.row_local = hc_perm_row_local(galEl);
     HC_HIP(c, hipMalloc((void **)&e.q_rows, 2 * HC_N * sizeof(u64)));
-    HC_HIP(c, hipMalloc((void **)&e.p_rows, 2 * HC_N * sizeof(u64)));
+    HC_HIP(c, hipMalloc((void **)&e.p_rows, 2 * HC_N * sizeof(HcTw)));
     HC_HIP(c, hipMemcpyAsync(e.q_rows, b_q, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     HC_HIP(c, hipMemcpyAsync(e.q_rows + HC_N, a_q, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     HC_HIP(c, hipMemcpyAsync(stage, b_p, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     HC_HIP(c, hipMemcpyAsync(stage + HC_N, a_p, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    int rc = hc_launch(c, "evk_lo_local", hc_k_lo_local, hc_pw_grid(2 * HC_N), (const u64 *)stage, e.p_rows, (size_t)2 * HC_N);
+    HcTw z; z.w = z.ws = 0;     // P rows: stored Montgomery form -> plain residues -> (w, floor(w*2^64/P)) pairs in lo-local order
+    int rc = hc_launch(c, "evk_from_mont", hc_k_pointwise<HC_PW_FROM_MONT>, hc_pw_grid(2 * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)2 * HC_N, mp.m, z);
+    if (!rc) rc = hc_launch(c, "make_pairs", hc_k_make_pairs, hc_pw_grid(2 * HC_N), (const u64 *)stage, e.p_rows, (size_t)2 * HC_N, mp.m.q, 1);
     hipStreamSynchronize(c->stream);
     hipFree(stage);
-    (void)m0; (void)mp;
+    (void)m0;
     if (rc) { hipFree(e.q_rows); hipFree(e.p_rows); return rc; }
     auto it = c->evk.find(galEl);
     if (it != c->evk.end()) { hipFree(it->second.q_rows); hipFree(it->second.p_rows); }

@@ -59,7 +59,7 @@ def test_conv_phases(env):
     pc.case_conv_phases(*env, max_ob=8)
 
 
-@pytest.mark.parametrize("max_ob,chunk", [(1, 32), (2, 32), (4, 1), (16, 5), (64, 32), (256, 32), (256, 7)])
+@pytest.mark.parametrize("max_ob,chunk", [(1, 32), (2, 32), (4, 1), (16, 5), (64, 32), (256, 64), (256, 7), (256, 256)])
 def test_conv_then_pack_vs_oracle(env, max_ob, chunk):
     pc.case_conv(*env, max_ob, chunk=chunk)
 
