@@ -145,3 +145,30 @@ def test_prep_ker_on_device(env, k, i_batch):
     """8f-4: prep_Ker on the GPU, vs the oracle and vs the reference binary's own pl_ker digests where a trace exists"""
     path = os.path.join(HERE, "golden", f"ref_trace_conv_{k}_{i_batch}.json")
     pc.case_prep_ker(*env, k=k, i_batch=i_batch, trace=json.load(open(path)) if os.path.exists(path) else None)
+
+
+def test_sharded_path_world1_on_gpu(env):
+    """optimal_conv_amd/sharded.py with torch CUDA tensors handed to the ABI and an RCCL process group of one rank
+    (the multi-rank logic is covered by the gloo tests on CPU; this checks the GPU plumbing: torch storage as device
+    pointers, stream hand-over around the collective)."""
+    import torch
+    import torch.distributed as dist
+    from optimal_conv_amd.sharded import conv_then_pack_sharded
+    ctx, O = env
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B, seed = 8, 0x77
+        ct_in, ker = pc.planted_conv_inputs(seed, B)
+        evk_all = pc.load_tree_keys(ctx, seed, B)
+        ctx.idx_load(None)
+        from oracle_lib import splitmix_rows
+        bias = splitmix_rows(seed + 5, Q0, pc.N)
+        kh = ctx.ker_load(ker)
+        res, sc = conv_then_pack_sharded(ctx, ctx.buf(ct_in), 2.0 ** 30, kh, 2.0 ** 30, B, 2.0 ** 30, ctx.buf(bias), device="cuda:0")
+        want, wsc = O.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, O.idx_plaintexts(), evk_all, B, 1, 2.0 ** 30, bias)
+        pc.eq(res.cpu().numpy().view(np.uint64).reshape(2, pc.N), want, "sharded (world 1, RCCL)")
+        assert sc == wsc
+    finally:
+        dist.destroy_process_group()
