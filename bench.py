@@ -88,14 +88,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    # HC_BENCH_BACKEND=gloo + fewer devices than ranks is the single-GPU dry run of the N>1 path (ranks share GPU 0);
+    # the real runs are one rank per GPU over RCCL.
+    backend = os.environ.get("HC_BENCH_BACKEND", "nccl" if ndev else "gloo")
+    device = local_rank if (ndev == 0 or local_rank < ndev or backend == "nccl") else local_rank % ndev
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(device)
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank) if backend == "nccl" else None)
+                                device_id=torch.device("cuda", device) if backend == "nccl" else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from optimal_conv_amd import Context
@@ -114,7 +118,7 @@ def main():
     bias = synth_rows(rng, Q0, N)
     lanes = []                      # one lane = one context/stream with its own resident ciphertext, keys and kernel plaintexts
     for s_ in range(S):
-        ctx = Context([Q0, Q1], [P0], device=local_rank)        # raises if no GPU / no libhconv.so
+        ctx = Context([Q0, Q1], [P0], device=device)            # raises if no GPU / no libhconv.so
         ctx.set_option("chunk_nodes", args.chunk)
         for gal, k4 in keys:
             ctx.evk_load(gal, k4)
@@ -150,7 +154,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}" if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 

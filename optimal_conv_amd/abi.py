@@ -70,6 +70,16 @@ def load(path=None):
     path = path or DEFAULT_LIB
     if path in _libs:
         return _libs[path]
+    if path == DEFAULT_LIB and "HCONV_NO_TORCH_PRELOAD" not in os.environ:
+        # PyTorch-ROCm wheels bundle their own libamdhip64. Two HIP runtimes in one process cannot both own the GPU:
+        # whichever initialises second sees "No HIP GPUs". Loading torch's runtime first makes libhconv.so's
+        # libamdhip64.so.7 dependency resolve to the already-loaded one, so torch.distributed (bench.py, sharded.py)
+        # and libhconv share a single runtime. Best effort: hosts without torch (the C++ CLI, cgo) are unaffected.
+        try:
+            import torch
+            torch.cuda.is_available()
+        except Exception:
+            pass
     if not os.path.exists(path):
         raise HconvError(f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
                          "optimal_conv_amd has no CPU fallback.")
