@@ -326,6 +326,14 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ker_interleave(const u64 *stage, 
         dst[id] = to_mont ? hc_mont(x, m.r2, m.q, m.qinv) : x;
     }
 }
+// [i][limb][N] plain NTT rows -> Montgomery form, same layout (hc_ker_load); in == out allowed
+__global__ __launch_bounds__(HC_TPB) void hc_k_ker_to_mont(const u64 *in, u64 *out, int max_bat, HcMod m0, HcMod m1) {
+    const size_t n = (size_t)max_bat * 2 * 65536;
+    for (size_t id = (size_t)blockIdx.x * HC_TPB + threadIdx.x; id < n; id += (size_t)gridDim.x * HC_TPB) {
+        const HcMod m = ((id >> 16) & 1) ? m1 : m0;
+        out[id] = hc_mont(in[id], m.r2, m.q, m.qinv);
+    }
+}
 // inverse of the above for inspection: dst_plain[i][limb][N] = from Montgomery form
 __global__ __launch_bounds__(HC_TPB) void hc_k_ker_from_mont(const u64 *ker, u64 *dst, int max_bat, HcMod m0, HcMod m1) {
     const size_t n = (size_t)max_bat * 2 * 65536;

@@ -450,16 +450,12 @@ extern "C" int hc_idx_load(hc_ctx *c, const uint64_t *idx_host) {
 }
 
 static int hc_ker_from_device(hc_ctx *c, u64 *d, int max_ob, bool take, hc_ker **out) {
-    // to Montgomery form, limb by limb: rows alternate Q0, Q1
+    // to Montgomery form in one launch; rows alternate Q0, Q1 ([i][limb][N] both in and out)
     u64 *dst = d;
     if (!take) { HC_HIP(c, hipMalloc((void **)&dst, (size_t)max_ob * 2 * HC_N * sizeof(u64))); }
-    HcTw z; z.w = z.ws = 0;
-    for (int i = 0; i < max_ob; i++) for (int l = 0; l < 2; l++) {
-        size_t off = ((size_t)i * 2 + (size_t)l) * HC_N;
-        int rc = hc_launch(c, "ker_to_mont", hc_k_pointwise<HC_PW_TO_MONT>, hc_pw_grid(HC_N), (const u64 *)(d + off), (const u64 *)(d + off), dst + off, (size_t)HC_N, c->mods[(size_t)l].m, z);
-        if (rc) { hipFree(dst); return rc; }
-    }
-    HC_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = hc_launch(c, "ker_to_mont", hc_k_ker_to_mont, hc_pw_grid((size_t)max_ob * 2 * HC_N), (const u64 *)d, dst, max_ob, c->mods[0].m, c->mods[1].m);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "hc_ker_load: stream synchronize failed");
+    if (rc) { hipFree(dst); return rc; }      // `take` means the buffer was ours to free as well
     hc_ker *k = new hc_ker(); k->d = dst; k->max_ob = max_ob; *out = k;
     return HC_OK;
 }

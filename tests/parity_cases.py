@@ -138,19 +138,20 @@ def load_tree_keys(ctx, seed, max_ob, norm=1):
     return evk_all
 
 
-def case_conv(ctx, O, max_ob, seed=0xBEEF, with_bias=True, chunk=None):
+def case_conv(ctx, O, max_ob, seed=0xBEEF, with_bias=True, chunk=None, norm=1, out_scale=2.0 ** 30):
+    """norm > 1 = the sparse packing of the reference's *_sparse kinds (only channels i % norm == 0 are live,
+    conv.go:526, 286-287); out_scale = 2^43 is what evalConv_BNRelu_new asks of the same operator (eval.go:433)."""
     ct_in, ker = planted_conv_inputs(seed, max_ob)
-    evk_all = load_tree_keys(ctx, seed, max_ob)
+    evk_all = load_tree_keys(ctx, seed, max_ob, norm)
     idx = O.idx_plaintexts()
     ctx.idx_load(None)                      # derived on the device; must equal the oracle's (checked via the result)
     bias = splitmix_rows(seed + 5, Q0, N) if with_bias else None
     if chunk is not None:
         ctx.set_option("chunk_nodes", chunk)
-    out_scale = 2.0 ** 30
-    got, sc = ctx.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, max_ob, 1, out_scale, bias)
-    want, wsc = O.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, idx, evk_all, max_ob, 1, out_scale, bias)
+    got, sc = ctx.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, max_ob, norm, out_scale, bias)
+    want, wsc = O.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, idx, evk_all, max_ob, norm, out_scale, bias)
     assert sc == wsc == out_scale
-    eq(got, want, f"conv_then_pack B={max_ob}")
+    eq(got, want, f"conv_then_pack B={max_ob} norm={norm} out_scale={out_scale}")
     return got
 
 

@@ -66,3 +66,8 @@ def test_prep_ker(env, k, i_batch):
     import json
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"ref_trace_conv_{k}_{i_batch}.json")
     pc.case_prep_ker(*env, k=k, i_batch=i_batch, trace=json.load(open(path)) if os.path.exists(path) else None)
+
+
+@pytest.mark.parametrize("max_ob,norm,out_scale", [(8, 2, 2.0 ** 30), (8, 4, 2.0 ** 30), (4, 1, 2.0 ** 43), (8, 8, 2.0 ** 30)])
+def test_conv_sparse_norm_and_relu_scale(env, max_ob, norm, out_scale):
+    pc.case_conv(*env, max_ob, norm=norm, out_scale=out_scale)

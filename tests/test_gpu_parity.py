@@ -172,3 +172,10 @@ def test_sharded_path_world1_on_gpu(env):
         assert sc == wsc
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("max_ob,norm,out_scale", [(64, 2, 2.0 ** 30), (256, 4, 2.0 ** 30), (16, 1, 2.0 ** 43), (256, 1, 2.0 ** 43), (16, 16, 2.0 ** 30)])
+def test_conv_sparse_norm_and_relu_scale(env, max_ob, norm, out_scale):
+    """the same operator as the reference's other callers use it: sparse packing (norm > 1: *_sparse kinds) and the
+    2^43 out_scale of evalConv_BNRelu_new (eval.go:433)"""
+    pc.case_conv(*env, max_ob, norm=norm, out_scale=out_scale)
