@@ -307,8 +307,65 @@ void GpuEvaluator::RotateGal(const Ciphertext &ct, uint64_t galEl, Ciphertext &o
 }
 
 // ---------------------------------------------------------------- conv_then_pack / evalConv_BN
+// pack_ctxts (conv.go:266-300), statement by statement, on the ckks.Evaluator subset (GpuEvaluator = one C-ABI call per
+// limb row). This is the path a cgo gpuEvaluator takes when conv.go is left untouched.
+static Ciphertext pack_ctxts(Context *c, GpuEvaluator &pack_eval, std::vector<Ciphertext> &ctxts_in, int max_cnum, int real_cnum, const std::vector<Plaintext> &idx) {
+    int step = max_cnum / 2;
+    const int norm = max_cnum / real_cnum;
+    std::vector<Ciphertext> &ctxts = ctxts_in;                       // CopyNew is not needed: the inputs are ours
+    for (int i = 0; i < max_cnum; i++) if (i % norm == 0) ctxts[(size_t)i].Scale *= (double)real_cnum;   // conv.go:274
+    int logStep = 0;
+    for (int i = step; i > 1; i /= 2) logStep++;
+    int j = c->logN - logStep;
+    while (step >= norm && step >= 1) {
+        for (int i = 0; i < step; i += norm) {
+            Ciphertext tmp1 = pack_eval.MulNew(ctxts[(size_t)(i + step)], idx[(size_t)logStep]);   // conv.go:288
+            Ciphertext tmp2 = pack_eval.SubNew(ctxts[(size_t)i], tmp1);                               // conv.go:289
+            pack_eval.Add(ctxts[(size_t)i], tmp1, tmp1);                                              // conv.go:290
+            pack_eval.RotateGal(tmp2, (1ull << j) + 1, tmp2);                                         // conv.go:291
+            pack_eval.Add(tmp1, tmp2, ctxts[(size_t)i]);                                              // conv.go:292
+            freeCt(c, tmp1); freeCt(c, tmp2);
+        }
+        step /= 2; logStep--; j++;
+    }
+    return ctxts[0];
+}
+// conv_then_pack (conv.go:522-546) op by op on the evaluator interface (HCONV_OPWISE=1): must give the same bits
+// as the fused kernels.
+static Ciphertext conv_then_pack_opwise(Context *c, const Ciphertext &ctxt_in, const KerPlain &pl_ker, int max_ob, int norm, double out_scale) {
+    GpuEvaluator pack_evaluator(c);
+    auto start = now();
+    std::vector<uint64_t> flat((size_t)max_ob * 2 * N);
+    HC(c->hc, hc_ker_download(c->hc, pl_ker.h, flat.data()));        // pl_ker[i] as Lattigo holds them (plain NTT rows)
+    uint64_t *dker = dev_upload(c, flat);
+    std::vector<Ciphertext> ctxt_out((size_t)max_ob);
+    for (int i = 0; i < max_ob; i++) if (i % norm == 0) {
+        Plaintext pt; pt.d = dker + (size_t)i * 2 * N; pt.level = 1; pt.Scale = pl_ker.Scale;
+        ctxt_out[(size_t)i] = pack_evaluator.MulNew(ctxt_in, pt);                                     // conv.go:527
+        pack_evaluator.SetScale(ctxt_out[(size_t)i], out_scale / (double)(max_ob / norm));            // conv.go:528
+    }
+    HC(c->hc, hc_sync(c->hc));
+    auto mt = now();
+    printf("\t mult time:  %s\n", dur(start).c_str());
+    // plain_idx (conv.go:248-253) as device plaintexts
+    std::vector<uint64_t> xs((size_t)LOGN * N, 0);
+    for (int s = 0; s < LOGN; s++) xs[(size_t)s * N + ((size_t)1 << s)] = 1;
+    uint64_t *didx = dev_upload(c, xs);
+    HC(c->hc, hc_ntt(c->hc, 0, didx, didx, LOGN));
+    std::vector<Plaintext> idx((size_t)LOGN);
+    for (int s = 0; s < LOGN; s++) { idx[(size_t)s].d = didx + (size_t)s * N; idx[(size_t)s].level = 0; idx[(size_t)s].Scale = 1.0; }
+    Ciphertext res = pack_ctxts(c, pack_evaluator, ctxt_out, max_ob, max_ob / norm, idx);
+    HC(c->hc, hc_sync(c->hc));
+    printf("\t Pack time:  %s\n", dur(mt).c_str());
+    for (int i = 1; i < max_ob; i++) if (ctxt_out[(size_t)i].d) freeCt(c, ctxt_out[(size_t)i]);
+    HC(c->hc, hc_free(c->hc, dker)); HC(c->hc, hc_free(c->hc, didx));
+    if (out_scale != res.Scale || 0 != res.level) panic("LV or scale after conv then pack, inconsistent");   // conv.go:541-543
+    return res;
+}
+
 Ciphertext conv_then_pack(Context *c, const Ciphertext &ctxt_in, const KerPlain &pl_ker, int max_ob, int norm, int ECD_LV, double out_scale, const Plaintext *pl_bn_b) {
     (void)ECD_LV;
+    if (getenv("HCONV_OPWISE")) return conv_then_pack_opwise(c, ctxt_in, pl_ker, max_ob, norm, out_scale);
     auto start = now();
     Ciphertext r; r.d = dev_rows(c, 2); r.level = 0;
     // The reference prints "mult time" and "Pack time" separately (conv.go:533,535); run the two phases through
@@ -380,6 +437,11 @@ void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool
         Ciphertext ctxt_input = EncryptNew(cont, EncodeCoeffs(input, cont->ECD_LV, cont->scale), cont->ECD_LV, cont->scale);
         printf("Encryption done in %s \n", dur(start).c_str());
         Ciphertext ct_result = evalConv_BN(cont, ctxt_input, ker_in, bn_a, bn_b, in_wid, ker_wid, raw_in_batch, raw_out_batch, norm, (double)(1 << 30), trans);
+        if (getenv("HCONV_PRINT_DIGEST")) {      // FNV-1a over the result ciphertext: lets tests compare code paths bit for bit
+            std::vector<uint64_t> h = dev_download(cont, ct_result.d, 2); uint64_t f = 1469598103934665603ull;
+            for (uint64_t w : h) for (int b = 0; b < 8; b++) { f ^= (w >> (8 * b)) & 0xff; f *= 1099511628211ull; }
+            printf("ciphertext digest: %016llx\n", (unsigned long long)f);
+        }
         start = now();
         std::vector<double> cfs_tmp = DecryptDecodeCoeffs(cont, ct_result);
         printf("Decryption Done in %s \n", dur(start).c_str());

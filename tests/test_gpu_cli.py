@@ -26,3 +26,16 @@ def test_conv_cli(tmp_path, k, i_batch, min_med):
     assert re.search(r"^Ours start\.$", txt, re.M) and re.search(r"^\t Pack time:  \S+$", txt, re.M)
     med = float(re.search(r"^MED Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M).group(1))
     assert med >= min_med, txt
+
+
+@pytest.mark.parametrize("k,i_batch", [(3, 1), (3, 3)])
+def test_opwise_evaluator_path_equals_fused_on_gpu(tmp_path, k, i_batch):
+    """the L0 ABI (one call per evaluator op, what the cgo shim binds) vs the fused L1 path: same seed, same bits"""
+    gen.write_case(str(tmp_path / "test_conv_data"), k, i_batch, 0)
+    digests = []
+    for extra in ({}, {"HCONV_OPWISE": "1"}):
+        out = subprocess.run([CLI, "conv", str(k), str(i_batch), "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
+                             env=dict(os.environ, HCONV_SEED="99", HCONV_PRINT_DIGEST="1", **extra))
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(re.search(r"^ciphertext digest: ([0-9a-f]{16})$", out.stdout, re.M).group(1))
+    assert digests[0] == digests[1]

@@ -51,3 +51,17 @@ def test_missing_csv_panics(cli, tmp_path):
     out = subprocess.run([cli, "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, HCONV_SEED="1"))
     assert out.returncode == 2 and "panic:" in out.stderr
+
+
+def test_opwise_evaluator_path_equals_fused(cli, tmp_path):
+    """HCONV_OPWISE=1 runs conv_then_pack/pack_ctxts statement by statement on the ckks.Evaluator subset (MulNew,
+    SetScale, SubNew, Add, RotateGal = the L0 ABI a cgo gpuEvaluator binds); with the same seed the result ciphertext
+    must be bit-identical to the fused kernels'."""
+    gen.write_case(str(tmp_path / "test_conv_data"), 3, 0, 0)
+    digests = []
+    for extra in ({}, {"HCONV_OPWISE": "1"}):
+        out = subprocess.run([cli, "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=1800,
+                             env=dict(os.environ, HCONV_SEED="99", HCONV_PRINT_DIGEST="1", **extra))
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(re.search(r"^ciphertext digest: ([0-9a-f]{16})$", out.stdout, re.M).group(1))
+    assert digests[0] == digests[1]
