@@ -365,6 +365,7 @@ struct HcLoopA {
     u64 *tmp;         // [chunk][2 polys][N]
     u64 *cts;         // [max_ob][2 polys][N]    level-0 outputs
     int i0, norm;     // first channel of this chunk; channel of job j is i0 + (j>>1)*norm, poly = j&1
+    int slot0, slot_step;   // its result goes to cts slot slot0 + (j>>1)*slot_step (= the channel index, or a compact ordinal)
     HcMod m0, m1;
     HcTw q1inv;       // Q1^-1 mod Q0
     u64 h, negh0;     // (Q1-1)>>1 ; Q0 - (h mod Q0)
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_a3(HcLoopA A, HcTwT
     const u64 *__restrict__ in = A.tmp + (size_t)job * 65536 + (size_t)row * 256;
     const u64 *__restrict__ c = A.ctc + ((size_t)p * 2) * 65536 + (size_t)blockIdx.x * 4096 + t;
     const u64 *__restrict__ k = A.ker + ((size_t)i * 2) * 65536 + (size_t)blockIdx.x * 4096 + t;
-    u64 *__restrict__ o = A.cts + ((size_t)i * 2 + p) * 65536 + (size_t)blockIdx.x * 4096 + t;
+    u64 *__restrict__ o = A.cts + ((size_t)(A.slot0 + (job >> 1) * A.slot_step) * 2 + p) * 65536 + (size_t)blockIdx.x * 4096 + t;
     const u64 q = A.m0.q;
     u64 e[16], a0[16];
 #pragma unroll

@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <map>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -67,6 +68,14 @@ struct HcModHost {
 };
 struct HcEvk { u64 *q_rows; HcTw *p_rows; bool row_local; };   // [2][N] each: q_rows Montgomery form; p_rows Shoup pairs, lo-local order
 struct HcProfRec { std::string name; hipEvent_t a, b; };
+// An internal lane = its own HIP stream + workspaces: one convolution is split by output channel i mod G into G
+// independent sub-trees (the decomposition sharded.py uses across GPUs) that run concurrently on one GPU.
+struct HcLane {
+    hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+    u64 *tmp = nullptr; size_t tmp_rows = 0;
+    u64 *cts = nullptr; size_t cts_rows = 0;
+    u64 *cts2 = nullptr; size_t cts2_rows = 0;
+};
 
 struct hc_ctx {
     int device = 0, nq = 0, np = 0;
@@ -79,7 +88,11 @@ struct hc_ctx {
     u64 *ws_cts2 = nullptr; size_t ws_cts2_rows = 0;   // tree pong
     u64 *ws_ctc = nullptr;
     u64 *ws_tmp = nullptr; size_t ws_tmp_rows = 0;
-    long chunk_nodes = 32;
+    long chunk_nodes = 64;
+    long lanes = 1;               // internal concurrency of ONE conv_then_pack (power of two; 1 = single stream)
+    std::vector<HcLane> lane;
+    hipEvent_t ev_fork = nullptr;
+    u64 *ws_gather = nullptr; size_t ws_gather_rows = 0;
     long profile = 0;
     std::vector<HcProfRec> prof;
     std::map<std::string, std::pair<double, long>> prof_acc;
@@ -218,6 +231,9 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     if (c->idx_pairs) hipFree(c->idx_pairs);
     if (c->ws_cts) hipFree(c->ws_cts);
     if (c->ws_cts2) hipFree(c->ws_cts2);
+    if (c->ws_gather) hipFree(c->ws_gather);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    for (auto &L : c->lane) { if (L.tmp) hipFree(L.tmp); if (L.cts) hipFree(L.cts); if (L.cts2) hipFree(L.cts2); if (L.done) hipEventDestroy(L.done); if (L.stream) { hipStreamSynchronize(L.stream); hipStreamDestroy(L.stream); } }
     if (c->ws_ctc) hipFree(c->ws_ctc);
     if (c->ws_tmp) hipFree(c->ws_tmp);
     if (c->t0) hipEventDestroy(c->t0);
@@ -294,7 +310,8 @@ extern "C" int hc_mul(hc_ctx *c, int mod, const uint64_t *a, const uint64_t *b, 
 extern "C" int hc_add(hc_ctx *c, int mod, const uint64_t *a, const uint64_t *b, uint64_t *out, int count) { HcTw z; z.w = z.ws = 0; if (!b) return HC_ERR_ARG; return hc_pw<HC_PW_ADD>(c, "hc_add", mod, a, b, out, count, z); }
 extern "C" int hc_sub(hc_ctx *c, int mod, const uint64_t *a, const uint64_t *b, uint64_t *out, int count) { HcTw z; z.w = z.ws = 0; if (!b) return HC_ERR_ARG; return hc_pw<HC_PW_SUB>(c, "hc_sub", mod, a, b, out, count, z); }
 extern "C" int hc_mul_const(hc_ctx *c, int mod, const uint64_t *a, uint64_t k, uint64_t *out, int count) {
-    if (!c) return HC_ERR_ARG; HC_TRY(hc_check_mod(c, mod, "hc_mul_const"));
+    if (!c) return HC_ERR_ARG;
+    HC_TRY(hc_check_mod(c, mod, "hc_mul_const"));
     u64 q = c->mods[(size_t)mod].m.q;
     return hc_pw<HC_PW_MULC>(c, "hc_mul_const", mod, a, a, out, count, h_pair(k % q, q));
 }
@@ -326,7 +343,7 @@ extern "C" uint64_t hc_const_for(double constant, double q_level_f, uint64_t q, 
 // ------------------------------------------------------------------ loop A plumbing
 static int hc_fill_loopA(hc_ctx *c, HcLoopA *A, const u64 *ker, u64 *cts, int norm) {
     const HcModHost &m0 = c->mods[0], &m1 = c->mods[1];
-    A->ctc = c->ws_ctc; A->ker = ker; A->tmp = c->ws_tmp; A->cts = cts; A->i0 = 0; A->norm = norm;
+    A->ctc = c->ws_ctc; A->ker = ker; A->tmp = c->ws_tmp; A->cts = cts; A->i0 = 0; A->norm = norm; A->slot0 = 0; A->slot_step = norm;
     A->m0 = m0.m; A->m1 = m1.m;
     A->q1inv = h_pair(h_inv(m1.m.q % m0.m.q, m0.m.q), m0.m.q);
     A->h = (m1.m.q - 1) >> 1; A->negh0 = m0.m.q - (A->h % m0.m.q);
@@ -344,21 +361,25 @@ static int hc_prepare_ctc(hc_ctx *c, const u64 *ct_in, const u64 cst[2]) {
     return HC_OK;
 }
 
-static int hc_loopA_run(hc_ctx *c, const u64 *ker_mont, int max_ob, int norm, u64 *cts) {
-    const int nch = max_ob / norm;                 // channels actually computed (i % norm == 0)
+// loop A over the channels i = i_first + j*i_stride, j < nch; result j goes to cts slot i (compact = false) or j
+static int hc_loopA_run_set(hc_ctx *c, const u64 *ker_mont, int i_first, int i_stride, int nch, u64 *cts, bool compact) {
     const long chunk = c->chunk_nodes < 1 ? 1 : c->chunk_nodes;
-    HC_TRY(hc_ensure_tmp(c, (size_t)(chunk < nch ? chunk : nch) * 5));
-    HcLoopA A; HC_TRY(hc_fill_loopA(c, &A, ker_mont, cts, norm));
+    HC_TRY(hc_ensure_tmp(c, (size_t)(chunk < nch ? chunk : nch) * 3));
+    HcLoopA A; HC_TRY(hc_fill_loopA(c, &A, ker_mont, cts, i_stride));
     const HcModHost &m0 = c->mods[0], &m1 = c->mods[1];
     for (int j0 = 0; j0 < nch; j0 += (int)chunk) {
         const int nj = (int)((nch - j0) < chunk ? (nch - j0) : chunk);
-        A.i0 = j0 * norm;
+        A.i0 = i_first + j0 * i_stride;
+        A.slot0 = compact ? j0 : A.i0; A.slot_step = compact ? 1 : i_stride;
         dim3 grid(16, (unsigned)(2 * nj));
         HC_TRY(hc_launch(c, "a1_mul_rowsinv", hc_k_a1, grid, A, m1.inv));
         HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "a2_colsinv_lift_colsfwd", hc_k_a2, grid, A, m1.inv, m0.fwd));
         HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "a3_rowsfwd_rescale", hc_k_a3, grid, A, m0.fwd));
     }
     return HC_OK;
+}
+static int hc_loopA_run(hc_ctx *c, const u64 *ker_mont, int max_ob, int norm, u64 *cts) {
+    return hc_loopA_run_set(c, ker_mont, 0, norm, max_ob / norm, cts, false);   // channels i % norm == 0 (conv.go:526)
 }
 
 // hc_div_round_last (level 1 only on this path): reuse loop A with ker = Montgomery one (c' (*) R = c')
@@ -685,6 +706,61 @@ static int hc_loopA_consts(hc_ctx *c, double ct_scale, double ker_scale, int max
     *target = tgt;
     return HC_OK;
 }
+// RAII swap of the context's stream + workspaces with a lane's, so every helper above runs on that lane unchanged
+struct HcLaneScope {
+    hc_ctx *c; HcLane *L;
+    HcLaneScope(hc_ctx *c_, HcLane *L_) : c(c_), L(L_) { swap(); }
+    ~HcLaneScope() { swap(); }
+    void swap() { std::swap(c->stream, L->stream); std::swap(c->ws_tmp, L->tmp); std::swap(c->ws_tmp_rows, L->tmp_rows);
+                  std::swap(c->ws_cts2, L->cts2); std::swap(c->ws_cts2_rows, L->cts2_rows); }
+};
+// One convolution on G internal lanes: lane g computes the channels i = g (mod G) (loop A) and the tree levels with
+// step >= G over them (hc_pack_run with stride log2 G) on its own stream; the G partial ciphertexts are then packed by
+// the last log2 G levels on the main stream. Same arithmetic, same order per node => same bits as the single-lane run.
+static int hc_conv_lanes(hc_ctx *c, const hc_ker *ker, int max_ob, int G, const u64 *bias, u64 *ct_out) {
+    if (G & (G - 1)) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two");
+    int log2g = 0; while ((1 << log2g) < G) log2g++;
+    const int nloc = max_ob / G;
+    if ((int)c->lane.size() < G) {
+        size_t old = c->lane.size(); c->lane.resize((size_t)G);
+        for (size_t g = old; g < (size_t)G; g++) { HC_HIP(c, hipStreamCreate(&c->lane[g].stream)); HC_HIP(c, hipEventCreate(&c->lane[g].done)); }
+    }
+    if (!c->ev_fork) HC_HIP(c, hipEventCreate(&c->ev_fork));
+    if (c->ws_gather_rows < (size_t)G * 2) {
+        HC_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->ws_gather) HC_HIP(c, hipFree(c->ws_gather));
+        c->ws_gather = nullptr; c->ws_gather_rows = 0;
+        HC_HIP(c, hipMalloc((void **)&c->ws_gather, (size_t)G * 2 * HC_N * sizeof(u64)));
+        c->ws_gather_rows = (size_t)G * 2;
+    }
+    HC_HIP(c, hipEventRecord(c->ev_fork, c->stream));          // ctc (and everything queued before) is ready
+    for (int g = 0; g < G; g++) {
+        HcLane &L = c->lane[(size_t)g];
+        if (L.cts_rows < (size_t)nloc * 2) {
+            HC_HIP(c, hipStreamSynchronize(L.stream));
+            if (L.cts) HC_HIP(c, hipFree(L.cts));
+            L.cts = nullptr; L.cts_rows = 0;
+            HC_HIP(c, hipMalloc((void **)&L.cts, (size_t)nloc * 2 * HC_N * sizeof(u64)));
+            L.cts_rows = (size_t)nloc * 2;
+        }
+        int rc;
+        {
+            HcLaneScope scope(c, &L);
+            rc = hipStreamWaitEvent(c->stream, c->ev_fork, 0) == hipSuccess ? HC_OK : hc_fail(c, HC_ERR_HIP, "hipStreamWaitEvent failed");
+            if (!rc) rc = hc_loopA_run_set(c, ker->d, g, G, nloc, L.cts, true);
+            if (!rc) rc = hc_pack_run(c, L.cts, nloc, nloc, nullptr, log2g);
+            if (!rc && hipMemcpyAsync(c->ws_gather + (size_t)g * 2 * HC_N, L.cts, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+                rc = hc_fail(c, HC_ERR_HIP, "lane gather copy failed");
+            if (!rc && hipEventRecord(L.done, c->stream) != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "hipEventRecord failed");
+        }
+        if (rc) return rc;
+    }
+    for (int g = 0; g < G; g++) HC_HIP(c, hipStreamWaitEvent(c->stream, c->lane[(size_t)g].done, 0));
+    HC_TRY(hc_pack_run(c, c->ws_gather, G, G, bias, 0));
+    HC_HIP(c, hipMemcpyAsync(ct_out, c->ws_gather, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    return HC_OK;
+}
+
 extern "C" int hc_conv_mult_phase(hc_ctx *c, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
                                   int max_ob, int norm, double out_scale, uint64_t *cts_out) {
     HC_ENTER(c);
@@ -700,11 +776,16 @@ extern "C" int hc_conv_then_pack(hc_ctx *c, const uint64_t *ct_in, double ct_sca
     if (!ct_in || !ker || !ct_out || ker->max_ob < max_ob) return hc_fail(c, HC_ERR_ARG, "hc_conv_then_pack: bad arguments");
     u64 cst[2]; double target;
     HC_TRY(hc_loopA_consts(c, ct_scale, ker_scale, max_ob, norm, out_scale, cst, &target));
-    HC_TRY(hc_ensure_cts(c, (size_t)max_ob * 2));
     HC_TRY(hc_prepare_ctc(c, (const u64 *)ct_in, cst));
-    HC_TRY(hc_loopA_run(c, ker->d, max_ob, norm, c->ws_cts));
-    HC_TRY(hc_pack_run(c, c->ws_cts, max_ob, max_ob / norm, (const u64 *)bias));
-    HC_HIP(c, hipMemcpyAsync(ct_out, c->ws_cts, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    const int G = (int)c->lanes;
+    if (G > 1 && norm == 1 && max_ob >= 2 * G) {
+        HC_TRY(hc_conv_lanes(c, ker, max_ob, G, (const u64 *)bias, (u64 *)ct_out));
+    } else {
+        HC_TRY(hc_ensure_cts(c, (size_t)max_ob * 2));
+        HC_TRY(hc_loopA_run(c, ker->d, max_ob, norm, c->ws_cts));
+        HC_TRY(hc_pack_run(c, c->ws_cts, max_ob, max_ob / norm, (const u64 *)bias));
+        HC_HIP(c, hipMemcpyAsync(ct_out, c->ws_cts, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    }
     // conv.go:274 multiplies the scale by real_cnum; conv.go:541 then demands out_scale and level 0
     const double final_scale = target * (double)(max_ob / norm);
     if (final_scale != out_scale) return hc_fail(c, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
@@ -716,6 +797,7 @@ extern "C" int hc_conv_then_pack(hc_ctx *c, const uint64_t *ct_in, double ct_sca
 extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!c || !name) return HC_ERR_ARG;
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
+    if (!strcmp(name, "lanes")) { if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
     return hc_fail(c, HC_ERR_ARG, "unknown option %s", name);
 }

@@ -71,3 +71,9 @@ def test_prep_ker(env, k, i_batch):
 @pytest.mark.parametrize("max_ob,norm,out_scale", [(8, 2, 2.0 ** 30), (8, 4, 2.0 ** 30), (4, 1, 2.0 ** 43), (8, 8, 2.0 ** 30)])
 def test_conv_sparse_norm_and_relu_scale(env, max_ob, norm, out_scale):
     pc.case_conv(*env, max_ob, norm=norm, out_scale=out_scale)
+
+
+@pytest.mark.parametrize("max_ob,lanes,chunk", [(8, 2, 32), (16, 4, 3), (16, 8, 32)])
+def test_conv_internal_lanes(env, max_ob, lanes, chunk):
+    """one convolution split over internal lanes (channels i mod G on their own streams) must give the same bits"""
+    pc.case_conv(*env, max_ob, lanes=lanes, chunk=chunk)

@@ -179,3 +179,9 @@ def test_conv_sparse_norm_and_relu_scale(env, max_ob, norm, out_scale):
     """the same operator as the reference's other callers use it: sparse packing (norm > 1: *_sparse kinds) and the
     2^43 out_scale of evalConv_BNRelu_new (eval.go:433)"""
     pc.case_conv(*env, max_ob, norm=norm, out_scale=out_scale)
+
+
+@pytest.mark.parametrize("max_ob,lanes,chunk", [(16, 2, 32), (64, 4, 64), (256, 4, 64), (256, 8, 16), (256, 2, 256)])
+def test_conv_internal_lanes(env, max_ob, lanes, chunk):
+    """one convolution split over internal lanes (channels i mod G on their own HIP streams) vs the oracle"""
+    pc.case_conv(*env, max_ob, lanes=lanes, chunk=chunk)
