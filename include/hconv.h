@@ -85,6 +85,15 @@ int hc_evk_load(hc_ctx *ctx, uint64_t galEl, const uint64_t *b_q, const uint64_t
 int hc_keyswitch_l0(hc_ctx *ctx, uint64_t galEl, const uint64_t *c1, uint64_t *d0, uint64_t *d1);
 int hc_rotate_gal_l0(hc_ctx *ctx, uint64_t galEl, const uint64_t *c0, const uint64_t *c1, uint64_t *o0, uint64_t *o1);
 
+/* General hybrid key switch, any level, alpha = np special primes, beta = ceil((level+1)/np) digits:
+ * rlwe.KeySwitcher.SwitchKeysInPlace for an NTT-domain input (what RotateNew / Relinearize call outside the conv
+ * path: BL baseline eval.go:123 at level 1 with two P primes; the bootstrapping chain with five).
+ * hc_swk_load: HOST rows [beta][2][level+1+np][N] = rlwe.SwitchingKey.Value[d][k].Coeffs restricted to the Q limbs
+ * 0..level followed by the np P limbs, stored form. hc_keyswitch: cx = (level+1) device rows (NTT); d0, d1 =
+ * (level+1) device rows each, canonical. Correctness-first composition (not fused). */
+int hc_swk_load(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *rows_host);
+int hc_keyswitch(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1);
+
 /* ---- L1: the fused hot path ---- */
 /* pl_ker as prep_Ker leaves it (conv.go:510-515): HOST array [max_ob][2][N], level 1, NTT domain. */
 int hc_ker_load(hc_ctx *ctx, const uint64_t *pl_ker_host, int max_ob, hc_ker **out);

@@ -37,6 +37,8 @@ SYMBOLS = {
     "hc_evk_load": (C.c_int, [C.c_void_p, C.c_uint64, u64p, u64p, u64p, u64p]),
     "hc_keyswitch_l0": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_rotate_gal_l0": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_swk_load": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, u64p]),
+    "hc_keyswitch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_ker_load": (C.c_int, [C.c_void_p, u64p, C.c_int, C.POINTER(C.c_void_p)]),
     "hc_ker_load_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "hc_prep_ker": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -235,6 +237,19 @@ class Context:
         d = self.buf(nwords=2 * self.N)
         self._ck(self.L.hc_keyswitch_l0(self.h, C.c_uint64(gal), src.ptr, d.at(0), d.at(self.N)))
         out = d.download((2, self.N))
+        src.free(); d.free()
+        return out[0], out[1]
+
+    def swk_load(self, key_id, level, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        self._ck(self.L.hc_swk_load(self.h, C.c_uint64(key_id), level, _hp(rows.reshape(-1))))
+
+    def keyswitch(self, key_id, level, cx):
+        cx = np.ascontiguousarray(cx, dtype=np.uint64).reshape(level + 1, self.N)
+        src = self.buf(cx)
+        d = self.buf(nwords=2 * (level + 1) * self.N)
+        self._ck(self.L.hc_keyswitch(self.h, C.c_uint64(key_id), level, src.ptr, d.at(0), d.at((level + 1) * self.N)))
+        out = d.download((2, level + 1, self.N))
         src.free(); d.free()
         return out[0], out[1]
 

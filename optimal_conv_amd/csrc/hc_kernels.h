@@ -629,3 +629,48 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, c
         o[kk * 256] = hc_addmod(t1[kk], lds[hc_rows_lds(kk, (int)(srcidx & 255))], q);
     }
 }
+
+// ================================================================ general hybrid key switch (any level, alpha P primes)
+// Building blocks for rlwe.KeySwitcher.SwitchKeysInPlace beyond the conv path's level-0 case (BL baseline: level 1 with
+// two special primes; bootstrapping: alpha = 5, several digits). Composed from the standalone transforms above plus
+// three pointwise kernels; correctness-first (one launch per limb), not fused.
+//
+// Exact fast basis extension (ring.reconstructRNS + ring.multSum): n <= 8 source limbs (coefficient domain, any
+// representatives) -> one target modulus t:
+//   y_i = x_i * (S/s_i)^-1 mod s_i ;  v = uint64(sum_i float64(y_i)/float64(s_i)) [fp64, limb order] ;
+//   out = sum_i y_i * (S/s_i mod t) - v * (S mod t)  mod t.      n == 1 degenerates to x mod t (the "copy" case).
+struct HcBasisExt {
+    int n;
+    u64 s[8];          // source moduli
+    HcTw inv[8];       // (S/s_i)^-1 mod s_i
+    HcTw hat[8];       // S/s_i mod t
+    HcTw smodt;        // S mod t
+    u64 t, mu_t;       // target modulus, floor(2^64/t)
+    u64 mu_s[8];       // floor(2^64/s_i)
+};
+__global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend(const u64 *src, size_t src_stride, u64 *dst, HcBasisExt B) {
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        if (B.n == 1) { dst[j] = hc_barrett64(hc_barrett64(src[j], B.s[0], B.mu_s[0]), B.t, B.mu_t); continue; }
+        double vi = 0.0; u64 acc = 0;
+        for (int i = 0; i < B.n; i++) {
+            const u64 x = hc_barrett64(src[(size_t)i * src_stride + j], B.s[i], B.mu_s[i]);
+            const u64 y = hc_mul_shoup(x, B.inv[i].w, B.inv[i].ws, B.s[i]);
+            vi += (double)y / (double)B.s[i];
+            acc = hc_addmod(acc, hc_mul_shoup(hc_barrett64(y, B.t, B.mu_t), B.hat[i].w, B.hat[i].ws, B.t), B.t);
+        }
+        const u64 v = (u64)vi;
+        dst[j] = hc_submod(acc, hc_mul_shoup(hc_barrett64(v, B.t, B.mu_t), B.smodt.w, B.smodt.ws, B.t), B.t);
+    }
+}
+// acc = (first ? 0 : acc) + evk (*)_mont c2   (evk in Lattigo's stored Montgomery form => plain product), canonical
+__global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac(const u64 *evk, const u64 *c2, u64 *acc, HcMod m, int first) {
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        const u64 p = hc_mont(c2[j], evk[j], m.q, m.qinv);
+        acc[j] = first ? p : hc_addmod(acc[j], p, m.q);
+    }
+}
+// ModDown tail: out = (acc - ext) * P^-1 mod q
+__global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown(const u64 *acc, const u64 *ext, u64 *out, u64 q, HcTw pinv) {
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
+        out[j] = hc_mul_shoup(hc_submod(acc[j], ext[j], q), pinv.w, pinv.ws, q);
+}

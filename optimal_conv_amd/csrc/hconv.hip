@@ -67,6 +67,7 @@ struct HcModHost {
     std::vector<void *> allocs;
 };
 struct HcEvk { u64 *q_rows; HcTw *p_rows; bool row_local; };   // [2][N] each: q_rows Montgomery form; p_rows Shoup pairs, lo-local order
+struct HcSwk { u64 *rows = nullptr; int level = 0, beta = 0; };   // general switching key: [beta][2][level+1+np][N], stored form
 struct HcProfRec { std::string name; hipEvent_t a, b; };
 // An internal lane = its own HIP stream + workspaces: one convolution is split by output channel i mod G into G
 // independent sub-trees (the decomposition sharded.py uses across GPUs) that run concurrently on one GPU.
@@ -82,6 +83,7 @@ struct hc_ctx {
     hipStream_t stream = nullptr;
     std::vector<HcModHost> mods;
     std::map<u64, HcEvk> evk;
+    std::map<u64, HcSwk> swk;
     u64 *idx_pairs = nullptr;    // [logN][N] idx plaintexts, Montgomery form
     // workspace
     u64 *ws_cts = nullptr; size_t ws_cts_rows = 0;     // loop A output / tree ping
@@ -228,6 +230,7 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     for (auto &r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto &mh : c->mods) for (void *d : mh.allocs) hipFree(d);
     for (auto &kv : c->evk) { hipFree(kv.second.q_rows); hipFree(kv.second.p_rows); }
+    for (auto &kv : c->swk) hipFree(kv.second.rows);
     if (c->idx_pairs) hipFree(c->idx_pairs);
     if (c->ws_cts) hipFree(c->ws_cts);
     if (c->ws_cts2) hipFree(c->ws_cts2);
@@ -678,6 +681,84 @@ extern "C" int hc_keyswitch_l0(hc_ctx *c, uint64_t galEl, const uint64_t *c1, ui
         if (!rc) rc = hc_permute(c, ginv, buf + HC_N, d1, 1);
     }
     hipStreamSynchronize(c->stream); hipFree(buf);
+    return rc;
+}
+
+// ------------------------------------------------------------------ general hybrid key switch (L0, any level)
+static HcBasisExt hc_make_bx(const std::vector<u64> &src, u64 t) {
+    HcBasisExt B; memset(&B, 0, sizeof B);
+    B.n = (int)src.size(); B.t = t; B.mu_t = (u64)((((u128)1) << 64) / t);
+    u64 smodt = 1;
+    for (int i = 0; i < B.n; i++) {
+        const u64 si = src[(size_t)i]; B.s[i] = si; B.mu_s[i] = (u64)((((u128)1) << 64) / si);
+        u64 hat_si = 1, hat_t = 1;
+        for (int j = 0; j < B.n; j++) if (j != i) { hat_si = h_mulmod(hat_si, src[(size_t)j] % si, si); hat_t = h_mulmod(hat_t, src[(size_t)j] % t, t); }
+        B.inv[i] = h_pair(h_inv(hat_si, si), si);
+        B.hat[i] = h_pair(hat_t, t);
+        smodt = h_mulmod(smodt, si % t, t);
+    }
+    B.smodt = h_pair(smodt, t);
+    return B;
+}
+extern "C" int hc_swk_load(hc_ctx *c, uint64_t key_id, int level, const uint64_t *rows_host) {
+    HC_ENTER(c);
+    if (!rows_host || level < 0 || level >= c->nq || c->np < 1 || c->np > 8) return hc_fail(c, HC_ERR_ARG, "hc_swk_load: bad arguments");
+    const int nt = level + 1 + c->np, beta = (level + 1 + c->np - 1) / c->np;
+    const size_t n = (size_t)beta * 2 * nt * HC_N;
+    HcSwk k; k.level = level; k.beta = beta;
+    HC_HIP(c, hipMalloc((void **)&k.rows, n * sizeof(u64)));
+    HC_HIP(c, hipMemcpyAsync(k.rows, rows_host, n * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hipStreamSynchronize(c->stream));
+    auto it = c->swk.find(key_id);
+    if (it != c->swk.end()) hipFree(it->second.rows);
+    c->swk[key_id] = k;
+    return HC_OK;
+}
+extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1) {
+    HC_ENTER(c);
+    auto it = c->swk.find(key_id);
+    if (it == c->swk.end()) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch: no switching key %llu loaded", (unsigned long long)key_id);
+    if (!cx || !d0 || !d1 || level != it->second.level) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch: bad arguments (key loaded for level %d)", it->second.level);
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = it->second.beta;
+    const u64 *evk = it->second.rows;
+    // scratch rows: coef[nl] | c2[1] | ext[1] | acc[2][nt] | pc[alpha]
+    u64 *buf = nullptr; const size_t rows = (size_t)nl + 2 + 2 * nt + alpha;
+    HC_HIP(c, hipMalloc((void **)&buf, rows * HC_N * sizeof(u64)));
+    u64 *coef = buf, *c2 = coef + (size_t)nl * HC_N, *ext = c2 + HC_N, *acc = ext + HC_N, *pc = acc + (size_t)2 * nt * HC_N;
+    int rc = HC_OK;
+    auto modidx = [&](int T) { return T < nl ? T : c->nq + (T - nl); };
+    for (int l = 0; l < nl && !rc; l++) rc = hc_intt(c, l, cx + (size_t)l * HC_N, coef + (size_t)l * HC_N, 1);       // cxInvNTT
+    for (int d = 0; d < beta && !rc; d++) {
+        const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl;
+        std::vector<u64> src; for (int i = lo; i < hi; i++) src.push_back(c->mods[(size_t)i].m.q);
+        for (int T = 0; T < nt && !rc; T++) {
+            const int mod = modidx(T); const HcMod &m = c->mods[(size_t)mod].m;
+            const u64 *c2row;
+            if (T >= lo && T < hi) c2row = cx + (size_t)T * HC_N;                       // the digit's own limbs reuse the NTT input
+            else {
+                rc = hc_launch(c, "ks_basis_extend", hc_k_basis_extend, hc_pw_grid(HC_N), (const u64 *)(coef + (size_t)lo * HC_N), (size_t)HC_N, ext, hc_make_bx(src, m.q));
+                if (!rc) rc = hc_ntt(c, mod, ext, c2, 1);
+                c2row = c2;
+            }
+            for (int k = 0; k < 2 && !rc; k++)
+                rc = hc_launch(c, "ks_mac", hc_k_ks_mac, hc_pw_grid(HC_N), evk + (((size_t)d * 2 + k) * nt + T) * HC_N, c2row, acc + ((size_t)k * nt + T) * HC_N, m, d == 0 ? 1 : 0);
+        }
+    }
+    // ModDownSplitNTTPQ
+    std::vector<u64> psrc; for (int j = 0; j < alpha; j++) psrc.push_back(c->mods[(size_t)(c->nq + j)].m.q);
+    for (int k = 0; k < 2 && !rc; k++) {
+        for (int j = 0; j < alpha && !rc; j++) rc = hc_intt(c, c->nq + j, acc + ((size_t)k * nt + nl + j) * HC_N, pc + (size_t)j * HC_N, 1);
+        u64 *out = k == 0 ? (u64 *)d0 : (u64 *)d1;
+        for (int l = 0; l < nl && !rc; l++) {
+            const HcMod &m = c->mods[(size_t)l].m;
+            u64 pmod = 1; for (u64 pj : psrc) pmod = h_mulmod(pmod, pj % m.q, m.q);
+            rc = hc_launch(c, "ks_basis_extend", hc_k_basis_extend, hc_pw_grid(HC_N), (const u64 *)pc, (size_t)HC_N, ext, hc_make_bx(psrc, m.q));
+            if (!rc) rc = hc_ntt(c, l, ext, ext, 1);
+            if (!rc) rc = hc_launch(c, "ks_moddown", hc_k_ks_moddown, hc_pw_grid(HC_N), (const u64 *)(acc + ((size_t)k * nt + l) * HC_N), (const u64 *)ext, out + (size_t)l * HC_N, m.q, h_pair(h_inv(pmod, m.q), m.q));
+        }
+    }
+    hipStreamSynchronize(c->stream);
+    hipFree(buf);
     return rc;
 }
 

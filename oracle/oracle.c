@@ -346,6 +346,77 @@ void or_keyswitch_l0(const or_ctx *c, const uint64_t *c1, const uint64_t *evk_b_
     free(cc); free(cp); free(acc); free(ext);
 }
 
+/* lattigo ring.reconstructRNS + ring.multSum (test_run @0x4e79b0 region; SURVEY 8(a)-R "modUpExact" row):
+ *   y_i = x_i * (S/s_i)^-1 mod s_i (canonical);  v = uint64( sum_i float64(y_i)/float64(s_i) )  [fp64, in limb order];
+ *   result = sum_i y_i * (S/s_i mod t) - v * (S mod t)  mod t.      S = prod s_i. */
+uint64_t or_basis_extend(const uint64_t *x, const uint64_t *src, int n, uint64_t t) {
+    uint64_t y[16]; double vi = 0.0;
+    for (int i = 0; i < n; i++) {
+        uint64_t si = src[i], hat_mod_si = 1;
+        for (int j = 0; j < n; j++) if (j != i) hat_mod_si = mulmod(hat_mod_si, src[j] % si, si);
+        y[i] = mulmod(x[i] % si, powmod(hat_mod_si, si - 2, si), si);
+        vi += (double)y[i] / (double)si;
+    }
+    uint64_t v = (uint64_t)vi, acc = 0, S_mod_t = 1;
+    for (int i = 0; i < n; i++) {
+        uint64_t hat_mod_t = 1;
+        for (int j = 0; j < n; j++) if (j != i) hat_mod_t = mulmod(hat_mod_t, src[j] % t, t);
+        acc = addmod(acc, mulmod(y[i] % t, hat_mod_t, t), t);
+        S_mod_t = mulmod(S_mod_t, src[i] % t, t);
+    }
+    return submod(acc, mulmod(v % t, S_mod_t, t), t);
+}
+
+/* general rlwe.(*KeySwitcher).SwitchKeysInPlace (NTT-domain input); see oracle.h */
+void or_keyswitch(const or_ctx *c, int level, const uint64_t *cx, const uint64_t *evk, uint64_t *d0, uint64_t *d1) {
+    const int N = c->N, alpha = c->np, nl = level + 1, nt = nl + alpha;          /* nt = limbs an evk row set covers */
+    const int beta = (nl + alpha - 1) / alpha;
+    const size_t n = (size_t)N;
+    uint64_t *coef = malloc(sizeof(uint64_t) * n * (size_t)nl);                   /* cxInvNTT */
+    uint64_t *acc = calloc(n * (size_t)nt * 2, sizeof(uint64_t));                 /* [k][limb][N] */
+    uint64_t *c2 = malloc(sizeof(uint64_t) * n), *tmp = malloc(sizeof(uint64_t) * n);
+    for (int l = 0; l < nl; l++) or_intt(c, l, cx + (size_t)l * n, coef + (size_t)l * n);
+    for (int d = 0; d < beta; d++) {
+        const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl, nd = hi - lo;
+        uint64_t src[16]; for (int i = 0; i < nd; i++) src[i] = c->m[lo + i].q;
+        for (int T = 0; T < nt; T++) {
+            const int mod = T < nl ? T : c->nq + (T - nl);                         /* ctx modulus index of target limb */
+            const or_mod *m = &c->m[mod];
+            if (T >= lo && T < hi) memcpy(c2, cx + (size_t)T * n, sizeof(uint64_t) * n);   /* the digit's own limbs: NTT input reused */
+            else {
+                if (nd == 1) for (int j = 0; j < N; j++) tmp[j] = coef[(size_t)lo * n + (size_t)j] % m->q;   /* copied residues */
+                else for (int j = 0; j < N; j++) {
+                    uint64_t x[16]; for (int i = 0; i < nd; i++) x[i] = coef[(size_t)(lo + i) * n + (size_t)j];
+                    tmp[j] = or_basis_extend(x, src, nd, m->q);
+                }
+                or_ntt(c, mod, tmp, c2);
+            }
+            for (int k = 0; k < 2; k++) {
+                const uint64_t *e = evk + (((size_t)d * 2 + (size_t)k) * (size_t)nt + (size_t)T) * n;
+                uint64_t *a = acc + ((size_t)k * (size_t)nt + (size_t)T) * n;
+                for (int j = 0; j < N; j++) a[j] = addmod(a[j], mred(e[j], c2[j], m->q, m->qinv), m->q);
+            }
+        }
+    }
+    /* ModDownSplitNTTPQ: InvNTT the P limbs, extend {P} -> each Q limb, (acc_Q - NTT(ext)) * P^-1 */
+    uint64_t psrc[16]; for (int j = 0; j < alpha; j++) psrc[j] = c->m[c->nq + j].q;
+    uint64_t *pc = malloc(sizeof(uint64_t) * n * (size_t)alpha);
+    uint64_t *dd[2] = {d0, d1};
+    for (int k = 0; k < 2; k++) {
+        for (int j = 0; j < alpha; j++) or_intt(c, c->nq + j, acc + ((size_t)k * (size_t)nt + (size_t)(nl + j)) * n, pc + (size_t)j * n);
+        for (int l = 0; l < nl; l++) {
+            const or_mod *m = &c->m[l];
+            uint64_t pinv = 1; for (int j = 0; j < alpha; j++) pinv = mulmod(pinv, psrc[j] % m->q, m->q);
+            pinv = powmod(pinv, m->q - 2, m->q);
+            for (int j = 0; j < N; j++) { uint64_t x[16]; for (int i = 0; i < alpha; i++) x[i] = pc[(size_t)i * n + (size_t)j]; tmp[j] = or_basis_extend(x, psrc, alpha, m->q); }
+            or_ntt(c, l, tmp, tmp);
+            const uint64_t *a = acc + ((size_t)k * (size_t)nt + (size_t)l) * n;
+            for (int j = 0; j < N; j++) dd[k][(size_t)l * n + (size_t)j] = mulmod(submod(a[j], tmp[j], m->q), pinv, m->q);
+        }
+    }
+    free(coef); free(acc); free(c2); free(tmp); free(pc);
+}
+
 /* lattigo ckks.(*evaluator).RotateGal -> permuteNTT (test_run @0x5245a0, @0x5248c0): key-switch c1, add c0 to
  * the first component, permute both. */
 void or_rotate_gal_l0(const or_ctx *c, const uint64_t *c0, const uint64_t *c1, const uint32_t *perm_idx,

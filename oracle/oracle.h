@@ -67,6 +67,17 @@ void or_div_round_last_ntt(const or_ctx *, int level, const uint64_t *x, uint64_
  * d0,d1: canonical rows mod Q0 */
 void or_keyswitch_l0(const or_ctx *, const uint64_t *c1, const uint64_t *evk_b_q, const uint64_t *evk_a_q,
                      const uint64_t *evk_b_p, const uint64_t *evk_a_p, uint64_t *d0, uint64_t *d1);
+/* ---- general hybrid key switch (any level, alpha = np special primes, beta = ceil((level+1)/alpha) digits) ----
+ * rlwe.KeySwitcher.SwitchKeysInPlace for an NTT-domain input: cx = (level+1) rows; evk = [beta][2][(level+1)+np][N]
+ * rows of rlwe.SwitchingKey.Value[d][k] restricted to the Q limbs 0..level followed by the np P limbs, stored form
+ * (NTT + Montgomery); d0,d1 = (level+1) canonical rows each. Restates DecomposeSingleNTT / ring.Decomposer.
+ * DecomposeAndSplit (single-limb digits are copied, multi-limb digits go through reconstructRNS + multSum with the
+ * fp64 overflow count), the Montgomery MAC over digits, and ring.FastBasisExtender.ModDownSplitNTTPQ with
+ * ring.modUpExact over np primes. Used by the BL path (level 1, np = 2) and by everything bootstrapping needs. */
+void or_keyswitch(const or_ctx *, int level, const uint64_t *cx, const uint64_t *evk, uint64_t *d0, uint64_t *d1);
+/* the exact fast basis extension both steps use: residues x[0..n) (any representatives) modulo src[0..n) -> modulus t */
+uint64_t or_basis_extend(const uint64_t *x, const uint64_t *src, int n, uint64_t t);
+
 /* ring.modUpExact for one P prime -> one Q prime, per coefficient (exposes the fp64 overflow count) */
 uint64_t or_modup_1p(uint64_t y, uint64_t p, uint64_t q);
 

@@ -212,6 +212,10 @@ static const uint64_t Q0 = 0x80000000080001ull, Q1 = 0x1ffffffea0001ull, P0 = 0x
 static uint64_t g_seed = 0xC0FFEE;
 static int g_mode_probe, g_in_ctp, g_verbose, g_lean, g_after_ctp, g_encode_calls;
 static int g_skip_bl = 1;
+/* general key-switch trace mode (-ks N -Q q0,q1,.. -P p0,..): plants and records the first N SwitchKeysInPlace calls at ANY level */
+static int g_ks_max = 0, g_ks_calls = 0, g_nQ = 0, g_nP = 0, g_nQ_total = 0, g_nQ_full = 0, g_ks_unique = 0; static uint64_t g_Q[64], g_Pm[16];
+#define SEED_KSX(call,l)        (g_seed + ((4ull<<32) | (uint64_t)((call)*64+(l))))
+#define SEED_KSEVK(id,d,k,li)   (g_seed + ((5ull<<32) | (uint64_t)((((id)*32+(d))*2+(k))*64+(li))))
 
 /* seed lanes: tag<<32 | index */
 #define SEED_CT(p,l)      (g_seed + ((1ull<<32) | (uint64_t)((p)*8+(l))))
@@ -280,7 +284,42 @@ static uint64_t g_evk_seen[64]; static int g_nevk;
 static void ret_switchkeys(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
     ud3_t *u = ud; emit_begin("SwitchKeysInPlace"); fprintf(g_out, ", \"evk\": %lu", u->c);
     emit_poly("p0", u->a, 1); emit_poly("p1", u->b, 1); emit_end(); }
-static void on_switchkeys(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_ctp) return;
+typedef struct { uint64_t p0, p1; int level, evk, call, alpha, beta; } ksrec_t;
+static ksrec_t g_ksrec[8]; static int g_ksrec_i;
+static void ret_switchkeys_general(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
+    ksrec_t *u = ud; emit_begin("SwitchKeysInPlace.general");
+    fprintf(g_out, ", \"call\": %d, \"level\": %d, \"evk\": %d, \"alpha\": %d, \"beta\": %d", u->call, u->level, u->evk, u->alpha, u->beta);
+    emit_poly("p0", u->p0, u->level + 1); emit_poly("p1", u->p1, u->level + 1); emit_end();
+    if (g_ks_calls >= g_ks_max) { fprintf(g_out, "\n ],\n \"exit_code\": 0}\n"); fflush(g_out); kill(g_pid, SIGKILL); exit(0); }
+}
+static void on_switchkeys_general(struct user_regs_struct *r) {
+    uint64_t level = rd64(r->rsp + 0x10), cx = rd64(r->rsp + 0x18), evk = rd64(r->rsp + 0x20);
+    uint64_t p0 = rd64(r->rsp + 0x28), p1 = rd64(r->rsp + 0x30);
+    if (g_ks_calls >= g_ks_max || (int)level >= g_nQ) return;
+    /* alpha = number of special-prime limbs of THIS key (the run may hold evaluators with different P) */
+    int alpha = g_nP;
+    { uint64_t v0 = rd64(evk); int limbs0 = poly_limbs(rd64(v0)); if (g_nQ_full) alpha = limbs0 - g_nQ_full; }
+    if (alpha < 1 || alpha > g_nP) return;
+    { static int seen[64][8]; if (g_ks_unique && seen[level][alpha] >= g_ks_unique) return; seen[level][alpha]++; }
+    int id = -1; for (int i = 0; i < g_nevk; i++) if (g_evk_seen[i] == evk) id = i;
+    if (id < 0) { if (g_nevk >= 64) return; id = g_nevk; g_evk_seen[g_nevk++] = evk; }
+    const int beta = ((int)level + 1 + alpha - 1) / alpha, call = g_ks_calls++;
+    if (poly_limbs(cx) < (int)level + 1) { fprintf(stderr, "cx has %d limbs < level+1\n", poly_limbs(cx)); exit(3); }
+    for (int l = 0; l <= (int)level; l++) plant_row(poly_row(cx, l, NULL), SEED_KSX(call, l), g_Q[l]);
+    uint64_t v = rd64(evk);                                   /* Value [][2]*ring.Poly */
+    for (int d = 0; d < beta; d++) for (int k = 0; k < 2; k++) {
+        uint64_t poly = rd64(v + 16ull * (uint64_t)d + 8ull * (uint64_t)k); int limbs = poly_limbs(poly);
+        if (g_nQ_total == 0) g_nQ_total = limbs - g_nP;
+        for (int l = 0; l <= (int)level; l++) plant_row(poly_row(poly, l, NULL), SEED_KSEVK(id, d, k, l), g_Q[l]);
+        for (int j = 0; j < alpha; j++) plant_row(poly_row(poly, limbs - alpha + j, NULL), SEED_KSEVK(id, d, k, 32 + j), g_Pm[j]);
+    }
+    ksrec_t *u = &g_ksrec[g_ksrec_i++ % 8]; u->p0 = p0; u->p1 = p1; u->level = (int)level; u->evk = id; u->call = call; u->alpha = alpha; u->beta = beta;
+    fprintf(stderr, "KS call %d level %lu evk %d beta %d\n", call, level, id, beta);
+    hook_return(r, ret_switchkeys_general, u);
+}
+static void on_switchkeys(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (g_ks_max) { on_switchkeys_general(r); return; }
+    if (!g_in_ctp) return;
     uint64_t level = rd64(r->rsp + 0x10), cx = rd64(r->rsp + 0x18), evk = rd64(r->rsp + 0x20);
     uint64_t p0 = rd64(r->rsp + 0x28), p1 = rd64(r->rsp + 0x30);
     int k = -1; for (int i = 0; i < g_nevk; i++) if (g_evk_seen[i] == evk) k = i;
@@ -311,6 +350,7 @@ static void ret_encode(pid_t t, struct user_regs_struct *r, void *ud) { (void)t;
     emit_begin("EncodeCoeffs"); fprintf(g_out, ", \"call\": %lu, \"ncoeffs\": %lu, \"scale\": %.17g", u->b, u->c, pt_scale(pt));
     emit_poly("pt", pt_poly(pt), poly_limbs(pt_poly(pt))); emit_end(); }
 static void on_encode(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (g_ks_max) return;
     if (g_lean && g_encode_calls >= 24) { g_encode_calls++; return; }
     hook_return(r, ret_encode, ud_new(rd64(r->rsp + 0x28), (uint64_t)g_encode_calls++, rd64(r->rsp + 0x18))); }
 
@@ -326,6 +366,7 @@ static void ret_ctp(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (v
 }
 static int g_ctp_calls;
 static void on_ctp(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (g_ks_max) return;
     uint64_t E = r->rsp;
     uint64_t ct_in = rd64(E + 0x80), ker = rd64(E + 0x88), nker = rd64(E + 0x90), idx = rd64(E + 0xa0), nidx = rd64(E + 0xa8);
     uint64_t max_ob = rd64(E + 0xb8), norm = rd64(E + 0xc0), ecd = rd64(E + 0xc8); double out_scale = rdf64(E + 0xd0);
@@ -382,6 +423,13 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[ai], "-probe")) g_mode_probe = 1;
         else if (!strcmp(argv[ai], "-v")) g_verbose = 1;
         else if (!strcmp(argv[ai], "-lean")) g_lean = 1;
+        else if (!strcmp(argv[ai], "-ks") && ai + 1 < argc) g_ks_max = atoi(argv[++ai]);
+        else if (!strcmp(argv[ai], "-ks-unique") && ai + 1 < argc) g_ks_unique = atoi(argv[++ai]);   /* at most this many calls per (level, alpha) */
+        else if (!strcmp(argv[ai], "-nq-full") && ai + 1 < argc) g_nQ_full = atoi(argv[++ai]);       /* Q limbs of a full key row: alpha = limbs - this */
+        else if ((!strcmp(argv[ai], "-Q") || !strcmp(argv[ai], "-P")) && ai + 1 < argc) {
+            int isq = argv[ai][1] == 'Q'; char *tok = strtok(argv[++ai], ",");
+            while (tok) { if (isq) g_Q[g_nQ++] = strtoull(tok, NULL, 0); else g_Pm[g_nP++] = strtoull(tok, NULL, 0); tok = strtok(NULL, ","); }
+        }
         else if (!strcmp(argv[ai], "-keep-bl")) g_skip_bl = 0;
         else if (!strcmp(argv[ai], "-seed") && ai + 1 < argc) g_seed = strtoull(argv[++ai], NULL, 0);
         else if (!strcmp(argv[ai], "-o") && ai + 1 < argc) outpath = argv[++ai];
@@ -414,6 +462,8 @@ int main(int argc, char **argv) {
     }
     fprintf(g_out, "{\"seed\": %lu, \"N\": %lu, \"lean\": %d, \"moduli\": {\"Q0\": %lu, \"Q1\": %lu, \"P\": %lu},\n \"argv\": [", g_seed, g_N, g_lean, Q0, Q1, P0);
     for (int i = ai + 1; i < argc; i++) fprintf(g_out, "%s\"%s\"", i > ai + 1 ? ", " : "", argv[i]);
+    fprintf(g_out, "],\n \"ks_Q\": ["); for (int i = 0; i < g_nQ; i++) fprintf(g_out, "%s%lu", i ? ", " : "", g_Q[i]);
+    fprintf(g_out, "], \"ks_P\": ["); for (int i = 0; i < g_nP; i++) fprintf(g_out, "%s%lu", i ? ", " : "", g_Pm[i]);
     fprintf(g_out, "],\n \"events\": [");
     bp_add(A_CONV_THEN_PACK, on_ctp, NULL);
     bp_add(A_ENCODECOEFFS, on_encode, NULL);

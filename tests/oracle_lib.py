@@ -64,6 +64,9 @@ def lib():
         L.or_rescale_drops.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, f64p]
         L.or_div_round_last_ntt.argtypes = [C.c_void_p, C.c_int, u64p, u64p]
         L.or_keyswitch_l0.argtypes = [C.c_void_p] + [u64p] * 7
+        L.or_keyswitch.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p, u64p]
+        L.or_basis_extend.restype = C.c_uint64
+        L.or_basis_extend.argtypes = [u64p, u64p, C.c_int, C.c_uint64]
         L.or_modup_1p.restype = C.c_uint64
         L.or_modup_1p.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         L.or_rotate_gal_l0.argtypes = [C.c_void_p, u64p, u64p, u32p] + [u64p] * 6
@@ -220,6 +223,15 @@ class Oracle:
         d1 = np.empty(self.N, dtype=np.uint64)
         e = [np.ascontiguousarray(r) for r in evk4]
         self.L.or_keyswitch_l0(self.ctx, p64(np.ascontiguousarray(c1)), p64(e[0]), p64(e[1]), p64(e[2]), p64(e[3]), p64(d0), p64(d1))
+        return d0, d1
+
+    def keyswitch(self, level, cx, evk):
+        """general key switch: cx (level+1, N); evk (beta, 2, level+1+np, N) stored form -> (d0, d1) each (level+1, N)"""
+        cx = np.ascontiguousarray(cx, dtype=np.uint64).reshape(level + 1, self.N)
+        evk = np.ascontiguousarray(evk, dtype=np.uint64)
+        d0 = np.empty((level + 1, self.N), dtype=np.uint64)
+        d1 = np.empty((level + 1, self.N), dtype=np.uint64)
+        self.L.or_keyswitch(self.ctx, level, p64(cx), p64(evk.reshape(-1)), p64(d0), p64(d1))
         return d0, d1
 
     def rotate_gal_l0(self, ct, gal, evk4):

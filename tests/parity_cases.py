@@ -191,3 +191,31 @@ def case_prep_ker(ctx, O, k=3, i_batch=1, trace=None):
         for e in trace["events"]:
             if e["op"] == "pl_ker_orig":
                 assert sha_rows(got[e["i"], 0], got[e["i"], 1]) == e["pt"]["sha256"], f"pl_ker[{e['i']}] vs reference binary"
+
+
+# moduli of the reference's parameter sets beyond the conv path: [7]'s level-1 prime, two ~30-bit
+# ReLU-level primes, a 60-bit StC prime; P chain of the bootstrapping evaluator
+Q1_BL = 0x10000000006E0001
+Q_MIX = [Q0, Q1_BL, 0x3FFC0001, 0x40080001, 0x1000000000B00001]
+P_CHAIN = [0x1FFFFFFFFFE00001, 0x1FFFFFFFFFC80001, 0x1FFFFFFFFFB40001, 0x1FFFFFFFFF500001, 0x1FFFFFFFFF420001]
+
+
+def case_keyswitch_general(make_ctx, make_oracle, shapes=((1, 2), (0, 1), (2, 2), (3, 2), (4, 3), (4, 5))):
+    """hc_keyswitch vs or_keyswitch for (level, alpha): single- and multi-limb digits, several digits, targets smaller
+    than sources (30-bit limbs), and the level-0/one-prime case that must also equal the fused path's key switch."""
+    for level, alpha in shapes:
+        Q, P = Q_MIX[: level + 1], P_CHAIN[:alpha]
+        ctx, O = make_ctx(Q, P), make_oracle(Q, P)
+        beta = (level + 1 + alpha - 1) // alpha
+        cx = np.stack([splitmix_rows(900 + 7 * level + l, Q[l], N) for l in range(level + 1)])
+        evk = np.empty((beta, 2, level + 1 + alpha, N), dtype=np.uint64)
+        for d in range(beta):
+            for k in range(2):
+                for T in range(level + 1 + alpha):
+                    q = Q[T] if T <= level else P[T - level - 1]
+                    evk[d, k, T] = splitmix_rows(5000 + ((d * 2 + k) * 16 + T) * 3 + alpha, q, N)
+        ctx.swk_load(77, level, evk)
+        g0, g1 = ctx.keyswitch(77, level, cx)
+        w0, w1 = O.keyswitch(level, cx, evk)
+        eq(g0, w0, f"keyswitch d0 level={level} alpha={alpha}"); eq(g1, w1, f"keyswitch d1 level={level} alpha={alpha}")
+        ctx.close()

@@ -77,3 +77,9 @@ def test_conv_sparse_norm_and_relu_scale(env, max_ob, norm, out_scale):
 def test_conv_internal_lanes(env, max_ob, lanes, chunk):
     """one convolution split over internal lanes (channels i mod G on their own streams) must give the same bits"""
     pc.case_conv(*env, max_ob, lanes=lanes, chunk=chunk)
+
+
+def test_keyswitch_general():
+    """general hybrid key switch (BL: level 1, two P primes; bootstrapping shapes) on the emulated kernels"""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    pc.case_keyswitch_general(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), lambda Q, P: Oracle(q=Q, p=P), shapes=((1, 2), (0, 1), (2, 2), (3, 2), (4, 5)))

@@ -185,3 +185,25 @@ def test_conv_sparse_norm_and_relu_scale(env, max_ob, norm, out_scale):
 def test_conv_internal_lanes(env, max_ob, lanes, chunk):
     """one convolution split over internal lanes (channels i mod G on their own HIP streams) vs the oracle"""
     pc.case_conv(*env, max_ob, lanes=lanes, chunk=chunk)
+
+
+def test_keyswitch_general_on_gpu():
+    """8f groundwork: the general hybrid key switch (any level, alpha P primes) vs the oracle, which is itself pinned
+    against the reference binary's BL and bootstrapping key switches (tests/test_oracle_pin_keyswitch.py)"""
+    from optimal_conv_amd import Context
+    pc.case_keyswitch_general(lambda Q, P: Context(Q, P), lambda Q, P: Oracle(q=Q, p=P))
+
+
+def test_keyswitch_general_vs_reference_bl_trace():
+    """GPU vs the digests the reference binary produced for RotateNew's key switch in the BL run (level 1, two P primes)"""
+    from optimal_conv_amd import Context
+    from test_oracle_pin_keyswitch import ks_inputs
+    d = json.load(open(os.path.join(HERE, "golden", "ref_trace_ks_bl_3_0.json")))
+    Q, P = d["ks_Q"], d["ks_P"]
+    ctx = Context(Q, P)
+    for e in d["events"]:
+        cx, evk = ks_inputs(d["seed"], e["call"], e["evk"], e["level"], Q, P, d["N"])
+        ctx.swk_load(1, e["level"], evk)
+        d0, d1 = ctx.keyswitch(1, e["level"], cx)
+        assert sha_rows(*d0) == e["p0"]["sha256"] and sha_rows(*d1) == e["p1"]["sha256"], f"call {e['call']}"
+    ctx.close()
