@@ -1,8 +1,9 @@
 // conv_main.cpp — the reference's CLI surface (main.go:578-645) over the MI355X engine:
 //     conv <ker_wid 3|5|7> <i_batch 0..3> <num_tests <= 10>
 // prints the same line shapes as the reference's `conv` run (SURVEY.md 8(a)-S "CLI output contract").
-// `convReLU` and `resnet` are next-rows of the scope table and exit with a clear message;
-// the "Base Line" (BL) comparison run is likewise a next-row (8f-2) and is reported as skipped.
+// It runs the slot-packed "Base Line" (hconv_bl.cpp, scope row 8f-2) and then "Ours" (hconv_host.cpp), as main.go:639-643 does.
+// `convReLU` and `resnet` are next-rows of the scope table and exit with a clear message.
+// HCONV_SKIP_BL=1 skips the baseline half (not a reference feature; for timing "Ours" alone).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string>
@@ -32,7 +33,8 @@ int main(int argc, char **argv) {
     printf("Convolution test start! (No Bootstrapping)\n");
     printf("Ker:  %d batches:  %d widths:  %d\n", ker_wid, batchs[i_batch], widths[i_batch]);
     printf("Base Line start.\n");
-    printf("(BL slot-packed baseline: next-row 8f-2, not built in this engine - skipped)\n");
+    if (getenv("HCONV_SKIP_BL") && atoi(getenv("HCONV_SKIP_BL"))) printf("(HCONV_SKIP_BL set: baseline skipped)\n");
+    else hconv::testConv_BL_in(batchs[i_batch], widths[i_batch], ker_wid, num_tests, boot);
     printf("Ours start.\n");
     hconv::testConv_in(batchs[i_batch], widths[i_batch], ker_wid, num_tests, boot);
     return 0;

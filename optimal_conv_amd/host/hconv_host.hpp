@@ -91,6 +91,8 @@ Ciphertext conv_then_pack(Context *cont, const Ciphertext &ctxt_in, const KerPla
 Ciphertext evalConv_BN(Context *cont, const Ciphertext &ct_input, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
                        const std::vector<double> &bn_b, int in_wid, int ker_wid, int real_ib, int real_ob, int norm, double out_scale, bool trans);
 void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool boot);
+// test_BL.go:16 — the slot-packed baseline the reference runs first (hconv_bl.cpp); boot = true is not built
+void testConv_BL_in(int real_batch, int in_wid, int ker_wid, int total_test_num, bool boot);
 
 // ckks.Evaluator subset used by conv.go, one C-ABI call per limb row
 class GpuEvaluator {

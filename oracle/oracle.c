@@ -349,22 +349,30 @@ void or_keyswitch_l0(const or_ctx *c, const uint64_t *c1, const uint64_t *evk_b_
 /* lattigo ring.reconstructRNS + ring.multSum (test_run @0x4e79b0 region; SURVEY 8(a)-R "modUpExact" row):
  *   y_i = x_i * (S/s_i)^-1 mod s_i (canonical);  v = uint64( sum_i float64(y_i)/float64(s_i) )  [fp64, in limb order];
  *   result = sum_i y_i * (S/s_i mod t) - v * (S mod t)  mod t.      S = prod s_i. */
+/* constants of one extension {src} -> t: inv[i] = (S/s_i)^-1 mod s_i, hat[i] = (S/s_i) mod t, S mod t */
+typedef struct { int n; uint64_t src[16], inv[16], hat[16], S, t; } bx_pre;
+static void bx_prepare(bx_pre *b, const uint64_t *src, int n, uint64_t t) {
+    b->n = n; b->t = t; b->S = 1;
+    for (int i = 0; i < n; i++) {
+        uint64_t si = src[i], hat_mod_si = 1, hat_mod_t = 1;
+        for (int j = 0; j < n; j++) if (j != i) { hat_mod_si = mulmod(hat_mod_si, src[j] % si, si); hat_mod_t = mulmod(hat_mod_t, src[j] % t, t); }
+        b->src[i] = si; b->inv[i] = powmod(hat_mod_si, si - 2, si); b->hat[i] = hat_mod_t;
+        b->S = mulmod(b->S, si % t, t);
+    }
+}
+static inline uint64_t bx_apply(const bx_pre *b, const uint64_t *x) {
+    double vi = 0.0; uint64_t acc = 0;
+    for (int i = 0; i < b->n; i++) {
+        const uint64_t si = b->src[i], y = mulmod(x[i] % si, b->inv[i], si);
+        vi += (double)y / (double)si;
+        acc = addmod(acc, mulmod(y % b->t, b->hat[i], b->t), b->t);
+    }
+    const uint64_t v = (uint64_t)vi;
+    return submod(acc, mulmod(v % b->t, b->S, b->t), b->t);
+}
 uint64_t or_basis_extend(const uint64_t *x, const uint64_t *src, int n, uint64_t t) {
-    uint64_t y[16]; double vi = 0.0;
-    for (int i = 0; i < n; i++) {
-        uint64_t si = src[i], hat_mod_si = 1;
-        for (int j = 0; j < n; j++) if (j != i) hat_mod_si = mulmod(hat_mod_si, src[j] % si, si);
-        y[i] = mulmod(x[i] % si, powmod(hat_mod_si, si - 2, si), si);
-        vi += (double)y[i] / (double)si;
-    }
-    uint64_t v = (uint64_t)vi, acc = 0, S_mod_t = 1;
-    for (int i = 0; i < n; i++) {
-        uint64_t hat_mod_t = 1;
-        for (int j = 0; j < n; j++) if (j != i) hat_mod_t = mulmod(hat_mod_t, src[j] % t, t);
-        acc = addmod(acc, mulmod(y[i] % t, hat_mod_t, t), t);
-        S_mod_t = mulmod(S_mod_t, src[i] % t, t);
-    }
-    return submod(acc, mulmod(v % t, S_mod_t, t), t);
+    bx_pre b; bx_prepare(&b, src, n, t);
+    return bx_apply(&b, x);
 }
 
 /* general rlwe.(*KeySwitcher).SwitchKeysInPlace (NTT-domain input); see oracle.h */
@@ -385,9 +393,12 @@ void or_keyswitch(const or_ctx *c, int level, const uint64_t *cx, const uint64_t
             if (T >= lo && T < hi) memcpy(c2, cx + (size_t)T * n, sizeof(uint64_t) * n);   /* the digit's own limbs: NTT input reused */
             else {
                 if (nd == 1) for (int j = 0; j < N; j++) tmp[j] = coef[(size_t)lo * n + (size_t)j] % m->q;   /* copied residues */
-                else for (int j = 0; j < N; j++) {
-                    uint64_t x[16]; for (int i = 0; i < nd; i++) x[i] = coef[(size_t)(lo + i) * n + (size_t)j];
-                    tmp[j] = or_basis_extend(x, src, nd, m->q);
+                else {
+                    bx_pre bx; bx_prepare(&bx, src, nd, m->q);
+                    for (int j = 0; j < N; j++) {
+                        uint64_t x[16]; for (int i = 0; i < nd; i++) x[i] = coef[(size_t)(lo + i) * n + (size_t)j];
+                        tmp[j] = bx_apply(&bx, x);
+                    }
                 }
                 or_ntt(c, mod, tmp, c2);
             }
@@ -408,7 +419,8 @@ void or_keyswitch(const or_ctx *c, int level, const uint64_t *cx, const uint64_t
             const or_mod *m = &c->m[l];
             uint64_t pinv = 1; for (int j = 0; j < alpha; j++) pinv = mulmod(pinv, psrc[j] % m->q, m->q);
             pinv = powmod(pinv, m->q - 2, m->q);
-            for (int j = 0; j < N; j++) { uint64_t x[16]; for (int i = 0; i < alpha; i++) x[i] = pc[(size_t)i * n + (size_t)j]; tmp[j] = or_basis_extend(x, psrc, alpha, m->q); }
+            bx_pre bx; bx_prepare(&bx, psrc, alpha, m->q);
+            for (int j = 0; j < N; j++) { uint64_t x[16]; for (int i = 0; i < alpha; i++) x[i] = pc[(size_t)i * n + (size_t)j]; tmp[j] = bx_apply(&bx, x); }
             or_ntt(c, l, tmp, tmp);
             const uint64_t *a = acc + ((size_t)k * (size_t)nt + (size_t)l) * n;
             for (int j = 0; j < N; j++) dd[k][(size_t)l * n + (size_t)j] = mulmod(submod(a[j], tmp[j], m->q), pinv, m->q);
@@ -657,6 +669,34 @@ void or_gen_galois_key_l0(const or_ctx *c, const int64_t *sk, uint64_t galEl, ui
             uint64_t v = submod(en[j], mulmod(a[j], s_out[j], m->q), m->q);
             v = addmod(v, mulmod(pmod, s_in[j], m->q), m->q);
             b[j] = mform(v, m); a[j] = mform(a[j], m);                           /* stored in Montgomery form */
+        }
+    }
+    free(sko); free(e); free(s_in); free(s_out); free(en);
+}
+/* general version of the above (any level, np special primes, beta digits of np limbs): digit d carries P*s on the Q
+ * limbs that belong to digit d only ((Q/Q_d)*[(Q/Q_d)^-1]_{Q_d} is 1 on those limbs and 0 on the others) */
+void or_gen_swk(const or_ctx *c, const int64_t *sk, uint64_t galEl, int level, uint64_t seed, uint64_t *rows) {
+    const int N = c->N, alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha; const size_t n = (size_t)N;
+    uint64_t twoN = 2 * (uint64_t)N, ginv = 1, g = galEl % twoN;
+    for (uint64_t e = twoN - 1, b = g; e; e >>= 1, b = (b * b) % twoN) if (e & 1) ginv = (ginv * b) % twoN;
+    int64_t *sko = calloc(n, sizeof(int64_t)), *e = malloc(sizeof(int64_t) * n);
+    for (int i = 0; i < N; i++) { uint64_t t = ((uint64_t)i * ginv) % twoN; if (t < (uint64_t)N) sko[t] = sk[i]; else sko[t - (uint64_t)N] = -sk[i]; }
+    uint64_t *s_in = malloc(sizeof(uint64_t) * n), *s_out = malloc(sizeof(uint64_t) * n), *en = malloc(sizeof(uint64_t) * n);
+    for (int d = 0; d < beta; d++) {
+        gauss(seed ^ (0xE44E44ull + (uint64_t)d * 7919), N, e);
+        for (int T = 0; T < nt; T++) {
+            const int mod = T < nl ? T : c->nq + (T - nl); const or_mod *m = &c->m[mod];
+            uint64_t *b = rows + (((size_t)d * 2 + 0) * (size_t)nt + (size_t)T) * n, *a = rows + (((size_t)d * 2 + 1) * (size_t)nt + (size_t)T) * n;
+            or_fill_seeded(seed + 0x1000 + (uint64_t)(d * 64 + T), m->q, N, a);
+            or_sk_rows(c, sk, mod, s_in); or_sk_rows(c, sko, mod, s_out);
+            signed_rows(c, e, mod, en); or_ntt(c, mod, en, en);
+            uint64_t pmod = 0;
+            if (T < nl && T >= d * alpha && T < (d + 1) * alpha) { pmod = 1; for (int j = 0; j < alpha; j++) pmod = mulmod(pmod, c->m[c->nq + j].q % m->q, m->q); }
+            for (int j = 0; j < N; j++) {
+                uint64_t v = submod(en[j], mulmod(a[j], s_out[j], m->q), m->q);
+                v = addmod(v, mulmod(pmod, s_in[j], m->q), m->q);
+                b[j] = mform(v, m); a[j] = mform(a[j], m);
+            }
         }
     }
     free(sko); free(e); free(s_in); free(s_out); free(en);

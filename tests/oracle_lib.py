@@ -84,6 +84,7 @@ def lib():
         L.or_gen_sk.argtypes = [C.c_void_p, C.c_uint64, C.c_int, i64p]
         L.or_sk_rows.argtypes = [C.c_void_p, i64p, C.c_int, u64p]
         L.or_gen_galois_key_l0.argtypes = [C.c_void_p, i64p, C.c_uint64, C.c_uint64, u64p]
+        L.or_gen_swk.argtypes = [C.c_void_p, i64p, C.c_uint64, C.c_int, C.c_uint64, u64p]
         L.or_encrypt.argtypes = [C.c_void_p, i64p, u64p, C.c_int, C.c_uint64, u64p]
         L.or_decrypt_decode_l0.argtypes = [C.c_void_p, i64p, u64p, C.c_double, f64p]
         L.or_fill_seeded.argtypes = [C.c_uint64, C.c_uint64, C.c_int, u64p]
@@ -311,6 +312,13 @@ class Oracle:
     def gen_galois_key_l0(self, sk, gal, seed):
         out = np.empty((4, self.N), dtype=np.uint64)
         self.L.or_gen_galois_key_l0(self.ctx, pi64(sk), C.c_uint64(gal), C.c_uint64(seed), p64(out))
+        return out
+
+    def gen_swk(self, sk, gal, level, seed):
+        alpha = len(self.p)
+        beta = (level + 1 + alpha - 1) // alpha
+        out = np.empty((beta, 2, level + 1 + alpha, self.N), dtype=np.uint64)
+        self.L.or_gen_swk(self.ctx, pi64(sk), C.c_uint64(gal), level, C.c_uint64(seed), p64(out.reshape(-1)))
         return out
 
     def encrypt(self, sk, pt_rows, level, seed):

@@ -1,7 +1,9 @@
 """Pins the oracle's GENERAL hybrid key switch (or_keyswitch: any level, alpha special primes, multi-limb digits)
 against the reference binary: oracle/pin/gotrace.c -ks traced rlwe.(*KeySwitcher).SwitchKeysInPlace calls of the BL
 baseline run (`conv 3 0 1`: RotateNew at level 1 with the two-prime P of main.go:416-430, eval.go:123), planting the
-input polynomial and the touched switching-key rows and recording SHA-256 of both outputs."""
+input polynomial and the touched switching-key rows and recording SHA-256 of both outputs. ref_trace_ks_relu_5_1.json
+is the same over `convReLU 5 1 1` (parameter set [6]: 28 Q primes, 5 special primes): one call for every level the
+bootstrapping chain key-switches at (levels 4..23, beta = 1..5 multi-limb digits) plus the level-0 single-P call."""
 import glob
 import json
 import os
@@ -35,10 +37,13 @@ def ks_inputs(seed, call, evk_id, level, Q, P, N):
 def test_general_keyswitch_vs_reference(path):
     d = json.load(open(path))
     Q, P, seed, N = d["ks_Q"], d["ks_P"], d["seed"], d["N"]
-    O = Oracle(q=Q, p=P)
+    ctxs = {}
     for e in d["events"]:
-        assert e["op"] == "SwitchKeysInPlace.general" and e["alpha"] == len(P)
-        cx, evk = ks_inputs(seed, e["call"], e["evk"], e["level"], Q, P, N)
+        assert e["op"] == "SwitchKeysInPlace.general" and 1 <= e["alpha"] <= len(P)
+        Pa = P[:e["alpha"]]          # a run may hold evaluators with different special-prime counts (convReLU: 1 and 5)
+        assert e["beta"] == -(-(e["level"] + 1) // len(Pa))
+        O = ctxs.setdefault(len(Pa), Oracle(q=Q, p=Pa))
+        cx, evk = ks_inputs(seed, e["call"], e["evk"], e["level"], Q, Pa, N)
         d0, d1 = O.keyswitch(e["level"], cx, evk)
         assert sha_rows(*d0) == e["p0"]["sha256"], f"call {e['call']}: p0"
         assert sha_rows(*d1) == e["p1"]["sha256"], f"call {e['call']}: p1"
