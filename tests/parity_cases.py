@@ -219,3 +219,54 @@ def case_keyswitch_general(make_ctx, make_oracle, shapes=((1, 2), (0, 1), (2, 2)
         w0, w1 = O.keyswitch(level, cx, evk)
         eq(g0, w0, f"keyswitch d0 level={level} alpha={alpha}"); eq(g1, w1, f"keyswitch d1 level={level} alpha={alpha}")
         ctx.close()
+
+
+# ---------------------------------------------------------------- BL baseline (scope row 8f-2)
+class BLDevice:
+    """oracle_bl.BLOracle's interface over the C ABI: the level-1 evaluator operations hconv_bl.cpp composes
+    (hc_mul / hc_add per limb; RotateNew = hc_keyswitch + hc_add + hc_permute). `O` is only the encoder's modulus source."""
+
+    def __init__(self, ctx, O):
+        self.ctx, self.O, self.loaded = ctx, O, set()
+
+    def mul_pt(self, ct, pt):
+        return np.stack([np.stack([self.ctx.mul(l, ct[p, l], pt[l]).reshape(-1) for l in range(2)]) for p in range(2)])
+
+    def add(self, a, b):
+        return np.stack([np.stack([self.ctx.add(l, a[p, l], b[p, l]).reshape(-1) for l in range(2)]) for p in range(2)])
+
+    def add_pt(self, a, pt):
+        out = a.copy()
+        for l in range(2):
+            out[0, l] = self.ctx.add(l, a[0, l], pt[l]).reshape(-1)
+        return out
+
+    def rotate(self, ct, k, swk):
+        import oracle_bl
+        gal = oracle_bl.gal_for_rotation(k)
+        if gal not in self.loaded:
+            self.ctx.swk_load(gal, 1, swk[gal]); self.loaded.add(gal)
+        d0, d1 = self.ctx.keyswitch(gal, 1, ct[1])
+        d0 = np.stack([self.ctx.add(l, d0[l], ct[0, l]).reshape(-1) for l in range(2)])
+        return np.stack([self.ctx.permute(gal, d0), self.ctx.permute(gal, d1)])
+
+
+def case_bl_conv(make_ctx, k=3, i_batch=0, seed=5):
+    """eval.go:78-134 evalConv_BN_BL_test (one of the four calls of test_BL.go:96-107) on the oracle and on the device
+    from the same ciphertext, keys and encoded plaintexts: the result ciphertext must be bit-identical."""
+    import golden.gen_conv_csv as gen
+    import oracle_bl as ob
+    B, W, raw, x, ker, bna, bnb = gen.make_case(k, i_batch, 0)
+    blo = ob.BLOracle(); O = blo.O
+    ctx = make_ctx([ob.Q0, ob.Q1_BL], list(ob.P_BL))
+    sk = O.gen_sk(seed)
+    hb = B // 2
+    rots = sorted({(a * W + b) % ob.SLOTS for a in range(-(k // 2), k // 2 + 1) for b in range(-(k // 2), k // 2 + 1)} | {r * W * W for r in range(1, hb)})
+    swk = {ob.gal_for_rotation(r): O.gen_swk(sk, ob.gal_for_rotation(r), 1, 1000 + r) for r in rots if r % ob.SLOTS}
+    pad_in = np.zeros((W, W, hb)); pad_in[:raw, :raw, :] = x.reshape(raw, raw, B)[:, :, :hb]
+    ct = O.encrypt(sk, ob.encode_slots(O, ob.reshape_input_BL(pad_in.reshape(-1), W), 1, 2.0 ** 30), 1, 50)
+    ksep = ker.reshape(k * k, B, B)[:, :hb, :hb].reshape(-1)
+    want = ob.evalConv_BN_BL_test(blo, ct, ksep, bna[:hb], bnb[:hb], W, k, hb, hb, k // 2, swk)
+    got = ob.evalConv_BN_BL_test(BLDevice(ctx, O), ct, ksep, bna[:hb], bnb[:hb], W, k, hb, hb, k // 2, swk)
+    eq(got, want, f"BL evalConv_BN_BL_test k={k} B={B}")
+    ctx.close()

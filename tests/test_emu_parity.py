@@ -83,3 +83,28 @@ def test_keyswitch_general():
     """general hybrid key switch (BL: level 1, two P primes; bootstrapping shapes) on the emulated kernels"""
     subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
     pc.case_keyswitch_general(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), lambda Q, P: Oracle(q=Q, p=P), shapes=((1, 2), (0, 1), (2, 2), (3, 2), (4, 5)))
+
+
+def test_bl_baseline_conv():
+    """scope row 8f-2: the slot-packed baseline's evalConv_BN_BL_test on the C ABI vs the oracle, bit for bit"""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    pc.case_bl_conv(lambda Q, P: Context(Q, P, lib_path=EMU_LIB))
+
+
+def test_keyswitch_general_vs_reference_relu_trace():
+    """hc_keyswitch (28 Q + 5 P moduli loaded) vs the reference binary's digests for the bootstrapping chain's key
+    switches; the emulator replays the cheap low levels and one five-digit call, the GPU test replays all of them"""
+    import json
+    from oracle_lib import sha_rows
+    from test_oracle_pin_keyswitch import ks_inputs
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    d = json.load(open(os.path.join(HERE, "golden", "ref_trace_ks_relu_5_1.json")))
+    Q, P = d["ks_Q"], d["ks_P"]
+    ctx = Context(Q, P, lib_path=EMU_LIB)
+    for e in [d["events"][1]] + d["events"][-3:]:
+        assert e["alpha"] == 5
+        cx, evk = ks_inputs(d["seed"], e["call"], e["evk"], e["level"], Q, P, d["N"])
+        ctx.swk_load(7, e["level"], evk)
+        d0, d1 = ctx.keyswitch(7, e["level"], cx)
+        assert sha_rows(*d0) == e["p0"]["sha256"] and sha_rows(*d1) == e["p1"]["sha256"], f"level {e['level']}"
+    ctx.close()

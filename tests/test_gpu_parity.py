@@ -194,16 +194,33 @@ def test_keyswitch_general_on_gpu():
     pc.case_keyswitch_general(lambda Q, P: Context(Q, P), lambda Q, P: Oracle(q=Q, p=P))
 
 
-def test_keyswitch_general_vs_reference_bl_trace():
-    """GPU vs the digests the reference binary produced for RotateNew's key switch in the BL run (level 1, two P primes)"""
+KS_TRACES = sorted(glob.glob(os.path.join(HERE, "golden", "ref_trace_ks_*.json")))
+
+
+@pytest.mark.parametrize("path", KS_TRACES, ids=[os.path.basename(t) for t in KS_TRACES])
+def test_keyswitch_general_vs_reference_traces(path):
+    """GPU vs the digests the reference binary produced for rlwe.SwitchKeysInPlace: the BL run's RotateNew (level 1, two
+    P primes) and one call per level of the convReLU bootstrapping chain (levels 4..23, five P primes, 1..5 digits)"""
     from optimal_conv_amd import Context
     from test_oracle_pin_keyswitch import ks_inputs
-    d = json.load(open(os.path.join(HERE, "golden", "ref_trace_ks_bl_3_0.json")))
+    d = json.load(open(path))
     Q, P = d["ks_Q"], d["ks_P"]
-    ctx = Context(Q, P)
+    ctxs = {}
     for e in d["events"]:
-        cx, evk = ks_inputs(d["seed"], e["call"], e["evk"], e["level"], Q, P, d["N"])
-        ctx.swk_load(1, e["level"], evk)
-        d0, d1 = ctx.keyswitch(1, e["level"], cx)
-        assert sha_rows(*d0) == e["p0"]["sha256"] and sha_rows(*d1) == e["p1"]["sha256"], f"call {e['call']}"
-    ctx.close()
+        Pa = P[: e["alpha"]]
+        if len(Pa) not in ctxs:
+            ctxs[len(Pa)] = Context(Q, Pa)
+        ctx = ctxs[len(Pa)]
+        cx, evk = ks_inputs(d["seed"], e["call"], e["evk"], e["level"], Q, Pa, d["N"])
+        ctx.swk_load(1000 + e["call"], e["level"], evk)
+        d0, d1 = ctx.keyswitch(1000 + e["call"], e["level"], cx)
+        assert sha_rows(*d0) == e["p0"]["sha256"] and sha_rows(*d1) == e["p1"]["sha256"], f"call {e['call']} level {e['level']}"
+    for ctx in ctxs.values():
+        ctx.close()
+
+
+def test_bl_baseline_conv_on_gpu():
+    """scope row 8f-2: evalConv_BN_BL_test (eval.go:78-134) composed from C-ABI calls vs the oracle, bit for bit"""
+    from optimal_conv_amd import Context
+    pc.case_bl_conv(lambda Q, P: Context(Q, P))
+    pc.case_bl_conv(lambda Q, P: Context(Q, P), k=5, i_batch=1)

@@ -34,8 +34,16 @@ def test_conv_3_0_1(cli, tmp_path):
                 r"^Plaintext \(kernel\) preparation, Done in \S+ $", r"^\t mult time:  \S+$", r"^\t Pack time:  \S+$",
                 r"^Conv \(with BN\) Done in \S+ $", r"^Decryption Done in \S+ $", r"^ValuesTest:", r"^ValuesWant:"):
         assert re.search(pat, txt, re.M), f"missing line {pat!r} in:\n{txt}"
-    med = float(re.search(r"^MED Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M).group(1))
-    assert med >= 22.0, txt
+    # the baseline half (test_BL.go): its own parameter line, ten rotation keys, four evalConv_BN_BL_test calls
+    for pat in (r"^CKKS parameters: logN = 16, logSlots = 15, h = 192, logQP = 1582, levels = 28, scale= 2\^30\.000000, sigma = 3\.200000 $",
+                r"^Num Rotations:  10$", r"^num batches in & out:  4 ,  4$", r"^preConv done in \S+ $", r"^Evaluation total done in \S+ $"):
+        assert re.search(pat, txt, re.M), f"missing line {pat!r} in:\n{txt}"
+    assert len(re.findall(r"^preConv done in", txt, re.M)) == 4
+    assert txt.index("Base Line start.") < txt.index("Num Rotations:  10") < txt.index("Ours start.") < txt.index("Num Rotations:  0")
+    meds = [float(m) for m in re.findall(r"^MED Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M)]
+    assert len(meds) == 2, txt
+    assert meds[0] >= 20.5, txt      # reference "Base Line" at B = 4: MED 21.4 bits
+    assert meds[1] >= 22.0, txt      # reference "Ours" at B = 4: MED 25.4 bits
 
 
 @pytest.mark.parametrize("argv,msg", [(["conv", "4", "0", "1"], "Wrong kernel wid (not in 3,5,7)"),
@@ -61,7 +69,7 @@ def test_opwise_evaluator_path_equals_fused(cli, tmp_path):
     digests = []
     for extra in ({}, {"HCONV_OPWISE": "1"}):
         out = subprocess.run([cli, "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=1800,
-                             env=dict(os.environ, HCONV_SEED="99", HCONV_PRINT_DIGEST="1", **extra))
+                             env=dict(os.environ, HCONV_SEED="99", HCONV_PRINT_DIGEST="1", HCONV_SKIP_BL="1", **extra))
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append(re.search(r"^ciphertext digest: ([0-9a-f]{16})$", out.stdout, re.M).group(1))
     assert digests[0] == digests[1]
