@@ -98,7 +98,7 @@ def test_keyswitch_general_vs_reference_relu_trace():
     from oracle_lib import sha_rows
     from test_oracle_pin_keyswitch import ks_inputs
     subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
-    d = json.load(open(os.path.join(HERE, "golden", "ref_trace_ks_relu_5_1.json")))
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_trace_ks_relu_5_1.json")))
     Q, P = d["ks_Q"], d["ks_P"]
     ctx = Context(Q, P, lib_path=EMU_LIB)
     for e in [d["events"][1]] + d["events"][-3:]:
