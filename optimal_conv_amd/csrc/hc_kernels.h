@@ -662,6 +662,19 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend(const u64 *src, size
         dst[j] = hc_submod(acc, hc_mul_shoup(hc_barrett64(v, B.t, B.mu_t), B.smodt.w, B.smodt.ws, B.t), B.t);
     }
 }
+// ring.DivRoundByLastModulusNTT, general level (the fused level-1 form is loop A's a2/a3): t = InvNTT_{qL}(x_L) (canonical);
+// lift:   v = ((t + h mod qL) + (q_i - h mod q_i)) mod q_i   with h = (qL-1)/2  -- the centred remainder, to be transformed mod q_i
+// finish: out_i = (x_i - NTT_{q_i}(v)) * qL^-1 mod q_i
+__global__ __launch_bounds__(HC_TPB) void hc_k_rescale_lift(const u64 *t, u64 *v, u64 qL, u64 h, u64 qi, u64 mu_i, u64 neg_h) {
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        const u64 s = hc_csub(t[j] + h, qL);
+        v[j] = hc_barrett64(s + neg_h, qi, mu_i);
+    }
+}
+__global__ __launch_bounds__(HC_TPB) void hc_k_rescale_finish(const u64 *x, const u64 *u, u64 *out, u64 q, HcTw qlinv) {
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
+        out[j] = hc_mul_shoup(hc_submod(x[j], u[j], q), qlinv.w, qlinv.ws, q);
+}
 // acc = (first ? 0 : acc) + evk (*)_mont c2   (evk in Lattigo's stored Montgomery form => plain product), canonical
 __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac(const u64 *evk, const u64 *c2, u64 *acc, HcMod m, int first) {
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {

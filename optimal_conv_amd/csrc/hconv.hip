@@ -388,8 +388,24 @@ static int hc_loopA_run(hc_ctx *c, const u64 *ker_mont, int max_ob, int norm, u6
 // hc_div_round_last (level 1 only on this path): reuse loop A with ker = Montgomery one (c' (*) R = c')
 extern "C" int hc_div_round_last(hc_ctx *c, int level, const uint64_t *x, uint64_t *out) {
     HC_ENTER(c);
-    if (level != 1 || c->nq < 2) return hc_fail(c, HC_ERR_UNSUPPORTED, "hc_div_round_last: only level 1 -> 0 (the conv path's rescale) is implemented");
+    if (level < 1 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "hc_div_round_last: level %d outside 1..%d", level, c->nq - 1);
     if (!x || !out) return hc_fail(c, HC_ERR_ARG, "hc_div_round_last: null");
+    if (level != 1) {
+        // general level (the leveled evaluator of the convReLU chain): InvNTT of the last limb, centred lift into every
+        // lower modulus, NTT there, subtract, multiply by qL^-1. in == out is allowed (row i is read before it is written).
+        const HcMod &mL = c->mods[(size_t)level].m; const u64 qL = mL.q, h = (qL - 1) >> 1;
+        u64 *buf = nullptr; HC_HIP(c, hipMalloc((void **)&buf, (size_t)2 * HC_N * sizeof(u64)));
+        u64 *t = buf, *v = buf + HC_N;
+        int rc = hc_intt(c, level, x + (size_t)level * HC_N, t, 1);
+        for (int i = 0; i < level && !rc; i++) {
+            const HcMod &m = c->mods[(size_t)i].m;
+            rc = hc_launch(c, "rescale_lift", hc_k_rescale_lift, hc_pw_grid(HC_N), (const u64 *)t, v, qL, h, m.q, m.mu, m.q - (h % m.q));
+            if (!rc) rc = hc_ntt(c, i, v, v, 1);
+            if (!rc) rc = hc_launch(c, "rescale_finish", hc_k_rescale_finish, hc_pw_grid(HC_N), x + (size_t)i * HC_N, (const u64 *)v, out + (size_t)i * HC_N, m.q, h_pair(h_inv(qL % m.q, m.q), m.q));
+        }
+        hipStreamSynchronize(c->stream); hipFree(buf);
+        return rc;
+    }
     // Build a "ciphertext" whose polynomial 0 is x and a kernel equal to R mod q (Montgomery form of 1).
     HC_TRY(hc_ensure_tmp(c, 16));
     if (!c->ws_ctc) HC_HIP(c, hipMalloc((void **)&c->ws_ctc, 4 * HC_N * sizeof(u64)));

@@ -677,10 +677,12 @@ void or_gen_galois_key_l0(const or_ctx *c, const int64_t *sk, uint64_t galEl, ui
  * limbs that belong to digit d only ((Q/Q_d)*[(Q/Q_d)^-1]_{Q_d} is 1 on those limbs and 0 on the others) */
 void or_gen_swk(const or_ctx *c, const int64_t *sk, uint64_t galEl, int level, uint64_t seed, uint64_t *rows) {
     const int N = c->N, alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha; const size_t n = (size_t)N;
+    const int relin = galEl == 0;                 /* galEl 0: relinearisation key, s_in = s^2, s_out = s */
     uint64_t twoN = 2 * (uint64_t)N, ginv = 1, g = galEl % twoN;
     for (uint64_t e = twoN - 1, b = g; e; e >>= 1, b = (b * b) % twoN) if (e & 1) ginv = (ginv * b) % twoN;
     int64_t *sko = calloc(n, sizeof(int64_t)), *e = malloc(sizeof(int64_t) * n);
-    for (int i = 0; i < N; i++) { uint64_t t = ((uint64_t)i * ginv) % twoN; if (t < (uint64_t)N) sko[t] = sk[i]; else sko[t - (uint64_t)N] = -sk[i]; }
+    if (relin) memcpy(sko, sk, sizeof(int64_t) * n);
+    else for (int i = 0; i < N; i++) { uint64_t t = ((uint64_t)i * ginv) % twoN; if (t < (uint64_t)N) sko[t] = sk[i]; else sko[t - (uint64_t)N] = -sk[i]; }
     uint64_t *s_in = malloc(sizeof(uint64_t) * n), *s_out = malloc(sizeof(uint64_t) * n), *en = malloc(sizeof(uint64_t) * n);
     for (int d = 0; d < beta; d++) {
         gauss(seed ^ (0xE44E44ull + (uint64_t)d * 7919), N, e);
@@ -689,6 +691,7 @@ void or_gen_swk(const or_ctx *c, const int64_t *sk, uint64_t galEl, int level, u
             uint64_t *b = rows + (((size_t)d * 2 + 0) * (size_t)nt + (size_t)T) * n, *a = rows + (((size_t)d * 2 + 1) * (size_t)nt + (size_t)T) * n;
             or_fill_seeded(seed + 0x1000 + (uint64_t)(d * 64 + T), m->q, N, a);
             or_sk_rows(c, sk, mod, s_in); or_sk_rows(c, sko, mod, s_out);
+            if (relin) for (int j = 0; j < N; j++) s_in[j] = mulmod(s_in[j], s_in[j], m->q);
             signed_rows(c, e, mod, en); or_ntt(c, mod, en, en);
             uint64_t pmod = 0;
             if (T < nl && T >= d * alpha && T < (d + 1) * alpha) { pmod = 1; for (int j = 0; j < alpha; j++) pmod = mulmod(pmod, c->m[c->nq + j].q % m->q, m->q); }

@@ -119,7 +119,7 @@ void or_sk_rows(const or_ctx *, const int64_t *sk_coeffs, int mod, uint64_t *out
 /* switching key digit 0 at level 0 for galEl: rows (b_q, a_q, b_p, a_p) in stored form (NTT + Montgomery) */
 void or_gen_galois_key_l0(const or_ctx *, const int64_t *sk_coeffs, uint64_t galEl, uint64_t seed, uint64_t *evk4);
 /* general switching key for galEl at `level`: rows [beta][2][level+1+np][N] in stored form (see or_keyswitch);
- * galEl == 0 generates a relinearisation-style key from s_in = s^2 is NOT done here: rotations/conjugation only */
+ * galEl == 0 generates the relinearisation key (s_in = s^2, s_out = s) */
 void or_gen_swk(const or_ctx *, const int64_t *sk_coeffs, uint64_t galEl, int level, uint64_t seed, uint64_t *rows);
 /* sk-encryption of an encoded plaintext (coefficient domain rows for moduli 0..level) -> ct [2][level+1][N] NTT */
 void or_encrypt(const or_ctx *, const int64_t *sk_coeffs, const uint64_t *pt_coeff_rows, int level, uint64_t seed,

@@ -1,0 +1,695 @@
+"""Leveled RNS-CKKS evaluator + the `convReLU` chain (scope row 8f-1) on the pinned residue primitives.
+
+TEST INFRASTRUCTURE / oracle side. The reference's `convReLU` path (eval.go:272-607 evalConv_BNRelu_new, kind "Conv") calls a
+bootstrapper that exists only inside the un-vendored Lattigo fork (test_run: ckks.(*Bootstrapper).BootstrappConv_CtoS / _StoC);
+its DFT-matrix constants come from Go's math library and cannot be reproduced bit for bit. What is restated here:
+  * every residue operation goes through primitives that ARE pinned to the reference binary (NTT, MRed products,
+    DivRoundByLastModulusNTT, the general hybrid key switch at every level of the chain, the automorphism);
+  * the level / modulus choreography of parameter set [6]: levels 27..24 CoeffsToSlots (53-bit primes),
+    23..16 sine evaluation (55-bit, Chebyshev degree 63 of cos + 2 double angles, K = 25, message ratio 256),
+    15..5 the ReLU sign polynomials of conv.go:435-480 (30-bit), 5 keep_ctxt mask (conv.go:417-431), 3..2 SlotsToCoeffs;
+  * the reference's own Go around it: out_scale 2^43 convolution, scale *= 2^pow, evalReLU, MulByPow2, keep_ctxt, Rescale.
+The evaluator is written against a small backend interface (ntt/intt/mul/add/sub/mul_const/permute/keyswitch/div_round_last on
+residue rows) so the same sequence runs on the oracle and on the device ABI and can be compared bit for bit.
+Acceptance is (a) bit-exact oracle == device for every stage from the same inputs, (b) decrypted precision against
+max(conv, 0) comparable to what the reference binary prints for `convReLU` (AVG 8.4 / MED 11.5 bits)."""
+import math
+
+import numpy as np
+
+from oracle_lib import Oracle
+
+# ckks.DefaultBootstrapParams[6] of the fork (order verified against test_run)
+Q_SET6 = [0x80000000080001, 0x1ffffffea0001, 0x1000000000b00001, 0x1000000000ce0001, 0x3ffffe80001,
+          0x3ffc0001, 0x40080001, 0x3fac0001, 0x40720001, 0x3f820001, 0x3f760001, 0x40980001, 0x3f5a0001, 0x3f540001, 0x40b00001, 0x40c20001,
+          0x80000000440001, 0x7fffffffba0001, 0x80000000500001, 0x7fffffffaa0001, 0x800000005e0001, 0x7fffffff7e0001, 0x7fffffff380001, 0x80000000ca0001,
+          0x200000000e0001, 0x20000000140001, 0x20000000280001, 0x1fffffffd80001]
+P_SET6 = [0x1fffffffffe00001, 0x1fffffffffc80001, 0x1fffffffffb40001, 0x1fffffffff500001, 0x1fffffffff420001]
+LV_CTS_TOP, LV_SINE_TOP, LV_RELU_TOP, LV_STC_TOP = 27, 23, 15, 3
+SIN_K, SIN_DEG, SIN_DOUBLE, MSG_RATIO = 25, 63, 2, 256.0
+
+
+# ------------------------------------------------------------------ backends
+class OracleBackend:
+    """residue-row operations on oracle/liboracle.so"""
+
+    def __init__(self, O):
+        self.O, self.N = O, O.N
+        self._perm = {}
+
+    def ntt(self, mod, a): return self.O.ntt(mod, a)
+    def intt(self, mod, a): return self.O.intt(mod, a)
+    def mul(self, mod, a, b): return self.O.mul(mod, a, b)
+    def add(self, mod, a, b): return self.O.add(mod, a, b)
+    def sub(self, mod, a, b): return self.O.sub(mod, a, b)
+    def mul_const(self, mod, a, c): return self.O.mul_scalar(mod, a, c)
+
+    def permute(self, gal, rows):
+        if gal not in self._perm:
+            self._perm[gal] = self.O.permute_index(gal)
+        return np.stack([self.O.permute(self._perm[gal], r) for r in rows])
+
+    def keyswitch(self, key, cx):
+        return self.O.keyswitch(key.level, cx, key.rows)
+
+    def div_round_last(self, level, rows):
+        return self.O.div_round_last(level, rows)
+
+
+class SwitchingKey:
+    def __init__(self, gal, level, rows):
+        self.gal, self.level, self.rows = gal, level, rows
+        self.loaded = False
+
+
+class Ct:
+    """ciphertext: rows [degree+1][level+1][N] in the NTT domain, canonical residues"""
+
+    def __init__(self, rows, scale):
+        self.rows, self.scale = rows, float(scale)
+
+    @property
+    def level(self): return self.rows.shape[1] - 1
+
+    def copy(self): return Ct(self.rows.copy(), self.scale)
+
+
+# ------------------------------------------------------------------ slot encoder for any ring degree
+class Encoder:
+    """ckks.encoderComplex128 (full slots): special FFT over the rotation group 5^j (as tests/oracle_bl.py, any logN)"""
+
+    def __init__(self, logN):
+        self.N, self.n, self.M = 1 << logN, 1 << (logN - 1), 1 << (logN + 1)
+        g, rg = 1, np.empty(self.n, dtype=np.int64)
+        for i in range(self.n):
+            rg[i] = g
+            g = g * 5 % self.M
+        self.rot_group = rg
+        ang = 2 * 3.141592653589793 * np.arange(self.M + 1, dtype=np.float64) / float(self.M)
+        self.roots = np.cos(ang) + 1j * np.sin(ang)
+        bits = logN - 1
+        idx = np.arange(self.n)
+        br = np.zeros(self.n, dtype=np.int64)
+        for b in range(bits):
+            br |= ((idx >> b) & 1) << (bits - 1 - b)
+        self.br = br
+
+    def inv_stage_twiddles(self, ln):
+        lenh, lenq = ln >> 1, ln << 2
+        return self.roots[(lenq - (self.rot_group[:lenh] % lenq)) * (self.M // lenq)]
+
+    def fwd_stage_twiddles(self, ln):
+        lenh, lenq = ln >> 1, ln << 2
+        return self.roots[(self.rot_group[:lenh] % lenq) * (self.M // lenq)]
+
+    def invfft(self, values):
+        v = np.array(values, dtype=np.complex128)
+        n, ln = self.n, self.n
+        while ln >= 2:
+            lenh = ln >> 1
+            w = self.inv_stage_twiddles(ln)
+            blk = v.reshape(n // ln, ln)
+            a, b = blk[:, :lenh].copy(), blk[:, lenh:].copy()
+            blk[:, :lenh] = a + b
+            blk[:, lenh:] = (a - b) * w
+            ln >>= 1
+        return (v / complex(float(n), 0))[self.br]
+
+    def fft(self, values):
+        v = np.array(values, dtype=np.complex128)[self.br]
+        n, ln = self.n, 2
+        while ln <= n:
+            lenh = ln >> 1
+            w = self.fwd_stage_twiddles(ln)
+            blk = v.reshape(n // ln, ln)
+            a, b = blk[:, :lenh].copy(), blk[:, lenh:] * w
+            blk[:, :lenh] = a + b
+            blk[:, lenh:] = a - b
+            ln <<= 1
+        return v
+
+    def slots_to_coeffs(self, values):
+        v = self.invfft(values)
+        return np.concatenate([v.real, v.imag])
+
+    def coeffs_to_slots(self, cf):
+        c = np.asarray(cf, dtype=np.float64)
+        return self.fft(c[: self.n] + 1j * c[self.n:])
+
+
+# ------------------------------------------------------------------ the evaluator
+class Ckks:
+    def __init__(self, logN=16, Q=Q_SET6, P=P_SET6, h=192, seed=1, backend=None, oracle=None):
+        self.logN, self.N, self.n, self.M = logN, 1 << logN, 1 << (logN - 1), 1 << (logN + 1)
+        self.Q, self.P = list(Q), list(P)
+        self.O = oracle if oracle is not None else Oracle(logN=logN, q=self.Q, p=self.P)      # key generation, encoding, decryption
+        self.be = backend if backend is not None else OracleBackend(self.O)
+        self.enc = Encoder(logN)
+        self.seed = seed
+        self.sk = self.O.gen_sk(seed, h)
+        self.keys = {}
+        self._mono_i = {}
+        self.counters = {"keyswitch": 0, "mul_relin": 0, "rotate": 0, "rescale": 0}
+
+    # ---- keys
+    def key(self, gal, level):
+        k = self.keys.get((gal, level))
+        if k is None:
+            k = SwitchingKey(gal, level, self.O.gen_swk(self.sk, gal, level, 7000003 * self.seed + 131 * gal + level))
+            self.keys[(gal, level)] = k
+        return k
+
+    def gal_rot(self, k): return pow(5, k % self.M, self.M)
+
+    # ---- encode / encrypt / decrypt
+    def encode_ntt(self, slots, level, scale):
+        rows = self.O.encode_coeffs(self.enc.slots_to_coeffs(slots), scale, list(range(level + 1)))
+        return np.stack([self.O.ntt(l, rows[l]) for l in range(level + 1)])
+
+    def encode_coeffs_ntt(self, cf, level, scale):
+        rows = self.O.encode_coeffs(np.asarray(cf, dtype=np.float64), scale, list(range(level + 1)))
+        return np.stack([self.O.ntt(l, rows[l]) for l in range(level + 1)])
+
+    def encrypt_coeffs(self, cf, level, scale, seed=99):
+        rows = self.O.encode_coeffs(np.asarray(cf, dtype=np.float64), scale, list(range(level + 1)))
+        return Ct(self.O.encrypt(self.sk, rows, level, seed), scale)
+
+    def encrypt_slots(self, slots, level, scale, seed=99):
+        return self.encrypt_coeffs(self.enc.slots_to_coeffs(slots), level, scale, seed)
+
+    def decrypt_coeffs(self, ct):
+        """float coefficients of the plaintext / scale; uses the two lowest limbs (CRT over Q0*Q1) or limb 0 alone"""
+        O, N = self.O, self.N
+        use = min(ct.level, 1) + 1
+        rows = []
+        for l in range(use):
+            s = np.empty(N, dtype=np.uint64)
+            import ctypes as C
+            O.L.or_sk_rows(O.ctx, self.sk.ctypes.data_as(C.POINTER(C.c_int64)), l, s.ctypes.data_as(C.POINTER(C.c_uint64)))
+            acc = ct.rows[0, l]
+            sp = s
+            for d in range(1, ct.rows.shape[0]):
+                acc = O.add(l, acc, O.mul(l, ct.rows[d, l], sp))
+                sp = O.mul(l, sp, s)
+            rows.append(O.intt(l, acc))
+        if use == 1:
+            q0 = self.Q[0]
+            x = rows[0].astype(np.int64)
+            x = np.where(rows[0] > q0 // 2, x - q0, x)
+            return x.astype(np.float64) / ct.scale
+        q0, q1 = self.Q[0], self.Q[1]
+        inv = pow(q0, -1, q1)
+        a0, a1 = rows[0].astype(object), rows[1].astype(object)
+        x = a0 + q0 * (((a1 - a0) * inv) % q1)
+        QQ = q0 * q1
+        x = np.where(x > QQ // 2, x - QQ, x)
+        return np.array([float(v) for v in x]) / ct.scale
+
+    def decrypt_slots(self, ct):
+        return self.enc.coeffs_to_slots(self.decrypt_coeffs(ct))
+
+    # ---- level / scale bookkeeping
+    def drop_to(self, ct, level):
+        assert level <= ct.level
+        return ct if level == ct.level else Ct(np.ascontiguousarray(ct.rows[:, : level + 1]), ct.scale)
+
+    def _align(self, a, b):
+        l = min(a.level, b.level)
+        return self.drop_to(a, l), self.drop_to(b, l)
+
+    @staticmethod
+    def _same_scale(a, b):
+        assert abs(a / b - 1.0) < 1e-9, (a, b)
+
+    # ---- linear operations
+    def _rowwise(self, fn, a_rows, b_rows):
+        return np.stack([fn(l, a_rows[l], b_rows[l]).reshape(-1) for l in range(a_rows.shape[0])])
+
+    def add(self, a, b):
+        a, b = self._align(a, b)
+        self._same_scale(a.scale, b.scale)
+        deg = max(a.rows.shape[0], b.rows.shape[0])
+        out = []
+        for d in range(deg):
+            if d < a.rows.shape[0] and d < b.rows.shape[0]:
+                out.append(self._rowwise(self.be.add, a.rows[d], b.rows[d]))
+            else:
+                out.append((a.rows[d] if d < a.rows.shape[0] else b.rows[d]).copy())
+        return Ct(np.stack(out), a.scale)
+
+    def sub(self, a, b):
+        a, b = self._align(a, b)
+        self._same_scale(a.scale, b.scale)
+        assert a.rows.shape[0] == b.rows.shape[0]
+        return Ct(np.stack([self._rowwise(self.be.sub, a.rows[d], b.rows[d]) for d in range(a.rows.shape[0])]), a.scale)
+
+    def mul_const_int(self, ct, k):
+        """every coefficient times the integer k (sign allowed); the scale label is the caller's business"""
+        rows = np.stack([np.stack([self.be.mul_const(l, ct.rows[d, l], k % self.Q[l]).reshape(-1) for l in range(ct.level + 1)])
+                         for d in range(ct.rows.shape[0])])
+        return Ct(rows, ct.scale)
+
+    def add_const_int(self, ct, k):
+        """adds the constant polynomial k: every NTT coefficient of c0 += k"""
+        rows = ct.rows.copy()
+        for l in range(ct.level + 1):
+            rows[0, l] = self.be.add(l, ct.rows[0, l], np.full(self.N, k % self.Q[l], dtype=np.uint64)).reshape(-1)
+        return Ct(rows, ct.scale)
+
+    def add_const(self, ct, c):
+        return self.add_const_int(ct, int(round(c * ct.scale)))
+
+    def mul_plain(self, ct, pt_rows, pt_scale):
+        L = ct.level
+        rows = np.stack([np.stack([self.be.mul(l, ct.rows[d, l], pt_rows[l]).reshape(-1) for l in range(L + 1)]) for d in range(ct.rows.shape[0])])
+        return Ct(rows, ct.scale * pt_scale)
+
+    def mul_by_i(self, ct):
+        """times X^(N/2), i.e. every slot times i (ckks.evaluator.MultByi); exact, no level, no scale change"""
+        rows = []
+        for l in range(ct.level + 1):
+            if l not in self._mono_i:
+                m = np.zeros(self.N, dtype=np.uint64)
+                m[self.N // 2] = 1
+                self._mono_i[l] = self.O.ntt(l, m)
+        return Ct(np.stack([np.stack([self.be.mul(l, ct.rows[d, l], self._mono_i[l]).reshape(-1) for l in range(ct.level + 1)])
+                            for d in range(ct.rows.shape[0])]), ct.scale)
+
+    def neg(self, ct):
+        z = Ct(np.zeros_like(ct.rows), ct.scale)
+        return self.sub(z, ct)
+
+    # ---- multiplication, rescale
+    def mul_relin(self, a, b):
+        a, b = self._align(a, b)
+        L = a.level
+        be = self.be
+        d0 = np.stack([be.mul(l, a.rows[0, l], b.rows[0, l]).reshape(-1) for l in range(L + 1)])
+        d1 = np.stack([be.add(l, be.mul(l, a.rows[0, l], b.rows[1, l]), be.mul(l, a.rows[1, l], b.rows[0, l])).reshape(-1) for l in range(L + 1)])
+        d2 = np.stack([be.mul(l, a.rows[1, l], b.rows[1, l]).reshape(-1) for l in range(L + 1)])
+        k0, k1 = be.keyswitch(self.key(0, L), d2)
+        self.counters["keyswitch"] += 1
+        self.counters["mul_relin"] += 1
+        c0 = np.stack([be.add(l, d0[l], k0[l]).reshape(-1) for l in range(L + 1)])
+        c1 = np.stack([be.add(l, d1[l], k1[l]).reshape(-1) for l in range(L + 1)])
+        return Ct(np.stack([c0, c1]), a.scale * b.scale)
+
+    def rescale(self, ct):
+        """one DivRoundByLastModulusNTT: level -= 1, scale /= q_level"""
+        L = ct.level
+        assert L >= 1
+        self.counters["rescale"] += 1
+        rows = np.stack([self.be.div_round_last(L, ct.rows[d]) for d in range(ct.rows.shape[0])])
+        return Ct(rows, ct.scale / float(self.Q[L]))
+
+    # ---- automorphisms
+    def _galois(self, ct, gal):
+        L = ct.level
+        be = self.be
+        d0, d1 = be.keyswitch(self.key(gal, L), ct.rows[1])
+        self.counters["keyswitch"] += 1
+        self.counters["rotate"] += 1
+        d0 = np.stack([be.add(l, d0[l], ct.rows[0, l]).reshape(-1) for l in range(L + 1)])
+        return Ct(np.stack([be.permute(gal, d0), be.permute(gal, np.ascontiguousarray(d1))]), ct.scale)
+
+    def rotate(self, ct, k):
+        k %= self.n
+        return ct if k == 0 else self._galois(ct, self.gal_rot(k))
+
+    def conjugate(self, ct):
+        return self._galois(ct, self.M - 1)
+
+    # ---- bootstrapping: modulus raise
+    def mod_raise(self, ct, level):
+        """level-0 ciphertext -> `level`: centred lift of each coefficient mod Q0 (ckks.(*Bootstrapper).modUp)"""
+        assert ct.level == 0
+        q0 = self.Q[0]
+        out = []
+        for d in range(2):
+            cf = self.be.intt(0, ct.rows[d, 0]).reshape(-1)
+            neg = cf > q0 // 2
+            rows = []
+            for l in range(level + 1):
+                q = self.Q[l]
+                r = cf % np.uint64(q)
+                rn = (np.uint64(q) - ((np.uint64(q0) - cf) % np.uint64(q))) % np.uint64(q)
+                rows.append(self.be.ntt(l, np.where(neg, rn, r).astype(np.uint64)).reshape(-1))
+            out.append(np.stack(rows))
+        return Ct(np.stack(out), ct.scale)
+
+    # ---- linear transforms (diagonal form, baby-step giant-step)
+    def matmul_diag(self, M2, M1):
+        """(M2 . M1) in diagonal form; each M is {rotation k: complex vector of n}"""
+        out = {}
+        for k2, d2 in M2.items():
+            for k1, d1 in M1.items():
+                k = (k1 + k2) % self.n
+                t = d2 * np.roll(d1, -k2)
+                out[k] = out[k] + t if k in out else t
+        return {k: v for k, v in out.items() if np.any(v != 0)}
+
+    def bsgs_split(self, ks):
+        best = None
+        n1 = 1
+        while n1 <= self.n:
+            babies = {k % n1 for k in ks}
+            giants = {k - k % n1 for k in ks}
+            cost = len(babies - {0}) + len(giants - {0})
+            if best is None or cost < best[0]:
+                best = (cost, n1)
+            n1 <<= 1
+        return best[1]
+
+    def linear_transform(self, ct, diags, pt_scale):
+        """sum_k diag_k (.) rot_k(ct), plaintext diagonals encoded at ct's level with scale pt_scale; no rescale here"""
+        L = ct.level
+        ks = sorted(diags)
+        n1 = self.bsgs_split(ks)
+        rots = {b: self.rotate(ct, b) for b in sorted({k % n1 for k in ks})}
+        acc = None
+        for g in sorted({k - k % n1 for k in ks}):
+            inner = None
+            for k in ks:
+                if k - k % n1 != g:
+                    continue
+                pt = self.encode_ntt(np.roll(diags[k], g), L, pt_scale)
+                term = self.mul_plain(rots[k % n1], pt, pt_scale)
+                inner = term if inner is None else self.add(inner, term)
+            inner = self.rotate(inner, g)
+            acc = inner if acc is None else self.add(acc, inner)
+        return acc
+
+    def dft_stage(self, ln, inverse):
+        """one radix-2 stage of the encoder's special (i)FFT as a 3-diagonal matrix (no bit reversal)"""
+        n, lenh = self.n, ln >> 1
+        j = np.arange(n) % ln
+        first = j < lenh
+        if inverse:       # out[p] = v[p] + v[p+lenh] (first half) ; (v[p-lenh] - v[p]) * w[j-lenh] (second half)
+            w = self.enc.inv_stage_twiddles(ln)
+            wj = w[(j - lenh) % lenh] if lenh > 0 else w
+            d0 = np.where(first, 1.0 + 0j, -wj)
+            dp = np.where(first, 1.0 + 0j, 0j)
+            dm = np.where(first, 0j, wj)
+        else:             # a = v[p], b = v[p+lenh] * w[j]: out[p] = a + b ; out[p+lenh] = a - b
+            w = self.enc.fwd_stage_twiddles(ln)
+            wj = w[j % lenh]
+            d0 = np.where(first, 1.0 + 0j, -wj)
+            dp = np.where(first, wj, 0j)
+            dm = np.where(first, 0j, 1.0 + 0j)
+        M = {0: d0}
+        for k, d in ((lenh % n, dp), ((-lenh) % n, dm)):
+            M[k] = M[k] + d if k in M else d
+        return M
+
+    def dft_groups(self, inverse, group_sizes, constant):
+        """the log2(n) stages in application order, merged into len(group_sizes) matrices; `constant` spread evenly"""
+        logn = self.logN - 1
+        lens = [self.n >> s for s in range(logn)] if inverse else [2 << s for s in range(logn)]
+        assert sum(group_sizes) == logn
+        groups, pos = [], 0
+        c = constant ** (1.0 / len(group_sizes))
+        for gs in group_sizes:
+            M = None
+            for ln in lens[pos: pos + gs]:
+                S = self.dft_stage(ln, inverse)
+                M = S if M is None else self.matmul_diag(S, M)
+            groups.append({k: v * c for k, v in M.items()})
+            pos += gs
+        return groups
+
+    # ---- polynomial evaluation (baby-step giant-step with exact scale management, depth ceil(log2(deg+1)))
+    def _power(self, T, i, cheby):
+        if i in T:
+            return T[i]
+        a, b = (i + 1) // 2, i // 2
+        A, B = self._power(T, a, cheby), self._power(T, b, cheby)
+        t = self.rescale(self.mul_relin(A, B))
+        if cheby:         # T_i = 2 T_a T_b - T_|a-b|
+            t = self.add(t, t)
+            c = a - b
+            if c == 0:
+                t = self.add_const(t, -1.0)
+            else:
+                Tc = self._power(T, c, cheby)
+                t, Tc2 = self._align(t, Tc)
+                t = self.sub(t, self._match_scale(Tc2, t.scale))
+        T[i] = t
+        return t
+
+    def _match_scale(self, ct, scale):
+        """ciphertext whose scale label differs from `scale` by a rounding-level factor: relabel (error << 2^-40)"""
+        assert abs(ct.scale / scale - 1.0) < 1e-6, (ct.scale, scale)
+        return Ct(ct.rows, scale)
+
+    def _plan_level(self, T_levels, coeffs, log_split, lead, cheby):
+        """level at which _eval_rec returns, without touching data (mirrors its control flow)"""
+        deg = len(coeffs) - 1
+        while deg > 0 and coeffs[deg] == 0:
+            deg -= 1
+        if deg < (1 << log_split):
+            if lead and log_split > 1 and deg > (1 << (log_split - 1)):
+                ld = deg.bit_length()
+                return self._plan_level(T_levels, coeffs[: deg + 1], ld >> 1, True, cheby)
+            lv = min([T_levels[i] for i in range(1, deg + 1) if coeffs[i] != 0] + [T_levels[1]])
+            return lv - 1
+        g = 1 << log_split
+        while g * 2 <= deg:
+            g *= 2
+        cq, cr = self._split(coeffs[: deg + 1], g, cheby)
+        lq = self._plan_level(T_levels, cq, log_split, lead, cheby)
+        lr = self._plan_level(T_levels, cr, log_split, False, cheby)
+        return min(min(lq, T_levels[g]) - 1, lr)
+
+    @staticmethod
+    def _split(coeffs, g, cheby):
+        """p = q * X_g + r (X_g = x^g or T_g)"""
+        deg = len(coeffs) - 1
+        cr = list(coeffs[:g])
+        cq = [0.0] * (deg - g + 1)
+        if not cheby:
+            cq = list(coeffs[g:])
+        else:             # T_(g+j) = 2 T_g T_j - T_(g-j)
+            cq[0] = coeffs[g]
+            for j in range(1, deg - g + 1):
+                cq[j] = 2.0 * coeffs[g + j]
+                cr[g - j] -= coeffs[g + j]
+        return cq, cr
+
+    def _eval_rec(self, T, T_levels, coeffs, log_split, lead, cheby, target_scale):
+        deg = len(coeffs) - 1
+        while deg > 0 and coeffs[deg] == 0:
+            deg -= 1
+        coeffs = list(coeffs[: deg + 1])
+        if deg < (1 << log_split):
+            if lead and log_split > 1 and deg > (1 << (log_split - 1)):
+                ld = deg.bit_length()
+                return self._eval_rec(T, T_levels, coeffs, ld >> 1, True, cheby, target_scale)
+            # leaf: sum_i c_i X_i at the lowest level among the X_i used, integer constants, one rescale
+            used = [i for i in range(1, deg + 1) if coeffs[i] != 0]
+            lv = min([T_levels[i] for i in used] + [T_levels[1]])
+            pre = target_scale * float(self.Q[lv])
+            acc = None
+            for i in used:
+                Xi = self.drop_to(self._power(T, i, cheby), lv)
+                term = self.mul_const_int(Xi, int(round(coeffs[i] * pre / Xi.scale)))
+                term.scale = pre
+                acc = term if acc is None else self.add(acc, term)
+            if acc is None:
+                acc = Ct(np.zeros((2, lv + 1, self.N), dtype=np.uint64), pre)
+            if coeffs[0] != 0:
+                acc = self.add_const_int(acc, int(round(coeffs[0] * pre)))
+            out = self.rescale(acc)
+            return self._match_scale(out, target_scale)
+        g = 1 << log_split
+        while g * 2 <= deg:
+            g *= 2
+        cq, cr = self._split(coeffs, g, cheby)
+        Xg = self._power(T, g, cheby)
+        lq = self._plan_level(T_levels, cq, log_split, lead, cheby)
+        lmul = min(lq, Xg.level)
+        q_target = target_scale * float(self.Q[lmul]) / Xg.scale
+        resq = self._eval_rec(T, T_levels, cq, log_split, lead, cheby, q_target)
+        assert resq.level == lq, (resq.level, lq)
+        prod = self.rescale(self.mul_relin(resq, Xg))
+        prod = self._match_scale(prod, target_scale)
+        if any(c != 0 for c in cr):
+            resr = self._eval_rec(T, T_levels, cr, log_split, False, cheby, target_scale)
+            prod = self.add(prod, resr)
+        return prod
+
+    def eval_poly(self, ct, coeffs, target_scale, cheby=False):
+        """p(ct) for p in the monomial (cheby=False) or Chebyshev basis on [-1,1]; consumes ceil(log2(deg+1)) levels"""
+        coeffs = [float(c) for c in coeffs]
+        deg = len(coeffs) - 1
+        log_deg = deg.bit_length()
+        log_split = log_deg >> 1
+        T = {1: ct}
+        need = list(range(2, 1 << log_split)) + [1 << i for i in range(log_split, log_deg)]
+        for i in need:
+            self._power(T, i, cheby)
+        for i in range(2, 1 << max(log_split, 1)):
+            self._power(T, i, cheby)
+        T_levels = {i: t.level for i, t in T.items()}
+        # the lead leaf may re-split with a smaller baby set: its powers exist already (they are sub-products)
+        return self._eval_rec(T, _Levels(self, T, cheby), coeffs, log_split, True, cheby, target_scale)
+
+
+class _Levels(dict):
+    """levels of power-basis elements, computing missing ones on demand (needed when the lead leaf re-splits)"""
+
+    def __init__(self, ck, T, cheby):
+        super().__init__()
+        self.ck, self.T, self.cheby = ck, T, cheby
+
+    def __missing__(self, i):
+        return self.ck._power(self.T, i, self.cheby).level
+
+
+def cheby_coeffs(f, deg):
+    """Chebyshev interpolation coefficients of f on [-1,1] (nodes of T_(deg+1))"""
+    m = deg + 1
+    k = np.arange(m)
+    u = np.cos(np.pi * (k + 0.5) / m)
+    fu = f(u)
+    c = np.array([2.0 / m * np.sum(fu * np.cos(j * np.pi * (k + 0.5) / m)) for j in range(m)])
+    c[0] /= 2
+    return c
+
+
+# ------------------------------------------------------------------ the convReLU chain (eval.go:272-607, kind "Conv")
+RELU1 = [0.0, 10.8541842577442, 0.0, -62.2833925211098, 0.0, 114.369227820443, 0.0, -62.8023496973074]            # conv.go:442
+RELU2 = [0.0, 4.13976170985111, 0.0, -5.84997640211679, 0.0, 2.94376255659280, 0.0, -0.454530437460152]             # conv.go:445
+RELU3 = [0.0, 3.29956739043733, 0.0, -7.84227260291355, 0.0, 12.8907764115564, 0.0, -12.4917112584486, 0.0, 6.94167991428074, 0.0,
+         -2.04298067399942, 0.0, 0.246407138926031]                                                                  # conv.go:452
+
+
+def reverse_bits(i, nbits):
+    r = 0
+    for b in range(nbits):
+        r |= ((i >> b) & 1) << (nbits - 1 - b)
+    return r
+
+
+def gen_keep_vec(vec_size, in_wid, kp_wid, ul):
+    """rot_util.go:141-174: 0/1 slot mask keeping rows/columns < kp_wid; slot order = bit-reversed coefficient order"""
+    logN = (2 * vec_size - 1).bit_length()
+    batch = 2 * vec_size // (in_wid * in_wid)
+    assert kp_wid >= in_wid // 2, "keep width too small. less than in_wid/2"
+    idx = np.zeros(vec_size, dtype=np.int64)
+    rows = in_wid // 2 if ul == 0 else kp_wid - in_wid // 2
+    i, j, b = np.meshgrid(np.arange(rows), np.arange(kp_wid), np.arange(batch), indexing="ij")
+    pos = (in_wid * batch * i + batch * j + b).reshape(-1)
+    rev = np.zeros_like(pos)
+    for bit in range(logN - 1):
+        rev |= ((pos >> bit) & 1) << (logN - 2 - bit)
+    idx[rev] = 1
+    return idx
+
+
+class Bootstrapper:
+    """my restatement of the fork's BootstrappConv_CtoS / BootstrappConv_StoC for full slots (log_sparse = 0): same modulus
+    chain and level assignment as parameter set [6]; DFT matrices from the encoder's own butterflies (no bit reversal, so
+    slot p holds coefficient bitrev(p)); sine by Chebyshev interpolation of cos(2*pi*(K*u - 1/4)/2^r) and r double angles."""
+
+    def __init__(self, C, cts_groups=(4, 4, 4, 3), stc_groups=(5, 5, 5)):
+        self.C = C
+        logn = C.logN - 1
+        cts_groups, stc_groups = self._fit(cts_groups, logn), self._fit(stc_groups, logn)
+        # CoeffsToSlots: (1/n) * prod(stages), times 1/2 (real/imaginary extraction) and 1/K (Chebyshev argument in [-1,1])
+        self.cts = C.dft_groups(True, cts_groups, 1.0 / (2.0 * C.n * SIN_K))
+        self.stc = C.dft_groups(False, stc_groups, 1.0)
+        f = lambda u: np.cos(2.0 * np.pi * (SIN_K * u - 0.25) / float(1 << SIN_DOUBLE))
+        self.sine = cheby_coeffs(f, SIN_DEG)
+
+    @staticmethod
+    def _fit(groups, logn):
+        g = list(groups)
+        while sum(g) > logn:                       # small test rings: shrink the largest group
+            g[g.index(max(g))] -= 1
+        assert sum(g) == logn and min(g) >= 1
+        return g
+
+    def ctos(self, ct0):
+        """level-0 coefficient-encoded ciphertext (value = coeff/scale in [-1,1], |coeff| <= Q0/MSG_RATIO) -> two
+        ciphertexts at level LV_RELU_TOP, scale 2^30, slot p of the first = value of coefficient bitrev(p), of the
+        second = coefficient n + bitrev(p)"""
+        C = self.C
+        q0 = float(C.Q[0])
+        msg_scale = ct0.scale
+        ct = C.mod_raise(ct0, LV_CTS_TOP)
+        ct.scale = q0                                            # slot values are now t'/Q0 = I + msg/Q0, |.| <= K
+        for G in self.cts:
+            ct = C.rescale(C.linear_transform(ct, G, float(C.Q[ct.level])))
+        assert ct.level == LV_SINE_TOP
+        cc = C.conjugate(ct)
+        parts = [C.add(ct, cc), C.mul_by_i(C.sub(cc, ct))]       # (w + conj w), -i (w - conj w); the 1/2 is in the matrices
+        # scale plan: after the double angles the value is sin(2 pi x) ~ 2 pi msg/Q0; relabelled by c_m it must sit at 2^30
+        c_m = q0 / (2.0 * np.pi * msg_scale)
+        s_out = 2.0 ** 30 * c_m
+        lv = LV_SINE_TOP - (SIN_DEG.bit_length())               # level after the Chebyshev evaluation
+        s = s_out
+        for r in range(SIN_DOUBLE):
+            s = math.sqrt(s * float(C.Q[LV_RELU_TOP + 1 + r]))
+        out = []
+        for p in parts:
+            c = C.eval_poly(p, self.sine, s, cheby=True)
+            assert c.level == lv, (c.level, lv)
+            for r in range(SIN_DOUBLE):
+                c = C.mul_relin(c, c)
+                c = C.add(c, c)
+                c = C.rescale(C.add_const(c, -1.0))
+            assert c.level == LV_RELU_TOP
+            c.scale = c.scale / c_m                               # value *= c_m: now msg/msg_scale
+            out.append(c)
+        return out
+
+    def stoc(self, ct_re, ct_im):
+        """slots (bit-reversed coefficient order) -> coefficients; input level >= LV_STC_TOP at scale ~2^60, output level 1"""
+        C = self.C
+        ct = C.add(ct_re, C.mul_by_i(ct_im)) if ct_im is not None else ct_re
+        ct = C.drop_to(ct, LV_STC_TOP)
+        G = self.stc
+        # level 3 carries all but the last matrix (their plaintext scales multiply to q3), level 2 the last at scale 2^30
+        first = G[:-1]
+        sc = float(C.Q[LV_STC_TOP]) ** (1.0 / len(first))
+        for M in first:
+            ct = C.linear_transform(ct, M, sc)
+        ct = C.rescale(ct)
+        ct = C.rescale(C.linear_transform(ct, G[-1], 2.0 ** 30))
+        return ct
+
+
+def eval_relu(C, ct_in, alpha):
+    """conv.go:435-480: x * (b*sign(x) + a) with the three composed minimax sign polynomials; returns level-5, scale^2"""
+    a, b = (alpha + 1) / 2.0, (1 - alpha) / 2.0
+    sc = 2.0 ** 30
+    s = C.eval_poly(ct_in, RELU1, sc)
+    s = C.eval_poly(s, RELU2, sc)
+    s = C.eval_poly(s, [c * b for c in RELU3], sc)
+    s = C.add_const(s, a)
+    return C.mul_relin(s, C.drop_to(ct_in, s.level))             # no rescale (conv.go:475-477)
+
+
+def keep_ctxt(C, ct, idx):
+    """conv.go:417-431: multiply by the 0/1 mask encoded at scale q_level, rescale once"""
+    L = ct.level
+    pt = C.encode_ntt(idx.astype(np.complex128), L, float(C.Q[L]))
+    return C.rescale(C.mul_plain(ct, pt, float(C.Q[L])))
+
+
+def conv_relu_tail(C, btp, ct_conv, alpha, pow_, in_wid, kp_wid, stages=None):
+    """eval.go:437-565 for kind "Conv", log_sparse 0, iter 2: ct_conv is the level-0 output of evalConv_BN at out_scale
+    2^(round(log2 Q0) - (pow+8)); returns the level-1, scale-2^30 coefficient-encoded ReLU(conv)"""
+    ct = Ct(ct_conv.rows, ct_conv.scale * 2.0 ** pow_)           # eval.go:437
+    boots = btp.ctos(ct)                                         # eval.go:450
+    if stages is not None:
+        stages["ctos"] = [b.copy() for b in boots]
+    keep = []
+    for ul in range(2):
+        r = eval_relu(C, boots[ul], alpha)                       # eval.go:473
+        r = C.mul_const_int(r, 1 << int(pow_))                   # MulByPow2 (eval.go:474)
+        if stages is not None:
+            stages.setdefault("relu", []).append(r.copy())
+        keep.append(keep_ctxt(C, r, gen_keep_vec(C.N // 2, in_wid, kp_wid, ul)))     # eval.go:534
+    out = btp.stoc(keep[0], keep[1])                             # eval.go:550
+    return out                                                   # Rescale (eval.go:564) is a no-op at level 1, scale 2^30

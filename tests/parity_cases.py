@@ -270,3 +270,84 @@ def case_bl_conv(make_ctx, k=3, i_batch=0, seed=5):
     got = ob.evalConv_BN_BL_test(BLDevice(ctx, O), ct, ksep, bna[:hb], bnb[:hb], W, k, hb, hb, k // 2, swk)
     eq(got, want, f"BL evalConv_BN_BL_test k={k} B={B}")
     ctx.close()
+
+
+# ---------------------------------------------------------------- convReLU chain (scope row 8f-1)
+class CkksDeviceBackend:
+    """oracle_ckks.OracleBackend's interface over the C ABI (numpy in / numpy out; every call uploads, runs HIP kernels,
+    downloads). Keys are loaded into the context on first use under an id unique per (galEl, level)."""
+
+    def __init__(self, ctx):
+        self.ctx, self.N = ctx, ctx.N
+        self._ids = {}
+
+    def ntt(self, mod, a): return self.ctx.ntt(mod, a)
+    def intt(self, mod, a): return self.ctx.intt(mod, a)
+    def mul(self, mod, a, b): return self.ctx.mul(mod, a, b)
+    def add(self, mod, a, b): return self.ctx.add(mod, a, b)
+    def sub(self, mod, a, b): return self.ctx.sub(mod, a, b)
+    def mul_const(self, mod, a, c): return self.ctx.mul_const(mod, a, c)
+    def permute(self, gal, rows): return self.ctx.permute(gal, rows)
+    def div_round_last(self, level, rows): return self.ctx.div_round_last(level, rows)
+
+    def keyswitch(self, key, cx):
+        kid = self._ids.get((key.gal, key.level))
+        if kid is None:
+            kid = self._ids[(key.gal, key.level)] = 1 + len(self._ids)
+            self.ctx.swk_load(kid, key.level, key.rows)
+        return self.ctx.keyswitch(kid, key.level, cx)
+
+
+def case_ckks_ops(make_ctx, logN=16, seed=3, levels=((23, 2.0 ** 55), (9, 2.0 ** 30))):
+    """leveled evaluator operations at the levels the convReLU chain uses them (multi-limb MulRelin with a five-digit
+    relinearisation key, Rescale, rotation, conjugation, the modulus raise): oracle backend vs device backend, bit for bit"""
+    import oracle_ckks as ck
+    Co = ck.Ckks(logN=logN, seed=seed)
+    ctx = make_ctx(Co.Q, Co.P)
+    Cd = ck.Ckks(logN=logN, seed=seed, backend=CkksDeviceBackend(ctx), oracle=Co.O)
+    Cd.keys = Co.keys                                    # same key material
+    rng = np.random.default_rng(seed)
+    n = Co.n
+    a = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    b = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    for L, sc in levels:
+        cta, ctb = Co.encrypt_slots(a, L, sc, seed=5), Co.encrypt_slots(b, L, sc, seed=6)
+        for name, f in (("mul_relin+rescale", lambda C: C.rescale(C.mul_relin(cta, ctb))), ("rotate", lambda C: C.rotate(cta, 5)),
+                        ("conjugate", lambda C: C.conjugate(cta)), ("mul_by_i/add_const", lambda C: C.add_const(C.mul_by_i(cta), 0.5))):
+            want, got = f(Co), f(Cd)
+            eq(got.rows, want.rows, f"ckks {name} level {L}")
+            assert got.scale == want.scale
+    ct0 = Co.encrypt_coeffs(rng.uniform(-10, 10, Co.N), 0, 2.0 ** 43, seed=8)
+    eq(Cd.mod_raise(ct0, 27).rows, Co.mod_raise(ct0, 27).rows, "mod_raise")
+    ctx.close()
+
+
+def case_conv_relu_tail(make_ctx, logN=16, seed=3, min_bits=8.0):
+    """the whole tail of evalConv_BNRelu_new (CtoS + sine, ReLU, mask, StoC) on the device ABI vs the oracle: every stage
+    bit-identical, and the decrypted result close to max(x, 0) (reference binary: MED 11.5 bits on its data)"""
+    import oracle_ckks as ck
+    Co = ck.Ckks(logN=logN, seed=seed)
+    ctx = make_ctx(Co.Q, Co.P)
+    Cd = ck.Ckks(logN=logN, seed=seed, backend=CkksDeviceBackend(ctx), oracle=Co.O)
+    Cd.keys = Co.keys
+    N, n = Co.N, Co.n
+    B = 4
+    W = int(round((N // B) ** 0.5))
+    kp = W - 1
+    m = np.random.default_rng(seed).uniform(-12, 12, N)
+    ct0 = Co.encrypt_coeffs(m, 0, 2.0 ** 43, seed=21)
+    btp_o, btp_d = ck.Bootstrapper(Co), ck.Bootstrapper(Cd)
+    so, sd = {}, {}
+    out_d = ck.conv_relu_tail(Cd, btp_d, ct0, 0.0, 4, W, kp, stages=sd)
+    out_o = ck.conv_relu_tail(Co, btp_o, ct0, 0.0, 4, W, kp, stages=so)
+    for ul in range(2):
+        eq(sd["ctos"][ul].rows, so["ctos"][ul].rows, f"CtoS+sine half {ul}")
+        eq(sd["relu"][ul].rows, so["relu"][ul].rows, f"ReLU half {ul}")
+    eq(out_d.rows, out_o.rows, "StoC output")
+    br = Co.enc.br
+    mask = np.concatenate([ck.gen_keep_vec(n, W, kp, 0)[br], ck.gen_keep_vec(n, W, kp, 1)[br]])
+    err = np.abs(Co.decrypt_coeffs(out_d) - np.maximum(m, 0) * mask)
+    bits = -np.log2(np.median(err))
+    assert bits >= min_bits, bits
+    ctx.close()
+    return bits

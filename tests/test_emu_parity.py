@@ -108,3 +108,10 @@ def test_keyswitch_general_vs_reference_relu_trace():
         d0, d1 = ctx.keyswitch(7, e["level"], cx)
         assert sha_rows(*d0) == e["p0"]["sha256"] and sha_rows(*d1) == e["p1"]["sha256"], f"level {e['level']}"
     ctx.close()
+
+
+def test_ckks_leveled_ops():
+    """scope row 8f-1 groundwork: leveled evaluator operations (multi-limb MulRelin + general Rescale, rotation, conjugation,
+    MultByi, AddConst, the bootstrapping modulus raise to level 27) composed from C-ABI calls vs the oracle, bit for bit"""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    pc.case_ckks_ops(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), levels=((6, 2.0 ** 30),))

@@ -224,3 +224,17 @@ def test_bl_baseline_conv_on_gpu():
     from optimal_conv_amd import Context
     pc.case_bl_conv(lambda Q, P: Context(Q, P))
     pc.case_bl_conv(lambda Q, P: Context(Q, P), k=5, i_batch=1)
+
+
+def test_ckks_leveled_ops_on_gpu():
+    """leveled evaluator operations at sine (23) and ReLU (9) levels of parameter set [6], device vs oracle, bit for bit"""
+    from optimal_conv_amd import Context
+    pc.case_ckks_ops(lambda Q, P: Context(Q, P))
+
+
+def test_conv_relu_tail_on_gpu():
+    """scope row 8f-1: CtoS + sine evaluation, the ReLU polynomials of conv.go:435-480, keep_ctxt mask, StoC on the device ABI:
+    every stage bit-identical to the oracle, decrypted result within the precision the reference prints for convReLU"""
+    from optimal_conv_amd import Context
+    bits = pc.case_conv_relu_tail(lambda Q, P: Context(Q, P))
+    print("median precision bits", bits)

@@ -1,0 +1,76 @@
+"""The oracle-side leveled CKKS evaluator and convReLU chain (tests/oracle_ckks.py) on a small ring (N = 2^10, same 28+5
+prime chain as parameter set [6]): homomorphic operations against their plaintext meaning, the DFT factorisation against
+the encoder, polynomial evaluation depth, and the whole CtoS -> sine -> ReLU -> mask -> StoC tail against max(x, 0)."""
+import numpy as np
+import pytest
+
+import oracle_ckks as ck
+
+
+@pytest.fixture(scope="module")
+def C():
+    return ck.Ckks(logN=10, h=64)
+
+
+def _err(C, ct, want):
+    return np.max(np.abs(C.decrypt_slots(ct) - want))
+
+
+def test_basic_ops(C):
+    rng = np.random.default_rng(1)
+    n = C.n
+    a = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    b = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    cta, ctb = C.encrypt_slots(a, 8, 2.0 ** 30, seed=5), C.encrypt_slots(b, 8, 2.0 ** 30, seed=6)
+    assert _err(C, C.add(cta, ctb), a + b) < 1e-5
+    m = C.rescale(C.mul_relin(cta, ctb))
+    assert m.level == 7 and _err(C, m, a * b) < 1e-5
+    assert _err(C, C.rotate(cta, 3), np.roll(a, -3)) < 1e-4
+    assert _err(C, C.conjugate(cta), np.conj(a)) < 1e-4
+    assert _err(C, C.mul_by_i(cta), 1j * a) < 1e-5
+    assert _err(C, C.add_const(cta, 0.25), a + 0.25) < 1e-5
+    d = {k: rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n) for k in (0, 1, 5, n - 2, 37)}
+    want = sum(d[k] * np.roll(a, -k) for k in d)
+    assert _err(C, C.rescale(C.linear_transform(cta, d, float(C.Q[8]))), want) < 1e-4
+
+
+def test_dft_factorisation(C):
+    rng = np.random.default_rng(2)
+    n = C.n
+    a = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    for inverse, gs in ((True, [3, 3, 3]), (False, [5, 4])):
+        v = a.copy()
+        for M in C.dft_groups(inverse, gs, 1.0):
+            v = sum(M[k] * np.roll(v, -k) for k in M)
+        ref = (C.enc.invfft(a) * n)[C.enc.br] if inverse else C.enc.fft(a[C.enc.br])
+        assert np.max(np.abs(v - ref)) < 1e-10
+
+
+@pytest.mark.parametrize("coeffs,depth", [(ck.RELU1, 3), (ck.RELU3, 4)])
+def test_poly_eval_depth_and_value(C, coeffs, depth):
+    x = np.random.default_rng(3).uniform(-1, 1, C.n)
+    ct = C.encrypt_slots(x + 0j, 12, 2.0 ** 30, seed=9)
+    r = C.eval_poly(ct, coeffs, 2.0 ** 30)
+    assert r.level == 12 - depth and r.scale == 2.0 ** 30
+    assert _err(C, r, np.polyval(coeffs[::-1], x)) < 1e-3
+
+
+def test_chebyshev_sine_depth_six(C):
+    f = lambda u: np.cos(2 * np.pi / 4 * (25 * u - 0.25))
+    u = np.random.default_rng(4).uniform(-1, 1, C.n)
+    ct = C.encrypt_slots(u + 0j, 23, float(C.Q[0]), seed=11)
+    r = C.eval_poly(ct, ck.cheby_coeffs(f, 63), 2.0 ** 55, cheby=True)
+    assert r.level == 17 and _err(C, r, f(u)) < 1e-6
+
+
+def test_conv_relu_tail_small_ring(C):
+    N, n = C.N, C.n
+    W, kp, pow_ = 16, 15, 4
+    m = np.random.default_rng(3).uniform(-12, 12, N)
+    out = ck.conv_relu_tail(C, ck.Bootstrapper(C), C.encrypt_coeffs(m, 0, 2.0 ** 43, seed=21), 0.0, pow_, W, kp)
+    assert out.level == 1 and abs(np.log2(out.scale) - 30) < 1e-6
+    br = C.enc.br
+    mask = np.concatenate([ck.gen_keep_vec(n, W, kp, 0)[br], ck.gen_keep_vec(n, W, kp, 1)[br]])
+    err = np.abs(C.decrypt_coeffs(out) - np.maximum(m, 0) * mask)
+    assert -np.log2(np.median(err)) >= 8.0       # reference binary on its data: MED 11.5, AVG 8.4 bits
+    assert np.max(err[mask == 0]) < 1e-3         # masked-out (padding) positions come back as zeros
