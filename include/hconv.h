@@ -75,6 +75,20 @@ int hc_div_round_last(hc_ctx *ctx, int level, const uint64_t *x, uint64_t *out);
 /* ring.PermuteNTTWithIndexLvl with ring.PermuteNTTIndex(galEl) (inside RotateGal, conv.go:291) */
 int hc_permute(hc_ctx *ctx, uint64_t galEl, const uint64_t *in, uint64_t *out, int count);
 
+/* ---- L0, leveled: a polynomial at `level` is (level+1) consecutive rows, row l modulo q_l (Lattigo's ring.Poly / ckks.Element
+ * at that level). One call covers all limbs. These are what a general-level ckks.Evaluator binds for the convReLU chain
+ * (eval.go:272-607): MulNew/MulRelin's tensor products, Add/Sub, MultByConst / MulByPow2, AddConst, and the bootstrapper's modUp. */
+int hc_lv_ntt(hc_ctx *ctx, int level, const uint64_t *in, uint64_t *out);
+int hc_lv_intt(hc_ctx *ctx, int level, const uint64_t *in, uint64_t *out);
+int hc_lv_mul(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
+int hc_lv_add(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
+int hc_lv_sub(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
+/* consts_host: level+1 host integers, one per limb (reduced mod q_l by the callee) */
+int hc_lv_mul_const(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *consts_host, uint64_t *out);
+int hc_lv_add_const(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *consts_host, uint64_t *out);
+/* test_run: ckks.(*Bootstrapper).modUp for one polynomial: in_q0 = NTT row mod q_0; out = level+1 NTT rows of the centred lift */
+int hc_lv_mod_raise(hc_ctx *ctx, int level, const uint64_t *in_q0, uint64_t *out);
+
 /* rlwe.SwitchingKey for galEl, digit 0, the rows level-0 key switching reads: limb Q0 and the single P limb of
  * Value[0][0] (b) and Value[0][1] (a), HOST pointers, stored form. Replaces GenRotationKeys' output being handed
  * to NewEvaluator (conv.go:258). */

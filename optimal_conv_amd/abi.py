@@ -39,6 +39,14 @@ SYMBOLS = {
     "hc_rotate_gal_l0": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_swk_load": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, u64p]),
     "hc_keyswitch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_lv_ntt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "hc_lv_intt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "hc_lv_mul": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_lv_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_lv_sub": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_lv_mul_const": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_void_p]),
+    "hc_lv_add_const": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_void_p]),
+    "hc_lv_mod_raise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_ker_load": (C.c_int, [C.c_void_p, u64p, C.c_int, C.POINTER(C.c_void_p)]),
     "hc_ker_load_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "hc_prep_ker": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -252,6 +260,27 @@ class Context:
         out = d.download((2, level + 1, self.N))
         src.free(); d.free()
         return out[0], out[1]
+
+    # ---- leveled polynomials: arrays of shape (level+1, N), row l modulo q_l
+    def _lv(self, fn, level, *arrays, consts=None, out_rows=None):
+        arrays = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, self.N) for a in arrays]
+        bufs = [self.buf(a) for a in arrays]
+        out = self.buf(nwords=(out_rows or (level + 1)) * self.N)
+        extra = () if consts is None else ((C.c_uint64 * (level + 1))(*[int(c) for c in consts]),)
+        self._ck(fn(self.h, level, *[b.ptr for b in bufs], *extra, out.ptr))
+        res = out.download(((out_rows or (level + 1)), self.N))
+        for b in bufs + [out]:
+            b.free()
+        return res
+
+    def lv_ntt(self, level, a): return self._lv(self.L.hc_lv_ntt, level, a)
+    def lv_intt(self, level, a): return self._lv(self.L.hc_lv_intt, level, a)
+    def lv_mul(self, level, a, b): return self._lv(self.L.hc_lv_mul, level, a, b)
+    def lv_add(self, level, a, b): return self._lv(self.L.hc_lv_add, level, a, b)
+    def lv_sub(self, level, a, b): return self._lv(self.L.hc_lv_sub, level, a, b)
+    def lv_mul_const(self, level, a, consts): return self._lv(self.L.hc_lv_mul_const, level, a, consts=consts)
+    def lv_add_const(self, level, a, consts): return self._lv(self.L.hc_lv_add_const, level, a, consts=consts)
+    def lv_mod_raise(self, level, row_q0): return self._lv(self.L.hc_lv_mod_raise, level, row_q0)
 
     def rotate_gal_l0(self, gal, ct):
         src = self.buf(np.ascontiguousarray(ct, dtype=np.uint64).reshape(2, self.N))

@@ -250,6 +250,34 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_pointwise(const u64 *a, const u64
         out[i] = r;
     }
 }
+// leveled polynomials (rows 0..level use moduli 0..level): one launch for all limbs, blockIdx.y = limb.
+// HC_PW_MULC multiplies by csts[limb]; HC_PW_ADDC adds csts[limb].w to every coefficient (a constant polynomial in the NTT domain)
+enum { HC_PW_ADDC = 6 };
+template <int OP>
+__global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const u64 *b, u64 *out, const HcMod *mods, const HcTw *csts) {
+    const int l = blockIdx.y; const HcMod m = mods[l];
+    const size_t base = (size_t)l * 65536;
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
+        const u64 x = a[base + i]; u64 r;
+        if (OP == HC_PW_MUL) r = hc_mont(x, hc_mont(b[base + i], m.r2, m.q, m.qinv), m.q, m.qinv);
+        else if (OP == HC_PW_ADD) r = hc_addmod(x, b[base + i], m.q);
+        else if (OP == HC_PW_SUB) r = hc_submod(x, b[base + i], m.q);
+        else if (OP == HC_PW_MULC) r = hc_mul_shoup(x, csts[l].w, csts[l].ws, m.q);
+        else r = hc_addmod(x, csts[l].w, m.q);
+        out[base + i] = r;
+    }
+}
+// ckks.(*Bootstrapper).modUp for one polynomial: coefficient row t (canonical mod q0) -> centred lift reduced into limb blockIdx.y
+__global__ __launch_bounds__(HC_TPB) void hc_k_mod_raise(const u64 *t, u64 *out, const HcMod *mods) {
+    const int l = blockIdx.y; const u64 q0 = mods[0].q, q = mods[l].q, mu = mods[l].mu;
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
+        const u64 x = t[i];
+        u64 r;
+        if (x > (q0 >> 1)) { r = hc_barrett64(q0 - x, q, mu); r = r ? q - r : 0; }
+        else r = hc_barrett64(x, q, mu);
+        out[(size_t)l * 65536 + i] = r;
+    }
+}
 // Shoup companion of a row of fixed multiplicands: ws = floor(w * 2^64 / q)
 __global__ __launch_bounds__(HC_TPB) void hc_k_shoup_companion(const u64 *w, u64 *ws, size_t n, u64 q) {
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * HC_TPB)

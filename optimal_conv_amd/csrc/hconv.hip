@@ -90,6 +90,7 @@ struct hc_ctx {
     u64 *ws_cts2 = nullptr; size_t ws_cts2_rows = 0;   // tree pong
     u64 *ws_ctc = nullptr;
     u64 *ws_tmp = nullptr; size_t ws_tmp_rows = 0;
+    HcMod *d_mods = nullptr; HcTw *d_csts = nullptr;      // device copies: all moduli (Q then P); per-call constants of the leveled ops
     long chunk_nodes = 64;
     long lanes = 1;               // internal concurrency of ONE conv_then_pack (power of two; 1 = single stream)
     std::vector<HcLane> lane;
@@ -219,6 +220,11 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
         int rc = hc_build_tables(c, &mh, false); if (!rc) rc = hc_build_tables(c, &mh, true);
         if (rc) { g_create_err = c->err; hc_ctx_destroy(c); return rc; }
     }
+    {   // device table of moduli for the leveled (all-limbs-in-one-launch) kernels
+        std::vector<HcMod> hm; for (auto &mh : c->mods) hm.push_back(mh.m);
+        if (hipMalloc((void **)&c->d_mods, hm.size() * sizeof(HcMod)) != hipSuccess || hipMalloc((void **)&c->d_csts, hm.size() * sizeof(HcTw)) != hipSuccess ||
+            hipMemcpy(c->d_mods, hm.data(), hm.size() * sizeof(HcMod), hipMemcpyHostToDevice) != hipSuccess) { g_create_err = "hc_ctx_create: device modulus table"; hc_ctx_destroy(c); return HC_ERR_HIP; }
+    }
     *out = c;
     return HC_OK;
 }
@@ -239,6 +245,8 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     for (auto &L : c->lane) { if (L.tmp) hipFree(L.tmp); if (L.cts) hipFree(L.cts); if (L.cts2) hipFree(L.cts2); if (L.done) hipEventDestroy(L.done); if (L.stream) { hipStreamSynchronize(L.stream); hipStreamDestroy(L.stream); } }
     if (c->ws_ctc) hipFree(c->ws_ctc);
     if (c->ws_tmp) hipFree(c->ws_tmp);
+    if (c->d_mods) hipFree(c->d_mods);
+    if (c->d_csts) hipFree(c->d_csts);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -322,6 +330,52 @@ extern "C" int hc_permute(hc_ctx *c, uint64_t galEl, const uint64_t *in, uint64_
     HC_ENTER(c);
     if (!in || !out || in == out || count < 1 || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_permute: bad arguments (in/out must differ, galEl odd)");
     return hc_launch(c, "permute", hc_k_permute, hc_pw_grid((size_t)count * HC_N), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), count);
+}
+
+// ---- leveled polynomials: rows 0..level <-> moduli 0..level (a ring.Poly at that level); one launch covers all limbs
+static int hc_lv_check(hc_ctx *c, const char *fn, int level, const void *a, const void *out) {
+    if (level < 0 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "%s: level %d outside 0..%d", fn, level, c->nq - 1);
+    if (!a || !out) return hc_fail(c, HC_ERR_ARG, "%s: null", fn);
+    return HC_OK;
+}
+static dim3 hc_lv_grid(int level) { return dim3(64, (unsigned)(level + 1)); }
+template <int OP>
+static int hc_lv_pw(hc_ctx *c, const char *fn, int level, const uint64_t *a, const uint64_t *b, uint64_t *out, const uint64_t *consts_host) {
+    HC_ENTER(c); HC_TRY(hc_lv_check(c, fn, level, a, out));
+    if ((OP == HC_PW_MUL || OP == HC_PW_ADD || OP == HC_PW_SUB) && !b) return hc_fail(c, HC_ERR_ARG, "%s: null", fn);
+    if (OP == HC_PW_MULC || OP == HC_PW_ADDC) {
+        if (!consts_host) return hc_fail(c, HC_ERR_ARG, "%s: null constants", fn);
+        std::vector<HcTw> h((size_t)level + 1);
+        for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; h[(size_t)l] = h_pair(consts_host[l] % q, q); }
+        HC_HIP(c, hipMemcpyAsync(c->d_csts, h.data(), h.size() * sizeof(HcTw), hipMemcpyHostToDevice, c->stream));
+        HC_HIP(c, hipStreamSynchronize(c->stream));      // h goes out of scope; the copy is tiny
+    }
+    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, hc_lv_grid(level), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, (const HcTw *)c->d_csts);
+}
+extern "C" int hc_lv_mul(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_MUL>(c, "hc_lv_mul", level, a, b, out, nullptr); }
+extern "C" int hc_lv_add(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_ADD>(c, "hc_lv_add", level, a, b, out, nullptr); }
+extern "C" int hc_lv_sub(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_SUB>(c, "hc_lv_sub", level, a, b, out, nullptr); }
+extern "C" int hc_lv_mul_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_MULC>(c, "hc_lv_mul_const", level, a, nullptr, out, consts); }
+extern "C" int hc_lv_add_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_ADDC>(c, "hc_lv_add_const", level, a, nullptr, out, consts); }
+extern "C" int hc_lv_ntt(hc_ctx *c, int level, const uint64_t *in, uint64_t *out) {
+    HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_ntt", level, in, out));
+    for (int l = 0; l <= level; l++) HC_TRY(hc_ntt(c, l, in + (size_t)l * HC_N, out + (size_t)l * HC_N, 1));
+    return HC_OK;
+}
+extern "C" int hc_lv_intt(hc_ctx *c, int level, const uint64_t *in, uint64_t *out) {
+    HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_intt", level, in, out));
+    for (int l = 0; l <= level; l++) HC_TRY(hc_intt(c, l, in + (size_t)l * HC_N, out + (size_t)l * HC_N, 1));
+    return HC_OK;
+}
+extern "C" int hc_lv_mod_raise(hc_ctx *c, int level, const uint64_t *in_q0, uint64_t *out) {
+    HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mod_raise", level, in_q0, out));
+    if ((const void *)in_q0 == (const void *)out) return hc_fail(c, HC_ERR_ARG, "hc_lv_mod_raise: in and out must differ");
+    u64 *t = nullptr; HC_HIP(c, hipMalloc((void **)&t, HC_N * sizeof(u64)));
+    int rc = hc_intt(c, 0, in_q0, t, 1);
+    if (!rc) rc = hc_launch(c, "mod_raise", hc_k_mod_raise, hc_lv_grid(level), (const u64 *)t, (u64 *)out, (const HcMod *)c->d_mods);
+    if (!rc) rc = hc_lv_ntt(c, level, out, out);
+    hipStreamSynchronize(c->stream); hipFree(t);
+    return rc;
 }
 
 // getConstAndScale + scaleUpExact of the reference's dependency: a float64 constant with a

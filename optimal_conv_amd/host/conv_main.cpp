@@ -2,7 +2,8 @@
 //     conv <ker_wid 3|5|7> <i_batch 0..3> <num_tests <= 10>
 // prints the same line shapes as the reference's `conv` run (SURVEY.md 8(a)-S "CLI output contract").
 // It runs the slot-packed "Base Line" (hconv_bl.cpp, scope row 8f-2) and then "Ours" (hconv_host.cpp), as main.go:639-643 does.
-// `convReLU` and `resnet` are next-rows of the scope table and exit with a clear message.
+// `convReLU k i n` runs "Ours" with the bootstrapping chain (hconv_relu.cpp, scope row 8f-1); its baseline half and `resnet`
+//  are not built and say so.
 // HCONV_SKIP_BL=1 skips the baseline half (not a reference feature; for timing "Ours" alone).
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,14 +27,12 @@ int main(int argc, char **argv) {
         hconv::panic("resnet: not built in this engine (scope table next-row 8f-3)");
     } else hconv::panic("wrong test type");
     if (i_batch < 0) hconv::panic("runtime error: index out of range");
-    if (boot) {
-        printf("Convolution followed by ReLU (& Bootstrapping) test start!\n");
-        hconv::panic("convReLU: bootstrapping chain is a next-row of the scope table (8f-1) and is not built in this engine");
-    }
-    printf("Convolution test start! (No Bootstrapping)\n");
+    if (boot) printf("Convolution followed by ReLU (& Bootstrapping) test start!\n");
+    else printf("Convolution test start! (No Bootstrapping)\n");
     printf("Ker:  %d batches:  %d widths:  %d\n", ker_wid, batchs[i_batch], widths[i_batch]);
     printf("Base Line start.\n");
-    if (getenv("HCONV_SKIP_BL") && atoi(getenv("HCONV_SKIP_BL"))) printf("(HCONV_SKIP_BL set: baseline skipped)\n");
+    if (boot) printf("(Base Line with bootstrapping, test_BL.go:113-183: not built in this engine - skipped)\n");
+    else if (getenv("HCONV_SKIP_BL") && atoi(getenv("HCONV_SKIP_BL"))) printf("(HCONV_SKIP_BL set: baseline skipped)\n");
     else hconv::testConv_BL_in(batchs[i_batch], widths[i_batch], ker_wid, num_tests, boot);
     printf("Ours start.\n");
     hconv::testConv_in(batchs[i_batch], widths[i_batch], ker_wid, num_tests, boot);

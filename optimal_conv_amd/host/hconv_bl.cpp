@@ -28,10 +28,10 @@
 #include <set>
 
 #include "hconv_host.hpp"
+#include "hconv_encoder.hpp"
 
 namespace hconv {
 
-typedef std::complex<double> cplx;
 #define HCB(c, call) do { int rc_ = (call); if (rc_) panic(std::string(#call) + ": " + hc_last_error(c)); } while (0)
 
 static const uint64_t BLQ[4] = {0x80000000080001ull, 0x10000000006e0001ull, 0x1fffffffffe00001ull, 0x1fffffffffc80001ull};   // Q0, Q1 of set [7]; P0, P1
@@ -108,59 +108,6 @@ static void bl_gen_key(BLContext *c, uint64_t galEl) {
     c->keys.insert(galEl);
 }
 
-// ---------------------------------------------------------------- slot encoder (ckks.encoderComplex128), full slots
-struct Encoder {
-    std::vector<int> rotGroup; std::vector<cplx> roots; std::vector<int> brev;
-    Encoder() {
-        const int slots = N / 2, m = 2 * N;
-        rotGroup.resize((size_t)slots); int g = 1; for (int i = 0; i < slots; i++) { rotGroup[(size_t)i] = g; g = (int)(((long)g * 5) % m); }
-        roots.resize((size_t)m + 1);
-        for (int i = 0; i <= m; i++) { double angle = 2 * 3.141592653589793 * (double)i / (double)m; roots[(size_t)i] = cplx(cos(angle), sin(angle)); }
-        brev.resize((size_t)slots); for (int i = 0; i < slots; i++) { int r = 0; for (int b = 0; b < 15; b++) r |= ((i >> b) & 1) << (14 - b); brev[(size_t)i] = r; }
-    }
-    void invfft(std::vector<cplx> &v) const {
-        const int n = N / 2, m = 2 * N;
-        for (int len = n; len >= 1; len >>= 1) {
-            const int lenh = len >> 1, lenq = len << 2, gap = m / lenq;
-            for (int i = 0; i < n; i += len) for (int j = 0; j < lenh; j++) {
-                const int idx = (lenq - (rotGroup[(size_t)j] % lenq)) * gap;
-                cplx u = v[(size_t)(i + j)] + v[(size_t)(i + j + lenh)], w = (v[(size_t)(i + j)] - v[(size_t)(i + j + lenh)]) * roots[(size_t)idx];
-                v[(size_t)(i + j)] = u; v[(size_t)(i + j + lenh)] = w;
-            }
-        }
-        for (auto &x : v) x /= cplx((double)n, 0);
-        for (int i = 0; i < n; i++) if (i < brev[(size_t)i]) std::swap(v[(size_t)i], v[(size_t)brev[(size_t)i]]);
-    }
-    void fft(std::vector<cplx> &v) const {
-        const int n = N / 2, m = 2 * N;
-        for (int i = 0; i < n; i++) if (i < brev[(size_t)i]) std::swap(v[(size_t)i], v[(size_t)brev[(size_t)i]]);
-        for (int len = 2; len <= n; len <<= 1) {
-            const int lenh = len >> 1, lenq = len << 2, gap = m / lenq;
-            for (int i = 0; i < n; i += len) for (int j = 0; j < lenh; j++) {
-                const int idx = (rotGroup[(size_t)j] % lenq) * gap;
-                cplx u = v[(size_t)(i + j)], w = v[(size_t)(i + j + lenh)] * roots[(size_t)idx];
-                v[(size_t)(i + j)] = u + w; v[(size_t)(i + j + lenh)] = u - w;
-            }
-        }
-    }
-    // encoder.Encode at level 1: coefficient-domain rows [2][N] (scaleUpVecExact rounding, as EncodeCoeffs)
-    std::vector<uint64_t> Encode(std::vector<cplx> values, double scale) const {
-        invfft(values);
-        std::vector<uint64_t> out((size_t)2 * N);
-        for (int i = 0; i < N; i++) {
-            const double val = i < N / 2 ? values[(size_t)i].real() : values[(size_t)(i - N / 2)].imag();
-            const bool neg = val < 0; const double x = neg ? -scale * val : scale * val;
-            for (int l = 0; l < 2; l++) {
-                uint64_t r;
-                if (x > 1.8446744073709552e+19) { int e2; double mant = frexp(x + 0.5, &e2); uint64_t mi = (uint64_t)ldexp(mant, 53); r = mi % BLQ[l]; for (int s = 0; s < e2 - 53; s++) r = addmod(r, r, BLQ[l]); }
-                else r = (uint64_t)(x + 0.5) % BLQ[l];
-                out[(size_t)l * N + (size_t)i] = neg ? BLQ[l] - r : r;
-            }
-        }
-        return out;
-    }
-};
-
 // ---------------------------------------------------------------- level-1 evaluator ops on the C ABI
 static BLCt bl_alloc(BLContext *c, double scale) { BLCt r; r.d = bl_rows(c, 4); r.Scale = scale; return r; }
 static void bl_free(BLContext *c, BLCt &ct) { if (ct.d) HCB(c->hc, hc_free(c->hc, ct.d)); ct.d = nullptr; }
@@ -227,7 +174,7 @@ static BLCt postConv_BL(BLContext *c, const Encoder &enc, const std::vector<BLCt
             postKer[(size_t)(k * in_wid * in_wid + ki * in_wid + kj)] = out_of_range ? cplx(0, 0)
                 : cplx(max_ker_rs[(((size_t)i * ker_wid + j) * max_batch + k) * max_batch + (size_t)((k - rot + max_batch) % max_batch)], 0);
         }
-        std::vector<uint64_t> rows = enc.Encode(postKer, c->scale);                                   // conv.go:165
+        std::vector<uint64_t> rows = enc.Encode(postKer, c->scale, BLQ, 2);                                   // conv.go:165
         HCB(c->hc, hc_upload(c->hc, pl, rows.data(), rows.size() * 8));
         for (int l = 0; l < 2; l++) HCB(c->hc, hc_ntt(c->hc, l, pl + (size_t)l * N, pl + (size_t)l * N, 1));   // conv.go:166
         BLCt term = MulNew(c, ct_in_rots[(size_t)iter], pl, c->scale);
@@ -248,7 +195,7 @@ static BLCt evalConv_BN_BL_test(BLContext *c, const Encoder &enc, const BLCt &ct
     for (size_t i = 0; i < bn_b.size(); i++) for (int j = 0; j < in_wid - pad; j++) for (int k = 0; k < in_wid - pad; k++)
         bn_b_slots[(size_t)(j + k * in_wid + norm * out_size * (int)i)] = cplx(bn_b[i], 0);             // eval.go:93-99
     uint64_t *pl_bn_b = bl_rows(c, 2);
-    { std::vector<uint64_t> rows = enc.Encode(bn_b_slots, scale_exp); HCB(c->hc, hc_upload(c->hc, pl_bn_b, rows.data(), rows.size() * 8));
+    { std::vector<uint64_t> rows = enc.Encode(bn_b_slots, scale_exp, BLQ, 2); HCB(c->hc, hc_upload(c->hc, pl_bn_b, rows.data(), rows.size() * 8));
       for (int l = 0; l < 2; l++) HCB(c->hc, hc_ntt(c->hc, l, pl_bn_b + (size_t)l * N, pl_bn_b + (size_t)l * N, 1)); }   // eval.go:101-102 EncodeNTT
     printf("Plaintext (kernel) preparation, Done in %s \n", dur(start).c_str());
     start = now();
@@ -364,8 +311,8 @@ void testConv_BL_in(int real_batch, int in_wid, int ker_wid, int total_test_num,
                 ker_in_sep[out][in][(size_t)(k * hb * hb + i * hb + j)] = ker_in[(size_t)(k * real_batch * real_batch + (i + in * hb) * real_batch + out * hb + j)];
         }
         auto start = now();
-        BLCt ct_input1 = bl_encrypt(cont, enc.Encode(reshape_input_BL(pad_input1, in_wid), cont->scale), cont->scale);
-        BLCt ct_input2 = bl_encrypt(cont, enc.Encode(reshape_input_BL(pad_input2, in_wid), cont->scale), cont->scale);
+        BLCt ct_input1 = bl_encrypt(cont, enc.Encode(reshape_input_BL(pad_input1, in_wid), cont->scale, BLQ, 2), cont->scale);
+        BLCt ct_input2 = bl_encrypt(cont, enc.Encode(reshape_input_BL(pad_input2, in_wid), cont->scale, BLQ, 2), cont->scale);
         printf("Encryption done in %s \n", dur(start).c_str());
         auto start_eval = now();
         BLCt ct_res[2];

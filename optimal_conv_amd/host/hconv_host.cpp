@@ -116,7 +116,6 @@ static void gen_and_load_galois_key(Context *c, uint64_t galEl) {
 Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, const std::vector<int> &kp_wids, bool boot, const std::string &kind) {
     (void)ker_wid; (void)in_wids; (void)kp_wids;
     if (kind != "Conv") panic("Wrong kinds!");                                     // main.go:404 (only the conv kind is built here)
-    if (boot) panic("convReLU (bootstrapping) is a next-row of the scope table and is not built in this engine");
     Context *c = new Context();
     double logqp = 0; for (uint64_t q : PARAMS6_Q) logqp += log2((double)q); for (uint64_t p : PARAMS6_P) logqp += log2((double)p);
     printf("CKKS parameters: logN = %d, logSlots = %d, h = %d, logQP = %d, levels = %d, scale= 2^%f, sigma = %f \n",
@@ -135,9 +134,15 @@ Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, cons
     // gen_idxNlogs (conv.go:241-261): idx[i] = NTT(X^(2^i)) on the device; Galois keys for 2^(i+1)+1, i < logN
     HC(c->hc, hc_idx_load(c->hc, nullptr));
     for (int i = 0; i < LOGN; i++) gen_and_load_galois_key(c, (1ull << (i + 1)) + 1);
+    if (boot) {                                                                                        // main.go:464-507
+        printf("Generating bootstrapping keys...\n");
+        auto start = now();
+        c->btp = newBoot(c->sk, c->seed, dev);       // DFT matrices now; rlk / rotation keys are generated at first use (same secret key)
+        printf("Done in %s \n", dur(start).c_str());
+    }
     return c;
 }
-void freeContext(Context *c) { if (!c) return; hc_ctx_destroy(c->hc); delete c; }
+void freeContext(Context *c) { if (!c) return; freeBoot(c->btp); hc_ctx_destroy(c->hc); delete c; }
 
 // ---------------------------------------------------------------- text I/O and float layout
 std::vector<double> readTxt(const std::string &name_file, int size) {      // main.go:971-990
@@ -436,6 +441,22 @@ void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool
         auto start = now();
         Ciphertext ctxt_input = EncryptNew(cont, EncodeCoeffs(input, cont->ECD_LV, cont->scale), cont->ECD_LV, cont->scale);
         printf("Encryption done in %s \n", dur(start).c_str());
+        if (boot) {                                                                                    // test.go:52-53, eval.go:272-607
+            const double pow_ = 4.0, alpha = 0.0;                                                      // test.go:22
+            const double out_scale = exp2(round(log2((double)MODQ[0]) - (pow_ + 8)));                  // eval.go:433
+            Ciphertext ct_conv = evalConv_BN(cont, ctxt_input, ker_in, bn_a, bn_b, in_wid, ker_wid, raw_in_batch, raw_out_batch, norm, out_scale, trans);
+            BootCiphertext ct_res = evalConv_BNRelu_tail(cont->btp, ct_conv.d, ct_conv.Scale, alpha, pow_, in_wid, kp_wid);
+            start = now();
+            std::vector<double> cfs = bootDecryptDecodeCoeffs(cont->btp, ct_res);
+            printf("Decryption Done in %s \n", dur(start).c_str());
+            std::vector<double> test_out = post_process(cfs, raw_in_wid, in_wid);
+            std::vector<double> real_out = readTxt(pre + "reluout" + suf, raw_in_wid * raw_in_wid * raw_in_batch);
+            printDebugCfsPlain(test_out, real_out);
+            long nk, nks; bootStats(cont->btp, &nk, &nks);
+            if (getenv("HCONV_BOOT_STATS")) printf("boot stats: %ld switching keys generated, %ld key switches\n", nk, nks);
+            freeCt(cont, ctxt_input); freeCt(cont, ct_conv); freeBootCt(cont->btp, ct_res);
+            continue;
+        }
         Ciphertext ct_result = evalConv_BN(cont, ctxt_input, ker_in, bn_a, bn_b, in_wid, ker_wid, raw_in_batch, raw_out_batch, norm, (double)(1 << 30), trans);
         if (getenv("HCONV_PRINT_DIGEST")) {      // FNV-1a over the result ciphertext: lets tests compare code paths bit for bit
             std::vector<uint64_t> h = dev_download(cont, ct_result.d, 2); uint64_t f = 1469598103934665603ull;

@@ -54,8 +54,12 @@ struct Plaintext {
     double Scale = 0;
 };
 
+struct Boot;                                   // hconv_relu.cpp: bootstrapper + leveled evaluator (cont.btp, cont.evaluator of main.go:464-507)
+struct BootCiphertext { uint64_t *d = nullptr; int level = 0; double Scale = 0; };   // device [2][level+1][N]
+
 struct Context {
     int logN = LOGN, Nn = N, ECD_LV = 1;       // main.go:46
+    Boot *btp = nullptr;                      // only when newContext(..., boot = true)
     hc_ctx *hc = nullptr;                     // pack_evaluator + evaluator (both run on the same device context)
     std::vector<int64_t> sk;                  // sparse ternary secret, h = 192 (main.go:410)
     std::vector<uint64_t> sk_ntt[3];          // NTT rows mod Q0, Q1, P (host)
@@ -91,6 +95,14 @@ Ciphertext conv_then_pack(Context *cont, const Ciphertext &ctxt_in, const KerPla
 Ciphertext evalConv_BN(Context *cont, const Ciphertext &ct_input, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
                        const std::vector<double> &bn_b, int in_wid, int ker_wid, int real_ib, int real_ob, int norm, double out_scale, bool trans);
 void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool boot);
+// ---- convReLU chain (hconv_relu.cpp; eval.go:272-607 for kind "Conv") ----
+Boot *newBoot(const std::vector<int64_t> &sk, uint64_t seed, int device);
+void freeBoot(Boot *);
+// everything after evalConv_BN: Scale *= 2^pow, BootstrappConv_CtoS, evalReLU + MulByPow2, keep_ctxt, BootstrappConv_StoC
+BootCiphertext evalConv_BNRelu_tail(Boot *B, const uint64_t *ct_conv_dev, double ct_scale, double alpha, double pow, int in_wid, int kp_wid);
+std::vector<double> bootDecryptDecodeCoeffs(Boot *B, const BootCiphertext &ct);
+void freeBootCt(Boot *B, BootCiphertext &ct);
+void bootStats(Boot *B, long *keys, long *keyswitches);
 // test_BL.go:16 — the slot-packed baseline the reference runs first (hconv_bl.cpp); boot = true is not built
 void testConv_BL_in(int real_batch, int in_wid, int ker_wid, int total_test_num, bool boot);
 

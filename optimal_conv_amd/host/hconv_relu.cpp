@@ -1,0 +1,544 @@
+// hconv_relu.cpp — the `convReLU` chain (scope row 8f-1) on the MI355X engine: everything after the convolution in
+// eval.go:272-607 evalConv_BNRelu_new for kind "Conv" (log_sparse 0, iter 2), with device-resident ciphertexts.
+//
+// Reference mapping (file:line -> here):
+//   eval.go:433-437  evalConv_BN at out_scale 2^(round(log2 Q0) - (pow+8)); Scale *= 2^pow      -> evalConv_BNRelu_new
+//   eval.go:450      cont.btp.BootstrappConv_CtoS (fork-only: test_run ckks.(*Bootstrapper).BootstrappConv_CtoS:
+//                    modUp, CoeffsToSlots, evaluateSine)                                         -> Boot::ctos
+//   conv.go:435-480  evalReLU (EvaluatePoly x3, AddConst, Mul, Relinearize)                      -> evalReLU
+//   eval.go:474      MulByPow2                                                                    -> mul_const_int(2^pow)
+//   conv.go:417-431  keep_ctxt, rot_util.go:141-174 gen_keep_vec                                 -> keep_ctxt, gen_keep_vec
+//   eval.go:550      cont.btp.BootstrappConv_StoC                                                 -> Boot::stoc
+//   main.go:464-507  bootstrapping keys (rlk + rotation keys over the five special primes)       -> Boot::key (generated on demand)
+// The bootstrapper exists only inside the un-vendored Lattigo fork; this is a restatement on the same modulus chain and level
+// assignment (parameter set [6]): levels 27..24 CoeffsToSlots, 23..16 sine (Chebyshev degree 63 of the cosine,
+// two double angles, K = 25, message ratio 256), 15..5 the ReLU polynomials, 5 the mask, 3..2 SlotsToCoeffs. It mirrors
+// tests/oracle_ckks.py statement by statement; that file run on the oracle and on this library's C ABI gives bit-identical
+// ciphertexts at every stage (tests/test_gpu_parity.py::test_conv_relu_tail_on_gpu). All residue arithmetic is C-ABI calls:
+// hc_lv_* (all limbs per launch), hc_keyswitch (hybrid, alpha = 5), hc_div_round_last, hc_permute; the slot encoder and the
+// float64 scale bookkeeping are host code, as in the reference.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <functional>
+#include <map>
+#include <memory>
+#include <set>
+
+#include "hconv_encoder.hpp"
+#include "hconv_host.hpp"
+
+namespace hconv {
+
+#define HCR(call) do { int rc_ = (call); if (rc_) panic(std::string(#call) + ": " + hc_last_error(hc)); } while (0)
+static const int LV_CTS_TOP = 27, LV_SINE_TOP = 23, LV_RELU_TOP = 15, LV_STC_TOP = 3;
+static const int SIN_K = 25, SIN_DEG = 63, SIN_DOUBLE = 2;
+typedef std::map<int, std::vector<cplx>> DiagMat;        // rotation k -> diagonal (n complex values)
+
+static inline uint64_t mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((u128)a * b) % q); }
+static std::string dur(std::chrono::steady_clock::time_point t0) {
+    double ns = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    char b[64];
+    if (ns < 1e6) snprintf(b, sizeof b, "%.6gµs", ns / 1e3); else if (ns < 1e9) snprintf(b, sizeof b, "%.9gms", ns / 1e6); else snprintf(b, sizeof b, "%.9gs", ns / 1e9);
+    return b;
+}
+static std::chrono::steady_clock::time_point now() { return std::chrono::steady_clock::now(); }
+
+// device-resident ciphertext: deg+1 polynomials, each a pooled block of NQ rows of which rows 0..level are live
+struct DCt {
+    std::shared_ptr<uint64_t> p[3];
+    int deg = 1, level = 0;
+    double scale = 0;
+};
+struct DPt { std::shared_ptr<uint64_t> p; int level = 0; double scale = 0; };
+
+struct Boot {
+    hc_ctx *hc = nullptr;
+    std::vector<uint64_t> Q, P;
+    int NQ = 0;
+    const int n = N / 2;
+    std::vector<int64_t> sk;
+    uint64_t *d_sk = nullptr;                               // [NQ+NP][N] NTT rows of sk on the device
+    std::map<std::pair<uint64_t, int>, uint64_t> key_ids;   // (galEl or 0 = relinearisation, level) -> id loaded with hc_swk_load
+    std::vector<uint64_t *> pool;
+    uint64_t rng_state = 0;
+    Encoder enc;
+    std::shared_ptr<uint64_t> mono_i;                        // NTT(X^(N/2)) for every limb
+    struct LT { int n1 = 1; std::map<int, std::map<int, DPt>> giant; double pt_scale = 0; int level = 0; };
+    std::vector<LT> cts, stc;
+    std::vector<double> sine;
+    long n_keyswitch = 0, n_keys = 0;
+
+    // ---------------- memory
+    std::shared_ptr<uint64_t> block() {
+        uint64_t *d;
+        if (!pool.empty()) { d = pool.back(); pool.pop_back(); }
+        else { void *v = nullptr; HCR(hc_malloc(hc, (size_t)NQ * N * 8, &v)); d = (uint64_t *)v; }
+        return std::shared_ptr<uint64_t>(d, [this](uint64_t *x) { pool.push_back(x); });
+    }
+    DCt new_ct(int level, int deg, double scale) { DCt c; c.deg = deg; c.level = level; c.scale = scale; for (int i = 0; i <= deg; i++) c.p[i] = block(); return c; }
+    static DCt drop_to(const DCt &a, int level) { if (level > a.level) panic("drop_to: level above the ciphertext's"); DCt c = a; c.level = level; return c; }
+
+    // ---------------- sampling (harness only; the reference's randomness is crypto/rand and unseeded)
+    uint64_t next() { uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+    void uniform_rows(uint64_t q, uint64_t *out) { int bits = 64 - __builtin_clzll(q); uint64_t mask = bits == 64 ? ~0ull : ((1ull << bits) - 1); for (int j = 0; j < N; j++) { uint64_t r; do r = next() & mask; while (r >= q); out[j] = r; } }
+    void gaussian(std::vector<int64_t> &e) {
+        e.resize(N);
+        for (int j = 0; j < N; j += 2) {        // Box-Muller, sigma 3.2, bound 6 sigma
+            double u1 = ((double)(next() >> 11) + 1.0) / 9007199254740993.0, u2 = (double)(next() >> 11) / 9007199254740992.0;
+            double r = sqrt(-2.0 * log(u1)) * 3.2, a = r * cos(6.283185307179586 * u2), b = r * sin(6.283185307179586 * u2);
+            if (fabs(a) > 19.2) a = 0; if (fabs(b) > 19.2) b = 0;
+            e[(size_t)j] = (int64_t)llround(a); e[(size_t)j + 1] = (int64_t)llround(b);
+        }
+    }
+    uint64_t modulus(int T, int nl) const { return T < nl ? Q[(size_t)T] : P[(size_t)(T - nl)]; }
+    int modidx(int T, int nl) const { return T < nl ? T : NQ + (T - nl); }
+
+    // ---------------- keys (rlwe.GenSwitchingKey restricted to the limbs a level-`level` key switch reads)
+    uint64_t key(uint64_t gal, int level) {
+        auto it = key_ids.find({gal, level});
+        if (it != key_ids.end()) return it->second;
+        const int alpha = (int)P.size(), nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
+        // s_out: the key the result is under. Rotation/conjugation by gal: automorphism by gal^-1 of s; relinearisation: s.
+        std::vector<int64_t> sko(N, 0);
+        if (gal == 0) sko = sk;
+        else {
+            const uint64_t twoN = 2ull * N; uint64_t ginv = 1, b = gal % twoN;
+            for (uint64_t e = twoN - 1; e; e >>= 1, b = (b * b) % twoN) if (e & 1) ginv = (ginv * b) % twoN;
+            for (int i = 0; i < N; i++) { uint64_t t = ((uint64_t)i * ginv) % twoN; if (t < (uint64_t)N) sko[t] = sk[(size_t)i]; else sko[t - N] = -sk[(size_t)i]; }
+        }
+        const size_t rows = (size_t)beta * 2 * nt;
+        void *v = nullptr; HCR(hc_malloc(hc, (rows + 3) * N * 8, &v));
+        uint64_t *d = (uint64_t *)v, *t0 = d + rows * N, *t1 = t0 + N, *t2 = t1 + N;
+        std::vector<uint64_t> ha((size_t)N), he((size_t)N), hs((size_t)N);
+        std::vector<int64_t> e;
+        for (int dgt = 0; dgt < beta; dgt++) {
+            gaussian(e);
+            for (int T = 0; T < nt; T++) {
+                const uint64_t q = modulus(T, nl); const int mod = modidx(T, nl);
+                uint64_t *b_row = d + (((size_t)dgt * 2 + 0) * nt + T) * N, *a_row = d + (((size_t)dgt * 2 + 1) * nt + T) * N;
+                uniform_rows(q, ha.data());
+                for (int j = 0; j < N; j++) { he[(size_t)j] = e[(size_t)j] >= 0 ? (uint64_t)e[(size_t)j] : q - (uint64_t)(-e[(size_t)j]); hs[(size_t)j] = sko[(size_t)j] >= 0 ? (uint64_t)sko[(size_t)j] : q - (uint64_t)(-sko[(size_t)j]); }
+                HCR(hc_upload(hc, a_row, ha.data(), (size_t)N * 8)); HCR(hc_upload(hc, t0, he.data(), (size_t)N * 8)); HCR(hc_upload(hc, t1, hs.data(), (size_t)N * 8));
+                HCR(hc_ntt(hc, mod, t0, t0, 1)); HCR(hc_ntt(hc, mod, t1, t1, 1));                   // NTT(e), NTT(s_out)
+                HCR(hc_mul(hc, mod, a_row, t1, t1, 1)); HCR(hc_sub(hc, mod, t0, t1, b_row, 1));    // b = e - a*s_out
+                if (T < nl && T >= dgt * alpha && T < (dgt + 1) * alpha) {                        // + P * s_in on the digit's own limbs
+                    uint64_t pmod = 1; for (uint64_t pj : P) pmod = mulmod(pmod, pj % q, q);
+                    const uint64_t *s_row = d_sk + (size_t)mod * N;
+                    if (gal == 0) { HCR(hc_mul(hc, mod, s_row, s_row, t2, 1)); HCR(hc_mul_const(hc, mod, t2, pmod, t2, 1)); }
+                    else HCR(hc_mul_const(hc, mod, s_row, pmod, t2, 1));
+                    HCR(hc_add(hc, mod, b_row, t2, b_row, 1));
+                }
+                const uint64_t R = (uint64_t)((((u128)1) << 64) % q);                              // stored form: Montgomery
+                HCR(hc_mul_const(hc, mod, b_row, R, b_row, 1)); HCR(hc_mul_const(hc, mod, a_row, R, a_row, 1));
+            }
+        }
+        HCR(hc_sync(hc));
+        std::vector<uint64_t> host(rows * N); HCR(hc_download(hc, host.data(), d, host.size() * 8));
+        const uint64_t id = 1 + key_ids.size();
+        HCR(hc_swk_load(hc, id, level, host.data()));
+        HCR(hc_free(hc, d));
+        key_ids[{gal, level}] = id; n_keys++;
+        return id;
+    }
+    uint64_t gal_rot(int k) const { const uint64_t twoN = 2ull * N; uint64_t e = (uint64_t)(int64_t)k & (twoN - 1), r = 1, b = 5; while (e) { if (e & 1) r = (r * b) % twoN; b = (b * b) % twoN; e >>= 1; } return r; }
+
+    // ---------------- evaluator (ckks.Evaluator at any level)
+    static void same_scale(double a, double b) { if (fabs(a / b - 1.0) > 1e-9) panic("scale mismatch in Add/Sub"); }
+    DCt add(const DCt &a0, const DCt &b0) {
+        const int L = std::min(a0.level, b0.level); same_scale(a0.scale, b0.scale);
+        DCt r = new_ct(L, std::max(a0.deg, b0.deg), a0.scale);
+        for (int d = 0; d <= r.deg; d++) {
+            if (d <= a0.deg && d <= b0.deg) HCR(hc_lv_add(hc, L, a0.p[d].get(), b0.p[d].get(), r.p[d].get()));
+            else HCR(hc_copy(hc, r.p[d].get(), (d <= a0.deg ? a0 : b0).p[d].get(), (size_t)(L + 1) * N * 8));
+        }
+        return r;
+    }
+    DCt sub(const DCt &a0, const DCt &b0) {
+        const int L = std::min(a0.level, b0.level); same_scale(a0.scale, b0.scale);
+        if (a0.deg != b0.deg) panic("sub: degrees differ");
+        DCt r = new_ct(L, a0.deg, a0.scale);
+        for (int d = 0; d <= r.deg; d++) HCR(hc_lv_sub(hc, L, a0.p[d].get(), b0.p[d].get(), r.p[d].get()));
+        return r;
+    }
+    std::vector<uint64_t> consts(const u128 mag, bool neg, int level) const {
+        std::vector<uint64_t> c((size_t)level + 1);
+        for (int l = 0; l <= level; l++) { uint64_t r = (uint64_t)(mag % Q[(size_t)l]); c[(size_t)l] = (neg && r) ? Q[(size_t)l] - r : r; }
+        return c;
+    }
+    static void split_int(double x, u128 *mag, bool *neg) {      // int(round(x)) for |x| < 2^127
+        *neg = x < 0; double a = fabs(x);
+        double r = nearbyint(a);                                   // ties-to-even, as Python's round() on floats
+        if (r < 18446744073709551616.0) *mag = (u128)(uint64_t)r;
+        else { int e; double m = frexp(r, &e); *mag = ((u128)(uint64_t)ldexp(m, 64)) << (e - 64); }
+    }
+    DCt mul_const_int(const DCt &a, double k_rounded_value) {      // k given as an integral double
+        u128 mag; bool neg; split_int(k_rounded_value, &mag, &neg);
+        std::vector<uint64_t> c = consts(mag, neg, a.level);
+        DCt r = new_ct(a.level, a.deg, a.scale);
+        for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul_const(hc, a.level, a.p[d].get(), c.data(), r.p[d].get()));
+        return r;
+    }
+    DCt add_const_int(const DCt &a, double k_rounded_value) {
+        u128 mag; bool neg; split_int(k_rounded_value, &mag, &neg);
+        std::vector<uint64_t> c = consts(mag, neg, a.level);
+        DCt r = a; r.p[0] = block();
+        HCR(hc_lv_add_const(hc, a.level, a.p[0].get(), c.data(), r.p[0].get()));
+        return r;
+    }
+    DCt add_const(const DCt &a, double c) { return add_const_int(a, nearbyint(c * a.scale)); }
+    DCt mul_plain(const DCt &a, const DPt &pt) {
+        if (pt.level < a.level) panic("mul_plain: plaintext below the ciphertext's level");
+        DCt r = new_ct(a.level, a.deg, a.scale * pt.scale);
+        for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul(hc, a.level, a.p[d].get(), pt.p.get(), r.p[d].get()));
+        return r;
+    }
+    DCt mul_by_i(const DCt &a) {
+        DCt r = new_ct(a.level, a.deg, a.scale);
+        for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul(hc, a.level, a.p[d].get(), mono_i.get(), r.p[d].get()));
+        return r;
+    }
+    DCt mul_relin(const DCt &a, const DCt &b) {                   // evaluator.MulRelin: tensor, key switch of c2 with the rlk
+        const int L = std::min(a.level, b.level);
+        DCt r = new_ct(L, 1, a.scale * b.scale);
+        auto d1 = block(), d2 = block(), t = block(), k = block();
+        HCR(hc_lv_mul(hc, L, a.p[0].get(), b.p[0].get(), r.p[0].get()));
+        HCR(hc_lv_mul(hc, L, a.p[0].get(), b.p[1].get(), d1.get()));
+        HCR(hc_lv_mul(hc, L, a.p[1].get(), b.p[0].get(), t.get()));
+        HCR(hc_lv_add(hc, L, d1.get(), t.get(), d1.get()));
+        HCR(hc_lv_mul(hc, L, a.p[1].get(), b.p[1].get(), d2.get()));
+        HCR(hc_keyswitch(hc, key(0, L), L, d2.get(), t.get(), k.get())); n_keyswitch++;
+        HCR(hc_lv_add(hc, L, r.p[0].get(), t.get(), r.p[0].get()));
+        HCR(hc_lv_add(hc, L, d1.get(), k.get(), r.p[1].get()));
+        return r;
+    }
+    DCt rescale(const DCt &a) {                                     // one DivRoundByLastModulusNTT
+        if (a.level < 1) panic("rescale at level 0");
+        DCt r = new_ct(a.level - 1, a.deg, a.scale / (double)Q[(size_t)a.level]);
+        for (int d = 0; d <= a.deg; d++) HCR(hc_div_round_last(hc, a.level, a.p[d].get(), r.p[d].get()));
+        return r;
+    }
+    DCt galois(const DCt &a, uint64_t gal) {                       // evaluator.permuteNTT: key switch c1, + c0, permute both
+        const int L = a.level;
+        DCt r = new_ct(L, 1, a.scale);
+        auto d0 = block(), d1 = block();
+        HCR(hc_keyswitch(hc, key(gal, L), L, a.p[1].get(), d0.get(), d1.get())); n_keyswitch++;
+        HCR(hc_lv_add(hc, L, d0.get(), a.p[0].get(), d0.get()));
+        HCR(hc_permute(hc, gal, d0.get(), r.p[0].get(), L + 1));
+        HCR(hc_permute(hc, gal, d1.get(), r.p[1].get(), L + 1));
+        return r;
+    }
+    DCt rotate(const DCt &a, int k) { k = ((k % n) + n) % n; return k == 0 ? a : galois(a, gal_rot(k)); }
+    DCt conjugate(const DCt &a) { return galois(a, 2ull * N - 1); }
+    DCt mod_raise(const DCt &a, int level) {                        // ckks.(*Bootstrapper).modUp
+        if (a.level != 0) panic("mod_raise expects a level-0 ciphertext");
+        DCt r = new_ct(level, 1, a.scale);
+        for (int d = 0; d < 2; d++) HCR(hc_lv_mod_raise(hc, level, a.p[d].get(), r.p[d].get()));
+        return r;
+    }
+    static DCt relabel(const DCt &a, double scale) { if (fabs(a.scale / scale - 1.0) > 1e-6) panic("relabel: scales are not close"); DCt r = a; r.scale = scale; return r; }
+
+    // ---------------- encoding
+    DPt encode(const std::vector<cplx> &slots, int level, double scale) {
+        std::vector<uint64_t> rows = enc.Encode(slots, scale, Q.data(), level + 1);
+        DPt pt; pt.level = level; pt.scale = scale; pt.p = block();
+        HCR(hc_upload(hc, pt.p.get(), rows.data(), rows.size() * 8));
+        HCR(hc_lv_ntt(hc, level, pt.p.get(), pt.p.get()));
+        return pt;
+    }
+
+    // ---------------- DFT matrices in diagonal form (the encoder's own butterflies, no bit reversal)
+    DiagMat dft_stage(int ln, bool inverse) const {
+        const int lenh = ln >> 1, lenq = ln << 2, gap = 2 * N / lenq;
+        std::vector<cplx> d0((size_t)n), dp((size_t)n, cplx(0, 0)), dm((size_t)n, cplx(0, 0));
+        for (int p = 0; p < n; p++) {
+            const int j = p % ln; const bool first = j < lenh; const int jj = first ? j : j - lenh;
+            const int idx = inverse ? (lenq - (enc.rotGroup[(size_t)jj] % lenq)) * gap : (enc.rotGroup[(size_t)jj] % lenq) * gap;
+            const cplx w = enc.roots[(size_t)idx];
+            if (inverse) { d0[(size_t)p] = first ? cplx(1, 0) : -w; if (first) dp[(size_t)p] = cplx(1, 0); else dm[(size_t)p] = w; }
+            else { d0[(size_t)p] = first ? cplx(1, 0) : -w; if (first) dp[(size_t)p] = w; else dm[(size_t)p] = cplx(1, 0); }
+        }
+        DiagMat M; M[0] = d0;
+        const int kp = lenh % n, km = ((-lenh) % n + n) % n;
+        auto acc = [&](int k, const std::vector<cplx> &d) { auto it = M.find(k); if (it == M.end()) M[k] = d; else for (int p = 0; p < n; p++) it->second[(size_t)p] += d[(size_t)p]; };
+        acc(kp, dp); acc(km, dm);
+        return M;
+    }
+    DiagMat matmul_diag(const DiagMat &M2, const DiagMat &M1) const {        // M2 . M1 (M1 applied first)
+        DiagMat out;
+        for (auto &e2 : M2) for (auto &e1 : M1) {
+            const int k2 = e2.first, k = (e1.first + k2) % n;
+            auto it = out.find(k); if (it == out.end()) it = out.emplace(k, std::vector<cplx>((size_t)n, cplx(0, 0))).first;
+            for (int p = 0; p < n; p++) it->second[(size_t)p] += e2.second[(size_t)p] * e1.second[(size_t)((p + k2) % n)];
+        }
+        for (auto it = out.begin(); it != out.end();) { bool nz = false; for (auto &v : it->second) if (v != cplx(0, 0)) { nz = true; break; } if (nz) ++it; else it = out.erase(it); }
+        return out;
+    }
+    std::vector<DiagMat> dft_groups(bool inverse, const std::vector<int> &sizes, double constant) const {
+        std::vector<int> lens; for (int s = 0; s < LOGN - 1; s++) lens.push_back(inverse ? n >> s : 2 << s);
+        const double c = pow(constant, 1.0 / (double)sizes.size());
+        std::vector<DiagMat> groups; size_t pos = 0;
+        for (int gs : sizes) {
+            DiagMat M; bool have = false;
+            for (int i = 0; i < gs; i++, pos++) { DiagMat S = dft_stage(lens[pos], inverse); M = have ? matmul_diag(S, M) : S; have = true; }
+            for (auto &e : M) for (auto &v : e.second) v *= c;
+            groups.push_back(std::move(M));
+        }
+        return groups;
+    }
+    LT plan(const DiagMat &M, int level, double pt_scale) {          // BSGS split + the pre-rotated, encoded diagonals
+        LT lt; lt.level = level; lt.pt_scale = pt_scale;
+        int best = -1;
+        for (int n1 = 1; n1 <= n; n1 <<= 1) {
+            std::set<int> babies, giants; for (auto &e : M) { babies.insert(e.first % n1); giants.insert(e.first - e.first % n1); }
+            babies.erase(0); giants.erase(0);
+            const int cost = (int)(babies.size() + giants.size());
+            if (best < 0 || cost < best) { best = cost; lt.n1 = n1; }
+        }
+        for (auto &e : M) {
+            const int k = e.first, g = k - k % lt.n1, b = k % lt.n1;
+            std::vector<cplx> rolled((size_t)n); for (int p = 0; p < n; p++) rolled[(size_t)p] = e.second[(size_t)(((p - g) % n + n) % n)];     // np.roll(diag, g)
+            lt.giant[g][b] = encode(rolled, level, pt_scale);
+        }
+        return lt;
+    }
+    DCt linear_transform(const DCt &ct, const LT &lt) {             // sum_k diag_k (.) rot_k(ct); no rescale
+        if (ct.level != lt.level) panic("linear_transform: ciphertext level differs from the encoded matrix level");
+        std::map<int, DCt> rots;
+        for (auto &g : lt.giant) for (auto &b : g.second) if (!rots.count(b.first)) rots[b.first] = rotate(ct, b.first);
+        DCt acc; bool have_acc = false;
+        for (auto &g : lt.giant) {
+            DCt inner; bool have = false;
+            for (auto &b : g.second) { DCt term = mul_plain(rots[b.first], b.second); inner = have ? add(inner, term) : term; have = true; }
+            inner = rotate(inner, g.first);
+            acc = have_acc ? add(acc, inner) : inner; have_acc = true;
+        }
+        return acc;
+    }
+
+    // ---------------- polynomial evaluation (tests/oracle_ckks.py: _power, _split, _plan_level, _eval_rec, eval_poly)
+    struct PolyEval {
+        Boot *B; bool cheby; std::map<int, DCt> T;
+        const DCt &power(int i) {
+            auto it = T.find(i); if (it != T.end()) return it->second;
+            const int a = (i + 1) / 2, b = i / 2;
+            DCt A = power(a), Bc = power(b);
+            DCt t = B->rescale(B->mul_relin(A, Bc));
+            if (cheby) {
+                t = B->add(t, t);
+                const int c = a - b;
+                if (c == 0) t = B->add_const(t, -1.0);
+                else { DCt Tc = power(c); const int L = std::min(t.level, Tc.level); t = B->sub(drop_to(t, L), relabel(drop_to(Tc, L), t.scale)); }
+            }
+            return T.emplace(i, t).first->second;
+        }
+        static void split(const std::vector<double> &c, int g, bool cheby, std::vector<double> &cq, std::vector<double> &cr) {
+            const int deg = (int)c.size() - 1;
+            cr.assign(c.begin(), c.begin() + g);
+            if (!cheby) { cq.assign(c.begin() + g, c.end()); return; }
+            cq.assign((size_t)(deg - g + 1), 0.0); cq[0] = c[(size_t)g];
+            for (int j = 1; j <= deg - g; j++) { cq[(size_t)j] = 2.0 * c[(size_t)(g + j)]; cr[(size_t)(g - j)] -= c[(size_t)(g + j)]; }
+        }
+        static int degree(const std::vector<double> &c) { int d = (int)c.size() - 1; while (d > 0 && c[(size_t)d] == 0) d--; return d; }
+        static int bit_length(int x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
+        int plan_level(std::vector<double> c, int log_split, bool lead) {
+            const int deg = degree(c); c.resize((size_t)deg + 1);
+            if (deg < (1 << log_split)) {
+                if (lead && log_split > 1 && deg > (1 << (log_split - 1))) return plan_level(c, bit_length(deg) >> 1, true);
+                int lv = power(1).level; for (int i = 1; i <= deg; i++) if (c[(size_t)i] != 0) lv = std::min(lv, power(i).level);
+                return lv - 1;
+            }
+            int g = 1 << log_split; while (g * 2 <= deg) g *= 2;
+            std::vector<double> cq, cr; split(c, g, cheby, cq, cr);
+            const int lq = plan_level(cq, log_split, lead), lr = plan_level(cr, log_split, false);
+            return std::min(std::min(lq, power(g).level) - 1, lr);
+        }
+        DCt rec(std::vector<double> c, int log_split, bool lead, double target) {
+            const int deg = degree(c); c.resize((size_t)deg + 1);
+            if (deg < (1 << log_split)) {
+                if (lead && log_split > 1 && deg > (1 << (log_split - 1))) return rec(c, bit_length(deg) >> 1, true, target);
+                int lv = power(1).level; for (int i = 1; i <= deg; i++) if (c[(size_t)i] != 0) lv = std::min(lv, power(i).level);
+                const double pre = target * (double)B->Q[(size_t)lv];
+                DCt acc; bool have = false;
+                for (int i = 1; i <= deg; i++) if (c[(size_t)i] != 0) {
+                    DCt Xi = drop_to(power(i), lv);
+                    DCt term = B->mul_const_int(Xi, nearbyint(c[(size_t)i] * pre / Xi.scale)); term.scale = pre;
+                    acc = have ? B->add(acc, term) : term; have = true;
+                }
+                if (!have) panic("polynomial leaf without a non-constant term");
+                if (c[0] != 0) acc = B->add_const_int(acc, nearbyint(c[0] * pre));
+                return relabel(B->rescale(acc), target);
+            }
+            int g = 1 << log_split; while (g * 2 <= deg) g *= 2;
+            std::vector<double> cq, cr; split(c, g, cheby, cq, cr);
+            const DCt Xg = power(g);
+            const int lq = plan_level(cq, log_split, lead), lmul = std::min(lq, Xg.level);
+            DCt resq = rec(cq, log_split, lead, target * (double)B->Q[(size_t)lmul] / Xg.scale);
+            if (resq.level != lq) panic("polynomial evaluation: planned level differs");
+            DCt prod = relabel(B->rescale(B->mul_relin(resq, Xg)), target);
+            bool rnz = false; for (double v : cr) if (v != 0) rnz = true;
+            if (rnz) prod = B->add(prod, rec(cr, log_split, false, target));
+            return prod;
+        }
+    };
+    DCt eval_poly(const DCt &ct, const std::vector<double> &coeffs, double target, bool cheby) {
+        PolyEval pe{this, cheby, {}};
+        pe.T[1] = ct;
+        const int deg = (int)coeffs.size() - 1, log_deg = PolyEval::bit_length(deg), log_split = log_deg >> 1;
+        for (int i = 2; i < (1 << log_split); i++) pe.power(i);
+        for (int i = log_split; i < log_deg; i++) pe.power(1 << i);
+        return pe.rec(coeffs, log_split, true, target);
+    }
+
+    // ---------------- the bootstrapper
+    void build(const std::vector<int64_t> &sk_in, uint64_t seed, int device) {
+        Q = PARAMS6_Q; P = PARAMS6_P; NQ = (int)Q.size(); sk = sk_in; rng_state = seed ^ 0xB007B007ull;
+        if (hc_ctx_create(&hc, LOGN, Q.data(), NQ, P.data(), (int)P.size(), device)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
+        const int nm = NQ + (int)P.size();
+        { void *v = nullptr; HCR(hc_malloc(hc, (size_t)nm * N * 8, &v)); d_sk = (uint64_t *)v; }
+        std::vector<uint64_t> h((size_t)N);
+        for (int m = 0; m < nm; m++) {
+            const uint64_t q = m < NQ ? Q[(size_t)m] : P[(size_t)(m - NQ)];
+            for (int j = 0; j < N; j++) h[(size_t)j] = sk[(size_t)j] >= 0 ? (uint64_t)sk[(size_t)j] : q - (uint64_t)(-sk[(size_t)j]);
+            HCR(hc_upload(hc, d_sk + (size_t)m * N, h.data(), (size_t)N * 8)); HCR(hc_ntt(hc, m, d_sk + (size_t)m * N, d_sk + (size_t)m * N, 1));
+        }
+        mono_i = block();
+        { std::vector<uint64_t> m((size_t)NQ * N, 0); for (int l = 0; l < NQ; l++) m[(size_t)l * N + N / 2] = 1; HCR(hc_upload(hc, mono_i.get(), m.data(), m.size() * 8)); HCR(hc_lv_ntt(hc, NQ - 1, mono_i.get(), mono_i.get())); }
+        // CoeffsToSlots: (1/n) prod(stages), times 1/2 (real/imaginary extraction) and 1/K (Chebyshev argument in [-1,1])
+        std::vector<DiagMat> G = dft_groups(true, {4, 4, 4, 3}, 1.0 / (2.0 * (double)n * SIN_K));
+        for (size_t i = 0; i < G.size(); i++) { const int lv = LV_CTS_TOP - (int)i; cts.push_back(plan(G[i], lv, (double)Q[(size_t)lv])); }
+        // SlotsToCoeffs: level 3 carries all but the last matrix (plaintext scales multiply to q3), level 2 the last at 2^30
+        G = dft_groups(false, {5, 5, 5}, 1.0);
+        const double sc3 = pow((double)Q[LV_STC_TOP], 1.0 / (double)(G.size() - 1));
+        for (size_t i = 0; i + 1 < G.size(); i++) stc.push_back(plan(G[i], LV_STC_TOP, sc3));
+        stc.push_back(plan(G.back(), LV_STC_TOP - 1, 1073741824.0));
+        // Chebyshev interpolant of cos(2 pi (K u - 1/4) / 2^r) on [-1,1]
+        const int m = SIN_DEG + 1; sine.assign((size_t)m, 0.0);
+        for (int j = 0; j < m; j++) {
+            double s = 0;
+            for (int k = 0; k < m; k++) { const double u = cos(M_PI * (k + 0.5) / m); s += cos(2.0 * M_PI * (SIN_K * u - 0.25) / (double)(1 << SIN_DOUBLE)) * cos(j * M_PI * (k + 0.5) / m); }
+            sine[(size_t)j] = 2.0 / m * s;
+        }
+        sine[0] /= 2;
+    }
+    void ctos(const DCt &ct0, DCt out[2]) {
+        const double q0 = (double)Q[0], msg_scale = ct0.scale;
+        DCt ct = mod_raise(ct0, LV_CTS_TOP); ct.scale = q0;             // slot values are now t'/Q0 = I + msg/Q0, |.| <= K
+        for (auto &lt : cts) ct = rescale(linear_transform(ct, lt));
+        if (ct.level != LV_SINE_TOP) panic("CoeffsToSlots ended at the wrong level");
+        DCt cc = conjugate(ct);
+        DCt parts[2] = {add(ct, cc), mul_by_i(sub(cc, ct))};           // (w + conj w), -i (w - conj w); the 1/2 is in the matrices
+        const double c_m = q0 / (2.0 * M_PI * msg_scale);
+        double s = 1073741824.0 * c_m;
+        for (int r = 0; r < SIN_DOUBLE; r++) s = sqrt(s * (double)Q[(size_t)(LV_RELU_TOP + 1 + r)]);
+        for (int h = 0; h < 2; h++) {
+            DCt c = eval_poly(parts[h], sine, s, true);
+            for (int r = 0; r < SIN_DOUBLE; r++) { c = mul_relin(c, c); c = add(c, c); c = rescale(add_const(c, -1.0)); }
+            if (c.level != LV_RELU_TOP) panic("sine evaluation ended at the wrong level");
+            c.scale = c.scale / c_m;                                     // value *= c_m: now msg / msg_scale
+            out[h] = c;
+        }
+    }
+    DCt stoc(const DCt &re, const DCt &im) {
+        DCt ct = drop_to(add(re, mul_by_i(im)), LV_STC_TOP);
+        for (size_t i = 0; i + 1 < stc.size(); i++) ct = linear_transform(ct, stc[i]);
+        ct = rescale(ct);
+        return rescale(linear_transform(ct, stc.back()));
+    }
+};
+
+// rot_util.go:141-174
+static std::vector<int> gen_keep_vec(int vec_size, int in_wid, int kp_wid, int ul) {
+    int logN = 0; for (; (1 << logN) < 2 * vec_size; logN++) {}
+    std::vector<int> idx((size_t)vec_size, 0); const int batch = 2 * vec_size / (in_wid * in_wid);
+    if (kp_wid < in_wid / 2) panic("keep width too small. less than in_wid/2");
+    if (ul != 0 && ul != 1) panic("ul not 0 nor 1");
+    const int rows = ul == 0 ? in_wid / 2 : kp_wid - in_wid / 2;
+    for (int i = 0; i < rows; i++) for (int j = 0; j < kp_wid; j++) for (int b = 0; b < batch; b++) {
+        uint32_t v = (uint32_t)(in_wid * batch * i + batch * j + b), r = 0; for (int k = 0; k < logN - 1; k++) r |= ((v >> k) & 1u) << (logN - 2 - k);
+        idx[r] = 1;
+    }
+    return idx;
+}
+// conv.go:435-480
+static DCt evalReLU(Boot *B, const DCt &ct_in, double alpha) {
+    const double a = (alpha + 1) / 2.0, b = (1 - alpha) / 2.0, sc = 1073741824.0;
+    const std::vector<double> c1 = {0.0, 10.8541842577442, 0.0, -62.2833925211098, 0.0, 114.369227820443, 0.0, -62.8023496973074};
+    const std::vector<double> c2 = {0.0, 4.13976170985111, 0.0, -5.84997640211679, 0.0, 2.94376255659280, 0.0, -0.454530437460152};
+    std::vector<double> c3 = {0.0, 3.29956739043733, 0.0, -7.84227260291355, 0.0, 12.8907764115564, 0.0, -12.4917112584486, 0.0, 6.94167991428074, 0.0, -2.04298067399942, 0.0, 0.246407138926031};
+    for (auto &v : c3) v *= b;
+    printf("Eval: ");
+    DCt s = B->eval_poly(ct_in, c1, sc, false);
+    s = B->eval_poly(s, c2, sc, false);
+    s = B->eval_poly(s, c3, sc, false);
+    s = B->add_const(s, a);
+    return B->mul_relin(s, Boot::drop_to(ct_in, s.level));            // Mul + Relinearize, no rescale (conv.go:475-477)
+}
+// conv.go:417-431
+static DCt keep_ctxt(Boot *B, const DCt &ct, const std::vector<int> &idx) {
+    std::vector<cplx> tmp((size_t)N / 2); for (size_t i = 0; i < idx.size(); i++) tmp[i] = cplx((double)idx[i], 0);
+    DPt pt = B->encode(tmp, ct.level, (double)B->Q[(size_t)ct.level]);
+    return B->rescale(B->mul_plain(ct, pt));
+}
+
+// ---------------------------------------------------------------- public surface (hconv_host.hpp)
+Boot *newBoot(const std::vector<int64_t> &sk, uint64_t seed, int device) { Boot *b = new Boot(); b->build(sk, seed, device); return b; }
+void freeBoot(Boot *b) {
+    if (!b) return;
+    b->cts.clear(); b->stc.clear(); b->mono_i.reset();
+    hc_ctx_destroy(b->hc); delete b;      // device blocks die with the context
+}
+
+// eval.go:272-607 for kind "Conv": ct_conv is evalConv_BN's level-0 result at out_scale 2^(round(log2 Q0) - (pow+8))
+BootCiphertext evalConv_BNRelu_tail(Boot *B, const uint64_t *ct_conv_dev, double ct_scale, double alpha, double pow_, int in_wid, int kp_wid) {
+    hc_ctx *hc = B->hc;
+    DCt ct = B->new_ct(0, 1, ct_scale * pow(2.0, pow_));                                            // eval.go:437
+    for (int d = 0; d < 2; d++) HCR(hc_copy(hc, ct.p[d].get(), ct_conv_dev + (size_t)d * N, (size_t)N * 8));
+    printf("Bootstrapping... Ours (until CtoS):\n");
+    auto start = now();
+    DCt boots[2]; B->ctos(ct, boots);                                                                 // eval.go:450
+    HCR(hc_sync(hc));
+    printf("Done in %s \n", dur(start).c_str());
+    start = now();
+    DCt keep[2];
+    for (int ul = 0; ul < 2; ul++) {
+        DCt r = evalReLU(B, boots[ul], alpha);                                                        // eval.go:473
+        boots[ul] = B->mul_const_int(r, pow(2.0, pow_));                                              // MulByPow2 (eval.go:474)
+    }
+    HCR(hc_sync(hc));
+    printf("ReLU Done in %s \n", dur(start).c_str());
+    start = now();
+    for (int ul = 0; ul < 2; ul++) keep[ul] = keep_ctxt(B, boots[ul], gen_keep_vec(N / 2, in_wid, kp_wid, ul));   // eval.go:534
+    DCt res = B->stoc(keep[0], keep[1]);                                                              // eval.go:550 ; Rescale (564) is a no-op here
+    HCR(hc_sync(hc));
+    printf("Boot (StoC) Done in %s \n", dur(start).c_str());
+    BootCiphertext out; out.level = res.level; out.Scale = res.scale;
+    { void *v = nullptr; HCR(hc_malloc(hc, (size_t)2 * (res.level + 1) * N * 8, &v)); out.d = (uint64_t *)v; }
+    for (int d = 0; d < 2; d++) HCR(hc_copy(hc, out.d + (size_t)d * (res.level + 1) * N, res.p[d].get(), (size_t)(res.level + 1) * N * 8));
+    HCR(hc_sync(hc));
+    return out;
+}
+// Decrypt at level 1 + DecodeCoeffs: CRT over Q0*Q1, centre, / scale
+std::vector<double> bootDecryptDecodeCoeffs(Boot *B, const BootCiphertext &ct) {
+    hc_ctx *hc = B->hc;
+    if (ct.level != 1) panic("bootDecryptDecodeCoeffs expects the level-1 result of the chain");
+    void *v = nullptr; HCR(hc_malloc(hc, (size_t)2 * N * 8, &v)); uint64_t *t = (uint64_t *)v;
+    HCR(hc_lv_mul(hc, 1, ct.d + (size_t)2 * N, B->d_sk, t)); HCR(hc_lv_add(hc, 1, ct.d, t, t)); HCR(hc_lv_intt(hc, 1, t, t));
+    std::vector<uint64_t> m((size_t)2 * N); HCR(hc_download(hc, m.data(), t, m.size() * 8)); HCR(hc_free(hc, t));
+    const uint64_t q0 = B->Q[0], q1 = B->Q[1]; uint64_t inv = 1; { uint64_t b = q0 % q1, e = q1 - 2; while (e) { if (e & 1) inv = mulmod(inv, b, q1); b = mulmod(b, b, q1); e >>= 1; } }
+    const u128 QQ = (u128)q0 * q1; std::vector<double> cf((size_t)N);
+    for (int j = 0; j < N; j++) {
+        const uint64_t a0 = m[(size_t)j], a1 = m[(size_t)N + j], d = (a1 % q1 + q1 - a0 % q1) % q1;
+        const u128 x = (u128)a0 + (u128)q0 * mulmod(d, inv, q1);
+        cf[(size_t)j] = x > QQ / 2 ? -(double)(QQ - x) / ct.Scale : (double)x / ct.Scale;
+    }
+    return cf;
+}
+void freeBootCt(Boot *B, BootCiphertext &ct) { hc_ctx *hc = B->hc; if (ct.d) HCR(hc_free(hc, ct.d)); ct.d = nullptr; }
+void bootStats(Boot *B, long *keys, long *keyswitches) { *keys = B->n_keys; *keyswitches = B->n_keyswitch; }
+
+}  // namespace hconv

@@ -2,7 +2,8 @@
 """Synthetic test_conv_data/*.csv generator (the reference ships none: README.md:21-24).
 
 File names and sizes follow the reference's readers (test.go:37-40,66-68; main.go:971-990):
-  test_conv{k}_batch_{B}_{in|ker|bna|bnb|out}_{iter}.csv, whitespace separated floats.
+  test_conv{k}_batch_{B}_{in|ker|bna|bnb|out|reluout}_{iter}.csv, whitespace separated floats
+  (reluout = max(out, 0), what `convReLU` compares against: test.go:66).
 Layouts: input HWC flat  in[(i*raw+j)*B+b]      (main.go:1007-1042 prep_Input)
          kernel HWIO flat ker[o + c*B + t*B*B]  (conv.go:184-202 reshape_ker)
 Expected output = zero-padded 'same' correlation on the raw x raw image, times bn_a plus bn_b.
@@ -45,9 +46,8 @@ def write_case(outdir, k, i_batch, it):
     B, W, raw, x, ker, a, b = make_case(k, i_batch, it)
     out = plain_conv(x, ker, a, b)
     os.makedirs(outdir, exist_ok=True)
-    os.makedirs(outdir, exist_ok=True)
     pre = os.path.join(outdir, f"test_conv{k}_batch_{B}_")
-    for name, arr in (("in", x), ("ker", ker), ("bna", a), ("bnb", b), ("out", out)):
+    for name, arr in (("in", x), ("ker", ker), ("bna", a), ("bnb", b), ("out", out), ("reluout", np.maximum(out, 0.0))):
         np.savetxt(f"{pre}{name}_{it}.csv", arr.reshape(-1), fmt="%.17g")
     return B, W, raw
 

@@ -55,6 +55,28 @@ class OracleBackend:
     def div_round_last(self, level, rows):
         return self.O.div_round_last(level, rows)
 
+    # leveled polynomials, (level+1, N) arrays: per-limb loops over the primitives above
+    def lv_mul(self, a, b): return np.stack([self.O.mul(l, a[l], b[l]).reshape(-1) for l in range(a.shape[0])])
+    def lv_add(self, a, b): return np.stack([self.O.add(l, a[l], b[l]).reshape(-1) for l in range(a.shape[0])])
+    def lv_sub(self, a, b): return np.stack([self.O.sub(l, a[l], b[l]).reshape(-1) for l in range(a.shape[0])])
+    def lv_mul_const(self, a, consts): return np.stack([self.O.mul_scalar(l, a[l], consts[l]).reshape(-1) for l in range(a.shape[0])])
+
+    def lv_add_const(self, a, consts):
+        return np.stack([self.O.add(l, a[l], np.full(self.N, consts[l], dtype=np.uint64)).reshape(-1) for l in range(a.shape[0])])
+
+    def lv_mod_raise(self, level, row_q0):
+        """centred lift of the coefficients mod q0 into every modulus 0..level (ckks.(*Bootstrapper).modUp)"""
+        q0 = self.O.q[0]
+        cf = self.O.intt(0, row_q0).reshape(-1)
+        neg = cf > q0 // 2
+        rows = []
+        for l in range(level + 1):
+            q = np.uint64(self.O.q[l])
+            r = cf % q
+            rn = (q - ((np.uint64(q0) - cf) % q)) % q
+            rows.append(self.O.ntt(l, np.where(neg, rn, r).astype(np.uint64)).reshape(-1))
+        return np.stack(rows)
+
 
 class SwitchingKey:
     def __init__(self, gal, level, rows):
@@ -222,8 +244,8 @@ class Ckks:
         assert abs(a / b - 1.0) < 1e-9, (a, b)
 
     # ---- linear operations
-    def _rowwise(self, fn, a_rows, b_rows):
-        return np.stack([fn(l, a_rows[l], b_rows[l]).reshape(-1) for l in range(a_rows.shape[0])])
+    def _consts(self, k, level):
+        return [k % self.Q[l] for l in range(level + 1)]
 
     def add(self, a, b):
         a, b = self._align(a, b)
@@ -232,7 +254,7 @@ class Ckks:
         out = []
         for d in range(deg):
             if d < a.rows.shape[0] and d < b.rows.shape[0]:
-                out.append(self._rowwise(self.be.add, a.rows[d], b.rows[d]))
+                out.append(self.be.lv_add(a.rows[d], b.rows[d]))
             else:
                 out.append((a.rows[d] if d < a.rows.shape[0] else b.rows[d]).copy())
         return Ct(np.stack(out), a.scale)
@@ -241,19 +263,17 @@ class Ckks:
         a, b = self._align(a, b)
         self._same_scale(a.scale, b.scale)
         assert a.rows.shape[0] == b.rows.shape[0]
-        return Ct(np.stack([self._rowwise(self.be.sub, a.rows[d], b.rows[d]) for d in range(a.rows.shape[0])]), a.scale)
+        return Ct(np.stack([self.be.lv_sub(a.rows[d], b.rows[d]) for d in range(a.rows.shape[0])]), a.scale)
 
     def mul_const_int(self, ct, k):
         """every coefficient times the integer k (sign allowed); the scale label is the caller's business"""
-        rows = np.stack([np.stack([self.be.mul_const(l, ct.rows[d, l], k % self.Q[l]).reshape(-1) for l in range(ct.level + 1)])
-                         for d in range(ct.rows.shape[0])])
-        return Ct(rows, ct.scale)
+        cs = self._consts(k, ct.level)
+        return Ct(np.stack([self.be.lv_mul_const(ct.rows[d], cs) for d in range(ct.rows.shape[0])]), ct.scale)
 
     def add_const_int(self, ct, k):
         """adds the constant polynomial k: every NTT coefficient of c0 += k"""
         rows = ct.rows.copy()
-        for l in range(ct.level + 1):
-            rows[0, l] = self.be.add(l, ct.rows[0, l], np.full(self.N, k % self.Q[l], dtype=np.uint64)).reshape(-1)
+        rows[0] = self.be.lv_add_const(ct.rows[0], self._consts(k, ct.level))
         return Ct(rows, ct.scale)
 
     def add_const(self, ct, c):
@@ -261,19 +281,18 @@ class Ckks:
 
     def mul_plain(self, ct, pt_rows, pt_scale):
         L = ct.level
-        rows = np.stack([np.stack([self.be.mul(l, ct.rows[d, l], pt_rows[l]).reshape(-1) for l in range(L + 1)]) for d in range(ct.rows.shape[0])])
-        return Ct(rows, ct.scale * pt_scale)
+        pt_rows = np.ascontiguousarray(pt_rows[: L + 1])
+        return Ct(np.stack([self.be.lv_mul(ct.rows[d], pt_rows) for d in range(ct.rows.shape[0])]), ct.scale * pt_scale)
 
     def mul_by_i(self, ct):
         """times X^(N/2), i.e. every slot times i (ckks.evaluator.MultByi); exact, no level, no scale change"""
-        rows = []
         for l in range(ct.level + 1):
             if l not in self._mono_i:
                 m = np.zeros(self.N, dtype=np.uint64)
                 m[self.N // 2] = 1
                 self._mono_i[l] = self.O.ntt(l, m)
-        return Ct(np.stack([np.stack([self.be.mul(l, ct.rows[d, l], self._mono_i[l]).reshape(-1) for l in range(ct.level + 1)])
-                            for d in range(ct.rows.shape[0])]), ct.scale)
+        mono = np.stack([self._mono_i[l] for l in range(ct.level + 1)])
+        return Ct(np.stack([self.be.lv_mul(ct.rows[d], mono) for d in range(ct.rows.shape[0])]), ct.scale)
 
     def neg(self, ct):
         z = Ct(np.zeros_like(ct.rows), ct.scale)
@@ -284,15 +303,13 @@ class Ckks:
         a, b = self._align(a, b)
         L = a.level
         be = self.be
-        d0 = np.stack([be.mul(l, a.rows[0, l], b.rows[0, l]).reshape(-1) for l in range(L + 1)])
-        d1 = np.stack([be.add(l, be.mul(l, a.rows[0, l], b.rows[1, l]), be.mul(l, a.rows[1, l], b.rows[0, l])).reshape(-1) for l in range(L + 1)])
-        d2 = np.stack([be.mul(l, a.rows[1, l], b.rows[1, l]).reshape(-1) for l in range(L + 1)])
+        d0 = be.lv_mul(a.rows[0], b.rows[0])
+        d1 = be.lv_add(be.lv_mul(a.rows[0], b.rows[1]), be.lv_mul(a.rows[1], b.rows[0]))
+        d2 = be.lv_mul(a.rows[1], b.rows[1])
         k0, k1 = be.keyswitch(self.key(0, L), d2)
         self.counters["keyswitch"] += 1
         self.counters["mul_relin"] += 1
-        c0 = np.stack([be.add(l, d0[l], k0[l]).reshape(-1) for l in range(L + 1)])
-        c1 = np.stack([be.add(l, d1[l], k1[l]).reshape(-1) for l in range(L + 1)])
-        return Ct(np.stack([c0, c1]), a.scale * b.scale)
+        return Ct(np.stack([be.lv_add(d0, k0), be.lv_add(d1, k1)]), a.scale * b.scale)
 
     def rescale(self, ct):
         """one DivRoundByLastModulusNTT: level -= 1, scale /= q_level"""
@@ -309,7 +326,7 @@ class Ckks:
         d0, d1 = be.keyswitch(self.key(gal, L), ct.rows[1])
         self.counters["keyswitch"] += 1
         self.counters["rotate"] += 1
-        d0 = np.stack([be.add(l, d0[l], ct.rows[0, l]).reshape(-1) for l in range(L + 1)])
+        d0 = be.lv_add(d0, ct.rows[0])
         return Ct(np.stack([be.permute(gal, d0), be.permute(gal, np.ascontiguousarray(d1))]), ct.scale)
 
     def rotate(self, ct, k):
@@ -323,19 +340,7 @@ class Ckks:
     def mod_raise(self, ct, level):
         """level-0 ciphertext -> `level`: centred lift of each coefficient mod Q0 (ckks.(*Bootstrapper).modUp)"""
         assert ct.level == 0
-        q0 = self.Q[0]
-        out = []
-        for d in range(2):
-            cf = self.be.intt(0, ct.rows[d, 0]).reshape(-1)
-            neg = cf > q0 // 2
-            rows = []
-            for l in range(level + 1):
-                q = self.Q[l]
-                r = cf % np.uint64(q)
-                rn = (np.uint64(q) - ((np.uint64(q0) - cf) % np.uint64(q))) % np.uint64(q)
-                rows.append(self.be.ntt(l, np.where(neg, rn, r).astype(np.uint64)).reshape(-1))
-            out.append(np.stack(rows))
-        return Ct(np.stack(out), ct.scale)
+        return Ct(np.stack([self.be.lv_mod_raise(level, ct.rows[d, 0]) for d in range(2)]), ct.scale)
 
     # ---- linear transforms (diagonal form, baby-step giant-step)
     def matmul_diag(self, M2, M1):

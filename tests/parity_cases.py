@@ -290,6 +290,14 @@ class CkksDeviceBackend:
     def permute(self, gal, rows): return self.ctx.permute(gal, rows)
     def div_round_last(self, level, rows): return self.ctx.div_round_last(level, rows)
 
+    # leveled polynomials: one ABI call for all limbs
+    def lv_mul(self, a, b): return self.ctx.lv_mul(a.shape[0] - 1, a, b)
+    def lv_add(self, a, b): return self.ctx.lv_add(a.shape[0] - 1, a, b)
+    def lv_sub(self, a, b): return self.ctx.lv_sub(a.shape[0] - 1, a, b)
+    def lv_mul_const(self, a, consts): return self.ctx.lv_mul_const(a.shape[0] - 1, a, consts)
+    def lv_add_const(self, a, consts): return self.ctx.lv_add_const(a.shape[0] - 1, a, consts)
+    def lv_mod_raise(self, level, row_q0): return self.ctx.lv_mod_raise(level, row_q0)
+
     def keyswitch(self, key, cx):
         kid = self._ids.get((key.gal, key.level))
         if kid is None:
