@@ -424,6 +424,14 @@ struct Boot {
             sine[(size_t)j] = 2.0 / m * s;
         }
         sine[0] /= 2;
+        // kgen.GenRelinearizationKey + GenRotationKeysForRotations(btpParams.RotationsForBootstrapping) (main.go:411,466-474):
+        // everything the chain switches with, so that no key generation falls inside the timed stages
+        for (auto *grp : {&cts, &stc}) for (auto &lt : *grp) for (auto &g : lt.giant) {
+            if (g.first) key(gal_rot(g.first), lt.level);
+            for (auto &b : g.second) if (b.first) key(gal_rot(b.first), lt.level);
+        }
+        key(2ull * N - 1, LV_SINE_TOP);
+        for (int l = LV_SINE_TOP; l >= LV_RELU_TOP - 10; l--) key(0, l);
     }
     void ctos(const DCt &ct0, DCt out[2]) {
         const double q0 = (double)Q[0], msg_scale = ct0.scale;

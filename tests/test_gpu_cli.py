@@ -41,3 +41,22 @@ def test_opwise_evaluator_path_equals_fused_on_gpu(tmp_path, k, i_batch):
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append(re.search(r"^ciphertext digest: ([0-9a-f]{16})$", out.stdout, re.M).group(1))
     assert digests[0] == digests[1]
+
+
+@pytest.mark.parametrize("k,i_batch", [(3, 0), (5, 1)])
+def test_conv_relu_cli(tmp_path, k, i_batch):
+    """`convReLU k i 1` (scope row 8f-1; BASELINE.md config 4 is k=5, i=1): convolution at out_scale 2^43, CtoS + sine,
+    ReLU polynomials, mask, StoC on the GPU; decrypted result vs max(conv, 0). The reference binary prints AVG 8.4 / MED 11.5
+    bits for `convReLU 5 1 1` (limited by the sign-polynomial approximation near 0)."""
+    gen.write_case(str(tmp_path / "test_conv_data"), k, i_batch, 0)
+    out = subprocess.run([CLI, "convReLU", str(k), str(i_batch), "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HCONV_SEED="31", HCONV_BOOT_STATS="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    txt = out.stdout
+    print(txt)
+    for pat in (r"^Convolution followed by ReLU \(& Bootstrapping\) test start!$", r"^Generating bootstrapping keys\.\.\.$",
+                r"^Bootstrapping\.\.\. Ours \(until CtoS\):$", r"^Done in \S+ $", r"^Eval: Eval: ReLU Done in \S+ $", r"^Boot \(StoC\) Done in \S+ $"):
+        assert re.search(pat, txt, re.M), f"missing line {pat!r} in:\n{txt}"
+    med = float(re.search(r"^MED Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M).group(1))
+    avg = float(re.search(r"^AVG Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M).group(1))
+    assert med >= 10.5 and avg >= 7.5, txt
