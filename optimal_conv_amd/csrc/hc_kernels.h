@@ -715,3 +715,122 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown(const u64 *acc, const 
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
         out[j] = hc_mul_shoup(hc_submod(acc[j], ext[j], q), pinv.w, pinv.ws, q);
 }
+
+// ================================================================ multi-modulus batches (leveled evaluator, general key switch)
+// One launch covers rows of DIFFERENT moduli: row y of the batch uses modulus index hc_mm_mod(y) = y < nl ? y : nq + (y - nl)
+// (the Q limbs 0..nl-1 of a level, then the special primes), blockIdx.z selects one of several operands zs_* words apart.
+// Rows in [skip_lo, skip_hi) are left untouched (a digit's own limbs during decomposition). Forward transforms use the
+// HC_FM_ALT folding, which every accepted modulus admits; outputs are canonical, so results equal the per-limb kernels'.
+struct HcRowMod { HcTwTab fwd, inv; u64 q, mu; };
+struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; };
+__device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl ? y : A.nq + (y - A.nl); }
+__global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd_mm(const u64 *in, u64 *out, HcMm A) {
+    __shared__ u64 lds[HC_COLS_LDS];
+    const int y = blockIdx.y; if (y >= A.skip_lo && y < A.skip_hi) return;
+    const HcRowMod &R = A.M[hc_mm_mod(A, y)];
+    const int t = threadIdx.x, c = t & 15, tid = t >> 4;
+    const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
+    in += (size_t)blockIdx.z * A.zs_in; out += (size_t)blockIdx.z * A.zs_out;
+    u64 e[16];
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) e[hi] = in[base + (size_t)(hi * 16 + tid) * 256];
+    hc_cols_fwd<HC_FM_ALT>(e, lds, R.fwd, c, tid, R.q);
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) out[base + (size_t)(tid * 16 + lo) * 256] = e[lo];
+}
+__global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, u64 *out, HcMm A) {
+    __shared__ u64 lds[HC_ROWS_LDS];
+    const int y = blockIdx.y; if (y >= A.skip_lo && y < A.skip_hi) return;
+    const HcRowMod &R = A.M[hc_mm_mod(A, y)];
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
+    const size_t pbase = (size_t)y * 65536;
+    in += (size_t)blockIdx.z * A.zs_in; out += (size_t)blockIdx.z * A.zs_out;
+    u64 e[16];
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) e[hi] = in[pbase + (size_t)row * 256 + hi * 16 + tid];
+    hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, R.q);
+    __syncthreads();
+    hc_rows_lo_to_lin(e, lds, t, rloc, tid);
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t] = hc_fwd_canon<HC_FM_ALT>(e[k], R.q, R.mu);
+}
+__global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
+    __shared__ u64 lds[HC_ROWS_LDS];
+    const int y = blockIdx.y; if (y >= A.skip_lo && y < A.skip_hi) return;
+    const HcRowMod &R = A.M[hc_mm_mod(A, y)];
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
+    const size_t pbase = (size_t)y * 65536;
+    in += (size_t)blockIdx.z * A.zs_in; out += (size_t)blockIdx.z * A.zs_out;
+    u64 e[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) e[k] = in[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t];
+    hc_rows_lin_to_lo(e, lds, t, rloc, tid);
+    __syncthreads();
+    hc_rows_inv(e, lds, R.inv, row, rloc, tid, R.q);
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) out[pbase + (size_t)row * 256 + hi * 16 + tid] = e[hi];
+}
+__global__ __launch_bounds__(HC_TPB) void hc_k_cols_inv_canon_mm(const u64 *in, u64 *out, HcMm A) {
+    __shared__ u64 lds[HC_COLS_LDS];
+    const int y = blockIdx.y; if (y >= A.skip_lo && y < A.skip_hi) return;
+    const HcRowMod &R = A.M[hc_mm_mod(A, y)];
+    const int t = threadIdx.x, c = t & 15, tid = t >> 4;
+    const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
+    in += (size_t)blockIdx.z * A.zs_in; out += (size_t)blockIdx.z * A.zs_out;
+    u64 e[16];
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) e[lo] = in[base + (size_t)(tid * 16 + lo) * 256];
+    hc_cols_inv(e, lds, R.inv, c, tid, R.q);
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_csub(e[hi], R.q);
+}
+// fast basis extension into every target row of the batch at once: B[y] holds the constants for target row y
+__global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend_mm(const u64 *src, size_t src_stride, u64 *dst, const HcBasisExt *Bs, int skip_lo, int skip_hi, size_t zs_src, size_t zs_dst) {
+    const int y = blockIdx.y; if (y >= skip_lo && y < skip_hi) return;
+    const HcBasisExt &B = Bs[y];
+    src += (size_t)blockIdx.z * zs_src; dst += (size_t)blockIdx.z * zs_dst + (size_t)y * 65536;
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        if (B.n == 1) { dst[j] = hc_barrett64(hc_barrett64(src[j], B.s[0], B.mu_s[0]), B.t, B.mu_t); continue; }
+        double vi = 0.0; u64 acc = 0;
+        for (int i = 0; i < B.n; i++) {
+            const u64 x = hc_barrett64(src[(size_t)i * src_stride + j], B.s[i], B.mu_s[i]);
+            const u64 yv = hc_mul_shoup(x, B.inv[i].w, B.inv[i].ws, B.s[i]);
+            vi += (double)yv / (double)B.s[i];
+            acc = hc_addmod(acc, hc_mul_shoup(hc_barrett64(yv, B.t, B.mu_t), B.hat[i].w, B.hat[i].ws, B.t), B.t);
+        }
+        const u64 v = (u64)vi;
+        dst[j] = hc_submod(acc, hc_mul_shoup(hc_barrett64(v, B.t, B.mu_t), B.smodt.w, B.smodt.ws, B.t), B.t);
+    }
+}
+// acc[k][T] (+)= evk[k][T] (*)_mont c2[T] for all limbs T and both key components k (blockIdx.z); a digit's own limbs
+// [lo,hi) read the NTT-domain input cx instead of the extended c2
+__global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_mm(const u64 *evk, const u64 *cx, const u64 *c2, u64 *acc, const HcMod *mods, int nl, int nq, int nt, int lo, int hi, int first) {
+    const int T = blockIdx.y, k = blockIdx.z;
+    const HcMod m = mods[T < nl ? T : nq + (T - nl)];
+    const u64 *e = evk + ((size_t)k * nt + T) * 65536, *x = (T >= lo && T < hi) ? cx + (size_t)T * 65536 : c2 + (size_t)T * 65536;
+    u64 *a = acc + ((size_t)k * nt + T) * 65536;
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        const u64 p = hc_mont(x[j], e[j], m.q, m.qinv);
+        a[j] = first ? p : hc_addmod(a[j], p, m.q);
+    }
+}
+// d_k[l] = (acc[k][l] - ext[k][l]) * P^-1 mod q_l for all limbs l and both k
+__global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_mm(const u64 *acc, size_t acc_zs, const u64 *ext, size_t ext_zs, u64 *d0, u64 *d1, const HcMod *mods, const HcTw *pinv) {
+    const int l = blockIdx.y, k = blockIdx.z; const u64 q = mods[l].q; const HcTw pi = pinv[l];
+    const u64 *a = acc + (size_t)k * acc_zs + (size_t)l * 65536, *x = ext + (size_t)k * ext_zs + (size_t)l * 65536;
+    u64 *o = (k ? d1 : d0) + (size_t)l * 65536;
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
+        o[j] = hc_mul_shoup(hc_submod(a[j], x[j], q), pi.w, pi.ws, q);
+}
+// general-level DivRoundByLastModulusNTT, all lower limbs per launch: lift (v[i] from t) and finish (out[i] = (x[i]-u[i]) * qL^-1)
+__global__ __launch_bounds__(HC_TPB) void hc_k_rescale_lift_mm(const u64 *t, u64 *v, const HcMod *mods, int level) {
+    const int i = blockIdx.y; const u64 qL = mods[level].q, h = (qL - 1) >> 1, qi = mods[i].q, mu_i = mods[i].mu, neg_h = qi - (h % qi);
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
+        v[(size_t)i * 65536 + j] = hc_barrett64(hc_csub(t[j] + h, qL) + neg_h, qi, mu_i);
+}
+__global__ __launch_bounds__(HC_TPB) void hc_k_rescale_finish_mm(const u64 *x, const u64 *u, u64 *out, const HcMod *mods, const HcTw *qlinv) {
+    const int i = blockIdx.y; const u64 q = mods[i].q; const HcTw w = qlinv[i];
+    const size_t b = (size_t)i * 65536;
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
+        out[b + j] = hc_mul_shoup(hc_submod(x[b + j], u[b + j], q), w.w, w.ws, q);
+}

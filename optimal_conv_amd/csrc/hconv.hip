@@ -91,6 +91,11 @@ struct hc_ctx {
     u64 *ws_ctc = nullptr;
     u64 *ws_tmp = nullptr; size_t ws_tmp_rows = 0;
     HcMod *d_mods = nullptr; HcTw *d_csts = nullptr;      // device copies: all moduli (Q then P); per-call constants of the leveled ops
+    HcRowMod *d_rowmods = nullptr;                          // per modulus: both twiddle tables + q, mu (multi-modulus batched transforms)
+    u64 *ws_mm = nullptr; size_t ws_mm_rows = 0;            // scratch of the batched key switch / rescale
+    struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr; };
+    std::map<int, KsPlan> ks_plan;                          // per level: basis-extension constants of every (digit, target limb)
+    std::map<int, HcTw *> rescale_plan;                     // per level: qL^-1 mod q_i
     long chunk_nodes = 64;
     long lanes = 1;               // internal concurrency of ONE conv_then_pack (power of two; 1 = single stream)
     std::vector<HcLane> lane;
@@ -225,6 +230,10 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
         if (hipMalloc((void **)&c->d_mods, hm.size() * sizeof(HcMod)) != hipSuccess || hipMalloc((void **)&c->d_csts, hm.size() * sizeof(HcTw)) != hipSuccess ||
             hipMemcpy(c->d_mods, hm.data(), hm.size() * sizeof(HcMod), hipMemcpyHostToDevice) != hipSuccess) { g_create_err = "hc_ctx_create: device modulus table"; hc_ctx_destroy(c); return HC_ERR_HIP; }
     }
+    {   std::vector<HcRowMod> hr; for (auto &mh : c->mods) { HcRowMod r; r.fwd = mh.fwd; r.inv = mh.inv; r.q = mh.m.q; r.mu = mh.m.mu; hr.push_back(r); }
+        if (hipMalloc((void **)&c->d_rowmods, hr.size() * sizeof(HcRowMod)) != hipSuccess ||
+            hipMemcpy(c->d_rowmods, hr.data(), hr.size() * sizeof(HcRowMod), hipMemcpyHostToDevice) != hipSuccess) { g_create_err = "hc_ctx_create: device table of transforms"; hc_ctx_destroy(c); return HC_ERR_HIP; }
+    }
     *out = c;
     return HC_OK;
 }
@@ -246,6 +255,10 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     if (c->ws_ctc) hipFree(c->ws_ctc);
     if (c->ws_tmp) hipFree(c->ws_tmp);
     if (c->d_mods) hipFree(c->d_mods);
+    if (c->d_rowmods) hipFree(c->d_rowmods);
+    if (c->ws_mm) hipFree(c->ws_mm);
+    for (auto &kv : c->ks_plan) { hipFree(kv.second.bx); hipFree(kv.second.bxdown); hipFree(kv.second.pinv); }
+    for (auto &kv : c->rescale_plan) hipFree(kv.second);
     if (c->d_csts) hipFree(c->d_csts);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
@@ -357,15 +370,39 @@ extern "C" int hc_lv_add(hc_ctx *c, int level, const uint64_t *a, const uint64_t
 extern "C" int hc_lv_sub(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_SUB>(c, "hc_lv_sub", level, a, b, out, nullptr); }
 extern "C" int hc_lv_mul_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_MULC>(c, "hc_lv_mul_const", level, a, nullptr, out, consts); }
 extern "C" int hc_lv_add_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_ADDC>(c, "hc_lv_add_const", level, a, nullptr, out, consts); }
+// batched transforms over rows of different moduli (row y <-> modulus y < nl ? y : nq + y - nl); z operands zs words apart
+static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out) {
+    HC_TRY(hc_ensure_tmp(c, (size_t)rows * z));
+    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi;
+    const dim3 grid(16, (unsigned)rows, (unsigned)z); const size_t zt = (size_t)rows * HC_N;
+    A.zs_in = zs_in; A.zs_out = zt; HC_TRY(hc_launch(c, "cols_fwd_mm", hc_k_cols_fwd_mm, grid, in, c->ws_tmp, A));
+    A.zs_in = zt; A.zs_out = zs_out; HC_TRY(hc_launch(c, "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
+    return HC_OK;
+}
+static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out) {
+    HC_TRY(hc_ensure_tmp(c, (size_t)rows * z));
+    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = A.skip_hi = 0;
+    const dim3 grid(16, (unsigned)rows, (unsigned)z); const size_t zt = (size_t)rows * HC_N;
+    A.zs_in = zs_in; A.zs_out = zt; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, in, c->ws_tmp, A));
+    A.zs_in = zt; A.zs_out = zs_out; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
+    return HC_OK;
+}
+static int hc_ensure_mm(hc_ctx *c, size_t rows) {
+    if (c->ws_mm_rows >= rows) return HC_OK;
+    HC_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->ws_mm) HC_HIP(c, hipFree(c->ws_mm));
+    c->ws_mm = nullptr; c->ws_mm_rows = 0;
+    HC_HIP(c, hipMalloc((void **)&c->ws_mm, rows * HC_N * sizeof(u64)));
+    c->ws_mm_rows = rows;
+    return HC_OK;
+}
 extern "C" int hc_lv_ntt(hc_ctx *c, int level, const uint64_t *in, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_ntt", level, in, out));
-    for (int l = 0; l <= level; l++) HC_TRY(hc_ntt(c, l, in + (size_t)l * HC_N, out + (size_t)l * HC_N, 1));
-    return HC_OK;
+    return hc_ntt_mm(c, in, out, level + 1, level + 1, 0, 0, 1, 0, 0);
 }
 extern "C" int hc_lv_intt(hc_ctx *c, int level, const uint64_t *in, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_intt", level, in, out));
-    for (int l = 0; l <= level; l++) HC_TRY(hc_intt(c, l, in + (size_t)l * HC_N, out + (size_t)l * HC_N, 1));
-    return HC_OK;
+    return hc_intt_mm(c, in, out, level + 1, level + 1, 1, 0, 0);
 }
 extern "C" int hc_lv_mod_raise(hc_ctx *c, int level, const uint64_t *in_q0, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mod_raise", level, in_q0, out));
@@ -445,20 +482,23 @@ extern "C" int hc_div_round_last(hc_ctx *c, int level, const uint64_t *x, uint64
     if (level < 1 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "hc_div_round_last: level %d outside 1..%d", level, c->nq - 1);
     if (!x || !out) return hc_fail(c, HC_ERR_ARG, "hc_div_round_last: null");
     if (level != 1) {
-        // general level (the leveled evaluator of the convReLU chain): InvNTT of the last limb, centred lift into every
-        // lower modulus, NTT there, subtract, multiply by qL^-1. in == out is allowed (row i is read before it is written).
-        const HcMod &mL = c->mods[(size_t)level].m; const u64 qL = mL.q, h = (qL - 1) >> 1;
-        u64 *buf = nullptr; HC_HIP(c, hipMalloc((void **)&buf, (size_t)2 * HC_N * sizeof(u64)));
-        u64 *t = buf, *v = buf + HC_N;
-        int rc = hc_intt(c, level, x + (size_t)level * HC_N, t, 1);
-        for (int i = 0; i < level && !rc; i++) {
-            const HcMod &m = c->mods[(size_t)i].m;
-            rc = hc_launch(c, "rescale_lift", hc_k_rescale_lift, hc_pw_grid(HC_N), (const u64 *)t, v, qL, h, m.q, m.mu, m.q - (h % m.q));
-            if (!rc) rc = hc_ntt(c, i, v, v, 1);
-            if (!rc) rc = hc_launch(c, "rescale_finish", hc_k_rescale_finish, hc_pw_grid(HC_N), x + (size_t)i * HC_N, (const u64 *)v, out + (size_t)i * HC_N, m.q, h_pair(h_inv(qL % m.q, m.q), m.q));
+        // general level (the leveled evaluator of the convReLU chain): InvNTT of the last limb, centred lift into every lower
+        // modulus, NTT there, subtract, multiply by qL^-1 -- six launches whatever the level. in == out is allowed.
+        const u64 qL = c->mods[(size_t)level].m.q;
+        auto it = c->rescale_plan.find(level);
+        if (it == c->rescale_plan.end()) {
+            std::vector<HcTw> h((size_t)level);
+            for (int i = 0; i < level; i++) { const u64 q = c->mods[(size_t)i].m.q; h[(size_t)i] = h_pair(h_inv(qL % q, q), q); }
+            HcTw *d = nullptr; HC_HIP(c, hipMalloc((void **)&d, h.size() * sizeof(HcTw)));
+            HC_HIP(c, hipMemcpy(d, h.data(), h.size() * sizeof(HcTw), hipMemcpyHostToDevice));
+            it = c->rescale_plan.emplace(level, d).first;
         }
-        hipStreamSynchronize(c->stream); hipFree(buf);
-        return rc;
+        HC_TRY(hc_ensure_mm(c, (size_t)level + 1));
+        u64 *t = c->ws_mm, *v = c->ws_mm + HC_N;
+        HC_TRY(hc_intt(c, level, x + (size_t)level * HC_N, t, 1));
+        HC_TRY(hc_launch(c, "rescale_lift_mm", hc_k_rescale_lift_mm, dim3(64, (unsigned)level), (const u64 *)t, v, (const HcMod *)c->d_mods, level));
+        HC_TRY(hc_ntt_mm(c, v, v, level, level, 0, 0, 1, 0, 0));
+        return hc_launch(c, "rescale_finish_mm", hc_k_rescale_finish_mm, dim3(64, (unsigned)level), x, (const u64 *)v, out, (const HcMod *)c->d_mods, (const HcTw *)it->second);
     }
     // Build a "ciphertext" whose polynomial 0 is x and a kernel equal to R mod q (Montgomery form of 1).
     HC_TRY(hc_ensure_tmp(c, 16));
@@ -791,45 +831,50 @@ extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_
     if (!cx || !d0 || !d1 || level != it->second.level) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch: bad arguments (key loaded for level %d)", it->second.level);
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = it->second.beta;
     const u64 *evk = it->second.rows;
-    // scratch rows: coef[nl] | c2[1] | ext[1] | acc[2][nt] | pc[alpha]
-    u64 *buf = nullptr; const size_t rows = (size_t)nl + 2 + 2 * nt + alpha;
-    HC_HIP(c, hipMalloc((void **)&buf, rows * HC_N * sizeof(u64)));
-    u64 *coef = buf, *c2 = coef + (size_t)nl * HC_N, *ext = c2 + HC_N, *acc = ext + HC_N, *pc = acc + (size_t)2 * nt * HC_N;
-    int rc = HC_OK;
-    auto modidx = [&](int T) { return T < nl ? T : c->nq + (T - nl); };
-    for (int l = 0; l < nl && !rc; l++) rc = hc_intt(c, l, cx + (size_t)l * HC_N, coef + (size_t)l * HC_N, 1);       // cxInvNTT
-    for (int d = 0; d < beta && !rc; d++) {
+    // constants of every basis extension of this level, built once: digit d -> target limb T, and {P} -> Q limb l
+    auto pit = c->ks_plan.find(level);
+    if (pit == c->ks_plan.end()) {
+        std::vector<HcBasisExt> hb((size_t)beta * nt), hd((size_t)nl); std::vector<HcTw> hp((size_t)nl);
+        auto modq = [&](int T) { return c->mods[(size_t)(T < nl ? T : c->nq + (T - nl))].m.q; };
+        for (int d = 0; d < beta; d++) {
+            const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl;
+            std::vector<u64> src; for (int i = lo; i < hi; i++) src.push_back(c->mods[(size_t)i].m.q);
+            for (int T = 0; T < nt; T++) hb[(size_t)d * nt + T] = hc_make_bx(src, modq(T));
+        }
+        std::vector<u64> psrc; for (int j = 0; j < alpha; j++) psrc.push_back(c->mods[(size_t)(c->nq + j)].m.q);
+        for (int l = 0; l < nl; l++) {
+            const u64 q = c->mods[(size_t)l].m.q; u64 pmod = 1; for (u64 pj : psrc) pmod = h_mulmod(pmod, pj % q, q);
+            hd[(size_t)l] = hc_make_bx(psrc, q); hp[(size_t)l] = h_pair(h_inv(pmod, q), q);
+        }
+        hc_ctx::KsPlan P;
+        HC_HIP(c, hipMalloc((void **)&P.bx, hb.size() * sizeof(HcBasisExt))); HC_HIP(c, hipMalloc((void **)&P.bxdown, hd.size() * sizeof(HcBasisExt))); HC_HIP(c, hipMalloc((void **)&P.pinv, hp.size() * sizeof(HcTw)));
+        HC_HIP(c, hipMemcpy(P.bx, hb.data(), hb.size() * sizeof(HcBasisExt), hipMemcpyHostToDevice));
+        HC_HIP(c, hipMemcpy(P.bxdown, hd.data(), hd.size() * sizeof(HcBasisExt), hipMemcpyHostToDevice));
+        HC_HIP(c, hipMemcpy(P.pinv, hp.data(), hp.size() * sizeof(HcTw), hipMemcpyHostToDevice));
+        pit = c->ks_plan.emplace(level, P).first;
+    }
+    const hc_ctx::KsPlan &P = pit->second;
+    // scratch rows: coef[nl] | c2[nt] | acc[2][nt] | pc[2][alpha] | ext[2][nl]
+    HC_TRY(hc_ensure_mm(c, (size_t)nl + nt + 2 * nt + 2 * alpha + 2 * nl));
+    u64 *coef = c->ws_mm, *c2 = coef + (size_t)nl * HC_N, *acc = c2 + (size_t)nt * HC_N, *pc = acc + (size_t)2 * nt * HC_N, *ext = pc + (size_t)2 * alpha * HC_N;
+    HC_TRY(hc_intt_mm(c, cx, coef, nl, nl, 1, 0, 0));                                                    // cxInvNTT, all limbs
+    for (int d = 0; d < beta; d++) {
         const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl;
-        std::vector<u64> src; for (int i = lo; i < hi; i++) src.push_back(c->mods[(size_t)i].m.q);
-        for (int T = 0; T < nt && !rc; T++) {
-            const int mod = modidx(T); const HcMod &m = c->mods[(size_t)mod].m;
-            const u64 *c2row;
-            if (T >= lo && T < hi) c2row = cx + (size_t)T * HC_N;                       // the digit's own limbs reuse the NTT input
-            else {
-                rc = hc_launch(c, "ks_basis_extend", hc_k_basis_extend, hc_pw_grid(HC_N), (const u64 *)(coef + (size_t)lo * HC_N), (size_t)HC_N, ext, hc_make_bx(src, m.q));
-                if (!rc) rc = hc_ntt(c, mod, ext, c2, 1);
-                c2row = c2;
-            }
-            for (int k = 0; k < 2 && !rc; k++)
-                rc = hc_launch(c, "ks_mac", hc_k_ks_mac, hc_pw_grid(HC_N), evk + (((size_t)d * 2 + k) * nt + T) * HC_N, c2row, acc + ((size_t)k * nt + T) * HC_N, m, d == 0 ? 1 : 0);
-        }
+        // DecomposeAndSplit: the digit's residues extended to every other limb (Q and P), then NTT there
+        HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(32, (unsigned)nt), (const u64 *)(coef + (size_t)lo * HC_N), (size_t)HC_N, c2, (const HcBasisExt *)(P.bx + (size_t)d * nt), lo, hi, (size_t)0, (size_t)0));
+        HC_TRY(hc_ntt_mm(c, c2, c2, nt, nl, lo, hi, 1, 0, 0));
+        HC_TRY(hc_launch(c, "ks_mac_mm", hc_k_ks_mac_mm, dim3(32, (unsigned)nt, 2), evk + (size_t)d * 2 * nt * HC_N, cx, (const u64 *)c2, acc, (const HcMod *)c->d_mods, nl, c->nq, nt, lo, hi, d == 0 ? 1 : 0));
     }
-    // ModDownSplitNTTPQ
-    std::vector<u64> psrc; for (int j = 0; j < alpha; j++) psrc.push_back(c->mods[(size_t)(c->nq + j)].m.q);
-    for (int k = 0; k < 2 && !rc; k++) {
-        for (int j = 0; j < alpha && !rc; j++) rc = hc_intt(c, c->nq + j, acc + ((size_t)k * nt + nl + j) * HC_N, pc + (size_t)j * HC_N, 1);
-        u64 *out = k == 0 ? (u64 *)d0 : (u64 *)d1;
-        for (int l = 0; l < nl && !rc; l++) {
-            const HcMod &m = c->mods[(size_t)l].m;
-            u64 pmod = 1; for (u64 pj : psrc) pmod = h_mulmod(pmod, pj % m.q, m.q);
-            rc = hc_launch(c, "ks_basis_extend", hc_k_basis_extend, hc_pw_grid(HC_N), (const u64 *)pc, (size_t)HC_N, ext, hc_make_bx(psrc, m.q));
-            if (!rc) rc = hc_ntt(c, l, ext, ext, 1);
-            if (!rc) rc = hc_launch(c, "ks_moddown", hc_k_ks_moddown, hc_pw_grid(HC_N), (const u64 *)(acc + ((size_t)k * nt + l) * HC_N), (const u64 *)ext, out + (size_t)l * HC_N, m.q, h_pair(h_inv(pmod, m.q), m.q));
-        }
+    // ModDownSplitNTTPQ for both components: InvNTT of the P limbs, {P} -> every Q limb, NTT, (acc - ext) * P^-1
+    {   HcMm A; A.M = c->d_rowmods; A.nl = 0; A.nq = c->nq; A.skip_lo = A.skip_hi = 0;                  // rows y -> modulus nq + y
+        HC_TRY(hc_ensure_tmp(c, (size_t)2 * alpha));
+        const dim3 grid(16, (unsigned)alpha, 2); const size_t zt = (size_t)alpha * HC_N;
+        A.zs_in = (size_t)nt * HC_N; A.zs_out = zt; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, (const u64 *)(acc + (size_t)nl * HC_N), c->ws_tmp, A));
+        A.zs_in = zt; A.zs_out = zt; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, pc, A));
     }
-    hipStreamSynchronize(c->stream);
-    hipFree(buf);
-    return rc;
+    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(32, (unsigned)nl, 2), (const u64 *)pc, (size_t)HC_N, ext, (const HcBasisExt *)P.bxdown, 0, 0, (size_t)alpha * HC_N, (size_t)nl * HC_N));
+    HC_TRY(hc_ntt_mm(c, ext, ext, nl, nl, 0, 0, 2, (size_t)nl * HC_N, (size_t)nl * HC_N));
+    return hc_launch(c, "ks_moddown_mm", hc_k_ks_moddown_mm, dim3(32, (unsigned)nl, 2), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)ext, (size_t)nl * HC_N, (u64 *)d0, (u64 *)d1, (const HcMod *)c->d_mods, (const HcTw *)P.pinv);
 }
 
 // ------------------------------------------------------------------ L1
