@@ -14,6 +14,9 @@ from optimal_conv_amd import Context
 ctx = Context([Q0, Q1], [P0], lib_path="$PWD/tests/kernel_emu/_build/libhconv_emu_ubsan.so"); O = Oracle()
 pc.case_ntt(ctx, O); pc.case_pointwise(ctx, O); pc.case_rescale(ctx, O); pc.case_keyswitch(ctx, O); pc.case_modup_overflow(ctx, O)
 pc.case_conv(ctx, O, 8, chunk=3); pc.case_prep_ker(ctx, O, 3, 0)
+LIB = "$PWD/tests/kernel_emu/_build/libhconv_emu_ubsan.so"
+pc.case_keyswitch_general(lambda Q, P: Context(Q, P, lib_path=LIB), lambda Q, P: Oracle(q=Q, p=P), shapes=((1, 2), (4, 3)))   # batched multi-modulus key switch
+pc.case_ckks_ops(lambda Q, P: Context(Q, P, lib_path=LIB), levels=((6, 2.0 ** 30),))                                        # hc_lv_*, general rescale, mod raise
 print("UBSAN KERNEL-SOURCE RUN OK")
 PY
 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libubsan.so) python /tmp/hc_ubsan_run.py
@@ -30,6 +33,9 @@ ct_in, ker = pc.planted_conv_inputs(5, 4)
 evk = np.zeros((16, 4, 65536), dtype=np.uint64)
 for j in (15, 16): evk[j - 1] = pc.seeded_evk(100 + j)
 O.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, O.idx_plaintexts(), evk, 4, 1, 2.0 ** 30, splitmix_rows(9, Q0, 65536))
+import oracle_ckks as ck
+C = ck.Ckks(logN=10, h=64)                                            # general key switch (5 special primes), rescale, relin key generation
+ck.conv_relu_tail(C, ck.Bootstrapper(C), C.encrypt_coeffs(np.linspace(-9, 9, C.N), 0, 2.0 ** 43, seed=2), 0.0, 4, 16, 15)
 sk = O.gen_sk(1); O.gen_galois_key_l0(sk, 65537, 3); O.encrypt(sk, O.encode_coeffs(np.linspace(-1, 1, 65536), 2.0 ** 30, [0, 1]), 1, 4)
 print("ASAN ORACLE RUN OK")
 PY
