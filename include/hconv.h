@@ -83,6 +83,9 @@ int hc_lv_intt(hc_ctx *ctx, int level, const uint64_t *in, uint64_t *out);
 int hc_lv_mul(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
 int hc_lv_add(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
 int hc_lv_sub(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
+/* the tensor step of evaluator.mulRelin (conv.go:476; EvaluatePoly): d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1; outputs may not alias inputs */
+int hc_lv_mul_tensor(hc_ctx *ctx, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1,
+                     uint64_t *d0, uint64_t *d1, uint64_t *d2);
 /* consts_host: level+1 host integers, one per limb (reduced mod q_l by the callee) */
 int hc_lv_mul_const(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *consts_host, uint64_t *out);
 int hc_lv_add_const(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *consts_host, uint64_t *out);

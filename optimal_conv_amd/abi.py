@@ -44,6 +44,7 @@ SYMBOLS = {
     "hc_lv_mul": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_lv_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_lv_sub": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_lv_mul_tensor": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 7),
     "hc_lv_mul_const": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_void_p]),
     "hc_lv_add_const": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_void_p]),
     "hc_lv_mod_raise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -280,6 +281,16 @@ class Context:
     def lv_sub(self, level, a, b): return self._lv(self.L.hc_lv_sub, level, a, b)
     def lv_mul_const(self, level, a, consts): return self._lv(self.L.hc_lv_mul_const, level, a, consts=consts)
     def lv_add_const(self, level, a, consts): return self._lv(self.L.hc_lv_add_const, level, a, consts=consts)
+    def lv_mul_tensor(self, level, a, b):
+        """a, b: (2, level+1, N) -> (d0, d1, d2)"""
+        A, B = self.buf(np.ascontiguousarray(a, dtype=np.uint64)), self.buf(np.ascontiguousarray(b, dtype=np.uint64))
+        n = (level + 1) * self.N
+        D = self.buf(nwords=3 * n)
+        self._ck(self.L.hc_lv_mul_tensor(self.h, level, A.at(0), A.at(n), B.at(0), B.at(n), D.at(0), D.at(n), D.at(2 * n)))
+        out = D.download((3, level + 1, self.N))
+        A.free(); B.free(); D.free()
+        return out[0], out[1], out[2]
+
     def lv_mod_raise(self, level, row_q0): return self._lv(self.L.hc_lv_mod_raise, level, row_q0)
 
     def rotate_gal_l0(self, gal, ct):

@@ -267,6 +267,18 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const 
         out[base + i] = r;
     }
 }
+// the tensor step of ckks.evaluator.mulRelin for all limbs: d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1 (canonical)
+__global__ __launch_bounds__(HC_TPB) void hc_k_lv_tensor(const u64 *a0, const u64 *a1, const u64 *b0, const u64 *b1, u64 *d0, u64 *d1, u64 *d2, const HcMod *mods) {
+    const int l = blockIdx.y; const HcMod m = mods[l];
+    const size_t base = (size_t)l * 65536;
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
+        const u64 x0 = a0[base + i], x1 = a1[base + i];
+        const u64 y0 = hc_mont(b0[base + i], m.r2, m.q, m.qinv), y1 = hc_mont(b1[base + i], m.r2, m.q, m.qinv);   // MForm, as mulRelin does
+        d0[base + i] = hc_mont(x0, y0, m.q, m.qinv);
+        d1[base + i] = hc_addmod(hc_mont(x0, y1, m.q, m.qinv), hc_mont(x1, y0, m.q, m.qinv), m.q);
+        d2[base + i] = hc_mont(x1, y1, m.q, m.qinv);
+    }
+}
 // ckks.(*Bootstrapper).modUp for one polynomial: coefficient row t (canonical mod q0) -> centred lift reduced into limb blockIdx.y
 __global__ __launch_bounds__(HC_TPB) void hc_k_mod_raise(const u64 *t, u64 *out, const HcMod *mods) {
     const int l = blockIdx.y; const u64 q0 = mods[0].q, q = mods[l].q, mu = mods[l].mu;
@@ -784,22 +796,35 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_inv_canon_mm(const u64 *in, 
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_csub(e[hi], R.q);
 }
-// fast basis extension into every target row of the batch at once: B[y] holds the constants for target row y
-__global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend_mm(const u64 *src, size_t src_stride, u64 *dst, const HcBasisExt *Bs, int skip_lo, int skip_hi, size_t zs_src, size_t zs_dst) {
-    const int y = blockIdx.y; if (y >= skip_lo && y < skip_hi) return;
-    const HcBasisExt &B = Bs[y];
-    src += (size_t)blockIdx.z * zs_src; dst += (size_t)blockIdx.z * zs_dst + (size_t)y * 65536;
+// fast basis extension into every target row of the batch: Bs[T] holds the constants for target row T (the source-side
+// constants s, inv, mu_s are the same in all of them). One thread owns a coefficient: y_i and the fp64 overflow count v are
+// computed once, then reused for the targets T = blockIdx.y, blockIdx.y + gridDim.y, ... (rows in [skip_lo, skip_hi) excepted).
+__global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend_mm(const u64 *src, size_t src_stride, u64 *dst, const HcBasisExt *Bs, int rows, int skip_lo, int skip_hi, size_t zs_src, size_t zs_dst) {
+    src += (size_t)blockIdx.z * zs_src; dst += (size_t)blockIdx.z * zs_dst;
+    const HcBasisExt &B0 = Bs[0];
+    const int n = B0.n;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        if (B.n == 1) { dst[j] = hc_barrett64(hc_barrett64(src[j], B.s[0], B.mu_s[0]), B.t, B.mu_t); continue; }
-        double vi = 0.0; u64 acc = 0;
-        for (int i = 0; i < B.n; i++) {
-            const u64 x = hc_barrett64(src[(size_t)i * src_stride + j], B.s[i], B.mu_s[i]);
-            const u64 yv = hc_mul_shoup(x, B.inv[i].w, B.inv[i].ws, B.s[i]);
-            vi += (double)yv / (double)B.s[i];
-            acc = hc_addmod(acc, hc_mul_shoup(hc_barrett64(yv, B.t, B.mu_t), B.hat[i].w, B.hat[i].ws, B.t), B.t);
+        u64 y[8]; double vi = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i < n) {
+            const u64 x = hc_barrett64(src[(size_t)i * src_stride + j], B0.s[i], B0.mu_s[i]);
+            y[i] = n == 1 ? x : hc_mul_shoup(x, B0.inv[i].w, B0.inv[i].ws, B0.s[i]);
+            vi += (double)y[i] / (double)B0.s[i];
         }
         const u64 v = (u64)vi;
-        dst[j] = hc_submod(acc, hc_mul_shoup(hc_barrett64(v, B.t, B.mu_t), B.smodt.w, B.smodt.ws, B.t), B.t);
+        for (int T = blockIdx.y; T < rows; T += gridDim.y) {
+            if (T >= skip_lo && T < skip_hi) continue;
+            const HcBasisExt &B = Bs[T];
+            u64 r;
+            if (n == 1) r = hc_barrett64(y[0], B.t, B.mu_t);
+            else {
+                u64 acc = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) if (i < n) acc = hc_addmod(acc, hc_mul_shoup(hc_barrett64(y[i], B.t, B.mu_t), B.hat[i].w, B.hat[i].ws, B.t), B.t);
+                r = hc_submod(acc, hc_mul_shoup(hc_barrett64(v, B.t, B.mu_t), B.smodt.w, B.smodt.ws, B.t), B.t);
+            }
+            dst[(size_t)T * 65536 + j] = r;
+        }
     }
 }
 // acc[k][T] (+)= evk[k][T] (*)_mont c2[T] for all limbs T and both key components k (blockIdx.z); a digit's own limbs

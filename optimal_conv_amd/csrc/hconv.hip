@@ -404,6 +404,11 @@ extern "C" int hc_lv_intt(hc_ctx *c, int level, const uint64_t *in, uint64_t *ou
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_intt", level, in, out));
     return hc_intt_mm(c, in, out, level + 1, level + 1, 1, 0, 0);
 }
+extern "C" int hc_lv_mul_tensor(hc_ctx *c, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *d0, uint64_t *d1, uint64_t *d2) {
+    HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mul_tensor", level, a0, d0));
+    if (!a1 || !b0 || !b1 || !d1 || !d2) return hc_fail(c, HC_ERR_ARG, "hc_lv_mul_tensor: null");
+    return hc_launch(c, "lv_tensor", hc_k_lv_tensor, hc_lv_grid(level), (const u64 *)a0, (const u64 *)a1, (const u64 *)b0, (const u64 *)b1, (u64 *)d0, (u64 *)d1, (u64 *)d2, (const HcMod *)c->d_mods);
+}
 extern "C" int hc_lv_mod_raise(hc_ctx *c, int level, const uint64_t *in_q0, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mod_raise", level, in_q0, out));
     if ((const void *)in_q0 == (const void *)out) return hc_fail(c, HC_ERR_ARG, "hc_lv_mod_raise: in and out must differ");
@@ -861,7 +866,7 @@ extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_
     for (int d = 0; d < beta; d++) {
         const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl;
         // DecomposeAndSplit: the digit's residues extended to every other limb (Q and P), then NTT there
-        HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(32, (unsigned)nt), (const u64 *)(coef + (size_t)lo * HC_N), (size_t)HC_N, c2, (const HcBasisExt *)(P.bx + (size_t)d * nt), lo, hi, (size_t)0, (size_t)0));
+        HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4), (const u64 *)(coef + (size_t)lo * HC_N), (size_t)HC_N, c2, (const HcBasisExt *)(P.bx + (size_t)d * nt), nt, lo, hi, (size_t)0, (size_t)0));
         HC_TRY(hc_ntt_mm(c, c2, c2, nt, nl, lo, hi, 1, 0, 0));
         HC_TRY(hc_launch(c, "ks_mac_mm", hc_k_ks_mac_mm, dim3(32, (unsigned)nt, 2), evk + (size_t)d * 2 * nt * HC_N, cx, (const u64 *)c2, acc, (const HcMod *)c->d_mods, nl, c->nq, nt, lo, hi, d == 0 ? 1 : 0));
     }
@@ -872,7 +877,7 @@ extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_
         A.zs_in = (size_t)nt * HC_N; A.zs_out = zt; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, (const u64 *)(acc + (size_t)nl * HC_N), c->ws_tmp, A));
         A.zs_in = zt; A.zs_out = zt; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, pc, A));
     }
-    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(32, (unsigned)nl, 2), (const u64 *)pc, (size_t)HC_N, ext, (const HcBasisExt *)P.bxdown, 0, 0, (size_t)alpha * HC_N, (size_t)nl * HC_N));
+    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4, 2), (const u64 *)pc, (size_t)HC_N, ext, (const HcBasisExt *)P.bxdown, nl, 0, 0, (size_t)alpha * HC_N, (size_t)nl * HC_N));
     HC_TRY(hc_ntt_mm(c, ext, ext, nl, nl, 0, 0, 2, (size_t)nl * HC_N, (size_t)nl * HC_N));
     return hc_launch(c, "ks_moddown_mm", hc_k_ks_moddown_mm, dim3(32, (unsigned)nl, 2), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)ext, (size_t)nl * HC_N, (u64 *)d0, (u64 *)d1, (const HcMod *)c->d_mods, (const HcTw *)P.pinv);
 }

@@ -206,11 +206,7 @@ struct Boot {
         const int L = std::min(a.level, b.level);
         DCt r = new_ct(L, 1, a.scale * b.scale);
         auto d1 = block(), d2 = block(), t = block(), k = block();
-        HCR(hc_lv_mul(hc, L, a.p[0].get(), b.p[0].get(), r.p[0].get()));
-        HCR(hc_lv_mul(hc, L, a.p[0].get(), b.p[1].get(), d1.get()));
-        HCR(hc_lv_mul(hc, L, a.p[1].get(), b.p[0].get(), t.get()));
-        HCR(hc_lv_add(hc, L, d1.get(), t.get(), d1.get()));
-        HCR(hc_lv_mul(hc, L, a.p[1].get(), b.p[1].get(), d2.get()));
+        HCR(hc_lv_mul_tensor(hc, L, a.p[0].get(), a.p[1].get(), b.p[0].get(), b.p[1].get(), r.p[0].get(), d1.get(), d2.get()));
         HCR(hc_keyswitch(hc, key(0, L), L, d2.get(), t.get(), k.get())); n_keyswitch++;
         HCR(hc_lv_add(hc, L, r.p[0].get(), t.get(), r.p[0].get()));
         HCR(hc_lv_add(hc, L, d1.get(), k.get(), r.p[1].get()));

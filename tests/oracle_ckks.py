@@ -303,9 +303,12 @@ class Ckks:
         a, b = self._align(a, b)
         L = a.level
         be = self.be
-        d0 = be.lv_mul(a.rows[0], b.rows[0])
-        d1 = be.lv_add(be.lv_mul(a.rows[0], b.rows[1]), be.lv_mul(a.rows[1], b.rows[0]))
-        d2 = be.lv_mul(a.rows[1], b.rows[1])
+        if hasattr(be, "lv_mul_tensor"):
+            d0, d1, d2 = be.lv_mul_tensor(a.rows, b.rows)
+        else:
+            d0 = be.lv_mul(a.rows[0], b.rows[0])
+            d1 = be.lv_add(be.lv_mul(a.rows[0], b.rows[1]), be.lv_mul(a.rows[1], b.rows[0]))
+            d2 = be.lv_mul(a.rows[1], b.rows[1])
         k0, k1 = be.keyswitch(self.key(0, L), d2)
         self.counters["keyswitch"] += 1
         self.counters["mul_relin"] += 1

@@ -297,6 +297,7 @@ class CkksDeviceBackend:
     def lv_mul_const(self, a, consts): return self.ctx.lv_mul_const(a.shape[0] - 1, a, consts)
     def lv_add_const(self, a, consts): return self.ctx.lv_add_const(a.shape[0] - 1, a, consts)
     def lv_mod_raise(self, level, row_q0): return self.ctx.lv_mod_raise(level, row_q0)
+    def lv_mul_tensor(self, a, b): return self.ctx.lv_mul_tensor(a.shape[1] - 1, a, b)
 
     def keyswitch(self, key, cx):
         kid = self._ids.get((key.gal, key.level))
