@@ -346,12 +346,14 @@ class Ckks:
         return Ct(np.stack([self.be.lv_mod_raise(level, ct.rows[d, 0]) for d in range(2)]), ct.scale)
 
     # ---- linear transforms (diagonal form, baby-step giant-step)
-    def matmul_diag(self, M2, M1):
-        """(M2 . M1) in diagonal form; each M is {rotation k: complex vector of n}"""
+    def matmul_diag(self, M2, M1, period=None):
+        """(M2 . M1) in diagonal form; each M is {rotation k: complex vector of n}. `period`: the vectors the product acts on
+        are periodic with this period (sparse slots), so rotation indices are taken modulo it"""
         out = {}
+        period = period or self.n
         for k2, d2 in M2.items():
             for k1, d1 in M1.items():
-                k = (k1 + k2) % self.n
+                k = (k1 + k2) % period
                 t = d2 * np.roll(d1, -k2)
                 out[k] = out[k] + t if k in out else t
         return {k: v for k, v in out.items() if np.any(v != 0)}
@@ -387,40 +389,47 @@ class Ckks:
             acc = inner if acc is None else self.add(acc, inner)
         return acc
 
-    def dft_stage(self, ln, inverse):
-        """one radix-2 stage of the encoder's special (i)FFT as a 3-diagonal matrix (no bit reversal)"""
+    def dft_stage(self, ln, inverse, enc=None, period=None):
+        """one radix-2 stage of the encoder's special (i)FFT as a 3-diagonal matrix (no bit reversal). With `enc` the encoder of
+        a subring X^D (sparse slots): the same butterflies with that ring's roots, tiled over the n full slots; rotation
+        indices modulo `period` (the slot vector's period)"""
         n, lenh = self.n, ln >> 1
+        enc = enc or self.enc
+        period = period or n
         j = np.arange(n) % ln
         first = j < lenh
         if inverse:       # out[p] = v[p] + v[p+lenh] (first half) ; (v[p-lenh] - v[p]) * w[j-lenh] (second half)
-            w = self.enc.inv_stage_twiddles(ln)
+            w = enc.inv_stage_twiddles(ln)
             wj = w[(j - lenh) % lenh] if lenh > 0 else w
             d0 = np.where(first, 1.0 + 0j, -wj)
             dp = np.where(first, 1.0 + 0j, 0j)
             dm = np.where(first, 0j, wj)
         else:             # a = v[p], b = v[p+lenh] * w[j]: out[p] = a + b ; out[p+lenh] = a - b
-            w = self.enc.fwd_stage_twiddles(ln)
+            w = enc.fwd_stage_twiddles(ln)
             wj = w[j % lenh]
             d0 = np.where(first, 1.0 + 0j, -wj)
             dp = np.where(first, wj, 0j)
             dm = np.where(first, 0j, 1.0 + 0j)
         M = {0: d0}
-        for k, d in ((lenh % n, dp), ((-lenh) % n, dm)):
+        for k, d in ((lenh % period, dp), ((-lenh) % period, dm)):
             M[k] = M[k] + d if k in M else d
         return M
 
-    def dft_groups(self, inverse, group_sizes, constant):
-        """the log2(n) stages in application order, merged into len(group_sizes) matrices; `constant` spread evenly"""
-        logn = self.logN - 1
-        lens = [self.n >> s for s in range(logn)] if inverse else [2 << s for s in range(logn)]
+    def dft_groups(self, inverse, group_sizes, constant, log_sparse=0):
+        """the log2(n_s) stages in application order, merged into len(group_sizes) matrices; `constant` spread evenly.
+        log_sparse > 0: the DFT of the subring X^(2^log_sparse) with n_s = n / 2^log_sparse slots, acting on n_s-periodic vectors"""
+        logn = self.logN - 1 - log_sparse
+        ns = self.n >> log_sparse
+        enc = self.enc if log_sparse == 0 else Encoder(self.logN - log_sparse)
+        lens = [ns >> s for s in range(logn)] if inverse else [2 << s for s in range(logn)]
         assert sum(group_sizes) == logn
         groups, pos = [], 0
         c = constant ** (1.0 / len(group_sizes))
         for gs in group_sizes:
             M = None
             for ln in lens[pos: pos + gs]:
-                S = self.dft_stage(ln, inverse)
-                M = S if M is None else self.matmul_diag(S, M)
+                S = self.dft_stage(ln, inverse, enc, ns)
+                M = S if M is None else self.matmul_diag(S, M, ns)
             groups.append({k: v * c for k, v in M.items()})
             pos += gs
         return groups
@@ -594,18 +603,55 @@ def gen_keep_vec(vec_size, in_wid, kp_wid, ul):
     return idx
 
 
+def gen_keep_vec_sparse(vec_size, in_wid, kp_wid, log_sparse):
+    """rot_util.go:179-218: one mask for the packed (low | high) ciphertext of sparse bootstrapping, period 2 n_s"""
+    logN = (2 * vec_size - 1).bit_length()
+    batch = 2 * vec_size // (in_wid * in_wid)
+    sparsity = 1 << log_sparse
+    assert sparsity > 1, "We do not support full packing in gen_keep_vec_sparse"
+    assert kp_wid >= in_wid // 2, "keep width too small. less than in_wid/2"
+    idx = np.zeros(vec_size, dtype=np.int64)
+
+    def rev(pos):
+        r = np.zeros_like(pos)
+        for bit in range(logN - 1):
+            r |= ((pos >> bit) & 1) << (logN - 2 - bit)
+        return r
+    for rows, off in ((in_wid // 2, 0), (kp_wid - in_wid // 2, vec_size // sparsity)):
+        i, j, b = np.meshgrid(np.arange(rows), np.arange(kp_wid), np.arange(batch // sparsity), indexing="ij")
+        idx[rev((in_wid * batch * i + batch * j + b * sparsity).reshape(-1)) + off] = 1
+    post_slot = 2 * vec_size // sparsity
+    for j in range(1, sparsity // 2):
+        idx[post_slot * j: post_slot * (j + 1)] = idx[:post_slot]
+    return idx
+
+
 class Bootstrapper:
     """my restatement of the fork's BootstrappConv_CtoS / BootstrappConv_StoC for full slots (log_sparse = 0): same modulus
     chain and level assignment as parameter set [6]; DFT matrices from the encoder's own butterflies (no bit reversal, so
     slot p holds coefficient bitrev(p)); sine by Chebyshev interpolation of cos(2*pi*(K*u - 1/4)/2^r) and r double angles."""
 
-    def __init__(self, C, cts_groups=(4, 4, 4, 3), stc_groups=(5, 5, 5)):
-        self.C = C
-        logn = C.logN - 1
+    def __init__(self, C, cts_groups=(4, 4, 4, 3), stc_groups=(5, 5, 5), log_sparse=0):
+        """log_sparse = ls > 0: the message occupies only the coefficients that are multiples of D = 2^ls (sparse packing,
+        eval.go "Conv_sparse"): the bootstrapping runs in the subring X^D with n_s = n/D slots (main.go:60-83 btp2..btp5):
+        SubSum, the n_s-point DFTs, and BOTH coefficient halves in ONE ciphertext (first half of every 2 n_s slots = low
+        half, second = high half; rot_util.go:179-218 gen_keep_vec_sparse uses the same layout)."""
+        self.C, self.ls = C, log_sparse
+        D = 1 << log_sparse
+        self.ns = ns = C.n // D
+        logn = C.logN - 1 - log_sparse
         cts_groups, stc_groups = self._fit(cts_groups, logn), self._fit(stc_groups, logn)
-        # CoeffsToSlots: (1/n) * prod(stages), times 1/2 (real/imaginary extraction) and 1/K (Chebyshev argument in [-1,1])
-        self.cts = C.dft_groups(True, cts_groups, 1.0 / (2.0 * C.n * SIN_K))
-        self.stc = C.dft_groups(False, stc_groups, 1.0)
+        # CoeffsToSlots: (1/n_s) * prod(stages), times 1/2 (real/imaginary extraction), 1/K (Chebyshev argument in [-1,1])
+        # and 1/D (SubSum multiplies the surviving coefficients by D)
+        self.cts = C.dft_groups(True, cts_groups, 1.0 / (2.0 * ns * SIN_K * D), log_sparse)
+        self.stc = C.dft_groups(False, stc_groups, 1.0, log_sparse)
+        if log_sparse:
+            p = np.arange(C.n) % (2 * ns)
+            m1, m2 = (p < ns).astype(np.complex128), (p >= ns).astype(np.complex128)
+            self.cts[-1] = {k: v * m1 for k, v in self.cts[-1].items()}          # keep w on the first half of every 2 n_s slots
+            # packed a = (re | im)  ->  w = re + i im on BOTH halves:  w = (m1 + i m2) a + (i m1 + m2) rot_{n_s}(a)
+            W = {0: m1 + 1j * m2, ns: 1j * m1 + m2}
+            self.stc[0] = C.matmul_diag(self.stc[0], W, 2 * ns)
         f = lambda u: np.cos(2.0 * np.pi * (SIN_K * u - 0.25) / float(1 << SIN_DOUBLE))
         self.sine = cheby_coeffs(f, SIN_DEG)
 
@@ -626,11 +672,15 @@ class Bootstrapper:
         msg_scale = ct0.scale
         ct = C.mod_raise(ct0, LV_CTS_TOP)
         ct.scale = q0                                            # slot values are now t'/Q0 = I + msg/Q0, |.| <= K
+        for j in range(self.ls):                                 # SubSum: trace onto the subring X^D (rotations by n_s 2^j)
+            ct = C.add(ct, C.rotate(ct, self.ns << j))
         for G in self.cts:
             ct = C.rescale(C.linear_transform(ct, G, float(C.Q[ct.level])))
         assert ct.level == LV_SINE_TOP
         cc = C.conjugate(ct)
         parts = [C.add(ct, cc), C.mul_by_i(C.sub(cc, ct))]       # (w + conj w), -i (w - conj w); the 1/2 is in the matrices
+        if self.ls:                                              # both halves into one ciphertext: re | im per 2 n_s slots
+            parts = [C.add(parts[0], C.rotate(parts[1], self.ns))]
         # scale plan: after the double angles the value is sin(2 pi x) ~ 2 pi msg/Q0; relabelled by c_m it must sit at 2^30
         c_m = q0 / (2.0 * np.pi * msg_scale)
         s_out = 2.0 ** 30 * c_m
@@ -654,7 +704,11 @@ class Bootstrapper:
     def stoc(self, ct_re, ct_im):
         """slots (bit-reversed coefficient order) -> coefficients; input level >= LV_STC_TOP at scale ~2^60, output level 1"""
         C = self.C
-        ct = C.add(ct_re, C.mul_by_i(ct_im)) if ct_im is not None else ct_re
+        if self.ls:
+            assert ct_im is None
+            ct = ct_re                                             # the (re | im) -> re + i im combination is inside stc[0]
+        else:
+            ct = C.add(ct_re, C.mul_by_i(ct_im))
         ct = C.drop_to(ct, LV_STC_TOP)
         G = self.stc
         # level 3 carries all but the last matrix (their plaintext scales multiply to q3), level 2 the last at scale 2^30
@@ -683,6 +737,20 @@ def keep_ctxt(C, ct, idx):
     L = ct.level
     pt = C.encode_ntt(idx.astype(np.complex128), L, float(C.Q[L]))
     return C.rescale(C.mul_plain(ct, pt, float(C.Q[L])))
+
+
+def conv_relu_tail_sparse(C, btp, ct_conv, alpha, pow_, in_wid, kp_wid, stages=None):
+    """eval.go:437-565 for kind "Conv_sparse" (log_sparse = btp.ls >= 1, iter 2 but one packed ciphertext): ct_conv holds the
+    convolution of a sparsely packed input (coefficients at multiples of 2^ls); returns level 1, scale 2^30, same packing"""
+    ct = Ct(ct_conv.rows, ct_conv.scale * 2.0 ** pow_)
+    (boot,) = btp.ctos(ct)
+    if stages is not None:
+        stages["ctos"] = [boot.copy()]
+    r = C.mul_const_int(eval_relu(C, boot, alpha), 1 << int(pow_))
+    if stages is not None:
+        stages["relu"] = [r.copy()]
+    keep = keep_ctxt(C, r, gen_keep_vec_sparse(C.N // 2, in_wid, kp_wid, btp.ls))
+    return btp.stoc(keep, None)
 
 
 def conv_relu_tail(C, btp, ct_conv, alpha, pow_, in_wid, kp_wid, stages=None):
