@@ -331,6 +331,41 @@ def case_ckks_ops(make_ctx, logN=16, seed=3, levels=((23, 2.0 ** 55), (9, 2.0 **
     ctx.close()
 
 
+def case_conv_relu_tail_sparse(make_ctx, log_sparse, logN=16, seed=3, min_bits=8.0):
+    """the tail of evalConv_BNRelu_new for kind "Conv_sparse" (sparse-slot bootstrapping: SubSum, n_s-point DFTs, both halves
+    in one ciphertext) on the device ABI vs the oracle: every stage bit-identical, result close to max(x, 0) on the support"""
+    import oracle_ckks as ck
+    Co = ck.Ckks(logN=logN, seed=seed)
+    ctx = make_ctx(Co.Q, Co.P)
+    Cd = ck.Ckks(logN=logN, seed=seed, backend=CkksDeviceBackend(ctx), oracle=Co.O)
+    Cd.keys = Co.keys
+    N, n, D = Co.N, Co.n, 1 << log_sparse
+    B = 4 * D
+    W = int(round((N // B) ** 0.5))
+    kp = W - 1
+    m = np.zeros(N)
+    m[::D] = np.random.default_rng(seed).uniform(-12, 12, N // D)
+    ct0 = Co.encrypt_coeffs(m, 0, 2.0 ** 43, seed=21)
+    so, sd = {}, {}
+    out_d = ck.conv_relu_tail_sparse(Cd, ck.Bootstrapper(Cd, log_sparse=log_sparse), ct0, 0.0, 4, W, kp, stages=sd)
+    out_o = ck.conv_relu_tail_sparse(Co, ck.Bootstrapper(Co, log_sparse=log_sparse), ct0, 0.0, 4, W, kp, stages=so)
+    eq(sd["ctos"][0].rows, so["ctos"][0].rows, "sparse CtoS+sine")
+    eq(sd["relu"][0].rows, so["relu"][0].rows, "sparse ReLU")
+    eq(out_d.rows, out_o.rows, "sparse StoC output")
+    ns = n // D
+    br = ck.Encoder(logN - log_sparse).br
+    keep = ck.gen_keep_vec_sparse(n, W, kp, log_sparse)[: 2 * ns]
+    mask = np.concatenate([keep[:ns][br], keep[ns:][br]])
+    want = np.zeros(N)
+    want[::D] = np.maximum(m[::D], 0) * mask
+    err = np.abs(Co.decrypt_coeffs(out_d) - want)
+    bits = -np.log2(np.median(err[::D]))
+    assert bits >= min_bits, bits
+    assert np.max(err.reshape(-1, D)[:, 1:]) < 1e-3          # nothing leaks off the sparse support
+    ctx.close()
+    return bits
+
+
 def case_conv_relu_tail(make_ctx, logN=16, seed=3, min_bits=8.0):
     """the whole tail of evalConv_BNRelu_new (CtoS + sine, ReLU, mask, StoC) on the device ABI vs the oracle: every stage
     bit-identical, and the decrypted result close to max(x, 0) (reference binary: MED 11.5 bits on its data)"""

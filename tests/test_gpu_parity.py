@@ -238,3 +238,11 @@ def test_conv_relu_tail_on_gpu():
     from optimal_conv_amd import Context
     bits = pc.case_conv_relu_tail(lambda Q, P: Context(Q, P))
     print("median precision bits", bits)
+
+
+@pytest.mark.parametrize("log_sparse", [2])
+def test_conv_relu_tail_sparse_on_gpu(log_sparse):
+    """scope row 8f-3 groundwork: the "Conv_sparse" tail (sparse-slot bootstrapping of the ResNet layers, log_sparse 2 = block 1)
+    on the device ABI, every stage bit-identical to the oracle"""
+    from optimal_conv_amd import Context
+    print("median precision bits", pc.case_conv_relu_tail_sparse(lambda Q, P: Context(Q, P), log_sparse))

@@ -74,3 +74,29 @@ def test_conv_relu_tail_small_ring(C):
     err = np.abs(C.decrypt_coeffs(out) - np.maximum(m, 0) * mask)
     assert -np.log2(np.median(err)) >= 8.0       # reference binary on its data: MED 11.5, AVG 8.4 bits
     assert np.max(err[mask == 0]) < 1e-3         # masked-out (padding) positions come back as zeros
+
+
+@pytest.mark.parametrize("ls", [1, 2, 3])
+def test_conv_relu_tail_sparse_small_ring(C, ls):
+    """sparse-slot bootstrapping (kind "Conv_sparse", main.go:60-83 btp2..btp5): message on the multiples of 2^ls only"""
+    N, n, D = C.N, C.n, 1 << ls
+    W, kp = int(round((N // (4 * D)) ** 0.5)), int(round((N // (4 * D)) ** 0.5)) - 1
+    m = np.zeros(N)
+    m[::D] = np.random.default_rng(5).uniform(-12, 12, N // D)
+    btp = ck.Bootstrapper(C, log_sparse=ls)
+    st = {}
+    out = ck.conv_relu_tail_sparse(C, btp, C.encrypt_coeffs(m, 0, 2.0 ** 43, seed=22), 0.0, 4, W, kp, stages=st)
+    assert out.level == 1
+    ns = n // D
+    br = ck.Encoder(C.logN - ls).br
+    sub = m[::D]
+    packed = np.concatenate([sub[:ns][br], sub[ns:][br]]) / 16.0          # (low | high) halves, bit-reversed, per 2 n_s slots
+    got = C.decrypt_slots(st["ctos"][0]).real
+    for blk in range(max(D // 2, 1)):
+        assert np.max(np.abs(got[blk * 2 * ns: (blk + 1) * 2 * ns] - packed)) < 1e-3
+    keep = ck.gen_keep_vec_sparse(n, W, kp, ls)[: 2 * ns]
+    want = np.zeros(N)
+    want[::D] = np.maximum(sub, 0) * np.concatenate([keep[:ns][br], keep[ns:][br]])
+    err = np.abs(C.decrypt_coeffs(out) - want)
+    assert -np.log2(np.median(err[::D])) >= 8.0
+    assert np.max(err.reshape(-1, D)[:, 1:]) < 1e-3
