@@ -2,8 +2,8 @@
 //     conv <ker_wid 3|5|7> <i_batch 0..3> <num_tests <= 10>
 // prints the same line shapes as the reference's `conv` run (SURVEY.md 8(a)-S "CLI output contract").
 // It runs the slot-packed "Base Line" (hconv_bl.cpp, scope row 8f-2) and then "Ours" (hconv_host.cpp), as main.go:639-643 does.
-// `convReLU k i n` runs "Ours" with the bootstrapping chain (hconv_relu.cpp, scope row 8f-1); its baseline half and `resnet`
-//  are not built and say so.
+// `convReLU k i n` runs "Ours" with the bootstrapping chain (hconv_relu.cpp, scope row 8f-1; its baseline half is not built and
+// says so); `resnet ker depth 1 n false` runs the encrypted ResNet inference (hconv_resnet.cpp, scope row 8f-3).
 // HCONV_SKIP_BL=1 skips the baseline half (not a reference feature; for timing "Ours" alone).
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,8 +23,13 @@ int main(int argc, char **argv) {
     } else if (test_name == "convReLU") {
         boot = true;
         if (num_tests > 10 || i_batch > 3) hconv::panic("Too many tests (>10) or too many batch index (>3)");
-    } else if (test_name == "resnet") {
-        hconv::panic("resnet: not built in this engine (scope table next-row 8f-3)");
+    } else if (test_name == "resnet") {                                   // main.go:609-621: resnet ker depth wide_case test_num cf100
+        if (argc < 7) hconv::panic("runtime error: index out of range (usage: resnet <ker_wid> <depth> <wide_case> <test_num> <cf100>)");
+        const int depth = atoi(argv[3]), wide_case = atoi(argv[4]), test_num = atoi(argv[5]);
+        const bool cf100 = std::string(argv[6]) == "true" || std::string(argv[6]) == "1";
+        if (wide_case != 1) hconv::panic("resnet: the wide variants (wide_case 2, 3: testResNet_crop_sparse_wide) are not built in this engine");
+        hconv::testResNet_crop_sparse(0, test_num, ker_wid, depth, false, cf100);
+        return 0;
     } else hconv::panic("wrong test type");
     if (i_batch < 0) hconv::panic("runtime error: index out of range");
     if (boot) printf("Convolution followed by ReLU (& Bootstrapping) test start!\n");

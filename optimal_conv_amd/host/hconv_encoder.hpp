@@ -14,14 +14,17 @@ typedef std::complex<double> cplx;
 
 struct Encoder {
     std::vector<int> rotGroup; std::vector<cplx> roots; std::vector<int> brev;
-    Encoder() {
+    int Nn, logn;                       // ring degree of this encoder (N, or N / 2^ls for the subring X^(2^ls) of sparse packing)
+    explicit Encoder(int logn_ = LOGN) : Nn(1 << logn_), logn(logn_) {
+        const int N = Nn;
         const int slots = N / 2, m = 2 * N;
         rotGroup.resize((size_t)slots); int g = 1; for (int i = 0; i < slots; i++) { rotGroup[(size_t)i] = g; g = (int)(((long)g * 5) % m); }
         roots.resize((size_t)m + 1);
         for (int i = 0; i <= m; i++) { double angle = 2 * 3.141592653589793 * (double)i / (double)m; roots[(size_t)i] = cplx(cos(angle), sin(angle)); }
-        brev.resize((size_t)slots); for (int i = 0; i < slots; i++) { int r = 0; for (int b = 0; b < 15; b++) r |= ((i >> b) & 1) << (14 - b); brev[(size_t)i] = r; }
+        brev.resize((size_t)slots); for (int i = 0; i < slots; i++) { int r = 0; for (int b = 0; b < logn - 1; b++) r |= ((i >> b) & 1) << (logn - 2 - b); brev[(size_t)i] = r; }
     }
     void invfft(std::vector<cplx> &v) const {
+        const int N = Nn;
         const int n = N / 2, m = 2 * N;
         for (int len = n; len >= 1; len >>= 1) {
             const int lenh = len >> 1, lenq = len << 2, gap = m / lenq;
@@ -35,6 +38,7 @@ struct Encoder {
         for (int i = 0; i < n; i++) if (i < brev[(size_t)i]) std::swap(v[(size_t)i], v[(size_t)brev[(size_t)i]]);
     }
     void fft(std::vector<cplx> &v) const {
+        const int N = Nn;
         const int n = N / 2, m = 2 * N;
         for (int i = 0; i < n; i++) if (i < brev[(size_t)i]) std::swap(v[(size_t)i], v[(size_t)brev[(size_t)i]]);
         for (int len = 2; len <= n; len <<= 1) {
@@ -48,6 +52,7 @@ struct Encoder {
     }
     // encoder.Encode for moduli q[0..nq): coefficient-domain rows [nq][N] (scaleUpVecExact rounding, as EncodeCoeffs)
     std::vector<uint64_t> Encode(std::vector<cplx> values, double scale, const uint64_t *BLQ, int nq) const {
+        const int N = Nn;
         invfft(values);
         std::vector<uint64_t> out((size_t)nq * N);
         for (int i = 0; i < N; i++) {

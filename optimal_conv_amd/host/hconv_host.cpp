@@ -110,12 +110,16 @@ static void gen_and_load_galois_key(Context *c, uint64_t galEl) {
         rows[2 * w] = bb; rows[2 * w + 1] = a;
     }
     HC(c->hc, hc_evk_load(c->hc, galEl, rows[0].data(), rows[1].data(), rows[2].data(), rows[3].data()));
+    if (galEl - 1 < 512) {      // 2^j+1 with j < 9 does not permute inside 256-coefficient rows: RotateGal takes the general key switch
+        std::vector<uint64_t> g; for (int r : {0, 2, 1, 3}) g.insert(g.end(), rows[r].begin(), rows[r].end());     // [digit 0][b | a][Q0, P][N]
+        HC(c->hc, hc_swk_load(c->hc, galEl, 0, g.data()));
+    }
 }
 
 // ---------------------------------------------------------------- newContext (main.go:44-462, kind "Conv")
 Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, const std::vector<int> &kp_wids, bool boot, const std::string &kind) {
     (void)ker_wid; (void)in_wids; (void)kp_wids;
-    if (kind != "Conv") panic("Wrong kinds!");                                     // main.go:404 (only the conv kind is built here)
+    if (kind != "Conv" && kind != "Resnet_crop_sparse") panic("Wrong kinds!");       // main.go:404 (the kinds the built command lines use)
     Context *c = new Context();
     double logqp = 0; for (uint64_t q : PARAMS6_Q) logqp += log2((double)q); for (uint64_t p : PARAMS6_P) logqp += log2((double)p);
     printf("CKKS parameters: logN = %d, logSlots = %d, h = %d, logQP = %d, levels = %d, scale= 2^%f, sigma = %f \n",
@@ -137,7 +141,9 @@ Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, cons
     if (boot) {                                                                                        // main.go:464-507
         printf("Generating bootstrapping keys...\n");
         auto start = now();
-        c->btp = newBoot(c->sk, c->seed, dev);       // DFT matrices now; rlk / rotation keys are generated at first use (same secret key)
+        // DFT matrices and every switching key, same secret key. "Conv": one full-slot bootstrapper; the resnet kind: the
+        // four sparse ones its layers use (btp2..btp5 of main.go:480-500; log_sparse 1..4)
+        c->btp = kind == "Conv" ? newBoot(c->sk, c->seed, dev, {0}) : newBoot(c->sk, c->seed, dev, {2, 1, 3, 4});
         printf("Done in %s \n", dur(start).c_str());
     }
     return c;
@@ -307,7 +313,14 @@ void GpuEvaluator::AddPlain(const Ciphertext &a, const Plaintext &b, Ciphertext 
 void GpuEvaluator::RotateGal(const Ciphertext &ct, uint64_t galEl, Ciphertext &out) {
     if (ct.level != 0) panic("RotateGal: level 0 expected on the pack path");
     if (!out.d) out = alloc(0, ct.Scale);
-    HC(cont->hc, hc_rotate_gal_l0(cont->hc, galEl, ct.d, ct.d + N, out.d, out.d + N));
+    if (galEl - 1 < 512) {      // the resnet's 8x8 layers (max_cnum 1024): evaluator.permuteNTT from the general primitives
+        uint64_t *d = dev_rows(cont, 2);
+        HC(cont->hc, hc_keyswitch(cont->hc, galEl, 0, ct.d + N, d, d + N));
+        HC(cont->hc, hc_add(cont->hc, 0, d, ct.d, d, 1));
+        HC(cont->hc, hc_permute(cont->hc, galEl, d, out.d, 1));
+        HC(cont->hc, hc_permute(cont->hc, galEl, d + N, out.d + N, 1));
+        HC(cont->hc, hc_free(cont->hc, d));
+    } else HC(cont->hc, hc_rotate_gal_l0(cont->hc, galEl, ct.d, ct.d + N, out.d, out.d + N));
     out.Scale = ct.Scale; out.level = 0;
 }
 
@@ -370,7 +383,9 @@ static Ciphertext conv_then_pack_opwise(Context *c, const Ciphertext &ctxt_in, c
 
 Ciphertext conv_then_pack(Context *c, const Ciphertext &ctxt_in, const KerPlain &pl_ker, int max_ob, int norm, int ECD_LV, double out_scale, const Plaintext *pl_bn_b) {
     (void)ECD_LV;
-    if (getenv("HCONV_OPWISE")) return conv_then_pack_opwise(c, ctxt_in, pl_ker, max_ob, norm, out_scale);
+    // the fused pack kernels permute inside 256-coefficient rows (Galois elements 2^j+1, j >= 9: max_ob <= 256, every `conv`
+    // configuration); the resnet's 8x8 layers (max_ob 1024) run the same algorithm op by op on the L0 ABI
+    if (getenv("HCONV_OPWISE") || max_ob > 256) return conv_then_pack_opwise(c, ctxt_in, pl_ker, max_ob, norm, out_scale);
     auto start = now();
     Ciphertext r; r.d = dev_rows(c, 2); r.level = 0;
     // The reference prints "mult time" and "Pack time" separately (conv.go:533,535); run the two phases through
@@ -445,7 +460,7 @@ void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool
             const double pow_ = 4.0, alpha = 0.0;                                                      // test.go:22
             const double out_scale = exp2(round(log2((double)MODQ[0]) - (pow_ + 8)));                  // eval.go:433
             Ciphertext ct_conv = evalConv_BN(cont, ctxt_input, ker_in, bn_a, bn_b, in_wid, ker_wid, raw_in_batch, raw_out_batch, norm, out_scale, trans);
-            BootCiphertext ct_res = evalConv_BNRelu_tail(cont->btp, ct_conv.d, ct_conv.Scale, alpha, pow_, in_wid, kp_wid);
+            BootCiphertext ct_res = evalConv_BNRelu_tail(cont->btp, "Conv", 0, ct_conv.d, ct_conv.Scale, alpha, pow_, in_wid, kp_wid);
             start = now();
             std::vector<double> cfs = bootDecryptDecodeCoeffs(cont->btp, ct_res);
             printf("Decryption Done in %s \n", dur(start).c_str());

@@ -96,13 +96,19 @@ Ciphertext evalConv_BN(Context *cont, const Ciphertext &ct_input, const std::vec
                        const std::vector<double> &bn_b, int in_wid, int ker_wid, int real_ib, int real_ob, int norm, double out_scale, bool trans);
 void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool boot);
 // ---- convReLU chain (hconv_relu.cpp; eval.go:272-607 for kind "Conv") ----
-Boot *newBoot(const std::vector<int64_t> &sk, uint64_t seed, int device);
+Boot *newBoot(const std::vector<int64_t> &sk, uint64_t seed, int device, const std::vector<int> &log_sparse_sets);   // one "bootstrapper" per log_sparse
 void freeBoot(Boot *);
 // everything after evalConv_BN: Scale *= 2^pow, BootstrappConv_CtoS, evalReLU + MulByPow2, keep_ctxt, BootstrappConv_StoC
-BootCiphertext evalConv_BNRelu_tail(Boot *B, const uint64_t *ct_conv_dev, double ct_scale, double alpha, double pow, int in_wid, int kp_wid);
+BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sparse, const uint64_t *ct_conv_dev, double ct_scale, double alpha, double pow, int in_wid, int kp_wid);
 std::vector<double> bootDecryptDecodeCoeffs(Boot *B, const BootCiphertext &ct);
 void freeBootCt(Boot *B, BootCiphertext &ct);
 void bootStats(Boot *B, long *keys, long *keyswitches);
+// eval.go:272-607 for kinds "Conv", "Conv_sparse", "StrConv_sparse" (hconv_resnet.cpp); returns a level-1, scale-2^30 ciphertext
+Ciphertext evalConv_BNRelu_new(Context *cont, const Ciphertext &ct_input, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
+                               const std::vector<double> &bn_b, double alpha, double pow, int in_wid, int kp_wid, int ker_wid, int real_ib, int real_ob,
+                               int norm, int log_sparse, const std::string &kind);
+// test.go:76-370 — `resnet ker depth 1 n cf100`
+void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug, bool cf100);
 // test_BL.go:16 — the slot-packed baseline the reference runs first (hconv_bl.cpp); boot = true is not built
 void testConv_BL_in(int real_batch, int in_wid, int ker_wid, int total_test_num, bool boot);
 

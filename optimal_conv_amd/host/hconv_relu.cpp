@@ -27,6 +27,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <numeric>
 #include <set>
 
 #include "hconv_encoder.hpp"
@@ -69,7 +70,8 @@ struct Boot {
     Encoder enc;
     std::shared_ptr<uint64_t> mono_i;                        // NTT(X^(N/2)) for every limb
     struct LT { int n1 = 1; std::map<int, std::map<int, DPt>> giant; double pt_scale = 0; int level = 0; };
-    std::vector<LT> cts, stc;
+    struct Set { int ls = 0, ns = 0; std::vector<LT> cts, stc; };      // one bootstrapper of the reference (btp, btp2..btp5: main.go:480-500)
+    std::map<int, Set> sets;                                           // by log_sparse
     std::vector<double> sine;
     long n_keyswitch = 0, n_keys = 0;
 
@@ -248,39 +250,48 @@ struct Boot {
     }
 
     // ---------------- DFT matrices in diagonal form (the encoder's own butterflies, no bit reversal)
-    DiagMat dft_stage(int ln, bool inverse) const {
-        const int lenh = ln >> 1, lenq = ln << 2, gap = 2 * N / lenq;
+    // `E`: encoder of the ring the DFT belongs to (the full ring, or the subring X^(2^ls) of sparse packing: same butterflies
+    // with that ring's roots, tiled over the n full slots); rotation indices modulo `period` (the slot vector's period)
+    DiagMat dft_stage(int ln, bool inverse, const Encoder &E, int period) const {
+        const int lenh = ln >> 1, lenq = ln << 2, gap = 2 * E.Nn / lenq;
         std::vector<cplx> d0((size_t)n), dp((size_t)n, cplx(0, 0)), dm((size_t)n, cplx(0, 0));
         for (int p = 0; p < n; p++) {
             const int j = p % ln; const bool first = j < lenh; const int jj = first ? j : j - lenh;
-            const int idx = inverse ? (lenq - (enc.rotGroup[(size_t)jj] % lenq)) * gap : (enc.rotGroup[(size_t)jj] % lenq) * gap;
-            const cplx w = enc.roots[(size_t)idx];
+            const int idx = inverse ? (lenq - (E.rotGroup[(size_t)jj] % lenq)) * gap : (E.rotGroup[(size_t)jj] % lenq) * gap;
+            const cplx w = E.roots[(size_t)idx];
             if (inverse) { d0[(size_t)p] = first ? cplx(1, 0) : -w; if (first) dp[(size_t)p] = cplx(1, 0); else dm[(size_t)p] = w; }
             else { d0[(size_t)p] = first ? cplx(1, 0) : -w; if (first) dp[(size_t)p] = w; else dm[(size_t)p] = cplx(1, 0); }
         }
         DiagMat M; M[0] = d0;
-        const int kp = lenh % n, km = ((-lenh) % n + n) % n;
+        const int kp = lenh % period, km = ((-lenh) % period + period) % period;
         auto acc = [&](int k, const std::vector<cplx> &d) { auto it = M.find(k); if (it == M.end()) M[k] = d; else for (int p = 0; p < n; p++) it->second[(size_t)p] += d[(size_t)p]; };
         acc(kp, dp); acc(km, dm);
         return M;
     }
-    DiagMat matmul_diag(const DiagMat &M2, const DiagMat &M1) const {        // M2 . M1 (M1 applied first)
+    DiagMat matmul_diag(const DiagMat &M2, const DiagMat &M1, int period) const {        // M2 . M1 (M1 applied first)
         DiagMat out;
         for (auto &e2 : M2) for (auto &e1 : M1) {
-            const int k2 = e2.first, k = (e1.first + k2) % n;
+            const int k2 = e2.first, k = (e1.first + k2) % period;
             auto it = out.find(k); if (it == out.end()) it = out.emplace(k, std::vector<cplx>((size_t)n, cplx(0, 0))).first;
             for (int p = 0; p < n; p++) it->second[(size_t)p] += e2.second[(size_t)p] * e1.second[(size_t)((p + k2) % n)];
         }
         for (auto it = out.begin(); it != out.end();) { bool nz = false; for (auto &v : it->second) if (v != cplx(0, 0)) { nz = true; break; } if (nz) ++it; else it = out.erase(it); }
         return out;
     }
-    std::vector<DiagMat> dft_groups(bool inverse, const std::vector<int> &sizes, double constant) const {
-        std::vector<int> lens; for (int s = 0; s < LOGN - 1; s++) lens.push_back(inverse ? n >> s : 2 << s);
+    static std::vector<int> fit(std::vector<int> g, int logn) {
+        while (std::accumulate(g.begin(), g.end(), 0) > logn) (*std::max_element(g.begin(), g.end()))--;
+        return g;
+    }
+    std::vector<DiagMat> dft_groups(bool inverse, std::vector<int> sizes, double constant, int ls) const {
+        const int logn = LOGN - 1 - ls, ns = n >> ls;
+        sizes = fit(sizes, logn);
+        Encoder sub(LOGN - ls); const Encoder &E = ls ? sub : enc;
+        std::vector<int> lens; for (int s = 0; s < logn; s++) lens.push_back(inverse ? ns >> s : 2 << s);
         const double c = pow(constant, 1.0 / (double)sizes.size());
         std::vector<DiagMat> groups; size_t pos = 0;
         for (int gs : sizes) {
             DiagMat M; bool have = false;
-            for (int i = 0; i < gs; i++, pos++) { DiagMat S = dft_stage(lens[pos], inverse); M = have ? matmul_diag(S, M) : S; have = true; }
+            for (int i = 0; i < gs; i++, pos++) { DiagMat S = dft_stage(lens[pos], inverse, E, ns); M = have ? matmul_diag(S, M, ns) : S; have = true; }
             for (auto &e : M) for (auto &v : e.second) v *= c;
             groups.push_back(std::move(M));
         }
@@ -404,14 +415,6 @@ struct Boot {
         }
         mono_i = block();
         { std::vector<uint64_t> m((size_t)NQ * N, 0); for (int l = 0; l < NQ; l++) m[(size_t)l * N + N / 2] = 1; HCR(hc_upload(hc, mono_i.get(), m.data(), m.size() * 8)); HCR(hc_lv_ntt(hc, NQ - 1, mono_i.get(), mono_i.get())); }
-        // CoeffsToSlots: (1/n) prod(stages), times 1/2 (real/imaginary extraction) and 1/K (Chebyshev argument in [-1,1])
-        std::vector<DiagMat> G = dft_groups(true, {4, 4, 4, 3}, 1.0 / (2.0 * (double)n * SIN_K));
-        for (size_t i = 0; i < G.size(); i++) { const int lv = LV_CTS_TOP - (int)i; cts.push_back(plan(G[i], lv, (double)Q[(size_t)lv])); }
-        // SlotsToCoeffs: level 3 carries all but the last matrix (plaintext scales multiply to q3), level 2 the last at 2^30
-        G = dft_groups(false, {5, 5, 5}, 1.0);
-        const double sc3 = pow((double)Q[LV_STC_TOP], 1.0 / (double)(G.size() - 1));
-        for (size_t i = 0; i + 1 < G.size(); i++) stc.push_back(plan(G[i], LV_STC_TOP, sc3));
-        stc.push_back(plan(G.back(), LV_STC_TOP - 1, 1073741824.0));
         // Chebyshev interpolant of cos(2 pi (K u - 1/4) / 2^r) on [-1,1]
         const int m = SIN_DEG + 1; sine.assign((size_t)m, 0.0);
         for (int j = 0; j < m; j++) {
@@ -420,41 +423,73 @@ struct Boot {
             sine[(size_t)j] = 2.0 / m * s;
         }
         sine[0] /= 2;
-        // kgen.GenRelinearizationKey + GenRotationKeysForRotations(btpParams.RotationsForBootstrapping) (main.go:411,466-474):
-        // everything the chain switches with, so that no key generation falls inside the timed stages
-        for (auto *grp : {&cts, &stc}) for (auto &lt : *grp) for (auto &g : lt.giant) {
+        key(2ull * N - 1, LV_SINE_TOP);                                      // conjugation
+        for (int l = LV_SINE_TOP; l >= LV_RELU_TOP - 10; l--) key(0, l);     // kgen.GenRelinearizationKey (main.go:411)
+    }
+    // One bootstrapper (main.go:480-507: btp for log_sparse 0, btp2..btp5 for 1..4): its DFT matrices, encoded, and every rotation
+    // key it switches with (GenRotationKeysForRotations(btpParams.RotationsForBootstrapping(LogSlots)), main.go:466-474).
+    // log_sparse = ls > 0 (sparse packing, coefficients on the multiples of D = 2^ls): the subring X^D with n_s = n/D slots; BOTH
+    // coefficient halves travel in ONE ciphertext (first half of every 2 n_s slots = low half, second = high half).
+    Set &set(int ls) {
+        auto it = sets.find(ls); if (it != sets.end()) return it->second;
+        Set S; S.ls = ls; S.ns = n >> ls;
+        const int D = 1 << ls, ns = S.ns;
+        // CoeffsToSlots: (1/n_s) prod(stages), times 1/2 (real/imaginary extraction), 1/K (Chebyshev argument in [-1,1]), 1/D (SubSum)
+        std::vector<DiagMat> G = dft_groups(true, {4, 4, 4, 3}, 1.0 / (2.0 * (double)ns * SIN_K * D), ls);
+        if (ls) for (auto &e : G.back()) for (int p = 0; p < n; p++) if (p % (2 * ns) >= ns) e.second[(size_t)p] = cplx(0, 0);   // keep w on the first half of every 2 n_s slots
+        for (size_t i = 0; i < G.size(); i++) { const int lv = LV_CTS_TOP - (int)i; S.cts.push_back(plan(G[i], lv, (double)Q[(size_t)lv])); }
+        // SlotsToCoeffs: level 3 carries all but the last matrix (plaintext scales multiply to q3), level 2 the last at 2^30
+        G = dft_groups(false, {5, 5, 5}, 1.0, ls);
+        if (ls) {       // packed a = (re | im)  ->  w = re + i im on both halves:  w = (m1 + i m2) a + (i m1 + m2) rot_{n_s}(a)
+            DiagMat W; W[0].resize((size_t)n); W[ns].resize((size_t)n);
+            for (int p = 0; p < n; p++) { const bool first = p % (2 * ns) < ns; W[0][(size_t)p] = first ? cplx(1, 0) : cplx(0, 1); W[ns][(size_t)p] = first ? cplx(0, 1) : cplx(1, 0); }
+            G[0] = matmul_diag(G[0], W, 2 * ns);
+        }
+        const double sc3 = pow((double)Q[LV_STC_TOP], 1.0 / (double)(G.size() - 1));
+        for (size_t i = 0; i + 1 < G.size(); i++) S.stc.push_back(plan(G[i], LV_STC_TOP, sc3));
+        S.stc.push_back(plan(G.back(), LV_STC_TOP - 1, 1073741824.0));
+        for (auto *grp : {&S.cts, &S.stc}) for (auto &lt : *grp) for (auto &g : lt.giant) {
             if (g.first) key(gal_rot(g.first), lt.level);
             for (auto &b : g.second) if (b.first) key(gal_rot(b.first), lt.level);
         }
-        key(2ull * N - 1, LV_SINE_TOP);
-        for (int l = LV_SINE_TOP; l >= LV_RELU_TOP - 10; l--) key(0, l);
+        for (int j = 0; j < ls; j++) key(gal_rot(ns << j), LV_CTS_TOP);       // SubSum
+        if (ls) key(gal_rot(ns), LV_SINE_TOP);                                 // packing the imaginary half next to the real one
+        return sets.emplace(ls, std::move(S)).first->second;
     }
-    void ctos(const DCt &ct0, DCt out[2]) {
+    // level-0 coefficient-encoded ciphertext -> slot-encoded at level 15, scale 2^30: two ciphertexts (low / high coefficient
+    // half, bit-reversed order) for ls = 0, one packed ciphertext for ls > 0
+    int ctos(const DCt &ct0, int ls, DCt out[2]) {
+        Set &S = set(ls);
         const double q0 = (double)Q[0], msg_scale = ct0.scale;
         DCt ct = mod_raise(ct0, LV_CTS_TOP); ct.scale = q0;             // slot values are now t'/Q0 = I + msg/Q0, |.| <= K
-        for (auto &lt : cts) ct = rescale(linear_transform(ct, lt));
+        for (int j = 0; j < ls; j++) ct = add(ct, rotate(ct, S.ns << j));                                  // SubSum: trace onto X^D
+        for (auto &lt : S.cts) ct = rescale(linear_transform(ct, lt));
         if (ct.level != LV_SINE_TOP) panic("CoeffsToSlots ended at the wrong level");
         DCt cc = conjugate(ct);
         DCt parts[2] = {add(ct, cc), mul_by_i(sub(cc, ct))};           // (w + conj w), -i (w - conj w); the 1/2 is in the matrices
+        int np = 2;
+        if (ls) { parts[0] = add(parts[0], rotate(parts[1], S.ns)); np = 1; }
         const double c_m = q0 / (2.0 * M_PI * msg_scale);
         double s = 1073741824.0 * c_m;
         for (int r = 0; r < SIN_DOUBLE; r++) s = sqrt(s * (double)Q[(size_t)(LV_RELU_TOP + 1 + r)]);
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < np; h++) {
             DCt c = eval_poly(parts[h], sine, s, true);
             for (int r = 0; r < SIN_DOUBLE; r++) { c = mul_relin(c, c); c = add(c, c); c = rescale(add_const(c, -1.0)); }
             if (c.level != LV_RELU_TOP) panic("sine evaluation ended at the wrong level");
             c.scale = c.scale / c_m;                                     // value *= c_m: now msg / msg_scale
             out[h] = c;
         }
+        return np;
     }
-    DCt stoc(const DCt &re, const DCt &im) {
-        DCt ct = drop_to(add(re, mul_by_i(im)), LV_STC_TOP);
-        for (size_t i = 0; i + 1 < stc.size(); i++) ct = linear_transform(ct, stc[i]);
+    DCt stoc(const DCt &re, const DCt *im, int ls) {
+        Set &S = set(ls);
+        if (ls && im) panic("sparse SlotsToCoeffs takes one packed ciphertext");
+        DCt ct = drop_to(ls ? re : add(re, mul_by_i(*im)), LV_STC_TOP);
+        for (size_t i = 0; i + 1 < S.stc.size(); i++) ct = linear_transform(ct, S.stc[i]);
         ct = rescale(ct);
-        return rescale(linear_transform(ct, stc.back()));
+        return rescale(linear_transform(ct, S.stc.back()));
     }
 };
-
 // rot_util.go:141-174
 static std::vector<int> gen_keep_vec(int vec_size, int in_wid, int kp_wid, int ul) {
     int logN = 0; for (; (1 << logN) < 2 * vec_size; logN++) {}
@@ -467,6 +502,55 @@ static std::vector<int> gen_keep_vec(int vec_size, int in_wid, int kp_wid, int u
         idx[r] = 1;
     }
     return idx;
+}
+// rot_util.go:179-218: one mask for the packed (low | high) ciphertext of sparse bootstrapping, period 2 n_s
+static std::vector<int> gen_keep_vec_sparse(int vec_size, int in_wid, int kp_wid, int log_sparse) {
+    int logN = 0; for (; (1 << logN) < 2 * vec_size; logN++) {}
+    std::vector<int> idx((size_t)vec_size, 0); const int batch = 2 * vec_size / (in_wid * in_wid), sparsity = 1 << log_sparse;
+    if (sparsity == 1) panic("We do not support full packing in gen_keep_vec_sparse");
+    if (kp_wid < in_wid / 2) panic("keep width too small. less than in_wid/2");
+    auto rev = [&](int x) { uint32_t v = (uint32_t)x, r = 0; for (int k = 0; k < logN - 1; k++) r |= ((v >> k) & 1u) << (logN - 2 - k); return (int)r; };
+    for (int i = 0; i < in_wid / 2; i++) for (int j = 0; j < kp_wid; j++) for (int b = 0; b < batch / sparsity; b++) idx[(size_t)rev(in_wid * batch * i + batch * j + b * sparsity)] = 1;
+    for (int i = 0; i < kp_wid - in_wid / 2; i++) for (int j = 0; j < kp_wid; j++) for (int b = 0; b < batch / sparsity; b++) idx[(size_t)(rev(in_wid * batch * i + batch * j + b * sparsity) + vec_size / sparsity)] = 1;
+    const int post_slot = 2 * vec_size / sparsity;
+    for (int i = 0; i < post_slot; i++) for (int j = 1; j < sparsity / 2; j++) idx[(size_t)(i + post_slot * j)] = idx[(size_t)i];
+    return idx;
+}
+// rot_util.go:557-612 (the log_sparse != 0 branch, the only one `resnet k d ...` reaches): masks and rotations of the two stages
+// of ext_double_ctxt that keep the stride-2 positions and re-pack them for the next (half-width) block
+typedef std::map<int, std::vector<int>> IdxMap;
+static void gen_comprs_sparse(int vec_size, int in_wid, int kp_wid, int log_sparse, IdxMap &m_idx, IdxMap &r_idx) {
+    if (log_sparse == 0) panic("gen_comprs_sparse: full packing (log_sparse 0) is not used by the resnet driver and is not built");
+    if (in_wid % 2) panic("input wid not divisible by 2");
+    const int batch = 2 * vec_size / (in_wid * in_wid * (1 << log_sparse)), min_wid = in_wid / 2, rep = 1 << (log_sparse - 1);
+    int log_in_wid = 0; for (; (1 << log_in_wid) < in_wid; log_in_wid++) {}
+    auto rev = [](int x, int bits) { int r = 0; for (int k = 0; k < bits; k++) r |= ((x >> k) & 1) << (bits - 1 - k); return r; };
+    auto tile = [&](std::vector<int> &t) { const int seg = vec_size / rep; for (int i = 0; i < seg; i++) for (int k = 1; k < rep; k++) t[(size_t)(i + k * seg)] = t[(size_t)i]; };
+    for (int j = 0; j < min_wid; j++) {
+        std::vector<int> tmp((size_t)vec_size, 0);
+        for (int b = 0; b < batch; b++) for (int i = 0; i < min_wid / 2; i++) for (int k = 0; k < 2; k++)
+            if (rev(j, log_in_wid - 1) < kp_wid && rev(i, log_in_wid - 2) + k * min_wid / 2 < kp_wid) tmp[(size_t)(k * in_wid * min_wid * batch + in_wid * in_wid * b / 2 + in_wid * j / 2 + i)] = 1;
+        tile(tmp); m_idx[j * min_wid / 2] = tmp;
+    }
+    for (int b = 0; b < batch; b++) {
+        std::vector<int> tmp((size_t)vec_size, 0);
+        for (int j = 0; j < min_wid; j++) for (int i = 0; i < min_wid / 2; i++) for (int k = 0; k < 2; k++) tmp[(size_t)(k * in_wid * min_wid * batch + b * in_wid * in_wid / 2 + j * min_wid / 2 + i)] = 1;
+        tile(tmp); r_idx[3 * b * min_wid * min_wid / 2] = tmp;
+    }
+}
+// conv.go:374-414: sum over (rot, mask) of Rotate(ct * mask, rot), twice (masks at scale sqrt(q_level)), one rescale
+static DCt ext_double_ctxt(Boot *B, const DCt &ct, const IdxMap &m_idx, const IdxMap &r_idx) {
+    const double sq = sqrt((double)B->Q[(size_t)ct.level]);
+    auto stage = [&](const DCt &in, const IdxMap &idx) {
+        DCt acc; bool have = false;
+        for (auto &e : idx) {
+            std::vector<cplx> tmp((size_t)N / 2); for (size_t i = 0; i < e.second.size(); i++) tmp[i] = cplx((double)e.second[i], 0);
+            DCt t = B->rotate(B->mul_plain(in, B->encode(tmp, in.level, sq)), e.first);
+            acc = have ? B->add(acc, t) : t; have = true;
+        }
+        return acc;
+    };
+    return B->rescale(stage(stage(ct, m_idx), r_idx));
 }
 // conv.go:435-480
 static DCt evalReLU(Boot *B, const DCt &ct_in, double alpha) {
@@ -490,34 +574,46 @@ static DCt keep_ctxt(Boot *B, const DCt &ct, const std::vector<int> &idx) {
 }
 
 // ---------------------------------------------------------------- public surface (hconv_host.hpp)
-Boot *newBoot(const std::vector<int64_t> &sk, uint64_t seed, int device) { Boot *b = new Boot(); b->build(sk, seed, device); return b; }
+Boot *newBoot(const std::vector<int64_t> &sk, uint64_t seed, int device, const std::vector<int> &log_sparse_sets) {
+    Boot *b = new Boot(); b->build(sk, seed, device);
+    for (int ls : log_sparse_sets) b->set(ls);
+    return b;
+}
 void freeBoot(Boot *b) {
     if (!b) return;
-    b->cts.clear(); b->stc.clear(); b->mono_i.reset();
+    b->sets.clear(); b->mono_i.reset();
     hc_ctx_destroy(b->hc); delete b;      // device blocks die with the context
 }
 
-// eval.go:272-607 for kind "Conv": ct_conv is evalConv_BN's level-0 result at out_scale 2^(round(log2 Q0) - (pow+8))
-BootCiphertext evalConv_BNRelu_tail(Boot *B, const uint64_t *ct_conv_dev, double ct_scale, double alpha, double pow_, int in_wid, int kp_wid) {
+// eval.go:437-565: everything after the convolution(s). ct_conv = the level-0 convolution result at out_scale
+// 2^(round(log2 Q0) - (pow+8)). kind "Conv" (log_sparse 0, two ciphertexts through sine/ReLU, keep_ctxt masks of gen_keep_vec),
+// "Conv_sparse" (one packed ciphertext, gen_keep_vec_sparse), "StrConv_sparse" (one packed ciphertext, ext_double_ctxt with
+// gen_comprs_sparse: kp_wid is then the NEXT block's raw width).
+BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sparse, const uint64_t *ct_conv_dev, double ct_scale, double alpha, double pow_, int in_wid, int kp_wid) {
     hc_ctx *hc = B->hc;
+    const bool sparse = kind == "Conv_sparse" || kind == "StrConv_sparse", stride = kind == "StrConv_sparse";
+    if (!sparse && kind != "Conv") panic("No kind!");
+    if (sparse == (log_sparse == 0)) panic("No cases for log_sparse");
     DCt ct = B->new_ct(0, 1, ct_scale * pow(2.0, pow_));                                            // eval.go:437
     for (int d = 0; d < 2; d++) HCR(hc_copy(hc, ct.p[d].get(), ct_conv_dev + (size_t)d * N, (size_t)N * 8));
     printf("Bootstrapping... Ours (until CtoS):\n");
     auto start = now();
-    DCt boots[2]; B->ctos(ct, boots);                                                                 // eval.go:450
+    DCt boots[2]; const int iter = B->ctos(ct, log_sparse, boots);                                     // eval.go:450-461
     HCR(hc_sync(hc));
     printf("Done in %s \n", dur(start).c_str());
     start = now();
-    DCt keep[2];
-    for (int ul = 0; ul < 2; ul++) {
+    for (int ul = 0; ul < iter; ul++) {
         DCt r = evalReLU(B, boots[ul], alpha);                                                        // eval.go:473
         boots[ul] = B->mul_const_int(r, pow(2.0, pow_));                                              // MulByPow2 (eval.go:474)
     }
     HCR(hc_sync(hc));
     printf("ReLU Done in %s \n", dur(start).c_str());
     start = now();
-    for (int ul = 0; ul < 2; ul++) keep[ul] = keep_ctxt(B, boots[ul], gen_keep_vec(N / 2, in_wid, kp_wid, ul));   // eval.go:534
-    DCt res = B->stoc(keep[0], keep[1]);                                                              // eval.go:550 ; Rescale (564) is a no-op here
+    DCt keep[2];
+    if (stride) { IdxMap m_idx, r_idx; gen_comprs_sparse(N / 2, in_wid, kp_wid, log_sparse, m_idx, r_idx); keep[0] = ext_double_ctxt(B, boots[0], m_idx, r_idx); }   // eval.go:500-506
+    else if (sparse) keep[0] = keep_ctxt(B, boots[0], gen_keep_vec_sparse(N / 2, in_wid, kp_wid, log_sparse));                                                       // eval.go:534
+    else for (int ul = 0; ul < 2; ul++) keep[ul] = keep_ctxt(B, boots[ul], gen_keep_vec(N / 2, in_wid, kp_wid, ul));
+    DCt res = B->stoc(keep[0], sparse ? nullptr : &keep[1], log_sparse);                              // eval.go:550-561 ; Rescale (564) is a no-op here
     HCR(hc_sync(hc));
     printf("Boot (StoC) Done in %s \n", dur(start).c_str());
     BootCiphertext out; out.level = res.level; out.Scale = res.scale;
