@@ -118,7 +118,7 @@ static void gen_and_load_galois_key(Context *c, uint64_t galEl) {
 
 // ---------------------------------------------------------------- newContext (main.go:44-462, kind "Conv")
 Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, const std::vector<int> &kp_wids, bool boot, const std::string &kind) {
-    (void)ker_wid; (void)in_wids; (void)kp_wids;
+    (void)ker_wid;
     if (kind != "Conv" && kind != "Resnet_crop_sparse") panic("Wrong kinds!");       // main.go:404 (the kinds the built command lines use)
     Context *c = new Context();
     double logqp = 0; for (uint64_t q : PARAMS6_Q) logqp += log2((double)q); for (uint64_t p : PARAMS6_P) logqp += log2((double)p);
@@ -144,6 +144,7 @@ Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, cons
         // DFT matrices and every switching key, same secret key. "Conv": one full-slot bootstrapper; the resnet kind: the
         // four sparse ones its layers use (btp2..btp5 of main.go:480-500; log_sparse 1..4)
         c->btp = kind == "Conv" ? newBoot(c->sk, c->seed, dev, {0}) : newBoot(c->sk, c->seed, dev, {2, 1, 3, 4});
+        if (kind != "Conv") { bootPrepareCompress(c->btp, in_wids[0], kp_wids[1], 1); bootPrepareCompress(c->btp, in_wids[1], kp_wids[2], 2); }   // main.go:163-215
         printf("Done in %s \n", dur(start).c_str());
     }
     return c;

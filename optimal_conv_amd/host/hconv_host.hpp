@@ -98,6 +98,7 @@ void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool
 // ---- convReLU chain (hconv_relu.cpp; eval.go:272-607 for kind "Conv") ----
 Boot *newBoot(const std::vector<int64_t> &sk, uint64_t seed, int device, const std::vector<int> &log_sparse_sets);   // one "bootstrapper" per log_sparse
 void freeBoot(Boot *);
+void bootPrepareCompress(Boot *B, int in_wid, int kp_wid, int log_sparse);   // rotation keys of a stride layer's ext_double_ctxt
 // everything after evalConv_BN: Scale *= 2^pow, BootstrappConv_CtoS, evalReLU + MulByPow2, keep_ctxt, BootstrappConv_StoC
 BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sparse, const uint64_t *ct_conv_dev, double ct_scale, double alpha, double pow, int in_wid, int kp_wid);
 std::vector<double> bootDecryptDecodeCoeffs(Boot *B, const BootCiphertext &ct);

@@ -579,6 +579,11 @@ Boot *newBoot(const std::vector<int64_t> &sk, uint64_t seed, int device, const s
     for (int ls : log_sparse_sets) b->set(ls);
     return b;
 }
+// main.go:163-215: the rotations of the stride layers' ext_double_ctxt belong to the evaluator's rotation keys
+void bootPrepareCompress(Boot *B, int in_wid, int kp_wid, int log_sparse) {
+    IdxMap m_idx, r_idx; gen_comprs_sparse(N / 2, in_wid, kp_wid, log_sparse, m_idx, r_idx);
+    for (auto *m : {&m_idx, &r_idx}) for (auto &e : *m) { const int k = ((e.first % B->n) + B->n) % B->n; if (k) B->key(B->gal_rot(k), LV_RELU_TOP - 10); }
+}
 void freeBoot(Boot *b) {
     if (!b) return;
     b->sets.clear(); b->mono_i.reset();

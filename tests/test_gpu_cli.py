@@ -60,3 +60,20 @@ def test_conv_relu_cli(tmp_path, k, i_batch):
     med = float(re.search(r"^MED Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M).group(1))
     avg = float(re.search(r"^AVG Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M).group(1))
     assert med >= 10.5 and avg >= 7.5, txt
+
+
+def test_resnet_cli_depth8(tmp_path):
+    """`resnet 3 8 1 1 false` (scope row 8f-3; the reference's depth-8 variant of BASELINE.md config 5): encrypted inference with
+    synthetic weights in the reference's file layout; the class scores must follow the plain float model of the same network"""
+    import numpy as np
+    import golden.gen_resnet_csv as rgen
+    (want, _), = rgen.write_case(str(tmp_path), 3, 8, 1)
+    out = subprocess.run([CLI, "resnet", "3", "8", "1", "1", "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
+                         env=dict(os.environ, HCONV_SEED="11"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    print(out.stdout[-1500:])
+    for pat in (r"^Block1, Layer  3 done!$", r"^Block1 to 2 done!$", r"^Block2 to 3 done!$", r"^Block3 done\.$", r"^Final FC done\.$", r"^Total done in \S+ $"):
+        assert re.search(pat, out.stdout, re.M), pat
+    got = np.loadtxt(tmp_path / "Resnet_enc_results" / "results_crop_ker3_d8_wid1" / "class_result_ker3_0.csv")
+    assert got.shape == (10,) and got.argmax() == want.argmax()
+    assert np.max(np.abs(got - want)) < 0.08, (got, want)
