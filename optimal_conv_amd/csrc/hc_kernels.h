@@ -602,8 +602,9 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTw
 //        F_1 = a_Q * t2.c1                      (k = 1)
 //        F_0 = t2.c0 * P + b_Q * t2.c1          (k = 0; also needs x_1, y_1)
 //   rows-forward mod Q0 of the k-th extension n_k ; d_k = (F_k - n_k) * P^-1 = [k==0] t2.c0 + (key switch)_k ;
-//   row-local Galois permutation through LDS ; dst[i][k] = t1_k + perm(d_k) (+ bias on k = 0 of the last node).
-// Requires the permutation to stay inside 256-blocks (galEl = 2^j+1, j >= 9).
+//   tile-local Galois permutation through LDS ; dst[i][k] = t1_k + perm(d_k) (+ bias on k = 0 of the last node).
+// Requires the permutation to stay inside the workgroup's 16-row tile (4096 consecutive coefficients): galEl = 2^j+1, j >= 5
+// (j >= 9 even stays inside one 256-coefficient row; j = 7, 8 are what the resnet's 8x8 layers, max_cnum 1024, add).
 template <int FM>
 __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, const u64 *bias) {
     __shared__ u64 lds[HC_ROWS_LDS];
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, c
     for (int kk = 0; kk < 16; kk++) {
         const u32 dstidx = (u32)((blockIdx.x * 16 + kk) * 256 + t);
         const u32 srcidx = hc_perm_src(dstidx, B.gal);
-        o[kk * 256] = hc_addmod(t1[kk], lds[hc_rows_lds(kk, (int)(srcidx & 255))], q);
+        o[kk * 256] = hc_addmod(t1[kk], lds[hc_rows_lds((int)((srcidx >> 8) & 15), (int)(srcidx & 255))], q);   // source stays inside this 16-row tile
     }
 }
 

@@ -523,14 +523,11 @@ extern "C" int hc_div_round_last(hc_ctx *c, int level, const uint64_t *x, uint64
 
 // ------------------------------------------------------------------ evk / idx / ker loading
 static bool hc_perm_row_local(u64 galEl) {
-    // ring.PermuteNTTIndex stays inside 256-element blocks iff it fixes the top 8 bits of the destination index
-    for (u32 i = 0; i < HC_N; i += 97) {
-        u32 r = h_bitrev16(i), t = (u32)(((galEl * (2ull * r + 1)) & 0x1FFFF) >> 1), s = h_bitrev16(t);
-        if ((s >> 8) != (i >> 8)) return false;
-    }
+    // ring.PermuteNTTIndex stays inside the 4096-coefficient tile a b5 workgroup holds in LDS iff it fixes the top 4 bits of the
+    // destination index (true for 2^j+1 with j >= 5; with j >= 9 it even fixes the top 8 bits, i.e. the 256-coefficient row)
     for (u32 i = 0; i < HC_N; i++) {
         u32 r = h_bitrev16(i), t = (u32)(((galEl * (2ull * r + 1)) & 0x1FFFF) >> 1), s = h_bitrev16(t);
-        if ((s >> 8) != (i >> 8)) return false;
+        if ((s >> 12) != (i >> 12)) return false;
     }
     return true;
 }
@@ -679,7 +676,7 @@ static int hc_fill_loopB(hc_ctx *c, HcLoopB *B, const u64 *src, u64 *dst, const 
 static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, int step, int logStep, int norm, u64 galEl, const u64 *bias_last) {
     auto it = c->evk.find(galEl);
     if (it == c->evk.end()) return hc_fail(c, HC_ERR_STATE, "pack: no switching key loaded for galEl=%llu (the reference panics in permuteNTT)", (unsigned long long)galEl);
-    if (!it->second.row_local) return hc_fail(c, HC_ERR_UNSUPPORTED, "pack: galEl=%llu does not permute inside 256-blocks (needs max_cnum <= 256)", (unsigned long long)galEl);
+    if (!it->second.row_local) return hc_fail(c, HC_ERR_UNSUPPORTED, "pack: galEl=%llu does not permute inside 4096-coefficient tiles (needs max_cnum <= 4096)", (unsigned long long)galEl);
     if (!c->idx_pairs) HC_TRY(hc_idx_load(c, nullptr));
     const int nodes = (step + norm - 1) / norm;
     const int chunk = (int)(c->chunk_nodes < nodes ? (c->chunk_nodes < 1 ? 1 : c->chunk_nodes) : nodes);
@@ -773,7 +770,7 @@ static int hc_ks_common(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uin
             if (!rc) rc = hc_launch(c, "ks_sub", hc_k_pointwise<HC_PW_SUB>, hc_pw_grid(2 * HC_N), (const u64 *)res, (const u64 *)y, res, (size_t)2 * HC_N, c->mods[0].m, z);
             if (!rc) { hipMemcpyAsync(o0, res, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); hipMemcpyAsync(o1, res + HC_N, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); }
         } else {
-            rc = hc_fail(c, HC_ERR_UNSUPPORTED, "level-0 key switch is exposed for Galois elements that permute inside 256-blocks (2^j+1, j>=9), the ones pack_ctxts uses");
+            rc = hc_fail(c, HC_ERR_UNSUPPORTED, "level-0 key switch is exposed for Galois elements that permute inside 4096-coefficient tiles (2^j+1, j>=5), the ones pack_ctxts uses");
         }
     }
     hipStreamSynchronize(c->stream);

@@ -110,7 +110,7 @@ static void gen_and_load_galois_key(Context *c, uint64_t galEl) {
         rows[2 * w] = bb; rows[2 * w + 1] = a;
     }
     HC(c->hc, hc_evk_load(c->hc, galEl, rows[0].data(), rows[1].data(), rows[2].data(), rows[3].data()));
-    if (galEl - 1 < 512) {      // 2^j+1 with j < 9 does not permute inside 256-coefficient rows: RotateGal takes the general key switch
+    if (galEl - 1 < 32) {       // 2^j+1 with j < 5 leaves the 4096-coefficient tile of the fused kernels: RotateGal takes the general key switch
         std::vector<uint64_t> g; for (int r : {0, 2, 1, 3}) g.insert(g.end(), rows[r].begin(), rows[r].end());     // [digit 0][b | a][Q0, P][N]
         HC(c->hc, hc_swk_load(c->hc, galEl, 0, g.data()));
     }
@@ -314,7 +314,7 @@ void GpuEvaluator::AddPlain(const Ciphertext &a, const Plaintext &b, Ciphertext 
 void GpuEvaluator::RotateGal(const Ciphertext &ct, uint64_t galEl, Ciphertext &out) {
     if (ct.level != 0) panic("RotateGal: level 0 expected on the pack path");
     if (!out.d) out = alloc(0, ct.Scale);
-    if (galEl - 1 < 512) {      // the resnet's 8x8 layers (max_cnum 1024): evaluator.permuteNTT from the general primitives
+    if (galEl - 1 < 32) {       // evaluator.permuteNTT from the general primitives
         uint64_t *d = dev_rows(cont, 2);
         HC(cont->hc, hc_keyswitch(cont->hc, galEl, 0, ct.d + N, d, d + N));
         HC(cont->hc, hc_add(cont->hc, 0, d, ct.d, d, 1));
@@ -384,9 +384,7 @@ static Ciphertext conv_then_pack_opwise(Context *c, const Ciphertext &ctxt_in, c
 
 Ciphertext conv_then_pack(Context *c, const Ciphertext &ctxt_in, const KerPlain &pl_ker, int max_ob, int norm, int ECD_LV, double out_scale, const Plaintext *pl_bn_b) {
     (void)ECD_LV;
-    // the fused pack kernels permute inside 256-coefficient rows (Galois elements 2^j+1, j >= 9: max_ob <= 256, every `conv`
-    // configuration); the resnet's 8x8 layers (max_ob 1024) run the same algorithm op by op on the L0 ABI
-    if (getenv("HCONV_OPWISE") || max_ob > 256) return conv_then_pack_opwise(c, ctxt_in, pl_ker, max_ob, norm, out_scale);
+    if (getenv("HCONV_OPWISE")) return conv_then_pack_opwise(c, ctxt_in, pl_ker, max_ob, norm, out_scale);
     auto start = now();
     Ciphertext r; r.d = dev_rows(c, 2); r.level = 0;
     // The reference prints "mult time" and "Pack time" separately (conv.go:533,535); run the two phases through

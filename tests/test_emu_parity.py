@@ -115,3 +115,10 @@ def test_ckks_leveled_ops():
     MultByi, AddConst, the bootstrapping modulus raise to level 27) composed from C-ABI calls vs the oracle, bit for bit"""
     subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
     pc.case_ckks_ops(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), levels=((6, 2.0 ** 30),))
+
+
+def test_conv_1024_channels_sparse_tile_local_galois(env):
+    """the resnet's 8x8 layers: max_ob = 1024 at norm 16; the pack tree then rotates by 2^7+1 and 2^8+1, which permute inside
+    the 4096-coefficient tile a b5 workgroup holds in LDS but not inside one 256-coefficient row"""
+    pc.case_keyswitch(*env, gals=(129, 257))
+    pc.case_conv(*env, 1024, norm=16, out_scale=2.0 ** 41)

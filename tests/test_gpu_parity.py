@@ -246,3 +246,10 @@ def test_conv_relu_tail_sparse_on_gpu(log_sparse):
     on the device ABI, every stage bit-identical to the oracle"""
     from optimal_conv_amd import Context
     print("median precision bits", pc.case_conv_relu_tail_sparse(lambda Q, P: Context(Q, P), log_sparse))
+
+
+def test_conv_1024_channels_sparse_tile_local_galois(env):
+    """max_ob = 1024 at norm 16 (the resnet's 8x8 layers): Galois elements 2^7+1, 2^8+1 through the fused kernels vs the oracle"""
+    pc.case_keyswitch(*env, gals=(129, 257, 33))
+    pc.case_conv(*env, 1024, norm=16)
+    pc.case_conv(*env, 1024, norm=16, out_scale=2.0 ** 41)
