@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PEAK = 256 * 64 * 2.4e9
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", *([a for a in os.environ.get("ISA_DEFS","").split() if a]), "-I" + ROOT + "/optimal_conv_amd/csrc", "-I" + ROOT + "/include",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", *os.environ.get("ISA_DEFS", "").split(), *([a for a in os.environ.get("ISA_DEFS","").split() if a]), "-I" + ROOT + "/optimal_conv_amd/csrc", "-I" + ROOT + "/include",
                        "-S", "--cuda-device-only", "-o", "/tmp/hconv_isa.s", ROOT + "/optimal_conv_amd/csrc/hconv.hip"])
 lines = open("/tmp/hconv_isa.s").read().split("\n")
 per_job = dict(a.split("=") for a in sys.argv[1:])
