@@ -206,6 +206,8 @@ static void plant_row(uint64_t rowptr, uint64_t seed, uint64_t q) {
 #define A_MULTBYCONST        0x51ee98ull
 #define A_DIVROUND           0x4f3ab3ull
 #define A_ENCODECOEFFS       0x518bb8ull
+#define A_RESCALE            0x522453ull  /* ckks.(*evaluator).Rescale */
+#define A_MULRELIN           0x522c7bull  /* ckks.(*evaluator).mulRelin (behind Mul / MulRelin / MulNew / MulRelinNew) */
 #define A_TYPE_FLOAT64       0x570a20ull  /* runtime type descriptor of float64 (seen in the interface word) */
 
 static const uint64_t Q0 = 0x80000000080001ull, Q1 = 0x1ffffffea0001ull, P0 = 0x1fffffffffe00001ull;
@@ -317,7 +319,10 @@ static void on_switchkeys_general(struct user_regs_struct *r) {
     fprintf(stderr, "KS call %d level %lu evk %d beta %d\n", call, level, id, beta);
     hook_return(r, ret_switchkeys_general, u);
 }
+static void nested_ks_plant(struct user_regs_struct *r);
+static int g_nested_ks_fwd(void);
 static void on_switchkeys(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (g_nested_ks_fwd()) { nested_ks_plant(r); return; }
     if (g_ks_max) { on_switchkeys_general(r); return; }
     if (!g_in_ctp) return;
     uint64_t level = rd64(r->rsp + 0x10), cx = rd64(r->rsp + 0x18), evk = rd64(r->rsp + 0x20);
@@ -340,6 +345,71 @@ static void on_switchkeys(pid_t t, struct user_regs_struct *r, void *ud) { (void
         }
     }
     if (!g_lean) hook_return(r, ret_switchkeys, ud_new(p0, p1, (uint64_t)k));
+}
+
+/* ---------- -ops N: the leveled evaluator of the convReLU chain. Plants both inputs of ckks.(*evaluator).mulRelin (relin = true,
+ * two degree-1 ciphertexts) and the input of ckks.(*evaluator).Rescale, first `-ops-unique` calls per (operation, level), and
+ * records level / scale / SHA-256 of the result. The relinearisation key the nested SwitchKeysInPlace reads is planted with the
+ * same seeds the -ks mode uses (SEED_KSEVK) and its id is recorded, the key-switch input is left alone (it is the real c2). */
+#define SEED_OPIN(call, operand, poly, limb) (g_seed + ((6ull << 32) | (((((uint64_t)(call)) * 2 + (uint64_t)(operand)) * 4 + (uint64_t)(poly)) * 64 + (uint64_t)(limb))))
+static int g_ops_max = 0, g_ops_calls = 0, g_ops_unique = 1, g_nested_ks = 0, g_nested_evk = -1, g_nested_alpha = 0;
+static int g_nested_ks_fwd(void) { return g_nested_ks; }
+typedef struct { uint64_t out; int call, level; double s0, s1, min_scale; } oprec_t;
+static oprec_t g_oprec[8]; static int g_oprec_i;
+static void ops_done_check(void) { if (g_ops_calls >= g_ops_max) { fprintf(g_out, "\n ],\n \"exit_code\": 0}\n"); fflush(g_out); kill(g_pid, SIGKILL); exit(0); } }
+static void plant_ct(uint64_t ct, int call, int operand) {
+    int limbs = poly_limbs(ct_poly(ct, 0));
+    for (int k = 0; k < 2; k++) for (int l = 0; l < limbs; l++) plant_row(poly_row(ct_poly(ct, k), l, NULL), SEED_OPIN(call, operand, k, l), g_Q[l]);
+}
+static void nested_ks_plant(struct user_regs_struct *r) {      /* inside a traced mulRelin: plant the key rows only */
+    uint64_t level = rd64(r->rsp + 0x10), evk = rd64(r->rsp + 0x20);
+    int alpha = g_nP; { uint64_t v0 = rd64(evk); int limbs0 = poly_limbs(rd64(v0)); if (g_nQ_full) alpha = limbs0 - g_nQ_full; }
+    int id = -1; for (int i = 0; i < g_nevk; i++) if (g_evk_seen[i] == evk) id = i;
+    if (id < 0) { id = g_nevk; g_evk_seen[g_nevk++] = evk; }
+    const int beta = ((int)level + 1 + alpha - 1) / alpha; uint64_t v = rd64(evk);
+    for (int d = 0; d < beta; d++) for (int k = 0; k < 2; k++) {
+        uint64_t poly = rd64(v + 16ull * (uint64_t)d + 8ull * (uint64_t)k); int limbs = poly_limbs(poly);
+        for (int l = 0; l <= (int)level; l++) plant_row(poly_row(poly, l, NULL), SEED_KSEVK(id, d, k, l), g_Q[l]);
+        for (int j = 0; j < alpha; j++) plant_row(poly_row(poly, limbs - alpha + j, NULL), SEED_KSEVK(id, d, k, 32 + j), g_Pm[j]);
+    }
+    g_nested_evk = id; g_nested_alpha = alpha;
+}
+static void ret_mulrelin(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
+    oprec_t *u = ud; g_nested_ks = 0;
+    emit_begin("MulRelin"); fprintf(g_out, ", \"call\": %d, \"level\": %d, \"square\": %d, \"scale0\": %.17g, \"scale1\": %.17g, \"evk\": %d, \"alpha\": %d", u->call, u->level, (int)u->min_scale, u->s0, u->s1, g_nested_evk, g_nested_alpha);
+    emit_ct("out", u->out); emit_end(); ops_done_check(); }
+static void on_mulrelin(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_ops_max || g_nested_ks) return;
+    /* mulRelin(recv, op0 Operand (itab, ptr), op1 Operand (itab, ptr), relin bool, ctOut *Ciphertext) */
+    uint64_t op0 = rd64(r->rsp + 0x18), op1 = rd64(r->rsp + 0x28), out = rd64(r->rsp + 0x38); uint8_t relin; rd(r->rsp + 0x30, &relin, 1);
+    if (!relin || ct_degree1(op0) != 2 || ct_degree1(op1) != 2) return;
+    int l0 = poly_limbs(ct_poly(op0, 0)) - 1, l1 = poly_limbs(ct_poly(op1, 0)) - 1, level = l0 < l1 ? l0 : l1;
+    if (l0 != l1 || level >= g_nQ) return;                      /* equal levels only: keeps the replay unambiguous */
+    { static int seen[64]; if (seen[level] >= g_ops_unique) return; seen[level]++; }
+    int call = g_ops_calls++;
+    plant_ct(op0, call, 0); if (op1 != op0) plant_ct(op1, call, 1);
+    oprec_t *u = &g_oprec[g_oprec_i++ % 8]; u->out = out; u->call = call; u->level = level; u->s0 = ct_scale(op0); u->s1 = ct_scale(op1); u->min_scale = op1 == op0 ? 1 : 0;
+    g_nested_ks = 1; g_nested_evk = -1;
+    fprintf(stderr, "MulRelin call %d level %d%s\n", call, level, op1 == op0 ? " (square)" : "");
+    hook_return(r, ret_mulrelin, u);
+}
+static void ret_rescale(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
+    oprec_t *u = ud;
+    emit_begin("Rescale"); fprintf(g_out, ", \"call\": %d, \"level\": %d, \"scale_in\": %.17g, \"min_scale\": %.17g", u->call, u->level, u->s0, u->min_scale);
+    emit_ct("out", u->out); emit_end(); ops_done_check(); }
+static void on_rescale(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_ops_max || g_nested_ks) return;
+    /* Rescale(recv, ctIn *Ciphertext, minScale float64, ctOut *Ciphertext) */
+    uint64_t in = rd64(r->rsp + 0x10), out = rd64(r->rsp + 0x20); double ms = rdf64(r->rsp + 0x18);
+    if (ct_degree1(in) != 2) return;
+    int level = poly_limbs(ct_poly(in, 0)) - 1;
+    if (level < 1 || level >= g_nQ) return;
+    { static int seen[64]; if (seen[level] >= g_ops_unique) return; seen[level]++; }
+    int call = g_ops_calls++;
+    plant_ct(in, call, 0);
+    oprec_t *u = &g_oprec[g_oprec_i++ % 8]; u->out = out; u->call = call; u->level = level; u->s0 = ct_scale(in); u->min_scale = ms;
+    fprintf(stderr, "Rescale call %d level %d scale %g\n", call, level, u->s0);
+    hook_return(r, ret_rescale, u);
 }
 
 /* (*encoderComplex128).EncodeCoeffs(coeffs []float64, pt *ckks.Plaintext): digest of the encoded plaintext
@@ -424,6 +494,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[ai], "-v")) g_verbose = 1;
         else if (!strcmp(argv[ai], "-lean")) g_lean = 1;
         else if (!strcmp(argv[ai], "-ks") && ai + 1 < argc) g_ks_max = atoi(argv[++ai]);
+        else if (!strcmp(argv[ai], "-ops") && ai + 1 < argc) g_ops_max = atoi(argv[++ai]);            /* trace this many Rescale / mulRelin calls */
+        else if (!strcmp(argv[ai], "-ops-unique") && ai + 1 < argc) g_ops_unique = atoi(argv[++ai]);
         else if (!strcmp(argv[ai], "-ks-unique") && ai + 1 < argc) g_ks_unique = atoi(argv[++ai]);   /* at most this many calls per (level, alpha) */
         else if (!strcmp(argv[ai], "-nq-full") && ai + 1 < argc) g_nQ_full = atoi(argv[++ai]);       /* Q limbs of a full key row: alpha = limbs - this */
         else if ((!strcmp(argv[ai], "-Q") || !strcmp(argv[ai], "-P")) && ai + 1 < argc) {
@@ -474,6 +546,7 @@ int main(int argc, char **argv) {
     bp_add(A_ROTATEGAL, on_rotgal, NULL);
     bp_add(A_SWITCHKEYS, on_switchkeys, NULL);
     bp_add(A_MULTBYCONST, on_multbyconst, NULL);
+    if (g_ops_max) { bp_add(A_RESCALE, on_rescale, NULL); bp_add(A_MULRELIN, on_mulrelin, NULL); }
 
     ptrace(PTRACE_CONT, pid, 0, 0);
     int exit_code = -1; uint64_t refire_addr = 0, refire_rsp = 0;

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 (`resnet 3 20 1 n false`, images/hour on N GPUs): images are independent ciphertexts, so N GPUs = N
+processes of the `conv resnet` CLI, one per device (HCONV_DEVICE), each classifying its own share of the images; no collective.
+Prints one JSON line: images/hour = images / max over ranks of the summed per-image "Total done in" times (context and key
+generation, which the reference also keeps outside its per-image timer, are reported separately).
+Usage: tools/resnet_throughput.py [--gpus N] [--images M per GPU] [--depth 20] [--ker 3]"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def to_seconds(tok):
+    m = re.match(r"([0-9.]+)(µs|ms|s)$", tok)
+    return float(m.group(1)) * {"µs": 1e-6, "ms": 1e-3, "s": 1.0}[m.group(2)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--images", type=int, default=2)
+    ap.add_argument("--depth", type=int, default=20)
+    ap.add_argument("--ker", type=int, default=3)
+    a = ap.parse_args()
+    import golden.gen_resnet_csv as rgen
+    cli = os.path.join(ROOT, "optimal_conv_amd", "host", "conv")
+    work = tempfile.mkdtemp(prefix="resnet_tp_")
+    rgen.write_case(work, a.ker, a.depth, a.images)
+    t0 = time.time()
+    procs = [subprocess.Popen([cli, "resnet", str(a.ker), str(a.depth), "1", str(a.images), "false"], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=dict(os.environ, HCONV_DEVICE=str(r), HCONV_SEED=str(100 + r))) for r in range(a.gpus)]
+    per_rank = []
+    for p in procs:
+        out = p.communicate()[0]
+        if p.returncode:
+            sys.exit(f"rank failed ({p.returncode}):\n{out[-2000:]}")
+        per_rank.append([to_seconds(t) for t in re.findall(r"^Total done in (\S+) $", out, re.M)])
+    wall = time.time() - t0
+    slowest = max(sum(t) for t in per_rank)
+    print(json.dumps({"metric": "encrypted ResNet inference, images/hour", "value": a.gpus * a.images / slowest * 3600.0, "unit": "images/hour", "n_gpus": a.gpus,
+                      "config": {"workload": f"resnet {a.ker} {a.depth} 1 {a.images} false", "images_per_gpu": a.images, "data": "synthetic weights and images"},
+                      "seconds_per_image": [sum(t) / len(t) for t in per_rank], "wall_seconds_including_context_and_keys": wall}))
+
+
+if __name__ == "__main__":
+    main()
