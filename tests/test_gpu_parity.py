@@ -253,3 +253,45 @@ def test_conv_1024_channels_sparse_tile_local_galois(env):
     pc.case_keyswitch(*env, gals=(129, 257, 33))
     pc.case_conv(*env, 1024, norm=16)
     pc.case_conv(*env, 1024, norm=16, out_scale=2.0 ** 41)
+
+
+def test_leveled_ops_vs_reference_trace_on_gpu():
+    """GPU vs the digests the reference binary produced for ckks.(*evaluator).mulRelin (tensor + relinearisation, levels 5..23)
+    and ckks.(*evaluator).Rescale (levels 1..27) on planted inputs in a `convReLU 5 1 1` run: hc_lv_mul_tensor + hc_keyswitch +
+    hc_lv_add, and the general-level hc_div_round_last"""
+    from optimal_conv_amd import Context
+    from test_oracle_pin_keyswitch import ks_inputs
+    from test_oracle_pin_ops import planted_ct
+    d = json.load(open(os.path.join(HERE, "golden", "ref_trace_ops_relu_5_1.json")))
+    Q, P, seed, N = d["ks_Q"], d["ks_P"], d["seed"], d["N"]
+    ctxs = {}
+    for e in d["events"]:
+        L, call = e["level"], e["call"]
+        want = [p["sha256"] for p in e["out"]["polys"]]
+        if e["op"] == "MulRelin":
+            Pa = P[: e["alpha"]]
+            if len(Pa) not in ctxs:
+                ctxs[len(Pa)] = Context(Q, Pa)
+            ctx = ctxs[len(Pa)]
+            a = planted_ct(seed, call, 0, L, Q, N)
+            b = a if e["square"] else planted_ct(seed, call, 1, L, Q, N)
+            _, evk = ks_inputs(seed, 0, e["evk"], L, Q, Pa, N)
+            d0, d1, d2 = ctx.lv_mul_tensor(L, a, b)
+            ctx.swk_load(500 + call, L, evk)
+            k0, k1 = ctx.keyswitch(500 + call, L, d2)
+            got = [sha_rows(*ctx.lv_add(L, d0, k0)), sha_rows(*ctx.lv_add(L, d1, k1))]
+        else:
+            if len(P) not in ctxs:
+                ctxs[len(P)] = Context(Q, P)
+            ctx = ctxs[len(P)]
+            ct = planted_ct(seed, call, 0, L, Q, N)
+            scale, lv = float(e["scale_in"]), L
+            while lv > 0 and scale / float(Q[lv]) >= e["min_scale"] / 2:
+                ct = np.stack([ctx.div_round_last(lv, ct[k]) for k in range(2)])
+                scale /= float(Q[lv])
+                lv -= 1
+            assert lv == e["out"]["level"]
+            got = [sha_rows(*ct[0]), sha_rows(*ct[1])]
+        assert got == want, f"{e['op']} call {call} level {L}"
+    for ctx in ctxs.values():
+        ctx.close()

@@ -51,12 +51,12 @@ def test_leveled_ops_vs_reference(path):
                 c0, c1 = mul_relin(O, a, b, evk, L)
                 ok = ok or [sha_rows(*c0), sha_rows(*c1)] == want
             assert ok, f"MulRelin call {call} level {L}"
-            assert e["out"]["level"] == L and e["out"]["scale"] == e["scale0"] * e["scale1"]
+            assert e["out"]["level"] == L and e["out"]["scale"] == float(e["scale0"]) * float(e["scale1"])
             n_mul += 1
         elif e["op"] == "Rescale":
             O = ctxs.setdefault(len(P), Oracle(q=Q, p=P))
             ct = planted_ct(seed, call, 0, L, Q, N)
-            scale, lv = e["scale_in"], L
+            scale, lv = float(e["scale_in"]), L
             while lv > 0 and scale / float(Q[lv]) >= e["min_scale"] / 2:          # ckks.(*evaluator).Rescale's drop rule
                 ct = np.stack([O.div_round_last(lv, ct[k]) for k in range(2)])
                 scale /= float(Q[lv])
