@@ -74,6 +74,7 @@ struct Boot {
     std::map<int, Set> sets;                                           // by log_sparse
     std::vector<double> sine;
     long n_keyswitch = 0, n_keys = 0;
+    std::map<std::string, DPt> pt_cache;                     // encoded 0/1 masks (keep_ctxt, ext_double_ctxt), by what defines them
 
     // ---------------- memory
     std::shared_ptr<uint64_t> block() {
@@ -241,6 +242,13 @@ struct Boot {
     static DCt relabel(const DCt &a, double scale) { if (fabs(a.scale / scale - 1.0) > 1e-6) panic("relabel: scales are not close"); DCt r = a; r.scale = scale; return r; }
 
     // ---------------- encoding
+    // a 0/1 slot mask at (level, scale): encoded once per context (the reference re-encodes them in every layer, conv.go:423, 381)
+    DPt encode_mask(const std::string &key, const std::vector<int> &idx, int level, double scale) {
+        const std::string k = key + "/" + std::to_string(level);
+        auto it = pt_cache.find(k); if (it != pt_cache.end()) return it->second;
+        std::vector<cplx> tmp((size_t)N / 2, cplx(0, 0)); for (size_t i = 0; i < idx.size(); i++) tmp[i] = cplx((double)idx[i], 0);
+        return pt_cache.emplace(k, encode(tmp, level, scale)).first->second;
+    }
     DPt encode(const std::vector<cplx> &slots, int level, double scale) {
         std::vector<uint64_t> rows = enc.Encode(slots, scale, Q.data(), level + 1);
         DPt pt; pt.level = level; pt.scale = scale; pt.p = block();
@@ -539,18 +547,17 @@ static void gen_comprs_sparse(int vec_size, int in_wid, int kp_wid, int log_spar
     }
 }
 // conv.go:374-414: sum over (rot, mask) of Rotate(ct * mask, rot), twice (masks at scale sqrt(q_level)), one rescale
-static DCt ext_double_ctxt(Boot *B, const DCt &ct, const IdxMap &m_idx, const IdxMap &r_idx) {
+static DCt ext_double_ctxt(Boot *B, const DCt &ct, const IdxMap &m_idx, const IdxMap &r_idx, const std::string &key) {
     const double sq = sqrt((double)B->Q[(size_t)ct.level]);
-    auto stage = [&](const DCt &in, const IdxMap &idx) {
+    auto stage = [&](const DCt &in, const IdxMap &idx, const char *which) {
         DCt acc; bool have = false;
         for (auto &e : idx) {
-            std::vector<cplx> tmp((size_t)N / 2); for (size_t i = 0; i < e.second.size(); i++) tmp[i] = cplx((double)e.second[i], 0);
-            DCt t = B->rotate(B->mul_plain(in, B->encode(tmp, in.level, sq)), e.first);
+            DCt t = B->rotate(B->mul_plain(in, B->encode_mask(key + which + std::to_string(e.first), e.second, in.level, sq)), e.first);
             acc = have ? B->add(acc, t) : t; have = true;
         }
         return acc;
     };
-    return B->rescale(stage(stage(ct, m_idx), r_idx));
+    return B->rescale(stage(stage(ct, m_idx, "/m"), r_idx, "/r"));
 }
 // conv.go:435-480
 static DCt evalReLU(Boot *B, const DCt &ct_in, double alpha) {
@@ -567,9 +574,8 @@ static DCt evalReLU(Boot *B, const DCt &ct_in, double alpha) {
     return B->mul_relin(s, Boot::drop_to(ct_in, s.level));            // Mul + Relinearize, no rescale (conv.go:475-477)
 }
 // conv.go:417-431
-static DCt keep_ctxt(Boot *B, const DCt &ct, const std::vector<int> &idx) {
-    std::vector<cplx> tmp((size_t)N / 2); for (size_t i = 0; i < idx.size(); i++) tmp[i] = cplx((double)idx[i], 0);
-    DPt pt = B->encode(tmp, ct.level, (double)B->Q[(size_t)ct.level]);
+static DCt keep_ctxt(Boot *B, const DCt &ct, const std::vector<int> &idx, const std::string &key) {
+    DPt pt = B->encode_mask(key, idx, ct.level, (double)B->Q[(size_t)ct.level]);
     return B->rescale(B->mul_plain(ct, pt));
 }
 
@@ -586,7 +592,7 @@ void bootPrepareCompress(Boot *B, int in_wid, int kp_wid, int log_sparse) {
 }
 void freeBoot(Boot *b) {
     if (!b) return;
-    b->sets.clear(); b->mono_i.reset();
+    b->sets.clear(); b->pt_cache.clear(); b->mono_i.reset();
     hc_ctx_destroy(b->hc); delete b;      // device blocks die with the context
 }
 
@@ -615,9 +621,10 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     printf("ReLU Done in %s \n", dur(start).c_str());
     start = now();
     DCt keep[2];
-    if (stride) { IdxMap m_idx, r_idx; gen_comprs_sparse(N / 2, in_wid, kp_wid, log_sparse, m_idx, r_idx); keep[0] = ext_double_ctxt(B, boots[0], m_idx, r_idx); }   // eval.go:500-506
-    else if (sparse) keep[0] = keep_ctxt(B, boots[0], gen_keep_vec_sparse(N / 2, in_wid, kp_wid, log_sparse));                                                       // eval.go:534
-    else for (int ul = 0; ul < 2; ul++) keep[ul] = keep_ctxt(B, boots[ul], gen_keep_vec(N / 2, in_wid, kp_wid, ul));
+    const std::string mk = std::to_string(in_wid) + "/" + std::to_string(kp_wid) + "/" + std::to_string(log_sparse);
+    if (stride) { IdxMap m_idx, r_idx; gen_comprs_sparse(N / 2, in_wid, kp_wid, log_sparse, m_idx, r_idx); keep[0] = ext_double_ctxt(B, boots[0], m_idx, r_idx, "comprs/" + mk); }   // eval.go:500-506
+    else if (sparse) keep[0] = keep_ctxt(B, boots[0], gen_keep_vec_sparse(N / 2, in_wid, kp_wid, log_sparse), "keep/" + mk);                                                       // eval.go:534
+    else for (int ul = 0; ul < 2; ul++) keep[ul] = keep_ctxt(B, boots[ul], gen_keep_vec(N / 2, in_wid, kp_wid, ul), "keep/" + mk + "/" + std::to_string(ul));
     DCt res = B->stoc(keep[0], sparse ? nullptr : &keep[1], log_sparse);                              // eval.go:550-561 ; Rescale (564) is a no-op here
     HCR(hc_sync(hc));
     printf("Boot (StoC) Done in %s \n", dur(start).c_str());

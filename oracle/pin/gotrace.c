@@ -208,6 +208,8 @@ static void plant_row(uint64_t rowptr, uint64_t seed, uint64_t q) {
 #define A_ENCODECOEFFS       0x518bb8ull
 #define A_RESCALE            0x522453ull  /* ckks.(*evaluator).Rescale */
 #define A_MULRELIN           0x522c7bull  /* ckks.(*evaluator).mulRelin (behind Mul / MulRelin / MulNew / MulRelinNew) */
+#define A_ROTATE             0x524438ull  /* ckks.(*evaluator).Rotate(ct0, k, ctOut) */
+#define A_MODUP              0x50741bull  /* ckks.(*Bootstrapper).modUp(ct) *Ciphertext */
 #define A_TYPE_FLOAT64       0x570a20ull  /* runtime type descriptor of float64 (seen in the interface word) */
 
 static const uint64_t Q0 = 0x80000000080001ull, Q1 = 0x1ffffffea0001ull, P0 = 0x1fffffffffe00001ull;
@@ -412,6 +414,39 @@ static void on_rescale(pid_t t, struct user_regs_struct *r, void *ud) { (void)t;
     hook_return(r, ret_rescale, u);
 }
 
+/* Rotate(recv, ct0 *Ciphertext, k int, ctOut *Ciphertext): planted input, planted rotation key (nested), first call per level */
+static void ret_rotate(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
+    oprec_t *u = ud; g_nested_ks = 0;
+    emit_begin("Rotate"); fprintf(g_out, ", \"call\": %d, \"level\": %d, \"k\": %ld, \"evk\": %d, \"alpha\": %d", u->call, u->level, (long)u->s0, g_nested_evk, g_nested_alpha);
+    emit_ct("out", u->out); emit_end(); ops_done_check(); }
+static void on_rotate(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_ops_max || g_nested_ks) return;
+    uint64_t in = rd64(r->rsp + 0x10), out = rd64(r->rsp + 0x20); int64_t k = (int64_t)rd64(r->rsp + 0x18);
+    if (ct_degree1(in) != 2) return;
+    int level = poly_limbs(ct_poly(in, 0)) - 1;
+    if (level >= g_nQ) return;
+    { static int seen[64]; if (seen[level] >= g_ops_unique) return; seen[level]++; }
+    int call = g_ops_calls++;
+    plant_ct(in, call, 0);
+    oprec_t *u = &g_oprec[g_oprec_i++ % 8]; u->out = out; u->call = call; u->level = level; u->s0 = (double)k;
+    g_nested_ks = 1; g_nested_evk = -1;
+    fprintf(stderr, "Rotate call %d level %d k %ld\n", call, level, (long)k);
+    hook_return(r, ret_rotate, u);
+}
+/* modUp(recv *Bootstrapper, ct *Ciphertext) *Ciphertext: planted level-0 input, result read from the return slot */
+static void ret_modup(pid_t t, struct user_regs_struct *r, void *ud) { (void)t;
+    oprec_t *u = ud; uint64_t out = rd64(r->rsp - 8 + 0x18);
+    emit_begin("modUp"); fprintf(g_out, ", \"call\": %d, \"level\": %d", u->call, u->level); emit_ct("out", out); emit_end(); ops_done_check(); }
+static void on_modup(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_ops_max) return;
+    { static int seen; if (seen >= g_ops_unique) return; seen++; }
+    uint64_t in = rd64(r->rsp + 0x10); int level = poly_limbs(ct_poly(in, 0)) - 1, call = g_ops_calls++;
+    plant_ct(in, call, 0);
+    oprec_t *u = &g_oprec[g_oprec_i++ % 8]; u->call = call; u->level = level;
+    fprintf(stderr, "modUp call %d input level %d\n", call, level);
+    hook_return(r, ret_modup, u);
+}
+
 /* (*encoderComplex128).EncodeCoeffs(coeffs []float64, pt *ckks.Plaintext): digest of the encoded plaintext
  * (coefficient domain, before ToNTT). Call order in `conv k i n` with BL skipped: 16 x gen_idxNlogs
  * (conv.go:251), 1 x input (test.go:46), B x prep_Ker (conv.go:513), 1 x bias (eval.go:242). */
@@ -546,7 +581,7 @@ int main(int argc, char **argv) {
     bp_add(A_ROTATEGAL, on_rotgal, NULL);
     bp_add(A_SWITCHKEYS, on_switchkeys, NULL);
     bp_add(A_MULTBYCONST, on_multbyconst, NULL);
-    if (g_ops_max) { bp_add(A_RESCALE, on_rescale, NULL); bp_add(A_MULRELIN, on_mulrelin, NULL); }
+    if (g_ops_max) { bp_add(A_RESCALE, on_rescale, NULL); bp_add(A_MULRELIN, on_mulrelin, NULL); bp_add(A_ROTATE, on_rotate, NULL); bp_add(A_MODUP, on_modup, NULL); }
 
     ptrace(PTRACE_CONT, pid, 0, 0);
     int exit_code = -1; uint64_t refire_addr = 0, refire_rsp = 0;

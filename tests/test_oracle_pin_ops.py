@@ -64,4 +64,22 @@ def test_leveled_ops_vs_reference(path):
             assert lv == e["out"]["level"] and scale == e["out"]["scale"], f"Rescale call {call}: level/scale"
             assert [sha_rows(*ct[0]), sha_rows(*ct[1])] == [p["sha256"] for p in e["out"]["polys"]], f"Rescale call {call} level {L}"
             n_res += 1
+        elif e["op"] == "Rotate":                                   # ckks.(*evaluator).Rotate -> permuteNTT: key switch c1, + c0, permute both
+            Pa = P[: e["alpha"]]
+            O = ctxs.setdefault(len(Pa), Oracle(q=Q, p=Pa))
+            ct = planted_ct(seed, call, 0, L, Q, N)
+            _, evk = ks_inputs(seed, 0, e["evk"], L, Q, Pa, N)
+            gal = pow(5, e["k"] % (2 * N), 2 * N)
+            d0, d1 = O.keyswitch(L, ct[1], evk)
+            idx = O.permute_index(gal)
+            o0 = [O.permute(idx, O.add(l, d0[l], ct[0, l])) for l in range(L + 1)]
+            o1 = [O.permute(idx, d1[l]) for l in range(L + 1)]
+            assert [sha_rows(*o0), sha_rows(*o1)] == [p["sha256"] for p in e["out"]["polys"]], f"Rotate call {call} level {L} k {e['k']}"
+        elif e["op"] == "modUp":                                    # ckks.(*Bootstrapper).modUp: centred lift of the level-0 residues
+            from oracle_ckks import OracleBackend
+            O = ctxs.setdefault(len(P), Oracle(q=Q, p=P))
+            ct = planted_ct(seed, call, 0, L, Q, N)
+            top = e["out"]["level"]
+            got = [sha_rows(*OracleBackend(O).lv_mod_raise(top, ct[k, 0])) for k in range(2)]
+            assert got == [p["sha256"] for p in e["out"]["polys"]], "modUp"
     assert n_mul and n_res
