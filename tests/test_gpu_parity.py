@@ -257,8 +257,8 @@ def test_conv_1024_channels_sparse_tile_local_galois(env):
 
 def test_leveled_ops_vs_reference_trace_on_gpu():
     """GPU vs the digests the reference binary produced for ckks.(*evaluator).mulRelin (tensor + relinearisation, levels 5..23)
-    and ckks.(*evaluator).Rescale (levels 1..27) on planted inputs in a `convReLU 5 1 1` run: hc_lv_mul_tensor + hc_keyswitch +
-    hc_lv_add, and the general-level hc_div_round_last"""
+    and ckks.(*evaluator).Rescale (levels 1..27) and ckks.(*Bootstrapper).modUp on planted inputs in a `convReLU 5 1 1` run:
+    hc_lv_mul_tensor + hc_keyswitch + hc_lv_add, the general-level hc_div_round_last, hc_lv_mod_raise"""
     from optimal_conv_amd import Context
     from test_oracle_pin_keyswitch import ks_inputs
     from test_oracle_pin_ops import planted_ct
@@ -280,6 +280,11 @@ def test_leveled_ops_vs_reference_trace_on_gpu():
             ctx.swk_load(500 + call, L, evk)
             k0, k1 = ctx.keyswitch(500 + call, L, d2)
             got = [sha_rows(*ctx.lv_add(L, d0, k0)), sha_rows(*ctx.lv_add(L, d1, k1))]
+        elif e["op"] == "modUp":                    # ckks.(*Bootstrapper).modUp on a planted level-0 ciphertext
+            if len(P) not in ctxs:
+                ctxs[len(P)] = Context(Q, P)
+            ct = planted_ct(seed, call, 0, L, Q, N)
+            got = [sha_rows(*ctxs[len(P)].lv_mod_raise(e["out"]["level"], ct[k, 0])) for k in range(2)]
         else:
             if len(P) not in ctxs:
                 ctxs[len(P)] = Context(Q, P)
