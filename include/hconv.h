@@ -97,7 +97,8 @@ int hc_lv_mod_raise(hc_ctx *ctx, int level, const uint64_t *in_q0, uint64_t *out
  * to NewEvaluator (conv.go:258). */
 int hc_evk_load(hc_ctx *ctx, uint64_t galEl, const uint64_t *b_q, const uint64_t *a_q, const uint64_t *b_p,
                 const uint64_t *a_p);
-/* rlwe.KeySwitcher.SwitchKeysInPlace at level 0 (c1 -> d0,d1) and evaluator.RotateGal at level 0 (conv.go:291).
+/* rlwe.KeySwitcher.SwitchKeysInPlace at level 0 (c1 -> d0,d1) and evaluator.RotateGal at level 0 (conv.go:291), for Galois
+ * elements that permute inside 4096-coefficient tiles (2^j+1, j >= 5: every pack tree up to max_cnum 4096).
  * in/out may alias for hc_rotate_gal_l0 (conv.go:291 rotates in place). */
 int hc_keyswitch_l0(hc_ctx *ctx, uint64_t galEl, const uint64_t *c1, uint64_t *d0, uint64_t *d1);
 int hc_rotate_gal_l0(hc_ctx *ctx, uint64_t galEl, const uint64_t *c0, const uint64_t *c1, uint64_t *o0, uint64_t *o1);
@@ -107,7 +108,8 @@ int hc_rotate_gal_l0(hc_ctx *ctx, uint64_t galEl, const uint64_t *c0, const uint
  * path: BL baseline eval.go:123 at level 1 with two P primes; the bootstrapping chain with five).
  * hc_swk_load: HOST rows [beta][2][level+1+np][N] = rlwe.SwitchingKey.Value[d][k].Coeffs restricted to the Q limbs
  * 0..level followed by the np P limbs, stored form. hc_keyswitch: cx = (level+1) device rows (NTT); d0, d1 =
- * (level+1) device rows each, canonical. Correctness-first composition (not fused). */
+ * (level+1) device rows each, canonical. One launch per step covers all limbs (multi-modulus transforms, one basis extension
+ * into every target limb, one accumulation of both key components): about 32 launches at level 27. */
 int hc_swk_load(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *rows_host);
 int hc_keyswitch(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1);
 
