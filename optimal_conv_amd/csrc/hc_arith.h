@@ -38,6 +38,30 @@ HC_HD u64 hc_mul_shoup_lazy(u64 x, u64 w, u64 wp, u64 q) {
     u64 hi = hc_mulhi(x, wp);
     return x * w - hi * q;
 }
+// ---- fp64 modular arithmetic for moduli below 2^49 (the inverse transform modulo Q1 of loop A) --------------------------------
+// Values are doubles holding exact integers. x*w mod q with w < q < 2^49 and |x| < 2^51: h = fl(x*w), l = fma(x,w,-h) is the exact
+// low part (Dekker/FMA), k = rint(x * (w/q)) misses the true quotient by less than 1, and h - k*q is an integer below 2^51 in
+// magnitude, hence exact in the fused multiply-add; adding l (an integer below 2^48) stays exact. The result is congruent to x*w and
+// |result| < q. Six full-rate fp64 instructions against ~24 issue slots of integer multiplies for the Shoup form.
+// hc_f64_reduce folds an exact integer |u| < 2^53 into |.| <= q/2 (+1). No contraction: the products must round where written.
+HC_HD double hc_f64_mulmod(double x, double w, double wq, double q) {
+#pragma clang fp contract(off)
+    const double h = x * w;
+    const double l = __builtin_fma(x, w, -h);
+    const double k = __builtin_rint(x * wq);
+    const double r = __builtin_fma(-k, q, h);
+    return r + l;
+}
+HC_HD double hc_f64_reduce(double u, double q, double qinv) {
+#pragma clang fp contract(off)
+    return __builtin_fma(-__builtin_rint(u * qinv), q, u);
+}
+HC_HD double hc_u2d(u64 x) { return __builtin_bit_cast(double, x); }
+HC_HD u64 hc_d2u(double x) { return __builtin_bit_cast(u64, x); }
+HC_HD double hc_f64_from_u(u64 x) { return hc_u2d(x | 0x4330000000000000ull) - 4503599627370496.0; }          // exact for x < 2^52
+// exact integer |v| < 2^51 (a double) + a 64-bit integer base, modulo 2^64: v's two's complement sits in the mantissa of v + 1.5*2^52
+HC_HD u64 hc_f64_to_u_plus(double v, u64 base) { return (hc_d2u(v + 6755399441055744.0) & 0x000FFFFFFFFFFFFFull) + (base - 0x0008000000000000ull); }
+
 // floor(w * 2^64 / q) for w < q < 2^62 by restoring division (load-time only; avoids 128-bit division on the device)
 HC_HD u64 hc_shoup_companion(u64 w, u64 q) {
     u64 r = w, quo = 0;

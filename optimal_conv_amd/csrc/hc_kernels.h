@@ -98,6 +98,32 @@ __device__ __forceinline__ void hc_gs_round(u64 (&e)[16], const TW &tw, u64 q, H
     }
 }
 
+// fp64 form of the inverse round for a modulus below 2^49 (hc_arith.h): the table entries are {w, w/q} as doubles in the bit
+// patterns of an HcTw. Bounds: every value entering a round is below q in magnitude; sums are folded after stages 1 and 3 (where
+// they could reach 4q), differences go through hc_f64_mulmod (|input| < 4q < 2^51); every value leaving the round is below q.
+struct HcF64Mod { double q, qinv; };
+template <bool LAST, class TW>
+__device__ __forceinline__ void hc_gs_round_f64(double (&e)[16], const TW &tw, HcF64Mod m, HcTw ninv, HcTw w_last) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int dist = 1 << s;
+#pragma unroll
+        for (int g = 0; g < (8 >> s); g++) {
+            HcTw w = tw((8 >> s) - 1 + g);
+            if (LAST && s == 3) w = w_last;
+            const double ww = hc_u2d(w.w), wq = hc_u2d(w.ws);
+#pragma unroll
+            for (int k = 0; k < dist; k++) {
+                const int a = g * 2 * dist + k, b = a + dist;
+                const double X = e[a], Y = e[b], u = X + Y, d = X - Y;
+                if (LAST && s == 3) e[a] = hc_f64_mulmod(u, hc_u2d(ninv.w), hc_u2d(ninv.ws), m.q);
+                else e[a] = (s & 1) ? hc_f64_reduce(u, m.q, m.qinv) : u;
+                e[b] = hc_f64_mulmod(d, ww, wq, m.q);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- tile geometry
 // LDS holds 8-byte words; a ds_read/write_b64 is serviced per half-wave over 32 word slots (64 banks x 4 B), so a
 // layout is conflict-free when the 32 lanes of a half-wave hit 32 distinct values of (word index mod 32).
@@ -158,6 +184,26 @@ __device__ __forceinline__ void hc_cols_inv(u64 (&e)[16], u64 *lds, const HcTwTa
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = lds[hc_cols_lds(hi * 16 + tid, c)];
     hc_gs_round<true>(e, HcRowsTwA{T.colsA}, q, T.ninv, T.w_last_ninv);
+}
+
+// fp64 forms of the two inverse passes (same data movement; LDS carries the doubles' bit patterns)
+__device__ __forceinline__ void hc_rows_inv_f64(double (&e)[16], u64 *lds, const HcTwTab &T, int row, int rloc, int tid, HcF64Mod m) {
+    hc_gs_round_f64<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, m, T.ninv, T.ninv);
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) lds[hc_rows_lds(rloc, tid * 16 + lo)] = hc_d2u(e[lo]);
+    __syncthreads();
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) e[hi] = hc_u2d(lds[hc_rows_lds(rloc, hi * 16 + tid)]);
+    hc_gs_round_f64<false>(e, HcRowsTwA{T.rowsA + row * 16}, m, T.ninv, T.ninv);
+}
+__device__ __forceinline__ void hc_cols_inv_f64(double (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, HcF64Mod m) {
+    hc_gs_round_f64<false>(e, HcRowsTwB{T.colsB + tid}, m, T.ninv, T.ninv);
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) lds[hc_cols_lds(tid * 16 + lo, c)] = hc_d2u(e[lo]);
+    __syncthreads();
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) e[hi] = hc_u2d(lds[hc_cols_lds(hi * 16 + tid, c)]);
+    hc_gs_round_f64<true>(e, HcRowsTwA{T.colsA}, m, T.ninv, T.w_last_ninv);
 }
 
 // rows tile <-> "linear" order (thread t holds column t of the 16 rows; k = local row) through LDS
@@ -410,7 +456,9 @@ struct HcLoopA {
     HcTw q1inv;       // Q1^-1 mod Q0
     u64 h, negh0;     // (Q1-1)>>1 ; Q0 - (h mod Q0)
 };
-// KA1: rows-inverse of a_1 (mod Q1). grid = (16, jobs)
+// KA1: rows-inverse of a_1 (mod Q1). grid = (16, jobs). F64 = 1: Q1 < 2^49, the transform runs in fp64 (T1inv = the fp64 table)
+// and tmp carries doubles (bit patterns) to KA2.
+template <int F64>
 __global__ __launch_bounds__(HC_TPB) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
@@ -424,13 +472,23 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
     }
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     __syncthreads();
-    hc_rows_inv(e, lds, T1inv, row, rloc, tid, A.m1.q);
     u64 *o = A.tmp + (size_t)job * 65536 + (size_t)row * 256;
+    if (F64) {
+        const HcF64Mod m{(double)A.m1.q, 1.0 / (double)A.m1.q};
+        double f[16];
 #pragma unroll
-    for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
+        for (int kk = 0; kk < 16; kk++) f[kk] = hc_f64_from_u(e[kk]);
+        hc_rows_inv_f64(f, lds, T1inv, row, rloc, tid, m);
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = hc_d2u(f[hi]);
+    } else {
+        hc_rows_inv(e, lds, T1inv, row, rloc, tid, A.m1.q);
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
+    }
 }
 // KA2: cols-inverse mod Q1, centred lift to Q0, cols-forward mod Q0, in place on tmp. grid = (16, jobs)
-template <int FM>
+template <int FM, int F64>
 __global__ __launch_bounds__(HC_TPB) void hc_k_a2(HcLoopA A, HcTwTab T1inv, HcTwTab T0fwd) {
     __shared__ u64 lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
@@ -438,11 +496,26 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_a2(HcLoopA A, HcTwTab T1inv, HcTw
     u64 e[16];
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = base[(size_t)(tid * 16 + lo) * 256];
+    if (F64) {
+        const double q1 = (double)A.m1.q, hh = (double)A.h;
+        const HcF64Mod m{q1, 1.0 / q1};
+        double f[16];
+#pragma unroll
+        for (int lo = 0; lo < 16; lo++) f[lo] = hc_u2d(e[lo]);
+        hc_cols_inv_f64(f, lds, T1inv, c, tid, m);
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) {
+            double v = f[hi];                                         // exact, |v| < Q1, congruent to t
+            v = v > hh ? v - q1 : (v < -hh ? v + q1 : v);             // [t + h]_{Q1} - h = the representative in [-h, h]
+            e[hi] = hc_f64_to_u_plus(v, A.m0.q);                      // + Q0: the same value mod Q0, in (0, 2*Q0)
+        }
+    } else {
     hc_cols_inv(e, lds, T1inv, c, tid, A.m1.q);
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) {
         u64 v = hc_csub(hc_csub(e[hi], A.m1.q) + A.h, A.m1.q);   // [t + h]_{Q1}
         e[hi] = v + A.negh0;                                      // (.. - h) mod Q0, lazy < 2*Q0
+    }
     }
     __syncthreads();
     hc_cols_fwd<FM>(e, lds, T0fwd, c, tid, A.m0.q);

@@ -64,6 +64,7 @@ struct HcModHost {
     HcMod m;
     u64 psi, psi_inv;
     HcTwTab fwd, inv;            // device tables
+    HcTwTab inv_f64;             // moduli below 2^49: the inverse tables as {w, w/q} doubles (fp64 inverse transform of loop A)
     std::vector<void *> allocs;
 };
 struct HcEvk { u64 *q_rows; HcTw *p_rows; bool row_local; };   // [2][N] each: q_rows Montgomery form; p_rows Shoup pairs, lo-local order
@@ -120,6 +121,7 @@ static int hc_fail(hc_ctx *c, int code, const char *fmt, ...) {
 
 // forward lazy-reduction mode by modulus size (see HC_FM_* in hc_kernels.h): 34q < 2^64 <=> q < 2^58.9
 static inline bool hc_fm_free(u64 q) { return q < (1ull << 58); }
+static inline bool hc_f64_ok(u64 q) { return q < (1ull << 49); }    // fp64 inverse transform (hc_arith.h): 4q < 2^51
 
 template <class K, class... Args>
 static int hc_launch(hc_ctx *c, const char *name, K kernel, dim3 grid, Args... args) {
@@ -189,6 +191,15 @@ static int hc_build_tables(hc_ctx *c, HcModHost *mh, bool inverse) {
     T.ninv = h_pair(mh->m.ninv, q);
     T.w_last_ninv = h_pair(h_mulmod(pw[1], mh->m.ninv, q), q);
     if (inverse) mh->inv = T; else mh->fwd = T;
+    if (inverse && hc_f64_ok(q)) {      // the same table as doubles: {w, w/q} (both exact inputs, one correctly rounded division)
+        auto conv = [&](HcTw x) { HcTw y; y.w = hc_d2u((double)x.w); y.ws = hc_d2u((double)x.w / (double)q); return y; };
+        for (auto *v : {&rowsA, &rowsB, &colsA, &colsB}) for (auto &x : *v) x = conv(x);
+        HcTwTab U; memset(&U, 0, sizeof U);
+        HC_TRY(hc_dev_upload(c, mh, rowsA, &U.rowsA)); HC_TRY(hc_dev_upload(c, mh, rowsB, &U.rowsB));
+        HC_TRY(hc_dev_upload(c, mh, colsA, &U.colsA)); HC_TRY(hc_dev_upload(c, mh, colsB, &U.colsB));
+        U.ninv = conv(T.ninv); U.w_last_ninv = conv(T.w_last_ninv);
+        mh->inv_f64 = U;
+    }
     return HC_OK;
 }
 
@@ -471,8 +482,15 @@ static int hc_loopA_run_set(hc_ctx *c, const u64 *ker_mont, int i_first, int i_s
         A.i0 = i_first + j0 * i_stride;
         A.slot0 = compact ? j0 : A.i0; A.slot_step = compact ? 1 : i_stride;
         dim3 grid(16, (unsigned)(2 * nj));
-        HC_TRY(hc_launch(c, "a1_mul_rowsinv", hc_k_a1, grid, A, m1.inv));
-        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "a2_colsinv_lift_colsfwd", hc_k_a2, grid, A, m1.inv, m0.fwd));
+        if (hc_f64_ok(m1.m.q)) {
+            HC_TRY(hc_launch(c, "a1_mul_rowsinv", hc_k_a1<1>, grid, A, m1.inv_f64));
+            HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2<HC_FM_FREE, 1>, grid, A, m1.inv_f64, m0.fwd)
+                                      : hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2<HC_FM_ALT, 1>, grid, A, m1.inv_f64, m0.fwd));
+        } else {
+            HC_TRY(hc_launch(c, "a1_mul_rowsinv", hc_k_a1<0>, grid, A, m1.inv));
+            HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2<HC_FM_FREE, 0>, grid, A, m1.inv, m0.fwd)
+                                      : hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2<HC_FM_ALT, 0>, grid, A, m1.inv, m0.fwd));
+        }
         HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "a3_rowsfwd_rescale", hc_k_a3, grid, A, m0.fwd));
     }
     return HC_OK;

@@ -17,7 +17,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
                        "-S", "--cuda-device-only", "-o", "/tmp/hconv_isa.s", ROOT + "/optimal_conv_amd/csrc/hconv.hip"])
 lines = open("/tmp/hconv_isa.s").read().split("\n")
 per_job = dict(a.split("=") for a in sys.argv[1:])
-want = ["hc_k_a1", "hc_k_a2ILi1", "hc_k_a3ILi1", "hc_k_b1", "hc_k_b2ILi2", "hc_k_b3ILi2", "hc_k_b4ILi1", "hc_k_b5ILi1"]
+want = ["hc_k_a1ILi1", "hc_k_a2ILi1ELi1", "hc_k_a3ILi1", "hc_k_b1", "hc_k_b2ILi2", "hc_k_b3ILi2", "hc_k_b4ILi1", "hc_k_b5ILi1"]
 print(f"{'kernel':14s} {'instr':>6s} {'VALU':>6s} {'mul':>5s} {'mov':>5s} {'nop':>5s} {'vmem':>5s} {'lds':>4s}  issue slots per job -> model time vs measured")
 for w in want:
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\d+" + w + r".*:\s", l))
