@@ -114,7 +114,6 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
     const std::vector<int> in_wids = {32, 16, 8}, raw_in_wids = {32 - ker_wid / 2, 16 - ker_wid / 2, 8 - ker_wid / 2};
     const int ker_size = ker_wid * ker_wid;
     int max_batch[3]; for (int i = 0; i < 3; i++) max_batch[i] = (1 << logN) / (in_wids[(size_t)i] * in_wids[(size_t)i]);
-    if (cf100) panic("resnet with cifar-100 heads (two final convolutions, test.go:287-315) is not built in this engine");
     Context *cont = newContext(logN, ker_wid, in_wids, raw_in_wids, true, "Resnet_crop_sparse");
     mkdir("Resnet_enc_results", 0755); mkdir(out_dir.c_str(), 0755);
     auto W = [&](int i, const char *what, int size) { return readTxt(weight_dir + "w" + std::to_string(i) + "-" + what + ".csv", size); };
@@ -169,17 +168,38 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
 
         int ker_inf_wid = raw_in_wids[2]; if (ker_inf_wid % 2 == 0) ker_inf_wid++;                       // test.go:279-334: reduce_mean + FC
         std::vector<double> ker_inf = readTxt(weight_dir + "final-fckernel.csv", real_batch[2] * fc_out);
-        std::vector<double> ker_inf_((size_t)(ker_inf_wid * ker_inf_wid * real_batch[2] * fc_out));
-        for (size_t i = 0; i < ker_inf.size(); i++) for (int b = 0; b < ker_inf_wid * ker_inf_wid; b++) ker_inf_[i + (size_t)b * real_batch[2] * fc_out] = ker_inf[i];
-        std::vector<double> bn_af((size_t)fc_out, 1.0 / (double)(raw_in_wids[2] * raw_in_wids[2]));
-        std::vector<double> bn_bf = readTxt(weight_dir + "final-fcbias.csv", fc_out);
-        Ciphertext ct_result = evalConv_BN(cont, ct_layer, ker_inf_, bn_af, bn_bf, in_wids[2], ker_inf_wid, real_batch[2], fc_out, norm[2], (double)(1 << 30), false);
+        std::vector<double> bn_bf = readTxt(weight_dir + "final-fcbias.csv", fc_out), res_out;
+        Ciphertext ct_result, ct_result2;
+        if (cf100) {                                                                                     // test.go:287-315: two convolutions of fc_out/2 outputs
+            const int ho = fc_out / 2; const size_t tap = (size_t)real_batch[2] * ho;
+            std::vector<double> k1((size_t)(ker_inf_wid * ker_inf_wid) * tap), k2(k1.size());
+            for (int i = 0; i < ho; i++) for (int j = 0; j < real_batch[2]; j++) for (int b = 0; b < ker_inf_wid * ker_inf_wid; b++) {
+                k1[(size_t)(j * ho + i) + (size_t)b * tap] = ker_inf[(size_t)(j * fc_out + i)];
+                k2[(size_t)(j * ho + i) + (size_t)b * tap] = ker_inf[(size_t)(j * fc_out + i + ho)];
+            }
+            std::vector<double> bn_af((size_t)ho, 1.0 / (double)(raw_in_wids[2] * raw_in_wids[2])), b1(bn_bf.begin(), bn_bf.begin() + ho), b2(bn_bf.begin() + ho, bn_bf.end());
+            ct_result = evalConv_BN(cont, ct_layer, k1, bn_af, b1, in_wids[2], ker_inf_wid, real_batch[2], ho, norm[2], (double)(1 << 30), false);
+            ct_result2 = evalConv_BN(cont, ct_layer, k2, bn_af, b2, in_wids[2], ker_inf_wid, real_batch[2], ho, norm[2], (double)(1 << 30), false);
+        } else {                                                                                         // test.go:316-334
+            std::vector<double> ker_inf_((size_t)(ker_inf_wid * ker_inf_wid * real_batch[2] * fc_out));
+            for (size_t i = 0; i < ker_inf.size(); i++) for (int b = 0; b < ker_inf_wid * ker_inf_wid; b++) ker_inf_[i + (size_t)b * real_batch[2] * fc_out] = ker_inf[i];
+            std::vector<double> bn_af((size_t)fc_out, 1.0 / (double)(raw_in_wids[2] * raw_in_wids[2]));
+            ct_result = evalConv_BN(cont, ct_layer, ker_inf_, bn_af, bn_bf, in_wids[2], ker_inf_wid, real_batch[2], fc_out, norm[2], (double)(1 << 30), false);
+        }
         printf("Final FC done.\n"); timings[5] = secs(start); start = now();
         printf("\n===============  DECRYPTION  ===============\n\n");
-        std::vector<double> res_tmp = DecryptDecodeCoeffs(cont, ct_result);
-        printf("Decryption Done in %s \n", dur(start).c_str());
-        std::vector<double> res_out = prt_mat_one_norm(res_tmp, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1);
-        res_out.resize((size_t)fc_out);
+        if (cf100) {
+            std::vector<double> r1 = DecryptDecodeCoeffs(cont, ct_result), r2 = DecryptDecodeCoeffs(cont, ct_result2);
+            printf("Decryption Done in %s \n", dur(start).c_str());
+            std::vector<double> o1 = prt_mat_one_norm(r1, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1), o2 = prt_mat_one_norm(r2, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1);
+            res_out.assign(o1.begin(), o1.begin() + fc_out / 2); res_out.insert(res_out.end(), o2.begin(), o2.begin() + fc_out / 2);
+            freeCt(cont, ct_result2);
+        } else {
+            std::vector<double> res_tmp = DecryptDecodeCoeffs(cont, ct_result);
+            printf("Decryption Done in %s \n", dur(start).c_str());
+            res_out = prt_mat_one_norm(res_tmp, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1);
+            res_out.resize((size_t)fc_out);
+        }
         printf("\n result:  ["); for (double v : res_out) printf("%.10f ", v); printf("]\n");
         writeTxt(out_dir + "class_result_" + ker_name + "_" + std::to_string(iter) + ".csv", res_out);
         printf("Blc1:  %g  sec\nBlc1->2:  %g  sec\nBlc2:  %g  sec\nBlc2->3:  %g  sec\nBlc3:  %g  sec\nFinal (reduce_mean & FC):  %g  sec\n", timings[0], timings[1], timings[2], timings[3], timings[4], timings[5]);

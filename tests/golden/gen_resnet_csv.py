@@ -13,9 +13,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle_resnet as rn  # noqa: E402
 
 
-def write_case(root, ker_wid=3, depth=8, n_images=1, seed=0):
-    net = rn.Net(16, ker_wid=ker_wid, depth=depth, seed=seed)
-    tag = f"crop_ker{ker_wid}_d{depth}_wid1"
+def write_case(root, ker_wid=3, depth=8, n_images=1, seed=0, cf100=False):
+    net = rn.Net(16, ker_wid=ker_wid, depth=depth, seed=seed, fc_out=100 if cf100 else 10)
+    tag = ("cf100_" if cf100 else "") + f"crop_ker{ker_wid}_d{depth}_wid1"
     wdir, pdir = os.path.join(root, "Resnet_weights", "weights_" + tag), os.path.join(root, "Resnet_plain_data", tag)
     os.makedirs(wdir, exist_ok=True)
     os.makedirs(pdir, exist_ok=True)
@@ -40,5 +40,6 @@ def write_case(root, ker_wid=3, depth=8, n_images=1, seed=0):
 
 if __name__ == "__main__":
     root, k, d, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-    for sc, amax in write_case(root, k, d, n):
+    cf100 = len(sys.argv) > 5 and sys.argv[5] in ("true", "1")
+    for sc, amax in write_case(root, k, d, n, cf100=cf100):
         print("scores", np.round(sc, 4), "max |activation|", amax)
