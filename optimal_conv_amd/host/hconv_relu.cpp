@@ -592,8 +592,11 @@ void bootPrepareCompress(Boot *B, int in_wid, int kp_wid, int log_sparse) {
 }
 void freeBoot(Boot *b) {
     if (!b) return;
-    b->sets.clear(); b->pt_cache.clear(); b->mono_i.reset();
-    hc_ctx_destroy(b->hc); delete b;      // device blocks die with the context
+    b->sets.clear(); b->pt_cache.clear(); b->mono_i.reset();      // every block returns to the pool
+    for (uint64_t *blk : b->pool) hc_free(b->hc, blk);
+    b->pool.clear();
+    if (b->d_sk) hc_free(b->hc, b->d_sk);
+    hc_ctx_destroy(b->hc); delete b;      // the switching keys are owned by the context
 }
 
 // eval.go:437-565: everything after the convolution(s). ct_conv = the level-0 convolution result at out_scale
