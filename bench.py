@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=64)
     ap.add_argument("--streams", type=int, default=3, help="independent ciphertexts in flight per GPU (one hc_ctx = one HIP stream each)")
     ap.add_argument("--lanes", type=int, default=1, help="internal lanes of one conv (channels i mod G on their own streams)")
+    ap.add_argument("--graph", type=int, default=0, help="replay each lane's conv as a captured hipGraph (measured: no gain, the kernels' own start-up latency dominates, not the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -122,6 +123,7 @@ def main():
         ctx = Context([Q0, Q1], [P0], device=device)            # raises if no GPU / no libhconv.so
         ctx.set_option("chunk_nodes", args.chunk)
         ctx.set_option("lanes", args.lanes)
+        ctx.set_option("graph", args.graph)
         for gal, k4 in keys:
             ctx.evk_load(gal, k4)
         ctx.idx_load(None)
@@ -199,7 +201,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"conv {args.ker_wid} {args.i_batch}", "ker_wid": args.ker_wid, "batch": B, "in_wid": W,
                        "logN": 16, "moduli": "ckks.DefaultBootstrapParams[6] Q0,Q1 + P=0x1fffffffffe00001",
-                       "convs_per_step_per_gpu": 1, "ciphertexts_in_flight_per_gpu": S, "chunk_nodes": args.chunk, "lanes_per_conv": args.lanes},
+                       "convs_per_step_per_gpu": 1, "ciphertexts_in_flight_per_gpu": S, "chunk_nodes": args.chunk, "lanes_per_conv": args.lanes, "hipgraph_replay": bool(args.graph)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic_from_profiles(B, args.chunk),
                          "unit_of_launch": "one conv_then_pack (all of its kernel launches on one stream)",

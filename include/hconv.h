@@ -150,7 +150,7 @@ int hc_pack_ctxts(hc_ctx *ctx, uint64_t *cts, int max_cnum, int real_cnum);
 int hc_pack_ctxts_strided(hc_ctx *ctx, uint64_t *cts, int count, int stride_log2, const uint64_t *bias);
 
 /* ---- tuning / measurement ---- */
-int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes", "profile" */
+int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes", "lanes", "profile", "graph" (hipGraph replay of hc_conv_then_pack) */
 /* HIP-event timing on the context's stream */
 int hc_timer_start(hc_ctx *ctx);
 int hc_timer_stop(hc_ctx *ctx, float *ms);

@@ -92,6 +92,13 @@ struct hc_ctx {
     u64 *ws_ctc = nullptr;
     u64 *ws_tmp = nullptr; size_t ws_tmp_rows = 0;
     HcMod *d_mods = nullptr; HcTw *d_csts = nullptr;      // device copies: all moduli (Q then P); per-call constants of the leveled ops
+    // hipGraph replay of a whole conv_then_pack (option "graph"): the launch list of a conv is static for fixed buffers and
+    // constants, so the second call with the same arguments is captured once and later calls are one graph launch
+    long use_graph = 0;
+    struct GraphKey { const void *ct_in, *ker, *bias; void *ct_out; int max_ob, norm; u64 c0, c1; long chunk;
+        bool operator<(const GraphKey &o) const { return memcmp(this, &o, sizeof *this) < 0; } };
+    struct GraphVal { int seen = 0; void *exec = nullptr; };
+    std::map<GraphKey, GraphVal> graphs;
     HcRowMod *d_rowmods = nullptr;                          // per modulus: both twiddle tables + q, mu (multi-modulus batched transforms)
     u64 *ws_mm = nullptr; size_t ws_mm_rows = 0;            // scratch of the batched key switch / rescale
     struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr; };
@@ -267,6 +274,9 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     if (c->ws_tmp) hipFree(c->ws_tmp);
     if (c->d_mods) hipFree(c->d_mods);
     if (c->d_rowmods) hipFree(c->d_rowmods);
+#ifndef HC_EMU
+    for (auto &kv : c->graphs) if (kv.second.exec) hipGraphExecDestroy((hipGraphExec_t)kv.second.exec);
+#endif
     if (c->ws_mm) hipFree(c->ws_mm);
     for (auto &kv : c->ks_plan) { hipFree(kv.second.bx); hipFree(kv.second.bxdown); hipFree(kv.second.pinv); }
     for (auto &kv : c->rescale_plan) hipFree(kv.second);
@@ -992,15 +1002,42 @@ extern "C" int hc_conv_then_pack(hc_ctx *c, const uint64_t *ct_in, double ct_sca
     if (!ct_in || !ker || !ct_out || ker->max_ob < max_ob) return hc_fail(c, HC_ERR_ARG, "hc_conv_then_pack: bad arguments");
     u64 cst[2]; double target;
     HC_TRY(hc_loopA_consts(c, ct_scale, ker_scale, max_ob, norm, out_scale, cst, &target));
-    HC_TRY(hc_prepare_ctc(c, (const u64 *)ct_in, cst));
     const int G = (int)c->lanes;
-    if (G > 1 && norm == 1 && max_ob >= 2 * G) {
-        HC_TRY(hc_conv_lanes(c, ker, max_ob, G, (const u64 *)bias, (u64 *)ct_out));
-    } else {
+    // conv.go:274 multiplies the scale by real_cnum; conv.go:541 then demands out_scale and level 0
+    const double final_scale_chk = target * (double)(max_ob / norm);
+    if (final_scale_chk != out_scale) return hc_fail(c, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
+    auto run_direct = [&]() -> int {
+        HC_TRY(hc_prepare_ctc(c, (const u64 *)ct_in, cst));
         HC_TRY(hc_ensure_cts(c, (size_t)max_ob * 2));
         HC_TRY(hc_loopA_run(c, ker->d, max_ob, norm, c->ws_cts));
         HC_TRY(hc_pack_run(c, c->ws_cts, max_ob, max_ob / norm, (const u64 *)bias));
         HC_HIP(c, hipMemcpyAsync(ct_out, c->ws_cts, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        return HC_OK;
+    };
+    if (G > 1 && norm == 1 && max_ob >= 2 * G) {
+        HC_TRY(hc_prepare_ctc(c, (const u64 *)ct_in, cst));
+        HC_TRY(hc_conv_lanes(c, ker, max_ob, G, (const u64 *)bias, (u64 *)ct_out));
+#ifndef HC_EMU
+    } else if (c->use_graph && !c->profile) {
+        hc_ctx::GraphKey key; memset(&key, 0, sizeof key);
+        key.ct_in = ct_in; key.ker = ker->d; key.bias = bias; key.ct_out = ct_out; key.max_ob = max_ob; key.norm = norm; key.c0 = cst[0]; key.c1 = cst[1]; key.chunk = c->chunk_nodes;
+        hc_ctx::GraphVal &g = c->graphs[key];
+        if (g.exec) { HC_HIP(c, hipGraphLaunch((hipGraphExec_t)g.exec, c->stream)); }
+        else if (g.seen++ == 0) { HC_TRY(run_direct()); }                      // first call: allocates every workspace
+        else {
+            hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+            HC_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = run_direct();
+            const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+            if (rc || e != hipSuccess || !graph) { if (graph) hipGraphDestroy(graph); c->use_graph = 0; if (rc) return rc; HC_TRY(run_direct()); }
+            else {
+                if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { hipGraphDestroy(graph); c->use_graph = 0; HC_TRY(run_direct()); }
+                else { hipGraphDestroy(graph); g.exec = exec; HC_HIP(c, hipGraphLaunch(exec, c->stream)); }
+            }
+        }
+#endif
+    } else {
+        HC_TRY(run_direct());
     }
     // conv.go:274 multiplies the scale by real_cnum; conv.go:541 then demands out_scale and level 0
     const double final_scale = target * (double)(max_ob / norm);
@@ -1015,6 +1052,7 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
     if (!strcmp(name, "lanes")) { if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
+    if (!strcmp(name, "graph")) { c->use_graph = value ? 1 : 0; return HC_OK; }
     return hc_fail(c, HC_ERR_ARG, "unknown option %s", name);
 }
 extern "C" int hc_timer_start(hc_ctx *c) { HC_ENTER(c); HC_HIP(c, hipEventRecord(c->t0, c->stream)); return HC_OK; }
