@@ -75,8 +75,8 @@ def cpu_baseline(B):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--i-batch", type=int, default=3, help="reference batch index (main.go:578): 3 => B=256, W=16 = `conv 3 3`")
     ap.add_argument("--ker-wid", type=int, default=3)
     ap.add_argument("--chunk", type=int, default=64)
@@ -146,6 +146,11 @@ def main():
         if torch.cuda.is_available():
             torch.cuda.synchronize()
 
+    # set-up, not warm-up: every lane's first conv allocates its context's workspaces (hipMalloc); do that outside both the
+    # warm-up count and the timed region so that a run with a small --warmup does not time allocations on the cold lanes
+    for L in lanes:
+        L["ctx"].conv_then_pack_dev(L["in"], 2.0 ** 30, L["ker"], 2.0 ** 30, B, 1, 2.0 ** 30, L["bias"], L["out"])
+    sync_all()
     for _ in range(args.warmup):
         one_step()
     barrier()
