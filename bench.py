@@ -2,9 +2,10 @@
 """bench.py — homomorphic convs/sec of the `conv 3 3` hot path (evalConv_BN: conv_then_pack + bias add,
 eval.go:250-260) on N MI355X GPUs.
 
-A "step" is one homomorphic convolution: one N=2^16 level-1 ciphertext in, B=256 kernel plaintexts, one level-0
-ciphertext out (conv.go:522-546 + eval.go:258), kernel plaintexts pre-encoded and excluded exactly as the reference
-excludes prep_Ker from its "Conv (with BN)" timer (eval.go:244). Inputs are synthetic uniform residues, resident in
+A "step" is one pass of the hot path over one batch of input: one homomorphic convolution on each of the S (--streams,
+default 3) ciphertexts resident on the GPU, each = one N=2^16 level-1 ciphertext in, B=256 kernel plaintexts, one level-0
+ciphertext out (conv.go:522-546 + eval.go:258); `value` counts convolutions (steps x S x GPUs / time). Kernel plaintexts are
+pre-encoded and excluded exactly as the reference excludes prep_Ker from its "Conv (with BN)" timer (eval.go:244). Inputs are synthetic uniform residues, resident in
 HBM before the timed region. Multi-GPU: ciphertexts (images) are independent, so rank r runs its own convolutions
 on GPU r with no data-path collective (weak scaling); torch.distributed only provides the barriers and the
 max-over-ranks reduction of the elapsed time.
@@ -75,8 +76,8 @@ def cpu_baseline(B):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--i-batch", type=int, default=3, help="reference batch index (main.go:578): 3 => B=256, W=16 = `conv 3 3`")
     ap.add_argument("--ker-wid", type=int, default=3)
     ap.add_argument("--chunk", type=int, default=64)
@@ -132,8 +133,9 @@ def main():
     counter = [0]
 
     def one_step():
-        L = lanes[counter[0] % S]; counter[0] += 1
-        L["ctx"].conv_then_pack_dev(L["in"], 2.0 ** 30, L["ker"], 2.0 ** 30, B, 1, 2.0 ** 30, L["bias"], L["out"])
+        """one pass of the hot path over one batch of input = one convolution on each of the S resident ciphertexts"""
+        for L in lanes:
+            L["ctx"].conv_then_pack_dev(L["in"], 2.0 ** 30, L["ker"], 2.0 ** 30, B, 1, 2.0 ** 30, L["bias"], L["out"])
 
     def sync_all():
         for L in lanes:
@@ -194,19 +196,19 @@ def main():
                 "achieved": per_conv / (conv_ms * 1e-3) / 1e12, "frac": t_min_ms / conv_ms, "source": "tools/isa_mix.py (static ISA mix x measured multiply rates)"}
 
     if rank == 0:
-        conv_ms_events = ev_ms / args.steps
+        conv_ms_events = ev_ms / (args.steps * S)
         alg_bytes = algorithmic_mib(B) * 2 ** 20
         achieved = alg_bytes / (conv_ms_events * 1e-3) / 1e9
         out = {
             "metric": "homomorphic convs/sec (conv_then_pack + BN bias, k x k, batch B, N=2^16)",
-            "value": world * args.steps / elapsed, "unit": "conv/s",
+            "value": world * args.steps * S / elapsed, "unit": "conv/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"conv {args.ker_wid} {args.i_batch}", "ker_wid": args.ker_wid, "batch": B, "in_wid": W,
                        "logN": 16, "moduli": "ckks.DefaultBootstrapParams[6] Q0,Q1 + P=0x1fffffffffe00001",
-                       "convs_per_step_per_gpu": 1, "ciphertexts_in_flight_per_gpu": S, "chunk_nodes": args.chunk, "lanes_per_conv": args.lanes, "hipgraph_replay": bool(args.graph)},
+                       "convs_per_step_per_gpu": S, "ciphertexts_in_flight_per_gpu": S, "chunk_nodes": args.chunk, "lanes_per_conv": args.lanes, "hipgraph_replay": bool(args.graph)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic_from_profiles(B, args.chunk),
                          "unit_of_launch": "one conv_then_pack (all of its kernel launches on one stream)",
