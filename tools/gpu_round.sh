@@ -15,5 +15,5 @@ R=$GRAFT_REPO_ROOT
 for pmc in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $R/$O/pmc_$pmc -o run -- python $R/bench.py --steps 3 --warmup 0 --streams 1 --no-cpu-baseline > $R/$O/pmc_$pmc.log 2>&1)
 done
-python tools/pmc_traffic.py $O/pmc_FETCH_SIZE/run_counter_collection.csv $O/pmc_WRITE_SIZE/run_counter_collection.csv 6 $O/traffic_conv_B256.json
+python tools/pmc_traffic.py $O/pmc_FETCH_SIZE/run_counter_collection.csv $O/pmc_WRITE_SIZE/run_counter_collection.csv 7 $O/traffic_conv_B256.json   # convs in that run: 1 set-up + 3 timed + 3 profiled (streams 1)
 find $O/prof -name "*stats*.csv" | head -3
