@@ -112,6 +112,12 @@ int hc_rotate_gal_l0(hc_ctx *ctx, uint64_t galEl, const uint64_t *c0, const uint
  * into every target limb, one accumulation of both key components): about 32 launches at level 27. */
 int hc_swk_load(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *rows_host);
 int hc_keyswitch(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1);
+/* Hoisted form (evaluator.RotateHoisted, conv.go:131; Lattigo's linear transforms): hc_keyswitch_decompose computes the digit
+ * decomposition of cx once and keeps it in the context; each hc_keyswitch_hoisted(key, level, cx, ...) then only does the inner
+ * product with its key and the ModDown. Bit-identical to hc_keyswitch. The decomposition is valid until the next hc_keyswitch /
+ * hc_keyswitch_decompose / hc_div_round_last on this context. */
+int hc_keyswitch_decompose(hc_ctx *ctx, int level, const uint64_t *cx);
+int hc_keyswitch_hoisted(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1);
 
 /* ---- L1: the fused hot path ---- */
 /* pl_ker as prep_Ker leaves it (conv.go:510-515): HOST array [max_ob][2][N], level 1, NTT domain. */

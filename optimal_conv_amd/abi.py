@@ -39,6 +39,8 @@ SYMBOLS = {
     "hc_rotate_gal_l0": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_swk_load": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, u64p]),
     "hc_keyswitch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_keyswitch_decompose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "hc_keyswitch_hoisted": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_lv_ntt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_lv_intt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_lv_mul": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -292,6 +294,20 @@ class Context:
         return out[0], out[1], out[2]
 
     def lv_mod_raise(self, level, row_q0): return self._lv(self.L.hc_lv_mod_raise, level, row_q0)
+
+    def keyswitch_hoisted(self, key_ids, level, cx):
+        """one decomposition of cx, then the inner product + ModDown with every key in key_ids: [(d0, d1), ...]"""
+        cx = np.ascontiguousarray(cx, dtype=np.uint64).reshape(level + 1, self.N)
+        src = self.buf(cx)
+        d = self.buf(nwords=2 * (level + 1) * self.N)
+        self._ck(self.L.hc_keyswitch_decompose(self.h, level, src.ptr))
+        outs = []
+        for kid in key_ids:
+            self._ck(self.L.hc_keyswitch_hoisted(self.h, C.c_uint64(kid), level, src.ptr, d.at(0), d.at((level + 1) * self.N)))
+            o = d.download((2, level + 1, self.N))
+            outs.append((o[0].copy(), o[1].copy()))
+        src.free(); d.free()
+        return outs
 
     def rotate_gal_l0(self, gal, ct):
         src = self.buf(np.ascontiguousarray(ct, dtype=np.uint64).reshape(2, self.N))

@@ -104,6 +104,7 @@ struct hc_ctx {
     struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr; };
     std::map<int, KsPlan> ks_plan;                          // per level: basis-extension constants of every (digit, target limb)
     std::map<int, HcTw *> rescale_plan;                     // per level: qL^-1 mod q_i
+    const void *hoist_cx = nullptr; int hoist_level = -1;   // the polynomial whose digit decomposition ws_mm currently holds
     long chunk_nodes = 64;
     long lanes = 1;               // internal concurrency of ONE conv_then_pack (power of two; 1 = single stream)
     std::vector<HcLane> lane;
@@ -412,7 +413,7 @@ static int hc_ensure_mm(hc_ctx *c, size_t rows) {
     if (c->ws_mm_rows >= rows) return HC_OK;
     HC_HIP(c, hipStreamSynchronize(c->stream));
     if (c->ws_mm) HC_HIP(c, hipFree(c->ws_mm));
-    c->ws_mm = nullptr; c->ws_mm_rows = 0;
+    c->ws_mm = nullptr; c->ws_mm_rows = 0; c->hoist_cx = nullptr;
     HC_HIP(c, hipMalloc((void **)&c->ws_mm, rows * HC_N * sizeof(u64)));
     c->ws_mm_rows = rows;
     return HC_OK;
@@ -527,6 +528,7 @@ extern "C" int hc_div_round_last(hc_ctx *c, int level, const uint64_t *x, uint64
             it = c->rescale_plan.emplace(level, d).first;
         }
         HC_TRY(hc_ensure_mm(c, (size_t)level + 1));
+        c->hoist_cx = nullptr;                                   // the scratch is shared with the key switch's decomposition
         u64 *t = c->ws_mm, *v = c->ws_mm + HC_N;
         HC_TRY(hc_intt(c, level, x + (size_t)level * HC_N, t, 1));
         HC_TRY(hc_launch(c, "rescale_lift_mm", hc_k_rescale_lift_mm, dim3(64, (unsigned)level), (const u64 *)t, v, (const HcMod *)c->d_mods, level));
@@ -854,14 +856,9 @@ extern "C" int hc_swk_load(hc_ctx *c, uint64_t key_id, int level, const uint64_t
     c->swk[key_id] = k;
     return HC_OK;
 }
-extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1) {
-    HC_ENTER(c);
-    auto it = c->swk.find(key_id);
-    if (it == c->swk.end()) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch: no switching key %llu loaded", (unsigned long long)key_id);
-    if (!cx || !d0 || !d1 || level != it->second.level) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch: bad arguments (key loaded for level %d)", it->second.level);
-    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = it->second.beta;
-    const u64 *evk = it->second.rows;
-    // constants of every basis extension of this level, built once: digit d -> target limb T, and {P} -> Q limb l
+// constants of every basis extension of a level, built once: digit d -> target limb T, and {P} -> Q limb l
+static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
     auto pit = c->ks_plan.find(level);
     if (pit == c->ks_plan.end()) {
         std::vector<HcBasisExt> hb((size_t)beta * nt), hd((size_t)nl); std::vector<HcTw> hp((size_t)nl);
@@ -883,17 +880,30 @@ extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_
         HC_HIP(c, hipMemcpy(P.pinv, hp.data(), hp.size() * sizeof(HcTw), hipMemcpyHostToDevice));
         pit = c->ks_plan.emplace(level, P).first;
     }
-    const hc_ctx::KsPlan &P = pit->second;
-    // scratch rows: coef[nl] | c2[nt] | acc[2][nt] | pc[2][alpha] | ext[2][nl]
-    HC_TRY(hc_ensure_mm(c, (size_t)nl + nt + 2 * nt + 2 * alpha + 2 * nl));
-    u64 *coef = c->ws_mm, *c2 = coef + (size_t)nl * HC_N, *acc = c2 + (size_t)nt * HC_N, *pc = acc + (size_t)2 * nt * HC_N, *ext = pc + (size_t)2 * alpha * HC_N;
+    *out = &pit->second;
+    return HC_OK;
+}
+// phase 1 (rlwe.KeySwitcher.DecomposeNTT / ring.Decomposer.DecomposeAndSplit): digits[d][T] = the d-th digit of cx extended to limb
+// T (Q limbs 0..level, then the P limbs), NTT domain; a digit's own limbs are not written (phase 2 reads cx there)
+static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, u64 *coef, u64 *digits) {
+    const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
     HC_TRY(hc_intt_mm(c, cx, coef, nl, nl, 1, 0, 0));                                                    // cxInvNTT, all limbs
     for (int d = 0; d < beta; d++) {
         const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl;
-        // DecomposeAndSplit: the digit's residues extended to every other limb (Q and P), then NTT there
-        HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4), (const u64 *)(coef + (size_t)lo * HC_N), (size_t)HC_N, c2, (const HcBasisExt *)(P.bx + (size_t)d * nt), nt, lo, hi, (size_t)0, (size_t)0));
+        u64 *c2 = digits + (size_t)d * nt * HC_N;
+        HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4), (const u64 *)(coef + (size_t)lo * HC_N), (size_t)HC_N, c2, (const HcBasisExt *)(P->bx + (size_t)d * nt), nt, lo, hi, (size_t)0, (size_t)0));
         HC_TRY(hc_ntt_mm(c, c2, c2, nt, nl, lo, hi, 1, 0, 0));
-        HC_TRY(hc_launch(c, "ks_mac_mm", hc_k_ks_mac_mm, dim3(32, (unsigned)nt, 2), evk + (size_t)d * 2 * nt * HC_N, cx, (const u64 *)c2, acc, (const HcMod *)c->d_mods, nl, c->nq, nt, lo, hi, d == 0 ? 1 : 0));
+    }
+    return HC_OK;
+}
+// phase 2: inner product with the key (both components), then ModDownSplitNTTPQ
+static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const u64 *digits, u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1) {
+    const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = key.beta;
+    for (int d = 0; d < beta; d++) {
+        const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl;
+        HC_TRY(hc_launch(c, "ks_mac_mm", hc_k_ks_mac_mm, dim3(32, (unsigned)nt, 2), (const u64 *)(key.rows + (size_t)d * 2 * nt * HC_N), cx, digits + (size_t)d * nt * HC_N, acc, (const HcMod *)c->d_mods, nl, c->nq, nt, lo, hi, d == 0 ? 1 : 0));
     }
     // ModDownSplitNTTPQ for both components: InvNTT of the P limbs, {P} -> every Q limb, NTT, (acc - ext) * P^-1
     {   HcMm A; A.M = c->d_rowmods; A.nl = 0; A.nq = c->nq; A.skip_lo = A.skip_hi = 0;                  // rows y -> modulus nq + y
@@ -902,9 +912,53 @@ extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_
         A.zs_in = (size_t)nt * HC_N; A.zs_out = zt; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, (const u64 *)(acc + (size_t)nl * HC_N), c->ws_tmp, A));
         A.zs_in = zt; A.zs_out = zt; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, pc, A));
     }
-    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4, 2), (const u64 *)pc, (size_t)HC_N, ext, (const HcBasisExt *)P.bxdown, nl, 0, 0, (size_t)alpha * HC_N, (size_t)nl * HC_N));
+    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4, 2), (const u64 *)pc, (size_t)HC_N, ext, (const HcBasisExt *)P->bxdown, nl, 0, 0, (size_t)alpha * HC_N, (size_t)nl * HC_N));
     HC_TRY(hc_ntt_mm(c, ext, ext, nl, nl, 0, 0, 2, (size_t)nl * HC_N, (size_t)nl * HC_N));
-    return hc_launch(c, "ks_moddown_mm", hc_k_ks_moddown_mm, dim3(32, (unsigned)nl, 2), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)ext, (size_t)nl * HC_N, (u64 *)d0, (u64 *)d1, (const HcMod *)c->d_mods, (const HcTw *)P.pinv);
+    return hc_launch(c, "ks_moddown_mm", hc_k_ks_moddown_mm, dim3(32, (unsigned)nl, 2), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)ext, (size_t)nl * HC_N, d0, d1, (const HcMod *)c->d_mods, (const HcTw *)P->pinv);
+}
+// scratch layout of one key switch at `level`: coef[nl] | digits[beta][nt] | acc[2][nt] | pc[2][alpha] | ext[2][nl]
+struct HcKsScratch { u64 *coef, *digits, *acc, *pc, *ext; };
+static int hc_ks_scratch(hc_ctx *c, int level, HcKsScratch *S) {
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
+    HC_TRY(hc_ensure_mm(c, (size_t)nl + (size_t)beta * nt + 2 * nt + 2 * alpha + 2 * nl));
+    S->coef = c->ws_mm; S->digits = S->coef + (size_t)nl * HC_N; S->acc = S->digits + (size_t)beta * nt * HC_N; S->pc = S->acc + (size_t)2 * nt * HC_N; S->ext = S->pc + (size_t)2 * alpha * HC_N;
+    return HC_OK;
+}
+static int hc_ks_find(hc_ctx *c, const char *fn, uint64_t key_id, int level, const HcSwk **key) {
+    auto it = c->swk.find(key_id);
+    if (it == c->swk.end()) return hc_fail(c, HC_ERR_STATE, "%s: no switching key %llu loaded", fn, (unsigned long long)key_id);
+    if (level != it->second.level) return hc_fail(c, HC_ERR_ARG, "%s: key %llu is loaded for level %d, not %d", fn, (unsigned long long)key_id, it->second.level, level);
+    *key = &it->second;
+    return HC_OK;
+}
+extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1) {
+    HC_ENTER(c);
+    const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch", key_id, level, &key));
+    if (!cx || !d0 || !d1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch: null");
+    HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
+    HC_TRY(hc_ks_decompose_into(c, level, cx, S.coef, S.digits));
+    c->hoist_cx = nullptr;                                   // the scratch no longer holds a hoisted decomposition
+    return hc_ks_apply_from(c, *key, level, cx, S.digits, S.acc, S.pc, S.ext, d0, d1);
+}
+// Hoisted key switching (evaluator.RotateHoisted, conv.go:131; the baby steps of a linear transform): the decomposition of cx is
+// computed once and kept in the context; every hc_keyswitch_hoisted with the same (cx, level) then only does the inner product with
+// ITS key and the ModDown. Results are bit-identical to hc_keyswitch. The decomposition stays valid until the next hc_keyswitch /
+// hc_keyswitch_decompose on this context or until cx is overwritten by the caller.
+extern "C" int hc_keyswitch_decompose(hc_ctx *c, int level, const uint64_t *cx) {
+    HC_ENTER(c);
+    if (!cx || level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_decompose: bad arguments");
+    HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
+    HC_TRY(hc_ks_decompose_into(c, level, cx, S.coef, S.digits));
+    c->hoist_cx = cx; c->hoist_level = level;
+    return HC_OK;
+}
+extern "C" int hc_keyswitch_hoisted(hc_ctx *c, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1) {
+    HC_ENTER(c);
+    const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_hoisted", key_id, level, &key));
+    if (!cx || !d0 || !d1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_hoisted: null");
+    if (c->hoist_cx != cx || c->hoist_level != level) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch_hoisted: no decomposition of this polynomial at level %d is held (call hc_keyswitch_decompose first)", level);
+    HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
+    return hc_ks_apply_from(c, *key, level, cx, S.digits, S.acc, S.pc, S.ext, d0, d1);
 }
 
 // ------------------------------------------------------------------ L1

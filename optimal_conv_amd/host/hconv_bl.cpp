@@ -159,9 +159,21 @@ static std::vector<double> post_process_BL(const std::vector<double> &in_vals, i
 }
 
 // ---------------------------------------------------------------- conv.go:120-178, eval.go:78-134
+// conv.go:120-143: evaluator.RotateHoisted of the input by every kernel offset: one digit decomposition of c1 for all of them
 static std::vector<BLCt> preConv_BL(BLContext *c, const BLCt &ct_in, int in_wid, int ker_wid) {
     std::vector<BLCt> rots; const int st = -(ker_wid / 2), end = ker_wid / 2;
-    for (int i = st; i <= end; i++) for (int j = st; j <= end; j++) rots.push_back(RotateNew(c, ct_in, i * in_wid + j));
+    HCB(c->hc, hc_keyswitch_decompose(c->hc, 1, ct_in.d + (size_t)2 * N));
+    uint64_t *d = bl_rows(c, 4);
+    for (int i = st; i <= end; i++) for (int j = st; j <= end; j++) {
+        const uint64_t gal = gal_for_rotation(i * in_wid + j);
+        BLCt r = bl_alloc(c, ct_in.Scale);
+        if (gal == 1) { HCB(c->hc, hc_copy(c->hc, r.d, ct_in.d, (size_t)4 * N * 8)); rots.push_back(r); continue; }
+        HCB(c->hc, hc_keyswitch_hoisted(c->hc, gal, 1, ct_in.d + (size_t)2 * N, d, d + (size_t)2 * N));
+        for (int l = 0; l < 2; l++) HCB(c->hc, hc_add(c->hc, l, d + (size_t)l * N, ct_in.d + (size_t)l * N, d + (size_t)l * N, 1));
+        HCB(c->hc, hc_permute(c->hc, gal, d, r.d, 4));
+        rots.push_back(r);
+    }
+    HCB(c->hc, hc_free(c->hc, d));
     return rots;
 }
 static BLCt postConv_BL(BLContext *c, const Encoder &enc, const std::vector<BLCt> &ct_in_rots, int in_wid, int ker_wid, int rot, int pad, const Ker4 &max_ker_rs, int max_batch) {

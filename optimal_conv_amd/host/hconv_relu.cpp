@@ -232,6 +232,24 @@ struct Boot {
         return r;
     }
     DCt rotate(const DCt &a, int k) { k = ((k % n) + n) % n; return k == 0 ? a : galois(a, gal_rot(k)); }
+    // evaluator.RotateHoisted: several rotations of ONE ciphertext share the digit decomposition of its c1
+    std::map<int, DCt> rotate_hoisted(const DCt &a, const std::vector<int> &ks) {
+        std::map<int, DCt> out; const int L = a.level; bool decomposed = false;
+        auto d0 = block(), d1 = block();
+        for (int k0 : ks) {
+            const int k = ((k0 % n) + n) % n;
+            if (k == 0) { out[k0] = a; continue; }
+            const uint64_t gal = gal_rot(k), id = key(gal, L);            // key generation (if any) before the decomposition is taken
+            if (!decomposed) { HCR(hc_keyswitch_decompose(hc, L, a.p[1].get())); decomposed = true; }
+            DCt r = new_ct(L, 1, a.scale);
+            HCR(hc_keyswitch_hoisted(hc, id, L, a.p[1].get(), d0.get(), d1.get())); n_keyswitch++;
+            HCR(hc_lv_add(hc, L, d0.get(), a.p[0].get(), d0.get()));
+            HCR(hc_permute(hc, gal, d0.get(), r.p[0].get(), L + 1));
+            HCR(hc_permute(hc, gal, d1.get(), r.p[1].get(), L + 1));
+            out[k0] = r;
+        }
+        return out;
+    }
     DCt conjugate(const DCt &a) { return galois(a, 2ull * N - 1); }
     DCt mod_raise(const DCt &a, int level) {                        // ckks.(*Bootstrapper).modUp
         if (a.level != 0) panic("mod_raise expects a level-0 ciphertext");
@@ -323,8 +341,8 @@ struct Boot {
     }
     DCt linear_transform(const DCt &ct, const LT &lt) {             // sum_k diag_k (.) rot_k(ct); no rescale
         if (ct.level != lt.level) panic("linear_transform: ciphertext level differs from the encoded matrix level");
-        std::map<int, DCt> rots;
-        for (auto &g : lt.giant) for (auto &b : g.second) if (!rots.count(b.first)) rots[b.first] = rotate(ct, b.first);
+        std::vector<int> babies; { std::set<int> seen; for (auto &g : lt.giant) for (auto &b : g.second) if (seen.insert(b.first).second) babies.push_back(b.first); }
+        std::map<int, DCt> rots = rotate_hoisted(ct, babies);          // the baby steps rotate the same ciphertext: one decomposition
         DCt acc; bool have_acc = false;
         for (auto &g : lt.giant) {
             DCt inner; bool have = false;

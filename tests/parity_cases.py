@@ -221,6 +221,30 @@ def case_keyswitch_general(make_ctx, make_oracle, shapes=((1, 2), (0, 1), (2, 2)
         ctx.close()
 
 
+def case_keyswitch_hoisted(make_ctx, make_oracle, level=4, alpha=3, nkeys=3):
+    """hc_keyswitch_decompose + hc_keyswitch_hoisted (evaluator.RotateHoisted): one decomposition, several keys; every result
+    must equal the oracle's (and hence hc_keyswitch's) bit for bit, and a stale decomposition must be refused"""
+    Q, P = Q_MIX[: level + 1], P_CHAIN[:alpha]
+    ctx, O = make_ctx(Q, P), make_oracle(Q, P)
+    beta = (level + 1 + alpha - 1) // alpha
+    cx = np.stack([splitmix_rows(1900 + l, Q[l], N) for l in range(level + 1)])
+    evks = []
+    for kid in range(nkeys):
+        evk = np.empty((beta, 2, level + 1 + alpha, N), dtype=np.uint64)
+        for d in range(beta):
+            for k in range(2):
+                for T in range(level + 1 + alpha):
+                    q = Q[T] if T <= level else P[T - level - 1]
+                    evk[d, k, T] = splitmix_rows(7000 + 1000 * kid + ((d * 2 + k) * 16 + T), q, N)
+        ctx.swk_load(10 + kid, level, evk)
+        evks.append(evk)
+    outs = ctx.keyswitch_hoisted([10 + kid for kid in range(nkeys)], level, cx)
+    for kid in range(nkeys):
+        w0, w1 = O.keyswitch(level, cx, evks[kid])
+        eq(outs[kid][0], w0, f"hoisted d0 key {kid}"); eq(outs[kid][1], w1, f"hoisted d1 key {kid}")
+    ctx.close()
+
+
 # ---------------------------------------------------------------- BL baseline (scope row 8f-2)
 class BLDevice:
     """oracle_bl.BLOracle's interface over the C ABI: the level-1 evaluator operations hconv_bl.cpp composes

@@ -122,3 +122,9 @@ def test_conv_1024_channels_sparse_tile_local_galois(env):
     the 4096-coefficient tile a b5 workgroup holds in LDS but not inside one 256-coefficient row"""
     pc.case_keyswitch(*env, gals=(129, 257))
     pc.case_conv(*env, 1024, norm=16, out_scale=2.0 ** 41)
+
+
+def test_keyswitch_hoisted():
+    """one digit decomposition shared by several key switches (RotateHoisted), bit-identical to the plain key switch"""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    pc.case_keyswitch_hoisted(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), lambda Q, P: Oracle(q=Q, p=P))

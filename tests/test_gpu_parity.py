@@ -300,3 +300,10 @@ def test_leveled_ops_vs_reference_trace_on_gpu():
         assert got == want, f"{e['op']} call {call} level {L}"
     for ctx in ctxs.values():
         ctx.close()
+
+
+def test_keyswitch_hoisted_on_gpu():
+    """hc_keyswitch_decompose + hc_keyswitch_hoisted vs the oracle key switch, several keys on one decomposition"""
+    from optimal_conv_amd import Context
+    pc.case_keyswitch_hoisted(lambda Q, P: Context(Q, P), lambda Q, P: Oracle(q=Q, p=P))
+    pc.case_keyswitch_hoisted(lambda Q, P: Context(Q, P), lambda Q, P: Oracle(q=Q, p=P), level=4, alpha=5, nkeys=2)
