@@ -81,6 +81,9 @@ int hc_permute(hc_ctx *ctx, uint64_t galEl, const uint64_t *in, uint64_t *out, i
 int hc_lv_ntt(hc_ctx *ctx, int level, const uint64_t *in, uint64_t *out);
 int hc_lv_intt(hc_ctx *ctx, int level, const uint64_t *in, uint64_t *out);
 int hc_lv_mul(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
+/* acc += a * b: one term of a linear transform's diagonal sum (MulNew by the encoded diagonal + Add, conv.go:168-171 and the
+ * bootstrapper's matrices) in one pass */
+int hc_lv_mul_acc(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *acc);
 int hc_lv_add(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
 int hc_lv_sub(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
 /* the tensor step of evaluator.mulRelin (conv.go:476; EvaluatePoly): d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1; outputs may not alias inputs */

@@ -44,6 +44,7 @@ SYMBOLS = {
     "hc_lv_ntt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_lv_intt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_lv_mul": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_lv_mul_acc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_lv_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_lv_sub": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_lv_mul_tensor": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 7),
@@ -280,6 +281,13 @@ class Context:
     def lv_intt(self, level, a): return self._lv(self.L.hc_lv_intt, level, a)
     def lv_mul(self, level, a, b): return self._lv(self.L.hc_lv_mul, level, a, b)
     def lv_add(self, level, a, b): return self._lv(self.L.hc_lv_add, level, a, b)
+
+    def lv_mul_acc(self, level, a, b, acc):
+        A, B_, D = self.buf(np.ascontiguousarray(a, dtype=np.uint64)), self.buf(np.ascontiguousarray(b, dtype=np.uint64)), self.buf(np.ascontiguousarray(acc, dtype=np.uint64))
+        self._ck(self.L.hc_lv_mul_acc(self.h, level, A.ptr, B_.ptr, D.ptr))
+        out = D.download((level + 1, self.N))
+        A.free(); B_.free(); D.free()
+        return out
     def lv_sub(self, level, a, b): return self._lv(self.L.hc_lv_sub, level, a, b)
     def lv_mul_const(self, level, a, consts): return self._lv(self.L.hc_lv_mul_const, level, a, consts=consts)
     def lv_add_const(self, level, a, consts): return self._lv(self.L.hc_lv_add_const, level, a, consts=consts)

@@ -298,10 +298,11 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_pointwise(const u64 *a, const u64
 }
 // leveled polynomials (rows 0..level use moduli 0..level): one launch for all limbs, blockIdx.y = limb.
 // HC_PW_MULC multiplies by csts[limb]; HC_PW_ADDC adds csts[limb].w to every coefficient (a constant polynomial in the NTT domain)
-enum { HC_PW_ADDC = 6 };
+enum { HC_PW_ADDC = 6, HC_PW_MAC = 7 };    // MAC: out = out + a * b (the diagonal sums of a linear transform)
+struct HcLvConsts { HcTw c[32]; };      // per-limb constants of one call, passed by value (no host-device copy, no synchronisation)
 template <int OP>
-__global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const u64 *b, u64 *out, const HcMod *mods, const HcTw *csts) {
-    const int l = blockIdx.y; const HcMod m = mods[l];
+__global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const u64 *b, u64 *out, const HcMod *mods, HcLvConsts K) {
+    const int l = blockIdx.y; const HcMod m = mods[l]; const HcTw *csts = K.c;
     const size_t base = (size_t)l * 65536;
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
         const u64 x = a[base + i]; u64 r;
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const 
         else if (OP == HC_PW_ADD) r = hc_addmod(x, b[base + i], m.q);
         else if (OP == HC_PW_SUB) r = hc_submod(x, b[base + i], m.q);
         else if (OP == HC_PW_MULC) r = hc_mul_shoup(x, csts[l].w, csts[l].ws, m.q);
+        else if (OP == HC_PW_MAC) r = hc_addmod(out[base + i], hc_mont(x, hc_mont(b[base + i], m.r2, m.q, m.qinv), m.q, m.qinv), m.q);
         else r = hc_addmod(x, csts[l].w, m.q);
         out[base + i] = r;
     }

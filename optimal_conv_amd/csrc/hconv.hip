@@ -377,17 +377,17 @@ static dim3 hc_lv_grid(int level) { return dim3(64, (unsigned)(level + 1)); }
 template <int OP>
 static int hc_lv_pw(hc_ctx *c, const char *fn, int level, const uint64_t *a, const uint64_t *b, uint64_t *out, const uint64_t *consts_host) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, fn, level, a, out));
-    if ((OP == HC_PW_MUL || OP == HC_PW_ADD || OP == HC_PW_SUB) && !b) return hc_fail(c, HC_ERR_ARG, "%s: null", fn);
+    if ((OP == HC_PW_MUL || OP == HC_PW_ADD || OP == HC_PW_SUB || OP == HC_PW_MAC) && !b) return hc_fail(c, HC_ERR_ARG, "%s: null", fn);
+    HcLvConsts K; memset(&K, 0, sizeof K);
     if (OP == HC_PW_MULC || OP == HC_PW_ADDC) {
         if (!consts_host) return hc_fail(c, HC_ERR_ARG, "%s: null constants", fn);
-        std::vector<HcTw> h((size_t)level + 1);
-        for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; h[(size_t)l] = h_pair(consts_host[l] % q, q); }
-        HC_HIP(c, hipMemcpyAsync(c->d_csts, h.data(), h.size() * sizeof(HcTw), hipMemcpyHostToDevice, c->stream));
-        HC_HIP(c, hipStreamSynchronize(c->stream));      // h goes out of scope; the copy is tiny
+        if (level >= 32) return hc_fail(c, HC_ERR_UNSUPPORTED, "%s: more than 32 limbs", fn);
+        for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[l] = h_pair(consts_host[l] % q, q); }
     }
-    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, hc_lv_grid(level), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, (const HcTw *)c->d_csts);
+    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, hc_lv_grid(level), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, K);
 }
 extern "C" int hc_lv_mul(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_MUL>(c, "hc_lv_mul", level, a, b, out, nullptr); }
+extern "C" int hc_lv_mul_acc(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *acc) { return hc_lv_pw<HC_PW_MAC>(c, "hc_lv_mul_acc", level, a, b, acc, nullptr); }
 extern "C" int hc_lv_add(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_ADD>(c, "hc_lv_add", level, a, b, out, nullptr); }
 extern "C" int hc_lv_sub(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_SUB>(c, "hc_lv_sub", level, a, b, out, nullptr); }
 extern "C" int hc_lv_mul_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_MULC>(c, "hc_lv_mul_const", level, a, nullptr, out, consts); }

@@ -346,7 +346,11 @@ struct Boot {
         DCt acc; bool have_acc = false;
         for (auto &g : lt.giant) {
             DCt inner; bool have = false;
-            for (auto &b : g.second) { DCt term = mul_plain(rots[b.first], b.second); inner = have ? add(inner, term) : term; have = true; }
+            for (auto &b : g.second) {
+                const DCt &r = rots[b.first];
+                if (!have) { inner = mul_plain(r, b.second); have = true; }
+                else for (int d = 0; d <= r.deg; d++) HCR(hc_lv_mul_acc(hc, r.level, r.p[d].get(), b.second.p.get(), inner.p[d].get()));   // same plaintext scale: the sum stays at inner.scale
+            }
             inner = rotate(inner, g.first);
             acc = have_acc ? add(acc, inner) : inner; have_acc = true;
         }

@@ -352,6 +352,9 @@ def case_ckks_ops(make_ctx, logN=16, seed=3, levels=((23, 2.0 ** 55), (9, 2.0 **
             assert got.scale == want.scale
     ct0 = Co.encrypt_coeffs(rng.uniform(-10, 10, Co.N), 0, 2.0 ** 43, seed=8)
     eq(Cd.mod_raise(ct0, 27).rows, Co.mod_raise(ct0, 27).rows, "mod_raise")
+    L = levels[0][0]                                     # acc += a*b in one pass == mul then add
+    x, y, z = (Co.encrypt_slots(a, L, 2.0 ** 30, seed=s_).rows[0] for s_ in (31, 32, 33))
+    eq(ctx.lv_mul_acc(L, x, y, z), Co.be.lv_add(z, Co.be.lv_mul(x, y)), "lv_mul_acc")
     ctx.close()
 
 
