@@ -810,11 +810,16 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown(const u64 *acc, const 
 // Rows in [skip_lo, skip_hi) are left untouched (a digit's own limbs during decomposition). Forward transforms use the
 // HC_FM_ALT folding, which every accepted modulus admits; outputs are canonical, so results equal the per-limb kernels'.
 struct HcRowMod { HcTwTab fwd, inv; u64 q, mu; };
-struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; };
+struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; int z_alpha; };
+// z_alpha > 0: operand z is digit z of a key switch and its own limbs [z*z_alpha, min((z+1)*z_alpha, nl)) are the rows to skip
+__device__ __forceinline__ bool hc_mm_skip(const HcMm &A, int y) {
+    if (A.z_alpha > 0) { const int lo = (int)blockIdx.z * A.z_alpha, hi = lo + A.z_alpha < A.nl ? lo + A.z_alpha : A.nl; return y >= lo && y < hi; }
+    return y >= A.skip_lo && y < A.skip_hi;
+}
 __device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl ? y : A.nq + (y - A.nl); }
 __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_COLS_LDS];
-    const int y = blockIdx.y; if (y >= A.skip_lo && y < A.skip_hi) return;
+    const int y = blockIdx.y; if (hc_mm_skip(A, y)) return;
     const HcRowMod &R = A.M[hc_mm_mod(A, y)];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
@@ -828,7 +833,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd_mm(const u64 *in, u64 *o
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_ROWS_LDS];
-    const int y = blockIdx.y; if (y >= A.skip_lo && y < A.skip_hi) return;
+    const int y = blockIdx.y; if (hc_mm_skip(A, y)) return;
     const HcRowMod &R = A.M[hc_mm_mod(A, y)];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
     const size_t pbase = (size_t)y * 65536;
@@ -844,7 +849,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, 
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_ROWS_LDS];
-    const int y = blockIdx.y; if (y >= A.skip_lo && y < A.skip_hi) return;
+    const int y = blockIdx.y; if (hc_mm_skip(A, y)) return;
     const HcRowMod &R = A.M[hc_mm_mod(A, y)];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
     const size_t pbase = (size_t)y * 65536;
@@ -860,7 +865,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *o
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_cols_inv_canon_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_COLS_LDS];
-    const int y = blockIdx.y; if (y >= A.skip_lo && y < A.skip_hi) return;
+    const int y = blockIdx.y; if (hc_mm_skip(A, y)) return;
     const HcRowMod &R = A.M[hc_mm_mod(A, y)];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
@@ -875,8 +880,10 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_inv_canon_mm(const u64 *in, 
 // fast basis extension into every target row of the batch: Bs[T] holds the constants for target row T (the source-side
 // constants s, inv, mu_s are the same in all of them). One thread owns a coefficient: y_i and the fp64 overflow count v are
 // computed once, then reused for the targets T = blockIdx.y, blockIdx.y + gridDim.y, ... (rows in [skip_lo, skip_hi) excepted).
-__global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend_mm(const u64 *src, size_t src_stride, u64 *dst, const HcBasisExt *Bs, int rows, int skip_lo, int skip_hi, size_t zs_src, size_t zs_dst) {
+// z_alpha > 0: operand z is digit z (constants Bs + z*rows, own limbs [z*z_alpha, ..) skipped, nl = number of Q limbs)
+__global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend_mm(const u64 *src, size_t src_stride, u64 *dst, const HcBasisExt *Bs, int rows, int skip_lo, int skip_hi, size_t zs_src, size_t zs_dst, int z_alpha, int nl) {
     src += (size_t)blockIdx.z * zs_src; dst += (size_t)blockIdx.z * zs_dst;
+    if (z_alpha > 0) { Bs += (size_t)blockIdx.z * rows; skip_lo = (int)blockIdx.z * z_alpha; skip_hi = skip_lo + z_alpha < nl ? skip_lo + z_alpha : nl; }
     const HcBasisExt &B0 = Bs[0];
     const int n = B0.n;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
@@ -913,6 +920,22 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_mm(const u64 *evk, const u
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
         const u64 p = hc_mont(x[j], e[j], m.q, m.qinv);
         a[j] = first ? p : hc_addmod(a[j], p, m.q);
+    }
+}
+// the whole inner product in one launch: acc[k][T] = sum_d evk[d][k][T] (*)_mont c2_d[T], digits laid out [beta][nt][N]
+__global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const u64 *cx, const u64 *digits, u64 *acc, const HcMod *mods, int nl, int nq, int nt, int alpha, int beta) {
+    const int T = blockIdx.y, k = blockIdx.z;
+    const HcMod m = mods[T < nl ? T : nq + (T - nl)];
+    u64 *a = acc + ((size_t)k * nt + T) * 65536;
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        u64 s = 0;
+        for (int d = 0; d < beta; d++) {
+            const int lo = d * alpha, hi = lo + alpha < nl ? lo + alpha : nl;
+            const u64 x = (T >= lo && T < hi) ? cx[(size_t)T * 65536 + j] : digits[((size_t)d * nt + T) * 65536 + j];
+            const u64 p = hc_mont(x, evk[(((size_t)d * 2 + k) * nt + T) * 65536 + j], m.q, m.qinv);
+            s = d == 0 ? p : hc_addmod(s, p, m.q);
+        }
+        a[j] = s;
     }
 }
 // d_k[l] = (acc[k][l] - ext[k][l]) * P^-1 mod q_l for all limbs l and both k

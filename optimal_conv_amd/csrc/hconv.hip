@@ -393,9 +393,9 @@ extern "C" int hc_lv_sub(hc_ctx *c, int level, const uint64_t *a, const uint64_t
 extern "C" int hc_lv_mul_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_MULC>(c, "hc_lv_mul_const", level, a, nullptr, out, consts); }
 extern "C" int hc_lv_add_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_ADDC>(c, "hc_lv_add_const", level, a, nullptr, out, consts); }
 // batched transforms over rows of different moduli (row y <-> modulus y < nl ? y : nq + y - nl); z operands zs words apart
-static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out) {
+static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z));
-    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi;
+    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = z_alpha;
     const dim3 grid(16, (unsigned)rows, (unsigned)z); const size_t zt = (size_t)rows * HC_N;
     A.zs_in = zs_in; A.zs_out = zt; HC_TRY(hc_launch(c, "cols_fwd_mm", hc_k_cols_fwd_mm, grid, in, c->ws_tmp, A));
     A.zs_in = zt; A.zs_out = zs_out; HC_TRY(hc_launch(c, "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
@@ -403,7 +403,7 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
 }
 static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z));
-    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = A.skip_hi = 0;
+    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = A.skip_hi = 0; A.z_alpha = 0;
     const dim3 grid(16, (unsigned)rows, (unsigned)z); const size_t zt = (size_t)rows * HC_N;
     A.zs_in = zs_in; A.zs_out = zt; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, in, c->ws_tmp, A));
     A.zs_in = zt; A.zs_out = zs_out; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
@@ -889,30 +889,23 @@ static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, u64 *coef, 
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
     HC_TRY(hc_intt_mm(c, cx, coef, nl, nl, 1, 0, 0));                                                    // cxInvNTT, all limbs
-    for (int d = 0; d < beta; d++) {
-        const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl;
-        u64 *c2 = digits + (size_t)d * nt * HC_N;
-        HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4), (const u64 *)(coef + (size_t)lo * HC_N), (size_t)HC_N, c2, (const HcBasisExt *)(P->bx + (size_t)d * nt), nt, lo, hi, (size_t)0, (size_t)0));
-        HC_TRY(hc_ntt_mm(c, c2, c2, nt, nl, lo, hi, 1, 0, 0));
-    }
-    return HC_OK;
+    // every digit at once (blockIdx.z = digit): extension of the digit's residues to all other limbs, then their transforms
+    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(128, 4, (unsigned)beta), (const u64 *)coef, (size_t)HC_N, digits, (const HcBasisExt *)P->bx, nt, 0, 0, (size_t)alpha * HC_N, (size_t)nt * HC_N, alpha, nl));
+    return hc_ntt_mm(c, digits, digits, nt, nl, 0, 0, beta, (size_t)nt * HC_N, (size_t)nt * HC_N, alpha);
 }
 // phase 2: inner product with the key (both components), then ModDownSplitNTTPQ
 static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const u64 *digits, u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = key.beta;
-    for (int d = 0; d < beta; d++) {
-        const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl;
-        HC_TRY(hc_launch(c, "ks_mac_mm", hc_k_ks_mac_mm, dim3(32, (unsigned)nt, 2), (const u64 *)(key.rows + (size_t)d * 2 * nt * HC_N), cx, digits + (size_t)d * nt * HC_N, acc, (const HcMod *)c->d_mods, nl, c->nq, nt, lo, hi, d == 0 ? 1 : 0));
-    }
+    HC_TRY(hc_launch(c, "ks_mac_all", hc_k_ks_mac_all, dim3(32, (unsigned)nt, 2), (const u64 *)key.rows, cx, digits, acc, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta));
     // ModDownSplitNTTPQ for both components: InvNTT of the P limbs, {P} -> every Q limb, NTT, (acc - ext) * P^-1
-    {   HcMm A; A.M = c->d_rowmods; A.nl = 0; A.nq = c->nq; A.skip_lo = A.skip_hi = 0;                  // rows y -> modulus nq + y
+    {   HcMm A; A.M = c->d_rowmods; A.nl = 0; A.nq = c->nq; A.skip_lo = A.skip_hi = 0; A.z_alpha = 0;  // rows y -> modulus nq + y
         HC_TRY(hc_ensure_tmp(c, (size_t)2 * alpha));
         const dim3 grid(16, (unsigned)alpha, 2); const size_t zt = (size_t)alpha * HC_N;
         A.zs_in = (size_t)nt * HC_N; A.zs_out = zt; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, (const u64 *)(acc + (size_t)nl * HC_N), c->ws_tmp, A));
         A.zs_in = zt; A.zs_out = zt; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, pc, A));
     }
-    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4, 2), (const u64 *)pc, (size_t)HC_N, ext, (const HcBasisExt *)P->bxdown, nl, 0, 0, (size_t)alpha * HC_N, (size_t)nl * HC_N));
+    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4, 2), (const u64 *)pc, (size_t)HC_N, ext, (const HcBasisExt *)P->bxdown, nl, 0, 0, (size_t)alpha * HC_N, (size_t)nl * HC_N, 0, nl));
     HC_TRY(hc_ntt_mm(c, ext, ext, nl, nl, 0, 0, 2, (size_t)nl * HC_N, (size_t)nl * HC_N));
     return hc_launch(c, "ks_moddown_mm", hc_k_ks_moddown_mm, dim3(32, (unsigned)nl, 2), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)ext, (size_t)nl * HC_N, d0, d1, (const HcMod *)c->d_mods, (const HcTw *)P->pinv);
 }
