@@ -748,8 +748,7 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, c
 
 // ================================================================ general hybrid key switch (any level, alpha P primes)
 // Building blocks for rlwe.KeySwitcher.SwitchKeysInPlace beyond the conv path's level-0 case (BL baseline: level 1 with
-// two special primes; bootstrapping: alpha = 5, several digits). Composed from the standalone transforms above plus
-// three pointwise kernels; correctness-first (one launch per limb), not fused.
+// two special primes; bootstrapping: alpha = 5, several digits); the kernels are in the multi-modulus section below.
 //
 // Exact fast basis extension (ring.reconstructRNS + ring.multSum): n <= 8 source limbs (coefficient domain, any
 // representatives) -> one target modulus t:
@@ -764,45 +763,9 @@ struct HcBasisExt {
     u64 t, mu_t;       // target modulus, floor(2^64/t)
     u64 mu_s[8];       // floor(2^64/s_i)
 };
-__global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend(const u64 *src, size_t src_stride, u64 *dst, HcBasisExt B) {
-    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        if (B.n == 1) { dst[j] = hc_barrett64(hc_barrett64(src[j], B.s[0], B.mu_s[0]), B.t, B.mu_t); continue; }
-        double vi = 0.0; u64 acc = 0;
-        for (int i = 0; i < B.n; i++) {
-            const u64 x = hc_barrett64(src[(size_t)i * src_stride + j], B.s[i], B.mu_s[i]);
-            const u64 y = hc_mul_shoup(x, B.inv[i].w, B.inv[i].ws, B.s[i]);
-            vi += (double)y / (double)B.s[i];
-            acc = hc_addmod(acc, hc_mul_shoup(hc_barrett64(y, B.t, B.mu_t), B.hat[i].w, B.hat[i].ws, B.t), B.t);
-        }
-        const u64 v = (u64)vi;
-        dst[j] = hc_submod(acc, hc_mul_shoup(hc_barrett64(v, B.t, B.mu_t), B.smodt.w, B.smodt.ws, B.t), B.t);
-    }
-}
 // ring.DivRoundByLastModulusNTT, general level (the fused level-1 form is loop A's a2/a3): t = InvNTT_{qL}(x_L) (canonical);
 // lift:   v = ((t + h mod qL) + (q_i - h mod q_i)) mod q_i   with h = (qL-1)/2  -- the centred remainder, to be transformed mod q_i
-// finish: out_i = (x_i - NTT_{q_i}(v)) * qL^-1 mod q_i
-__global__ __launch_bounds__(HC_TPB) void hc_k_rescale_lift(const u64 *t, u64 *v, u64 qL, u64 h, u64 qi, u64 mu_i, u64 neg_h) {
-    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        const u64 s = hc_csub(t[j] + h, qL);
-        v[j] = hc_barrett64(s + neg_h, qi, mu_i);
-    }
-}
-__global__ __launch_bounds__(HC_TPB) void hc_k_rescale_finish(const u64 *x, const u64 *u, u64 *out, u64 q, HcTw qlinv) {
-    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
-        out[j] = hc_mul_shoup(hc_submod(x[j], u[j], q), qlinv.w, qlinv.ws, q);
-}
-// acc = (first ? 0 : acc) + evk (*)_mont c2   (evk in Lattigo's stored Montgomery form => plain product), canonical
-__global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac(const u64 *evk, const u64 *c2, u64 *acc, HcMod m, int first) {
-    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        const u64 p = hc_mont(c2[j], evk[j], m.q, m.qinv);
-        acc[j] = first ? p : hc_addmod(acc[j], p, m.q);
-    }
-}
-// ModDown tail: out = (acc - ext) * P^-1 mod q
-__global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown(const u64 *acc, const u64 *ext, u64 *out, u64 q, HcTw pinv) {
-    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
-        out[j] = hc_mul_shoup(hc_submod(acc[j], ext[j], q), pinv.w, pinv.ws, q);
-}
+// finish: out_i = (x_i - NTT_{q_i}(v)) * qL^-1 mod q_i                                   (hc_k_rescale_{lift,finish}_mm below)
 
 // ================================================================ multi-modulus batches (leveled evaluator, general key switch)
 // One launch covers rows of DIFFERENT moduli: row y of the batch uses modulus index hc_mm_mod(y) = y < nl ? y : nq + (y - nl)
@@ -912,16 +875,6 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend_mm(const u64 *src, s
 }
 // acc[k][T] (+)= evk[k][T] (*)_mont c2[T] for all limbs T and both key components k (blockIdx.z); a digit's own limbs
 // [lo,hi) read the NTT-domain input cx instead of the extended c2
-__global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_mm(const u64 *evk, const u64 *cx, const u64 *c2, u64 *acc, const HcMod *mods, int nl, int nq, int nt, int lo, int hi, int first) {
-    const int T = blockIdx.y, k = blockIdx.z;
-    const HcMod m = mods[T < nl ? T : nq + (T - nl)];
-    const u64 *e = evk + ((size_t)k * nt + T) * 65536, *x = (T >= lo && T < hi) ? cx + (size_t)T * 65536 : c2 + (size_t)T * 65536;
-    u64 *a = acc + ((size_t)k * nt + T) * 65536;
-    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        const u64 p = hc_mont(x[j], e[j], m.q, m.qinv);
-        a[j] = first ? p : hc_addmod(a[j], p, m.q);
-    }
-}
 // the whole inner product in one launch: acc[k][T] = sum_d evk[d][k][T] (*)_mont c2_d[T], digits laid out [beta][nt][N]
 __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const u64 *cx, const u64 *digits, u64 *acc, const HcMod *mods, int nl, int nq, int nt, int alpha, int beta) {
     const int T = blockIdx.y, k = blockIdx.z;
