@@ -175,7 +175,9 @@ __device__ __forceinline__ void hc_cols_fwd(u64 (&e)[16], u64 *lds, const HcTwTa
     for (int lo = 0; lo < 16; lo++) e[lo] = lds[hc_cols_lds(tid * 16 + lo, c)];
     hc_ct_round<FM>(e, HcRowsTwB{T.colsB + tid}, q);
 }
-// inverse cols pass incl. N^-1: in e[lo] = (tid*16+lo, c) [lazy < 2q]; out e[hi] = (hi*16+tid, c) [lazy < 2q]
+// inverse cols pass incl. N^-1 (SCALE = false: without it, for callers that folded N^-1 into a fixed multiplicand upstream):
+// in e[lo] = (tid*16+lo, c) [lazy < 2q]; out e[hi] = (hi*16+tid, c) [lazy < 2q]
+template <bool SCALE = true>
 __device__ __forceinline__ void hc_cols_inv(u64 (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, u64 q) {
     hc_gs_round<false>(e, HcRowsTwB{T.colsB + tid}, q, T.ninv, T.ninv);
 #pragma unroll
@@ -183,7 +185,7 @@ __device__ __forceinline__ void hc_cols_inv(u64 (&e)[16], u64 *lds, const HcTwTa
     __syncthreads();
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = lds[hc_cols_lds(hi * 16 + tid, c)];
-    hc_gs_round<true>(e, HcRowsTwA{T.colsA}, q, T.ninv, T.w_last_ninv);
+    hc_gs_round<SCALE>(e, HcRowsTwA{T.colsA}, q, T.ninv, T.w_last_ninv);
 }
 
 // fp64 forms of the two inverse passes (same data movement; LDS carries the doubles' bit patterns)
@@ -561,11 +563,12 @@ struct HcLoopB {
     u64 *dst;            // [max_cnum][2][N] where it writes node results (slot i); src != dst: the two ping-pong
     u64 *tmpC;           // [chunk][N]      c1 of t2 through iNTT_Q0 / NTT_P
     u64 *tmpE;           // [chunk][2][N]   P-part accumulators through iNTT_P / NTT_Q0
+    u64 *tmpT;           // [chunk][N]      t2.c1 itself (canonical, natural order): b1 -> b5
     // fixed multiplicands are kept in Montgomery form (w * 2^64 mod q), 8 bytes each: one hc_mont per use gives the
     // canonical product for ANY 64-bit other operand. (Lattigo stores switching keys exactly like this.)
     const u64 *idx;      // [N]             idx[s] plaintext, natural order
-    const u64 *evkQ;     // [2][N]          b_Q, a_Q natural order
-    const HcTw *evkP;    // [2][N]          b_P, a_P as Shoup pairs in lo-local-coalesced order (hc_k_b3 multiplies
+    const u64 *evkQ;     // [2][N]          b_Q * P^-1, a_Q * P^-1 mod Q0 (Montgomery form), natural order
+    const HcTw *evkP;    // [2][N]          b_P * N^-1, a_P * N^-1 mod P as Shoup pairs in lo-local-coalesced order (hc_k_b3 multiplies
                          //                 lazy transform outputs inside a register-tight kernel: measured faster than
                          //                 the Montgomery form there)
     int n0, step, norm;  // first node of this chunk
@@ -576,9 +579,8 @@ struct HcLoopB {
     u64 vthresh;         // smallest y with uint64(float64(y)/float64(P)) >= 1 (P if none): the fp64 overflow count as a compare
     u32 gal;             // Galois element of this level
 };
-// KB1: t2.c1 = y1 - I*x1 and its rows-inverse (mod Q0). grid = (16, nodes). Everything else a node needs from x and y
-// (t1, t2.c0, the Q-part of the key switch) is formed in KB5 straight from src, so nothing but the 1-row key-switch
-// operand leaves this kernel.
+// KB1: t2.c1 = y1 - I*x1 (kept in tmpT for KB5) and its rows-inverse (mod Q0). grid = (16, nodes). Everything else a node needs
+// from x and y (t1, t2.c0, the Q-part of the key switch) is formed in KB5 from src and tmpT.
 __global__ __launch_bounds__(HC_TPB) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
@@ -595,6 +597,9 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
     for (int kk = 0; kk < 16; kk++) I[kk] = idx[kk * 256];
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) e[kk] = hc_submod(yy[kk], hc_mont(e[kk], I[kk], q, qinv), q);   // t2.c1 (conv.go:288-289)
+    u64 *__restrict__ tt = B.tmpT + (size_t)node * 65536 + tile;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) tt[kk * 256] = e[kk];
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     __syncthreads();
     hc_rows_inv(e, lds, T0inv, row, rloc, tid, q);
@@ -657,14 +662,16 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTw
     u64 e[16];
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = base[(size_t)(tid * 16 + lo) * 256];
-    hc_cols_inv(e, lds, TPinv, c, tid, P);
+    hc_cols_inv<false>(e, lds, TPinv, c, tid, P);                 // N^-1 mod P is inside the key rows (hc_evk_load)
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) {
         const u64 yv = hc_csub(e[hi], P);                        // [d]_P in [0,P)
         // ring.reconstructRNS: v = uint64(float64(y)/float64(P)) (0 or 1 for one P prime). y -> v is monotone, so
         // the host finds the switch point with the very same fp64 expression and the kernel only compares.
-        u64 r = hc_barrett64(yv, q, B.mu0);
-        if (yv >= B.vthresh) r = hc_submod(r, B.pmodq.w, q);
+        // The extension is carried pre-divided by P (the division ModDown ends with): ext * P^-1 = y * P^-1 - v mod Q0. One Shoup
+        // product of the 64-bit y replaces the Barrett reduction here and removes the P^-1 product from b5 (same canonical residues).
+        u64 r = hc_mul_shoup(yv, B.pinv.w, B.pinv.ws, q);
+        if (yv >= B.vthresh) r = hc_submod(r, 1, q);
         e[hi] = r;
     }
     __syncthreads();
@@ -673,10 +680,10 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTw
     for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
 }
 // KB5: one job per (node, polynomial k): grid = (16, 2*nodes), job = node*2 + k.
-//   front end (linear layout, straight from src):  m_k = I*x_k ; t1_k = y_k + m_k ; t2.c_k = y_k - m_k ;
-//        F_1 = a_Q * t2.c1                      (k = 1)
-//        F_0 = t2.c0 * P + b_Q * t2.c1          (k = 0; also needs x_1, y_1)
-//   rows-forward mod Q0 of the k-th extension n_k ; d_k = (F_k - n_k) * P^-1 = [k==0] t2.c0 + (key switch)_k ;
+//   front end (linear layout, from src and b1's t2.c1):  m_k = I*x_k ; t1_k = y_k + m_k ; t2.c_k = y_k - m_k  (k = 1: m_1 = y_1 - t2.c1)
+//        F_1 = (a_Q / P) * t2.c1                (k = 1)      (hc_evk_load stores the Q rows of the key times P^-1 mod Q0)
+//        F_0 = t2.c0 + (b_Q / P) * t2.c1        (k = 0)
+//   rows-forward mod Q0 of the k-th extension (b4 hands it over divided by P) n_k ; d_k = F_k - n_k = [k==0] t2.c0 + (key switch)_k ;
 //   tile-local Galois permutation through LDS ; dst[i][k] = t1_k + perm(d_k) (+ bias on k = 0 of the last node).
 // Requires the permutation to stay inside the workgroup's 16-row tile (4096 consecutive coefficients): galEl = 2^j+1, j >= 5
 // (j >= 9 even stays inside one 256-coefficient row; j = 7, 8 are what the resnet's 8x8 layers, max_cnum 1024, add).
@@ -690,10 +697,9 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, c
     const u64 *__restrict__ in = B.tmpE + (size_t)job * 65536 + (size_t)row * 256;
     const u64 *__restrict__ yk = B.src + ((size_t)i * 2 + k) * 65536 + tile;
     const u64 *__restrict__ xk = B.src + ((size_t)(i + B.step) * 2 + k) * 65536 + tile;
-    const u64 *__restrict__ y1 = B.src + ((size_t)i * 2 + 1) * 65536 + tile;
-    const u64 *__restrict__ x1 = B.src + ((size_t)(i + B.step) * 2 + 1) * 65536 + tile;
+    const u64 *__restrict__ tc1 = B.tmpT + (size_t)node * 65536 + tile;    // t2.c1 = y1 - I*x1 from b1
     const u64 *__restrict__ idx = B.idx + tile;
-    const u64 *__restrict__ evk = B.evkQ + (size_t)k * 65536 + tile;      // b_Q for k = 0, a_Q for k = 1
+    const u64 *__restrict__ evk = B.evkQ + (size_t)k * 65536 + tile;      // b_Q/P for k = 0, a_Q/P for k = 1
     const u64 qinv = B.m0.qinv;
     u64 *__restrict__ o = B.dst + ((size_t)i * 2 + k) * 65536 + tile;
     u64 e[16], f[16], t1[16];
@@ -701,24 +707,24 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, c
     for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
 #pragma unroll
     for (int b = 0; b < 4; b++) {               // batches of 4 residues: all loads of a batch before its arithmetic
-        u64 X[4], Y[4], X1[4], Y1[4], I[4], K[4];
+        u64 X[4], Y[4], I[4], K[4], T[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int off = (b * 4 + j) * 256;
-            X[j] = xk[off]; Y[j] = yk[off]; I[j] = idx[off]; K[j] = evk[off];
-            if (k == 0) { X1[j] = x1[off]; Y1[j] = y1[off]; }
+            Y[j] = yk[off]; K[j] = evk[off]; T[j] = tc1[off];
+            if (k == 0) { X[j] = xk[off]; I[j] = idx[off]; }
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int kk = b * 4 + j;
-            const u64 m = hc_mont(X[j], I[j], q, qinv);
-            const u64 t2 = hc_submod(Y[j], m, q);
-            t1[kk] = hc_addmod(Y[j], m, q);                                                   // conv.go:290
+            const u64 g = hc_mont(T[j], K[j], q, qinv);                                           // (key row / P) * t2.c1
             if (k == 0) {
-                const u64 t2c1 = hc_submod(Y1[j], hc_mont(X1[j], I[j], q, qinv), q);
-                f[kk] = hc_addmod(hc_mul_shoup(t2, B.pmodq.w, B.pmodq.ws, q), hc_mont(t2c1, K[j], q, qinv), q);
+                const u64 m = hc_mont(X[j], I[j], q, qinv);
+                t1[kk] = hc_addmod(Y[j], m, q);                                                   // conv.go:290
+                f[kk] = hc_addmod(hc_submod(Y[j], m, q), g, q);                                   // t2.c0 + ...
             } else {
-                f[kk] = hc_mont(t2, K[j], q, qinv);
+                t1[kk] = hc_addmod(Y[j], hc_submod(Y[j], T[j], q), q);                            // y1 + I*x1 with I*x1 = y1 - t2.c1
+                f[kk] = g;
             }
         }
     }
@@ -732,7 +738,7 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, c
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
         u64 n = hc_fwd_canon<FM>(e[kk], q, B.m0.mu);
-        e[kk] = hc_mul_shoup(hc_submod(f[kk], n, q), B.pinv.w, B.pinv.ws, q);
+        e[kk] = hc_submod(f[kk], n, q);                                                          // n = NTT(ext * P^-1), F already / P
     }
     __syncthreads();
 #pragma unroll

@@ -566,7 +566,7 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
     if (!b_q || !a_q || !b_p || !a_p || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_evk_load: bad arguments");
     if (c->np != 1) return hc_fail(c, HC_ERR_UNSUPPORTED, "hc_evk_load: level-0 key switching with one special prime (the pack evaluator of main.go:446-456) is what is implemented; np=%d", c->np);
     const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
-    // Lattigo's stored form IS the Montgomery form the kernels multiply with: the Q rows are kept as they come,
+    // Lattigo's stored form IS the Montgomery form the kernels multiply with: the Q rows are taken as they come (times P^-1, below),
     // the P rows are only re-ordered into the lo-local coalesced order hc_k_b3 reads.
     u64 *stage = nullptr; HC_HIP(c, hipMalloc((void **)&stage, 2 * HC_N * sizeof(u64)));
     HcEvk e; e.q_rows = nullptr; e.p_rows = nullptr; e.row_local = hc_perm_row_local(galEl);
@@ -576,12 +576,16 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
     HC_HIP(c, hipMemcpyAsync(e.q_rows + HC_N, a_q, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     HC_HIP(c, hipMemcpyAsync(stage, b_p, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     HC_HIP(c, hipMemcpyAsync(stage + HC_N, a_p, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    // Q rows times P^-1 mod Q0 once, here: ModDown's final division is then already inside b5's product with the key (hc_k_b4/b5)
+    const HcTw pinv = h_pair(h_inv(mp.m.q % m0.m.q, m0.m.q), m0.m.q);
+    int rc = hc_launch(c, "evk_div_p", hc_k_pointwise<HC_PW_MULC>, hc_pw_grid(2 * HC_N), (const u64 *)e.q_rows, (const u64 *)e.q_rows, e.q_rows, (size_t)2 * HC_N, m0.m, pinv);
     HcTw z; z.w = z.ws = 0;     // P rows: stored Montgomery form -> plain residues -> (w, floor(w*2^64/P)) pairs in lo-local order
-    int rc = hc_launch(c, "evk_from_mont", hc_k_pointwise<HC_PW_FROM_MONT>, hc_pw_grid(2 * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)2 * HC_N, mp.m, z);
+    if (!rc) rc = hc_launch(c, "evk_from_mont", hc_k_pointwise<HC_PW_FROM_MONT>, hc_pw_grid(2 * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)2 * HC_N, mp.m, z);
+    // ... times N^-1 mod P: the inverse transform of the P accumulators (hc_k_b4) then runs without its scaling products
+    if (!rc) rc = hc_launch(c, "evk_ninv", hc_k_pointwise<HC_PW_MULC>, hc_pw_grid(2 * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)2 * HC_N, mp.m, h_pair(mp.m.ninv, mp.m.q));
     if (!rc) rc = hc_launch(c, "make_pairs", hc_k_make_pairs, hc_pw_grid(2 * HC_N), (const u64 *)stage, e.p_rows, (size_t)2 * HC_N, mp.m.q, 1);
     hipStreamSynchronize(c->stream);
     hipFree(stage);
-    (void)m0;
     if (rc) { hipFree(e.q_rows); hipFree(e.p_rows); return rc; }
     auto it = c->evk.find(galEl);
     if (it != c->evk.end()) { hipFree(it->second.q_rows); hipFree(it->second.p_rows); }
@@ -685,7 +689,7 @@ extern "C" void hc_ker_free(hc_ctx *c, hc_ker *k) { if (!k) return; if (c) { hip
 static int hc_fill_loopB(hc_ctx *c, HcLoopB *B, const u64 *src, u64 *dst, const HcEvk &e, int logStep, int step, int norm, u64 galEl, int chunk) {
     const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
     B->src = src; B->dst = dst;
-    B->tmpC = c->ws_tmp; B->tmpE = c->ws_tmp + (size_t)chunk * HC_N;
+    B->tmpC = c->ws_tmp; B->tmpE = c->ws_tmp + (size_t)chunk * HC_N; B->tmpT = c->ws_tmp + (size_t)chunk * 3 * HC_N;
     B->idx = c->idx_pairs + (size_t)logStep * HC_N;
     B->evkQ = e.q_rows; B->evkP = e.p_rows;
     B->n0 = 0; B->step = step; B->norm = norm;
@@ -710,7 +714,7 @@ static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, int step, int logS
     if (!c->idx_pairs) HC_TRY(hc_idx_load(c, nullptr));
     const int nodes = (step + norm - 1) / norm;
     const int chunk = (int)(c->chunk_nodes < nodes ? (c->chunk_nodes < 1 ? 1 : c->chunk_nodes) : nodes);
-    HC_TRY(hc_ensure_tmp(c, (size_t)chunk * 3));
+    HC_TRY(hc_ensure_tmp(c, (size_t)chunk * 4));
     HcLoopB B; HC_TRY(hc_fill_loopB(c, &B, src, dst, it->second, logStep, step, norm, galEl, chunk));
     const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
     for (int n0 = 0; n0 < nodes; n0 += chunk) {
@@ -788,7 +792,7 @@ static int hc_ks_common(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uin
         if (rotate && local) {
             // slots: y at 0, x = 0 at 1 => one node with step = 1; the idx row is irrelevant because x = 0
             const int chunk = 1;
-            rc = hc_ensure_tmp(c, 3);
+            rc = hc_ensure_tmp(c, 4);
             HcLoopB B; if (!rc) rc = hc_fill_loopB(c, &B, y, res, it->second, 0, 1, 1, galEl, chunk);
             const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
             if (!rc) rc = hc_launch(c, "b1_node_rowsinv", hc_k_b1, dim3(16, 1), B, m0.inv);

@@ -187,7 +187,9 @@ static void emit_ct(const char *key, uint64_t ct) {
 }
 static void emit_end(void) { fprintf(g_out, "}"); fflush(g_out); }
 
+static int g_noplant = 0;   /* -noplant: log levels / scales / digests of the run's own data, overwrite nothing */
 static void plant_row(uint64_t rowptr, uint64_t seed, uint64_t q) {
+    if (g_noplant) return;
     for (uint64_t j = 0; j < g_N; j++) g_tmp[j] = splitmix64_at(seed, j) % q;
     wr(rowptr, g_tmp, g_N * 8);
 }
@@ -538,6 +540,7 @@ int main(int argc, char **argv) {
             while (tok) { if (isq) g_Q[g_nQ++] = strtoull(tok, NULL, 0); else g_Pm[g_nP++] = strtoull(tok, NULL, 0); tok = strtok(NULL, ","); }
         }
         else if (!strcmp(argv[ai], "-keep-bl")) g_skip_bl = 0;
+        else if (!strcmp(argv[ai], "-noplant")) g_noplant = 1;
         else if (!strcmp(argv[ai], "-seed") && ai + 1 < argc) g_seed = strtoull(argv[++ai], NULL, 0);
         else if (!strcmp(argv[ai], "-o") && ai + 1 < argc) outpath = argv[++ai];
         else usage();
