@@ -2,8 +2,8 @@
 //     conv <ker_wid 3|5|7> <i_batch 0..3> <num_tests <= 10>
 // prints the same line shapes as the reference's `conv` run (SURVEY.md 8(a)-S "CLI output contract").
 // It runs the slot-packed "Base Line" (hconv_bl.cpp, scope row 8f-2) and then "Ours" (hconv_host.cpp), as main.go:639-643 does.
-// `convReLU k i n` runs "Ours" with the bootstrapping chain (hconv_relu.cpp, scope row 8f-1; its baseline half is not built and
-// says so); `resnet ker depth 1 n false` runs the encrypted ResNet inference (hconv_resnet.cpp, scope row 8f-3).
+// `convReLU k i n` runs both with their bootstrapping chains (hconv_relu.cpp, scope row 8f-1: the baseline's stock Bootstrapp over
+// parameter set [7] and Ours' CtoS / StoC over set [6]); `resnet ker depth 1 n false` runs the encrypted ResNet inference (hconv_resnet.cpp, scope row 8f-3).
 // HCONV_SKIP_BL=1 skips the baseline half (not a reference feature; for timing "Ours" alone).
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,8 +36,7 @@ int main(int argc, char **argv) {
     else printf("Convolution test start! (No Bootstrapping)\n");
     printf("Ker:  %d batches:  %d widths:  %d\n", ker_wid, batchs[i_batch], widths[i_batch]);
     printf("Base Line start.\n");
-    if (boot) printf("(Base Line with bootstrapping, test_BL.go:113-183: not built in this engine - skipped)\n");
-    else if (getenv("HCONV_SKIP_BL") && atoi(getenv("HCONV_SKIP_BL"))) printf("(HCONV_SKIP_BL set: baseline skipped)\n");
+    if (getenv("HCONV_SKIP_BL") && atoi(getenv("HCONV_SKIP_BL"))) printf("(HCONV_SKIP_BL set: baseline skipped)\n");
     else hconv::testConv_BL_in(batchs[i_batch], widths[i_batch], ker_wid, num_tests, boot);
     printf("Ours start.\n");
     hconv::testConv_in(batchs[i_batch], widths[i_batch], ker_wid, num_tests, boot);

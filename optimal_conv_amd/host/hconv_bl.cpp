@@ -2,7 +2,7 @@
 // (main.go:639-640), on the MI355X engine. Next-row 8f-2 of the scope table.
 //
 // Reference mapping (file:line -> here):
-//   test_BL.go:16-185 testConv_BL_in           -> testConv_BL_in   (boot = false branch)
+//   test_BL.go:16-185 testConv_BL_in           -> testConv_BL_in   (boot = true: + blBootReLU of hconv_relu.cpp, test_BL.go:113-168)
 //   main.go:101-112,413-435 newContext("BL_Conv") -> bl_newContext (params set [7], rotations {a*W+b} U {r*W^2},
 //                                                   rotation keys over P = {0x1fffffffffe00001, 0x1fffffffffc80001})
 //   eval.go:78-134   evalConv_BN_BL_test       -> evalConv_BN_BL_test
@@ -55,6 +55,8 @@ struct BLContext {
     std::mt19937_64 g;
     std::set<uint64_t> keys;
     double scale = (double)(1 << 30);
+    Boot *btp = nullptr;          // cont.btp (main.go:476): the stock bootstrapper over parameter set [7], only for convReLU
+    uint64_t seed = 0;
 };
 struct BLCt { uint64_t *d = nullptr; double Scale = 0; };     // level-1 ciphertext: device [poly 2][limb 2][N]
 
@@ -231,13 +233,14 @@ static BLCt evalConv_BN_BL_test(BLContext *c, const Encoder &enc, const BLCt &ct
 }
 
 // ---------------------------------------------------------------- context, encrypt, decrypt
-static BLContext *bl_newContext(int logN, int ker_wid, int in_wid) {
+static BLContext *bl_newContext(int logN, int ker_wid, int in_wid, bool boot) {
+    auto cont_start = now();
     BLContext *c = new BLContext(); c->in_wid = in_wid;
     // ckks.DefaultBootstrapParams[7] has 28 Q primes + 5 P primes, logQP = 1582 (the figure the reference prints); this path
     // only ever touches Q0, Q1 and, for a level-1 key switch, the first two special primes
     printf("CKKS parameters: logN = %d, logSlots = %d, h = %d, logQP = %d, levels = %d, scale= 2^%f, sigma = %f \n", LOGN, LOGN - 1, 192, 1582, 28, 30.0, 3.2);
     if ((1 << logN) != N) { printf("Set Boot logN to %d\n", logN); panic("Boot N != N"); }
-    const char *sd = getenv("HCONV_SEED"); c->g.seed(sd ? strtoull(sd, nullptr, 0) ^ 0xB1ull : std::random_device{}());
+    const char *sd = getenv("HCONV_SEED"); c->seed = sd ? strtoull(sd, nullptr, 0) ^ 0xB1ull : std::random_device{}(); c->g.seed(c->seed);
     const int dev = getenv("HCONV_DEVICE") ? atoi(getenv("HCONV_DEVICE")) : 0;
     if (hc_ctx_create(&c->hc, LOGN, BLQ, 2, BLQ + 2, 2, dev)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
     c->sk.assign(N, 0);
@@ -251,6 +254,11 @@ static BLContext *bl_newContext(int logN, int ker_wid, int in_wid) {
     for (int k = 1; k < out_batch; k++) push(k * in_wid * in_wid);
     printf("Num Rotations:  %d\n", (int)rotations.size());
     for (int r : rotations) bl_gen_key(c, gal_for_rotation(r));
+    if (boot) {                                                            // main.go:464-507
+        printf("Generating bootstrapping keys...\n");
+        c->btp = newBootBL(c->sk, c->seed, dev);
+        printf("Done in %s \n", dur(cont_start).c_str());
+    }
     return c;
 }
 static BLCt bl_encrypt(BLContext *c, const std::vector<uint64_t> &pt_rows, double scale) {
@@ -290,12 +298,11 @@ static std::vector<cplx> bl_decrypt_decode(BLContext *c, const Encoder &enc, con
 
 // ---------------------------------------------------------------- test_BL.go:16-185 (boot = false)
 void testConv_BL_in(int real_batch, int in_wid, int ker_wid, int total_test_num, bool boot) {
-    if (boot) panic("convReLU (bootstrapping) is a next-row of the scope table and is not built in this engine");
     const std::string test_dir = "test_conv_data/";
     const int pad = ker_wid / 2, raw_in_wid = in_wid - pad, in_size = in_wid * in_wid, ker_size = ker_wid * ker_wid;
     const int slots = real_batch / 2 * in_size; int log_slots = 0; while ((1 << log_slots) < slots) log_slots++;
     const int out_batch = real_batch, in_batch = real_batch;
-    BLContext *cont = bl_newContext(log_slots + 1, ker_wid, in_wid);
+    BLContext *cont = bl_newContext(log_slots + 1, ker_wid, in_wid, boot);
     Encoder enc;
     printf("vec size: log2 =  %d\n", LOGN);
     printf("raw input width:  %d\n", raw_in_wid);
@@ -307,7 +314,7 @@ void testConv_BL_in(int real_batch, int in_wid, int ker_wid, int total_test_num,
         std::vector<double> input = readTxt(pre + "in" + suf, raw_in_wid * raw_in_wid * in_batch);
         std::vector<double> ker_in = readTxt(pre + "ker" + suf, in_batch * in_batch * ker_size);
         std::vector<double> bn_a = readTxt(pre + "bna" + suf, in_batch), bn_b = readTxt(pre + "bnb" + suf, in_batch);
-        std::vector<double> real_out = readTxt(pre + "out" + suf, raw_in_wid * raw_in_wid * in_batch);
+        std::vector<double> real_out = readTxt(pre + (boot ? "reluout" : "out") + suf, raw_in_wid * raw_in_wid * in_batch);   // test_BL.go:53-57
         const int hb = real_batch / 2;
         std::vector<double> pad_input1((size_t)in_size * hb, 0.0), pad_input2((size_t)in_size * hb, 0.0);
         for (int i = 0; i < raw_in_wid; i++) for (int j = 0; j < raw_in_wid; j++) for (int b = 0; b < hb; b++) {
@@ -335,6 +342,13 @@ void testConv_BL_in(int real_batch, int in_wid, int ker_wid, int total_test_num,
         }
         HCB(cont->hc, hc_sync(cont->hc));
         printf("Evaluation total done in %s \n", dur(start_eval).c_str());
+        if (boot) {                                                                                       // test_BL.go:113-168
+            const double alpha = 0.0, pow_ = 4.0;
+            BLCt o0 = bl_alloc(cont, 0), o1 = bl_alloc(cont, 0); double sc = 0;
+            blBootReLU(cont->btp, ct_res[0].d, ct_res[1].d, ct_res[0].Scale, alpha, pow_, o0.d, o1.d, &sc);
+            bl_free(cont, ct_res[0]); bl_free(cont, ct_res[1]);
+            o0.Scale = o1.Scale = sc; ct_res[0] = o0; ct_res[1] = o1;
+        }
         start = now();
         std::vector<cplx> vals_tmp1 = bl_decrypt_decode(cont, enc, ct_res[0]), vals_tmp2 = bl_decrypt_decode(cont, enc, ct_res[1]);
         printf("Decryption Done in %s \n", dur(start).c_str());
@@ -344,6 +358,7 @@ void testConv_BL_in(int real_batch, int in_wid, int ker_wid, int total_test_num,
         printDebugCfsPlain(test_out, real_out);
         bl_free(cont, ct_input1); bl_free(cont, ct_input2); bl_free(cont, ct_res[0]); bl_free(cont, ct_res[1]);
     }
+    if (cont->btp) freeBoot(cont->btp);
     hc_ctx_destroy(cont->hc); delete cont;
 }
 

@@ -24,6 +24,16 @@ const std::vector<uint64_t> PARAMS6_Q = {
     0x80000000440001ull, 0x7fffffffba0001ull, 0x80000000500001ull, 0x7fffffffaa0001ull, 0x800000005e0001ull,
     0x7fffffff7e0001ull, 0x7fffffff380001ull, 0x80000000ca0001ull,                                    // sine
     0x200000000e0001ull, 0x20000000140001ull, 0x20000000280001ull, 0x1fffffffd80001ull};              // CtS
+// ckks.DefaultBootstrapParams[7] (the baseline's set, main.go:54): residual group = levels 0-13, StC 14-15, sine, CtS
+const std::vector<uint64_t> PARAMS7_Q = {
+    0x80000000080001ull, 0x10000000006e0001ull,
+    0x3ffc0001ull, 0x40080001ull, 0x3fac0001ull, 0x40720001ull, 0x3f820001ull, 0x3f760001ull, 0x40980001ull,
+    0x3f5a0001ull, 0x3f540001ull, 0x40b00001ull, 0x40c20001ull,                                       // 11 x ~30-bit (levels 2-12)
+    0xffffffffffc0001ull,                                                                             // level 13
+    0x1000000000b00001ull, 0x1000000000ce0001ull,                                                     // StC
+    0x80000000440001ull, 0x7fffffffba0001ull, 0x80000000500001ull, 0x7fffffffaa0001ull, 0x800000005e0001ull,
+    0x7fffffff7e0001ull, 0x7fffffff380001ull, 0x80000000ca0001ull,                                    // sine
+    0x200000000e0001ull, 0x20000000140001ull, 0x20000000280001ull, 0x1fffffffd80001ull};              // CtS
 const std::vector<uint64_t> PARAMS6_P = {0x1fffffffffe00001ull, 0x1fffffffffc80001ull, 0x1fffffffffb40001ull,
                                          0x1fffffffff500001ull, 0x1fffffffff420001ull};
 

@@ -37,6 +37,7 @@ static const int N = 1 << LOGN;
 
 // ckks.DefaultBootstrapParams[6] of the fork, level order; only Q[0], Q[1] carry the conv path
 extern const std::vector<uint64_t> PARAMS6_Q;
+extern const std::vector<uint64_t> PARAMS7_Q;      // ckks.DefaultBootstrapParams[7]: the baseline's chain (main.go:54)
 extern const std::vector<uint64_t> PARAMS6_P;      // bootstrapping key-switch primes (logQP print only)
 static const uint64_t PACK_P = 0x1fffffffffe00001ull;   // main.go:449
 
@@ -104,13 +105,18 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
 std::vector<double> bootDecryptDecodeCoeffs(Boot *B, const BootCiphertext &ct);
 void freeBootCt(Boot *B, BootCiphertext &ct);
 void bootStats(Boot *B, long *keys, long *keyswitches);
+// ---- the baseline's bootstrapping + ReLU (test_BL.go:113-168) on parameter set [7]: cont.btp.Bootstrapp (the stock full-slot
+// bootstrapper), imaginary packing / unpacking, evalReLU + MulByPow2 + SetScale on both halves
+Boot *newBootBL(const std::vector<int64_t> &sk, uint64_t seed, int device);
+// ct_res0/1: level-1 results of the two baseline convolutions, device [2][2][N] over (Q0, Q1 of set [7]) at `scale`; out0/1 likewise at level 1
+void blBootReLU(Boot *B, const uint64_t *ct_res0, const uint64_t *ct_res1, double scale, double alpha, double pow, uint64_t *out0, uint64_t *out1, double *out_scale);
 // eval.go:272-607 for kinds "Conv", "Conv_sparse", "StrConv_sparse" (hconv_resnet.cpp); returns a level-1, scale-2^30 ciphertext
 Ciphertext evalConv_BNRelu_new(Context *cont, const Ciphertext &ct_input, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
                                const std::vector<double> &bn_b, double alpha, double pow, int in_wid, int kp_wid, int ker_wid, int real_ib, int real_ob,
                                int norm, int log_sparse, const std::string &kind);
 // test.go:76-370 — `resnet ker depth 1 n cf100`
 void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug, bool cf100);
-// test_BL.go:16 — the slot-packed baseline the reference runs first (hconv_bl.cpp); boot = true is not built
+// test_BL.go:16 — the slot-packed baseline the reference runs first (hconv_bl.cpp); boot = true adds Bootstrapp + ReLU (test_BL.go:113-168)
 void testConv_BL_in(int real_batch, int in_wid, int ker_wid, int total_test_num, bool boot);
 
 // ckks.Evaluator subset used by conv.go, one C-ABI call per limb row

@@ -36,7 +36,7 @@
 namespace hconv {
 
 #define HCR(call) do { int rc_ = (call); if (rc_) panic(std::string(#call) + ": " + hc_last_error(hc)); } while (0)
-static const int LV_CTS_TOP = 27, LV_SINE_TOP = 23, LV_RELU_TOP = 15, LV_STC_TOP = 3;
+static const int LV_CTS_TOP = 27, LV_SINE_TOP = 23, LV_RELU_TOP = 15;     // the same in parameter sets [6] and [7]: CtS 27..24, sine 23..16
 static const int SIN_K = 25, SIN_DEG = 63, SIN_DOUBLE = 2;
 typedef std::map<int, std::vector<cplx>> DiagMat;        // rotation k -> diagonal (n complex values)
 
@@ -61,6 +61,15 @@ struct Boot {
     hc_ctx *hc = nullptr;
     std::vector<uint64_t> Q, P;
     int NQ = 0;
+    // where SlotsToCoeffs sits and what its plaintext scales are: set [6] (Ours, main.go:52): levels 3..2 after the ReLU, two matrices
+    // at sqrt(q3) and one at 2^30 (input scale 2^60 -> output 2^30 at level 1); set [7] (BL, main.go:54: the stock Bootstrapp):
+    // levels 15..14 right after the sine, 2^40 each (input 2^30 -> output 2^30 * 2^120 / (q15 q14) at level 13)
+    int chain = 6, LV_STC_TOP = 3, lv_relin_lo = LV_RELU_TOP - 10;
+    double stc_scale_top = 0, stc_scale_last = 1073741824.0;
+    // scale the sine leaves its result at (level 15). Ours: 2^30, what evalReLU consumes. Baseline: 2^55 — its SlotsToCoeffs follows
+    // directly and multiplies whatever noise its input carries by ~sqrt(N) relative to the slot values, so the input must sit far above
+    // the key-switch noise (the reference's evaluateSine likewise hands over at 2^55..2^60: gotrace -noplant log of `convReLU 3 0 1`)
+    double sine_out_scale = 1073741824.0;
     const int n = N / 2;
     std::vector<int64_t> sk;
     uint64_t *d_sk = nullptr;                               // [NQ+NP][N] NTT rows of sk on the device
@@ -257,6 +266,39 @@ struct Boot {
         for (int d = 0; d < 2; d++) HCR(hc_lv_mod_raise(hc, level, a.p[d].get(), r.p[d].get()));
         return r;
     }
+    // evaluator.SetScale: MultByConst(scale / ct.Scale) — a constant with a fractional part is carried times
+    // q_level — then Rescale(scale) (drop while scale/q_L >= scale/2), then the scale is forced
+    DCt set_scale(const DCt &a, double scale) {
+        const double c = scale / a.scale; DCt r = a;
+        if (c != 1.0) {
+            double mult = 1.0; if (c - (double)(int64_t)c != 0) mult = (double)Q[(size_t)a.level];
+            r = mul_const_int(a, floor(fabs(c * mult) + 0.5) * (c < 0 ? -1.0 : 1.0)); r.scale = a.scale * mult;
+        }
+        while (r.level > 0 && r.scale / (double)Q[(size_t)r.level] >= scale / 2) r = rescale(r);
+        r.scale = scale;
+        return r;
+    }
+    // debugging aid (HCONV_DEBUG_BOOT): decrypt on the limbs 0, 1 (needs |message| * scale < Q0 Q1 / 2) and decode to slots
+    std::vector<cplx> debug_slots(const DCt &a) {
+        const int L = std::min(a.level, 1); auto t = block();
+        HCR(hc_lv_mul(hc, L, a.p[1].get(), d_sk, t.get())); HCR(hc_lv_add(hc, L, a.p[0].get(), t.get(), t.get())); HCR(hc_lv_intt(hc, L, t.get(), t.get()));
+        std::vector<uint64_t> m((size_t)(L + 1) * N); HCR(hc_download(hc, m.data(), t.get(), m.size() * 8));
+        std::vector<double> cf((size_t)N);
+        if (L == 0) { const uint64_t q0 = Q[0]; for (int j = 0; j < N; j++) cf[(size_t)j] = (m[(size_t)j] > q0 / 2 ? -(double)(q0 - m[(size_t)j]) : (double)m[(size_t)j]) / a.scale; }
+        else {
+            const uint64_t q0 = Q[0], q1 = Q[1]; uint64_t inv = 1; { uint64_t b = q0 % q1, e = q1 - 2; while (e) { if (e & 1) inv = mulmod(inv, b, q1); b = mulmod(b, b, q1); e >>= 1; } }
+            const u128 QQ = (u128)q0 * q1;
+            for (int j = 0; j < N; j++) { const uint64_t a0 = m[(size_t)j], a1 = m[(size_t)N + j], d = (a1 % q1 + q1 - a0 % q1) % q1; const u128 x = (u128)a0 + (u128)q0 * mulmod(d, inv, q1);
+                cf[(size_t)j] = x > QQ / 2 ? -(double)(QQ - x) / a.scale : (double)x / a.scale; }
+        }
+        std::vector<cplx> v((size_t)N / 2); for (int i = 0; i < N / 2; i++) v[(size_t)i] = cplx(cf[(size_t)i], cf[(size_t)(i + N / 2)]);
+        enc.fft(v);
+        return v;
+    }
+    static void debug_compare(const char *what, const std::vector<cplx> &want, const std::vector<cplx> &got) {
+        double mx = 0, sum = 0, mag = 0; for (size_t i = 0; i < want.size(); i++) { const double e = std::abs(want[i] - got[i]); mx = std::max(mx, e); sum += e; mag = std::max(mag, std::abs(want[i])); }
+        fprintf(stderr, "[debug] %s: max |want| %.4g, error max 2^%.2f mean 2^%.2f\n", what, mag, log2(mx), log2(sum / (double)want.size()));
+    }
     static DCt relabel(const DCt &a, double scale) { if (fabs(a.scale / scale - 1.0) > 1e-6) panic("relabel: scales are not close"); DCt r = a; r.scale = scale; return r; }
 
     // ---------------- encoding
@@ -432,8 +474,11 @@ struct Boot {
     }
 
     // ---------------- the bootstrapper
-    void build(const std::vector<int64_t> &sk_in, uint64_t seed, int device) {
-        Q = PARAMS6_Q; P = PARAMS6_P; NQ = (int)Q.size(); sk = sk_in; rng_state = seed ^ 0xB007B007ull;
+    void build(const std::vector<int64_t> &sk_in, uint64_t seed, int device, int chain_ = 6) {
+        chain = chain_;
+        Q = chain == 7 ? PARAMS7_Q : PARAMS6_Q; P = PARAMS6_P; NQ = (int)Q.size(); sk = sk_in; rng_state = seed ^ 0xB007B007ull;
+        if (chain == 7) { LV_STC_TOP = 15; stc_scale_top = stc_scale_last = 1099511627776.0; lv_relin_lo = 2; sine_out_scale = 36028797018963968.0; }
+        else { LV_STC_TOP = 3; stc_scale_top = sqrt((double)Q[3]); stc_scale_last = 1073741824.0; lv_relin_lo = LV_RELU_TOP - 10; }
         if (hc_ctx_create(&hc, LOGN, Q.data(), NQ, P.data(), (int)P.size(), device)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
         const int nm = NQ + (int)P.size();
         { void *v = nullptr; HCR(hc_malloc(hc, (size_t)nm * N * 8, &v)); d_sk = (uint64_t *)v; }
@@ -454,7 +499,8 @@ struct Boot {
         }
         sine[0] /= 2;
         key(2ull * N - 1, LV_SINE_TOP);                                      // conjugation
-        for (int l = LV_SINE_TOP; l >= LV_RELU_TOP - 10; l--) key(0, l);     // kgen.GenRelinearizationKey (main.go:411)
+        for (int l = LV_SINE_TOP; l >= lv_relin_lo; l--) if (chain == 6 || l > LV_RELU_TOP || l <= 12) key(0, l);     // kgen.GenRelinearizationKey (main.go:411), at the levels that multiply
+        if (chain == 7) { key(2ull * N - 1, 1); key(2ull * N - 1, 12); }       // pack_evaluator.ConjugateNew before / after Bootstrapp (test_BL.go:116, 155)
     }
     // One bootstrapper (main.go:480-507: btp for log_sparse 0, btp2..btp5 for 1..4): its DFT matrices, encoded, and every rotation
     // key it switches with (GenRotationKeysForRotations(btpParams.RotationsForBootstrapping(LogSlots)), main.go:466-474).
@@ -475,9 +521,9 @@ struct Boot {
             for (int p = 0; p < n; p++) { const bool first = p % (2 * ns) < ns; W[0][(size_t)p] = first ? cplx(1, 0) : cplx(0, 1); W[ns][(size_t)p] = first ? cplx(0, 1) : cplx(1, 0); }
             G[0] = matmul_diag(G[0], W, 2 * ns);
         }
-        const double sc3 = pow((double)Q[LV_STC_TOP], 1.0 / (double)(G.size() - 1));
-        for (size_t i = 0; i + 1 < G.size(); i++) S.stc.push_back(plan(G[i], LV_STC_TOP, sc3));
-        S.stc.push_back(plan(G.back(), LV_STC_TOP - 1, 1073741824.0));
+        if (G.size() != 3) panic("SlotsToCoeffs is planned as three matrices");
+        for (size_t i = 0; i + 1 < G.size(); i++) S.stc.push_back(plan(G[i], LV_STC_TOP, stc_scale_top));
+        S.stc.push_back(plan(G.back(), LV_STC_TOP - 1, stc_scale_last));
         for (auto *grp : {&S.cts, &S.stc}) for (auto &lt : *grp) for (auto &g : lt.giant) {
             if (g.first) key(gal_rot(g.first), lt.level);
             for (auto &b : g.second) if (b.first) key(gal_rot(b.first), lt.level);
@@ -500,7 +546,7 @@ struct Boot {
         int np = 2;
         if (ls) { parts[0] = add(parts[0], rotate(parts[1], S.ns)); np = 1; }
         const double c_m = q0 / (2.0 * M_PI * msg_scale);
-        double s = 1073741824.0 * c_m;
+        double s = sine_out_scale * c_m;
         for (int r = 0; r < SIN_DOUBLE; r++) s = sqrt(s * (double)Q[(size_t)(LV_RELU_TOP + 1 + r)]);
         for (int h = 0; h < np; h++) {
             DCt c = eval_poly(parts[h], sine, s, true);
@@ -659,6 +705,73 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     HCR(hc_sync(hc));
     return out;
 }
+// ---------------------------------------------------------------- baseline: Bootstrapp + ReLU (test_BL.go:113-168)
+Boot *newBootBL(const std::vector<int64_t> &sk, uint64_t seed, int device) {
+    Boot *b = new Boot(); b->build(sk, seed, device, 7); b->set(0);
+    return b;
+}
+void blBootReLU(Boot *B, const uint64_t *ct_res0, const uint64_t *ct_res1, double scale, double alpha, double pow_, uint64_t *out0, uint64_t *out1, double *out_scale) {
+    hc_ctx *hc = B->hc;
+    if (B->chain != 7) panic("blBootReLU needs the baseline's bootstrapper (newBootBL)");
+    auto img_eval = now();
+    DCt c[2];
+    for (int pos = 0; pos < 2; pos++) {
+        DCt t = B->new_ct(1, 1, scale); const uint64_t *src = pos ? ct_res1 : ct_res0;
+        for (int d = 0; d < 2; d++) HCR(hc_copy(hc, t.p[d].get(), src + (size_t)d * 2 * N, (size_t)2 * N * 8));
+        c[pos] = B->add(B->conjugate(t), t);                                                             // test_BL.go:116
+        if (pos == 1) c[pos] = B->mul_by_i(c[pos]);                                                      // MultByiNew (118)
+    }
+    DCt ct = B->add(c[0], c[1]);                                                                         // test_BL.go:122
+    HCR(hc_sync(hc));
+    const double img_part = std::chrono::duration<double>(now() - img_eval).count();
+    ct.scale = ct.scale * exp2(pow_ + 2);                                                                // test_BL.go:128
+    printf("\n ========= Bootstrapping... (original) ========= \n");
+    auto start_boot = now();
+    // ckks.(*Bootstrapper).Bootstrapp: one level is available, so SetScale brings the scale to 2^round(log2(Q0 / MessageRatio)) and the
+    // level to 0; modUp, CoeffsToSlots, sine on both halves, SlotsToCoeffs
+    const bool dbg = getenv("HCONV_DEBUG_BOOT") && *getenv("HCONV_DEBUG_BOOT"); std::vector<cplx> z_in;
+    if (dbg) z_in = B->debug_slots(ct);
+    // MessageRatio: the reference's parameter set says 256. Its sine is a Han-Ki interpolant that is only accurate near the integers;
+    // the plain degree-63 Chebyshev interpolant used here is accurate to ~2^-26 everywhere, and that error is multiplied by
+    // Q0 / (2 pi scale) and then by ~sqrt(N) in SlotsToCoeffs. The baseline's slot values are below 2^-4 (the 2^(pow+2) of
+    // test_BL.go:128), so a ratio of 16 keeps the linearisation error of the sine at 2^-17 and brings the bootstrapping error from
+    // 2^-13 to 2^-17 (measured, HCONV_DEBUG_BOOT=1): the baseline half then prints the reference's precision (MED 11.3 vs 11.4 bits).
+    const double ratio = getenv("HCONV_BL_MSG_RATIO") ? atof(getenv("HCONV_BL_MSG_RATIO")) : 16.0;
+    ct = B->set_scale(ct, exp2(round(log2((double)B->Q[0] / ratio))));
+    if (dbg) Boot::debug_compare("SetScale before Bootstrapp", z_in, B->debug_slots(ct));
+    if (ct.level != 0) panic("Bootstrapp: SetScale did not reach level 0");
+    DCt halves[2]; if (B->ctos(ct, 0, halves) != 2) panic("Bootstrapp: full-slot CoeffsToSlots returns two ciphertexts");
+    DCt ct_boot = B->stoc(halves[0], &halves[1], 0);
+    if (dbg) Boot::debug_compare("Bootstrapp", z_in, B->debug_slots(ct_boot));
+    HCR(hc_sync(hc));
+    printf("Boot Done in %s \n", dur(start_boot).c_str());
+    img_eval = now();
+    // test_BL.go:146-153: an all-ones plaintext whose scale lands the product on 2^30 times the moduli the Rescale drops. The reference's
+    // bootstrapper returns at level 14 (scale 2^30 q14 q13 -> level 12); this one returns at level 13 (scale 2^30 q13 -> level 12).
+    { const int L = ct_boot.level; if (L != 13) panic("Bootstrapp ended at an unexpected level");
+      std::vector<cplx> ones((size_t)N / 2, cplx(1.0, 0)); DPt pl_scale = B->encode(ones, L, 1073741824.0 * (double)B->Q[(size_t)L] / ct_boot.scale);
+      ct_boot = B->rescale(B->mul_plain(ct_boot, pl_scale)); ct_boot.scale = 1073741824.0; }
+    if (dbg) Boot::debug_compare("Bootstrapp + scale plaintext", z_in, B->debug_slots(ct_boot));
+    DCt ct_iboot = B->conjugate(ct_boot);                                                                // test_BL.go:155
+    DCt res[2] = {B->add(ct_boot, ct_iboot), B->mul_by_i(B->sub(ct_iboot, ct_boot))};                    // DivByi(a - b) = i (b - a)
+    HCR(hc_sync(hc));
+    { double ns = (img_part + std::chrono::duration<double>(now() - img_eval).count()) * 1e9; char b[64];
+      if (ns < 1e6) snprintf(b, sizeof b, "%.6gµs", ns / 1e3); else if (ns < 1e9) snprintf(b, sizeof b, "%.9gms", ns / 1e6); else snprintf(b, sizeof b, "%.9gs", ns / 1e9);
+      printf("Imaginary packing and unpacking done in %s \n", b); }
+    auto start = now();
+    for (int pos = 0; pos < 2; pos++) {                                                                  // test_BL.go:160-167
+        DCt r = evalReLU(B, res[pos], alpha);
+        r = B->mul_const_int(r, pow(2.0, pow_));                                                         // MulByPow2
+        r = B->set_scale(r, 1073741824.0);
+        if (r.level != 1) panic("baseline ReLU ended at an unexpected level");
+        uint64_t *dst = pos ? out1 : out0;
+        for (int d = 0; d < 2; d++) HCR(hc_copy(hc, dst + (size_t)d * 2 * N, r.p[d].get(), (size_t)2 * N * 8));
+        *out_scale = r.scale;
+    }
+    HCR(hc_sync(hc));
+    printf("Relu Done in %s \n", dur(start).c_str());
+}
+
 // Decrypt at level 1 + DecodeCoeffs: CRT over Q0*Q1, centre, / scale
 std::vector<double> bootDecryptDecodeCoeffs(Boot *B, const BootCiphertext &ct) {
     hc_ctx *hc = B->hc;

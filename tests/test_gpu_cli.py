@@ -57,9 +57,15 @@ def test_conv_relu_cli(tmp_path, k, i_batch):
     for pat in (r"^Convolution followed by ReLU \(& Bootstrapping\) test start!$", r"^Generating bootstrapping keys\.\.\.$",
                 r"^Bootstrapping\.\.\. Ours \(until CtoS\):$", r"^Done in \S+ $", r"^Eval: Eval: ReLU Done in \S+ $", r"^Boot \(StoC\) Done in \S+ $"):
         assert re.search(pat, txt, re.M), f"missing line {pat!r} in:\n{txt}"
-    med = float(re.search(r"^MED Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M).group(1))
-    avg = float(re.search(r"^AVG Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M).group(1))
-    assert med >= 10.5 and avg >= 7.5, txt
+    for pat in (r"^ ========= Bootstrapping\.\.\. \(original\) ========= $", r"^Boot Done in \S+ $", r"^Imaginary packing and unpacking done in \S+ $",
+                r"^Eval: Eval: Relu Done in \S+ $"):                                       # the baseline half (test_BL.go:113-168)
+        assert re.search(pat, txt, re.M), f"missing baseline line {pat!r} in:\n{txt}"
+    meds = [float(m) for m in re.findall(r"^MED Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M)]
+    avgs = [float(m) for m in re.findall(r"^AVG Prec : \(([-0-9.]+), \+Inf\) Log2", txt, re.M)]
+    assert len(meds) == 2, txt                      # baseline, then Ours
+    # the reference binary prints AVG 8.27 / MED 11.41 for its baseline half of `convReLU 3 0 1` (gotrace -noplant run)
+    assert meds[0] >= 10.0 and avgs[0] >= 7.5, txt
+    assert meds[1] >= 10.5 and avgs[1] >= 7.5, txt
 
 
 @pytest.mark.parametrize("cf100", [False, True])
