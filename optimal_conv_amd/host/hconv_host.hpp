@@ -115,7 +115,7 @@ Ciphertext evalConv_BNRelu_new(Context *cont, const Ciphertext &ct_input, const 
                                const std::vector<double> &bn_b, double alpha, double pow, int in_wid, int kp_wid, int ker_wid, int real_ib, int real_ob,
                                int norm, int log_sparse, const std::string &kind);
 // test.go:76-370 — `resnet ker depth 1 n cf100`
-void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug, bool cf100);
+void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug, bool cf100, int wide_case = 1);   // wide_case 2: test.go:638 testResNet_crop_sparse_wide
 // test_BL.go:16 — the slot-packed baseline the reference runs first (hconv_bl.cpp); boot = true adds Bootstrapp + ReLU (test_BL.go:113-168)
 void testConv_BL_in(int real_batch, int in_wid, int ker_wid, int total_test_num, bool boot);
 

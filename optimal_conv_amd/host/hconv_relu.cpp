@@ -592,26 +592,43 @@ static std::vector<int> gen_keep_vec_sparse(int vec_size, int in_wid, int kp_wid
     for (int i = 0; i < post_slot; i++) for (int j = 1; j < sparsity / 2; j++) idx[(size_t)(i + post_slot * j)] = idx[(size_t)i];
     return idx;
 }
-// rot_util.go:557-612 (the log_sparse != 0 branch, the only one `resnet k d ...` reaches): masks and rotations of the two stages
-// of ext_double_ctxt that keep the stride-2 positions and re-pack them for the next (half-width) block
+// rot_util.go:557-722: masks and rotations of the two stages of ext_double_ctxt that keep the stride-2 positions and re-pack them
+// for the next (half-width) block. log_sparse != 0: one packed ciphertext (ul unused). log_sparse == 0 (full packing, the wide
+// networks' first stride layer): the upper (ul = 0) and lower (ul = 1) ciphertexts get their own masks; pos = 0 only.
 typedef std::map<int, std::vector<int>> IdxMap;
-static void gen_comprs_sparse(int vec_size, int in_wid, int kp_wid, int log_sparse, IdxMap &m_idx, IdxMap &r_idx) {
-    if (log_sparse == 0) panic("gen_comprs_sparse: full packing (log_sparse 0) is not used by the resnet driver and is not built");
+static void gen_comprs_sparse(int vec_size, int in_wid, int kp_wid, int log_sparse, int ul, IdxMap &m_idx, IdxMap &r_idx) {
     if (in_wid % 2) panic("input wid not divisible by 2");
-    const int batch = 2 * vec_size / (in_wid * in_wid * (1 << log_sparse)), min_wid = in_wid / 2, rep = 1 << (log_sparse - 1);
+    const int batch = 2 * vec_size / (in_wid * in_wid * (1 << log_sparse)), min_wid = in_wid / 2;
     int log_in_wid = 0; for (; (1 << log_in_wid) < in_wid; log_in_wid++) {}
     auto rev = [](int x, int bits) { int r = 0; for (int k = 0; k < bits; k++) r |= ((x >> k) & 1) << (bits - 1 - k); return r; };
-    auto tile = [&](std::vector<int> &t) { const int seg = vec_size / rep; for (int i = 0; i < seg; i++) for (int k = 1; k < rep; k++) t[(size_t)(i + k * seg)] = t[(size_t)i]; };
-    for (int j = 0; j < min_wid; j++) {
-        std::vector<int> tmp((size_t)vec_size, 0);
-        for (int b = 0; b < batch; b++) for (int i = 0; i < min_wid / 2; i++) for (int k = 0; k < 2; k++)
-            if (rev(j, log_in_wid - 1) < kp_wid && rev(i, log_in_wid - 2) + k * min_wid / 2 < kp_wid) tmp[(size_t)(k * in_wid * min_wid * batch + in_wid * in_wid * b / 2 + in_wid * j / 2 + i)] = 1;
-        tile(tmp); m_idx[j * min_wid / 2] = tmp;
+    if (log_sparse != 0) {
+        const int rep = 1 << (log_sparse - 1);
+        auto tile = [&](std::vector<int> &t) { const int seg = vec_size / rep; for (int i = 0; i < seg; i++) for (int k = 1; k < rep; k++) t[(size_t)(i + k * seg)] = t[(size_t)i]; };
+        for (int j = 0; j < min_wid; j++) {
+            std::vector<int> tmp((size_t)vec_size, 0);
+            for (int b = 0; b < batch; b++) for (int i = 0; i < min_wid / 2; i++) for (int k = 0; k < 2; k++)
+                if (rev(j, log_in_wid - 1) < kp_wid && rev(i, log_in_wid - 2) + k * min_wid / 2 < kp_wid) tmp[(size_t)(k * in_wid * min_wid * batch + in_wid * in_wid * b / 2 + in_wid * j / 2 + i)] = 1;
+            tile(tmp); m_idx[j * min_wid / 2] = tmp;
+        }
+        for (int b = 0; b < batch; b++) {
+            std::vector<int> tmp((size_t)vec_size, 0);
+            for (int j = 0; j < min_wid; j++) for (int i = 0; i < min_wid / 2; i++) for (int k = 0; k < 2; k++) tmp[(size_t)(k * in_wid * min_wid * batch + b * in_wid * in_wid / 2 + j * min_wid / 2 + i)] = 1;
+            tile(tmp); r_idx[3 * b * min_wid * min_wid / 2] = tmp;
+        }
+        return;
     }
-    for (int b = 0; b < batch; b++) {
+    if (ul != 0 && ul != 1) panic("ul not 0 nor 1");
+    auto keep = [&](int j, int i) { return rev(j, log_in_wid - 1) < kp_wid && rev(i, log_in_wid - 2) + (ul ? min_wid / 2 : 0) < kp_wid; };
+    const int G = batch > 8 * min_wid ? 8 : (batch > 4 * min_wid ? 4 : 1);          // rot_util.go:617, 656, 693: blocks of G batches move together
+    for (int j = 0; j < min_wid; j++) for (int bk = 0; bk < G; bk++) {
         std::vector<int> tmp((size_t)vec_size, 0);
-        for (int j = 0; j < min_wid; j++) for (int i = 0; i < min_wid / 2; i++) for (int k = 0; k < 2; k++) tmp[(size_t)(k * in_wid * min_wid * batch + b * in_wid * in_wid / 2 + j * min_wid / 2 + i)] = 1;
-        tile(tmp); r_idx[3 * b * min_wid * min_wid / 2] = tmp;
+        for (int b = 0; b < batch / G; b++) for (int i = 0; i < min_wid / 2; i++) if (keep(j, i)) tmp[(size_t)(G * in_wid * min_wid * b + bk * min_wid * in_wid + min_wid * j + i)] = 1;
+        m_idx[j * min_wid / 2 + (G - 1) * bk * min_wid * min_wid / 2] = tmp;
+    }
+    for (int b = 0; b < batch / G; b++) {
+        std::vector<int> tmp((size_t)vec_size, 0);
+        for (int bk = 0; bk < G; bk++) for (int j = 0; j < min_wid; j++) for (int i = 0; i < min_wid / 2; i++) tmp[(size_t)(G * b * in_wid * min_wid + bk * min_wid * min_wid / 2 + j * min_wid / 2 + i)] = 1;
+        r_idx[3 * b * G * min_wid * min_wid / 2] = tmp;
     }
 }
 // conv.go:374-414: sum over (rot, mask) of Rotate(ct * mask, rot), twice (masks at scale sqrt(q_level)), one rescale
@@ -655,8 +672,10 @@ Boot *newBoot(const std::vector<int64_t> &sk, uint64_t seed, int device, const s
 }
 // main.go:163-215: the rotations of the stride layers' ext_double_ctxt belong to the evaluator's rotation keys
 void bootPrepareCompress(Boot *B, int in_wid, int kp_wid, int log_sparse) {
-    IdxMap m_idx, r_idx; gen_comprs_sparse(N / 2, in_wid, kp_wid, log_sparse, m_idx, r_idx);
-    for (auto *m : {&m_idx, &r_idx}) for (auto &e : *m) { const int k = ((e.first % B->n) + B->n) % B->n; if (k) B->key(B->gal_rot(k), LV_RELU_TOP - 10); }
+    for (int ul = 0; ul < (log_sparse ? 1 : 2); ul++) {
+        IdxMap m_idx, r_idx; gen_comprs_sparse(N / 2, in_wid, kp_wid, log_sparse, ul, m_idx, r_idx);
+        for (auto *m : {&m_idx, &r_idx}) for (auto &e : *m) { const int k = ((e.first % B->n) + B->n) % B->n; if (k) B->key(B->gal_rot(k), LV_RELU_TOP - 10); }
+    }
 }
 void freeBoot(Boot *b) {
     if (!b) return;
@@ -675,7 +694,8 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     hc_ctx *hc = B->hc;
     const bool sparse = kind == "Conv_sparse" || kind == "StrConv_sparse", stride = kind == "StrConv_sparse";
     if (!sparse && kind != "Conv") panic("No kind!");
-    if (sparse == (log_sparse == 0)) panic("No cases for log_sparse");
+    if (!sparse && log_sparse != 0) panic("No cases for log_sparse");
+    if (sparse && log_sparse == 0 && !stride) panic("Conv_sparse with full packing (log_sparse 0: the wide_case 3 network) is not built");
     DCt ct = B->new_ct(0, 1, ct_scale * pow(2.0, pow_));                                            // eval.go:437
     for (int d = 0; d < 2; d++) HCR(hc_copy(hc, ct.p[d].get(), ct_conv_dev + (size_t)d * N, (size_t)N * 8));
     printf("Bootstrapping... Ours (until CtoS):\n");
@@ -693,10 +713,11 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     start = now();
     DCt keep[2];
     const std::string mk = std::to_string(in_wid) + "/" + std::to_string(kp_wid) + "/" + std::to_string(log_sparse);
-    if (stride) { IdxMap m_idx, r_idx; gen_comprs_sparse(N / 2, in_wid, kp_wid, log_sparse, m_idx, r_idx); keep[0] = ext_double_ctxt(B, boots[0], m_idx, r_idx, "comprs/" + mk); }   // eval.go:500-506
+    if (stride) for (int ul = 0; ul < iter; ul++) {                                                                                                                            // eval.go:500-506: m_idx / m_idx_l
+        IdxMap m_idx, r_idx; gen_comprs_sparse(N / 2, in_wid, kp_wid, log_sparse, ul, m_idx, r_idx); keep[ul] = ext_double_ctxt(B, boots[ul], m_idx, r_idx, "comprs/" + mk + "/" + std::to_string(ul)); }
     else if (sparse) keep[0] = keep_ctxt(B, boots[0], gen_keep_vec_sparse(N / 2, in_wid, kp_wid, log_sparse), "keep/" + mk);                                                       // eval.go:534
     else for (int ul = 0; ul < 2; ul++) keep[ul] = keep_ctxt(B, boots[ul], gen_keep_vec(N / 2, in_wid, kp_wid, ul), "keep/" + mk + "/" + std::to_string(ul));
-    DCt res = B->stoc(keep[0], sparse ? nullptr : &keep[1], log_sparse);                              // eval.go:550-561 ; Rescale (564) is a no-op here
+    DCt res = B->stoc(keep[0], iter == 2 ? &keep[1] : nullptr, log_sparse);                              // eval.go:550-561 ; Rescale (564) is a no-op here
     HCR(hc_sync(hc));
     printf("Boot (StoC) Done in %s \n", dur(start).c_str());
     BootCiphertext out; out.level = res.level; out.Scale = res.scale;

@@ -1,4 +1,4 @@
-// hconv_resnet.cpp — `resnet <ker> <depth> 1 <n> <cf100>` (scope row 8f-3): the reference's encrypted ResNet inference
+// hconv_resnet.cpp — `resnet <ker> <depth> <wide_case 1|2> <n> <cf100>` (scope row 8f-3): the reference's encrypted ResNet inference
 // (test.go:76-370 testResNet_crop_sparse) on the MI355X engine, and the layer operator it is built from
 // (eval.go:272-607 evalConv_BNRelu_new for kinds "Conv_sparse" / "StrConv_sparse").
 //
@@ -99,22 +99,31 @@ static void writeTxt(const std::string &name, const std::vector<double> &v) {
     for (double d : v) { snprintf(buf, sizeof buf, "%.17g\n", d); f << buf; }
 }
 
-// test.go:76-370
-void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug, bool cf100) {
+// test.go:76-370 (wide_case 1) and test.go:638-912 testResNet_crop_sparse_wide (wide_case 2: twice the channels, first layer 3 -> 16
+// -> 32, first stride layer on full packing; wide_case 3 — 48/96/192 channels with "StrConv_sparse_full" — is not built)
+void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug, bool cf100, int wide_case) {
     (void)debug;
-    const std::string ker_name = "ker" + std::to_string(ker_wid), tag = std::string(cf100 ? "cf100_" : "") + "crop_" + ker_name + "_d" + std::to_string(depth) + "_wid1/";
+    if (wide_case != 1 && wide_case != 2) panic("wrong wide_case (the wide_case 3 network of testResNet_crop_sparse_wide is not built)");
+    const bool wide = wide_case != 1;
+    const std::string ker_name = "ker" + std::to_string(ker_wid), tag = std::string(cf100 ? "cf100_" : "") + "crop_" + ker_name + "_d" + std::to_string(depth) + "_wid" + std::to_string(wide_case) + "/";
     const std::string weight_dir = "Resnet_weights/weights_" + tag, out_dir = "Resnet_enc_results/results_" + tag, img_dir = "Resnet_plain_data/" + tag;
     int fc_out = 10; double init_pow = 6.0, mid_pow = 6.0, final_pow = 6.0;
-    if (cf100) { fc_out = 100; final_pow = ker_wid == 3 ? 7.0 : (ker_wid == 5 ? 6.0 : 5.0); init_pow = 5.0; mid_pow = 5.0; }
+    if (!wide) { if (cf100) { fc_out = 100; final_pow = ker_wid == 3 ? 7.0 : (ker_wid == 5 ? 6.0 : 5.0); init_pow = 5.0; mid_pow = 5.0; } }
+    else {                                                                                               // test.go:645-665
+        init_pow = mid_pow = final_pow = ker_wid == 5 ? 6.0 : 5.0;
+        if (cf100) { fc_out = 100; final_pow = 7.0; init_pow = 5.0; mid_pow = 5.0; if (ker_wid == 5 && depth == 8) { init_pow = 6.0; final_pow = 6.0; } }
+    }
     int num_blcs[3];
     if (depth == 20) { num_blcs[0] = 7; num_blcs[1] = 5; num_blcs[2] = 5; } else if (depth == 14) { num_blcs[0] = 5; num_blcs[1] = 3; num_blcs[2] = 3; }
     else if (depth == 8) { num_blcs[0] = 3; num_blcs[1] = 1; num_blcs[2] = 1; } else panic("wrong depth (not in 8, 14, 20)!");
-    const int real_batch[3] = {16, 32, 64}, norm[3] = {4, 8, 16};
+    const int init_batch = 16;                                                                           // test.go:667
+    const int real_batch[3] = {wide ? 32 : 16, wide ? 64 : 32, wide ? 128 : 64}, norm[3] = {wide ? 2 : 4, wide ? 4 : 8, wide ? 8 : 16};
+    const int log_sparse[3] = {wide ? 1 : 2, wide ? 2 : 3, wide ? 3 : 4};
     const int logN = 16; const double alpha = 0.0;
     const std::vector<int> in_wids = {32, 16, 8}, raw_in_wids = {32 - ker_wid / 2, 16 - ker_wid / 2, 8 - ker_wid / 2};
     const int ker_size = ker_wid * ker_wid;
     int max_batch[3]; for (int i = 0; i < 3; i++) max_batch[i] = (1 << logN) / (in_wids[(size_t)i] * in_wids[(size_t)i]);
-    Context *cont = newContext(logN, ker_wid, in_wids, raw_in_wids, true, "Resnet_crop_sparse");
+    Context *cont = newContext(logN, ker_wid, in_wids, raw_in_wids, true, wide ? "Resnet_crop_sparse_wide2" : "Resnet_crop_sparse");
     mkdir("Resnet_enc_results", 0755); mkdir(out_dir.c_str(), 0755);
     auto W = [&](int i, const char *what, int size) { return readTxt(weight_dir + "w" + std::to_string(i) + "-" + what + ".csv", size); };
 
@@ -136,32 +145,38 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
 
         double pow_ = init_pow;                                                                          // ResNet Block 1
         for (int i = 1; i <= num_blcs[0]; i++) {
-            const int ker_in_batch = i == 1 ? 3 : real_batch[0];
-            step(evalConv_BNRelu_new(cont, ct_layer, W(i - 1, "conv", ker_in_batch * real_batch[0] * ker_size), W(i - 1, "a", real_batch[0]), W(i - 1, "b", real_batch[0]),
-                                     alpha, pow_, in_wids[0], raw_in_wids[0], ker_wid, ker_in_batch, real_batch[0], norm[0], 2, "Conv_sparse"));
-            pow_ = mid_pow;
+            if (wide && i == 5) pow_ = mid_pow;                                                          // test.go:742-744
+            // wide: 3 -> init_batch -> real_batch[0] over the first two layers (test.go:745-763); narrow: init_batch == real_batch[0]
+            const int ib = i == 1 ? 3 : (wide && i == 2 ? init_batch : real_batch[0]), ob = wide && i == 1 ? init_batch : real_batch[0];
+            step(evalConv_BNRelu_new(cont, ct_layer, W(i - 1, "conv", ib * ob * ker_size), W(i - 1, "a", ob), W(i - 1, "b", ob),
+                                     alpha, pow_, in_wids[0], raw_in_wids[0], ker_wid, ib, ob, norm[0], log_sparse[0], "Conv_sparse"));
+            if (!wide) pow_ = mid_pow;
             printf("Block1, Layer  %d done!\n", i);
         }
         printf("Block1 done.\n"); timings[0] = secs(start); start = now();
         step(evalConv_BNRelu_new(cont, ct_layer, W(num_blcs[0], "conv", real_batch[0] * real_batch[1] * ker_size), W(num_blcs[0], "a", real_batch[1]), W(num_blcs[0], "b", real_batch[1]),
-                                 alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], real_batch[1], norm[1], 1, "StrConv_sparse"));           // test.go:200
+                                 alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], real_batch[1], norm[1], log_sparse[0] - 1, "StrConv_sparse"));           // test.go:200, 791
         printf("Block1 to 2 done!\n"); timings[1] = secs(start); start = now();
         for (int i = 1; i <= num_blcs[1]; i++) {                                                         // ResNet Block 2
+            if (wide && i == 5) pow_ = init_pow;                                                         // test.go:819-821
             const int w = num_blcs[0] + i;
             step(evalConv_BNRelu_new(cont, ct_layer, W(w, "conv", real_batch[1] * real_batch[1] * ker_size), W(w, "a", real_batch[1]), W(w, "b", real_batch[1]),
-                                     alpha, pow_, in_wids[1], raw_in_wids[1], ker_wid, real_batch[1], real_batch[1], norm[1], 3, "Conv_sparse"));
+                                     alpha, pow_, in_wids[1], raw_in_wids[1], ker_wid, real_batch[1], real_batch[1], norm[1], log_sparse[1], "Conv_sparse"));
             printf("Block2, Layer  %d done!\n", i);
         }
         printf("Block2 done.\n"); timings[2] = secs(start); start = now();
+        if (wide) pow_ = mid_pow;                                                                        // test.go:833
         { const int w = num_blcs[0] + num_blcs[1] + 1;
           step(evalConv_BNRelu_new(cont, ct_layer, W(w, "conv", real_batch[1] * real_batch[2] * ker_size), W(w, "a", real_batch[2]), W(w, "b", real_batch[2]),
-                                   alpha, pow_, in_wids[1], raw_in_wids[2], ker_wid, real_batch[1], real_batch[2], norm[2], 2, "StrConv_sparse")); }               // test.go:225
+                                   alpha, pow_, in_wids[1], raw_in_wids[2], ker_wid, real_batch[1], real_batch[2], norm[2], log_sparse[1] - 1, "StrConv_sparse")); }               // test.go:225, 838
         printf("Block2 to 3 done!\n"); timings[3] = secs(start); start = now();
         for (int i = 1; i <= num_blcs[2]; i++) {                                                         // ResNet Block 3
             const int w = num_blcs[0] + num_blcs[1] + i + 1;
+            if (wide && i == 3) pow_ = init_pow;                                                         // test.go:845-850
+            if (wide && i == 5) pow_ = mid_pow;
             if (i == num_blcs[2]) pow_ = final_pow;
             step(evalConv_BNRelu_new(cont, ct_layer, W(w, "conv", real_batch[2] * real_batch[2] * ker_size), W(w, "a", real_batch[2]), W(w, "b", real_batch[2]),
-                                     alpha, pow_, in_wids[2], raw_in_wids[2], ker_wid, real_batch[2], real_batch[2], norm[2], 4, "Conv_sparse"));
+                                     alpha, pow_, in_wids[2], raw_in_wids[2], ker_wid, real_batch[2], real_batch[2], norm[2], log_sparse[2], "Conv_sparse"));
             printf("Block3, Layer  %d done!\n", i);
         }
         printf("Block3 done.\n"); timings[4] = secs(start); start = now();
@@ -170,7 +185,7 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
         std::vector<double> ker_inf = readTxt(weight_dir + "final-fckernel.csv", real_batch[2] * fc_out);
         std::vector<double> bn_bf = readTxt(weight_dir + "final-fcbias.csv", fc_out), res_out;
         Ciphertext ct_result, ct_result2;
-        if (cf100) {                                                                                     // test.go:287-315: two convolutions of fc_out/2 outputs
+        if (cf100 && !wide) {                                                                            // test.go:287-315: two convolutions of fc_out/2 outputs (the wide driver keeps one: test.go:865-882)
             const int ho = fc_out / 2; const size_t tap = (size_t)real_batch[2] * ho;
             std::vector<double> k1((size_t)(ker_inf_wid * ker_inf_wid) * tap), k2(k1.size());
             for (int i = 0; i < ho; i++) for (int j = 0; j < real_batch[2]; j++) for (int b = 0; b < ker_inf_wid * ker_inf_wid; b++) {
@@ -188,7 +203,7 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
         }
         printf("Final FC done.\n"); timings[5] = secs(start); start = now();
         printf("\n===============  DECRYPTION  ===============\n\n");
-        if (cf100) {
+        if (cf100 && !wide) {
             std::vector<double> r1 = DecryptDecodeCoeffs(cont, ct_result), r2 = DecryptDecodeCoeffs(cont, ct_result2);
             printf("Decryption Done in %s \n", dur(start).c_str());
             std::vector<double> o1 = prt_mat_one_norm(r1, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1), o2 = prt_mat_one_norm(r2, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1);

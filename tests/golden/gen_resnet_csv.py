@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Synthetic inputs for `resnet <ker> <depth> 1 <n> false` in the reference's file layout (test.go:78-80,128,171-183,285,329):
+"""Synthetic inputs for `resnet <ker> <depth> <wide_case 1|2> <n> false` in the reference's file layout (test.go:78-80,128,171-183,285,329):
   Resnet_weights/weights_crop_ker{k}_d{depth}_wid1/w{i}-conv.csv (HWIO flat), w{i}-a.csv, w{i}-b.csv, final-fckernel.csv, final-fcbias.csv
   Resnet_plain_data/crop_ker{k}_d{depth}_wid1/test_image_{iter}.csv  (32 x 32 x 3, HWC; only the raw window is read)
 plus what the plain float model of the same network outputs: Resnet_plain_data/.../expected_scores_{iter}.csv.
@@ -13,9 +13,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle_resnet as rn  # noqa: E402
 
 
-def write_case(root, ker_wid=3, depth=8, n_images=1, seed=0, cf100=False):
-    net = rn.Net(16, ker_wid=ker_wid, depth=depth, seed=seed, fc_out=100 if cf100 else 10)
-    tag = ("cf100_" if cf100 else "") + f"crop_ker{ker_wid}_d{depth}_wid1"
+def write_case(root, ker_wid=3, depth=8, n_images=1, seed=0, cf100=False, wide=1):
+    net = rn.Net(16, ker_wid=ker_wid, depth=depth, seed=seed, fc_out=100 if cf100 else 10, wide=wide)
+    tag = ("cf100_" if cf100 else "") + f"crop_ker{ker_wid}_d{depth}_wid{wide}"
     wdir, pdir = os.path.join(root, "Resnet_weights", "weights_" + tag), os.path.join(root, "Resnet_plain_data", tag)
     os.makedirs(wdir, exist_ok=True)
     os.makedirs(pdir, exist_ok=True)
@@ -41,5 +41,6 @@ def write_case(root, ker_wid=3, depth=8, n_images=1, seed=0, cf100=False):
 if __name__ == "__main__":
     root, k, d, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     cf100 = len(sys.argv) > 5 and sys.argv[5] in ("true", "1")
-    for sc, amax in write_case(root, k, d, n, cf100=cf100):
+    wide = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+    for sc, amax in write_case(root, k, d, n, cf100=cf100, wide=wide):
         print("scores", np.round(sc, 4), "max |activation|", amax)

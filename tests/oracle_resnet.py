@@ -92,10 +92,13 @@ class Net:
     """shapes of testResNet_crop_sparse for a ring of 2^logN (logN = 16 is the reference's network; smaller rings scale the
     widths down and keep batch x norm = N / width^2)"""
 
-    def __init__(self, logN, ker_wid=3, depth=8, fc_out=10, seed=0):
-        self.logN, self.k, self.fc_out = logN, ker_wid, fc_out
+    def __init__(self, logN, ker_wid=3, depth=8, fc_out=10, seed=0, wide=1):
+        self.logN, self.k, self.fc_out, self.wide = logN, ker_wid, fc_out, wide
         shapes = {16: ((32, 16, 8), (16, 32, 64)), 14: ((16, 8, 4), (16, 32, 64)), 12: ((16, 8, 4), (4, 8, 16))}
         self.in_wids, self.real_batch = [list(t) for t in shapes[logN]]
+        if wide == 2:       # testResNet_crop_sparse_wide, wide_case 2 (test.go:681-684): twice the channels, first layer 3 -> 16 -> 32
+            assert logN == 16
+            self.real_batch = [32, 64, 128]
         self.raw = [w - ker_wid // 2 for w in self.in_wids]
         self.max_batch = [(1 << logN) // (w * w) for w in self.in_wids]
         self.norm = [m // r for m, r in zip(self.max_batch, self.real_batch)]
@@ -109,8 +112,8 @@ class Net:
                 cout = self.real_batch[blk]
                 self.layers.append(("StrConv_sparse", blk - 1, self._w(rng, k, cin, cout), rng.uniform(0.8, 1.2, cout), rng.uniform(-0.1, 0.1, cout)))
                 cin = cout
-            for _ in range(self.blocks[blk] - (0 if blk == 0 else 0)):
-                cout = self.real_batch[blk]
+            for li in range(self.blocks[blk]):
+                cout = 16 if (wide == 2 and blk == 0 and li == 0) else self.real_batch[blk]      # init_batch = 16 (test.go:667)
                 self.layers.append(("Conv_sparse", blk, self._w(rng, k, cin, cout), rng.uniform(0.8, 1.2, cout), rng.uniform(-0.1, 0.1, cout)))
                 cin = cout
         self.fc_w = rng.uniform(-1, 1, (cin, fc_out)) / np.sqrt(cin)

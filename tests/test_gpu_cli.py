@@ -68,20 +68,20 @@ def test_conv_relu_cli(tmp_path, k, i_batch):
     assert meds[1] >= 10.5 and avgs[1] >= 7.5, txt
 
 
-@pytest.mark.parametrize("cf100", [False, True])
-def test_resnet_cli_depth8(tmp_path, cf100):
+@pytest.mark.parametrize("cf100,wide", [(False, 1), (True, 1), (False, 2)])
+def test_resnet_cli_depth8(tmp_path, cf100, wide):
     """`resnet 3 8 1 1 false` (scope row 8f-3; the reference's depth-8 variant of BASELINE.md config 5): encrypted inference with
     synthetic weights in the reference's file layout; the class scores must follow the plain float model of the same network"""
     import numpy as np
     import golden.gen_resnet_csv as rgen
-    (want, _), = rgen.write_case(str(tmp_path), 3, 8, 1, cf100=cf100)
-    out = subprocess.run([CLI, "resnet", "3", "8", "1", "1", "true" if cf100 else "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
+    (want, _), = rgen.write_case(str(tmp_path), 3, 8, 1, cf100=cf100, wide=wide)     # wide = 2: testResNet_crop_sparse_wide (test.go:638), first stride layer on full packing
+    out = subprocess.run([CLI, "resnet", "3", "8", str(wide), "1", "true" if cf100 else "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
                          env=dict(os.environ, HCONV_SEED="11"))
     assert out.returncode == 0, out.stderr[-2000:]
     print(out.stdout[-1500:])
     for pat in (r"^Block1, Layer  3 done!$", r"^Block1 to 2 done!$", r"^Block2 to 3 done!$", r"^Block3 done\.$", r"^Final FC done\.$", r"^Total done in \S+ $"):
         assert re.search(pat, out.stdout, re.M), pat
-    got = np.loadtxt(tmp_path / "Resnet_enc_results" / (("results_cf100_" if cf100 else "results_") + "crop_ker3_d8_wid1") / "class_result_ker3_0.csv")
+    got = np.loadtxt(tmp_path / "Resnet_enc_results" / (("results_cf100_" if cf100 else "results_") + f"crop_ker3_d8_wid{wide}") / "class_result_ker3_0.csv")
     assert got.shape == ((100,) if cf100 else (10,))                                         # cf100: two final convolutions (test.go:287-315)
     if not cf100:
         assert got.argmax() == want.argmax()
