@@ -72,6 +72,8 @@ int hc_mul_const(hc_ctx *ctx, int mod, const uint64_t *a, uint64_t c, uint64_t *
 uint64_t hc_const_for(double constant, double q_level_as_f64, uint64_t q, double *scale_mult);
 /* ring.DivRoundByLastModulusNTT, one drop: x = (level+1) rows, out = level rows (inside Rescale/SetScale) */
 int hc_div_round_last(hc_ctx *ctx, int level, const uint64_t *x, uint64_t *out);
+/* the same drop on both polynomials of a ciphertext in one set of launches (evaluator.Rescale; x0 / x1 need not be adjacent) */
+int hc_div_round_last2(hc_ctx *ctx, int level, const uint64_t *x0, const uint64_t *x1, uint64_t *out0, uint64_t *out1);
 /* ring.PermuteNTTWithIndexLvl with ring.PermuteNTTIndex(galEl) (inside RotateGal, conv.go:291) */
 int hc_permute(hc_ctx *ctx, uint64_t galEl, const uint64_t *in, uint64_t *out, int count);
 

@@ -33,6 +33,7 @@ SYMBOLS = {
     "hc_mul_const": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]),
     "hc_const_for": (C.c_uint64, [C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_double)]),
     "hc_div_round_last": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "hc_div_round_last2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_permute": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]),
     "hc_evk_load": (C.c_int, [C.c_void_p, C.c_uint64, u64p, u64p, u64p, u64p]),
     "hc_keyswitch_l0": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -224,6 +225,16 @@ class Context:
         sm = C.c_double(0)
         v = self.L.hc_const_for(constant, float(q_level), C.c_uint64(q), C.byref(sm))
         return int(v), sm.value
+
+    def div_round_last2(self, level, x0, x1):
+        """both polynomials of a ciphertext in one set of launches (separate allocations, as the host side holds them)"""
+        srcs = [self.buf(np.ascontiguousarray(x, dtype=np.uint64).reshape(level + 1, self.N)) for x in (x0, x1)]
+        dsts = [self.buf(nwords=level * self.N) for _ in range(2)]
+        self._ck(self.L.hc_div_round_last2(self.h, level, srcs[0].ptr, srcs[1].ptr, dsts[0].ptr, dsts[1].ptr))
+        out = [d.download((level, self.N)) for d in dsts]
+        for b in srcs + dsts:
+            b.free()
+        return out
 
     def div_round_last(self, level, x):
         x = np.ascontiguousarray(x, dtype=np.uint64).reshape(level + 1, self.N)

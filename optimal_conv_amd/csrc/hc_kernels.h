@@ -906,14 +906,17 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_mm(const u64 *acc, siz
         o[j] = hc_mul_shoup(hc_submod(a[j], x[j], q), pi.w, pi.ws, q);
 }
 // general-level DivRoundByLastModulusNTT, all lower limbs per launch: lift (v[i] from t) and finish (out[i] = (x[i]-u[i]) * qL^-1)
+// blockIdx.z = polynomial (a ciphertext's two polynomials in one launch; xs / os = distance between them in words, modulo 2^64)
 __global__ __launch_bounds__(HC_TPB) void hc_k_rescale_lift_mm(const u64 *t, u64 *v, const HcMod *mods, int level) {
     const int i = blockIdx.y; const u64 qL = mods[level].q, h = (qL - 1) >> 1, qi = mods[i].q, mu_i = mods[i].mu, neg_h = qi - (h % qi);
+    t += (size_t)blockIdx.z * 65536; v += (size_t)blockIdx.z * level * 65536;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
         v[(size_t)i * 65536 + j] = hc_barrett64(hc_csub(t[j] + h, qL) + neg_h, qi, mu_i);
 }
-__global__ __launch_bounds__(HC_TPB) void hc_k_rescale_finish_mm(const u64 *x, const u64 *u, u64 *out, const HcMod *mods, const HcTw *qlinv) {
+__global__ __launch_bounds__(HC_TPB) void hc_k_rescale_finish_mm(const u64 *x, size_t xs, const u64 *u, size_t us, u64 *out, size_t os, const HcMod *mods, const HcTw *qlinv) {
     const int i = blockIdx.y; const u64 q = mods[i].q; const HcTw w = qlinv[i];
     const size_t b = (size_t)i * 65536;
+    x += (size_t)blockIdx.z * xs; u += (size_t)blockIdx.z * us; out += (size_t)blockIdx.z * os;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
         out[b + j] = hc_mul_shoup(hc_submod(x[b + j], u[b + j], q), w.w, w.ws, q);
 }

@@ -401,9 +401,9 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
     A.zs_in = zt; A.zs_out = zs_out; HC_TRY(hc_launch(c, "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
-static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out) {
+static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out, int skip_lo = 0, int skip_hi = 0) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z));
-    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = A.skip_hi = 0; A.z_alpha = 0;
+    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = 0;
     const dim3 grid(16, (unsigned)rows, (unsigned)z); const size_t zt = (size_t)rows * HC_N;
     A.zs_in = zs_in; A.zs_out = zt; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, in, c->ws_tmp, A));
     A.zs_in = zt; A.zs_out = zs_out; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
@@ -511,8 +511,7 @@ static int hc_loopA_run(hc_ctx *c, const u64 *ker_mont, int max_ob, int norm, u6
 }
 
 // hc_div_round_last (level 1 only on this path): reuse loop A with ker = Montgomery one (c' (*) R = c')
-extern "C" int hc_div_round_last(hc_ctx *c, int level, const uint64_t *x, uint64_t *out) {
-    HC_ENTER(c);
+static int hc_div_round_last_n(hc_ctx *c, int level, const u64 *x, size_t xs, u64 *out, size_t os, int np) {
     if (level < 1 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "hc_div_round_last: level %d outside 1..%d", level, c->nq - 1);
     if (!x || !out) return hc_fail(c, HC_ERR_ARG, "hc_div_round_last: null");
     if (level != 1) {
@@ -527,14 +526,17 @@ extern "C" int hc_div_round_last(hc_ctx *c, int level, const uint64_t *x, uint64
             HC_HIP(c, hipMemcpy(d, h.data(), h.size() * sizeof(HcTw), hipMemcpyHostToDevice));
             it = c->rescale_plan.emplace(level, d).first;
         }
-        HC_TRY(hc_ensure_mm(c, (size_t)level + 1));
+        // np polynomials per launch (blockIdx.z): x, x + xs and out, out + os (distances in words, modulo 2^64)
+        HC_TRY(hc_ensure_mm(c, (size_t)np * (level + 1)));
         c->hoist_cx = nullptr;                                   // the scratch is shared with the key switch's decomposition
-        u64 *t = c->ws_mm, *v = c->ws_mm + HC_N;
-        HC_TRY(hc_intt(c, level, x + (size_t)level * HC_N, t, 1));
-        HC_TRY(hc_launch(c, "rescale_lift_mm", hc_k_rescale_lift_mm, dim3(64, (unsigned)level), (const u64 *)t, v, (const HcMod *)c->d_mods, level));
-        HC_TRY(hc_ntt_mm(c, v, v, level, level, 0, 0, 1, 0, 0));
-        return hc_launch(c, "rescale_finish_mm", hc_k_rescale_finish_mm, dim3(64, (unsigned)level), x, (const u64 *)v, out, (const HcMod *)c->d_mods, (const HcTw *)it->second);
+        u64 *t = c->ws_mm, *v = c->ws_mm + (size_t)np * HC_N;
+        // InvNTT of the last limb of every polynomial: the multi-modulus kernels over rows 0..level with rows below `level` skipped
+        HC_TRY(hc_intt_mm(c, x, t - (size_t)level * HC_N, level + 1, level + 1, np, xs, (size_t)HC_N, 0, level));
+        HC_TRY(hc_launch(c, "rescale_lift_mm", hc_k_rescale_lift_mm, dim3(64, (unsigned)level, (unsigned)np), (const u64 *)t, v, (const HcMod *)c->d_mods, level));
+        HC_TRY(hc_ntt_mm(c, v, v, level, level, 0, 0, np, (size_t)level * HC_N, (size_t)level * HC_N));
+        return hc_launch(c, "rescale_finish_mm", hc_k_rescale_finish_mm, dim3(64, (unsigned)level, (unsigned)np), x, xs, (const u64 *)v, (size_t)level * HC_N, out, os, (const HcMod *)c->d_mods, (const HcTw *)it->second);
     }
+    if (np != 1) { HC_TRY(hc_div_round_last_n(c, level, x, 0, out, 0, 1)); return hc_div_round_last_n(c, level, x + xs, 0, out + os, 0, 1); }
     // Build a "ciphertext" whose polynomial 0 is x and a kernel equal to R mod q (Montgomery form of 1).
     HC_TRY(hc_ensure_tmp(c, 16));
     if (!c->ws_ctc) HC_HIP(c, hipMalloc((void **)&c->ws_ctc, 4 * HC_N * sizeof(u64)));
@@ -549,6 +551,14 @@ extern "C" int hc_div_round_last(hc_ctx *c, int level, const uint64_t *x, uint64
     if (!rc) { hipMemcpyAsync(out, cts, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); hipStreamSynchronize(c->stream); }
     hipFree(scratch);
     return rc;
+}
+extern "C" int hc_div_round_last(hc_ctx *c, int level, const uint64_t *x, uint64_t *out) { HC_ENTER(c); return hc_div_round_last_n(c, level, x, 0, out, 0, 1); }
+// evaluator.Rescale's one drop on both polynomials of a ciphertext (they may live in separate allocations): same residues as two
+// hc_div_round_last calls, half the launches -- the last limb's inverse transform is a 16-workgroup launch whose cost is latency
+extern "C" int hc_div_round_last2(hc_ctx *c, int level, const uint64_t *x0, const uint64_t *x1, uint64_t *out0, uint64_t *out1) {
+    HC_ENTER(c);
+    if (!x0 || !x1 || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_div_round_last2: null");
+    return hc_div_round_last_n(c, level, x0, (size_t)(x1 - x0), out0, (size_t)(out1 - out0), 2);
 }
 
 // ------------------------------------------------------------------ evk / idx / ker loading

@@ -227,7 +227,8 @@ struct Boot {
     DCt rescale(const DCt &a) {                                     // one DivRoundByLastModulusNTT
         if (a.level < 1) panic("rescale at level 0");
         DCt r = new_ct(a.level - 1, a.deg, a.scale / (double)Q[(size_t)a.level]);
-        for (int d = 0; d <= a.deg; d++) HCR(hc_div_round_last(hc, a.level, a.p[d].get(), r.p[d].get()));
+        if (a.deg == 1) HCR(hc_div_round_last2(hc, a.level, a.p[0].get(), a.p[1].get(), r.p[0].get(), r.p[1].get()));     // both polynomials per launch
+        else for (int d = 0; d <= a.deg; d++) HCR(hc_div_round_last(hc, a.level, a.p[d].get(), r.p[d].get()));
         return r;
     }
     DCt galois(const DCt &a, uint64_t gal) {                       // evaluator.permuteNTT: key switch c1, + c0, permute both
@@ -686,6 +687,19 @@ void freeBoot(Boot *b) {
     hc_ctx_destroy(b->hc); delete b;      // the switching keys are owned by the context
 }
 
+// HCONV_PROFILE=1: per-kernel HIP-event totals of one layer's tail (hc_set_option("profile")) on stderr; event records between
+// launches perturb the stream, so the printed wall times of such a run are not the ones to quote
+static void profile_dump(Boot *B, const char *label) {
+    hc_ctx *hc = B->hc; char names[8192];
+    if (hc_profile_names(hc, names, sizeof names)) return;
+    std::vector<std::pair<double, std::string>> rows; double tot = 0; long nl = 0;
+    for (char *tok = strtok(names, ","); tok; tok = strtok(nullptr, ",")) { double ms = 0; long n = 0; hc_profile_get(hc, tok, &ms, &n); char b[160]; snprintf(b, sizeof b, "%-28s %6ld launches %8.3f ms %7.1f us/launch", tok, n, ms, n ? 1e3 * ms / (double)n : 0.0); rows.push_back({ms, b}); tot += ms; nl += n; }
+    std::sort(rows.rbegin(), rows.rend());
+    fprintf(stderr, "[profile] %s: %ld launches, %.3f ms of kernels\n", label, nl, tot);
+    for (auto &r : rows) fprintf(stderr, "[profile]   %s\n", r.second.c_str());
+    hc_profile_get(hc, nullptr, nullptr, nullptr);
+}
+
 // eval.go:437-565: everything after the convolution(s). ct_conv = the level-0 convolution result at out_scale
 // 2^(round(log2 Q0) - (pow+8)). kind "Conv" (log_sparse 0, two ciphertexts through sine/ReLU, keep_ctxt masks of gen_keep_vec),
 // "Conv_sparse" (one packed ciphertext, gen_keep_vec_sparse), "StrConv_sparse" (one packed ciphertext, ext_double_ctxt with
@@ -698,6 +712,8 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     if (sparse && log_sparse == 0 && !stride) panic("Conv_sparse with full packing (log_sparse 0: the wide_case 3 network) is not built");
     DCt ct = B->new_ct(0, 1, ct_scale * pow(2.0, pow_));                                            // eval.go:437
     for (int d = 0; d < 2; d++) HCR(hc_copy(hc, ct.p[d].get(), ct_conv_dev + (size_t)d * N, (size_t)N * 8));
+    const bool prof = getenv("HCONV_PROFILE") && atoi(getenv("HCONV_PROFILE"));
+    if (prof) { HCR(hc_set_option(hc, "profile", 1)); hc_profile_get(hc, nullptr, nullptr, nullptr); }
     printf("Bootstrapping... Ours (until CtoS):\n");
     auto start = now();
     DCt boots[2]; const int iter = B->ctos(ct, log_sparse, boots);                                     // eval.go:450-461
@@ -720,6 +736,7 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     DCt res = B->stoc(keep[0], iter == 2 ? &keep[1] : nullptr, log_sparse);                              // eval.go:550-561 ; Rescale (564) is a no-op here
     HCR(hc_sync(hc));
     printf("Boot (StoC) Done in %s \n", dur(start).c_str());
+    if (prof) { profile_dump(B, (kind + " log_sparse " + std::to_string(log_sparse)).c_str()); HCR(hc_set_option(hc, "profile", 0)); }
     BootCiphertext out; out.level = res.level; out.Scale = res.scale;
     { void *v = nullptr; HCR(hc_malloc(hc, (size_t)2 * (res.level + 1) * N * 8, &v)); out.d = (uint64_t *)v; }
     for (int d = 0; d < 2; d++) HCR(hc_copy(hc, out.d + (size_t)d * (res.level + 1) * N, res.p[d].get(), (size_t)(res.level + 1) * N * 8));

@@ -355,6 +355,11 @@ def case_ckks_ops(make_ctx, logN=16, seed=3, levels=((23, 2.0 ** 55), (9, 2.0 **
     L = levels[0][0]                                     # acc += a*b in one pass == mul then add
     x, y, z = (Co.encrypt_slots(a, L, 2.0 ** 30, seed=s_).rows[0] for s_ in (31, 32, 33))
     eq(ctx.lv_mul_acc(L, x, y, z), Co.be.lv_add(z, Co.be.lv_mul(x, y)), "lv_mul_acc")
+    for L, _ in levels:                                  # Rescale's drop on both polynomials per launch == per polynomial == oracle
+        ct = Co.encrypt_slots(a, L, 2.0 ** 40, seed=41).rows
+        got = ctx.div_round_last2(L, ct[0], ct[1])
+        for k in range(2):
+            eq(got[k], Co.O.div_round_last(L, ct[k]), f"div_round_last2 level {L} poly {k}")
     ctx.close()
 
 
