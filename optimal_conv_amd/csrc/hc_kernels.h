@@ -872,8 +872,9 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend_mm(const u64 *src, s
             else {
                 u64 acc = 0;
 #pragma unroll
-                for (int i = 0; i < 8; i++) if (i < n) acc = hc_addmod(acc, hc_mul_shoup(hc_barrett64(y[i], B.t, B.mu_t), B.hat[i].w, B.hat[i].ws, B.t), B.t);
-                r = hc_submod(acc, hc_mul_shoup(hc_barrett64(v, B.t, B.mu_t), B.smodt.w, B.smodt.ws, B.t), B.t);
+                // the Shoup product reduces ANY 64-bit multiplicand, so y_i (< s_i, possibly > t) needs no reduction modulo t of its own
+                for (int i = 0; i < 8; i++) if (i < n) acc = hc_addmod(acc, hc_mul_shoup(y[i], B.hat[i].w, B.hat[i].ws, B.t), B.t);
+                r = hc_submod(acc, hc_mul_shoup(v, B.smodt.w, B.smodt.ws, B.t), B.t);
             }
             dst[(size_t)T * 65536 + j] = r;
         }
@@ -896,6 +897,46 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const 
         }
         a[j] = s;
     }
+}
+// The same inner product with the digits' second transform pass inside (the plain, non-hoisted key switch): `half` holds the digits
+// after the cols pass only ([beta][nt][N], what hc_k_cols_fwd_mm wrote); a workgroup owns a 16-row tile of limb T, and for every
+// digit runs the rows pass on its tile (or, on a digit's own limbs, takes the NTT-domain input cx as it is), canonicalises, and
+// accumulates both key components in registers. The transformed digits never travel to HBM and back: per key switch that is
+// 2 * beta * nt rows of traffic less, in a chain whose key switches are bandwidth-bound.
+// grid = (16, nt)
+__global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_mac(const u64 *evk, const u64 *cx, const u64 *half, u64 *acc, const HcRowMod *M, const HcMod *mods, int nl, int nq, int nt, int alpha, int beta) {
+    __shared__ u64 lds[HC_ROWS_LDS];
+    const int T = blockIdx.y, mod = T < nl ? T : nq + (T - nl);
+    const HcRowMod &R = M[mod]; const u64 q = R.q, qinv = mods[mod].qinv;
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
+    const size_t lin = (size_t)T * 65536 + (size_t)blockIdx.x * 4096 + t;          // + k * 256: element (tile row k, column t)
+    u64 a0[16], a1[16], e[16];
+    for (int d = 0; d < beta; d++) {
+        const int lo = d * alpha, hi = lo + alpha < nl ? lo + alpha : nl;
+        const u64 *kb = evk + ((size_t)d * 2 * nt) * 65536 + lin, *ka = kb + (size_t)nt * 65536;
+        if (T >= lo && T < hi) {                                                   // block-uniform
+#pragma unroll
+            for (int k = 0; k < 16; k++) e[k] = cx[lin + k * 256];
+        } else {
+            const u64 *in = half + ((size_t)d * nt + T) * 65536 + (size_t)row * 256;
+#pragma unroll
+            for (int h = 0; h < 16; h++) e[h] = in[h * 16 + tid];
+            if (d) __syncthreads();                                                // the previous digit's exchange is done with the LDS
+            hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, q);
+            __syncthreads();
+            hc_rows_lo_to_lin(e, lds, t, rloc, tid);
+#pragma unroll
+            for (int k = 0; k < 16; k++) e[k] = hc_fwd_canon<HC_FM_ALT>(e[k], q, R.mu);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u64 p0 = hc_mont(e[k], kb[k * 256], q, qinv), p1 = hc_mont(e[k], ka[k * 256], q, qinv);
+            a0[k] = d == 0 ? p0 : hc_addmod(a0[k], p0, q);
+            a1[k] = d == 0 ? p1 : hc_addmod(a1[k], p1, q);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { acc[lin + k * 256] = a0[k]; acc[(size_t)nt * 65536 + lin + k * 256] = a1[k]; }
 }
 // d_k[l] = (acc[k][l] - ext[k][l]) * P^-1 mod q_l for all limbs l and both k
 __global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_mm(const u64 *acc, size_t acc_zs, const u64 *ext, size_t ext_zs, u64 *d0, u64 *d1, const HcMod *mods, const HcTw *pinv) {

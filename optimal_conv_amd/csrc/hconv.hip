@@ -95,6 +95,7 @@ struct hc_ctx {
     // hipGraph replay of a whole conv_then_pack (option "graph"): the launch list of a conv is static for fixed buffers and
     // constants, so the second call with the same arguments is captured once and later calls are one graph launch
     long use_graph = 0;
+    long ks_fused = 0;                                      // plain key switch with the digits' second transform pass inside the inner product (hc_k_rows_fwd_mac): measured 3 % slower per ResNet image (202 VGPRs, a serial loop over the digits), so off
     struct GraphKey { const void *ct_in, *ker, *bias; void *ct_out; int max_ob, norm; u64 c0, c1; long chunk;
         bool operator<(const GraphKey &o) const { return memcmp(this, &o, sizeof *this) < 0; } };
     struct GraphVal { int seen = 0; void *exec = nullptr; };
@@ -393,11 +394,12 @@ extern "C" int hc_lv_sub(hc_ctx *c, int level, const uint64_t *a, const uint64_t
 extern "C" int hc_lv_mul_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_MULC>(c, "hc_lv_mul_const", level, a, nullptr, out, consts); }
 extern "C" int hc_lv_add_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_ADDC>(c, "hc_lv_add_const", level, a, nullptr, out, consts); }
 // batched transforms over rows of different moduli (row y <-> modulus y < nl ? y : nq + y - nl); z operands zs words apart
-static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0) {
+static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0, bool cols_only = false) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z));
     HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = z_alpha;
     const dim3 grid(16, (unsigned)rows, (unsigned)z); const size_t zt = (size_t)rows * HC_N;
     A.zs_in = zs_in; A.zs_out = zt; HC_TRY(hc_launch(c, "cols_fwd_mm", hc_k_cols_fwd_mm, grid, in, c->ws_tmp, A));
+    if (cols_only) return HC_OK;                                  // the caller's next kernel runs the rows pass itself, from ws_tmp ([z][rows][N])
     A.zs_in = zt; A.zs_out = zs_out; HC_TRY(hc_launch(c, "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
@@ -899,19 +901,21 @@ static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
 }
 // phase 1 (rlwe.KeySwitcher.DecomposeNTT / ring.Decomposer.DecomposeAndSplit): digits[d][T] = the d-th digit of cx extended to limb
 // T (Q limbs 0..level, then the P limbs), NTT domain; a digit's own limbs are not written (phase 2 reads cx there)
-static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, u64 *coef, u64 *digits) {
+static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, u64 *coef, u64 *digits, bool half = false) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
     HC_TRY(hc_intt_mm(c, cx, coef, nl, nl, 1, 0, 0));                                                    // cxInvNTT, all limbs
     // every digit at once (blockIdx.z = digit): extension of the digit's residues to all other limbs, then their transforms
     HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(128, 4, (unsigned)beta), (const u64 *)coef, (size_t)HC_N, digits, (const HcBasisExt *)P->bx, nt, 0, 0, (size_t)alpha * HC_N, (size_t)nt * HC_N, alpha, nl));
-    return hc_ntt_mm(c, digits, digits, nt, nl, 0, 0, beta, (size_t)nt * HC_N, (size_t)nt * HC_N, alpha);
+    // half: only the cols pass, into ws_tmp; hc_k_rows_fwd_mac finishes the transform inside the inner product (plain key switch)
+    return hc_ntt_mm(c, digits, digits, nt, nl, 0, 0, beta, (size_t)nt * HC_N, (size_t)nt * HC_N, alpha, half);
 }
 // phase 2: inner product with the key (both components), then ModDownSplitNTTPQ
-static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const u64 *digits, u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1) {
+static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const u64 *digits, u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1, bool half = false) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = key.beta;
-    HC_TRY(hc_launch(c, "ks_mac_all", hc_k_ks_mac_all, dim3(32, (unsigned)nt, 2), (const u64 *)key.rows, cx, digits, acc, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta));
+    if (half) HC_TRY(hc_launch(c, "ks_rows_fwd_mac", hc_k_rows_fwd_mac, dim3(16, (unsigned)nt), (const u64 *)key.rows, cx, (const u64 *)c->ws_tmp, acc, (const HcRowMod *)c->d_rowmods, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta));
+    else HC_TRY(hc_launch(c, "ks_mac_all", hc_k_ks_mac_all, dim3(32, (unsigned)nt, 2), (const u64 *)key.rows, cx, digits, acc, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta));
     // ModDownSplitNTTPQ for both components: InvNTT of the P limbs, {P} -> every Q limb, NTT, (acc - ext) * P^-1
     {   HcMm A; A.M = c->d_rowmods; A.nl = 0; A.nq = c->nq; A.skip_lo = A.skip_hi = 0; A.z_alpha = 0;  // rows y -> modulus nq + y
         HC_TRY(hc_ensure_tmp(c, (size_t)2 * alpha));
@@ -943,9 +947,10 @@ extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_
     const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch", key_id, level, &key));
     if (!cx || !d0 || !d1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch: null");
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
-    HC_TRY(hc_ks_decompose_into(c, level, cx, S.coef, S.digits));
+    const bool half = c->ks_fused != 0;
+    HC_TRY(hc_ks_decompose_into(c, level, cx, S.coef, S.digits, half));
     c->hoist_cx = nullptr;                                   // the scratch no longer holds a hoisted decomposition
-    return hc_ks_apply_from(c, *key, level, cx, S.digits, S.acc, S.pc, S.ext, d0, d1);
+    return hc_ks_apply_from(c, *key, level, cx, S.digits, S.acc, S.pc, S.ext, d0, d1, half);
 }
 // Hoisted key switching (evaluator.RotateHoisted, conv.go:131; the baby steps of a linear transform): the decomposition of cx is
 // computed once and kept in the context; every hc_keyswitch_hoisted with the same (cx, level) then only does the inner product with
@@ -1114,6 +1119,7 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!strcmp(name, "lanes")) { if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "graph")) { c->use_graph = value ? 1 : 0; return HC_OK; }
+    if (!strcmp(name, "ks_fused")) { c->ks_fused = value ? 1 : 0; return HC_OK; }      // plain key switch: rows pass inside the inner product (default off: measured slower)
     return hc_fail(c, HC_ERR_ARG, "unknown option %s", name);
 }
 extern "C" int hc_timer_start(hc_ctx *c) { HC_ENTER(c); HC_HIP(c, hipEventRecord(c->t0, c->stream)); return HC_OK; }
