@@ -18,8 +18,12 @@
 #include <stdlib.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <fstream>
+#include <mutex>
+#include <thread>
 
 #include "hconv_host.hpp"
 
@@ -123,11 +127,20 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
     const std::vector<int> in_wids = {32, 16, 8}, raw_in_wids = {32 - ker_wid / 2, 16 - ker_wid / 2, 8 - ker_wid / 2};
     const int ker_size = ker_wid * ker_wid;
     int max_batch[3]; for (int i = 0; i < 3; i++) max_batch[i] = (1 << logN) / (in_wids[(size_t)i] * in_wids[(size_t)i]);
-    Context *cont = newContext(logN, ker_wid, in_wids, raw_in_wids, true, wide ? "Resnet_crop_sparse_wide2" : "Resnet_crop_sparse");
     mkdir("Resnet_enc_results", 0755); mkdir(out_dir.c_str(), 0755);
     auto W = [&](int i, const char *what, int size) { return readTxt(weight_dir + "w" + std::to_string(i) + "-" + what + ".csv", size); };
+    const char *kind_name = wide ? "Resnet_crop_sparse_wide2" : "Resnet_crop_sparse";
 
-    for (int iter = st; iter < end; iter++) {
+    // HCONV_IMAGE_THREADS=K (not a reference feature): K host threads, each with its own context (keys, bootstrappers, stream),
+    // classify disjoint shares of the images at the same time. A layer's launches are mostly far below one wave of workgroups, so the
+    // images of several streams overlap on the CUs (separate PROCESSES time-slice the device instead: tools/resnet_throughput.py).
+    const int n_threads = std::max(1, std::min(getenv("HCONV_IMAGE_THREADS") ? atoi(getenv("HCONV_IMAGE_THREADS")) : 1, end - st));
+    std::mutex mu; std::condition_variable cv; int ready = 0; std::chrono::steady_clock::time_point t_go;
+    auto run_images = [&](int tix) {
+    Context *cont;
+    { std::lock_guard<std::mutex> g(mu); cont = newContext(logN, ker_wid, in_wids, raw_in_wids, true, kind_name); }      // one at a time: key generation prints and allocates
+    { std::unique_lock<std::mutex> g(mu); if (++ready == n_threads) { t_go = now(); cv.notify_all(); } else cv.wait(g, [&] { return ready == n_threads; }); }
+    for (int iter = st + tix; iter < end; iter += n_threads) {
         printf("Running  %d -th iter... ker size:  %d\n", iter, ker_wid);
         std::vector<double> image = readTxt(img_dir + "test_image_" + std::to_string(iter) + ".csv", in_wids[0] * in_wids[0] * 3);
         std::vector<double> input((size_t)N, 0.0); int k = 0;
@@ -221,7 +234,13 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
         printf("Total done in %s \n", dur(begin_start).c_str());
         freeCt(cont, ct_layer); freeCt(cont, ct_result);
     }
-    freeContext(cont);
+    { std::lock_guard<std::mutex> g(mu); freeContext(cont); }
+    };
+    if (n_threads == 1) { run_images(0); return; }
+    std::vector<std::thread> th; for (int t = 0; t < n_threads; t++) th.emplace_back(run_images, t);
+    for (auto &t : th) t.join();
+    // all contexts were ready at t_go; context release is included in the figure below (a few hipFree), image work dominates
+    printf("All %d images done in %s  (%d image threads)\n", end - st, dur(t_go).c_str(), n_threads);
 }
 
 }  // namespace hconv
