@@ -24,6 +24,12 @@ Q_SET6 = [0x80000000080001, 0x1ffffffea0001, 0x1000000000b00001, 0x1000000000ce0
           0x3ffc0001, 0x40080001, 0x3fac0001, 0x40720001, 0x3f820001, 0x3f760001, 0x40980001, 0x3f5a0001, 0x3f540001, 0x40b00001, 0x40c20001,
           0x80000000440001, 0x7fffffffba0001, 0x80000000500001, 0x7fffffffaa0001, 0x800000005e0001, 0x7fffffff7e0001, 0x7fffffff380001, 0x80000000ca0001,
           0x200000000e0001, 0x20000000140001, 0x20000000280001, 0x1fffffffd80001]
+# ckks.DefaultBootstrapParams[7], the baseline's chain (main.go:54): residual group = levels 0-13, StC 14-15, sine 16-23, CtS 24-27
+Q_SET7 = [0x80000000080001, 0x10000000006e0001,
+          0x3ffc0001, 0x40080001, 0x3fac0001, 0x40720001, 0x3f820001, 0x3f760001, 0x40980001, 0x3f5a0001, 0x3f540001, 0x40b00001, 0x40c20001,
+          0xffffffffffc0001, 0x1000000000b00001, 0x1000000000ce0001,
+          0x80000000440001, 0x7fffffffba0001, 0x80000000500001, 0x7fffffffaa0001, 0x800000005e0001, 0x7fffffff7e0001, 0x7fffffff380001, 0x80000000ca0001,
+          0x200000000e0001, 0x20000000140001, 0x20000000280001, 0x1fffffffd80001]
 P_SET6 = [0x1fffffffffe00001, 0x1fffffffffc80001, 0x1fffffffffb40001, 0x1fffffffff500001, 0x1fffffffff420001]
 LV_CTS_TOP, LV_SINE_TOP, LV_RELU_TOP, LV_STC_TOP = 27, 23, 15, 3
 SIN_K, SIN_DEG, SIN_DOUBLE, MSG_RATIO = 25, 63, 2, 256.0
@@ -323,6 +329,20 @@ class Ckks:
         return Ct(rows, ct.scale / float(self.Q[L]))
 
     # ---- automorphisms
+    def set_scale(self, ct, scale):
+        """evaluator.SetScale: MultByConst(scale / ct.Scale) — a constant with a fractional part is carried times q_level —, Rescale
+        (drop while scale/q_L >= scale/2), then the scale is forced (host/hconv_relu.cpp Boot::set_scale)"""
+        c = scale / ct.scale
+        r = ct
+        if c != 1.0:
+            mult = float(self.Q[ct.level]) if c - float(int(c)) != 0 else 1.0
+            r = self.mul_const_int(ct, int(math.floor(abs(c * mult) + 0.5)) * (-1 if c < 0 else 1))
+            r.scale = ct.scale * mult
+        while r.level > 0 and r.scale / float(self.Q[r.level]) >= scale / 2:
+            r = self.rescale(r)
+        r.scale = scale
+        return r
+
     def _galois(self, ct, gal):
         L = ct.level
         be = self.be
@@ -631,7 +651,11 @@ class Bootstrapper:
     chain and level assignment as parameter set [6]; DFT matrices from the encoder's own butterflies (no bit reversal, so
     slot p holds coefficient bitrev(p)); sine by Chebyshev interpolation of cos(2*pi*(K*u - 1/4)/2^r) and r double angles."""
 
-    def __init__(self, C, cts_groups=(4, 4, 4, 3), stc_groups=(5, 5, 5), log_sparse=0):
+    def __init__(self, C, cts_groups=(4, 4, 4, 3), stc_groups=(5, 5, 5), log_sparse=0, stc_top=LV_STC_TOP, stc_scales=None, sine_out_scale=2.0 ** 30):
+        # stc_top / stc_scales / sine_out_scale: where SlotsToCoeffs sits and at which plaintext scales, and the scale the sine hands over
+        # at. Defaults = Ours on parameter set [6] (levels 3..2: sqrt(q3) twice, then 2^30; sine out at 2^30). The baseline's stock
+        # Bootstrapp on set [7]: stc_top 15, scales (2^40, 2^40), sine out at 2^55 (host/hconv_relu.cpp Boot::build, chain 7).
+        self.stc_top, self.stc_scales, self.sine_out_scale = stc_top, stc_scales, sine_out_scale
         """log_sparse = ls > 0: the message occupies only the coefficients that are multiples of D = 2^ls (sparse packing,
         eval.go "Conv_sparse"): the bootstrapping runs in the subring X^D with n_s = n/D slots (main.go:60-83 btp2..btp5):
         SubSum, the n_s-point DFTs, and BOTH coefficient halves in ONE ciphertext (first half of every 2 n_s slots = low
@@ -683,7 +707,7 @@ class Bootstrapper:
             parts = [C.add(parts[0], C.rotate(parts[1], self.ns))]
         # scale plan: after the double angles the value is sin(2 pi x) ~ 2 pi msg/Q0; relabelled by c_m it must sit at 2^30
         c_m = q0 / (2.0 * np.pi * msg_scale)
-        s_out = 2.0 ** 30 * c_m
+        s_out = self.sine_out_scale * c_m
         lv = LV_SINE_TOP - (SIN_DEG.bit_length())               # level after the Chebyshev evaluation
         s = s_out
         for r in range(SIN_DOUBLE):
@@ -709,15 +733,15 @@ class Bootstrapper:
             ct = ct_re                                             # the (re | im) -> re + i im combination is inside stc[0]
         else:
             ct = C.add(ct_re, C.mul_by_i(ct_im))
-        ct = C.drop_to(ct, LV_STC_TOP)
+        ct = C.drop_to(ct, self.stc_top)
         G = self.stc
-        # level 3 carries all but the last matrix (their plaintext scales multiply to q3), level 2 the last at scale 2^30
+        # Ours: level 3 carries all but the last matrix (their plaintext scales multiply to q3), level 2 the last at scale 2^30
         first = G[:-1]
-        sc = float(C.Q[LV_STC_TOP]) ** (1.0 / len(first))
+        sc, sc_last = self.stc_scales if self.stc_scales is not None else (float(C.Q[self.stc_top]) ** (1.0 / len(first)), 2.0 ** 30)
         for M in first:
             ct = C.linear_transform(ct, M, sc)
         ct = C.rescale(ct)
-        ct = C.rescale(C.linear_transform(ct, G[-1], 2.0 ** 30))
+        ct = C.rescale(C.linear_transform(ct, G[-1], sc_last))
         return ct
 
 
@@ -769,3 +793,37 @@ def conv_relu_tail(C, btp, ct_conv, alpha, pow_, in_wid, kp_wid, stages=None):
         keep.append(keep_ctxt(C, r, gen_keep_vec(C.N // 2, in_wid, kp_wid, ul)))     # eval.go:534
     out = btp.stoc(keep[0], keep[1])                             # eval.go:550
     return out                                                   # Rescale (eval.go:564) is a no-op at level 1, scale 2^30
+
+
+# ------------------------------------------------------------------ the baseline's Bootstrapp + ReLU (test_BL.go:113-168)
+def bl_bootstrapper(C):
+    """the stock Bootstrapp as restated in host/hconv_relu.cpp for parameter set [7] (newBootBL)"""
+    return Bootstrapper(C, stc_top=15, stc_scales=(2.0 ** 40, 2.0 ** 40), sine_out_scale=2.0 ** 55)
+
+
+def bl_boot_relu(C, btp, ct_res, alpha, pow_, msg_ratio=16.0, stages=None):
+    """test_BL.go:113-168 (blBootReLU of host/hconv_relu.cpp): ct_res = the two level-1 slot-encoded convolution results;
+    returns the two level-1, scale-2^30 ciphertexts holding ReLU of their real parts"""
+    c = []
+    for pos in range(2):
+        t = C.add(C.conjugate(ct_res[pos]), ct_res[pos])
+        c.append(C.mul_by_i(t) if pos == 1 else t)
+    ct = C.add(c[0], c[1])
+    ct = Ct(ct.rows, ct.scale * 2.0 ** (pow_ + 2))
+    ct = C.set_scale(ct, 2.0 ** round(math.log2(float(C.Q[0]) / msg_ratio)))
+    assert ct.level == 0
+    halves = btp.ctos(ct)
+    ct_boot = btp.stoc(halves[0], halves[1])
+    if stages is not None:
+        stages["boot"] = [ct_boot.copy()]
+    L = ct_boot.level
+    pl = C.encode_ntt(np.ones(C.n, dtype=np.complex128), L, 2.0 ** 30 * float(C.Q[L]) / ct_boot.scale)
+    ct_boot = C.rescale(C.mul_plain(ct_boot, pl, 2.0 ** 30 * float(C.Q[L]) / ct_boot.scale))
+    ct_boot.scale = 2.0 ** 30
+    ci = C.conjugate(ct_boot)
+    res = [C.add(ct_boot, ci), C.mul_by_i(C.sub(ci, ct_boot))]
+    out = []
+    for pos in range(2):
+        r = C.mul_const_int(eval_relu(C, res[pos], alpha), 1 << int(pow_))
+        out.append(C.set_scale(r, 2.0 ** 30))
+    return out

@@ -427,3 +427,29 @@ def case_conv_relu_tail(make_ctx, logN=16, seed=3, min_bits=8.0):
     assert bits >= min_bits, bits
     ctx.close()
     return bits
+
+
+def case_bl_boot_relu(make_ctx, logN=16, seed=5, min_bits=9.0):
+    """the baseline half of convReLU after its convolutions (test_BL.go:113-168: conjugate / imaginary packing, SetScale, the stock
+    Bootstrapp on parameter set [7], all-ones plaintext, unpacking, ReLU, SetScale) on the device ABI vs the oracle backend: the
+    bootstrapped ciphertext and both results bit-identical, decrypted result close to max(x, 0)"""
+    import oracle_ckks as ck
+    Co = ck.Ckks(logN=logN, Q=ck.Q_SET7, seed=seed, h=192 if logN >= 14 else 32)
+    ctx = make_ctx(Co.Q, Co.P)
+    Cd = ck.Ckks(logN=logN, Q=ck.Q_SET7, seed=seed, h=192 if logN >= 14 else 32, backend=CkksDeviceBackend(ctx), oracle=Co.O)
+    Cd.keys = Co.keys
+    rng = np.random.default_rng(seed)
+    x = [rng.uniform(-1, 1, Co.n), rng.uniform(-1, 1, Co.n)]
+    cts = [Co.encrypt_slots(x[k].astype(np.complex128), 1, 2.0 ** 60, seed=70 + k) for k in range(2)]     # the convolutions leave scale 2^60 at level 1
+    st_o, st_d = {}, {}
+    want = ck.bl_boot_relu(Co, ck.bl_bootstrapper(Co), cts, 0.0, 4.0, stages=st_o)
+    got = ck.bl_boot_relu(Cd, ck.bl_bootstrapper(Cd), cts, 0.0, 4.0, stages=st_d)
+    eq(st_d["boot"][0].rows, st_o["boot"][0].rows, "baseline Bootstrapp")
+    for k in range(2):
+        eq(got[k].rows, want[k].rows, f"baseline ReLU result {k}")
+        assert got[k].level == 1 and got[k].scale == 2.0 ** 30
+        dec = Co.decrypt_slots(got[k]).real
+        err = np.abs(dec - np.maximum(x[k], 0))
+        bits = -np.log2(np.median(err) + 1e-30)
+        assert bits >= min_bits, f"baseline ReLU half {k}: median precision {bits:.2f} bits"
+    ctx.close()

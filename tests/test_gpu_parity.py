@@ -240,6 +240,13 @@ def test_conv_relu_tail_on_gpu():
     print("median precision bits", bits)
 
 
+def test_baseline_boot_relu_on_gpu():
+    """the baseline half of convReLU (test_BL.go:113-168: imaginary packing, SetScale, stock Bootstrapp over parameter set [7], ReLU
+    from level 12, SetScale) through the C ABI vs the oracle backend at full size: bootstrapped ciphertext and both results bit for bit"""
+    from optimal_conv_amd import Context
+    pc.case_bl_boot_relu(lambda Q, P: Context(Q, P))
+
+
 @pytest.mark.parametrize("log_sparse", [2])
 def test_conv_relu_tail_sparse_on_gpu(log_sparse):
     """scope row 8f-3 groundwork: the "Conv_sparse" tail (sparse-slot bootstrapping of the ResNet layers, log_sparse 2 = block 1)

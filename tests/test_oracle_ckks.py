@@ -100,3 +100,21 @@ def test_conv_relu_tail_sparse_small_ring(C, ls):
     err = np.abs(C.decrypt_coeffs(out) - want)
     assert -np.log2(np.median(err[::D])) >= 8.0
     assert np.max(err.reshape(-1, D)[:, 1:]) < 1e-3
+
+
+def test_baseline_bootstrapp_relu_small_ring():
+    """the baseline half of convReLU (test_BL.go:113-168) on parameter set [7], oracle side, N = 2^10: two slot-encoded level-1
+    ciphertexts -> imaginary packing, SetScale, stock Bootstrapp (StC at levels 15-14 right after the sine), ReLU from level 12"""
+    C = ck.Ckks(logN=10, Q=ck.Q_SET7, h=32)
+    rng = np.random.default_rng(9)
+    x = [rng.uniform(-1, 1, C.n) for _ in range(2)]
+    cts = [C.encrypt_slots(x[k] + 0j, 1, 2.0 ** 60, seed=30 + k) for k in range(2)]
+    st = {}
+    out = ck.bl_boot_relu(C, ck.bl_bootstrapper(C), cts, 0.0, 4.0, stages=st)
+    assert st["boot"][0].level == 13
+    packed = (x[0] + 1j * x[1]) / 32.0                       # (a + conj a) = 2 Re at a scale relabelled by 2^(pow+2) = 64
+    assert np.max(np.abs(C.decrypt_slots(st["boot"][0]) - packed)) < 2e-4
+    for k in range(2):
+        assert out[k].level == 1 and out[k].scale == 2.0 ** 30
+        err = np.abs(C.decrypt_slots(out[k]).real - np.maximum(x[k], 0))
+        assert -np.log2(np.median(err)) >= 8.0
