@@ -27,8 +27,7 @@ int main(int argc, char **argv) {
         if (argc < 7) hconv::panic("runtime error: index out of range (usage: resnet <ker_wid> <depth> <wide_case> <test_num> <cf100>)");
         const int depth = atoi(argv[3]), wide_case = atoi(argv[4]), test_num = atoi(argv[5]);
         const bool cf100 = std::string(argv[6]) == "true" || std::string(argv[6]) == "1";
-        if (wide_case == 3) hconv::panic("resnet: wide_case 3 (48/96/192 channels, StrConv_sparse_full) is not built in this engine");
-        if (wide_case != 1 && wide_case != 2) hconv::panic("Wrong wide case!");                            // main.go:628
+        if (wide_case < 1 || wide_case > 3) hconv::panic("Wrong wide case!");                              // main.go:628
         hconv::testResNet_crop_sparse(0, test_num, ker_wid, depth, false, cf100, wide_case);
         return 0;
     } else hconv::panic("wrong test type");

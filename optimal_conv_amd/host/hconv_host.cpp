@@ -129,7 +129,7 @@ static void gen_and_load_galois_key(Context *c, uint64_t galEl) {
 // ---------------------------------------------------------------- newContext (main.go:44-462, kind "Conv")
 Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, const std::vector<int> &kp_wids, bool boot, const std::string &kind) {
     (void)ker_wid;
-    if (kind != "Conv" && kind != "Resnet_crop_sparse" && kind != "Resnet_crop_sparse_wide2") panic("Wrong kinds!");       // main.go:404 (the kinds the built command lines use)
+    if (kind != "Conv" && kind != "Resnet_crop_sparse" && kind != "Resnet_crop_sparse_wide2" && kind != "Resnet_crop_sparse_wide3") panic("Wrong kinds!");       // main.go:404 (the kinds the built command lines use)
     Context *c = new Context();
     double logqp = 0; for (uint64_t q : PARAMS6_Q) logqp += log2((double)q); for (uint64_t p : PARAMS6_P) logqp += log2((double)p);
     printf("CKKS parameters: logN = %d, logSlots = %d, h = %d, logQP = %d, levels = %d, scale= 2^%f, sigma = %f \n",
@@ -153,9 +153,10 @@ Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, cons
         auto start = now();
         // DFT matrices and every switching key, same secret key. "Conv": one full-slot bootstrapper; the resnet kind: the
         // four sparse ones its layers use (btp2..btp5 of main.go:480-500; log_sparse 1..4)
-        const bool wide2 = kind == "Resnet_crop_sparse_wide2";      // layers at log_sparse 1, 2, 3; stride layers at 0 (full packing) and 1
-        c->btp = kind == "Conv" ? newBoot(c->sk, c->seed, dev, {0}) : newBoot(c->sk, c->seed, dev, wide2 ? std::vector<int>{1, 0, 2, 3} : std::vector<int>{2, 1, 3, 4});
-        if (kind != "Conv") { bootPrepareCompress(c->btp, in_wids[0], kp_wids[1], wide2 ? 0 : 1); bootPrepareCompress(c->btp, in_wids[1], kp_wids[2], wide2 ? 1 : 2); }   // main.go:163-215
+        const bool wide2 = kind == "Resnet_crop_sparse_wide2", wide3 = kind == "Resnet_crop_sparse_wide3";
+        // wide2: layers at log_sparse 1, 2, 3, stride layers at 0 (full packing) and 1; wide3: layers at 0, 1, 2, both stride layers at 0
+        c->btp = kind == "Conv" ? newBoot(c->sk, c->seed, dev, {0}) : newBoot(c->sk, c->seed, dev, wide3 ? std::vector<int>{0, 1, 2} : (wide2 ? std::vector<int>{1, 0, 2, 3} : std::vector<int>{2, 1, 3, 4}));
+        if (kind != "Conv") { bootPrepareCompress(c->btp, in_wids[0], kp_wids[1], (wide2 || wide3) ? 0 : 1); bootPrepareCompress(c->btp, in_wids[1], kp_wids[2], wide3 ? 0 : (wide2 ? 1 : 2)); }   // main.go:163-215
         printf("Done in %s \n", dur(start).c_str());
     }
     return c;

@@ -707,10 +707,9 @@ static void profile_dump(Boot *B, const char *label) {
 // gen_comprs_sparse: kp_wid is then the NEXT block's raw width).
 BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sparse, const uint64_t *ct_conv_dev, double ct_scale, double alpha, double pow_, int in_wid, int kp_wid) {
     hc_ctx *hc = B->hc;
-    const bool sparse = kind == "Conv_sparse" || kind == "StrConv_sparse", stride = kind == "StrConv_sparse";
+    const bool stride = kind == "StrConv_sparse" || kind == "StrConv_sparse_full", sparse = kind == "Conv_sparse" || stride;
     if (!sparse && kind != "Conv") panic("No kind!");
     if (!sparse && log_sparse != 0) panic("No cases for log_sparse");
-    if (sparse && log_sparse == 0 && !stride) panic("Conv_sparse with full packing (log_sparse 0: the wide_case 3 network) is not built");
     DCt ct = B->new_ct(0, 1, ct_scale * pow(2.0, pow_));                                            // eval.go:437
     for (int d = 0; d < 2; d++) HCR(hc_copy(hc, ct.p[d].get(), ct_conv_dev + (size_t)d * N, (size_t)N * 8));
     const bool prof = getenv("HCONV_PROFILE") && atoi(getenv("HCONV_PROFILE"));
@@ -732,7 +731,8 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     const std::string mk = std::to_string(in_wid) + "/" + std::to_string(kp_wid) + "/" + std::to_string(log_sparse);
     if (stride) for (int ul = 0; ul < iter; ul++) {                                                                                                                            // eval.go:500-506: m_idx / m_idx_l
         IdxMap m_idx, r_idx; gen_comprs_sparse(N / 2, in_wid, kp_wid, log_sparse, ul, m_idx, r_idx); keep[ul] = ext_double_ctxt(B, boots[ul], m_idx, r_idx, "comprs/" + mk + "/" + std::to_string(ul)); }
-    else if (sparse) keep[0] = keep_ctxt(B, boots[0], gen_keep_vec_sparse(N / 2, in_wid, kp_wid, log_sparse), "keep/" + mk);                                                       // eval.go:534
+    else if (sparse && log_sparse) keep[0] = keep_ctxt(B, boots[0], gen_keep_vec_sparse(N / 2, in_wid, kp_wid, log_sparse), "keep/" + mk);                                         // eval.go:534
+    // "Conv_sparse" on full packing (wide_case 3, block 1) keeps with gen_keep_vec per half, like "Conv" (main.go:155-156)
     else for (int ul = 0; ul < 2; ul++) keep[ul] = keep_ctxt(B, boots[ul], gen_keep_vec(N / 2, in_wid, kp_wid, ul), "keep/" + mk + "/" + std::to_string(ul));
     DCt res = B->stoc(keep[0], iter == 2 ? &keep[1] : nullptr, log_sparse);                              // eval.go:550-561 ; Rescale (564) is a no-op here
     HCR(hc_sync(hc));

@@ -1,4 +1,4 @@
-// hconv_resnet.cpp — `resnet <ker> <depth> <wide_case 1|2> <n> <cf100>` (scope row 8f-3): the reference's encrypted ResNet inference
+// hconv_resnet.cpp — `resnet <ker> <depth> <wide_case 1|2|3> <n> <cf100>` (scope row 8f-3): the reference's encrypted ResNet inference
 // (test.go:76-370 testResNet_crop_sparse) on the MI355X engine, and the layer operator it is built from
 // (eval.go:272-607 evalConv_BNRelu_new for kinds "Conv_sparse" / "StrConv_sparse").
 //
@@ -71,6 +71,10 @@ Ciphertext evalConv_BNRelu_new(Context *cont, const Ciphertext &ct_input, const 
         const int max_batch = N / (in_wid * in_wid);
         if ((in_wid - ker_wid / 2) % 2 == 0) mul_monomial_l0(cont, r1, N - max_batch * (in_wid + 1), true);                                      // eval.go:377-387
         ct_conv = r1;
+    } else if (kind == "StrConv_sparse_full") {                                                            // eval.go:389-412 (modify_ker, full): one convolution, then the offset monomial
+        ct_conv = evalConv_BN(cont, ct_input, ker_in, bn_a, bn_b, in_wid, ker_wid, real_ib, real_ob, norm, out_scale, false);
+        const int max_batch = N / (in_wid * in_wid);
+        if ((in_wid - ker_wid / 2) % 2 == 0) mul_monomial_l0(cont, ct_conv, N - max_batch * (in_wid + 1), true);
     } else if (kind == "Conv_sparse" || kind == "Conv") {
         ct_conv = evalConv_BN(cont, ct_input, ker_in, bn_a, bn_b, in_wid, ker_wid, real_ib, real_ob, norm, out_scale, false);                   // eval.go:433
     } else panic("No kind!");
@@ -104,10 +108,10 @@ static void writeTxt(const std::string &name, const std::vector<double> &v) {
 }
 
 // test.go:76-370 (wide_case 1) and test.go:638-912 testResNet_crop_sparse_wide (wide_case 2: twice the channels, first layer 3 -> 16
-// -> 32, first stride layer on full packing; wide_case 3 — 48/96/192 channels with "StrConv_sparse_full" — is not built)
+// -> 32, first stride layer on full packing; wide_case 3: 48/96/192 channels, block 1 and both stride layers on full packing)
 void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug, bool cf100, int wide_case) {
     (void)debug;
-    if (wide_case != 1 && wide_case != 2) panic("wrong wide_case (the wide_case 3 network of testResNet_crop_sparse_wide is not built)");
+    if (wide_case < 1 || wide_case > 3) panic("wrong wide_case (2 nor 3)!");
     const bool wide = wide_case != 1;
     const std::string ker_name = "ker" + std::to_string(ker_wid), tag = std::string(cf100 ? "cf100_" : "") + "crop_" + ker_name + "_d" + std::to_string(depth) + "_wid" + std::to_string(wide_case) + "/";
     const std::string weight_dir = "Resnet_weights/weights_" + tag, out_dir = "Resnet_enc_results/results_" + tag, img_dir = "Resnet_plain_data/" + tag;
@@ -121,15 +125,16 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
     if (depth == 20) { num_blcs[0] = 7; num_blcs[1] = 5; num_blcs[2] = 5; } else if (depth == 14) { num_blcs[0] = 5; num_blcs[1] = 3; num_blcs[2] = 3; }
     else if (depth == 8) { num_blcs[0] = 3; num_blcs[1] = 1; num_blcs[2] = 1; } else panic("wrong depth (not in 8, 14, 20)!");
     const int init_batch = 16;                                                                           // test.go:667
-    const int real_batch[3] = {wide ? 32 : 16, wide ? 64 : 32, wide ? 128 : 64}, norm[3] = {wide ? 2 : 4, wide ? 4 : 8, wide ? 8 : 16};
-    const int log_sparse[3] = {wide ? 1 : 2, wide ? 2 : 3, wide ? 3 : 4};
+    const int w3 = wide_case == 3;                                                                       // test.go:686-691: 48/96/192 channels, norm 1/2/4, block 1 on full packing
+    const int real_batch[3] = {w3 ? 48 : (wide ? 32 : 16), w3 ? 96 : (wide ? 64 : 32), w3 ? 192 : (wide ? 128 : 64)}, norm[3] = {w3 ? 1 : (wide ? 2 : 4), w3 ? 2 : (wide ? 4 : 8), w3 ? 4 : (wide ? 8 : 16)};
+    const int log_sparse[3] = {w3 ? 0 : (wide ? 1 : 2), w3 ? 1 : (wide ? 2 : 3), w3 ? 2 : (wide ? 3 : 4)};
     const int logN = 16; const double alpha = 0.0;
     const std::vector<int> in_wids = {32, 16, 8}, raw_in_wids = {32 - ker_wid / 2, 16 - ker_wid / 2, 8 - ker_wid / 2};
     const int ker_size = ker_wid * ker_wid;
     int max_batch[3]; for (int i = 0; i < 3; i++) max_batch[i] = (1 << logN) / (in_wids[(size_t)i] * in_wids[(size_t)i]);
     mkdir("Resnet_enc_results", 0755); mkdir(out_dir.c_str(), 0755);
     auto W = [&](int i, const char *what, int size) { return readTxt(weight_dir + "w" + std::to_string(i) + "-" + what + ".csv", size); };
-    const char *kind_name = wide ? "Resnet_crop_sparse_wide2" : "Resnet_crop_sparse";
+    const char *kind_name = w3 ? "Resnet_crop_sparse_wide3" : (wide ? "Resnet_crop_sparse_wide2" : "Resnet_crop_sparse");
 
     // HCONV_IMAGE_THREADS=K (not a reference feature): K host threads, each with its own context (keys, bootstrappers, stream),
     // classify disjoint shares of the images at the same time. A layer's launches are mostly far below one wave of workgroups, so the
@@ -167,8 +172,31 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
             printf("Block1, Layer  %d done!\n", i);
         }
         printf("Block1 done.\n"); timings[0] = secs(start); start = now();
-        step(evalConv_BNRelu_new(cont, ct_layer, W(num_blcs[0], "conv", real_batch[0] * real_batch[1] * ker_size), W(num_blcs[0], "a", real_batch[1]), W(num_blcs[0], "b", real_batch[1]),
+        if (!w3) step(evalConv_BNRelu_new(cont, ct_layer, W(num_blcs[0], "conv", real_batch[0] * real_batch[1] * ker_size), W(num_blcs[0], "a", real_batch[1]), W(num_blcs[0], "b", real_batch[1]),
                                  alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], real_batch[1], norm[1], log_sparse[0] - 1, "StrConv_sparse"));           // test.go:200, 791
+        else {                                                                                           // test.go:775-812: even / odd output channels as two full-packing stride layers, X^2 shift, add
+            const std::vector<double> ker12 = W(num_blcs[0], "conv", real_batch[0] * real_batch[1] * ker_size), a12 = W(num_blcs[0], "a", real_batch[1]), b12 = W(num_blcs[0], "b", real_batch[1]);
+            const int ho = real_batch[1] / 2; std::vector<double> k0(ker12.size() / 2), k1(ker12.size() / 2), a0((size_t)ho), a1((size_t)ho), b0((size_t)ho), b1((size_t)ho);
+            for (int k = 0; k < ker_size; k++) for (int i = 0; i < real_batch[0]; i++) for (int j = 0; j < ho; j++) {
+                k0[(size_t)(k * real_batch[0] * ho + (i * ho + j))] = ker12[(size_t)(k * real_batch[0] * real_batch[1] + (i * real_batch[1] + 2 * j))];
+                k1[(size_t)(k * real_batch[0] * ho + (i * ho + j))] = ker12[(size_t)(k * real_batch[0] * real_batch[1] + (i * real_batch[1] + 2 * j + 1))];
+            }
+            for (int i = 0; i < ho; i++) { a0[(size_t)i] = a12[(size_t)(2 * i)]; a1[(size_t)i] = a12[(size_t)(2 * i + 1)]; b0[(size_t)i] = b12[(size_t)(2 * i)]; b1[(size_t)i] = b12[(size_t)(2 * i + 1)]; }
+            Ciphertext r1 = evalConv_BNRelu_new(cont, ct_layer, k0, a0, b0, alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], ho, norm[0], 0, "StrConv_sparse_full");
+            Ciphertext r2 = evalConv_BNRelu_new(cont, ct_layer, k1, a1, b1, alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], ho, norm[0], 0, "StrConv_sparse_full");
+            {   // MulNew(ct_result2, EncodeCoeffs(X^2 at scale 1)) at level 1, AddNew (test.go:804-811)
+                void *v = nullptr; HCX(cont->hc, hc_malloc(cont->hc, (size_t)2 * N * 8, &v)); uint64_t *pt = (uint64_t *)v;
+                std::vector<uint64_t> m((size_t)2 * N, 0); m[2] = 1; m[(size_t)N + 2] = 1;
+                HCX(cont->hc, hc_upload(cont->hc, pt, m.data(), m.size() * 8));
+                for (int l = 0; l < 2; l++) HCX(cont->hc, hc_ntt(cont->hc, l, pt + (size_t)l * N, pt + (size_t)l * N, 1));
+                for (int d = 0; d < 2; d++) for (int l = 0; l < 2; l++) {
+                    uint64_t *row2 = r2.d + ((size_t)d * 2 + l) * N, *row1 = r1.d + ((size_t)d * 2 + l) * N;
+                    HCX(cont->hc, hc_mul(cont->hc, l, row2, pt + (size_t)l * N, row2, 1)); HCX(cont->hc, hc_add(cont->hc, l, row1, row2, row1, 1));
+                }
+                HCX(cont->hc, hc_free(cont->hc, pt));
+            }
+            freeCt(cont, r2); step(r1);
+        }
         printf("Block1 to 2 done!\n"); timings[1] = secs(start); start = now();
         for (int i = 1; i <= num_blcs[1]; i++) {                                                         // ResNet Block 2
             if (wide && i == 5) pow_ = init_pow;                                                         // test.go:819-821

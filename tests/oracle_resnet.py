@@ -96,12 +96,12 @@ class Net:
         self.logN, self.k, self.fc_out, self.wide = logN, ker_wid, fc_out, wide
         shapes = {16: ((32, 16, 8), (16, 32, 64)), 14: ((16, 8, 4), (16, 32, 64)), 12: ((16, 8, 4), (4, 8, 16))}
         self.in_wids, self.real_batch = [list(t) for t in shapes[logN]]
-        if wide == 2:       # testResNet_crop_sparse_wide, wide_case 2 (test.go:681-684): twice the channels, first layer 3 -> 16 -> 32
+        if wide in (2, 3):  # testResNet_crop_sparse_wide (test.go:681-691): wide_case 2 = 32/64/128 channels, 3 = 48/96/192; first layer 3 -> 16 -> real_batch[0]
             assert logN == 16
-            self.real_batch = [32, 64, 128]
+            self.real_batch = [32, 64, 128] if wide == 2 else [48, 96, 192]
         self.raw = [w - ker_wid // 2 for w in self.in_wids]
         self.max_batch = [(1 << logN) // (w * w) for w in self.in_wids]
-        self.norm = [m // r for m, r in zip(self.max_batch, self.real_batch)]
+        self.norm = [m // r for m, r in zip(self.max_batch, self.real_batch)]      # wide 3: 64 // 48 = 1, 256 // 96 = 2, 1024 // 192 = 4 (test.go:688)
         self.blocks = {20: (7, 5, 5), 14: (5, 3, 3), 8: (3, 1, 1)}[depth]
         rng = np.random.default_rng(seed)
         k = ker_wid
@@ -113,7 +113,7 @@ class Net:
                 self.layers.append(("StrConv_sparse", blk - 1, self._w(rng, k, cin, cout), rng.uniform(0.8, 1.2, cout), rng.uniform(-0.1, 0.1, cout)))
                 cin = cout
             for li in range(self.blocks[blk]):
-                cout = 16 if (wide == 2 and blk == 0 and li == 0) else self.real_batch[blk]      # init_batch = 16 (test.go:667)
+                cout = 16 if (wide in (2, 3) and blk == 0 and li == 0) else self.real_batch[blk]      # init_batch = 16 (test.go:667)
                 self.layers.append(("Conv_sparse", blk, self._w(rng, k, cin, cout), rng.uniform(0.8, 1.2, cout), rng.uniform(-0.1, 0.1, cout)))
                 cin = cout
         self.fc_w = rng.uniform(-1, 1, (cin, fc_out)) / np.sqrt(cin)

@@ -68,13 +68,13 @@ def test_conv_relu_cli(tmp_path, k, i_batch):
     assert meds[1] >= 10.5 and avgs[1] >= 7.5, txt
 
 
-@pytest.mark.parametrize("cf100,wide", [(False, 1), (True, 1), (False, 2)])
+@pytest.mark.parametrize("cf100,wide", [(False, 1), (True, 1), (False, 2), (False, 3)])
 def test_resnet_cli_depth8(tmp_path, cf100, wide):
     """`resnet 3 8 1 1 false` (scope row 8f-3; the reference's depth-8 variant of BASELINE.md config 5): encrypted inference with
     synthetic weights in the reference's file layout; the class scores must follow the plain float model of the same network"""
     import numpy as np
     import golden.gen_resnet_csv as rgen
-    (want, _), = rgen.write_case(str(tmp_path), 3, 8, 1, cf100=cf100, wide=wide)     # wide = 2: testResNet_crop_sparse_wide (test.go:638), first stride layer on full packing
+    (want, _), = rgen.write_case(str(tmp_path), 3, 8, 1, cf100=cf100, wide=wide)     # wide = 2, 3: testResNet_crop_sparse_wide (test.go:638); 2: first stride layer on full packing; 3: 48/96/192 channels, block 1 and both stride layers on full packing
     out = subprocess.run([CLI, "resnet", "3", "8", str(wide), "1", "true" if cf100 else "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
                          env=dict(os.environ, HCONV_SEED="11"))
     assert out.returncode == 0, out.stderr[-2000:]
