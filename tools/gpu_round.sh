@@ -22,3 +22,7 @@ CFGS=5,1 bash tools/gpu_blrelu.sh > $O/convrelu_5_1_summary.txt 2>&1; cp gpurun_
 timeout 600 python tools/resnet_throughput.py --images 6 > $O/resnet20_throughput_1gpu.json 2> $O/resnet20_throughput.err; cut -c1-300 $O/resnet20_throughput_1gpu.json
 bash tools/gpu_resnet.sh 20 > $O/resnet20_cli_summary.txt 2>&1; cp gpurun_out/resnet/cli_resnet_20.txt $O/resnet20_cli.txt
 bash tools/gpu_resnet_wide.sh 20 > $O/resnet20_wide2_summary.txt 2>&1; cp gpurun_out/resnet/cli_resnet_w2_20.txt $O/resnet20_wide2_cli.txt; tail -3 $O/resnet20_wide2_cli.txt
+bash tools/gpu_resnet_wide.sh 8 3 > $O/resnet8_wide3_summary.txt 2>&1; cp gpurun_out/resnet/cli_resnet_w3_8.txt $O/resnet8_wide3_cli.txt; tail -3 $O/resnet8_wide3_cli.txt
+bash tools/gpu_relu_prof.sh > $O/relu_prof_summary.txt 2>&1; cp $(find gpurun_out/relu_prof/prof -name "*kernel_stats*.csv" | head -1) $O/convrelu_5_1_kernel_stats.csv 2>/dev/null
+# single-GPU dry run of the N > 1 bookkeeping (two ranks share GPU 0, gloo barriers): not a scaling number
+HC_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29633 bench.py --gpus 2 --steps 20 --warmup 3 > $O/bench_2ranks_1gpu_dryrun.json 2> $O/bench_2ranks.err; cut -c1-200 $O/bench_2ranks_1gpu_dryrun.json
