@@ -95,6 +95,7 @@ struct hc_ctx {
     // hipGraph replay of a whole conv_then_pack (option "graph"): the launch list of a conv is static for fixed buffers and
     // constants, so the second call with the same arguments is captured once and later calls are one graph launch
     long use_graph = 0;
+    int async_alloc = 0;                                    // HCONV_ASYNC_ALLOC=1: stream-ordered allocator + non-blocking stream (see hcx_malloc)
     long ks_fused = 0;                                      // plain key switch with the digits' second transform pass inside the inner product (hc_k_rows_fwd_mac): measured 3 % slower per ResNet image (202 VGPRs, a serial loop over the digits), so off
     struct GraphKey { const void *ct_in, *ker, *bias; void *ct_out; int max_ob, norm; u64 c0, c1; long chunk;
         bool operator<(const GraphKey &o) const { return memcmp(this, &o, sizeof *this) < 0; } };
@@ -129,6 +130,16 @@ static int hc_fail(hc_ctx *c, int code, const char *fmt, ...) {
 #define HC_ENTER(c) do { if (!(c)) return HC_ERR_ARG; HC_HIP(c, hipSetDevice((c)->device)); } while (0)
 
 // forward lazy-reduction mode by modulus size (see HC_FM_* in hc_kernels.h): 34q < 2^64 <=> q < 2^58.9
+// Allocation: plain hipMalloc / hipFree by default. hipFree synchronises the whole device, which is harmless with one context but
+// serialises independent contexts driven from several host threads (a thread's free waits for every other thread's queued work);
+// HCONV_ASYNC_ALLOC=1 at context creation switches this context to the stream-ordered allocator (hipMallocAsync / hipFreeAsync on
+// its own stream, a non-blocking stream) so that nothing in a steady-state call touches other streams.
+static hipError_t hcx_malloc(hc_ctx *c, void **p, size_t n) { return (c && c->async_alloc) ? hipMallocAsync(p, n ? n : 1, c->stream) : hipMalloc(p, n); }
+static hipError_t hcx_free(hc_ctx *c, void *p) { if (!p) return hipSuccess; return (c && c->async_alloc) ? hipFreeAsync(p, c->stream) : hipFree(p); }
+static hipError_t hcx_h2d(hc_ctx *c, void *dst, const void *src, size_t n) {      // blocking copy on the context's stream (not the null stream)
+    hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
+}
 static inline bool hc_fm_free(u64 q) { return q < (1ull << 58); }
 static inline bool hc_f64_ok(u64 q) { return q < (1ull << 49); }    // fp64 inverse transform (hc_arith.h): 4q < 2^51
 
@@ -161,8 +172,8 @@ static int hc_prof_flush(hc_ctx *c) {
 template <class T>
 static int hc_dev_upload(hc_ctx *c, HcModHost *owner, const std::vector<T> &v, const T **out) {
     void *d = nullptr;
-    HC_HIP(c, hipMalloc(&d, v.size() * sizeof(T)));
-    HC_HIP(c, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    HC_HIP(c, hcx_malloc(c, &d, v.size() * sizeof(T)));
+    HC_HIP(c, hcx_h2d(c, d, v.data(), v.size() * sizeof(T)));
     owner->allocs.push_back(d);
     *out = (const T *)d;
     return HC_OK;
@@ -223,7 +234,12 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
         return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: HIP device %d not available (%d devices) - this library has no CPU path", device, ndev);
     hc_ctx *c = new hc_ctx();
     c->device = device; c->nq = nq; c->np = np;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: cannot create stream on device %d", device); }
+    { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa && atoi(aa) ? 1 : 0; }
+    if (c->async_alloc && hipSetDevice(device) == hipSuccess) {      // keep freed blocks in the pool instead of returning them to the driver at every synchronisation
+        hipMemPool_t pool; uint64_t thr = ~0ull;
+        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+    }
+    if (hipSetDevice(device) != hipSuccess || (c->async_alloc ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: cannot create stream on device %d", device); }
     hipEventCreate(&c->t0); hipEventCreate(&c->t1);
     c->mods.resize((size_t)(nq + np));
     for (int i = 0; i < nq + np; i++) {
@@ -247,12 +263,12 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
     }
     {   // device table of moduli for the leveled (all-limbs-in-one-launch) kernels
         std::vector<HcMod> hm; for (auto &mh : c->mods) hm.push_back(mh.m);
-        if (hipMalloc((void **)&c->d_mods, hm.size() * sizeof(HcMod)) != hipSuccess || hipMalloc((void **)&c->d_csts, hm.size() * sizeof(HcTw)) != hipSuccess ||
-            hipMemcpy(c->d_mods, hm.data(), hm.size() * sizeof(HcMod), hipMemcpyHostToDevice) != hipSuccess) { g_create_err = "hc_ctx_create: device modulus table"; hc_ctx_destroy(c); return HC_ERR_HIP; }
+        if (hcx_malloc(c, (void **)&c->d_mods, hm.size() * sizeof(HcMod)) != hipSuccess || hcx_malloc(c, (void **)&c->d_csts, hm.size() * sizeof(HcTw)) != hipSuccess ||
+            hcx_h2d(c, c->d_mods, hm.data(), hm.size() * sizeof(HcMod)) != hipSuccess) { g_create_err = "hc_ctx_create: device modulus table"; hc_ctx_destroy(c); return HC_ERR_HIP; }
     }
     {   std::vector<HcRowMod> hr; for (auto &mh : c->mods) { HcRowMod r; r.fwd = mh.fwd; r.inv = mh.inv; r.q = mh.m.q; r.mu = mh.m.mu; hr.push_back(r); }
-        if (hipMalloc((void **)&c->d_rowmods, hr.size() * sizeof(HcRowMod)) != hipSuccess ||
-            hipMemcpy(c->d_rowmods, hr.data(), hr.size() * sizeof(HcRowMod), hipMemcpyHostToDevice) != hipSuccess) { g_create_err = "hc_ctx_create: device table of transforms"; hc_ctx_destroy(c); return HC_ERR_HIP; }
+        if (hcx_malloc(c, (void **)&c->d_rowmods, hr.size() * sizeof(HcRowMod)) != hipSuccess ||
+            hcx_h2d(c, c->d_rowmods, hr.data(), hr.size() * sizeof(HcRowMod)) != hipSuccess) { g_create_err = "hc_ctx_create: device table of transforms"; hc_ctx_destroy(c); return HC_ERR_HIP; }
     }
     *out = c;
     return HC_OK;
@@ -290,8 +306,8 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
 }
 
 // ------------------------------------------------------------------ memory
-extern "C" int hc_malloc(hc_ctx *c, size_t bytes, void **dptr) { HC_ENTER(c); if (!dptr) return hc_fail(c, HC_ERR_ARG, "hc_malloc: null"); HC_HIP(c, hipMalloc(dptr, bytes)); return HC_OK; }
-extern "C" int hc_free(hc_ctx *c, void *dptr) { HC_ENTER(c); HC_HIP(c, hipStreamSynchronize(c->stream)); HC_HIP(c, hipFree(dptr)); return HC_OK; }
+extern "C" int hc_malloc(hc_ctx *c, size_t bytes, void **dptr) { HC_ENTER(c); if (!dptr) return hc_fail(c, HC_ERR_ARG, "hc_malloc: null"); HC_HIP(c, hcx_malloc(c, dptr, bytes)); return HC_OK; }
+extern "C" int hc_free(hc_ctx *c, void *dptr) { HC_ENTER(c); HC_HIP(c, hipStreamSynchronize(c->stream)); HC_HIP(c, hcx_free(c, dptr)); return HC_OK; }
 extern "C" int hc_upload(hc_ctx *c, void *dst, const void *src, size_t bytes) {
     HC_ENTER(c); if (!dst || !src) return hc_fail(c, HC_ERR_ARG, "hc_upload: null pointer");
     HC_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
@@ -321,9 +337,9 @@ static dim3 hc_pw_grid(size_t n) { size_t b = (n + HC_TPB - 1) / HC_TPB; if (b >
 static int hc_ensure_tmp(hc_ctx *c, size_t rows) {
     if (c->ws_tmp_rows >= rows) return HC_OK;
     HC_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->ws_tmp) HC_HIP(c, hipFree(c->ws_tmp));
+    if (c->ws_tmp) HC_HIP(c, hcx_free(c, c->ws_tmp));
     c->ws_tmp = nullptr; c->ws_tmp_rows = 0;
-    HC_HIP(c, hipMalloc((void **)&c->ws_tmp, rows * HC_N * sizeof(u64)));
+    HC_HIP(c, hcx_malloc(c, (void **)&c->ws_tmp, rows * HC_N * sizeof(u64)));
     c->ws_tmp_rows = rows;
     return HC_OK;
 }
@@ -414,9 +430,9 @@ static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int 
 static int hc_ensure_mm(hc_ctx *c, size_t rows) {
     if (c->ws_mm_rows >= rows) return HC_OK;
     HC_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->ws_mm) HC_HIP(c, hipFree(c->ws_mm));
+    if (c->ws_mm) HC_HIP(c, hcx_free(c, c->ws_mm));
     c->ws_mm = nullptr; c->ws_mm_rows = 0; c->hoist_cx = nullptr;
-    HC_HIP(c, hipMalloc((void **)&c->ws_mm, rows * HC_N * sizeof(u64)));
+    HC_HIP(c, hcx_malloc(c, (void **)&c->ws_mm, rows * HC_N * sizeof(u64)));
     c->ws_mm_rows = rows;
     return HC_OK;
 }
@@ -436,11 +452,11 @@ extern "C" int hc_lv_mul_tensor(hc_ctx *c, int level, const uint64_t *a0, const 
 extern "C" int hc_lv_mod_raise(hc_ctx *c, int level, const uint64_t *in_q0, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mod_raise", level, in_q0, out));
     if ((const void *)in_q0 == (const void *)out) return hc_fail(c, HC_ERR_ARG, "hc_lv_mod_raise: in and out must differ");
-    u64 *t = nullptr; HC_HIP(c, hipMalloc((void **)&t, HC_N * sizeof(u64)));
+    u64 *t = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&t, HC_N * sizeof(u64)));
     int rc = hc_intt(c, 0, in_q0, t, 1);
     if (!rc) rc = hc_launch(c, "mod_raise", hc_k_mod_raise, hc_lv_grid(level), (const u64 *)t, (u64 *)out, (const HcMod *)c->d_mods);
     if (!rc) rc = hc_lv_ntt(c, level, out, out);
-    hipStreamSynchronize(c->stream); hipFree(t);
+    hipStreamSynchronize(c->stream); hcx_free(c, t);
     return rc;
 }
 
@@ -475,7 +491,7 @@ static int hc_fill_loopA(hc_ctx *c, HcLoopA *A, const u64 *ker, u64 *cts, int no
 
 // ct_in (2x2 rows) times per-limb constants -> ws_ctc
 static int hc_prepare_ctc(hc_ctx *c, const u64 *ct_in, const u64 cst[2]) {
-    if (!c->ws_ctc) HC_HIP(c, hipMalloc((void **)&c->ws_ctc, 4 * HC_N * sizeof(u64)));
+    if (!c->ws_ctc) HC_HIP(c, hcx_malloc(c, (void **)&c->ws_ctc, 4 * HC_N * sizeof(u64)));
     for (int p = 0; p < 2; p++) for (int l = 0; l < 2; l++) {
         const HcMod &m = c->mods[(size_t)l].m;
         size_t off = ((size_t)p * 2 + (size_t)l) * HC_N;
@@ -524,8 +540,8 @@ static int hc_div_round_last_n(hc_ctx *c, int level, const u64 *x, size_t xs, u6
         if (it == c->rescale_plan.end()) {
             std::vector<HcTw> h((size_t)level);
             for (int i = 0; i < level; i++) { const u64 q = c->mods[(size_t)i].m.q; h[(size_t)i] = h_pair(h_inv(qL % q, q), q); }
-            HcTw *d = nullptr; HC_HIP(c, hipMalloc((void **)&d, h.size() * sizeof(HcTw)));
-            HC_HIP(c, hipMemcpy(d, h.data(), h.size() * sizeof(HcTw), hipMemcpyHostToDevice));
+            HcTw *d = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&d, h.size() * sizeof(HcTw)));
+            HC_HIP(c, hcx_h2d(c, d, h.data(), h.size() * sizeof(HcTw)));
             it = c->rescale_plan.emplace(level, d).first;
         }
         // np polynomials per launch (blockIdx.z): x, x + xs and out, out + os (distances in words, modulo 2^64)
@@ -541,8 +557,8 @@ static int hc_div_round_last_n(hc_ctx *c, int level, const u64 *x, size_t xs, u6
     if (np != 1) { HC_TRY(hc_div_round_last_n(c, level, x, 0, out, 0, 1)); return hc_div_round_last_n(c, level, x + xs, 0, out + os, 0, 1); }
     // Build a "ciphertext" whose polynomial 0 is x and a kernel equal to R mod q (Montgomery form of 1).
     HC_TRY(hc_ensure_tmp(c, 16));
-    if (!c->ws_ctc) HC_HIP(c, hipMalloc((void **)&c->ws_ctc, 4 * HC_N * sizeof(u64)));
-    u64 *scratch = nullptr; HC_HIP(c, hipMalloc((void **)&scratch, (size_t)(2 + 4) * HC_N * sizeof(u64)));
+    if (!c->ws_ctc) HC_HIP(c, hcx_malloc(c, (void **)&c->ws_ctc, 4 * HC_N * sizeof(u64)));
+    u64 *scratch = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&scratch, (size_t)(2 + 4) * HC_N * sizeof(u64)));
     u64 *one = scratch, *cts = scratch + 2 * HC_N;
     std::vector<u64> h((size_t)2 * HC_N);
     for (int l = 0; l < 2; l++) { u64 q = c->mods[(size_t)l].m.q; u64 r = (u64)((((u128)1) << 64) % q); for (int j = 0; j < HC_N; j++) h[(size_t)l * HC_N + (size_t)j] = r; }
@@ -551,7 +567,7 @@ static int hc_div_round_last_n(hc_ctx *c, int level, const u64 *x, size_t xs, u6
     HC_HIP(c, hipMemcpyAsync(c->ws_ctc + 2 * HC_N, x, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
     int rc = hc_loopA_run(c, one, 1, 1, cts);
     if (!rc) { hipMemcpyAsync(out, cts, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); hipStreamSynchronize(c->stream); }
-    hipFree(scratch);
+    hcx_free(c, scratch);
     return rc;
 }
 extern "C" int hc_div_round_last(hc_ctx *c, int level, const uint64_t *x, uint64_t *out) { HC_ENTER(c); return hc_div_round_last_n(c, level, x, 0, out, 0, 1); }
@@ -580,10 +596,10 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
     const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
     // Lattigo's stored form IS the Montgomery form the kernels multiply with: the Q rows are taken as they come (times P^-1, below),
     // the P rows are only re-ordered into the lo-local coalesced order hc_k_b3 reads.
-    u64 *stage = nullptr; HC_HIP(c, hipMalloc((void **)&stage, 2 * HC_N * sizeof(u64)));
+    u64 *stage = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&stage, 2 * HC_N * sizeof(u64)));
     HcEvk e; e.q_rows = nullptr; e.p_rows = nullptr; e.row_local = hc_perm_row_local(galEl);
-    HC_HIP(c, hipMalloc((void **)&e.q_rows, 2 * HC_N * sizeof(u64)));
-    HC_HIP(c, hipMalloc((void **)&e.p_rows, 2 * HC_N * sizeof(HcTw)));
+    HC_HIP(c, hcx_malloc(c, (void **)&e.q_rows, 2 * HC_N * sizeof(u64)));
+    HC_HIP(c, hcx_malloc(c, (void **)&e.p_rows, 2 * HC_N * sizeof(HcTw)));
     HC_HIP(c, hipMemcpyAsync(e.q_rows, b_q, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     HC_HIP(c, hipMemcpyAsync(e.q_rows + HC_N, a_q, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     HC_HIP(c, hipMemcpyAsync(stage, b_p, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
@@ -597,10 +613,10 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
     if (!rc) rc = hc_launch(c, "evk_ninv", hc_k_pointwise<HC_PW_MULC>, hc_pw_grid(2 * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)2 * HC_N, mp.m, h_pair(mp.m.ninv, mp.m.q));
     if (!rc) rc = hc_launch(c, "make_pairs", hc_k_make_pairs, hc_pw_grid(2 * HC_N), (const u64 *)stage, e.p_rows, (size_t)2 * HC_N, mp.m.q, 1);
     hipStreamSynchronize(c->stream);
-    hipFree(stage);
-    if (rc) { hipFree(e.q_rows); hipFree(e.p_rows); return rc; }
+    hcx_free(c, stage);
+    if (rc) { hcx_free(c, e.q_rows); hcx_free(c, e.p_rows); return rc; }
     auto it = c->evk.find(galEl);
-    if (it != c->evk.end()) { hipFree(it->second.q_rows); hipFree(it->second.p_rows); }
+    if (it != c->evk.end()) { hcx_free(c, it->second.q_rows); hcx_free(c, it->second.p_rows); }
     c->evk[galEl] = e;
     return HC_OK;
 }
@@ -608,7 +624,7 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
 extern "C" int hc_idx_load(hc_ctx *c, const uint64_t *idx_host) {
     HC_ENTER(c);
     const HcModHost &m0 = c->mods[0];
-    u64 *stage = nullptr; HC_HIP(c, hipMalloc((void **)&stage, (size_t)HC_LOGN * HC_N * sizeof(u64)));
+    u64 *stage = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&stage, (size_t)HC_LOGN * HC_N * sizeof(u64)));
     int rc = HC_OK;
     if (idx_host) {
         HC_HIP(c, hipMemcpyAsync(stage, idx_host, (size_t)HC_LOGN * HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
@@ -617,16 +633,16 @@ extern "C" int hc_idx_load(hc_ctx *c, const uint64_t *idx_host) {
         u64 one = 1;
         for (int i = 0; i < HC_LOGN; i++) HC_HIP(c, hipMemcpyAsync(stage + (size_t)i * HC_N + ((size_t)1 << i), &one, sizeof one, hipMemcpyHostToDevice, c->stream));
         HC_HIP(c, hipStreamSynchronize(c->stream));
-        u64 *tmp = nullptr; HC_HIP(c, hipMalloc((void **)&tmp, (size_t)HC_LOGN * HC_N * sizeof(u64)));
+        u64 *tmp = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&tmp, (size_t)HC_LOGN * HC_N * sizeof(u64)));
         rc = HC_LAUNCH_FM(m0.m.q, c, "cols_fwd", hc_k_cols_fwd, dim3(16, HC_LOGN), (const u64 *)stage, tmp, m0.fwd, m0.m.q);
         if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "rows_fwd_canon", hc_k_rows_fwd_canon, dim3(16, HC_LOGN), (const u64 *)tmp, stage, m0.fwd, m0.m.q, m0.m.mu);
-        hipStreamSynchronize(c->stream); hipFree(tmp);
+        hipStreamSynchronize(c->stream); hcx_free(c, tmp);
     }
     HcTw z; z.w = z.ws = 0;
     if (!rc) rc = hc_launch(c, "idx_to_mont", hc_k_pointwise<HC_PW_TO_MONT>, hc_pw_grid((size_t)HC_LOGN * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)HC_LOGN * HC_N, m0.m, z);
     hipStreamSynchronize(c->stream);
-    if (rc) { hipFree(stage); return rc; }
-    if (c->idx_pairs) hipFree(c->idx_pairs);
+    if (rc) { hcx_free(c, stage); return rc; }
+    if (c->idx_pairs) hcx_free(c, c->idx_pairs);
     c->idx_pairs = stage;
     return HC_OK;
 }
@@ -634,17 +650,17 @@ extern "C" int hc_idx_load(hc_ctx *c, const uint64_t *idx_host) {
 static int hc_ker_from_device(hc_ctx *c, u64 *d, int max_ob, bool take, hc_ker **out) {
     // to Montgomery form in one launch; rows alternate Q0, Q1 ([i][limb][N] both in and out)
     u64 *dst = d;
-    if (!take) { HC_HIP(c, hipMalloc((void **)&dst, (size_t)max_ob * 2 * HC_N * sizeof(u64))); }
+    if (!take) { HC_HIP(c, hcx_malloc(c, (void **)&dst, (size_t)max_ob * 2 * HC_N * sizeof(u64))); }
     int rc = hc_launch(c, "ker_to_mont", hc_k_ker_to_mont, hc_pw_grid((size_t)max_ob * 2 * HC_N), (const u64 *)d, dst, max_ob, c->mods[0].m, c->mods[1].m);
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "hc_ker_load: stream synchronize failed");
-    if (rc) { hipFree(dst); return rc; }      // `take` means the buffer was ours to free as well
+    if (rc) { hcx_free(c, dst); return rc; }      // `take` means the buffer was ours to free as well
     hc_ker *k = new hc_ker(); k->d = dst; k->max_ob = max_ob; *out = k;
     return HC_OK;
 }
 extern "C" int hc_ker_load(hc_ctx *c, const uint64_t *host, int max_ob, hc_ker **out) {
     HC_ENTER(c);
     if (!host || !out || max_ob < 1 || c->nq < 2) return hc_fail(c, HC_ERR_ARG, "hc_ker_load: bad arguments");
-    u64 *d = nullptr; HC_HIP(c, hipMalloc((void **)&d, (size_t)max_ob * 2 * HC_N * sizeof(u64)));
+    u64 *d = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&d, (size_t)max_ob * 2 * HC_N * sizeof(u64)));
     HC_HIP(c, hipMemcpyAsync(d, host, (size_t)max_ob * 2 * HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     return hc_ker_from_device(c, d, max_ob, true, out);
 }
@@ -666,10 +682,10 @@ extern "C" int hc_prep_ker(hc_ctx *c, const double *ker_in, int ker_len, const d
     const int adj = (max_bat - 1) + max_bat * (in_wid + 1) * (ker_wid - 1) / 2;
     if (2 * adj > HC_N) return hc_fail(c, HC_ERR_ARG, "hc_prep_ker: kernel too wide for this input width");
     double *dk = nullptr, *da = nullptr; u64 *stage = nullptr, *dst = nullptr, *tmp = nullptr;
-    HC_HIP(c, hipMalloc((void **)&dk, (size_t)ker_len * sizeof(double)));
-    HC_HIP(c, hipMalloc((void **)&da, (size_t)real_ob * sizeof(double)));
-    HC_HIP(c, hipMalloc((void **)&stage, (size_t)max_bat * 2 * HC_N * sizeof(u64)));
-    HC_HIP(c, hipMalloc((void **)&dst, (size_t)max_bat * 2 * HC_N * sizeof(u64)));
+    HC_HIP(c, hcx_malloc(c, (void **)&dk, (size_t)ker_len * sizeof(double)));
+    HC_HIP(c, hcx_malloc(c, (void **)&da, (size_t)real_ob * sizeof(double)));
+    HC_HIP(c, hcx_malloc(c, (void **)&stage, (size_t)max_bat * 2 * HC_N * sizeof(u64)));
+    HC_HIP(c, hcx_malloc(c, (void **)&dst, (size_t)max_bat * 2 * HC_N * sizeof(u64)));
     HC_HIP(c, hipMemcpyAsync(dk, ker_in, (size_t)ker_len * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HC_HIP(c, hipMemcpyAsync(da, bn_a, (size_t)real_ob * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HC_HIP(c, hipMemsetAsync(stage, 0, (size_t)max_bat * 2 * HC_N * sizeof(u64), c->stream));
@@ -680,8 +696,8 @@ extern "C" int hc_prep_ker(hc_ctx *c, const double *ker_in, int ker_len, const d
     for (int l = 0; l < 2 && !rc; l++) rc = hc_ntt(c, l, stage + (size_t)l * max_bat * HC_N, stage + (size_t)l * max_bat * HC_N, max_bat);
     if (!rc) rc = hc_launch(c, "ker_interleave", hc_k_ker_interleave, hc_pw_grid((size_t)max_bat * 2 * HC_N), (const u64 *)stage, dst, max_bat, c->mods[0].m, c->mods[1].m, 1);
     hipStreamSynchronize(c->stream);
-    hipFree(dk); hipFree(da); hipFree(stage); (void)tmp;
-    if (rc) { hipFree(dst); return rc; }
+    hcx_free(c, dk); hcx_free(c, da); hcx_free(c, stage); (void)tmp;
+    if (rc) { hcx_free(c, dst); return rc; }
     hc_ker *k = new hc_ker(); k->d = dst; k->max_ob = max_bat; *out = k;
     return HC_OK;
 }
@@ -689,13 +705,13 @@ extern "C" int hc_prep_ker(hc_ctx *c, const double *ker_in, int ker_len, const d
 extern "C" int hc_ker_download(hc_ctx *c, const hc_ker *k, uint64_t *host_out) {
     HC_ENTER(c); if (!k || !host_out) return hc_fail(c, HC_ERR_ARG, "hc_ker_download: null");
     u64 *tmp = nullptr; const size_t n = (size_t)k->max_ob * 2 * HC_N;
-    HC_HIP(c, hipMalloc((void **)&tmp, n * sizeof(u64)));
+    HC_HIP(c, hcx_malloc(c, (void **)&tmp, n * sizeof(u64)));
     int rc = hc_launch(c, "ker_from_mont", hc_k_ker_from_mont, hc_pw_grid(n), (const u64 *)k->d, tmp, k->max_ob, c->mods[0].m, c->mods[1].m);
     if (!rc) { HC_HIP(c, hipMemcpyAsync(host_out, tmp, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream)); }
-    hipStreamSynchronize(c->stream); hipFree(tmp);
+    hipStreamSynchronize(c->stream); hcx_free(c, tmp);
     return rc;
 }
-extern "C" void hc_ker_free(hc_ctx *c, hc_ker *k) { if (!k) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } hipFree(k->d); delete k; }
+extern "C" void hc_ker_free(hc_ctx *c, hc_ker *k) { if (!k) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } hcx_free(c, k->d); delete k; }
 
 // ------------------------------------------------------------------ loop B plumbing
 static int hc_fill_loopB(hc_ctx *c, HcLoopB *B, const u64 *src, u64 *dst, const HcEvk &e, int logStep, int step, int norm, u64 galEl, int chunk) {
@@ -754,9 +770,9 @@ static int hc_pack_run(hc_ctx *c, u64 *cts, int max_cnum, int real_cnum, const u
     const size_t pong_rows = (size_t)(max_cnum / 2 > 0 ? max_cnum / 2 : 1) * 2;
     if (c->ws_cts2_rows < pong_rows) {
         HC_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->ws_cts2) HC_HIP(c, hipFree(c->ws_cts2));
+        if (c->ws_cts2) HC_HIP(c, hcx_free(c, c->ws_cts2));
         c->ws_cts2 = nullptr; c->ws_cts2_rows = 0;
-        HC_HIP(c, hipMalloc((void **)&c->ws_cts2, pong_rows * HC_N * sizeof(u64)));
+        HC_HIP(c, hcx_malloc(c, (void **)&c->ws_cts2, pong_rows * HC_N * sizeof(u64)));
         c->ws_cts2_rows = pong_rows;
     }
     u64 *src = cts, *dst = c->ws_cts2;
@@ -792,7 +808,7 @@ static int hc_ks_common(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uin
     // never takes this detour.
     auto it = c->evk.find(galEl);
     if (it == c->evk.end()) return hc_fail(c, HC_ERR_STATE, "no switching key loaded for galEl=%llu", (unsigned long long)galEl);
-    u64 *buf = nullptr; HC_HIP(c, hipMalloc((void **)&buf, (size_t)6 * HC_N * sizeof(u64)));
+    u64 *buf = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&buf, (size_t)6 * HC_N * sizeof(u64)));
     u64 *y = buf, *x = buf + 2 * HC_N, *res = buf + 4 * HC_N;
     int rc = HC_OK;
     hipMemsetAsync(x, 0, 2 * HC_N * sizeof(u64), c->stream);
@@ -820,7 +836,7 @@ static int hc_ks_common(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uin
         }
     }
     hipStreamSynchronize(c->stream);
-    hipFree(buf);
+    hcx_free(c, buf);
     return rc;
 }
 extern "C" int hc_rotate_gal_l0(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uint64_t *c1, uint64_t *o0, uint64_t *o1) {
@@ -830,7 +846,7 @@ extern "C" int hc_rotate_gal_l0(hc_ctx *c, uint64_t galEl, const uint64_t *c0, c
 extern "C" int hc_keyswitch_l0(hc_ctx *c, uint64_t galEl, const uint64_t *c1, uint64_t *d0, uint64_t *d1) {
     // SwitchKeysInPlace(c1) = Permute_{g^-1}( RotateGal((0, c1)) ): undo the permutation with the inverse element
     HC_ENTER(c); if (!c1 || !d0 || !d1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_l0: null");
-    u64 *buf = nullptr; HC_HIP(c, hipMalloc((void **)&buf, (size_t)2 * HC_N * sizeof(u64)));
+    u64 *buf = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&buf, (size_t)2 * HC_N * sizeof(u64)));
     int rc = hc_ks_common(c, galEl, nullptr, c1, buf, buf + HC_N, true);
     if (!rc) {
         u64 twoN = 2ull * HC_N, ginv = 1, b = galEl % twoN;
@@ -838,7 +854,7 @@ extern "C" int hc_keyswitch_l0(hc_ctx *c, uint64_t galEl, const uint64_t *c1, ui
         rc = hc_permute(c, ginv, buf, d0, 1);
         if (!rc) rc = hc_permute(c, ginv, buf + HC_N, d1, 1);
     }
-    hipStreamSynchronize(c->stream); hipFree(buf);
+    hipStreamSynchronize(c->stream); hcx_free(c, buf);
     return rc;
 }
 
@@ -864,11 +880,11 @@ extern "C" int hc_swk_load(hc_ctx *c, uint64_t key_id, int level, const uint64_t
     const int nt = level + 1 + c->np, beta = (level + 1 + c->np - 1) / c->np;
     const size_t n = (size_t)beta * 2 * nt * HC_N;
     HcSwk k; k.level = level; k.beta = beta;
-    HC_HIP(c, hipMalloc((void **)&k.rows, n * sizeof(u64)));
+    HC_HIP(c, hcx_malloc(c, (void **)&k.rows, n * sizeof(u64)));
     HC_HIP(c, hipMemcpyAsync(k.rows, rows_host, n * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     HC_HIP(c, hipStreamSynchronize(c->stream));
     auto it = c->swk.find(key_id);
-    if (it != c->swk.end()) hipFree(it->second.rows);
+    if (it != c->swk.end()) hcx_free(c, it->second.rows);
     c->swk[key_id] = k;
     return HC_OK;
 }
@@ -890,10 +906,10 @@ static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
             hd[(size_t)l] = hc_make_bx(psrc, q); hp[(size_t)l] = h_pair(h_inv(pmod, q), q);
         }
         hc_ctx::KsPlan P;
-        HC_HIP(c, hipMalloc((void **)&P.bx, hb.size() * sizeof(HcBasisExt))); HC_HIP(c, hipMalloc((void **)&P.bxdown, hd.size() * sizeof(HcBasisExt))); HC_HIP(c, hipMalloc((void **)&P.pinv, hp.size() * sizeof(HcTw)));
-        HC_HIP(c, hipMemcpy(P.bx, hb.data(), hb.size() * sizeof(HcBasisExt), hipMemcpyHostToDevice));
-        HC_HIP(c, hipMemcpy(P.bxdown, hd.data(), hd.size() * sizeof(HcBasisExt), hipMemcpyHostToDevice));
-        HC_HIP(c, hipMemcpy(P.pinv, hp.data(), hp.size() * sizeof(HcTw), hipMemcpyHostToDevice));
+        HC_HIP(c, hcx_malloc(c, (void **)&P.bx, hb.size() * sizeof(HcBasisExt))); HC_HIP(c, hcx_malloc(c, (void **)&P.bxdown, hd.size() * sizeof(HcBasisExt))); HC_HIP(c, hcx_malloc(c, (void **)&P.pinv, hp.size() * sizeof(HcTw)));
+        HC_HIP(c, hcx_h2d(c, P.bx, hb.data(), hb.size() * sizeof(HcBasisExt)));
+        HC_HIP(c, hcx_h2d(c, P.bxdown, hd.data(), hd.size() * sizeof(HcBasisExt)));
+        HC_HIP(c, hcx_h2d(c, P.pinv, hp.data(), hp.size() * sizeof(HcTw)));
         pit = c->ks_plan.emplace(level, P).first;
     }
     *out = &pit->second;
@@ -977,9 +993,9 @@ extern "C" int hc_keyswitch_hoisted(hc_ctx *c, uint64_t key_id, int level, const
 static int hc_ensure_cts(hc_ctx *c, size_t rows) {
     if (c->ws_cts_rows >= rows) return HC_OK;
     HC_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->ws_cts) HC_HIP(c, hipFree(c->ws_cts));
+    if (c->ws_cts) HC_HIP(c, hcx_free(c, c->ws_cts));
     c->ws_cts = nullptr; c->ws_cts_rows = 0;
-    HC_HIP(c, hipMalloc((void **)&c->ws_cts, rows * HC_N * sizeof(u64)));
+    HC_HIP(c, hcx_malloc(c, (void **)&c->ws_cts, rows * HC_N * sizeof(u64)));
     c->ws_cts_rows = rows;
     return HC_OK;
 }
@@ -1020,9 +1036,9 @@ static int hc_conv_lanes(hc_ctx *c, const hc_ker *ker, int max_ob, int G, const 
     if (!c->ev_fork) HC_HIP(c, hipEventCreate(&c->ev_fork));
     if (c->ws_gather_rows < (size_t)G * 2) {
         HC_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->ws_gather) HC_HIP(c, hipFree(c->ws_gather));
+        if (c->ws_gather) HC_HIP(c, hcx_free(c, c->ws_gather));
         c->ws_gather = nullptr; c->ws_gather_rows = 0;
-        HC_HIP(c, hipMalloc((void **)&c->ws_gather, (size_t)G * 2 * HC_N * sizeof(u64)));
+        HC_HIP(c, hcx_malloc(c, (void **)&c->ws_gather, (size_t)G * 2 * HC_N * sizeof(u64)));
         c->ws_gather_rows = (size_t)G * 2;
     }
     HC_HIP(c, hipEventRecord(c->ev_fork, c->stream));          // ctc (and everything queued before) is ready
@@ -1030,9 +1046,9 @@ static int hc_conv_lanes(hc_ctx *c, const hc_ker *ker, int max_ob, int G, const 
         HcLane &L = c->lane[(size_t)g];
         if (L.cts_rows < (size_t)nloc * 2) {
             HC_HIP(c, hipStreamSynchronize(L.stream));
-            if (L.cts) HC_HIP(c, hipFree(L.cts));
+            if (L.cts) HC_HIP(c, hcx_free(c, L.cts));
             L.cts = nullptr; L.cts_rows = 0;
-            HC_HIP(c, hipMalloc((void **)&L.cts, (size_t)nloc * 2 * HC_N * sizeof(u64)));
+            HC_HIP(c, hcx_malloc(c, (void **)&L.cts, (size_t)nloc * 2 * HC_N * sizeof(u64)));
             L.cts_rows = (size_t)nloc * 2;
         }
         int rc;
