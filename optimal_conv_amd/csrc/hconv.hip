@@ -95,7 +95,9 @@ struct hc_ctx {
     // hipGraph replay of a whole conv_then_pack (option "graph"): the launch list of a conv is static for fixed buffers and
     // constants, so the second call with the same arguments is captured once and later calls are one graph launch
     long use_graph = 0;
-    int async_alloc = 0;                                    // HCONV_ASYNC_ALLOC=1: stream-ordered allocator + non-blocking stream (see hcx_malloc)
+    struct CacheBlk { size_t n = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    std::map<char *, CacheBlk> cache_blk; std::map<size_t, std::vector<void *>> cache_free;      // HCONV_ASYNC_ALLOC=1: sizes of the blocks this context allocated; parked blocks by size
+    int async_alloc = 0;                                    // HCONV_ASYNC_ALLOC=1: non-blocking stream + cached allocations (see hcx_malloc)
     long ks_fused = 0;                                      // plain key switch with the digits' second transform pass inside the inner product (hc_k_rows_fwd_mac): measured 3 % slower per ResNet image (202 VGPRs, a serial loop over the digits), so off
     struct GraphKey { const void *ct_in, *ker, *bias; void *ct_out; int max_ob, norm; u64 c0, c1; long chunk;
         bool operator<(const GraphKey &o) const { return memcmp(this, &o, sizeof *this) < 0; } };
@@ -131,13 +133,49 @@ static int hc_fail(hc_ctx *c, int code, const char *fmt, ...) {
 
 // forward lazy-reduction mode by modulus size (see HC_FM_* in hc_kernels.h): 34q < 2^64 <=> q < 2^58.9
 // Allocation: plain hipMalloc / hipFree by default. hipFree synchronises the whole device, which is harmless with one context but
-// serialises independent contexts driven from several host threads (a thread's free waits for every other thread's queued work);
-// HCONV_ASYNC_ALLOC=1 at context creation switches this context to the stream-ordered allocator (hipMallocAsync / hipFreeAsync on
-// its own stream, a non-blocking stream) so that nothing in a steady-state call touches other streams.
-static hipError_t hcx_malloc(hc_ctx *c, void **p, size_t n) { return (c && c->async_alloc) ? hipMallocAsync(p, n ? n : 1, c->stream) : hipMalloc(p, n); }
-static hipError_t hcx_free(hc_ctx *c, void *p) { if (!p) return hipSuccess; return (c && c->async_alloc) ? hipFreeAsync(p, c->stream) : hipFree(p); }
+// serialises independent contexts driven from several host threads (a thread's free waits for every other thread's queued work).
+// HCONV_ASYNC_ALLOC=1 at context creation gives this context a non-blocking stream and a cache of its own hipMalloc blocks: hc_free
+// parks a block, the next request of the same size takes it — no hipFree, hence no device-wide synchronisation, in steady state
+// (a layer asks for the same sizes again and again). Reuse is safe because every use of a block is queued on this context's stream
+// (see hcx_h2d_async for the one host-side exception). ROCm 7.2's own stream-ordered allocator (hipMallocAsync / hipFreeAsync) was
+// tried first and is NOT used: with it `conv 3 3` returned wrong loop-A outputs for channels 19..243 as soon as the 256 MiB staging
+// block of hc_prep_ker was recycled, with synchronous or asynchronous frees alike, while this cache — the same reuse pattern on plain
+// hipMalloc blocks — is bit-exact.
+static hipError_t hcx_malloc(hc_ctx *c, void **p, size_t n) {
+    if (!(c && c->async_alloc)) return hipMalloc(p, n);
+    auto it = c->cache_free.find(n);
+    if (it != c->cache_free.end() && !it->second.empty()) { *p = it->second.back(); it->second.pop_back(); return hipSuccess; }
+    hipError_t e = hipMalloc(p, n);
+    if (e == hipSuccess) { hc_ctx::CacheBlk b; b.n = n; c->cache_blk[(char *)*p] = b; }
+    return e;
+}
+static hipError_t hcx_free(hc_ctx *c, void *p) {
+    if (!p) return hipSuccess;
+    if (!(c && c->async_alloc)) return hipFree(p);
+    auto it = c->cache_blk.find((char *)p);
+    if (it == c->cache_blk.end()) return hipFree(p);
+    // everything queued so far may still read or write the block: remember that point of the stream (see hcx_h2d_async)
+    if (!it->second.ev && hipEventCreateWithFlags(&it->second.ev, hipEventDisableTiming) != hipSuccess) it->second.ev = nullptr;
+    if (it->second.ev && hipEventRecord(it->second.ev, c->stream) == hipSuccess) it->second.pending = true;
+    else { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) return e; it->second.pending = false; }
+    c->cache_free[it->second.n].push_back(p);
+    return hipSuccess;
+}
+// Host-to-device copy "on the stream" from pageable memory. The runtime may carry such a copy out at once from the host instead of
+// queueing it. With hipFree that is invisible (it drains the device first); with cached blocks a block parked while kernels that
+// use it are still queued could be handed out again and be overwritten by an eager copy before those kernels ran. So a copy into a
+// recycled block first waits for the event recorded when the block was parked — normally long complete, so nothing stalls, and
+// never anything of another context.
+static hipError_t hcx_h2d_async(hc_ctx *c, void *dst, const void *src, size_t n) {
+    if (c->async_alloc && !c->cache_blk.empty()) {
+        auto it = c->cache_blk.upper_bound((char *)dst);
+        if (it != c->cache_blk.begin()) { --it; if ((char *)dst < it->first + it->second.n && it->second.pending) {
+            hipError_t e = hipEventSynchronize(it->second.ev); if (e != hipSuccess) return e; it->second.pending = false; } }
+    }
+    return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->stream);
+}
 static hipError_t hcx_h2d(hc_ctx *c, void *dst, const void *src, size_t n) {      // blocking copy on the context's stream (not the null stream)
-    hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hcx_h2d_async(c, dst, src, n);
     return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
 }
 static inline bool hc_fm_free(u64 q) { return q < (1ull << 58); }
@@ -235,10 +273,6 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
     hc_ctx *c = new hc_ctx();
     c->device = device; c->nq = nq; c->np = np;
     { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa && atoi(aa) ? 1 : 0; }
-    if (c->async_alloc && hipSetDevice(device) == hipSuccess) {      // keep freed blocks in the pool instead of returning them to the driver at every synchronisation
-        hipMemPool_t pool; uint64_t thr = ~0ull;
-        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-    }
     if (hipSetDevice(device) != hipSuccess || (c->async_alloc ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: cannot create stream on device %d", device); }
     hipEventCreate(&c->t0); hipEventCreate(&c->t1);
     c->mods.resize((size_t)(nq + np));
@@ -279,6 +313,8 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto &kv : c->cache_free) for (void *d : kv.second) hipFree(d);      // blocks parked by the caching allocator
+    for (auto &kv : c->cache_blk) if (kv.second.ev) hipEventDestroy(kv.second.ev);
     for (auto &mh : c->mods) for (void *d : mh.allocs) hipFree(d);
     for (auto &kv : c->evk) { hipFree(kv.second.q_rows); hipFree(kv.second.p_rows); }
     for (auto &kv : c->swk) hipFree(kv.second.rows);
@@ -310,7 +346,7 @@ extern "C" int hc_malloc(hc_ctx *c, size_t bytes, void **dptr) { HC_ENTER(c); if
 extern "C" int hc_free(hc_ctx *c, void *dptr) { HC_ENTER(c); HC_HIP(c, hipStreamSynchronize(c->stream)); HC_HIP(c, hcx_free(c, dptr)); return HC_OK; }
 extern "C" int hc_upload(hc_ctx *c, void *dst, const void *src, size_t bytes) {
     HC_ENTER(c); if (!dst || !src) return hc_fail(c, HC_ERR_ARG, "hc_upload: null pointer");
-    HC_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hcx_h2d_async(c, dst, src, bytes));
     HC_HIP(c, hipStreamSynchronize(c->stream));   // the host buffer may be released right after return (cgo rule)
     return HC_OK;
 }
@@ -562,7 +598,7 @@ static int hc_div_round_last_n(hc_ctx *c, int level, const u64 *x, size_t xs, u6
     u64 *one = scratch, *cts = scratch + 2 * HC_N;
     std::vector<u64> h((size_t)2 * HC_N);
     for (int l = 0; l < 2; l++) { u64 q = c->mods[(size_t)l].m.q; u64 r = (u64)((((u128)1) << 64) % q); for (int j = 0; j < HC_N; j++) h[(size_t)l * HC_N + (size_t)j] = r; }
-    HC_HIP(c, hipMemcpyAsync(one, h.data(), h.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hcx_h2d_async(c, one, h.data(), h.size() * sizeof(u64)));
     HC_HIP(c, hipMemcpyAsync(c->ws_ctc, x, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
     HC_HIP(c, hipMemcpyAsync(c->ws_ctc + 2 * HC_N, x, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
     int rc = hc_loopA_run(c, one, 1, 1, cts);
@@ -600,10 +636,10 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
     HcEvk e; e.q_rows = nullptr; e.p_rows = nullptr; e.row_local = hc_perm_row_local(galEl);
     HC_HIP(c, hcx_malloc(c, (void **)&e.q_rows, 2 * HC_N * sizeof(u64)));
     HC_HIP(c, hcx_malloc(c, (void **)&e.p_rows, 2 * HC_N * sizeof(HcTw)));
-    HC_HIP(c, hipMemcpyAsync(e.q_rows, b_q, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    HC_HIP(c, hipMemcpyAsync(e.q_rows + HC_N, a_q, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    HC_HIP(c, hipMemcpyAsync(stage, b_p, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
-    HC_HIP(c, hipMemcpyAsync(stage + HC_N, a_p, HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hcx_h2d_async(c, e.q_rows, b_q, HC_N * sizeof(u64)));
+    HC_HIP(c, hcx_h2d_async(c, e.q_rows + HC_N, a_q, HC_N * sizeof(u64)));
+    HC_HIP(c, hcx_h2d_async(c, stage, b_p, HC_N * sizeof(u64)));
+    HC_HIP(c, hcx_h2d_async(c, stage + HC_N, a_p, HC_N * sizeof(u64)));
     // Q rows times P^-1 mod Q0 once, here: ModDown's final division is then already inside b5's product with the key (hc_k_b4/b5)
     const HcTw pinv = h_pair(h_inv(mp.m.q % m0.m.q, m0.m.q), m0.m.q);
     int rc = hc_launch(c, "evk_div_p", hc_k_pointwise<HC_PW_MULC>, hc_pw_grid(2 * HC_N), (const u64 *)e.q_rows, (const u64 *)e.q_rows, e.q_rows, (size_t)2 * HC_N, m0.m, pinv);
@@ -627,11 +663,11 @@ extern "C" int hc_idx_load(hc_ctx *c, const uint64_t *idx_host) {
     u64 *stage = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&stage, (size_t)HC_LOGN * HC_N * sizeof(u64)));
     int rc = HC_OK;
     if (idx_host) {
-        HC_HIP(c, hipMemcpyAsync(stage, idx_host, (size_t)HC_LOGN * HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        HC_HIP(c, hcx_h2d_async(c, stage, idx_host, (size_t)HC_LOGN * HC_N * sizeof(u64)));
     } else {   // conv.go:248-253: coeffs[1<<i] = 1 -> EncodeCoeffs(scale 1) -> ToNTT, on the device
         HC_HIP(c, hipMemsetAsync(stage, 0, (size_t)HC_LOGN * HC_N * sizeof(u64), c->stream));
         u64 one = 1;
-        for (int i = 0; i < HC_LOGN; i++) HC_HIP(c, hipMemcpyAsync(stage + (size_t)i * HC_N + ((size_t)1 << i), &one, sizeof one, hipMemcpyHostToDevice, c->stream));
+        for (int i = 0; i < HC_LOGN; i++) HC_HIP(c, hcx_h2d_async(c, stage + (size_t)i * HC_N + ((size_t)1 << i), &one, sizeof one));
         HC_HIP(c, hipStreamSynchronize(c->stream));
         u64 *tmp = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&tmp, (size_t)HC_LOGN * HC_N * sizeof(u64)));
         rc = HC_LAUNCH_FM(m0.m.q, c, "cols_fwd", hc_k_cols_fwd, dim3(16, HC_LOGN), (const u64 *)stage, tmp, m0.fwd, m0.m.q);
@@ -661,7 +697,7 @@ extern "C" int hc_ker_load(hc_ctx *c, const uint64_t *host, int max_ob, hc_ker *
     HC_ENTER(c);
     if (!host || !out || max_ob < 1 || c->nq < 2) return hc_fail(c, HC_ERR_ARG, "hc_ker_load: bad arguments");
     u64 *d = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&d, (size_t)max_ob * 2 * HC_N * sizeof(u64)));
-    HC_HIP(c, hipMemcpyAsync(d, host, (size_t)max_ob * 2 * HC_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hcx_h2d_async(c, d, host, (size_t)max_ob * 2 * HC_N * sizeof(u64)));
     return hc_ker_from_device(c, d, max_ob, true, out);
 }
 extern "C" int hc_ker_load_device(hc_ctx *c, const uint64_t *dptr, int max_ob, hc_ker **out) {
@@ -686,8 +722,8 @@ extern "C" int hc_prep_ker(hc_ctx *c, const double *ker_in, int ker_len, const d
     HC_HIP(c, hcx_malloc(c, (void **)&da, (size_t)real_ob * sizeof(double)));
     HC_HIP(c, hcx_malloc(c, (void **)&stage, (size_t)max_bat * 2 * HC_N * sizeof(u64)));
     HC_HIP(c, hcx_malloc(c, (void **)&dst, (size_t)max_bat * 2 * HC_N * sizeof(u64)));
-    HC_HIP(c, hipMemcpyAsync(dk, ker_in, (size_t)ker_len * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HC_HIP(c, hipMemcpyAsync(da, bn_a, (size_t)real_ob * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hcx_h2d_async(c, dk, ker_in, (size_t)ker_len * sizeof(double)));
+    HC_HIP(c, hcx_h2d_async(c, da, bn_a, (size_t)real_ob * sizeof(double)));
     HC_HIP(c, hipMemsetAsync(stage, 0, (size_t)max_bat * 2 * HC_N * sizeof(u64), c->stream));
     HcPrepKer P; P.ker_in = dk; P.bn_a = da; P.stage = stage; P.in_wid = in_wid; P.ker_wid = ker_wid; P.real_ib = real_ib; P.real_ob = real_ob;
     P.norm = norm; P.max_bat = max_bat; P.scale = scale; P.q0 = c->mods[0].m.q; P.q1 = c->mods[1].m.q;
@@ -881,7 +917,7 @@ extern "C" int hc_swk_load(hc_ctx *c, uint64_t key_id, int level, const uint64_t
     const size_t n = (size_t)beta * 2 * nt * HC_N;
     HcSwk k; k.level = level; k.beta = beta;
     HC_HIP(c, hcx_malloc(c, (void **)&k.rows, n * sizeof(u64)));
-    HC_HIP(c, hipMemcpyAsync(k.rows, rows_host, n * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HC_HIP(c, hcx_h2d_async(c, k.rows, rows_host, n * sizeof(u64)));
     HC_HIP(c, hipStreamSynchronize(c->stream));
     auto it = c->swk.find(key_id);
     if (it != c->swk.end()) hcx_free(c, it->second.rows);

@@ -337,6 +337,12 @@ void GpuEvaluator::RotateGal(const Ciphertext &ct, uint64_t galEl, Ciphertext &o
     out.Scale = ct.Scale; out.level = 0;
 }
 
+static void dbg_digest(Context *c, const char *what, const uint64_t *d, size_t rows) {      // HCONV_DBG_STAGES: FNV-1a of device rows, on stderr
+    if (!getenv("HCONV_DBG_STAGES")) return;
+    std::vector<uint64_t> h = dev_download(c, d, rows); uint64_t f = 1469598103934665603ull;
+    for (uint64_t w : h) for (int b = 0; b < 8; b++) { f ^= (w >> (8 * b)) & 0xff; f *= 1099511628211ull; }
+    fprintf(stderr, "[stage] %-28s %016llx\n", what, (unsigned long long)f);
+}
 // ---------------------------------------------------------------- conv_then_pack / evalConv_BN
 // pack_ctxts (conv.go:266-300), statement by statement, on the ckks.Evaluator subset (GpuEvaluator = one C-ABI call per
 // limb row). This is the path a cgo gpuEvaluator takes when conv.go is left untouched.
@@ -404,11 +410,13 @@ Ciphertext conv_then_pack(Context *c, const Ciphertext &ctxt_in, const KerPlain 
     uint64_t *cts = dev_rows(c, (size_t)max_ob * 2);
     HC(c->hc, hc_conv_mult_phase(c->hc, ctxt_in.d, ctxt_in.Scale, pl_ker.h, pl_ker.Scale, max_ob, norm, out_scale, cts));
     HC(c->hc, hc_sync(c->hc));
+    dbg_digest(c, "ct_in", ctxt_in.d, 4); dbg_digest(c, "mult slot 0", cts, 2); dbg_digest(c, "mult slot last", cts + (size_t)(max_ob - 1) * 2 * N, 2); dbg_digest(c, "mult all", cts, (size_t)max_ob * 2);
     auto mt = now();
     printf("\t mult time:  %s\n", dur(start).c_str());
     HC(c->hc, hc_pack_ctxts(c->hc, cts, max_ob, max_ob / norm));
     HC(c->hc, hc_sync(c->hc));
     printf("\t Pack time:  %s\n", dur(mt).c_str());
+    dbg_digest(c, "pack result", cts, 2);
     HC(c->hc, hc_copy(c->hc, r.d, cts, (size_t)2 * N * 8));     // keep the pack result (slot 0), drop the workspace
     HC(c->hc, hc_free(c->hc, cts));
     r.Scale = (out_scale / (double)(max_ob / norm)) * (double)(max_ob / norm);            // conv.go:528 then conv.go:274
@@ -429,6 +437,7 @@ Ciphertext evalConv_BN(Context *c, const Ciphertext &ct_input, const std::vector
     HC(c->hc, hc_sync(c->hc));
     printf("Plaintext (kernel) preparation, Done in %s \n", dur(start).c_str());                                      // eval.go:244
     start = now();
+    dbg_digest(c, "bias plaintext", pl_bn_b.d, 1);
     Ciphertext ct_res = conv_then_pack(c, ct_input, pl_ker, max_batch, norm, c->ECD_LV, out_scale, &pl_bn_b);          // eval.go:251
     if (pl_bn_b.Scale != ct_res.Scale || ct_res.level != 0) {                                                          // eval.go:252-257
         printf("plain scale:  %g\nctxt scale:  %g\nctxt lv:  %d\n", pl_bn_b.Scale, ct_res.Scale, ct_res.level);

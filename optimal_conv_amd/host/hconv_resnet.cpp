@@ -139,9 +139,10 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
     // HCONV_IMAGE_THREADS=K (not a reference feature): K host threads, each with its own context (keys, bootstrappers, stream),
     // classify disjoint shares of the images at the same time. A layer's launches are mostly far below one wave of workgroups, so the
     // images of several streams overlap on the CUs (separate PROCESSES time-slice the device instead: tools/resnet_throughput.py).
-    // Measured on MI355X, ResNet-20, 12 images: 1 thread 4 771 images/hour, 3 threads 6 823, 4 threads 4 984, 6 threads 6 425.
+    // Measured on MI355X, ResNet-20, 24 images, HCONV_ASYNC_ALLOC=1: 1 thread 4 704 images/hour, 2 threads 5 982, 3 threads 5 553,
+    // 4 threads 5 340 (each image is ~60 000 kernel launches; the threads share the runtime's launch path).
     const int n_threads = std::max(1, std::min(getenv("HCONV_IMAGE_THREADS") ? atoi(getenv("HCONV_IMAGE_THREADS")) : 1, end - st));
-    if (n_threads > 1) setenv("HCONV_ASYNC_ALLOC", "1", 0);      // several contexts in one process: stream-ordered allocation, or every hipFree stalls all of them
+    if (n_threads > 1) setenv("HCONV_ASYNC_ALLOC", "1", 0);      // several contexts in one process: cached allocations on non-blocking streams, or every hipFree stalls all of them
     std::mutex mu; std::condition_variable cv; int ready = 0; std::chrono::steady_clock::time_point t_go;
     auto run_images = [&](int tix) {
     Context *cont;

@@ -64,11 +64,7 @@ static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
-static inline hipError_t hipMallocAsync(void **p, size_t n, hipStream_t) { return hipMalloc(p, n); }
-static inline hipError_t hipFreeAsync(void *p, hipStream_t) { return hipFree(p); }
-typedef int hipMemPool_t; enum { hipMemPoolAttrReleaseThreshold = 0, hipStreamNonBlocking = 1 };
-static inline hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t *, int) { return hipSuccess; }
-static inline hipError_t hipMemPoolSetAttribute(hipMemPool_t, int, void *) { return hipSuccess; }
+enum { hipStreamNonBlocking = 1 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memmove(d, s, n); return hipSuccess; }
@@ -81,6 +77,8 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipEmuEvent{0}; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = hip_emu_now_ms(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }

@@ -19,7 +19,7 @@ python tools/pmc_traffic.py $O/pmc_FETCH_SIZE/run_counter_collection.csv $O/pmc_
 find $O/prof -name "*stats*.csv" | head -3
 # the other CLI configurations: convReLU (baseline + Ours), ResNet-20 throughput, the wide ResNet
 CFGS=5,1 bash tools/gpu_blrelu.sh > $O/convrelu_5_1_summary.txt 2>&1; cp gpurun_out/blrelu/run_5_1.log $O/convrelu_5_1_cli.txt
-timeout 600 python tools/resnet_throughput.py --images 12 --threads 3 > $O/resnet20_throughput_1gpu.json 2> $O/resnet20_throughput.err; cut -c1-300 $O/resnet20_throughput_1gpu.json
+timeout 600 python tools/resnet_throughput.py --images 24 --threads 2 > $O/resnet20_throughput_1gpu.json 2> $O/resnet20_throughput.err; cut -c1-300 $O/resnet20_throughput_1gpu.json
 bash tools/gpu_resnet.sh 20 > $O/resnet20_cli_summary.txt 2>&1; cp gpurun_out/resnet/cli_resnet_20.txt $O/resnet20_cli.txt
 bash tools/gpu_resnet_wide.sh 20 > $O/resnet20_wide2_summary.txt 2>&1; cp gpurun_out/resnet/cli_resnet_w2_20.txt $O/resnet20_wide2_cli.txt; tail -3 $O/resnet20_wide2_cli.txt
 bash tools/gpu_resnet_wide.sh 8 3 > $O/resnet8_wide3_summary.txt 2>&1; cp gpurun_out/resnet/cli_resnet_w3_8.txt $O/resnet8_wide3_cli.txt; tail -3 $O/resnet8_wide3_cli.txt

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 5 (`resnet 3 20 1 n false`, images/hour on N GPUs): images are independent ciphertexts, so N GPUs = N
 processes of the `conv resnet` CLI, one per device (HCONV_DEVICE), each classifying its own share of the images with --threads image
-threads (own context and stream each, stream-ordered allocation: 3 is the measured optimum on MI355X); no collective.
+threads (own context and non-blocking stream each, cached allocations: 2 is the measured optimum on MI355X); no collective.
 Prints one JSON line: images/hour = images / max over ranks of the summed per-image "Total done in" times (context and key
 generation, which the reference also keeps outside its per-image timer, are reported separately).
 Usage: tools/resnet_throughput.py [--gpus N] [--images M per GPU] [--depth 20] [--ker 3]"""
@@ -26,11 +26,11 @@ def to_seconds(tok):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--images", type=int, default=12)
+    ap.add_argument("--images", type=int, default=24)
     ap.add_argument("--depth", type=int, default=20)
     ap.add_argument("--ker", type=int, default=3)
     ap.add_argument("--procs-per-gpu", type=int, default=1, help="independent CLI processes sharing one device: a layer's launches are mostly one wave of workgroups, so the images of several processes overlap on the CUs")
-    ap.add_argument("--threads", type=int, default=3, help="HCONV_IMAGE_THREADS: image threads inside one CLI process (own context and stream each); the images of a GPU are shared among them")
+    ap.add_argument("--threads", type=int, default=2, help="HCONV_IMAGE_THREADS: image threads inside one CLI process (own context and stream each); the images of a GPU are shared among them")
     a = ap.parse_args()
     import golden.gen_resnet_csv as rgen
     cli = os.path.join(ROOT, "optimal_conv_amd", "host", "conv")
