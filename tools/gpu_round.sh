@@ -26,3 +26,5 @@ bash tools/gpu_resnet_wide.sh 8 3 > $O/resnet8_wide3_summary.txt 2>&1; cp gpurun
 bash tools/gpu_relu_prof.sh > $O/relu_prof_summary.txt 2>&1; cp $(find gpurun_out/relu_prof/prof -name "*kernel_stats*.csv" | head -1) $O/convrelu_5_1_kernel_stats.csv 2>/dev/null
 # single-GPU dry run of the N > 1 bookkeeping (two ranks share GPU 0, gloo barriers): not a scaling number
 HC_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29633 bench.py --gpus 2 --steps 20 --warmup 3 > $O/bench_2ranks_1gpu_dryrun.json 2> $O/bench_2ranks.err; cut -c1-200 $O/bench_2ranks_1gpu_dryrun.json
+# the whole GPU suite once more with cached allocations on non-blocking streams (the mode the image threads use)
+HCONV_ASYNC_ALLOC=1 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu_async_alloc.log 2>&1; echo "pytest (HCONV_ASYNC_ALLOC=1) exit $?" >> $O/pytest_gpu_async_alloc.log; tail -2 $O/pytest_gpu_async_alloc.log
