@@ -1,9 +1,10 @@
 #!/bin/bash
-# CPU-side sanitizer runs (GPU ASan is not available on this pool): UBSan over the kernel SOURCES running under the fiber
-# emulator + host orchestration, ASan+UBSan over the oracle. Both must print "... RUN OK" with no sanitizer report.
+# CPU-side sanitizer runs (GPU ASan is not available on this pool): UBSan and ASan over the kernel SOURCES running under the fiber
+# emulator + host orchestration, ASan+UBSan over the oracle. All must print "... RUN OK" with no sanitizer report.
 set -eu
 cd "$(dirname "$0")/.."
 make -s -C tests/kernel_emu "$PWD/tests/kernel_emu/_build/libhconv_emu_ubsan.so"
+make -s -C tests/kernel_emu "$PWD/tests/kernel_emu/_build/libhconv_emu_asan.so"
 make -s -C oracle asan
 cat > /tmp/hc_ubsan_run.py <<PY
 import sys
@@ -40,3 +41,23 @@ sk = O.gen_sk(1); O.gen_galois_key_l0(sk, 65537, 3); O.encrypt(sk, O.encode_coef
 print("ASAN ORACLE RUN OK")
 PY
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" python /tmp/hc_asan_run.py
+
+# AddressSanitizer over the kernel sources + orchestration under the emulator (device memory = heap blocks), in both allocation modes
+cat > /tmp/hc_asan_emu.py <<PY
+import sys, os
+sys.path.insert(0, "$PWD"); sys.path.insert(0, "$PWD/tests")
+import parity_cases as pc
+from oracle_lib import Oracle, Q0, Q1, P0
+from optimal_conv_amd import Context
+LIB = "$PWD/tests/kernel_emu/_build/libhconv_emu_asan.so"
+for mode in ("0", "1"):
+    os.environ["HCONV_ASYNC_ALLOC"] = mode
+    ctx = Context([Q0, Q1], [P0], lib_path=LIB); O = Oracle()
+    pc.case_ntt(ctx, O); pc.case_rescale(ctx, O); pc.case_keyswitch(ctx, O)
+    pc.case_conv(ctx, O, 8, chunk=3); pc.case_conv(ctx, O, 4); pc.case_prep_ker(ctx, O, 3, 0)
+    ctx.close()
+    pc.case_keyswitch_general(lambda Q, P: Context(Q, P, lib_path=LIB), lambda Q, P: Oracle(q=Q, p=P), shapes=((1, 2), (4, 3)))
+    pc.case_ckks_ops(lambda Q, P: Context(Q, P, lib_path=LIB), levels=((6, 2.0 ** 30),))
+    print("ASAN KERNEL-SOURCE RUN OK (HCONV_ASYNC_ALLOC=%s)" % mode)
+PY
+ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python /tmp/hc_asan_emu.py
