@@ -88,6 +88,10 @@ int hc_lv_mul(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint
 int hc_lv_mul_acc(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *acc);
 int hc_lv_add(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
 int hc_lv_sub(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
+/* the pointwise operations above on BOTH polynomials of a ciphertext in one launch (out_k = a_k op b_k, k = 0, 1; the polynomials may live
+ * in separate allocations; pass b1 = b0 for a plaintext operand; HC_LV_MUL_CONST takes `consts` and ignores b; HC_LV_MUL_ACC accumulates into out) */
+enum { HC_LV_MUL = 0, HC_LV_ADD = 1, HC_LV_SUB = 2, HC_LV_MUL_CONST = 3, HC_LV_MUL_ACC = 7 };
+int hc_lv_op2(hc_ctx *ctx, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1, const uint64_t *consts);
 /* the tensor step of evaluator.mulRelin (conv.go:476; EvaluatePoly): d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1; outputs may not alias inputs */
 int hc_lv_mul_tensor(hc_ctx *ctx, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1,
                      uint64_t *d0, uint64_t *d1, uint64_t *d2);

@@ -33,6 +33,7 @@ SYMBOLS = {
     "hc_mul_const": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]),
     "hc_const_for": (C.c_uint64, [C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_double)]),
     "hc_div_round_last": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "hc_lv_op2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_div_round_last2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_permute": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]),
     "hc_evk_load": (C.c_int, [C.c_void_p, C.c_uint64, u64p, u64p, u64p, u64p]),
@@ -299,6 +300,18 @@ class Context:
         out = D.download((level + 1, self.N))
         A.free(); B_.free(); D.free()
         return out
+    def lv_op2(self, op, level, a, b=None, out=None, consts=None, shared_b=False):
+        """hc_lv_op2: a, b, out = (2, level+1, N) ciphertexts (b = (level+1, N) with shared_b: a plaintext operand); separate allocations per polynomial"""
+        A = [self.buf(np.ascontiguousarray(a[k], dtype=np.uint64)) for k in range(2)]
+        Bs = [] if b is None else ([self.buf(np.ascontiguousarray(b, dtype=np.uint64))] * 2 if shared_b else [self.buf(np.ascontiguousarray(b[k], dtype=np.uint64)) for k in range(2)])
+        O = [self.buf(np.ascontiguousarray(out[k], dtype=np.uint64)) if out is not None else self.buf(nwords=(level + 1) * self.N) for k in range(2)]
+        cs = (C.c_uint64 * (level + 1))(*[int(x) for x in consts]) if consts is not None else None
+        self._ck(self.L.hc_lv_op2(self.h, op, level, A[0].ptr, A[1].ptr, Bs[0].ptr if Bs else None, Bs[1].ptr if Bs else None, O[0].ptr, O[1].ptr, cs))
+        res = np.stack([O[k].download((level + 1, self.N)) for k in range(2)])
+        for x in A + O + (Bs[:1] if shared_b else Bs):
+            x.free()
+        return res
+
     def lv_sub(self, level, a, b): return self._lv(self.L.hc_lv_sub, level, a, b)
     def lv_mul_const(self, level, a, consts): return self._lv(self.L.hc_lv_mul_const, level, a, consts=consts)
     def lv_add_const(self, level, a, consts): return self._lv(self.L.hc_lv_add_const, level, a, consts=consts)

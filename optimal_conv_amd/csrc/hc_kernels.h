@@ -303,9 +303,10 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_pointwise(const u64 *a, const u64
 enum { HC_PW_ADDC = 6, HC_PW_MAC = 7 };    // MAC: out = out + a * b (the diagonal sums of a linear transform)
 struct HcLvConsts { HcTw c[32]; };      // per-limb constants of one call, passed by value (no host-device copy, no synchronisation)
 template <int OP>
-__global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const u64 *b, u64 *out, const HcMod *mods, HcLvConsts K) {
+__global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const u64 *b, u64 *out, const HcMod *mods, HcLvConsts K, size_t as = 0, size_t bs = 0, size_t os = 0) {
     const int l = blockIdx.y; const HcMod m = mods[l]; const HcTw *csts = K.c;
     const size_t base = (size_t)l * 65536;
+    a += (size_t)blockIdx.z * as; b += (size_t)blockIdx.z * bs; out += (size_t)blockIdx.z * os;      // blockIdx.z = polynomial of a ciphertext (distances modulo 2^64)
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
         const u64 x = a[base + i]; u64 r;
         if (OP == HC_PW_MUL) r = hc_mont(x, hc_mont(b[base + i], m.r2, m.q, m.qinv), m.q, m.qinv);

@@ -437,7 +437,32 @@ static int hc_lv_pw(hc_ctx *c, const char *fn, int level, const uint64_t *a, con
         if (level >= 32) return hc_fail(c, HC_ERR_UNSUPPORTED, "%s: more than 32 limbs", fn);
         for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[l] = h_pair(consts_host[l] % q, q); }
     }
-    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, hc_lv_grid(level), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, K);
+    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, hc_lv_grid(level), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, K, (size_t)0, (size_t)0, (size_t)0);
+}
+// the same operations on both polynomials of a ciphertext in one launch (they may live in separate allocations; b1 == b0 for a plaintext operand)
+template <int OP>
+static int hc_lv_pw2(hc_ctx *c, const char *fn, int level, const u64 *a0, const u64 *a1, const u64 *b0, const u64 *b1, u64 *o0, u64 *o1, const uint64_t *consts_host) {
+    HC_TRY(hc_lv_check(c, fn, level, a0, o0));
+    if (!a1 || !o1 || ((OP == HC_PW_MUL || OP == HC_PW_ADD || OP == HC_PW_SUB || OP == HC_PW_MAC) && (!b0 || !b1))) return hc_fail(c, HC_ERR_ARG, "%s: null", fn);
+    HcLvConsts K; memset(&K, 0, sizeof K);
+    if (OP == HC_PW_MULC) {
+        if (!consts_host) return hc_fail(c, HC_ERR_ARG, "%s: null constants", fn);
+        if (level >= 32) return hc_fail(c, HC_ERR_UNSUPPORTED, "%s: more than 32 limbs", fn);
+        for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[l] = h_pair(consts_host[l] % q, q); }
+    }
+    const u64 *bb0 = b0 ? b0 : a0, *bb1 = b1 ? b1 : a1;
+    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(64, (unsigned)(level + 1), 2), a0, bb0, o0, (const HcMod *)c->d_mods, K, (size_t)(a1 - a0), (size_t)(bb1 - bb0), (size_t)(o1 - o0));
+}
+extern "C" int hc_lv_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1, const uint64_t *consts) {
+    HC_ENTER(c);
+    switch (op) {
+        case HC_LV_MUL: return hc_lv_pw2<HC_PW_MUL>(c, "hc_lv_op2(mul)", level, a0, a1, b0, b1, out0, out1, nullptr);
+        case HC_LV_ADD: return hc_lv_pw2<HC_PW_ADD>(c, "hc_lv_op2(add)", level, a0, a1, b0, b1, out0, out1, nullptr);
+        case HC_LV_SUB: return hc_lv_pw2<HC_PW_SUB>(c, "hc_lv_op2(sub)", level, a0, a1, b0, b1, out0, out1, nullptr);
+        case HC_LV_MUL_CONST: return hc_lv_pw2<HC_PW_MULC>(c, "hc_lv_op2(mul_const)", level, a0, a1, nullptr, nullptr, out0, out1, consts);
+        case HC_LV_MUL_ACC: return hc_lv_pw2<HC_PW_MAC>(c, "hc_lv_op2(mul_acc)", level, a0, a1, b0, b1, out0, out1, nullptr);
+    }
+    return hc_fail(c, HC_ERR_ARG, "hc_lv_op2: unknown operation %d", op);
 }
 extern "C" int hc_lv_mul(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_MUL>(c, "hc_lv_mul", level, a, b, out, nullptr); }
 extern "C" int hc_lv_mul_acc(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *acc) { return hc_lv_pw<HC_PW_MAC>(c, "hc_lv_mul_acc", level, a, b, acc, nullptr); }

@@ -164,6 +164,7 @@ struct Boot {
     DCt add(const DCt &a0, const DCt &b0) {
         const int L = std::min(a0.level, b0.level); same_scale(a0.scale, b0.scale);
         DCt r = new_ct(L, std::max(a0.deg, b0.deg), a0.scale);
+        if (a0.deg == 1 && b0.deg == 1) { HCR(hc_lv_op2(hc, HC_LV_ADD, L, a0.p[0].get(), a0.p[1].get(), b0.p[0].get(), b0.p[1].get(), r.p[0].get(), r.p[1].get(), nullptr)); return r; }   // both polynomials per launch
         for (int d = 0; d <= r.deg; d++) {
             if (d <= a0.deg && d <= b0.deg) HCR(hc_lv_add(hc, L, a0.p[d].get(), b0.p[d].get(), r.p[d].get()));
             else HCR(hc_copy(hc, r.p[d].get(), (d <= a0.deg ? a0 : b0).p[d].get(), (size_t)(L + 1) * N * 8));
@@ -174,7 +175,8 @@ struct Boot {
         const int L = std::min(a0.level, b0.level); same_scale(a0.scale, b0.scale);
         if (a0.deg != b0.deg) panic("sub: degrees differ");
         DCt r = new_ct(L, a0.deg, a0.scale);
-        for (int d = 0; d <= r.deg; d++) HCR(hc_lv_sub(hc, L, a0.p[d].get(), b0.p[d].get(), r.p[d].get()));
+        if (r.deg == 1) HCR(hc_lv_op2(hc, HC_LV_SUB, L, a0.p[0].get(), a0.p[1].get(), b0.p[0].get(), b0.p[1].get(), r.p[0].get(), r.p[1].get(), nullptr));
+        else for (int d = 0; d <= r.deg; d++) HCR(hc_lv_sub(hc, L, a0.p[d].get(), b0.p[d].get(), r.p[d].get()));
         return r;
     }
     std::vector<uint64_t> consts(const u128 mag, bool neg, int level) const {
@@ -192,7 +194,8 @@ struct Boot {
         u128 mag; bool neg; split_int(k_rounded_value, &mag, &neg);
         std::vector<uint64_t> c = consts(mag, neg, a.level);
         DCt r = new_ct(a.level, a.deg, a.scale);
-        for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul_const(hc, a.level, a.p[d].get(), c.data(), r.p[d].get()));
+        if (a.deg == 1) HCR(hc_lv_op2(hc, HC_LV_MUL_CONST, a.level, a.p[0].get(), a.p[1].get(), nullptr, nullptr, r.p[0].get(), r.p[1].get(), c.data()));
+        else for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul_const(hc, a.level, a.p[d].get(), c.data(), r.p[d].get()));
         return r;
     }
     DCt add_const_int(const DCt &a, double k_rounded_value) {
@@ -206,12 +209,14 @@ struct Boot {
     DCt mul_plain(const DCt &a, const DPt &pt) {
         if (pt.level < a.level) panic("mul_plain: plaintext below the ciphertext's level");
         DCt r = new_ct(a.level, a.deg, a.scale * pt.scale);
-        for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul(hc, a.level, a.p[d].get(), pt.p.get(), r.p[d].get()));
+        if (a.deg == 1) HCR(hc_lv_op2(hc, HC_LV_MUL, a.level, a.p[0].get(), a.p[1].get(), pt.p.get(), pt.p.get(), r.p[0].get(), r.p[1].get(), nullptr));
+        else for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul(hc, a.level, a.p[d].get(), pt.p.get(), r.p[d].get()));
         return r;
     }
     DCt mul_by_i(const DCt &a) {
         DCt r = new_ct(a.level, a.deg, a.scale);
-        for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul(hc, a.level, a.p[d].get(), mono_i.get(), r.p[d].get()));
+        if (a.deg == 1) HCR(hc_lv_op2(hc, HC_LV_MUL, a.level, a.p[0].get(), a.p[1].get(), mono_i.get(), mono_i.get(), r.p[0].get(), r.p[1].get(), nullptr));
+        else for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul(hc, a.level, a.p[d].get(), mono_i.get(), r.p[d].get()));
         return r;
     }
     DCt mul_relin(const DCt &a, const DCt &b) {                   // evaluator.MulRelin: tensor, key switch of c2 with the rlk
@@ -392,7 +397,8 @@ struct Boot {
             for (auto &b : g.second) {
                 const DCt &r = rots[b.first];
                 if (!have) { inner = mul_plain(r, b.second); have = true; }
-                else for (int d = 0; d <= r.deg; d++) HCR(hc_lv_mul_acc(hc, r.level, r.p[d].get(), b.second.p.get(), inner.p[d].get()));   // same plaintext scale: the sum stays at inner.scale
+                else if (r.deg == 1) HCR(hc_lv_op2(hc, HC_LV_MUL_ACC, r.level, r.p[0].get(), r.p[1].get(), b.second.p.get(), b.second.p.get(), inner.p[0].get(), inner.p[1].get(), nullptr));   // same plaintext scale: the sum stays at inner.scale
+                else for (int d = 0; d <= r.deg; d++) HCR(hc_lv_mul_acc(hc, r.level, r.p[d].get(), b.second.p.get(), inner.p[d].get()));
             }
             inner = rotate(inner, g.first);
             acc = have_acc ? add(acc, inner) : inner; have_acc = true;

@@ -355,6 +355,15 @@ def case_ckks_ops(make_ctx, logN=16, seed=3, levels=((23, 2.0 ** 55), (9, 2.0 **
     L = levels[0][0]                                     # acc += a*b in one pass == mul then add
     x, y, z = (Co.encrypt_slots(a, L, 2.0 ** 30, seed=s_).rows[0] for s_ in (31, 32, 33))
     eq(ctx.lv_mul_acc(L, x, y, z), Co.be.lv_add(z, Co.be.lv_mul(x, y)), "lv_mul_acc")
+    for L, _ in levels:                                  # hc_lv_op2: both polynomials per launch == the per-polynomial operations
+        ca, cb = Co.encrypt_slots(a, L, 2.0 ** 30, seed=51).rows, Co.encrypt_slots(b, L, 2.0 ** 30, seed=52).rows
+        be = Co.be
+        eq(ctx.lv_op2(1, L, ca, cb), np.stack([be.lv_add(ca[k], cb[k]) for k in range(2)]), f"lv_op2 add level {L}")
+        eq(ctx.lv_op2(2, L, ca, cb), np.stack([be.lv_sub(ca[k], cb[k]) for k in range(2)]), f"lv_op2 sub level {L}")
+        eq(ctx.lv_op2(0, L, ca, cb[0], shared_b=True), np.stack([be.lv_mul(ca[k], cb[0]) for k in range(2)]), f"lv_op2 mul by a plaintext level {L}")
+        eq(ctx.lv_op2(7, L, ca, cb[1], out=cb, shared_b=True), np.stack([be.lv_add(cb[k], be.lv_mul(ca[k], cb[1])) for k in range(2)]), f"lv_op2 mul_acc level {L}")
+        ks = [int(Co.Q[l] // 3 + 7 * l) for l in range(L + 1)]
+        eq(ctx.lv_op2(3, L, ca, consts=ks), np.stack([be.lv_mul_const(ca[k], ks) for k in range(2)]), f"lv_op2 mul_const level {L}")
     for L, _ in levels:                                  # Rescale's drop on both polynomials per launch == per polynomial == oracle
         ct = Co.encrypt_slots(a, L, 2.0 ** 40, seed=41).rows
         got = ctx.div_round_last2(L, ct[0], ct[1])
