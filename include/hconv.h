@@ -92,6 +92,9 @@ int hc_lv_sub(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint
  * in separate allocations; pass b1 = b0 for a plaintext operand; HC_LV_MUL_CONST takes `consts` and ignores b; HC_LV_MUL_ACC accumulates into out) */
 enum { HC_LV_MUL = 0, HC_LV_ADD = 1, HC_LV_SUB = 2, HC_LV_MUL_CONST = 3, HC_LV_MUL_ACC = 7 };
 int hc_lv_op2(hc_ctx *ctx, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1, const uint64_t *consts);
+/* evaluator.permuteNTT's tail after the key switch (RotateNew, RotateHoisted, ConjugateNew): out0 = Permute_galEl(d0 + c0),
+ * out1 = Permute_galEl(d1) over limbs 0..level in one launch; same residues as hc_lv_add + two hc_permute calls */
+int hc_rotate_finish(hc_ctx *ctx, uint64_t galEl, int level, const uint64_t *d0, const uint64_t *d1, const uint64_t *c0, uint64_t *out0, uint64_t *out1);
 /* the tensor step of evaluator.mulRelin (conv.go:476; EvaluatePoly): d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1; outputs may not alias inputs */
 int hc_lv_mul_tensor(hc_ctx *ctx, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1,
                      uint64_t *d0, uint64_t *d1, uint64_t *d2);

@@ -34,6 +34,7 @@ SYMBOLS = {
     "hc_const_for": (C.c_uint64, [C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_double)]),
     "hc_div_round_last": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_lv_op2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_rotate_finish": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_div_round_last2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_permute": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]),
     "hc_evk_load": (C.c_int, [C.c_void_p, C.c_uint64, u64p, u64p, u64p, u64p]),
@@ -300,6 +301,15 @@ class Context:
         out = D.download((level + 1, self.N))
         A.free(); B_.free(); D.free()
         return out
+    def rotate_finish(self, gal, level, d0, d1, c0):
+        bufs = [self.buf(np.ascontiguousarray(x, dtype=np.uint64)) for x in (d0, d1, c0)]
+        outs = [self.buf(nwords=(level + 1) * self.N) for _ in range(2)]
+        self._ck(self.L.hc_rotate_finish(self.h, C.c_uint64(gal), level, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, outs[0].ptr, outs[1].ptr))
+        res = [o.download((level + 1, self.N)) for o in outs]
+        for x in bufs + outs:
+            x.free()
+        return res
+
     def lv_op2(self, op, level, a, b=None, out=None, consts=None, shared_b=False):
         """hc_lv_op2: a, b, out = (2, level+1, N) ciphertexts (b = (level+1, N) with shared_b: a plaintext operand); separate allocations per polynomial"""
         A = [self.buf(np.ascontiguousarray(a[k], dtype=np.uint64)) for k in range(2)]

@@ -446,6 +446,17 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_permute(const u64 *in, u64 *out, 
         out[i] = in[(i & ~(size_t)0xFFFF) + hc_perm_src((u32)(i & 0xFFFF), g)];
 }
 
+// evaluator.permuteNTT's tail for all limbs of both polynomials in one launch: out0 = Permute_g(d0 + c0), out1 = Permute_g(d1)
+// (d = the key switch of c1). grid = (64, level + 1, 2)
+__global__ __launch_bounds__(HC_TPB) void hc_k_rotate_finish(const u64 *d0, const u64 *d1, const u64 *c0, u64 *o0, u64 *o1, const HcMod *mods, u32 g) {
+    const int l = blockIdx.y; const u64 q = mods[l].q; const size_t base = (size_t)l * 65536;
+    if (blockIdx.z == 0) {
+        for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) { const size_t s = base + hc_perm_src((u32)i, g); o0[base + i] = hc_addmod(d0[s], c0[s], q); }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) o1[base + i] = d1[base + hc_perm_src((u32)i, g)];
+    }
+}
+
 // ================================================================ loop A (conv.go:525-531), fused
 // Per output channel i and ciphertext polynomial p:
 //   a_l = c'_p[l] (*) k_i[l]  (l = 0,1; c' = ct_in * MultByConst constant, k in Montgomery form)

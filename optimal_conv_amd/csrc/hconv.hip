@@ -420,6 +420,14 @@ extern "C" int hc_permute(hc_ctx *c, uint64_t galEl, const uint64_t *in, uint64_
     return hc_launch(c, "permute", hc_k_permute, hc_pw_grid((size_t)count * HC_N), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), count);
 }
 
+// evaluator.permuteNTT after the key switch (RotateNew / RotateHoisted / ConjugateNew): out0 = Permute(d0 + c0), out1 = Permute(d1), all limbs, one launch
+extern "C" int hc_rotate_finish(hc_ctx *c, uint64_t galEl, int level, const uint64_t *d0, const uint64_t *d1, const uint64_t *c0, uint64_t *out0, uint64_t *out1) {
+    HC_ENTER(c);
+    if (level < 0 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "hc_rotate_finish: level %d outside 0..%d", level, c->nq - 1);
+    if (!d0 || !d1 || !c0 || !out0 || !out1 || out0 == d0 || out0 == c0 || out1 == d1 || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_rotate_finish: bad arguments (outputs must differ from inputs, galEl odd)");
+    return hc_launch(c, "rotate_finish", hc_k_rotate_finish, dim3(64, (unsigned)(level + 1), 2), (const u64 *)d0, (const u64 *)d1, (const u64 *)c0, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, (u32)(galEl & 0x1FFFF));
+}
+
 // ---- leveled polynomials: rows 0..level <-> moduli 0..level (a ring.Poly at that level); one launch covers all limbs
 static int hc_lv_check(hc_ctx *c, const char *fn, int level, const void *a, const void *out) {
     if (level < 0 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "%s: level %d outside 0..%d", fn, level, c->nq - 1);

@@ -241,9 +241,7 @@ struct Boot {
         DCt r = new_ct(L, 1, a.scale);
         auto d0 = block(), d1 = block();
         HCR(hc_keyswitch(hc, key(gal, L), L, a.p[1].get(), d0.get(), d1.get())); n_keyswitch++;
-        HCR(hc_lv_add(hc, L, d0.get(), a.p[0].get(), d0.get()));
-        HCR(hc_permute(hc, gal, d0.get(), r.p[0].get(), L + 1));
-        HCR(hc_permute(hc, gal, d1.get(), r.p[1].get(), L + 1));
+        HCR(hc_rotate_finish(hc, gal, L, d0.get(), d1.get(), a.p[0].get(), r.p[0].get(), r.p[1].get()));      // + c0, permute both: one launch
         return r;
     }
     DCt rotate(const DCt &a, int k) { k = ((k % n) + n) % n; return k == 0 ? a : galois(a, gal_rot(k)); }
@@ -258,9 +256,7 @@ struct Boot {
             if (!decomposed) { HCR(hc_keyswitch_decompose(hc, L, a.p[1].get())); decomposed = true; }
             DCt r = new_ct(L, 1, a.scale);
             HCR(hc_keyswitch_hoisted(hc, id, L, a.p[1].get(), d0.get(), d1.get())); n_keyswitch++;
-            HCR(hc_lv_add(hc, L, d0.get(), a.p[0].get(), d0.get()));
-            HCR(hc_permute(hc, gal, d0.get(), r.p[0].get(), L + 1));
-            HCR(hc_permute(hc, gal, d1.get(), r.p[1].get(), L + 1));
+            HCR(hc_rotate_finish(hc, gal, L, d0.get(), d1.get(), a.p[0].get(), r.p[0].get(), r.p[1].get()));
             out[k0] = r;
         }
         return out;

@@ -362,6 +362,9 @@ def case_ckks_ops(make_ctx, logN=16, seed=3, levels=((23, 2.0 ** 55), (9, 2.0 **
         eq(ctx.lv_op2(2, L, ca, cb), np.stack([be.lv_sub(ca[k], cb[k]) for k in range(2)]), f"lv_op2 sub level {L}")
         eq(ctx.lv_op2(0, L, ca, cb[0], shared_b=True), np.stack([be.lv_mul(ca[k], cb[0]) for k in range(2)]), f"lv_op2 mul by a plaintext level {L}")
         eq(ctx.lv_op2(7, L, ca, cb[1], out=cb, shared_b=True), np.stack([be.lv_add(cb[k], be.lv_mul(ca[k], cb[1])) for k in range(2)]), f"lv_op2 mul_acc level {L}")
+        gal = Co.gal_rot(5)                               # hc_rotate_finish == add + two permutes
+        r0, r1 = ctx.rotate_finish(gal, L, ca[0], ca[1], cb[0])
+        eq(r0, be.permute(gal, be.lv_add(ca[0], cb[0])), f"rotate_finish poly 0 level {L}"); eq(r1, be.permute(gal, ca[1]), f"rotate_finish poly 1 level {L}")
         ks = [int(Co.Q[l] // 3 + 7 * l) for l in range(L + 1)]
         eq(ctx.lv_op2(3, L, ca, consts=ks), np.stack([be.lv_mul_const(ca[k], ks) for k in range(2)]), f"lv_op2 mul_const level {L}")
     for L, _ in levels:                                  # Rescale's drop on both polynomials per launch == per polynomial == oracle
