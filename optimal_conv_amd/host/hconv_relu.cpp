@@ -225,8 +225,7 @@ struct Boot {
         auto d1 = block(), d2 = block(), t = block(), k = block();
         HCR(hc_lv_mul_tensor(hc, L, a.p[0].get(), a.p[1].get(), b.p[0].get(), b.p[1].get(), r.p[0].get(), d1.get(), d2.get()));
         HCR(hc_keyswitch(hc, key(0, L), L, d2.get(), t.get(), k.get())); n_keyswitch++;
-        HCR(hc_lv_add(hc, L, r.p[0].get(), t.get(), r.p[0].get()));
-        HCR(hc_lv_add(hc, L, d1.get(), k.get(), r.p[1].get()));
+        HCR(hc_lv_op2(hc, HC_LV_ADD, L, r.p[0].get(), d1.get(), t.get(), k.get(), r.p[0].get(), r.p[1].get(), nullptr));      // (d0 + ks0, d1 + ks1) in one launch
         return r;
     }
     DCt rescale(const DCt &a) {                                     // one DivRoundByLastModulusNTT
