@@ -95,6 +95,10 @@ int hc_lv_op2(hc_ctx *ctx, int op, int level, const uint64_t *a0, const uint64_t
 /* evaluator.permuteNTT's tail after the key switch (RotateNew, RotateHoisted, ConjugateNew): out0 = Permute_galEl(d0 + c0),
  * out1 = Permute_galEl(d1) over limbs 0..level in one launch; same residues as hc_lv_add + two hc_permute calls */
 int hc_rotate_finish(hc_ctx *ctx, uint64_t galEl, int level, const uint64_t *d0, const uint64_t *d1, const uint64_t *c0, uint64_t *out0, uint64_t *out1);
+/* RotateNew / ConjugateNew / one rotation of RotateHoisted as a single call: key switch of c1 with key `key_id` (the key of galEl), + c0,
+ * permutation of both polynomials, with the addition and the permutation inside ModDown's last pass. hoisted != 0: reuse the decomposition
+ * left by hc_keyswitch_decompose(level, c1). Same residues as hc_keyswitch (or hc_keyswitch_hoisted) + hc_rotate_finish. */
+int hc_keyswitch_rotate(hc_ctx *ctx, uint64_t key_id, uint64_t galEl, int level, const uint64_t *c0, const uint64_t *c1, uint64_t *out0, uint64_t *out1, int hoisted);
 /* the tensor step of evaluator.mulRelin (conv.go:476; EvaluatePoly): d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1; outputs may not alias inputs */
 int hc_lv_mul_tensor(hc_ctx *ctx, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1,
                      uint64_t *d0, uint64_t *d1, uint64_t *d2);

@@ -35,6 +35,7 @@ SYMBOLS = {
     "hc_div_round_last": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_lv_op2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_rotate_finish": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_keyswitch_rotate": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "hc_div_round_last2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_permute": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]),
     "hc_evk_load": (C.c_int, [C.c_void_p, C.c_uint64, u64p, u64p, u64p, u64p]),
@@ -301,6 +302,17 @@ class Context:
         out = D.download((level + 1, self.N))
         A.free(); B_.free(); D.free()
         return out
+    def keyswitch_rotate(self, key_id, gal, level, c0, c1, hoisted=False):
+        b0, b1 = self.buf(np.ascontiguousarray(c0, dtype=np.uint64)), self.buf(np.ascontiguousarray(c1, dtype=np.uint64))
+        outs = [self.buf(nwords=(level + 1) * self.N) for _ in range(2)]
+        if hoisted:
+            self._ck(self.L.hc_keyswitch_decompose(self.h, level, b1.ptr))
+        self._ck(self.L.hc_keyswitch_rotate(self.h, C.c_uint64(key_id), C.c_uint64(gal), level, b0.ptr, b1.ptr, outs[0].ptr, outs[1].ptr, 1 if hoisted else 0))
+        res = [o.download((level + 1, self.N)) for o in outs]
+        for x in [b0, b1] + outs:
+            x.free()
+        return res
+
     def rotate_finish(self, gal, level, d0, d1, c0):
         bufs = [self.buf(np.ascontiguousarray(x, dtype=np.uint64)) for x in (d0, d1, c0)]
         outs = [self.buf(nwords=(level + 1) * self.N) for _ in range(2)]

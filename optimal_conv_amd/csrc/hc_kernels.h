@@ -958,6 +958,20 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_mm(const u64 *acc, siz
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
         o[j] = hc_mul_shoup(hc_submod(a[j], x[j], q), pi.w, pi.ws, q);
 }
+// ModDown's last step and evaluator.permuteNTT's tail in one pass (rotations: the key-switched polynomials never reach HBM unpermuted):
+//   out_0[l][i] = ((acc_0 - ext_0) * P^-1 + c0)[l][src(i)],  out_1[l][i] = ((acc_1 - ext_1) * P^-1)[l][src(i)],  src = PermuteNTTIndex(g)
+__global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_rotate_mm(const u64 *acc, size_t acc_zs, const u64 *ext, size_t ext_zs, const u64 *c0, u64 *o0, u64 *o1, const HcMod *mods, const HcTw *pinv, u32 g) {
+    const int l = blockIdx.y, k = blockIdx.z; const u64 q = mods[l].q; const HcTw pi = pinv[l];
+    const size_t base = (size_t)l * 65536;
+    const u64 *a = acc + (size_t)k * acc_zs + base, *x = ext + (size_t)k * ext_zs + base;
+    u64 *o = (k ? o1 : o0) + base;
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        const u32 s = hc_perm_src((u32)j, g);
+        u64 r = hc_mul_shoup(hc_submod(a[s], x[s], q), pi.w, pi.ws, q);
+        if (k == 0) r = hc_addmod(r, c0[base + s], q);
+        o[j] = r;
+    }
+}
 // general-level DivRoundByLastModulusNTT, all lower limbs per launch: lift (v[i] from t) and finish (out[i] = (x[i]-u[i]) * qL^-1)
 // blockIdx.z = polynomial (a ciphertext's two polynomials in one launch; xs / os = distance between them in words, modulo 2^64)
 __global__ __launch_bounds__(HC_TPB) void hc_k_rescale_lift_mm(const u64 *t, u64 *v, const HcMod *mods, int level) {

@@ -996,7 +996,7 @@ static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, u64 *coef, 
     return hc_ntt_mm(c, digits, digits, nt, nl, 0, 0, beta, (size_t)nt * HC_N, (size_t)nt * HC_N, alpha, half);
 }
 // phase 2: inner product with the key (both components), then ModDownSplitNTTPQ
-static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const u64 *digits, u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1, bool half = false) {
+static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const u64 *digits, u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1, bool half = false, uint64_t rot_gal = 0, const u64 *rot_c0 = nullptr) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = key.beta;
     if (half) HC_TRY(hc_launch(c, "ks_rows_fwd_mac", hc_k_rows_fwd_mac, dim3(16, (unsigned)nt), (const u64 *)key.rows, cx, (const u64 *)c->ws_tmp, acc, (const HcRowMod *)c->d_rowmods, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta));
@@ -1010,6 +1010,8 @@ static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *c
     }
     HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4, 2), (const u64 *)pc, (size_t)HC_N, ext, (const HcBasisExt *)P->bxdown, nl, 0, 0, (size_t)alpha * HC_N, (size_t)nl * HC_N, 0, nl));
     HC_TRY(hc_ntt_mm(c, ext, ext, nl, nl, 0, 0, 2, (size_t)nl * HC_N, (size_t)nl * HC_N));
+    if (rot_gal)     // a rotation: + c0 and the permutation ride in ModDown's last pass (d0, d1 = the rotated ciphertext)
+        return hc_launch(c, "ks_moddown_rotate_mm", hc_k_ks_moddown_rotate_mm, dim3(32, (unsigned)nl, 2), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)ext, (size_t)nl * HC_N, rot_c0, d0, d1, (const HcMod *)c->d_mods, (const HcTw *)P->pinv, (u32)(rot_gal & 0x1FFFF));
     return hc_launch(c, "ks_moddown_mm", hc_k_ks_moddown_mm, dim3(32, (unsigned)nl, 2), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)ext, (size_t)nl * HC_N, d0, d1, (const HcMod *)c->d_mods, (const HcTw *)P->pinv);
 }
 // scratch layout of one key switch at `level`: coef[nl] | digits[beta][nt] | acc[2][nt] | pc[2][alpha] | ext[2][nl]
@@ -1056,6 +1058,23 @@ extern "C" int hc_keyswitch_hoisted(hc_ctx *c, uint64_t key_id, int level, const
     if (c->hoist_cx != cx || c->hoist_level != level) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch_hoisted: no decomposition of this polynomial at level %d is held (call hc_keyswitch_decompose first)", level);
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
     return hc_ks_apply_from(c, *key, level, cx, S.digits, S.acc, S.pc, S.ext, d0, d1);
+}
+
+// evaluator.RotateNew / ConjugateNew (permuteNTT) as ONE call: key switch of c1 with the key of galEl, + c0, permutation of both polynomials;
+// the same residues as hc_keyswitch + hc_rotate_finish. hoisted != 0: uses the decomposition hc_keyswitch_decompose(level, c1) left in the
+// context (evaluator.RotateHoisted). Outputs must not alias the inputs.
+extern "C" int hc_keyswitch_rotate(hc_ctx *c, uint64_t key_id, uint64_t galEl, int level, const uint64_t *c0, const uint64_t *c1, uint64_t *out0, uint64_t *out1, int hoisted) {
+    HC_ENTER(c);
+    const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_rotate", key_id, level, &key));
+    if (!c0 || !c1 || !out0 || !out1 || out0 == c0 || out0 == c1 || out1 == c1 || out1 == c0 || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_rotate: bad arguments (outputs must differ from inputs, galEl odd)");
+    HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
+    if (hoisted) {
+        if (c->hoist_cx != c1 || c->hoist_level != level) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch_rotate: no decomposition of this polynomial at level %d is held (call hc_keyswitch_decompose first)", level);
+    } else {
+        HC_TRY(hc_ks_decompose_into(c, level, c1, S.coef, S.digits, false));
+        c->hoist_cx = nullptr;
+    }
+    return hc_ks_apply_from(c, *key, level, c1, S.digits, S.acc, S.pc, S.ext, out0, out1, false, galEl, c0);
 }
 
 // ------------------------------------------------------------------ L1

@@ -238,24 +238,20 @@ struct Boot {
     DCt galois(const DCt &a, uint64_t gal) {                       // evaluator.permuteNTT: key switch c1, + c0, permute both
         const int L = a.level;
         DCt r = new_ct(L, 1, a.scale);
-        auto d0 = block(), d1 = block();
-        HCR(hc_keyswitch(hc, key(gal, L), L, a.p[1].get(), d0.get(), d1.get())); n_keyswitch++;
-        HCR(hc_rotate_finish(hc, gal, L, d0.get(), d1.get(), a.p[0].get(), r.p[0].get(), r.p[1].get()));      // + c0, permute both: one launch
+        HCR(hc_keyswitch_rotate(hc, key(gal, L), gal, L, a.p[0].get(), a.p[1].get(), r.p[0].get(), r.p[1].get(), 0)); n_keyswitch++;   // + c0 and the permutation inside ModDown's last pass
         return r;
     }
     DCt rotate(const DCt &a, int k) { k = ((k % n) + n) % n; return k == 0 ? a : galois(a, gal_rot(k)); }
     // evaluator.RotateHoisted: several rotations of ONE ciphertext share the digit decomposition of its c1
     std::map<int, DCt> rotate_hoisted(const DCt &a, const std::vector<int> &ks) {
         std::map<int, DCt> out; const int L = a.level; bool decomposed = false;
-        auto d0 = block(), d1 = block();
         for (int k0 : ks) {
             const int k = ((k0 % n) + n) % n;
             if (k == 0) { out[k0] = a; continue; }
             const uint64_t gal = gal_rot(k), id = key(gal, L);            // key generation (if any) before the decomposition is taken
             if (!decomposed) { HCR(hc_keyswitch_decompose(hc, L, a.p[1].get())); decomposed = true; }
             DCt r = new_ct(L, 1, a.scale);
-            HCR(hc_keyswitch_hoisted(hc, id, L, a.p[1].get(), d0.get(), d1.get())); n_keyswitch++;
-            HCR(hc_rotate_finish(hc, gal, L, d0.get(), d1.get(), a.p[0].get(), r.p[0].get(), r.p[1].get()));
+            HCR(hc_keyswitch_rotate(hc, id, gal, L, a.p[0].get(), a.p[1].get(), r.p[0].get(), r.p[1].get(), 1)); n_keyswitch++;
             out[k0] = r;
         }
         return out;

@@ -355,6 +355,16 @@ def case_ckks_ops(make_ctx, logN=16, seed=3, levels=((23, 2.0 ** 55), (9, 2.0 **
     L = levels[0][0]                                     # acc += a*b in one pass == mul then add
     x, y, z = (Co.encrypt_slots(a, L, 2.0 ** 30, seed=s_).rows[0] for s_ in (31, 32, 33))
     eq(ctx.lv_mul_acc(L, x, y, z), Co.be.lv_add(z, Co.be.lv_mul(x, y)), "lv_mul_acc")
+    dev = Cd.be                                          # hc_keyswitch_rotate (plain and hoisted) == key switch + add + permutations on the oracle
+    for L, sc in levels:
+        ct = Co.encrypt_slots(a, L, sc, seed=61)
+        for k in (3, -7):
+            gal = Co.gal_rot(k); key = Co.key(gal, L)
+            dev.keyswitch(key, ct.rows[1])               # loads the key into the context under dev._ids[(gal, L)]
+            want = Co.rotate(ct, k).rows
+            for hoisted in (False, True):
+                got = ctx.keyswitch_rotate(dev._ids[(gal, L)], gal, L, ct.rows[0], ct.rows[1], hoisted=hoisted)
+                eq(np.stack(got), want, f"keyswitch_rotate k={k} level {L} hoisted={hoisted}")
     for L, _ in levels:                                  # hc_lv_op2: both polynomials per launch == the per-polynomial operations
         ca, cb = Co.encrypt_slots(a, L, 2.0 ** 30, seed=51).rows, Co.encrypt_slots(b, L, 2.0 ** 30, seed=52).rows
         be = Co.be
