@@ -14,7 +14,7 @@
 // assignment (parameter set [6]): levels 27..24 CoeffsToSlots, 23..16 sine (Chebyshev degree 63 of the cosine,
 // two double angles, K = 25, message ratio 256), 15..5 the ReLU polynomials, 5 the mask, 3..2 SlotsToCoeffs. It mirrors
 // tests/oracle_ckks.py statement by statement; that file run on the oracle and on this library's C ABI gives bit-identical
-// ciphertexts at every stage (tests/test_gpu_parity.py::test_conv_relu_tail_on_gpu). All residue arithmetic is C-ABI calls:
+// ciphertexts at every stage (tests/test_gpu_a_parity.py::test_conv_relu_tail_on_gpu). All residue arithmetic is C-ABI calls:
 // hc_lv_* (all limbs per launch), hc_keyswitch (hybrid, alpha = 5), hc_div_round_last, hc_permute; the slot encoder and the
 // float64 scale bookkeeping are host code, as in the reference.
 #include <math.h>

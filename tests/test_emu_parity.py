@@ -1,7 +1,7 @@
 """CPU-side check of the HIP kernel SOURCES: optimal_conv_amd/csrc is compiled with g++ against the fiber emulator
 in tests/kernel_emu (threads = ucontext fibers, __syncthreads = yield) and driven through the same C ABI and the
 same parity cases as the GPU tests. This validates indexing, LDS exchanges, barrier placement and the host
-orchestration without a GPU; it says nothing about gfx950 code generation - tests/test_gpu_parity.py does that.
+orchestration without a GPU; it says nothing about gfx950 code generation - tests/test_gpu_a_parity.py does that.
 The emulated library is test infrastructure and is never loaded by the package itself."""
 import os
 import subprocess

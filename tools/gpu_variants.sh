@@ -8,7 +8,7 @@ for v in "${VS[@]}"; do
   name="${v%%:*}"; flags="${v#*:}"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result $flags -shared -o optimal_conv_amd/libhconv.so optimal_conv_amd/csrc/hconv.hip 2> gpurun_out/variants/build_$name.log || { echo "BUILD FAILED $name"; tail -3 gpurun_out/variants/build_$name.log; continue; }
   touch optimal_conv_amd/libhconv.so
-  ok=$(timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "digests" 2>&1 | tail -1)
+  ok=$(timeout 300 python -m pytest tests/test_gpu_a_parity.py -x -q -k "digests" 2>&1 | tail -1)
   for st in ${STREAMS:-1 3}; do
     timeout 300 python bench.py --steps 24 --warmup 6 --chunk ${CHUNK:-64} --streams $st --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); k=d['roofline']['kernels']; print('$name','streams',d['config']['ciphertexts_in_flight_per_gpu'],'ms/conv %.3f'%d['ms_per_step'], 'conv/s %.1f'%d['value'], ' '.join('%s=%.3f'%(n.split('_')[0],v['ms_per_conv']) for n,v in sorted(k.items())))"
   done

