@@ -2,9 +2,10 @@
 """bench.py — homomorphic convs/sec of the `conv 3 3` hot path (evalConv_BN: conv_then_pack + bias add,
 eval.go:250-260) on N MI355X GPUs.
 
-A "step" is one pass of the hot path over one batch of input: one homomorphic convolution on each of the S (--streams,
-default 3) ciphertexts resident on the GPU, each = one N=2^16 level-1 ciphertext in, B=256 kernel plaintexts, one level-0
-ciphertext out (conv.go:522-546 + eval.go:258); `value` counts convolutions (steps x S x GPUs / time). Kernel plaintexts are
+A "step" is one pass of the hot path over one batch of input: one homomorphic convolution on each of the ciphertexts resident
+on the GPU (--batch ciphertexts per hc_conv_then_pack_batch call, i.e. per launch set, times --streams contexts), each = one
+N=2^16 level-1 ciphertext in, its own B=256 kernel plaintexts, one level-0 ciphertext out (conv.go:522-546 + eval.go:258);
+`value` counts convolutions (steps x batch x streams x GPUs / time). Kernel plaintexts are
 pre-encoded and excluded exactly as the reference excludes prep_Ker from its "Conv (with BN)" timer (eval.go:244). Inputs are synthetic uniform residues, resident in
 HBM before the timed region. Multi-GPU: ciphertexts (images) are independent, so rank r runs its own convolutions
 on GPU r with no data-path collective (weak scaling); torch.distributed only provides the barriers and the
@@ -80,10 +81,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--i-batch", type=int, default=3, help="reference batch index (main.go:578): 3 => B=256, W=16 = `conv 3 3`")
     ap.add_argument("--ker-wid", type=int, default=3)
-    ap.add_argument("--chunk", type=int, default=64)
-    ap.add_argument("--streams", type=int, default=3, help="independent ciphertexts in flight per GPU (one hc_ctx = one HIP stream each)")
+    ap.add_argument("--chunk", type=int, default=512, help="jobs (channels / tree nodes, summed over the batch) per kernel launch")
+    ap.add_argument("--batch", type=int, default=8, help="ciphertexts per hc_conv_then_pack_batch call (one launch set covers them all)")
+    ap.add_argument("--streams", type=int, default=2, help="contexts (HIP streams) per GPU, each with its own batch of resident ciphertexts")
+    ap.add_argument("--batch-alt", type=int, default=0, help="experiment: odd-numbered contexts use this batch size instead (desynchronises the streams)")
     ap.add_argument("--lanes", type=int, default=1, help="internal lanes of one conv (channels i mod G on their own streams)")
-    ap.add_argument("--graph", type=int, default=0, help="replay each lane's conv as a captured hipGraph (measured: no gain, the kernels' own start-up latency dominates, not the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -108,6 +110,7 @@ def main():
     from optimal_conv_amd import Context
     B, W = BATCHS[args.i_batch], WIDTHS[args.i_batch]
     S = max(1, args.streams)
+    NB = max(1, min(16, args.batch))
     rng = np.random.default_rng(0xC0FFEE + args.i_batch + 1000 * rank)
     ct_in = np.stack([np.stack([synth_rows(rng, Q0, N), synth_rows(rng, Q1, N)]) for _ in range(2)])
     pl_ker = np.empty((B, 2, N), dtype=np.uint64)
@@ -124,18 +127,24 @@ def main():
         ctx = Context([Q0, Q1], [P0], device=device)            # raises if no GPU / no libhconv.so
         ctx.set_option("chunk_nodes", args.chunk)
         ctx.set_option("lanes", args.lanes)
-        ctx.set_option("graph", args.graph)
         for gal, k4 in keys:
             ctx.evk_load(gal, k4)
         ctx.idx_load(None)
-        lanes.append({"ctx": ctx, "ker": ctx.ker_load(pl_ker), "in": ctx.buf(ct_in), "bias": ctx.buf(bias), "out": ctx.buf(nwords=2 * N)})
+        # every resident ciphertext has its own input, its own kernel plaintexts (distinct HBM copies, channel-rolled so that no two
+        # are equal) and its own output; the BN bias plaintext is the layer's
+        L = {"ctx": ctx, "bias": ctx.buf(bias), "ker": [], "in": [], "out": []}
+        for z in range(args.batch_alt if (args.batch_alt and s_ % 2) else NB):
+            L["ker"].append(ctx.ker_load(np.roll(pl_ker, s_ * NB + z, axis=0)))
+            L["in"].append(ctx.buf(np.roll(ct_in, 17 * (s_ * NB + z) + 1, axis=2)))
+            L["out"].append(ctx.buf(nwords=2 * N))
+        lanes.append(L)
     ctx = lanes[0]["ctx"]
     counter = [0]
 
     def one_step():
         """one pass of the hot path over one batch of input = one convolution on each of the S resident ciphertexts"""
         for L in lanes:
-            L["ctx"].conv_then_pack_dev(L["in"], 2.0 ** 30, L["ker"], 2.0 ** 30, B, 1, 2.0 ** 30, L["bias"], L["out"])
+            L["ctx"].conv_then_pack_batch_dev(L["in"], 2.0 ** 30, L["ker"], 2.0 ** 30, B, 1, 2.0 ** 30, [L["bias"]] * len(L["in"]), L["out"])
 
     def sync_all():
         for L in lanes:
@@ -150,8 +159,7 @@ def main():
 
     # set-up, not warm-up: every lane's first conv allocates its context's workspaces (hipMalloc); do that outside both the
     # warm-up count and the timed region so that a run with a small --warmup does not time allocations on the cold lanes
-    for L in lanes:
-        L["ctx"].conv_then_pack_dev(L["in"], 2.0 ** 30, L["ker"], 2.0 ** 30, B, 1, 2.0 ** 30, L["bias"], L["out"])
+    one_step()
     sync_all()
     for _ in range(args.warmup):
         one_step()
@@ -174,11 +182,12 @@ def main():
     ctx.set_option("profile", 1)
     ctx.profile_reset()
     nprof = max(1, min(3, args.steps))
+    L0 = lanes[0]
     for _ in range(nprof):
-        lanes[0]["ctx"].conv_then_pack_dev(lanes[0]["in"], 2.0 ** 30, lanes[0]["ker"], 2.0 ** 30, B, 1, 2.0 ** 30, lanes[0]["bias"], lanes[0]["out"])
+        ctx.conv_then_pack_batch_dev(L0["in"], 2.0 ** 30, L0["ker"], 2.0 ** 30, B, 1, 2.0 ** 30, [L0["bias"]] * NB, L0["out"])
     prof = ctx.profile()
     ctx.set_option("profile", 0)
-    kern = {k: {"ms_per_conv": v[0] / nprof, "launches_per_conv": v[1] // nprof} for k, v in prof.items()}
+    kern = {k: {"ms_per_conv": v[0] / (nprof * NB), "launches_per_batch": v[1] // nprof, "avg_launch_us": 1e3 * v[0] / max(1, v[1])} for k, v in prof.items()}
     dom = max(kern, key=lambda k: kern[k]["ms_per_conv"]) if kern else None
 
     def valu_model(conv_ms):
@@ -196,22 +205,23 @@ def main():
                 "achieved": per_conv / (conv_ms * 1e-3) / 1e12, "frac": t_min_ms / conv_ms, "source": "tools/isa_mix.py (static ISA mix x measured multiply rates)"}
 
     if rank == 0:
-        conv_ms_events = ev_ms / (args.steps * S)
+        per_step = sum(len(L["in"]) for L in lanes)
+        conv_ms_events = ev_ms / (args.steps * per_step)
         alg_bytes = algorithmic_mib(B) * 2 ** 20
         achieved = alg_bytes / (conv_ms_events * 1e-3) / 1e9
         out = {
             "metric": "homomorphic convs/sec (conv_then_pack + BN bias, k x k, batch B, N=2^16)",
-            "value": world * args.steps * S / elapsed, "unit": "conv/s",
+            "value": world * args.steps * per_step / elapsed, "unit": "conv/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"conv {args.ker_wid} {args.i_batch}", "ker_wid": args.ker_wid, "batch": B, "in_wid": W,
                        "logN": 16, "moduli": "ckks.DefaultBootstrapParams[6] Q0,Q1 + P=0x1fffffffffe00001",
-                       "convs_per_step_per_gpu": S, "ciphertexts_in_flight_per_gpu": S, "chunk_nodes": args.chunk, "lanes_per_conv": args.lanes, "hipgraph_replay": bool(args.graph)},
+                       "convs_per_step_per_gpu": per_step, "ciphertexts_per_launch_set": NB, "contexts_per_gpu": S, "chunk_nodes": args.chunk, "lanes_per_conv": args.lanes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic_from_profiles(B, args.chunk),
-                         "unit_of_launch": "one conv_then_pack (all of its kernel launches on one stream)",
+                         "unit_of_launch": "one conv_then_pack (its share of the batched launch set: all kernels of loop A and of the pack tree)",
                          "algorithmic_bytes_per_conv": alg_bytes, "conv_ms_hip_events": conv_ms_events,
                          "dominant_kernel": dom, "kernels": kern, "valu": valu_model(conv_ms_events)},
         }
@@ -219,7 +229,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out), flush=True)
     for L in lanes:
-        L["ctx"].ker_free(L["ker"])
+        for k in L["ker"]:
+            L["ctx"].ker_free(k)
         L["ctx"].close()
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -160,6 +160,15 @@ int hc_idx_load(hc_ctx *ctx, const uint64_t *idx_host);
 int hc_conv_then_pack(hc_ctx *ctx, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
                       int max_ob, int norm, double out_scale, const uint64_t *bias, uint64_t *ct_out,
                       double *scale_out);
+/* The same convolution on n <= 16 independent ciphertexts (the images of a batch going through one layer: test.go:76-370 runs
+ * them one after another through evalConv_BN, eval.go:224-263) as ONE set of kernel launches: every launch covers all n
+ * ciphertexts, so the switching keys, idx plaintexts and twiddles are fetched once per launch and the top levels of the pack
+ * tree (1..16 nodes each) are n times wider. ct_in, ker, bias (or NULL, or NULL entries), ct_out: HOST arrays of n device
+ * pointers / handles (entries of ker and bias may repeat); same shapes and scales for all; results are bit-identical to n
+ * separate hc_conv_then_pack calls. */
+int hc_conv_then_pack_batch(hc_ctx *ctx, int n, const uint64_t *const *ct_in, double ct_scale, const hc_ker *const *ker,
+                            double ker_scale, int max_ob, int norm, double out_scale, const uint64_t *const *bias,
+                            uint64_t *const *ct_out, double *scale_out);
 /* loop A only (conv.go:525-531): cts_out = device [max_ob][2][N]; and loop B only (pack_ctxts, conv.go:266-300),
  * in place on cts (result in slot 0). Exposed for parity tests and profiling. */
 int hc_conv_mult_phase(hc_ctx *ctx, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
@@ -172,7 +181,7 @@ int hc_pack_ctxts(hc_ctx *ctx, uint64_t *cts, int max_cnum, int real_cnum);
 int hc_pack_ctxts_strided(hc_ctx *ctx, uint64_t *cts, int count, int stride_log2, const uint64_t *bias);
 
 /* ---- tuning / measurement ---- */
-int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes", "lanes", "profile", "graph" (hipGraph replay of hc_conv_then_pack) */
+int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes", "lanes", "profile", "ks_fused" */
 /* HIP-event timing on the context's stream */
 int hc_timer_start(hc_ctx *ctx);
 int hc_timer_stop(hc_ctx *ctx, float *ms);

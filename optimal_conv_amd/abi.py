@@ -64,6 +64,8 @@ SYMBOLS = {
     "hc_idx_load": (C.c_int, [C.c_void_p, u64p]),
     "hc_conv_then_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double,
                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "hc_conv_then_pack_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.POINTER(C.c_void_p), C.c_double, C.c_int, C.c_int,
+                                          C.c_double, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_double)]),
     "hc_conv_mult_phase": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double,
                                      C.c_void_p]),
     "hc_pack_ctxts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -85,7 +87,7 @@ _libs = {}
 
 def load(path=None):
     """dlopen libhconv.so and type every entry point. Raises if the HIP library is missing."""
-    path = path or DEFAULT_LIB
+    path = path or os.environ.get("HCONV_LIB") or DEFAULT_LIB      # HCONV_LIB: another BUILD of this same HIP library (tools/build_variant.sh)
     if path in _libs:
         return _libs[path]
     if path == DEFAULT_LIB and "HCONV_NO_TORCH_PRELOAD" not in os.environ:
@@ -400,6 +402,16 @@ class Context:
         sc = C.c_double(0)
         self._ck(self.L.hc_conv_then_pack(self.h, ct_in_buf.ptr, ct_scale, ker, ker_scale, max_ob, norm, out_scale,
                                           bias_buf.ptr if bias_buf is not None else None, out_buf.ptr, C.byref(sc)))
+        return sc.value
+
+    def conv_then_pack_batch_dev(self, ct_in_bufs, ct_scale, kers, ker_scale, max_ob, norm, out_scale, bias_bufs, out_bufs):
+        """hc_conv_then_pack_batch: n ciphertexts through one launch set; kers = handles (may repeat), bias_bufs = list or None"""
+        n = len(ct_in_bufs)
+        arr = C.c_void_p * n
+        cin = arr(*[b.ptr for b in ct_in_bufs]); ck = arr(*kers); co = arr(*[b.ptr for b in out_bufs])
+        cb = arr(*[(b.ptr if b is not None else None) for b in bias_bufs]) if bias_bufs is not None else None
+        sc = C.c_double(0)
+        self._ck(self.L.hc_conv_then_pack_batch(self.h, n, cin, ct_scale, ck, ker_scale, max_ob, norm, out_scale, cb, co, C.byref(sc)))
         return sc.value
 
     def conv_then_pack(self, ct_in, ct_scale, pl_ker, ker_scale, max_ob, norm, out_scale, bias=None):

@@ -72,6 +72,46 @@ HC_HD u64 hc_shoup_companion(u64 w, u64 q) {
     return quo;
 }
 HC_HD u64 hc_csub(u64 x, u64 q) { return x >= q ? x - q : x; }
+
+// ---- the lazy product of the butterflies (round 2) ---------------------------------------------------------------------------
+// Measured on MI355X (tools/ubench4.hip, profiles/round2_ubench_instr.txt): v_mad_u64_u32, v_mul_lo_u32, v_mul_hi_u32, 64-bit adds
+// and shifts, carry pairs and fp64 FMA ALL issue at one wave64 instruction per 4 cycles; only 32-bit moves/adds/logic are faster.
+// So the cost of a modular product is its INSTRUCTION COUNT, not its multiplier count. hc_mulhi_lo2 takes the high half of
+// x * p from the three partial products that reach it and drops the low halves' carries: 2 v_mul_hi_u32 + 1 v_mad_u64_u32 + one
+// 64-bit add instead of the exact form's 1 + 3 multiplies, 5 register moves and an add; the result is floor(x*p/2^64) - {0,1,2}.
+// hc_shoup4 then forms x*w - hi*q as ONE multiply-add chain x*w + hi*(2^64 - q) (2 v_mad_u64_u32 + 4 v_mul_lo_u32 + 2 v_add3_u32)
+// instead of two separate low products and a 64-bit subtraction: 12 instructions for the whole product against 22. Its result is
+// congruent to x*w and lies in [0, 4q) for ANY 64-bit x (exact hi: [0, 2q); each unit hi is short adds q). Needs 4q < 2^64.
+HC_HD u64 hc_mulhi_lo2(u64 x, u64 p) {
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), p0 = (u32)p, p1 = (u32)(p >> 32);
+    return (u64)x1 * p1 + (((u64)x0 * p1) >> 32) + (((u64)x1 * p0) >> 32);
+}
+// A kernel-uniform value the optimiser cannot see through: without it x*w + hi*(0 - q) is canonicalised back into x*w - hi*q.
+HC_HD u64 hc_opaque_uniform(u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 r;
+    asm("; uniform constant kept opaque" : "=s"(r) : "0"(v));      // (readfirstlane of a uniform value is folded away; this is not)
+    return r;
+#else
+    return v;
+#endif
+}
+// per-kernel constants of one modulus (q must be uniform over the wave: every call site takes it from kernel arguments or from a
+// table indexed by blockIdx)
+struct HcQ { u64 q, nq, q4, nq4, nq2; };     // nq = 2^64 - q, q4 = 4q, nq4 = 2^64 - 4q, nq2 = 2^64 - 2q
+HC_HD HcQ hc_q(u64 q) {
+    HcQ Q; Q.q = q; Q.nq = hc_opaque_uniform(0 - q); Q.q4 = 4 * q; Q.nq4 = hc_opaque_uniform(0 - 4 * q); Q.nq2 = hc_opaque_uniform(0 - 2 * q);
+    return Q;
+}
+HC_HD u64 hc_shoup4(u64 x, u64 w, u64 wp, const HcQ &Q) { return x * w + hc_mulhi_lo2(x, wp) * Q.nq; }
+// x < 2b with b <= 2^63 and nb = 2^64 - b: x - b if that is non-negative, else x (one 64-bit add, a sign test on the high word,
+// two selects: no carry chain). Result < b.
+HC_HD u64 hc_fold(u64 x, u64 nb) { const u64 t = x + nb; return (int)(u32)(t >> 32) < 0 ? x : t; }
+HC_HD u64 hc_canon4(u64 x, const HcQ &Q) { return hc_fold(hc_fold(x, Q.nq2), Q.nq); }                  // [0,4q) -> [0,q)
+HC_HD u64 hc_canon8(u64 x, const HcQ &Q) { return hc_canon4(hc_fold(x, Q.nq4), Q); }                   // [0,8q) -> [0,q)
+// x mod q for ANY 64-bit x, mu = floor(2^64/q): the Barrett quotient through the same short high product (<= 3 short), so the
+// remainder estimate is in [0, 4q); two folds make it canonical
+HC_HD u64 hc_reduce64(u64 x, u64 mu, const HcQ &Q) { return hc_canon4(x + hc_mulhi_lo2(x, mu) * Q.nq, Q); }
 HC_HD u64 hc_mul_shoup(u64 x, u64 w, u64 wp, u64 q) { return hc_csub(hc_mul_shoup_lazy(x, w, wp, q), q); }
 
 // Montgomery product a*b*2^-64 mod q, canonical, for a*b < q*2^64; qinv = q^-1 mod 2^64

@@ -42,15 +42,16 @@ struct HcTwTab {
 // ---------------------------------------------------------------- radix-16 rounds
 // Slot numbering: a 4-stage round has 1+2+4+8 twiddles; the stage with 2^s twiddles uses slots (2^s - 1 + g).
 // Forward rounds walk s = 0..3 (distance 8,4,2,1); inverse rounds walk distance 1,2,4,8 (s = 3..0).
-// Forward lazy-reduction modes (Harvey butterflies; T = w*Y is in [0,2q) for ANY 64-bit Y, so only X needs care):
-//   HC_FM_FREE  no conditional subtraction at all: every stage adds at most 2q to the bound, 16 stages of a full
-//               transform turn inputs < 2q into outputs < 34q. Needs 34q < 2^64, i.e. moduli below 2^58 (Q0, Q1).
-//   HC_FM_ALT   X is folded by 4q before stages 0 and 2 of each round: inputs < 8q stay < 8q. Needs 8q < 2^64, which
-//               holds for every modulus this library accepts (q < 2^61 incl. the 61-bit P: 8P = 2^64 - 2^24 + 8).
+// Every butterfly product is hc_shoup4 (hc_arith.h): T = w*Y in [0,4q) for ANY 64-bit Y, so only X needs care.
+// Forward lazy-reduction modes:
+//   HC_FM_FREE  no fold at all: every stage adds at most 4q to the bound, 16 stages of a full transform turn inputs < 6q into
+//               outputs < 70q. Needs 74q < 2^64, i.e. moduli below 2^57 (Q0, Q1 and the 30..55-bit primes of the chains).
+//   HC_FM_ALT   X is folded by 4q before every stage: inputs < 8q stay < 8q. Needs 8q < 2^64, which holds for every modulus
+//               this library accepts (q < 2^61 incl. the 61-bit P: 8P = 2^64 - 2^24 + 8).
+// Inverse rounds keep every value in [0,4q): sums are folded by 4q, differences X - Y + 4q go straight into the product.
 enum { HC_FM_FREE = 1, HC_FM_ALT = 2 };
 template <int FM, class TW>
-__device__ __forceinline__ void hc_ct_round(u64 (&e)[16], const TW &tw, u64 q) {
-    const u64 twoq = 2 * q, fourq = 4 * q;
+__device__ __forceinline__ void hc_ct_round(u64 (&e)[16], const TW &tw, const HcQ &Q) {
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int half = 8 >> s;
@@ -61,24 +62,23 @@ __device__ __forceinline__ void hc_ct_round(u64 (&e)[16], const TW &tw, u64 q) {
             for (int k = 0; k < half; k++) {
                 const int a = g * 2 * half + k, b = a + half;
                 u64 X = e[a];
-                if (FM == HC_FM_ALT && (s == 0 || s == 2)) X = hc_csub(X, fourq);
-                u64 T = hc_mul_shoup_lazy(e[b], w.w, w.ws, q);
+                if (FM == HC_FM_ALT) X = hc_fold(X, Q.nq4);
+                const u64 T = hc_shoup4(e[b], w.w, w.ws, Q);
                 e[a] = X + T;
-                e[b] = X - T + twoq;
+                e[b] = (X + Q.q4) - T;
             }
         }
     }
 }
-// canonical residue of a forward-transform output (FREE: < 34q -> Barrett with mu = floor(2^64/q); ALT: < 8q)
+// canonical residue of a forward-transform output (FREE: < 70q -> short Barrett with mu = floor(2^64/q); ALT: < 8q)
 template <int FM>
-__device__ __forceinline__ u64 hc_fwd_canon(u64 x, u64 q, u64 mu) {
-    if (FM == HC_FM_FREE) { u64 r = x - hc_mulhi(x, mu) * q; return hc_csub(r, q); }
-    return hc_csub(hc_csub(hc_csub(x, 4 * q), 2 * q), q);
+__device__ __forceinline__ u64 hc_fwd_canon(u64 x, const HcQ &Q, u64 mu) {
+    if (FM == HC_FM_FREE) return hc_reduce64(x, mu, Q);
+    return hc_canon8(x, Q);
 }
-// LAST: the final stage also multiplies by N^-1 (folded into the twiddle for the "-" output).
+// LAST: the final stage also multiplies by N^-1 (folded into the twiddle for the "-" output). In and out: [0,4q).
 template <bool LAST, class TW>
-__device__ __forceinline__ void hc_gs_round(u64 (&e)[16], const TW &tw, u64 q, HcTw ninv, HcTw w_last) {
-    const u64 twoq = 2 * q;
+__device__ __forceinline__ void hc_gs_round(u64 (&e)[16], const TW &tw, const HcQ &Q, HcTw ninv, HcTw w_last) {
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int dist = 1 << s;
@@ -89,10 +89,10 @@ __device__ __forceinline__ void hc_gs_round(u64 (&e)[16], const TW &tw, u64 q, H
 #pragma unroll
             for (int k = 0; k < dist; k++) {
                 const int a = g * 2 * dist + k, b = a + dist;
-                u64 X = e[a], Y = e[b];
-                if (LAST && s == 3) e[a] = hc_mul_shoup_lazy(X + Y, ninv.w, ninv.ws, q);
-                else e[a] = hc_csub(X + Y, twoq);
-                e[b] = hc_mul_shoup_lazy(X - Y + twoq, w.w, w.ws, q);
+                const u64 X = e[a], Y = e[b], u = X + Y, d = (X + Q.q4) - Y;
+                if (LAST && s == 3) e[a] = hc_shoup4(u, ninv.w, ninv.ws, Q);
+                else e[a] = hc_fold(u, Q.nq4);
+                e[b] = hc_shoup4(d, w.w, w.ws, Q);
             }
         }
     }
@@ -145,47 +145,47 @@ struct HcRowsTwB { const HcTw *p; __device__ __forceinline__ HcTw operator()(int
 // forward rows pass on registers: in  e[hi] = element (row, hi*16+tid)  [lazy < 4q]
 //                                 out e[lo] = element (row, tid*16+lo)  [lazy, bound per forward mode]
 template <int FM>
-__device__ __forceinline__ void hc_rows_fwd(u64 (&e)[16], u64 *lds, const HcTwTab &T, int row, int rloc, int tid, u64 q) {
-    hc_ct_round<FM>(e, HcRowsTwA{T.rowsA + row * 16}, q);
+__device__ __forceinline__ void hc_rows_fwd(u64 (&e)[16], u64 *lds, const HcTwTab &T, int row, int rloc, int tid, const HcQ &Q) {
+    hc_ct_round<FM>(e, HcRowsTwA{T.rowsA + row * 16}, Q);
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) lds[hc_rows_lds(rloc, hi * 16 + tid)] = e[hi];
     __syncthreads();
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = lds[hc_rows_lds(rloc, tid * 16 + lo)];
-    hc_ct_round<FM>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, q);
+    hc_ct_round<FM>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, Q);
 }
-// inverse rows pass: in e[lo] = (row, tid*16+lo) [lazy < 2q]; out e[hi] = (row, hi*16+tid) [lazy < 2q]
-__device__ __forceinline__ void hc_rows_inv(u64 (&e)[16], u64 *lds, const HcTwTab &T, int row, int rloc, int tid, u64 q) {
-    hc_gs_round<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, q, T.ninv, T.ninv);
+// inverse rows pass: in e[lo] = (row, tid*16+lo) [lazy < 4q]; out e[hi] = (row, hi*16+tid) [lazy < 4q]
+__device__ __forceinline__ void hc_rows_inv(u64 (&e)[16], u64 *lds, const HcTwTab &T, int row, int rloc, int tid, const HcQ &Q) {
+    hc_gs_round<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, Q, T.ninv, T.ninv);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) lds[hc_rows_lds(rloc, tid * 16 + lo)] = e[lo];
     __syncthreads();
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = lds[hc_rows_lds(rloc, hi * 16 + tid)];
-    hc_gs_round<false>(e, HcRowsTwA{T.rowsA + row * 16}, q, T.ninv, T.ninv);
+    hc_gs_round<false>(e, HcRowsTwA{T.rowsA + row * 16}, Q, T.ninv, T.ninv);
 }
-// forward cols pass: in e[hi] = (hi*16+tid, c) [lazy < 4q]; out e[lo] = (tid*16+lo, c) [lazy < 4q]
+// forward cols pass: in e[hi] = (hi*16+tid, c); out e[lo] = (tid*16+lo, c) [lazy, bounds per forward mode]
 template <int FM>
-__device__ __forceinline__ void hc_cols_fwd(u64 (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, u64 q) {
-    hc_ct_round<FM>(e, HcRowsTwA{T.colsA}, q);
+__device__ __forceinline__ void hc_cols_fwd(u64 (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, const HcQ &Q) {
+    hc_ct_round<FM>(e, HcRowsTwA{T.colsA}, Q);
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) lds[hc_cols_lds(hi * 16 + tid, c)] = e[hi];
     __syncthreads();
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = lds[hc_cols_lds(tid * 16 + lo, c)];
-    hc_ct_round<FM>(e, HcRowsTwB{T.colsB + tid}, q);
+    hc_ct_round<FM>(e, HcRowsTwB{T.colsB + tid}, Q);
 }
 // inverse cols pass incl. N^-1 (SCALE = false: without it, for callers that folded N^-1 into a fixed multiplicand upstream):
-// in e[lo] = (tid*16+lo, c) [lazy < 2q]; out e[hi] = (hi*16+tid, c) [lazy < 2q]
+// in e[lo] = (tid*16+lo, c) [lazy < 4q]; out e[hi] = (hi*16+tid, c) [lazy < 4q]
 template <bool SCALE = true>
-__device__ __forceinline__ void hc_cols_inv(u64 (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, u64 q) {
-    hc_gs_round<false>(e, HcRowsTwB{T.colsB + tid}, q, T.ninv, T.ninv);
+__device__ __forceinline__ void hc_cols_inv(u64 (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, const HcQ &Q) {
+    hc_gs_round<false>(e, HcRowsTwB{T.colsB + tid}, Q, T.ninv, T.ninv);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) lds[hc_cols_lds(tid * 16 + lo, c)] = e[lo];
     __syncthreads();
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = lds[hc_cols_lds(hi * 16 + tid, c)];
-    hc_gs_round<SCALE>(e, HcRowsTwA{T.colsA}, q, T.ninv, T.w_last_ninv);
+    hc_gs_round<SCALE>(e, HcRowsTwA{T.colsA}, Q, T.ninv, T.w_last_ninv);
 }
 
 // fp64 forms of the two inverse passes (same data movement; LDS carries the doubles' bit patterns)
@@ -237,10 +237,11 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd(const u64 *in, u64 *out,
     __shared__ u64 lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)blockIdx.y * 65536 + blockIdx.x * 16 + c;
+    const HcQ Q = hc_q(q);
     u64 e[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[base + (size_t)(hi * 16 + tid) * 256];
-    hc_cols_fwd<FM>(e, lds, T, c, tid, q);
+    hc_cols_fwd<FM>(e, lds, T, c, tid, Q);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) out[base + (size_t)(tid * 16 + lo) * 256] = e[lo];
 }
@@ -252,11 +253,12 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon(const u64 *in, u64
     u64 e[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[pbase + (size_t)row * 256 + hi * 16 + tid];
-    hc_rows_fwd<FM>(e, lds, T, row, rloc, tid, q);
+    const HcQ Q = hc_q(q);
+    hc_rows_fwd<FM>(e, lds, T, row, rloc, tid, Q);
     __syncthreads();
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
-    for (int k = 0; k < 16; k++) out[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t] = hc_fwd_canon<FM>(e[k], q, mu);
+    for (int k = 0; k < 16; k++) out[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t] = hc_fwd_canon<FM>(e[k], Q, mu);
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv(const u64 *in, u64 *out, HcTwTab T, u64 q) {
     __shared__ u64 lds[HC_ROWS_LDS];
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv(const u64 *in, u64 *out,
     for (int k = 0; k < 16; k++) e[k] = in[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t];
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     __syncthreads();
-    hc_rows_inv(e, lds, T, row, rloc, tid, q);
+    hc_rows_inv(e, lds, T, row, rloc, tid, hc_q(q));
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[pbase + (size_t)row * 256 + hi * 16 + tid] = e[hi];
 }
@@ -278,9 +280,10 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_inv_canon(const u64 *in, u64
     u64 e[16];
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = in[base + (size_t)(tid * 16 + lo) * 256];
-    hc_cols_inv(e, lds, T, c, tid, q);
+    const HcQ Q = hc_q(q);
+    hc_cols_inv(e, lds, T, c, tid, Q);
 #pragma unroll
-    for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_csub(e[hi], q);
+    for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_canon4(e[hi], Q);
 }
 
 // ================================================================ pointwise kernels (L0 API + load-time conversions)
@@ -368,6 +371,21 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_make_pairs(const u64 *w, HcTw *ou
     }
 }
 
+// ct_in times MultByConst's per-limb integer constants, as Shoup pairs (c', floor(c' * 2^64 / q)): the fixed operand of loop A.
+// grid = (64, 4 rows = [poly][limb], ciphertexts of a batch)
+#define HC_MAXB 16                    // ciphertexts per batched conv launch set
+struct HcPtrs { const u64 *p[HC_MAXB]; };      // one device pointer per ciphertext of a batch (kernel argument, indexed by blockIdx)
+struct HcCtc { HcMod m0, m1; HcTw c0, c1; };
+__global__ __launch_bounds__(HC_TPB) void hc_k_ctc_pairs(HcPtrs ct_in, HcTw *out, HcCtc K) {
+    const int r = blockIdx.y, l = r & 1; const HcMod m = l ? K.m1 : K.m0; const HcTw cst = l ? K.c1 : K.c0;
+    const u64 *in = ct_in.p[blockIdx.z] + (size_t)r * 65536;
+    HcTw *o = out + ((size_t)blockIdx.z * 4 + r) * 65536;
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
+        HcTw p; p.w = hc_mul_shoup(in[i], cst.w, cst.ws, m.q); p.ws = hc_shoup_companion(p.w, m.q);
+        o[i] = p;
+    }
+}
+
 // ================================================================ prep_Ker on the device (conv.go:487-518)
 // One thread per non-zero of the kernel plaintexts: (i = output channel, j = input channel, k = tap). Restates
 // reshape_ker (conv.go:184-202), the BN scaling (492-496), the max_bat embedding (498-508), encode_ker_final
@@ -417,23 +435,6 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ker_interleave(const u64 *stage, 
         dst[id] = to_mont ? hc_mont(x, m.r2, m.q, m.qinv) : x;
     }
 }
-// [i][limb][N] plain NTT rows -> Montgomery form, same layout (hc_ker_load); in == out allowed
-__global__ __launch_bounds__(HC_TPB) void hc_k_ker_to_mont(const u64 *in, u64 *out, int max_bat, HcMod m0, HcMod m1) {
-    const size_t n = (size_t)max_bat * 2 * 65536;
-    for (size_t id = (size_t)blockIdx.x * HC_TPB + threadIdx.x; id < n; id += (size_t)gridDim.x * HC_TPB) {
-        const HcMod m = ((id >> 16) & 1) ? m1 : m0;
-        out[id] = hc_mont(in[id], m.r2, m.q, m.qinv);
-    }
-}
-// inverse of the above for inspection: dst_plain[i][limb][N] = from Montgomery form
-__global__ __launch_bounds__(HC_TPB) void hc_k_ker_from_mont(const u64 *ker, u64 *dst, int max_bat, HcMod m0, HcMod m1) {
-    const size_t n = (size_t)max_bat * 2 * 65536;
-    for (size_t id = (size_t)blockIdx.x * HC_TPB + threadIdx.x; id < n; id += (size_t)gridDim.x * HC_TPB) {
-        const HcMod m = ((id >> 16) & 1) ? m1 : m0;
-        dst[id] = hc_mont(ker[id], 1, m.q, m.qinv);
-    }
-}
-
 // ring.PermuteNTTIndex on the fly: source index of destination i for Galois element g (N = 2^16)
 __device__ __forceinline__ u32 hc_perm_src(u32 i, u32 g) {
     u32 r = __brev(i) >> 16;
@@ -459,56 +460,100 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rotate_finish(const u64 *d0, cons
 
 // ================================================================ loop A (conv.go:525-531), fused
 // Per output channel i and ciphertext polynomial p:
-//   a_l = c'_p[l] (*) k_i[l]  (l = 0,1; c' = ct_in * MultByConst constant, k in Montgomery form)
+//   a_l = c'_p[l] (*) k_i[l]  (l = 0,1; c' = ct_in * MultByConst constant, kept as Shoup pairs: it is the FIXED operand of 2B products)
 //   rescale by Q1: t = INTT_Q1(a_1); t = [t + h]_{Q1}; u = NTT_Q0(t - h); out = (a_0 - u) * Q1^-1 mod Q0
+// Grids: HC_JOB = job (channel x polynomial, or tree node), HC_TILE = the 16 tiles of a row, blockIdx.z = ciphertext of a batch
+// (loop A's rows kernels). The JOB index is the fast one on purpose: workgroups are dispatched x-first, so the workgroups in flight at
+// any time work on the same tile of different jobs and share that tile's fixed operands -- 64 KiB of per-row twiddles, 64 KiB of c'
+// pairs, 64-128 KiB of key / idx pairs per tile, as much as or more than the 32-96 KiB of data a workgroup moves -- out of L2. With
+// the tile index fast (round 1) every resident workgroup wanted a different tile of every table and those bytes came over the fabric.
+#ifndef HC_JOB_FAST
+#define HC_JOB_FAST 0       // 16 tiles over 8 XCDs: with the tile index fast, XCD r serves tiles r and r + 8 of EVERY job, so each L2 keeps just
+#endif                      // two tiles of every twiddle / key / c' table (measured 2-4 % faster than job-fast, which cycles all 16 through every L2)
+#if HC_JOB_FAST
+#define HC_JOB blockIdx.x
+#define HC_TILE blockIdx.y
+#define HC_NJOBS gridDim.x
+#else
+#define HC_JOB blockIdx.y
+#define HC_TILE blockIdx.x
+#define HC_NJOBS gridDim.y
+#endif
+#define HC_FREE_OFF 72                // FREE-mode forward outputs are below 70q (hc_ct_round): X + 72q - (such a value) stays positive
 struct HcLoopA {
-    const u64 *ctc;   // [2 polys][2 limbs][N]   ct_in times the integer constant, canonical
-    const u64 *ker;   // [max_ob][2 limbs][N]    Montgomery form
+    const HcTw *ctc;  // [2 polys][2 limbs][N]   ct_in times the integer constant (canonical) with its Shoup companion
+    HcPtrs ker;       // per ciphertext: [max_ob][2 limbs][N] kernel plaintexts, plain NTT residues (what prep_Ker's pl_ker[i] holds)
     u64 *tmp;         // [chunk][2 polys][N]
     u64 *cts;         // [max_ob][2 polys][N]    level-0 outputs
     int i0, norm;     // first channel of this chunk; channel of job j is i0 + (j>>1)*norm, poly = j&1
     int slot0, slot_step;   // its result goes to cts slot slot0 + (j>>1)*slot_step (= the channel index, or a compact ordinal)
+    size_t cts_stride;   // blockIdx.z = ciphertext of a batch: ctc is [z][2][2][N]; cts of consecutive ciphertexts are cts_stride words apart
+    int njobs;        // jobs per ciphertext in this launch
     HcMod m0, m1;
     HcTw q1inv;       // Q1^-1 mod Q0
     u64 h, negh0;     // (Q1-1)>>1 ; Q0 - (h mod Q0)
 };
-// KA1: rows-inverse of a_1 (mod Q1). grid = (16, jobs). F64 = 1: Q1 < 2^49, the transform runs in fp64 (T1inv = the fp64 table)
+// KA1: rows-inverse of a_1 (mod Q1). grid = (jobs, 16, batch). F64 = 1: Q1 < 2^49, the transform runs in fp64 (T1inv = the fp64 table)
 // and tmp carries doubles (bit patterns) to KA2.
+#ifndef HC_DBG_A1
+#define HC_DBG_A1 0       // experiments only (tools/build_variant.sh): 1 = no c' loads, 2 = no transform, 3 = linear stores, 4 = no stores
+#endif
 template <int F64>
 __global__ __launch_bounds__(HC_TPB) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
     __shared__ u64 lds[HC_ROWS_LDS];
-    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
-    const int job = blockIdx.y, p = job & 1, i = A.i0 + (job >> 1) * A.norm;
-    const u64 *c = A.ctc + ((size_t)p * 2 + 1) * 65536, *k = A.ker + ((size_t)i * 2 + 1) * 65536;
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
+    const int job = HC_JOB, p = job & 1, i = A.i0 + (job >> 1) * A.norm, z = blockIdx.z;
+    const HcTw *__restrict__ c = A.ctc + ((size_t)z * 4 + (size_t)p * 2 + 1) * 65536;
+    const u64 *__restrict__ k = A.ker.p[z] + ((size_t)i * 2 + 1) * 65536;
+    const HcQ Q = hc_q(A.m1.q);
     u64 e[16];
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
-        const size_t off = (size_t)(blockIdx.x * 16 + kk) * 256 + t;
-        e[kk] = hc_mont(c[off], k[off], A.m1.q, A.m1.qinv);
+        const size_t off = (size_t)(HC_TILE * 16 + kk) * 256 + t;
+        HcTw cw;
+        if (HC_DBG_A1 == 1) { cw.w = A.h + kk; cw.ws = A.negh0; } else cw = c[off];
+        e[kk] = hc_shoup4(k[off], cw.w, cw.ws, Q);                              // [0, 4*Q1)
+    }
+    u64 *o = A.tmp + ((size_t)z * A.njobs + job) * 65536 + (size_t)row * 256;
+    if (HC_DBG_A1 == 2) {
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
+        return;
     }
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     __syncthreads();
-    u64 *o = A.tmp + (size_t)job * 65536 + (size_t)row * 256;
     if (F64) {
         const HcF64Mod m{(double)A.m1.q, 1.0 / (double)A.m1.q};
         double f[16];
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) f[kk] = hc_f64_from_u(e[kk]);
+        for (int kk = 0; kk < 16; kk++) f[kk] = hc_f64_reduce(hc_f64_from_u(e[kk]), m.q, m.qinv);   // 4*Q1 < 2^51: exact; |f| <= Q1/2
         hc_rows_inv_f64(f, lds, T1inv, row, rloc, tid, m);
+        if (HC_DBG_A1 == 3) {
+            u64 *ol = A.tmp + ((size_t)z * A.njobs + job) * 65536 + (size_t)HC_TILE * 4096 + t;
+#pragma unroll
+            for (int hi = 0; hi < 16; hi++) ol[hi * 256] = hc_d2u(f[hi]);
+        } else if (HC_DBG_A1 == 4) {
+            double sacc = 0;
+#pragma unroll
+            for (int hi = 0; hi < 16; hi++) sacc += f[hi];
+            if (sacc == 1.2345) o[0] = 1;
+        } else {
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = hc_d2u(f[hi]);
+        }
     } else {
-        hc_rows_inv(e, lds, T1inv, row, rloc, tid, A.m1.q);
+        hc_rows_inv(e, lds, T1inv, row, rloc, tid, Q);
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
     }
 }
-// KA2: cols-inverse mod Q1, centred lift to Q0, cols-forward mod Q0, in place on tmp. grid = (16, jobs)
+// KA2: cols-inverse mod Q1, centred lift to Q0, cols-forward mod Q0, in place on tmp. grid = (jobs * batch, 16)
 template <int FM, int F64>
 __global__ __launch_bounds__(HC_TPB) void hc_k_a2(HcLoopA A, HcTwTab T1inv, HcTwTab T0fwd) {
     __shared__ u64 lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
-    u64 *base = A.tmp + (size_t)blockIdx.y * 65536 + blockIdx.x * 16 + c;
+    u64 *base = A.tmp + (size_t)HC_JOB * 65536 + HC_TILE * 16 + c;
+    const HcQ Q0 = hc_q(A.m0.q);
     u64 e[16];
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = base[(size_t)(tid * 16 + lo) * 256];
@@ -526,45 +571,47 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_a2(HcLoopA A, HcTwTab T1inv, HcTw
             e[hi] = hc_f64_to_u_plus(v, A.m0.q);                      // + Q0: the same value mod Q0, in (0, 2*Q0)
         }
     } else {
-    hc_cols_inv(e, lds, T1inv, c, tid, A.m1.q);
+        const HcQ Q1 = hc_q(A.m1.q);
+        hc_cols_inv(e, lds, T1inv, c, tid, Q1);
 #pragma unroll
-    for (int hi = 0; hi < 16; hi++) {
-        u64 v = hc_csub(hc_csub(e[hi], A.m1.q) + A.h, A.m1.q);   // [t + h]_{Q1}
-        e[hi] = v + A.negh0;                                      // (.. - h) mod Q0, lazy < 2*Q0
-    }
+        for (int hi = 0; hi < 16; hi++) {
+            const u64 v = hc_csub(hc_canon4(e[hi], Q1) + A.h, A.m1.q);   // [t + h]_{Q1}
+            e[hi] = hc_reduce64(v + A.negh0, A.m0.mu, Q0);                // (.. - h) mod Q0 (Q1 may exceed Q0 here: reduce fully)
+        }
     }
     __syncthreads();
-    hc_cols_fwd<FM>(e, lds, T0fwd, c, tid, A.m0.q);
+    hc_cols_fwd<FM>(e, lds, T0fwd, c, tid, Q0);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
 }
-// KA3: rows-forward mod Q0, then out = (a_0 - u) * Q1^-1. grid = (16, jobs)
+// KA3: rows-forward mod Q0, then out = (a_0 - u) * Q1^-1. grid = (jobs, 16, batch)
 // a_0 = c'_p[0] (*) k_i[0] is formed first, in the linear layout the epilogue uses, so that every global load of
 // the kernel is issued before the transform starts and nothing stalls behind the stores at the end.
 template <int FM>
 __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_a3(HcLoopA A, HcTwTab T0fwd) {
     __shared__ u64 lds[HC_ROWS_LDS];
-    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
-    const int job = blockIdx.y, p = job & 1, i = A.i0 + (job >> 1) * A.norm;
-    const u64 *__restrict__ in = A.tmp + (size_t)job * 65536 + (size_t)row * 256;
-    const u64 *__restrict__ c = A.ctc + ((size_t)p * 2) * 65536 + (size_t)blockIdx.x * 4096 + t;
-    const u64 *__restrict__ k = A.ker + ((size_t)i * 2) * 65536 + (size_t)blockIdx.x * 4096 + t;
-    u64 *__restrict__ o = A.cts + ((size_t)(A.slot0 + (job >> 1) * A.slot_step) * 2 + p) * 65536 + (size_t)blockIdx.x * 4096 + t;
-    const u64 q = A.m0.q;
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
+    const int job = HC_JOB, p = job & 1, i = A.i0 + (job >> 1) * A.norm, z = blockIdx.z;
+    const u64 *__restrict__ in = A.tmp + ((size_t)z * A.njobs + job) * 65536 + (size_t)row * 256;
+    const HcTw *__restrict__ c = A.ctc + ((size_t)z * 4 + (size_t)p * 2) * 65536 + (size_t)HC_TILE * 4096 + t;
+    const u64 *__restrict__ k = A.ker.p[z] + ((size_t)i * 2) * 65536 + (size_t)HC_TILE * 4096 + t;
+    u64 *__restrict__ o = A.cts + (size_t)z * A.cts_stride + ((size_t)(A.slot0 + (job >> 1) * A.slot_step) * 2 + p) * 65536 + (size_t)HC_TILE * 4096 + t;
+    const HcQ Q = hc_q(A.m0.q);
     u64 e[16], a0[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) a0[kk] = c[kk * 256];
+    for (int kk = 0; kk < 16; kk++) a0[kk] = k[kk * 256];
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) a0[kk] = hc_mont(a0[kk], k[kk * 256], q, A.m0.qinv);
-    hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, q);
+    for (int kk = 0; kk < 16; kk++) { const HcTw cw = c[kk * 256]; a0[kk] = hc_shoup4(a0[kk], cw.w, cw.ws, Q); }      // [0, 4q)
+    hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, Q);
     __syncthreads();
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
-        u64 u = hc_fwd_canon<FM>(e[kk], q, A.m0.mu);
-        o[kk * 256] = hc_mul_shoup(hc_submod(a0[kk], u, q), A.q1inv.w, A.q1inv.ws, q);
+        // FREE: u = e < 70q stays lazy, a_0 + 72q - u is positive and below 2^64; ALT (8q < 2^64 only): u canonical first
+        const u64 d = FM == HC_FM_FREE ? a0[kk] + HC_FREE_OFF * Q.q - e[kk] : a0[kk] + Q.q - hc_canon8(e[kk], Q);
+        o[kk * 256] = hc_canon4(hc_shoup4(d, A.q1inv.w, A.q1inv.ws, Q), Q);
     }
 }
 
@@ -575,15 +622,14 @@ struct HcLoopB {
     u64 *dst;            // [max_cnum][2][N] where it writes node results (slot i); src != dst: the two ping-pong
     u64 *tmpC;           // [chunk][N]      c1 of t2 through iNTT_Q0 / NTT_P
     u64 *tmpE;           // [chunk][2][N]   P-part accumulators through iNTT_P / NTT_Q0
-    u64 *tmpT;           // [chunk][N]      t2.c1 itself (canonical, natural order): b1 -> b5
-    // fixed multiplicands are kept in Montgomery form (w * 2^64 mod q), 8 bytes each: one hc_mont per use gives the
-    // canonical product for ANY 64-bit other operand. (Lattigo stores switching keys exactly like this.)
-    const u64 *idx;      // [N]             idx[s] plaintext, natural order
-    const u64 *evkQ;     // [2][N]          b_Q * P^-1, a_Q * P^-1 mod Q0 (Montgomery form), natural order
-    const HcTw *evkP;    // [2][N]          b_P * N^-1, a_P * N^-1 mod P as Shoup pairs in lo-local-coalesced order (hc_k_b3 multiplies
-                         //                 lazy transform outputs inside a register-tight kernel: measured faster than
-                         //                 the Montgomery form there)
+    u64 *tmpT;           // [chunk][N]      t2.c1 itself (lazy < 4q, natural order): b1 -> b5
+    // fixed multiplicands (idx plaintext, both halves of the switching key) are Shoup pairs: one hc_shoup4 per use
+    const HcTw *idx;     // [N]             idx[s] plaintext, natural order
+    const HcTw *evkQ;    // [2][N]          b_Q * P^-1, a_Q * P^-1 mod Q0, natural order
+    const HcTw *evkP;    // [2][N]          b_P * N^-1, a_P * N^-1 mod P in lo-local-coalesced order (hc_k_b3)
     int n0, step, norm;  // first node of this chunk
+    int nodes;           // nodes of this launch per ciphertext (HC_JOB = z * nodes + node for a batch)
+    size_t src_stride, dst_stride;   // distance between the ciphertext arrays of consecutive batch members (u64 words)
     HcMod m0, mp;
     HcTw pmodq;          // P mod Q0
     HcTw pinv;           // P^-1 mod Q0
@@ -591,135 +637,140 @@ struct HcLoopB {
     u64 vthresh;         // smallest y with uint64(float64(y)/float64(P)) >= 1 (P if none): the fp64 overflow count as a compare
     u32 gal;             // Galois element of this level
 };
-// KB1: t2.c1 = y1 - I*x1 (kept in tmpT for KB5) and its rows-inverse (mod Q0). grid = (16, nodes). Everything else a node needs
+// KB1: t2.c1 = y1 - I*x1 (kept in tmpT for KB5) and its rows-inverse (mod Q0). grid = (batch*nodes, 16). Everything else a node needs
 // from x and y (t1, t2.c0, the Q-part of the key switch) is formed in KB5 from src and tmpT.
 __global__ __launch_bounds__(HC_TPB) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
     __shared__ u64 lds[HC_ROWS_LDS];
-    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
-    const int node = blockIdx.y, i = (B.n0 + node) * B.norm;
-    const size_t tile = (size_t)blockIdx.x * 4096 + t;
-    const u64 *__restrict__ y1 = B.src + ((size_t)i * 2 + 1) * 65536 + tile;
-    const u64 *__restrict__ x1 = B.src + ((size_t)(i + B.step) * 2 + 1) * 65536 + tile;
-    const u64 *__restrict__ idx = B.idx + tile;
-    const u64 q = B.m0.q, qinv = B.m0.qinv;
-    u64 e[16], yy[16], I[16];
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
+    const int job = HC_JOB, z = job / B.nodes, node = job - z * B.nodes, i = (B.n0 + node) * B.norm;
+    const size_t tile = (size_t)HC_TILE * 4096 + t;
+    const u64 *__restrict__ y1 = B.src + (size_t)z * B.src_stride + ((size_t)i * 2 + 1) * 65536 + tile;
+    const u64 *__restrict__ x1 = B.src + (size_t)z * B.src_stride + ((size_t)(i + B.step) * 2 + 1) * 65536 + tile;
+    const HcTw *__restrict__ idx = B.idx + tile;
+    const HcQ Q = hc_q(B.m0.q);
+    u64 e[16], yy[16];
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) { e[kk] = x1[kk * 256]; yy[kk] = y1[kk * 256]; }
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) I[kk] = idx[kk * 256];
-#pragma unroll
-    for (int kk = 0; kk < 16; kk++) e[kk] = hc_submod(yy[kk], hc_mont(e[kk], I[kk], q, qinv), q);   // t2.c1 (conv.go:288-289)
-    u64 *__restrict__ tt = B.tmpT + (size_t)node * 65536 + tile;
+    for (int kk = 0; kk < 16; kk++) {
+        const HcTw I = idx[kk * 256];
+        e[kk] = hc_fold(yy[kk] + Q.q4 - hc_shoup4(e[kk], I.w, I.ws, Q), Q.nq4);                    // t2.c1 (conv.go:288-289), lazy < 4q
+    }
+    u64 *__restrict__ tt = B.tmpT + (size_t)job * 65536 + tile;
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) tt[kk * 256] = e[kk];
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     __syncthreads();
-    hc_rows_inv(e, lds, T0inv, row, rloc, tid, q);
-    u64 *__restrict__ o = B.tmpC + (size_t)node * 65536 + (size_t)row * 256;
+    hc_rows_inv(e, lds, T0inv, row, rloc, tid, Q);
+    u64 *__restrict__ o = B.tmpC + (size_t)job * 65536 + (size_t)row * 256;
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
 }
-// KB2: cols-inverse mod Q0 (-> canonical c < Q0 < P), cols-forward mod P, in place on tmpC. grid = (16, nodes)
+// KB2: cols-inverse mod Q0 (-> canonical c < Q0 < P), cols-forward mod P, in place on tmpC. grid = (batch*nodes, 16)
 template <int FMP>
 __global__ __launch_bounds__(HC_TPB) void hc_k_b2(HcLoopB B, HcTwTab T0inv, HcTwTab TPfwd) {
     __shared__ u64 lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
-    u64 *base = B.tmpC + (size_t)blockIdx.y * 65536 + blockIdx.x * 16 + c;
+    u64 *base = B.tmpC + (size_t)HC_JOB * 65536 + HC_TILE * 16 + c;
+    const HcQ Q0 = hc_q(B.m0.q), QP = hc_q(B.mp.q);
     u64 e[16];
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = base[(size_t)(tid * 16 + lo) * 256];
-    hc_cols_inv(e, lds, T0inv, c, tid, B.m0.q);
+    hc_cols_inv(e, lds, T0inv, c, tid, Q0);
 #pragma unroll
-    for (int hi = 0; hi < 16; hi++) e[hi] = hc_csub(e[hi], B.m0.q);
+    for (int hi = 0; hi < 16; hi++) e[hi] = hc_canon4(e[hi], Q0);          // the integer in [0, Q0) is what is read modulo P
     __syncthreads();
-    hc_cols_fwd<FMP>(e, lds, TPfwd, c, tid, B.mp.q);
+    hc_cols_fwd<FMP>(e, lds, TPfwd, c, tid, QP);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
 }
-// KB3: rows-forward mod P, multiply by b_P and a_P, rows-inverse mod P of both. grid = (16, nodes)
+// KB3: rows-forward mod P, multiply by b_P and a_P, rows-inverse mod P of both. grid = (batch*nodes, 16)
 template <int FMP>
 __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b3(HcLoopB B, HcTwTab TPfwd, HcTwTab TPinv) {
     __shared__ u64 lds[HC_ROWS_LDS];
-    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
-    const int node = blockIdx.y;
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
+    const int node = HC_JOB;
     const u64 *in = B.tmpC + (size_t)node * 65536 + (size_t)row * 256;
-    const u64 q = B.mp.q;
+    const HcQ Q = hc_q(B.mp.q);
     u64 cp[16], e[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) cp[hi] = in[hi * 16 + tid];
-    hc_rows_fwd<FMP>(cp, lds, TPfwd, row, rloc, tid, q);
+    hc_rows_fwd<FMP>(cp, lds, TPfwd, row, rloc, tid, Q);
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const HcTw *__restrict__ ev = B.evkP + (size_t)k * 65536 + (size_t)blockIdx.x * 4096 + t;
+        const HcTw *__restrict__ ev = B.evkP + (size_t)k * 65536 + (size_t)HC_TILE * 4096 + t;
 #pragma unroll
         for (int lo = 0; lo < 16; lo++) {
             const HcTw w = ev[lo * 256];
-            e[lo] = hc_mul_shoup_lazy(cp[lo], w.w, w.ws, q);
+            e[lo] = hc_shoup4(cp[lo], w.w, w.ws, Q);
         }
         __syncthreads();
-        hc_rows_inv(e, lds, TPinv, row, rloc, tid, q);
+        hc_rows_inv(e, lds, TPinv, row, rloc, tid, Q);
         u64 *o = B.tmpE + ((size_t)node * 2 + k) * 65536 + (size_t)row * 256;
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
     }
 }
 // KB4: cols-inverse mod P, exact basis extension P -> Q0 (ring.modUpExact, one P prime), cols-forward mod Q0.
-// grid = (16, 2*nodes), in place on tmpE
+// grid = (2*batch*nodes, 16), in place on tmpE
 template <int FM>
 __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTwTab T0fwd) {
     __shared__ u64 lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
-    u64 *base = B.tmpE + (size_t)blockIdx.y * 65536 + blockIdx.x * 16 + c;
-    const u64 P = B.mp.q, q = B.m0.q;
+    u64 *base = B.tmpE + (size_t)HC_JOB * 65536 + HC_TILE * 16 + c;
+    const HcQ QP = hc_q(B.mp.q), Q = hc_q(B.m0.q);
     u64 e[16];
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = base[(size_t)(tid * 16 + lo) * 256];
-    hc_cols_inv<false>(e, lds, TPinv, c, tid, P);                 // N^-1 mod P is inside the key rows (hc_evk_load)
+    hc_cols_inv<false>(e, lds, TPinv, c, tid, QP);                 // N^-1 mod P is inside the key rows (hc_evk_load)
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) {
-        const u64 yv = hc_csub(e[hi], P);                        // [d]_P in [0,P)
+        const u64 yv = hc_canon4(e[hi], QP);                       // [d]_P in [0,P)
         // ring.reconstructRNS: v = uint64(float64(y)/float64(P)) (0 or 1 for one P prime). y -> v is monotone, so
         // the host finds the switch point with the very same fp64 expression and the kernel only compares.
         // The extension is carried pre-divided by P (the division ModDown ends with): ext * P^-1 = y * P^-1 - v mod Q0. One Shoup
-        // product of the 64-bit y replaces the Barrett reduction here and removes the P^-1 product from b5 (same canonical residues).
-        u64 r = hc_mul_shoup(yv, B.pinv.w, B.pinv.ws, q);
-        if (yv >= B.vthresh) r = hc_submod(r, 1, q);
+        // product of the 64-bit y replaces the Barrett reduction here and removes the P^-1 product from b5 (same residues; lazy < 5q).
+        u64 r = hc_shoup4(yv, B.pinv.w, B.pinv.ws, Q);
+        if (yv >= B.vthresh) r += Q.q - 1;
         e[hi] = r;
     }
     __syncthreads();
-    hc_cols_fwd<FM>(e, lds, T0fwd, c, tid, q);
+    hc_cols_fwd<FM>(e, lds, T0fwd, c, tid, Q);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) base[(size_t)(tid * 16 + lo) * 256] = e[lo];
 }
-// KB5: one job per (node, polynomial k): grid = (16, 2*nodes), job = node*2 + k.
+// KB5: one job per (node, polynomial k): grid = (2*batch*nodes, 16), job = (z*nodes + node)*2 + k.
 //   front end (linear layout, from src and b1's t2.c1):  m_k = I*x_k ; t1_k = y_k + m_k ; t2.c_k = y_k - m_k  (k = 1: m_1 = y_1 - t2.c1)
 //        F_1 = (a_Q / P) * t2.c1                (k = 1)      (hc_evk_load stores the Q rows of the key times P^-1 mod Q0)
 //        F_0 = t2.c0 + (b_Q / P) * t2.c1        (k = 0)
 //   rows-forward mod Q0 of the k-th extension (b4 hands it over divided by P) n_k ; d_k = F_k - n_k = [k==0] t2.c0 + (key switch)_k ;
 //   tile-local Galois permutation through LDS ; dst[i][k] = t1_k + perm(d_k) (+ bias on k = 0 of the last node).
+// FREE mode (Q0 < 2^57): every term stays lazy (t1 < 7q, F < 9q, n < 70q) and ONE short Barrett reduction makes the stored value
+// canonical; ALT mode has no such headroom and works on canonical terms.
 // Requires the permutation to stay inside the workgroup's 16-row tile (4096 consecutive coefficients): galEl = 2^j+1, j >= 5
 // (j >= 9 even stays inside one 256-coefficient row; j = 7, 8 are what the resnet's 8x8 layers, max_cnum 1024, add).
 template <int FM>
-__global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, const u64 *bias) {
+__global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, HcPtrs biases) {
     __shared__ u64 lds[HC_ROWS_LDS];
-    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
-    const int job = blockIdx.y, node = job >> 1, k = job & 1, i = (B.n0 + node) * B.norm;
-    const u64 q = B.m0.q;
-    const size_t tile = (size_t)blockIdx.x * 4096 + t;
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
+    const int job = HC_JOB, zn = job >> 1, k = job & 1, z = zn / B.nodes, node = zn - z * B.nodes, i = (B.n0 + node) * B.norm;
+    const HcQ Q = hc_q(B.m0.q);
+    const u64 q = Q.q;
+    const size_t tile = (size_t)HC_TILE * 4096 + t;
     const u64 *__restrict__ in = B.tmpE + (size_t)job * 65536 + (size_t)row * 256;
-    const u64 *__restrict__ yk = B.src + ((size_t)i * 2 + k) * 65536 + tile;
-    const u64 *__restrict__ xk = B.src + ((size_t)(i + B.step) * 2 + k) * 65536 + tile;
-    const u64 *__restrict__ tc1 = B.tmpT + (size_t)node * 65536 + tile;    // t2.c1 = y1 - I*x1 from b1
-    const u64 *__restrict__ idx = B.idx + tile;
-    const u64 *__restrict__ evk = B.evkQ + (size_t)k * 65536 + tile;      // b_Q/P for k = 0, a_Q/P for k = 1
-    const u64 qinv = B.m0.qinv;
-    u64 *__restrict__ o = B.dst + ((size_t)i * 2 + k) * 65536 + tile;
+    const u64 *__restrict__ yk = B.src + (size_t)z * B.src_stride + ((size_t)i * 2 + k) * 65536 + tile;
+    const u64 *__restrict__ xk = B.src + (size_t)z * B.src_stride + ((size_t)(i + B.step) * 2 + k) * 65536 + tile;
+    const u64 *__restrict__ tc1 = B.tmpT + (size_t)zn * 65536 + tile;      // t2.c1 = y1 - I*x1 from b1 (lazy < 4q)
+    const HcTw *__restrict__ idx = B.idx + tile;
+    const HcTw *__restrict__ evk = B.evkQ + (size_t)k * 65536 + tile;      // b_Q/P for k = 0, a_Q/P for k = 1
+    u64 *__restrict__ o = B.dst + (size_t)z * B.dst_stride + ((size_t)i * 2 + k) * 65536 + tile;
+    const u64 *__restrict__ bias = biases.p[z];        // null except on the last node of the tree (eval.go:258)
     u64 e[16], f[16], t1[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
 #pragma unroll
     for (int b = 0; b < 4; b++) {               // batches of 4 residues: all loads of a batch before its arithmetic
-        u64 X[4], Y[4], I[4], K[4], T[4];
+        u64 X[4], Y[4], T[4]; HcTw I[4], K[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int off = (b * 4 + j) * 256;
@@ -729,28 +780,37 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, c
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int kk = b * 4 + j;
-            const u64 g = hc_mont(T[j], K[j], q, qinv);                                           // (key row / P) * t2.c1
+            u64 g = hc_shoup4(T[j], K[j].w, K[j].ws, Q);                                          // (key row / P) * t2.c1, < 4q
+            if (FM != HC_FM_FREE) g = hc_canon4(g, Q);
             if (k == 0) {
-                const u64 m = hc_mont(X[j], I[j], q, qinv);
-                t1[kk] = hc_addmod(Y[j], m, q);                                                   // conv.go:290
-                f[kk] = hc_addmod(hc_submod(Y[j], m, q), g, q);                                   // t2.c0 + ...
+                u64 m = hc_shoup4(X[j], I[j].w, I[j].ws, Q);
+                if (FM == HC_FM_FREE) {
+                    t1[kk] = Y[j] + m;                                                            // conv.go:290, < 5q
+                    f[kk] = Y[j] + Q.q4 - m + g;                                                  // t2.c0 + ..., < 9q
+                } else {
+                    m = hc_canon4(m, Q);
+                    t1[kk] = hc_addmod(Y[j], m, q);
+                    f[kk] = hc_addmod(hc_submod(Y[j], m, q), g, q);
+                }
             } else {
-                t1[kk] = hc_addmod(Y[j], hc_submod(Y[j], T[j], q), q);                            // y1 + I*x1 with I*x1 = y1 - t2.c1
+                if (FM == HC_FM_FREE) t1[kk] = Y[j] + Y[j] + Q.q4 - T[j];                         // y1 + I*x1 with I*x1 = y1 - t2.c1, < 6q
+                else t1[kk] = hc_addmod(Y[j], hc_submod(Y[j], hc_canon4(T[j], Q), q), q);
                 f[kk] = g;
             }
         }
     }
     if (bias != nullptr && k == 0) {
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) t1[kk] = hc_addmod(t1[kk], bias[tile + kk * 256], q);
+        for (int kk = 0; kk < 16; kk++) t1[kk] = FM == HC_FM_FREE ? t1[kk] + bias[tile + kk * 256] : hc_addmod(t1[kk], bias[tile + kk * 256], q);
     }
-    hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, q);
+    hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, Q);
     __syncthreads();
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
-        u64 n = hc_fwd_canon<FM>(e[kk], q, B.m0.mu);
-        e[kk] = hc_submod(f[kk], n, q);                                                          // n = NTT(ext * P^-1), F already / P
+        // n = NTT(ext * P^-1), F already / P
+        if (FM == HC_FM_FREE) e[kk] = f[kk] + HC_FREE_OFF * q - e[kk];                            // < 81q
+        else e[kk] = hc_submod(f[kk], hc_canon8(e[kk], Q), q);
     }
     __syncthreads();
 #pragma unroll
@@ -758,9 +818,10 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, c
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
-        const u32 dstidx = (u32)((blockIdx.x * 16 + kk) * 256 + t);
+        const u32 dstidx = (u32)((HC_TILE * 16 + kk) * 256 + t);
         const u32 srcidx = hc_perm_src(dstidx, B.gal);
-        o[kk * 256] = hc_addmod(t1[kk], lds[hc_rows_lds((int)((srcidx >> 8) & 15), (int)(srcidx & 255))], q);   // source stays inside this 16-row tile
+        const u64 d = lds[hc_rows_lds((int)((srcidx >> 8) & 15), (int)(srcidx & 255))];          // source stays inside this 16-row tile
+        o[kk * 256] = FM == HC_FM_FREE ? hc_reduce64(t1[kk] + d, B.m0.mu, Q) : hc_addmod(t1[kk], d, q);
     }
 }
 
@@ -808,7 +869,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd_mm(const u64 *in, u64 *o
     u64 e[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[base + (size_t)(hi * 16 + tid) * 256];
-    hc_cols_fwd<HC_FM_ALT>(e, lds, R.fwd, c, tid, R.q);
+    hc_cols_fwd<HC_FM_ALT>(e, lds, R.fwd, c, tid, hc_q(R.q));
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) out[base + (size_t)(tid * 16 + lo) * 256] = e[lo];
 }
@@ -822,11 +883,12 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, 
     u64 e[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[pbase + (size_t)row * 256 + hi * 16 + tid];
-    hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, R.q);
+    const HcQ Q = hc_q(R.q);
+    hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, Q);
     __syncthreads();
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
-    for (int k = 0; k < 16; k++) out[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t] = hc_fwd_canon<HC_FM_ALT>(e[k], R.q, R.mu);
+    for (int k = 0; k < 16; k++) out[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu);
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_ROWS_LDS];
@@ -840,7 +902,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *o
     for (int k = 0; k < 16; k++) e[k] = in[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t];
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     __syncthreads();
-    hc_rows_inv(e, lds, R.inv, row, rloc, tid, R.q);
+    hc_rows_inv(e, lds, R.inv, row, rloc, tid, hc_q(R.q));
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[pbase + (size_t)row * 256 + hi * 16 + tid] = e[hi];
 }
@@ -854,9 +916,10 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_inv_canon_mm(const u64 *in, 
     u64 e[16];
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = in[base + (size_t)(tid * 16 + lo) * 256];
-    hc_cols_inv(e, lds, R.inv, c, tid, R.q);
+    const HcQ Q = hc_q(R.q);
+    hc_cols_inv(e, lds, R.inv, c, tid, Q);
 #pragma unroll
-    for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_csub(e[hi], R.q);
+    for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_canon4(e[hi], Q);
 }
 // fast basis extension into every target row of the batch: Bs[T] holds the constants for target row T (the source-side
 // constants s, inv, mu_s are the same in all of them). One thread owns a coefficient: y_i and the fp64 overflow count v are
@@ -919,7 +982,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const 
 __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_mac(const u64 *evk, const u64 *cx, const u64 *half, u64 *acc, const HcRowMod *M, const HcMod *mods, int nl, int nq, int nt, int alpha, int beta) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int T = blockIdx.y, mod = T < nl ? T : nq + (T - nl);
-    const HcRowMod &R = M[mod]; const u64 q = R.q, qinv = mods[mod].qinv;
+    const HcRowMod &R = M[mod]; const u64 q = R.q, qinv = mods[mod].qinv; const HcQ Q = hc_q(q);
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
     const size_t lin = (size_t)T * 65536 + (size_t)blockIdx.x * 4096 + t;          // + k * 256: element (tile row k, column t)
     u64 a0[16], a1[16], e[16];
@@ -934,11 +997,11 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_mac(const u64 *evk, cons
 #pragma unroll
             for (int h = 0; h < 16; h++) e[h] = in[h * 16 + tid];
             if (d) __syncthreads();                                                // the previous digit's exchange is done with the LDS
-            hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, q);
+            hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, Q);
             __syncthreads();
             hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
-            for (int k = 0; k < 16; k++) e[k] = hc_fwd_canon<HC_FM_ALT>(e[k], q, R.mu);
+            for (int k = 0; k < 16; k++) e[k] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu);
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) {

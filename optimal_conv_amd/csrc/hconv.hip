@@ -67,7 +67,7 @@ struct HcModHost {
     HcTwTab inv_f64;             // moduli below 2^49: the inverse tables as {w, w/q} doubles (fp64 inverse transform of loop A)
     std::vector<void *> allocs;
 };
-struct HcEvk { u64 *q_rows; HcTw *p_rows; bool row_local; };   // [2][N] each: q_rows Montgomery form; p_rows Shoup pairs, lo-local order
+struct HcEvk { HcTw *q_rows; HcTw *p_rows; bool row_local; };   // [2][N] each, Shoup pairs: q_rows (key / P mod Q0) natural order; p_rows (key / N mod P) lo-local order
 struct HcSwk { u64 *rows = nullptr; int level = 0, beta = 0; };   // general switching key: [beta][2][level+1+np][N], stored form
 struct HcProfRec { std::string name; hipEvent_t a, b; };
 // An internal lane = its own HIP stream + workspaces: one convolution is split by output channel i mod G into G
@@ -85,24 +85,17 @@ struct hc_ctx {
     std::vector<HcModHost> mods;
     std::map<u64, HcEvk> evk;
     std::map<u64, HcSwk> swk;
-    u64 *idx_pairs = nullptr;    // [logN][N] idx plaintexts, Montgomery form
+    HcTw *idx_pairs = nullptr;   // [logN][N] idx plaintexts as Shoup pairs
     // workspace
     u64 *ws_cts = nullptr; size_t ws_cts_rows = 0;     // loop A output / tree ping
     u64 *ws_cts2 = nullptr; size_t ws_cts2_rows = 0;   // tree pong
-    u64 *ws_ctc = nullptr;
+    HcTw *ws_ctc = nullptr; size_t ws_ctc_cts = 0;     // [batch][2 polys][2 limbs][N] ct_in times the MultByConst constants, Shoup pairs
     u64 *ws_tmp = nullptr; size_t ws_tmp_rows = 0;
     HcMod *d_mods = nullptr; HcTw *d_csts = nullptr;      // device copies: all moduli (Q then P); per-call constants of the leveled ops
-    // hipGraph replay of a whole conv_then_pack (option "graph"): the launch list of a conv is static for fixed buffers and
-    // constants, so the second call with the same arguments is captured once and later calls are one graph launch
-    long use_graph = 0;
     struct CacheBlk { size_t n = 0; hipEvent_t ev = nullptr; bool pending = false; };
     std::map<char *, CacheBlk> cache_blk; std::map<size_t, std::vector<void *>> cache_free;      // HCONV_ASYNC_ALLOC=1: sizes of the blocks this context allocated; parked blocks by size
     int async_alloc = 0;                                    // HCONV_ASYNC_ALLOC=1: non-blocking stream + cached allocations (see hcx_malloc)
     long ks_fused = 0;                                      // plain key switch with the digits' second transform pass inside the inner product (hc_k_rows_fwd_mac): measured 3 % slower per ResNet image (202 VGPRs, a serial loop over the digits), so off
-    struct GraphKey { const void *ct_in, *ker, *bias; void *ct_out; int max_ob, norm; u64 c0, c1; long chunk;
-        bool operator<(const GraphKey &o) const { return memcmp(this, &o, sizeof *this) < 0; } };
-    struct GraphVal { int seen = 0; void *exec = nullptr; };
-    std::map<GraphKey, GraphVal> graphs;
     HcRowMod *d_rowmods = nullptr;                          // per modulus: both twiddle tables + q, mu (multi-modulus batched transforms)
     u64 *ws_mm = nullptr; size_t ws_mm_rows = 0;            // scratch of the batched key switch / rescale
     struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr; };
@@ -178,7 +171,7 @@ static hipError_t hcx_h2d(hc_ctx *c, void *dst, const void *src, size_t n) {    
     hipError_t e = hcx_h2d_async(c, dst, src, n);
     return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
 }
-static inline bool hc_fm_free(u64 q) { return q < (1ull << 58); }
+static inline bool hc_fm_free(u64 q) { return q < (1ull << 57); }     // 74q < 2^64 (hc_ct_round)
 static inline bool hc_f64_ok(u64 q) { return q < (1ull << 49); }    // fp64 inverse transform (hc_arith.h): 4q < 2^51
 
 template <class K, class... Args>
@@ -266,6 +259,7 @@ extern "C" const char *hc_last_error(const hc_ctx *c) { return c ? c->err.c_str(
 
 extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, const uint64_t *p, int np, int device) {
     if (!out || !q || nq < 1 || np < 0 || (np > 0 && !p)) return hc_fail(nullptr, HC_ERR_ARG, "hc_ctx_create: bad arguments");
+    if (np > 8) return hc_fail(nullptr, HC_ERR_UNSUPPORTED, "hc_ctx_create: np=%d special primes; the key switch's basis-extension tables hold at most 8 (the reference's parameter sets use 1, 2 or 5)", np);
     if (logN != HC_LOGN) return hc_fail(nullptr, HC_ERR_UNSUPPORTED, "hc_ctx_create: logN=%d (this build is specialised for logN=16, the only ring degree the reference CLI uses: main.go:578-579)", logN);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0)
@@ -308,36 +302,37 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
     return HC_OK;
 }
 
+// Releases everything the context owns. void by ABI; a failing HIP call does not stop the teardown, but the first one is kept where
+// hc_last_error(NULL) finds it (and reported on stderr): a leak or a sticky device error must not pass silently.
 extern "C" void hc_ctx_destroy(hc_ctx *c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    for (auto &r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-    for (auto &kv : c->cache_free) for (void *d : kv.second) hipFree(d);      // blocks parked by the caching allocator
-    for (auto &kv : c->cache_blk) if (kv.second.ev) hipEventDestroy(kv.second.ev);
-    for (auto &mh : c->mods) for (void *d : mh.allocs) hipFree(d);
-    for (auto &kv : c->evk) { hipFree(kv.second.q_rows); hipFree(kv.second.p_rows); }
-    for (auto &kv : c->swk) hipFree(kv.second.rows);
-    if (c->idx_pairs) hipFree(c->idx_pairs);
-    if (c->ws_cts) hipFree(c->ws_cts);
-    if (c->ws_cts2) hipFree(c->ws_cts2);
-    if (c->ws_gather) hipFree(c->ws_gather);
-    if (c->ev_fork) hipEventDestroy(c->ev_fork);
-    for (auto &L : c->lane) { if (L.tmp) hipFree(L.tmp); if (L.cts) hipFree(L.cts); if (L.cts2) hipFree(L.cts2); if (L.done) hipEventDestroy(L.done); if (L.stream) { hipStreamSynchronize(L.stream); hipStreamDestroy(L.stream); } }
-    if (c->ws_ctc) hipFree(c->ws_ctc);
-    if (c->ws_tmp) hipFree(c->ws_tmp);
-    if (c->d_mods) hipFree(c->d_mods);
-    if (c->d_rowmods) hipFree(c->d_rowmods);
-#ifndef HC_EMU
-    for (auto &kv : c->graphs) if (kv.second.exec) hipGraphExecDestroy((hipGraphExec_t)kv.second.exec);
-#endif
-    if (c->ws_mm) hipFree(c->ws_mm);
-    for (auto &kv : c->ks_plan) { hipFree(kv.second.bx); hipFree(kv.second.bxdown); hipFree(kv.second.pinv); }
-    for (auto &kv : c->rescale_plan) hipFree(kv.second);
-    if (c->d_csts) hipFree(c->d_csts);
-    if (c->t0) hipEventDestroy(c->t0);
-    if (c->t1) hipEventDestroy(c->t1);
-    if (c->stream) hipStreamDestroy(c->stream);
+    hipError_t first = hipSuccess; const char *what = nullptr;
+    auto D = [&](hipError_t e, const char *w) { if (e != hipSuccess && first == hipSuccess) { first = e; what = w; } };
+    auto F = [&](void *d) { if (d) D(hipFree(d), "hipFree"); };
+    D(hipSetDevice(c->device), "hipSetDevice");
+    if (c->stream) D(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    for (auto &r : c->prof) { D(hipEventDestroy(r.a), "hipEventDestroy"); D(hipEventDestroy(r.b), "hipEventDestroy"); }
+    for (auto &kv : c->cache_free) for (void *d : kv.second) F(d);      // blocks parked by the caching allocator
+    for (auto &kv : c->cache_blk) if (kv.second.ev) D(hipEventDestroy(kv.second.ev), "hipEventDestroy");
+    for (auto &mh : c->mods) for (void *d : mh.allocs) F(d);
+    for (auto &kv : c->evk) { F(kv.second.q_rows); F(kv.second.p_rows); }
+    for (auto &kv : c->swk) F(kv.second.rows);
+    F(c->idx_pairs); F(c->ws_cts); F(c->ws_cts2); F(c->ws_gather);
+    if (c->ev_fork) D(hipEventDestroy(c->ev_fork), "hipEventDestroy");
+    for (auto &L : c->lane) {
+        if (L.stream) D(hipStreamSynchronize(L.stream), "hipStreamSynchronize");
+        F(L.tmp); F(L.cts); F(L.cts2);
+        if (L.done) D(hipEventDestroy(L.done), "hipEventDestroy");
+        if (L.stream) D(hipStreamDestroy(L.stream), "hipStreamDestroy");
+    }
+    F(c->ws_ctc); F(c->ws_tmp); F(c->d_mods); F(c->d_rowmods); F(c->ws_mm);
+    for (auto &kv : c->ks_plan) { F(kv.second.bx); F(kv.second.bxdown); F(kv.second.pinv); }
+    for (auto &kv : c->rescale_plan) F(kv.second);
+    F(c->d_csts);
+    if (c->t0) D(hipEventDestroy(c->t0), "hipEventDestroy");
+    if (c->t1) D(hipEventDestroy(c->t1), "hipEventDestroy");
+    if (c->stream) D(hipStreamDestroy(c->stream), "hipStreamDestroy");
+    if (first != hipSuccess) { hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_destroy: %s: %s", what, hipGetErrorString(first)); fprintf(stderr, "libhconv: %s\n", g_create_err.c_str()); }
     delete c;
 }
 
@@ -549,52 +544,67 @@ extern "C" uint64_t hc_const_for(double constant, double q_level_f, uint64_t q, 
 }
 
 // ------------------------------------------------------------------ loop A plumbing
-static int hc_fill_loopA(hc_ctx *c, HcLoopA *A, const u64 *ker, u64 *cts, int norm) {
+// grid of the fused conv kernels: `jobs` x 16 tiles (x batch); which of the two is blockIdx.x follows HC_JOB_FAST (hc_kernels.h)
+static dim3 hc_grid(int jobs, int z = 1) { return HC_JOB_FAST ? dim3((unsigned)jobs, 16, (unsigned)z) : dim3(16, (unsigned)jobs, (unsigned)z); }
+static HcPtrs hc_ptrs1(const u64 *p) { HcPtrs P; memset(&P, 0, sizeof P); P.p[0] = p; return P; }
+static int hc_fill_loopA(hc_ctx *c, HcLoopA *A, const HcPtrs &kers, u64 *cts, size_t cts_stride, int norm) {
     const HcModHost &m0 = c->mods[0], &m1 = c->mods[1];
-    A->ctc = c->ws_ctc; A->ker = ker; A->tmp = c->ws_tmp; A->cts = cts; A->i0 = 0; A->norm = norm; A->slot0 = 0; A->slot_step = norm;
+    A->ctc = c->ws_ctc; A->ker = kers; A->tmp = c->ws_tmp; A->cts = cts; A->i0 = 0; A->norm = norm; A->slot0 = 0; A->slot_step = norm;
+    A->cts_stride = cts_stride;
     A->m0 = m0.m; A->m1 = m1.m;
     A->q1inv = h_pair(h_inv(m1.m.q % m0.m.q, m0.m.q), m0.m.q);
     A->h = (m1.m.q - 1) >> 1; A->negh0 = m0.m.q - (A->h % m0.m.q);
     return HC_OK;
 }
 
-// ct_in (2x2 rows) times per-limb constants -> ws_ctc
-static int hc_prepare_ctc(hc_ctx *c, const u64 *ct_in, const u64 cst[2]) {
-    if (!c->ws_ctc) HC_HIP(c, hcx_malloc(c, (void **)&c->ws_ctc, 4 * HC_N * sizeof(u64)));
-    for (int p = 0; p < 2; p++) for (int l = 0; l < 2; l++) {
-        const HcMod &m = c->mods[(size_t)l].m;
-        size_t off = ((size_t)p * 2 + (size_t)l) * HC_N;
-        HC_TRY(hc_launch(c, "ctc", hc_k_pointwise<HC_PW_MULC>, hc_pw_grid(HC_N), ct_in + off, ct_in + off, c->ws_ctc + off, (size_t)HC_N, m, h_pair(cst[l] % m.q, m.q)));
-    }
+// ct_in (2x2 rows) of n ciphertexts times per-limb constants -> ws_ctc as Shoup pairs: c' is the fixed operand of the 2B products
+// of loop A, so its companion floor(c' * 2^64 / q) is computed once per conv (4 rows per ciphertext)
+static int hc_ensure_ctc(hc_ctx *c, size_t nct) {
+    if (c->ws_ctc_cts >= nct) return HC_OK;
+    HC_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->ws_ctc) HC_HIP(c, hcx_free(c, c->ws_ctc));
+    c->ws_ctc = nullptr; c->ws_ctc_cts = 0;
+    HC_HIP(c, hcx_malloc(c, (void **)&c->ws_ctc, nct * 4 * HC_N * sizeof(HcTw)));
+    c->ws_ctc_cts = nct;
     return HC_OK;
 }
+static int hc_prepare_ctc(hc_ctx *c, const HcPtrs &ct_in, int n, const u64 cst[2]) {
+    HC_TRY(hc_ensure_ctc(c, (size_t)n));
+    HcCtc K; K.m0 = c->mods[0].m; K.m1 = c->mods[1].m;
+    K.c0 = h_pair(cst[0] % K.m0.q, K.m0.q); K.c1 = h_pair(cst[1] % K.m1.q, K.m1.q);
+    return hc_launch(c, "ctc", hc_k_ctc_pairs, dim3(64, 4, (unsigned)n), ct_in, c->ws_ctc, K);
+}
 
-// loop A over the channels i = i_first + j*i_stride, j < nch; result j goes to cts slot i (compact = false) or j
-static int hc_loopA_run_set(hc_ctx *c, const u64 *ker_mont, int i_first, int i_stride, int nch, u64 *cts, bool compact) {
-    const long chunk = c->chunk_nodes < 1 ? 1 : c->chunk_nodes;
-    HC_TRY(hc_ensure_tmp(c, (size_t)(chunk < nch ? chunk : nch) * 3));
-    HcLoopA A; HC_TRY(hc_fill_loopA(c, &A, ker_mont, cts, i_stride));
+// loop A over the channels i = i_first + j*i_stride, j < nch, of each of the n ciphertexts of a batch (blockIdx.z); result j goes to
+// cts slot i (compact = false) or j of that ciphertext's array (arrays cts_stride words apart)
+static int hc_loopA_run_set(hc_ctx *c, const HcPtrs &kers, int n, int i_first, int i_stride, int nch, u64 *cts, size_t cts_stride, bool compact) {
+    if (!hc_fm_free(c->mods[0].m.q) && 0) return HC_ERR_UNSUPPORTED;
+    long chunk = (c->chunk_nodes < 1 ? 1 : c->chunk_nodes) / n; if (chunk < 1) chunk = 1;     // channels per ciphertext per launch
+    if (chunk > nch) chunk = nch;
+    HC_TRY(hc_ensure_tmp(c, (size_t)n * (size_t)chunk * 2));
+    HcLoopA A; HC_TRY(hc_fill_loopA(c, &A, kers, cts, cts_stride, i_stride));
     const HcModHost &m0 = c->mods[0], &m1 = c->mods[1];
     for (int j0 = 0; j0 < nch; j0 += (int)chunk) {
         const int nj = (int)((nch - j0) < chunk ? (nch - j0) : chunk);
         A.i0 = i_first + j0 * i_stride;
         A.slot0 = compact ? j0 : A.i0; A.slot_step = compact ? 1 : i_stride;
-        dim3 grid(16, (unsigned)(2 * nj));
+        A.njobs = 2 * nj;
+        const dim3 grid = hc_grid(2 * nj, n), flat = hc_grid(2 * nj * n);
         if (hc_f64_ok(m1.m.q)) {
             HC_TRY(hc_launch(c, "a1_mul_rowsinv", hc_k_a1<1>, grid, A, m1.inv_f64));
-            HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2<HC_FM_FREE, 1>, grid, A, m1.inv_f64, m0.fwd)
-                                      : hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2<HC_FM_ALT, 1>, grid, A, m1.inv_f64, m0.fwd));
+            HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2<HC_FM_FREE, 1>, flat, A, m1.inv_f64, m0.fwd)
+                                      : hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2<HC_FM_ALT, 1>, flat, A, m1.inv_f64, m0.fwd));
         } else {
             HC_TRY(hc_launch(c, "a1_mul_rowsinv", hc_k_a1<0>, grid, A, m1.inv));
-            HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2<HC_FM_FREE, 0>, grid, A, m1.inv, m0.fwd)
-                                      : hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2<HC_FM_ALT, 0>, grid, A, m1.inv, m0.fwd));
+            HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2<HC_FM_FREE, 0>, flat, A, m1.inv, m0.fwd)
+                                      : hc_launch(c, "a2_colsinv_lift_colsfwd", hc_k_a2<HC_FM_ALT, 0>, flat, A, m1.inv, m0.fwd));
         }
         HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "a3_rowsfwd_rescale", hc_k_a3, grid, A, m0.fwd));
     }
     return HC_OK;
 }
-static int hc_loopA_run(hc_ctx *c, const u64 *ker_mont, int max_ob, int norm, u64 *cts) {
-    return hc_loopA_run_set(c, ker_mont, 0, norm, max_ob / norm, cts, false);   // channels i % norm == 0 (conv.go:526)
+static int hc_loopA_run(hc_ctx *c, const u64 *ker, int max_ob, int norm, u64 *cts) {
+    return hc_loopA_run_set(c, hc_ptrs1(ker), 1, 0, norm, max_ob / norm, cts, 0, false);   // channels i % norm == 0 (conv.go:526)
 }
 
 // hc_div_round_last (level 1 only on this path): reuse loop A with ker = Montgomery one (c' (*) R = c')
@@ -624,18 +634,20 @@ static int hc_div_round_last_n(hc_ctx *c, int level, const u64 *x, size_t xs, u6
         return hc_launch(c, "rescale_finish_mm", hc_k_rescale_finish_mm, dim3(64, (unsigned)level, (unsigned)np), x, xs, (const u64 *)v, (size_t)level * HC_N, out, os, (const HcMod *)c->d_mods, (const HcTw *)it->second);
     }
     if (np != 1) { HC_TRY(hc_div_round_last_n(c, level, x, 0, out, 0, 1)); return hc_div_round_last_n(c, level, x + xs, 0, out + os, 0, 1); }
-    // Build a "ciphertext" whose polynomial 0 is x and a kernel equal to R mod q (Montgomery form of 1).
+    // Build a "ciphertext" whose polynomial 0 is x (constants 1) and a kernel plaintext equal to 1 everywhere.
     HC_TRY(hc_ensure_tmp(c, 16));
-    if (!c->ws_ctc) HC_HIP(c, hcx_malloc(c, (void **)&c->ws_ctc, 4 * HC_N * sizeof(u64)));
-    u64 *scratch = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&scratch, (size_t)(2 + 4) * HC_N * sizeof(u64)));
-    u64 *one = scratch, *cts = scratch + 2 * HC_N;
-    std::vector<u64> h((size_t)2 * HC_N);
-    for (int l = 0; l < 2; l++) { u64 q = c->mods[(size_t)l].m.q; u64 r = (u64)((((u128)1) << 64) % q); for (int j = 0; j < HC_N; j++) h[(size_t)l * HC_N + (size_t)j] = r; }
-    HC_HIP(c, hcx_h2d_async(c, one, h.data(), h.size() * sizeof(u64)));
-    HC_HIP(c, hipMemcpyAsync(c->ws_ctc, x, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-    HC_HIP(c, hipMemcpyAsync(c->ws_ctc + 2 * HC_N, x, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-    int rc = hc_loopA_run(c, one, 1, 1, cts);
-    if (!rc) { hipMemcpyAsync(out, cts, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); hipStreamSynchronize(c->stream); }
+    u64 *scratch = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&scratch, (size_t)(2 + 4 + 4) * HC_N * sizeof(u64)));
+    u64 *one = scratch, *cts = scratch + 2 * HC_N, *xx = scratch + 6 * HC_N;
+    std::vector<u64> h((size_t)2 * HC_N, 1);
+    int rc = HC_OK;
+    if (hcx_h2d_async(c, one, h.data(), h.size() * sizeof(u64)) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess
+        || hipMemcpyAsync(xx, x, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) != hipSuccess
+        || hipMemcpyAsync(xx + 2 * HC_N, x, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "hc_div_round_last: staging copies failed");
+    const u64 ones[2] = {1, 1};
+    if (!rc) rc = hc_prepare_ctc(c, hc_ptrs1(xx), 1, ones);
+    if (!rc) rc = hc_loopA_run(c, one, 1, 1, cts);
+    if (!rc && hipMemcpyAsync(out, cts, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "hc_div_round_last: result copy failed");
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = hc_fail(c, HC_ERR_HIP, "hc_div_round_last: stream synchronize failed");
     hcx_free(c, scratch);
     return rc;
 }
@@ -667,22 +679,27 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
     // the P rows are only re-ordered into the lo-local coalesced order hc_k_b3 reads.
     u64 *stage = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&stage, 2 * HC_N * sizeof(u64)));
     HcEvk e; e.q_rows = nullptr; e.p_rows = nullptr; e.row_local = hc_perm_row_local(galEl);
-    HC_HIP(c, hcx_malloc(c, (void **)&e.q_rows, 2 * HC_N * sizeof(u64)));
+    u64 *stageq = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&stageq, 2 * HC_N * sizeof(u64)));
+    HC_HIP(c, hcx_malloc(c, (void **)&e.q_rows, 2 * HC_N * sizeof(HcTw)));
     HC_HIP(c, hcx_malloc(c, (void **)&e.p_rows, 2 * HC_N * sizeof(HcTw)));
-    HC_HIP(c, hcx_h2d_async(c, e.q_rows, b_q, HC_N * sizeof(u64)));
-    HC_HIP(c, hcx_h2d_async(c, e.q_rows + HC_N, a_q, HC_N * sizeof(u64)));
+    HC_HIP(c, hcx_h2d_async(c, stageq, b_q, HC_N * sizeof(u64)));
+    HC_HIP(c, hcx_h2d_async(c, stageq + HC_N, a_q, HC_N * sizeof(u64)));
     HC_HIP(c, hcx_h2d_async(c, stage, b_p, HC_N * sizeof(u64)));
     HC_HIP(c, hcx_h2d_async(c, stage + HC_N, a_p, HC_N * sizeof(u64)));
-    // Q rows times P^-1 mod Q0 once, here: ModDown's final division is then already inside b5's product with the key (hc_k_b4/b5)
+    // Q rows: stored Montgomery form -> plain residues, times P^-1 mod Q0 once, here (ModDown's final division is then already inside
+    // b5's product with the key, hc_k_b4/b5), then (w, floor(w*2^64/Q0)) pairs in natural order
     const HcTw pinv = h_pair(h_inv(mp.m.q % m0.m.q, m0.m.q), m0.m.q);
-    int rc = hc_launch(c, "evk_div_p", hc_k_pointwise<HC_PW_MULC>, hc_pw_grid(2 * HC_N), (const u64 *)e.q_rows, (const u64 *)e.q_rows, e.q_rows, (size_t)2 * HC_N, m0.m, pinv);
-    HcTw z; z.w = z.ws = 0;     // P rows: stored Montgomery form -> plain residues -> (w, floor(w*2^64/P)) pairs in lo-local order
+    HcTw z; z.w = z.ws = 0;
+    int rc = hc_launch(c, "evk_from_mont", hc_k_pointwise<HC_PW_FROM_MONT>, hc_pw_grid(2 * HC_N), (const u64 *)stageq, (const u64 *)stageq, stageq, (size_t)2 * HC_N, m0.m, z);
+    if (!rc) rc = hc_launch(c, "evk_div_p", hc_k_pointwise<HC_PW_MULC>, hc_pw_grid(2 * HC_N), (const u64 *)stageq, (const u64 *)stageq, stageq, (size_t)2 * HC_N, m0.m, pinv);
+    if (!rc) rc = hc_launch(c, "make_pairs", hc_k_make_pairs, hc_pw_grid(2 * HC_N), (const u64 *)stageq, e.q_rows, (size_t)2 * HC_N, m0.m.q, 0);
+    // P rows: stored Montgomery form -> plain residues -> (w, floor(w*2^64/P)) pairs in lo-local order
     if (!rc) rc = hc_launch(c, "evk_from_mont", hc_k_pointwise<HC_PW_FROM_MONT>, hc_pw_grid(2 * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)2 * HC_N, mp.m, z);
     // ... times N^-1 mod P: the inverse transform of the P accumulators (hc_k_b4) then runs without its scaling products
     if (!rc) rc = hc_launch(c, "evk_ninv", hc_k_pointwise<HC_PW_MULC>, hc_pw_grid(2 * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)2 * HC_N, mp.m, h_pair(mp.m.ninv, mp.m.q));
     if (!rc) rc = hc_launch(c, "make_pairs", hc_k_make_pairs, hc_pw_grid(2 * HC_N), (const u64 *)stage, e.p_rows, (size_t)2 * HC_N, mp.m.q, 1);
-    hipStreamSynchronize(c->stream);
-    hcx_free(c, stage);
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = hc_fail(c, HC_ERR_HIP, "hc_evk_load: stream synchronize failed");
+    hcx_free(c, stage); hcx_free(c, stageq);
     if (rc) { hcx_free(c, e.q_rows); hcx_free(c, e.p_rows); return rc; }
     auto it = c->evk.find(galEl);
     if (it != c->evk.end()) { hcx_free(c, it->second.q_rows); hcx_free(c, it->second.p_rows); }
@@ -707,20 +724,25 @@ extern "C" int hc_idx_load(hc_ctx *c, const uint64_t *idx_host) {
         if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "rows_fwd_canon", hc_k_rows_fwd_canon, dim3(16, HC_LOGN), (const u64 *)tmp, stage, m0.fwd, m0.m.q, m0.m.mu);
         hipStreamSynchronize(c->stream); hcx_free(c, tmp);
     }
-    HcTw z; z.w = z.ws = 0;
-    if (!rc) rc = hc_launch(c, "idx_to_mont", hc_k_pointwise<HC_PW_TO_MONT>, hc_pw_grid((size_t)HC_LOGN * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)HC_LOGN * HC_N, m0.m, z);
-    hipStreamSynchronize(c->stream);
-    if (rc) { hcx_free(c, stage); return rc; }
+    HcTw *pairs = nullptr;
+    if (!rc && hcx_malloc(c, (void **)&pairs, (size_t)HC_LOGN * HC_N * sizeof(HcTw)) != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "hc_idx_load: allocation failed");
+    if (!rc) rc = hc_launch(c, "idx_pairs", hc_k_make_pairs, hc_pw_grid((size_t)HC_LOGN * HC_N), (const u64 *)stage, pairs, (size_t)HC_LOGN * HC_N, m0.m.q, 0);
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = hc_fail(c, HC_ERR_HIP, "hc_idx_load: stream synchronize failed");
+    hcx_free(c, stage);
+    if (rc) { hcx_free(c, pairs); return rc; }
     if (c->idx_pairs) hcx_free(c, c->idx_pairs);
-    c->idx_pairs = stage;
+    c->idx_pairs = pairs;
     return HC_OK;
 }
 
 static int hc_ker_from_device(hc_ctx *c, u64 *d, int max_ob, bool take, hc_ker **out) {
-    // to Montgomery form in one launch; rows alternate Q0, Q1 ([i][limb][N] both in and out)
+    // kernel plaintexts are used as they are (plain NTT residues, [i][limb][N]): loop A multiplies them by the Shoup pairs of c'
     u64 *dst = d;
-    if (!take) { HC_HIP(c, hcx_malloc(c, (void **)&dst, (size_t)max_ob * 2 * HC_N * sizeof(u64))); }
-    int rc = hc_launch(c, "ker_to_mont", hc_k_ker_to_mont, hc_pw_grid((size_t)max_ob * 2 * HC_N), (const u64 *)d, dst, max_ob, c->mods[0].m, c->mods[1].m);
+    int rc = HC_OK;
+    if (!take) {
+        HC_HIP(c, hcx_malloc(c, (void **)&dst, (size_t)max_ob * 2 * HC_N * sizeof(u64)));
+        if (hipMemcpyAsync(dst, d, (size_t)max_ob * 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "hc_ker_load: device copy failed");
+    }
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "hc_ker_load: stream synchronize failed");
     if (rc) { hcx_free(c, dst); return rc; }      // `take` means the buffer was ours to free as well
     hc_ker *k = new hc_ker(); k->d = dst; k->max_ob = max_ob; *out = k;
@@ -763,7 +785,7 @@ extern "C" int hc_prep_ker(hc_ctx *c, const double *ker_in, int ker_len, const d
     int rc = hc_launch(c, "prep_ker_scatter", hc_k_prep_ker, hc_pw_grid((size_t)ker_len), P);
     HC_HIP(c, hipStreamSynchronize(c->stream));      // host buffers may go away after return; hc_ntt below may regrow ws_tmp
     for (int l = 0; l < 2 && !rc; l++) rc = hc_ntt(c, l, stage + (size_t)l * max_bat * HC_N, stage + (size_t)l * max_bat * HC_N, max_bat);
-    if (!rc) rc = hc_launch(c, "ker_interleave", hc_k_ker_interleave, hc_pw_grid((size_t)max_bat * 2 * HC_N), (const u64 *)stage, dst, max_bat, c->mods[0].m, c->mods[1].m, 1);
+    if (!rc) rc = hc_launch(c, "ker_interleave", hc_k_ker_interleave, hc_pw_grid((size_t)max_bat * 2 * HC_N), (const u64 *)stage, dst, max_bat, c->mods[0].m, c->mods[1].m, 0);
     hipStreamSynchronize(c->stream);
     hcx_free(c, dk); hcx_free(c, da); hcx_free(c, stage); (void)tmp;
     if (rc) { hcx_free(c, dst); return rc; }
@@ -773,12 +795,10 @@ extern "C" int hc_prep_ker(hc_ctx *c, const double *ker_in, int ker_len, const d
 // plain (non-Montgomery) NTT rows of a kernel handle, [max_ob][2][N] to the HOST: what prep_Ker's pl_ker[i].Value.Coeffs hold
 extern "C" int hc_ker_download(hc_ctx *c, const hc_ker *k, uint64_t *host_out) {
     HC_ENTER(c); if (!k || !host_out) return hc_fail(c, HC_ERR_ARG, "hc_ker_download: null");
-    u64 *tmp = nullptr; const size_t n = (size_t)k->max_ob * 2 * HC_N;
-    HC_HIP(c, hcx_malloc(c, (void **)&tmp, n * sizeof(u64)));
-    int rc = hc_launch(c, "ker_from_mont", hc_k_ker_from_mont, hc_pw_grid(n), (const u64 *)k->d, tmp, k->max_ob, c->mods[0].m, c->mods[1].m);
-    if (!rc) { HC_HIP(c, hipMemcpyAsync(host_out, tmp, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream)); }
-    hipStreamSynchronize(c->stream); hcx_free(c, tmp);
-    return rc;
+    const size_t n = (size_t)k->max_ob * 2 * HC_N;
+    HC_HIP(c, hipMemcpyAsync(host_out, k->d, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HC_HIP(c, hipStreamSynchronize(c->stream));
+    return HC_OK;
 }
 extern "C" void hc_ker_free(hc_ctx *c, hc_ker *k) { if (!k) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } hcx_free(c, k->d); delete k; }
 
@@ -789,7 +809,7 @@ static int hc_fill_loopB(hc_ctx *c, HcLoopB *B, const u64 *src, u64 *dst, const 
     B->tmpC = c->ws_tmp; B->tmpE = c->ws_tmp + (size_t)chunk * HC_N; B->tmpT = c->ws_tmp + (size_t)chunk * 3 * HC_N;
     B->idx = c->idx_pairs + (size_t)logStep * HC_N;
     B->evkQ = e.q_rows; B->evkP = e.p_rows;
-    B->n0 = 0; B->step = step; B->norm = norm;
+    B->n0 = 0; B->step = step; B->norm = norm; B->nodes = 1; B->src_stride = 0; B->dst_stride = 0;
     B->m0 = m0.m; B->mp = mp.m;
     B->pmodq = h_pair(mp.m.q % m0.m.q, m0.m.q);
     B->pinv = h_pair(h_inv(mp.m.q % m0.m.q, m0.m.q), m0.m.q);
@@ -803,30 +823,34 @@ static int hc_fill_loopB(hc_ctx *c, HcLoopB *B, const u64 *src, u64 *dst, const 
     B->gal = (u32)(galEl & 0x1FFFF);
     return HC_OK;
 }
-// one tree level: nodes i = 0, norm, 2*norm, ... < step
-static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, int step, int logStep, int norm, u64 galEl, const u64 *bias_last) {
+// one tree level of each of the n ciphertexts of a batch: nodes i = 0, norm, 2*norm, ... < step; arrays sstride / dstride words apart
+static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, size_t sstride, size_t dstride, int n, int step, int logStep, int norm, u64 galEl, const HcPtrs *bias_last) {
     auto it = c->evk.find(galEl);
     if (it == c->evk.end()) return hc_fail(c, HC_ERR_STATE, "pack: no switching key loaded for galEl=%llu (the reference panics in permuteNTT)", (unsigned long long)galEl);
     if (!it->second.row_local) return hc_fail(c, HC_ERR_UNSUPPORTED, "pack: galEl=%llu does not permute inside 4096-coefficient tiles (needs max_cnum <= 4096)", (unsigned long long)galEl);
     if (!c->idx_pairs) HC_TRY(hc_idx_load(c, nullptr));
     const int nodes = (step + norm - 1) / norm;
-    const int chunk = (int)(c->chunk_nodes < nodes ? (c->chunk_nodes < 1 ? 1 : c->chunk_nodes) : nodes);
-    HC_TRY(hc_ensure_tmp(c, (size_t)chunk * 4));
-    HcLoopB B; HC_TRY(hc_fill_loopB(c, &B, src, dst, it->second, logStep, step, norm, galEl, chunk));
+    long chunkl = (c->chunk_nodes < 1 ? 1 : c->chunk_nodes) / n; if (chunkl < 1) chunkl = 1;          // nodes per ciphertext per launch
+    const int chunk = (int)(chunkl < nodes ? chunkl : nodes);
+    HC_TRY(hc_ensure_tmp(c, (size_t)n * chunk * 4));
+    HcLoopB B; HC_TRY(hc_fill_loopB(c, &B, src, dst, it->second, logStep, step, norm, galEl, n * chunk));
+    B.src_stride = sstride; B.dst_stride = dstride;
+    HcPtrs nobias; memset(&nobias, 0, sizeof nobias);
     const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
     for (int n0 = 0; n0 < nodes; n0 += chunk) {
         const int nn = (nodes - n0) < chunk ? (nodes - n0) : chunk;
-        B.n0 = n0;
-        HC_TRY(hc_launch(c, "b1_node_rowsinv", hc_k_b1, dim3(16, (unsigned)nn), B, m0.inv));
-        HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b2_colsinv_colsfwdP", hc_k_b2, dim3(16, (unsigned)nn), B, m0.inv, mp.fwd));
-        HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, dim3(16, (unsigned)nn), B, mp.fwd, mp.inv));
-        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, dim3(16, (unsigned)(2 * nn)), B, mp.inv, m0.fwd));
-        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, (unsigned)(2 * nn)), B, m0.fwd, bias_last));
+        B.n0 = n0; B.nodes = nn;
+        const dim3 g1 = hc_grid(n * nn), g2 = hc_grid(2 * n * nn);
+        HC_TRY(hc_launch(c, "b1_node_rowsinv", hc_k_b1, g1, B, m0.inv));
+        HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b2_colsinv_colsfwdP", hc_k_b2, g1, B, m0.inv, mp.fwd));
+        HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, g1, B, mp.fwd, mp.inv));
+        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, g2, B, mp.inv, m0.fwd));
+        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, g2, B, m0.fwd, bias_last ? *bias_last : nobias));
     }
     return HC_OK;
 }
-// conv.go:266-300 on device-resident level-0 ciphertexts, in place (result in slot 0)
-static int hc_pack_run(hc_ctx *c, u64 *cts, int max_cnum, int real_cnum, const u64 *bias, int stride_log2 = 0) {
+// conv.go:266-300 on device-resident level-0 ciphertexts, in place (result in slot 0), for each of the n ciphertext arrays of a batch
+static int hc_pack_run(hc_ctx *c, u64 *cts, size_t cstride, int n, int max_cnum, int real_cnum, const HcPtrs *bias, int stride_log2 = 0) {
     if (max_cnum < 1 || real_cnum < 1 || max_cnum % real_cnum || (max_cnum & (max_cnum - 1)) || (real_cnum & (real_cnum - 1)))
         return hc_fail(c, HC_ERR_ARG, "pack: max_cnum=%d real_cnum=%d must be powers of two", max_cnum, real_cnum);
     const int norm = max_cnum / real_cnum;
@@ -836,7 +860,7 @@ static int hc_pack_run(hc_ctx *c, u64 *cts, int max_cnum, int real_cnum, const u
     int j = HC_LOGN - logStep - stride_log2;      // slot m stands for global ciphertext index m << stride_log2
     // Tree levels ping-pong between the caller's array and an internal one: a level reads slots i and i+step of
     // `src` and writes slot i of `dst` (i < step), so no kernel ever reads a row another workgroup is writing.
-    const size_t pong_rows = (size_t)(max_cnum / 2 > 0 ? max_cnum / 2 : 1) * 2;
+    const size_t pong_one = (size_t)(max_cnum / 2 > 0 ? max_cnum / 2 : 1) * 2, pong_rows = pong_one * (size_t)n;
     if (c->ws_cts2_rows < pong_rows) {
         HC_HIP(c, hipStreamSynchronize(c->stream));
         if (c->ws_cts2) HC_HIP(c, hcx_free(c, c->ws_cts2));
@@ -845,28 +869,33 @@ static int hc_pack_run(hc_ctx *c, u64 *cts, int max_cnum, int real_cnum, const u
         c->ws_cts2_rows = pong_rows;
     }
     u64 *src = cts, *dst = c->ws_cts2;
+    size_t sstride = cstride, dstride = pong_one * HC_N;
     bool bias_done = false;
     while (step >= norm && step >= 1) {
         const bool last = (step / 2 < norm) || step == 1;
-        HC_TRY(hc_pack_level(c, src, dst, step, logStep + stride_log2, norm, (1ull << j) + 1, last ? bias : nullptr));
+        HC_TRY(hc_pack_level(c, src, dst, sstride, dstride, n, step, logStep + stride_log2, norm, (1ull << j) + 1, last ? bias : nullptr));
         if (last) bias_done = true;
         u64 *t = src; src = dst; dst = t;
+        size_t ts = sstride; sstride = dstride; dstride = ts;
         step /= 2; logStep--; j++;
     }
-    if (src != cts) HC_HIP(c, hipMemcpyAsync(cts, src, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));   // result -> slot 0
+    if (src != cts) for (int z = 0; z < n; z++)      // result -> slot 0 of the caller's array
+        HC_HIP(c, hipMemcpyAsync(cts + (size_t)z * cstride, src + (size_t)z * sstride, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
     if (bias && !bias_done) {   // max_cnum == real_cnum == 1: no tree level ran
-        HcTw z; z.w = z.ws = 0;
-        HC_TRY(hc_launch(c, "bias_add", hc_k_pointwise<HC_PW_ADD>, hc_pw_grid(HC_N), (const u64 *)cts, bias, cts, (size_t)HC_N, c->mods[0].m, z));
+        HcTw z0; z0.w = z0.ws = 0;
+        for (int z = 0; z < n; z++) if (bias->p[z])
+            HC_TRY(hc_launch(c, "bias_add", hc_k_pointwise<HC_PW_ADD>, hc_pw_grid(HC_N), (const u64 *)(cts + (size_t)z * cstride), bias->p[z], cts + (size_t)z * cstride, (size_t)HC_N, c->mods[0].m, z0));
     }
     return HC_OK;
 }
 extern "C" int hc_pack_ctxts(hc_ctx *c, uint64_t *cts, int max_cnum, int real_cnum) {
     HC_ENTER(c); if (!cts) return hc_fail(c, HC_ERR_ARG, "hc_pack_ctxts: null");
-    return hc_pack_run(c, (u64 *)cts, max_cnum, real_cnum, nullptr);
+    return hc_pack_run(c, (u64 *)cts, 0, 1, max_cnum, real_cnum, nullptr);
 }
 extern "C" int hc_pack_ctxts_strided(hc_ctx *c, uint64_t *cts, int count, int stride_log2, const uint64_t *bias) {
     HC_ENTER(c); if (!cts) return hc_fail(c, HC_ERR_ARG, "hc_pack_ctxts_strided: null");
-    return hc_pack_run(c, (u64 *)cts, count, count, (const u64 *)bias, stride_log2);
+    const HcPtrs bp = hc_ptrs1((const u64 *)bias);
+    return hc_pack_run(c, (u64 *)cts, 0, 1, count, count, bias ? &bp : nullptr, stride_log2);
 }
 
 // ------------------------------------------------------------------ key switch / rotate at level 0 (L0 API)
@@ -880,10 +909,11 @@ static int hc_ks_common(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uin
     u64 *buf = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&buf, (size_t)6 * HC_N * sizeof(u64)));
     u64 *y = buf, *x = buf + 2 * HC_N, *res = buf + 4 * HC_N;
     int rc = HC_OK;
-    hipMemsetAsync(x, 0, 2 * HC_N * sizeof(u64), c->stream);
-    if (c0) hipMemcpyAsync(y, c0, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); else hipMemsetAsync(y, 0, HC_N * sizeof(u64), c->stream);
-    hipMemcpyAsync(y + HC_N, c1, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream);
-    if (!c->idx_pairs) rc = hc_idx_load(c, nullptr);
+    hipError_t he = hipMemsetAsync(x, 0, 2 * HC_N * sizeof(u64), c->stream);
+    if (he == hipSuccess) he = c0 ? hipMemcpyAsync(y, c0, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) : hipMemsetAsync(y, 0, HC_N * sizeof(u64), c->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(y + HC_N, c1, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream);
+    if (he != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "level-0 key switch: staging copies failed: %s", hipGetErrorString(he));
+    if (!rc && !c->idx_pairs) rc = hc_idx_load(c, nullptr);
     const bool local = it->second.row_local;
     if (!rc) {
         if (rotate && local) {
@@ -892,20 +922,22 @@ static int hc_ks_common(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uin
             rc = hc_ensure_tmp(c, 4);
             HcLoopB B; if (!rc) rc = hc_fill_loopB(c, &B, y, res, it->second, 0, 1, 1, galEl, chunk);
             const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
-            if (!rc) rc = hc_launch(c, "b1_node_rowsinv", hc_k_b1, dim3(16, 1), B, m0.inv);
-            if (!rc) rc = HC_LAUNCH_FM(mp.m.q, c, "b2_colsinv_colsfwdP", hc_k_b2, dim3(16, 1), B, m0.inv, mp.fwd);
-            if (!rc) rc = HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, dim3(16, 1), B, mp.fwd, mp.inv);
-            if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, dim3(16, 2), B, mp.inv, m0.fwd);
-            if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, dim3(16, 2), B, m0.fwd, (const u64 *)nullptr);
+            if (!rc) rc = hc_launch(c, "b1_node_rowsinv", hc_k_b1, hc_grid(1), B, m0.inv);
+            if (!rc) rc = HC_LAUNCH_FM(mp.m.q, c, "b2_colsinv_colsfwdP", hc_k_b2, hc_grid(1), B, m0.inv, mp.fwd);
+            if (!rc) rc = HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, hc_grid(1), B, mp.fwd, mp.inv);
+            if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, hc_grid(2), B, mp.inv, m0.fwd);
+            HcPtrs nobias; memset(&nobias, 0, sizeof nobias);
+            if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, hc_grid(2), B, m0.fwd, nobias);
             HcTw z; z.w = z.ws = 0;      // node result = y + RotateGal(y): subtract y again
             if (!rc) rc = hc_launch(c, "ks_sub", hc_k_pointwise<HC_PW_SUB>, hc_pw_grid(2 * HC_N), (const u64 *)res, (const u64 *)y, res, (size_t)2 * HC_N, c->mods[0].m, z);
-            if (!rc) { hipMemcpyAsync(o0, res, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); hipMemcpyAsync(o1, res + HC_N, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream); }
+            if (!rc && (hipMemcpyAsync(o0, res, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) != hipSuccess
+                        || hipMemcpyAsync(o1, res + HC_N, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)) rc = hc_fail(c, HC_ERR_HIP, "level-0 key switch: result copies failed");
         } else {
             rc = hc_fail(c, HC_ERR_UNSUPPORTED, "level-0 key switch is exposed for Galois elements that permute inside 4096-coefficient tiles (2^j+1, j>=5), the ones pack_ctxts uses");
         }
     }
-    hipStreamSynchronize(c->stream);
-    hcx_free(c, buf);
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = hc_fail(c, HC_ERR_HIP, "level-0 key switch: stream synchronize failed");
+    if (hcx_free(c, buf) != hipSuccess && !rc) rc = hc_fail(c, HC_ERR_HIP, "level-0 key switch: free failed");
     return rc;
 }
 extern "C" int hc_rotate_gal_l0(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uint64_t *c1, uint64_t *o0, uint64_t *o1) {
@@ -1143,8 +1175,8 @@ static int hc_conv_lanes(hc_ctx *c, const hc_ker *ker, int max_ob, int G, const 
         {
             HcLaneScope scope(c, &L);
             rc = hipStreamWaitEvent(c->stream, c->ev_fork, 0) == hipSuccess ? HC_OK : hc_fail(c, HC_ERR_HIP, "hipStreamWaitEvent failed");
-            if (!rc) rc = hc_loopA_run_set(c, ker->d, g, G, nloc, L.cts, true);
-            if (!rc) rc = hc_pack_run(c, L.cts, nloc, nloc, nullptr, log2g);
+            if (!rc) rc = hc_loopA_run_set(c, hc_ptrs1(ker->d), 1, g, G, nloc, L.cts, 0, true);
+            if (!rc) rc = hc_pack_run(c, L.cts, 0, 1, nloc, nloc, nullptr, log2g);
             if (!rc && hipMemcpyAsync(c->ws_gather + (size_t)g * 2 * HC_N, L.cts, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
                 rc = hc_fail(c, HC_ERR_HIP, "lane gather copy failed");
             if (!rc && hipEventRecord(L.done, c->stream) != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "hipEventRecord failed");
@@ -1152,7 +1184,8 @@ static int hc_conv_lanes(hc_ctx *c, const hc_ker *ker, int max_ob, int G, const 
         if (rc) return rc;
     }
     for (int g = 0; g < G; g++) HC_HIP(c, hipStreamWaitEvent(c->stream, c->lane[(size_t)g].done, 0));
-    HC_TRY(hc_pack_run(c, c->ws_gather, G, G, bias, 0));
+    const HcPtrs bp = hc_ptrs1(bias);
+    HC_TRY(hc_pack_run(c, c->ws_gather, 0, 1, G, G, bias ? &bp : nullptr, 0));
     HC_HIP(c, hipMemcpyAsync(ct_out, c->ws_gather, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
     return HC_OK;
 }
@@ -1163,8 +1196,22 @@ extern "C" int hc_conv_mult_phase(hc_ctx *c, const uint64_t *ct_in, double ct_sc
     if (!ct_in || !ker || !cts_out || ker->max_ob < max_ob) return hc_fail(c, HC_ERR_ARG, "hc_conv_mult_phase: bad arguments");
     u64 cst[2]; double target;
     HC_TRY(hc_loopA_consts(c, ct_scale, ker_scale, max_ob, norm, out_scale, cst, &target));
-    HC_TRY(hc_prepare_ctc(c, (const u64 *)ct_in, cst));
+    HC_TRY(hc_prepare_ctc(c, hc_ptrs1((const u64 *)ct_in), 1, cst));
     return hc_loopA_run(c, ker->d, max_ob, norm, (u64 *)cts_out);
+}
+// n convolutions (same shape and scales, independent ciphertexts) as ONE launch set: every kernel of loop A and of the pack tree
+// covers all n ciphertexts (a grid dimension), the switching keys, idx plaintexts and twiddle tables are shared, and the top tree
+// levels (1..16 nodes per ciphertext, latency-bound when launched alone) carry n times the work per launch.
+static int hc_conv_batch_run(hc_ctx *c, int n, const HcPtrs &ct_in, const HcPtrs &kers, const HcPtrs &bias, bool any_bias, u64 *const *ct_out,
+                             int max_ob, int norm, const u64 cst[2]) {
+    HC_TRY(hc_prepare_ctc(c, ct_in, n, cst));
+    HC_TRY(hc_ensure_cts(c, (size_t)n * max_ob * 2));
+    const size_t cstride = (size_t)max_ob * 2 * HC_N;
+    HC_TRY(hc_loopA_run_set(c, kers, n, 0, norm, max_ob / norm, c->ws_cts, cstride, false));
+    HC_TRY(hc_pack_run(c, c->ws_cts, cstride, n, max_ob, max_ob / norm, any_bias ? &bias : nullptr));
+    for (int z = 0; z < n; z++)
+        HC_HIP(c, hipMemcpyAsync(ct_out[z], c->ws_cts + (size_t)z * cstride, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    return HC_OK;
 }
 extern "C" int hc_conv_then_pack(hc_ctx *c, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
                                  int max_ob, int norm, double out_scale, const uint64_t *bias, uint64_t *ct_out, double *scale_out) {
@@ -1174,44 +1221,35 @@ extern "C" int hc_conv_then_pack(hc_ctx *c, const uint64_t *ct_in, double ct_sca
     HC_TRY(hc_loopA_consts(c, ct_scale, ker_scale, max_ob, norm, out_scale, cst, &target));
     const int G = (int)c->lanes;
     // conv.go:274 multiplies the scale by real_cnum; conv.go:541 then demands out_scale and level 0
-    const double final_scale_chk = target * (double)(max_ob / norm);
-    if (final_scale_chk != out_scale) return hc_fail(c, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
-    auto run_direct = [&]() -> int {
-        HC_TRY(hc_prepare_ctc(c, (const u64 *)ct_in, cst));
-        HC_TRY(hc_ensure_cts(c, (size_t)max_ob * 2));
-        HC_TRY(hc_loopA_run(c, ker->d, max_ob, norm, c->ws_cts));
-        HC_TRY(hc_pack_run(c, c->ws_cts, max_ob, max_ob / norm, (const u64 *)bias));
-        HC_HIP(c, hipMemcpyAsync(ct_out, c->ws_cts, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-        return HC_OK;
-    };
-    if (G > 1 && norm == 1 && max_ob >= 2 * G) {
-        HC_TRY(hc_prepare_ctc(c, (const u64 *)ct_in, cst));
-        HC_TRY(hc_conv_lanes(c, ker, max_ob, G, (const u64 *)bias, (u64 *)ct_out));
-#ifndef HC_EMU
-    } else if (c->use_graph && !c->profile) {
-        hc_ctx::GraphKey key; memset(&key, 0, sizeof key);
-        key.ct_in = ct_in; key.ker = ker->d; key.bias = bias; key.ct_out = ct_out; key.max_ob = max_ob; key.norm = norm; key.c0 = cst[0]; key.c1 = cst[1]; key.chunk = c->chunk_nodes;
-        hc_ctx::GraphVal &g = c->graphs[key];
-        if (g.exec) { HC_HIP(c, hipGraphLaunch((hipGraphExec_t)g.exec, c->stream)); }
-        else if (g.seen++ == 0) { HC_TRY(run_direct()); }                      // first call: allocates every workspace
-        else {
-            hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-            HC_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            const int rc = run_direct();
-            const hipError_t e = hipStreamEndCapture(c->stream, &graph);
-            if (rc || e != hipSuccess || !graph) { if (graph) hipGraphDestroy(graph); c->use_graph = 0; if (rc) return rc; HC_TRY(run_direct()); }
-            else {
-                if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { hipGraphDestroy(graph); c->use_graph = 0; HC_TRY(run_direct()); }
-                else { hipGraphDestroy(graph); g.exec = exec; HC_HIP(c, hipGraphLaunch(exec, c->stream)); }
-            }
-        }
-#endif
-    } else {
-        HC_TRY(run_direct());
-    }
-    // conv.go:274 multiplies the scale by real_cnum; conv.go:541 then demands out_scale and level 0
     const double final_scale = target * (double)(max_ob / norm);
     if (final_scale != out_scale) return hc_fail(c, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
+    if (G > 1 && norm == 1 && max_ob >= 2 * G) {
+        HC_TRY(hc_prepare_ctc(c, hc_ptrs1((const u64 *)ct_in), 1, cst));
+        HC_TRY(hc_conv_lanes(c, ker, max_ob, G, (const u64 *)bias, (u64 *)ct_out));
+    } else {
+        u64 *outs[1] = {(u64 *)ct_out};
+        HC_TRY(hc_conv_batch_run(c, 1, hc_ptrs1((const u64 *)ct_in), hc_ptrs1(ker->d), hc_ptrs1((const u64 *)bias), bias != nullptr, outs, max_ob, norm, cst));
+    }
+    if (scale_out) *scale_out = final_scale;
+    return HC_OK;
+}
+extern "C" int hc_conv_then_pack_batch(hc_ctx *c, int n, const uint64_t *const *ct_in, double ct_scale, const hc_ker *const *ker, double ker_scale,
+                                       int max_ob, int norm, double out_scale, const uint64_t *const *bias, uint64_t *const *ct_out, double *scale_out) {
+    HC_ENTER(c);
+    if (n < 1 || n > HC_MAXB) return hc_fail(c, HC_ERR_ARG, "hc_conv_then_pack_batch: n=%d outside 1..%d", n, HC_MAXB);
+    if (!ct_in || !ker || !ct_out) return hc_fail(c, HC_ERR_ARG, "hc_conv_then_pack_batch: null");
+    HcPtrs pin, pker, pbias; memset(&pin, 0, sizeof pin); memset(&pker, 0, sizeof pker); memset(&pbias, 0, sizeof pbias);
+    u64 *outs[HC_MAXB]; bool any_bias = false;
+    for (int z = 0; z < n; z++) {
+        if (!ct_in[z] || !ker[z] || !ct_out[z] || ker[z]->max_ob < max_ob) return hc_fail(c, HC_ERR_ARG, "hc_conv_then_pack_batch: bad arguments for ciphertext %d", z);
+        pin.p[z] = (const u64 *)ct_in[z]; pker.p[z] = ker[z]->d; outs[z] = (u64 *)ct_out[z];
+        if (bias && bias[z]) { pbias.p[z] = (const u64 *)bias[z]; any_bias = true; }
+    }
+    u64 cst[2]; double target;
+    HC_TRY(hc_loopA_consts(c, ct_scale, ker_scale, max_ob, norm, out_scale, cst, &target));
+    const double final_scale = target * (double)(max_ob / norm);
+    if (final_scale != out_scale) return hc_fail(c, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
+    HC_TRY(hc_conv_batch_run(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
     if (scale_out) *scale_out = final_scale;
     return HC_OK;
 }
@@ -1222,7 +1260,6 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
     if (!strcmp(name, "lanes")) { if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
-    if (!strcmp(name, "graph")) { c->use_graph = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "ks_fused")) { c->ks_fused = value ? 1 : 0; return HC_OK; }      // plain key switch: rows pass inside the inner product (default off: measured slower)
     return hc_fail(c, HC_ERR_ARG, "unknown option %s", name);
 }

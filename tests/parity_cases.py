@@ -157,6 +157,40 @@ def case_conv(ctx, O, max_ob, seed=0xBEEF, with_bias=True, chunk=None, norm=1, o
     return got
 
 
+def case_conv_batch(ctx, O, max_ob, n, seed=0xBA7C, chunk=None, shared_ker=False, oracle_members=(0,)):
+    """hc_conv_then_pack_batch: n independent ciphertexts (own inputs, own or shared kernel plaintexts, a bias on the even members
+    only) through ONE launch set == n separate hc_conv_then_pack calls bit for bit, and == the oracle for `oracle_members`."""
+    evk_all = load_tree_keys(ctx, seed, max_ob, 1)
+    ctx.idx_load(None)
+    if chunk is not None:
+        ctx.set_option("chunk_nodes", chunk)
+    ins, kers, biases = [], [], []
+    for z in range(n):
+        ct_in, ker = planted_conv_inputs(seed + 17 * z, max_ob)
+        ins.append(ct_in); kers.append(kers[0] if (shared_ker and z) else ker)
+        biases.append(splitmix_rows(seed + 5 + z, Q0, N) if z % 2 == 0 else None)
+    hk = [ctx.ker_load(k) for k in (kers[:1] if shared_ker else kers)]
+    hk = hk * n if shared_ker else hk
+    bin_ = [ctx.buf(x) for x in ins]
+    bb = [ctx.buf(b) if b is not None else None for b in biases]
+    bout = [ctx.buf(nwords=2 * N) for _ in range(n)]
+    sc = ctx.conv_then_pack_batch_dev(bin_, 2.0 ** 30, hk, 2.0 ** 30, max_ob, 1, 2.0 ** 30, bb, bout)
+    assert sc == 2.0 ** 30
+    got = [b.download((2, N)) for b in bout]
+    one = ctx.buf(nwords=2 * N)
+    for z in range(n):
+        ctx.conv_then_pack_dev(bin_[z], 2.0 ** 30, hk[z], 2.0 ** 30, max_ob, 1, 2.0 ** 30, bb[z], one)
+        eq(got[z], one.download((2, N)), f"batch member {z} of {n} vs a separate conv_then_pack (B={max_ob})")
+    idx = O.idx_plaintexts()
+    for z in oracle_members:
+        want, _ = O.conv_then_pack(ins[z], 2.0 ** 30, kers[z], 2.0 ** 30, idx, evk_all, max_ob, 1, 2.0 ** 30, biases[z])
+        eq(got[z], want, f"batch member {z} of {n} vs the oracle (B={max_ob})")
+    for b in bin_ + bout + [x for x in bb if x is not None] + [one]:
+        b.free()
+    for h in (hk[:1] if shared_ker else hk):
+        ctx.ker_free(h)
+
+
 def case_conv_phases(ctx, O, max_ob=4, seed=0xF00D):
     """loop A and loop B separately (hc_conv_mult_phase / hc_pack_ctxts)"""
     ct_in, ker = planted_conv_inputs(seed, max_ob)

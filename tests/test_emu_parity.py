@@ -79,6 +79,12 @@ def test_conv_internal_lanes(env, max_ob, lanes, chunk):
     pc.case_conv(*env, max_ob, lanes=lanes, chunk=chunk)
 
 
+@pytest.mark.parametrize("max_ob,n,chunk,shared", [(4, 3, 64, False), (8, 2, 3, True), (2, 5, 4, False)])
+def test_conv_batch(env, max_ob, n, chunk, shared):
+    """hc_conv_then_pack_batch (n ciphertexts per launch set) == n separate convolutions == the oracle"""
+    pc.case_conv_batch(*env, max_ob, n, chunk=chunk, shared_ker=shared)
+
+
 def test_keyswitch_general():
     """general hybrid key switch (BL: level 1, two P primes; bootstrapping shapes) on the emulated kernels"""
     subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])

@@ -187,6 +187,14 @@ def test_conv_internal_lanes(env, max_ob, lanes, chunk):
     pc.case_conv(*env, max_ob, lanes=lanes, chunk=chunk)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_ob,n,chunk,shared", [(4, 3, 64, False), (16, 8, 64, True), (64, 4, 48, False), (256, 4, 128, False), (256, 8, 512, True)])
+def test_conv_batch(env, max_ob, n, chunk, shared):
+    """hc_conv_then_pack_batch (n ciphertexts per launch set, the bench's configuration at B=256) == n separate convolutions
+    bit for bit == the oracle for member 0"""
+    pc.case_conv_batch(*env, max_ob, n, chunk=chunk, shared_ker=shared)
+
+
 def test_keyswitch_general_on_gpu():
     """8f groundwork: the general hybrid key switch (any level, alpha P primes) vs the oracle, which is itself pinned
     against the reference binary's BL and bootstrapping key switches (tests/test_oracle_pin_keyswitch.py)"""
