@@ -171,6 +171,15 @@ static hipError_t hcx_h2d(hc_ctx *c, void *dst, const void *src, size_t n) {    
     hipError_t e = hcx_h2d_async(c, dst, src, n);
     return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
 }
+// Device temporaries of one call: every block allocated through it is released when the call returns, on every path (an early
+// HC_HIP / HC_TRY return included); keep() hands a block over to the caller (the result the call produces).
+struct HcScratch {
+    hc_ctx *c; std::vector<void *> blocks;
+    explicit HcScratch(hc_ctx *c_) : c(c_) {}
+    ~HcScratch() { if (blocks.empty()) return; hipStreamSynchronize(c->stream); for (void *p : blocks) hcx_free(c, p); }
+    template <class T> hipError_t alloc(T **p, size_t bytes) { *p = nullptr; hipError_t e = hcx_malloc(c, (void **)p, bytes); if (e == hipSuccess) blocks.push_back(*p); return e; }
+    void keep(void *p) { for (auto it = blocks.begin(); it != blocks.end(); ++it) if (*it == p) { blocks.erase(it); return; } }
+};
 static inline bool hc_fm_free(u64 q) { return q < (1ull << 57); }     // 74q < 2^64 (hc_ct_round)
 static inline bool hc_f64_ok(u64 q) { return q < (1ull << 49); }    // fp64 inverse transform (hc_arith.h): 4q < 2^51
 
@@ -677,11 +686,12 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
     const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
     // Lattigo's stored form IS the Montgomery form the kernels multiply with: the Q rows are taken as they come (times P^-1, below),
     // the P rows are only re-ordered into the lo-local coalesced order hc_k_b3 reads.
-    u64 *stage = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&stage, 2 * HC_N * sizeof(u64)));
+    HcScratch S(c);
+    u64 *stage = nullptr; HC_HIP(c, S.alloc(&stage, 2 * HC_N * sizeof(u64)));
     HcEvk e; e.q_rows = nullptr; e.p_rows = nullptr; e.row_local = hc_perm_row_local(galEl);
-    u64 *stageq = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&stageq, 2 * HC_N * sizeof(u64)));
-    HC_HIP(c, hcx_malloc(c, (void **)&e.q_rows, 2 * HC_N * sizeof(HcTw)));
-    HC_HIP(c, hcx_malloc(c, (void **)&e.p_rows, 2 * HC_N * sizeof(HcTw)));
+    u64 *stageq = nullptr; HC_HIP(c, S.alloc(&stageq, 2 * HC_N * sizeof(u64)));
+    HC_HIP(c, S.alloc(&e.q_rows, 2 * HC_N * sizeof(HcTw)));
+    HC_HIP(c, S.alloc(&e.p_rows, 2 * HC_N * sizeof(HcTw)));
     HC_HIP(c, hcx_h2d_async(c, stageq, b_q, HC_N * sizeof(u64)));
     HC_HIP(c, hcx_h2d_async(c, stageq + HC_N, a_q, HC_N * sizeof(u64)));
     HC_HIP(c, hcx_h2d_async(c, stage, b_p, HC_N * sizeof(u64)));
@@ -699,8 +709,8 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
     if (!rc) rc = hc_launch(c, "evk_ninv", hc_k_pointwise<HC_PW_MULC>, hc_pw_grid(2 * HC_N), (const u64 *)stage, (const u64 *)stage, stage, (size_t)2 * HC_N, mp.m, h_pair(mp.m.ninv, mp.m.q));
     if (!rc) rc = hc_launch(c, "make_pairs", hc_k_make_pairs, hc_pw_grid(2 * HC_N), (const u64 *)stage, e.p_rows, (size_t)2 * HC_N, mp.m.q, 1);
     if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = hc_fail(c, HC_ERR_HIP, "hc_evk_load: stream synchronize failed");
-    hcx_free(c, stage); hcx_free(c, stageq);
-    if (rc) { hcx_free(c, e.q_rows); hcx_free(c, e.p_rows); return rc; }
+    if (rc) return rc;
+    S.keep(e.q_rows); S.keep(e.p_rows);
     auto it = c->evk.find(galEl);
     if (it != c->evk.end()) { hcx_free(c, it->second.q_rows); hcx_free(c, it->second.p_rows); }
     c->evk[galEl] = e;
@@ -710,8 +720,8 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
 extern "C" int hc_idx_load(hc_ctx *c, const uint64_t *idx_host) {
     HC_ENTER(c);
     const HcModHost &m0 = c->mods[0];
-    u64 *stage = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&stage, (size_t)HC_LOGN * HC_N * sizeof(u64)));
-    int rc = HC_OK;
+    HcScratch S(c);
+    u64 *stage = nullptr; HC_HIP(c, S.alloc(&stage, (size_t)HC_LOGN * HC_N * sizeof(u64)));
     if (idx_host) {
         HC_HIP(c, hcx_h2d_async(c, stage, idx_host, (size_t)HC_LOGN * HC_N * sizeof(u64)));
     } else {   // conv.go:248-253: coeffs[1<<i] = 1 -> EncodeCoeffs(scale 1) -> ToNTT, on the device
@@ -719,18 +729,15 @@ extern "C" int hc_idx_load(hc_ctx *c, const uint64_t *idx_host) {
         u64 one = 1;
         for (int i = 0; i < HC_LOGN; i++) HC_HIP(c, hcx_h2d_async(c, stage + (size_t)i * HC_N + ((size_t)1 << i), &one, sizeof one));
         HC_HIP(c, hipStreamSynchronize(c->stream));
-        u64 *tmp = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&tmp, (size_t)HC_LOGN * HC_N * sizeof(u64)));
-        rc = HC_LAUNCH_FM(m0.m.q, c, "cols_fwd", hc_k_cols_fwd, dim3(16, HC_LOGN), (const u64 *)stage, tmp, m0.fwd, m0.m.q);
-        if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "rows_fwd_canon", hc_k_rows_fwd_canon, dim3(16, HC_LOGN), (const u64 *)tmp, stage, m0.fwd, m0.m.q, m0.m.mu);
-        hipStreamSynchronize(c->stream); hcx_free(c, tmp);
+        u64 *tmp = nullptr; HC_HIP(c, S.alloc(&tmp, (size_t)HC_LOGN * HC_N * sizeof(u64)));
+        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "cols_fwd", hc_k_cols_fwd, dim3(16, HC_LOGN), (const u64 *)stage, tmp, m0.fwd, m0.m.q));
+        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "rows_fwd_canon", hc_k_rows_fwd_canon, dim3(16, HC_LOGN), (const u64 *)tmp, stage, m0.fwd, m0.m.q, m0.m.mu));
     }
-    HcTw *pairs = nullptr;
-    if (!rc && hcx_malloc(c, (void **)&pairs, (size_t)HC_LOGN * HC_N * sizeof(HcTw)) != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "hc_idx_load: allocation failed");
-    if (!rc) rc = hc_launch(c, "idx_pairs", hc_k_make_pairs, hc_pw_grid((size_t)HC_LOGN * HC_N), (const u64 *)stage, pairs, (size_t)HC_LOGN * HC_N, m0.m.q, 0);
-    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = hc_fail(c, HC_ERR_HIP, "hc_idx_load: stream synchronize failed");
-    hcx_free(c, stage);
-    if (rc) { hcx_free(c, pairs); return rc; }
-    if (c->idx_pairs) hcx_free(c, c->idx_pairs);
+    HcTw *pairs = nullptr; HC_HIP(c, S.alloc(&pairs, (size_t)HC_LOGN * HC_N * sizeof(HcTw)));
+    HC_TRY(hc_launch(c, "idx_pairs", hc_k_make_pairs, hc_pw_grid((size_t)HC_LOGN * HC_N), (const u64 *)stage, pairs, (size_t)HC_LOGN * HC_N, m0.m.q, 0));
+    HC_HIP(c, hipStreamSynchronize(c->stream));
+    S.keep(pairs);
+    if (c->idx_pairs) HC_HIP(c, hcx_free(c, c->idx_pairs));
     c->idx_pairs = pairs;
     return HC_OK;
 }
@@ -751,8 +758,10 @@ static int hc_ker_from_device(hc_ctx *c, u64 *d, int max_ob, bool take, hc_ker *
 extern "C" int hc_ker_load(hc_ctx *c, const uint64_t *host, int max_ob, hc_ker **out) {
     HC_ENTER(c);
     if (!host || !out || max_ob < 1 || c->nq < 2) return hc_fail(c, HC_ERR_ARG, "hc_ker_load: bad arguments");
-    u64 *d = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&d, (size_t)max_ob * 2 * HC_N * sizeof(u64)));
+    HcScratch S(c);
+    u64 *d = nullptr; HC_HIP(c, S.alloc(&d, (size_t)max_ob * 2 * HC_N * sizeof(u64)));
     HC_HIP(c, hcx_h2d_async(c, d, host, (size_t)max_ob * 2 * HC_N * sizeof(u64)));
+    S.keep(d);                                   // hc_ker_from_device owns it from here (and frees it on failure)
     return hc_ker_from_device(c, d, max_ob, true, out);
 }
 extern "C" int hc_ker_load_device(hc_ctx *c, const uint64_t *dptr, int max_ob, hc_ker **out) {
@@ -772,11 +781,12 @@ extern "C" int hc_prep_ker(hc_ctx *c, const double *ker_in, int ker_len, const d
     if (norm * real_ib > max_bat || norm * real_ob > max_bat) return hc_fail(c, HC_ERR_ARG, "hc_prep_ker: norm*batch exceeds max_bat=%d", max_bat);
     const int adj = (max_bat - 1) + max_bat * (in_wid + 1) * (ker_wid - 1) / 2;
     if (2 * adj > HC_N) return hc_fail(c, HC_ERR_ARG, "hc_prep_ker: kernel too wide for this input width");
-    double *dk = nullptr, *da = nullptr; u64 *stage = nullptr, *dst = nullptr, *tmp = nullptr;
-    HC_HIP(c, hcx_malloc(c, (void **)&dk, (size_t)ker_len * sizeof(double)));
-    HC_HIP(c, hcx_malloc(c, (void **)&da, (size_t)real_ob * sizeof(double)));
-    HC_HIP(c, hcx_malloc(c, (void **)&stage, (size_t)max_bat * 2 * HC_N * sizeof(u64)));
-    HC_HIP(c, hcx_malloc(c, (void **)&dst, (size_t)max_bat * 2 * HC_N * sizeof(u64)));
+    HcScratch S(c);
+    double *dk = nullptr, *da = nullptr; u64 *stage = nullptr, *dst = nullptr;
+    HC_HIP(c, S.alloc(&dk, (size_t)ker_len * sizeof(double)));
+    HC_HIP(c, S.alloc(&da, (size_t)real_ob * sizeof(double)));
+    HC_HIP(c, S.alloc(&stage, (size_t)max_bat * 2 * HC_N * sizeof(u64)));
+    HC_HIP(c, S.alloc(&dst, (size_t)max_bat * 2 * HC_N * sizeof(u64)));
     HC_HIP(c, hcx_h2d_async(c, dk, ker_in, (size_t)ker_len * sizeof(double)));
     HC_HIP(c, hcx_h2d_async(c, da, bn_a, (size_t)real_ob * sizeof(double)));
     HC_HIP(c, hipMemsetAsync(stage, 0, (size_t)max_bat * 2 * HC_N * sizeof(u64), c->stream));
@@ -786,9 +796,9 @@ extern "C" int hc_prep_ker(hc_ctx *c, const double *ker_in, int ker_len, const d
     HC_HIP(c, hipStreamSynchronize(c->stream));      // host buffers may go away after return; hc_ntt below may regrow ws_tmp
     for (int l = 0; l < 2 && !rc; l++) rc = hc_ntt(c, l, stage + (size_t)l * max_bat * HC_N, stage + (size_t)l * max_bat * HC_N, max_bat);
     if (!rc) rc = hc_launch(c, "ker_interleave", hc_k_ker_interleave, hc_pw_grid((size_t)max_bat * 2 * HC_N), (const u64 *)stage, dst, max_bat, c->mods[0].m, c->mods[1].m, 0);
-    hipStreamSynchronize(c->stream);
-    hcx_free(c, dk); hcx_free(c, da); hcx_free(c, stage); (void)tmp;
-    if (rc) { hcx_free(c, dst); return rc; }
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "hc_prep_ker: stream synchronize failed");
+    if (rc) return rc;
+    S.keep(dst);
     hc_ker *k = new hc_ker(); k->d = dst; k->max_ob = max_bat; *out = k;
     return HC_OK;
 }

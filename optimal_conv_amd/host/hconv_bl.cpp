@@ -52,11 +52,11 @@ struct BLContext {
     int in_wid = 0;
     std::vector<int64_t> sk;
     std::vector<uint64_t> sk_ntt[4];
-    std::mt19937_64 g;
+    ChaChaRng g;
     std::set<uint64_t> keys;
     double scale = (double)(1 << 30);
     Boot *btp = nullptr;          // cont.btp (main.go:476): the stock bootstrapper over parameter set [7], only for convReLU
-    uint64_t seed = 0;
+    Seed256 seed;
 };
 struct BLCt { uint64_t *d = nullptr; double Scale = 0; };     // level-1 ciphertext: device [poly 2][limb 2][N]
 
@@ -240,7 +240,7 @@ static BLContext *bl_newContext(int logN, int ker_wid, int in_wid, bool boot) {
     // only ever touches Q0, Q1 and, for a level-1 key switch, the first two special primes
     printf("CKKS parameters: logN = %d, logSlots = %d, h = %d, logQP = %d, levels = %d, scale= 2^%f, sigma = %f \n", LOGN, LOGN - 1, 192, 1582, 28, 30.0, 3.2);
     if ((1 << logN) != N) { printf("Set Boot logN to %d\n", logN); panic("Boot N != N"); }
-    const char *sd = getenv("HCONV_SEED"); c->seed = sd ? strtoull(sd, nullptr, 0) ^ 0xB1ull : std::random_device{}(); c->g.seed(c->seed);
+    c->seed = seedFromEnvironment(); c->g.reseed(c->seed, 0x424c);
     const int dev = getenv("HCONV_DEVICE") ? atoi(getenv("HCONV_DEVICE")) : 0;
     if (hc_ctx_create(&c->hc, LOGN, BLQ, 2, BLQ + 2, 2, dev)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
     c->sk.assign(N, 0);

@@ -76,7 +76,7 @@ static std::vector<uint64_t> gpu_ntt(Context *c, int mod, const std::vector<uint
 }
 
 // ---------------------------------------------------------------- sampling (harness only)
-static std::mt19937_64 &rng(Context *c) { static std::mt19937_64 g; static bool init = false; if (!init) { g.seed(c->seed); init = true; } return g; }
+static ChaChaRng &rng(Context *c) { return c->g; }      // one generator per context (image threads own their contexts)
 static std::vector<uint64_t> uniform_row(Context *c, uint64_t q) {
     std::vector<uint64_t> r(N); std::uniform_int_distribution<uint64_t> d(0, q - 1); auto &g = rng(c);
     for (auto &x : r) x = d(g);
@@ -135,8 +135,7 @@ Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, cons
     printf("CKKS parameters: logN = %d, logSlots = %d, h = %d, logQP = %d, levels = %d, scale= 2^%f, sigma = %f \n",
            LOGN, LOGN - 1, 192, (int)llround(logqp), (int)PARAMS6_Q.size(), log2(c->scale), 3.2);       // main.go:85-86
     if ((1 << logN) != N) { printf("Set Boot logN to %d\n", logN); panic("Boot N != N"); }           // main.go:87-90
-    const char *sd = getenv("HCONV_SEED");
-    c->seed = sd ? strtoull(sd, nullptr, 0) : std::random_device{}();
+    c->seed = seedFromEnvironment(); c->g.reseed(c->seed, 0x436f6e76);      // 256 bits from getrandom(2) unless HCONV_SEED asks for deterministic keys
     int dev = getenv("HCONV_DEVICE") ? atoi(getenv("HCONV_DEVICE")) : 0;
     uint64_t q[2] = {MODQ[0], MODQ[1]}, p[1] = {PACK_P};
     if (hc_ctx_create(&c->hc, LOGN, q, 2, p, 1, dev)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/hconv.h"
+#include "hconv_prng.hpp"
 
 namespace hconv {
 
@@ -66,7 +67,8 @@ struct Context {
     std::vector<uint64_t> sk_ntt[3];          // NTT rows mod Q0, Q1, P (host)
     double scale = (double)(1 << 30);
     int num_rotations = 0;
-    uint64_t seed = 0;
+    Seed256 seed;                             // key of this context's generators (hconv_prng.hpp)
+    ChaChaRng g;                              // this context's own generator: secret key, Galois keys, encryption randomness
 };
 
 // ---- harness / reference-shaped API ----
@@ -97,7 +99,7 @@ Ciphertext evalConv_BN(Context *cont, const Ciphertext &ct_input, const std::vec
                        const std::vector<double> &bn_b, int in_wid, int ker_wid, int real_ib, int real_ob, int norm, double out_scale, bool trans);
 void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool boot);
 // ---- convReLU chain (hconv_relu.cpp; eval.go:272-607 for kind "Conv") ----
-Boot *newBoot(const std::vector<int64_t> &sk, uint64_t seed, int device, const std::vector<int> &log_sparse_sets);   // one "bootstrapper" per log_sparse
+Boot *newBoot(const std::vector<int64_t> &sk, const Seed256 &seed, int device, const std::vector<int> &log_sparse_sets);   // one "bootstrapper" per log_sparse
 void freeBoot(Boot *);
 void bootPrepareCompress(Boot *B, int in_wid, int kp_wid, int log_sparse);   // rotation keys of a stride layer's ext_double_ctxt
 // everything after evalConv_BN: Scale *= 2^pow, BootstrappConv_CtoS, evalReLU + MulByPow2, keep_ctxt, BootstrappConv_StoC
@@ -107,7 +109,7 @@ void freeBootCt(Boot *B, BootCiphertext &ct);
 void bootStats(Boot *B, long *keys, long *keyswitches);
 // ---- the baseline's bootstrapping + ReLU (test_BL.go:113-168) on parameter set [7]: cont.btp.Bootstrapp (the stock full-slot
 // bootstrapper), imaginary packing / unpacking, evalReLU + MulByPow2 + SetScale on both halves
-Boot *newBootBL(const std::vector<int64_t> &sk, uint64_t seed, int device);
+Boot *newBootBL(const std::vector<int64_t> &sk, const Seed256 &seed, int device);
 // ct_res0/1: level-1 results of the two baseline convolutions, device [2][2][N] over (Q0, Q1 of set [7]) at `scale`; out0/1 likewise at level 1
 void blBootReLU(Boot *B, const uint64_t *ct_res0, const uint64_t *ct_res1, double scale, double alpha, double pow, uint64_t *out0, uint64_t *out1, double *out_scale);
 // eval.go:272-607 for kinds "Conv", "Conv_sparse", "StrConv_sparse" (hconv_resnet.cpp); returns a level-1, scale-2^30 ciphertext

@@ -75,7 +75,7 @@ struct Boot {
     uint64_t *d_sk = nullptr;                               // [NQ+NP][N] NTT rows of sk on the device
     std::map<std::pair<uint64_t, int>, uint64_t> key_ids;   // (galEl or 0 = relinearisation, level) -> id loaded with hc_swk_load
     std::vector<uint64_t *> pool;
-    uint64_t rng_state = 0;
+    ChaChaRng rng;                    // the bootstrapper's own key stream (switching keys, encryption masks)
     Encoder enc;
     std::shared_ptr<uint64_t> mono_i;                        // NTT(X^(N/2)) for every limb
     struct LT { int n1 = 1; std::map<int, std::map<int, DPt>> giant; double pt_scale = 0; int level = 0; };
@@ -96,7 +96,7 @@ struct Boot {
     static DCt drop_to(const DCt &a, int level) { if (level > a.level) panic("drop_to: level above the ciphertext's"); DCt c = a; c.level = level; return c; }
 
     // ---------------- sampling (harness only; the reference's randomness is crypto/rand and unseeded)
-    uint64_t next() { uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+    uint64_t next() { return rng(); }
     void uniform_rows(uint64_t q, uint64_t *out) { int bits = 64 - __builtin_clzll(q); uint64_t mask = bits == 64 ? ~0ull : ((1ull << bits) - 1); for (int j = 0; j < N; j++) { uint64_t r; do r = next() & mask; while (r >= q); out[j] = r; } }
     void gaussian(std::vector<int64_t> &e) {
         e.resize(N);
@@ -472,9 +472,9 @@ struct Boot {
     }
 
     // ---------------- the bootstrapper
-    void build(const std::vector<int64_t> &sk_in, uint64_t seed, int device, int chain_ = 6) {
+    void build(const std::vector<int64_t> &sk_in, const Seed256 &seed, int device, int chain_ = 6) {
         chain = chain_;
-        Q = chain == 7 ? PARAMS7_Q : PARAMS6_Q; P = PARAMS6_P; NQ = (int)Q.size(); sk = sk_in; rng_state = seed ^ 0xB007B007ull;
+        Q = chain == 7 ? PARAMS7_Q : PARAMS6_Q; P = PARAMS6_P; NQ = (int)Q.size(); sk = sk_in; rng.reseed(seed, 0xB007B007ull + (uint64_t)chain_);
         if (chain == 7) { LV_STC_TOP = 15; stc_scale_top = stc_scale_last = 1099511627776.0; lv_relin_lo = 2; sine_out_scale = 36028797018963968.0; }
         else { LV_STC_TOP = 3; stc_scale_top = sqrt((double)Q[3]); stc_scale_last = 1073741824.0; lv_relin_lo = LV_RELU_TOP - 10; }
         if (hc_ctx_create(&hc, LOGN, Q.data(), NQ, P.data(), (int)P.size(), device)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
@@ -664,7 +664,7 @@ static DCt keep_ctxt(Boot *B, const DCt &ct, const std::vector<int> &idx, const 
 }
 
 // ---------------------------------------------------------------- public surface (hconv_host.hpp)
-Boot *newBoot(const std::vector<int64_t> &sk, uint64_t seed, int device, const std::vector<int> &log_sparse_sets) {
+Boot *newBoot(const std::vector<int64_t> &sk, const Seed256 &seed, int device, const std::vector<int> &log_sparse_sets) {
     Boot *b = new Boot(); b->build(sk, seed, device);
     for (int ls : log_sparse_sets) b->set(ls);
     return b;
@@ -742,7 +742,7 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     return out;
 }
 // ---------------------------------------------------------------- baseline: Bootstrapp + ReLU (test_BL.go:113-168)
-Boot *newBootBL(const std::vector<int64_t> &sk, uint64_t seed, int device) {
+Boot *newBootBL(const std::vector<int64_t> &sk, const Seed256 &seed, int device) {
     Boot *b = new Boot(); b->build(sk, seed, device, 7); b->set(0);
     return b;
 }

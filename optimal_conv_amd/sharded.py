@@ -41,9 +41,11 @@ def conv_then_pack_sharded(ctx, ct_in_buf, ct_scale, ker_local, ker_scale, B, ou
     dist.gather(part, gathered, dst=0, group=group)          # the only exchange: world x 1 MiB
     if rank != 0:
         return None, None
-    if str(device).startswith("cuda"):
-        torch.cuda.synchronize()
     allp = torch.cat(gathered)                                  # [world][2][N], slot g = global channel g
+    if str(device).startswith("cuda"):
+        # torch's gather and cat run on torch's stream, the tree below on libhconv's own (possibly non-blocking) stream:
+        # everything torch queued must be complete before the library reads `allp`
+        torch.cuda.synchronize()
     ctx._ck(ctx.L.hc_pack_ctxts_strided(ctx.h, C.c_void_p(allp.data_ptr()), world, 0, bias_buf.ptr if bias_buf is not None else None))
     ctx.sync()
     return allp[: 2 * N], out_scale
