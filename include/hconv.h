@@ -56,6 +56,10 @@ int hc_upload(hc_ctx *ctx, void *dst_dptr, const void *src_host, size_t bytes);
 int hc_download(hc_ctx *ctx, void *dst_host, const void *src_dptr, size_t bytes);
 int hc_copy(hc_ctx *ctx, void *dst_dptr, const void *src_dptr, size_t bytes); /* device to device, on the stream */
 int hc_sync(hc_ctx *ctx);
+int hc_device_count(int *n);          /* HIP devices visible to the process */
+/* device-to-device copy between the devices of two contexts (hipMemcpyPeerAsync: xGMI between the GPUs of a node), queued on
+ * dst_ctx's stream behind everything src_ctx has queued so far; no host synchronisation */
+int hc_copy_peer(hc_ctx *dst_ctx, void *dst_dptr, hc_ctx *src_ctx, const void *src_dptr, size_t bytes);
 
 /* ---- L0: one call per ring / evaluator primitive (rows are device pointers; `count` consecutive rows) ---- */
 /* ring.NTTLvl / ring.InvNTTLvl on limb `mod` (encoder.ToNTT conv.go:514; inside Rescale and key switching) */
@@ -169,6 +173,15 @@ int hc_conv_then_pack(hc_ctx *ctx, const uint64_t *ct_in, double ct_scale, const
 int hc_conv_then_pack_batch(hc_ctx *ctx, int n, const uint64_t *const *ct_in, double ct_scale, const hc_ker *const *ker,
                             double ker_scale, int max_ob, int norm, double out_scale, const uint64_t *const *bias,
                             uint64_t *const *ct_out, double *scale_out);
+/* ONE convolution sharded over G devices (BASELINE config `conv 7 3` over 8 GPUs): ctxs[g] = a context on device
+ * g with the same moduli and switching keys; ct_in[g] = that device's replica of the level-1 input; ker[g] = that device's
+ * handle to all max_ob kernel plaintexts (device g multiplies the channels g, g + G, ...). Each device runs loop A and the tree
+ * levels with step >= G on its own stream; device 0 collects the G partial ciphertexts (1 MiB each) with peer copies ordered by
+ * events -- no host synchronisation, no other exchange -- and finishes the last log2 G levels and the bias. bias and ct_out are
+ * on device 0. Bit-identical to hc_conv_then_pack on one device. G a power of two <= 16 dividing max_ob; contexts may share a device. */
+int hc_conv_then_pack_sharded(hc_ctx *const *ctxs, int G, const uint64_t *const *ct_in, double ct_scale, const hc_ker *const *ker,
+                              double ker_scale, int max_ob, double out_scale, const uint64_t *bias, uint64_t *ct_out,
+                              double *scale_out);
 /* loop A only (conv.go:525-531): cts_out = device [max_ob][2][N]; and loop B only (pack_ctxts, conv.go:266-300),
  * in place on cts (result in slot 0). Exposed for parity tests and profiling. */
 int hc_conv_mult_phase(hc_ctx *ctx, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,

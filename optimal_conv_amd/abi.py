@@ -66,6 +66,10 @@ SYMBOLS = {
                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "hc_conv_then_pack_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.POINTER(C.c_void_p), C.c_double, C.c_int, C.c_int,
                                           C.c_double, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_double)]),
+    "hc_conv_then_pack_sharded": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_double, C.POINTER(C.c_void_p), C.c_double, C.c_int,
+                                            C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "hc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "hc_copy_peer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "hc_conv_mult_phase": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double,
                                      C.c_void_p]),
     "hc_pack_ctxts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -412,6 +416,17 @@ class Context:
         cb = arr(*[(b.ptr if b is not None else None) for b in bias_bufs]) if bias_bufs is not None else None
         sc = C.c_double(0)
         self._ck(self.L.hc_conv_then_pack_batch(self.h, n, cin, ct_scale, ck, ker_scale, max_ob, norm, out_scale, cb, co, C.byref(sc)))
+        return sc.value
+
+    @staticmethod
+    def conv_then_pack_sharded_dev(ctxs, ct_in_bufs, ct_scale, kers, ker_scale, max_ob, out_scale, bias_buf, out_buf):
+        """hc_conv_then_pack_sharded: ONE convolution over len(ctxs) contexts (devices); bias_buf / out_buf belong to ctxs[0]"""
+        G = len(ctxs)
+        arr = C.c_void_p * G
+        ch = arr(*[c.h for c in ctxs]); cin = arr(*[b.ptr for b in ct_in_bufs]); ck = arr(*kers)
+        sc = C.c_double(0)
+        ctxs[0]._ck(ctxs[0].L.hc_conv_then_pack_sharded(ch, G, cin, ct_scale, ck, ker_scale, max_ob, out_scale,
+                                                         bias_buf.ptr if bias_buf is not None else None, out_buf.ptr, C.byref(sc)))
         return sc.value
 
     def conv_then_pack(self, ct_in, ct_scale, pl_ker, ker_scale, max_ob, norm, out_scale, bias=None):

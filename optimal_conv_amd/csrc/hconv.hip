@@ -106,6 +106,7 @@ struct hc_ctx {
     long lanes = 1;               // internal concurrency of ONE conv_then_pack (power of two; 1 = single stream)
     std::vector<HcLane> lane;
     hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_shard = nullptr;     // hc_conv_then_pack_sharded: this device's partial ciphertext is complete / has been collected
     u64 *ws_gather = nullptr; size_t ws_gather_rows = 0;
     long profile = 0;
     std::vector<HcProfRec> prof;
@@ -136,6 +137,9 @@ static int hc_fail(hc_ctx *c, int code, const char *fmt, ...) {
 // hipMalloc blocks — is bit-exact.
 static hipError_t hcx_malloc(hc_ctx *c, void **p, size_t n) {
     if (!(c && c->async_alloc)) return hipMalloc(p, n);
+#ifndef HC_EMU
+    if (c->async_alloc == 2) return hipMallocAsync(p, n, c->stream);          // diagnostic mode: ROCm's stream-ordered allocator (see tools/repro_mallocasync.hip)
+#endif
     auto it = c->cache_free.find(n);
     if (it != c->cache_free.end() && !it->second.empty()) { *p = it->second.back(); it->second.pop_back(); return hipSuccess; }
     hipError_t e = hipMalloc(p, n);
@@ -145,6 +149,9 @@ static hipError_t hcx_malloc(hc_ctx *c, void **p, size_t n) {
 static hipError_t hcx_free(hc_ctx *c, void *p) {
     if (!p) return hipSuccess;
     if (!(c && c->async_alloc)) return hipFree(p);
+#ifndef HC_EMU
+    if (c->async_alloc == 2) return hipFreeAsync(p, c->stream);
+#endif
     auto it = c->cache_blk.find((char *)p);
     if (it == c->cache_blk.end()) return hipFree(p);
     // everything queued so far may still read or write the block: remember that point of the stream (see hcx_h2d_async)
@@ -275,7 +282,7 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
         return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: HIP device %d not available (%d devices) - this library has no CPU path", device, ndev);
     hc_ctx *c = new hc_ctx();
     c->device = device; c->nq = nq; c->np = np;
-    { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa && atoi(aa) ? 1 : 0; }
+    { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa ? (atoi(aa) == 2 ? 2 : (atoi(aa) ? 1 : 0)) : 0; }
     if (hipSetDevice(device) != hipSuccess || (c->async_alloc ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: cannot create stream on device %d", device); }
     hipEventCreate(&c->t0); hipEventCreate(&c->t1);
     c->mods.resize((size_t)(nq + np));
@@ -328,6 +335,7 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     for (auto &kv : c->swk) F(kv.second.rows);
     F(c->idx_pairs); F(c->ws_cts); F(c->ws_cts2); F(c->ws_gather);
     if (c->ev_fork) D(hipEventDestroy(c->ev_fork), "hipEventDestroy");
+    if (c->ev_shard) D(hipEventDestroy(c->ev_shard), "hipEventDestroy");
     for (auto &L : c->lane) {
         if (L.stream) D(hipStreamSynchronize(L.stream), "hipStreamSynchronize");
         F(L.tmp); F(L.cts); F(L.cts2);
@@ -363,6 +371,18 @@ extern "C" int hc_download(hc_ctx *c, void *dst, const void *src, size_t bytes) 
 extern "C" int hc_copy(hc_ctx *c, void *dst, const void *src, size_t bytes) {
     HC_ENTER(c); if (!dst || !src) return hc_fail(c, HC_ERR_ARG, "hc_copy: null pointer");
     HC_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return HC_OK;
+}
+extern "C" int hc_device_count(int *n) { if (!n) return HC_ERR_ARG; return hipGetDeviceCount(n) == hipSuccess ? HC_OK : HC_ERR_HIP; }
+// device-to-device copy between two contexts' devices (xGMI between GPUs of a node), queued on dst's stream after everything src has queued
+extern "C" int hc_copy_peer(hc_ctx *dst_ctx, void *dst, hc_ctx *src_ctx, const void *src, size_t bytes) {
+    HC_ENTER(src_ctx);
+    if (!dst_ctx || !dst || !src) return hc_fail(src_ctx, HC_ERR_ARG, "hc_copy_peer: null");
+    if (!src_ctx->ev_shard) HC_HIP(src_ctx, hipEventCreateWithFlags(&src_ctx->ev_shard, hipEventDisableTiming));
+    HC_HIP(src_ctx, hipEventRecord(src_ctx->ev_shard, src_ctx->stream));
+    HC_ENTER(dst_ctx);
+    HC_HIP(dst_ctx, hipStreamWaitEvent(dst_ctx->stream, src_ctx->ev_shard, 0));
+    HC_HIP(dst_ctx, hipMemcpyPeerAsync(dst, dst_ctx->device, src, src_ctx->device, bytes, dst_ctx->stream));
     return HC_OK;
 }
 extern "C" int hc_sync(hc_ctx *c) { HC_ENTER(c); HC_HIP(c, hipStreamSynchronize(c->stream)); return hc_prof_flush(c); }
@@ -1261,6 +1281,66 @@ extern "C" int hc_conv_then_pack_batch(hc_ctx *c, int n, const uint64_t *const *
     if (final_scale != out_scale) return hc_fail(c, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
     HC_TRY(hc_conv_batch_run(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
     if (scale_out) *scale_out = final_scale;
+    return HC_OK;
+}
+
+// ONE convolution sharded over G devices (BASELINE config 3: `conv 7 3`, B = 256 over 8 GPUs). conv.go:525-531's B products are
+// independent and conv.go:286-297's tree pairs (i, i + step), so with the output channels dealt i mod G every tree level with
+// step >= G is local to a device; only the last log2 G levels need the G partial ciphertexts (1 MiB each) in one place.
+// ctxs[g] lives on device g (any devices; all on one device works too and is how the one-GPU boxes exercise this path), holds the
+// same keys, a replica of the input ciphertext ct_in[g] and the kernel plaintexts ker[g] (all B of them; device g uses channels
+// g, g + G, ...). Device g: loop A on its channels + the strided local tree, on its own stream. Device 0: waits on G events, pulls
+// the partials with hipMemcpyPeerAsync (xGMI between GPUs of a node) on ITS stream, runs the last log2 G levels and the bias.
+// No host synchronisation anywhere; the call returns with everything queued. Same arithmetic per node => same bits as one device.
+extern "C" int hc_conv_then_pack_sharded(hc_ctx *const *ctxs, int G, const uint64_t *const *ct_in, double ct_scale, const hc_ker *const *ker, double ker_scale,
+                                         int max_ob, double out_scale, const uint64_t *bias, uint64_t *ct_out, double *scale_out) {
+    if (!ctxs || G < 1 || !ctxs[0]) return HC_ERR_ARG;
+    hc_ctx *c0 = ctxs[0];
+    HC_ENTER(c0);
+    if (G > HC_MAXB || (G & (G - 1)) || !ct_in || !ker || !ct_out) return hc_fail(c0, HC_ERR_ARG, "hc_conv_then_pack_sharded: G=%d must be a power of two <= %d, pointers non-null", G, HC_MAXB);
+    if (max_ob < G || max_ob % G) return hc_fail(c0, HC_ERR_ARG, "hc_conv_then_pack_sharded: max_ob=%d must be a multiple of G=%d", max_ob, G);
+    int log2g = 0; while ((1 << log2g) < G) log2g++;
+    const int nloc = max_ob / G;
+    u64 cst[2]; double target;
+    HC_TRY(hc_loopA_consts(c0, ct_scale, ker_scale, max_ob, 1, out_scale, cst, &target));
+    if (target * (double)max_ob != out_scale) return hc_fail(c0, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
+    for (int g = 0; g < G; g++) {
+        hc_ctx *c = ctxs[g];
+        if (!c || !ct_in[g] || !ker[g] || ker[g]->max_ob < max_ob) return hc_fail(c0, HC_ERR_ARG, "hc_conv_then_pack_sharded: bad arguments for device slot %d", g);
+        HC_ENTER(c);
+        if (c->nq != c0->nq || c->mods[0].m.q != c0->mods[0].m.q || c->mods[1].m.q != c0->mods[1].m.q) return hc_fail(c0, HC_ERR_ARG, "hc_conv_then_pack_sharded: contexts differ in their moduli");
+        if (!c->ev_shard) HC_HIP(c, hipEventCreateWithFlags(&c->ev_shard, hipEventDisableTiming));
+        HC_TRY(hc_prepare_ctc(c, hc_ptrs1((const u64 *)ct_in[g]), 1, cst));
+        HC_TRY(hc_ensure_cts(c, (size_t)nloc * 2));
+        HC_TRY(hc_loopA_run_set(c, hc_ptrs1(ker[g]->d), 1, g, G, nloc, c->ws_cts, 0, true));     // channels g, g + G, ...: slot m = channel g + G m
+        HC_TRY(hc_pack_run(c, c->ws_cts, 0, 1, nloc, nloc, nullptr, log2g));                      // levels with step >= G
+        HC_HIP(c, hipEventRecord(c->ev_shard, c->stream));
+        if (c != c0 && c->device != c0->device) {                                                   // direct xGMI copies when the devices can
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, c0->device, c->device) == hipSuccess && can) { hipSetDevice(c0->device); (void)hipDeviceEnablePeerAccess(c->device, 0); (void)hipGetLastError(); }
+        }
+    }
+    HC_ENTER(c0);
+    if (c0->ws_gather_rows < (size_t)G * 2) {
+        HC_HIP(c0, hipStreamSynchronize(c0->stream));
+        if (c0->ws_gather) HC_HIP(c0, hcx_free(c0, c0->ws_gather));
+        c0->ws_gather = nullptr; c0->ws_gather_rows = 0;
+        HC_HIP(c0, hcx_malloc(c0, (void **)&c0->ws_gather, (size_t)G * 2 * HC_N * sizeof(u64)));
+        c0->ws_gather_rows = (size_t)G * 2;
+    }
+    for (int g = 0; g < G; g++) {
+        hc_ctx *c = ctxs[g];
+        if (c != c0) HC_HIP(c0, hipStreamWaitEvent(c0->stream, c->ev_shard, 0));
+        HC_HIP(c0, hipMemcpyPeerAsync(c0->ws_gather + (size_t)g * 2 * HC_N, c0->device, c->ws_cts, c->device, 2 * HC_N * sizeof(u64), c0->stream));
+    }
+    if (!c0->ev_fork) HC_HIP(c0, hipEventCreate(&c0->ev_fork));
+    HC_HIP(c0, hipEventRecord(c0->ev_fork, c0->stream));                                            // the partials have been collected:
+    for (int g = 1; g < G; g++) if (ctxs[g] != c0) { HC_HIP(c0, hipSetDevice(ctxs[g]->device)); HC_HIP(c0, hipStreamWaitEvent(ctxs[g]->stream, c0->ev_fork, 0)); }   // ... device g may reuse its workspace
+    HC_ENTER(c0);
+    const HcPtrs bp = hc_ptrs1((const u64 *)bias);
+    HC_TRY(hc_pack_run(c0, c0->ws_gather, 0, 1, G, G, bias ? &bp : nullptr, 0));                    // the last log2 G levels + eval.go:258's bias
+    HC_HIP(c0, hipMemcpyAsync(ct_out, c0->ws_gather, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c0->stream));
+    if (scale_out) *scale_out = out_scale;
     return HC_OK;
 }
 

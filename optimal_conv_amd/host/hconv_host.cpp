@@ -120,6 +120,7 @@ static void gen_and_load_galois_key(Context *c, uint64_t galEl) {
         rows[2 * w] = bb; rows[2 * w + 1] = a;
     }
     HC(c->hc, hc_evk_load(c->hc, galEl, rows[0].data(), rows[1].data(), rows[2].data(), rows[3].data()));
+    for (size_t g = 1; g < c->shards.size(); g++) HC(c->shards[g], hc_evk_load(c->shards[g], galEl, rows[0].data(), rows[1].data(), rows[2].data(), rows[3].data()));
     if (galEl - 1 < 32) {       // 2^j+1 with j < 5 leaves the 4096-coefficient tile of the fused kernels: RotateGal takes the general key switch
         std::vector<uint64_t> g; for (int r : {0, 2, 1, 3}) g.insert(g.end(), rows[r].begin(), rows[r].end());     // [digit 0][b | a][Q0, P][N]
         HC(c->hc, hc_swk_load(c->hc, galEl, 0, g.data()));
@@ -139,13 +140,20 @@ Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, cons
     int dev = getenv("HCONV_DEVICE") ? atoi(getenv("HCONV_DEVICE")) : 0;
     uint64_t q[2] = {MODQ[0], MODQ[1]}, p[1] = {PACK_P};
     if (hc_ctx_create(&c->hc, LOGN, q, 2, p, 1, dev)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
+    c->shards.push_back(c->hc);
+    if (const char *ng = getenv("HCONV_GPUS")) {       // one convolution over G devices (contexts share devices when the box has fewer)
+        const int G = atoi(ng); int ndev = 1; hc_device_count(&ndev);
+        if (G < 1 || G > 16 || (G & (G - 1))) panic("HCONV_GPUS must be a power of two in 1..16");
+        for (int g = 1; g < G; g++) { hc_ctx *h = nullptr; if (hc_ctx_create(&h, LOGN, q, 2, p, 1, (dev + g) % ndev)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr)); c->shards.push_back(h); }
+        if (G > 1) printf("Sharding every convolution over %d device contexts (%d device%s visible)\n", G, ndev, ndev == 1 ? "" : "s");
+    }
     // kgen.GenKeyPairSparse(h = 192) (main.go:410)
     c->sk.assign(N, 0);
     { auto &g = rng(c); int placed = 0; while (placed < 192) { uint64_t r = g(); int pos = (int)(r % N); if (!c->sk[pos]) { c->sk[pos] = (r >> 40) & 1 ? 1 : -1; placed++; } } }
     for (int m = 0; m < 3; m++) c->sk_ntt[m] = gpu_ntt(c, m, signed_row(c->sk, MODQ[m]));
     printf("Num Rotations:  %d\n", c->num_rotations);                                                  // main.go:412
     // gen_idxNlogs (conv.go:241-261): idx[i] = NTT(X^(2^i)) on the device; Galois keys for 2^(i+1)+1, i < logN
-    HC(c->hc, hc_idx_load(c->hc, nullptr));
+    for (hc_ctx *h : c->shards) HC(h, hc_idx_load(h, nullptr));
     for (int i = 0; i < LOGN; i++) gen_and_load_galois_key(c, (1ull << (i + 1)) + 1);
     if (boot) {                                                                                        // main.go:464-507
         printf("Generating bootstrapping keys...\n");
@@ -160,7 +168,7 @@ Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, cons
     }
     return c;
 }
-void freeContext(Context *c) { if (!c) return; freeBoot(c->btp); hc_ctx_destroy(c->hc); delete c; }
+void freeContext(Context *c) { if (!c) return; freeBoot(c->btp); for (size_t g = 1; g < c->shards.size(); g++) hc_ctx_destroy(c->shards[g]); hc_ctx_destroy(c->hc); delete c; }
 
 // ---------------------------------------------------------------- text I/O and float layout
 std::vector<double> readTxt(const std::string &name_file, int size) {      // main.go:971-990
@@ -275,6 +283,8 @@ KerPlain prep_Ker(Context *c, const std::vector<double> &ker_in, const std::vect
     if (trans || pos != 0 || ECD_LV != 1) panic("prep_Ker: only the conv path's (pos=0, trans=false, ECD_LV=1) form is built");
     KerPlain k; k.max_bat = N / (in_wid * in_wid); k.Scale = c->scale;
     HC(c->hc, hc_prep_ker(c->hc, ker_in.data(), (int)ker_in.size(), BN_a.data(), in_wid, ker_wid, real_ib, real_ob, norm, c->scale, &k.h));
+    k.shard_h.push_back(k.h);
+    for (size_t g = 1; g < c->shards.size(); g++) { hc_ker *h = nullptr; HC(c->shards[g], hc_prep_ker(c->shards[g], ker_in.data(), (int)ker_in.size(), BN_a.data(), in_wid, ker_wid, real_ib, real_ob, norm, c->scale, &h)); k.shard_h.push_back(h); }
     return k;
 }
 
@@ -404,6 +414,27 @@ Ciphertext conv_then_pack(Context *c, const Ciphertext &ctxt_in, const KerPlain 
     if (getenv("HCONV_OPWISE")) return conv_then_pack_opwise(c, ctxt_in, pl_ker, max_ob, norm, out_scale);
     auto start = now();
     Ciphertext r; r.d = dev_rows(c, 2); r.level = 0;
+    const int G = (int)c->shards.size();
+    if (G > 1 && norm == 1 && max_ob % G == 0 && (int)pl_ker.shard_h.size() == G) {
+        // ONE convolution over G devices: replicas of the input by peer copies, then hc_conv_then_pack_sharded (channels i mod G per
+        // device, one collection of G x 1 MiB partials on device 0, last log2 G levels there). The two phases overlap across devices,
+        // so "mult time" here is the time to queue the work and "Pack time" the time until the result is complete.
+        std::vector<uint64_t *> rep((size_t)G); std::vector<const uint64_t *> ins((size_t)G);
+        rep[0] = nullptr; ins[0] = ctxt_in.d;
+        for (int g = 1; g < G; g++) { void *p = nullptr; HC(c->shards[(size_t)g], hc_malloc(c->shards[(size_t)g], (size_t)4 * N * 8, &p)); rep[(size_t)g] = (uint64_t *)p; ins[(size_t)g] = rep[(size_t)g];
+                                      HC(c->shards[(size_t)g], hc_copy_peer(c->shards[(size_t)g], p, c->hc, ctxt_in.d, (size_t)4 * N * 8)); }
+        double sc = 0;
+        HC(c->hc, hc_conv_then_pack_sharded(c->shards.data(), G, ins.data(), ctxt_in.Scale, pl_ker.shard_h.data(), pl_ker.Scale, max_ob, out_scale, nullptr, r.d, &sc));
+        printf("\t mult time:  %s\n", dur(start).c_str());
+        auto mt = now();
+        HC(c->hc, hc_sync(c->hc));
+        printf("\t Pack time:  %s\n", dur(mt).c_str());
+        dbg_digest(c, "pack result", r.d, 2);
+        for (int g = 1; g < G; g++) { HC(c->shards[(size_t)g], hc_sync(c->shards[(size_t)g])); HC(c->shards[(size_t)g], hc_free(c->shards[(size_t)g], rep[(size_t)g])); }
+        r.Scale = sc;
+        if (out_scale != r.Scale || 0 != r.level) panic("LV or scale after conv then pack, inconsistent");   // conv.go:541-543
+        return r;
+    }
     // The reference prints "mult time" and "Pack time" separately (conv.go:533,535); run the two phases through
     // the same fused kernels, synchronising in between only to print the split.
     uint64_t *cts = dev_rows(c, (size_t)max_ob * 2);
@@ -446,6 +477,7 @@ Ciphertext evalConv_BN(Context *c, const Ciphertext &ct_input, const std::vector
     HC(c->hc, hc_sync(c->hc));
     printf("Conv (with BN) Done in %s \n", dur(start).c_str());                                                       // eval.go:260
     hc_ker_free(c->hc, pl_ker.h);
+    for (size_t g = 1; g < pl_ker.shard_h.size(); g++) hc_ker_free(c->shards[g], pl_ker.shard_h[g]);
     HC(c->hc, hc_free(c->hc, pl_bn_b.d));
     return ct_res;
 }

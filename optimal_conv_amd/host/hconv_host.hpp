@@ -63,6 +63,8 @@ struct Context {
     int logN = LOGN, Nn = N, ECD_LV = 1;       // main.go:46
     Boot *btp = nullptr;                      // only when newContext(..., boot = true)
     hc_ctx *hc = nullptr;                     // pack_evaluator + evaluator (both run on the same device context)
+    std::vector<hc_ctx *> shards;             // HCONV_GPUS=G > 1: shards[0] = hc, shards[g] = a context on device g (mod the device count)
+                                              // with the same Galois keys: ONE convolution runs i mod G over them (`conv 7 3`)
     std::vector<int64_t> sk;                  // sparse ternary secret, h = 192 (main.go:410)
     std::vector<uint64_t> sk_ntt[3];          // NTT rows mod Q0, Q1, P (host)
     double scale = (double)(1 << 30);
@@ -89,7 +91,7 @@ std::vector<double> DecryptDecodeCoeffs(Context *cont, const Ciphertext &ct);
 void freeCt(Context *cont, Ciphertext &ct);
 
 // kernel plaintexts: handle to the B device-resident plaintexts
-struct KerPlain { hc_ker *h = nullptr; int max_bat = 0; double Scale = 0; };
+struct KerPlain { hc_ker *h = nullptr; int max_bat = 0; double Scale = 0; std::vector<hc_ker *> shard_h; };   // shard_h[g]: the same plaintexts on device g
 KerPlain prep_Ker(Context *cont, const std::vector<double> &ker_in, const std::vector<double> &BN_a, int in_wid, int ker_wid,
                   int real_ib, int real_ob, int norm, int ECD_LV, int pos, bool trans);
 

@@ -37,11 +37,17 @@ def conv_then_pack_sharded(ctx, ct_in_buf, ct_scale, ker_local, ker_scale, B, ou
     ctx._ck(ctx.L.hc_pack_ctxts_strided(ctx.h, p, nloc, log2g, None))
     ctx.sync()
     part = cts[: 2 * N]
-    gathered = [torch.empty(2 * N, dtype=torch.int64, device=device) for _ in range(world)] if rank == 0 else None
+    # gloo moves host memory only: the single-GPU dry run of the N-rank path (ranks share one device, gloo barriers) stages the
+    # 1 MiB partials through the host; over RCCL the CUDA tensors go as they are (xGMI)
+    via_host = part.is_cuda and dist.get_backend(group) == "gloo"
+    xdev = "cpu" if via_host else device
+    if via_host:
+        part = part.cpu()
+    gathered = [torch.empty(2 * N, dtype=torch.int64, device=xdev) for _ in range(world)] if rank == 0 else None
     dist.gather(part, gathered, dst=0, group=group)          # the only exchange: world x 1 MiB
     if rank != 0:
         return None, None
-    allp = torch.cat(gathered)                                  # [world][2][N], slot g = global channel g
+    allp = torch.cat(gathered).to(device)                       # [world][2][N], slot g = global channel g
     if str(device).startswith("cuda"):
         # torch's gather and cat run on torch's stream, the tree below on libhconv's own (possibly non-blocking) stream:
         # everything torch queued must be complete before the library reads `allp`

@@ -191,6 +191,33 @@ def case_conv_batch(ctx, O, max_ob, n, seed=0xBA7C, chunk=None, shared_ker=False
         ctx.ker_free(h)
 
 
+def case_conv_sharded_abi(make_ctx, O, max_ob, G, seed=0x5AAD):
+    """hc_conv_then_pack_sharded: ONE convolution over G contexts (here all on one device; on a node: one per GPU) -- channels i mod G
+    per context, strided local trees, peer copies of the G partials to context 0, last log2 G levels there -- == the oracle."""
+    ctxs = [make_ctx() for _ in range(G)]
+    ct_in, ker = planted_conv_inputs(seed, max_ob)
+    bias = splitmix_rows(seed + 5, Q0, N)
+    evk_all = None
+    ins, hk = [], []
+    for c in ctxs:
+        evk_all = load_tree_keys(c, seed, max_ob, 1)
+        c.idx_load(None)
+        ins.append(c.buf(ct_in)); hk.append(c.ker_load(ker))
+    bb = ctxs[0].buf(bias); out = ctxs[0].buf(nwords=2 * N)
+    sc = ctxs[0].conv_then_pack_sharded_dev(ctxs, ins, 2.0 ** 30, hk, 2.0 ** 30, max_ob, 2.0 ** 30, bb, out)
+    got = out.download((2, N))
+    want, wsc = O.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, O.idx_plaintexts(), evk_all, max_ob, 1, 2.0 ** 30, bias)
+    assert sc == wsc
+    eq(got, want, f"hc_conv_then_pack_sharded B={max_ob} G={G}")
+    # a second call on the same contexts (workspaces reused, events re-recorded) must give the same bits
+    ctxs[0].conv_then_pack_sharded_dev(ctxs, ins, 2.0 ** 30, hk, 2.0 ** 30, max_ob, 2.0 ** 30, bb, out)
+    eq(out.download((2, N)), want, f"hc_conv_then_pack_sharded B={max_ob} G={G}, second call")
+    for c, h in zip(ctxs, hk):
+        c.ker_free(h)
+    for c in ctxs:
+        c.close()
+
+
 def case_conv_phases(ctx, O, max_ob=4, seed=0xF00D):
     """loop A and loop B separately (hc_conv_mult_phase / hc_pack_ctxts)"""
     ct_in, ker = planted_conv_inputs(seed, max_ob)

@@ -85,6 +85,12 @@ def test_conv_batch(env, max_ob, n, chunk, shared):
     pc.case_conv_batch(*env, max_ob, n, chunk=chunk, shared_ker=shared)
 
 
+@pytest.mark.parametrize("max_ob,G", [(8, 2), (8, 4), (4, 4)])
+def test_conv_sharded_over_contexts(env, max_ob, G):
+    """hc_conv_then_pack_sharded over G contexts (the C-ABI form of BASELINE config 3's decomposition) on the emulated kernels"""
+    pc.case_conv_sharded_abi(lambda: Context([Q0, Q1], [P0], lib_path=EMU_LIB), env[1], max_ob, G)
+
+
 def test_keyswitch_general():
     """general hybrid key switch (BL: level 1, two P primes; bootstrapping shapes) on the emulated kernels"""
     subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])

@@ -195,6 +195,14 @@ def test_conv_batch(env, max_ob, n, chunk, shared):
     pc.case_conv_batch(*env, max_ob, n, chunk=chunk, shared_ker=shared)
 
 
+@pytest.mark.parametrize("max_ob,G", [(16, 4), (256, 8)])
+def test_conv_sharded_over_contexts_on_gpu(env, max_ob, G):
+    """hc_conv_then_pack_sharded: BASELINE config 3's shape (B = 256 channels over 8 device contexts, peer copies of the 8 partials,
+    last 3 levels on context 0) through the C ABI -- the 8 contexts share this box's one GPU -- bit-exact vs the oracle"""
+    from optimal_conv_amd import Context
+    pc.case_conv_sharded_abi(lambda: Context([Q0, Q1], [P0]), env[1], max_ob, G)
+
+
 def test_keyswitch_general_on_gpu():
     """8f groundwork: the general hybrid key switch (any level, alpha P primes) vs the oracle, which is itself pinned
     against the reference binary's BL and bootstrapping key switches (tests/test_oracle_pin_keyswitch.py)"""

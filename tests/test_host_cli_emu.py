@@ -73,3 +73,18 @@ def test_opwise_evaluator_path_equals_fused(cli, tmp_path):
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append(re.search(r"^ciphertext digest: ([0-9a-f]{16})$", out.stdout, re.M).group(1))
     assert digests[0] == digests[1]
+
+
+def test_conv_cli_sharded_over_contexts_same_ciphertext(cli, tmp_path):
+    """HCONV_GPUS=G: the CLI shards every convolution i mod G over G device contexts (hc_conv_then_pack_sharded; on a one-device box
+    the contexts share the device). Same seed => the same ciphertext, bit for bit, as the unsharded run."""
+    gen.write_case(str(tmp_path / "test_conv_data"), 3, 0, 0)
+    digests = []
+    for extra in ({}, {"HCONV_GPUS": "4"}):
+        out = subprocess.run([cli, "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=1200,
+                             env=dict(os.environ, HCONV_SEED="77", HCONV_PRINT_DIGEST="1", HCONV_SKIP_BL="1", **extra))
+        assert out.returncode == 0, out.stderr[-2000:]
+        if extra:
+            assert "Sharding every convolution over 4 device contexts" in out.stdout
+        digests.append(re.search(r"^ciphertext digest: ([0-9a-f]{16})$", out.stdout, re.M).group(1))
+    assert digests[0] == digests[1]
