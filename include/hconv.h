@@ -193,6 +193,20 @@ int hc_pack_ctxts(hc_ctx *ctx, uint64_t *cts, int max_cnum, int real_cnum);
  * row mod Q0 or NULL) is added to the result as eval.go:258 does. */
 int hc_pack_ctxts_strided(hc_ctx *ctx, uint64_t *cts, int count, int stride_log2, const uint64_t *bias);
 
+/* ---- slot encoder: ckks.Encoder.Encode (+ ToNTT = EncodeNTT), full slots (conv.go:165-166, eval.go:102; the BL baseline's plaintexts) ----
+ * values: DEVICE [count][N/2] complex128 as (re, im) pairs; OVERWRITTEN (Lattigo's special inverse FFT runs in place). scale as in
+ * Encode; level: rows 0..level (moduli 0..level) are produced; to_ntt != 0: the rows are left in the NTT domain. out: DEVICE
+ * [count][level+1][N]. IEEE fp64 without contraction in the reference's operand order: the same residues as the CPU encoder. */
+int hc_encode_slots(hc_ctx *ctx, double *values, int count, int level, double scale, int to_ntt, uint64_t *out);
+/* conv.go:167-172 in one launch: out[2][level+1][N] = sum over t < ntaps (<= 64) of ciphertext cts[t] ([2][level+1][N], device) x
+ * plaintext pts[t] ([level+1][N], NTT domain, device [ntaps][level+1][N]); cts is a HOST array of device pointers. Exact modular
+ * sums: the same residues as the reference's MulNew + Add chain. */
+int hc_lv_mul_sum(hc_ctx *ctx, int level, const uint64_t *const *cts, const uint64_t *pts, int ntaps, uint64_t *out);
+/* conv.go:150-164 on the device: the slot vectors `postKer` of all ker_wid^2 kernel taps of output rotation `rot`, from
+ * max_ker_rs = reshape_ker_BL's [ker_wid][ker_wid][max_batch][max_batch] doubles (DEVICE); values_out: DEVICE [ker_wid^2][N/2][2] */
+int hc_bl_post_ker_slots(hc_ctx *ctx, const double *max_ker_rs, int in_wid, int ker_wid, int pad, int max_batch, int rot,
+                         double *values_out);
+
 /* ---- tuning / measurement ---- */
 int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes", "lanes", "profile", "ks_fused" */
 /* HIP-event timing on the context's stream */

@@ -68,6 +68,9 @@ SYMBOLS = {
                                           C.c_double, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_double)]),
     "hc_conv_then_pack_sharded": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_double, C.POINTER(C.c_void_p), C.c_double, C.c_int,
                                             C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "hc_encode_slots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
+    "hc_bl_post_ker_slots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hc_lv_mul_sum": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p]),
     "hc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "hc_copy_peer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "hc_conv_mult_phase": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double,
@@ -417,6 +420,17 @@ class Context:
         sc = C.c_double(0)
         self._ck(self.L.hc_conv_then_pack_batch(self.h, n, cin, ct_scale, ck, ker_scale, max_ob, norm, out_scale, cb, co, C.byref(sc)))
         return sc.value
+
+    def encode_slots(self, values, level, scale, to_ntt=True):
+        """hc_encode_slots: values complex128 [count][N/2] (host) -> uint64 [count][level+1][N]"""
+        v = np.ascontiguousarray(values, dtype=np.complex128).reshape(-1, self.N // 2)
+        count = v.shape[0]
+        dv = self.buf(v.view(np.float64).reshape(-1).view(np.uint64))
+        out = self.buf(nwords=count * (level + 1) * self.N)
+        self._ck(self.L.hc_encode_slots(self.h, dv.ptr, count, level, scale, 1 if to_ntt else 0, out.ptr))
+        res = out.download((count, level + 1, self.N))
+        dv.free(); out.free()
+        return res
 
     @staticmethod
     def conv_then_pack_sharded_dev(ctxs, ct_in_bufs, ct_scale, kers, ker_scale, max_ob, out_scale, bias_buf, out_buf):

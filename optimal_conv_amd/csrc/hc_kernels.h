@@ -1050,3 +1050,111 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rescale_finish_mm(const u64 *x, s
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
         out[b + j] = hc_mul_shoup(hc_submod(x[b + j], u[b + j], q), w.w, w.ws, q);
 }
+
+// ================================================================ slot encoder (ckks.Encoder.Encode / EncodeNTT, full slots)
+// Lattigo's "special" inverse FFT over the rotation group 5^j (encoder.go invfft; restated on the host in hconv_encoder.hpp and, for
+// the tests, in tests/oracle_bl.py): n = N/2 = 2^15 complex values, stages len = n .. 2 (distance len/2, large first), butterfly
+//     u = a + b ;  w = (a - b) * roots[(4 len - rotGroup[j] mod 4 len) * (2N / 4 len)],   j = position inside the block,
+// then division by n, the bit-reversal permutation, real parts -> coefficients [0, n), imaginary parts -> [n, N), and
+// scaleUpVecExact's rounding (uint64(|v| * scale + 0.5) mod q, q - . for negative v). Plain IEEE fp64 with NO contraction and the
+// reference's operand order, so the doubles -- and therefore the residues -- are the ones the reference's Go code produces: the
+// root table comes from hc_gomath.h (math.Cos / math.Sin as Go's runtime evaluates them; SHA-256 equal to the table inside the
+// reference binary), and tests/test_oracle_pin_encoder.py pins the oracle this kernel is compared with to the binary's own
+// invfft / Encode digests. n is viewed as 128 rows x 256 columns: pass A runs the 7 stages that pair
+// rows (tile = 128 rows x 16 columns = 32 KiB of LDS), pass B the 8 stages inside a row (tile = 8 rows x 256 columns).
+struct HcCplx { double re, im; };
+struct HcSlotEnc { const HcCplx *roots; const int *rot_group; };     // roots[0 .. 2N], rot_group[0 .. N/2)
+__device__ __forceinline__ void hc_sfft_inv_bfly(HcCplx &a, HcCplx &b, const HcSlotEnc &E, int j, int len) {
+#pragma clang fp contract(off)
+    const int lenq = len << 2, gap = 131072 / lenq;
+    const HcCplx r = E.roots[(lenq - (E.rot_group[j] % lenq)) * gap];
+    const double ur = a.re + b.re, ui = a.im + b.im, dr = a.re - b.re, di = a.im - b.im;
+    const double p0 = dr * r.re, p1 = di * r.im, p2 = dr * r.im, p3 = di * r.re;
+    a.re = ur; a.im = ui; b.re = p0 - p1; b.im = p2 + p3;
+}
+// pass A: grid = (16 column tiles, count); in/out: [count][32768] complex, in place allowed
+__global__ __launch_bounds__(HC_TPB) void hc_k_sfft_inv_a(const HcCplx *in, HcCplx *out, HcSlotEnc E) {
+    __shared__ HcCplx lds[2048];                       // [128 rows][16 columns]
+    const int t = threadIdx.x, c0 = blockIdx.x * 16;
+    const size_t base = (size_t)blockIdx.y * 32768;
+    for (int e = t; e < 2048; e += HC_TPB) { const int r = e >> 4, c = e & 15; lds[e] = in[base + (size_t)r * 256 + c0 + c]; }
+    __syncthreads();
+    for (int Lh = 64; Lh >= 1; Lh >>= 1) {             // distance in rows; len = 2 * Lh * 256
+        for (int b = t; b < 1024; b += HC_TPB) {
+            const int c = b & 15, q = b >> 4;          // q: butterfly number among the 64 of a column
+            const int blk = q / Lh, rr = q - blk * Lh, r = blk * 2 * Lh + rr;
+            hc_sfft_inv_bfly(lds[r * 16 + c], lds[(r + Lh) * 16 + c], E, rr * 256 + c0 + c, 2 * Lh * 256);
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < 2048; e += HC_TPB) { const int r = e >> 4, c = e & 15; out[base + (size_t)r * 256 + c0 + c] = lds[e]; }
+}
+// pass B: grid = (16 row tiles, count)
+__global__ __launch_bounds__(HC_TPB) void hc_k_sfft_inv_b(const HcCplx *in, HcCplx *out, HcSlotEnc E) {
+    __shared__ HcCplx lds[2048];                       // [8 rows][256 columns]
+    const int t = threadIdx.x;
+    const size_t base = (size_t)blockIdx.y * 32768 + (size_t)blockIdx.x * 2048;
+    for (int e = t; e < 2048; e += HC_TPB) lds[e] = in[base + e];
+    __syncthreads();
+    for (int lenh = 128; lenh >= 1; lenh >>= 1) {
+        for (int b = t; b < 1024; b += HC_TPB) {
+            const int row = b >> 7, q = b & 127;       // 128 butterflies per row
+            const int blk = q / lenh, j = q - blk * lenh, cidx = blk * 2 * lenh + j;
+            hc_sfft_inv_bfly(lds[row * 256 + cidx], lds[row * 256 + cidx + lenh], E, j, 2 * lenh);
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < 2048; e += HC_TPB) out[base + e] = lds[e];
+}
+// division by n, bit reversal, real | imaginary split, scaleUpVecExact: w [count][32768] complex -> rows [count][nl][N], coefficient
+// domain, modulus of row l = mods[l]. grid = (64, count)
+__global__ __launch_bounds__(HC_TPB) void hc_k_slots_round(const HcCplx *w, u64 *out, const HcMod *mods, int nl, double scale) {
+#pragma clang fp contract(off)
+    const HcCplx *v = w + (size_t)blockIdx.y * 32768; u64 *o = out + (size_t)blockIdx.y * nl * 65536;
+    for (int i = blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += gridDim.x * HC_TPB) {
+        const int tix = i & 32767, src = (int)(__brev((u32)tix) >> 17);
+        const double val = (i < 32768 ? v[src].re : v[src].im) * (1.0 / 32768.0);       // exact: a power of two
+        const bool neg = val < 0; const double x = neg ? -scale * val : scale * val;
+        for (int l = 0; l < nl; l++) {
+            const u64 q = mods[l].q; u64 r;
+            if (x > 1.8446744073709552e+19) {           // above 2^64: the 53-bit mantissa times 2^(e - 53), reduced by doubling
+                int e2; const double mant = frexp(x + 0.5, &e2); const u64 mi = (u64)ldexp(mant, 53); r = mi % q;
+                for (int sft = 0; sft < e2 - 53; sft++) { r += r; if (r >= q) r -= q; }
+            } else r = (u64)(x + 0.5) % q;
+            o[(size_t)l * 65536 + i] = neg ? q - r : r;          // q itself when r == 0, as scaleUpVecExact leaves it (the NTT maps it to the same row as 0)
+        }
+    }
+}
+// conv.go:150-164 on the device: the slot vectors postKer of ALL kernel taps (i, j) of one output rotation `rot`
+//   postKer[k*in_wid^2 + ki*in_wid + kj] = max_ker_rs[i][j][k][(k - rot) mod max_batch]  when tap (i, j) of position (ki, kj) lies
+//   inside the (in_wid - pad)^2 image, else 0.        out: [ker_wid^2][32768] complex (imaginary parts 0). grid = (128, ker_wid^2)
+__global__ __launch_bounds__(HC_TPB) void hc_k_bl_post_ker(const double *max_ker_rs, HcCplx *out, int in_wid, int ker_wid, int pad, int max_batch, int rot) {
+    const int tap = blockIdx.y, i = tap / ker_wid, j = tap - i * ker_wid, in_sz = in_wid * in_wid, lim = in_wid - pad, h = ker_wid / 2;
+    for (int s = blockIdx.x * HC_TPB + threadIdx.x; s < 32768; s += gridDim.x * HC_TPB) {
+        const int k = s / in_sz, rem = s - k * in_sz, ki = rem / in_wid, kj = rem - ki * in_wid;
+        double v = 0.0;
+        if (k < max_batch && ki < lim && kj < lim) {
+            const bool out_of_range = (ki + i - h < 0) || (ki + i - h >= lim) || (kj + j - h < 0) || (kj + j - h >= lim);
+            if (!out_of_range) v = max_ker_rs[(((size_t)i * ker_wid + j) * max_batch + k) * max_batch + (size_t)((k - rot + max_batch) % max_batch)];
+        }
+        HcCplx c; c.re = v; c.im = 0.0; out[(size_t)tap * 32768 + s] = c;
+    }
+}
+
+// sum over taps of ciphertext x plaintext (conv.go:168-171: MulNew for every kernel tap, Add into the accumulator): out[p][l] =
+// sum_t ct_t[p][l] (*) pt_t[l] mod q_l for both polynomials p and all limbs l of a level in ONE launch. Exact modular sums, so the
+// result equals the reference's chain of MulNew / Add whatever the order. grid = (64, level + 1, 2)
+#define HC_MAXTAPS 64
+struct HcTapPtrs { const u64 *ct[HC_MAXTAPS]; };
+__global__ __launch_bounds__(HC_TPB) void hc_k_lv_mul_sum(HcTapPtrs cts, const u64 *pts, int ntaps, int nl, u64 *out, const HcMod *mods) {
+    const int l = blockIdx.y, p = blockIdx.z; const HcMod m = mods[l];
+    const size_t row = ((size_t)p * nl + l) * 65536;
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
+        u64 acc = 0;
+        for (int t = 0; t < ntaps; t++) {
+            const u64 y = hc_mont(pts[((size_t)t * nl + l) * 65536 + i], m.r2, m.q, m.qinv);                     // MForm, as MulNew does
+            acc = hc_addmod(acc, hc_mont(cts.ct[t][row + i], y, m.q, m.qinv), m.q);
+        }
+        out[row + i] = acc;
+    }
+}

@@ -19,6 +19,7 @@
 
 #include "../../include/hconv.h"
 #include "hc_kernels.h"
+#include "hc_gomath.h"
 
 #define HC_N 65536
 #define HC_LOGN 16
@@ -106,6 +107,7 @@ struct hc_ctx {
     long lanes = 1;               // internal concurrency of ONE conv_then_pack (power of two; 1 = single stream)
     std::vector<HcLane> lane;
     hipEvent_t ev_fork = nullptr;
+    HcCplx *enc_roots = nullptr; int *enc_rot_group = nullptr;      // slot encoder tables (hc_encode_slots), built at first use
     hipEvent_t ev_shard = nullptr;     // hc_conv_then_pack_sharded: this device's partial ciphertext is complete / has been collected
     u64 *ws_gather = nullptr; size_t ws_gather_rows = 0;
     long profile = 0;
@@ -342,6 +344,7 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
         if (L.done) D(hipEventDestroy(L.done), "hipEventDestroy");
         if (L.stream) D(hipStreamDestroy(L.stream), "hipStreamDestroy");
     }
+    F(c->enc_roots); F(c->enc_rot_group);
     F(c->ws_ctc); F(c->ws_tmp); F(c->d_mods); F(c->d_rowmods); F(c->ws_mm);
     for (auto &kv : c->ks_plan) { F(kv.second.bx); F(kv.second.bxdown); F(kv.second.pinv); }
     for (auto &kv : c->rescale_plan) F(kv.second);
@@ -1342,6 +1345,49 @@ extern "C" int hc_conv_then_pack_sharded(hc_ctx *const *ctxs, int G, const uint6
     HC_HIP(c0, hipMemcpyAsync(ct_out, c0->ws_gather, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c0->stream));
     if (scale_out) *scale_out = out_scale;
     return HC_OK;
+}
+
+// ------------------------------------------------------------------ slot encoder (ckks.Encoder.EncodeNTT), BL baseline's plaintexts
+static int hc_enc_tables(hc_ctx *c) {
+    if (c->enc_roots) return HC_OK;
+    const int m = 2 * HC_N, slots = HC_N / 2;
+    std::vector<HcCplx> roots((size_t)m + 1); std::vector<int> rg((size_t)slots);
+    for (int i = 0; i < m; i++) { const double angle = 2 * 3.141592653589793 * (double)i / (double)m; roots[(size_t)i].re = hc_gomath::go_cos(angle); roots[(size_t)i].im = hc_gomath::go_sin(angle); }   // ckks.NewEncoder, with Go's own math.Cos / math.Sin
+    roots[(size_t)m] = roots[0];
+    int g = 1; for (int i = 0; i < slots; i++) { rg[(size_t)i] = g; g = (int)(((long)g * 5) % m); }
+    HcScratch S(c);
+    HC_HIP(c, S.alloc(&c->enc_roots, roots.size() * sizeof(HcCplx))); HC_HIP(c, S.alloc(&c->enc_rot_group, rg.size() * sizeof(int)));
+    HC_HIP(c, hcx_h2d(c, c->enc_roots, roots.data(), roots.size() * sizeof(HcCplx)));
+    HC_HIP(c, hcx_h2d(c, c->enc_rot_group, rg.data(), rg.size() * sizeof(int)));
+    S.keep(c->enc_roots); S.keep(c->enc_rot_group);
+    return HC_OK;
+}
+// values: DEVICE [count][N/2] complex128 (re, im); overwritten (the transform runs in place). out: DEVICE [count][level+1][N]
+extern "C" int hc_encode_slots(hc_ctx *c, double *values, int count, int level, double scale, int to_ntt, uint64_t *out) {
+    HC_ENTER(c);
+    if (!values || !out || count < 1 || count > 65535 || level < 0 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "hc_encode_slots: bad arguments");
+    HC_TRY(hc_enc_tables(c));
+    HcSlotEnc E; E.roots = c->enc_roots; E.rot_group = c->enc_rot_group;
+    HcCplx *v = (HcCplx *)values;
+    HC_TRY(hc_launch(c, "sfft_inv_a", hc_k_sfft_inv_a, dim3(16, (unsigned)count), (const HcCplx *)v, v, E));
+    HC_TRY(hc_launch(c, "sfft_inv_b", hc_k_sfft_inv_b, dim3(16, (unsigned)count), (const HcCplx *)v, v, E));
+    HC_TRY(hc_launch(c, "slots_round", hc_k_slots_round, dim3(64, (unsigned)count), (const HcCplx *)v, (u64 *)out, (const HcMod *)c->d_mods, level + 1, scale));
+    if (to_ntt) { c->hoist_cx = nullptr; HC_TRY(hc_ntt_mm(c, (const u64 *)out, (u64 *)out, level + 1, level + 1, 0, 0, count, (size_t)(level + 1) * HC_N, (size_t)(level + 1) * HC_N)); }
+    return HC_OK;
+}
+// out[2][level+1][N] = sum over t < ntaps of cts[t] (ciphertext [2][level+1][N]) x pts[t] (plaintext [level+1][N], NTT domain): the
+// MulNew / Add chain of conv.go:167-172 in one launch. cts: HOST array of ntaps device pointers; pts: device, [ntaps][level+1][N]
+extern "C" int hc_lv_mul_sum(hc_ctx *c, int level, const uint64_t *const *cts, const uint64_t *pts, int ntaps, uint64_t *out) {
+    HC_ENTER(c);
+    if (!cts || !pts || !out || ntaps < 1 || ntaps > HC_MAXTAPS || level < 0 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "hc_lv_mul_sum: bad arguments (1 <= ntaps <= %d)", HC_MAXTAPS);
+    HcTapPtrs T; memset(&T, 0, sizeof T);
+    for (int t = 0; t < ntaps; t++) { if (!cts[t]) return hc_fail(c, HC_ERR_ARG, "hc_lv_mul_sum: null ciphertext %d", t); T.ct[t] = (const u64 *)cts[t]; }
+    return hc_launch(c, "lv_mul_sum", hc_k_lv_mul_sum, dim3(64, (unsigned)(level + 1), 2), T, (const u64 *)pts, ntaps, level + 1, (u64 *)out, (const HcMod *)c->d_mods);
+}
+extern "C" int hc_bl_post_ker_slots(hc_ctx *c, const double *max_ker_rs, int in_wid, int ker_wid, int pad, int max_batch, int rot, double *values_out) {
+    HC_ENTER(c);
+    if (!max_ker_rs || !values_out || in_wid < 1 || ker_wid < 1 || max_batch < 1 || (long)max_batch * in_wid * in_wid > HC_N / 2) return hc_fail(c, HC_ERR_ARG, "hc_bl_post_ker_slots: bad arguments");
+    return hc_launch(c, "bl_post_ker", hc_k_bl_post_ker, dim3(128, (unsigned)(ker_wid * ker_wid)), max_ker_rs, (HcCplx *)values_out, in_wid, ker_wid, pad, max_batch, rot);
 }
 
 // ------------------------------------------------------------------ options / timing

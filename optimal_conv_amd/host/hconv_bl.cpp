@@ -178,24 +178,18 @@ static std::vector<BLCt> preConv_BL(BLContext *c, const BLCt &ct_in, int in_wid,
     HCB(c->hc, hc_free(c->hc, d));
     return rots;
 }
-static BLCt postConv_BL(BLContext *c, const Encoder &enc, const std::vector<BLCt> &ct_in_rots, int in_wid, int ker_wid, int rot, int pad, const Ker4 &max_ker_rs, int max_batch) {
-    const int slots = N / 2; std::vector<cplx> postKer((size_t)slots);
-    uint64_t *pl = bl_rows(c, 2); BLCt ct_out; int iter = 0;
-    for (int i = 0; i < ker_wid; i++) for (int j = 0; j < ker_wid; j++) {
-        std::fill(postKer.begin(), postKer.end(), cplx(0, 0));
-        for (int k = 0; k < max_batch; k++) for (int ki = 0; ki < in_wid - pad; ki++) for (int kj = 0; kj < in_wid - pad; kj++) {
-            const bool out_of_range = (ki + i - ker_wid / 2 < 0) || (ki + i - ker_wid / 2 >= in_wid - pad) || (kj + j - ker_wid / 2 < 0) || (kj + j - ker_wid / 2 >= in_wid - pad);
-            postKer[(size_t)(k * in_wid * in_wid + ki * in_wid + kj)] = out_of_range ? cplx(0, 0)
-                : cplx(max_ker_rs[(((size_t)i * ker_wid + j) * max_batch + k) * max_batch + (size_t)((k - rot + max_batch) % max_batch)], 0);
-        }
-        std::vector<uint64_t> rows = enc.Encode(postKer, c->scale, BLQ, 2);                                   // conv.go:165
-        HCB(c->hc, hc_upload(c->hc, pl, rows.data(), rows.size() * 8));
-        for (int l = 0; l < 2; l++) HCB(c->hc, hc_ntt(c->hc, l, pl + (size_t)l * N, pl + (size_t)l * N, 1));   // conv.go:166
-        BLCt term = MulNew(c, ct_in_rots[(size_t)iter], pl, c->scale);
-        if (i == 0 && j == 0) ct_out = term; else { Add(c, ct_out, term, ct_out); bl_free(c, term); }
-        iter++;
-    }
-    HCB(c->hc, hc_free(c->hc, pl));
+// conv.go:146-178 for one output rotation. The k^2 plaintexts of a rotation are built ON THE DEVICE: hc_bl_post_ker_slots writes the slot
+// vectors postKer (conv.go:150-164) from the device copy of max_ker_rs, hc_encode_slots runs Lattigo's encoder (special inverse FFT in
+// fp64, scaleUpVecExact, ToNTT: conv.go:165-166) on all of them at once -- the same residues the host encoder produces (both are compared
+// with the oracle that is pinned to the reference binary's own Encode digests).
+static BLCt postConv_BL(BLContext *c, const std::vector<BLCt> &ct_in_rots, int in_wid, int ker_wid, int rot, int pad, const double *d_max_ker_rs, int max_batch, double *d_slots, uint64_t *d_pl) {
+    const int taps = ker_wid * ker_wid;
+    HCB(c->hc, hc_bl_post_ker_slots(c->hc, d_max_ker_rs, in_wid, ker_wid, pad, max_batch, rot, d_slots));
+    HCB(c->hc, hc_encode_slots(c->hc, d_slots, taps, 1, c->scale, 1, d_pl));                              // conv.go:165-166 for every tap
+    BLCt ct_out = bl_alloc(c, ct_in_rots[0].Scale * c->scale);                                             // conv.go:167-172: MulNew per tap, Add
+    std::vector<const uint64_t *> cts((size_t)taps);
+    for (int it = 0; it < taps; it++) cts[(size_t)it] = ct_in_rots[(size_t)it].d;
+    HCB(c->hc, hc_lv_mul_sum(c->hc, 1, cts.data(), d_pl, taps, ct_out.d));
     return ct_out;
 }
 static BLCt evalConv_BN_BL_test(BLContext *c, const Encoder &enc, const BLCt &ct_input, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
@@ -209,8 +203,13 @@ static BLCt evalConv_BN_BL_test(BLContext *c, const Encoder &enc, const BLCt &ct
     for (size_t i = 0; i < bn_b.size(); i++) for (int j = 0; j < in_wid - pad; j++) for (int k = 0; k < in_wid - pad; k++)
         bn_b_slots[(size_t)(j + k * in_wid + norm * out_size * (int)i)] = cplx(bn_b[i], 0);             // eval.go:93-99
     uint64_t *pl_bn_b = bl_rows(c, 2);
-    { std::vector<uint64_t> rows = enc.Encode(bn_b_slots, scale_exp, BLQ, 2); HCB(c->hc, hc_upload(c->hc, pl_bn_b, rows.data(), rows.size() * 8));
-      for (int l = 0; l < 2; l++) HCB(c->hc, hc_ntt(c->hc, l, pl_bn_b + (size_t)l * N, pl_bn_b + (size_t)l * N, 1)); }   // eval.go:101-102 EncodeNTT
+    const int taps = ker_wid * ker_wid;
+    void *vp = nullptr; HCB(c->hc, hc_malloc(c->hc, (size_t)taps * (N / 2) * 16, &vp)); double *d_slots = (double *)vp;     // [taps][N/2] complex128
+    HCB(c->hc, hc_malloc(c->hc, max_ker_rs.size() * sizeof(double), &vp)); double *d_ker = (double *)vp;
+    HCB(c->hc, hc_upload(c->hc, d_ker, max_ker_rs.data(), max_ker_rs.size() * sizeof(double)));
+    uint64_t *d_pl = bl_rows(c, (size_t)taps * 2);
+    HCB(c->hc, hc_upload(c->hc, d_slots, bn_b_slots.data(), bn_b_slots.size() * 16));
+    HCB(c->hc, hc_encode_slots(c->hc, d_slots, 1, 1, scale_exp, 1, pl_bn_b));                                          // eval.go:101-102 EncodeNTT
     printf("Plaintext (kernel) preparation, Done in %s \n", dur(start).c_str());
     start = now();
     std::vector<BLCt> ct_inputs_rots = preConv_BL(c, ct_input, in_wid, ker_wid);
@@ -219,7 +218,7 @@ static BLCt evalConv_BN_BL_test(BLContext *c, const Encoder &enc, const BLCt &ct
     const int rot_iters = (norm * real_ob == max_batch) ? real_ob : max_batch;
     BLCt ct_res;
     for (int i = 0; i < rot_iters; i++) {
-        BLCt ct_tmp = postConv_BL(c, enc, ct_inputs_rots, in_wid, ker_wid, norm * i, pad, max_ker_rs, max_batch);
+        BLCt ct_tmp = postConv_BL(c, ct_inputs_rots, in_wid, ker_wid, norm * i, pad, d_ker, max_batch, d_slots, d_pl);
         if (i == 0) ct_res = ct_tmp;
         else { BLCt r = RotateNew(c, ct_tmp, norm * i * out_size); Add(c, ct_res, r, ct_res); bl_free(c, r); bl_free(c, ct_tmp); }   // eval.go:123
     }
@@ -228,7 +227,8 @@ static BLCt evalConv_BN_BL_test(BLContext *c, const Encoder &enc, const BLCt &ct
     HCB(c->hc, hc_sync(c->hc));
     printf("Conv (with BN) Done in %s \n", dur(start).c_str());
     for (auto &r : ct_inputs_rots) bl_free(c, r);
-    HCB(c->hc, hc_free(c->hc, pl_bn_b));
+    HCB(c->hc, hc_free(c->hc, pl_bn_b)); HCB(c->hc, hc_free(c->hc, d_slots)); HCB(c->hc, hc_free(c->hc, d_ker)); HCB(c->hc, hc_free(c->hc, d_pl));
+    (void)enc;
     return ct_res;
 }
 

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "hconv_host.hpp"
+#include "../csrc/hc_gomath.h"
 
 namespace hconv {
 typedef std::complex<double> cplx;
@@ -20,7 +21,10 @@ struct Encoder {
         const int slots = N / 2, m = 2 * N;
         rotGroup.resize((size_t)slots); int g = 1; for (int i = 0; i < slots; i++) { rotGroup[(size_t)i] = g; g = (int)(((long)g * 5) % m); }
         roots.resize((size_t)m + 1);
-        for (int i = 0; i <= m; i++) { double angle = 2 * 3.141592653589793 * (double)i / (double)m; roots[(size_t)i] = cplx(cos(angle), sin(angle)); }
+        // ckks.NewEncoder: roots[i] = complex(math.Cos(angle), math.Sin(angle)) with GO's math library (hc_gomath.h restates it; the C
+        // library's cos / sin differ in the last bit for ~40 % of the entries), roots[m] = roots[0]
+        for (int i = 0; i < m; i++) { double angle = 2 * 3.141592653589793 * (double)i / (double)m; roots[(size_t)i] = cplx(hc_gomath::go_cos(angle), hc_gomath::go_sin(angle)); }
+        roots[(size_t)m] = roots[0];
         brev.resize((size_t)slots); for (int i = 0; i < slots; i++) { int r = 0; for (int b = 0; b < logn - 1; b++) r |= ((i >> b) & 1) << (logn - 2 - b); brev[(size_t)i] = r; }
     }
     void invfft(std::vector<cplx> &v) const {
@@ -62,7 +66,7 @@ struct Encoder {
                 uint64_t r;
                 if (x > 1.8446744073709552e+19) { int e2; double mant = frexp(x + 0.5, &e2); uint64_t mi = (uint64_t)ldexp(mant, 53); r = mi % BLQ[l]; for (int s = 0; s < e2 - 53; s++) { r += r; if (r >= BLQ[l]) r -= BLQ[l]; } }
                 else r = (uint64_t)(x + 0.5) % BLQ[l];
-                out[(size_t)l * N + (size_t)i] = (neg && r) ? BLQ[l] - r : r;
+                out[(size_t)l * N + (size_t)i] = neg ? BLQ[l] - r : r;      // BLQ[l] itself when r == 0, as scaleUpVecExact leaves it
             }
         }
         return out;

@@ -212,6 +212,8 @@ static void plant_row(uint64_t rowptr, uint64_t seed, uint64_t q) {
 #define A_MULRELIN           0x522c7bull  /* ckks.(*evaluator).mulRelin (behind Mul / MulRelin / MulNew / MulRelinNew) */
 #define A_ROTATE             0x524438ull  /* ckks.(*evaluator).Rotate(ct0, k, ctOut) */
 #define A_MODUP              0x50741bull  /* ckks.(*Bootstrapper).modUp(ct) *Ciphertext */
+#define A_INVFFT             0x5185d3ull  /* ckks.invfft(values []complex128, N, M uint64, rotGroup []uint64, roots []complex128) */
+#define A_ENCODE             0x514cf3ull  /* ckks.(*encoderComplex128).Encode(pt *Plaintext, values []complex128, logSlots uint64) */
 #define A_TYPE_FLOAT64       0x570a20ull  /* runtime type descriptor of float64 (seen in the interface word) */
 
 static const uint64_t Q0 = 0x80000000080001ull, Q1 = 0x1ffffffea0001ull, P0 = 0x1fffffffffe00001ull;
@@ -461,6 +463,44 @@ static void on_encode(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; 
     if (g_lean && g_encode_calls >= 24) { g_encode_calls++; return; }
     hook_return(r, ret_encode, ud_new(rd64(r->rsp + 0x28), (uint64_t)g_encode_calls++, rd64(r->rsp + 0x18))); }
 
+/* -enc N: the slot encoder of the BL baseline run (needs -keep-bl): the first N ckks.invfft calls -- SHA-256 of the complex128
+ * input and output vectors, and once of the encoder's root table (math.Cos / math.Sin of Go's runtime) and rotation group -- and
+ * the plaintext every Encode call leaves (coefficient domain, scaleUpVecExact applied). Nothing is planted: the data are the
+ * run's own (the CSVs tests/golden/gen_conv_csv.py writes), which the oracle regenerates. */
+static int g_enc_max = 0, g_enc_calls = 0, g_encode_slots_calls = 0;
+static void sha_mem(uint64_t addr, uint64_t bytes, char hex[65]) {
+    sha256_t s; sha_init(&s); uint8_t buf[65536];
+    while (bytes) { size_t k = bytes > sizeof buf ? sizeof buf : (size_t)bytes; rd(addr, buf, k); sha_update(&s, buf, k); addr += k; bytes -= k; }
+    sha_final(&s, hex);
+}
+static void enc_done_check(void) { if (g_enc_calls >= g_enc_max && g_encode_slots_calls >= g_enc_max) { fprintf(g_out, "\n ],\n \"exit_code\": 0}\n"); fflush(g_out); kill(g_pid, SIGKILL); exit(0); } }
+static void ret_invfft(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
+    ud3_t *u = ud; char hex[65]; sha_mem(u->a, u->b * 16, hex);
+    double head[4]; rd(u->a, head, 32);
+    fprintf(g_out, ", \"out\": \"%s\", \"out_head\": [%.17g, %.17g, %.17g, %.17g]", hex, head[0], head[1], head[2], head[3]); emit_end(); enc_done_check(); }
+static void on_invfft(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_enc_max || g_enc_calls >= g_enc_max) return;
+    uint64_t vp = rd64(r->rsp + 8), vl = rd64(r->rsp + 0x10), Nn = rd64(r->rsp + 0x20), M = rd64(r->rsp + 0x28);
+    uint64_t gp = rd64(r->rsp + 0x30), gl = rd64(r->rsp + 0x38), rp = rd64(r->rsp + 0x48), rl = rd64(r->rsp + 0x50);
+    char hex[65];
+    if (g_enc_calls == 0) {
+        emit_begin("encoder_tables"); fprintf(g_out, ", \"N\": %lu, \"M\": %lu, \"roots_len\": %lu, \"rotgroup_len\": %lu", Nn, M, rl, gl);
+        sha_mem(rp, rl * 16, hex); fprintf(g_out, ", \"roots\": \"%s\"", hex);
+        sha_mem(rp, (rl - 1) * 16, hex); fprintf(g_out, ", \"roots_without_last\": \"%s\"", hex);
+        sha_mem(gp, gl * 8, hex); fprintf(g_out, ", \"rotgroup\": \"%s\"", hex);
+        double w[4]; rd(rp + 16, w, 32); fprintf(g_out, ", \"roots_1_2\": [%.17g, %.17g, %.17g, %.17g]", w[0], w[1], w[2], w[3]); emit_end();
+    }
+    emit_begin("invfft"); sha_mem(vp, vl * 16, hex);
+    fprintf(g_out, ", \"call\": %d, \"n\": %lu, \"in\": \"%s\"", g_enc_calls++, vl, hex);
+    hook_return(r, ret_invfft, ud_new(vp, vl, 0)); }
+static void ret_encode_slots(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
+    ud3_t *u = ud; uint64_t pt = u->a;
+    emit_begin("Encode"); fprintf(g_out, ", \"call\": %lu, \"nvalues\": %lu, \"scale\": %.17g", u->b, u->c, pt_scale(pt));
+    emit_poly("pt", pt_poly(pt), poly_limbs(pt_poly(pt))); emit_end(); enc_done_check(); }
+static void on_encode_slots(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_enc_max || g_encode_slots_calls >= g_enc_max) return;
+    hook_return(r, ret_encode_slots, ud_new(rd64(r->rsp + 0x10), (uint64_t)g_encode_slots_calls++, rd64(r->rsp + 0x20))); }
+
 /* conv_then_pack(params (0x68 bytes by value), pack_evaluator (itab,ptr), ctxt_in, pl_ker (ptr,len,cap),
  *                plain_idx (ptr,len,cap), max_ob, norm, ECD_LV int, out_scale float64) *Ciphertext
  * entry-rsp offsets (from the frame layout of test_run:main.conv_then_pack, sub $0x150 / args at 0x158):
@@ -539,6 +579,7 @@ int main(int argc, char **argv) {
             int isq = argv[ai][1] == 'Q'; char *tok = strtok(argv[++ai], ",");
             while (tok) { if (isq) g_Q[g_nQ++] = strtoull(tok, NULL, 0); else g_Pm[g_nP++] = strtoull(tok, NULL, 0); tok = strtok(NULL, ","); }
         }
+        else if (!strcmp(argv[ai], "-enc") && ai + 1 < argc) g_enc_max = atoi(argv[++ai]);            /* trace the slot encoder: this many invfft / Encode calls */
         else if (!strcmp(argv[ai], "-keep-bl")) g_skip_bl = 0;
         else if (!strcmp(argv[ai], "-noplant")) g_noplant = 1;
         else if (!strcmp(argv[ai], "-seed") && ai + 1 < argc) g_seed = strtoull(argv[++ai], NULL, 0);
@@ -584,6 +625,7 @@ int main(int argc, char **argv) {
     bp_add(A_ROTATEGAL, on_rotgal, NULL);
     bp_add(A_SWITCHKEYS, on_switchkeys, NULL);
     bp_add(A_MULTBYCONST, on_multbyconst, NULL);
+    if (g_enc_max) { bp_add(A_INVFFT, on_invfft, NULL); bp_add(A_ENCODE, on_encode_slots, NULL); }
     if (g_ops_max) { bp_add(A_RESCALE, on_rescale, NULL); bp_add(A_MULRELIN, on_mulrelin, NULL); bp_add(A_ROTATE, on_rotate, NULL); bp_add(A_MODUP, on_modup, NULL); }
 
     ptrace(PTRACE_CONT, pid, 0, 0);

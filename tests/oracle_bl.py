@@ -27,28 +27,43 @@ _g = 1
 for _i in range(SLOTS):
     ROT_GROUP[_i] = _g
     _g = _g * 5 % M
-_ang = 2 * 3.141592653589793 * np.arange(M + 1, dtype=np.float64) / float(M)
-ROOTS = np.cos(_ang) + 1j * np.sin(_ang)
+import go_math
+
+# roots[i] = exp(2 pi i / M) through math.Cos / math.Sin AS GO'S RUNTIME EVALUATES THEM (tests/go_math.py), which is what
+# ckks.NewEncoder calls; the C library's (and numpy's) differ in the last bit for ~40 % of the entries. roots[M] = roots[0] as
+# encoder.go sets it. SHA-256 of this table == the table inside the reference binary (tests/test_oracle_pin_encoder.py).
+_ROOT_RE = np.array([go_math.go_cos(2 * 3.141592653589793 * float(i) / float(M)) for i in range(M)] + [0.0], dtype=np.float64)
+_ROOT_IM = np.array([go_math.go_sin(2 * 3.141592653589793 * float(i) / float(M)) for i in range(M)] + [0.0], dtype=np.float64)
+_ROOT_RE[M], _ROOT_IM[M] = _ROOT_RE[0], _ROOT_IM[0]
+ROOTS = _ROOT_RE + 1j * _ROOT_IM
 _BR = _bitrev_perm(SLOTS)
+
+
+def _cmul(ar, ai, br, bi):
+    """complex product the way Go (and C without contraction) evaluates it: four rounded products, one subtraction, one addition.
+    Separate numpy calls, so nothing can be fused into a multiply-add."""
+    p0, p1, p2, p3 = ar * br, ai * bi, ar * bi, ai * br
+    return p0 - p1, p2 + p3
 
 
 def invfft_special(values):
     """ckks invfft (Lattigo v2.2 encoder.go): decimation stages len = n .. 1, twiddle roots[(lenq - rotGroup[j]%lenq)*gap]"""
     v = np.array(values, dtype=np.complex128)
     n = len(v)
+    re, im = v.real.copy(), v.imag.copy()
     ln = n
     while ln >= 1:
         lenh, lenq = ln >> 1, ln << 2
         if lenh:
             gap = M // lenq
             idx = (lenq - (ROT_GROUP[:lenh] % lenq)) * gap
-            w = ROOTS[idx]
-            blk = v.reshape(n // ln, ln)
-            a, b = blk[:, :lenh].copy(), blk[:, lenh:].copy()
-            blk[:, :lenh] = a + b
-            blk[:, lenh:] = (a - b) * w
+            wr, wi = _ROOT_RE[idx], _ROOT_IM[idx]
+            br, bi = re.reshape(n // ln, ln), im.reshape(n // ln, ln)
+            ar, ai, cr, ci = br[:, :lenh].copy(), bi[:, :lenh].copy(), br[:, lenh:].copy(), bi[:, lenh:].copy()
+            br[:, :lenh] = ar + cr; bi[:, :lenh] = ai + ci
+            br[:, lenh:], bi[:, lenh:] = _cmul(ar - cr, ai - ci, wr, wi)
         ln >>= 1
-    v = v / complex(float(n), 0)
+    v = (re * (1.0 / float(n))) + 1j * (im * (1.0 / float(n)))          # n is a power of two: exact
     return v[_BR[:n]] if n == SLOTS else v[_bitrev_perm(n)]
 
 
@@ -56,18 +71,20 @@ def fft_special(values):
     v = np.array(values, dtype=np.complex128)
     n = len(v)
     v = v[_BR[:n]] if n == SLOTS else v[_bitrev_perm(n)]
+    re, im = v.real.copy(), v.imag.copy()
     ln = 2
     while ln <= n:
         lenh, lenq = ln >> 1, ln << 2
         gap = M // lenq
         idx = (ROT_GROUP[:lenh] % lenq) * gap
-        w = ROOTS[idx]
-        blk = v.reshape(n // ln, ln)
-        a, b = blk[:, :lenh].copy(), blk[:, lenh:] * w
-        blk[:, :lenh] = a + b
-        blk[:, lenh:] = a - b
+        wr, wi = _ROOT_RE[idx], _ROOT_IM[idx]
+        br, bi = re.reshape(n // ln, ln), im.reshape(n // ln, ln)
+        ar, ai = br[:, :lenh].copy(), bi[:, :lenh].copy()
+        tr, ti = _cmul(br[:, lenh:].copy(), bi[:, lenh:].copy(), wr, wi)
+        br[:, :lenh] = ar + tr; bi[:, :lenh] = ai + ti
+        br[:, lenh:] = ar - tr; bi[:, lenh:] = ai - ti
         ln <<= 1
-    return v
+    return re + 1j * im
 
 
 def encode_slots(O, values, level, scale):

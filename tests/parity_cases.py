@@ -218,6 +218,44 @@ def case_conv_sharded_abi(make_ctx, O, max_ob, G, seed=0x5AAD):
         c.close()
 
 
+def case_encode_slots(ctx, O, seed=77):
+    """hc_encode_slots (ckks.Encoder.EncodeNTT on the device: special inverse FFT in fp64, scaleUpVecExact, NTT) == the oracle's
+    encoder, residue for residue: random slots at scale 2^30, a plaintext of BN biases at scale 2^60 (eval.go:93-102), a sparse 0/1
+    vector, and values whose scaled magnitude exceeds 2^64 (scaleUpVecExact's big branch)."""
+    import oracle_bl as ob
+    rng = np.random.default_rng(seed)
+    n = N // 2
+    v0 = rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)
+    v1 = np.zeros(n, dtype=np.complex128); v1[::257] = 0.37; v1[5] = -1.0
+    v2 = (rng.integers(0, 2, n) * 1.0).astype(np.complex128)
+    for vals, scale in (([v0, v1, v2], 2.0 ** 30), ([v1, v0], 2.0 ** 60), ([v0 * 4096.0], 2.0 ** 60)):
+        got = ctx.encode_slots(np.stack(vals), 1, scale, to_ntt=True)
+        for z, v in enumerate(vals):
+            eq(got[z], ob.encode_slots_ntt(O, v, 1, scale), f"encode_slots vector {z} scale 2^{int(np.log2(scale))}")
+        got_c = ctx.encode_slots(np.stack(vals[:1]), 0, scale, to_ntt=False)
+        eq(got_c[0], ob.encode_slots(O, vals[0], 0, scale), "encode_slots, coefficient domain, level 0")
+
+
+def case_lv_mul_sum(ctx, O, ntaps=5, seed=91):
+    """hc_lv_mul_sum (the MulNew / Add chain of conv.go:167-172 in one launch) == the sum of products computed with Python integers"""
+    import ctypes as C
+    qs = [Q0, Q1]
+    cts = [np.stack([np.stack([rows(seed + 100 * t + 10 * p + l, qs[l])[0] for l in range(2)]) for p in range(2)]) for t in range(ntaps)]
+    pts = np.stack([np.stack([rows(seed + 7000 + 10 * t + l, qs[l])[0] for l in range(2)]) for t in range(ntaps)])
+    bufs = [ctx.buf(c) for c in cts]; bp = ctx.buf(pts); out = ctx.buf(nwords=4 * N)
+    arr = (C.c_void_p * ntaps)(*[b.ptr for b in bufs])
+    ctx._ck(ctx.L.hc_lv_mul_sum(ctx.h, 1, arr, bp.ptr, ntaps, out.ptr))
+    got = out.download((2, 2, N))
+    for p in range(2):
+        for l in range(2):
+            acc = np.zeros(N, dtype=object)
+            for t in range(ntaps):
+                acc = (acc + cts[t][p, l].astype(object) * pts[t, l].astype(object)) % qs[l]
+            eq(got[p, l], acc.astype(np.uint64), f"lv_mul_sum poly {p} limb {l}")
+    for b in bufs + [bp, out]:
+        b.free()
+
+
 def case_conv_phases(ctx, O, max_ob=4, seed=0xF00D):
     """loop A and loop B separately (hc_conv_mult_phase / hc_pack_ctxts)"""
     ct_in, ker = planted_conv_inputs(seed, max_ob)

@@ -91,6 +91,15 @@ def test_conv_sharded_over_contexts(env, max_ob, G):
     pc.case_conv_sharded_abi(lambda: Context([Q0, Q1], [P0], lib_path=EMU_LIB), env[1], max_ob, G)
 
 
+def test_lv_mul_sum(env):
+    pc.case_lv_mul_sum(*env)
+
+
+def test_encode_slots(env):
+    """the slot encoder's kernels (fp64 special FFT without contraction, rounding, NTT) under the emulator vs the oracle"""
+    pc.case_encode_slots(*env)
+
+
 def test_keyswitch_general():
     """general hybrid key switch (BL: level 1, two P primes; bootstrapping shapes) on the emulated kernels"""
     subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])

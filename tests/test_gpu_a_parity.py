@@ -203,6 +203,15 @@ def test_conv_sharded_over_contexts_on_gpu(env, max_ob, G):
     pc.case_conv_sharded_abi(lambda: Context([Q0, Q1], [P0]), env[1], max_ob, G)
 
 
+def test_lv_mul_sum_on_gpu(env):
+    pc.case_lv_mul_sum(*env, ntaps=49)
+
+
+def test_encode_slots_on_gpu(env):
+    """hc_encode_slots on the GPU == the oracle's Lattigo encoder restatement, every residue (fp64 on gfx950 without contraction)"""
+    pc.case_encode_slots(*env)
+
+
 def test_keyswitch_general_on_gpu():
     """8f groundwork: the general hybrid key switch (any level, alpha P primes) vs the oracle, which is itself pinned
     against the reference binary's BL and bootstrapping key switches (tests/test_oracle_pin_keyswitch.py)"""
