@@ -190,19 +190,13 @@ def main():
     kern = {k: {"ms_per_conv": v[0] / (nprof * NB), "launches_per_batch": v[1] // nprof, "avg_launch_us": 1e3 * v[0] / max(1, v[1])} for k, v in prof.items()}
     dom = max(kern, key=lambda k: kern[k]["ms_per_conv"]) if kern else None
 
-    def valu_model(conv_ms):
-        """the roofline that actually binds these integer kernels: VALU issue slots per conv (static instruction mix of the
-        gfx950 build priced with measured multiply rates: tools/isa_mix.py -> profiles/valu_slots_conv.json) against the
-        chip's 256 CUs x 64 lanes x 2.4 GHz; frac = model-minimum time / measured time"""
+    def counters():
+        """per-kernel hardware counters of the same command (rocprofv3 --pmc passes, tools/gpu_r2_pmc.sh -> profiles/round2_conv33_counters.json):
+        fabric bytes, achieved TB/s, VALU-pipe utilisation. Counters cannot be read from inside this process; None if not committed."""
         try:
-            d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "valu_slots_conv.json")))
+            return json.load(open(os.path.join(ROOT, "profiles", "round2_conv33_counters.json")))
         except OSError:
             return None
-        sl, jb = d["slots_per_job"], d["jobs_per_unit"]
-        per_conv = B * sum(sl[k] * jb[k] for k in ("a1", "a2", "a3")) + (B - 1) * sum(sl[k] * jb[k] for k in ("b1", "b2", "b3", "b4", "b5"))
-        t_min_ms = per_conv / d["peak_lane_slots_per_s"] * 1e3
-        return {"bound": "valu", "lane_slots_per_conv": per_conv, "peak": d["peak_lane_slots_per_s"] / 1e12, "unit": "T lane-slots/s",
-                "achieved": per_conv / (conv_ms * 1e-3) / 1e12, "frac": t_min_ms / conv_ms, "source": "tools/isa_mix.py (static ISA mix x measured multiply rates)"}
 
     if rank == 0:
         per_step = sum(len(L["in"]) for L in lanes)
@@ -223,7 +217,7 @@ def main():
                          "traffic": traffic_from_profiles(B, args.chunk),
                          "unit_of_launch": "one conv_then_pack (its share of the batched launch set: all kernels of loop A and of the pack tree)",
                          "algorithmic_bytes_per_conv": alg_bytes, "conv_ms_hip_events": conv_ms_events,
-                         "dominant_kernel": dom, "kernels": kern, "valu": valu_model(conv_ms_events)},
+                         "dominant_kernel": dom, "kernels": kern, "counters": counters()},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
