@@ -462,7 +462,67 @@ struct Boot {
             return prod;
         }
     };
+    // ---------------- ckks.(*evaluator).EvaluatePoly in the standard basis, AS THE REFERENCE'S FORK EVALUATES IT (evalReLU's three sign
+    // polynomials, conv.go:460-477): computePowerBasis (C[n] = Rescale(MulRelin(C[ceil n/2], C[n/2]))), recurse / splitCoeffs (baby-step
+    // giant-step, the giant power's level picks the modulus that fixes the quotient's target scale), evaluatePolyFromPowerBasis
+    // (MultByGaussianIntegerAndAdd with int64(c * targetScale * q / scale_of_power): truncation, not rounding; one Rescale), Add with the
+    // smaller-scale operand multiplied by uint64(ratio). tests/lattigo_poly.py is the same code on the oracle and reproduces EVERY nested
+    // ciphertext digest the reference binary produced for these polynomials (tests/test_oracle_pin_poly.py, gotrace -poly).
+    struct LPoly { std::vector<double> c; int max_deg; bool lead; int degree() const { return (int)c.size() - 1; } };
+    DCt lt_rescale(DCt a, double min_scale) { while (a.level > 0 && a.scale / (double)Q[(size_t)a.level] >= min_scale / 2) a = rescale(a); return a; }   // ckks Rescale's drop rule
+    DCt lt_add(const DCt &a, const DCt &b) {                           // evaluateInPlace: uint64(ratio) * the smaller-scale operand
+        if (a.scale > b.scale) { const double k = floor(a.scale / b.scale); DCt bb = k != 0 ? mul_const_int(b, k) : b; bb.scale = a.scale; return add(a, bb); }
+        if (b.scale > a.scale) { const double k = floor(b.scale / a.scale); DCt aa = k != 0 ? mul_const_int(a, k) : a; aa.scale = b.scale; return add(aa, b); }
+        return add(a, b);
+    }
+    void lt_power(std::map<int, DCt> &C, int n, double sc) {
+        if (C.count(n)) return;
+        const int a = (n + 1) / 2, b = n >> 1;
+        lt_power(C, a, sc); lt_power(C, b, sc);
+        C[n] = lt_rescale(mul_relin(C[a], C[b]), sc);
+    }
+    DCt lt_leaf(double target, const LPoly &p, std::map<int, DCt> &C, double sc) {
+        if (p.degree() == 0) panic("EvaluatePoly: constant leaf (not produced by the sign polynomials)");
+        const int lv = C[p.degree()].level; const double qi = (double)Q[(size_t)lv];
+        DCt res; bool have = false;
+        if (fabs(p.c[0]) > 1e-14) panic("EvaluatePoly: constant term in a leaf (AddConst; not produced by the sign polynomials)");
+        for (int key = p.degree(); key > 0; key--) if (fabs(p.c[(size_t)key]) > 1e-14) {
+            const double const_scale = target * qi / C[key].scale;
+            DCt term = mul_const_int(drop_to(C[key], lv), trunc(p.c[(size_t)key] * const_scale));          // Go's int64(float64)
+            term.scale = target * qi;
+            res = have ? add(res, term) : term; have = true;
+        }
+        if (!have) panic("EvaluatePoly: empty leaf");
+        return lt_rescale(res, sc);
+    }
+    DCt lt_recurse(double target, int log_split, int log_degree, const LPoly &p, std::map<int, DCt> &C, double sc) {
+        if (p.degree() < (1 << log_split)) {
+            if (p.lead && log_split > 1 && p.degree() > (1 << (log_split - 1))) { const int ld = PolyEval::bit_length(p.degree()); return lt_recurse(target, ld >> 1, ld, p, C, sc); }
+            return lt_leaf(target, p, C, sc);
+        }
+        int next_power = 1 << log_split; while (next_power < (p.degree() >> 1) + 1) next_power <<= 1;
+        LPoly pr{std::vector<double>(p.c.begin(), p.c.begin() + next_power), p.max_deg == p.degree() ? next_power - 1 : p.max_deg - (p.degree() - next_power + 1), false};
+        LPoly pq{std::vector<double>(p.c.begin() + next_power, p.c.end()), p.max_deg, p.lead};
+        int level = C[next_power].level - 1; if (p.max_deg >= (1 << (log_degree - 1)) && p.lead) level++;
+        DCt res = lt_recurse(target * (double)Q[(size_t)level] / C[next_power].scale, log_split, log_degree, pq, C, sc);
+        DCt tmp = lt_recurse(target, log_split, log_degree, pr, C, sc);
+        if (res.level > tmp.level) res = drop_to(res, tmp.level + 1);                                     // DropLevel
+        res = mul_relin(res, C[next_power]);
+        if (res.level > tmp.level) { res = lt_rescale(res, sc); res = lt_add(res, tmp); }
+        else { res = lt_add(res, tmp); res = lt_rescale(res, sc); }
+        return res;
+    }
+    DCt eval_poly_lattigo(const DCt &ct, const std::vector<double> &coeffs, double target) {
+        std::map<int, DCt> C; C[1] = ct;
+        LPoly p{coeffs, (int)coeffs.size() - 1, true};
+        const double sc = 1073741824.0;                                                                  // evaluator.scale = params.Scale()
+        const int log_degree = PolyEval::bit_length(p.degree()), log_split = log_degree >> 1;
+        for (int i = 2; i < (1 << log_split); i++) lt_power(C, i, sc);
+        for (int i = log_split; i < log_degree; i++) lt_power(C, 1 << i, sc);
+        return lt_recurse(target, log_split, log_degree, p, C, sc);
+    }
     DCt eval_poly(const DCt &ct, const std::vector<double> &coeffs, double target, bool cheby) {
+        if (!cheby) return eval_poly_lattigo(ct, coeffs, target);
         PolyEval pe{this, cheby, {}};
         pe.T[1] = ct;
         const int deg = (int)coeffs.size() - 1, log_deg = PolyEval::bit_length(deg), log_split = log_deg >> 1;

@@ -214,6 +214,13 @@ static void plant_row(uint64_t rowptr, uint64_t seed, uint64_t q) {
 #define A_MODUP              0x50741bull  /* ckks.(*Bootstrapper).modUp(ct) *Ciphertext */
 #define A_INVFFT             0x5185d3ull  /* ckks.invfft(values []complex128, N, M uint64, rotGroup []uint64, roots []complex128) */
 #define A_ENCODE             0x514cf3ull  /* ckks.(*encoderComplex128).Encode(pt *Plaintext, values []complex128, logSlots uint64) */
+#define A_EVALPOLY           0x52d3dbull  /* ckks.(*evaluator).EvaluatePoly(ct0 *Ciphertext, pol *Poly, targetScale float64) (*Ciphertext, error) */
+#define A_MGIAA              0x520060ull  /* ckks.(*evaluator).MultByGaussianIntegerAndAdd(ct0, cReal, cImag int64, ctOut) */
+#define A_ADDCONST           0x51d9f3ull  /* ckks.(*evaluator).AddConst(ct0, constant interface{}, ctOut) */
+#define A_DROPLEVEL          0x5223a0ull  /* ckks.(*evaluator).DropLevel(ct0, levels uint64) */
+#define A_RECURSE            0x52eb18ull  /* ckks.recurse(targetScale, logSplit, logDegree, coeffs *Poly, C, evaluator) */
+#define A_POLYLEAF           0x52fd1bull  /* ckks.evaluatePolyFromPowerBasis(targetScale, coeffs *Poly, C, evaluator) */
+#define A_POWERBASIS         0x52dbd3ull  /* ckks.computePowerBasis(n, C, scale, evaluator) */
 #define A_TYPE_FLOAT64       0x570a20ull  /* runtime type descriptor of float64 (seen in the interface word) */
 
 static const uint64_t Q0 = 0x80000000080001ull, Q1 = 0x1ffffffea0001ull, P0 = 0x1fffffffffe00001ull;
@@ -257,7 +264,11 @@ static void on_subnew(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; 
 static void ret_add(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r;
     emit_begin(((ud3_t*)ud)->b ? "Add.bias" : "Add"); emit_ct("out", ((ud3_t*)ud)->a); emit_end(); }
 static int g_add_calls;
+static int g_in_poly_fwd(void);
+static void on_p_add(pid_t t, struct user_regs_struct *r, void *ud);
+static void on_p_multbyconst(pid_t t, struct user_regs_struct *r, void *ud);
 static void on_add(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (g_in_poly_fwd()) { on_p_add(t, r, ud); return; }
     /* Add(recv, op0 (itab,ptr), op1 (itab,ptr), ctOut) */
     if (g_after_ctp) {           /* eval.go:258  Add(ct_res, pl_bn_b, ct_res) */
         g_after_ctp = 0;
@@ -280,7 +291,9 @@ static void ret_multbyconst(pid_t t, struct user_regs_struct *r, void *ud) { (vo
     ud3_t *u = ud; double c; memcpy(&c, &u->b, 8);
     emit_begin("MultByConst"); fprintf(g_out, ", \"const_is_f64\": %d, \"const\": %.17g", (int)u->c, c);
     emit_ct("out", u->a); emit_end(); }
-static void on_multbyconst(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_ctp || g_lean) return;
+static void on_multbyconst(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (g_in_poly_fwd()) { on_p_multbyconst(t, r, ud); return; }
+    if (!g_in_ctp || g_lean) return;
     /* MultByConst(recv, ct0 *Ciphertext, constant interface{} (2 words), ctOut *Ciphertext) */
     if (g_mode_probe) dump_words("MultByConst args", r->rsp + 8, 6);
     uint64_t ty = rd64(r->rsp + 0x18), data = rd64(r->rsp + 0x20);
@@ -501,6 +514,81 @@ static void on_encode_slots(pid_t t, struct user_regs_struct *r, void *ud) { (vo
     if (!g_enc_max || g_encode_slots_calls >= g_enc_max) return;
     hook_return(r, ret_encode_slots, ud_new(rd64(r->rsp + 0x10), (uint64_t)g_encode_slots_calls++, rd64(r->rsp + 0x20))); }
 
+/* -poly N: ckks.(*evaluator).EvaluatePoly one level up (conv.go:460-477: the three sign polynomials of evalReLU). At the entry of the
+ * first N calls the input ciphertext is planted (SEED_OPIN(call, 0, poly, limb) mod q_limb); every relinearisation key a nested
+ * SwitchKeysInPlace reads is planted as in -ks / -ops (SEED_KSEVK by key identity). Recorded: the polynomial (maxDeg, lead, the real
+ * parts of its coefficients), targetScale, and -- log only -- every nested computePowerBasis / recurse / evaluatePolyFromPowerBasis /
+ * mulRelin / Rescale / MultByGaussianIntegerAndAdd / AddConst / DropLevel with its arguments, levels, scales and the SHA-256 of each
+ * ciphertext result, then the returned ciphertext. The oracle replays the polynomial on the same planted data and must reproduce
+ * every digest. */
+static int g_poly_max = 0, g_poly_calls = 0, g_in_poly = 0;
+static int g_in_poly_fwd(void) { return g_in_poly; }
+static void emit_polyarg(const char *key, uint64_t pol) {
+    uint64_t maxdeg = rd64(pol), cp = rd64(pol + 8), cl = rd64(pol + 16); uint8_t lead; rd(pol + 32, &lead, 1);
+    fprintf(g_out, ", \"%s\": {\"maxDeg\": %lu, \"lead\": %d, \"coeffs\": [", key, maxdeg, (int)lead);
+    for (uint64_t i = 0; i < cl; i++) { double c[2]; rd(cp + 16 * i, c, 16); fprintf(g_out, "%s[%.17g, %.17g]", i ? ", " : "", c[0], c[1]); }
+    fprintf(g_out, "]}");
+}
+typedef struct { uint64_t out; int id; } prec_t;
+static prec_t g_prec[64]; static int g_prec_i;
+static prec_t *prec_new(uint64_t out) { prec_t *u = &g_prec[g_prec_i++ % 64]; u->out = out; u->id = 0; return u; }
+static void ret_p_ct(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r; prec_t *u = ud; emit_ct("out", u->out); emit_end(); }
+static void on_p_mulrelin(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_poly) return;
+    uint64_t op0 = rd64(r->rsp + 0x18), op1 = rd64(r->rsp + 0x28), out = rd64(r->rsp + 0x38); uint8_t relin; rd(r->rsp + 0x30, &relin, 1);
+    emit_begin("p.mulRelin"); fprintf(g_out, ", \"relin\": %d, \"level0\": %d, \"level1\": %d, \"scale0\": %.17g, \"scale1\": %.17g, \"square\": %d", (int)relin,
+        poly_limbs(ct_poly(op0, 0)) - 1, poly_limbs(ct_poly(op1, 0)) - 1, ct_scale(op0), ct_scale(op1), op0 == op1);
+    hook_return(r, ret_p_ct, prec_new(out)); }
+static void on_p_rescale(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_poly) return;
+    uint64_t in = rd64(r->rsp + 0x10), out = rd64(r->rsp + 0x20); double ms = rdf64(r->rsp + 0x18);
+    emit_begin("p.Rescale"); fprintf(g_out, ", \"level_in\": %d, \"scale_in\": %.17g, \"min_scale\": %.17g", poly_limbs(ct_poly(in, 0)) - 1, ct_scale(in), ms);
+    hook_return(r, ret_p_ct, prec_new(out)); }
+static void on_p_mgiaa(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_poly) return;
+    uint64_t in = rd64(r->rsp + 0x10), out = rd64(r->rsp + 0x28); int64_t cr = (int64_t)rd64(r->rsp + 0x18), ci = (int64_t)rd64(r->rsp + 0x20);
+    emit_begin("p.MultByGaussianIntegerAndAdd"); fprintf(g_out, ", \"cReal\": %ld, \"cImag\": %ld, \"level_in\": %d, \"scale_in\": %.17g, \"level_out\": %d, \"scale_out\": %.17g",
+        (long)cr, (long)ci, poly_limbs(ct_poly(in, 0)) - 1, ct_scale(in), poly_limbs(ct_poly(out, 0)) - 1, ct_scale(out));
+    hook_return(r, ret_p_ct, prec_new(out)); }
+static void on_p_addconst(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_poly) return;
+    uint64_t in = rd64(r->rsp + 0x10), ty = rd64(r->rsp + 0x18), data = rd64(r->rsp + 0x20), out = rd64(r->rsp + 0x28); double c[2] = {0, 0};
+    if (ty == A_TYPE_FLOAT64) c[0] = rdf64(data); else rd(data, c, 16);
+    emit_begin("p.AddConst"); fprintf(g_out, ", \"type\": %lu, \"re\": %.17g, \"im\": %.17g, \"level\": %d, \"scale\": %.17g", ty, c[0], c[1], poly_limbs(ct_poly(in, 0)) - 1, ct_scale(in));
+    hook_return(r, ret_p_ct, prec_new(out)); }
+static void on_p_droplevel(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_poly) return;
+    uint64_t in = rd64(r->rsp + 0x10);
+    emit_begin("p.DropLevel"); fprintf(g_out, ", \"levels\": %lu, \"level_in\": %d", rd64(r->rsp + 0x18), poly_limbs(ct_poly(in, 0)) - 1); emit_end(); }
+static void on_p_recurse(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_poly) return;
+    emit_begin("p.recurse"); fprintf(g_out, ", \"targetScale\": %.17g, \"logSplit\": %lu, \"logDegree\": %lu", rdf64(r->rsp + 8), rd64(r->rsp + 0x10), rd64(r->rsp + 0x18));
+    emit_polyarg("coeffs", rd64(r->rsp + 0x20)); emit_end(); }
+static void on_p_leaf(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_poly) return;
+    emit_begin("p.evaluatePolyFromPowerBasis"); fprintf(g_out, ", \"targetScale\": %.17g", rdf64(r->rsp + 8)); emit_polyarg("coeffs", rd64(r->rsp + 0x10)); emit_end(); }
+static void on_p_powerbasis(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_poly) return;
+    emit_begin("p.computePowerBasis"); fprintf(g_out, ", \"n\": %lu, \"scale\": %.17g", rd64(r->rsp + 8), rdf64(r->rsp + 0x18)); emit_end(); }
+static void on_p_add(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_poly) return;
+    uint64_t op0 = rd64(r->rsp + 0x18), op1 = rd64(r->rsp + 0x28), out = rd64(r->rsp + 0x30);
+    emit_begin("p.Add"); fprintf(g_out, ", \"level0\": %d, \"level1\": %d, \"scale0\": %.17g, \"scale1\": %.17g, \"out_is_op0\": %d", poly_limbs(ct_poly(op0, 0)) - 1, poly_limbs(ct_poly(op1, 0)) - 1,
+        ct_scale(op0), ct_scale(op1), out == op0);
+    hook_return(r, ret_p_ct, prec_new(out)); }
+static void on_p_multbyconst(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_poly) return;
+    uint64_t in = rd64(r->rsp + 0x10), ty = rd64(r->rsp + 0x18), data = rd64(r->rsp + 0x20), out = rd64(r->rsp + 0x28); uint64_t raw = rd64(data);
+    emit_begin("p.MultByConst"); fprintf(g_out, ", \"type\": %lu, \"is_f64\": %d, \"raw_u64\": %lu, \"as_f64\": %.17g, \"level\": %d, \"scale\": %.17g", ty, ty == A_TYPE_FLOAT64, raw, rdf64(data),
+        poly_limbs(ct_poly(in, 0)) - 1, ct_scale(in));
+    hook_return(r, ret_p_ct, prec_new(out)); }
+static void ret_evalpoly(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    uint64_t out = rd64(r->rsp - 8 + 0x28);
+    g_in_poly = 0; g_nested_ks = 0;
+    emit_begin("EvaluatePoly.end"); fprintf(g_out, ", \"call\": %d, \"err\": %lu", g_poly_calls - 1, rd64(r->rsp - 8 + 0x30)); if (out) emit_ct("out", out); emit_end();
+    if (g_poly_calls >= g_poly_max) { fprintf(g_out, "\n ],\n \"exit_code\": 0}\n"); fflush(g_out); kill(g_pid, SIGKILL); exit(0); } }
+static void on_evalpoly(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_poly_max || g_in_poly || g_poly_calls >= g_poly_max) return;
+    uint64_t ct0 = rd64(r->rsp + 0x10), pol = rd64(r->rsp + 0x18); double ts = rdf64(r->rsp + 0x20);
+    int level = poly_limbs(ct_poly(ct0, 0)) - 1, call = g_poly_calls++;
+    if (level >= g_nQ) { fprintf(stderr, "EvaluatePoly at level %d: pass the modulus chain with -Q\n", level); exit(3); }
+    plant_ct(ct0, 1000 + call, 0);
+    emit_begin("EvaluatePoly.begin"); fprintf(g_out, ", \"call\": %d, \"level\": %d, \"scale_in\": %.17g, \"targetScale\": %.17g", call, level, ct_scale(ct0), ts);
+    emit_polyarg("pol", pol); emit_ct("in", ct0); emit_end();
+    g_in_poly = 1; g_nested_ks = 1; g_nested_evk = -1;
+    fprintf(stderr, "EvaluatePoly call %d level %d scale %g target %g\n", call, level, ct_scale(ct0), ts);
+    hook_return(r, ret_evalpoly, NULL); }
+
 /* conv_then_pack(params (0x68 bytes by value), pack_evaluator (itab,ptr), ctxt_in, pl_ker (ptr,len,cap),
  *                plain_idx (ptr,len,cap), max_ob, norm, ECD_LV int, out_scale float64) *Ciphertext
  * entry-rsp offsets (from the frame layout of test_run:main.conv_then_pack, sub $0x150 / args at 0x158):
@@ -579,6 +667,7 @@ int main(int argc, char **argv) {
             int isq = argv[ai][1] == 'Q'; char *tok = strtok(argv[++ai], ",");
             while (tok) { if (isq) g_Q[g_nQ++] = strtoull(tok, NULL, 0); else g_Pm[g_nP++] = strtoull(tok, NULL, 0); tok = strtok(NULL, ","); }
         }
+        else if (!strcmp(argv[ai], "-poly") && ai + 1 < argc) g_poly_max = atoi(argv[++ai]);          /* trace this many EvaluatePoly calls (planted input and keys) */
         else if (!strcmp(argv[ai], "-enc") && ai + 1 < argc) g_enc_max = atoi(argv[++ai]);            /* trace the slot encoder: this many invfft / Encode calls */
         else if (!strcmp(argv[ai], "-keep-bl")) g_skip_bl = 0;
         else if (!strcmp(argv[ai], "-noplant")) g_noplant = 1;
@@ -625,6 +714,9 @@ int main(int argc, char **argv) {
     bp_add(A_ROTATEGAL, on_rotgal, NULL);
     bp_add(A_SWITCHKEYS, on_switchkeys, NULL);
     bp_add(A_MULTBYCONST, on_multbyconst, NULL);
+    if (g_poly_max) { bp_add(A_EVALPOLY, on_evalpoly, NULL); bp_add(A_MULRELIN, on_p_mulrelin, NULL); bp_add(A_RESCALE, on_p_rescale, NULL); bp_add(A_MGIAA, on_p_mgiaa, NULL);
+                      bp_add(A_ADDCONST, on_p_addconst, NULL); bp_add(A_DROPLEVEL, on_p_droplevel, NULL); bp_add(A_RECURSE, on_p_recurse, NULL); bp_add(A_POLYLEAF, on_p_leaf, NULL);
+                      bp_add(A_POWERBASIS, on_p_powerbasis, NULL); bp_add(A_ADD, on_p_add, NULL); bp_add(A_MULTBYCONST, on_p_multbyconst, NULL); }
     if (g_enc_max) { bp_add(A_INVFFT, on_invfft, NULL); bp_add(A_ENCODE, on_encode_slots, NULL); }
     if (g_ops_max) { bp_add(A_RESCALE, on_rescale, NULL); bp_add(A_MULRELIN, on_mulrelin, NULL); bp_add(A_ROTATE, on_rotate, NULL); bp_add(A_MODUP, on_modup, NULL); }
 

@@ -17,3 +17,25 @@ for cfg in "3 0" "3 1" "3 3"; do
   "$SCRATCH/gotrace" $lean -o "trace_conv_$1_$2.json" -- "$SCRATCH/test_run_scratch" conv "$1" "$2" 1 > "log_$1_$2.txt" 2>&1
   cp "trace_conv_$1_$2.json" "$REPO/tests/golden/ref_trace_conv_$1_$2.json"
 done
+
+# ---- round 2 ----
+# the slot encoder of the BL baseline half (nothing planted): root table, 24 invfft in/out vectors, Encode plaintexts
+python3 "$REPO/tests/golden/gen_conv_csv.py" "$SCRATCH/test_conv_data" 3 0 1
+"$SCRATCH/gotrace" -keep-bl -noplant -enc 24 -o trace_enc_3_0.json -- "$SCRATCH/test_run_scratch" conv 3 0 1 > log_enc.txt 2>&1
+cp trace_enc_3_0.json "$REPO/tests/golden/ref_trace_enc_3_0.json"
+# ckks.(*evaluator).EvaluatePoly: the three sign polynomials of evalReLU with planted input and relinearisation key, every nested op
+Q=$(python3 -c "import sys; sys.path.insert(0,'$REPO/tests'); import oracle_ckks as c; print(','.join(hex(q) for q in c.Q_SET6))")
+P=$(python3 -c "import sys; sys.path.insert(0,'$REPO/tests'); import oracle_ckks as c; print(','.join(hex(q) for q in c.P_SET6))")
+python3 "$REPO/tests/golden/gen_conv_csv.py" "$SCRATCH/test_conv_data" 5 1 1
+"$SCRATCH/gotrace" -poly 3 -Q $Q -P $P -nq-full 28 -o trace_poly_5_1.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_poly.txt 2>&1
+# keep the EvaluatePoly events only; an Add whose scale matching calls MultByConst is written around the nested event: reorder
+python3 - "$REPO/tests/golden/ref_trace_poly_5_1.json" <<'PY'
+import json, re, sys
+t = open("trace_poly_5_1.json").read()
+pat = re.compile(r'(\{"op": "p\.Add"[^\n{}]*?"out_is_op0": \d),\n  (\{"op": "p\.MultByConst".*?\}\]\}\})(, "out": \{.*?\}\]\}\})', re.S)
+t = pat.sub(lambda m: m.group(2) + ',\n  ' + m.group(1) + m.group(3), t)
+d = json.loads(t)
+d["events"] = [e for e in d["events"] if e["op"].startswith("p.") or e["op"].startswith("EvaluatePoly")]
+d["note"] = "gotrace -poly 3 over `convReLU 5 1 1`; a MultByConst that an Add's scale matching calls is listed BEFORE that Add (it completes first)"
+json.dump(d, open(sys.argv[1], "w"), indent=0)
+PY

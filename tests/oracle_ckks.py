@@ -555,7 +555,12 @@ class Ckks:
         return prod
 
     def eval_poly(self, ct, coeffs, target_scale, cheby=False):
-        """p(ct) for p in the monomial (cheby=False) or Chebyshev basis on [-1,1]; consumes ceil(log2(deg+1)) levels"""
+        """p(ct) for p in the monomial (cheby=False) or Chebyshev basis on [-1,1]; consumes ceil(log2(deg+1)) levels.
+        Monomial basis = ckks.(*evaluator).EvaluatePoly exactly as the reference's fork evaluates it (tests/lattigo_poly.py; pinned to
+        the binary's own nested digests by tests/test_oracle_pin_poly.py); the Chebyshev form below is this repository's restatement."""
+        if not cheby:
+            import lattigo_poly
+            return lattigo_poly.evaluate_poly(_LattigoBackend(self), ct, [float(c) for c in coeffs], target_scale, 2.0 ** 30)
         coeffs = [float(c) for c in coeffs]
         deg = len(coeffs) - 1
         log_deg = deg.bit_length()
@@ -569,6 +574,41 @@ class Ckks:
         T_levels = {i: t.level for i, t in T.items()}
         # the lead leaf may re-split with a smaller baby set: its powers exist already (they are sub-products)
         return self._eval_rec(T, _Levels(self, T, cheby), coeffs, log_split, True, cheby, target_scale)
+
+
+class _LattigoBackend:
+    """tests/lattigo_poly.py's backend over this chain's ciphertexts (whatever residue backend the Ckks object runs on)"""
+
+    def __init__(self, ck):
+        self.ck = ck
+
+    def level(self, ct): return ct.level
+    def scale(self, ct): return ct.scale
+    def q(self, level): return self.ck.Q[level]
+    def mul_relin(self, a, b): return self.ck.mul_relin(a, b)
+
+    def rescale(self, ct, min_scale):
+        while ct.level > 0 and ct.scale / float(self.ck.Q[ct.level]) >= min_scale / 2:
+            ct = self.ck.rescale(ct)
+        return ct
+
+    def zero(self, level, scale):
+        return Ct(np.zeros((2, level + 1, self.ck.N), dtype=np.uint64), scale)
+
+    def mul_int(self, ct, c):
+        return self.ck.mul_const_int(ct, c)
+
+    def mul_int_add(self, ct, c, acc):
+        term = self.ck.mul_const_int(self.ck.drop_to(ct, acc.level), c)
+        term.scale = acc.scale
+        return self.ck.add(acc, term)
+
+    def add_rows(self, a, b, scale):
+        a, b = self.ck._align(a, b)
+        return self.ck.add(Ct(a.rows, scale), Ct(b.rows, scale))
+
+    def drop(self, ct, levels): return self.ck.drop_to(ct, ct.level - levels)
+    def add_const(self, ct, c): return self.ck.add_const(ct, c)
 
 
 class _Levels(dict):

@@ -334,6 +334,74 @@ def test_leveled_ops_vs_reference_trace_on_gpu():
         ctx.close()
 
 
+def test_evaluate_poly_vs_reference_trace_on_gpu():
+    """ckks.(*evaluator).EvaluatePoly on the GPU vs the reference binary: the three sign polynomials of evalReLU (conv.go:460-477) on the
+    planted inputs and relinearisation key of `gotrace -poly` (tests/golden/ref_trace_poly_5_1.json), composed from hc_lv_mul_tensor +
+    hc_keyswitch + hc_lv_add, hc_div_round_last, hc_lv_mul_const through the C ABI (tests/lattigo_poly.py drives them): every nested
+    mulRelin / Rescale / MultByGaussianIntegerAndAdd / Add digest and the returned ciphertexts must be the binary's."""
+    from optimal_conv_amd import Context
+    import lattigo_poly as lp
+    from test_oracle_pin_keyswitch import ks_inputs
+    from test_oracle_pin_ops import planted_ct
+    from test_oracle_pin_poly import Ct, ReplayBackend, RLK_ID
+
+    d = json.load(open(os.path.join(HERE, "golden", "ref_trace_poly_5_1.json")))
+    Q, P, seed, N = d["ks_Q"], d["ks_P"], d["seed"], d["N"]
+    ctx = Context(Q, P)
+
+    class Dev(ReplayBackend):                      # the replay backend with every residue operation on the device
+        loaded = set()
+
+        def mul_relin(self, a, b):
+            L = min(self.level(a), self.level(b))
+            ar, br = np.ascontiguousarray(a.rows[:, : L + 1]), np.ascontiguousarray(b.rows[:, : L + 1])
+            if L not in self.loaded:
+                ctx.swk_load(9000 + L, L, ks_inputs(seed, 0, RLK_ID, L, Q, P, N)[1]); self.loaded.add(L)
+            d0, d1, d2 = ctx.lv_mul_tensor(L, ar, br)
+            k0, k1 = ctx.keyswitch(9000 + L, L, d2)
+            return self._emit("p.mulRelin", Ct(np.stack([ctx.lv_add(L, d0, k0), ctx.lv_add(L, d1, k1)]), a.scale * b.scale))
+
+        def rescale(self, ct, min_scale):
+            rows, scale, lv = ct.rows, ct.scale, self.level(ct)
+            while lv > 0 and scale / float(Q[lv]) >= min_scale / 2:
+                rows = np.stack([ctx.div_round_last(lv, np.ascontiguousarray(rows[k])) for k in range(2)])
+                scale /= float(Q[lv]); lv -= 1
+            return self._emit("p.Rescale", Ct(rows, scale))
+
+        def _mul_int(self, ct, c):
+            L = self.level(ct)
+            return np.stack([ctx.lv_mul_const(L, np.ascontiguousarray(ct.rows[k]), [c % Q[l] for l in range(L + 1)]) for k in range(2)])
+
+        def _add(self, L, x, y):
+            return np.stack([ctx.lv_add(L, np.ascontiguousarray(x[k, : L + 1]), np.ascontiguousarray(y[k, : L + 1])) for k in range(2)])
+
+        def mul_int_add(self, ct, c, acc):
+            L = self.level(acc)
+            return self._emit("p.MultByGaussianIntegerAndAdd", Ct(self._add(L, acc.rows, self._mul_int(Ct(np.ascontiguousarray(ct.rows[:, : L + 1]), ct.scale), c)), acc.scale), cReal=c)
+
+        def add_rows(self, a, b, scale):
+            L = min(self.level(a), self.level(b))
+            return self._emit("p.Add", Ct(self._add(L, a.rows, b.rows), scale))
+
+    ev = [e for e in d["events"] if e["op"].startswith("p.") or e["op"].startswith("EvaluatePoly")]
+    begins = [i for i, e in enumerate(ev) if e["op"] == "EvaluatePoly.begin"]
+    for bi, i0 in enumerate(begins):
+        i1 = begins[bi + 1] if bi + 1 < len(begins) else len(ev)
+        b, end = ev[i0], next(e for e in ev[i0:i1] if e["op"] == "EvaluatePoly.end")
+        be = Dev(None, Q, None)
+        out = lp.evaluate_poly(be, Ct(planted_ct(seed, 1000 + b["call"], 0, b["level"], Q, N), b["scale_in"]), [c[0] for c in b["pol"]["coeffs"]], b["targetScale"], 2.0 ** 30)
+        want = [e for e in ev[i0:i1] if e["op"] in ("p.mulRelin", "p.Rescale", "p.MultByGaussianIntegerAndAdd", "p.Add", "p.MultByConst")]
+        got = be.log
+        assert [e["op"] for e in want] == [g["op"] for g in got]
+        for k, (w, g) in enumerate(zip(want, got)):
+            if w["op"] == "p.MultByConst":       # result sits in a full-length pool ciphertext in the reference: compare the constant only
+                assert w["as_f64"] == float(g["const"])
+                continue
+            assert [p["sha256"] for p in w["out"]["polys"]] == g["polys"] and w["out"]["scale"] == g["scale"], f"EvaluatePoly call {b['call']} op {k} {w['op']}"
+        assert [p["sha256"] for p in end["out"]["polys"]] == [sha_rows(*out.rows[0]), sha_rows(*out.rows[1])], f"EvaluatePoly call {b['call']}: returned ciphertext"
+    ctx.close()
+
+
 def test_keyswitch_hoisted_on_gpu():
     """hc_keyswitch_decompose + hc_keyswitch_hoisted vs the oracle key switch, several keys on one decomposition"""
     from optimal_conv_amd import Context
