@@ -383,6 +383,9 @@ def test_evaluate_poly_vs_reference_trace_on_gpu():
             L = min(self.level(a), self.level(b))
             return self._emit("p.Add", Ct(self._add(L, a.rows, b.rows), scale))
 
+        def zero(self, level, scale):
+            return Ct(np.zeros((2, level + 1, N), dtype=np.uint64), scale)
+
     ev = [e for e in d["events"] if e["op"].startswith("p.") or e["op"].startswith("EvaluatePoly")]
     begins = [i for i, e in enumerate(ev) if e["op"] == "EvaluatePoly.begin"]
     for bi, i0 in enumerate(begins):
