@@ -495,9 +495,6 @@ struct HcLoopA {
 };
 // KA1: rows-inverse of a_1 (mod Q1). grid = (jobs, 16, batch). F64 = 1: Q1 < 2^49, the transform runs in fp64 (T1inv = the fp64 table)
 // and tmp carries doubles (bit patterns) to KA2.
-#ifndef HC_DBG_A1
-#define HC_DBG_A1 0       // experiments only (tools/build_variant.sh): 1 = no c' loads, 2 = no transform, 3 = linear stores, 4 = no stores
-#endif
 template <int F64>
 __global__ __launch_bounds__(HC_TPB) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
     __shared__ u64 lds[HC_ROWS_LDS];
@@ -510,16 +507,10 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
         const size_t off = (size_t)(HC_TILE * 16 + kk) * 256 + t;
-        HcTw cw;
-        if (HC_DBG_A1 == 1) { cw.w = A.h + kk; cw.ws = A.negh0; } else cw = c[off];
+        const HcTw cw = c[off];
         e[kk] = hc_shoup4(k[off], cw.w, cw.ws, Q);                              // [0, 4*Q1)
     }
     u64 *o = A.tmp + ((size_t)z * A.njobs + job) * 65536 + (size_t)row * 256;
-    if (HC_DBG_A1 == 2) {
-#pragma unroll
-        for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = e[hi];
-        return;
-    }
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     __syncthreads();
     if (F64) {
@@ -528,19 +519,8 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
 #pragma unroll
         for (int kk = 0; kk < 16; kk++) f[kk] = hc_f64_reduce(hc_f64_from_u(e[kk]), m.q, m.qinv);   // 4*Q1 < 2^51: exact; |f| <= Q1/2
         hc_rows_inv_f64(f, lds, T1inv, row, rloc, tid, m);
-        if (HC_DBG_A1 == 3) {
-            u64 *ol = A.tmp + ((size_t)z * A.njobs + job) * 65536 + (size_t)HC_TILE * 4096 + t;
-#pragma unroll
-            for (int hi = 0; hi < 16; hi++) ol[hi * 256] = hc_d2u(f[hi]);
-        } else if (HC_DBG_A1 == 4) {
-            double sacc = 0;
-#pragma unroll
-            for (int hi = 0; hi < 16; hi++) sacc += f[hi];
-            if (sacc == 1.2345) o[0] = 1;
-        } else {
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) o[hi * 16 + tid] = hc_d2u(f[hi]);
-        }
     } else {
         hc_rows_inv(e, lds, T1inv, row, rloc, tid, Q);
 #pragma unroll
