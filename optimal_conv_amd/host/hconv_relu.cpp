@@ -769,6 +769,10 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     if (!sparse && log_sparse != 0) panic("No cases for log_sparse");
     DCt ct = B->new_ct(0, 1, ct_scale * pow(2.0, pow_));                                            // eval.go:437
     for (int d = 0; d < 2; d++) HCR(hc_copy(hc, ct.p[d].get(), ct_conv_dev + (size_t)d * N, (size_t)N * 8));
+    // ct_conv_dev belongs to ANOTHER context (the convolution's): the copy above is queued on this context's stream, and the caller frees
+    // the source as soon as this function returns. Wait for the copy (the stream holds nothing else at this point) so that the hand-over
+    // does not depend on how the two contexts' streams happen to be scheduled (cached allocations recycle a freed block at once).
+    HCR(hc_sync(hc));
     const bool prof = getenv("HCONV_PROFILE") && atoi(getenv("HCONV_PROFILE"));
     if (prof) { HCR(hc_set_option(hc, "profile", 1)); hc_profile_get(hc, nullptr, nullptr, nullptr); }
     printf("Bootstrapping... Ours (until CtoS):\n");
