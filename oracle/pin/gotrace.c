@@ -220,6 +220,8 @@ static void plant_row(uint64_t rowptr, uint64_t seed, uint64_t q) {
 #define A_DROPLEVEL          0x5223a0ull  /* ckks.(*evaluator).DropLevel(ct0, levels uint64) */
 #define A_RECURSE            0x52eb18ull  /* ckks.recurse(targetScale, logSplit, logDegree, coeffs *Poly, C, evaluator) */
 #define A_POLYLEAF           0x52fd1bull  /* ckks.evaluatePolyFromPowerBasis(targetScale, coeffs *Poly, C, evaluator) */
+#define A_ENCDIAG            0x517ab8ull  /* ckks.(*encoderComplex128).encodeDiagonal(logSlots, level, scale, m []complex128) [2]*ring.Poly */
+#define A_ENCMAT             0x5173bbull  /* ckks.(*encoderComplex128).EncodeDiagMatrixBSGSAtLvl(level, diagMatrix, scale, maxN1N2Ratio, logSlots) *PtDiagMatrix */
 #define A_POWERBASIS         0x52dbd3ull  /* ckks.computePowerBasis(n, C, scale, evaluator) */
 #define A_TYPE_FLOAT64       0x570a20ull  /* runtime type descriptor of float64 (seen in the interface word) */
 
@@ -514,6 +516,135 @@ static void on_encode_slots(pid_t t, struct user_regs_struct *r, void *ud) { (vo
     if (!g_enc_max || g_encode_slots_calls >= g_enc_max) return;
     hook_return(r, ret_encode_slots, ud_new(rd64(r->rsp + 0x10), (uint64_t)g_encode_slots_calls++, rd64(r->rsp + 0x20))); }
 
+/* -diag N: the plaintext diagonals of the bootstrapper's DFT matrices (ckks.(*Bootstrapper).genDFTMatrices -> GenCoeffsToSlotsMatrix /
+ * GenSlotsToCoeffsMatrix -> EncodeDiagMatrixBSGSAtLvl -> encodeDiagonal). Nothing is planted. Recorded per matrix: level, scale,
+ * maxN1N2Ratio, logSlots and - on return - N1; per diagonal (Go iterates the index MAP, so the order inside a matrix is arbitrary):
+ * level, scale, the SHA-256 of the complex128 values handed to the encoder and of the two encoded polynomials (mod Q: level+1 limbs in
+ * NTT + Montgomery form; mod P). The run is killed after N diagonals or when the first convolution starts. -dump FILE additionally
+ * writes the raw values (build-container analysis only; never committed). */
+static int g_diag_max = 0, g_diag_calls = 0, g_diag_mats = 0; static FILE *g_dump;
+static void diag_done(void) { fprintf(g_out, "\n ],\n \"exit_code\": 0}\n"); fflush(g_out); if (g_dump) fclose(g_dump); kill(g_pid, SIGKILL); exit(0); }
+static void ret_encdiag(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; ud3_t *u = ud; (void)u;
+    /* results sit above the arguments: [rsp-8+0x40], [rsp-8+0x48] relative to the entry rsp; here rsp = entry rsp + 8 */
+    uint64_t mq = rd64(r->rsp + 0x38), mp = rd64(r->rsp + 0x40);
+    emit_poly("mQ", mq, poly_limbs(mq)); emit_poly("mP", mp, poly_limbs(mp)); emit_end();
+    if (g_diag_calls >= g_diag_max) diag_done(); }
+static void on_encdiag(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_diag_max) return;
+    uint64_t logslots = rd64(r->rsp + 0x10), level = rd64(r->rsp + 0x18), vp = rd64(r->rsp + 0x28), vl = rd64(r->rsp + 0x30); double scale = rdf64(r->rsp + 0x20);
+    char hex[65]; sha_mem(vp, vl * 16, hex);
+    emit_begin("encodeDiagonal"); fprintf(g_out, ", \"call\": %d, \"matrix\": %d, \"logSlots\": %lu, \"level\": %lu, \"scale\": %.17g, \"n\": %lu, \"values\": \"%s\"", g_diag_calls++, g_diag_mats - 1, logslots, level, scale, vl, hex);
+    if (g_dump) { uint64_t hdr[4] = {(uint64_t)(g_diag_mats - 1), level, vl, 0}; memcpy(&hdr[3], &scale, 8); fwrite(hdr, 8, 4, g_dump);
+                  uint8_t *buf = malloc(vl * 16); rd(vp, buf, vl * 16); fwrite(buf, 16, vl, g_dump); free(buf); fflush(g_dump); }
+    hook_return(r, ret_encdiag, ud_new(0, 0, 0)); }
+static void ret_encmat(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; ud3_t *u = ud;
+    uint64_t m = rd64(r->rsp + 0x30);
+    emit_begin("matrix_done"); fprintf(g_out, ", \"matrix\": %lu, \"LogSlots\": %lu, \"N1\": %lu, \"Level\": %lu, \"Scale\": %.17g", u->a, rd64(m), rd64(m + 8), rd64(m + 16), rdf64(m + 24)); emit_end(); }
+static void on_encmat(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_diag_max) return;
+    emit_begin("EncodeDiagMatrixBSGSAtLvl"); fprintf(g_out, ", \"matrix\": %d, \"level\": %lu, \"scale\": %.17g, \"maxN1N2Ratio\": %.17g, \"logSlots\": %lu", g_diag_mats, rd64(r->rsp + 0x10), rdf64(r->rsp + 0x20), rdf64(r->rsp + 0x28), rd64(r->rsp + 0x30)); emit_end();
+    hook_return(r, ret_encmat, ud_new((uint64_t)g_diag_mats++, 0, 0)); }
+static void on_ctp_diag(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r; (void)ud; if (g_diag_max) diag_done(); }
+
+/* -flow: log-only walk through the convReLU chain between the entry of ckks.(*Bootstrapper).BootstrappConv_CtoS (eval.go:450) and the
+ * return of ckks.SlotsToCoeffs (inside BootstrappConv_StoC, eval.go:543-550): every evaluator call on the way with the level and scale
+ * of its ciphertext arguments and results and its scalar arguments. Nothing is planted, nothing is digested (the run's keys are random);
+ * what is pinned is the STAGE STRUCTURE: which op at which level with which scale / constant. Hooks sit behind the stack check. */
+typedef struct { const char *name; uint64_t fn; int in_ct[3]; int in_iface[2]; int f64[2]; int i64[2]; int out_arg; int out_res[2]; int out_slice; } flow_t;
+#define NA (-1)
+static flow_t g_flow[] = {
+  /* name                       fn         in_ct (entry rsp +)   operands by iface(data) f64 args   int args   ctOut arg  results (entry rsp +)  []*ct result */
+  {"BootstrappConv_CtoS",       0x506800, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  NA,        {0x18, 0x20},          NA},
+  {"modUp",                     0x507400, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  NA,        {0x18, NA},            NA},
+  {"CoeffsToSlots",             0x507dc0, {0x08, NA, NA},        {NA, NA},              {NA, NA},  {0x18, NA},NA,        {0x38, 0x40},          NA},
+  {"SlotsToCoeffs",             0x508140, {0x08, 0x10, NA},      {NA, NA},              {NA, NA},  {0x20, NA},NA,        {0x40, NA},            NA},
+  {"evaluateSine",              0x508380, {0x10, 0x18, NA},      {NA, NA},              {NA, NA},  {NA, NA},  NA,        {0x20, 0x28},          NA},
+  {"evaluateCheby",             0x508540, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  NA,        {0x18, NA},            NA},
+  {"EvaluateCheby",             0x52d7c0, {0x10, NA, NA},        {NA, NA},              {0x20, NA},{NA, NA},  NA,        {0x28, NA},            NA},
+  {"EvaluatePoly",              0x52d3c0, {0x10, NA, NA},        {NA, NA},              {0x20, NA},{NA, NA},  NA,        {0x28, NA},            NA},
+  {"LinearTransform",           0x5264c0, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {0x20, NA},NA,        {NA, NA},              0x28},
+  {"MultByConst",               0x51ee80, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {0x18, 0x20}, 0x28,   {NA, NA},              NA},
+  {"AddConst",                  0x51d9e0, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {0x18, 0x20}, 0x28,   {NA, NA},              NA},
+  {"Rescale",                   0x522440, {0x10, NA, NA},        {NA, NA},              {0x18, NA},{NA, NA},  0x20,      {NA, NA},              NA},
+  {"DropLevel",                 0x5223a0, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {0x18, NA},0x10,      {NA, NA},              NA},
+  {"SetScale",                  0x521b80, {0x10, NA, NA},        {NA, NA},              {0x18, NA},{NA, NA},  0x10,      {NA, NA},              NA},
+  {"mulRelin",                  0x522c60, {0x10, NA, NA},        {0x20, NA},            {NA, NA},  {0x28, NA},0x30,      {NA, NA},              NA},
+  {"Conjugate",                 0x5247e0, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  0x18,      {NA, NA},              NA},
+  {"ConjugateNew",              0x524680, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  NA,        {0x18, NA},            NA},
+  {"MultByi",                   0x520b00, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  0x18,      {NA, NA},              NA},
+  {"MultByiNew",                0x5209a0, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  NA,        {0x18, NA},            NA},
+  {"DivByi",                    0x521280, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  0x18,      {NA, NA},              NA},
+  {"Add",                       0x51aee0, {NA, NA, NA},          {0x18, 0x28},          {NA, NA},  {NA, NA},  0x30,      {NA, NA},              NA},
+  {"AddNew",                    0x51b1a0, {NA, NA, NA},          {0x18, 0x28},          {NA, NA},  {NA, NA},  NA,        {0x30, NA},            NA},
+  {"Sub",                       0x51b320, {NA, NA, NA},          {0x18, 0x28},          {NA, NA},  {NA, NA},  0x30,      {NA, NA},              NA},
+  {"SubNew",                    0x51b9a0, {NA, NA, NA},          {0x18, 0x28},          {NA, NA},  {NA, NA},  NA,        {0x30, NA},            NA},
+  {"Neg",                       0x51d260, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  0x18,      {NA, NA},              NA},
+  {"MulByPow2",                 0x521e80, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {0x18, NA},0x20,      {NA, NA},              NA},
+  {"MulByPow2New",              0x521d00, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {0x18, NA},NA,        {0x20, NA},            NA},
+  {"ScaleUp",                   0x521ac0, {0x10, NA, NA},        {NA, NA},              {0x18, NA},{NA, NA},  0x20,      {NA, NA},              NA},
+  {"Rotate",                    0x524420, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {0x18, NA},0x20,      {NA, NA},              NA},
+  {"RotateNew",                 0x5242a0, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {0x18, NA},NA,        {0x20, NA},            NA},
+  {"main.evalReLU",             0x53a040, {NA, NA, NA},          {NA, NA},              {NA, NA},  {NA, NA},  NA,        {NA, NA},              NA},
+  {"main.keep_ctxt",            0x5399c0, {NA, NA, NA},          {NA, NA},              {NA, NA},  {NA, NA},  NA,        {NA, NA},              NA},
+};
+static int g_flow_on = 0, g_flow_mode = 0, g_flow_depth = 0;
+static uint64_t post_check(uint64_t fn) {            /* first instruction behind Go's stack check (function start if it has none) */
+    uint8_t b[40]; rd(fn, b, sizeof b);
+    if (!(b[0] == 0x64 && b[1] == 0x48 && b[2] == 0x8b)) return fn;
+    for (int i = 9; i < 30; i++) if (b[i] == 0x3b && (b[i+1] == 0x61 || b[i+1] == 0x41) && b[i+2] == 0x10) {
+        if (b[i+3] == 0x0f && b[i+4] == 0x86) return fn + (uint64_t)i + 9;
+        if (b[i+3] == 0x76) return fn + (uint64_t)i + 5;
+    }
+    fprintf(stderr, "no stack check found at %#lx\n", fn); exit(3);
+}
+static int plausible_ct(uint64_t p) {                  /* heap pointer whose first word points at a []*ring.Poly header of length 2 or 3 */
+    if (p < 0xc000000000ull || p > 0xd000000000ull) return 0;
+    uint64_t inner = rd64(p); if (inner < 0xc000000000ull || inner > 0xd000000000ull) return 0;
+    uint64_t n = rd64(inner + 8); return n >= 1 && n <= 3 && rd64(inner) >= 0xc000000000ull;
+}
+static void flow_ct(const char *key, int idx, uint64_t ct) {
+    if (!plausible_ct(ct)) { fprintf(g_out, ", \"%s%d\": null", key, idx); return; }
+    fprintf(g_out, ", \"%s%d\": {\"level\": %d, \"scale\": %.17g, \"degree\": %d}", key, idx, poly_limbs(ct_poly(ct, 0)) - 1, ct_scale(ct), ct_degree1(ct) - 1);
+}
+typedef struct { flow_t *f; uint64_t out_arg; int depth; } flowret_t;
+static flowret_t g_flowret[MAXPEND]; static int g_flowret_i;
+static void flow_done(void) { fprintf(g_out, "\n ],\n \"exit_code\": 0}\n"); fflush(g_out); kill(g_pid, SIGKILL); exit(0); }
+static void ret_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; flowret_t *u = ud; flow_t *f = u->f;
+    uint64_t E = r->rsp - 8;                           /* the entry stack pointer */
+    emit_begin("ret"); fprintf(g_out, ", \"fn\": \"%s\", \"depth\": %d", f->name, u->depth);
+    if (u->out_arg) flow_ct("out", 0, u->out_arg);
+    for (int i = 0; i < 2; i++) if (f->out_res[i] != NA) flow_ct("res", i, rd64(E + (uint64_t)f->out_res[i]));
+    if (f->out_slice != NA) { uint64_t p = rd64(E + (uint64_t)f->out_slice), n = rd64(E + (uint64_t)f->out_slice + 8); for (uint64_t i = 0; i < n && i < 2; i++) flow_ct("res", (int)i, rd64(p + 8 * i)); }
+    emit_end(); g_flow_depth = u->depth;
+    if (!strcmp(f->name, "SlotsToCoeffs")) flow_done(); }
+static void on_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; flow_t *f = ud;
+    if (!g_flow_mode) return;
+    if (!g_flow_on) { if (strcmp(f->name, "BootstrappConv_CtoS")) return; g_flow_on = 1; }
+    uint64_t E = r->rsp;
+    emit_begin("call"); fprintf(g_out, ", \"fn\": \"%s\", \"depth\": %d", f->name, g_flow_depth);
+    for (int i = 0; i < 3; i++) if (f->in_ct[i] != NA) flow_ct("in", i, rd64(E + (uint64_t)f->in_ct[i]));
+    for (int i = 0; i < 2; i++) if (f->in_iface[i] != NA) flow_ct("op", i, rd64(E + (uint64_t)f->in_iface[i]));
+    for (int i = 0; i < 2; i++) if (f->f64[i] != NA) fprintf(g_out, ", \"f%d\": %.17g", i, rdf64(E + (uint64_t)f->f64[i]));
+    for (int i = 0; i < 2; i++) if (f->i64[i] != NA) fprintf(g_out, ", \"i%d\": %ld", i, (long)rd64(E + (uint64_t)f->i64[i]));
+    if (!strcmp(f->name, "MultByConst") || !strcmp(f->name, "AddConst")) {      /* constant interface{}: type word + data word */
+        uint64_t ty = rd64(E + 0x18), data = rd64(E + 0x20); uint64_t w0 = 0, w1 = 0;
+        if (data >= 0x400000) { w0 = rd64(data); w1 = rd64(data + 8); }
+        double d0, d1; memcpy(&d0, &w0, 8); memcpy(&d1, &w1, 8);
+        fprintf(g_out, ", \"const_type\": %lu, \"const_words\": [%lu, %lu], \"const_f64\": [%.17g, %.17g]", ty, w0, w1, d0, d1);
+    }
+    if (!strcmp(f->name, "LinearTransform")) {           /* *PtDiagMatrix: LogSlots, N1, Level, Scale */
+        uint64_t m = rd64(E + 0x20);
+        if (m >= 0xc000000000ull) fprintf(g_out, ", \"matrix\": {\"ptr\": %lu, \"LogSlots\": %lu, \"N1\": %lu, \"Level\": %lu, \"Scale\": %.17g}", m, rd64(m), rd64(m + 8), rd64(m + 16), rdf64(m + 24));
+    }
+    if (!strcmp(f->name, "EvaluateCheby")) {             /* *ChebyshevInterpolation{Poly{maxDeg, coeffs, lead}, a, b} */
+        uint64_t c = rd64(E + 0x18);
+        fprintf(g_out, ", \"cheby\": {\"maxDeg\": %lu, \"ncoeffs\": %lu, \"lead\": %lu}", rd64(c), rd64(c + 16), rd64(c + 32) & 0xff);
+    }
+    emit_end();
+    flowret_t *u = &g_flowret[g_flowret_i++ % MAXPEND]; u->f = f; u->depth = g_flow_depth++;
+    u->out_arg = f->out_arg != NA ? rd64(E + (uint64_t)f->out_arg) : 0;
+    hook_return(r, ret_flow, u); }
+
 /* -poly N: ckks.(*evaluator).EvaluatePoly one level up (conv.go:460-477: the three sign polynomials of evalReLU). At the entry of the
  * first N calls the input ciphertext is planted (SEED_OPIN(call, 0, poly, limb) mod q_limb); every relinearisation key a nested
  * SwitchKeysInPlace reads is planted as in -ks / -ops (SEED_KSEVK by key identity). Recorded: the polynomial (maxDeg, lead, the real
@@ -601,6 +732,7 @@ static void ret_ctp(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (v
 }
 static int g_ctp_calls;
 static void on_ctp(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (g_diag_max) { on_ctp_diag(t, r, ud); return; }
     if (g_ks_max) return;
     uint64_t E = r->rsp;
     uint64_t ct_in = rd64(E + 0x80), ker = rd64(E + 0x88), nker = rd64(E + 0x90), idx = rd64(E + 0xa0), nidx = rd64(E + 0xa8);
@@ -669,6 +801,9 @@ int main(int argc, char **argv) {
         }
         else if (!strcmp(argv[ai], "-poly") && ai + 1 < argc) g_poly_max = atoi(argv[++ai]);          /* trace this many EvaluatePoly calls (planted input and keys) */
         else if (!strcmp(argv[ai], "-enc") && ai + 1 < argc) g_enc_max = atoi(argv[++ai]);            /* trace the slot encoder: this many invfft / Encode calls */
+        else if (!strcmp(argv[ai], "-diag") && ai + 1 < argc) g_diag_max = atoi(argv[++ai]);          /* digest this many encoded DFT diagonals */
+        else if (!strcmp(argv[ai], "-dump") && ai + 1 < argc) { g_dump = fopen(argv[++ai], "wb"); if (!g_dump) { perror("dump"); return 2; } }
+        else if (!strcmp(argv[ai], "-flow")) g_flow_mode = 1;
         else if (!strcmp(argv[ai], "-keep-bl")) g_skip_bl = 0;
         else if (!strcmp(argv[ai], "-noplant")) g_noplant = 1;
         else if (!strcmp(argv[ai], "-seed") && ai + 1 < argc) g_seed = strtoull(argv[++ai], NULL, 0);
@@ -705,6 +840,8 @@ int main(int argc, char **argv) {
     fprintf(g_out, "],\n \"ks_Q\": ["); for (int i = 0; i < g_nQ; i++) fprintf(g_out, "%s%lu", i ? ", " : "", g_Q[i]);
     fprintf(g_out, "], \"ks_P\": ["); for (int i = 0; i < g_nP; i++) fprintf(g_out, "%s%lu", i ? ", " : "", g_Pm[i]);
     fprintf(g_out, "],\n \"events\": [");
+    if (g_flow_mode) for (size_t i = 0; i < sizeof g_flow / sizeof g_flow[0]; i++) bp_add(post_check(g_flow[i].fn), on_flow, &g_flow[i]);
+    if (g_flow_mode) goto hooks_done;          /* the flow hooks share addresses with the ones below (the first handler of an address wins) */
     bp_add(A_CONV_THEN_PACK, on_ctp, NULL);
     bp_add(A_ENCODECOEFFS, on_encode, NULL);
     bp_add(A_MULNEW, on_mulnew, NULL);
@@ -717,8 +854,10 @@ int main(int argc, char **argv) {
     if (g_poly_max) { bp_add(A_EVALPOLY, on_evalpoly, NULL); bp_add(A_MULRELIN, on_p_mulrelin, NULL); bp_add(A_RESCALE, on_p_rescale, NULL); bp_add(A_MGIAA, on_p_mgiaa, NULL);
                       bp_add(A_ADDCONST, on_p_addconst, NULL); bp_add(A_DROPLEVEL, on_p_droplevel, NULL); bp_add(A_RECURSE, on_p_recurse, NULL); bp_add(A_POLYLEAF, on_p_leaf, NULL);
                       bp_add(A_POWERBASIS, on_p_powerbasis, NULL); bp_add(A_ADD, on_p_add, NULL); bp_add(A_MULTBYCONST, on_p_multbyconst, NULL); }
+    if (g_diag_max) { bp_add(A_ENCDIAG, on_encdiag, NULL); bp_add(A_ENCMAT, on_encmat, NULL); }
     if (g_enc_max) { bp_add(A_INVFFT, on_invfft, NULL); bp_add(A_ENCODE, on_encode_slots, NULL); }
     if (g_ops_max) { bp_add(A_RESCALE, on_rescale, NULL); bp_add(A_MULRELIN, on_mulrelin, NULL); bp_add(A_ROTATE, on_rotate, NULL); bp_add(A_MODUP, on_modup, NULL); }
+hooks_done:
 
     ptrace(PTRACE_CONT, pid, 0, 0);
     int exit_code = -1; uint64_t refire_addr = 0, refire_rsp = 0;

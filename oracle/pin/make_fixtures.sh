@@ -39,3 +39,19 @@ d["events"] = [e for e in d["events"] if e["op"].startswith("p.") or e["op"].sta
 d["note"] = "gotrace -poly 3 over `convReLU 5 1 1`; a MultByConst that an Add's scale matching calls is listed BEFORE that Add (it completes first)"
 json.dump(d, open(sys.argv[1], "w"), indent=0)
 PY
+# the bootstrapper's DFT matrices: every diagonal genDFTMatrices hands to encodeDiagonal (value digest) and what comes back (mod Q, mod P)
+"$SCRATCH/gotrace" -diag 1000 -o trace_diag_5_1.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_diag.txt 2>&1
+python3 - "$REPO/tests/golden/ref_trace_diag_5_1.json" <<'PY'
+import json, sys
+d = json.load(open("trace_diag_5_1.json"))
+ev = []
+for e in d["events"]:
+    if e["op"] in ("EncodeDiagMatrixBSGSAtLvl", "matrix_done"):
+        ev.append(e)
+    elif e["op"] == "encodeDiagonal":      # digests only; the order inside a matrix is Go's map order, i.e. arbitrary
+        ev.append({"op": e["op"], "matrix": e["matrix"], "level": e["level"], "scale": e["scale"], "n": e["n"], "values": e["values"],
+                   "mQ": e["mQ"]["sha256"], "mQ_limbs": e["mQ"]["limbs"], "mP": e["mP"]["sha256"], "mP_limbs": e["mP"]["limbs"]})
+d["events"] = ev
+d["note"] = "gotrace -diag over `convReLU 5 1 1`: nothing planted; matrices 0-3 CoeffsToSlots, 4-6 and 7-9 the two SlotsToCoeffs sets"
+json.dump(d, open(sys.argv[1], "w"), indent=0)
+PY
