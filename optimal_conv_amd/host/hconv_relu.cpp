@@ -31,6 +31,7 @@
 #include <set>
 
 #include "hconv_encoder.hpp"
+#include "hconv_sha256.hpp"
 #include "hconv_host.hpp"
 
 namespace hconv {
@@ -362,7 +363,76 @@ struct Boot {
         }
         return groups;
     }
-    LT plan(const DiagMat &M, int level, double pt_scale) {          // BSGS split + the pre-rotated, encoded diagonals
+    // ---------------- the same matrices as the reference's Lattigo fork builds them (full slots, ls = 0)
+    // ckks.(*Bootstrapper).genDFTMatrices -> GenCoeffsToSlotsMatrix / GenSlotsToCoeffsMatrix -> computeDFTMatrices (fftPlainVec /
+    // fftInvPlainVec, genFFTDiagMatrix, multiplyFFTMatrixWithNextFFTLevel) of github.com/dwkim606/test_lattigo (binary only): the
+    // radix-2 levels as (a, b, c) diagonals, merged ceil(remaining / depth-left) at a time, every complex product evaluated as Go does
+    // (four rounded products, no fused multiply-add; build flags carry no -march, so the compiler has no FMA to contract into) and the
+    // sums in the fork's order; roots = the encoder's table (computeRoots(2n) is the same Go cos / sin of the same angles).
+    // tests/golden/ref_trace_diag_5_1.json holds the SHA-256 of every vector the binary hands to its encoder and of every encoded
+    // polynomial; HCONV_DFT_DIGESTS=<file> makes this host write its own (tests/test_emu.py, tests/test_gpu_z_cli.py compare).
+    static cplx go_mul(cplx x, cplx y) { return cplx(x.real() * y.real() - x.imag() * y.imag(), x.real() * y.imag() + x.imag() * y.real()); }
+    static void add_to(DiagMat &M, int k, std::vector<cplx> v) {
+        auto it = M.find(k);
+        if (it == M.end()) M.emplace(k, std::move(v)); else for (size_t p = 0; p < v.size(); p++) it->second[p] += v[p];
+    }
+    std::vector<DiagMat> lattigo_dft(bool inverse, int depth, double diffscale) const {
+        const int logn = LOGN - 1, ns = n;
+        std::vector<int> pow5((size_t)(2 * ns + 1), 1);
+        for (size_t i = 1; i < pow5.size(); i++) pow5[i] = (int)(((long)pow5[i - 1] * 5) & (4L * ns - 1));
+        std::vector<std::vector<cplx>> a, b, c;
+        for (int s = 0; s < logn; s++) {
+            const int m = inverse ? ns >> s : 2 << s, tt = m >> 1, gap = ns / m, mask = (m << 2) - 1;
+            std::vector<cplx> va((size_t)ns, cplx(0, 0)), vb((size_t)ns, cplx(0, 0)), vc((size_t)ns, cplx(0, 0));
+            for (int i = 0; i < ns; i += m) for (int j = 0; j < tt; j++) {
+                const int k = inverse ? ((m << 2) - (pow5[(size_t)j] & mask)) * gap : (pow5[(size_t)j] & mask) * gap;
+                const cplx w = enc.roots[(size_t)k];
+                va[(size_t)(i + j)] = cplx(1, 0); va[(size_t)(i + j + tt)] = -w;
+                if (inverse) { vb[(size_t)(i + j)] = cplx(1, 0); vc[(size_t)(i + j + tt)] = w; }
+                else { vb[(size_t)(i + j)] = w; vc[(size_t)(i + j + tt)] = cplx(1, 0); }
+            }
+            a.push_back(std::move(va)); b.push_back(std::move(vb)); c.push_back(std::move(vc));
+        }
+        std::vector<int> merge((size_t)depth, 0);
+        for (int i = 0, lvl = logn; i < depth; i++) { const int d = (lvl + depth - i - 1) / (depth - i); merge[(size_t)(inverse ? i : depth - i - 1)] = d; lvl -= d; }
+        auto rot_of = [&](int level) { return inverse ? 1 << (level - 1) : 1 << (logn - level); };
+        auto rotated_times = [&](const std::vector<cplx> &v, int r, const std::vector<cplx> &w) {       // mul(rotate(v, r), w): rotate is to the left
+            std::vector<cplx> out((size_t)ns); for (int p = 0; p < ns; p++) out[(size_t)p] = go_mul(v[(size_t)((p + r) & (ns - 1))], w[(size_t)p]); return out; };
+        std::vector<DiagMat> out;
+        for (int i = 0, lvl = logn; i < depth; i++) {
+            DiagMat M; { const int r = rot_of(lvl), x = logn - lvl; add_to(M, 0, a[(size_t)x]); add_to(M, r, b[(size_t)x]); add_to(M, ns - r, c[(size_t)x]); }
+            for (int j = 0, nxt = lvl - 1; j < merge[(size_t)i] - 1; j++, nxt--) {
+                const int r = rot_of(nxt) & (ns - 1), x = logn - nxt;
+                DiagMat nw;
+                for (auto &e : M) {           // the fork ranges over a Go map here; at every position at most two of the three terms are non-zero, so the sums do not depend on the order
+                    add_to(nw, e.first, rotated_times(e.second, 0, a[(size_t)x]));
+                    add_to(nw, (e.first + r) & (ns - 1), rotated_times(e.second, r, b[(size_t)x]));
+                    add_to(nw, (e.first - r) & (ns - 1), rotated_times(e.second, ns - r, c[(size_t)x]));
+                }
+                M = std::move(nw);
+            }
+            for (auto &e : M) for (auto &v : e.second) v = go_mul(v, cplx(diffscale, 0));
+            out.push_back(std::move(M)); lvl -= merge[(size_t)i];
+        }
+        return out;
+    }
+    // findbestbabygiantstepsplit / bsgsIndex of the fork (maxN1N2Ratio = 16): the first N1 with more hoisted (baby) rotations than giant
+    // ones, doubled until their ratio reaches 16
+    static int lattigo_n1(const DiagMat &M, int slots, double max_ratio = 16.0) {
+        for (int n1 = 1; n1 < slots; n1 <<= 1) {
+            std::map<int, int> index; for (auto &e : M) index[(e.first & (slots - 1)) / n1]++;
+            if (!index.count(0)) continue;
+            int hoisted = index[0] - 1, normal = (int)index.size() - 1;
+            if (normal == 0) return n1 / 2;
+            if (hoisted > normal) {
+                while ((double)hoisted / (double)normal < max_ratio) { if (normal / 2 == 0) break; n1 *= 2; hoisted = hoisted * 2 + 1; normal /= 2; }
+                return n1;
+            }
+        }
+        return 1;
+    }
+    FILE *dft_digests = nullptr;
+    LT plan(const DiagMat &M, int level, double pt_scale, bool lattigo_split = false, const char *tag = "") {          // BSGS split + the pre-rotated, encoded diagonals
         LT lt; lt.level = level; lt.pt_scale = pt_scale;
         int best = -1;
         for (int n1 = 1; n1 <= n; n1 <<= 1) {
@@ -371,10 +441,19 @@ struct Boot {
             const int cost = (int)(babies.size() + giants.size());
             if (best < 0 || cost < best) { best = cost; lt.n1 = n1; }
         }
+        if (lattigo_split) lt.n1 = lattigo_n1(M, n);
         for (auto &e : M) {
             const int k = e.first, g = k - k % lt.n1, b = k % lt.n1;
-            std::vector<cplx> rolled((size_t)n); for (int p = 0; p < n; p++) rolled[(size_t)p] = e.second[(size_t)(((p - g) % n + n) % n)];     // np.roll(diag, g)
+            std::vector<cplx> rolled((size_t)n); for (int p = 0; p < n; p++) rolled[(size_t)p] = e.second[(size_t)(((p - g) % n + n) % n)];     // np.roll(diag, g) = the fork's rotate(v, -N1*j)
             lt.giant[g][b] = encode(rolled, level, pt_scale);
+            if (dft_digests) {      // what the reference's encodeDiagonal receives and returns (mod Q): values; NTT rows in Montgomery form + the spare zero limb
+                Sha256 hv; hv.update(rolled.data(), rolled.size() * sizeof(cplx));
+                std::vector<uint64_t> rows((size_t)(level + 1) * N), zero((size_t)N, 0);
+                HCR(hc_download(hc, rows.data(), lt.giant[g][b].p.get(), rows.size() * 8));
+                for (int l = 0; l <= level; l++) { const uint64_t q = Q[(size_t)l], r = (uint64_t)((((u128)1) << 64) % q); for (int j = 0; j < N; j++) rows[(size_t)l * N + j] = mulmod(rows[(size_t)l * N + j], r, q); }
+                Sha256 hq; hq.update(rows.data(), rows.size() * 8); hq.update(zero.data(), zero.size() * 8);
+                fprintf(dft_digests, "{\"matrix\": \"%s\", \"chain\": %d, \"level\": %d, \"scale\": %.17g, \"N1\": %d, \"k\": %d, \"values\": \"%s\", \"mQ\": \"%s\"}\n", tag, chain, level, pt_scale, lt.n1, k, hv.hex().c_str(), hq.hex().c_str());
+            }
         }
         return lt;
     }
@@ -568,27 +647,37 @@ struct Boot {
     Set &set(int ls) {
         auto it = sets.find(ls); if (it != sets.end()) return it->second;
         Set S; S.ls = ls; S.ns = n >> ls;
+        if (!dft_digests && getenv("HCONV_DFT_DIGESTS") && *getenv("HCONV_DFT_DIGESTS")) { dft_digests = fopen(getenv("HCONV_DFT_DIGESTS"), "a"); if (!dft_digests) panic("HCONV_DFT_DIGESTS: cannot open the file"); }
         const int D = 1 << ls, ns = S.ns;
         // CoeffsToSlots: (1/n_s) prod(stages), times 1/2 (real/imaginary extraction), 1/K (Chebyshev argument in [-1,1]), 1/D (SubSum)
-        std::vector<DiagMat> G = dft_groups(true, {4, 4, 4, 3}, 1.0 / (2.0 * (double)ns * SIN_K * D), ls);
+        // Full slots: the fork's own matrices (lattigo_dft) with its constant coeffsToSlotsDiffScale = (2 / ((b-a) N scFac qDiff))^(1/4), b-a = 2K/scFac,
+        // qDiff = q0 / 2^round(log2 q0) (genDFTMatrices) - the same 1/(2 n K) as below divided by qDiff, which ctos() accounts for by
+        // labelling the raised ciphertext 2^round(log2 q0) instead of q0 - and its baby-step size N1. For parameter set [6] these are the
+        // reference binary's diagonals bit for bit (tests/golden/ref_trace_diag_5_1.json). Sparse slots keep this file's own generator.
+        const double scfac = (double)(1 << SIN_DOUBLE), qdiff = (double)Q[0] / exp2(round(log2((double)Q[0])));
+        std::vector<DiagMat> G = ls ? dft_groups(true, {4, 4, 4, 3}, 1.0 / (2.0 * (double)ns * SIN_K * D), ls)
+                                    : lattigo_dft(true, 4, pow(2.0 / ((2.0 * SIN_K / scfac) * (double)N * scfac * qdiff), 1.0 / 4.0));
         if (ls) for (auto &e : G.back()) for (int p = 0; p < n; p++) if (p % (2 * ns) >= ns) e.second[(size_t)p] = cplx(0, 0);   // keep w on the first half of every 2 n_s slots
-        for (size_t i = 0; i < G.size(); i++) { const int lv = LV_CTS_TOP - (int)i; S.cts.push_back(plan(G[i], lv, (double)Q[(size_t)lv])); }
+        static const char *cts_tag[4] = {"cts0", "cts1", "cts2", "cts3"}, *stc_tag[3] = {"stc0", "stc1", "stc2"};
+        for (size_t i = 0; i < G.size(); i++) { const int lv = LV_CTS_TOP - (int)i; S.cts.push_back(plan(G[i], lv, (double)Q[(size_t)lv], ls == 0, cts_tag[i])); }
         // SlotsToCoeffs: level 3 carries all but the last matrix (plaintext scales multiply to q3), level 2 the last at 2^30
-        G = dft_groups(false, {5, 5, 5}, 1.0, ls);
+        // (the fork: the set NewBootstrapper_mod builds with scale 1 - the reference's SlotsToCoeffs call uses it - at the same three scales)
+        G = ls ? dft_groups(false, {5, 5, 5}, 1.0, ls) : lattigo_dft(false, 3, 1.0);
         if (ls) {       // packed a = (re | im)  ->  w = re + i im on both halves:  w = (m1 + i m2) a + (i m1 + m2) rot_{n_s}(a)
             DiagMat W; W[0].resize((size_t)n); W[ns].resize((size_t)n);
             for (int p = 0; p < n; p++) { const bool first = p % (2 * ns) < ns; W[0][(size_t)p] = first ? cplx(1, 0) : cplx(0, 1); W[ns][(size_t)p] = first ? cplx(0, 1) : cplx(1, 0); }
             G[0] = matmul_diag(G[0], W, 2 * ns);
         }
         if (G.size() != 3) panic("SlotsToCoeffs is planned as three matrices");
-        for (size_t i = 0; i + 1 < G.size(); i++) S.stc.push_back(plan(G[i], LV_STC_TOP, stc_scale_top));
-        S.stc.push_back(plan(G.back(), LV_STC_TOP - 1, stc_scale_last));
+        for (size_t i = 0; i + 1 < G.size(); i++) S.stc.push_back(plan(G[i], LV_STC_TOP, stc_scale_top, ls == 0, stc_tag[i]));
+        S.stc.push_back(plan(G.back(), LV_STC_TOP - 1, stc_scale_last, ls == 0, stc_tag[2]));
         for (auto *grp : {&S.cts, &S.stc}) for (auto &lt : *grp) for (auto &g : lt.giant) {
             if (g.first) key(gal_rot(g.first), lt.level);
             for (auto &b : g.second) if (b.first) key(gal_rot(b.first), lt.level);
         }
         for (int j = 0; j < ls; j++) key(gal_rot(ns << j), LV_CTS_TOP);       // SubSum
         if (ls) key(gal_rot(ns), LV_SINE_TOP);                                 // packing the imaginary half next to the real one
+        if (dft_digests) fflush(dft_digests);
         return sets.emplace(ls, std::move(S)).first->second;
     }
     // level-0 coefficient-encoded ciphertext -> slot-encoded at level 15, scale 2^30: two ciphertexts (low / high coefficient
@@ -596,7 +685,7 @@ struct Boot {
     int ctos(const DCt &ct0, int ls, DCt out[2]) {
         Set &S = set(ls);
         const double q0 = (double)Q[0], msg_scale = ct0.scale;
-        DCt ct = mod_raise(ct0, LV_CTS_TOP); ct.scale = q0;             // slot values are now t'/Q0 = I + msg/Q0, |.| <= K
+        DCt ct = mod_raise(ct0, LV_CTS_TOP); ct.scale = ls ? q0 : exp2(round(log2(q0)));   // slot values are now t'/Q0 = I + msg/Q0, |.| <= K (full slots: the 1/qDiff sits in the matrices)
         for (int j = 0; j < ls; j++) ct = add(ct, rotate(ct, S.ns << j));                                  // SubSum: trace onto X^D
         for (auto &lt : S.cts) ct = rescale(linear_transform(ct, lt));
         if (ct.level != LV_SINE_TOP) panic("CoeffsToSlots ended at the wrong level");

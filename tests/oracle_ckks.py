@@ -103,6 +103,19 @@ class Ct:
 
 
 # ------------------------------------------------------------------ slot encoder for any ring degree
+_GO_ROOTS = {}
+
+
+def _go_roots(M):
+    if M not in _GO_ROOTS:
+        import go_math
+        re = np.array([go_math.go_cos(2 * 3.141592653589793 * float(i) / float(M)) for i in range(M)] + [1.0])
+        im = np.array([go_math.go_sin(2 * 3.141592653589793 * float(i) / float(M)) for i in range(M)] + [0.0])
+        re[M], im[M] = re[0], im[0]
+        _GO_ROOTS[M] = re + 1j * im
+    return _GO_ROOTS[M]
+
+
 class Encoder:
     """ckks.encoderComplex128 (full slots): special FFT over the rotation group 5^j (as tests/oracle_bl.py, any logN)"""
 
@@ -113,8 +126,7 @@ class Encoder:
             rg[i] = g
             g = g * 5 % self.M
         self.rot_group = rg
-        ang = 2 * 3.141592653589793 * np.arange(self.M + 1, dtype=np.float64) / float(self.M)
-        self.roots = np.cos(ang) + 1j * np.sin(ang)
+        self.roots = _go_roots(self.M)            # Go's math.Cos / math.Sin (tests/go_math.py): the reference encoder's table, bit for bit
         bits = logN - 1
         idx = np.arange(self.n)
         br = np.zeros(self.n, dtype=np.int64)
@@ -130,31 +142,39 @@ class Encoder:
         lenh, lenq = ln >> 1, ln << 2
         return self.roots[(self.rot_group[:lenh] % lenq) * (self.M // lenq)]
 
+    # the two transforms with every complex product as four rounded real products (what Go and the device encoder compute; numpy's own
+    # complex multiply may fuse) - tests/oracle_bl.py's pinned invfft_special / fft_special for any ring degree
     def invfft(self, values):
         v = np.array(values, dtype=np.complex128)
         n, ln = self.n, self.n
+        re, im = v.real.copy(), v.imag.copy()
         while ln >= 2:
             lenh = ln >> 1
             w = self.inv_stage_twiddles(ln)
-            blk = v.reshape(n // ln, ln)
-            a, b = blk[:, :lenh].copy(), blk[:, lenh:].copy()
-            blk[:, :lenh] = a + b
-            blk[:, lenh:] = (a - b) * w
+            br, bi = re.reshape(n // ln, ln), im.reshape(n // ln, ln)
+            ar, ai, cr, ci = br[:, :lenh].copy(), bi[:, :lenh].copy(), br[:, lenh:].copy(), bi[:, lenh:].copy()
+            br[:, :lenh] = ar + cr; bi[:, :lenh] = ai + ci
+            dr, di = ar - cr, ai - ci
+            p0, p1, p2, p3 = dr * w.real, di * w.imag, dr * w.imag, di * w.real
+            br[:, lenh:] = p0 - p1; bi[:, lenh:] = p2 + p3
             ln >>= 1
-        return (v / complex(float(n), 0))[self.br]
+        return ((re * (1.0 / float(n))) + 1j * (im * (1.0 / float(n))))[self.br]
 
     def fft(self, values):
         v = np.array(values, dtype=np.complex128)[self.br]
         n, ln = self.n, 2
+        re, im = v.real.copy(), v.imag.copy()
         while ln <= n:
             lenh = ln >> 1
             w = self.fwd_stage_twiddles(ln)
-            blk = v.reshape(n // ln, ln)
-            a, b = blk[:, :lenh].copy(), blk[:, lenh:] * w
-            blk[:, :lenh] = a + b
-            blk[:, lenh:] = a - b
+            br, bi = re.reshape(n // ln, ln), im.reshape(n // ln, ln)
+            ar, ai, cr, ci = br[:, :lenh].copy(), bi[:, :lenh].copy(), br[:, lenh:].copy(), bi[:, lenh:].copy()
+            p0, p1, p2, p3 = cr * w.real, ci * w.imag, cr * w.imag, ci * w.real
+            tr, ti = p0 - p1, p2 + p3
+            br[:, :lenh] = ar + tr; bi[:, :lenh] = ai + ti
+            br[:, lenh:] = ar - tr; bi[:, lenh:] = ai - ti
             ln <<= 1
-        return v
+        return re + 1j * im
 
     def slots_to_coeffs(self, values):
         v = self.invfft(values)
@@ -390,11 +410,12 @@ class Ckks:
             n1 <<= 1
         return best[1]
 
-    def linear_transform(self, ct, diags, pt_scale):
-        """sum_k diag_k (.) rot_k(ct), plaintext diagonals encoded at ct's level with scale pt_scale; no rescale here"""
+    def linear_transform(self, ct, diags, pt_scale, n1=None):
+        """sum_k diag_k (.) rot_k(ct), plaintext diagonals encoded at ct's level with scale pt_scale; no rescale here.
+        n1: baby-step size (None: the cheapest split; the bootstrapper passes the fork's findbestbabygiantstepsplit)"""
         L = ct.level
         ks = sorted(diags)
-        n1 = self.bsgs_split(ks)
+        n1 = n1 or self.bsgs_split(ks)
         rots = {b: self.rotate(ct, b) for b in sorted({k % n1 for k in ks})}
         acc = None
         for g in sorted({k - k % n1 for k in ks}):
@@ -707,8 +728,24 @@ class Bootstrapper:
         cts_groups, stc_groups = self._fit(cts_groups, logn), self._fit(stc_groups, logn)
         # CoeffsToSlots: (1/n_s) * prod(stages), times 1/2 (real/imaginary extraction), 1/K (Chebyshev argument in [-1,1])
         # and 1/D (SubSum multiplies the surviving coefficients by D)
-        self.cts = C.dft_groups(True, cts_groups, 1.0 / (2.0 * ns * SIN_K * D), log_sparse)
-        self.stc = C.dft_groups(False, stc_groups, 1.0, log_sparse)
+        if log_sparse == 0:
+            # full slots: the matrices exactly as the reference's Lattigo fork builds them (tests/lattigo_dft.py; for logN = 16 pinned
+            # against the binary in tests/test_oracle_pin_dft.py), its constant (1/qDiff included: ctos() labels the raised ciphertext
+            # 2^round(log2 q0)) and its baby-step sizes
+            import lattigo_dft as ld
+            qdiff = float(C.Q[0]) / 2.0 ** round(math.log2(float(C.Q[0])))
+            sc_fac = float(1 << SIN_DOUBLE)
+            d_cts = math.pow(2.0 / ((2.0 * SIN_K / sc_fac) * float(C.N) * sc_fac * qdiff), 1.0 / len(cts_groups))
+            cts = ld.compute_dft_matrices(logn, logn, len(cts_groups), d_cts, True)
+            stc = ld.compute_dft_matrices(logn, logn, len(stc_groups), 1.0, False)
+            self.cts_n1 = [ld.find_best_bsgs_split(list(M), ns, 16.0) for M in cts]
+            self.stc_n1 = [ld.find_best_bsgs_split(list(M), ns, 16.0) for M in stc]
+            self.cts = [{k: v.complex() for k, v in M.items()} for M in cts]
+            self.stc = [{k: v.complex() for k, v in M.items()} for M in stc]
+        else:
+            self.cts = C.dft_groups(True, cts_groups, 1.0 / (2.0 * ns * SIN_K * D), log_sparse)
+            self.stc = C.dft_groups(False, stc_groups, 1.0, log_sparse)
+            self.cts_n1, self.stc_n1 = [None] * len(self.cts), [None] * len(self.stc)
         if log_sparse:
             p = np.arange(C.n) % (2 * ns)
             m1, m2 = (p < ns).astype(np.complex128), (p >= ns).astype(np.complex128)
@@ -735,11 +772,11 @@ class Bootstrapper:
         q0 = float(C.Q[0])
         msg_scale = ct0.scale
         ct = C.mod_raise(ct0, LV_CTS_TOP)
-        ct.scale = q0                                            # slot values are now t'/Q0 = I + msg/Q0, |.| <= K
+        ct.scale = q0 if self.ls else 2.0 ** round(math.log2(q0))   # slot values are now t'/Q0 = I + msg/Q0, |.| <= K (full slots: 1/qDiff is in the matrices)
         for j in range(self.ls):                                 # SubSum: trace onto the subring X^D (rotations by n_s 2^j)
             ct = C.add(ct, C.rotate(ct, self.ns << j))
-        for G in self.cts:
-            ct = C.rescale(C.linear_transform(ct, G, float(C.Q[ct.level])))
+        for G, n1 in zip(self.cts, self.cts_n1):
+            ct = C.rescale(C.linear_transform(ct, G, float(C.Q[ct.level]), n1))
         assert ct.level == LV_SINE_TOP
         cc = C.conjugate(ct)
         parts = [C.add(ct, cc), C.mul_by_i(C.sub(cc, ct))]       # (w + conj w), -i (w - conj w); the 1/2 is in the matrices
@@ -778,10 +815,10 @@ class Bootstrapper:
         # Ours: level 3 carries all but the last matrix (their plaintext scales multiply to q3), level 2 the last at scale 2^30
         first = G[:-1]
         sc, sc_last = self.stc_scales if self.stc_scales is not None else (float(C.Q[self.stc_top]) ** (1.0 / len(first)), 2.0 ** 30)
-        for M in first:
-            ct = C.linear_transform(ct, M, sc)
+        for M, n1 in zip(first, self.stc_n1):
+            ct = C.linear_transform(ct, M, sc, n1)
         ct = C.rescale(ct)
-        ct = C.rescale(C.linear_transform(ct, G[-1], sc_last))
+        ct = C.rescale(C.linear_transform(ct, G[-1], sc_last, self.stc_n1[-1]))
         return ct
 
 

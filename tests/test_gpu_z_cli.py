@@ -57,17 +57,46 @@ def test_conv_7_3_cli_sharded_over_8_contexts(tmp_path):
     assert digests[0] == digests[1]
 
 
+def check_dft_digests_against_reference(path):
+    """HCONV_DFT_DIGESTS: the host's CoeffsToSlots / SlotsToCoeffs diagonals of parameter set [6] against what the reference binary
+    hands to and gets from its encoder (tests/golden/ref_trace_diag_5_1.json, gotrace -diag): all 93 CoeffsToSlots value vectors AND
+    their encoded polynomials (NTT, Montgomery form, 25..28 limbs) and all 158 SlotsToCoeffs value vectors (the reference encodes
+    those 12 levels higher than it uses them, so only the values compare), with the reference's baby-step sizes N1."""
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_trace_diag_5_1.json")))
+    ref_n1 = {e["matrix"]: e["N1"] for e in ref["events"] if e["op"] == "matrix_done"}
+    ref_d = {}
+    for e in ref["events"]:
+        if e["op"] == "encodeDiagonal":
+            ref_d.setdefault(e["matrix"], {})[e["values"]] = e
+    mine = [json.loads(l) for l in open(path) if l.strip()]
+    mine = [e for e in mine if e["chain"] == 6]
+    names = {"cts0": 0, "cts1": 1, "cts2": 2, "cts3": 3, "stc0": 7, "stc1": 8, "stc2": 9}
+    seen = {m: set() for m in names.values()}
+    for e in mine:
+        m = names[e["matrix"]]
+        assert e["N1"] == ref_n1[m], e
+        r = ref_d[m].get(e["values"])
+        assert r is not None, f"diagonal {e['matrix']}[{e['k']}]: value vector differs from the reference's"
+        if m < 4:
+            assert (e["level"], e["scale"]) == (r["level"], r["scale"]) and e["mQ"] == r["mQ"], f"encoded diagonal {e['matrix']}[{e['k']}] differs"
+        seen[m].add(e["values"])
+    assert [len(seen[m]) for m in (0, 1, 2, 3, 7, 8, 9)] == [16, 31, 31, 15, 63, 63, 32]
+
+
 @pytest.mark.parametrize("k,i_batch", [(3, 0), (5, 1)])
 def test_conv_relu_cli(tmp_path, k, i_batch):
     """`convReLU k i 1` (scope row 8f-1; BASELINE.md config 4 is k=5, i=1): convolution at out_scale 2^43, CtoS + sine,
     ReLU polynomials, mask, StoC on the GPU; decrypted result vs max(conv, 0). The reference binary prints AVG 8.4 / MED 11.5
     bits for `convReLU 5 1 1` (limited by the sign-polynomial approximation near 0)."""
     gen.write_case(str(tmp_path / "test_conv_data"), k, i_batch, 0)
+    dig = tmp_path / "dft_digests.jsonl"
     out = subprocess.run([CLI, "convReLU", str(k), str(i_batch), "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
-                         env=dict(os.environ, HCONV_SEED="31", HCONV_BOOT_STATS="1"))
+                         env=dict(os.environ, HCONV_SEED="31", HCONV_BOOT_STATS="1", HCONV_DFT_DIGESTS=str(dig)))
     assert out.returncode == 0, out.stderr[-2000:]
     txt = out.stdout
     print(txt)
+    check_dft_digests_against_reference(dig)
     for pat in (r"^Convolution followed by ReLU \(& Bootstrapping\) test start!$", r"^Generating bootstrapping keys\.\.\.$",
                 r"^Bootstrapping\.\.\. Ours \(until CtoS\):$", r"^Done in \S+ $", r"^Eval: Eval: ReLU Done in \S+ $", r"^Boot \(StoC\) Done in \S+ $"):
         assert re.search(pat, txt, re.M), f"missing line {pat!r} in:\n{txt}"
