@@ -119,7 +119,7 @@ static void bp_release(bp_t *b) { if (--b->refs == 0) bp_disarm(b); }
 /* pending function returns: LIFO per return address (Go may relocate the goroutine stack between
  * entry and return, so the stack pointer cannot be used to match them). */
 typedef struct { uint64_t ret_addr; handler_t fn; void *ud; } pend_t;
-#define MAXPEND 64
+#define MAXPEND 256
 static pend_t g_pend[MAXPEND]; static int g_npend;
 static void on_return_bp(pid_t tid, struct user_regs_struct *r, void *ud);
 static void hook_return(struct user_regs_struct *r, handler_t fn, void *ud) {
@@ -547,7 +547,7 @@ static void on_encmat(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; 
 static void on_ctp_diag(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r; (void)ud; if (g_diag_max) diag_done(); }
 
 /* -flow: log-only walk through the convReLU chain between the entry of ckks.(*Bootstrapper).BootstrappConv_CtoS (eval.go:450) and the
- * return of ckks.SlotsToCoeffs (inside BootstrappConv_StoC, eval.go:543-550): every evaluator call on the way with the level and scale
+ * return of main.evalConv_BNRelu_new (eval.go:272-607; BootstrappConv_StoC, eval.go:543-550, is inlined into it): every evaluator call on the way with the level and scale
  * of its ciphertext arguments and results and its scalar arguments. Nothing is planted, nothing is digested (the run's keys are random);
  * what is pinned is the STAGE STRUCTURE: which op at which level with which scale / constant. Hooks sit behind the stack check. */
 typedef struct { const char *name; uint64_t fn; int in_ct[3]; int in_iface[2]; int f64[2]; int i64[2]; int out_arg; int out_res[2]; int out_slice; } flow_t;
@@ -568,7 +568,7 @@ static flow_t g_flow[] = {
   {"Rescale",                   0x522440, {0x10, NA, NA},        {NA, NA},              {0x18, NA},{NA, NA},  0x20,      {NA, NA},              NA},
   {"DropLevel",                 0x5223a0, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {0x18, NA},0x10,      {NA, NA},              NA},
   {"SetScale",                  0x521b80, {0x10, NA, NA},        {NA, NA},              {0x18, NA},{NA, NA},  0x10,      {NA, NA},              NA},
-  {"mulRelin",                  0x522c60, {0x10, NA, NA},        {0x20, NA},            {NA, NA},  {0x28, NA},0x30,      {NA, NA},              NA},
+  {"mulRelin",                  0x522c60, {NA, NA, NA},          {0x18, 0x28},          {NA, NA},  {0x30, NA},0x38,      {NA, NA},              NA},
   {"Conjugate",                 0x5247e0, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  0x18,      {NA, NA},              NA},
   {"ConjugateNew",              0x524680, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  NA,        {0x18, NA},            NA},
   {"MultByi",                   0x520b00, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  0x18,      {NA, NA},              NA},
@@ -586,6 +586,7 @@ static flow_t g_flow[] = {
   {"RotateNew",                 0x5242a0, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {0x18, NA},NA,        {0x20, NA},            NA},
   {"main.evalReLU",             0x53a040, {NA, NA, NA},          {NA, NA},              {NA, NA},  {NA, NA},  NA,        {NA, NA},              NA},
   {"main.keep_ctxt",            0x5399c0, {NA, NA, NA},          {NA, NA},              {NA, NA},  {NA, NA},  NA,        {NA, NA},              NA},
+  {"main.evalConv_BNRelu_new",  0x53d440, {NA, NA, NA},          {NA, NA},              {NA, NA},  {NA, NA},  NA,        {NA, NA},              NA},
 };
 static int g_flow_on = 0, g_flow_mode = 0, g_flow_depth = 0;
 static uint64_t post_check(uint64_t fn) {            /* first instruction behind Go's stack check (function start if it has none) */
@@ -607,7 +608,8 @@ static void flow_ct(const char *key, int idx, uint64_t ct) {
     fprintf(g_out, ", \"%s%d\": {\"level\": %d, \"scale\": %.17g, \"degree\": %d}", key, idx, poly_limbs(ct_poly(ct, 0)) - 1, ct_scale(ct), ct_degree1(ct) - 1);
 }
 typedef struct { flow_t *f; uint64_t out_arg; int depth; } flowret_t;
-static flowret_t g_flowret[MAXPEND]; static int g_flowret_i;
+#define MAXFLOWRET 4096
+static flowret_t g_flowret[MAXFLOWRET]; static int g_flowret_i;
 static void flow_done(void) { fprintf(g_out, "\n ],\n \"exit_code\": 0}\n"); fflush(g_out); kill(g_pid, SIGKILL); exit(0); }
 static void ret_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; flowret_t *u = ud; flow_t *f = u->f;
     uint64_t E = r->rsp - 8;                           /* the entry stack pointer */
@@ -616,10 +618,13 @@ static void ret_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; f
     for (int i = 0; i < 2; i++) if (f->out_res[i] != NA) flow_ct("res", i, rd64(E + (uint64_t)f->out_res[i]));
     if (f->out_slice != NA) { uint64_t p = rd64(E + (uint64_t)f->out_slice), n = rd64(E + (uint64_t)f->out_slice + 8); for (uint64_t i = 0; i < n && i < 2; i++) flow_ct("res", (int)i, rd64(p + 8 * i)); }
     emit_end(); g_flow_depth = u->depth;
-    if (!strcmp(f->name, "SlotsToCoeffs")) flow_done(); }
+    if (!strcmp(f->name, "main.evalConv_BNRelu_new")) flow_done(); }
 static void on_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; flow_t *f = ud;
     if (!g_flow_mode) return;
-    if (!g_flow_on) { if (strcmp(f->name, "BootstrappConv_CtoS")) return; g_flow_on = 1; }
+    if (!g_flow_on) {                                   /* the enclosing layer function is hooked from its entry so that its return ends the run */
+        if (!strcmp(f->name, "main.evalConv_BNRelu_new")) { flowret_t *u0 = &g_flowret[g_flowret_i++ % MAXFLOWRET]; u0->f = f; u0->depth = 0; u0->out_arg = 0; hook_return(r, ret_flow, u0); return; }
+        if (strcmp(f->name, "BootstrappConv_CtoS")) return;
+        g_flow_on = 1; g_flow_depth = 1; }
     uint64_t E = r->rsp;
     emit_begin("call"); fprintf(g_out, ", \"fn\": \"%s\", \"depth\": %d", f->name, g_flow_depth);
     for (int i = 0; i < 3; i++) if (f->in_ct[i] != NA) flow_ct("in", i, rd64(E + (uint64_t)f->in_ct[i]));
@@ -641,7 +646,7 @@ static void on_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; fl
         fprintf(g_out, ", \"cheby\": {\"maxDeg\": %lu, \"ncoeffs\": %lu, \"lead\": %lu}", rd64(c), rd64(c + 16), rd64(c + 32) & 0xff);
     }
     emit_end();
-    flowret_t *u = &g_flowret[g_flowret_i++ % MAXPEND]; u->f = f; u->depth = g_flow_depth++;
+    flowret_t *u = &g_flowret[g_flowret_i++ % MAXFLOWRET]; u->f = f; u->depth = g_flow_depth++;
     u->out_arg = f->out_arg != NA ? rd64(E + (uint64_t)f->out_arg) : 0;
     hook_return(r, ret_flow, u); }
 
@@ -652,7 +657,7 @@ static void on_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; fl
  * mulRelin / Rescale / MultByGaussianIntegerAndAdd / AddConst / DropLevel with its arguments, levels, scales and the SHA-256 of each
  * ciphertext result, then the returned ciphertext. The oracle replays the polynomial on the same planted data and must reproduce
  * every digest. */
-static int g_poly_max = 0, g_poly_calls = 0, g_in_poly = 0;
+static int g_poly_max = 0, g_poly_calls = 0, g_in_poly = 0, g_cheby = 0;   /* -cheby N: the same trace over EvaluateCheby (the sine of evaluateSine) */
 static int g_in_poly_fwd(void) { return g_in_poly; }
 static void emit_polyarg(const char *key, uint64_t pol) {
     uint64_t maxdeg = rd64(pol), cp = rd64(pol + 8), cl = rd64(pol + 16); uint8_t lead; rd(pol + 32, &lead, 1);
@@ -698,6 +703,11 @@ static void on_p_add(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (
     emit_begin("p.Add"); fprintf(g_out, ", \"level0\": %d, \"level1\": %d, \"scale0\": %.17g, \"scale1\": %.17g, \"out_is_op0\": %d", poly_limbs(ct_poly(op0, 0)) - 1, poly_limbs(ct_poly(op1, 0)) - 1,
         ct_scale(op0), ct_scale(op1), out == op0);
     hook_return(r, ret_p_ct, prec_new(out)); }
+static void on_p_sub(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_poly) return;
+    uint64_t op0 = rd64(r->rsp + 0x18), op1 = rd64(r->rsp + 0x28), out = rd64(r->rsp + 0x30);
+    emit_begin("p.Sub"); fprintf(g_out, ", \"level0\": %d, \"level1\": %d, \"scale0\": %.17g, \"scale1\": %.17g, \"out_is_op0\": %d", poly_limbs(ct_poly(op0, 0)) - 1, poly_limbs(ct_poly(op1, 0)) - 1,
+        ct_scale(op0), ct_scale(op1), out == op0);
+    hook_return(r, ret_p_ct, prec_new(out)); }
 static void on_p_multbyconst(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_poly) return;
     uint64_t in = rd64(r->rsp + 0x10), ty = rd64(r->rsp + 0x18), data = rd64(r->rsp + 0x20), out = rd64(r->rsp + 0x28); uint64_t raw = rd64(data);
     emit_begin("p.MultByConst"); fprintf(g_out, ", \"type\": %lu, \"is_f64\": %d, \"raw_u64\": %lu, \"as_f64\": %.17g, \"level\": %d, \"scale\": %.17g", ty, ty == A_TYPE_FLOAT64, raw, rdf64(data),
@@ -715,7 +725,9 @@ static void on_evalpoly(pid_t t, struct user_regs_struct *r, void *ud) { (void)t
     if (level >= g_nQ) { fprintf(stderr, "EvaluatePoly at level %d: pass the modulus chain with -Q\n", level); exit(3); }
     plant_ct(ct0, 1000 + call, 0);
     emit_begin("EvaluatePoly.begin"); fprintf(g_out, ", \"call\": %d, \"level\": %d, \"scale_in\": %.17g, \"targetScale\": %.17g", call, level, ct_scale(ct0), ts);
-    emit_polyarg("pol", pol); emit_ct("in", ct0); emit_end();
+    emit_polyarg("pol", pol);
+    if (g_cheby) { double ab[4]; rd(pol + 40, ab, 32); fprintf(g_out, ", \"a\": %.17g, \"b\": %.17g", ab[0], ab[2]); }
+    emit_ct("in", ct0); emit_end();
     g_in_poly = 1; g_nested_ks = 1; g_nested_evk = -1;
     fprintf(stderr, "EvaluatePoly call %d level %d scale %g target %g\n", call, level, ct_scale(ct0), ts);
     hook_return(r, ret_evalpoly, NULL); }
@@ -799,6 +811,7 @@ int main(int argc, char **argv) {
             int isq = argv[ai][1] == 'Q'; char *tok = strtok(argv[++ai], ",");
             while (tok) { if (isq) g_Q[g_nQ++] = strtoull(tok, NULL, 0); else g_Pm[g_nP++] = strtoull(tok, NULL, 0); tok = strtok(NULL, ","); }
         }
+        else if (!strcmp(argv[ai], "-cheby") && ai + 1 < argc) { g_poly_max = atoi(argv[++ai]); g_cheby = 1; }
         else if (!strcmp(argv[ai], "-poly") && ai + 1 < argc) g_poly_max = atoi(argv[++ai]);          /* trace this many EvaluatePoly calls (planted input and keys) */
         else if (!strcmp(argv[ai], "-enc") && ai + 1 < argc) g_enc_max = atoi(argv[++ai]);            /* trace the slot encoder: this many invfft / Encode calls */
         else if (!strcmp(argv[ai], "-diag") && ai + 1 < argc) g_diag_max = atoi(argv[++ai]);          /* digest this many encoded DFT diagonals */
@@ -851,7 +864,8 @@ int main(int argc, char **argv) {
     bp_add(A_ROTATEGAL, on_rotgal, NULL);
     bp_add(A_SWITCHKEYS, on_switchkeys, NULL);
     bp_add(A_MULTBYCONST, on_multbyconst, NULL);
-    if (g_poly_max) { bp_add(A_EVALPOLY, on_evalpoly, NULL); bp_add(A_MULRELIN, on_p_mulrelin, NULL); bp_add(A_RESCALE, on_p_rescale, NULL); bp_add(A_MGIAA, on_p_mgiaa, NULL);
+    if (g_poly_max) { bp_add(g_cheby ? post_check(0x52d7c0) : A_EVALPOLY, on_evalpoly, NULL);
+                      if (g_cheby) { bp_add(post_check(0x52f400), on_p_recurse, NULL); bp_add(post_check(0x52dee0), on_p_powerbasis, NULL); bp_add(post_check(0x51b320), on_p_sub, NULL); } bp_add(A_MULRELIN, on_p_mulrelin, NULL); bp_add(A_RESCALE, on_p_rescale, NULL); bp_add(A_MGIAA, on_p_mgiaa, NULL);
                       bp_add(A_ADDCONST, on_p_addconst, NULL); bp_add(A_DROPLEVEL, on_p_droplevel, NULL); bp_add(A_RECURSE, on_p_recurse, NULL); bp_add(A_POLYLEAF, on_p_leaf, NULL);
                       bp_add(A_POWERBASIS, on_p_powerbasis, NULL); bp_add(A_ADD, on_p_add, NULL); bp_add(A_MULTBYCONST, on_p_multbyconst, NULL); }
     if (g_diag_max) { bp_add(A_ENCDIAG, on_encdiag, NULL); bp_add(A_ENCMAT, on_encmat, NULL); }

@@ -34,12 +34,12 @@ def lattigo_add(be, a, b):
     sa, sb = be.scale(a), be.scale(b)
     if sa > sb:
         k = int(sa / sb)
-        if k != 0:
+        if k > 1:          # (k == 1 multiplies by one: the binary's op log shows no MultByConst for it)
             b = be.mul_int(b, k)
         return be.add_rows(a, b, sa)
     if sb > sa:
         k = int(sb / sa)
-        if k != 0:
+        if k > 1:          # (k == 1 multiplies by one: the binary's op log shows no MultByConst for it)
             a = be.mul_int(a, k)
         return be.add_rows(a, b, sb)
     return be.add_rows(a, b, sa)
@@ -116,3 +116,92 @@ def evaluate_poly(be, ct, coeffs, target_scale, scale):
     for i in range(log_split, log_degree):
         compute_power_basis(be, C, 1 << i, scale)
     return recurse(be, target_scale, log_split, log_degree, p, C, scale)
+
+
+# ------------------------------------------------------------------ Chebyshev basis (the sine of evaluateSine)
+# ckks.(*evaluator).EvaluateCheby @52d7c0, computePowerBasisCheby @52dee0, splitCoeffsCheby @52e7c0, recurseCheby @52f400; the leaf
+# (evaluatePolyFromPowerBasis) is shared with the standard basis. Pinned by tests/golden/ref_trace_cheby_5_1.json (gotrace -cheby 1).
+# Additional backend calls: sub_rows(a, b, scale) [a - b at the lower level].
+def lattigo_sub(be, a, b):
+    """evaluator.Sub(a, b, a) with the same scale matching as Add"""
+    sa, sb = be.scale(a), be.scale(b)
+    if sa > sb:
+        k = int(sa / sb)
+        if k > 1:          # (k == 1 multiplies by one: the binary's op log shows no MultByConst for it)
+            b = be.mul_int(b, k)
+        return be.sub_rows(a, b, sa)
+    if sb > sa:
+        k = int(sb / sa)
+        if k > 1:          # (k == 1 multiplies by one: the binary's op log shows no MultByConst for it)
+            a = be.mul_int(a, k)
+        return be.sub_rows(a, b, sb)
+    return be.sub_rows(a, b, sa)
+
+
+def compute_power_basis_cheby(be, C, n, scale):
+    """C[n] = 2 C[a] C[b] - C[|a-b|], a = ceil(n/2), b = floor(n/2) (C[0] = 1 is not stored)"""
+    if n in C:
+        return
+    a, b = (n + 1) // 2, n >> 1
+    c = a - b
+    compute_power_basis_cheby(be, C, a, scale)
+    compute_power_basis_cheby(be, C, b, scale)
+    if c != 0:
+        compute_power_basis_cheby(be, C, c, scale)
+    t = be.rescale(be.mul_relin(C[a], C[b]), scale)
+    t = lattigo_add(be, t, t)
+    C[n] = be.add_const(t, -1.0) if c == 0 else lattigo_sub(be, t, C[c])
+
+
+def split_coeffs_cheby(p, split):
+    """p = q * T_split + r in the Chebyshev basis: q_0 = p_split, q_j = 2 p_(split+j), r_(split-j) -= p_(split+j)"""
+    r = Poly(p.coeffs[:split], split - 1 if p.max_deg == p.degree() else p.max_deg - (p.degree() - split + 1), False)
+    q = Poly([0.0] * (p.degree() - split + 1), p.max_deg, p.lead)
+    q.coeffs[0] = p.coeffs[split]
+    for i, j in zip(range(split + 1, p.degree() + 1), range(1, p.degree() + 1)):
+        q.coeffs[i - split] = 2 * p.coeffs[i]
+        r.coeffs[split - j] -= p.coeffs[i]
+    return q, r
+
+
+def recurse_cheby(be, target_scale, log_split, log_degree, p, C, scale):
+    if p.degree() < (1 << log_split):
+        if p.lead and log_split > 1 and p.max_deg > ((1 << log_degree) - (1 << (log_split - 1))):
+            log_degree = p.degree().bit_length()
+            log_split = log_degree >> 1
+            return recurse_cheby(be, target_scale, log_split, log_degree, p, C, scale)
+        return evaluate_from_power_basis(be, target_scale, p, C, scale)
+    next_power = 1 << log_split
+    while next_power < (p.degree() >> 1) + 1:
+        next_power <<= 1
+    pq, pr = split_coeffs_cheby(p, next_power)
+    level = be.level(C[next_power]) - 1
+    if p.max_deg >= 1 << (log_degree - 1) and p.lead:
+        level += 1
+    current_qi = float(be.q(level))
+    res = recurse_cheby(be, target_scale * current_qi / be.scale(C[next_power]), log_split, log_degree, pq, C, scale)
+    tmp = recurse_cheby(be, target_scale, log_split, log_degree, pr, C, scale)
+    if be.level(res) > be.level(tmp):
+        while be.level(res) != be.level(tmp) + 1:
+            res = be.drop(res, 1)
+    res = be.mul_relin(res, C[next_power])
+    if be.level(res) > be.level(tmp):
+        res = be.rescale(res, scale)
+        res = lattigo_add(be, res, tmp)
+    else:
+        res = lattigo_add(be, res, tmp)
+        res = be.rescale(res, scale)
+    return res
+
+
+def evaluate_cheby(be, ct, coeffs, target_scale, scale, max_deg=None, lead=True):
+    """EvaluateCheby(ct, cheby, target_scale): ct already holds T_1 (the change of variable is the caller's, evaluateCheby @508540)"""
+    p = Poly(coeffs, max_deg, lead)
+    C = {1: ct}
+    log_degree = p.degree().bit_length()
+    log_split = log_degree >> 1
+    for i in range(2, 1 << log_split):
+        compute_power_basis_cheby(be, C, i, scale)
+    for i in range(log_split, log_degree):
+        compute_power_basis_cheby(be, C, 1 << i, scale)
+    return recurse_cheby(be, target_scale, log_split, log_degree, p, C, scale)
