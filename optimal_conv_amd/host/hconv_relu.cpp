@@ -32,6 +32,7 @@
 
 #include "hconv_encoder.hpp"
 #include "hconv_sha256.hpp"
+#include "hconv_sine_coeffs.hpp"
 #include "hconv_host.hpp"
 
 namespace hconv {
@@ -206,7 +207,15 @@ struct Boot {
         HCR(hc_lv_add_const(hc, a.level, a.p[0].get(), c.data(), r.p[0].get()));
         return r;
     }
-    DCt add_const(const DCt &a, double c) { return add_const_int(a, nearbyint(c * a.scale)); }
+    // evaluator.AddConst with a real constant: scaleUpExact(c, scale, q) = floor(|c * scale| + 0.5), sign restored modulo q (the AddConst digests of
+    // tests/golden/ref_trace_cheby_5_1.json pin the rule)
+    DCt add_const(const DCt &a, double c) { const double k = floor(fabs(a.scale * c) + 0.5); return add_const_int(a, c < 0 ? -k : k); }
+    // evaluator.MultByConst with a float64: a constant with a fractional part is carried times q_level (set_scale below uses the same rule)
+    DCt mul_const_float(const DCt &a, double c) {
+        const double mult = c - (double)(int64_t)c != 0 ? (double)Q[(size_t)a.level] : 1.0;
+        DCt r = mul_const_int(a, floor(fabs(c * mult) + 0.5) * (c < 0 ? -1.0 : 1.0)); r.scale = a.scale * mult;
+        return r;
+    }
     DCt mul_plain(const DCt &a, const DPt &pt) {
         if (pt.level < a.level) panic("mul_plain: plaintext below the ciphertext's level");
         DCt r = new_ct(a.level, a.deg, a.scale * pt.scale);
@@ -550,8 +559,8 @@ struct Boot {
     struct LPoly { std::vector<double> c; int max_deg; bool lead; int degree() const { return (int)c.size() - 1; } };
     DCt lt_rescale(DCt a, double min_scale) { while (a.level > 0 && a.scale / (double)Q[(size_t)a.level] >= min_scale / 2) a = rescale(a); return a; }   // ckks Rescale's drop rule
     DCt lt_add(const DCt &a, const DCt &b) {                           // evaluateInPlace: uint64(ratio) * the smaller-scale operand
-        if (a.scale > b.scale) { const double k = floor(a.scale / b.scale); DCt bb = k != 0 ? mul_const_int(b, k) : b; bb.scale = a.scale; return add(a, bb); }
-        if (b.scale > a.scale) { const double k = floor(b.scale / a.scale); DCt aa = k != 0 ? mul_const_int(a, k) : a; aa.scale = b.scale; return add(aa, b); }
+        if (a.scale > b.scale) { const double k = floor(a.scale / b.scale); DCt bb = k > 1 ? mul_const_int(b, k) : b; bb.scale = a.scale; return add(a, bb); }
+        if (b.scale > a.scale) { const double k = floor(b.scale / a.scale); DCt aa = k > 1 ? mul_const_int(a, k) : a; aa.scale = b.scale; return add(aa, b); }
         return add(a, b);
     }
     void lt_power(std::map<int, DCt> &C, int n, double sc) {
@@ -590,6 +599,64 @@ struct Boot {
         if (res.level > tmp.level) { res = lt_rescale(res, sc); res = lt_add(res, tmp); }
         else { res = lt_add(res, tmp); res = lt_rescale(res, sc); }
         return res;
+    }
+    // ---- the Chebyshev basis of the same evaluator (EvaluateCheby @52d7c0: computePowerBasisCheby, splitCoeffsCheby, recurseCheby; the leaf is
+    // shared): tests/lattigo_poly.py's Chebyshev path, which reproduces every nested digest of the binary's sine evaluation
+    // (tests/test_oracle_pin_cheby.py; on the GPU test_evaluate_cheby_vs_reference_trace_on_gpu)
+    DCt lt_sub(const DCt &a, const DCt &b) {
+        if (a.scale > b.scale) { const double k = floor(a.scale / b.scale); DCt bb = k > 1 ? mul_const_int(b, k) : b; bb.scale = a.scale; return sub(a, bb); }
+        if (b.scale > a.scale) { const double k = floor(b.scale / a.scale); DCt aa = k > 1 ? mul_const_int(a, k) : a; aa.scale = b.scale; return sub(aa, b); }
+        return sub(a, b);
+    }
+    void lt_power_cheby(std::map<int, DCt> &C, int n, double sc) {                   // C[n] = 2 C[a] C[b] - C[a-b]
+        if (C.count(n)) return;
+        const int a = (n + 1) / 2, b = n >> 1, c = a - b;
+        lt_power_cheby(C, a, sc); lt_power_cheby(C, b, sc); if (c) lt_power_cheby(C, c, sc);
+        DCt t = lt_rescale(mul_relin(C[a], C[b]), sc);
+        t = lt_add(t, t);
+        C[n] = c == 0 ? add_const(t, -1.0) : lt_sub(t, C[c]);
+    }
+    DCt lt_leaf_any(double target, const LPoly &p, std::map<int, DCt> &C, double sc) {       // evaluatePolyFromPowerBasis incl. the constant term
+        const bool c0 = fabs(p.c[0]) > 1e-14;
+        if (p.degree() == 0) { DCt z = mul_const_int(C[1], 0.0); z.scale = target; return c0 ? add_const(z, p.c[0]) : z; }
+        const int lv = C[p.degree()].level; const double qi = (double)Q[(size_t)lv];
+        DCt res; bool have = false;
+        for (int key = p.degree(); key > 0; key--) if (fabs(p.c[(size_t)key]) > 1e-14) {
+            const double const_scale = target * qi / C[key].scale;
+            DCt term = mul_const_int(drop_to(C[key], lv), trunc(p.c[(size_t)key] * const_scale));          // Go's int64(float64)
+            term.scale = target * qi;
+            res = have ? add(res, term) : term; have = true;
+        }
+        if (!have) { res = mul_const_int(drop_to(C[1], lv), 0.0); res.scale = target * qi; }
+        if (c0) res = add_const(res, p.c[0]);                // the reference adds it first; residues mod q do not depend on the order
+        return lt_rescale(res, sc);
+    }
+    DCt lt_recurse_cheby(double target, int log_split, int log_degree, const LPoly &p, std::map<int, DCt> &C, double sc) {
+        if (p.degree() < (1 << log_split)) {
+            if (p.lead && log_split > 1 && p.max_deg > ((1 << log_degree) - (1 << (log_split - 1)))) { const int ld = PolyEval::bit_length(p.degree()); return lt_recurse_cheby(target, ld >> 1, ld, p, C, sc); }
+            return lt_leaf_any(target, p, C, sc);
+        }
+        int next_power = 1 << log_split; while (next_power < (p.degree() >> 1) + 1) next_power <<= 1;
+        LPoly pr{std::vector<double>(p.c.begin(), p.c.begin() + next_power), p.max_deg == p.degree() ? next_power - 1 : p.max_deg - (p.degree() - next_power + 1), false};
+        LPoly pq{std::vector<double>((size_t)(p.degree() - next_power + 1), 0.0), p.max_deg, p.lead};
+        pq.c[0] = p.c[(size_t)next_power];
+        for (int i = next_power + 1, j = 1; i <= p.degree(); i++, j++) { pq.c[(size_t)(i - next_power)] = 2 * p.c[(size_t)i]; pr.c[(size_t)(next_power - j)] -= p.c[(size_t)i]; }
+        int level = C[next_power].level - 1; if (p.max_deg >= (1 << (log_degree - 1)) && p.lead) level++;
+        DCt res = lt_recurse_cheby(target * (double)Q[(size_t)level] / C[next_power].scale, log_split, log_degree, pq, C, sc);
+        DCt tmp = lt_recurse_cheby(target, log_split, log_degree, pr, C, sc);
+        if (res.level > tmp.level) res = drop_to(res, tmp.level + 1);
+        res = mul_relin(res, C[next_power]);
+        if (res.level > tmp.level) { res = lt_rescale(res, sc); res = lt_add(res, tmp); }
+        else { res = lt_add(res, tmp); res = lt_rescale(res, sc); }
+        return res;
+    }
+    DCt eval_cheby_lattigo(const DCt &ct, const std::vector<double> &coeffs, double target, double sc) {
+        std::map<int, DCt> C; C[1] = ct;
+        LPoly p{coeffs, (int)coeffs.size() - 1, true};
+        const int log_degree = PolyEval::bit_length(p.degree()), log_split = log_degree >> 1;
+        for (int i = 2; i < (1 << log_split); i++) lt_power_cheby(C, i, sc);
+        for (int i = log_split; i < log_degree; i++) lt_power_cheby(C, 1 << i, sc);
+        return lt_recurse_cheby(target, log_split, log_degree, p, C, sc);
     }
     DCt eval_poly_lattigo(const DCt &ct, const std::vector<double> &coeffs, double target) {
         std::map<int, DCt> C; C[1] = ct;
@@ -682,7 +749,44 @@ struct Boot {
     }
     // level-0 coefficient-encoded ciphertext -> slot-encoded at level 15, scale 2^30: two ciphertexts (low / high coefficient
     // half, bit-reversed order) for ls = 0, one packed ciphertext for ls > 0
+    // Full slots on parameter set [6]: ckks.(*Bootstrapper).BootstrappConv_CtoS op for op as the reference's fork runs it (gotrace -flow,
+    // tests/golden/ref_flow_5_1.json; tests/oracle_ckks.py Bootstrapper._ctos_fork is the same on the oracle): ScaleUp to prescale =
+    // 2^round(log2(q0 / MessageRatio)), modUp, ScaleUp to sinescale / MessageRatio, four times LinearTransform + Rescale(min = the scale
+    // before), ct + conj and (ct - conj) / i, the label sinescale = 2^round(log2 q0), AddConst(-0.5 / (scFac (b - a))), EvaluateCheby with the
+    // fork's coefficients towards sqrt(sqrt(sinescale q16) q17), two double angles with (1/2pi)^(1/4) squared along, the label params.scale,
+    // MultByConst(q0 / sinescale * params.scale / prescale) and Rescale: two ciphertexts at level 14, scale 2^30.
+    int ctos_fork(const DCt &ct0, DCt out[2]) {
+        Set &S = set(0);
+        const double q0 = (double)Q[0], msg_ratio = 256.0, pscale = 1073741824.0;
+        const double prescale = exp2(round(log2(q0 / msg_ratio))), sinescale = exp2(round(log2(q0)));
+        if (ct0.level != 0 || prescale < ct0.scale) panic("BootstrappConv_CtoS: the input must sit on level 0 below the prescale");
+        double k = floor(prescale / ct0.scale + 0.5);
+        DCt ct = mul_const_int(ct0, k); ct.scale = ct0.scale * k;
+        ct = mod_raise(ct, LV_CTS_TOP);
+        k = floor((sinescale / msg_ratio) / ct.scale + 0.5);
+        { const double s0 = ct.scale; ct = mul_const_int(ct, k); ct.scale = s0 * k; }
+        for (auto &lt : S.cts) { const double s_in = ct.scale; ct = lt_rescale(linear_transform(ct, lt), s_in); }
+        if (ct.level != LV_SINE_TOP) panic("CoeffsToSlots ended at the wrong level");
+        DCt cc = conjugate(ct);
+        DCt parts[2] = {add(ct, cc), mul_by_i(sub(cc, ct))};           // DivByi(ct - conj) = -i (ct - conj) = i (conj - ct): the same residues
+        double target = sinescale;
+        for (int r = 0; r < SIN_DOUBLE; r++) target = sqrt(target * (double)Q[(size_t)(LV_RELU_TOP + 1 + r)]);
+        const std::vector<double> coeffs(FORK_SINE_COEFFS, FORK_SINE_COEFFS + 63);
+        const double scfac = (double)(1 << SIN_DOUBLE);
+        for (int h = 0; h < 2; h++) {
+            DCt c = parts[h]; c.scale = sinescale;
+            c = add_const(c, -0.5 / (scfac * (2.0 * SIN_K / scfac)));
+            c = eval_cheby_lattigo(c, coeffs, target, sinescale);
+            double sqrt2pi = pow(0.15915494309189535, 1.0 / scfac);
+            for (int r = 0; r < SIN_DOUBLE; r++) { sqrt2pi *= sqrt2pi; c = mul_relin(c, c); c = add(c, c); c = lt_rescale(add_const(c, -sqrt2pi), sinescale); }
+            if (c.level != LV_RELU_TOP) panic("sine evaluation ended at the wrong level");
+            c.scale = pscale;
+            out[h] = lt_rescale(mul_const_float(c, (q0 / sinescale) * (pscale / prescale)), pscale);
+        }
+        return 2;
+    }
     int ctos(const DCt &ct0, int ls, DCt out[2]) {
+        if (ls == 0 && chain == 6) return ctos_fork(ct0, out);
         Set &S = set(ls);
         const double q0 = (double)Q[0], msg_scale = ct0.scale;
         DCt ct = mod_raise(ct0, LV_CTS_TOP); ct.scale = ls ? q0 : exp2(round(log2(q0)));   // slot values are now t'/Q0 = I + msg/Q0, |.| <= K (full slots: the 1/qDiff sits in the matrices)

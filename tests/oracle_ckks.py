@@ -303,7 +303,25 @@ class Ckks:
         return Ct(rows, ct.scale)
 
     def add_const(self, ct, c):
-        return self.add_const_int(ct, int(round(c * ct.scale)))
+        """evaluator.AddConst with a real constant: scaleUpExact(c, ct.Scale, q) = floor(|c * scale| + 0.5) (the 0.5 added at 53 bits), sign
+        restored modulo q (pinned by the AddConst digests of tests/golden/ref_trace_cheby_5_1.json)"""
+        k = int(float(ct.scale) * abs(float(c)) + 0.5)
+        return self.add_const_int(ct, -k if c < 0 else k)
+
+    def mul_const_float(self, ct, c):
+        """evaluator.MultByConst with a float64: a constant with a fractional part is carried times q_level (the scale grows by q_level),
+        rounded by scaleUpExact (the rule set_scale below uses; pinned with the convolution's SetScale in test_oracle_pin.py)"""
+        mult = float(self.Q[ct.level]) if c - float(int(c)) != 0 else 1.0
+        k = int(mult * abs(float(c)) + 0.5)
+        r = self.mul_const_int(ct, -k if c < 0 else k)
+        r.scale = ct.scale * mult
+        return r
+
+    def rescale_to(self, ct, min_scale):
+        """evaluator.Rescale(ct, minScale): drop limbs while scale / q_level >= minScale / 2"""
+        while ct.level > 0 and ct.scale / float(self.Q[ct.level]) >= min_scale / 2:
+            ct = self.rescale(ct)
+        return ct
 
     def mul_plain(self, ct, pt_rows, pt_scale):
         L = ct.level
@@ -628,6 +646,10 @@ class _LattigoBackend:
         a, b = self.ck._align(a, b)
         return self.ck.add(Ct(a.rows, scale), Ct(b.rows, scale))
 
+    def sub_rows(self, a, b, scale):
+        a, b = self.ck._align(a, b)
+        return self.ck.sub(Ct(a.rows, scale), Ct(b.rows, scale))
+
     def drop(self, ct, levels): return self.ck.drop_to(ct, ct.level - levels)
     def add_const(self, ct, c): return self.ck.add_const(ct, c)
 
@@ -707,6 +729,18 @@ def gen_keep_vec_sparse(vec_size, in_wid, kp_wid, log_sparse):
     return idx
 
 
+def _fork_sine_coeffs():
+    """the 63 Chebyshev coefficients (*Bootstrapper).genSinePoly produces for K = 25, SinRescal = 2, degree 62 (Cos1 on [-6.25, 6.25], times
+    (1/2pi)^(1/4)), read off the reference binary's EvaluateCheby call (tests/golden/ref_trace_cheby_5_1.json; the product holds the same
+    table in host/hconv_sine_coeffs.hpp)"""
+    import json, os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_trace_cheby_5_1.json")))
+    return [c[0] for c in d["events"][0]["pol"]["coeffs"]]
+
+
+FORK_SINE_COEFFS = _fork_sine_coeffs()
+
+
 class Bootstrapper:
     """my restatement of the fork's BootstrappConv_CtoS / BootstrappConv_StoC for full slots (log_sparse = 0): same modulus
     chain and level assignment as parameter set [6]; DFT matrices from the encoder's own butterflies (no bit reversal, so
@@ -717,6 +751,7 @@ class Bootstrapper:
         # at. Defaults = Ours on parameter set [6] (levels 3..2: sqrt(q3) twice, then 2^30; sine out at 2^30). The baseline's stock
         # Bootstrapp on set [7]: stc_top 15, scales (2^40, 2^40), sine out at 2^55 (host/hconv_relu.cpp Boot::build, chain 7).
         self.stc_top, self.stc_scales, self.sine_out_scale = stc_top, stc_scales, sine_out_scale
+        self.fork_flow = stc_top == LV_STC_TOP and stc_scales is None          # Ours on parameter set [6]; the baseline's stock Bootstrapp keeps the restated flow
         """log_sparse = ls > 0: the message occupies only the coefficients that are multiples of D = 2^ls (sparse packing,
         eval.go "Conv_sparse"): the bootstrapping runs in the subring X^D with n_s = n/D slots (main.go:60-83 btp2..btp5):
         SubSum, the n_s-point DFTs, and BOTH coefficient halves in ONE ciphertext (first half of every 2 n_s slots = low
@@ -768,6 +803,8 @@ class Bootstrapper:
         """level-0 coefficient-encoded ciphertext (value = coeff/scale in [-1,1], |coeff| <= Q0/MSG_RATIO) -> two
         ciphertexts at level LV_RELU_TOP, scale 2^30, slot p of the first = value of coefficient bitrev(p), of the
         second = coefficient n + bitrev(p)"""
+        if self.ls == 0 and self.fork_flow:
+            return self._ctos_fork(ct0)
         C = self.C
         q0 = float(C.Q[0])
         msg_scale = ct0.scale
@@ -799,6 +836,53 @@ class Bootstrapper:
                 c = C.rescale(C.add_const(c, -1.0))
             assert c.level == LV_RELU_TOP
             c.scale = c.scale / c_m                               # value *= c_m: now msg/msg_scale
+            out.append(c)
+        return out
+
+    def _ctos_fork(self, ct0):
+        """full slots, parameter set [6]: ckks.(*Bootstrapper).BootstrappConv_CtoS op for op as the reference's fork runs it
+        (tests/golden/ref_flow_5_1.json, gotrace -flow): ScaleUp to prescale = 2^round(log2(q0 / MessageRatio)), modUp, ScaleUp to
+        sinescale / MessageRatio, CoeffsToSlots (LinearTransform + Rescale(min = the scale before) four times; ct + conj, (ct - conj) / i),
+        evaluateSine (label sinescale = 2^round(log2 q0); AddConst(-0.5 / (scFac (b - a))); EvaluateCheby with the fork's 63 coefficients
+        towards sqrt(sqrt(sinescale q16) q17); two double angles with (1/2pi)^(1/4) squared along; label params.scale), MultByConst(q0 /
+        sinescale * params.scale / prescale) and Rescale. Every op is pinned against the binary on planted data (modUp, mulRelin, Rescale,
+        key switch, EvaluateCheby incl. AddConst / Add / Sub; MultByConst with SetScale) except LinearTransform's inside (its diagonals
+        are: tests/test_oracle_pin_dft.py). Output: two ciphertexts at level 14, scale 2^30."""
+        import lattigo_poly
+        C = self.C
+        q0 = float(C.Q[0])
+        prescale, sinescale, pscale = 2.0 ** round(math.log2(q0 / MSG_RATIO)), 2.0 ** round(math.log2(q0)), 2.0 ** 30
+        assert ct0.level == 0 and prescale >= ct0.scale
+        k = int(math.floor(prescale / ct0.scale + 0.5))
+        ct = C.mul_const_int(ct0, k); ct.scale = ct0.scale * k                      # ScaleUp(ct, round(prescale / scale))
+        ct = C.mod_raise(ct, LV_CTS_TOP)
+        k = int(math.floor((sinescale / MSG_RATIO) / ct.scale + 0.5))
+        s0 = ct.scale
+        ct = C.mul_const_int(ct, k); ct.scale = s0 * k
+        for G, n1 in zip(self.cts, self.cts_n1):                                    # CoeffsToSlots -> dft: LinearTransform, Rescale(min = scale before)
+            s_in = ct.scale
+            ct = C.rescale_to(C.linear_transform(ct, G, float(C.Q[ct.level]), n1), s_in)
+        assert ct.level == LV_SINE_TOP
+        cc = C.conjugate(ct)
+        parts = [C.add(ct, cc), C.neg(C.mul_by_i(C.sub(ct, cc)))]                   # DivByi = times -i
+        be = _LattigoBackend(C)
+        target = sinescale
+        for r in range(SIN_DOUBLE):
+            target = math.sqrt(target * float(C.Q[LV_RELU_TOP + 1 + r]))
+        out = []
+        for c in parts:
+            c = Ct(c.rows, sinescale)                                               # evaluateSine: ct.Scale = sinescale (times MessageRatio)
+            c = C.add_const(c, -0.5 / (float(1 << SIN_DOUBLE) * (2.0 * SIN_K / float(1 << SIN_DOUBLE))))     # -0.5 / (scFac (b - a)) = -0.01
+            c = lattigo_poly.evaluate_cheby(be, c, FORK_SINE_COEFFS, target, sinescale, max_deg=len(FORK_SINE_COEFFS) - 1, lead=True)
+            sqrt2pi = math.pow(0.15915494309189535, 1.0 / float(1 << SIN_DOUBLE))
+            for r in range(SIN_DOUBLE):
+                sqrt2pi *= sqrt2pi
+                c = C.mul_relin(c, c)
+                c = C.add(c, c)
+                c = C.rescale_to(C.add_const(c, -sqrt2pi), sinescale)
+            assert c.level == LV_RELU_TOP
+            c = Ct(c.rows, pscale)                                                  # ct.Scale = params.scale
+            c = C.rescale_to(C.mul_const_float(c, (q0 / sinescale) * (pscale / prescale)), pscale)
             out.append(c)
         return out
 

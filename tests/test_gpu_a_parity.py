@@ -334,20 +334,11 @@ def test_leveled_ops_vs_reference_trace_on_gpu():
         ctx.close()
 
 
-def test_evaluate_poly_vs_reference_trace_on_gpu():
-    """ckks.(*evaluator).EvaluatePoly on the GPU vs the reference binary: the three sign polynomials of evalReLU (conv.go:460-477) on the
-    planted inputs and relinearisation key of `gotrace -poly` (tests/golden/ref_trace_poly_5_1.json), composed from hc_lv_mul_tensor +
-    hc_keyswitch + hc_lv_add, hc_div_round_last, hc_lv_mul_const through the C ABI (tests/lattigo_poly.py drives them): every nested
-    mulRelin / Rescale / MultByGaussianIntegerAndAdd / Add digest and the returned ciphertexts must be the binary's."""
-    from optimal_conv_amd import Context
-    import lattigo_poly as lp
+def _device_replay_backend(ctx, Q, P, seed, N):
+    """tests/test_oracle_pin_poly.py's ReplayBackend with every residue operation on the device through the C ABI"""
     from test_oracle_pin_keyswitch import ks_inputs
-    from test_oracle_pin_ops import planted_ct
     from test_oracle_pin_poly import Ct, ReplayBackend, RLK_ID
-
-    d = json.load(open(os.path.join(HERE, "golden", "ref_trace_poly_5_1.json")))
-    Q, P, seed, N = d["ks_Q"], d["ks_P"], d["seed"], d["N"]
-    ctx = Context(Q, P)
+    from test_oracle_pin_cheby import scale_up_exact
 
     class Dev(ReplayBackend):                      # the replay backend with every residue operation on the device
         loaded = set()
@@ -386,6 +377,38 @@ def test_evaluate_poly_vs_reference_trace_on_gpu():
         def zero(self, level, scale):
             return Ct(np.zeros((2, level + 1, N), dtype=np.uint64), scale)
 
+
+        def add_const(self, ct, c):                 # evaluator.AddConst with a real constant (scaleUpExact per limb)
+            L = self.level(ct)
+            rows = ct.rows.copy()
+            rows[0] = ctx.lv_add_const(L, np.ascontiguousarray(ct.rows[0]), [scale_up_exact(c, ct.scale, Q[l]) for l in range(L + 1)])
+            return self._emit("p.AddConst", Ct(rows, ct.scale), const=c)
+
+        def sub_rows(self, a, b, scale):
+            L = min(self.level(a), self.level(b))
+            rows = np.stack([ctx.lv_sub(L, np.ascontiguousarray(a.rows[k, : L + 1]), np.ascontiguousarray(b.rows[k, : L + 1])) for k in range(2)])
+            return self._emit("p.Sub", Ct(rows, scale))
+
+    return Dev
+
+
+def test_evaluate_poly_vs_reference_trace_on_gpu():
+    """ckks.(*evaluator).EvaluatePoly on the GPU vs the reference binary: the three sign polynomials of evalReLU (conv.go:460-477) on the
+    planted inputs and relinearisation key of `gotrace -poly` (tests/golden/ref_trace_poly_5_1.json), composed from hc_lv_mul_tensor +
+    hc_keyswitch + hc_lv_add, hc_div_round_last, hc_lv_mul_const through the C ABI (tests/lattigo_poly.py drives them): every nested
+    mulRelin / Rescale / MultByGaussianIntegerAndAdd / Add digest and the returned ciphertexts must be the binary's."""
+    from optimal_conv_amd import Context
+    import lattigo_poly as lp
+    from test_oracle_pin_keyswitch import ks_inputs
+    from test_oracle_pin_ops import planted_ct
+    from test_oracle_pin_poly import Ct, ReplayBackend, RLK_ID
+
+    d = json.load(open(os.path.join(HERE, "golden", "ref_trace_poly_5_1.json")))
+    Q, P, seed, N = d["ks_Q"], d["ks_P"], d["seed"], d["N"]
+    ctx = Context(Q, P)
+
+    Dev = _device_replay_backend(ctx, Q, P, seed, N)
+
     ev = [e for e in d["events"] if e["op"].startswith("p.") or e["op"].startswith("EvaluatePoly")]
     begins = [i for i, e in enumerate(ev) if e["op"] == "EvaluatePoly.begin"]
     for bi, i0 in enumerate(begins):
@@ -402,6 +425,35 @@ def test_evaluate_poly_vs_reference_trace_on_gpu():
                 continue
             assert [p["sha256"] for p in w["out"]["polys"]] == g["polys"] and w["out"]["scale"] == g["scale"], f"EvaluatePoly call {b['call']} op {k} {w['op']}"
         assert [p["sha256"] for p in end["out"]["polys"]] == [sha_rows(*out.rows[0]), sha_rows(*out.rows[1])], f"EvaluatePoly call {b['call']}: returned ciphertext"
+    ctx.close()
+
+
+def test_evaluate_cheby_vs_reference_trace_on_gpu():
+    """ckks.(*evaluator).EvaluateCheby on the GPU vs the reference binary: the sine of evaluateSine (63 Chebyshev coefficients, level 23 -> 17,
+    evaluator scale 2^55) on the planted input and relinearisation key of `gotrace -cheby` (tests/golden/ref_trace_cheby_5_1.json), through
+    the C ABI: every nested mulRelin / Rescale / Add / Sub / AddConst / MultByGaussianIntegerAndAdd digest and the returned ciphertext"""
+    from optimal_conv_amd import Context
+    import lattigo_poly as lp
+    from test_oracle_pin_ops import planted_ct
+    from test_oracle_pin_poly import Ct
+
+    d = json.load(open(os.path.join(HERE, "golden", "ref_trace_cheby_5_1.json")))
+    Q, P, seed, N = d["ks_Q"], d["ks_P"], d["seed"], d["N"]
+    ctx = Context(Q, P)
+    be = _device_replay_backend(ctx, Q, P, seed, N)(None, Q, None)
+    ev = d["events"]
+    b, end = ev[0], ev[-1]
+    out = lp.evaluate_cheby(be, Ct(planted_ct(seed, 1000 + b["call"], 0, b["level"], Q, N), b["scale_in"]), [c[0] for c in b["pol"]["coeffs"]], b["targetScale"], 2.0 ** 55,
+                            max_deg=b["pol"]["maxDeg"], lead=bool(b["pol"]["lead"]))
+    want = [e for e in ev if e["op"] in ("p.mulRelin", "p.Rescale", "p.MultByGaussianIntegerAndAdd", "p.Add", "p.Sub", "p.AddConst", "p.MultByConst")]
+    got = be.log
+    assert [e["op"] for e in want] == [g["op"] for g in got]
+    for k, (w, g) in enumerate(zip(want, got)):
+        if w["op"] == "p.MultByConst":
+            assert w["as_f64"] == float(g["const"])
+            continue
+        assert [p["sha256"] for p in w["out"]["polys"]] == g["polys"] and w["out"]["scale"] == g["scale"], f"op {k} {w['op']}"
+    assert [p["sha256"] for p in end["out"]["polys"]] == [sha_rows(*out.rows[0]), sha_rows(*out.rows[1])], "returned ciphertext"
     ctx.close()
 
 
