@@ -66,7 +66,7 @@ struct Boot {
     // where SlotsToCoeffs sits and what its plaintext scales are: set [6] (Ours, main.go:52): levels 3..2 after the ReLU, two matrices
     // at sqrt(q3) and one at 2^30 (input scale 2^60 -> output 2^30 at level 1); set [7] (BL, main.go:54: the stock Bootstrapp):
     // levels 15..14 right after the sine, 2^40 each (input 2^30 -> output 2^30 * 2^120 / (q15 q14) at level 13)
-    int chain = 6, LV_STC_TOP = 3, lv_relin_lo = LV_RELU_TOP - 10;
+    int chain = 6, LV_STC_TOP = 3, lv_relin_lo = LV_RELU_TOP - 11;
     double stc_scale_top = 0, stc_scale_last = 1073741824.0;
     // scale the sine leaves its result at (level 15). Ours: 2^30, what evalReLU consumes. Baseline: 2^55 — its SlotsToCoeffs follows
     // directly and multiplies whatever noise its input carries by ~sqrt(N) relative to the slot values, so the input must sit far above
@@ -682,7 +682,7 @@ struct Boot {
         chain = chain_;
         Q = chain == 7 ? PARAMS7_Q : PARAMS6_Q; P = PARAMS6_P; NQ = (int)Q.size(); sk = sk_in; rng.reseed(seed, 0xB007B007ull + (uint64_t)chain_);
         if (chain == 7) { LV_STC_TOP = 15; stc_scale_top = stc_scale_last = 1099511627776.0; lv_relin_lo = 2; sine_out_scale = 36028797018963968.0; }
-        else { LV_STC_TOP = 3; stc_scale_top = sqrt((double)Q[3]); stc_scale_last = 1073741824.0; lv_relin_lo = LV_RELU_TOP - 10; }
+        else { LV_STC_TOP = 3; stc_scale_top = sqrt((double)Q[3]); stc_scale_last = 1073741824.0; lv_relin_lo = LV_RELU_TOP - 11; }
         if (hc_ctx_create(&hc, LOGN, Q.data(), NQ, P.data(), (int)P.size(), device)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
         if (getenv("HCONV_KS_FUSED")) HCR(hc_set_option(hc, "ks_fused", atoi(getenv("HCONV_KS_FUSED"))));     // A/B switch of the fused inner product
         const int nm = NQ + (int)P.size();
@@ -737,7 +737,9 @@ struct Boot {
         }
         if (G.size() != 3) panic("SlotsToCoeffs is planned as three matrices");
         for (size_t i = 0; i + 1 < G.size(); i++) S.stc.push_back(plan(G[i], LV_STC_TOP, stc_scale_top, ls == 0, stc_tag[i]));
-        S.stc.push_back(plan(G.back(), LV_STC_TOP - 1, stc_scale_last, ls == 0, stc_tag[2]));
+        // the fork applies all three matrices on level 3 and rescales twice afterwards (ckks.SlotsToCoeffs -> dft: the Rescale after each
+        // LinearTransform finds nothing to drop); full slots on parameter set [6] do the same, the other bootstrappers keep the split above
+        S.stc.push_back(plan(G.back(), ls == 0 && chain == 6 ? LV_STC_TOP : LV_STC_TOP - 1, stc_scale_last, ls == 0, stc_tag[2]));
         for (auto *grp : {&S.cts, &S.stc}) for (auto &lt : *grp) for (auto &g : lt.giant) {
             if (g.first) key(gal_rot(g.first), lt.level);
             for (auto &b : g.second) if (b.first) key(gal_rot(b.first), lt.level);
@@ -813,6 +815,10 @@ struct Boot {
         Set &S = set(ls);
         if (ls && im) panic("sparse SlotsToCoeffs takes one packed ciphertext");
         DCt ct = drop_to(ls ? re : add(re, mul_by_i(*im)), LV_STC_TOP);
+        if (ls == 0 && chain == 6) {        // ckks.SlotsToCoeffs as the fork runs it (ref_flow_5_1.json): MultByi + Add, three LinearTransforms each followed by Rescale(min = the scale before), then eval.go:564's Rescale(2^30): level 3 -> 1
+            for (auto &lt : S.stc) { const double s_in = ct.scale; ct = lt_rescale(linear_transform(ct, lt), s_in); }
+            return lt_rescale(ct, 1073741824.0);
+        }
         for (size_t i = 0; i + 1 < S.stc.size(); i++) ct = linear_transform(ct, S.stc[i]);
         ct = rescale(ct);
         return rescale(linear_transform(ct, S.stc.back()));

@@ -896,6 +896,14 @@ class Bootstrapper:
             ct = C.add(ct_re, C.mul_by_i(ct_im))
         ct = C.drop_to(ct, self.stc_top)
         G = self.stc
+        if self.ls == 0 and self.fork_flow:
+            # ckks.SlotsToCoeffs as the fork runs it (tests/golden/ref_flow_5_1.json): three LinearTransforms on level 3, each followed by
+            # Rescale(min = the scale before) - which finds nothing to drop -, then eval.go:564's Rescale(2^30): level 3 -> 1
+            sc = math.sqrt(float(C.Q[self.stc_top]))
+            for M, n1, s_pt in zip(G, self.stc_n1, (sc, sc, 2.0 ** 30)):
+                s_in = ct.scale
+                ct = C.rescale_to(C.linear_transform(ct, M, s_pt, n1), s_in)
+            return C.rescale_to(ct, 2.0 ** 30)
         # Ours: level 3 carries all but the last matrix (their plaintext scales multiply to q3), level 2 the last at scale 2^30
         first = G[:-1]
         sc, sc_last = self.stc_scales if self.stc_scales is not None else (float(C.Q[self.stc_top]) ** (1.0 / len(first)), 2.0 ** 30)
