@@ -55,3 +55,9 @@ d["events"] = ev
 d["note"] = "gotrace -diag over `convReLU 5 1 1`: nothing planted; matrices 0-3 CoeffsToSlots, 4-6 and 7-9 the two SlotsToCoeffs sets"
 json.dump(d, open(sys.argv[1], "w"), indent=0)
 PY
+# the stage structure of the convReLU chain (log only) and the sine's EvaluateCheby with planted input and relinearisation key
+"$SCRATCH/gotrace" -flow -o trace_flow_5_1.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_flow.txt 2>&1
+python3 "$REPO/oracle/pin/mk_flow_fixture.py" "$REPO/tests/golden/ref_flow_5_1.json"
+"$SCRATCH/gotrace" -cheby 1 -Q $Q -P $P -nq-full 28 -o trace_cheby_5_1.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_cheby.txt 2>&1
+python3 "$REPO/oracle/pin/mk_cheby_fixture.py" "$REPO/tests/golden/ref_trace_cheby_5_1.json"
+python3 "$REPO/tools/gen_sine_table.py"      # host/hconv_sine_coeffs.hpp from the fixture
