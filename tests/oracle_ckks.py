@@ -929,7 +929,7 @@ def keep_ctxt(C, ct, idx):
     """conv.go:417-431: multiply by the 0/1 mask encoded at scale q_level, rescale once"""
     L = ct.level
     pt = C.encode_ntt(idx.astype(np.complex128), L, float(C.Q[L]))
-    return C.rescale(C.mul_plain(ct, pt, float(C.Q[L])))
+    return C.rescale_to(C.mul_plain(ct, pt, float(C.Q[L])), 2.0 ** 30)        # Rescale(ct, params.Scale()): one limb here
 
 
 def conv_relu_tail_sparse(C, btp, ct_conv, alpha, pow_, in_wid, kp_wid, stages=None):

@@ -118,3 +118,48 @@ def test_baseline_bootstrapp_relu_small_ring():
         assert out[k].level == 1 and out[k].scale == 2.0 ** 30
         err = np.abs(C.decrypt_slots(out[k]).real - np.maximum(x[k], 0))
         assert -np.log2(np.median(err)) >= 8.0
+
+
+def test_chain_follows_the_reference_flow_level_for_level_and_scale_for_scale():
+    """tests/golden/ref_flow_5_1.json (gotrace -flow over the reference binary's `convReLU 5 1 1`): the level and the float64 scale of every
+    ciphertext after modUp, each LinearTransform, each Rescale outside the polynomial evaluators, EvaluateCheby, the three EvaluatePoly
+    calls, the float MultByConst - 60 checkpoints from the entry of BootstrappConv_CtoS to the Rescale behind SlotsToCoeffs. The oracle's
+    chain on a small ring (same modulus chain, so the same float64 scale arithmetic) must pass through exactly the same values."""
+    import json, os
+    import lattigo_poly
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_flow_5_1.json")))["events"]
+    want = []
+    for e in ref:
+        if e["fn"] in ("modUp", "LinearTransform", "Rescale", "EvaluateCheby", "EvaluatePoly") or (e["fn"] == "MultByConst" and e.get("const_type") == "float64" and e["depth"] <= 1):
+            want.append((e["fn"], e["out"][0][0], e["out"][0][1]))
+    C = ck.Ckks(logN=10, h=64)
+    got = []
+    def wrap(obj, name, label):
+        f = getattr(obj, name)
+        def g(*a, **k):
+            depth[0] += 1
+            r = f(*a, **k)
+            depth[0] -= 1
+            if depth[0] == 0:                      # calls made from inside another logged call (the evaluators' own rescales) are theirs
+                got.append((label, r.level, r.scale))
+            return r
+        setattr(obj, name, g)
+    depth = [0]
+    for name, label in (("mod_raise", "modUp"), ("linear_transform", "LinearTransform"), ("rescale_to", "Rescale"), ("eval_poly", "EvaluatePoly"), ("mul_const_float", "MultByConst")):
+        wrap(C, name, label)
+    orig = lattigo_poly.evaluate_cheby
+    def cheby(*a, **k):
+        depth[0] += 1
+        r = orig(*a, **k)
+        depth[0] -= 1
+        got.append(("EvaluateCheby", r.level, r.scale))
+        return r
+    lattigo_poly.evaluate_cheby = cheby
+    try:
+        m = np.random.default_rng(3).uniform(-12, 12, C.N)
+        out = ck.conv_relu_tail(C, ck.Bootstrapper(C), C.encrypt_coeffs(m, 0, 2.0 ** 43, seed=21), 0.0, 4, 16, 15)
+    finally:
+        lattigo_poly.evaluate_cheby = orig
+    assert (out.level, out.scale) == (1, 1073741823.9892578)         # what the reference hands to the next convolution
+    # the reference rescales both halves' results one after the other where this chain finishes one half before the other: compare as multisets per stage
+    assert sorted(got) == sorted(want), (len(got), len(want))
