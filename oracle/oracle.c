@@ -375,14 +375,19 @@ uint64_t or_basis_extend(const uint64_t *x, const uint64_t *src, int n, uint64_t
     return bx_apply(&b, x);
 }
 
-/* general rlwe.(*KeySwitcher).SwitchKeysInPlace (NTT-domain input); see oracle.h */
-void or_keyswitch(const or_ctx *c, int level, const uint64_t *cx, const uint64_t *evk, uint64_t *d0, uint64_t *d1) {
+/* general rlwe.(*KeySwitcher).SwitchKeysInPlace (NTT-domain input); see oracle.h. Its two halves are callable on their own:
+ * or_keyswitch_qp  = rlwe.(*KeySwitcher).SwitchKeysInPlaceNoModDown / DecomposeNTT + KeyswitchHoistedNoModDown (test_run @4fe660, @4fdf80,
+ *                    @4ff060): digit decomposition, basis extension of every digit to all level+1+alpha limbs, inner product with the key:
+ *                    acc[k][limb][N], limbs = Q_0..Q_level then P_0..P_(alpha-1), canonical residues, NTT domain;
+ * or_mod_down      = ring.(*FastBasisExtender).ModDownSplitNTTPQ (@4e4c40) on ONE polynomial in that layout: InvNTT of the P limbs, extension
+ *                    {P} -> each Q limb, (x_Q - NTT(ext)) * P^-1. */
+void or_keyswitch_qp(const or_ctx *c, int level, const uint64_t *cx, const uint64_t *evk, uint64_t *acc) {
     const int N = c->N, alpha = c->np, nl = level + 1, nt = nl + alpha;          /* nt = limbs an evk row set covers */
     const int beta = (nl + alpha - 1) / alpha;
     const size_t n = (size_t)N;
     uint64_t *coef = malloc(sizeof(uint64_t) * n * (size_t)nl);                   /* cxInvNTT */
-    uint64_t *acc = calloc(n * (size_t)nt * 2, sizeof(uint64_t));                 /* [k][limb][N] */
     uint64_t *c2 = malloc(sizeof(uint64_t) * n), *tmp = malloc(sizeof(uint64_t) * n);
+    memset(acc, 0, sizeof(uint64_t) * n * (size_t)nt * 2);                        /* [k][limb][N] */
     for (int l = 0; l < nl; l++) or_intt(c, l, cx + (size_t)l * n, coef + (size_t)l * n);
     for (int d = 0; d < beta; d++) {
         const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl, nd = hi - lo;
@@ -409,24 +414,33 @@ void or_keyswitch(const or_ctx *c, int level, const uint64_t *cx, const uint64_t
             }
         }
     }
-    /* ModDownSplitNTTPQ: InvNTT the P limbs, extend {P} -> each Q limb, (acc_Q - NTT(ext)) * P^-1 */
+    free(coef); free(c2); free(tmp);
+}
+void or_mod_down(const or_ctx *c, int level, const uint64_t *x_qp, uint64_t *out) {
+    const int N = c->N, alpha = c->np, nl = level + 1;
+    const size_t n = (size_t)N;
     uint64_t psrc[16]; for (int j = 0; j < alpha; j++) psrc[j] = c->m[c->nq + j].q;
-    uint64_t *pc = malloc(sizeof(uint64_t) * n * (size_t)alpha);
-    uint64_t *dd[2] = {d0, d1};
-    for (int k = 0; k < 2; k++) {
-        for (int j = 0; j < alpha; j++) or_intt(c, c->nq + j, acc + ((size_t)k * (size_t)nt + (size_t)(nl + j)) * n, pc + (size_t)j * n);
-        for (int l = 0; l < nl; l++) {
-            const or_mod *m = &c->m[l];
-            uint64_t pinv = 1; for (int j = 0; j < alpha; j++) pinv = mulmod(pinv, psrc[j] % m->q, m->q);
-            pinv = powmod(pinv, m->q - 2, m->q);
-            bx_pre bx; bx_prepare(&bx, psrc, alpha, m->q);
-            for (int j = 0; j < N; j++) { uint64_t x[16]; for (int i = 0; i < alpha; i++) x[i] = pc[(size_t)i * n + (size_t)j]; tmp[j] = bx_apply(&bx, x); }
-            or_ntt(c, l, tmp, tmp);
-            const uint64_t *a = acc + ((size_t)k * (size_t)nt + (size_t)l) * n;
-            for (int j = 0; j < N; j++) dd[k][(size_t)l * n + (size_t)j] = mulmod(submod(a[j], tmp[j], m->q), pinv, m->q);
-        }
+    uint64_t *pc = malloc(sizeof(uint64_t) * n * (size_t)alpha), *tmp = malloc(sizeof(uint64_t) * n);
+    for (int j = 0; j < alpha; j++) or_intt(c, c->nq + j, x_qp + (size_t)(nl + j) * n, pc + (size_t)j * n);
+    for (int l = 0; l < nl; l++) {
+        const or_mod *m = &c->m[l];
+        uint64_t pinv = 1; for (int j = 0; j < alpha; j++) pinv = mulmod(pinv, psrc[j] % m->q, m->q);
+        pinv = powmod(pinv, m->q - 2, m->q);
+        bx_pre bx; bx_prepare(&bx, psrc, alpha, m->q);
+        for (int j = 0; j < N; j++) { uint64_t x[16]; for (int i = 0; i < alpha; i++) x[i] = pc[(size_t)i * n + (size_t)j]; tmp[j] = bx_apply(&bx, x); }
+        or_ntt(c, l, tmp, tmp);
+        const uint64_t *a = x_qp + (size_t)l * n;
+        for (int j = 0; j < N; j++) out[(size_t)l * n + (size_t)j] = mulmod(submod(a[j] % m->q, tmp[j], m->q), pinv, m->q);
     }
-    free(coef); free(acc); free(c2); free(tmp); free(pc);
+    free(pc); free(tmp);
+}
+void or_keyswitch(const or_ctx *c, int level, const uint64_t *cx, const uint64_t *evk, uint64_t *d0, uint64_t *d1) {
+    const size_t n = (size_t)c->N, nt = (size_t)(level + 1 + c->np);
+    uint64_t *acc = malloc(sizeof(uint64_t) * n * nt * 2);
+    or_keyswitch_qp(c, level, cx, evk, acc);
+    or_mod_down(c, level, acc, d0);
+    or_mod_down(c, level, acc + nt * n, d1);
+    free(acc);
 }
 
 /* lattigo ckks.(*evaluator).RotateGal -> permuteNTT (test_run @0x5245a0, @0x5248c0): key-switch c1, add c0 to

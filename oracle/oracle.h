@@ -75,6 +75,10 @@ void or_keyswitch_l0(const or_ctx *, const uint64_t *c1, const uint64_t *evk_b_q
  * fp64 overflow count), the Montgomery MAC over digits, and ring.FastBasisExtender.ModDownSplitNTTPQ with
  * ring.modUpExact over np primes. Used by the BL path (level 1, np = 2) and by everything bootstrapping needs. */
 void or_keyswitch(const or_ctx *, int level, const uint64_t *cx, const uint64_t *evk, uint64_t *d0, uint64_t *d1);
+/* the two halves of or_keyswitch (rlwe SwitchKeysInPlaceNoModDown / KeyswitchHoistedNoModDown, ring ModDownSplitNTTPQ):
+ * acc = [2][level+1+np][N] in the basis Q_0..Q_level, P_0..P_(np-1); or_mod_down takes ONE such polynomial to [level+1][N] */
+void or_keyswitch_qp(const or_ctx *, int level, const uint64_t *cx, const uint64_t *evk, uint64_t *acc);
+void or_mod_down(const or_ctx *, int level, const uint64_t *x_qp, uint64_t *out);
 /* the exact fast basis extension both steps use: residues x[0..n) (any representatives) modulo src[0..n) -> modulus t */
 uint64_t or_basis_extend(const uint64_t *x, const uint64_t *src, int n, uint64_t t);
 

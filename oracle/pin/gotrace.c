@@ -650,6 +650,56 @@ static void on_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; fl
     u->out_arg = f->out_arg != NA ? rd64(E + (uint64_t)f->out_arg) : 0;
     hook_return(r, ret_flow, u); }
 
+/* -lt N: ckks.(*evaluator).LinearTransform (-> MultiplyByDiagMatrixBSGS) on planted data: at the entry of the first N calls inside the
+ * convReLU chain the input ciphertext is planted (SEED_OPIN(3000 + call, 0, poly, limb)); every rotation key a nested
+ * KeyswitchHoistedNoModDown (baby steps) reads is planted with key identity LT_BABY_ID, every key a nested SwitchKeysInPlaceNoModDown
+ * (giant steps) reads with LT_GIANT_ID - the SAME rows for every baby key and for every giant key, because Go walks the giant steps in
+ * map order and the tracer cannot tell which rotation a key belongs to; the algorithm does not care what the key rows are. The
+ * plaintext diagonals are the run's own (pinned by -diag). Recorded: the matrix header, per nested ModDownSplitNTTPQ the digests of its
+ * inputs (mod Q, mod P) and output, per SwitchKeysInPlaceNoModDown the digest of its input, and the returned ciphertext. */
+#define LT_BABY_ID 40
+#define LT_GIANT_ID 41
+static int g_lt_max = 0, g_lt_calls = 0, g_in_lt = 0;
+static void lt_plant_key(uint64_t level, uint64_t evk, int id) {
+    int alpha = g_nP; { uint64_t v0 = rd64(evk); int limbs0 = poly_limbs(rd64(v0)); if (g_nQ_full) alpha = limbs0 - g_nQ_full; }
+    const int beta = ((int)level + 1 + alpha - 1) / alpha; uint64_t v = rd64(evk);
+    for (int d = 0; d < beta; d++) for (int k = 0; k < 2; k++) {
+        uint64_t poly = rd64(v + 16ull * (uint64_t)d + 8ull * (uint64_t)k); int limbs = poly_limbs(poly);
+        for (int l = 0; l <= (int)level; l++) plant_row(poly_row(poly, l, NULL), SEED_KSEVK(id, d, k, l), g_Q[l]);
+        for (int j = 0; j < alpha; j++) plant_row(poly_row(poly, limbs - alpha + j, NULL), SEED_KSEVK(id, d, k, 32 + j), g_Pm[j]);
+    }
+}
+static void on_lt_ks_hoisted(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_lt) return;
+    uint64_t level = rd64(r->rsp + 0x10), evk = rd64(r->rsp + 0x48);
+    lt_plant_key(level, evk, LT_BABY_ID);
+    emit_begin("lt.KeyswitchHoistedNoModDown"); fprintf(g_out, ", \"level\": %lu", level); emit_end(); }
+static void on_lt_ks_nomoddown(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_lt) return;
+    uint64_t level = rd64(r->rsp + 0x10), cx = rd64(r->rsp + 0x18), evk = rd64(r->rsp + 0x20);
+    lt_plant_key(level, evk, LT_GIANT_ID);
+    emit_begin("lt.SwitchKeysInPlaceNoModDown"); fprintf(g_out, ", \"level\": %lu", level); emit_poly("cx", cx, (int)level + 1); emit_end(); }
+static void ret_lt_moddown(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r; ud3_t *u = ud; emit_poly("out", u->a, (int)u->b + 1); emit_end(); }
+static void on_lt_moddown(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_lt) return;
+    uint64_t level = rd64(r->rsp + 0x10), pq = rd64(r->rsp + 0x18), pp = rd64(r->rsp + 0x20), out = rd64(r->rsp + 0x28);
+    emit_begin("lt.ModDownSplitNTTPQ"); fprintf(g_out, ", \"level\": %lu", level); emit_poly("inQ", pq, (int)level + 1); emit_poly("inP", pp, poly_limbs(pp));
+    hook_return(r, ret_lt_moddown, ud_new(out, level, 0)); }
+static void ret_lt(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    uint64_t E = r->rsp - 8, p = rd64(E + 0x28), n = rd64(E + 0x30);
+    g_in_lt = 0;
+    emit_begin("LinearTransform.end"); fprintf(g_out, ", \"call\": %d, \"nres\": %lu", g_lt_calls - 1, n); if (n) emit_ct("out", rd64(p)); emit_end();
+    if (g_lt_calls >= g_lt_max) { fprintf(g_out, "\n ],\n \"exit_code\": 0}\n"); fflush(g_out); kill(g_pid, SIGKILL); exit(0); } }
+static void on_lt(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_lt_max || g_in_lt || g_lt_calls >= g_lt_max) return;
+    uint64_t ct0 = rd64(r->rsp + 0x10), m = rd64(r->rsp + 0x20);
+    int level = poly_limbs(ct_poly(ct0, 0)) - 1, call = g_lt_calls++;
+    if (level >= g_nQ) { fprintf(stderr, "LinearTransform at level %d: pass the modulus chain with -Q\n", level); exit(3); }
+    plant_ct(ct0, 3000 + call, 0);
+    emit_begin("LinearTransform.begin"); fprintf(g_out, ", \"call\": %d, \"level\": %d, \"scale_in\": %.17g, \"matrix\": {\"LogSlots\": %lu, \"N1\": %lu, \"Level\": %lu, \"Scale\": %.17g}",
+        call, level, ct_scale(ct0), rd64(m), rd64(m + 8), rd64(m + 16), rdf64(m + 24));
+    emit_ct("in", ct0); emit_end();
+    g_in_lt = 1;
+    fprintf(stderr, "LinearTransform call %d level %d\n", call, level);
+    hook_return(r, ret_lt, NULL); }
+
 /* -poly N: ckks.(*evaluator).EvaluatePoly one level up (conv.go:460-477: the three sign polynomials of evalReLU). At the entry of the
  * first N calls the input ciphertext is planted (SEED_OPIN(call, 0, poly, limb) mod q_limb); every relinearisation key a nested
  * SwitchKeysInPlace reads is planted as in -ks / -ops (SEED_KSEVK by key identity). Recorded: the polynomial (maxDeg, lead, the real
@@ -817,6 +867,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[ai], "-diag") && ai + 1 < argc) g_diag_max = atoi(argv[++ai]);          /* digest this many encoded DFT diagonals */
         else if (!strcmp(argv[ai], "-dump") && ai + 1 < argc) { g_dump = fopen(argv[++ai], "wb"); if (!g_dump) { perror("dump"); return 2; } }
         else if (!strcmp(argv[ai], "-flow")) g_flow_mode = 1;
+        else if (!strcmp(argv[ai], "-lt") && ai + 1 < argc) g_lt_max = atoi(argv[++ai]);               /* trace this many LinearTransform calls (planted input and rotation keys) */
         else if (!strcmp(argv[ai], "-keep-bl")) g_skip_bl = 0;
         else if (!strcmp(argv[ai], "-noplant")) g_noplant = 1;
         else if (!strcmp(argv[ai], "-seed") && ai + 1 < argc) g_seed = strtoull(argv[++ai], NULL, 0);
@@ -868,6 +919,8 @@ int main(int argc, char **argv) {
                       if (g_cheby) { bp_add(post_check(0x52f400), on_p_recurse, NULL); bp_add(post_check(0x52dee0), on_p_powerbasis, NULL); bp_add(post_check(0x51b320), on_p_sub, NULL); } bp_add(A_MULRELIN, on_p_mulrelin, NULL); bp_add(A_RESCALE, on_p_rescale, NULL); bp_add(A_MGIAA, on_p_mgiaa, NULL);
                       bp_add(A_ADDCONST, on_p_addconst, NULL); bp_add(A_DROPLEVEL, on_p_droplevel, NULL); bp_add(A_RECURSE, on_p_recurse, NULL); bp_add(A_POLYLEAF, on_p_leaf, NULL);
                       bp_add(A_POWERBASIS, on_p_powerbasis, NULL); bp_add(A_ADD, on_p_add, NULL); bp_add(A_MULTBYCONST, on_p_multbyconst, NULL); }
+    if (g_lt_max) { bp_add(post_check(0x5264c0), on_lt, NULL); bp_add(post_check(0x4ff060), on_lt_ks_hoisted, NULL); bp_add(post_check(0x4fe660), on_lt_ks_nomoddown, NULL);
+                    bp_add(post_check(0x4e4c40), on_lt_moddown, NULL); }
     if (g_diag_max) { bp_add(A_ENCDIAG, on_encdiag, NULL); bp_add(A_ENCMAT, on_encmat, NULL); }
     if (g_enc_max) { bp_add(A_INVFFT, on_invfft, NULL); bp_add(A_ENCODE, on_encode_slots, NULL); }
     if (g_ops_max) { bp_add(A_RESCALE, on_rescale, NULL); bp_add(A_MULRELIN, on_mulrelin, NULL); bp_add(A_ROTATE, on_rotate, NULL); bp_add(A_MODUP, on_modup, NULL); }

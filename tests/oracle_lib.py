@@ -65,6 +65,8 @@ def lib():
         L.or_div_round_last_ntt.argtypes = [C.c_void_p, C.c_int, u64p, u64p]
         L.or_keyswitch_l0.argtypes = [C.c_void_p] + [u64p] * 7
         L.or_keyswitch.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p, u64p]
+        L.or_keyswitch_qp.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p]
+        L.or_mod_down.argtypes = [C.c_void_p, C.c_int, u64p, u64p]
         L.or_basis_extend.restype = C.c_uint64
         L.or_basis_extend.argtypes = [u64p, u64p, C.c_int, C.c_uint64]
         L.or_modup_1p.restype = C.c_uint64
@@ -234,6 +236,21 @@ class Oracle:
         d1 = np.empty((level + 1, self.N), dtype=np.uint64)
         self.L.or_keyswitch(self.ctx, level, p64(cx), p64(evk.reshape(-1)), p64(d0), p64(d1))
         return d0, d1
+
+    def keyswitch_qp(self, level, cx, evk):
+        """SwitchKeysInPlaceNoModDown: (2, level+1+np, N) in the basis Q_0..Q_level, P_0..P_(np-1), before the division by P"""
+        cx = np.ascontiguousarray(cx, dtype=np.uint64).reshape(level + 1, self.N)
+        evk = np.ascontiguousarray(evk, dtype=np.uint64)
+        acc = np.empty((2, level + 1 + len(self.p), self.N), dtype=np.uint64)
+        self.L.or_keyswitch_qp(self.ctx, level, p64(cx), p64(evk.reshape(-1)), p64(acc))
+        return acc
+
+    def mod_down(self, level, x_qp):
+        """ModDownSplitNTTPQ of one polynomial (level+1+np, N) -> (level+1, N)"""
+        x = np.ascontiguousarray(x_qp, dtype=np.uint64).reshape(level + 1 + len(self.p), self.N)
+        out = np.empty((level + 1, self.N), dtype=np.uint64)
+        self.L.or_mod_down(self.ctx, level, p64(x), p64(out))
+        return out
 
     def rotate_gal_l0(self, ct, gal, evk4):
         """ct: (2,N); evk4 rows ordered (b_q, a_q, b_p, a_p) in Lattigo's stored form."""
