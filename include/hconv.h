@@ -137,6 +137,17 @@ int hc_keyswitch(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, ui
  * product with its key and the ModDown. Bit-identical to hc_keyswitch. The decomposition is valid until the next hc_keyswitch /
  * hc_keyswitch_decompose / hc_div_round_last on this context. */
 int hc_keyswitch_decompose(hc_ctx *ctx, int level, const uint64_t *cx);
+/* The key switch in two halves, and arithmetic in the extended basis QP (rows Q_0..Q_level, then P_0..P_(np-1)) between them: what Lattigo's
+ * MultiplyByDiagMatrixBSGS (the linear transforms of CoeffsToSlots / SlotsToCoeffs; test_run @52a580) is made of.
+ *  hc_keyswitch_qp  rlwe.(*KeySwitcher).SwitchKeysInPlaceNoModDown (@4fe660; hoisted = 0) / KeyswitchHoistedNoModDown (@4ff060; hoisted != 0: uses
+ *                   the decomposition hc_keyswitch_decompose(level, cx) left): acc[2][level+1+np][N], canonical residues, NTT domain.
+ *  hc_mod_down2     ring.(*FastBasisExtender).ModDownSplitNTTPQ (@4e4c40) on the two polynomials x[2][level+1+np][N] -> out0, out1 [level+1][N].
+ *                   hc_keyswitch == hc_keyswitch_qp followed by hc_mod_down2, bit for bit.
+ *  hc_qp_op2        out_k = a_k (op) b_k for k = 0, 1 over all level+1+np rows; op = HC_LV_MUL, HC_LV_ADD or HC_LV_MUL_ACC (out_k += a_k * b_k);
+ *                   b1 == b0 for a plaintext operand. (hc_permute works on any rows, so it permutes QP polynomials as they are.) */
+int hc_keyswitch_qp(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *acc, int hoisted);
+int hc_mod_down2(hc_ctx *ctx, int level, const uint64_t *x, uint64_t *out0, uint64_t *out1);
+int hc_qp_op2(hc_ctx *ctx, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1);
 int hc_keyswitch_hoisted(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1);
 
 /* ---- L1: the fused hot path ---- */

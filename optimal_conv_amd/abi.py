@@ -45,6 +45,9 @@ SYMBOLS = {
     "hc_keyswitch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_keyswitch_decompose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "hc_keyswitch_hoisted": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_keyswitch_qp": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "hc_mod_down2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_qp_op2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_lv_ntt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_lv_intt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_lv_mul": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -357,6 +360,43 @@ class Context:
         return out[0], out[1], out[2]
 
     def lv_mod_raise(self, level, row_q0): return self._lv(self.L.hc_lv_mod_raise, level, row_q0)
+
+    # ---- the extended basis QP (rows Q_0..Q_level then P_0..P_(np-1)): the halves of the key switch and arithmetic between them
+    def keyswitch_qp(self, key_ids, level, cx, hoisted=True):
+        """SwitchKeysInPlaceNoModDown / KeyswitchHoistedNoModDown with every key in key_ids on one polynomial: [(2, level+1+np, N), ...]"""
+        cx = np.ascontiguousarray(cx, dtype=np.uint64).reshape(level + 1, self.N)
+        nt = level + 1 + len(self.p)
+        src, acc = self.buf(cx), self.buf(nwords=2 * nt * self.N)
+        if hoisted:
+            self._ck(self.L.hc_keyswitch_decompose(self.h, level, src.ptr))
+        outs = []
+        for kid in key_ids:
+            self._ck(self.L.hc_keyswitch_qp(self.h, C.c_uint64(kid), level, src.ptr, acc.ptr, 1 if hoisted else 0))
+            outs.append(acc.download((2, nt, self.N)).copy())
+        src.free(); acc.free()
+        return outs
+
+    def mod_down2(self, level, x):
+        """ModDownSplitNTTPQ of the two polynomials x (2, level+1+np, N) -> (2, level+1, N)"""
+        nt = level + 1 + len(self.p)
+        X = self.buf(np.ascontiguousarray(x, dtype=np.uint64).reshape(2, nt, self.N))
+        O = self.buf(nwords=2 * (level + 1) * self.N)
+        self._ck(self.L.hc_mod_down2(self.h, level, X.ptr, O.at(0), O.at((level + 1) * self.N)))
+        out = O.download((2, level + 1, self.N))
+        X.free(); O.free()
+        return out
+
+    def qp_op2(self, op, level, a, b, out=None, shared_b=False):
+        """hc_qp_op2: a, out (2, nt, N); b (2, nt, N) or, with shared_b, one plaintext (nt, N)"""
+        nt = level + 1 + len(self.p)
+        A = self.buf(np.ascontiguousarray(a, dtype=np.uint64).reshape(2, nt, self.N))
+        B_ = self.buf(np.ascontiguousarray(b, dtype=np.uint64))
+        O = self.buf(np.ascontiguousarray(out, dtype=np.uint64).reshape(2, nt, self.N)) if out is not None else self.buf(nwords=2 * nt * self.N)
+        n = nt * self.N
+        self._ck(self.L.hc_qp_op2(self.h, op, level, A.at(0), A.at(n), B_.at(0), B_.at(0 if shared_b else n), O.at(0), O.at(n)))
+        res = O.download((2, nt, self.N))
+        A.free(); B_.free(); O.free()
+        return res
 
     def keyswitch_hoisted(self, key_ids, level, cx):
         """one decomposition of cx, then the inner product + ModDown with every key in key_ids: [(d0, d1), ...]"""

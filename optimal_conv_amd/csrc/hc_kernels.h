@@ -305,10 +305,13 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_pointwise(const u64 *a, const u64
 // HC_PW_MULC multiplies by csts[limb]; HC_PW_ADDC adds csts[limb].w to every coefficient (a constant polynomial in the NTT domain)
 enum { HC_PW_ADDC = 6, HC_PW_MAC = 7 };    // MAC: out = out + a * b (the diagonal sums of a linear transform)
 struct HcLvConsts { HcTw c[32]; };      // per-limb constants of one call, passed by value (no host-device copy, no synchronisation)
+#define HC_ROW_IS_MOD 0x7fffffff
 template <int OP>
-__global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const u64 *b, u64 *out, const HcMod *mods, HcLvConsts K, size_t as = 0, size_t bs = 0, size_t os = 0) {
-    const int l = blockIdx.y; const HcMod m = mods[l]; const HcTw *csts = K.c;
-    const size_t base = (size_t)l * 65536;
+// nlq / nqt: rows 0..nlq-1 belong to moduli 0..nlq-1, rows from nlq on to moduli nqt, nqt+1, ... (a polynomial in the extended basis
+// Q_0..Q_level, P_0..P_(np-1) of the key switch: nlq = level + 1, nqt = number of Q moduli of the context); nlq = HC_ROW_IS_MOD: row = modulus
+__global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const u64 *b, u64 *out, const HcMod *mods, HcLvConsts K, size_t as, size_t bs, size_t os, int nlq, int nqt) {
+    const int row = blockIdx.y, l = row < nlq ? row : nqt + (row - nlq); const HcMod m = mods[l]; const HcTw *csts = K.c;
+    const size_t base = (size_t)row * 65536;
     a += (size_t)blockIdx.z * as; b += (size_t)blockIdx.z * bs; out += (size_t)blockIdx.z * os;      // blockIdx.z = polynomial of a ciphertext (distances modulo 2^64)
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
         const u64 x = a[base + i]; u64 r;

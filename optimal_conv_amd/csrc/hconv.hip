@@ -476,7 +476,7 @@ static int hc_lv_pw(hc_ctx *c, const char *fn, int level, const uint64_t *a, con
         if (level >= 32) return hc_fail(c, HC_ERR_UNSUPPORTED, "%s: more than 32 limbs", fn);
         for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[l] = h_pair(consts_host[l] % q, q); }
     }
-    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, hc_lv_grid(level), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, K, (size_t)0, (size_t)0, (size_t)0);
+    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, hc_lv_grid(level), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, K, (size_t)0, (size_t)0, (size_t)0, HC_ROW_IS_MOD, 0);
 }
 // the same operations on both polynomials of a ciphertext in one launch (they may live in separate allocations; b1 == b0 for a plaintext operand)
 template <int OP>
@@ -490,7 +490,7 @@ static int hc_lv_pw2(hc_ctx *c, const char *fn, int level, const u64 *a0, const 
         for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[l] = h_pair(consts_host[l] % q, q); }
     }
     const u64 *bb0 = b0 ? b0 : a0, *bb1 = b1 ? b1 : a1;
-    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(64, (unsigned)(level + 1), 2), a0, bb0, o0, (const HcMod *)c->d_mods, K, (size_t)(a1 - a0), (size_t)(bb1 - bb0), (size_t)(o1 - o0));
+    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(64, (unsigned)(level + 1), 2), a0, bb0, o0, (const HcMod *)c->d_mods, K, (size_t)(a1 - a0), (size_t)(bb1 - bb0), (size_t)(o1 - o0), HC_ROW_IS_MOD, 0);
 }
 extern "C" int hc_lv_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1, const uint64_t *consts) {
     HC_ENTER(c);
@@ -1064,13 +1064,20 @@ static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, u64 *coef, 
     // half: only the cols pass, into ws_tmp; hc_k_rows_fwd_mac finishes the transform inside the inner product (plain key switch)
     return hc_ntt_mm(c, digits, digits, nt, nl, 0, 0, beta, (size_t)nt * HC_N, (size_t)nt * HC_N, alpha, half);
 }
+static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1, uint64_t rot_gal, const u64 *rot_c0);
 // phase 2: inner product with the key (both components), then ModDownSplitNTTPQ
 static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const u64 *digits, u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1, bool half = false, uint64_t rot_gal = 0, const u64 *rot_c0 = nullptr) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = key.beta;
     if (half) HC_TRY(hc_launch(c, "ks_rows_fwd_mac", hc_k_rows_fwd_mac, dim3(16, (unsigned)nt), (const u64 *)key.rows, cx, (const u64 *)c->ws_tmp, acc, (const HcRowMod *)c->d_rowmods, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta));
     else HC_TRY(hc_launch(c, "ks_mac_all", hc_k_ks_mac_all, dim3(32, (unsigned)nt, 2), (const u64 *)key.rows, cx, digits, acc, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta));
-    // ModDownSplitNTTPQ for both components: InvNTT of the P limbs, {P} -> every Q limb, NTT, (acc - ext) * P^-1
+    return hc_ks_moddown(c, level, acc, pc, ext, d0, d1, rot_gal, rot_c0);
+}
+// ring.(*FastBasisExtender).ModDownSplitNTTPQ for the two polynomials acc[2][nt][N] (basis Q_0..Q_level, P_0..P_(np-1), canonical, NTT):
+// InvNTT of the P limbs, {P} -> every Q limb, NTT, (acc - ext) * P^-1
+static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1, uint64_t rot_gal, const u64 *rot_c0) {
+    const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha;
     {   HcMm A; A.M = c->d_rowmods; A.nl = 0; A.nq = c->nq; A.skip_lo = A.skip_hi = 0; A.z_alpha = 0;  // rows y -> modulus nq + y
         HC_TRY(hc_ensure_tmp(c, (size_t)2 * alpha));
         const dim3 grid(16, (unsigned)alpha, 2); const size_t zt = (size_t)alpha * HC_N;
@@ -1144,6 +1151,50 @@ extern "C" int hc_keyswitch_rotate(hc_ctx *c, uint64_t key_id, uint64_t galEl, i
         c->hoist_cx = nullptr;
     }
     return hc_ks_apply_from(c, *key, level, c1, S.digits, S.acc, S.pc, S.ext, out0, out1, false, galEl, c0);
+}
+
+// ---- the key switch in two halves and arithmetic in the extended basis (Lattigo's MultiplyByDiagMatrixBSGS keeps the baby-step rotations,
+// their products with the plaintext diagonals and the giant-step sums in QP and divides by P once per giant step; host: Boot::linear_transform_qp)
+// hc_keyswitch_qp = rlwe.(*KeySwitcher).SwitchKeysInPlaceNoModDown (hoisted == 0) / KeyswitchHoistedNoModDown (hoisted != 0: the decomposition
+// hc_keyswitch_decompose(level, cx) left in the context): acc[2][level+1+np][N], rows Q_0..Q_level then P_0..P_(np-1), canonical, NTT.
+extern "C" int hc_keyswitch_qp(hc_ctx *c, uint64_t key_id, int level, const uint64_t *cx, uint64_t *acc, int hoisted) {
+    HC_ENTER(c);
+    const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_qp", key_id, level, &key));
+    if (!cx || !acc) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_qp: null");
+    HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
+    if (hoisted) {
+        if (c->hoist_cx != cx || c->hoist_level != level) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch_qp: no decomposition of this polynomial at level %d is held (call hc_keyswitch_decompose first)", level);
+    } else {
+        HC_TRY(hc_ks_decompose_into(c, level, cx, S.coef, S.digits, false));
+        c->hoist_cx = nullptr;
+    }
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha;
+    return hc_launch(c, "ks_mac_all", hc_k_ks_mac_all, dim3(32, (unsigned)nt, 2), (const u64 *)key->rows, cx, (const u64 *)S.digits, (u64 *)acc, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, key->beta);
+}
+// hc_mod_down2 = ring.(*FastBasisExtender).ModDownSplitNTTPQ on the two polynomials x[2][level+1+np][N] -> out0, out1 [level+1][N]. A hoisted
+// decomposition held by the context survives it.
+extern "C" int hc_mod_down2(hc_ctx *c, int level, const uint64_t *x, uint64_t *out0, uint64_t *out1) {
+    HC_ENTER(c);
+    if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_mod_down2: level %d outside 0..%d or no special primes", level, c->nq - 1);
+    if (!x || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_mod_down2: null");
+    HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
+    return hc_ks_moddown(c, level, (const u64 *)x, S.pc, S.ext, (u64 *)out0, (u64 *)out1, 0, nullptr);
+}
+// hc_qp_op2: out_k = a_k (op) b_k, k = 0, 1, over the level+1+np rows of the extended basis (op: HC_LV_MUL, HC_LV_ADD, HC_LV_MUL_ACC; b1 == b0
+// for a plaintext operand; products of two NTT residues as hc_lv_mul)
+extern "C" int hc_qp_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1) {
+    HC_ENTER(c);
+    if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: level %d outside 0..%d or no special primes", level, c->nq - 1);
+    if (!a0 || !a1 || !b0 || !b1 || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: null");
+    HcLvConsts K; memset(&K, 0, sizeof K);
+    const dim3 grid(64, (unsigned)(level + 1 + c->np), 2);
+    const size_t as = (size_t)(a1 - a0), bs = (size_t)(b1 - b0), os = (size_t)(out1 - out0);
+    switch (op) {
+        case HC_LV_MUL: return hc_launch(c, "hc_qp_op2(mul)", hc_k_lv_pointwise<HC_PW_MUL>, grid, (const u64 *)a0, (const u64 *)b0, (u64 *)out0, (const HcMod *)c->d_mods, K, as, bs, os, level + 1, c->nq);
+        case HC_LV_ADD: return hc_launch(c, "hc_qp_op2(add)", hc_k_lv_pointwise<HC_PW_ADD>, grid, (const u64 *)a0, (const u64 *)b0, (u64 *)out0, (const HcMod *)c->d_mods, K, as, bs, os, level + 1, c->nq);
+        case HC_LV_MUL_ACC: return hc_launch(c, "hc_qp_op2(mul_acc)", hc_k_lv_pointwise<HC_PW_MAC>, grid, (const u64 *)a0, (const u64 *)b0, (u64 *)out0, (const HcMod *)c->d_mods, K, as, bs, os, level + 1, c->nq);
+    }
+    return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: unknown operation %d", op);
 }
 
 // ------------------------------------------------------------------ L1

@@ -80,7 +80,7 @@ struct Boot {
     ChaChaRng rng;                    // the bootstrapper's own key stream (switching keys, encryption masks)
     Encoder enc;
     std::shared_ptr<uint64_t> mono_i;                        // NTT(X^(N/2)) for every limb
-    struct LT { int n1 = 1; std::map<int, std::map<int, DPt>> giant; double pt_scale = 0; int level = 0; };
+    struct LT { int n1 = 1; std::map<int, std::map<int, DPt>> giant; double pt_scale = 0; int level = 0; bool qp = false; };   // qp: the diagonals are encoded mod Q_0..Q_level AND mod every P (rows [level+1+np][N]) for linear_transform_qp
     struct Set { int ls = 0, ns = 0; std::vector<LT> cts, stc; };      // one bootstrapper of the reference (btp, btp2..btp5: main.go:480-500)
     std::map<int, Set> sets;                                           // by log_sparse
     std::vector<double> sine;
@@ -93,6 +93,14 @@ struct Boot {
         if (!pool.empty()) { d = pool.back(); pool.pop_back(); }
         else { void *v = nullptr; HCR(hc_malloc(hc, (size_t)NQ * N * 8, &v)); d = (uint64_t *)v; }
         return std::shared_ptr<uint64_t>(d, [this](uint64_t *x) { pool.push_back(x); });
+    }
+    // two polynomials in the extended basis, [2][level+1+np][N] at the start of a 2 (NQ+NP)-row allocation (hc_keyswitch_qp / hc_mod_down2 layout)
+    std::vector<uint64_t *> pool_qp;
+    std::shared_ptr<uint64_t> block_qp2() {
+        uint64_t *d;
+        if (!pool_qp.empty()) { d = pool_qp.back(); pool_qp.pop_back(); }
+        else { void *v = nullptr; HCR(hc_malloc(hc, (size_t)2 * (NQ + P.size()) * N * 8, &v)); d = (uint64_t *)v; }
+        return std::shared_ptr<uint64_t>(d, [this](uint64_t *x) { pool_qp.push_back(x); });
     }
     DCt new_ct(int level, int deg, double scale) { DCt c; c.deg = deg; c.level = level; c.scale = scale; for (int i = 0; i <= deg; i++) c.p[i] = block(); return c; }
     static DCt drop_to(const DCt &a, int level) { if (level > a.level) panic("drop_to: level above the ciphertext's"); DCt c = a; c.level = level; return c; }
@@ -324,6 +332,19 @@ struct Boot {
         return pt;
     }
 
+    // a diagonal as the reference's encodeDiagonal leaves it (minus the Montgomery factor): mod Q_0..Q_level and mod every P, NTT domain
+    DPt encode_qp(const std::vector<cplx> &slots, int level, double scale) {
+        const int nl = level + 1, np = (int)P.size();
+        std::vector<uint64_t> mods(Q.begin(), Q.begin() + nl); mods.insert(mods.end(), P.begin(), P.end());
+        std::vector<uint64_t> rows = enc.Encode(slots, scale, mods.data(), nl + np);
+        DPt pt; pt.level = level; pt.scale = scale;
+        { void *v = nullptr; HCR(hc_malloc(hc, rows.size() * 8, &v)); uint64_t *d = (uint64_t *)v; hc_ctx *h = hc; pt.p = std::shared_ptr<uint64_t>(d, [h](uint64_t *x) { hc_free(h, x); }); }
+        HCR(hc_upload(hc, pt.p.get(), rows.data(), rows.size() * 8));
+        HCR(hc_lv_ntt(hc, level, pt.p.get(), pt.p.get()));
+        for (int j = 0; j < np; j++) { uint64_t *r = pt.p.get() + (size_t)(nl + j) * N; HCR(hc_ntt(hc, NQ + j, r, r, 1)); }
+        return pt;
+    }
+
     // ---------------- DFT matrices in diagonal form (the encoder's own butterflies, no bit reversal)
     // `E`: encoder of the ring the DFT belongs to (the full ring, or the subring X^(2^ls) of sparse packing: same butterflies
     // with that ring's roots, tiled over the n full slots); rotation indices modulo `period` (the slot vector's period)
@@ -454,20 +475,93 @@ struct Boot {
         for (auto &e : M) {
             const int k = e.first, g = k - k % lt.n1, b = k % lt.n1;
             std::vector<cplx> rolled((size_t)n); for (int p = 0; p < n; p++) rolled[(size_t)p] = e.second[(size_t)(((p - g) % n + n) % n)];     // np.roll(diag, g) = the fork's rotate(v, -N1*j)
-            lt.giant[g][b] = encode(rolled, level, pt_scale);
+            lt.giant[g][b] = lattigo_split && chain == 6 ? encode_qp(rolled, level, pt_scale) : encode(rolled, level, pt_scale);
+            lt.qp = lattigo_split && chain == 6;
             if (dft_digests) {      // what the reference's encodeDiagonal receives and returns (mod Q): values; NTT rows in Montgomery form + the spare zero limb
                 Sha256 hv; hv.update(rolled.data(), rolled.size() * sizeof(cplx));
                 std::vector<uint64_t> rows((size_t)(level + 1) * N), zero((size_t)N, 0);
                 HCR(hc_download(hc, rows.data(), lt.giant[g][b].p.get(), rows.size() * 8));
                 for (int l = 0; l <= level; l++) { const uint64_t q = Q[(size_t)l], r = (uint64_t)((((u128)1) << 64) % q); for (int j = 0; j < N; j++) rows[(size_t)l * N + j] = mulmod(rows[(size_t)l * N + j], r, q); }
                 Sha256 hq; hq.update(rows.data(), rows.size() * 8); hq.update(zero.data(), zero.size() * 8);
-                fprintf(dft_digests, "{\"matrix\": \"%s\", \"chain\": %d, \"level\": %d, \"scale\": %.17g, \"N1\": %d, \"k\": %d, \"values\": \"%s\", \"mQ\": \"%s\"}\n", tag, chain, level, pt_scale, lt.n1, k, hv.hex().c_str(), hq.hex().c_str());
+                std::string mp = "";
+                if (lt.qp) {            // ... and mod P
+                    const int np = (int)P.size(); std::vector<uint64_t> prow((size_t)np * N);
+                    HCR(hc_download(hc, prow.data(), lt.giant[g][b].p.get() + (size_t)(level + 1) * N, prow.size() * 8));
+                    for (int j = 0; j < np; j++) { const uint64_t q = P[(size_t)j], r = (uint64_t)((((u128)1) << 64) % q); for (int i = 0; i < N; i++) prow[(size_t)j * N + i] = mulmod(prow[(size_t)j * N + i], r, q); }
+                    Sha256 hp; hp.update(prow.data(), prow.size() * 8); mp = hp.hex();
+                }
+                fprintf(dft_digests, "{\"matrix\": \"%s\", \"chain\": %d, \"level\": %d, \"scale\": %.17g, \"N1\": %d, \"k\": %d, \"values\": \"%s\", \"mQ\": \"%s\", \"mP\": \"%s\"}\n", tag, chain, level, pt_scale, lt.n1, k, hv.hex().c_str(), hq.hex().c_str(), mp.c_str());
             }
         }
         return lt;
     }
+    // ckks.(*evaluator).LinearTransform -> MultiplyByDiagMatrixBSGS exactly as the reference's fork computes it (test_run @52a580; tests/lattigo_lt.py
+    // is the same algorithm on the oracle and reproduces the binary's ModDown inputs / outputs and result on planted data, tests/test_oracle_pin_lt.py;
+    // tests/oracle_ckks.py Ckks.linear_transform_qp is this function on the oracle chain). Everything stays in the extended basis QP until a
+    // complete sum exists: the baby-step rotations are key-switched WITHOUT the division by P on one digit decomposition and get P*c0 added
+    // (rot_i = (phi_i(P c0 + d0_i), phi_i(d1_i)) mod QP); per giant step j != 0 their products with the diagonals (encoded mod Q and mod P) are
+    // summed in QP and brought down ONCE, a rotation-0 diagonal multiplies the input itself after that division, the second component is
+    // key-switched again without ModDown and permuted into QP accumulators, the first is permuted straight into the result; giant step 0 adds
+    // its products to the same accumulators, which are brought down once. 2 ModDowns per giant step + 2 instead of 2 per baby step.
+    DCt linear_transform_qp(const DCt &ct, const LT &lt) {
+        const int L = ct.level, nl = L + 1, np = (int)P.size(), nt = nl + np; const size_t zs = (size_t)nt * N;
+        std::map<int, std::vector<int>> index; std::set<int> babies;
+        for (auto &g : lt.giant) for (auto &b : g.second) { index[g.first / lt.n1].push_back(b.first); if (b.first) babies.insert(b.first); }
+        for (int b : babies) key(gal_rot(b), L);                                    // key generation (if any) before a decomposition is taken
+        for (auto &g : lt.giant) if (g.first) key(gal_rot(g.first), L);
+        std::vector<uint64_t> pmod((size_t)nl), zeros((size_t)nl, 0);
+        for (int l = 0; l < nl; l++) { uint64_t r = 1; for (uint64_t pj : P) r = mulmod(r, pj % Q[(size_t)l], Q[(size_t)l]); pmod[(size_t)l] = r; }
+        auto pc0 = block(); HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), pmod.data(), pc0.get()));                       // P * c0
+        std::map<int, std::shared_ptr<uint64_t>> rot;
+        if (!babies.empty()) {
+            HCR(hc_keyswitch_decompose(hc, L, ct.p[1].get()));
+            auto acc = block_qp2();
+            for (int b : babies) {
+                const uint64_t gal = gal_rot(b);
+                HCR(hc_keyswitch_qp(hc, key(gal, L), L, ct.p[1].get(), acc.get(), 1)); n_keyswitch++;
+                HCR(hc_lv_add(hc, L, acc.get(), pc0.get(), acc.get()));                                                  // the Q rows of the first component
+                auto r = block_qp2(); HCR(hc_permute(hc, gal, acc.get(), r.get(), 2 * nt));
+                rot[b] = r;
+            }
+        }
+        DCt res = new_ct(L, 1, ct.scale * lt.pt_scale); bool have_res[2] = {false, false};
+        auto add_to_res = [&](int k, const std::shared_ptr<uint64_t> &x) { if (have_res[k]) HCR(hc_lv_add(hc, L, res.p[k].get(), x.get(), res.p[k].get())); else { res.p[k] = x; have_res[k] = true; } };
+        auto B = block_qp2(); bool haveB = false;
+        for (auto &ix : index) {
+            const int j = ix.first; if (j == 0) continue;
+            const int g = j * lt.n1; const uint64_t gal = gal_rot(g);
+            const auto &row = lt.giant.at(g);
+            auto A = block_qp2(); bool haveA = false;
+            for (int i : ix.second) if (i) {
+                const uint64_t *pt = row.at(i).p.get(); uint64_t *r = rot[i].get();
+                HCR(hc_qp_op2(hc, haveA ? HC_LV_MUL_ACC : HC_LV_MUL, L, r, r + zs, pt, pt, A.get(), A.get() + zs)); haveA = true;
+            }
+            auto a0 = block(), a1 = block();
+            if (haveA) HCR(hc_mod_down2(hc, L, A.get(), a0.get(), a1.get()));
+            else { HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), zeros.data(), a0.get())); HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), zeros.data(), a1.get())); }
+            if (row.count(0)) { const uint64_t *pt = row.at(0).p.get(); HCR(hc_lv_op2(hc, HC_LV_MUL_ACC, L, ct.p[0].get(), ct.p[1].get(), pt, pt, a0.get(), a1.get(), nullptr)); }
+            auto e = block_qp2();
+            HCR(hc_keyswitch_qp(hc, key(gal, L), L, a1.get(), e.get(), 0)); n_keyswitch++;
+            { auto t = block(); HCR(hc_permute(hc, gal, a0.get(), t.get(), nl)); add_to_res(0, t); }
+            if (!haveB) { HCR(hc_permute(hc, gal, e.get(), B.get(), 2 * nt)); haveB = true; }
+            else { auto t = block_qp2(); HCR(hc_permute(hc, gal, e.get(), t.get(), 2 * nt)); HCR(hc_qp_op2(hc, HC_LV_ADD, L, B.get(), B.get() + zs, t.get(), t.get() + zs, B.get(), B.get() + zs)); }
+        }
+        if (index.count(0)) for (int i : index[0]) if (i) {
+            const uint64_t *pt = lt.giant.at(0).at(i).p.get(); uint64_t *r = rot[i].get();
+            HCR(hc_qp_op2(hc, haveB ? HC_LV_MUL_ACC : HC_LV_MUL, L, r, r + zs, pt, pt, B.get(), B.get() + zs)); haveB = true;
+        }
+        if (haveB) { auto d0 = block(), d1 = block(); HCR(hc_mod_down2(hc, L, B.get(), d0.get(), d1.get())); add_to_res(0, d0); add_to_res(1, d1); }
+        if (lt.giant.count(0) && lt.giant.at(0).count(0)) {
+            const uint64_t *pt = lt.giant.at(0).at(0).p.get();
+            if (have_res[0] && have_res[1]) HCR(hc_lv_op2(hc, HC_LV_MUL_ACC, L, ct.p[0].get(), ct.p[1].get(), pt, pt, res.p[0].get(), res.p[1].get(), nullptr));
+            else for (int k = 0; k < 2; k++) { auto t = block(); HCR(hc_lv_mul(hc, L, ct.p[k].get(), pt, t.get())); add_to_res(k, t); }
+        }
+        if (!have_res[0] || !have_res[1]) panic("linear_transform_qp: empty matrix");
+        return res;
+    }
     DCt linear_transform(const DCt &ct, const LT &lt) {             // sum_k diag_k (.) rot_k(ct); no rescale
         if (ct.level != lt.level) panic("linear_transform: ciphertext level differs from the encoded matrix level");
+        if (lt.qp) return linear_transform_qp(ct, lt);
         std::vector<int> babies; { std::set<int> seen; for (auto &g : lt.giant) for (auto &b : g.second) if (seen.insert(b.first).second) babies.push_back(b.first); }
         std::map<int, DCt> rots = rotate_hoisted(ct, babies);          // the baby steps rotate the same ciphertext: one decomposition
         DCt acc; bool have_acc = false;

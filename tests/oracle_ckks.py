@@ -61,6 +61,14 @@ class OracleBackend:
     def div_round_last(self, level, rows):
         return self.O.div_round_last(level, rows)
 
+    # the extended basis QP (rows Q_0..Q_level, then the P limbs): the two halves of the key switch and row-wise arithmetic
+    def _qp_mods(self, nt): return list(range(nt - len(self.O.p))) + [len(self.O.q) + j for j in range(len(self.O.p))]
+    def keyswitch_qp(self, keys, cx): return [self.O.keyswitch_qp(k.level, cx, k.rows) for k in keys]       # one decomposition, several keys
+    def mod_down2(self, level, x): return np.stack([self.O.mod_down(level, x[0]), self.O.mod_down(level, x[1])])
+    def qp_mul(self, a, pt): m = self._qp_mods(a.shape[1]); return np.stack([np.stack([self.O.mul(m[t], a[k, t], pt[t]).reshape(-1) for t in range(len(m))]) for k in range(2)])
+    def qp_add(self, a, b): m = self._qp_mods(a.shape[1]); return np.stack([np.stack([self.O.add(m[t], a[k, t], b[k, t]).reshape(-1) for t in range(len(m))]) for k in range(2)])
+    def qp_mul_acc(self, a, pt, acc): return self.qp_add(acc, self.qp_mul(a, pt))
+
     # leveled polynomials, (level+1, N) arrays: per-limb loops over the primitives above
     def lv_mul(self, a, b): return np.stack([self.O.mul(l, a[l], b[l]).reshape(-1) for l in range(a.shape[0])])
     def lv_add(self, a, b): return np.stack([self.O.add(l, a[l], b[l]).reshape(-1) for l in range(a.shape[0])])
@@ -213,6 +221,12 @@ class Ckks:
     def encode_ntt(self, slots, level, scale):
         rows = self.O.encode_coeffs(self.enc.slots_to_coeffs(slots), scale, list(range(level + 1)))
         return np.stack([self.O.ntt(l, rows[l]) for l in range(level + 1)])
+
+    def encode_ntt_qp(self, slots, level, scale):
+        """the plaintext as encodeDiagonal leaves it (minus the Montgomery factor): rows mod Q_0..Q_level and mod every P, NTT domain"""
+        mods = list(range(level + 1)) + [len(self.Q) + j for j in range(len(self.P))]
+        rows = self.O.encode_coeffs(self.enc.slots_to_coeffs(slots), scale, mods)
+        return np.stack([self.O.ntt(m, rows[i]).reshape(-1) for i, m in enumerate(mods)])
 
     def encode_coeffs_ntt(self, cf, level, scale):
         rows = self.O.encode_coeffs(np.asarray(cf, dtype=np.float64), scale, list(range(level + 1)))
@@ -447,6 +461,63 @@ class Ckks:
             inner = self.rotate(inner, g)
             acc = inner if acc is None else self.add(acc, inner)
         return acc
+
+    def linear_transform_qp(self, ct, diags, pt_scale, n1):
+        """ckks.(*evaluator).LinearTransform -> MultiplyByDiagMatrixBSGS exactly as the reference's fork computes it (tests/lattigo_lt.py is the
+        same algorithm on the bare oracle, pinned against the binary in tests/test_oracle_pin_lt.py): baby-step rotations key-switched without
+        the division by P on one digit decomposition, P*c0 added, products with the diagonals (encoded mod Q and mod P) summed in QP, ONE
+        ModDown per giant step, a second key switch without ModDown for the giant rotation, the outer sums brought down once; rotation-0
+        diagonals multiply the input itself after the division. host/hconv_relu.cpp Boot::linear_transform_qp is the product's copy."""
+        L, be = ct.level, self.be
+        nl = L + 1
+        index = {}
+        for k in sorted(diags):
+            index.setdefault((k % self.n) // n1, []).append((k % self.n) & (n1 - 1))
+        pts = {k: self.encode_ntt_qp(np.roll(diags[k], ((k % self.n) // n1) * n1), L, pt_scale) for k in diags}
+        c0, c1 = ct.rows[0], ct.rows[1]
+        Pbig = 1
+        for p in self.P:
+            Pbig *= p
+        pc0 = be.lv_mul_const(c0, [Pbig % self.Q[l] for l in range(nl)])
+        babies = sorted({i for js in index.values() for i in js if i})
+        accs = be.keyswitch_qp([self.key(self.gal_rot(i), L) for i in babies], c1) if babies else []
+        self.counters["keyswitch"] += len(babies)
+        rot = {}
+        for i, acc in zip(babies, accs):
+            acc = acc.copy()
+            acc[0, :nl] = be.lv_add(acc[0, :nl], pc0)                              # phi(P c0 + d0): added before the permutation
+            g = self.gal_rot(i)
+            rot[i] = np.stack([be.permute(g, acc[0]), be.permute(g, acc[1])])
+        res = [None, None]
+        B = None
+        for j in sorted(index):
+            if j == 0:
+                continue
+            A = None
+            for i in index[j]:
+                if i:
+                    A = be.qp_mul(rot[i], pts[n1 * j + i]) if A is None else be.qp_mul_acc(rot[i], pts[n1 * j + i], A)
+            a = be.mod_down2(L, A) if A is not None else np.zeros((2, nl, self.N), dtype=np.uint64)
+            if 0 in index[j]:
+                ptq = pts[n1 * j][:nl]
+                a = np.stack([be.lv_add(a[k], be.lv_mul(ct.rows[k], ptq)) for k in range(2)])
+            g = self.gal_rot(n1 * j)
+            e = be.keyswitch_qp([self.key(g, L)], np.ascontiguousarray(a[1]))[0]
+            self.counters["keyswitch"] += 1
+            t = be.permute(g, a[0])
+            res[0] = t if res[0] is None else be.lv_add(res[0], t)
+            e = np.stack([be.permute(g, e[0]), be.permute(g, e[1])])
+            B = e if B is None else be.qp_add(B, e)
+        for i in index.get(0, []):
+            if i:
+                B = be.qp_mul(rot[i], pts[i]) if B is None else be.qp_mul_acc(rot[i], pts[i], B)
+        if B is not None:
+            d = be.mod_down2(L, B)
+            res = [d[k] if res[k] is None else be.lv_add(res[k], d[k]) for k in range(2)]
+        if 0 in index.get(0, []):
+            ptq = pts[0][:nl]
+            res = [be.lv_mul(ct.rows[k], ptq) if res[k] is None else be.lv_add(res[k], be.lv_mul(ct.rows[k], ptq)) for k in range(2)]
+        return Ct(np.stack(res), ct.scale * pt_scale)
 
     def dft_stage(self, ln, inverse, enc=None, period=None):
         """one radix-2 stage of the encoder's special (i)FFT as a 3-diagonal matrix (no bit reversal). With `enc` the encoder of
@@ -861,7 +932,7 @@ class Bootstrapper:
         ct = C.mul_const_int(ct, k); ct.scale = s0 * k
         for G, n1 in zip(self.cts, self.cts_n1):                                    # CoeffsToSlots -> dft: LinearTransform, Rescale(min = scale before)
             s_in = ct.scale
-            ct = C.rescale_to(C.linear_transform(ct, G, float(C.Q[ct.level]), n1), s_in)
+            ct = C.rescale_to(C.linear_transform_qp(ct, G, float(C.Q[ct.level]), n1), s_in)
         assert ct.level == LV_SINE_TOP
         cc = C.conjugate(ct)
         parts = [C.add(ct, cc), C.neg(C.mul_by_i(C.sub(ct, cc)))]                   # DivByi = times -i
@@ -902,7 +973,7 @@ class Bootstrapper:
             sc = math.sqrt(float(C.Q[self.stc_top]))
             for M, n1, s_pt in zip(G, self.stc_n1, (sc, sc, 2.0 ** 30)):
                 s_in = ct.scale
-                ct = C.rescale_to(C.linear_transform(ct, M, s_pt, n1), s_in)
+                ct = C.rescale_to(C.linear_transform_qp(ct, M, s_pt, n1), s_in)
             return C.rescale_to(ct, 2.0 ** 30)
         # Ours: level 3 carries all but the last matrix (their plaintext scales multiply to q3), level 2 the last at scale 2^30
         first = G[:-1]

@@ -344,6 +344,47 @@ def case_keyswitch_hoisted(make_ctx, make_oracle, level=4, alpha=3, nkeys=3):
     ctx.close()
 
 
+def case_keyswitch_qp_mod_down(make_ctx, make_oracle, level=4, alpha=3, nkeys=2):
+    """hc_keyswitch_qp (hoisted and not), hc_mod_down2, hc_qp_op2 and hc_permute on QP rows against the oracle's or_keyswitch_qp / or_mod_down:
+    the pieces of the reference's MultiplyByDiagMatrixBSGS; hc_keyswitch_qp followed by hc_mod_down2 must equal hc_keyswitch"""
+    Q, P = Q_MIX[: level + 1], P_CHAIN[:alpha]
+    ctx, O = make_ctx(Q, P), make_oracle(Q, P)
+    beta, nt = (level + 1 + alpha - 1) // alpha, level + 1 + alpha
+    mods = list(range(level + 1)) + [len(Q) + j for j in range(alpha)]
+    cx = np.stack([splitmix_rows(2900 + l, Q[l], N) for l in range(level + 1)])
+    evks = []
+    for kid in range(nkeys):
+        evk = np.empty((beta, 2, nt, N), dtype=np.uint64)
+        for d in range(beta):
+            for k in range(2):
+                for T in range(nt):
+                    q = Q[T] if T <= level else P[T - level - 1]
+                    evk[d, k, T] = splitmix_rows(8000 + 1000 * kid + ((d * 2 + k) * 16 + T), q, N)
+        ctx.swk_load(20 + kid, level, evk)
+        evks.append(evk)
+    want = [O.keyswitch_qp(level, cx, e) for e in evks]
+    for hoisted in (True, False):
+        got = ctx.keyswitch_qp([20 + kid for kid in range(nkeys)], level, cx, hoisted=hoisted)
+        for kid in range(nkeys):
+            eq(got[kid], want[kid], f"keyswitch_qp key {kid} hoisted={hoisted}")
+    down = ctx.mod_down2(level, want[0])
+    eq(down[0], O.mod_down(level, want[0][0]), "mod_down2 poly 0"); eq(down[1], O.mod_down(level, want[0][1]), "mod_down2 poly 1")
+    w0, w1 = O.keyswitch(level, cx, evks[0])
+    eq(down[0], w0, "keyswitch_qp + mod_down2 == keyswitch (d0)"); eq(down[1], w1, "keyswitch_qp + mod_down2 == keyswitch (d1)")
+    # arithmetic over the QP rows: product with a plaintext (shared), accumulate, add; permutation of QP rows
+    pt = np.stack([splitmix_rows(3300 + t, (Q + P)[t] if t <= level else P[t - level - 1], N) for t in range(nt)])
+    ref_mul = np.stack([np.stack([O.mul(mods[t], want[0][k, t], pt[t]).reshape(-1) for t in range(nt)]) for k in range(2)])
+    eq(ctx.qp_op2(0, level, want[0], pt, shared_b=True), ref_mul, "qp mul by a plaintext")
+    ref_mac = np.stack([np.stack([O.add(mods[t], want[1][k, t], ref_mul[k, t]).reshape(-1) for t in range(nt)]) for k in range(2)])
+    eq(ctx.qp_op2(7, level, want[0], pt, out=want[1], shared_b=True), ref_mac, "qp multiply-accumulate")
+    ref_add = np.stack([np.stack([O.add(mods[t], want[0][k, t], want[1][k, t]).reshape(-1) for t in range(nt)]) for k in range(2)])
+    eq(ctx.qp_op2(1, level, want[0], want[1]), ref_add, "qp add")
+    gal = pow(5, 3, 2 * N)
+    idx = O.permute_index(gal)
+    eq(ctx.permute(gal, want[0][0]), np.stack([O.permute(idx, r) for r in want[0][0]]), "permute over QP rows")
+    ctx.close()
+
+
 # ---------------------------------------------------------------- BL baseline (scope row 8f-2)
 class BLDevice:
     """oracle_bl.BLOracle's interface over the C ABI: the level-1 evaluator operations hconv_bl.cpp composes
@@ -422,12 +463,22 @@ class CkksDeviceBackend:
     def lv_mod_raise(self, level, row_q0): return self.ctx.lv_mod_raise(level, row_q0)
     def lv_mul_tensor(self, a, b): return self.ctx.lv_mul_tensor(a.shape[1] - 1, a, b)
 
-    def keyswitch(self, key, cx):
+    def _kid(self, key):
         kid = self._ids.get((key.gal, key.level))
         if kid is None:
             kid = self._ids[(key.gal, key.level)] = 1 + len(self._ids)
             self.ctx.swk_load(kid, key.level, key.rows)
-        return self.ctx.keyswitch(kid, key.level, cx)
+        return kid
+
+    def keyswitch(self, key, cx):
+        return self.ctx.keyswitch(self._kid(key), key.level, cx)
+
+    # the extended basis QP: hc_keyswitch_decompose + hc_keyswitch_qp (one decomposition, several keys), hc_mod_down2, hc_qp_op2
+    def keyswitch_qp(self, keys, cx): return self.ctx.keyswitch_qp([self._kid(k) for k in keys], keys[0].level, cx, hoisted=True)
+    def mod_down2(self, level, x): return self.ctx.mod_down2(level, x)
+    def qp_mul(self, a, pt): return self.ctx.qp_op2(0, a.shape[1] - 1 - len(self.ctx.p), a, pt, shared_b=True)
+    def qp_add(self, a, b): return self.ctx.qp_op2(1, a.shape[1] - 1 - len(self.ctx.p), a, b)
+    def qp_mul_acc(self, a, pt, acc): return self.ctx.qp_op2(7, a.shape[1] - 1 - len(self.ctx.p), a, pt, out=acc, shared_b=True)
 
 
 def case_ckks_ops(make_ctx, logN=16, seed=3, levels=((23, 2.0 ** 55), (9, 2.0 ** 30))):

@@ -145,6 +145,12 @@ def test_conv_1024_channels_sparse_tile_local_galois(env):
     pc.case_conv(*env, 1024, norm=16, out_scale=2.0 ** 41)
 
 
+def test_keyswitch_qp_mod_down():
+    """the halves of the key switch (inner product in QP; ModDownSplitNTTPQ) and arithmetic on QP rows: the reference's BSGS linear transform is made of them"""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    pc.case_keyswitch_qp_mod_down(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), lambda Q, P: Oracle(q=Q, p=P))
+
+
 def test_keyswitch_hoisted():
     """one digit decomposition shared by several key switches (RotateHoisted), bit-identical to the plain key switch"""
     subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])

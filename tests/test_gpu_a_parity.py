@@ -457,6 +457,59 @@ def test_evaluate_cheby_vs_reference_trace_on_gpu():
     ctx.close()
 
 
+def test_linear_transform_vs_reference_trace_on_gpu():
+    """ckks.(*evaluator).LinearTransform (MultiplyByDiagMatrixBSGS) on the GPU vs the reference binary: tests/lattigo_lt.py composed from
+    hc_keyswitch_qp, hc_mod_down2, hc_permute and the row operations through the C ABI on the planted input and rotation keys of `gotrace -lt`
+    (tests/golden/ref_trace_lt_5_1.json; CoeffsToSlots' first matrix, level 27): every ModDown input / output and the returned ciphertext"""
+    from optimal_conv_amd import Context
+    import lattigo_lt
+    from test_oracle_pin_keyswitch import ks_inputs
+    from test_oracle_pin_lt import BABY_ID, GIANT_ID, encoded_diagonals
+    from test_oracle_pin_ops import planted_ct
+
+    d = json.load(open(os.path.join(HERE, "golden", "ref_trace_lt_5_1.json")))
+    Q, P, seed, N = d["ks_Q"], d["ks_P"], d["seed"], d["N"]
+    ctx = Context(Q, P)
+
+    class DevO:                                     # the subset of oracle_lib.Oracle that lattigo_lt uses, on the device
+        q, p = list(Q), list(P)
+        def __init__(self): self.N, self.keys = N, {}
+        def permute_index(self, gal): return gal
+        def permute(self, gal, row): return ctx.permute(gal, row).reshape(-1)
+        def mul(self, mod, a, b): return ctx.mul(mod, a, b)
+        def add(self, mod, a, b): return ctx.add(mod, a, b)
+        def mul_scalar(self, mod, a, s): return ctx.mul_const(mod, a, s)
+        def mod_down(self, level, x): return ctx.mod_down2(level, np.stack([x, x]))[0]
+        def keyswitch_qp(self, level, cx, evk):
+            kid = self.keys.get(id(evk))
+            if kid is None:
+                kid = self.keys[id(evk)] = 700 + len(self.keys)
+                ctx.swk_load(kid, level, evk)
+            return ctx.keyswitch_qp([kid], level, cx, hoisted=False)[0]
+
+    ev = d["events"]
+    b, end = ev[0], ev[-1]
+    L = b["level"]
+    ct = planted_ct(seed, 3000 + b["call"], 0, L, Q, N)
+    n1, diags = encoded_diagonals(Oracle(q=Q, p=P), Q, P, L, b["matrix"]["Scale"])
+    keys = {kid: ks_inputs(seed, 0, kid, L, Q, P, N)[1] for kid in (BABY_ID, GIANT_ID)}
+    res, log = lattigo_lt.multiply_by_diag_matrix_bsgs(DevO(), L, ct, diags, n1, 1 << 15, lambda k: keys[BABY_ID if k < n1 else GIANT_ID])
+    want_md = [e for e in ev if e["op"] == "lt.ModDownSplitNTTPQ"]
+    got_md = [g for g in log if g[0] == "ModDown"]
+    assert len(want_md) == len(got_md) == 4
+    for w, g in zip(want_md, got_md):
+        assert w["inQ"]["sha256"] == sha_rows(*g[1]) and w["inP"]["sha256"] == sha_rows(*g[2]) and w["out"]["sha256"] == sha_rows(*g[3])
+    assert [p["sha256"] for p in end["out"]["polys"]] == [sha_rows(*res[0]), sha_rows(*res[1])], "returned ciphertext"
+    ctx.close()
+
+
+def test_keyswitch_qp_mod_down_on_gpu():
+    """hc_keyswitch_qp / hc_mod_down2 / hc_qp_op2 vs the oracle (the pieces of the reference's MultiplyByDiagMatrixBSGS)"""
+    from optimal_conv_amd import Context
+    pc.case_keyswitch_qp_mod_down(lambda Q, P: Context(Q, P), lambda Q, P: Oracle(q=Q, p=P))
+    pc.case_keyswitch_qp_mod_down(lambda Q, P: Context(Q, P), lambda Q, P: Oracle(q=Q, p=P), level=4, alpha=5, nkeys=2)
+
+
 def test_keyswitch_hoisted_on_gpu():
     """hc_keyswitch_decompose + hc_keyswitch_hoisted vs the oracle key switch, several keys on one decomposition"""
     from optimal_conv_amd import Context

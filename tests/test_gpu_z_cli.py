@@ -60,7 +60,7 @@ def test_conv_7_3_cli_sharded_over_8_contexts(tmp_path):
 def check_dft_digests_against_reference(path):
     """HCONV_DFT_DIGESTS: the host's CoeffsToSlots / SlotsToCoeffs diagonals of parameter set [6] against what the reference binary
     hands to and gets from its encoder (tests/golden/ref_trace_diag_5_1.json, gotrace -diag): all 93 CoeffsToSlots value vectors AND
-    their encoded polynomials (NTT, Montgomery form, 25..28 limbs) and all 158 SlotsToCoeffs value vectors (the reference encodes
+    their encoded polynomials mod Q (NTT, Montgomery form, 25..28 limbs) and mod P (5 limbs) and all 158 SlotsToCoeffs value vectors (the reference encodes
     those 12 levels higher than it uses them, so only the values compare), with the reference's baby-step sizes N1."""
     import json
     ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_trace_diag_5_1.json")))
@@ -79,7 +79,7 @@ def check_dft_digests_against_reference(path):
         r = ref_d[m].get(e["values"])
         assert r is not None, f"diagonal {e['matrix']}[{e['k']}]: value vector differs from the reference's"
         if m < 4:
-            assert (e["level"], e["scale"]) == (r["level"], r["scale"]) and e["mQ"] == r["mQ"], f"encoded diagonal {e['matrix']}[{e['k']}] differs"
+            assert (e["level"], e["scale"]) == (r["level"], r["scale"]) and e["mQ"] == r["mQ"] and e["mP"] == r["mP"], f"encoded diagonal {e['matrix']}[{e['k']}] differs"
         seen[m].add(e["values"])
     assert [len(seen[m]) for m in (0, 1, 2, 3, 7, 8, 9)] == [16, 31, 31, 15, 63, 63, 32]
 

@@ -145,7 +145,7 @@ def test_chain_follows_the_reference_flow_level_for_level_and_scale_for_scale():
             return r
         setattr(obj, name, g)
     depth = [0]
-    for name, label in (("mod_raise", "modUp"), ("linear_transform", "LinearTransform"), ("rescale_to", "Rescale"), ("eval_poly", "EvaluatePoly"), ("mul_const_float", "MultByConst")):
+    for name, label in (("mod_raise", "modUp"), ("linear_transform_qp", "LinearTransform"), ("rescale_to", "Rescale"), ("eval_poly", "EvaluatePoly"), ("mul_const_float", "MultByConst")):
         wrap(C, name, label)
     orig = lattigo_poly.evaluate_cheby
     def cheby(*a, **k):
@@ -163,3 +163,19 @@ def test_chain_follows_the_reference_flow_level_for_level_and_scale_for_scale():
     assert (out.level, out.scale) == (1, 1073741823.9892578)         # what the reference hands to the next convolution
     # the reference rescales both halves' results one after the other where this chain finishes one half before the other: compare as multisets per stage
     assert sorted(got) == sorted(want), (len(got), len(want))
+
+
+def test_linear_transform_qp_equals_the_pinned_restatement(C):
+    """oracle_ckks.Ckks.linear_transform_qp (what the chain runs, on any backend) against tests/lattigo_lt.py (the bare-oracle restatement that
+    reproduces the reference binary's LinearTransform checkpoint by checkpoint, tests/test_oracle_pin_lt.py): same diagonals, same keys -> same residues"""
+    import lattigo_lt
+    btp = ck.Bootstrapper(C)
+    G, n1 = btp.cts[0], btp.cts_n1[0]
+    L = 6
+    u = np.random.default_rng(9).uniform(-1, 1, C.n) + 0j
+    ct = C.encrypt_slots(u, L, 2.0 ** 40, seed=13)
+    got = C.linear_transform_qp(ct, G, float(C.Q[L]), n1)
+    pts = {k: C.encode_ntt_qp(np.roll(G[k], (k // n1) * n1), L, float(C.Q[L])) for k in G}
+    want, _ = lattigo_lt.multiply_by_diag_matrix_bsgs(C.O, L, ct.rows, pts, n1, C.n, lambda k: C.key(C.gal_rot(k), L).rows)
+    assert np.array_equal(got.rows, want)
+    assert _err(C, got, sum(np.roll(u, -k) * G[k] for k in G)) < 1e-5      # and it is the matrix-vector product
