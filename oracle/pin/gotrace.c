@@ -589,6 +589,16 @@ static flow_t g_flow[] = {
   {"main.evalConv_BNRelu_new",  0x53d440, {NA, NA, NA},          {NA, NA},              {NA, NA},  {NA, NA},  NA,        {NA, NA},              NA},
 };
 static int g_flow_on = 0, g_flow_mode = 0, g_flow_depth = 0;
+/* -chain: -flow plus planted data and digests, end to end: the input of BootstrappConv_CtoS is planted (SEED_OPIN(4000, 0, poly, limb)), every
+ * switching key is planted by the KIND of key switch that reads it - SwitchKeysInPlace (relinearisation, conjugation): id CH_SWITCH_ID,
+ * KeyswitchHoistedNoModDown (baby steps): LT_BABY_ID, SwitchKeysInPlaceNoModDown (giant steps): LT_GIANT_ID - and the results of
+ * BootstrappConv_CtoS, CoeffsToSlots, evaluateSine, SlotsToCoeffs and the Rescale behind it are digested. */
+#define CH_SWITCH_ID 42
+static int g_chain = 0;
+static void lt_plant_key(uint64_t level, uint64_t evk, int id);
+static void on_ch_switch(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_flow_on) return; lt_plant_key(rd64(r->rsp + 0x10), rd64(r->rsp + 0x20), CH_SWITCH_ID); }
+static void on_ch_baby(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_flow_on) return; lt_plant_key(rd64(r->rsp + 0x10), rd64(r->rsp + 0x48), 40); }
+static void on_ch_giant(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_flow_on) return; lt_plant_key(rd64(r->rsp + 0x10), rd64(r->rsp + 0x20), 41); }
 static uint64_t post_check(uint64_t fn) {            /* first instruction behind Go's stack check (function start if it has none) */
     uint8_t b[40]; rd(fn, b, sizeof b);
     if (!(b[0] == 0x64 && b[1] == 0x48 && b[2] == 0x8b)) return fn;
@@ -617,6 +627,16 @@ static void ret_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; f
     if (u->out_arg) flow_ct("out", 0, u->out_arg);
     for (int i = 0; i < 2; i++) if (f->out_res[i] != NA) flow_ct("res", i, rd64(E + (uint64_t)f->out_res[i]));
     if (f->out_slice != NA) { uint64_t p = rd64(E + (uint64_t)f->out_slice), n = rd64(E + (uint64_t)f->out_slice + 8); for (uint64_t i = 0; i < n && i < 2; i++) flow_ct("res", (int)i, rd64(p + 8 * i)); }
+    if (g_chain) {
+        const int want = !strcmp(f->name, "BootstrappConv_CtoS") || !strcmp(f->name, "CoeffsToSlots") || !strcmp(f->name, "evaluateSine") || !strcmp(f->name, "SlotsToCoeffs") ||
+                         !strcmp(f->name, "LinearTransform") || !strcmp(f->name, "ConjugateNew") || !strcmp(f->name, "modUp") || !strcmp(f->name, "EvaluateCheby") || !strcmp(f->name, "EvaluatePoly") ||
+                         (!strcmp(f->name, "Rescale") && u->depth <= 2) || (!strcmp(f->name, "MultByConst") && u->depth <= 1) || (!strcmp(f->name, "mulRelin") && u->depth <= 1);
+        if (want) {
+            if (u->out_arg && plausible_ct(u->out_arg)) emit_ct("digest_out", u->out_arg);
+            for (int i = 0; i < 2; i++) if (f->out_res[i] != NA) { uint64_t c = rd64(E + (uint64_t)f->out_res[i]); char key[16]; snprintf(key, sizeof key, "digest_res%d", i); if (plausible_ct(c)) emit_ct(key, c); }
+            if (f->out_slice != NA) { uint64_t p = rd64(E + (uint64_t)f->out_slice), n = rd64(E + (uint64_t)f->out_slice + 8); if (n && plausible_ct(rd64(p))) emit_ct("digest_res0", rd64(p)); }
+        }
+    }
     emit_end(); g_flow_depth = u->depth;
     if (!strcmp(f->name, "main.evalConv_BNRelu_new")) flow_done(); }
 static void on_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; flow_t *f = ud;
@@ -624,7 +644,8 @@ static void on_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; fl
     if (!g_flow_on) {                                   /* the enclosing layer function is hooked from its entry so that its return ends the run */
         if (!strcmp(f->name, "main.evalConv_BNRelu_new")) { flowret_t *u0 = &g_flowret[g_flowret_i++ % MAXFLOWRET]; u0->f = f; u0->depth = 0; u0->out_arg = 0; hook_return(r, ret_flow, u0); return; }
         if (strcmp(f->name, "BootstrappConv_CtoS")) return;
-        g_flow_on = 1; g_flow_depth = 1; }
+        g_flow_on = 1; g_flow_depth = 1;
+        if (g_chain) { uint64_t ct = rd64(r->rsp + 0x10); if (poly_limbs(ct_poly(ct, 0)) != 1) { fprintf(stderr, "-chain expects a level-0 input\n"); exit(3); } plant_ct(ct, 4000, 0); } }
     uint64_t E = r->rsp;
     emit_begin("call"); fprintf(g_out, ", \"fn\": \"%s\", \"depth\": %d", f->name, g_flow_depth);
     for (int i = 0; i < 3; i++) if (f->in_ct[i] != NA) flow_ct("in", i, rd64(E + (uint64_t)f->in_ct[i]));
@@ -867,6 +888,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[ai], "-diag") && ai + 1 < argc) g_diag_max = atoi(argv[++ai]);          /* digest this many encoded DFT diagonals */
         else if (!strcmp(argv[ai], "-dump") && ai + 1 < argc) { g_dump = fopen(argv[++ai], "wb"); if (!g_dump) { perror("dump"); return 2; } }
         else if (!strcmp(argv[ai], "-flow")) g_flow_mode = 1;
+        else if (!strcmp(argv[ai], "-chain")) { g_flow_mode = 1; g_chain = 1; }
         else if (!strcmp(argv[ai], "-lt") && ai + 1 < argc) g_lt_max = atoi(argv[++ai]);               /* trace this many LinearTransform calls (planted input and rotation keys) */
         else if (!strcmp(argv[ai], "-keep-bl")) g_skip_bl = 0;
         else if (!strcmp(argv[ai], "-noplant")) g_noplant = 1;
@@ -905,6 +927,7 @@ int main(int argc, char **argv) {
     fprintf(g_out, "], \"ks_P\": ["); for (int i = 0; i < g_nP; i++) fprintf(g_out, "%s%lu", i ? ", " : "", g_Pm[i]);
     fprintf(g_out, "],\n \"events\": [");
     if (g_flow_mode) for (size_t i = 0; i < sizeof g_flow / sizeof g_flow[0]; i++) bp_add(post_check(g_flow[i].fn), on_flow, &g_flow[i]);
+    if (g_chain) { bp_add(post_check(0x4fdd40), on_ch_switch, NULL); bp_add(post_check(0x4ff060), on_ch_baby, NULL); bp_add(post_check(0x4fe660), on_ch_giant, NULL); }
     if (g_flow_mode) goto hooks_done;          /* the flow hooks share addresses with the ones below (the first handler of an address wins) */
     bp_add(A_CONV_THEN_PACK, on_ctp, NULL);
     bp_add(A_ENCODECOEFFS, on_encode, NULL);

@@ -1,6 +1,7 @@
-"""oracle/pin/make_fixtures.sh helper: trace_flow_5_1.json (gotrace -flow, in the current directory) -> tests/golden/ref_flow_5_1.json (argv[1])"""
+"""oracle/pin/make_fixtures.sh helper: a gotrace -flow / -chain trace (argv[2], default trace_flow_5_1.json in the current directory) ->
+tests/golden/ref_flow_5_1.json / ref_trace_chain_5_1.json (argv[1]); -chain traces carry planted-data digests, kept as "digests"""
 import json, re, sys, struct
-t = open('trace_flow_5_1.json').read()
+t = open(sys.argv[2] if len(sys.argv) > 2 else 'trace_flow_5_1.json').read()
 t = re.sub(r'-?nan', 'null', t); t = re.sub(r'(?<![\w.])-?inf', 'null', t)
 d = json.loads(t)
 TYPES = {5704224: "float64", 5704032: "complex128", 5706272: "int", 5708320: "uint64"}
@@ -36,5 +37,8 @@ for e in d["events"]:
         if ev is not None:
             res = [e[k] for k in ("out0", "res0", "res1") if e.get(k)]
             ev["out"] = [[c["level"], c["scale"], c["degree"]] for c in res]
-json.dump({"argv": d["argv"], "note": "gotrace -flow over `convReLU 5 1 1`: every evaluator call from the entry of BootstrappConv_CtoS to the return of evalConv_BNRelu_new; [level, scale, degree] of ciphertext arguments and results; nothing planted, no digests (the run's keys are random); the insides of EvaluatePoly / EvaluateCheby are in ref_trace_poly_5_1 / ref_trace_cheby_5_1", "events": out}, open(sys.argv[1], "w"), indent=0)
+            dg = [e[k] for k in ("digest_out", "digest_res0", "digest_res1") if e.get(k)]
+            if dg: ev["digests"] = [{"level": c["level"], "scale": c["scale"], "polys": [p["sha256"] for p in c["polys"]]} for c in dg]
+extra = {k: d[k] for k in ("seed", "N", "ks_Q", "ks_P") if k in d}
+json.dump({**extra, "argv": d["argv"], "note": "gotrace -flow over `convReLU 5 1 1`: every evaluator call from the entry of BootstrappConv_CtoS to the return of evalConv_BNRelu_new; [level, scale, degree] of ciphertext arguments and results; nothing planted, no digests (the run's keys are random); the insides of EvaluatePoly / EvaluateCheby are in ref_trace_poly_5_1 / ref_trace_cheby_5_1", "events": out}, open(sys.argv[1], "w"), indent=0)
 print(len(out))

@@ -1,0 +1,75 @@
+"""Replays the reference's convReLU tail (BootstrappConv_CtoS -> evalReLU -> keep_ctxt -> SlotsToCoeffs -> Rescale) on the planted data of
+`gotrace -chain` (tests/golden/ref_trace_chain_5_1.json) with tests/oracle_ckks.py's chain on any residue backend, and compares the SHA-256
+of every recorded ciphertext. Used by tests/test_oracle_pin_chain.py (oracle backend) and tests/test_gpu_a_parity.py (device backend)."""
+import json
+import os
+
+import numpy as np
+
+import oracle_ckks as ck
+from oracle_lib import sha_rows
+from test_oracle_pin_keyswitch import ks_inputs
+from test_oracle_pin_ops import planted_ct
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TRACE = os.path.join(HERE, "golden", "ref_trace_chain_5_1.json")
+# SwitchKeysInPlace (relinearisation, conjugation) calls SwitchKeysInPlaceNoModDown in the fork, so the tracer's giant-step hook plants LAST on
+# those keys too: both kinds hold id 41; the hoisted baby-step keys hold id 40
+KIND_ID = {"switch": 41, "baby": 40, "giant": 41}
+
+
+def digests(ct):
+    return [sha_rows(*ct.rows[0]), sha_rows(*ct.rows[1])]
+
+
+def replay(backend_factory=None, k=5, i_batch=1):
+    """returns (checkpoints compared, trace); raises AssertionError on the first difference"""
+    import golden.gen_conv_csv as gen
+    d = json.load(open(TRACE))
+    Q, P, seed, N = d["ks_Q"], d["ks_P"], d["seed"], d["N"]
+    ev = d["events"]
+    C = ck.Ckks(logN=16)
+    if backend_factory is not None:
+        C.be = backend_factory(C)
+    rows_cache = {}
+    def key_source(kind, gal, level):
+        ident = (kind, level)                       # the tracer plants by kind only: every key of a kind holds the same rows
+        if ident not in rows_cache:
+            rows_cache[ident] = ks_inputs(seed, 0, KIND_ID[kind], level, Q, P, N)[1]
+        return rows_cache[ident]
+    C.key_source = key_source
+    first = ev[0]
+    assert first["fn"] == "BootstrappConv_CtoS"
+    ct = ck.Ct(planted_ct(seed, 4000, 0, 0, Q, N), first["in"][0][1])
+    btp = ck.Bootstrapper(C)
+    want = {e["fn"]: e for e in ev if "digests" in e and e["fn"] in ("BootstrappConv_CtoS", "SlotsToCoeffs")}
+    final = [e for e in ev if e["fn"] == "Rescale" and "digests" in e][-1]
+    n = 0
+    boots = btp.ctos(ct)
+    for got, w in zip(boots, want["BootstrappConv_CtoS"]["digests"]):
+        assert (got.level, got.scale) == (w["level"], w["scale"]) and digests(got) == w["polys"], "BootstrappConv_CtoS result"
+        n += 1
+    B, W = gen.make_case(k, i_batch, 0)[:2]
+    kp = W - k // 2                                   # set_Variables (eval.go:13-54): kp_wid = raw_in_wid
+    keep = []
+    for ul in range(2):
+        r = ck.eval_relu(C, boots[ul], 0.0)          # alpha = 0, pow = 4 (test.go:22)
+        r = C.mul_const_int(r, 1 << 4)
+        keep.append(ck.keep_ctxt(C, r, ck.gen_keep_vec(C.N // 2, W, kp, ul)))
+    C_stoc_in = keep
+    # SlotsToCoeffs' own result (before the Rescale behind it) is the scale-2^150 ciphertext: reproduce the two steps separately
+    ctx = C.add(C_stoc_in[0], C.mul_by_i(C_stoc_in[1]))
+    sc = float(C.Q[3]) ** 0.5 if False else None
+    import math
+    s1 = math.sqrt(float(C.Q[btp.stc_top]))
+    for M, n1, s_pt in zip(btp.stc, btp.stc_n1, (s1, s1, 2.0 ** 30)):
+        s_in = ctx.scale
+        ctx = C.rescale_to(C.linear_transform_qp(ctx, M, s_pt, n1), s_in)
+    w = want["SlotsToCoeffs"]["digests"][0]
+    assert (ctx.level, ctx.scale) == (w["level"], w["scale"]) and digests(ctx) == w["polys"], "SlotsToCoeffs result"
+    n += 1
+    out = C.rescale_to(ctx, 2.0 ** 30)
+    w = final["digests"][0]
+    assert (out.level, out.scale) == (w["level"], w["scale"]) and digests(out) == w["polys"], "the ciphertext the layer hands on"
+    n += 1
+    return n, d

@@ -204,15 +204,22 @@ class Ckks:
         self.seed = seed
         self.sk = self.O.gen_sk(seed, h)
         self.keys = {}
+        self.key_source = None
         self._mono_i = {}
         self.counters = {"keyswitch": 0, "mul_relin": 0, "rotate": 0, "rescale": 0}
 
     # ---- keys
-    def key(self, gal, level):
-        k = self.keys.get((gal, level))
+    def key(self, gal, level, kind="switch"):
+        """kind: which key switch reads the key - "switch" (SwitchKeysInPlace: relinearisation, conjugation, plain rotations), "baby" /
+        "giant" (the hoisted and the second key switch of a linear transform). Real keys do not depend on it; `key_source(kind, gal, level)`
+        (tests that replay a reference trace: the tracer plants key rows by kind) may."""
+        ident = (gal, level) if self.key_source is None else (gal, level, kind)
+        k = self.keys.get(ident)
         if k is None:
-            k = SwitchingKey(gal, level, self.O.gen_swk(self.sk, gal, level, 7000003 * self.seed + 131 * gal + level))
-            self.keys[(gal, level)] = k
+            rows = self.O.gen_swk(self.sk, gal, level, 7000003 * self.seed + 131 * gal + level) if self.key_source is None else self.key_source(kind, gal, level)
+            k = SwitchingKey(gal, level, rows)
+            k.kind = kind if self.key_source is not None else ""
+            self.keys[ident] = k
         return k
 
     def gal_rot(self, k): return pow(5, k % self.M, self.M)
@@ -480,7 +487,7 @@ class Ckks:
             Pbig *= p
         pc0 = be.lv_mul_const(c0, [Pbig % self.Q[l] for l in range(nl)])
         babies = sorted({i for js in index.values() for i in js if i})
-        accs = be.keyswitch_qp([self.key(self.gal_rot(i), L) for i in babies], c1) if babies else []
+        accs = be.keyswitch_qp([self.key(self.gal_rot(i), L, "baby") for i in babies], c1) if babies else []
         self.counters["keyswitch"] += len(babies)
         rot = {}
         for i, acc in zip(babies, accs):
@@ -502,7 +509,7 @@ class Ckks:
                 ptq = pts[n1 * j][:nl]
                 a = np.stack([be.lv_add(a[k], be.lv_mul(ct.rows[k], ptq)) for k in range(2)])
             g = self.gal_rot(n1 * j)
-            e = be.keyswitch_qp([self.key(g, L)], np.ascontiguousarray(a[1]))[0]
+            e = be.keyswitch_qp([self.key(g, L, "giant")], np.ascontiguousarray(a[1]))[0]
             self.counters["keyswitch"] += 1
             t = be.permute(g, a[0])
             res[0] = t if res[0] is None else be.lv_add(res[0], t)

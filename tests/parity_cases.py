@@ -464,9 +464,10 @@ class CkksDeviceBackend:
     def lv_mul_tensor(self, a, b): return self.ctx.lv_mul_tensor(a.shape[1] - 1, a, b)
 
     def _kid(self, key):
-        kid = self._ids.get((key.gal, key.level))
+        ident = (key.gal, key.level) if not getattr(key, "kind", "") else (key.gal, key.level, key.kind)
+        kid = self._ids.get(ident)
         if kid is None:
-            kid = self._ids[(key.gal, key.level)] = 1 + len(self._ids)
+            kid = self._ids[ident] = 1 + len(self._ids)
             self.ctx.swk_load(kid, key.level, key.rows)
         return kid
 

@@ -1,0 +1,15 @@
+"""The whole convReLU tail against the reference binary, end to end: `gotrace -chain` planted the input of BootstrappConv_CtoS and every
+switching key (by the kind of key switch that reads it) in a `convReLU 5 1 1` run of /root/reference/test_run and recorded the SHA-256 of the
+ciphertexts BootstrappConv_CtoS returns (two, level 14), of SlotsToCoeffs' result and of the ciphertext the layer hands on after the last Rescale
+(tests/golden/ref_trace_chain_5_1.json). tests/oracle_ckks.py's chain -- modUp, four BSGS linear transforms in the extended basis, conjugation,
+the sine (EvaluateCheby + double angles), MultByConst, three EvaluatePoly + the product of evalReLU, MulByPow2, the keep mask, three more linear
+transforms, two rescales: 207 key switches, 28 levels -- replayed on the oracle must arrive at the SAME residues."""
+import pytest
+
+import chain_replay
+
+
+@pytest.mark.slow
+def test_convrelu_tail_end_to_end_equals_the_reference_binary():
+    n, _ = chain_replay.replay()
+    assert n == 4
