@@ -61,3 +61,20 @@ python3 "$REPO/oracle/pin/mk_flow_fixture.py" "$REPO/tests/golden/ref_flow_5_1.j
 "$SCRATCH/gotrace" -cheby 1 -Q $Q -P $P -nq-full 28 -o trace_cheby_5_1.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_cheby.txt 2>&1
 python3 "$REPO/oracle/pin/mk_cheby_fixture.py" "$REPO/tests/golden/ref_trace_cheby_5_1.json"
 python3 "$REPO/tools/gen_sine_table.py"      # host/hconv_sine_coeffs.hpp from the fixture
+# LinearTransform (MultiplyByDiagMatrixBSGS) on a planted input and planted rotation keys, and the whole convReLU tail end to end
+"$SCRATCH/gotrace" -lt 1 -Q $Q -P $P -nq-full 28 -o trace_lt_5_1.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_lt.txt 2>&1
+python3 - "$REPO/tests/golden/ref_trace_lt_5_1.json" <<'PY'
+import json, sys
+d = json.load(open("trace_lt_5_1.json"))
+ev = [e for e in d["events"] if e["op"].startswith("lt.") or e["op"].startswith("LinearTransform")]
+for e in ev:
+    for k, v in list(e.items()):
+        if isinstance(v, dict) and "head" in v: v.pop("head")
+        if isinstance(v, dict) and "polys" in v:
+            for p in v["polys"]: p.pop("head", None)
+d["events"] = ev
+d["note"] = "gotrace -lt 1 over `convReLU 5 1 1`: the first LinearTransform of CoeffsToSlots (level 27, 16 diagonals, N1 = 16384) on a planted input; every baby-step rotation key planted as key id 40, every giant-step key as id 41 (SEED_KSEVK); the diagonals are the run's own (ref_trace_diag_5_1.json matrix 0)"
+json.dump(d, open(sys.argv[1], "w"), indent=0)
+PY
+"$SCRATCH/gotrace" -chain -Q $Q -P $P -nq-full 28 -o trace_chain_5_1.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_chain.txt 2>&1
+python3 "$REPO/oracle/pin/mk_flow_fixture.py" "$REPO/tests/golden/ref_trace_chain_5_1.json" trace_chain_5_1.json

@@ -457,6 +457,21 @@ def test_evaluate_cheby_vs_reference_trace_on_gpu():
     ctx.close()
 
 
+def test_convrelu_tail_end_to_end_vs_reference_trace_on_gpu():
+    """the whole convReLU tail on the GPU against the reference binary: tests/chain_replay.py (planted input and keys of `gotrace -chain`,
+    tests/golden/ref_trace_chain_5_1.json) with every residue operation of the chain through the C ABI - BootstrappConv_CtoS' two results,
+    SlotsToCoeffs' result and the ciphertext the layer hands on must have the binary's SHA-256"""
+    from optimal_conv_amd import Context
+    import chain_replay
+    holder = {}
+    def backend(C):
+        holder["ctx"] = Context(C.Q, C.P)
+        return pc.CkksDeviceBackend(holder["ctx"])
+    n, _ = chain_replay.replay(backend)
+    assert n == 4
+    holder["ctx"].close()
+
+
 def test_linear_transform_vs_reference_trace_on_gpu():
     """ckks.(*evaluator).LinearTransform (MultiplyByDiagMatrixBSGS) on the GPU vs the reference binary: tests/lattigo_lt.py composed from
     hc_keyswitch_qp, hc_mod_down2, hc_permute and the row operations through the C ABI on the planted input and rotation keys of `gotrace -lt`
