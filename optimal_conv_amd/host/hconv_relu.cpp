@@ -121,10 +121,35 @@ struct Boot {
     int modidx(int T, int nl) const { return T < nl ? T : NQ + (T - nl); }
 
     // ---------------- keys (rlwe.GenSwitchingKey restricted to the limbs a level-`level` key switch reads)
-    uint64_t key(uint64_t gal, int level) {
-        auto it = key_ids.find({gal, level});
+    // kind: which key switch reads the key (0: SwitchKeysInPlace - relinearisation, conjugation, plain rotations; 1: the hoisted baby steps of a
+    // linear transform; 2: its giant steps). Real keys do not depend on it. HCONV_CHAIN_REPLAY=<seed> (tests only): no key is generated;
+    // every key holds the rows `gotrace -chain` planted into the reference binary for its kind (oracle/pin/gotrace.c: SEED_KSEVK with id 40 for
+    // the baby steps, 41 for everything else), so that the chain can be compared with the binary's digests (tests/test_gpu_z_cli.py).
+    uint64_t replay_seed = 0;
+    std::vector<uint64_t> replay_rows; int replay_rows_id = -1, replay_rows_level = -1;
+    static uint64_t splitmix_at(uint64_t seed, uint64_t i) { uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+    uint64_t key(uint64_t gal, int level, int kind = 0) {
+        const uint64_t ident = replay_seed ? (gal | ((uint64_t)(kind == 1 ? 1 : 2) << 40)) : gal;
+        auto it = key_ids.find({ident, level});
         if (it != key_ids.end()) return it->second;
         const int alpha = (int)P.size(), nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
+        if (replay_seed) {
+            const int pid = kind == 1 ? 40 : 41;
+            if (replay_rows_id != pid || replay_rows_level != level) {
+                replay_rows.resize((size_t)beta * 2 * nt * N);
+                for (int d = 0; d < beta; d++) for (int k = 0; k < 2; k++) for (int T = 0; T < nt; T++) {
+                    const uint64_t q = modulus(T, nl), li = T < nl ? (uint64_t)T : 32 + (uint64_t)(T - nl);
+                    const uint64_t sd = replay_seed + ((5ull << 32) | (uint64_t)((((pid * 32 + d) * 2 + k) * 64) + (int)li));
+                    uint64_t *row = replay_rows.data() + (((size_t)d * 2 + k) * nt + T) * N;
+                    for (int j = 0; j < N; j++) row[j] = splitmix_at(sd, (uint64_t)j) % q;
+                }
+                replay_rows_id = pid; replay_rows_level = level;
+            }
+            const uint64_t id = 1 + key_ids.size();
+            HCR(hc_swk_load(hc, id, level, replay_rows.data()));
+            key_ids[{ident, level}] = id; n_keys++;
+            return id;
+        }
         // s_out: the key the result is under. Rotation/conjugation by gal: automorphism by gal^-1 of s; relinearisation: s.
         std::vector<int64_t> sko(N, 0);
         if (gal == 0) sko = sk;
@@ -164,7 +189,7 @@ struct Boot {
         const uint64_t id = 1 + key_ids.size();
         HCR(hc_swk_load(hc, id, level, host.data()));
         HCR(hc_free(hc, d));
-        key_ids[{gal, level}] = id; n_keys++;
+        key_ids[{ident, level}] = id; n_keys++;
         return id;
     }
     uint64_t gal_rot(int k) const { const uint64_t twoN = 2ull * N; uint64_t e = (uint64_t)(int64_t)k & (twoN - 1), r = 1, b = 5; while (e) { if (e & 1) r = (r * b) % twoN; b = (b * b) % twoN; e >>= 1; } return r; }
@@ -507,8 +532,8 @@ struct Boot {
         const int L = ct.level, nl = L + 1, np = (int)P.size(), nt = nl + np; const size_t zs = (size_t)nt * N;
         std::map<int, std::vector<int>> index; std::set<int> babies;
         for (auto &g : lt.giant) for (auto &b : g.second) { index[g.first / lt.n1].push_back(b.first); if (b.first) babies.insert(b.first); }
-        for (int b : babies) key(gal_rot(b), L);                                    // key generation (if any) before a decomposition is taken
-        for (auto &g : lt.giant) if (g.first) key(gal_rot(g.first), L);
+        for (int b : babies) key(gal_rot(b), L, 1);                                 // key generation (if any) before a decomposition is taken
+        for (auto &g : lt.giant) if (g.first) key(gal_rot(g.first), L, 2);
         std::vector<uint64_t> pmod((size_t)nl), zeros((size_t)nl, 0);
         for (int l = 0; l < nl; l++) { uint64_t r = 1; for (uint64_t pj : P) r = mulmod(r, pj % Q[(size_t)l], Q[(size_t)l]); pmod[(size_t)l] = r; }
         auto pc0 = block(); HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), pmod.data(), pc0.get()));                       // P * c0
@@ -518,7 +543,7 @@ struct Boot {
             auto acc = block_qp2();
             for (int b : babies) {
                 const uint64_t gal = gal_rot(b);
-                HCR(hc_keyswitch_qp(hc, key(gal, L), L, ct.p[1].get(), acc.get(), 1)); n_keyswitch++;
+                HCR(hc_keyswitch_qp(hc, key(gal, L, 1), L, ct.p[1].get(), acc.get(), 1)); n_keyswitch++;
                 HCR(hc_lv_add(hc, L, acc.get(), pc0.get(), acc.get()));                                                  // the Q rows of the first component
                 auto r = block_qp2(); HCR(hc_permute(hc, gal, acc.get(), r.get(), 2 * nt));
                 rot[b] = r;
@@ -541,7 +566,7 @@ struct Boot {
             else { HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), zeros.data(), a0.get())); HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), zeros.data(), a1.get())); }
             if (row.count(0)) { const uint64_t *pt = row.at(0).p.get(); HCR(hc_lv_op2(hc, HC_LV_MUL_ACC, L, ct.p[0].get(), ct.p[1].get(), pt, pt, a0.get(), a1.get(), nullptr)); }
             auto e = block_qp2();
-            HCR(hc_keyswitch_qp(hc, key(gal, L), L, a1.get(), e.get(), 0)); n_keyswitch++;
+            HCR(hc_keyswitch_qp(hc, key(gal, L, 2), L, a1.get(), e.get(), 0)); n_keyswitch++;
             { auto t = block(); HCR(hc_permute(hc, gal, a0.get(), t.get(), nl)); add_to_res(0, t); }
             if (!haveB) { HCR(hc_permute(hc, gal, e.get(), B.get(), 2 * nt)); haveB = true; }
             else { auto t = block_qp2(); HCR(hc_permute(hc, gal, e.get(), t.get(), 2 * nt)); HCR(hc_qp_op2(hc, HC_LV_ADD, L, B.get(), B.get() + zs, t.get(), t.get() + zs, B.get(), B.get() + zs)); }
@@ -774,6 +799,7 @@ struct Boot {
     // ---------------- the bootstrapper
     void build(const std::vector<int64_t> &sk_in, const Seed256 &seed, int device, int chain_ = 6) {
         chain = chain_;
+        if (chain == 6 && getenv("HCONV_CHAIN_REPLAY") && *getenv("HCONV_CHAIN_REPLAY")) { replay_seed = strtoull(getenv("HCONV_CHAIN_REPLAY"), nullptr, 0); fprintf(stderr, "hconv: HCONV_CHAIN_REPLAY: planted keys and input (test mode; results are meaningless as ciphertexts)\n"); }
         Q = chain == 7 ? PARAMS7_Q : PARAMS6_Q; P = PARAMS6_P; NQ = (int)Q.size(); sk = sk_in; rng.reseed(seed, 0xB007B007ull + (uint64_t)chain_);
         if (chain == 7) { LV_STC_TOP = 15; stc_scale_top = stc_scale_last = 1099511627776.0; lv_relin_lo = 2; sine_out_scale = 36028797018963968.0; }
         else { LV_STC_TOP = 3; stc_scale_top = sqrt((double)Q[3]); stc_scale_last = 1073741824.0; lv_relin_lo = LV_RELU_TOP - 11; }
@@ -835,8 +861,8 @@ struct Boot {
         // LinearTransform finds nothing to drop); full slots on parameter set [6] do the same, the other bootstrappers keep the split above
         S.stc.push_back(plan(G.back(), ls == 0 && chain == 6 ? LV_STC_TOP : LV_STC_TOP - 1, stc_scale_last, ls == 0, stc_tag[2]));
         for (auto *grp : {&S.cts, &S.stc}) for (auto &lt : *grp) for (auto &g : lt.giant) {
-            if (g.first) key(gal_rot(g.first), lt.level);
-            for (auto &b : g.second) if (b.first) key(gal_rot(b.first), lt.level);
+            if (g.first) key(gal_rot(g.first), lt.level, 2);
+            for (auto &b : g.second) if (b.first) key(gal_rot(b.first), lt.level, 1);
         }
         for (int j = 0; j < ls; j++) key(gal_rot(ns << j), LV_CTS_TOP);       // SubSum
         if (ls) key(gal_rot(ns), LV_SINE_TOP);                                 // packing the imaginary half next to the real one
@@ -1066,6 +1092,21 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     // the source as soon as this function returns. Wait for the copy (the stream holds nothing else at this point) so that the hand-over
     // does not depend on how the two contexts' streams happen to be scheduled (cached allocations recycle a freed block at once).
     HCR(hc_sync(hc));
+    auto replay_digest = [&](const char *what, const DCt &c) {      // SHA-256 of each polynomial's rows 0..level, as gotrace's emit_ct
+        std::string line = std::string("replay digest ") + what + " level " + std::to_string(c.level);
+        char sc[40]; snprintf(sc, sizeof sc, " scale %.17g", c.scale); line += sc;
+        for (int d = 0; d <= c.deg; d++) { std::vector<uint64_t> rows((size_t)(c.level + 1) * N); HCR(hc_download(hc, rows.data(), c.p[d].get(), rows.size() * 8)); Sha256 h; h.update(rows.data(), rows.size() * 8); line += " " + h.hex(); }
+        printf("%s\n", line.c_str());
+    };
+    if (B->replay_seed) {                                           // the input gotrace -chain plants at the entry of BootstrappConv_CtoS: SEED_OPIN(4000, 0, poly, limb 0)
+        if (sparse) panic("HCONV_CHAIN_REPLAY covers the full-slot chain only");
+        std::vector<uint64_t> row((size_t)N);
+        for (int k = 0; k < 2; k++) {
+            const uint64_t sd = B->replay_seed + ((6ull << 32) | (uint64_t)((((4000 * 2 + 0) * 4 + k) * 64) + 0));
+            for (int j = 0; j < N; j++) row[(size_t)j] = Boot::splitmix_at(sd, (uint64_t)j) % B->Q[0];
+            HCR(hc_upload(hc, ct.p[k].get(), row.data(), (size_t)N * 8));
+        }
+    }
     const bool prof = getenv("HCONV_PROFILE") && atoi(getenv("HCONV_PROFILE"));
     if (prof) { HCR(hc_set_option(hc, "profile", 1)); hc_profile_get(hc, nullptr, nullptr, nullptr); }
     printf("Bootstrapping... Ours (until CtoS):\n");
@@ -1073,6 +1114,7 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     DCt boots[2]; const int iter = B->ctos(ct, log_sparse, boots);                                     // eval.go:450-461
     HCR(hc_sync(hc));
     printf("Done in %s \n", dur(start).c_str());
+    if (B->replay_seed) for (int ul = 0; ul < iter; ul++) replay_digest(ul ? "ctos1" : "ctos0", boots[ul]);
     start = now();
     for (int ul = 0; ul < iter; ul++) {
         DCt r = evalReLU(B, boots[ul], alpha);                                                        // eval.go:473
@@ -1091,6 +1133,7 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     DCt res = B->stoc(keep[0], iter == 2 ? &keep[1] : nullptr, log_sparse);                              // eval.go:550-561 ; Rescale (564) is a no-op here
     HCR(hc_sync(hc));
     printf("Boot (StoC) Done in %s \n", dur(start).c_str());
+    if (B->replay_seed) replay_digest("final", res);
     if (prof) { profile_dump(B, (kind + " log_sparse " + std::to_string(log_sparse)).c_str()); HCR(hc_set_option(hc, "profile", 0)); }
     BootCiphertext out; out.level = res.level; out.Scale = res.scale;
     { void *v = nullptr; HCR(hc_malloc(hc, (size_t)2 * (res.level + 1) * N * 8, &v)); out.d = (uint64_t *)v; }

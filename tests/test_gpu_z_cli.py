@@ -111,6 +111,26 @@ def test_conv_relu_cli(tmp_path, k, i_batch):
     assert meds[1] >= 10.5 and avgs[1] >= 7.5, txt
 
 
+def test_conv_relu_cli_replays_the_reference_chain(tmp_path):
+    """The PRODUCT path (C++ host + HIP kernels) against the reference binary, end to end: with HCONV_CHAIN_REPLAY=<seed> the CLI's convReLU
+    tail runs on the input and the switching keys `gotrace -chain` planted into /root/reference/test_run (tests/golden/ref_trace_chain_5_1.json)
+    and prints the SHA-256 of BootstrappConv_CtoS' two results and of the ciphertext the layer hands on: they must be the binary's."""
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_trace_chain_5_1.json")))
+    ev = ref["events"]
+    ctos = next(e for e in ev if e["fn"] == "BootstrappConv_CtoS")["digests"]
+    final = [e for e in ev if e["fn"] == "Rescale" and "digests" in e][-1]["digests"][0]
+    gen.write_case(str(tmp_path / "test_conv_data"), 5, 1, 0)
+    out = subprocess.run([CLI, "convReLU", "5", "1", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HCONV_SEED="31", HCONV_CHAIN_REPLAY=str(ref["seed"])))
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = {m.group(1): (int(m.group(2)), float(m.group(3)), m.group(4).split()) for m in re.finditer(r"^replay digest (\S+) level (\d+) scale (\S+) ((?:[0-9a-f]{64} ?)+)$", out.stdout, re.M)}
+    assert set(got) == {"ctos0", "ctos1", "final"}, out.stdout[-2000:]
+    for name, want in (("ctos0", ctos[0]), ("ctos1", ctos[1]), ("final", final)):
+        lv, sc, polys = got[name]
+        assert (lv, sc) == (want["level"], want["scale"]) and polys == want["polys"], f"{name}: the host chain differs from the reference binary"
+
+
 @pytest.mark.parametrize("cf100,wide", [(False, 1), (True, 1), (False, 2), (False, 3)])
 def test_resnet_cli_depth8(tmp_path, cf100, wide):
     """`resnet 3 8 1 1 false` (scope row 8f-3; the reference's depth-8 variant of BASELINE.md config 5): encrypted inference with
