@@ -381,13 +381,13 @@ uint64_t or_basis_extend(const uint64_t *x, const uint64_t *src, int n, uint64_t
  *                    acc[k][limb][N], limbs = Q_0..Q_level then P_0..P_(alpha-1), canonical residues, NTT domain;
  * or_mod_down      = ring.(*FastBasisExtender).ModDownSplitNTTPQ (@4e4c40) on ONE polynomial in that layout: InvNTT of the P limbs, extension
  *                    {P} -> each Q limb, (x_Q - NTT(ext)) * P^-1. */
-void or_keyswitch_qp(const or_ctx *c, int level, const uint64_t *cx, const uint64_t *evk, uint64_t *acc) {
+/* rlwe.(*KeySwitcher).DecomposeNTT: digits[d][T][N] = the d-th digit of cx extended to limb T (Q_0..Q_level, then the P limbs), NTT domain */
+void or_keyswitch_decompose(const or_ctx *c, int level, const uint64_t *cx, uint64_t *digits) {
     const int N = c->N, alpha = c->np, nl = level + 1, nt = nl + alpha;          /* nt = limbs an evk row set covers */
     const int beta = (nl + alpha - 1) / alpha;
     const size_t n = (size_t)N;
     uint64_t *coef = malloc(sizeof(uint64_t) * n * (size_t)nl);                   /* cxInvNTT */
-    uint64_t *c2 = malloc(sizeof(uint64_t) * n), *tmp = malloc(sizeof(uint64_t) * n);
-    memset(acc, 0, sizeof(uint64_t) * n * (size_t)nt * 2);                        /* [k][limb][N] */
+    uint64_t *tmp = malloc(sizeof(uint64_t) * n);
     for (int l = 0; l < nl; l++) or_intt(c, l, cx + (size_t)l * n, coef + (size_t)l * n);
     for (int d = 0; d < beta; d++) {
         const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl, nd = hi - lo;
@@ -395,6 +395,7 @@ void or_keyswitch_qp(const or_ctx *c, int level, const uint64_t *cx, const uint6
         for (int T = 0; T < nt; T++) {
             const int mod = T < nl ? T : c->nq + (T - nl);                         /* ctx modulus index of target limb */
             const or_mod *m = &c->m[mod];
+            uint64_t *c2 = digits + ((size_t)d * (size_t)nt + (size_t)T) * n;
             if (T >= lo && T < hi) memcpy(c2, cx + (size_t)T * n, sizeof(uint64_t) * n);   /* the digit's own limbs: NTT input reused */
             else {
                 if (nd == 1) for (int j = 0; j < N; j++) tmp[j] = coef[(size_t)lo * n + (size_t)j] % m->q;   /* copied residues */
@@ -407,14 +408,31 @@ void or_keyswitch_qp(const or_ctx *c, int level, const uint64_t *cx, const uint6
                 }
                 or_ntt(c, mod, tmp, c2);
             }
-            for (int k = 0; k < 2; k++) {
-                const uint64_t *e = evk + (((size_t)d * 2 + (size_t)k) * (size_t)nt + (size_t)T) * n;
-                uint64_t *a = acc + ((size_t)k * (size_t)nt + (size_t)T) * n;
-                for (int j = 0; j < N; j++) a[j] = addmod(a[j], mred(e[j], c2[j], m->q, m->qinv), m->q);
-            }
         }
     }
-    free(coef); free(c2); free(tmp);
+    free(coef); free(tmp);
+}
+/* rlwe.(*KeySwitcher).KeyswitchHoistedNoModDown: the inner product of a decomposition with one key */
+void or_keyswitch_mac(const or_ctx *c, int level, const uint64_t *digits, const uint64_t *evk, uint64_t *acc) {
+    const int N = c->N, alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
+    const size_t n = (size_t)N;
+    memset(acc, 0, sizeof(uint64_t) * n * (size_t)nt * 2);                        /* [k][limb][N] */
+    for (int d = 0; d < beta; d++) for (int T = 0; T < nt; T++) {
+        const or_mod *m = &c->m[T < nl ? T : c->nq + (T - nl)];
+        const uint64_t *c2 = digits + ((size_t)d * (size_t)nt + (size_t)T) * n;
+        for (int k = 0; k < 2; k++) {
+            const uint64_t *e = evk + (((size_t)d * 2 + (size_t)k) * (size_t)nt + (size_t)T) * n;
+            uint64_t *a = acc + ((size_t)k * (size_t)nt + (size_t)T) * n;
+            for (int j = 0; j < N; j++) a[j] = addmod(a[j], mred(e[j], c2[j], m->q, m->qinv), m->q);
+        }
+    }
+}
+void or_keyswitch_qp(const or_ctx *c, int level, const uint64_t *cx, const uint64_t *evk, uint64_t *acc) {
+    const int nt = level + 1 + c->np, beta = (level + 1 + c->np - 1) / c->np;
+    uint64_t *digits = malloc(sizeof(uint64_t) * (size_t)c->N * (size_t)nt * (size_t)beta);
+    or_keyswitch_decompose(c, level, cx, digits);
+    or_keyswitch_mac(c, level, digits, evk, acc);
+    free(digits);
 }
 void or_mod_down(const or_ctx *c, int level, const uint64_t *x_qp, uint64_t *out) {
     const int N = c->N, alpha = c->np, nl = level + 1;

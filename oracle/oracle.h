@@ -78,6 +78,9 @@ void or_keyswitch(const or_ctx *, int level, const uint64_t *cx, const uint64_t 
 /* the two halves of or_keyswitch (rlwe SwitchKeysInPlaceNoModDown / KeyswitchHoistedNoModDown, ring ModDownSplitNTTPQ):
  * acc = [2][level+1+np][N] in the basis Q_0..Q_level, P_0..P_(np-1); or_mod_down takes ONE such polynomial to [level+1][N] */
 void or_keyswitch_qp(const or_ctx *, int level, const uint64_t *cx, const uint64_t *evk, uint64_t *acc);
+/* or_keyswitch_qp in its own two steps (hoisting: one decomposition, several keys): digits = [beta][level+1+np][N] */
+void or_keyswitch_decompose(const or_ctx *, int level, const uint64_t *cx, uint64_t *digits);
+void or_keyswitch_mac(const or_ctx *, int level, const uint64_t *digits, const uint64_t *evk, uint64_t *acc);
 void or_mod_down(const or_ctx *, int level, const uint64_t *x_qp, uint64_t *out);
 /* the exact fast basis extension both steps use: residues x[0..n) (any representatives) modulo src[0..n) -> modulus t */
 uint64_t or_basis_extend(const uint64_t *x, const uint64_t *src, int n, uint64_t t);

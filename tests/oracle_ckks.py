@@ -63,7 +63,7 @@ class OracleBackend:
 
     # the extended basis QP (rows Q_0..Q_level, then the P limbs): the two halves of the key switch and row-wise arithmetic
     def _qp_mods(self, nt): return list(range(nt - len(self.O.p))) + [len(self.O.q) + j for j in range(len(self.O.p))]
-    def keyswitch_qp(self, keys, cx): return [self.O.keyswitch_qp(k.level, cx, k.rows) for k in keys]       # one decomposition, several keys
+    def keyswitch_qp(self, keys, cx): return self.O.keyswitch_qp_hoisted(keys[0].level, cx, [k.rows for k in keys])      # one decomposition, several keys
     def mod_down2(self, level, x): return np.stack([self.O.mod_down(level, x[0]), self.O.mod_down(level, x[1])])
     def qp_mul(self, a, pt): m = self._qp_mods(a.shape[1]); return np.stack([np.stack([self.O.mul(m[t], a[k, t], pt[t]).reshape(-1) for t in range(len(m))]) for k in range(2)])
     def qp_add(self, a, b): m = self._qp_mods(a.shape[1]); return np.stack([np.stack([self.O.add(m[t], a[k, t], b[k, t]).reshape(-1) for t in range(len(m))]) for k in range(2)])

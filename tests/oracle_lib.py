@@ -67,6 +67,8 @@ def lib():
         L.or_keyswitch.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p, u64p]
         L.or_keyswitch_qp.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p]
         L.or_mod_down.argtypes = [C.c_void_p, C.c_int, u64p, u64p]
+        L.or_keyswitch_decompose.argtypes = [C.c_void_p, C.c_int, u64p, u64p]
+        L.or_keyswitch_mac.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p]
         L.or_basis_extend.restype = C.c_uint64
         L.or_basis_extend.argtypes = [u64p, u64p, C.c_int, C.c_uint64]
         L.or_modup_1p.restype = C.c_uint64
@@ -244,6 +246,20 @@ class Oracle:
         acc = np.empty((2, level + 1 + len(self.p), self.N), dtype=np.uint64)
         self.L.or_keyswitch_qp(self.ctx, level, p64(cx), p64(evk.reshape(-1)), p64(acc))
         return acc
+
+    def keyswitch_qp_hoisted(self, level, cx, evks):
+        """one digit decomposition of cx, the inner product with every key of `evks`: [(2, level+1+np, N), ...]"""
+        cx = np.ascontiguousarray(cx, dtype=np.uint64).reshape(level + 1, self.N)
+        nt = level + 1 + len(self.p)
+        beta = -(-(level + 1) // len(self.p))
+        digits = np.empty((beta, nt, self.N), dtype=np.uint64)
+        self.L.or_keyswitch_decompose(self.ctx, level, p64(cx), p64(digits))
+        outs = []
+        for evk in evks:
+            acc = np.empty((2, nt, self.N), dtype=np.uint64)
+            self.L.or_keyswitch_mac(self.ctx, level, p64(digits), p64(np.ascontiguousarray(evk, dtype=np.uint64).reshape(-1)), p64(acc))
+            outs.append(acc)
+        return outs
 
     def mod_down(self, level, x_qp):
         """ModDownSplitNTTPQ of one polynomial (level+1+np, N) -> (level+1, N)"""
