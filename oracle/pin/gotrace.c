@@ -555,6 +555,7 @@ typedef struct { const char *name; uint64_t fn; int in_ct[3]; int in_iface[2]; i
 static flow_t g_flow[] = {
   /* name                       fn         in_ct (entry rsp +)   operands by iface(data) f64 args   int args   ctOut arg  results (entry rsp +)  []*ct result */
   {"BootstrappConv_CtoS",       0x506800, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  NA,        {0x18, 0x20},          NA},
+  {"Bootstrapp",                0x505ce0, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  NA,        {0x18, NA},            NA},
   {"modUp",                     0x507400, {0x10, NA, NA},        {NA, NA},              {NA, NA},  {NA, NA},  NA,        {0x18, NA},            NA},
   {"CoeffsToSlots",             0x507dc0, {0x08, NA, NA},        {NA, NA},              {NA, NA},  {0x18, NA},NA,        {0x38, 0x40},          NA},
   {"SlotsToCoeffs",             0x508140, {0x08, 0x10, NA},      {NA, NA},              {NA, NA},  {0x20, NA},NA,        {0x40, NA},            NA},
@@ -594,7 +595,7 @@ static int g_flow_on = 0, g_flow_mode = 0, g_flow_depth = 0;
  * KeyswitchHoistedNoModDown (baby steps): LT_BABY_ID, SwitchKeysInPlaceNoModDown (giant steps): LT_GIANT_ID - and the results of
  * BootstrappConv_CtoS, CoeffsToSlots, evaluateSine, SlotsToCoeffs and the Rescale behind it are digested. */
 #define CH_SWITCH_ID 42
-static int g_chain = 0;
+static int g_chain = 0, g_flow_bl = 0;
 static void lt_plant_key(uint64_t level, uint64_t evk, int id);
 static void on_ch_switch(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_flow_on) return; lt_plant_key(rd64(r->rsp + 0x10), rd64(r->rsp + 0x20), CH_SWITCH_ID); }
 static void on_ch_baby(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_flow_on) return; lt_plant_key(rd64(r->rsp + 0x10), rd64(r->rsp + 0x48), 40); }
@@ -638,14 +639,16 @@ static void ret_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; f
         }
     }
     emit_end(); g_flow_depth = u->depth;
-    if (!strcmp(f->name, "main.evalConv_BNRelu_new")) flow_done(); }
+    if (!strcmp(f->name, "main.evalConv_BNRelu_new") || (g_flow_bl && !strcmp(f->name, "Bootstrapp"))) flow_done(); }
 static void on_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; flow_t *f = ud;
     if (!g_flow_mode) return;
     if (!g_flow_on) {                                   /* the enclosing layer function is hooked from its entry so that its return ends the run */
         if (!strcmp(f->name, "main.evalConv_BNRelu_new")) { flowret_t *u0 = &g_flowret[g_flowret_i++ % MAXFLOWRET]; u0->f = f; u0->depth = 0; u0->out_arg = 0; hook_return(r, ret_flow, u0); return; }
+        if (g_flow_bl) { if (strcmp(f->name, "Bootstrapp")) return; g_flow_on = 1; g_flow_depth = 0; goto log_call; }     /* -flow-bl: the stock Bootstrapp of the baseline half, entry to return */
         if (strcmp(f->name, "BootstrappConv_CtoS")) return;
         g_flow_on = 1; g_flow_depth = 1;
         if (g_chain) { uint64_t ct = rd64(r->rsp + 0x10); if (poly_limbs(ct_poly(ct, 0)) != 1) { fprintf(stderr, "-chain expects a level-0 input\n"); exit(3); } plant_ct(ct, 4000, 0); } }
+log_call:;
     uint64_t E = r->rsp;
     emit_begin("call"); fprintf(g_out, ", \"fn\": \"%s\", \"depth\": %d", f->name, g_flow_depth);
     for (int i = 0; i < 3; i++) if (f->in_ct[i] != NA) flow_ct("in", i, rd64(E + (uint64_t)f->in_ct[i]));
@@ -889,6 +892,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[ai], "-dump") && ai + 1 < argc) { g_dump = fopen(argv[++ai], "wb"); if (!g_dump) { perror("dump"); return 2; } }
         else if (!strcmp(argv[ai], "-flow")) g_flow_mode = 1;
         else if (!strcmp(argv[ai], "-chain")) { g_flow_mode = 1; g_chain = 1; }
+        else if (!strcmp(argv[ai], "-flow-bl")) { g_flow_mode = 1; g_flow_bl = 1; g_skip_bl = 0; }
         else if (!strcmp(argv[ai], "-lt") && ai + 1 < argc) g_lt_max = atoi(argv[++ai]);               /* trace this many LinearTransform calls (planted input and rotation keys) */
         else if (!strcmp(argv[ai], "-keep-bl")) g_skip_bl = 0;
         else if (!strcmp(argv[ai], "-noplant")) g_noplant = 1;

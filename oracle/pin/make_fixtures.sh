@@ -78,3 +78,6 @@ json.dump(d, open(sys.argv[1], "w"), indent=0)
 PY
 "$SCRATCH/gotrace" -chain -Q $Q -P $P -nq-full 28 -o trace_chain_5_1.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_chain.txt 2>&1
 python3 "$REPO/oracle/pin/mk_flow_fixture.py" "$REPO/tests/golden/ref_trace_chain_5_1.json" trace_chain_5_1.json
+# the baseline half's stock Bootstrapp, log only
+"$SCRATCH/gotrace" -flow-bl -o trace_flow_bl_5_1.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_flow_bl.txt 2>&1
+python3 "$REPO/oracle/pin/mk_flow_fixture.py" "$REPO/tests/golden/ref_flow_bl_5_1.json" trace_flow_bl_5_1.json
