@@ -80,7 +80,7 @@ struct Boot {
     ChaChaRng rng;                    // the bootstrapper's own key stream (switching keys, encryption masks)
     Encoder enc;
     std::shared_ptr<uint64_t> mono_i;                        // NTT(X^(N/2)) for every limb
-    struct LT { int n1 = 1; std::map<int, std::map<int, DPt>> giant; double pt_scale = 0; int level = 0; bool qp = false; };   // qp: the diagonals are encoded mod Q_0..Q_level AND mod every P (rows [level+1+np][N]) for linear_transform_qp
+    struct LT { int n1 = 1; std::map<int, std::map<int, DPt>> giant; double pt_scale = 0; int level = 0; bool qp = false; };   // the diagonals are encoded mod Q_0..Q_level AND mod every P (rows [level+1+np][N]) for linear_transform_qp
     struct Set { int ls = 0, ns = 0; std::vector<LT> cts, stc; };      // one bootstrapper of the reference (btp, btp2..btp5: main.go:480-500)
     std::map<int, Set> sets;                                           // by log_sparse
     std::vector<double> sine;
@@ -285,20 +285,6 @@ struct Boot {
         return r;
     }
     DCt rotate(const DCt &a, int k) { k = ((k % n) + n) % n; return k == 0 ? a : galois(a, gal_rot(k)); }
-    // evaluator.RotateHoisted: several rotations of ONE ciphertext share the digit decomposition of its c1
-    std::map<int, DCt> rotate_hoisted(const DCt &a, const std::vector<int> &ks) {
-        std::map<int, DCt> out; const int L = a.level; bool decomposed = false;
-        for (int k0 : ks) {
-            const int k = ((k0 % n) + n) % n;
-            if (k == 0) { out[k0] = a; continue; }
-            const uint64_t gal = gal_rot(k), id = key(gal, L);            // key generation (if any) before the decomposition is taken
-            if (!decomposed) { HCR(hc_keyswitch_decompose(hc, L, a.p[1].get())); decomposed = true; }
-            DCt r = new_ct(L, 1, a.scale);
-            HCR(hc_keyswitch_rotate(hc, id, gal, L, a.p[0].get(), a.p[1].get(), r.p[0].get(), r.p[1].get(), 1)); n_keyswitch++;
-            out[k0] = r;
-        }
-        return out;
-    }
     DCt conjugate(const DCt &a) { return galois(a, 2ull * N - 1); }
     DCt mod_raise(const DCt &a, int level) {                        // ckks.(*Bootstrapper).modUp
         if (a.level != 0) panic("mod_raise expects a level-0 ciphertext");
@@ -500,8 +486,8 @@ struct Boot {
         for (auto &e : M) {
             const int k = e.first, g = k - k % lt.n1, b = k % lt.n1;
             std::vector<cplx> rolled((size_t)n); for (int p = 0; p < n; p++) rolled[(size_t)p] = e.second[(size_t)(((p - g) % n + n) % n)];     // np.roll(diag, g) = the fork's rotate(v, -N1*j)
-            lt.giant[g][b] = lattigo_split && chain == 6 ? encode_qp(rolled, level, pt_scale) : encode(rolled, level, pt_scale);
-            lt.qp = lattigo_split && chain == 6;
+            lt.giant[g][b] = encode_qp(rolled, level, pt_scale);      // every bootstrapper's linear transforms run in the extended basis (linear_transform_qp)
+            lt.qp = true;
             if (dft_digests) {      // what the reference's encodeDiagonal receives and returns (mod Q): values; NTT rows in Montgomery form + the spare zero limb
                 Sha256 hv; hv.update(rolled.data(), rolled.size() * sizeof(cplx));
                 std::vector<uint64_t> rows((size_t)(level + 1) * N), zero((size_t)N, 0);
@@ -586,22 +572,7 @@ struct Boot {
     }
     DCt linear_transform(const DCt &ct, const LT &lt) {             // sum_k diag_k (.) rot_k(ct); no rescale
         if (ct.level != lt.level) panic("linear_transform: ciphertext level differs from the encoded matrix level");
-        if (lt.qp) return linear_transform_qp(ct, lt);
-        std::vector<int> babies; { std::set<int> seen; for (auto &g : lt.giant) for (auto &b : g.second) if (seen.insert(b.first).second) babies.push_back(b.first); }
-        std::map<int, DCt> rots = rotate_hoisted(ct, babies);          // the baby steps rotate the same ciphertext: one decomposition
-        DCt acc; bool have_acc = false;
-        for (auto &g : lt.giant) {
-            DCt inner; bool have = false;
-            for (auto &b : g.second) {
-                const DCt &r = rots[b.first];
-                if (!have) { inner = mul_plain(r, b.second); have = true; }
-                else if (r.deg == 1) HCR(hc_lv_op2(hc, HC_LV_MUL_ACC, r.level, r.p[0].get(), r.p[1].get(), b.second.p.get(), b.second.p.get(), inner.p[0].get(), inner.p[1].get(), nullptr));   // same plaintext scale: the sum stays at inner.scale
-                else for (int d = 0; d <= r.deg; d++) HCR(hc_lv_mul_acc(hc, r.level, r.p[d].get(), b.second.p.get(), inner.p[d].get()));
-            }
-            inner = rotate(inner, g.first);
-            acc = have_acc ? add(acc, inner) : inner; have_acc = true;
-        }
-        return acc;
+        return linear_transform_qp(ct, lt);
     }
 
     // ---------------- polynomial evaluation (tests/oracle_ckks.py: _power, _split, _plan_level, _eval_rec, eval_poly)

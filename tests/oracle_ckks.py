@@ -469,7 +469,7 @@ class Ckks:
             acc = inner if acc is None else self.add(acc, inner)
         return acc
 
-    def linear_transform_qp(self, ct, diags, pt_scale, n1):
+    def linear_transform_qp(self, ct, diags, pt_scale, n1=None):
         """ckks.(*evaluator).LinearTransform -> MultiplyByDiagMatrixBSGS exactly as the reference's fork computes it (tests/lattigo_lt.py is the
         same algorithm on the bare oracle, pinned against the binary in tests/test_oracle_pin_lt.py): baby-step rotations key-switched without
         the division by P on one digit decomposition, P*c0 added, products with the diagonals (encoded mod Q and mod P) summed in QP, ONE
@@ -477,6 +477,7 @@ class Ckks:
         diagonals multiply the input itself after the division. host/hconv_relu.cpp Boot::linear_transform_qp is the product's copy."""
         L, be = ct.level, self.be
         nl = L + 1
+        n1 = n1 or self.bsgs_split(sorted(diags))          # sparse slots / the baseline: this repository's cheapest split
         index = {}
         for k in sorted(diags):
             index.setdefault((k % self.n) // n1, []).append((k % self.n) & (n1 - 1))
@@ -891,7 +892,7 @@ class Bootstrapper:
         for j in range(self.ls):                                 # SubSum: trace onto the subring X^D (rotations by n_s 2^j)
             ct = C.add(ct, C.rotate(ct, self.ns << j))
         for G, n1 in zip(self.cts, self.cts_n1):
-            ct = C.rescale(C.linear_transform(ct, G, float(C.Q[ct.level]), n1))
+            ct = C.rescale(C.linear_transform_qp(ct, G, float(C.Q[ct.level]), n1))
         assert ct.level == LV_SINE_TOP
         cc = C.conjugate(ct)
         parts = [C.add(ct, cc), C.mul_by_i(C.sub(cc, ct))]       # (w + conj w), -i (w - conj w); the 1/2 is in the matrices
@@ -986,9 +987,9 @@ class Bootstrapper:
         first = G[:-1]
         sc, sc_last = self.stc_scales if self.stc_scales is not None else (float(C.Q[self.stc_top]) ** (1.0 / len(first)), 2.0 ** 30)
         for M, n1 in zip(first, self.stc_n1):
-            ct = C.linear_transform(ct, M, sc, n1)
+            ct = C.linear_transform_qp(ct, M, sc, n1)
         ct = C.rescale(ct)
-        ct = C.rescale(C.linear_transform(ct, G[-1], sc_last, self.stc_n1[-1]))
+        ct = C.rescale(C.linear_transform_qp(ct, G[-1], sc_last, self.stc_n1[-1]))
         return ct
 
 
