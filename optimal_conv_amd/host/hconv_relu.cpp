@@ -1031,6 +1031,8 @@ void freeBoot(Boot *b) {
     b->sets.clear(); b->pt_cache.clear(); b->mono_i.reset();      // every block returns to the pool
     for (uint64_t *blk : b->pool) hc_free(b->hc, blk);
     b->pool.clear();
+    for (uint64_t *blk : b->pool_qp) hc_free(b->hc, blk);
+    b->pool_qp.clear();
     if (b->d_sk) hc_free(b->hc, b->d_sk);
     hc_ctx_destroy(b->hc); delete b;      // the switching keys are owned by the context
 }
