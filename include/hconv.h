@@ -142,7 +142,8 @@ int hc_keyswitch_decompose(hc_ctx *ctx, int level, const uint64_t *cx);
  *  hc_keyswitch_qp  rlwe.(*KeySwitcher).SwitchKeysInPlaceNoModDown (@4fe660; hoisted = 0) / KeyswitchHoistedNoModDown (@4ff060; hoisted != 0: uses
  *                   the decomposition hc_keyswitch_decompose(level, cx) left): acc[2][level+1+np][N], canonical residues, NTT domain.
  *  hc_mod_down2     ring.(*FastBasisExtender).ModDownSplitNTTPQ (@4e4c40) on the two polynomials x[2][level+1+np][N] -> out0, out1 [level+1][N].
- *                   hc_keyswitch == hc_keyswitch_qp followed by hc_mod_down2, bit for bit.
+ *                   hc_keyswitch == hc_keyswitch_qp followed by hc_mod_down2, bit for bit. A decomposition held by hc_keyswitch_decompose
+ *                   survives hc_mod_down2 / hc_keyswitch_qp(hoisted = 0) only at the SAME level; a call at another level drops it.
  *  hc_qp_op2        out_k = a_k (op) b_k for k = 0, 1 over all level+1+np rows; op = HC_LV_MUL, HC_LV_ADD or HC_LV_MUL_ACC (out_k += a_k * b_k);
  *                   b1 == b0 for a plaintext operand. (hc_permute works on any rows, so it permutes QP polynomials as they are.) */
 int hc_keyswitch_qp(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *acc, int hoisted);

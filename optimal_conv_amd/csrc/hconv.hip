@@ -127,7 +127,7 @@ static int hc_fail(hc_ctx *c, int code, const char *fmt, ...) {
 #define HC_HIP(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hc_fail(c, HC_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 #define HC_ENTER(c) do { if (!(c)) return HC_ERR_ARG; HC_HIP(c, hipSetDevice((c)->device)); } while (0)
 
-// forward lazy-reduction mode by modulus size (see HC_FM_* in hc_kernels.h): 34q < 2^64 <=> q < 2^58.9
+// forward lazy-reduction mode by modulus size (see HC_FM_* in hc_kernels.h): FREE needs 74q < 2^64 <=> q < 2^57 (hc_fm_free); ALT needs 8q < 2^64
 // Allocation: plain hipMalloc / hipFree by default. hipFree synchronises the whole device, which is harmless with one context but
 // serialises independent contexts driven from several host threads (a thread's free waits for every other thread's queued work).
 // HCONV_ASYNC_ALLOC=1 at context creation gives this context a non-blocking stream and a cache of its own hipMalloc blocks: hc_free
@@ -290,8 +290,8 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
     c->mods.resize((size_t)(nq + np));
     for (int i = 0; i < nq + np; i++) {
         const u64 qi = i < nq ? q[i] : p[i - nq];
-        if (qi >> 62 || !h_is_prime(qi) || (qi - 1) % (2ull * HC_N)) {
-            std::string e = "hc_ctx_create: modulus is not an NTT-friendly prime below 2^62";
+        if (qi >> 61 || !h_is_prime(qi) || (qi - 1) % (2ull * HC_N)) {     // the lazy butterflies keep values below 8q: 8q < 2^64 (hc_kernels.h, HC_FM_ALT)
+            std::string e = "hc_ctx_create: modulus is not an NTT-friendly prime below 2^61";
             hc_ctx_destroy(c); g_create_err = e; return HC_ERR_ARG;
         }
         HcModHost &mh = c->mods[(size_t)i];
@@ -614,7 +614,6 @@ static int hc_prepare_ctc(hc_ctx *c, const HcPtrs &ct_in, int n, const u64 cst[2
 // loop A over the channels i = i_first + j*i_stride, j < nch, of each of the n ciphertexts of a batch (blockIdx.z); result j goes to
 // cts slot i (compact = false) or j of that ciphertext's array (arrays cts_stride words apart)
 static int hc_loopA_run_set(hc_ctx *c, const HcPtrs &kers, int n, int i_first, int i_stride, int nch, u64 *cts, size_t cts_stride, bool compact) {
-    if (!hc_fm_free(c->mods[0].m.q) && 0) return HC_ERR_UNSUPPORTED;
     long chunk = (c->chunk_nodes < 1 ? 1 : c->chunk_nodes) / n; if (chunk < 1) chunk = 1;     // channels per ciphertext per launch
     if (chunk > nch) chunk = nch;
     HC_TRY(hc_ensure_tmp(c, (size_t)n * (size_t)chunk * 2));
@@ -1172,12 +1171,13 @@ extern "C" int hc_keyswitch_qp(hc_ctx *c, uint64_t key_id, int level, const uint
     return hc_launch(c, "ks_mac_all", hc_k_ks_mac_all, dim3(32, (unsigned)nt, 2), (const u64 *)key->rows, cx, (const u64 *)S.digits, (u64 *)acc, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, key->beta);
 }
 // hc_mod_down2 = ring.(*FastBasisExtender).ModDownSplitNTTPQ on the two polynomials x[2][level+1+np][N] -> out0, out1 [level+1][N]. A hoisted
-// decomposition held by the context survives it.
+// decomposition held by the context survives it when it was taken at this same level (any other level drops it).
 extern "C" int hc_mod_down2(hc_ctx *c, int level, const uint64_t *x, uint64_t *out0, uint64_t *out1) {
     HC_ENTER(c);
     if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_mod_down2: level %d outside 0..%d or no special primes", level, c->nq - 1);
     if (!x || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_mod_down2: null");
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
+    if (level != c->hoist_level) c->hoist_cx = nullptr;      // the scratch layout depends on the level: pc / ext of another level overlap the held digits
     return hc_ks_moddown(c, level, (const u64 *)x, S.pc, S.ext, (u64 *)out0, (u64 *)out1, 0, nullptr);
 }
 // hc_qp_op2: out_k = a_k (op) b_k, k = 0, 1, over the level+1+np rows of the extended basis (op: HC_LV_MUL, HC_LV_ADD, HC_LV_MUL_ACC; b1 == b0
@@ -1411,10 +1411,12 @@ static int hc_enc_tables(hc_ctx *c) {
     roots[(size_t)m] = roots[0];
     int g = 1; for (int i = 0; i < slots; i++) { rg[(size_t)i] = g; g = (int)(((long)g * 5) % m); }
     HcScratch S(c);
-    HC_HIP(c, S.alloc(&c->enc_roots, roots.size() * sizeof(HcCplx))); HC_HIP(c, S.alloc(&c->enc_rot_group, rg.size() * sizeof(int)));
-    HC_HIP(c, hcx_h2d(c, c->enc_roots, roots.data(), roots.size() * sizeof(HcCplx)));
-    HC_HIP(c, hcx_h2d(c, c->enc_rot_group, rg.data(), rg.size() * sizeof(int)));
-    S.keep(c->enc_roots); S.keep(c->enc_rot_group);
+    decltype(c->enc_roots) d_roots = nullptr; decltype(c->enc_rot_group) d_rg = nullptr;      // the context sees the tables only once both uploads succeeded
+    HC_HIP(c, S.alloc(&d_roots, roots.size() * sizeof(HcCplx))); HC_HIP(c, S.alloc(&d_rg, rg.size() * sizeof(int)));
+    HC_HIP(c, hcx_h2d(c, d_roots, roots.data(), roots.size() * sizeof(HcCplx)));
+    HC_HIP(c, hcx_h2d(c, d_rg, rg.data(), rg.size() * sizeof(int)));
+    S.keep(d_roots); S.keep(d_rg);
+    c->enc_roots = d_roots; c->enc_rot_group = d_rg;
     return HC_OK;
 }
 // values: DEVICE [count][N/2] complex128 (re, im); overwritten (the transform runs in place). out: DEVICE [count][level+1][N]

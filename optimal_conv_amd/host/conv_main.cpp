@@ -5,6 +5,7 @@
 // `convReLU k i n` runs both with their bootstrapping chains (hconv_relu.cpp, scope row 8f-1: the baseline's stock Bootstrapp over
 // parameter set [7] and Ours' CtoS / StoC over set [6]); `resnet ker depth 1 n false` runs the encrypted ResNet inference (hconv_resnet.cpp, scope row 8f-3).
 // HCONV_SKIP_BL=1 skips the baseline half (not a reference feature; for timing "Ours" alone).
+// `conv --test-mode <args>` honours the test-only overrides HCONV_SEED / HCONV_CHAIN_REPLAY; without the flag they are fatal when set.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string>
@@ -12,6 +13,10 @@
 #include "hconv_host.hpp"
 
 int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "--test-mode") {      // not a reference feature: enables HCONV_SEED / HCONV_CHAIN_REPLAY (hconv_host.hpp)
+        hconv::testMode() = true; argv[1] = argv[0]; argv++; argc--;
+        fprintf(stderr, "hconv: --test-mode: test-only overrides from the environment are honoured\n");
+    }
     const int batchs[5] = {4, 16, 64, 256, 1024}, widths[5] = {128, 64, 32, 16, 8};   // main.go:578-579
     if (argc < 5) hconv::panic("runtime error: index out of range (usage: conv|convReLU <ker_wid> <i_batch> <num_tests>)");
     const std::string test_name = argv[1];

@@ -41,6 +41,13 @@ void panic(const std::string &msg) {
     fprintf(stderr, "panic: %s\n", msg.c_str());
     exit(2);
 }
+bool &testMode() { static bool on = false; return on; }
+const char *testOnlyEnv(const char *name) {
+    const char *v = getenv(name);
+    if (!v || !*v) return nullptr;
+    if (!testMode()) panic(std::string(name) + " is set but the CLI was not started with --test-mode: refusing to run with test-only key / input overrides");
+    return v;
+}
 #define HC(c, call) do { int rc_ = (call); if (rc_) panic(std::string(#call) + ": " + hc_last_error(c)); } while (0)
 
 static const uint64_t MODQ[3] = {0x80000000080001ull, 0x1ffffffea0001ull, PACK_P};   // Q0, Q1, P (ABI indices 0,1,2)

@@ -43,6 +43,11 @@ extern const std::vector<uint64_t> PARAMS6_P;      // bootstrapping key-switch p
 static const uint64_t PACK_P = 0x1fffffffffe00001ull;   // main.go:449
 
 [[noreturn]] void panic(const std::string &msg);        // Go's panic(): message to stderr, exit status 2
+// Test-only overrides (HCONV_SEED: deterministic keys; HCONV_CHAIN_REPLAY: planted keys and input) take effect only when the CLI was
+// started with --test-mode as its first argument; set in the environment WITHOUT that flag they end the process (an inherited variable
+// must never turn a deployment into key-less or predictable computation).
+bool &testMode();
+const char *testOnlyEnv(const char *name);              // getenv(name) under --test-mode; nullptr when unset; panic when set without the flag
 
 // Device-resident ciphertext / plaintext (ckks.Ciphertext{Value []*ring.Poly; Scale}, ckks.Plaintext)
 struct Ciphertext {

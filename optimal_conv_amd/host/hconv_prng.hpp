@@ -15,10 +15,12 @@
 
 namespace hconv {
 
+const char *testOnlyEnv(const char *name);      // hconv_host.cpp: honoured only under --test-mode, fatal otherwise
+
 struct Seed256 { uint32_t key[8]; bool deterministic = false; };
 
 inline Seed256 seedFromEnvironment() {
-    Seed256 s; const char *sd = getenv("HCONV_SEED");
+    Seed256 s; const char *sd = testOnlyEnv("HCONV_SEED");
     if (sd) {
         uint64_t z = strtoull(sd, nullptr, 0);
         for (int i = 0; i < 4; i++) {          // splitmix64 expansion of the test seed

@@ -770,7 +770,7 @@ struct Boot {
     // ---------------- the bootstrapper
     void build(const std::vector<int64_t> &sk_in, const Seed256 &seed, int device, int chain_ = 6) {
         chain = chain_;
-        if (chain == 6 && getenv("HCONV_CHAIN_REPLAY") && *getenv("HCONV_CHAIN_REPLAY")) { replay_seed = strtoull(getenv("HCONV_CHAIN_REPLAY"), nullptr, 0); fprintf(stderr, "hconv: HCONV_CHAIN_REPLAY: planted keys and input (test mode; results are meaningless as ciphertexts)\n"); }
+        if (chain == 6 && testOnlyEnv("HCONV_CHAIN_REPLAY")) { replay_seed = strtoull(testOnlyEnv("HCONV_CHAIN_REPLAY"), nullptr, 0); fprintf(stderr, "hconv: HCONV_CHAIN_REPLAY: planted keys and input (test mode; results are meaningless as ciphertexts)\n"); }
         Q = chain == 7 ? PARAMS7_Q : PARAMS6_Q; P = PARAMS6_P; NQ = (int)Q.size(); sk = sk_in; rng.reseed(seed, 0xB007B007ull + (uint64_t)chain_);
         if (chain == 7) { LV_STC_TOP = 15; stc_scale_top = stc_scale_last = 1099511627776.0; lv_relin_lo = 2; sine_out_scale = 36028797018963968.0; }
         else { LV_STC_TOP = 3; stc_scale_top = sqrt((double)Q[3]); stc_scale_last = 1073741824.0; lv_relin_lo = LV_RELU_TOP - 11; }

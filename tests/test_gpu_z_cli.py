@@ -18,7 +18,7 @@ CLI = os.path.join(ROOT, "optimal_conv_amd", "host", "conv")
 def test_conv_cli(tmp_path, k, i_batch, min_bl, min_med):
     assert os.path.exists(CLI), "host CLI not built (__graft_entry__.build)"
     gen.write_case(str(tmp_path / "test_conv_data"), k, i_batch, 0)
-    out = subprocess.run([CLI, "conv", str(k), str(i_batch), "1"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
+    out = subprocess.run([CLI, "--test-mode", "conv", str(k), str(i_batch), "1"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, HCONV_SEED="2024"))
     assert out.returncode == 0, out.stderr[-2000:]
     txt = out.stdout
@@ -36,7 +36,7 @@ def test_opwise_evaluator_path_equals_fused_on_gpu(tmp_path, k, i_batch):
     gen.write_case(str(tmp_path / "test_conv_data"), k, i_batch, 0)
     digests = []
     for extra in ({}, {"HCONV_OPWISE": "1"}):
-        out = subprocess.run([CLI, "conv", str(k), str(i_batch), "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
+        out = subprocess.run([CLI, "--test-mode", "conv", str(k), str(i_batch), "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
                              env=dict(os.environ, HCONV_SEED="99", HCONV_PRINT_DIGEST="1", HCONV_SKIP_BL="1", **extra))
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append(re.search(r"^ciphertext digest: ([0-9a-f]{16})$", out.stdout, re.M).group(1))
@@ -50,7 +50,7 @@ def test_conv_7_3_cli_sharded_over_8_contexts(tmp_path):
     gen.write_case(str(tmp_path / "test_conv_data"), 7, 3, 0)
     digests = []
     for extra in ({}, {"HCONV_GPUS": "8"}):
-        out = subprocess.run([CLI, "conv", "7", "3", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
+        out = subprocess.run([CLI, "--test-mode", "conv", "7", "3", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
                              env=dict(os.environ, HCONV_SEED="99", HCONV_PRINT_DIGEST="1", HCONV_SKIP_BL="1", **extra))
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append(re.search(r"^ciphertext digest: ([0-9a-f]{16})$", out.stdout, re.M).group(1))
@@ -91,7 +91,7 @@ def test_conv_relu_cli(tmp_path, k, i_batch):
     bits for `convReLU 5 1 1` (limited by the sign-polynomial approximation near 0)."""
     gen.write_case(str(tmp_path / "test_conv_data"), k, i_batch, 0)
     dig = tmp_path / "dft_digests.jsonl"
-    out = subprocess.run([CLI, "convReLU", str(k), str(i_batch), "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
+    out = subprocess.run([CLI, "--test-mode", "convReLU", str(k), str(i_batch), "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, HCONV_SEED="31", HCONV_BOOT_STATS="1", HCONV_DFT_DIGESTS=str(dig)))
     assert out.returncode == 0, out.stderr[-2000:]
     txt = out.stdout
@@ -121,7 +121,7 @@ def test_conv_relu_cli_replays_the_reference_chain(tmp_path):
     ctos = next(e for e in ev if e["fn"] == "BootstrappConv_CtoS")["digests"]
     final = [e for e in ev if e["fn"] == "Rescale" and "digests" in e][-1]["digests"][0]
     gen.write_case(str(tmp_path / "test_conv_data"), 5, 1, 0)
-    out = subprocess.run([CLI, "convReLU", "5", "1", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
+    out = subprocess.run([CLI, "--test-mode", "convReLU", "5", "1", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, HCONV_SEED="31", HCONV_CHAIN_REPLAY=str(ref["seed"])))
     assert out.returncode == 0, out.stderr[-2000:]
     got = {m.group(1): (int(m.group(2)), float(m.group(3)), m.group(4).split()) for m in re.finditer(r"^replay digest (\S+) level (\d+) scale (\S+) ((?:[0-9a-f]{64} ?)+)$", out.stdout, re.M)}
@@ -138,7 +138,7 @@ def test_resnet_cli_depth8(tmp_path, cf100, wide):
     import numpy as np
     import golden.gen_resnet_csv as rgen
     (want, _), = rgen.write_case(str(tmp_path), 3, 8, 1, cf100=cf100, wide=wide)     # wide = 2, 3: testResNet_crop_sparse_wide (test.go:638); 2: first stride layer on full packing; 3: 48/96/192 channels, block 1 and both stride layers on full packing
-    out = subprocess.run([CLI, "resnet", "3", "8", str(wide), "1", "true" if cf100 else "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
+    out = subprocess.run([CLI, "--test-mode", "resnet", "3", "8", str(wide), "1", "true" if cf100 else "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
                          env=dict(os.environ, HCONV_SEED="11"))
     assert out.returncode == 0, out.stderr[-2000:]
     print(out.stdout[-1500:])
@@ -161,7 +161,7 @@ def test_resnet_cli_depth20(tmp_path):
     import numpy as np
     import golden.gen_resnet_csv as rgen
     (want, _), = rgen.write_case(str(tmp_path), 3, 20, 1)
-    out = subprocess.run([CLI, "resnet", "3", "20", "1", "1", "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
+    out = subprocess.run([CLI, "--test-mode", "resnet", "3", "20", "1", "1", "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
                          env=dict(os.environ, HCONV_SEED="11"))
     assert out.returncode == 0, out.stderr[-2000:]
     print(out.stdout[-1500:])

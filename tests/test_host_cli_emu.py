@@ -23,7 +23,7 @@ def cli():
 
 def test_conv_3_0_1(cli, tmp_path):
     gen.write_case(str(tmp_path / "test_conv_data"), 3, 0, 0)
-    out = subprocess.run([cli, "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=1200,
+    out = subprocess.run([cli, "--test-mode", "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=1200,
                          env=dict(os.environ, HCONV_SEED="12345"))
     assert out.returncode == 0, out.stderr[-2000:]
     txt = out.stdout
@@ -56,7 +56,7 @@ def test_cli_argument_panics(cli, tmp_path, argv, msg):
 
 
 def test_missing_csv_panics(cli, tmp_path):
-    out = subprocess.run([cli, "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
+    out = subprocess.run([cli, "--test-mode", "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, HCONV_SEED="1"))
     assert out.returncode == 2 and "panic:" in out.stderr
 
@@ -68,7 +68,7 @@ def test_opwise_evaluator_path_equals_fused(cli, tmp_path):
     gen.write_case(str(tmp_path / "test_conv_data"), 3, 0, 0)
     digests = []
     for extra in ({}, {"HCONV_OPWISE": "1"}):
-        out = subprocess.run([cli, "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=1800,
+        out = subprocess.run([cli, "--test-mode", "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=1800,
                              env=dict(os.environ, HCONV_SEED="99", HCONV_PRINT_DIGEST="1", HCONV_SKIP_BL="1", **extra))
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append(re.search(r"^ciphertext digest: ([0-9a-f]{16})$", out.stdout, re.M).group(1))
@@ -81,10 +81,16 @@ def test_conv_cli_sharded_over_contexts_same_ciphertext(cli, tmp_path):
     gen.write_case(str(tmp_path / "test_conv_data"), 3, 0, 0)
     digests = []
     for extra in ({}, {"HCONV_GPUS": "4"}):
-        out = subprocess.run([cli, "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=1200,
+        out = subprocess.run([cli, "--test-mode", "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=1200,
                              env=dict(os.environ, HCONV_SEED="77", HCONV_PRINT_DIGEST="1", HCONV_SKIP_BL="1", **extra))
         assert out.returncode == 0, out.stderr[-2000:]
         if extra:
             assert "Sharding every convolution over 4 device contexts" in out.stdout
         digests.append(re.search(r"^ciphertext digest: ([0-9a-f]{16})$", out.stdout, re.M).group(1))
     assert digests[0] == digests[1]
+
+
+def test_test_only_overrides_need_the_test_mode_flag(cli, tmp_path):
+    """HCONV_SEED (deterministic keys) inherited from the environment without --test-mode must end the process, not run."""
+    out = subprocess.run([cli, "conv", "3", "0", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=120, env=dict(os.environ, HCONV_SEED="1"))
+    assert out.returncode == 2 and "HCONV_SEED is set but the CLI was not started with --test-mode" in out.stderr

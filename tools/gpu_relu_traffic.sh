@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
 W=/tmp/relutraffic; mkdir -p $W; cd $W
 PYTHONPATH=$R/tests python -c "import golden.gen_conv_csv as g; [g.write_case('test_conv_data',5,1,i) for i in range(2)]"
 for pmc in FETCH_SIZE WRITE_SIZE; do
-  HCONV_SKIP_BL=1 HCONV_SEED=7 timeout 900 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $O/pmc_$pmc -o run -- $R/optimal_conv_amd/host/conv convReLU 5 1 2 > $O/run_$pmc.log 2>&1
+  HCONV_SKIP_BL=1 HCONV_SEED=7 timeout 900 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $O/pmc_$pmc -o run -- $R/optimal_conv_amd/host/conv --test-mode convReLU 5 1 2 > $O/run_$pmc.log 2>&1
 done
 python - <<PY
 import csv, collections, json, glob

@@ -24,9 +24,9 @@ PY
 OUT=round2/pmc BATCH=8 BENCH_ARGS="--streams 1" PMC_CONVS=48 bash tools/gpu_r2_pmc.sh > $O/pmc_table.txt 2>&1; tail -14 $O/pmc_table.txt
 # the other CLI configurations
 mkdir -p /tmp/cli && cd /tmp/cli
-python $R/tests/golden/gen_conv_csv.py test_conv_data 3 3 1 > /dev/null; HCONV_SEED=5 timeout 600 $R/optimal_conv_amd/host/conv conv 3 3 1 > $R/$O/cli_conv_3_3.txt 2>&1
-python $R/tests/golden/gen_conv_csv.py test_conv_data 7 3 1 > /dev/null; HCONV_SEED=5 HCONV_GPUS=8 HCONV_SKIP_BL=1 timeout 600 $R/optimal_conv_amd/host/conv conv 7 3 1 > $R/$O/cli_conv_7_3_sharded8.txt 2>&1
-python $R/tests/golden/gen_conv_csv.py test_conv_data 5 1 1 > /dev/null; HCONV_SEED=5 timeout 900 $R/optimal_conv_amd/host/conv convReLU 5 1 1 > $R/$O/cli_convrelu_5_1.txt 2>&1
+python $R/tests/golden/gen_conv_csv.py test_conv_data 3 3 1 > /dev/null; HCONV_SEED=5 timeout 600 $R/optimal_conv_amd/host/conv --test-mode conv 3 3 1 > $R/$O/cli_conv_3_3.txt 2>&1
+python $R/tests/golden/gen_conv_csv.py test_conv_data 7 3 1 > /dev/null; HCONV_SEED=5 HCONV_GPUS=8 HCONV_SKIP_BL=1 timeout 600 $R/optimal_conv_amd/host/conv --test-mode conv 7 3 1 > $R/$O/cli_conv_7_3_sharded8.txt 2>&1
+python $R/tests/golden/gen_conv_csv.py test_conv_data 5 1 1 > /dev/null; HCONV_SEED=5 timeout 900 $R/optimal_conv_amd/host/conv --test-mode convReLU 5 1 1 > $R/$O/cli_convrelu_5_1.txt 2>&1
 grep -E "Conv \(with BN\)|Evaluation total|MED Prec|Boot|ReLU Done|Done in" $R/$O/cli_conv_3_3.txt $R/$O/cli_convrelu_5_1.txt | cut -c1-150 | tail -30
 cd $R
 timeout 900 python tools/resnet_throughput.py --images 24 --threads 2 > $O/resnet20_throughput_1gpu.json 2> $O/resnet20_throughput.err; cut -c1-300 $O/resnet20_throughput_1gpu.json

@@ -37,7 +37,7 @@ def main():
     work = tempfile.mkdtemp(prefix="resnet_tp_")
     rgen.write_case(work, a.ker, a.depth, a.images)
     t0 = time.time()
-    procs = [subprocess.Popen([cli, "resnet", str(a.ker), str(a.depth), "1", str(a.images), "false"], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+    procs = [subprocess.Popen([cli, "--test-mode", "resnet", str(a.ker), str(a.depth), "1", str(a.images), "false"], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                               env=dict(os.environ, HCONV_DEVICE=str(r // a.procs_per_gpu), HCONV_SEED=str(100 + r), HCONV_IMAGE_THREADS=str(a.threads), HCONV_ASYNC_ALLOC=os.environ.get("HCONV_ASYNC_ALLOC", "1"))) for r in range(a.gpus * a.procs_per_gpu)]
     per_rank, spans = [], []
     for p in procs:

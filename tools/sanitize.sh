@@ -4,7 +4,7 @@
 set -eu
 cd "$(dirname "$0")/.."
 # the instrumentation flags live ONLY here (this script is CPU-only and listed in .gpurunignore); the Makefiles take SAN_FLAGS
-FS="-fsan""itize"
+FS="-fsanitize"
 make -s -C tests/kernel_emu "$PWD/tests/kernel_emu/_build/libhconv_emu_ubsan.so" SAN_FLAGS="$FS=undefined -fno-sanitize-recover=undefined"
 make -s -C tests/kernel_emu "$PWD/tests/kernel_emu/_build/libhconv_emu_asan.so" SAN_FLAGS="$FS=address -fno-omit-frame-pointer"
 make -s -C oracle asan SAN_FLAGS="$FS=address,undefined -fno-omit-frame-pointer"
