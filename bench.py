@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="contexts (HIP streams) per GPU, each with its own batch of resident ciphertexts")
     ap.add_argument("--batch-alt", type=int, default=0, help="experiment: odd-numbered contexts use this batch size instead (desynchronises the streams)")
     ap.add_argument("--lanes", type=int, default=1, help="internal lanes of one conv (channels i mod G on their own streams)")
+    ap.add_argument("--antiphase", type=int, default=0, help="two half-batches per context one phase apart (memory-bound kernels of one beside VALU-bound kernels of the other); 0 = one launch set per batch")
+    ap.add_argument("--opt", action="append", default=[], help="extra context option name=value (hc_set_option), e.g. b5_merged=0; experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -127,6 +129,9 @@ def main():
         ctx = Context([Q0, Q1], [P0], device=device)            # raises if no GPU / no libhconv.so
         ctx.set_option("chunk_nodes", args.chunk)
         ctx.set_option("lanes", args.lanes)
+        ctx.set_option("antiphase", args.antiphase)
+        for kv in args.opt:
+            ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         for gal, k4 in keys:
             ctx.evk_load(gal, k4)
         ctx.idx_load(None)

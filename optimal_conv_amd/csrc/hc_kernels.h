@@ -498,8 +498,11 @@ struct HcLoopA {
 };
 // KA1: rows-inverse of a_1 (mod Q1). grid = (jobs, 16, batch). F64 = 1: Q1 < 2^49, the transform runs in fp64 (T1inv = the fp64 table)
 // and tmp carries doubles (bit patterns) to KA2.
+#ifndef HC_A_WAVES
+#define HC_A_WAVES 5          // a1 / a2 sat at 98 / 99 VGPRs = four waves per SIMD by two or three registers
+#endif
 template <int F64>
-__global__ __launch_bounds__(HC_TPB) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
+__global__ __launch_bounds__(HC_TPB, HC_A_WAVES) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
     const int job = HC_JOB, p = job & 1, i = A.i0 + (job >> 1) * A.norm, z = blockIdx.z;
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
 }
 // KA2: cols-inverse mod Q1, centred lift to Q0, cols-forward mod Q0, in place on tmp. grid = (jobs * batch, 16)
 template <int FM, int F64>
-__global__ __launch_bounds__(HC_TPB) void hc_k_a2(HcLoopA A, HcTwTab T1inv, HcTwTab T0fwd) {
+__global__ __launch_bounds__(HC_TPB, HC_A_WAVES) void hc_k_a2(HcLoopA A, HcTwTab T1inv, HcTwTab T0fwd) {
     __shared__ u64 lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     u64 *base = A.tmp + (size_t)HC_JOB * 65536 + HC_TILE * 16 + c;
@@ -605,7 +608,7 @@ struct HcLoopB {
     u64 *dst;            // [max_cnum][2][N] where it writes node results (slot i); src != dst: the two ping-pong
     u64 *tmpC;           // [chunk][N]      c1 of t2 through iNTT_Q0 / NTT_P
     u64 *tmpE;           // [chunk][2][N]   P-part accumulators through iNTT_P / NTT_Q0
-    u64 *tmpT;           // [chunk][N]      t2.c1 itself (lazy < 4q, natural order): b1 -> b5
+    u64 *tmpT;           // [chunk][N]      t2.c1 itself (lazy < 4q, natural order): b1 -> the two-job b5; null when b5m (which recomputes it) follows
     // fixed multiplicands (idx plaintext, both halves of the switching key) are Shoup pairs: one hc_shoup4 per use
     const HcTw *idx;     // [N]             idx[s] plaintext, natural order
     const HcTw *evkQ;    // [2][N]          b_Q * P^-1, a_Q * P^-1 mod Q0, natural order
@@ -622,7 +625,7 @@ struct HcLoopB {
 };
 // KB1: t2.c1 = y1 - I*x1 (kept in tmpT for KB5) and its rows-inverse (mod Q0). grid = (batch*nodes, 16). Everything else a node needs
 // from x and y (t1, t2.c0, the Q-part of the key switch) is formed in KB5 from src and tmpT.
-__global__ __launch_bounds__(HC_TPB) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
+__global__ __launch_bounds__(HC_TPB, HC_A_WAVES) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
     const int job = HC_JOB, z = job / B.nodes, node = job - z * B.nodes, i = (B.n0 + node) * B.norm;
@@ -639,9 +642,11 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
         const HcTw I = idx[kk * 256];
         e[kk] = hc_fold(yy[kk] + Q.q4 - hc_shoup4(e[kk], I.w, I.ws, Q), Q.nq4);                    // t2.c1 (conv.go:288-289), lazy < 4q
     }
-    u64 *__restrict__ tt = B.tmpT + (size_t)job * 65536 + tile;
+    if (B.tmpT != nullptr) {       // only the two-job b5 (tile-local permutations, L0 key switch) reads it back; b5m recomputes t2.c1
+        u64 *__restrict__ tt = B.tmpT + (size_t)job * 65536 + tile;
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) tt[kk * 256] = e[kk];
+        for (int kk = 0; kk < 16; kk++) tt[kk * 256] = e[kk];
+    }
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     __syncthreads();
     hc_rows_inv(e, lds, T0inv, row, rloc, tid, Q);
@@ -732,8 +737,32 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTw
 // canonical; ALT mode has no such headroom and works on canonical terms.
 // Requires the permutation to stay inside the workgroup's 16-row tile (4096 consecutive coefficients): galEl = 2^j+1, j >= 5
 // (j >= 9 even stays inside one 256-coefficient row; j = 7, 8 are what the resnet's 8x8 layers, max_cnum 1024, add).
-template <int FM>
-__global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, HcPtrs biases) {
+// ROWLOCAL = 1 (galEl = 2^j + 1 with j >= 9: every pack tree up to 256 channels): the permutation stays inside a 256-coefficient row, so
+// the epilogue runs in batches of HC_B5_ROWS rows -- operands loaded, t1 and d formed, d through that row of LDS, gathered, stored -- and
+// nothing but the transform's 16 residues lives across the transform: <= 96 VGPRs, five workgroups per CU (round 2 held t1 and F, 64
+// VGPRs, across the transform: 138 VGPRs, three per CU, and its load / transform / store phases did not overlap).
+// ROWLOCAL = 0 (j = 5..8, the 1024-channel trees of the resnet's 8x8 layers): the gather reads the whole 16-row tile, so all of d is
+// formed before it.
+#ifndef HC_B5_ROWS
+#define HC_B5_ROWS 2
+#endif
+template <int FM, int K0>
+__device__ __forceinline__ void hc_b5_terms(u64 Y, u64 T, HcTw K, u64 X, HcTw I, const HcQ &Q, u64 &t1, u64 &f) {
+    const u64 q = Q.q;
+    u64 g = hc_shoup4(T, K.w, K.ws, Q);                                                  // (key row / P) * t2.c1, < 4q
+    if (FM != HC_FM_FREE) g = hc_canon4(g, Q);
+    if (K0) {
+        u64 m = hc_shoup4(X, I.w, I.ws, Q);
+        if (FM == HC_FM_FREE) { t1 = Y + m; f = Y + Q.q4 - m + g; }                      // conv.go:290, < 5q ; t2.c0 + ..., < 9q
+        else { m = hc_canon4(m, Q); t1 = hc_addmod(Y, m, q); f = hc_addmod(hc_submod(Y, m, q), g, q); }
+    } else {
+        if (FM == HC_FM_FREE) t1 = Y + Y + Q.q4 - T;                                     // y1 + I*x1 with I*x1 = y1 - t2.c1, < 6q
+        else t1 = hc_addmod(Y, hc_submod(Y, hc_canon4(T, Q), q), q);
+        f = g;
+    }
+}
+template <int FM, int ROWLOCAL>
+__global__ __launch_bounds__(HC_TPB, ROWLOCAL ? 5 : 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, HcPtrs biases, HcPtrs outs) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
     const int job = HC_JOB, zn = job >> 1, k = job & 1, z = zn / B.nodes, node = zn - z * B.nodes, i = (B.n0 + node) * B.norm;
@@ -746,65 +775,148 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, H
     const u64 *__restrict__ tc1 = B.tmpT + (size_t)zn * 65536 + tile;      // t2.c1 = y1 - I*x1 from b1 (lazy < 4q)
     const HcTw *__restrict__ idx = B.idx + tile;
     const HcTw *__restrict__ evk = B.evkQ + (size_t)k * 65536 + tile;      // b_Q/P for k = 0, a_Q/P for k = 1
-    u64 *__restrict__ o = B.dst + (size_t)z * B.dst_stride + ((size_t)i * 2 + k) * 65536 + tile;
-    const u64 *__restrict__ bias = biases.p[z];        // null except on the last node of the tree (eval.go:258)
-    u64 e[16], f[16], t1[16];
+    // the root node (i = 0 of the last level) may write straight to the caller's ciphertext (outs.p[z] = [2][N]) instead of slot 0
+    u64 *__restrict__ o = (outs.p[z] != nullptr ? const_cast<u64 *>(outs.p[z]) + (size_t)k * 65536 : B.dst + (size_t)z * B.dst_stride + ((size_t)i * 2 + k) * 65536) + tile;
+    const u64 *__restrict__ bias = (k == 0 && biases.p[z] != nullptr) ? biases.p[z] + tile : nullptr;        // null except on the last node of the tree (eval.go:258)
+    u64 e[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
-#pragma unroll
-    for (int b = 0; b < 4; b++) {               // batches of 4 residues: all loads of a batch before its arithmetic
-        u64 X[4], Y[4], T[4]; HcTw I[4], K[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int off = (b * 4 + j) * 256;
-            Y[j] = yk[off]; K[j] = evk[off]; T[j] = tc1[off];
-            if (k == 0) { X[j] = xk[off]; I[j] = idx[off]; }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int kk = b * 4 + j;
-            u64 g = hc_shoup4(T[j], K[j].w, K[j].ws, Q);                                          // (key row / P) * t2.c1, < 4q
-            if (FM != HC_FM_FREE) g = hc_canon4(g, Q);
-            if (k == 0) {
-                u64 m = hc_shoup4(X[j], I[j].w, I[j].ws, Q);
-                if (FM == HC_FM_FREE) {
-                    t1[kk] = Y[j] + m;                                                            // conv.go:290, < 5q
-                    f[kk] = Y[j] + Q.q4 - m + g;                                                  // t2.c0 + ..., < 9q
-                } else {
-                    m = hc_canon4(m, Q);
-                    t1[kk] = hc_addmod(Y[j], m, q);
-                    f[kk] = hc_addmod(hc_submod(Y[j], m, q), g, q);
-                }
-            } else {
-                if (FM == HC_FM_FREE) t1[kk] = Y[j] + Y[j] + Q.q4 - T[j];                         // y1 + I*x1 with I*x1 = y1 - t2.c1, < 6q
-                else t1[kk] = hc_addmod(Y[j], hc_submod(Y[j], hc_canon4(T[j], Q), q), q);
-                f[kk] = g;
-            }
-        }
-    }
-    if (bias != nullptr && k == 0) {
-#pragma unroll
-        for (int kk = 0; kk < 16; kk++) t1[kk] = FM == HC_FM_FREE ? t1[kk] + bias[tile + kk * 256] : hc_addmod(t1[kk], bias[tile + kk * 256], q);
-    }
     hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, Q);
     __syncthreads();
-    hc_rows_lo_to_lin(e, lds, t, rloc, tid);
+    hc_rows_lo_to_lin(e, lds, t, rloc, tid);          // e[kk] = n = NTT(ext * P^-1) at (row kk, column t)
+    __syncthreads();
+    if (ROWLOCAL) {
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
-        // n = NTT(ext * P^-1), F already / P
-        if (FM == HC_FM_FREE) e[kk] = f[kk] + HC_FREE_OFF * q - e[kk];                            // < 81q
-        else e[kk] = hc_submod(f[kk], hc_canon8(e[kk], Q), q);
+        for (int b = 0; b < 16; b += HC_B5_ROWS) {
+            u64 Y[HC_B5_ROWS], T[HC_B5_ROWS], X[HC_B5_ROWS], t1[HC_B5_ROWS], bs[HC_B5_ROWS]; HcTw K[HC_B5_ROWS], I[HC_B5_ROWS];
+#pragma unroll
+            for (int j = 0; j < HC_B5_ROWS; j++) {
+                const int off = (b + j) * 256;
+                Y[j] = yk[off]; K[j] = evk[off]; T[j] = tc1[off];
+                if (k == 0) { X[j] = xk[off]; I[j] = idx[off]; } else { X[j] = 0; I[j] = K[j]; }
+                bs[j] = bias != nullptr ? bias[off] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < HC_B5_ROWS; j++) {
+                const int kk = b + j;
+                u64 f;
+                if (k == 0) hc_b5_terms<FM, 1>(Y[j], T[j], K[j], X[j], I[j], Q, t1[j], f);
+                else hc_b5_terms<FM, 0>(Y[j], T[j], K[j], X[j], I[j], Q, t1[j], f);
+                if (FM == HC_FM_FREE) { t1[j] += bs[j]; f = f + HC_FREE_OFF * q - e[kk]; }                 // d < 81q
+                else { t1[j] = hc_addmod(t1[j], bs[j], q); f = hc_submod(f, hc_canon8(e[kk], Q), q); }
+                lds[hc_rows_lds(kk, t)] = f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < HC_B5_ROWS; j++) {
+                const int kk = b + j;
+                const u32 srcidx = hc_perm_src((u32)((HC_TILE * 16 + kk) * 256 + t), B.gal);
+                const u64 d = lds[hc_rows_lds(kk, (int)(srcidx & 255))];                                   // the source is in the same row
+                o[kk * 256] = FM == HC_FM_FREE ? hc_reduce64(t1[j] + d, B.m0.mu, Q) : hc_addmod(t1[j], d, q);
+            }
+        }
+    } else {
+        u64 t1[16];
+#pragma unroll
+        for (int b = 0; b < 16; b += 4) {
+            u64 Y[4], T[4], X[4]; HcTw K[4], I[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int off = (b + j) * 256;
+                Y[j] = yk[off]; K[j] = evk[off]; T[j] = tc1[off];
+                if (k == 0) { X[j] = xk[off]; I[j] = idx[off]; } else { X[j] = 0; I[j] = K[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int kk = b + j;
+                u64 f;
+                if (k == 0) hc_b5_terms<FM, 1>(Y[j], T[j], K[j], X[j], I[j], Q, t1[kk], f);
+                else hc_b5_terms<FM, 0>(Y[j], T[j], K[j], X[j], I[j], Q, t1[kk], f);
+                if (bias != nullptr) t1[kk] = FM == HC_FM_FREE ? t1[kk] + bias[kk * 256] : hc_addmod(t1[kk], bias[kk * 256], q);
+                lds[hc_rows_lds(kk, t)] = FM == HC_FM_FREE ? f + HC_FREE_OFF * q - e[kk] : hc_submod(f, hc_canon8(e[kk], Q), q);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            const u32 srcidx = hc_perm_src((u32)((HC_TILE * 16 + kk) * 256 + t), B.gal);
+            const u64 d = lds[hc_rows_lds((int)((srcidx >> 8) & 15), (int)(srcidx & 255))];               // source stays inside this 16-row tile
+            o[kk * 256] = FM == HC_FM_FREE ? hc_reduce64(t1[kk] + d, B.m0.mu, Q) : hc_addmod(t1[kk], d, q);
+        }
     }
-    __syncthreads();
+}
+
+// KB5M: one workgroup per (node, tile) does BOTH polynomials, k = 1 first: grid = (batch*nodes, 16). Row-local permutations only
+// (galEl = 2^j + 1, j >= 9). Against two hc_k_b5 jobs: t2.c1 = y1 - I*x1 is recomputed from x1, y1 and idx in the k = 1 epilogue (the very
+// expression b1 fed into the key switch) and kept in registers for k = 0, so b1 does not write tmpT and nobody reads it (1.5 MiB less
+// per node: 0.5 written, 2 x 0.5 read, against 0.5 more for x1), and idx is read once per node. Per row batch of either polynomial:
+//   k = 1: m1 = I*x1 ; T = y1 - m1 ; t1 = y1 + m1 ; F = (a_Q/P)*T                      k = 0: m = I*x0 ; t1 = y0 + m ; F = y0 - m + (b_Q/P)*T
+//   d = F - n_k (n_k = rows-forward of the k-th extension, divided by P by b4) ; through the LDS row ; dst = reduce(t1 + perm(d)) (+ bias, k = 0)
+#ifndef HC_B5M_UNROLL
+#define HC_B5M_UNROLL 2
+#endif
+#ifndef HC_B5M_WAVES
+#define HC_B5M_WAVES 3
+#endif
+template <int FM>
+__global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTwTab T0fwd, HcPtrs biases, HcPtrs outs) {
+    __shared__ u64 lds[HC_ROWS_LDS];
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
+    const int zn = HC_JOB, z = zn / B.nodes, node = zn - z * B.nodes, i = (B.n0 + node) * B.norm;
+    const HcQ Q = hc_q(B.m0.q);
+    const u64 q = Q.q;
+    const size_t tile = (size_t)HC_TILE * 4096 + t;
+    const u64 *__restrict__ ys = B.src + (size_t)z * B.src_stride + (size_t)i * 2 * 65536 + tile;                  // y_k = ys[k * 65536 + ...]
+    const u64 *__restrict__ xs = B.src + (size_t)z * B.src_stride + (size_t)(i + B.step) * 2 * 65536 + tile;
+    const HcTw *__restrict__ idx = B.idx + tile;
+    const HcTw *__restrict__ evk = B.evkQ + tile;                                                                  // b_Q/P, then a_Q/P 65536 pairs on
+    u64 *__restrict__ o = (outs.p[z] != nullptr ? const_cast<u64 *>(outs.p[z]) : B.dst + (size_t)z * B.dst_stride + (size_t)i * 2 * 65536) + tile;
+    const u64 *__restrict__ bias = biases.p[z] != nullptr ? biases.p[z] + tile : nullptr;        // null except on the last node of the tree (eval.go:258)
+    u64 e[16], T[16];
+#pragma unroll HC_B5M_UNROLL
+    for (int k = 1; k >= 0; k--) {
+        const u64 *__restrict__ in = B.tmpE + ((size_t)zn * 2 + k) * 65536 + (size_t)row * 256;
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) lds[hc_rows_lds(kk, t)] = e[kk];
-    __syncthreads();
+        for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
+        if (k == 0) __syncthreads();                      // the last gather of k = 1 is done before the transform writes LDS again
+        hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, Q);
+        __syncthreads();
+        hc_rows_lo_to_lin(e, lds, t, rloc, tid);          // e[kk] = n_k at (row kk, column t)
+        __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
-        const u32 dstidx = (u32)((HC_TILE * 16 + kk) * 256 + t);
-        const u32 srcidx = hc_perm_src(dstidx, B.gal);
-        const u64 d = lds[hc_rows_lds((int)((srcidx >> 8) & 15), (int)(srcidx & 255))];          // source stays inside this 16-row tile
-        o[kk * 256] = FM == HC_FM_FREE ? hc_reduce64(t1[kk] + d, B.m0.mu, Q) : hc_addmod(t1[kk], d, q);
+        for (int b = 0; b < 16; b += HC_B5_ROWS) {
+            u64 Y[HC_B5_ROWS], X[HC_B5_ROWS], t1[HC_B5_ROWS], bs[HC_B5_ROWS]; HcTw K[HC_B5_ROWS], I[HC_B5_ROWS];
+#pragma unroll
+            for (int j = 0; j < HC_B5_ROWS; j++) {
+                const int off = (b + j) * 256;
+                Y[j] = ys[(size_t)k * 65536 + off]; X[j] = xs[(size_t)k * 65536 + off]; I[j] = idx[off]; K[j] = evk[(size_t)k * 65536 + off];
+                bs[j] = (k == 0 && bias != nullptr) ? bias[off] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < HC_B5_ROWS; j++) {
+                const int kk = b + j;
+                u64 m = hc_shoup4(X[j], I[j].w, I[j].ws, Q), f;                                            // I * x_k, < 4q
+                if (k == 1) T[kk] = hc_fold(Y[j] + Q.q4 - m, Q.nq4);                                       // t2.c1 (conv.go:288-289) as b1 formed it, lazy < 4q
+                u64 g = hc_shoup4(T[kk], K[j].w, K[j].ws, Q);                                              // (key row / P) * t2.c1, < 4q
+                if (FM == HC_FM_FREE) {
+                    t1[j] = Y[j] + m + bs[j];                                                              // conv.go:290 (+ bias), < 6q
+                    f = (k == 0 ? Y[j] + Q.q4 - m + g : g) + HC_FREE_OFF * q - e[kk];                      // t2.c_k + (key switch)_k - n_k, < 81q
+                } else {
+                    m = hc_canon4(m, Q); g = hc_canon4(g, Q);
+                    t1[j] = hc_addmod(hc_addmod(Y[j], m, q), bs[j], q);
+                    f = hc_submod(k == 0 ? hc_addmod(hc_submod(Y[j], m, q), g, q) : g, hc_canon8(e[kk], Q), q);
+                }
+                lds[hc_rows_lds(kk, t)] = f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < HC_B5_ROWS; j++) {
+                const int kk = b + j;
+                const u32 srcidx = hc_perm_src((u32)((HC_TILE * 16 + kk) * 256 + t), B.gal);
+                const u64 d = lds[hc_rows_lds(kk, (int)(srcidx & 255))];                                   // the source is in the same row
+                o[(size_t)k * 65536 + kk * 256] = FM == HC_FM_FREE ? hc_reduce64(t1[j] + d, B.m0.mu, Q) : hc_addmod(t1[j], d, q);
+            }
+        }
     }
 }
 

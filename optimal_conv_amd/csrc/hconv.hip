@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <functional>
 #include <map>
 #include <utility>
 #include <string>
@@ -68,7 +69,7 @@ struct HcModHost {
     HcTwTab inv_f64;             // moduli below 2^49: the inverse tables as {w, w/q} doubles (fp64 inverse transform of loop A)
     std::vector<void *> allocs;
 };
-struct HcEvk { HcTw *q_rows; HcTw *p_rows; bool row_local; };   // [2][N] each, Shoup pairs: q_rows (key / P mod Q0) natural order; p_rows (key / N mod P) lo-local order
+struct HcEvk { HcTw *q_rows; HcTw *p_rows; bool row_local; bool row256; };   // row_local: the permutation stays inside 4096-coefficient tiles; row256: even inside 256-coefficient rows   // [2][N] each, Shoup pairs: q_rows (key / P mod Q0) natural order; p_rows (key / N mod P) lo-local order
 struct HcSwk { u64 *rows = nullptr; int level = 0, beta = 0; };   // general switching key: [beta][2][level+1+np][N], stored form
 struct HcProfRec { std::string name; hipEvent_t a, b; };
 // An internal lane = its own HIP stream + workspaces: one convolution is split by output channel i mod G into G
@@ -78,7 +79,14 @@ struct HcLane {
     u64 *tmp = nullptr; size_t tmp_rows = 0;
     u64 *cts = nullptr; size_t cts_rows = 0;
     u64 *cts2 = nullptr; size_t cts2_rows = 0;
+    // a half-batch of hc_conv_then_pack_batch in anti-phase with the other half (hc_conv_batch_antiphase): its own loop-A outputs and c' pairs
+    u64 *bcts = nullptr; size_t bcts_rows = 0;
+    HcTw *ctc = nullptr; size_t ctc_cts = 0;
+    std::vector<hipEvent_t> step_ev; size_t step_next = 0;      // ring of events for the lock-step barriers between the two lanes
 };
+// One queued operation of a recorded launch sequence (hc_ctx::rec): kind 'V' = bound by the vector ALU (the cols kernels a2, b2, b4 and
+// b3), 'M' = bound by memory (a1, a3, b1, b5, copies). See hc_conv_batch_antiphase.
+struct HcOp { char kind; std::function<hipError_t(hipStream_t)> run; };
 
 struct hc_ctx {
     int device = 0, nq = 0, np = 0;
@@ -110,6 +118,10 @@ struct hc_ctx {
     HcCplx *enc_roots = nullptr; int *enc_rot_group = nullptr;      // slot encoder tables (hc_encode_slots), built at first use
     hipEvent_t ev_shard = nullptr;     // hc_conv_then_pack_sharded: this device's partial ciphertext is complete / has been collected
     u64 *ws_gather = nullptr; size_t ws_gather_rows = 0;
+    std::vector<HcOp> *rec = nullptr;     // non-null: hc_launch / hc_copy_d2d append to it instead of enqueueing on the stream
+    long b5_merged = 1;                   // row-local pack levels: one b5 workgroup per (node, tile) for both polynomials (hc_k_b5m); 0 = two jobs (A/B switch)
+    long antiphase = 0;                   // hc_conv_then_pack_batch with n >= 2: two half-batches on two streams, memory-bound phases of one against VALU-bound phases of the other.
+                                          // OFF by default: measured no gain (profiles/round3_antiphase_trace.txt) -- co-resident kernels time-slice the CU's wave slots and the VALU pipe
     long profile = 0;
     std::vector<HcProfRec> prof;
     std::map<std::string, std::pair<double, long>> prof_acc;
@@ -192,8 +204,16 @@ struct HcScratch {
 static inline bool hc_fm_free(u64 q) { return q < (1ull << 57); }     // 74q < 2^64 (hc_ct_round)
 static inline bool hc_f64_ok(u64 q) { return q < (1ull << 49); }    // fp64 inverse transform (hc_arith.h): 4q < 2^51
 
+static char hc_op_kind(const char *name) {       // by kernel name: the measured bound of each kernel of the conv path
+    if ((name[0] == 'a' && name[1] == '2') || (name[0] == 'b' && (name[1] == '2' || name[1] == '3' || name[1] == '4'))) return 'V';
+    return 'M';
+}
 template <class K, class... Args>
 static int hc_launch(hc_ctx *c, const char *name, K kernel, dim3 grid, Args... args) {
+    if (c->rec) {
+        c->rec->push_back(HcOp{hc_op_kind(name), [=](hipStream_t st) -> hipError_t { hipLaunchKernelGGL(kernel, grid, dim3(HC_TPB), 0, st, args...); return hipGetLastError(); }});
+        return HC_OK;
+    }
     hipEvent_t a = nullptr, b = nullptr;
     if (c->profile) { HC_HIP(c, hipEventCreate(&a)); HC_HIP(c, hipEventCreate(&b)); HC_HIP(c, hipEventRecord(a, c->stream)); }
     hipLaunchKernelGGL(kernel, grid, dim3(HC_TPB), 0, c->stream, args...);
@@ -202,6 +222,12 @@ static int hc_launch(hc_ctx *c, const char *name, K kernel, dim3 grid, Args... a
     return HC_OK;
 }
 #define HC_TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
+// device-to-device copy on the context's stream (or into the recorded sequence)
+static int hc_copy_d2d(hc_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (c->rec) { c->rec->push_back(HcOp{'M', [=](hipStream_t st) -> hipError_t { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st); }}); return HC_OK; }
+    HC_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return HC_OK;
+}
 // pick the kernel instantiation whose forward transform uses the lazy-reduction mode the modulus q allows
 #define HC_LAUNCH_FM(q, c, name, KERNEL, grid, ...) \
     (hc_fm_free(q) ? hc_launch(c, name, KERNEL<HC_FM_FREE>, grid, __VA_ARGS__) : hc_launch(c, name, KERNEL<HC_FM_ALT>, grid, __VA_ARGS__))
@@ -340,7 +366,8 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     if (c->ev_shard) D(hipEventDestroy(c->ev_shard), "hipEventDestroy");
     for (auto &L : c->lane) {
         if (L.stream) D(hipStreamSynchronize(L.stream), "hipStreamSynchronize");
-        F(L.tmp); F(L.cts); F(L.cts2);
+        F(L.tmp); F(L.cts); F(L.cts2); F(L.bcts); F(L.ctc);
+        for (hipEvent_t e : L.step_ev) D(hipEventDestroy(e), "hipEventDestroy");
         if (L.done) D(hipEventDestroy(L.done), "hipEventDestroy");
         if (L.stream) D(hipStreamDestroy(L.stream), "hipStreamDestroy");
     }
@@ -696,12 +723,12 @@ extern "C" int hc_div_round_last2(hc_ctx *c, int level, const uint64_t *x0, cons
 }
 
 // ------------------------------------------------------------------ evk / idx / ker loading
-static bool hc_perm_row_local(u64 galEl) {
+static bool hc_perm_row_local(u64 galEl, int top_bits = 4) {
     // ring.PermuteNTTIndex stays inside the 4096-coefficient tile a b5 workgroup holds in LDS iff it fixes the top 4 bits of the
     // destination index (true for 2^j+1 with j >= 5; with j >= 9 it even fixes the top 8 bits, i.e. the 256-coefficient row)
     for (u32 i = 0; i < HC_N; i++) {
         u32 r = h_bitrev16(i), t = (u32)(((galEl * (2ull * r + 1)) & 0x1FFFF) >> 1), s = h_bitrev16(t);
-        if ((s >> 12) != (i >> 12)) return false;
+        if ((s >> (16 - top_bits)) != (i >> (16 - top_bits))) return false;
     }
     return true;
 }
@@ -714,7 +741,7 @@ extern "C" int hc_evk_load(hc_ctx *c, uint64_t galEl, const uint64_t *b_q, const
     // the P rows are only re-ordered into the lo-local coalesced order hc_k_b3 reads.
     HcScratch S(c);
     u64 *stage = nullptr; HC_HIP(c, S.alloc(&stage, 2 * HC_N * sizeof(u64)));
-    HcEvk e; e.q_rows = nullptr; e.p_rows = nullptr; e.row_local = hc_perm_row_local(galEl);
+    HcEvk e; e.q_rows = nullptr; e.p_rows = nullptr; e.row_local = hc_perm_row_local(galEl); e.row256 = e.row_local && hc_perm_row_local(galEl, 8);
     u64 *stageq = nullptr; HC_HIP(c, S.alloc(&stageq, 2 * HC_N * sizeof(u64)));
     HC_HIP(c, S.alloc(&e.q_rows, 2 * HC_N * sizeof(HcTw)));
     HC_HIP(c, S.alloc(&e.p_rows, 2 * HC_N * sizeof(HcTw)));
@@ -860,7 +887,7 @@ static int hc_fill_loopB(hc_ctx *c, HcLoopB *B, const u64 *src, u64 *dst, const 
     return HC_OK;
 }
 // one tree level of each of the n ciphertexts of a batch: nodes i = 0, norm, 2*norm, ... < step; arrays sstride / dstride words apart
-static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, size_t sstride, size_t dstride, int n, int step, int logStep, int norm, u64 galEl, const HcPtrs *bias_last) {
+static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, size_t sstride, size_t dstride, int n, int step, int logStep, int norm, u64 galEl, const HcPtrs *bias_last, const HcPtrs *outs_last = nullptr) {
     auto it = c->evk.find(galEl);
     if (it == c->evk.end()) return hc_fail(c, HC_ERR_STATE, "pack: no switching key loaded for galEl=%llu (the reference panics in permuteNTT)", (unsigned long long)galEl);
     if (!it->second.row_local) return hc_fail(c, HC_ERR_UNSUPPORTED, "pack: galEl=%llu does not permute inside 4096-coefficient tiles (needs max_cnum <= 4096)", (unsigned long long)galEl);
@@ -871,6 +898,7 @@ static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, size_t sstride, si
     HC_TRY(hc_ensure_tmp(c, (size_t)n * chunk * 4));
     HcLoopB B; HC_TRY(hc_fill_loopB(c, &B, src, dst, it->second, logStep, step, norm, galEl, n * chunk));
     B.src_stride = sstride; B.dst_stride = dstride;
+    if (it->second.row256 && c->b5_merged) B.tmpT = nullptr;      // hc_k_b5m recomputes t2.c1: b1 need not store it
     HcPtrs nobias; memset(&nobias, 0, sizeof nobias);
     const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
     for (int n0 = 0; n0 < nodes; n0 += chunk) {
@@ -881,12 +909,16 @@ static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, size_t sstride, si
         HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b2_colsinv_colsfwdP", hc_k_b2, g1, B, m0.inv, mp.fwd));
         HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, g1, B, mp.fwd, mp.inv));
         HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, g2, B, mp.inv, m0.fwd));
-        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, g2, B, m0.fwd, bias_last ? *bias_last : nobias));
+        const HcPtrs pb = bias_last ? *bias_last : nobias, po = outs_last ? *outs_last : nobias;
+        if (it->second.row256 && c->b5_merged) HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5m, g1, B, m0.fwd, pb, po));
+        else if (it->second.row256) HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_FREE, 1>, g2, B, m0.fwd, pb, po) : hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_ALT, 1>, g2, B, m0.fwd, pb, po));
+        else HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_FREE, 0>, g2, B, m0.fwd, pb, po) : hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_ALT, 0>, g2, B, m0.fwd, pb, po));
     }
     return HC_OK;
 }
 // conv.go:266-300 on device-resident level-0 ciphertexts, in place (result in slot 0), for each of the n ciphertext arrays of a batch
-static int hc_pack_run(hc_ctx *c, u64 *cts, size_t cstride, int n, int max_cnum, int real_cnum, const HcPtrs *bias, int stride_log2 = 0) {
+// outs != null: the root node writes ciphertext z straight to outs->p[z] ([2][N]) instead of slot 0 of its array
+static int hc_pack_run(hc_ctx *c, u64 *cts, size_t cstride, int n, int max_cnum, int real_cnum, const HcPtrs *bias, int stride_log2 = 0, const HcPtrs *outs = nullptr) {
     if (max_cnum < 1 || real_cnum < 1 || max_cnum % real_cnum || (max_cnum & (max_cnum - 1)) || (real_cnum & (real_cnum - 1)))
         return hc_fail(c, HC_ERR_ARG, "pack: max_cnum=%d real_cnum=%d must be powers of two", max_cnum, real_cnum);
     const int norm = max_cnum / real_cnum;
@@ -906,22 +938,24 @@ static int hc_pack_run(hc_ctx *c, u64 *cts, size_t cstride, int n, int max_cnum,
     }
     u64 *src = cts, *dst = c->ws_cts2;
     size_t sstride = cstride, dstride = pong_one * HC_N;
-    bool bias_done = false;
+    bool bias_done = false, out_done = false;
     while (step >= norm && step >= 1) {
         const bool last = (step / 2 < norm) || step == 1;
-        HC_TRY(hc_pack_level(c, src, dst, sstride, dstride, n, step, logStep + stride_log2, norm, (1ull << j) + 1, last ? bias : nullptr));
-        if (last) bias_done = true;
+        HC_TRY(hc_pack_level(c, src, dst, sstride, dstride, n, step, logStep + stride_log2, norm, (1ull << j) + 1, last ? bias : nullptr, last ? outs : nullptr));
+        if (last) { bias_done = true; out_done = outs != nullptr; }
         u64 *t = src; src = dst; dst = t;
         size_t ts = sstride; sstride = dstride; dstride = ts;
         step /= 2; logStep--; j++;
     }
+    if (out_done) return HC_OK;
     if (src != cts) for (int z = 0; z < n; z++)      // result -> slot 0 of the caller's array
-        HC_HIP(c, hipMemcpyAsync(cts + (size_t)z * cstride, src + (size_t)z * sstride, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        HC_TRY(hc_copy_d2d(c, cts + (size_t)z * cstride, src + (size_t)z * sstride, 2 * HC_N * sizeof(u64)));
     if (bias && !bias_done) {   // max_cnum == real_cnum == 1: no tree level ran
         HcTw z0; z0.w = z0.ws = 0;
         for (int z = 0; z < n; z++) if (bias->p[z])
             HC_TRY(hc_launch(c, "bias_add", hc_k_pointwise<HC_PW_ADD>, hc_pw_grid(HC_N), (const u64 *)(cts + (size_t)z * cstride), bias->p[z], cts + (size_t)z * cstride, (size_t)HC_N, c->mods[0].m, z0));
     }
+    if (outs) for (int z = 0; z < n; z++) HC_TRY(hc_copy_d2d(c, (void *)outs->p[z], cts + (size_t)z * cstride, 2 * HC_N * sizeof(u64)));
     return HC_OK;
 }
 extern "C" int hc_pack_ctxts(hc_ctx *c, uint64_t *cts, int max_cnum, int real_cnum) {
@@ -963,7 +997,8 @@ static int hc_ks_common(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uin
             if (!rc) rc = HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, hc_grid(1), B, mp.fwd, mp.inv);
             if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, hc_grid(2), B, mp.inv, m0.fwd);
             HcPtrs nobias; memset(&nobias, 0, sizeof nobias);
-            if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, hc_grid(2), B, m0.fwd, nobias);
+            if (!rc) rc = hc_fm_free(m0.m.q) ? hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_FREE, 0>, hc_grid(2), B, m0.fwd, nobias, nobias)
+                                             : hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_ALT, 0>, hc_grid(2), B, m0.fwd, nobias, nobias);
             HcTw z; z.w = z.ws = 0;      // node result = y + RotateGal(y): subtract y again
             if (!rc) rc = hc_launch(c, "ks_sub", hc_k_pointwise<HC_PW_SUB>, hc_pw_grid(2 * HC_N), (const u64 *)res, (const u64 *)y, res, (size_t)2 * HC_N, c->mods[0].m, z);
             if (!rc && (hipMemcpyAsync(o0, res, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) != hipSuccess
@@ -1296,9 +1331,75 @@ static int hc_conv_batch_run(hc_ctx *c, int n, const HcPtrs &ct_in, const HcPtrs
     HC_TRY(hc_ensure_cts(c, (size_t)n * max_ob * 2));
     const size_t cstride = (size_t)max_ob * 2 * HC_N;
     HC_TRY(hc_loopA_run_set(c, kers, n, 0, norm, max_ob / norm, c->ws_cts, cstride, false));
-    HC_TRY(hc_pack_run(c, c->ws_cts, cstride, n, max_ob, max_ob / norm, any_bias ? &bias : nullptr));
-    for (int z = 0; z < n; z++)
-        HC_HIP(c, hipMemcpyAsync(ct_out[z], c->ws_cts + (size_t)z * cstride, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    HcPtrs outs; memset(&outs, 0, sizeof outs); for (int z = 0; z < n; z++) outs.p[z] = ct_out[z];
+    return hc_pack_run(c, c->ws_cts, cstride, n, max_ob, max_ob / norm, any_bias ? &bias : nullptr, 0, &outs);      // the root node writes ct_out itself
+}
+// ---- two half-batches in anti-phase ---------------------------------------------------------------------------------------------
+// The kernels of the conv are either bound by the vector ALU (the cols kernels a2, b2, b4 and b3: 77-86 % of the VALU pipe, little
+// memory traffic) or by memory (a1, a3, b1, b5: 3.6-4.5 TB/s, 40-47 % of the pipe); both resources are needed for about the same
+// total time, and a kernel of one kind leaves the other resource idle. hc_conv_then_pack_batch therefore runs
+// the two halves of its batch on two streams, ONE PHASE APART: each half's launch sequence is recorded (hc_ctx::rec) and cut into
+// phases of consecutive launches of one kind ( M: ctc a1 | V: a2 | M: a3 a1 | ... | M: a3 b1 | V: b2 b3 b4 | M: b5 b1 | ... ), the
+// second half starts one phase late, and after every phase the two streams wait for each other (two events per step). So at any time
+// a memory-bound phase of one half shares the CUs with a VALU-bound phase of the other. Same kernels on the same data in the same
+// per-ciphertext order: same bits. (Independent contexts on several streams get the same overlap only where their phases happen to
+// line up: +11 % in round 2; this is the deterministic form.)
+struct HcBatchLaneScope {
+    hc_ctx *c; HcLane *L;
+    HcBatchLaneScope(hc_ctx *c_, HcLane *L_) : c(c_), L(L_) { swap(); }
+    ~HcBatchLaneScope() { swap(); }
+    void swap() { std::swap(c->stream, L->stream); std::swap(c->ws_tmp, L->tmp); std::swap(c->ws_tmp_rows, L->tmp_rows);
+                  std::swap(c->ws_cts2, L->cts2); std::swap(c->ws_cts2_rows, L->cts2_rows);
+                  std::swap(c->ws_cts, L->bcts); std::swap(c->ws_cts_rows, L->bcts_rows); std::swap(c->ws_ctc, L->ctc); std::swap(c->ws_ctc_cts, L->ctc_cts); }
+};
+static int hc_lane_step_event(hc_ctx *c, HcLane &L, hipEvent_t *ev) {
+    if (L.step_ev.size() < 128) { hipEvent_t e; HC_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); L.step_ev.push_back(e); *ev = e; return HC_OK; }
+    *ev = L.step_ev[L.step_next]; L.step_next = (L.step_next + 1) % L.step_ev.size();     // 128 steps back: long complete
+    return HC_OK;
+}
+static int hc_conv_batch_antiphase(hc_ctx *c, int n, const HcPtrs &ct_in, const HcPtrs &kers, const HcPtrs &bias, bool any_bias, u64 *const *ct_out,
+                                   int max_ob, int norm, const u64 cst[2]) {
+    if (c->lane.size() < 2) {
+        size_t old = c->lane.size(); c->lane.resize(2);
+        for (size_t g = old; g < 2; g++) { HC_HIP(c, hipStreamCreate(&c->lane[g].stream)); HC_HIP(c, hipEventCreate(&c->lane[g].done)); }
+    }
+    if (!c->ev_fork) HC_HIP(c, hipEventCreate(&c->ev_fork));
+    HC_HIP(c, hipEventRecord(c->ev_fork, c->stream));            // whatever the caller queued before (uploads, the previous layer) comes first
+    const int nh[2] = {(n + 1) / 2, n / 2}, off[2] = {0, (n + 1) / 2};
+    std::vector<HcOp> ops[2];
+    for (int h = 0; h < 2; h++) {
+        HcPtrs pin, pker, pbias; memset(&pin, 0, sizeof pin); memset(&pker, 0, sizeof pker); memset(&pbias, 0, sizeof pbias);
+        for (int z = 0; z < nh[h]; z++) { pin.p[z] = ct_in.p[off[h] + z]; pker.p[z] = kers.p[off[h] + z]; pbias.p[z] = bias.p[off[h] + z]; }
+        HcBatchLaneScope scope(c, &c->lane[(size_t)h]);
+        HC_HIP(c, hipStreamWaitEvent(c->stream, c->ev_fork, 0));
+        // size the lane's temporaries for the whole sequence up front: a workspace that grew while the sequence is being recorded
+        // would leave the launches recorded before it pointing at the freed block
+        long ch = (c->chunk_nodes < 1 ? 1 : c->chunk_nodes) / nh[h]; if (ch < 1) ch = 1;
+        const long nch = max_ob / norm, cha = ch < nch ? ch : nch, chb = ch < (nch / 2 > 0 ? nch / 2 : 1) ? ch : (nch / 2 > 0 ? nch / 2 : 1);
+        const size_t rows_a = (size_t)nh[h] * (size_t)cha * 2, rows_b = (size_t)nh[h] * (size_t)chb * 4;
+        HC_TRY(hc_ensure_tmp(c, rows_a > rows_b ? rows_a : rows_b));
+        c->rec = &ops[h];
+        const int rc = hc_conv_batch_run(c, nh[h], pin, pker, pbias, any_bias, ct_out + off[h], max_ob, norm, cst);
+        c->rec = nullptr;
+        if (rc) return rc;
+    }
+    // phases = maximal runs of one kind
+    std::vector<std::pair<size_t, size_t>> ph[2];
+    for (int h = 0; h < 2; h++)
+        for (size_t i = 0; i < ops[h].size();) { size_t j = i; while (j < ops[h].size() && ops[h][j].kind == ops[h][i].kind) j++; ph[h].push_back({i, j}); i = j; }
+    const size_t steps = ph[0].size() > ph[1].size() + 1 ? ph[0].size() : ph[1].size() + 1;
+    HcLane &L0 = c->lane[0], &L1 = c->lane[1];
+    for (size_t s = 0; s < steps; s++) {
+        if (s < ph[0].size()) for (size_t i = ph[0][s].first; i < ph[0][s].second; i++) HC_HIP(c, ops[0][i].run(L0.stream));
+        if (s >= 1 && s - 1 < ph[1].size()) for (size_t i = ph[1][s - 1].first; i < ph[1][s - 1].second; i++) HC_HIP(c, ops[1][i].run(L1.stream));
+        if (s + 1 < steps) {         // lock step: neither lane starts its next phase before the other has finished this one
+            hipEvent_t e0, e1; HC_TRY(hc_lane_step_event(c, L0, &e0)); HC_TRY(hc_lane_step_event(c, L1, &e1));
+            HC_HIP(c, hipEventRecord(e0, L0.stream)); HC_HIP(c, hipEventRecord(e1, L1.stream));
+            HC_HIP(c, hipStreamWaitEvent(L0.stream, e1, 0)); HC_HIP(c, hipStreamWaitEvent(L1.stream, e0, 0));
+        }
+    }
+    HC_HIP(c, hipEventRecord(L0.done, L0.stream)); HC_HIP(c, hipEventRecord(L1.done, L1.stream));
+    HC_HIP(c, hipStreamWaitEvent(c->stream, L0.done, 0)); HC_HIP(c, hipStreamWaitEvent(c->stream, L1.done, 0));
     return HC_OK;
 }
 extern "C" int hc_conv_then_pack(hc_ctx *c, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
@@ -1337,7 +1438,8 @@ extern "C" int hc_conv_then_pack_batch(hc_ctx *c, int n, const uint64_t *const *
     HC_TRY(hc_loopA_consts(c, ct_scale, ker_scale, max_ob, norm, out_scale, cst, &target));
     const double final_scale = target * (double)(max_ob / norm);
     if (final_scale != out_scale) return hc_fail(c, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
-    HC_TRY(hc_conv_batch_run(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
+    if (n >= 2 && c->antiphase && !c->profile) HC_TRY(hc_conv_batch_antiphase(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
+    else HC_TRY(hc_conv_batch_run(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
     if (scale_out) *scale_out = final_scale;
     return HC_OK;
 }
@@ -1452,6 +1554,8 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!c || !name) return HC_ERR_ARG;
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
     if (!strcmp(name, "lanes")) { if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
+    if (!strcmp(name, "b5_merged")) { c->b5_merged = value ? 1 : 0; return HC_OK; }
+    if (!strcmp(name, "antiphase")) { c->antiphase = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "ks_fused")) { c->ks_fused = value ? 1 : 0; return HC_OK; }      // plain key switch: rows pass inside the inner product (default off: measured slower)
     return hc_fail(c, HC_ERR_ARG, "unknown option %s", name);
