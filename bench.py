@@ -37,15 +37,17 @@ def algorithmic_mib(B):
     return 5 * B - 1 + 2.5 * np.log2(B) + 0.5
 
 
-def traffic_from_profiles(B, chunk):
-    """HBM bytes per conv from the committed rocprofv3 PMC passes (tools/pmc_traffic.py); PMC counters cannot be
-    read from inside this process, so the figure is the one measured with the same command and committed under
-    profiles/. None when no measurement for this workload exists."""
-    path = os.path.join(ROOT, "profiles", f"traffic_conv_B{B}.json")
-    try:
-        return json.load(open(path))["bytes_per_conv"]
-    except Exception:
-        return None
+def traffic_from_profiles(B):
+    """HBM-side (L2 <-> fabric) bytes per conv from the committed rocprofv3 PMC passes (tools/gpu_r3_pmc.sh -> tools/pmc_traffic.py).
+    PMC counters cannot be read from inside this process, so the figure is the one measured with the command recorded beside it
+    (`measured_with`: contexts, ciphertexts per launch set, commit) and committed under profiles/. (None, None) when there is none."""
+    for name in (f"round3_traffic_conv_B{B}.json", f"traffic_conv_B{B}.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return d["bytes_per_conv"], {"file": "profiles/" + name, **d.get("measured_with", {"note": d.get("method", "")})}
+        except Exception:
+            continue
+    return None, None
 
 
 def synth_rows(rng, q, shape):
@@ -195,19 +197,28 @@ def main():
     kern = {k: {"ms_per_conv": v[0] / (nprof * NB), "launches_per_batch": v[1] // nprof, "avg_launch_us": 1e3 * v[0] / max(1, v[1])} for k, v in prof.items()}
     dom = max(kern, key=lambda k: kern[k]["ms_per_conv"]) if kern else None
 
-    def counters():
-        """per-kernel hardware counters of the same command (rocprofv3 --pmc passes, tools/gpu_r2_pmc.sh -> profiles/round2_conv33_counters.json):
-        fabric bytes, achieved TB/s, VALU-pipe utilisation. Counters cannot be read from inside this process; None if not committed."""
-        try:
-            return json.load(open(os.path.join(ROOT, "profiles", "round2_conv33_counters.json")))
-        except OSError:
-            return None
+    # ONE convolution alone on an otherwise idle GPU (what the `conv` CLI does): latency, not throughput
+    L0["ctx"].sync()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        ctx.conv_then_pack_batch_dev(L0["in"][:1], 2.0 ** 30, L0["ker"][:1], 2.0 ** 30, B, 1, 2.0 ** 30, [L0["bias"]], L0["out"][:1])
+    L0["ctx"].sync()
+    single_ms = (time.perf_counter() - t1) / 10 * 1e3
 
     if rank == 0:
         per_step = sum(len(L["in"]) for L in lanes)
         conv_ms_events = ev_ms / (args.steps * per_step)
         alg_bytes = algorithmic_mib(B) * 2 ** 20
         achieved = alg_bytes / (conv_ms_events * 1e-3) / 1e9
+        traffic, traffic_how = traffic_from_profiles(B)
+        mib = 2 ** 20
+        loops = {}        # per-loop share of the roofline from the one-stream kernel profile above (SURVEY.md 8d splits the algorithmic bytes the same way)
+        if kern:
+            la = sum(v["ms_per_conv"] for k, v in kern.items() if k[0] == "a" or k.startswith("ctc"))
+            lb = sum(v["ms_per_conv"] for k, v in kern.items() if k[0] == "b")
+            for name, ms, alg in (("loop_A", la, (2 * B + 2) * mib), ("loop_B", lb, (3 * (B - 1) + 2.5 * np.log2(B) + 0.5) * mib)):
+                if ms > 0:
+                    loops[name] = {"ms_per_conv_one_stream": ms, "algorithmic_bytes": alg, "frac": alg / (ms * 1e-3) / 1e9 / 8000.0}
         out = {
             "metric": "homomorphic convs/sec (conv_then_pack + BN bias, k x k, batch B, N=2^16)",
             "value": world * args.steps * per_step / elapsed, "unit": "conv/s",
@@ -219,10 +230,12 @@ def main():
                        "logN": 16, "moduli": "ckks.DefaultBootstrapParams[6] Q0,Q1 + P=0x1fffffffffe00001",
                        "convs_per_step_per_gpu": per_step, "ciphertexts_per_launch_set": NB, "contexts_per_gpu": S, "chunk_nodes": args.chunk, "lanes_per_conv": args.lanes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic_from_profiles(B, args.chunk),
+                         "traffic": traffic, "traffic_measured_with": traffic_how,
                          "unit_of_launch": "one conv_then_pack (its share of the batched launch set: all kernels of loop A and of the pack tree)",
                          "algorithmic_bytes_per_conv": alg_bytes, "conv_ms_hip_events": conv_ms_events,
-                         "dominant_kernel": dom, "kernels": kern, "counters": counters()},
+                         "dominant_kernel": dom, "kernels": kern,
+                         "kernels_measured_with": {"contexts": 1, "ciphertexts_per_launch_set": NB, "note": "HIP events around every launch of one context, separate untimed pass"},
+                         "loops": loops, "single_conv_ms": single_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)

@@ -119,6 +119,8 @@ struct hc_ctx {
     hipEvent_t ev_shard = nullptr;     // hc_conv_then_pack_sharded: this device's partial ciphertext is complete / has been collected
     u64 *ws_gather = nullptr; size_t ws_gather_rows = 0;
     std::vector<HcOp> *rec = nullptr;     // non-null: hc_launch / hc_copy_d2d append to it instead of enqueueing on the stream
+    long peer_access = 1;                 // hc_conv_then_pack_sharded: enable direct peer copies between distinct devices (0: leave the copies to hipMemcpyPeerAsync's staging)
+    unsigned peer_enabled = 0;            // bit d: peer access from this context's device to device d was enabled by (or found enabled for) this context
     long b5_merged = 1;                   // row-local pack levels: one b5 workgroup per (node, tile) for both polynomials (hc_k_b5m); 0 = two jobs (A/B switch)
     long antiphase = 0;                   // hc_conv_then_pack_batch with n >= 2: two half-batches on two streams, memory-bound phases of one against VALU-bound phases of the other.
                                           // OFF by default: measured no gain (profiles/round3_antiphase_trace.txt) -- co-resident kernels time-slice the CU's wave slots and the VALU pipe
@@ -1475,9 +1477,16 @@ extern "C" int hc_conv_then_pack_sharded(hc_ctx *const *ctxs, int G, const uint6
         HC_TRY(hc_loopA_run_set(c, hc_ptrs1(ker[g]->d), 1, g, G, nloc, c->ws_cts, 0, true));     // channels g, g + G, ...: slot m = channel g + G m
         HC_TRY(hc_pack_run(c, c->ws_cts, 0, 1, nloc, nloc, nullptr, log2g));                      // levels with step >= G
         HC_HIP(c, hipEventRecord(c->ev_shard, c->stream));
-        if (c != c0 && c->device != c0->device) {                                                   // direct xGMI copies when the devices can
+        if (c != c0 && c->device != c0->device && c0->peer_access) {                                // direct xGMI copies when the devices can
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, c0->device, c->device) == hipSuccess && can) { hipSetDevice(c0->device); (void)hipDeviceEnablePeerAccess(c->device, 0); (void)hipGetLastError(); }
+            HC_HIP(c0, hipDeviceCanAccessPeer(&can, c0->device, c->device));
+            if (can) {
+                HC_HIP(c0, hipSetDevice(c0->device));
+                const hipError_t pe = hipDeviceEnablePeerAccess(c->device, 0);
+                if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();               // a previous call (or another context of this process) did it
+                else if (pe != hipSuccess) return hc_fail(c0, HC_ERR_HIP, "hc_conv_then_pack_sharded: hipDeviceEnablePeerAccess(device %d -> %d): %s", c0->device, c->device, hipGetErrorString(pe));
+                c0->peer_enabled |= 1u << (unsigned)(c->device & 31);
+            }     // else: hipMemcpyPeerAsync stages through the host (slower, same bits)
         }
     }
     HC_ENTER(c0);
@@ -1554,6 +1563,7 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!c || !name) return HC_ERR_ARG;
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
     if (!strcmp(name, "lanes")) { if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
+    if (!strcmp(name, "peer_access")) { c->peer_access = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "b5_merged")) { c->b5_merged = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "antiphase")) { c->antiphase = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }

@@ -545,6 +545,19 @@ static void on_encmat(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; 
     emit_begin("EncodeDiagMatrixBSGSAtLvl"); fprintf(g_out, ", \"matrix\": %d, \"level\": %lu, \"scale\": %.17g, \"maxN1N2Ratio\": %.17g, \"logSlots\": %lu", g_diag_mats, rd64(r->rsp + 0x10), rdf64(r->rsp + 0x20), rdf64(r->rsp + 0x28), rd64(r->rsp + 0x30)); emit_end();
     hook_return(r, ret_encmat, ud_new((uint64_t)g_diag_mats++, 0, 0)); }
 static void on_ctp_diag(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)r; (void)ud; if (g_diag_max) diag_done(); }
+/* -logslots K (with -diag): make the binary build a SPARSE-slot bootstrapper, the one main.go:480-500 creates as btp2..btp5 for the resnet
+ * (this snapshot of the binary never does). At the entry of ckks.NewBootstrapper_mod(params Parameters (by value, 13 words: logN at +0,
+ * logSlots at +0x58 (newBootstrapper @5105c0 reads it there for dslots), btpParams *BootstrappingParameters, key) the two LogSlots
+ * (the Parameters copy on the stack and btpParams+0xf8) are overwritten with K, which is what `params2 = ...; btpParams.LogSlots = LogN - 2`
+ * amounts to. genDFTMatrices then runs on K and -diag records its diagonals; CheckKeys fails afterwards (the run's rotation keys are the
+ * full-slot ones) and the run panics, which ends the trace. */
+static int g_logslots = 0;
+static void on_newbtp_mod(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_logslots) return;
+    uint64_t k = (uint64_t)g_logslots, bp = rd64(r->rsp + 0x70);
+    uint64_t old_p = rd64(r->rsp + 0x60), old_b = rd64(bp + 0xf8), logn = rd64(r->rsp + 0x8);
+    wr(r->rsp + 0x60, &k, 8); wr(bp + 0xf8, &k, 8);
+    emit_begin("NewBootstrapper_mod.patched"); fprintf(g_out, ", \"logN\": %lu, \"params_logSlots_was\": %lu, \"btpParams_LogSlots_was\": %lu, \"LogSlots\": %lu", logn, old_p, old_b, k); emit_end(); }
 
 /* -flow: log-only walk through the convReLU chain between the entry of ckks.(*Bootstrapper).BootstrappConv_CtoS (eval.go:450) and the
  * return of main.evalConv_BNRelu_new (eval.go:272-607; BootstrappConv_StoC, eval.go:543-550, is inlined into it): every evaluator call on the way with the level and scale
@@ -889,6 +902,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[ai], "-poly") && ai + 1 < argc) g_poly_max = atoi(argv[++ai]);          /* trace this many EvaluatePoly calls (planted input and keys) */
         else if (!strcmp(argv[ai], "-enc") && ai + 1 < argc) g_enc_max = atoi(argv[++ai]);            /* trace the slot encoder: this many invfft / Encode calls */
         else if (!strcmp(argv[ai], "-diag") && ai + 1 < argc) g_diag_max = atoi(argv[++ai]);          /* digest this many encoded DFT diagonals */
+        else if (!strcmp(argv[ai], "-logslots") && ai + 1 < argc) g_logslots = atoi(argv[++ai]);      /* with -diag: sparse-slot bootstrapper (see on_newbtp_mod) */
         else if (!strcmp(argv[ai], "-dump") && ai + 1 < argc) { g_dump = fopen(argv[++ai], "wb"); if (!g_dump) { perror("dump"); return 2; } }
         else if (!strcmp(argv[ai], "-flow")) g_flow_mode = 1;
         else if (!strcmp(argv[ai], "-chain")) { g_flow_mode = 1; g_chain = 1; }
@@ -948,7 +962,7 @@ int main(int argc, char **argv) {
                       bp_add(A_POWERBASIS, on_p_powerbasis, NULL); bp_add(A_ADD, on_p_add, NULL); bp_add(A_MULTBYCONST, on_p_multbyconst, NULL); }
     if (g_lt_max) { bp_add(post_check(0x5264c0), on_lt, NULL); bp_add(post_check(0x4ff060), on_lt_ks_hoisted, NULL); bp_add(post_check(0x4fe660), on_lt_ks_nomoddown, NULL);
                     bp_add(post_check(0x4e4c40), on_lt_moddown, NULL); }
-    if (g_diag_max) { bp_add(A_ENCDIAG, on_encdiag, NULL); bp_add(A_ENCMAT, on_encmat, NULL); }
+    if (g_diag_max) { bp_add(A_ENCDIAG, on_encdiag, NULL); bp_add(A_ENCMAT, on_encmat, NULL); if (g_logslots) bp_add(post_check(0x510240), on_newbtp_mod, NULL); }
     if (g_enc_max) { bp_add(A_INVFFT, on_invfft, NULL); bp_add(A_ENCODE, on_encode_slots, NULL); }
     if (g_ops_max) { bp_add(A_RESCALE, on_rescale, NULL); bp_add(A_MULRELIN, on_mulrelin, NULL); bp_add(A_ROTATE, on_rotate, NULL); bp_add(A_MODUP, on_modup, NULL); }
 hooks_done:

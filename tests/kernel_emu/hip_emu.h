@@ -37,6 +37,7 @@ typedef int hipError_t;
 typedef void *hipStream_t;
 typedef struct hipEmuEvent *hipEvent_t;
 #define hipSuccess 0
+#define hipErrorPeerAccessAlreadyEnabled 704
 #define hipMemcpyHostToDevice 1
 #define hipMemcpyDeviceToHost 2
 #define hipMemcpyDeviceToDevice 3

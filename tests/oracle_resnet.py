@@ -73,6 +73,23 @@ def ext_double_ctxt(C, ct, m_idx, r_idx):
     return C.rescale(res)
 
 
+def strconv_relu_tail_sparse(C, btp, ct_conv, pow_, in_wid, kp_next, stages=None):
+    """eval.go:437-565 for kind "StrConv_sparse" after the two half convolutions were joined (eval.go:361-387): bootstrapping with
+    log_sparse = btp.ls, ReLU, MulByPow2, then ext_double_ctxt (conv.go:374-414) with the gen_comprs_sparse masks (rot_util.go:557-612)
+    that keep the stride-2 positions and re-pack them for the next, half-width block, SlotsToCoeffs. Returns level 1, scale 2^30."""
+    (boot,) = btp.ctos(ck.Ct(ct_conv.rows, ct_conv.scale * 2.0 ** pow_))
+    if stages is not None:
+        stages["ctos"] = [boot.copy()]
+    r = C.mul_const_int(ck.eval_relu(C, boot, 0.0), 1 << int(pow_))
+    if stages is not None:
+        stages["relu"] = [r.copy()]
+    m_idx, r_idx = gen_comprs_sparse(C.N // 2, in_wid, kp_next, btp.ls)
+    ext = ext_double_ctxt(C, r, m_idx, r_idx)
+    if stages is not None:
+        stages["ext"] = [ext.copy()]
+    return btp.stoc(ext, None)
+
+
 # ---------------------------------------------------------------- plain model
 def plain_conv_same(x, ker):
     """x (H, W, Cin), ker (k, k, Cin, Cout): zero-padded 'same' correlation"""
@@ -217,13 +234,7 @@ class ResNetOracle:
             ct_conv = self.mul_monomial_l0(ct_conv, self.N - max_batch * (in_wid + 1), -1)
         if stages is not None:
             stages["conv"] = ct_conv
-        btp = self.bootstrapper(ls)
-        (boot,) = btp.ctos(ck.Ct(ct_conv.rows, ct_conv.scale * 2.0 ** pow_))
-        r = C.mul_const_int(ck.eval_relu(C, boot, 0.0), 1 << int(pow_))
-        if stages is not None:
-            stages["relu"] = r
-        m_idx, r_idx = gen_comprs_sparse(self.N // 2, in_wid, net.raw[blk + 1], ls)
-        return btp.stoc(ext_double_ctxt(C, r, m_idx, r_idx), None)
+        return strconv_relu_tail_sparse(C, self.bootstrapper(ls), ct_conv, pow_, in_wid, net.raw[blk + 1], stages=stages)
 
     # ---- layouts
     def pack_input(self, image):

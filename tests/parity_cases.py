@@ -1,6 +1,9 @@
 """Parity cases shared by the GPU tests (libhconv.so on a real MI355X) and the CPU kernel-emulation tests
 (the same kernel sources run under tests/kernel_emu). Every case compares the C-ABI result with the oracle,
 bit for bit, on seeded inputs; `ctx` is an optimal_conv_amd.Context, `O` an oracle_lib.Oracle."""
+import json
+import os
+
 import numpy as np
 
 from oracle_lib import P0, Q0, Q1, splitmix_rows
@@ -536,27 +539,73 @@ def case_ckks_ops(make_ctx, logN=16, seed=3, levels=((23, 2.0 ** 55), (9, 2.0 **
     ctx.close()
 
 
-def case_conv_relu_tail_sparse(make_ctx, log_sparse, logN=16, seed=3, min_bits=8.0):
+SPARSE_TAIL_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_sparse_tail_digests.json")
+
+
+def sha_ct(ct):
+    """SHA-256 over the residue rows of a ciphertext (both polynomials, every limb, little-endian uint64)"""
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(ct.rows, dtype="<u8").tobytes()).hexdigest()
+
+
+def sparse_tail_input(Co, log_sparse, seed):
+    """the planted level-0 convolution output of the sparse tails: a message on the multiples of 2^log_sparse at scale 2^43"""
+    N, D = Co.N, 1 << log_sparse
+    m = np.zeros(N)
+    m[::D] = np.random.default_rng(seed).uniform(-12, 12, N // D)
+    return m, Co.encrypt_coeffs(m, 0, 2.0 ** 43, seed=21)
+
+
+def sparse_tail_oracle_digests(kind, log_sparse, in_wid, logN=16, seed=3):
+    """the oracle side of case_conv_relu_tail_sparse / case_strconv_tail_sparse as stage digests (tests/golden/gen_sparse_tail_digests.py)"""
+    import oracle_ckks as ck
+    import oracle_resnet as orn
+    Co = ck.Ckks(logN=logN, seed=seed)
+    _, ct0 = sparse_tail_input(Co, log_sparse, seed)
+    so = {}
+    if kind == "conv":
+        out = ck.conv_relu_tail_sparse(Co, ck.Bootstrapper(Co, log_sparse=log_sparse), ct0, 0.0, 4, in_wid, in_wid - 1, stages=so)
+    else:
+        out = orn.strconv_relu_tail_sparse(Co, ck.Bootstrapper(Co, log_sparse=log_sparse), ct0, 4, in_wid, in_wid // 2 - 1, stages=so)
+    d = {k: sha_ct(v[0]) for k, v in so.items()}
+    d["out"] = sha_ct(out)
+    return d
+
+
+def _sparse_tail_fixture(kind, log_sparse, in_wid, logN, seed):
+    if logN != 16 or seed != 3 or not os.path.exists(SPARSE_TAIL_FIXTURE) or os.environ.get("HCONV_TEST_FULL_ORACLE"):
+        return None
+    return json.load(open(SPARSE_TAIL_FIXTURE))["cases"].get(f"{kind}_ls{log_sparse}_w{in_wid}")
+
+
+def case_conv_relu_tail_sparse(make_ctx, log_sparse, logN=16, seed=3, min_bits=8.0, in_wid=None):
     """the tail of evalConv_BNRelu_new for kind "Conv_sparse" (sparse-slot bootstrapping: SubSum, n_s-point DFTs, both halves
-    in one ciphertext) on the device ABI vs the oracle: every stage bit-identical, result close to max(x, 0) on the support"""
+    in one ciphertext) on the device ABI vs the oracle: every stage bit-identical, result close to max(x, 0) on the support.
+    in_wid = None: the square geometry with 4 * 2^log_sparse channels (even log_sparse); otherwise the image width of a resnet block
+    (32 / 16 / 8 with log_sparse 2 / 3 / 4: test.go:76-370). With the committed oracle digests for this case
+    (golden/oracle_sparse_tail_digests.json, made by golden/gen_sparse_tail_digests.py in the build container) the oracle chain is
+    not re-run on the GPU box; HCONV_TEST_FULL_ORACLE=1 forces it."""
     import oracle_ckks as ck
     Co = ck.Ckks(logN=logN, seed=seed)
     ctx = make_ctx(Co.Q, Co.P)
     Cd = ck.Ckks(logN=logN, seed=seed, backend=CkksDeviceBackend(ctx), oracle=Co.O)
     Cd.keys = Co.keys
     N, n, D = Co.N, Co.n, 1 << log_sparse
-    B = 4 * D
-    W = int(round((N // B) ** 0.5))
+    W = int(round((N // (4 * D)) ** 0.5)) if in_wid is None else in_wid
     kp = W - 1
-    m = np.zeros(N)
-    m[::D] = np.random.default_rng(seed).uniform(-12, 12, N // D)
-    ct0 = Co.encrypt_coeffs(m, 0, 2.0 ** 43, seed=21)
+    m, ct0 = sparse_tail_input(Co, log_sparse, seed)
     so, sd = {}, {}
     out_d = ck.conv_relu_tail_sparse(Cd, ck.Bootstrapper(Cd, log_sparse=log_sparse), ct0, 0.0, 4, W, kp, stages=sd)
-    out_o = ck.conv_relu_tail_sparse(Co, ck.Bootstrapper(Co, log_sparse=log_sparse), ct0, 0.0, 4, W, kp, stages=so)
-    eq(sd["ctos"][0].rows, so["ctos"][0].rows, "sparse CtoS+sine")
-    eq(sd["relu"][0].rows, so["relu"][0].rows, "sparse ReLU")
-    eq(out_d.rows, out_o.rows, "sparse StoC output")
+    fx = _sparse_tail_fixture("conv", log_sparse, W, logN, seed)
+    if fx is None:
+        out_o = ck.conv_relu_tail_sparse(Co, ck.Bootstrapper(Co, log_sparse=log_sparse), ct0, 0.0, 4, W, kp, stages=so)
+        eq(sd["ctos"][0].rows, so["ctos"][0].rows, "sparse CtoS+sine")
+        eq(sd["relu"][0].rows, so["relu"][0].rows, "sparse ReLU")
+        eq(out_d.rows, out_o.rows, "sparse StoC output")
+    else:
+        assert sha_ct(sd["ctos"][0]) == fx["ctos"], "sparse CtoS+sine differs from the oracle's digest"
+        assert sha_ct(sd["relu"][0]) == fx["relu"], "sparse ReLU differs from the oracle's digest"
+        assert sha_ct(out_d) == fx["out"], "sparse StoC output differs from the oracle's digest"
     ns = n // D
     br = ck.Encoder(logN - log_sparse).br
     keep = ck.gen_keep_vec_sparse(n, W, kp, log_sparse)[: 2 * ns]
@@ -569,6 +618,33 @@ def case_conv_relu_tail_sparse(make_ctx, log_sparse, logN=16, seed=3, min_bits=8
     assert np.max(err.reshape(-1, D)[:, 1:]) < 1e-3          # nothing leaks off the sparse support
     ctx.close()
     return bits
+
+
+def case_strconv_tail_sparse(make_ctx, log_sparse, in_wid, logN=16, seed=3):
+    """the tail of evalConv_BNRelu_new for kind "StrConv_sparse" (eval.go:335-392 after the joined half convolutions): sparse-slot
+    bootstrapping with log_sparse, ReLU, ext_double_ctxt (conv.go:374-414) with the gen_comprs_sparse masks (rot_util.go:557-612),
+    SlotsToCoeffs, on the device ABI vs the oracle: bootstrapped ciphertext, ReLU, the re-packed ciphertext and the result bit for bit"""
+    import oracle_ckks as ck
+    import oracle_resnet as orn
+    Co = ck.Ckks(logN=logN, seed=seed)
+    ctx = make_ctx(Co.Q, Co.P)
+    Cd = ck.Ckks(logN=logN, seed=seed, backend=CkksDeviceBackend(ctx), oracle=Co.O)
+    Cd.keys = Co.keys
+    _, ct0 = sparse_tail_input(Co, log_sparse, seed)
+    kp_next = in_wid // 2 - 1
+    so, sd = {}, {}
+    out_d = orn.strconv_relu_tail_sparse(Cd, ck.Bootstrapper(Cd, log_sparse=log_sparse), ct0, 4, in_wid, kp_next, stages=sd)
+    fx = _sparse_tail_fixture("strconv", log_sparse, in_wid, logN, seed)
+    if fx is None:
+        out_o = orn.strconv_relu_tail_sparse(Co, ck.Bootstrapper(Co, log_sparse=log_sparse), ct0, 4, in_wid, kp_next, stages=so)
+        for st in ("ctos", "relu", "ext"):
+            eq(sd[st][0].rows, so[st][0].rows, f"StrConv_sparse {st}")
+        eq(out_d.rows, out_o.rows, "StrConv_sparse StoC output")
+    else:
+        for st in ("ctos", "relu", "ext"):
+            assert sha_ct(sd[st][0]) == fx[st], f"StrConv_sparse {st} differs from the oracle's digest"
+        assert sha_ct(out_d) == fx["out"], "StrConv_sparse StoC output differs from the oracle's digest"
+    ctx.close()
 
 
 def case_conv_relu_tail(make_ctx, logN=16, seed=3, min_bits=8.0):

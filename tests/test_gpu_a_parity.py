@@ -272,12 +272,22 @@ def test_baseline_boot_relu_on_gpu():
     pc.case_bl_boot_relu(lambda Q, P: Context(Q, P))
 
 
-@pytest.mark.parametrize("log_sparse", [2])
-def test_conv_relu_tail_sparse_on_gpu(log_sparse):
-    """scope row 8f-3 groundwork: the "Conv_sparse" tail (sparse-slot bootstrapping of the ResNet layers, log_sparse 2 = block 1)
-    on the device ABI, every stage bit-identical to the oracle"""
+@pytest.mark.parametrize("log_sparse,in_wid", [(2, None), (2, 32), (3, 16), (4, 8), (1, 32)])
+def test_conv_relu_tail_sparse_on_gpu(log_sparse, in_wid):
+    """scope row 8f-3: the "Conv_sparse" tail (sparse-slot bootstrapping of the ResNet layers) on the device ABI, every stage bit-identical
+    to the oracle at full size: the square log_sparse-2 case of round 2, and the geometries of `resnet 3 20 1 n false` (test.go:76-370:
+    log_sparse 2 / 3 / 4 on 32 / 16 / 8-wide images), plus log_sparse 1 (the bootstrapper of the first stride layer) on its 32-wide image"""
     from optimal_conv_amd import Context
-    print("median precision bits", pc.case_conv_relu_tail_sparse(lambda Q, P: Context(Q, P), log_sparse))
+    print("median precision bits", pc.case_conv_relu_tail_sparse(lambda Q, P: Context(Q, P), log_sparse, in_wid=in_wid))
+
+
+@pytest.mark.parametrize("log_sparse,in_wid", [(1, 32), (2, 16)])
+def test_strconv_tail_sparse_on_gpu(log_sparse, in_wid):
+    """scope row 8f-3: the "StrConv_sparse" tail of the two stride layers of `resnet 3 20 1 n false` (eval.go:335-392 after the half
+    convolutions are joined): bootstrapping with log_sparse 1 / 2, ReLU, ext_double_ctxt (conv.go:374-414) with the gen_comprs_sparse
+    masks (rot_util.go:557-612), SlotsToCoeffs: the bootstrapped, the activated, the re-packed and the returned ciphertext == the oracle's"""
+    from optimal_conv_amd import Context
+    pc.case_strconv_tail_sparse(lambda Q, P: Context(Q, P), log_sparse, in_wid)
 
 
 def test_conv_1024_channels_sparse_tile_local_galois(env):

@@ -22,18 +22,19 @@ WORKER = textwrap.dedent("""
     from oracle_lib import Oracle, Q0, Q1, P0, splitmix_rows
     from optimal_conv_amd import Context
     from optimal_conv_amd.sharded import conv_then_pack_sharded, local_channels
-    torch.cuda.set_device(0)
+    dev = int(os.environ["LOCAL_RANK"]) if os.environ.get("HC_TEST_DEVICE_PER_RANK") else 0      # one GPU per rank on a multi-GPU node
+    torch.cuda.set_device(dev)
     backend = os.environ.get("HC_TEST_BACKEND", "nccl")
-    dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]), device_id=torch.device("cuda", 0) if backend == "nccl" else None)
+    dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]), device_id=torch.device("cuda", dev) if backend == "nccl" else None)
     rank, world = dist.get_rank(), dist.get_world_size()
     B, seed = int(os.environ.get("HC_TEST_B", "16")), 0xABCD
-    ctx = Context([Q0, Q1], [P0], device=0)
+    ctx = Context([Q0, Q1], [P0], device=dev)
     ct_in, ker = pc.planted_conv_inputs(seed, B)
     evk_all = pc.load_tree_keys(ctx, seed, B)
     ctx.idx_load(None)
     bias = splitmix_rows(seed + 5, Q0, pc.N)
     kh = ctx.ker_load(ker[local_channels(B, rank, world)])
-    res, sc = conv_then_pack_sharded(ctx, ctx.buf(ct_in), 2.0 ** 30, kh, 2.0 ** 30, B, 2.0 ** 30, ctx.buf(bias), device="cuda:0")
+    res, sc = conv_then_pack_sharded(ctx, ctx.buf(ct_in), 2.0 ** 30, kh, 2.0 ** 30, B, 2.0 ** 30, ctx.buf(bias), device="cuda:%%d" %% dev)
     if rank == 0:
         O = Oracle()
         want, wsc = O.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, O.idx_plaintexts(), evk_all, B, 1, 2.0 ** 30, bias)
@@ -64,3 +65,53 @@ def test_sharded_conv_config3_shape_8_ranks_on_one_gpu(tmp_path):
     8 x 1 MiB, the last 3 tree levels on rank 0 -- executed once on the one GPU this pool has: the 8 ranks share device 0 and talk
     over gloo (the partials are staged through the host; on an 8-GPU node the same code runs over RCCL). Bit-exact vs the oracle."""
     _run(tmp_path, 8, {"HC_TEST_BACKEND": "gloo", "HC_TEST_B": "256"})
+
+
+# ---- two or more physical GPUs (skipped on the one-GPU boxes of this pool; the driver's multi-GPU node runs them) ----
+def _ngpu():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+needs2 = pytest.mark.skipif(_ngpu() < 2, reason="needs two MI355X in the box")
+
+
+@needs2
+def test_sharded_conv_rccl_two_gpus(tmp_path):
+    """conv.go:286-297 over two PHYSICAL devices: ranks 0 and 1 on GPUs 0 and 1, the gather of the two partials over RCCL / xGMI"""
+    _run(tmp_path, 2, {"HC_TEST_DEVICE_PER_RANK": "1", "HC_TEST_B": "64"})
+
+
+@needs2
+@pytest.mark.parametrize("peer", [1, 0])
+def test_conv_sharded_over_two_devices_c_abi(peer):
+    """hc_conv_then_pack_sharded with its contexts on DISTINCT devices: cross-device events, hipMemcpyPeerAsync of the partials with
+    (peer = 1: hipDeviceEnablePeerAccess must succeed where hipDeviceCanAccessPeer says so) and without direct peer access, == the oracle"""
+    import parity_cases as pc
+    from oracle_lib import Oracle, P0, Q0, Q1
+    from optimal_conv_amd import Context
+    G = 2 if _ngpu() < 4 else 4
+    devs = iter(range(G))
+
+    def make():
+        c = Context([Q0, Q1], [P0], device=next(devs))
+        c.set_option("peer_access", peer)
+        return c
+    pc.case_conv_sharded_abi(make, Oracle(), 64, G)
+
+
+@needs2
+def test_bench_two_gpus_over_rccl(tmp_path):
+    """the driver's N = 2 launch line: one rank per GPU over RCCL, ONE JSON line from rank 0 with n_gpus = 2 and about twice the N = 1 rate"""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--steps", "3", "--warmup", "1", "--batch", "2", "--streams", "2", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
+    j1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    j2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["unit"] == "conv/s"
+    assert 1.5 * j1["value"] < j2["value"] < 2.5 * j1["value"], (j1["value"], j2["value"])

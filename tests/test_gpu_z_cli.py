@@ -131,7 +131,12 @@ def test_conv_relu_cli_replays_the_reference_chain(tmp_path):
         assert (lv, sc) == (want["level"], want["scale"]) and polys == want["polys"], f"{name}: the host chain differs from the reference binary"
 
 
-@pytest.mark.parametrize("cf100,wide", [(False, 1), (True, 1), (False, 2), (False, 3)])
+# wide_case 2 / 3 (testResNet_crop_sparse_wide) and the CIFAR-100 head are outside SURVEY.md section 8's rows (section 2 row 14): they run only
+# with HCONV_TEST_WIDE=1, so that the default -m gpu run spends its minutes on the in-scope rows
+_WIDE = pytest.mark.skipif(not os.environ.get("HCONV_TEST_WIDE"), reason="out-of-scope resnet variants: set HCONV_TEST_WIDE=1")
+
+
+@pytest.mark.parametrize("cf100,wide", [(False, 1), pytest.param(True, 1, marks=_WIDE), pytest.param(False, 2, marks=_WIDE), pytest.param(False, 3, marks=_WIDE)])
 def test_resnet_cli_depth8(tmp_path, cf100, wide):
     """`resnet 3 8 1 1 false` (scope row 8f-3; the reference's depth-8 variant of BASELINE.md config 5): encrypted inference with
     synthetic weights in the reference's file layout; the class scores must follow the plain float model of the same network"""
