@@ -499,7 +499,7 @@ struct HcLoopA {
 // KA1: rows-inverse of a_1 (mod Q1). grid = (jobs, 16, batch). F64 = 1: Q1 < 2^49, the transform runs in fp64 (T1inv = the fp64 table)
 // and tmp carries doubles (bit patterns) to KA2.
 #ifndef HC_A_WAVES
-#define HC_A_WAVES 5          // a1 / a2 sat at 98 / 99 VGPRs = four waves per SIMD by two or three registers
+#define HC_A_WAVES 4          // a1 / a2 sit at 98 / 99 VGPRs; forcing five waves per SIMD spills 8 / 28 bytes per lane (+19 % fabric writes on a2) and measured no faster
 #endif
 template <int F64>
 __global__ __launch_bounds__(HC_TPB, HC_A_WAVES) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {

@@ -552,6 +552,14 @@ static void on_ctp_diag(pid_t t, struct user_regs_struct *r, void *ud) { (void)t
  * amounts to. genDFTMatrices then runs on K and -diag records its diagonals; CheckKeys fails afterwards (the run's rotation keys are the
  * full-slot ones) and the run panics, which ends the trace. */
 static int g_logslots = 0;
+/* the same K for the rotation-key list: (*BootstrappingParameters).RotationsForBootstrapping(logSlots) is called by main.newContext
+ * (main.go:466) before the keys are generated; with its argument patched the run owns the rotation keys of the sparse bootstrapper, CheckKeys
+ * passes and a `convReLU` run goes on to call BootstrappConv_CtoS on it (-flow / -chain over the sparse bootstrapper) */
+static void on_rots_for_btp(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_logslots) return;
+    uint64_t k = (uint64_t)g_logslots, old = rd64(r->rsp + 0x10);
+    wr(r->rsp + 0x10, &k, 8);
+    emit_begin("RotationsForBootstrapping.patched"); fprintf(g_out, ", \"logSlots_was\": %lu, \"logSlots\": %lu", old, k); emit_end(); }
 static void on_newbtp_mod(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
     if (!g_logslots) return;
     uint64_t k = (uint64_t)g_logslots, bp = rd64(r->rsp + 0x70);
@@ -946,6 +954,7 @@ int main(int argc, char **argv) {
     fprintf(g_out, "],\n \"events\": [");
     if (g_flow_mode) for (size_t i = 0; i < sizeof g_flow / sizeof g_flow[0]; i++) bp_add(post_check(g_flow[i].fn), on_flow, &g_flow[i]);
     if (g_chain) { bp_add(post_check(0x4fdd40), on_ch_switch, NULL); bp_add(post_check(0x4ff060), on_ch_baby, NULL); bp_add(post_check(0x4fe660), on_ch_giant, NULL); }
+    if (g_logslots) { bp_add(post_check(0x510240), on_newbtp_mod, NULL); bp_add(post_check(0x50aa20), on_rots_for_btp, NULL); }
     if (g_flow_mode) goto hooks_done;          /* the flow hooks share addresses with the ones below (the first handler of an address wins) */
     bp_add(A_CONV_THEN_PACK, on_ctp, NULL);
     bp_add(A_ENCODECOEFFS, on_encode, NULL);
@@ -962,7 +971,7 @@ int main(int argc, char **argv) {
                       bp_add(A_POWERBASIS, on_p_powerbasis, NULL); bp_add(A_ADD, on_p_add, NULL); bp_add(A_MULTBYCONST, on_p_multbyconst, NULL); }
     if (g_lt_max) { bp_add(post_check(0x5264c0), on_lt, NULL); bp_add(post_check(0x4ff060), on_lt_ks_hoisted, NULL); bp_add(post_check(0x4fe660), on_lt_ks_nomoddown, NULL);
                     bp_add(post_check(0x4e4c40), on_lt_moddown, NULL); }
-    if (g_diag_max) { bp_add(A_ENCDIAG, on_encdiag, NULL); bp_add(A_ENCMAT, on_encmat, NULL); if (g_logslots) bp_add(post_check(0x510240), on_newbtp_mod, NULL); }
+    if (g_diag_max) { bp_add(A_ENCDIAG, on_encdiag, NULL); bp_add(A_ENCMAT, on_encmat, NULL); }
     if (g_enc_max) { bp_add(A_INVFFT, on_invfft, NULL); bp_add(A_ENCODE, on_encode_slots, NULL); }
     if (g_ops_max) { bp_add(A_RESCALE, on_rescale, NULL); bp_add(A_MULRELIN, on_mulrelin, NULL); bp_add(A_ROTATE, on_rotate, NULL); bp_add(A_MODUP, on_modup, NULL); }
 hooks_done:

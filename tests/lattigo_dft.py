@@ -128,9 +128,24 @@ def multiply_with_next_level(vec, logL, N, next_level, a, b, c, inverse):
     return new
 
 
+def gen_wfft_repack(logL):
+    """genWfftRepack: the two diagonals (rotations 0 and 2^logL) of the map (re | im) -> re + i im that precedes SlotsToCoeffs on sparse slots"""
+    n = 1 << logL
+    a, b = CVec.zeros(2 * n), CVec.zeros(2 * n)
+    a.re[:n] = 1.0; a.im[n:] = 1.0
+    b.im[:n] = 1.0; b.re[n:] = 1.0
+    v = {}
+    _add_to(v, 0, a)
+    _add_to(v, n, b)
+    return v
+
+
 def compute_dft_matrices(log_slots, logd_slots, max_depth, diffscale, inverse):
-    """computeDFTMatrices for logSlots == logdSlots (full slots; the repacking branches do not apply): list of {rotation: CVec}"""
-    assert log_slots == logd_slots
+    """computeDFTMatrices: list of {rotation: CVec}. logd_slots == log_slots: full slots. logd_slots == log_slots + 1 (sparse slots, the
+    resnet's btp2..btp5, main.go:480-500): vectors of 2^logd_slots entries (both halves filled by fftPlainVec's size = 2), SlotsToCoeffs'
+    first matrix is the repacking map merged with its DFT levels (rotations modulo 2^logd_slots), CoeffsToSlots' last matrix has its upper
+    half zeroed -- pinned by tests/golden/ref_trace_diag_sparse_ls13.json (gotrace -diag -logslots 13)."""
+    assert logd_slots in (log_slots, log_slots + 1)
     slots = 1 << log_slots
     roots = compute_roots(slots << 1)
     pow5 = _pow5(slots)
@@ -142,13 +157,22 @@ def compute_dft_matrices(log_slots, logd_slots, max_depth, diffscale, inverse):
         lvl -= depth
     out, lvl = [], log_slots
     for i in range(max_depth):
-        M = gen_fft_diag_matrix(log_slots, lvl, a[log_slots - lvl], b[log_slots - lvl], c[log_slots - lvl], inverse)
+        if log_slots != logd_slots and not inverse and i == 0:
+            M = multiply_with_next_level(gen_wfft_repack(log_slots), log_slots, 2 << log_slots, lvl, a[log_slots - lvl], b[log_slots - lvl], c[log_slots - lvl], inverse)
+            nmod = 2 << log_slots
+        else:
+            M = gen_fft_diag_matrix(log_slots, lvl, a[log_slots - lvl], b[log_slots - lvl], c[log_slots - lvl], inverse)
+            nmod = 1 << log_slots
         nxt = lvl - 1
         for _ in range(merge[i] - 1):
-            M = multiply_with_next_level(M, log_slots, 1 << log_slots, nxt, a[log_slots - nxt], b[log_slots - nxt], c[log_slots - nxt], inverse)
+            M = multiply_with_next_level(M, log_slots, nmod, nxt, a[log_slots - nxt], b[log_slots - nxt], c[log_slots - nxt], inverse)
             nxt -= 1
         out.append(M)
         lvl -= merge[i]
+    if log_slots != logd_slots and inverse:          # repacking after CoeffsToSlots: the last matrix times (1, ..., 1, 0, ..., 0)
+        for v in out[max_depth - 1].values():
+            v.re[slots:2 * slots] = 0.0
+            v.im[slots:2 * slots] = 0.0
     return [{k: v.scale(diffscale) for k, v in M.items()} for M in out]
 
 

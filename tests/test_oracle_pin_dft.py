@@ -84,3 +84,78 @@ def test_encoded_diagonals(matrices):
             bad_limbs += (hq != e["mQ"]) + (hp != e["mP"])
             checked += 1
     assert checked >= 100 and bad_limbs == 0
+
+
+# ---- sparse slots: the bootstrappers main.go:480-500 builds as btp2..btp5 for the resnet ------------------------------------------
+# The reference snapshot in /root/reference never calls them, but its Lattigo fork holds the code: `gotrace -diag -logslots K` overwrites
+# both LogSlots at the entry of ckks.NewBootstrapper_mod in a `convReLU 5 1 1` run, genDFTMatrices then builds the sparse matrices
+# (vectors of 2^(K+1) entries: CoeffsToSlots 16/15/15/15 diagonals at K = 13 with the upper half of the last matrix zeroed, SlotsToCoeffs
+# 62/31/32 with the (re | im) -> re + i im repacking merged into the first) and the tracer digests every diagonal as for full slots.
+# tests/lattigo_dft.py's sparse branches (computeDFTMatrices' repacking, genWfftRepack) must reproduce every value vector, every N1
+# and - through the encoder's sparse embedding (values at stride N/2 / 2^(K+1) of the coefficient vector) - the encoded polynomials.
+SPARSE = {}
+for _ls in (14, 13, 12, 11):
+    _p = os.path.join(HERE, "golden", f"ref_trace_diag_sparse_ls{_ls}.json")
+    if os.path.exists(_p):
+        SPARSE[_ls] = json.load(open(_p))
+
+
+def _sparse_tables(ls):
+    ev = SPARSE[ls]["events"]
+    mats = {e["matrix"]: e for e in ev if e["op"] == "matrix_done"}
+    diags, counts = {}, {}
+    for e in ev:
+        if e["op"] == "encodeDiagonal":
+            diags.setdefault(e["matrix"], {})[e["values"]] = e
+            counts.setdefault(e["matrix"], []).append(e["values"])      # the repacking matrix holds pairs of equal diagonals: keep the multiset
+    return mats, diags, counts
+
+
+@pytest.mark.parametrize("ls", sorted(SPARSE))
+def test_sparse_diagonal_values_and_baby_step_split(ls):
+    mats, diags, counts = _sparse_tables(ls)
+    assert [e for e in SPARSE[ls]["events"] if e["op"] == "NewBootstrapper_mod.patched"][0]["LogSlots"] == ls
+    cts = ld.compute_dft_matrices(ls, ls + 1, 4, ld.cts_diffscale(Q0), True)
+    stc_a = ld.compute_dft_matrices(ls, ls + 1, 3, math.pow(QDIFF * 2.0 ** -17, 1.0 / 3.0), False)
+    stc_b = ld.compute_dft_matrices(ls, ls + 1, 3, 1.0, False)
+    differing = total = 0
+    for m, M in enumerate(cts + stc_a + stc_b):
+        assert mats[m]["LogSlots"] == ls + 1                          # the matrices live on 2 * 2^ls slots
+        n1, vecs = ld.encoder_inputs(M, 2 << ls)
+        assert n1 == mats[m]["N1"], (m, n1, mats[m]["N1"])
+        got = sorted(hashlib.sha256(v.bytes()).hexdigest() for v in vecs.values())
+        assert len(got) == len(counts[m]), (m, len(got), len(counts[m]))
+        differing += sum(1 for a, b in zip(got, sorted(counts[m])) if a != b)
+        total += len(got)
+    assert differing == 0, f"{differing} of {total} diagonals differ"
+
+
+@pytest.mark.parametrize("ls", sorted(SPARSE)[-1:])
+def test_sparse_encoded_diagonals(ls):
+    """encodeDiagonal on 2^(ls+1) slots: invfft on the short vector, the results spread at stride gap = (N/2) / 2^(ls+1) over the real and
+    the imaginary half of the coefficient vector (ckks.(*encoderComplex128).Embed), ScaleUp, NTT, MForm - mod Q and mod P"""
+    mats, diags, _ = _sparse_tables(ls)
+    O = Oracle(logN=16, q=list(oc.Q_SET6), p=list(oc.P_SET6))
+    nQ, mods_all = len(oc.Q_SET6), list(oc.Q_SET6) + list(oc.P_SET6)
+    zero = np.zeros(1 << 16, dtype=np.uint64)
+    cts = ld.compute_dft_matrices(ls, ls + 1, 4, ld.cts_diffscale(Q0), True)
+    stc_b = ld.compute_dft_matrices(ls, ls + 1, 3, 1.0, False)
+    gap = (1 << 15) >> (ls + 1)
+    bad = checked = 0
+    for m, M in ((0, cts[0]), (3, cts[3]), (7, stc_b[0]), (9, stc_b[2])):
+        _, vecs = ld.encoder_inputs(M, 2 << ls)
+        for k, v in sorted(vecs.items())[::5]:
+            e = diags[m][hashlib.sha256(v.bytes()).hexdigest()]
+            lvl = e["level"]
+            w = ob.invfft_special(v.complex())
+            cf = np.zeros(1 << 16)
+            cf[0:1 << 15:gap] = w.real
+            cf[1 << 15::gap] = w.imag
+            mods = list(range(lvl + 1)) + [nQ + j for j in range(len(oc.P_SET6))]
+            rows = O.encode_coeffs(cf, e["scale"], mods)
+            out = [O.mul_scalar(mod, O.ntt(mod, rows[i]).reshape(-1), (1 << 64) % mods_all[mod]).reshape(-1) for i, mod in enumerate(mods)]
+            hq = hashlib.sha256(np.concatenate(out[: lvl + 1] + [zero]).tobytes()).hexdigest()
+            hp = hashlib.sha256(np.concatenate(out[lvl + 1:]).tobytes()).hexdigest()
+            bad += (hq != e["mQ"]) + (hp != e["mP"])
+            checked += 1
+    assert checked >= 10 and bad == 0, (checked, bad)

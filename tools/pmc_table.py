@@ -54,7 +54,7 @@ import json
 convs = int(os.environ.get("PMC_CONVS", "0"))
 out = {"method": "rocprofv3 --kernel-trace --pmc, separate passes (FETCH_SIZE x2 gfx950 correction; WRITE_SIZE as reported; SQ counters per wave; "
                  "valu_pipe_pct = wave64 VALU instructions x 4 cycles / (duration x clock x 1024 SIMDs); clock = GRBM_GUI_ACTIVE / 8 XCDs / duration)",
-       "command": "bench.py --steps 2 --warmup 1 --batch 8 --streams 1", "kernels": rows_json}
+       "command": os.environ.get("PMC_COMMAND", "bench.py --steps 2 --warmup 1 --batch 8 --streams 1"), "kernels": rows_json}
 if convs:
     out["convs_in_run"] = convs
     out["fabric_bytes_per_conv"] = sum((v["read_MiB_per_call"] + v["write_MiB_per_call"]) * v["calls"] for k, v in rows_json.items() if k.startswith("hc_k_a") or k.startswith("hc_k_b")) * 2 ** 20 / convs
