@@ -54,13 +54,12 @@ struct Encoder {
             }
         }
     }
-    // encoder.Encode for moduli q[0..nq): coefficient-domain rows [nq][N] (scaleUpVecExact rounding, as EncodeCoeffs)
-    std::vector<uint64_t> Encode(std::vector<cplx> values, double scale, const uint64_t *BLQ, int nq) const {
+    // scaleUpVecExact over a real coefficient vector of this ring: rows [nq][N]
+    std::vector<uint64_t> ScaleUp(const std::vector<double> &cf, double scale, const uint64_t *BLQ, int nq) const {
         const int N = Nn;
-        invfft(values);
         std::vector<uint64_t> out((size_t)nq * N);
         for (int i = 0; i < N; i++) {
-            const double val = i < N / 2 ? values[(size_t)i].real() : values[(size_t)(i - N / 2)].imag();
+            const double val = cf[(size_t)i];
             const bool neg = val < 0; const double x = neg ? -scale * val : scale * val;
             for (int l = 0; l < nq; l++) {
                 uint64_t r;
@@ -70,6 +69,24 @@ struct Encoder {
             }
         }
         return out;
+    }
+    // encoder.Encode for moduli q[0..nq): coefficient-domain rows [nq][N] (scaleUpVecExact rounding, as EncodeCoeffs)
+    std::vector<uint64_t> Encode(std::vector<cplx> values, double scale, const uint64_t *BLQ, int nq) const {
+        const int N = Nn;
+        invfft(values);
+        std::vector<double> cf((size_t)N);
+        for (int i = 0; i < N; i++) cf[(size_t)i] = i < N / 2 ? values[(size_t)i].real() : values[(size_t)(i - N / 2)].imag();
+        return ScaleUp(cf, scale, BLQ, nq);
+    }
+    // ckks.(*encoderComplex128).Embed with logSlots < logN - 1 (sparse slots: the resnet's bootstrappers): `sub` is the encoder of the ring
+    // with values.size() slots (same roots at the same angles, same rotation group modulo every stage's 4 len); its inverse transform lands at
+    // stride gap = (N/2) / values.size() of the real and of the imaginary half of THIS ring's coefficient vector
+    std::vector<uint64_t> EncodeSparse(const Encoder &sub, std::vector<cplx> values, double scale, const uint64_t *BLQ, int nq) const {
+        const int N = Nn, slots = (int)values.size(), gap = (N / 2) / slots;
+        sub.invfft(values);
+        std::vector<double> cf((size_t)N, 0.0);
+        for (int i = 0; i < slots; i++) { cf[(size_t)(i * gap)] = values[(size_t)i].real(); cf[(size_t)(N / 2 + i * gap)] = values[(size_t)i].imag(); }
+        return ScaleUp(cf, scale, BLQ, nq);
     }
 };
 

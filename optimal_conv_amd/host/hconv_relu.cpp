@@ -83,6 +83,7 @@ struct Boot {
     struct LT { int n1 = 1; std::map<int, std::map<int, DPt>> giant; double pt_scale = 0; int level = 0; bool qp = false; };   // the diagonals are encoded mod Q_0..Q_level AND mod every P (rows [level+1+np][N]) for linear_transform_qp
     struct Set { int ls = 0, ns = 0; std::vector<LT> cts, stc; };      // one bootstrapper of the reference (btp, btp2..btp5: main.go:480-500)
     std::map<int, Set> sets;                                           // by log_sparse
+    std::map<int, Encoder> sub_enc;                                    // encoders of the rings with fewer slots (sparse embedding), by log2 of their degree
     std::vector<double> sine;
     long n_keyswitch = 0, n_keys = 0;
     std::map<std::string, DPt> pt_cache;                     // encoded 0/1 masks (keep_ctxt, ext_double_ctxt), by what defines them
@@ -347,7 +348,13 @@ struct Boot {
     DPt encode_qp(const std::vector<cplx> &slots, int level, double scale) {
         const int nl = level + 1, np = (int)P.size();
         std::vector<uint64_t> mods(Q.begin(), Q.begin() + nl); mods.insert(mods.end(), P.begin(), P.end());
-        std::vector<uint64_t> rows = enc.Encode(slots, scale, mods.data(), nl + np);
+        std::vector<uint64_t> rows;
+        if ((int)slots.size() == N / 2) rows = enc.Encode(slots, scale, mods.data(), nl + np);
+        else {                                  // a sparse-slot diagonal: the encoder's sparse embedding (pinned: ref_trace_diag_sparse_ls*.json)
+            int lg = 0; while ((1 << lg) < (int)slots.size()) lg++;
+            auto it = sub_enc.find(lg + 1); if (it == sub_enc.end()) it = sub_enc.emplace(lg + 1, Encoder(lg + 1)).first;
+            rows = enc.EncodeSparse(it->second, slots, scale, mods.data(), nl + np);
+        }
         DPt pt; pt.level = level; pt.scale = scale;
         { void *v = nullptr; HCR(hc_malloc(hc, rows.size() * 8, &v)); uint64_t *d = (uint64_t *)v; hc_ctx *h = hc; pt.p = std::shared_ptr<uint64_t>(d, [h](uint64_t *x) { hc_free(h, x); }); }
         HCR(hc_upload(hc, pt.p.get(), rows.data(), rows.size() * 8));
@@ -417,44 +424,60 @@ struct Boot {
         auto it = M.find(k);
         if (it == M.end()) M.emplace(k, std::move(v)); else for (size_t p = 0; p < v.size(); p++) it->second[p] += v[p];
     }
-    std::vector<DiagMat> lattigo_dft(bool inverse, int depth, double diffscale) const {
-        const int logn = LOGN - 1, ns = n;
+    // ls > 0 (sparse slots, round 3): logSlots = LOGN-1-ls, vectors of dslots = 2 * 2^logSlots entries (fftPlainVec fills both halves),
+    // SlotsToCoeffs' first matrix = genWfftRepack (the (re | im) -> re + i im map: diagonals 0 and 2^logSlots) merged with its DFT levels
+    // (rotations modulo dslots), CoeffsToSlots' last matrix zeroed on its upper half: computeDFTMatrices' repacking branches, pinned against
+    // the binary by tests/golden/ref_trace_diag_sparse_ls*.json (gotrace -diag -logslots K).
+    std::vector<DiagMat> lattigo_dft(bool inverse, int depth, double diffscale, int ls = 0) const {
+        const int logn = LOGN - 1 - ls, ns = n >> ls, ds = ls ? 2 * ns : ns, size = ls ? 2 : 1;
         std::vector<int> pow5((size_t)(2 * ns + 1), 1);
         for (size_t i = 1; i < pow5.size(); i++) pow5[i] = (int)(((long)pow5[i - 1] * 5) & (4L * ns - 1));
+        const int root_gap = n / ns;                             // computeRoots(2 ns)[k] = the full ring's root of the same angle
         std::vector<std::vector<cplx>> a, b, c;
         for (int s = 0; s < logn; s++) {
             const int m = inverse ? ns >> s : 2 << s, tt = m >> 1, gap = ns / m, mask = (m << 2) - 1;
-            std::vector<cplx> va((size_t)ns, cplx(0, 0)), vb((size_t)ns, cplx(0, 0)), vc((size_t)ns, cplx(0, 0));
+            std::vector<cplx> va((size_t)ds, cplx(0, 0)), vb((size_t)ds, cplx(0, 0)), vc((size_t)ds, cplx(0, 0));
             for (int i = 0; i < ns; i += m) for (int j = 0; j < tt; j++) {
                 const int k = inverse ? ((m << 2) - (pow5[(size_t)j] & mask)) * gap : (pow5[(size_t)j] & mask) * gap;
-                const cplx w = enc.roots[(size_t)k];
-                va[(size_t)(i + j)] = cplx(1, 0); va[(size_t)(i + j + tt)] = -w;
-                if (inverse) { vb[(size_t)(i + j)] = cplx(1, 0); vc[(size_t)(i + j + tt)] = w; }
-                else { vb[(size_t)(i + j)] = w; vc[(size_t)(i + j + tt)] = cplx(1, 0); }
+                const cplx w = enc.roots[(size_t)k * (size_t)root_gap];
+                for (int u = 0; u < size; u++) {
+                    const size_t i1 = (size_t)(i + j + u * ns), i2 = (size_t)(i + j + tt + u * ns);
+                    va[i1] = cplx(1, 0); va[i2] = -w;
+                    if (inverse) { vb[i1] = cplx(1, 0); vc[i2] = w; }
+                    else { vb[i1] = w; vc[i2] = cplx(1, 0); }
+                }
             }
             a.push_back(std::move(va)); b.push_back(std::move(vb)); c.push_back(std::move(vc));
         }
         std::vector<int> merge((size_t)depth, 0);
         for (int i = 0, lvl = logn; i < depth; i++) { const int d = (lvl + depth - i - 1) / (depth - i); merge[(size_t)(inverse ? i : depth - i - 1)] = d; lvl -= d; }
         auto rot_of = [&](int level) { return inverse ? 1 << (level - 1) : 1 << (logn - level); };
-        auto rotated_times = [&](const std::vector<cplx> &v, int r, const std::vector<cplx> &w) {       // mul(rotate(v, r), w): rotate is to the left
-            std::vector<cplx> out((size_t)ns); for (int p = 0; p < ns; p++) out[(size_t)p] = go_mul(v[(size_t)((p + r) & (ns - 1))], w[(size_t)p]); return out; };
+        auto rotated_times = [&](const std::vector<cplx> &v, int r, const std::vector<cplx> &w) {       // mul(rotate(v, r), w): rotate is to the left, over the vector's own length
+            std::vector<cplx> out((size_t)ds); for (int p = 0; p < ds; p++) out[(size_t)p] = go_mul(v[(size_t)((p + r) & (ds - 1))], w[(size_t)p]); return out; };
+        auto times_next = [&](const DiagMat &M, int nmod, int nxt) {
+            const int r = rot_of(nxt) & (nmod - 1), x = logn - nxt;
+            DiagMat nw;
+            for (auto &e : M) {           // the fork ranges over a Go map here; at every position at most two of the three terms are non-zero, so the sums do not depend on the order
+                add_to(nw, e.first, rotated_times(e.second, 0, a[(size_t)x]));
+                add_to(nw, (e.first + r) & (nmod - 1), rotated_times(e.second, r, b[(size_t)x]));
+                add_to(nw, (e.first - r) & (nmod - 1), rotated_times(e.second, ds - r, c[(size_t)x]));
+            }
+            return nw;
+        };
         std::vector<DiagMat> out;
         for (int i = 0, lvl = logn; i < depth; i++) {
-            DiagMat M; { const int r = rot_of(lvl), x = logn - lvl; add_to(M, 0, a[(size_t)x]); add_to(M, r, b[(size_t)x]); add_to(M, ns - r, c[(size_t)x]); }
-            for (int j = 0, nxt = lvl - 1; j < merge[(size_t)i] - 1; j++, nxt--) {
-                const int r = rot_of(nxt) & (ns - 1), x = logn - nxt;
-                DiagMat nw;
-                for (auto &e : M) {           // the fork ranges over a Go map here; at every position at most two of the three terms are non-zero, so the sums do not depend on the order
-                    add_to(nw, e.first, rotated_times(e.second, 0, a[(size_t)x]));
-                    add_to(nw, (e.first + r) & (ns - 1), rotated_times(e.second, r, b[(size_t)x]));
-                    add_to(nw, (e.first - r) & (ns - 1), rotated_times(e.second, ns - r, c[(size_t)x]));
-                }
-                M = std::move(nw);
-            }
-            for (auto &e : M) for (auto &v : e.second) v = go_mul(v, cplx(diffscale, 0));
+            DiagMat M; int nmod = ns;
+            if (ls && !inverse && i == 0) {      // genWfftRepack, merged with the first DFT level
+                DiagMat W; W[0].assign((size_t)ds, cplx(0, 0)); W[ns].assign((size_t)ds, cplx(0, 0));
+                for (int p = 0; p < ns; p++) { W[0][(size_t)p] = cplx(1, 0); W[0][(size_t)(p + ns)] = cplx(0, 1); W[ns][(size_t)p] = cplx(0, 1); W[ns][(size_t)(p + ns)] = cplx(1, 0); }
+                nmod = ds;
+                M = times_next(W, nmod, lvl);
+            } else { const int r = rot_of(lvl), x = logn - lvl; add_to(M, 0, a[(size_t)x]); add_to(M, r, b[(size_t)x]); add_to(M, ns - r, c[(size_t)x]); }
+            for (int j = 0, nxt = lvl - 1; j < merge[(size_t)i] - 1; j++, nxt--) M = times_next(M, nmod, nxt);
             out.push_back(std::move(M)); lvl -= merge[(size_t)i];
         }
+        if (ls && inverse) for (auto &e : out.back()) for (int p = ns; p < ds; p++) e.second[(size_t)p] = cplx(0, 0);       // repacking after CoeffsToSlots
+        for (auto &M : out) for (auto &e : M) for (auto &v : e.second) v = go_mul(v, cplx(diffscale, 0));
         return out;
     }
     // findbestbabygiantstepsplit / bsgsIndex of the fork (maxN1N2Ratio = 16): the first N1 with more hoisted (baby) rotations than giant
@@ -473,8 +496,10 @@ struct Boot {
         return 1;
     }
     FILE *dft_digests = nullptr;
-    LT plan(const DiagMat &M, int level, double pt_scale, bool lattigo_split = false, const char *tag = "") {          // BSGS split + the pre-rotated, encoded diagonals
+    // slots: the length of M's vectors (n, or 2^(logSlots+1) for a sparse-slot matrix: rotations modulo it, sparse embedding)
+    LT plan(const DiagMat &M, int level, double pt_scale, bool lattigo_split = false, const char *tag = "", int slots = 0) {          // BSGS split + the pre-rotated, encoded diagonals
         LT lt; lt.level = level; lt.pt_scale = pt_scale;
+        const int n = slots ? slots : this->n;
         int best = -1;
         for (int n1 = 1; n1 <= n; n1 <<= 1) {
             std::set<int> babies, giants; for (auto &e : M) { babies.insert(e.first % n1); giants.insert(e.first - e.first % n1); }
@@ -813,24 +838,26 @@ struct Boot {
         // labelling the raised ciphertext 2^round(log2 q0) instead of q0 - and its baby-step size N1. For parameter set [6] these are the
         // reference binary's diagonals bit for bit (tests/golden/ref_trace_diag_5_1.json). Sparse slots keep this file's own generator.
         const double scfac = (double)(1 << SIN_DOUBLE), qdiff = (double)Q[0] / exp2(round(log2((double)Q[0])));
-        std::vector<DiagMat> G = ls ? dft_groups(true, {4, 4, 4, 3}, 1.0 / (2.0 * (double)ns * SIN_K * D), ls)
-                                    : lattigo_dft(true, 4, pow(2.0 / ((2.0 * SIN_K / scfac) * (double)N * scfac * qdiff), 1.0 / 4.0));
-        if (ls) for (auto &e : G.back()) for (int p = 0; p < n; p++) if (p % (2 * ns) >= ns) e.second[(size_t)p] = cplx(0, 0);   // keep w on the first half of every 2 n_s slots
+        const bool fork = chain == 6;           // parameter set [6] (Ours): the fork's matrices, sparse slots included (round 3); the baseline's chain keeps this file's generator for ls > 0
+        const int period = ls && fork ? 2 * ns : 0;
+        std::vector<DiagMat> G = ls && !fork ? dft_groups(true, {4, 4, 4, 3}, 1.0 / (2.0 * (double)ns * SIN_K * D), ls)
+                                             : lattigo_dft(true, 4, pow(2.0 / ((2.0 * SIN_K / scfac) * (double)N * scfac * qdiff), 1.0 / 4.0), ls);
+        if (ls && !fork) for (auto &e : G.back()) for (int p = 0; p < n; p++) if (p % (2 * ns) >= ns) e.second[(size_t)p] = cplx(0, 0);   // keep w on the first half of every 2 n_s slots
         static const char *cts_tag[4] = {"cts0", "cts1", "cts2", "cts3"}, *stc_tag[3] = {"stc0", "stc1", "stc2"};
-        for (size_t i = 0; i < G.size(); i++) { const int lv = LV_CTS_TOP - (int)i; S.cts.push_back(plan(G[i], lv, (double)Q[(size_t)lv], ls == 0, cts_tag[i])); }
+        for (size_t i = 0; i < G.size(); i++) { const int lv = LV_CTS_TOP - (int)i; S.cts.push_back(plan(G[i], lv, (double)Q[(size_t)lv], ls == 0 || fork, cts_tag[i], period)); }
         // SlotsToCoeffs: level 3 carries all but the last matrix (plaintext scales multiply to q3), level 2 the last at 2^30
         // (the fork: the set NewBootstrapper_mod builds with scale 1 - the reference's SlotsToCoeffs call uses it - at the same three scales)
-        G = ls ? dft_groups(false, {5, 5, 5}, 1.0, ls) : lattigo_dft(false, 3, 1.0);
-        if (ls) {       // packed a = (re | im)  ->  w = re + i im on both halves:  w = (m1 + i m2) a + (i m1 + m2) rot_{n_s}(a)
+        G = ls && !fork ? dft_groups(false, {5, 5, 5}, 1.0, ls) : lattigo_dft(false, 3, 1.0, ls);
+        if (ls && !fork) {       // packed a = (re | im)  ->  w = re + i im on both halves:  w = (m1 + i m2) a + (i m1 + m2) rot_{n_s}(a)
             DiagMat W; W[0].resize((size_t)n); W[ns].resize((size_t)n);
             for (int p = 0; p < n; p++) { const bool first = p % (2 * ns) < ns; W[0][(size_t)p] = first ? cplx(1, 0) : cplx(0, 1); W[ns][(size_t)p] = first ? cplx(0, 1) : cplx(1, 0); }
             G[0] = matmul_diag(G[0], W, 2 * ns);
         }
         if (G.size() != 3) panic("SlotsToCoeffs is planned as three matrices");
-        for (size_t i = 0; i + 1 < G.size(); i++) S.stc.push_back(plan(G[i], LV_STC_TOP, stc_scale_top, ls == 0, stc_tag[i]));
+        for (size_t i = 0; i + 1 < G.size(); i++) S.stc.push_back(plan(G[i], LV_STC_TOP, stc_scale_top, ls == 0 || fork, stc_tag[i], period));
         // the fork applies all three matrices on level 3 and rescales twice afterwards (ckks.SlotsToCoeffs -> dft: the Rescale after each
         // LinearTransform finds nothing to drop); full slots on parameter set [6] do the same, the other bootstrappers keep the split above
-        S.stc.push_back(plan(G.back(), ls == 0 && chain == 6 ? LV_STC_TOP : LV_STC_TOP - 1, stc_scale_last, ls == 0, stc_tag[2]));
+        S.stc.push_back(plan(G.back(), fork ? LV_STC_TOP : LV_STC_TOP - 1, stc_scale_last, ls == 0 || fork, stc_tag[2], period));
         for (auto *grp : {&S.cts, &S.stc}) for (auto &lt : *grp) for (auto &g : lt.giant) {
             if (g.first) key(gal_rot(g.first), lt.level, 2);
             for (auto &b : g.second) if (b.first) key(gal_rot(b.first), lt.level, 1);
@@ -848,8 +875,10 @@ struct Boot {
     // before), ct + conj and (ct - conj) / i, the label sinescale = 2^round(log2 q0), AddConst(-0.5 / (scFac (b - a))), EvaluateCheby with the
     // fork's coefficients towards sqrt(sqrt(sinescale q16) q17), two double angles with (1/2pi)^(1/4) squared along, the label params.scale,
     // MultByConst(q0 / sinescale * params.scale / prescale) and Rescale: two ciphertexts at level 14, scale 2^30.
-    int ctos_fork(const DCt &ct0, DCt out[2]) {
-        Set &S = set(0);
+    // Sparse slots (ls > 0, round 3; gotrace -flow -logslots 13 shows the binary's op sequence): subSum after the second ScaleUp (Rotate by 2^i,
+    // Add, i = logSlots .. logN-2), and after DivByi the repacking Rotate(ct1, 2^logSlots) + Add(ct0, ct1): one ciphertext through the sine.
+    int ctos_fork(const DCt &ct0, DCt out[2], int ls = 0) {
+        Set &S = set(ls);
         const double q0 = (double)Q[0], msg_ratio = 256.0, pscale = 1073741824.0;
         const double prescale = exp2(round(log2(q0 / msg_ratio))), sinescale = exp2(round(log2(q0)));
         if (ct0.level != 0 || prescale < ct0.scale) panic("BootstrappConv_CtoS: the input must sit on level 0 below the prescale");
@@ -858,15 +887,18 @@ struct Boot {
         ct = mod_raise(ct, LV_CTS_TOP);
         k = floor((sinescale / msg_ratio) / ct.scale + 0.5);
         { const double s0 = ct.scale; ct = mul_const_int(ct, k); ct.scale = s0 * k; }
+        for (int i = LOGN - 1 - ls; i < LOGN - 1; i++) ct = add(ct, rotate(ct, 1 << i));                   // subSum
         for (auto &lt : S.cts) { const double s_in = ct.scale; ct = lt_rescale(linear_transform(ct, lt), s_in); }
         if (ct.level != LV_SINE_TOP) panic("CoeffsToSlots ended at the wrong level");
         DCt cc = conjugate(ct);
         DCt parts[2] = {add(ct, cc), mul_by_i(sub(cc, ct))};           // DivByi(ct - conj) = -i (ct - conj) = i (conj - ct): the same residues
+        const int nparts = ls ? 1 : 2;
+        if (ls) parts[0] = add(parts[0], rotate(parts[1], S.ns));      // repacking: the imaginary half next to the real one
         double target = sinescale;
         for (int r = 0; r < SIN_DOUBLE; r++) target = sqrt(target * (double)Q[(size_t)(LV_RELU_TOP + 1 + r)]);
         const std::vector<double> coeffs(FORK_SINE_COEFFS, FORK_SINE_COEFFS + 63);
         const double scfac = (double)(1 << SIN_DOUBLE);
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < nparts; h++) {
             DCt c = parts[h]; c.scale = sinescale;
             c = add_const(c, -0.5 / (scfac * (2.0 * SIN_K / scfac)));
             c = eval_cheby_lattigo(c, coeffs, target, sinescale);
@@ -876,10 +908,10 @@ struct Boot {
             c.scale = pscale;
             out[h] = lt_rescale(mul_const_float(c, (q0 / sinescale) * (pscale / prescale)), pscale);
         }
-        return 2;
+        return nparts;
     }
     int ctos(const DCt &ct0, int ls, DCt out[2]) {
-        if (ls == 0 && chain == 6) return ctos_fork(ct0, out);
+        if (chain == 6) return ctos_fork(ct0, out, ls);
         Set &S = set(ls);
         const double q0 = (double)Q[0], msg_scale = ct0.scale;
         DCt ct = mod_raise(ct0, LV_CTS_TOP); ct.scale = ls ? q0 : exp2(round(log2(q0)));   // slot values are now t'/Q0 = I + msg/Q0, |.| <= K (full slots: the 1/qDiff sits in the matrices)
@@ -906,7 +938,7 @@ struct Boot {
         Set &S = set(ls);
         if (ls && im) panic("sparse SlotsToCoeffs takes one packed ciphertext");
         DCt ct = drop_to(ls ? re : add(re, mul_by_i(*im)), LV_STC_TOP);
-        if (ls == 0 && chain == 6) {        // ckks.SlotsToCoeffs as the fork runs it (ref_flow_5_1.json): MultByi + Add, three LinearTransforms each followed by Rescale(min = the scale before), then eval.go:564's Rescale(2^30): level 3 -> 1
+        if (chain == 6) {        // ckks.SlotsToCoeffs as the fork runs it (sparse slots: one packed ciphertext, no MultByi + Add) (ref_flow_5_1.json): MultByi + Add, three LinearTransforms each followed by Rescale(min = the scale before), then eval.go:564's Rescale(2^30): level 3 -> 1
             for (auto &lt : S.stc) { const double s_in = ct.scale; ct = lt_rescale(linear_transform(ct, lt), s_in); }
             return lt_rescale(ct, 1073741824.0);
         }

@@ -6,7 +6,10 @@ t = re.sub(r'-?nan', 'null', t); t = re.sub(r'(?<![\w.])-?inf', 'null', t)
 d = json.loads(t)
 TYPES = {5704224: "float64", 5704032: "complex128", 5706272: "int", 5708320: "uint64"}
 out, stack, hide = [], [], None
+patched = [e for e in d["events"] if e["op"].endswith(".patched")]      # gotrace -logslots: the sparse-slot bootstrapper
 for e in d["events"]:
+    if "fn" not in e:
+        continue
     fn = e["fn"]
     if e["op"] == "call":
         stack.append(fn)
@@ -40,5 +43,6 @@ for e in d["events"]:
             dg = [e[k] for k in ("digest_out", "digest_res0", "digest_res1") if e.get(k)]
             if dg: ev["digests"] = [{"level": c["level"], "scale": c["scale"], "polys": [p["sha256"] for p in c["polys"]]} for c in dg]
 extra = {k: d[k] for k in ("seed", "N", "ks_Q", "ks_P") if k in d}
+if patched: extra["patched"] = patched
 json.dump({**extra, "argv": d["argv"], "note": "gotrace -flow over `convReLU 5 1 1`: every evaluator call from the entry of BootstrappConv_CtoS to the return of evalConv_BNRelu_new; [level, scale, degree] of ciphertext arguments and results; nothing planted, no digests (the run's keys are random); the insides of EvaluatePoly / EvaluateCheby are in ref_trace_poly_5_1 / ref_trace_cheby_5_1", "events": out}, open(sys.argv[1], "w"), indent=0)
 print(len(out))

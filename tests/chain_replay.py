@@ -73,3 +73,52 @@ def replay(backend_factory=None, k=5, i_batch=1):
     assert (out.level, out.scale) == (w["level"], w["scale"]) and digests(out) == w["polys"], "the ciphertext the layer hands on"
     n += 1
     return n, d
+
+
+SPARSE_TRACE = os.path.join(HERE, "golden", "ref_trace_chain_sparse_ls13.json")
+
+
+def replay_sparse(backend_factory=None):
+    """BootstrappConv_CtoS of the SPARSE-slot bootstrapper (LogSlots 13 = log_sparse 2, the resnet's btp3) on the planted data of
+    `gotrace -chain -logslots 13` (tests/golden/ref_trace_chain_sparse_ls13.json): modUp, subSum, the four sparse LinearTransforms, the
+    conjugation, the repacked CoeffsToSlots result, EvaluateCheby, evaluateSine and the ciphertext BootstrappConv_CtoS ends on must carry the
+    reference binary's SHA-256. Returns the number of checkpoints compared."""
+    d = json.load(open(SPARSE_TRACE))
+    Q, P, seed, N = d["ks_Q"], d["ks_P"], d["seed"], d["N"]
+    ev = d["events"]
+    ls = 15 - [p for p in d["patched"] if p["op"].startswith("NewBootstrapper_mod")][0]["LogSlots"]
+    C = ck.Ckks(logN=16)
+    if backend_factory is not None:
+        C.be = backend_factory(C)
+    rows_cache = {}
+
+    def key_source(kind, gal, level):
+        ident = (kind, level)
+        if ident not in rows_cache:
+            rows_cache[ident] = ks_inputs(seed, 0, KIND_ID[kind], level, Q, P, N)[1]
+        return rows_cache[ident]
+    C.key_source = key_source
+    first = ev[0]
+    assert first["fn"] == "BootstrappConv_CtoS"
+    ct = ck.Ct(planted_ct(seed, 4000, 0, 0, Q, N), first["in"][0][1])
+    btp = ck.Bootstrapper(C, log_sparse=ls)
+    btp.debug = {}
+    (boot,) = btp.ctos(ct)
+    dbg = btp.debug
+    want = [e for e in ev if "digests" in e]
+    n = 0
+
+    def check(got, w, what):
+        nonlocal n
+        assert (got.level, got.scale) == (w["level"], w["scale"]) and digests(got) == w["polys"], what
+        n += 1
+    lts = [e for e in want if e["fn"] == "LinearTransform"]
+    check(dbg["modUp"], [e for e in want if e["fn"] == "modUp"][0]["digests"][0], "modUp")
+    for i, e in enumerate(lts):
+        check(dbg["LinearTransform"][i], e["digests"][0], f"sparse LinearTransform {i}")
+    check(dbg["ConjugateNew"], [e for e in want if e["fn"] == "ConjugateNew"][0]["digests"][0], "ConjugateNew")
+    check(dbg["CoeffsToSlots"][0], [e for e in want if e["fn"] == "CoeffsToSlots"][0]["digests"][0], "CoeffsToSlots (repacked)")
+    check(dbg["EvaluateCheby"][0], [e for e in want if e["fn"] == "EvaluateCheby"][0]["digests"][0], "EvaluateCheby")
+    check(dbg["evaluateSine"][0], [e for e in want if e["fn"] == "evaluateSine"][0]["digests"][0], "evaluateSine")
+    check(boot, [e for e in want if e["fn"] == "Rescale"][-1]["digests"][0], "the ciphertext BootstrappConv_CtoS ends on")
+    return n

@@ -153,8 +153,9 @@ class Encoder:
     # the two transforms with every complex product as four rounded real products (what Go and the device encoder compute; numpy's own
     # complex multiply may fuse) - tests/oracle_bl.py's pinned invfft_special / fft_special for any ring degree
     def invfft(self, values):
+        """any power-of-two length n <= N/2 (shorter vectors: the sparse-slot embedding, ckks.(*encoderComplex128).Embed with logSlots < logN-1)"""
         v = np.array(values, dtype=np.complex128)
-        n, ln = self.n, self.n
+        n = ln = len(v)
         re, im = v.real.copy(), v.imag.copy()
         while ln >= 2:
             lenh = ln >> 1
@@ -166,7 +167,14 @@ class Encoder:
             p0, p1, p2, p3 = dr * w.real, di * w.imag, dr * w.imag, di * w.real
             br[:, lenh:] = p0 - p1; bi[:, lenh:] = p2 + p3
             ln >>= 1
-        return ((re * (1.0 / float(n))) + 1j * (im * (1.0 / float(n))))[self.br]
+        if n == self.n:
+            perm = self.br
+        else:
+            bits, idx = n.bit_length() - 1, np.arange(n)
+            perm = np.zeros(n, dtype=np.int64)
+            for b in range(bits):
+                perm |= ((idx >> b) & 1) << (bits - 1 - b)
+        return ((re * (1.0 / float(n))) + 1j * (im * (1.0 / float(n))))[perm]
 
     def fft(self, values):
         v = np.array(values, dtype=np.complex128)[self.br]
@@ -185,8 +193,16 @@ class Encoder:
         return re + 1j * im
 
     def slots_to_coeffs(self, values):
+        """Embed: the inverse transform of the slot vector; a vector of fewer than N/2 slots lands at stride (N/2) / len(values) of the real
+        and of the imaginary half of the coefficient vector (pinned against the binary's sparse encodeDiagonal: tests/test_oracle_pin_dft.py)"""
         v = self.invfft(values)
-        return np.concatenate([v.real, v.imag])
+        if len(v) == self.n:
+            return np.concatenate([v.real, v.imag])
+        gap = self.n // len(v)
+        cf = np.zeros(self.N)
+        cf[0:self.n:gap] = v.real
+        cf[self.n::gap] = v.imag
+        return cf
 
     def coeffs_to_slots(self, cf):
         c = np.asarray(cf, dtype=np.float64)
@@ -469,7 +485,7 @@ class Ckks:
             acc = inner if acc is None else self.add(acc, inner)
         return acc
 
-    def linear_transform_qp(self, ct, diags, pt_scale, n1=None):
+    def linear_transform_qp(self, ct, diags, pt_scale, n1=None, slots=None):
         """ckks.(*evaluator).LinearTransform -> MultiplyByDiagMatrixBSGS exactly as the reference's fork computes it (tests/lattigo_lt.py is the
         same algorithm on the bare oracle, pinned against the binary in tests/test_oracle_pin_lt.py): baby-step rotations key-switched without
         the division by P on one digit decomposition, P*c0 added, products with the diagonals (encoded mod Q and mod P) summed in QP, ONE
@@ -477,11 +493,12 @@ class Ckks:
         diagonals multiply the input itself after the division. host/hconv_relu.cpp Boot::linear_transform_qp is the product's copy."""
         L, be = ct.level, self.be
         nl = L + 1
-        n1 = n1 or self.bsgs_split(sorted(diags))          # sparse slots / the baseline: this repository's cheapest split
+        n1 = n1 or self.bsgs_split(sorted(diags))          # the baseline: this repository's cheapest split
+        ns = slots or self.n                               # slots = 2^(logSlots+1) < N/2: a sparse-slot matrix (diagonals of that length, rotations modulo it, sparse embedding)
         index = {}
         for k in sorted(diags):
-            index.setdefault((k % self.n) // n1, []).append((k % self.n) & (n1 - 1))
-        pts = {k: self.encode_ntt_qp(np.roll(diags[k], ((k % self.n) // n1) * n1), L, pt_scale) for k in diags}
+            index.setdefault((k % ns) // n1, []).append((k % ns) & (n1 - 1))
+        pts = {k: self.encode_ntt_qp(np.roll(diags[k], ((k % ns) // n1) * n1), L, pt_scale) for k in diags}
         c0, c1 = ct.rows[0], ct.rows[1]
         Pbig = 1
         for p in self.P:
@@ -842,31 +859,37 @@ class Bootstrapper:
         cts_groups, stc_groups = self._fit(cts_groups, logn), self._fit(stc_groups, logn)
         # CoeffsToSlots: (1/n_s) * prod(stages), times 1/2 (real/imaginary extraction), 1/K (Chebyshev argument in [-1,1])
         # and 1/D (SubSum multiplies the surviving coefficients by D)
-        if log_sparse == 0:
-            # full slots: the matrices exactly as the reference's Lattigo fork builds them (tests/lattigo_dft.py; for logN = 16 pinned
-            # against the binary in tests/test_oracle_pin_dft.py), its constant (1/qDiff included: ctos() labels the raised ciphertext
-            # 2^round(log2 q0)) and its baby-step sizes
+        self.period = None
+        if log_sparse == 0 or self.fork_flow:
+            # the matrices exactly as the reference's Lattigo fork builds them (tests/lattigo_dft.py; for logN = 16 pinned against the binary
+            # in tests/test_oracle_pin_dft.py: full slots, and - since round 3 - the sparse-slot sets with their repacking), its constant
+            # (1/qDiff included: ctos() labels the raised ciphertext 2^round(log2 q0)) and its baby-step sizes. Sparse slots: vectors of
+            # 2 n_s entries, rotations modulo 2 n_s, CoeffsToSlots' last matrix zero on the upper half, SlotsToCoeffs' first matrix merged
+            # with the (re | im) -> re + i im map; the plaintexts use the encoder's sparse embedding.
             import lattigo_dft as ld
             qdiff = float(C.Q[0]) / 2.0 ** round(math.log2(float(C.Q[0])))
             sc_fac = float(1 << SIN_DOUBLE)
             d_cts = math.pow(2.0 / ((2.0 * SIN_K / sc_fac) * float(C.N) * sc_fac * qdiff), 1.0 / len(cts_groups))
-            cts = ld.compute_dft_matrices(logn, logn, len(cts_groups), d_cts, True)
-            stc = ld.compute_dft_matrices(logn, logn, len(stc_groups), 1.0, False)
-            self.cts_n1 = [ld.find_best_bsgs_split(list(M), ns, 16.0) for M in cts]
-            self.stc_n1 = [ld.find_best_bsgs_split(list(M), ns, 16.0) for M in stc]
+            logd = logn + (1 if log_sparse else 0)
+            cts = ld.compute_dft_matrices(logn, logd, len(cts_groups), d_cts, True)
+            stc = ld.compute_dft_matrices(logn, logd, len(stc_groups), 1.0, False)
+            self.cts_n1 = [ld.find_best_bsgs_split(list(M), 1 << logd, 16.0) for M in cts]
+            self.stc_n1 = [ld.find_best_bsgs_split(list(M), 1 << logd, 16.0) for M in stc]
             self.cts = [{k: v.complex() for k, v in M.items()} for M in cts]
             self.stc = [{k: v.complex() for k, v in M.items()} for M in stc]
+            if log_sparse:
+                self.period = 1 << logd
         else:
             self.cts = C.dft_groups(True, cts_groups, 1.0 / (2.0 * ns * SIN_K * D), log_sparse)
             self.stc = C.dft_groups(False, stc_groups, 1.0, log_sparse)
             self.cts_n1, self.stc_n1 = [None] * len(self.cts), [None] * len(self.stc)
-        if log_sparse:
-            p = np.arange(C.n) % (2 * ns)
-            m1, m2 = (p < ns).astype(np.complex128), (p >= ns).astype(np.complex128)
-            self.cts[-1] = {k: v * m1 for k, v in self.cts[-1].items()}          # keep w on the first half of every 2 n_s slots
-            # packed a = (re | im)  ->  w = re + i im on BOTH halves:  w = (m1 + i m2) a + (i m1 + m2) rot_{n_s}(a)
-            W = {0: m1 + 1j * m2, ns: 1j * m1 + m2}
-            self.stc[0] = C.matmul_diag(self.stc[0], W, 2 * ns)
+            if log_sparse:
+                p = np.arange(C.n) % (2 * ns)
+                m1, m2 = (p < ns).astype(np.complex128), (p >= ns).astype(np.complex128)
+                self.cts[-1] = {k: v * m1 for k, v in self.cts[-1].items()}          # keep w on the first half of every 2 n_s slots
+                # packed a = (re | im)  ->  w = re + i im on BOTH halves:  w = (m1 + i m2) a + (i m1 + m2) rot_{n_s}(a)
+                W = {0: m1 + 1j * m2, ns: 1j * m1 + m2}
+                self.stc[0] = C.matmul_diag(self.stc[0], W, 2 * ns)
         f = lambda u: np.cos(2.0 * np.pi * (SIN_K * u - 0.25) / float(1 << SIN_DOUBLE))
         self.sine = cheby_coeffs(f, SIN_DEG)
 
@@ -882,7 +905,7 @@ class Bootstrapper:
         """level-0 coefficient-encoded ciphertext (value = coeff/scale in [-1,1], |coeff| <= Q0/MSG_RATIO) -> two
         ciphertexts at level LV_RELU_TOP, scale 2^30, slot p of the first = value of coefficient bitrev(p), of the
         second = coefficient n + bitrev(p)"""
-        if self.ls == 0 and self.fork_flow:
+        if self.fork_flow:
             return self._ctos_fork(ct0)
         C = self.C
         q0 = float(C.Q[0])
@@ -935,15 +958,29 @@ class Bootstrapper:
         k = int(math.floor(prescale / ct0.scale + 0.5))
         ct = C.mul_const_int(ct0, k); ct.scale = ct0.scale * k                      # ScaleUp(ct, round(prescale / scale))
         ct = C.mod_raise(ct, LV_CTS_TOP)
+        dbg = getattr(self, "debug", None)                                          # tests: intermediate ciphertexts by the reference's function names
+        if dbg is not None:
+            dbg["modUp"] = ct.copy()
         k = int(math.floor((sinescale / MSG_RATIO) / ct.scale + 0.5))
         s0 = ct.scale
         ct = C.mul_const_int(ct, k); ct.scale = s0 * k
+        for i in range(C.logN - 1 - self.ls, C.logN - 1):                           # subSum (sparse slots): Rotate by 2^i, Add, i = logSlots .. logN-2
+            ct = C.add(ct, C.rotate(ct, 1 << i))
         for G, n1 in zip(self.cts, self.cts_n1):                                    # CoeffsToSlots -> dft: LinearTransform, Rescale(min = scale before)
             s_in = ct.scale
-            ct = C.rescale_to(C.linear_transform_qp(ct, G, float(C.Q[ct.level]), n1), s_in)
+            lt = C.linear_transform_qp(ct, G, float(C.Q[ct.level]), n1, slots=self.period)
+            if dbg is not None:
+                dbg.setdefault("LinearTransform", []).append(lt.copy())
+            ct = C.rescale_to(lt, s_in)
         assert ct.level == LV_SINE_TOP
         cc = C.conjugate(ct)
+        if dbg is not None:
+            dbg["ConjugateNew"] = cc.copy()
         parts = [C.add(ct, cc), C.neg(C.mul_by_i(C.sub(ct, cc)))]                   # DivByi = times -i
+        if self.ls:                                                                 # repacking: Rotate(ct1, slots), Add(ct0, ct1, ct0); ct1 = nil from here on
+            parts = [C.add(parts[0], C.rotate(parts[1], self.ns))]
+        if dbg is not None:
+            dbg["CoeffsToSlots"] = [p.copy() for p in parts]
         be = _LattigoBackend(C)
         target = sinescale
         for r in range(SIN_DOUBLE):
@@ -953,6 +990,8 @@ class Bootstrapper:
             c = Ct(c.rows, sinescale)                                               # evaluateSine: ct.Scale = sinescale (times MessageRatio)
             c = C.add_const(c, -0.5 / (float(1 << SIN_DOUBLE) * (2.0 * SIN_K / float(1 << SIN_DOUBLE))))     # -0.5 / (scFac (b - a)) = -0.01
             c = lattigo_poly.evaluate_cheby(be, c, FORK_SINE_COEFFS, target, sinescale, max_deg=len(FORK_SINE_COEFFS) - 1, lead=True)
+            if dbg is not None:
+                dbg.setdefault("EvaluateCheby", []).append(c.copy())
             sqrt2pi = math.pow(0.15915494309189535, 1.0 / float(1 << SIN_DOUBLE))
             for r in range(SIN_DOUBLE):
                 sqrt2pi *= sqrt2pi
@@ -961,6 +1000,8 @@ class Bootstrapper:
                 c = C.rescale_to(C.add_const(c, -sqrt2pi), sinescale)
             assert c.level == LV_RELU_TOP
             c = Ct(c.rows, pscale)                                                  # ct.Scale = params.scale
+            if dbg is not None:
+                dbg.setdefault("evaluateSine", []).append(c.copy())
             c = C.rescale_to(C.mul_const_float(c, (q0 / sinescale) * (pscale / prescale)), pscale)
             out.append(c)
         return out
@@ -975,13 +1016,13 @@ class Bootstrapper:
             ct = C.add(ct_re, C.mul_by_i(ct_im))
         ct = C.drop_to(ct, self.stc_top)
         G = self.stc
-        if self.ls == 0 and self.fork_flow:
+        if self.fork_flow:
             # ckks.SlotsToCoeffs as the fork runs it (tests/golden/ref_flow_5_1.json): three LinearTransforms on level 3, each followed by
             # Rescale(min = the scale before) - which finds nothing to drop -, then eval.go:564's Rescale(2^30): level 3 -> 1
             sc = math.sqrt(float(C.Q[self.stc_top]))
             for M, n1, s_pt in zip(G, self.stc_n1, (sc, sc, 2.0 ** 30)):
                 s_in = ct.scale
-                ct = C.rescale_to(C.linear_transform_qp(ct, M, s_pt, n1), s_in)
+                ct = C.rescale_to(C.linear_transform_qp(ct, M, s_pt, n1, slots=self.period), s_in)
             return C.rescale_to(ct, 2.0 ** 30)
         # Ours: level 3 carries all but the last matrix (their plaintext scales multiply to q3), level 2 the last at scale 2^30
         first = G[:-1]

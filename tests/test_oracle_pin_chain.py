@@ -13,3 +13,11 @@ import chain_replay
 def test_convrelu_tail_end_to_end_equals_the_reference_binary():
     n, _ = chain_replay.replay()
     assert n == 4
+
+
+@pytest.mark.slow
+def test_sparse_ctos_equals_the_reference_binary():
+    """round 3: BootstrappConv_CtoS of the sparse-slot bootstrapper (log_sparse 2; the resnet's btp3, main.go:480-500) against the binary's digests
+    on planted data (`gotrace -chain -logslots 13`): subSum, the sparse DFT matrices with their repacking, the packed (re | im) ciphertext through
+    the sine - ten checkpoints from modUp to the ciphertext the function ends on"""
+    assert chain_replay.replay_sparse() == 10
