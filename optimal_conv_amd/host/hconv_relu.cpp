@@ -1116,10 +1116,16 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     if (prof) { HCR(hc_set_option(hc, "profile", 1)); hc_profile_get(hc, nullptr, nullptr, nullptr); }
     printf("Bootstrapping... Ours (until CtoS):\n");
     auto start = now();
-    DCt boots[2]; const int iter = B->ctos(ct, log_sparse, boots);                                     // eval.go:450-461
+    // test mode, with HCONV_CHAIN_REPLAY: HCONV_REPLAY_LOG_SPARSE=ls runs BootstrappConv_CtoS of the SPARSE-slot bootstrapper on the planted input, as
+    // `gotrace -chain -logslots 15-ls` made the reference binary do inside this very `convReLU` run (tests/golden/ref_trace_chain_sparse_ls13.json);
+    // the binary's run ends there (it panics on the nil second result), so does this one
+    const char *rls = B->replay_seed ? testOnlyEnv("HCONV_REPLAY_LOG_SPARSE") : nullptr;
+    const int ls_run = rls ? atoi(rls) : log_sparse;
+    DCt boots[2]; const int iter = B->ctos(ct, ls_run, boots);                                         // eval.go:450-461
     HCR(hc_sync(hc));
     printf("Done in %s \n", dur(start).c_str());
     if (B->replay_seed) for (int ul = 0; ul < iter; ul++) replay_digest(ul ? "ctos1" : "ctos0", boots[ul]);
+    if (rls) { printf("replay of the sparse-slot BootstrappConv_CtoS done (log_sparse %d)\n", ls_run); fflush(stdout); exit(0); }
     start = now();
     for (int ul = 0; ul < iter; ul++) {
         DCt r = evalReLU(B, boots[ul], alpha);                                                        // eval.go:473

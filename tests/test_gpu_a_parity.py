@@ -467,6 +467,19 @@ def test_evaluate_cheby_vs_reference_trace_on_gpu():
     ctx.close()
 
 
+def test_sparse_ctos_vs_reference_trace_on_gpu():
+    """round 3: BootstrappConv_CtoS of the sparse-slot bootstrapper (log_sparse 2) with every residue operation through the C ABI against the
+    reference binary's digests on planted data (tests/golden/ref_trace_chain_sparse_ls13.json, gotrace -chain -logslots 13): ten checkpoints"""
+    from optimal_conv_amd import Context
+    import chain_replay
+    holder = {}
+    def backend(C):
+        holder["ctx"] = Context(C.Q, C.P)
+        return pc.CkksDeviceBackend(holder["ctx"])
+    assert chain_replay.replay_sparse(backend) == 10
+    holder["ctx"].close()
+
+
 def test_convrelu_tail_end_to_end_vs_reference_trace_on_gpu():
     """the whole convReLU tail on the GPU against the reference binary: tests/chain_replay.py (planted input and keys of `gotrace -chain`,
     tests/golden/ref_trace_chain_5_1.json) with every residue operation of the chain through the C ABI - BootstrappConv_CtoS' two results,

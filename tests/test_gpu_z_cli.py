@@ -131,6 +131,26 @@ def test_conv_relu_cli_replays_the_reference_chain(tmp_path):
         assert (lv, sc) == (want["level"], want["scale"]) and polys == want["polys"], f"{name}: the host chain differs from the reference binary"
 
 
+def test_conv_relu_cli_replays_the_reference_sparse_ctos(tmp_path):
+    """The PRODUCT path against the reference binary on the SPARSE-slot bootstrapper (round 3): `gotrace -chain -logslots 13` made
+    /root/reference/test_run build and call the bootstrapper the resnet uses as btp3 (log_sparse 2) on planted data inside a `convReLU 5 1 1`
+    run (tests/golden/ref_trace_chain_sparse_ls13.json). With HCONV_CHAIN_REPLAY=<seed> HCONV_REPLAY_LOG_SPARSE=2 the CLI runs the same
+    BootstrappConv_CtoS - subSum, the fork's sparse DFT matrices in the encoder's sparse embedding, the repacked (re | im) ciphertext through
+    the sine - on the same input and keys: the SHA-256 of its result must be the binary's."""
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_trace_chain_sparse_ls13.json")))
+    want = [e for e in ref["events"] if e["fn"] == "Rescale" and "digests" in e][-1]["digests"][0]
+    ls = 15 - [p for p in ref["patched"] if p["op"].startswith("NewBootstrapper_mod")][0]["LogSlots"]
+    gen.write_case(str(tmp_path / "test_conv_data"), 5, 1, 0)
+    out = subprocess.run([CLI, "--test-mode", "convReLU", "5", "1", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HCONV_SEED="31", HCONV_CHAIN_REPLAY=str(ref["seed"]), HCONV_REPLAY_LOG_SPARSE=str(ls), HCONV_SKIP_BL="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = {m.group(1): (int(m.group(2)), float(m.group(3)), m.group(4).split()) for m in re.finditer(r"^replay digest (\S+) level (\d+) scale (\S+) ((?:[0-9a-f]{64} ?)+)$", out.stdout, re.M)}
+    assert set(got) == {"ctos0"}, out.stdout[-2000:]
+    lv, sc, polys = got["ctos0"]
+    assert (lv, sc) == (want["level"], want["scale"]) and polys == want["polys"], "the host's sparse BootstrappConv_CtoS differs from the reference binary"
+
+
 # wide_case 2 / 3 (testResNet_crop_sparse_wide) and the CIFAR-100 head are outside SURVEY.md section 8's rows (section 2 row 14): they run only
 # with HCONV_TEST_WIDE=1, so that the default -m gpu run spends its minutes on the in-scope rows
 _WIDE = pytest.mark.skipif(not os.environ.get("HCONV_TEST_WIDE"), reason="out-of-scope resnet variants: set HCONV_TEST_WIDE=1")
