@@ -920,6 +920,231 @@ __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTw
     }
 }
 
+// ================================================================ loop B for SMALL tree levels (round 3)
+// The top levels of a pack tree have 1..16 nodes: 16..256 workgroups for 256 CUs, one wave per SIMD, and a level costs the LATENCY of five
+// kernels (77..105 us whatever the node count; 0.45 ms of a lone convolution's 1.76) - each thread of the kernels above walks 64..192 butterflies
+// one after the other, and a 4096-residue tile is the work of ONE CU however many threads share it (1024 threads on the same tile measured 56 us per
+// level: the CU's four SIMDs issue the same 16 384 butterflies per pass). The S kernels below therefore cut the TILE to a quarter: 4 rows x 256 (rows passes)
+// or 256 x 4 columns (cols passes) = 1024 residues per 256-thread workgroup, four residues per thread, 64 workgroups per row instead of 16. The tile
+// lives in LDS (natural order, 8 KiB), a pass is four radix-4 rounds (two butterfly stages each) in place with a barrier between them. Same tables (the twiddle of a butterfly is looked up where hc_ct_round / hc_gs_round would
+// find it), same tmp layouts, same values: forward stages fold X by 4q (the HC_FM_ALT rule, every accepted modulus), inverse stages keep [0, 4q),
+// outputs canonical - so a level may run on either set of kernels and give the same bits.
+#define HC_STPB 256
+#define HC_STILES 64               // quarter tiles per row
+#define HC_S_LDS 1024
+template <bool ROWS> __device__ __forceinline__ int hc_s_addr(int line, int x) { return ROWS ? line * 256 + x : x * 4 + line; }
+__device__ __forceinline__ int hc_s_pos(int u, int lo) { return (u & ((1 << lo) - 1)) | ((u >> lo) << (lo + 2)); }     // u (6 bits) with two zero bits inserted at lo, lo + 1
+// twiddle of the forward butterfly at distance D whose lower element sits at position x of its 256-point line (gline: global row, rows passes)
+template <bool ROWS, int D> __device__ __forceinline__ HcTw hc_s_tw_fwd(const HcTwTab &T, int x, int gline) {
+    if (D >= 16) { constexpr int s = D == 128 ? 0 : D == 64 ? 1 : D == 32 ? 2 : 3; const int slot = (1 << s) - 1 + (x >> (8 - s)); return ROWS ? T.rowsA[gline * 16 + slot] : T.colsA[slot]; }
+    constexpr int s = D == 8 ? 0 : D == 4 ? 1 : D == 2 ? 2 : 3; const int slot = (1 << s) - 1 + ((x & 15) >> (4 - s));
+    return ROWS ? T.rowsB[gline * 256 + slot * 16 + (x >> 4)] : T.colsB[slot * 16 + (x >> 4)];
+}
+template <bool ROWS, int D> __device__ __forceinline__ HcTw hc_s_tw_inv(const HcTwTab &T, int x, int gline) {
+    if (D <= 8) { constexpr int s = D == 1 ? 0 : D == 2 ? 1 : D == 4 ? 2 : 3; const int slot = (8 >> s) - 1 + ((x & 15) >> (s + 1)); return ROWS ? T.rowsB[gline * 256 + slot * 16 + (x >> 4)] : T.colsB[slot * 16 + (x >> 4)]; }
+    constexpr int s = D == 16 ? 0 : D == 32 ? 1 : D == 64 ? 2 : 3; const int slot = (8 >> s) - 1 + (x >> (5 + s));
+    return ROWS ? T.rowsA[gline * 16 + slot] : T.colsA[slot];
+}
+__device__ __forceinline__ void hc_s_bf_fwd(u64 &X, u64 &Y, HcTw w, const HcQ &Q) { const u64 x = hc_fold(X, Q.nq4), t = hc_shoup4(Y, w.w, w.ws, Q); X = x + t; Y = (x + Q.q4) - t; }
+__device__ __forceinline__ void hc_s_bf_inv(u64 &X, u64 &Y, HcTw w, const HcQ &Q) { const u64 u = X + Y, d = (X + Q.q4) - Y; X = hc_fold(u, Q.nq4); Y = hc_shoup4(d, w.w, w.ws, Q); }
+// The twelve twiddles a thread needs for a pass (three per radix-4 round) depend only on its position: they are loaded BEFORE the pass, together with the
+// tile, so that the four rounds do not each start with an L2 round trip behind their barrier (measured: a 1-node level 56.5 us with per-round loads).
+template <bool ROWS> __device__ __forceinline__ void hc_s_tw_load_fwd(HcTw (&w)[12], const HcTwTab &T, int gline, int u) {
+    { const int x0 = hc_s_pos(u, 6); w[0] = hc_s_tw_fwd<ROWS, 128>(T, x0, gline); w[1] = hc_s_tw_fwd<ROWS, 64>(T, x0, gline); w[2] = hc_s_tw_fwd<ROWS, 64>(T, x0 + 128, gline); }
+    { const int x0 = hc_s_pos(u, 4); w[3] = hc_s_tw_fwd<ROWS, 32>(T, x0, gline); w[4] = hc_s_tw_fwd<ROWS, 16>(T, x0, gline); w[5] = hc_s_tw_fwd<ROWS, 16>(T, x0 + 32, gline); }
+    { const int x0 = hc_s_pos(u, 2); w[6] = hc_s_tw_fwd<ROWS, 8>(T, x0, gline); w[7] = hc_s_tw_fwd<ROWS, 4>(T, x0, gline); w[8] = hc_s_tw_fwd<ROWS, 4>(T, x0 + 8, gline); }
+    { const int x0 = hc_s_pos(u, 0); w[9] = hc_s_tw_fwd<ROWS, 2>(T, x0, gline); w[10] = hc_s_tw_fwd<ROWS, 1>(T, x0, gline); w[11] = hc_s_tw_fwd<ROWS, 1>(T, x0 + 2, gline); }
+}
+template <bool ROWS> __device__ __forceinline__ void hc_s_tw_load_inv(HcTw (&w)[12], const HcTwTab &T, int gline, int u) {
+    { const int x0 = hc_s_pos(u, 0); w[0] = hc_s_tw_inv<ROWS, 1>(T, x0, gline); w[1] = hc_s_tw_inv<ROWS, 1>(T, x0 + 2, gline); w[2] = hc_s_tw_inv<ROWS, 2>(T, x0, gline); }
+    { const int x0 = hc_s_pos(u, 2); w[3] = hc_s_tw_inv<ROWS, 4>(T, x0, gline); w[4] = hc_s_tw_inv<ROWS, 4>(T, x0 + 8, gline); w[5] = hc_s_tw_inv<ROWS, 8>(T, x0, gline); }
+    { const int x0 = hc_s_pos(u, 4); w[6] = hc_s_tw_inv<ROWS, 16>(T, x0, gline); w[7] = hc_s_tw_inv<ROWS, 16>(T, x0 + 32, gline); w[8] = hc_s_tw_inv<ROWS, 32>(T, x0, gline); }
+    { const int x0 = hc_s_pos(u, 6); w[9] = hc_s_tw_inv<ROWS, 64>(T, x0, gline); w[10] = hc_s_tw_inv<ROWS, 64>(T, x0 + 128, gline); w[11] = hc_s_tw_inv<ROWS, 128>(T, x0, gline); }
+}
+// one radix-4 round of a forward pass: distances D and D/2 (wa: stage D; wb, wc: stage D/2 of the lower / upper pair)
+template <bool ROWS, int D> __device__ __forceinline__ void hc_s_round_fwd(u64 *lds, HcTw wa, HcTw wb, HcTw wc, int line, int u, const HcQ &Q) {
+    constexpr int lo = D == 128 ? 6 : D == 32 ? 4 : D == 8 ? 2 : 0, H = D / 2;
+    const int x0 = hc_s_pos(u, lo);
+    u64 e0 = lds[hc_s_addr<ROWS>(line, x0)], e1 = lds[hc_s_addr<ROWS>(line, x0 + H)], e2 = lds[hc_s_addr<ROWS>(line, x0 + D)], e3 = lds[hc_s_addr<ROWS>(line, x0 + D + H)];
+    hc_s_bf_fwd(e0, e2, wa, Q); hc_s_bf_fwd(e1, e3, wa, Q);
+    hc_s_bf_fwd(e0, e1, wb, Q); hc_s_bf_fwd(e2, e3, wc, Q);
+    lds[hc_s_addr<ROWS>(line, x0)] = e0; lds[hc_s_addr<ROWS>(line, x0 + H)] = e1; lds[hc_s_addr<ROWS>(line, x0 + D)] = e2; lds[hc_s_addr<ROWS>(line, x0 + D + H)] = e3;
+}
+// one radix-4 round of an inverse pass: distances D and 2D (wa, wb: stage D of the lower / upper pair; wc: stage 2D). SCALE_LAST (D == 64 of a cols pass that carries
+// N^-1): the final stage multiplies its sums by N^-1 and uses the twiddle that has N^-1 folded in (hc_gs_round<LAST>)
+template <bool ROWS, int D, bool SCALE_LAST> __device__ __forceinline__ void hc_s_round_inv(u64 *lds, const HcTwTab &T, HcTw wa, HcTw wb, HcTw wc, int line, int u, const HcQ &Q) {
+    constexpr int lo = D == 1 ? 0 : D == 4 ? 2 : D == 16 ? 4 : 6, G = 2 * D;
+    const int x0 = hc_s_pos(u, lo);
+    u64 e0 = lds[hc_s_addr<ROWS>(line, x0)], e1 = lds[hc_s_addr<ROWS>(line, x0 + D)], e2 = lds[hc_s_addr<ROWS>(line, x0 + G)], e3 = lds[hc_s_addr<ROWS>(line, x0 + G + D)];
+    hc_s_bf_inv(e0, e1, wa, Q); hc_s_bf_inv(e2, e3, wb, Q);
+    if (SCALE_LAST) {
+        const u64 ua = e0 + e2, da = (e0 + Q.q4) - e2, ub = e1 + e3, db = (e1 + Q.q4) - e3;
+        e0 = hc_shoup4(ua, T.ninv.w, T.ninv.ws, Q); e2 = hc_shoup4(da, T.w_last_ninv.w, T.w_last_ninv.ws, Q);
+        e1 = hc_shoup4(ub, T.ninv.w, T.ninv.ws, Q); e3 = hc_shoup4(db, T.w_last_ninv.w, T.w_last_ninv.ws, Q);
+    } else { hc_s_bf_inv(e0, e2, wc, Q); hc_s_bf_inv(e1, e3, wc, Q); }
+    lds[hc_s_addr<ROWS>(line, x0)] = e0; lds[hc_s_addr<ROWS>(line, x0 + D)] = e1; lds[hc_s_addr<ROWS>(line, x0 + G)] = e2; lds[hc_s_addr<ROWS>(line, x0 + G + D)] = e3;
+}
+// whole passes over the tile in LDS with preloaded twiddles; every thread must call them; they end with a barrier (the tile is complete and visible)
+template <bool ROWS> __device__ __forceinline__ void hc_s_pass_fwd(u64 *lds, const HcTw (&w)[12], int line, int u, const HcQ &Q) {
+    hc_s_round_fwd<ROWS, 128>(lds, w[0], w[1], w[2], line, u, Q); __syncthreads();
+    hc_s_round_fwd<ROWS, 32>(lds, w[3], w[4], w[5], line, u, Q); __syncthreads();
+    hc_s_round_fwd<ROWS, 8>(lds, w[6], w[7], w[8], line, u, Q); __syncthreads();
+    hc_s_round_fwd<ROWS, 2>(lds, w[9], w[10], w[11], line, u, Q); __syncthreads();
+}
+template <bool ROWS, bool SCALE> __device__ __forceinline__ void hc_s_pass_inv(u64 *lds, const HcTwTab &T, const HcTw (&w)[12], int line, int u, const HcQ &Q) {
+    hc_s_round_inv<ROWS, 1, false>(lds, T, w[0], w[1], w[2], line, u, Q); __syncthreads();
+    hc_s_round_inv<ROWS, 4, false>(lds, T, w[3], w[4], w[5], line, u, Q); __syncthreads();
+    hc_s_round_inv<ROWS, 16, false>(lds, T, w[6], w[7], w[8], line, u, Q); __syncthreads();
+    hc_s_round_inv<ROWS, 64, SCALE>(lds, T, w[9], w[10], w[11], line, u, Q); __syncthreads();
+}
+// thread -> (line, u): rows tiles: 64 consecutive threads per row; cols tiles: the column index is the fast one
+#define HC_S_ROWS_MAP const int t = threadIdx.x, line = t >> 6, u = t & 63, grow = HC_TILE * 4 + line
+#define HC_S_COLS_MAP const int t = threadIdx.x, line = t & 3, u = t >> 2
+
+// SB1: t2.c1 = y1 - I*x1, rows-inverse mod Q0 -> tmpC. grid = (64, batch*nodes)
+__global__ __launch_bounds__(HC_STPB) void hc_k_sb1(HcLoopB B, HcTwTab T0inv) {
+    __shared__ u64 lds[HC_S_LDS];
+    HC_S_ROWS_MAP;
+    const int job = HC_JOB, z = job / B.nodes, node = job - z * B.nodes, i = (B.n0 + node) * B.norm;
+    const size_t tile = (size_t)HC_TILE * 1024;
+    const u64 *__restrict__ y1 = B.src + (size_t)z * B.src_stride + ((size_t)i * 2 + 1) * 65536 + tile;
+    const u64 *__restrict__ x1 = B.src + (size_t)z * B.src_stride + ((size_t)(i + B.step) * 2 + 1) * 65536 + tile;
+    const HcTw *__restrict__ idx = B.idx + tile;
+    const HcQ Q = hc_q(B.m0.q);
+    HcTw w[12]; hc_s_tw_load_inv<true>(w, T0inv, grow, u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = k * 256 + t; const HcTw I = idx[p];
+        lds[p] = hc_fold(y1[p] + Q.q4 - hc_shoup4(x1[p], I.w, I.ws, Q), Q.nq4);          // t2.c1 (conv.go:288-289), lazy < 4q
+    }
+    __syncthreads();
+    hc_s_pass_inv<true, false>(lds, T0inv, w, line, u, Q);
+    u64 *__restrict__ o = B.tmpC + (size_t)job * 65536 + tile;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k * 256 + t] = lds[k * 256 + t];
+}
+// SB2: cols-inverse mod Q0 (with N^-1) -> canonical -> cols-forward mod P, in place on tmpC. grid = (64, batch*nodes); the tile is 256 rows x 4 columns
+__global__ __launch_bounds__(HC_STPB) void hc_k_sb2(HcLoopB B, HcTwTab T0inv, HcTwTab TPfwd) {
+    __shared__ u64 lds[HC_S_LDS];
+    HC_S_COLS_MAP;
+    u64 *base = B.tmpC + (size_t)HC_JOB * 65536 + HC_TILE * 4;
+    const HcQ Q0 = hc_q(B.m0.q), QP = hc_q(B.mp.q);
+    HcTw w[12]; hc_s_tw_load_inv<false>(w, T0inv, 0, u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int r = k * 64 + u; lds[r * 4 + line] = base[(size_t)r * 256 + line]; }
+    __syncthreads();
+    hc_s_pass_inv<false, true>(lds, T0inv, w, line, u, Q0);
+    hc_s_tw_load_fwd<false>(w, TPfwd, 0, u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int a = (k * 64 + u) * 4 + line; lds[a] = hc_canon4(lds[a], Q0); }       // each thread its own four words: no barrier needed before, one after
+    __syncthreads();
+    hc_s_pass_fwd<false>(lds, w, line, u, QP);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int r = k * 64 + u; base[(size_t)r * 256 + line] = lds[r * 4 + line]; }
+}
+// SB3: rows-forward mod P, times the k-th P row of the key, rows-inverse mod P -> tmpE[k]. grid = (64, batch*nodes, 2): blockIdx.z = k (both polynomials in parallel;
+// the forward pass is done twice, a level's latency is what counts here)
+__global__ __launch_bounds__(HC_STPB) void hc_k_sb3(HcLoopB B, HcTwTab TPfwd, HcTwTab TPinv) {
+    __shared__ u64 lds[HC_S_LDS];
+    HC_S_ROWS_MAP;
+    const int node = HC_JOB, k = blockIdx.z;
+    const size_t tile = (size_t)HC_TILE * 1024;
+    const u64 *in = B.tmpC + (size_t)node * 65536 + tile;
+    const HcQ Q = hc_q(B.mp.q);
+    HcTw w[12]; hc_s_tw_load_fwd<true>(w, TPfwd, grow, u);
+#pragma unroll
+    for (int j = 0; j < 4; j++) lds[j * 256 + t] = in[j * 256 + t];
+    __syncthreads();
+    hc_s_pass_fwd<true>(lds, w, line, u, Q);
+    hc_s_tw_load_inv<true>(w, TPinv, grow, u);
+    const HcTw *__restrict__ ev = B.evkP + (size_t)k * 65536;                    // lo-local coalesced order: natural (R, C = tid*16 + lo) -> ((R>>4)*16 + lo)*256 + (R&15)*16 + tid
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = j * 256 + t, R = HC_TILE * 4 + (p >> 8), C = p & 255;
+        const HcTw w = ev[((R >> 4) * 16 + (C & 15)) * 256 + (R & 15) * 16 + (C >> 4)];
+        lds[p] = hc_shoup4(lds[p], w.w, w.ws, Q);                                  // < 4q for any 64-bit input: what the inverse pass takes
+    }
+    __syncthreads();
+    hc_s_pass_inv<true, false>(lds, TPinv, w, line, u, Q);
+    u64 *o = B.tmpE + ((size_t)node * 2 + k) * 65536 + tile;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j * 256 + t] = lds[j * 256 + t];
+}
+// SB4: cols-inverse mod P (N^-1 is inside the key rows), exact extension P -> Q0 divided by P, cols-forward mod Q0, in place on tmpE. grid = (64, 2*batch*nodes)
+__global__ __launch_bounds__(HC_STPB) void hc_k_sb4(HcLoopB B, HcTwTab TPinv, HcTwTab T0fwd) {
+    __shared__ u64 lds[HC_S_LDS];
+    HC_S_COLS_MAP;
+    u64 *base = B.tmpE + (size_t)HC_JOB * 65536 + HC_TILE * 4;
+    const HcQ QP = hc_q(B.mp.q), Q = hc_q(B.m0.q);
+    HcTw w[12]; hc_s_tw_load_inv<false>(w, TPinv, 0, u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int r = k * 64 + u; lds[r * 4 + line] = base[(size_t)r * 256 + line]; }
+    __syncthreads();
+    hc_s_pass_inv<false, false>(lds, TPinv, w, line, u, QP);
+    hc_s_tw_load_fwd<false>(w, T0fwd, 0, u);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int a = (k * 64 + u) * 4 + line;
+        const u64 yv = hc_canon4(lds[a], QP);                      // [d]_P in [0, P)
+        u64 r = hc_shoup4(yv, B.pinv.w, B.pinv.ws, Q);             // y * P^-1 mod Q0, lazy (hc_k_b4)
+        if (yv >= B.vthresh) r += Q.q - 1;                          // - v with v = uint64(float64(y) / float64(P))
+        lds[a] = r;
+    }
+    __syncthreads();
+    hc_s_pass_fwd<false>(lds, w, line, u, Q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int r = k * 64 + u; base[(size_t)r * 256 + line] = lds[r * 4 + line]; }
+}
+// SB5: per (node, polynomial k): rows-forward of the k-th extension, d = F - n through LDS with the row-local Galois gather, dst = t1 + perm(d) (+ bias on k = 0 of
+// the root). grid = (64, 2*batch*nodes): job = (z*nodes + node)*2 + k. t2.c1 is recomputed from x1, y1, idx (as hc_k_b5m does). galEl = 2^j + 1 with j >= 9 only (the permutation stays inside a row).
+__global__ __launch_bounds__(HC_STPB) void hc_k_sb5(HcLoopB B, HcTwTab T0fwd, HcPtrs biases, HcPtrs outs) {
+    __shared__ u64 lds[HC_S_LDS];
+    HC_S_ROWS_MAP;
+    const int job = HC_JOB, zn = job >> 1, k = job & 1, z = zn / B.nodes, node = zn - z * B.nodes, i = (B.n0 + node) * B.norm;
+    const HcQ Q = hc_q(B.m0.q);
+    const size_t tile = (size_t)HC_TILE * 1024;
+    const u64 *__restrict__ in = B.tmpE + (size_t)job * 65536 + tile;
+    const u64 *__restrict__ ys = B.src + (size_t)z * B.src_stride + (size_t)i * 2 * 65536 + tile;
+    const u64 *__restrict__ xs = B.src + (size_t)z * B.src_stride + (size_t)(i + B.step) * 2 * 65536 + tile;
+    const HcTw *__restrict__ idx = B.idx + tile;
+    const HcTw *__restrict__ evk = B.evkQ + (size_t)k * 65536 + tile;
+    u64 *__restrict__ o = (outs.p[z] != nullptr ? const_cast<u64 *>(outs.p[z]) + (size_t)k * 65536 : B.dst + (size_t)z * B.dst_stride + ((size_t)i * 2 + k) * 65536) + tile;
+    const u64 *__restrict__ bias = (k == 0 && biases.p[z] != nullptr) ? biases.p[z] + tile : nullptr;
+    HcTw w[12]; hc_s_tw_load_fwd<true>(w, T0fwd, grow, u);
+#pragma unroll
+    for (int j = 0; j < 4; j++) lds[j * 256 + t] = in[j * 256 + t];
+    __syncthreads();
+    hc_s_pass_fwd<true>(lds, w, line, u, Q);
+    u64 t1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = j * 256 + t;
+        const HcTw I = idx[p], K = evk[p];
+        const u64 y1 = ys[65536 + p], x1 = xs[65536 + p];
+        const u64 T = hc_fold(y1 + Q.q4 - hc_shoup4(x1, I.w, I.ws, Q), Q.nq4);                    // t2.c1, the expression of hc_k_sb1 / hc_k_b1
+        const u64 g = hc_canon4(hc_shoup4(T, K.w, K.ws, Q), Q);                                   // (key row / P) * t2.c1
+        const u64 n = hc_canon8(lds[p], Q);
+        u64 f;
+        if (k == 0) {
+            const u64 y0 = ys[p], m = hc_canon4(hc_shoup4(xs[p], I.w, I.ws, Q), Q);
+            t1[j] = hc_addmod(y0, m, Q.q);
+            if (bias != nullptr) t1[j] = hc_addmod(t1[j], bias[p], Q.q);
+            f = hc_addmod(hc_submod(y0, m, Q.q), g, Q.q);
+        } else {
+            t1[j] = hc_addmod(y1, hc_submod(y1, hc_canon4(T, Q), Q.q), Q.q);                      // y1 + I*x1 with I*x1 = y1 - t2.c1
+            f = g;
+        }
+        lds[p] = hc_submod(f, n, Q.q);                                                             // d_k (each thread overwrites only the words it read)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = j * 256 + t;
+        const u32 srcidx = hc_perm_src((u32)(HC_TILE * 1024 + p), B.gal);
+        o[p] = hc_addmod(t1[j], lds[srcidx & 1023], Q.q);                                          // row-local permutation: the source is in this 4-row tile
+    }
+}
+
 // ================================================================ general hybrid key switch (any level, alpha P primes)
 // Building blocks for rlwe.KeySwitcher.SwitchKeysInPlace beyond the conv path's level-0 case (BL baseline: level 1 with
 // two special primes; bootstrapping: alpha = 5, several digits); the kernels are in the multi-modulus section below.

@@ -119,6 +119,7 @@ struct hc_ctx {
     hipEvent_t ev_shard = nullptr;     // hc_conv_then_pack_sharded: this device's partial ciphertext is complete / has been collected
     u64 *ws_gather = nullptr; size_t ws_gather_rows = 0;
     std::vector<HcOp> *rec = nullptr;     // non-null: hc_launch / hc_copy_d2d append to it instead of enqueueing on the stream
+    long small_levels = 16;               // pack-tree launches of at most this many nodes (summed over the batch) run on the 1024-thread S kernels; 0 = never
     long peer_access = 1;                 // hc_conv_then_pack_sharded: enable direct peer copies between distinct devices (0: leave the copies to hipMemcpyPeerAsync's staging)
     unsigned peer_enabled = 0;            // bit d: peer access from this context's device to device d was enabled by (or found enabled for) this context
     long b5_merged = 1;                   // row-local pack levels: one b5 workgroup per (node, tile) for both polynomials (hc_k_b5m); 0 = two jobs (A/B switch)
@@ -210,15 +211,15 @@ static char hc_op_kind(const char *name) {       // by kernel name: the measured
     if ((name[0] == 'a' && name[1] == '2') || (name[0] == 'b' && (name[1] == '2' || name[1] == '3' || name[1] == '4'))) return 'V';
     return 'M';
 }
-template <class K, class... Args>
+template <int TPB = HC_TPB, class K, class... Args>
 static int hc_launch(hc_ctx *c, const char *name, K kernel, dim3 grid, Args... args) {
     if (c->rec) {
-        c->rec->push_back(HcOp{hc_op_kind(name), [=](hipStream_t st) -> hipError_t { hipLaunchKernelGGL(kernel, grid, dim3(HC_TPB), 0, st, args...); return hipGetLastError(); }});
+        c->rec->push_back(HcOp{hc_op_kind(name), [=](hipStream_t st) -> hipError_t { hipLaunchKernelGGL(kernel, grid, dim3(TPB), 0, st, args...); return hipGetLastError(); }});
         return HC_OK;
     }
     hipEvent_t a = nullptr, b = nullptr;
     if (c->profile) { HC_HIP(c, hipEventCreate(&a)); HC_HIP(c, hipEventCreate(&b)); HC_HIP(c, hipEventRecord(a, c->stream)); }
-    hipLaunchKernelGGL(kernel, grid, dim3(HC_TPB), 0, c->stream, args...);
+    hipLaunchKernelGGL(kernel, grid, dim3(TPB), 0, c->stream, args...);
     HC_HIP(c, hipGetLastError());
     if (c->profile) { HC_HIP(c, hipEventRecord(b, c->stream)); c->prof.push_back({name, a, b}); }
     return HC_OK;
@@ -907,6 +908,19 @@ static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, size_t sstride, si
         const int nn = (nodes - n0) < chunk ? (nodes - n0) : chunk;
         B.n0 = n0; B.nodes = nn;
         const dim3 g1 = hc_grid(n * nn), g2 = hc_grid(2 * n * nn);
+        if (c->small_levels > 0 && (long)n * nn <= c->small_levels && it->second.row256 && !HC_JOB_FAST) {
+            // a level of a few nodes is one partial wave of workgroups and costs the latency of its five kernels: quarter tiles (1024 residues per workgroup, four per
+            // thread: hc_kernels.h, "loop B for SMALL tree levels") spread a row over 64 CUs instead of 16. Same tables, same tmp layouts, same bits.
+            const HcPtrs pb = bias_last ? *bias_last : nobias, po = outs_last ? *outs_last : nobias;
+            B.tmpT = nullptr;
+            const dim3 s1(HC_STILES, (unsigned)(n * nn)), s2(HC_STILES, (unsigned)(2 * n * nn)), s3(HC_STILES, (unsigned)(n * nn), 2);
+            HC_TRY(hc_launch<HC_STPB>(c, "b1_node_rowsinv", hc_k_sb1, s1, B, m0.inv));
+            HC_TRY(hc_launch<HC_STPB>(c, "b2_colsinv_colsfwdP", hc_k_sb2, s1, B, m0.inv, mp.fwd));
+            HC_TRY(hc_launch<HC_STPB>(c, "b3_rowsfwdP_mac_rowsinvP", hc_k_sb3, s3, B, mp.fwd, mp.inv));
+            HC_TRY(hc_launch<HC_STPB>(c, "b4_colsinvP_modup_colsfwd", hc_k_sb4, s2, B, mp.inv, m0.fwd));
+            HC_TRY(hc_launch<HC_STPB>(c, "b5_rowsfwd_moddown_perm_add", hc_k_sb5, s2, B, m0.fwd, pb, po));
+            continue;
+        }
         HC_TRY(hc_launch(c, "b1_node_rowsinv", hc_k_b1, g1, B, m0.inv));
         HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b2_colsinv_colsfwdP", hc_k_b2, g1, B, m0.inv, mp.fwd));
         HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, g1, B, mp.fwd, mp.inv));
@@ -1563,6 +1577,7 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!c || !name) return HC_ERR_ARG;
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
     if (!strcmp(name, "lanes")) { if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
+    if (!strcmp(name, "small_levels")) { if (value < 0) return hc_fail(c, HC_ERR_ARG, "small_levels must be >= 0"); c->small_levels = value; return HC_OK; }
     if (!strcmp(name, "peer_access")) { c->peer_access = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "b5_merged")) { c->b5_merged = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "antiphase")) { c->antiphase = value ? 1 : 0; return HC_OK; }

@@ -61,6 +61,17 @@ def test_conv_then_pack(env, max_ob, chunk):
     pc.case_conv(*env, max_ob, chunk=chunk)
 
 
+@pytest.mark.parametrize("max_ob,chunk", [(4, 1), (16, 32)])
+def test_conv_then_pack_without_the_small_level_kernels(env, max_ob, chunk):
+    """trees of up to 16 nodes run on the 1024-thread S kernels by default (round 3); with small_levels = 0 the same trees go through the
+    256-thread kernels of the big levels (b1 .. b4, b5m): both must give the oracle's bits"""
+    env[0].set_option("small_levels", 0)
+    try:
+        pc.case_conv(*env, max_ob, chunk=chunk)
+    finally:
+        env[0].set_option("small_levels", 16)
+
+
 @pytest.mark.parametrize("k,i_batch", [(3, 0), (5, 1), (7, 2)])
 def test_prep_ker(env, k, i_batch):
     import json

@@ -64,6 +64,17 @@ def test_conv_then_pack_vs_oracle(env, max_ob, chunk):
     pc.case_conv(*env, max_ob, chunk=chunk)
 
 
+@pytest.mark.parametrize("max_ob,chunk", [(4, 1), (16, 5), (64, 32)])
+def test_conv_then_pack_without_the_small_level_kernels(env, max_ob, chunk):
+    """trees of up to 16 nodes run on the 1024-thread S kernels by default (round 3); with small_levels = 0 the same trees go through the
+    256-thread kernels of the big levels (b1 .. b4, b5m): both must give the oracle's bits"""
+    env[0].set_option("small_levels", 0)
+    try:
+        pc.case_conv(*env, max_ob, chunk=chunk)
+    finally:
+        env[0].set_option("small_levels", 16)
+
+
 def test_conv_deterministic_across_chunking(env):
     """results must not depend on launch geometry (SURVEY.md 8b 'Determinism')"""
     ctx, O = env
