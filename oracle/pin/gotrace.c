@@ -714,6 +714,33 @@ static void lt_plant_key(uint64_t level, uint64_t evk, int id) {
         for (int j = 0; j < alpha; j++) plant_row(poly_row(poly, limbs - alpha + j, NULL), SEED_KSEVK(id, d, k, 32 + j), g_Pm[j]);
     }
 }
+/* -blop N (with -keep-bl -noplant, `conv k i 1`): the BASELINE operator main.evalConv_BN_BL_test (eval.go:78-134: preConv_BL's hoisted input rotations, the
+ * k^2 plaintext products per output rotation, the output rotations, the BN bias) as a whole on planted data: at the entry of the first N calls the input
+ * ciphertext is planted (SEED_OPIN(5000 + call, 0, poly, limb)), every rotation key its KeyswitchHoisted (input rotations) reads is planted with identity
+ * LT_BABY_ID and every key a RotateNew's SwitchKeysInPlaceNoModDown reads with LT_GIANT_ID (the same rows for every key of a kind), and the returned
+ * ciphertext is digested. The plaintexts are the run's own (kernel CSVs through the pinned slot encoder). Args (Go 1.16 stack ABI): cont, ct_input, ker_in,
+ * bn_a, bn_b (3 slices), seven ints, two bools: 0x98 bytes from [rsp+8]; the result pointer follows at [rsp+0xa0]. */
+static int g_blop_max = 0, g_blop_calls = 0, g_in_blop = 0;
+static void ret_blop(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    uint64_t E = r->rsp - 8, ct = rd64(E + 0xa0);
+    g_in_blop = 0;
+    emit_begin("evalConv_BN_BL_test.ret"); fprintf(g_out, ", \"call\": %d", g_blop_calls - 1); emit_ct("out", ct); emit_end();
+    if (g_blop_calls >= g_blop_max) { fprintf(g_out, "\n ],\n \"exit_code\": 0}\n"); fflush(g_out); kill(g_pid, SIGKILL); exit(0); } }
+static void on_blop(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud;
+    if (!g_blop_max || g_blop_calls >= g_blop_max) return;
+    uint64_t ct = rd64(r->rsp + 0x10); const int call = g_blop_calls++;
+    plant_ct(ct, 5000 + call, 0);
+    g_in_blop = 1;
+    emit_begin("evalConv_BN_BL_test.call"); fprintf(g_out, ", \"call\": %d, \"in_wid\": %lu, \"ker_wid\": %lu, \"real_ib\": %lu, \"real_ob\": %lu, \"pos\": %lu, \"norm\": %lu, \"pad\": %lu",
+        call, rd64(r->rsp + 0x60), rd64(r->rsp + 0x68), rd64(r->rsp + 0x70), rd64(r->rsp + 0x78), rd64(r->rsp + 0x80), rd64(r->rsp + 0x88), rd64(r->rsp + 0x90));
+    emit_ct("in", ct); emit_end();
+    hook_return(r, ret_blop, ud_new(0, 0, 0)); }
+static void blop_plant(uint64_t level, uint64_t evk, int id, const char *what) {
+    const uint64_t v0 = rd64(evk); const int limbs0 = poly_limbs(rd64(v0));
+    if ((int)level >= g_nQ || limbs0 - g_nQ_full < 1 || limbs0 - g_nQ_full > g_nP) { fprintf(stderr, "-blop: %s at level %lu with %d-limb key rows does not fit -Q / -P / -nq-full\n", what, level, limbs0); exit(3); }
+    lt_plant_key(level, evk, id); }
+static void on_blop_hoisted(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_blop) return; blop_plant(rd64(r->rsp + 0x10), rd64(r->rsp + 0x48), LT_BABY_ID, "KeyswitchHoistedNoModDown"); }
+static void on_blop_switch(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_blop) return; blop_plant(rd64(r->rsp + 0x10), rd64(r->rsp + 0x20), LT_GIANT_ID, "SwitchKeysInPlaceNoModDown"); }
 static void on_lt_ks_hoisted(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; (void)ud; if (!g_in_lt) return;
     uint64_t level = rd64(r->rsp + 0x10), evk = rd64(r->rsp + 0x48);
     lt_plant_key(level, evk, LT_BABY_ID);
@@ -910,6 +937,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[ai], "-poly") && ai + 1 < argc) g_poly_max = atoi(argv[++ai]);          /* trace this many EvaluatePoly calls (planted input and keys) */
         else if (!strcmp(argv[ai], "-enc") && ai + 1 < argc) g_enc_max = atoi(argv[++ai]);            /* trace the slot encoder: this many invfft / Encode calls */
         else if (!strcmp(argv[ai], "-diag") && ai + 1 < argc) g_diag_max = atoi(argv[++ai]);          /* digest this many encoded DFT diagonals */
+        else if (!strcmp(argv[ai], "-blop") && ai + 1 < argc) g_blop_max = atoi(argv[++ai]);          /* the baseline operator evalConv_BN_BL_test on planted input and keys */
         else if (!strcmp(argv[ai], "-logslots") && ai + 1 < argc) g_logslots = atoi(argv[++ai]);      /* with -diag: sparse-slot bootstrapper (see on_newbtp_mod) */
         else if (!strcmp(argv[ai], "-dump") && ai + 1 < argc) { g_dump = fopen(argv[++ai], "wb"); if (!g_dump) { perror("dump"); return 2; } }
         else if (!strcmp(argv[ai], "-flow")) g_flow_mode = 1;
@@ -971,6 +999,7 @@ int main(int argc, char **argv) {
                       bp_add(A_POWERBASIS, on_p_powerbasis, NULL); bp_add(A_ADD, on_p_add, NULL); bp_add(A_MULTBYCONST, on_p_multbyconst, NULL); }
     if (g_lt_max) { bp_add(post_check(0x5264c0), on_lt, NULL); bp_add(post_check(0x4ff060), on_lt_ks_hoisted, NULL); bp_add(post_check(0x4fe660), on_lt_ks_nomoddown, NULL);
                     bp_add(post_check(0x4e4c40), on_lt_moddown, NULL); }
+    if (g_blop_max) { bp_add(post_check(0x53bb80), on_blop, NULL); bp_add(post_check(0x4ff060), on_blop_hoisted, NULL); bp_add(post_check(0x4fe660), on_blop_switch, NULL); }
     if (g_diag_max) { bp_add(A_ENCDIAG, on_encdiag, NULL); bp_add(A_ENCMAT, on_encmat, NULL); }
     if (g_enc_max) { bp_add(A_INVFFT, on_invfft, NULL); bp_add(A_ENCODE, on_encode_slots, NULL); }
     if (g_ops_max) { bp_add(A_RESCALE, on_rescale, NULL); bp_add(A_MULRELIN, on_mulrelin, NULL); bp_add(A_ROTATE, on_rotate, NULL); bp_add(A_MODUP, on_modup, NULL); }

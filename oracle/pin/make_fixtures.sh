@@ -81,3 +81,29 @@ python3 "$REPO/oracle/pin/mk_flow_fixture.py" "$REPO/tests/golden/ref_trace_chai
 # the baseline half's stock Bootstrapp, log only
 "$SCRATCH/gotrace" -flow-bl -o trace_flow_bl_5_1.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_flow_bl.txt 2>&1
 python3 "$REPO/oracle/pin/mk_flow_fixture.py" "$REPO/tests/golden/ref_flow_bl_5_1.json" trace_flow_bl_5_1.json
+
+# ---- round 3 ----
+# the sparse-slot bootstrappers (main.go:480-500's btp2..btp5; this snapshot never calls them): DFT matrices per LogSlots, and BootstrappConv_CtoS on planted data at LogSlots 13.
+# ONE run at a time: a convReLU run holds up to 37 GB.
+python3 "$REPO/tests/golden/gen_conv_csv.py" "$SCRATCH/test_conv_data" 5 1 1
+for ls in 14 13 12 11; do
+  "$SCRATCH/gotrace" -diag 4000 -logslots $ls -o trace_diag_ls$ls.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_diag_ls$ls.txt 2>&1 || true      # ends in CheckKeys' panic, after genDFTMatrices
+  python3 - "$REPO/tests/golden/ref_trace_diag_sparse_ls$ls.json" trace_diag_ls$ls.json $ls <<'PY'
+import json, sys
+d = json.load(open(sys.argv[2])); ls = int(sys.argv[3]); ev = []
+for e in d["events"]:
+    if e["op"] in ("EncodeDiagMatrixBSGSAtLvl", "matrix_done", "NewBootstrapper_mod.patched"): ev.append(e)
+    elif e["op"] == "encodeDiagonal":
+        ev.append({"op": e["op"], "matrix": e["matrix"], "level": e["level"], "scale": e["scale"], "n": e["n"], "values": e["values"],
+                   "mQ": e["mQ"]["sha256"], "mQ_limbs": e["mQ"]["limbs"], "mP": e["mP"]["sha256"], "mP_limbs": e["mP"]["limbs"]})
+d["events"] = ev
+d["note"] = f"gotrace -diag 4000 -logslots {ls} over `convReLU 5 1 1`: both LogSlots of ckks.NewBootstrapper_mod overwritten with {ls} (the resnet's btp{16 - ls}); matrices 0-3 CoeffsToSlots, 4-6 and 7-9 the two SlotsToCoeffs sets"
+json.dump(d, open(sys.argv[1], "w"), indent=0)
+PY
+done
+"$SCRATCH/gotrace" -chain -logslots 13 -Q $Q -P $P -nq-full 28 -o trace_chain_ls13.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_chain_ls13.txt 2>&1 || true   # ends in the binary's own panic after BootstrappConv_CtoS' first result
+python3 "$REPO/oracle/pin/mk_flow_fixture.py" "$REPO/tests/golden/ref_trace_chain_sparse_ls13.json" trace_chain_ls13.json
+# the baseline operator evalConv_BN_BL_test as a whole on planted input and rotation keys
+python3 "$REPO/tests/golden/gen_conv_csv.py" "$SCRATCH/test_conv_data" 3 0 1
+"$SCRATCH/gotrace" -keep-bl -blop 2 -Q 0x80000000080001,0x10000000006E0001 -P 0x1FFFFFFFFFE00001,0x1FFFFFFFFFC80001 -nq-full 28 -o trace_blop_3_0.json -- "$SCRATCH/test_run_scratch" conv 3 0 1 > log_blop.txt 2>&1
+python3 -c "import json,sys; d=json.load(open(\"trace_blop_3_0.json\")); d[\"events\"]=[e for e in d[\"events\"] if e[\"op\"].startswith(\"evalConv_BN_BL_test\")]; json.dump(d, open(sys.argv[1], \"w\"), indent=0)" "$REPO/tests/golden/ref_trace_blop_3_0.json"

@@ -178,8 +178,10 @@ def postKer(max_ker_rs, i, j, in_wid, ker_wid, rot, pad, max_batch):      # conv
     return out.reshape(-1)
 
 
-def evalConv_BN_BL_test(bl, ct_input, ker_in, bn_a, bn_b, in_wid, ker_wid, real_ib, real_ob, pad, swk, scale=2.0 ** 30):
-    """eval.go:78-134 (pos = 0, norm = 1, trans = false): returns level-1 ciphertext at scale^2"""
+def evalConv_BN_BL_test(bl, ct_input, ker_in, bn_a, bn_b, in_wid, ker_wid, real_ib, real_ob, pad, swk, scale=2.0 ** 30, swk_out=None):
+    """eval.go:78-134 (pos = 0, norm = 1, trans = false): returns level-1 ciphertext at scale^2. swk: keys of preConv_BL's (hoisted) input rotations and,
+    unless swk_out is given, of the output rotations (RotateNew) too - a replay of the reference's planted keys holds one set per KIND of key switch"""
+    swk_out = swk if swk_out is None else swk_out
     O = bl.O
     in_size = in_wid * in_wid
     max_batch = N // (2 * in_size)
@@ -202,7 +204,7 @@ def evalConv_BN_BL_test(bl, ct_input, ker_in, bn_a, bn_b, in_wid, ker_wid, real_
                 term = bl.mul_pt(ct_rots[it], pl)
                 ct_tmp = term if ct_tmp is None else bl.add(ct_tmp, term)
                 it += 1
-        ct_res = ct_tmp if r == 0 else bl.add(ct_res, bl.rotate(ct_tmp, r * in_size, swk))
+        ct_res = ct_tmp if r == 0 else bl.add(ct_res, bl.rotate(ct_tmp, r * in_size, swk_out))
     return bl.add_pt(ct_res, pl_bn_b)
 
 
