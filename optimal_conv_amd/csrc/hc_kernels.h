@@ -999,6 +999,9 @@ template <bool ROWS, bool SCALE> __device__ __forceinline__ void hc_s_pass_inv(u
 }
 // thread -> (line, u): rows tiles: 64 consecutive threads per row; cols tiles: the column index is the fast one
 #define HC_S_ROWS_MAP const int t = threadIdx.x, line = t >> 6, u = t & 63, grow = HC_TILE * 4 + line
+// cols tiles are 32 bytes wide: four neighbours share every 128-byte line, so the eight tiles an XCD serves (blockIdx.x mod 8 picks the XCD) are made NEIGHBOURS - two lines'
+// worth of columns per XCD - instead of every eighth tile, which made all eight L2s fetch every line
+#define HC_S_CTILE ((int)((blockIdx.x & 7) * 8 + (blockIdx.x >> 3)))
 #define HC_S_COLS_MAP const int t = threadIdx.x, line = t & 3, u = t >> 2
 
 // SB1: t2.c1 = y1 - I*x1, rows-inverse mod Q0 -> tmpC. grid = (64, batch*nodes)
@@ -1027,7 +1030,7 @@ __global__ __launch_bounds__(HC_STPB) void hc_k_sb1(HcLoopB B, HcTwTab T0inv) {
 __global__ __launch_bounds__(HC_STPB) void hc_k_sb2(HcLoopB B, HcTwTab T0inv, HcTwTab TPfwd) {
     __shared__ u64 lds[HC_S_LDS];
     HC_S_COLS_MAP;
-    u64 *base = B.tmpC + (size_t)HC_JOB * 65536 + HC_TILE * 4;
+    u64 *base = B.tmpC + (size_t)HC_JOB * 65536 + HC_S_CTILE * 4;
     const HcQ Q0 = hc_q(B.m0.q), QP = hc_q(B.mp.q);
     HcTw w[12]; hc_s_tw_load_inv<false>(w, T0inv, 0, u);
 #pragma unroll
@@ -1074,7 +1077,7 @@ __global__ __launch_bounds__(HC_STPB) void hc_k_sb3(HcLoopB B, HcTwTab TPfwd, Hc
 __global__ __launch_bounds__(HC_STPB) void hc_k_sb4(HcLoopB B, HcTwTab TPinv, HcTwTab T0fwd) {
     __shared__ u64 lds[HC_S_LDS];
     HC_S_COLS_MAP;
-    u64 *base = B.tmpE + (size_t)HC_JOB * 65536 + HC_TILE * 4;
+    u64 *base = B.tmpE + (size_t)HC_JOB * 65536 + HC_S_CTILE * 4;
     const HcQ QP = hc_q(B.mp.q), Q = hc_q(B.m0.q);
     HcTw w[12]; hc_s_tw_load_inv<false>(w, TPinv, 0, u);
 #pragma unroll

@@ -262,6 +262,18 @@ def test_bl_baseline_conv_on_gpu():
     pc.case_bl_conv(lambda Q, P: Context(Q, P), k=5, i_batch=1)
 
 
+def test_bl_operator_vs_reference_trace_on_gpu():
+    """round 3: evalConv_BN_BL_test (eval.go:78-134) as a WHOLE against the reference binary: the planted input ciphertext and rotation keys of
+    `gotrace -blop` (tests/golden/ref_trace_blop_3_0.json), the composition hconv_bl.cpp uses (hc_mul / hc_add per limb, hc_keyswitch over two special
+    primes + hc_permute) through the C ABI: both returned ciphertexts must carry the binary's SHA-256"""
+    from optimal_conv_amd import Context
+    import oracle_bl as ob
+    import test_oracle_pin_bl_op as blop
+    ctx = Context([ob.Q0, ob.Q1_BL], list(ob.P_BL))
+    assert blop.replay(lambda: pc.BLDevice(ctx, ob.BLOracle().O)) == 2
+    ctx.close()
+
+
 def test_ckks_leveled_ops_on_gpu():
     """leveled evaluator operations at sine (23) and ReLU (9) levels of parameter set [6], device vs oracle, bit for bit"""
     from optimal_conv_amd import Context
