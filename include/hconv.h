@@ -51,7 +51,7 @@ int hc_version(void);
 
 /* ---- device memory ---- */
 int hc_malloc(hc_ctx *ctx, size_t bytes, void **dptr);
-int hc_free(hc_ctx *ctx, void *dptr);
+int hc_free(hc_ctx *ctx, void *dptr);   /* into the context that allocated it; does not wait for the stream (blocks are recycled in stream order) */
 int hc_upload(hc_ctx *ctx, void *dst_dptr, const void *src_host, size_t bytes);
 int hc_download(hc_ctx *ctx, void *dst_host, const void *src_dptr, size_t bytes);
 int hc_copy(hc_ctx *ctx, void *dst_dptr, const void *src_dptr, size_t bytes); /* device to device, on the stream */

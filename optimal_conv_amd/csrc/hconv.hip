@@ -170,7 +170,7 @@ static hipError_t hcx_free(hc_ctx *c, void *p) {
     if (c->async_alloc == 2) return hipFreeAsync(p, c->stream);
 #endif
     auto it = c->cache_blk.find((char *)p);
-    if (it == c->cache_blk.end()) return hipFree(p);
+    if (it == c->cache_blk.end()) return hipErrorInvalidDevicePointer;      // not a block of this context: its owner's table would keep pointing at it
     // everything queued so far may still read or write the block: remember that point of the stream (see hcx_h2d_async)
     if (!it->second.ev && hipEventCreateWithFlags(&it->second.ev, hipEventDisableTiming) != hipSuccess) it->second.ev = nullptr;
     if (it->second.ev && hipEventRecord(it->second.ev, c->stream) == hipSuccess) it->second.pending = true;
@@ -389,10 +389,18 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
 // ------------------------------------------------------------------ memory
 extern "C" int hc_malloc(hc_ctx *c, size_t bytes, void **dptr) { HC_ENTER(c); if (!dptr) return hc_fail(c, HC_ERR_ARG, "hc_malloc: null"); HC_HIP(c, hcx_malloc(c, dptr, bytes)); return HC_OK; }
 // hipFree drains the device by itself. With cached allocations (HCONV_ASYNC_ALLOC=1) the block is parked for reuse by THIS context, and
-// a host that hands device buffers from one context to another (the resnet driver: convolution context -> bootstrapper context) frees them
-// right after queueing the consumer: the synchronisation here keeps that pattern safe (measured: dropping it breaks `resnet ... true` under
-// HCONV_ASYNC_ALLOC=1), at the price round 1's verdict noted.
-extern "C" int hc_free(hc_ctx *c, void *dptr) { HC_ENTER(c); HC_HIP(c, hipStreamSynchronize(c->stream)); HC_HIP(c, hcx_free(c, dptr)); return HC_OK; }
+// hc_free does not wait for the stream. Plain mode: hipFree drains the device itself. Cached mode (HCONV_ASYNC_ALLOC=1): the block is parked behind an event
+// and handed out again only to work queued on this same stream (hcx_free / hcx_h2d_async). What the caller owes: a block is freed into the context that
+// allocated it, after every OTHER context that was handed the pointer has been waited for (hc_sync) - the resnet host does both at its two hand-overs
+// (hconv_resnet.cpp evalConv_BNRelu_new, hconv_relu.cpp evalConv_BNRelu_tail). Round 2 kept a stream synchronisation here because dropping it broke
+// `resnet ... true` under cached allocations: the layer output was a bootstrapper-context block released into the convolution context.
+extern "C" int hc_free(hc_ctx *c, void *dptr) {
+    HC_ENTER(c);
+    hipError_t e = hcx_free(c, dptr);
+    if (e == hipErrorInvalidDevicePointer) return hc_fail(c, HC_ERR_ARG, "hc_free: %p was not allocated by this context (with cached allocations a block goes back to the context it came from)", dptr);
+    HC_HIP(c, e);
+    return HC_OK;
+}
 extern "C" int hc_upload(hc_ctx *c, void *dst, const void *src, size_t bytes) {
     HC_ENTER(c); if (!dst || !src) return hc_fail(c, HC_ERR_ARG, "hc_upload: null pointer");
     HC_HIP(c, hcx_h2d_async(c, dst, src, bytes));

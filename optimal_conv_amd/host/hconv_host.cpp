@@ -518,6 +518,7 @@ void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool
             const double pow_ = 4.0, alpha = 0.0;                                                      // test.go:22
             const double out_scale = exp2(round(log2((double)MODQ[0]) - (pow_ + 8)));                  // eval.go:433
             Ciphertext ct_conv = evalConv_BN(cont, ctxt_input, ker_in, bn_a, bn_b, in_wid, ker_wid, raw_in_batch, raw_out_batch, norm, out_scale, trans);
+            HC(cont->hc, hc_sync(cont->hc));                                                           // hand-over to the bootstrapper's context (another stream)
             BootCiphertext ct_res = evalConv_BNRelu_tail(cont->btp, "Conv", 0, ct_conv.d, ct_conv.Scale, alpha, pow_, in_wid, kp_wid);
             start = now();
             std::vector<double> cfs = bootDecryptDecodeCoeffs(cont->btp, ct_res);

@@ -795,9 +795,12 @@ struct Boot {
     // ---------------- the bootstrapper
     void build(const std::vector<int64_t> &sk_in, const Seed256 &seed, int device, int chain_ = 6) {
         chain = chain_;
+        if (chain == 7 && testOnlyEnv("HCONV_CHAIN_REPLAY_BL")) { replay_seed = strtoull(testOnlyEnv("HCONV_CHAIN_REPLAY_BL"), nullptr, 0); fprintf(stderr, "hconv: HCONV_CHAIN_REPLAY_BL: planted keys and input for the baseline's Bootstrapp (test mode; the run ends behind it)\n"); }
         if (chain == 6 && testOnlyEnv("HCONV_CHAIN_REPLAY")) { replay_seed = strtoull(testOnlyEnv("HCONV_CHAIN_REPLAY"), nullptr, 0); fprintf(stderr, "hconv: HCONV_CHAIN_REPLAY: planted keys and input (test mode; results are meaningless as ciphertexts)\n"); }
         Q = chain == 7 ? PARAMS7_Q : PARAMS6_Q; P = PARAMS6_P; NQ = (int)Q.size(); sk = sk_in; rng.reseed(seed, 0xB007B007ull + (uint64_t)chain_);
-        if (chain == 7) { LV_STC_TOP = 15; stc_scale_top = stc_scale_last = 1099511627776.0; lv_relin_lo = 2; sine_out_scale = 36028797018963968.0; }
+        // parameter set [7] (kind "BL_Conv", main.go:52-55): the stock NewBootstrapper (main.go:476-479). SlotsToCoeffs sits right behind the sine on levels 15, 15, 14 at
+        // plaintext scales sqrt(q15), sqrt(q15), 2^30 (tests/golden/ref_flow_bl_5_1.json)
+        if (chain == 7) { LV_STC_TOP = 15; stc_scale_top = sqrt((double)Q[15]); stc_scale_last = 1073741824.0; lv_relin_lo = 2; }
         else { LV_STC_TOP = 3; stc_scale_top = sqrt((double)Q[3]); stc_scale_last = 1073741824.0; lv_relin_lo = LV_RELU_TOP - 11; }
         if (hc_ctx_create(&hc, LOGN, Q.data(), NQ, P.data(), (int)P.size(), device)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
         if (getenv("HCONV_KS_FUSED")) HCR(hc_set_option(hc, "ks_fused", atoi(getenv("HCONV_KS_FUSED"))));     // A/B switch of the fused inner product
@@ -847,7 +850,9 @@ struct Boot {
         for (size_t i = 0; i < G.size(); i++) { const int lv = LV_CTS_TOP - (int)i; S.cts.push_back(plan(G[i], lv, (double)Q[(size_t)lv], ls == 0 || fork, cts_tag[i], period)); }
         // SlotsToCoeffs: level 3 carries all but the last matrix (plaintext scales multiply to q3), level 2 the last at 2^30
         // (the fork: the set NewBootstrapper_mod builds with scale 1 - the reference's SlotsToCoeffs call uses it - at the same three scales)
-        G = ls && !fork ? dft_groups(false, {5, 5, 5}, 1.0, ls) : lattigo_dft(false, 3, 1.0, ls);
+        // (the stock Bootstrapp of parameter set [7]: the set with the bootstrapping scale, (qDiff * params.scale / prescale)^(1/3) per matrix - matrices 4-6 of ref_trace_diag_5_1.json)
+        const double stc_const = chain == 7 ? pow(qdiff * 1073741824.0 / exp2(round(log2((double)Q[0] / 256.0))), 1.0 / 3.0) : 1.0;
+        G = ls && !fork ? dft_groups(false, {5, 5, 5}, 1.0, ls) : lattigo_dft(false, 3, stc_const, ls);
         if (ls && !fork) {       // packed a = (re | im)  ->  w = re + i im on both halves:  w = (m1 + i m2) a + (i m1 + m2) rot_{n_s}(a)
             DiagMat W; W[0].resize((size_t)n); W[ns].resize((size_t)n);
             for (int p = 0; p < n; p++) { const bool first = p % (2 * ns) < ns; W[0][(size_t)p] = first ? cplx(1, 0) : cplx(0, 1); W[ns][(size_t)p] = first ? cplx(0, 1) : cplx(1, 0); }
@@ -877,13 +882,21 @@ struct Boot {
     // MultByConst(q0 / sinescale * params.scale / prescale) and Rescale: two ciphertexts at level 14, scale 2^30.
     // Sparse slots (ls > 0, round 3; gotrace -flow -logslots 13 shows the binary's op sequence): subSum after the second ScaleUp (Rotate by 2^i,
     // Add, i = logSlots .. logN-2), and after DivByi the repacking Rotate(ct1, 2^logSlots) + Add(ct0, ct1): one ciphertext through the sine.
-    int ctos_fork(const DCt &ct0, DCt out[2], int ls = 0) {
+    // stock = true: the first half of the stock ckks.(*Bootstrapper).Bootstrapp (the baseline, parameter set [7]; gotrace -flow-bl, tests/golden/ref_flow_bl_5_1.json): SetScale(ct,
+    // prescale) - MultByConst + Rescale down to level 0 - instead of the first ScaleUp, the same modUp / ScaleUp / CoeffsToSlots / evaluateSine, and no MultByConst + Rescale at
+    // the end: two ciphertexts at level 15, scale 2^30, for SlotsToCoeffs.
+    int ctos_fork(const DCt &ct0, DCt out[2], int ls = 0, bool stock = false) {
         Set &S = set(ls);
         const double q0 = (double)Q[0], msg_ratio = 256.0, pscale = 1073741824.0;
         const double prescale = exp2(round(log2(q0 / msg_ratio))), sinescale = exp2(round(log2(q0)));
-        if (ct0.level != 0 || prescale < ct0.scale) panic("BootstrappConv_CtoS: the input must sit on level 0 below the prescale");
-        double k = floor(prescale / ct0.scale + 0.5);
-        DCt ct = mul_const_int(ct0, k); ct.scale = ct0.scale * k;
+        DCt ct;
+        if (stock) { ct = set_scale(ct0, prescale); if (ct.level != 0) panic("Bootstrapp: SetScale did not reach level 0"); }
+        else {
+            if (ct0.level != 0 || prescale < ct0.scale) panic("BootstrappConv_CtoS: the input must sit on level 0 below the prescale");
+            const double k0 = floor(prescale / ct0.scale + 0.5);
+            ct = mul_const_int(ct0, k0); ct.scale = ct0.scale * k0;
+        }
+        double k;
         ct = mod_raise(ct, LV_CTS_TOP);
         k = floor((sinescale / msg_ratio) / ct.scale + 0.5);
         { const double s0 = ct.scale; ct = mul_const_int(ct, k); ct.scale = s0 * k; }
@@ -906,12 +919,13 @@ struct Boot {
             for (int r = 0; r < SIN_DOUBLE; r++) { sqrt2pi *= sqrt2pi; c = mul_relin(c, c); c = add(c, c); c = lt_rescale(add_const(c, -sqrt2pi), sinescale); }
             if (c.level != LV_RELU_TOP) panic("sine evaluation ended at the wrong level");
             c.scale = pscale;
-            out[h] = lt_rescale(mul_const_float(c, (q0 / sinescale) * (pscale / prescale)), pscale);
+            out[h] = stock ? c : lt_rescale(mul_const_float(c, (q0 / sinescale) * (pscale / prescale)), pscale);
         }
         return nparts;
     }
     int ctos(const DCt &ct0, int ls, DCt out[2]) {
         if (chain == 6) return ctos_fork(ct0, out, ls);
+        if (chain == 7 && ls == 0) return ctos_fork(ct0, out, 0, true);
         Set &S = set(ls);
         const double q0 = (double)Q[0], msg_scale = ct0.scale;
         DCt ct = mod_raise(ct0, LV_CTS_TOP); ct.scale = ls ? q0 : exp2(round(log2(q0)));   // slot values are now t'/Q0 = I + msg/Q0, |.| <= K (full slots: the 1/qDiff sits in the matrices)
@@ -937,6 +951,11 @@ struct Boot {
     DCt stoc(const DCt &re, const DCt *im, int ls) {
         Set &S = set(ls);
         if (ls && im) panic("sparse SlotsToCoeffs takes one packed ciphertext");
+        if (chain == 7 && ls == 0) {      // ckks.SlotsToCoeffs inside the stock Bootstrapp (ref_flow_bl_5_1.json): MultByi + Add, LinearTransform on the matrices' own levels 15, 15, 14, each followed by a Rescale(min = the scale before) that finds nothing to drop: level 14, scale ~2^120
+            DCt ct = add(re, mul_by_i(*im));
+            for (auto &lt : S.stc) { if (ct.level > lt.level) ct = drop_to(ct, lt.level); const double s_in = ct.scale; ct = lt_rescale(linear_transform(ct, lt), s_in); }
+            return ct;
+        }
         DCt ct = drop_to(ls ? re : add(re, mul_by_i(*im)), LV_STC_TOP);
         if (chain == 6) {        // ckks.SlotsToCoeffs as the fork runs it (sparse slots: one packed ciphertext, no MultByi + Add) (ref_flow_5_1.json): MultByi + Add, three LinearTransforms each followed by Rescale(min = the scale before), then eval.go:564's Rescale(2^30): level 3 -> 1
             for (auto &lt : S.stc) { const double s_in = ct.scale; ct = lt_rescale(linear_transform(ct, lt), s_in); }
@@ -1082,6 +1101,14 @@ static void profile_dump(Boot *B, const char *label) {
     hc_profile_get(hc, nullptr, nullptr, nullptr);
 }
 
+// test mode (HCONV_CHAIN_REPLAY / HCONV_CHAIN_REPLAY_BL): SHA-256 of each polynomial's rows 0..level, as gotrace's emit_ct
+static void replay_digest_line(Boot *B, const char *what, const DCt &c) {
+    hc_ctx *hc = B->hc;
+    std::string line = std::string("replay digest ") + what + " level " + std::to_string(c.level);
+    char sc[40]; snprintf(sc, sizeof sc, " scale %.17g", c.scale); line += sc;
+    for (int d = 0; d <= c.deg; d++) { std::vector<uint64_t> rows((size_t)(c.level + 1) * N); HCR(hc_download(hc, rows.data(), c.p[d].get(), rows.size() * 8)); Sha256 h; h.update(rows.data(), rows.size() * 8); line += " " + h.hex(); }
+    printf("%s\n", line.c_str());
+}
 // eval.go:437-565: everything after the convolution(s). ct_conv = the level-0 convolution result at out_scale
 // 2^(round(log2 Q0) - (pow+8)). kind "Conv" (log_sparse 0, two ciphertexts through sine/ReLU, keep_ctxt masks of gen_keep_vec),
 // "Conv_sparse" (one packed ciphertext, gen_keep_vec_sparse), "StrConv_sparse" (one packed ciphertext, ext_double_ctxt with
@@ -1097,12 +1124,7 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     // the source as soon as this function returns. Wait for the copy (the stream holds nothing else at this point) so that the hand-over
     // does not depend on how the two contexts' streams happen to be scheduled (cached allocations recycle a freed block at once).
     HCR(hc_sync(hc));
-    auto replay_digest = [&](const char *what, const DCt &c) {      // SHA-256 of each polynomial's rows 0..level, as gotrace's emit_ct
-        std::string line = std::string("replay digest ") + what + " level " + std::to_string(c.level);
-        char sc[40]; snprintf(sc, sizeof sc, " scale %.17g", c.scale); line += sc;
-        for (int d = 0; d <= c.deg; d++) { std::vector<uint64_t> rows((size_t)(c.level + 1) * N); HCR(hc_download(hc, rows.data(), c.p[d].get(), rows.size() * 8)); Sha256 h; h.update(rows.data(), rows.size() * 8); line += " " + h.hex(); }
-        printf("%s\n", line.c_str());
-    };
+    auto replay_digest = [&](const char *what, const DCt &c) { replay_digest_line(B, what, c); };
     if (B->replay_seed) {                                           // the input gotrace -chain plants at the entry of BootstrappConv_CtoS: SEED_OPIN(4000, 0, poly, limb 0)
         if (sparse) panic("HCONV_CHAIN_REPLAY covers the full-slot chain only");
         std::vector<uint64_t> row((size_t)N);
@@ -1174,30 +1196,31 @@ void blBootReLU(Boot *B, const uint64_t *ct_res0, const uint64_t *ct_res1, doubl
     ct.scale = ct.scale * exp2(pow_ + 2);                                                                // test_BL.go:128
     printf("\n ========= Bootstrapping... (original) ========= \n");
     auto start_boot = now();
-    // ckks.(*Bootstrapper).Bootstrapp: one level is available, so SetScale brings the scale to 2^round(log2(Q0 / MessageRatio)) and the
-    // level to 0; modUp, CoeffsToSlots, sine on both halves, SlotsToCoeffs
+    // ckks.(*Bootstrapper).Bootstrapp, stock, op for op as the reference binary runs it (gotrace -flow-bl: tests/golden/ref_flow_bl_5_1.json; on planted data: ref_trace_chain_bl_5_1.json):
+    // SetScale to 2^round(log2(Q0 / MessageRatio)) (MessageRatio 256) down to level 0, modUp, CoeffsToSlots, the sine on both halves, SlotsToCoeffs on levels 15, 15, 14
     const bool dbg = getenv("HCONV_DEBUG_BOOT") && *getenv("HCONV_DEBUG_BOOT"); std::vector<cplx> z_in;
     if (dbg) z_in = B->debug_slots(ct);
-    // MessageRatio: the reference's parameter set says 256. Its sine is a Han-Ki interpolant that is only accurate near the integers;
-    // the plain degree-63 Chebyshev interpolant used here is accurate to ~2^-26 everywhere, and that error is multiplied by
-    // Q0 / (2 pi scale) and then by ~sqrt(N) in SlotsToCoeffs. The baseline's slot values are below 2^-4 (the 2^(pow+2) of
-    // test_BL.go:128), so a ratio of 16 keeps the linearisation error of the sine at 2^-17 and brings the bootstrapping error from
-    // 2^-13 to 2^-17 (measured, HCONV_DEBUG_BOOT=1): the baseline half then prints the reference's precision (MED 11.3 vs 11.4 bits).
-    const double ratio = getenv("HCONV_BL_MSG_RATIO") ? atof(getenv("HCONV_BL_MSG_RATIO")) : 16.0;
-    ct = B->set_scale(ct, exp2(round(log2((double)B->Q[0] / ratio))));
-    if (dbg) Boot::debug_compare("SetScale before Bootstrapp", z_in, B->debug_slots(ct));
-    if (ct.level != 0) panic("Bootstrapp: SetScale did not reach level 0");
+    if (B->replay_seed) {            // the input gotrace -flow-bl -chain plants at the entry of Bootstrapp: SEED_OPIN(4001, 0, poly, limb), both limbs of the level-1 ciphertext
+        std::vector<uint64_t> rows((size_t)2 * N);
+        for (int k = 0; k < 2; k++) {
+            for (int l = 0; l < 2; l++) { const uint64_t sd = B->replay_seed + ((6ull << 32) | (uint64_t)((((4001 * 2 + 0) * 4 + k) * 64) + l));
+                for (int j = 0; j < N; j++) rows[(size_t)l * N + (size_t)j] = Boot::splitmix_at(sd, (uint64_t)j) % B->Q[(size_t)l]; }
+            HCR(hc_upload(hc, ct.p[k].get(), rows.data(), rows.size() * 8));
+        }
+    }
     DCt halves[2]; if (B->ctos(ct, 0, halves) != 2) panic("Bootstrapp: full-slot CoeffsToSlots returns two ciphertexts");
+    if (B->replay_seed) for (int h = 0; h < 2; h++) replay_digest_line(B, h ? "sine1" : "sine0", halves[h]);
     DCt ct_boot = B->stoc(halves[0], &halves[1], 0);
+    if (B->replay_seed) { replay_digest_line(B, "bootstrapp", ct_boot); printf("replay of the baseline's Bootstrapp done\n"); fflush(stdout); exit(0); }
     if (dbg) Boot::debug_compare("Bootstrapp", z_in, B->debug_slots(ct_boot));
     HCR(hc_sync(hc));
     printf("Boot Done in %s \n", dur(start_boot).c_str());
     img_eval = now();
-    // test_BL.go:146-153: an all-ones plaintext whose scale lands the product on 2^30 times the moduli the Rescale drops. The reference's
-    // bootstrapper returns at level 14 (scale 2^30 q14 q13 -> level 12); this one returns at level 13 (scale 2^30 q13 -> level 12).
-    { const int L = ct_boot.level; if (L != 13) panic("Bootstrapp ended at an unexpected level");
-      std::vector<cplx> ones((size_t)N / 2, cplx(1.0, 0)); DPt pl_scale = B->encode(ones, L, 1073741824.0 * (double)B->Q[(size_t)L] / ct_boot.scale);
-      ct_boot = B->rescale(B->mul_plain(ct_boot, pl_scale)); ct_boot.scale = 1073741824.0; }
+    // test_BL.go:146-153: an all-ones plaintext at scale 2^30 q14 q13 / ct_boot.Scale, Mul, Rescale(params.Scale): level 14, scale ~2^120 -> level 12, scale 2^30
+    { const int L = ct_boot.level; if (L != 14) panic("Bootstrapp ended at an unexpected level");
+      std::vector<cplx> ones((size_t)N / 2, cplx(1.0, 0)); DPt pl_scale = B->encode(ones, L, 1073741824.0 * (double)B->Q[14] * (double)B->Q[13] / ct_boot.scale);
+      ct_boot = B->lt_rescale(B->mul_plain(ct_boot, pl_scale), 1073741824.0);
+      if (ct_boot.level != 12) panic("the baseline's rescale after Bootstrapp ended at an unexpected level"); }
     if (dbg) Boot::debug_compare("Bootstrapp + scale plaintext", z_in, B->debug_slots(ct_boot));
     DCt ct_iboot = B->conjugate(ct_boot);                                                                // test_BL.go:155
     DCt res[2] = {B->add(ct_boot, ct_iboot), B->mul_by_i(B->sub(ct_iboot, ct_boot))};                    // DivByi(a - b) = i (b - a)

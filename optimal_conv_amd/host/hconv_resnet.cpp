@@ -78,9 +78,20 @@ Ciphertext evalConv_BNRelu_new(Context *cont, const Ciphertext &ct_input, const 
     } else if (kind == "Conv_sparse" || kind == "Conv") {
         ct_conv = evalConv_BN(cont, ct_input, ker_in, bn_a, bn_b, in_wid, ker_wid, real_ib, real_ob, norm, out_scale, false);                   // eval.go:433
     } else panic("No kind!");
+    // hand-over to the bootstrapper's context (its own stream): everything queued on the convolution context - the stride layers end on a product and an addition that
+    // nothing has waited for - must be complete before the other stream reads ct_conv
+    HCX(cont->hc, hc_sync(cont->hc));
     BootCiphertext r = evalConv_BNRelu_tail(cont->btp, kind, log_sparse, ct_conv.d, ct_conv.Scale, alpha, pow_, in_wid, kp_wid);
     freeCt(cont, ct_conv);
-    Ciphertext out; out.d = r.d; out.level = r.level; out.Scale = r.Scale;     // [2][2][N] over (Q0, Q1): what the next convolution reads
+    // [2][2][N] over (Q0, Q1): what the next convolution reads. The result block belongs to the bootstrapper's context and goes back to it; the layer's output is a
+    // block of the convolution context (a block released into a context that did not allocate it would leave the owner's block table pointing at memory it no longer
+    // owns - the lifetime bug hc_free's stream synchronisation used to hide). The tail has synchronised its stream, so the copy sees the finished result.
+    Ciphertext out; out.level = r.level; out.Scale = r.Scale;
+    const size_t bytes = (size_t)2 * (r.level + 1) * N * 8;
+    { void *v = nullptr; HCX(cont->hc, hc_malloc(cont->hc, bytes, &v)); out.d = (uint64_t *)v; }
+    HCX(cont->hc, hc_copy(cont->hc, out.d, r.d, bytes));
+    HCX(cont->hc, hc_sync(cont->hc));
+    freeBootCt(cont->btp, r);
     return out;
 }
 

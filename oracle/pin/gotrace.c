@@ -650,7 +650,7 @@ static void ret_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; f
     for (int i = 0; i < 2; i++) if (f->out_res[i] != NA) flow_ct("res", i, rd64(E + (uint64_t)f->out_res[i]));
     if (f->out_slice != NA) { uint64_t p = rd64(E + (uint64_t)f->out_slice), n = rd64(E + (uint64_t)f->out_slice + 8); for (uint64_t i = 0; i < n && i < 2; i++) flow_ct("res", (int)i, rd64(p + 8 * i)); }
     if (g_chain) {
-        const int want = !strcmp(f->name, "BootstrappConv_CtoS") || !strcmp(f->name, "CoeffsToSlots") || !strcmp(f->name, "evaluateSine") || !strcmp(f->name, "SlotsToCoeffs") ||
+        const int want = !strcmp(f->name, "BootstrappConv_CtoS") || !strcmp(f->name, "Bootstrapp") || (!strcmp(f->name, "SetScale") && u->depth <= 1) || !strcmp(f->name, "CoeffsToSlots") || !strcmp(f->name, "evaluateSine") || !strcmp(f->name, "SlotsToCoeffs") ||
                          !strcmp(f->name, "LinearTransform") || !strcmp(f->name, "ConjugateNew") || !strcmp(f->name, "modUp") || !strcmp(f->name, "EvaluateCheby") || !strcmp(f->name, "EvaluatePoly") ||
                          (!strcmp(f->name, "Rescale") && u->depth <= 2) || (!strcmp(f->name, "MultByConst") && u->depth <= 1) || (!strcmp(f->name, "mulRelin") && u->depth <= 1);
         if (want) {
@@ -665,7 +665,9 @@ static void on_flow(pid_t t, struct user_regs_struct *r, void *ud) { (void)t; fl
     if (!g_flow_mode) return;
     if (!g_flow_on) {                                   /* the enclosing layer function is hooked from its entry so that its return ends the run */
         if (!strcmp(f->name, "main.evalConv_BNRelu_new")) { flowret_t *u0 = &g_flowret[g_flowret_i++ % MAXFLOWRET]; u0->f = f; u0->depth = 0; u0->out_arg = 0; hook_return(r, ret_flow, u0); return; }
-        if (g_flow_bl) { if (strcmp(f->name, "Bootstrapp")) return; g_flow_on = 1; g_flow_depth = 0; goto log_call; }     /* -flow-bl: the stock Bootstrapp of the baseline half, entry to return */
+        if (g_flow_bl) { if (strcmp(f->name, "Bootstrapp")) return; g_flow_on = 1; g_flow_depth = 0;                    /* -flow-bl: the stock Bootstrapp of the baseline half, entry to return */
+            if (g_chain) plant_ct(rd64(r->rsp + (uint64_t)f->in_ct[0]), 4001, 0);                                            /* with -chain: planted input (both limbs of the level-1 ciphertext), planted keys, digests */
+            goto log_call; }
         if (strcmp(f->name, "BootstrappConv_CtoS")) return;
         g_flow_on = 1; g_flow_depth = 1;
         if (g_chain) { uint64_t ct = rd64(r->rsp + 0x10); if (poly_limbs(ct_poly(ct, 0)) != 1) { fprintf(stderr, "-chain expects a level-0 input\n"); exit(3); } plant_ct(ct, 4000, 0); } }

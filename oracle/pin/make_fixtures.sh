@@ -107,3 +107,9 @@ python3 "$REPO/oracle/pin/mk_flow_fixture.py" "$REPO/tests/golden/ref_trace_chai
 python3 "$REPO/tests/golden/gen_conv_csv.py" "$SCRATCH/test_conv_data" 3 0 1
 "$SCRATCH/gotrace" -keep-bl -blop 2 -Q 0x80000000080001,0x10000000006E0001 -P 0x1FFFFFFFFFE00001,0x1FFFFFFFFFC80001 -nq-full 28 -o trace_blop_3_0.json -- "$SCRATCH/test_run_scratch" conv 3 0 1 > log_blop.txt 2>&1
 python3 -c "import json,sys; d=json.load(open(\"trace_blop_3_0.json\")); d[\"events\"]=[e for e in d[\"events\"] if e[\"op\"].startswith(\"evalConv_BN_BL_test\")]; json.dump(d, open(sys.argv[1], \"w\"), indent=0)" "$REPO/tests/golden/ref_trace_blop_3_0.json"
+
+# round 3, the baseline half of convReLU: the stock ckks.(*Bootstrapper).Bootstrapp on parameter set [7] (kind "BL_Conv", main.go:52-55) on planted input and keys, digests from
+# SetScale to the returned ciphertext (the run ends at Bootstrapp's return)
+Q7=$(python3 -c "import sys; sys.path.insert(0,'$REPO/tests'); import oracle_ckks as c; print(','.join(hex(q) for q in c.Q_SET7))")
+"$SCRATCH/gotrace" -flow-bl -chain -Q $Q7 -P $P -nq-full 28 -o trace_chain_bl_5_1.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_chain_bl.txt 2>&1
+python3 "$REPO/oracle/pin/mk_flow_fixture.py" "$REPO/tests/golden/ref_trace_chain_bl_5_1.json" trace_chain_bl_5_1.json

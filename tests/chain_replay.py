@@ -122,3 +122,64 @@ def replay_sparse(backend_factory=None):
     check(dbg["evaluateSine"][0], [e for e in want if e["fn"] == "evaluateSine"][0]["digests"][0], "evaluateSine")
     check(boot, [e for e in want if e["fn"] == "Rescale"][-1]["digests"][0], "the ciphertext BootstrappConv_CtoS ends on")
     return n
+
+
+BL_TRACE = os.path.join(HERE, "golden", "ref_trace_chain_bl_5_1.json")
+
+
+def replay_bl(backend_factory=None):
+    """The BASELINE half of convReLU: the stock ckks.(*Bootstrapper).Bootstrapp (test_BL.go:133) of the reference binary on planted data - `gotrace -flow-bl -chain` planted
+    the level-1 input at its entry and every switching key by kind, and digested SetScale, modUp, the seven LinearTransforms, the conjugation, CoeffsToSlots, both
+    EvaluateCheby, evaluateSine, SlotsToCoeffs and the returned ciphertext (tests/golden/ref_trace_chain_bl_5_1.json; parameter set [7], stock NewBootstrapper: main.go:52-55,
+    476-479). tests/oracle_ckks.py's stock flow on any residue backend must arrive at the same residues. Returns the number of checkpoints compared."""
+    d = json.load(open(BL_TRACE))
+    Q, P, seed, N = d["ks_Q"], d["ks_P"], d["seed"], d["N"]
+    assert Q == list(ck.Q_SET7) and P == list(ck.P_SET6)
+    ev = d["events"]
+    C = ck.Ckks(logN=16, Q=ck.Q_SET7)
+    if backend_factory is not None:
+        C.be = backend_factory(C)
+    rows_cache = {}
+
+    def key_source(kind, gal, level):
+        ident = (kind, level)
+        if ident not in rows_cache:
+            rows_cache[ident] = ks_inputs(seed, 0, KIND_ID[kind], level, Q, P, N)[1]
+        return rows_cache[ident]
+    C.key_source = key_source
+    first = ev[0]
+    assert first["fn"] == "Bootstrapp" and first["in"][0][0] == 1
+    ct = ck.Ct(planted_ct(seed, 4001, 0, 1, Q, N), first["in"][0][1])
+    btp = ck.bl_bootstrapper(C)
+    btp.debug = {}
+    out = btp.bootstrapp(ct)
+    dbg = btp.debug
+    want = [e for e in ev if "digests" in e]
+    n = 0
+
+    def check(got, w, what):
+        nonlocal n
+        assert (got.level, got.scale) == (w["level"], w["scale"]) and digests(got) == w["polys"], what
+        n += 1
+
+    def only(fn, i=0, last=False):
+        es = [e for e in want if e["fn"] == fn]
+        return (es[-1] if last else es[i])["digests"]
+    check(dbg["SetScale"], only("SetScale")[0], "SetScale")
+    check(dbg["modUp"], only("modUp")[0], "modUp")
+    lts = [e for e in want if e["fn"] == "LinearTransform"]
+    assert len(lts) == 7
+    for i in range(4):
+        check(dbg["LinearTransform"][i], lts[i]["digests"][0], f"CoeffsToSlots LinearTransform {i}")
+    check(dbg["ConjugateNew"], only("ConjugateNew")[0], "ConjugateNew")
+    for h in range(2):
+        check(dbg["CoeffsToSlots"][h], only("CoeffsToSlots")[h], f"CoeffsToSlots result {h}")
+    chebs = [e for e in want if e["fn"] == "EvaluateCheby"]
+    for h in range(2):
+        check(dbg["EvaluateCheby"][h], chebs[h]["digests"][0], f"EvaluateCheby {h}")
+        check(dbg["evaluateSine"][h], only("evaluateSine")[h], f"evaluateSine result {h}")
+    for i in range(3):
+        check(dbg["StoC_LinearTransform"][i], lts[4 + i]["digests"][0], f"SlotsToCoeffs LinearTransform {i}")
+    check(out, only("SlotsToCoeffs")[0], "SlotsToCoeffs")
+    check(out, only("Bootstrapp")[0], "the ciphertext Bootstrapp returns")
+    return n

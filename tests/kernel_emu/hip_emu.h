@@ -38,6 +38,7 @@ typedef void *hipStream_t;
 typedef struct hipEmuEvent *hipEvent_t;
 #define hipSuccess 0
 #define hipErrorPeerAccessAlreadyEnabled 704
+#define hipErrorInvalidDevicePointer 17
 #define hipMemcpyHostToDevice 1
 #define hipMemcpyDeviceToHost 2
 #define hipMemcpyDeviceToDevice 3

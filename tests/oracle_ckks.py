@@ -842,12 +842,16 @@ class Bootstrapper:
     chain and level assignment as parameter set [6]; DFT matrices from the encoder's own butterflies (no bit reversal, so
     slot p holds coefficient bitrev(p)); sine by Chebyshev interpolation of cos(2*pi*(K*u - 1/4)/2^r) and r double angles."""
 
-    def __init__(self, C, cts_groups=(4, 4, 4, 3), stc_groups=(5, 5, 5), log_sparse=0, stc_top=LV_STC_TOP, stc_scales=None, sine_out_scale=2.0 ** 30):
+    def __init__(self, C, cts_groups=(4, 4, 4, 3), stc_groups=(5, 5, 5), log_sparse=0, stc_top=LV_STC_TOP, stc_scales=None, sine_out_scale=2.0 ** 30, stock=False):
         # stc_top / stc_scales / sine_out_scale: where SlotsToCoeffs sits and at which plaintext scales, and the scale the sine hands over
         # at. Defaults = Ours on parameter set [6] (levels 3..2: sqrt(q3) twice, then 2^30; sine out at 2^30). The baseline's stock
         # Bootstrapp on set [7]: stc_top 15, scales (2^40, 2^40), sine out at 2^55 (host/hconv_relu.cpp Boot::build, chain 7).
         self.stc_top, self.stc_scales, self.sine_out_scale = stc_top, stc_scales, sine_out_scale
-        self.fork_flow = stc_top == LV_STC_TOP and stc_scales is None          # Ours on parameter set [6]; the baseline's stock Bootstrapp keeps the restated flow
+        # stock = the baseline's ckks.(*Bootstrapper).Bootstrapp on parameter set [7] (test_BL.go:133; kind "BL_Conv": main.go:52-55, 476-479), op for op as
+        # the binary runs it (tests/golden/ref_flow_bl_5_1.json): the same CoeffsToSlots and sine as the fork's BootstrappConv_CtoS, SlotsToCoeffs with the
+        # bootstrapping-scale matrix set on levels 15, 15, 14
+        self.stock = stock
+        self.fork_flow = stock or (stc_top == LV_STC_TOP and stc_scales is None)   # Ours on parameter set [6] / the baseline's stock Bootstrapp; anything else keeps the restated flow
         """log_sparse = ls > 0: the message occupies only the coefficients that are multiples of D = 2^ls (sparse packing,
         eval.go "Conv_sparse"): the bootstrapping runs in the subring X^D with n_s = n/D slots (main.go:60-83 btp2..btp5):
         SubSum, the n_s-point DFTs, and BOTH coefficient halves in ONE ciphertext (first half of every 2 n_s slots = low
@@ -872,7 +876,11 @@ class Bootstrapper:
             d_cts = math.pow(2.0 / ((2.0 * SIN_K / sc_fac) * float(C.N) * sc_fac * qdiff), 1.0 / len(cts_groups))
             logd = logn + (1 if log_sparse else 0)
             cts = ld.compute_dft_matrices(logn, logd, len(cts_groups), d_cts, True)
-            stc = ld.compute_dft_matrices(logn, logd, len(stc_groups), 1.0, False)
+            # SlotsToCoeffs: the Conv variant's set has constant 1; the stock Bootstrapp's carries (qDiff * params.scale / prescale)^(1/3) per matrix
+            # (both sets pinned against the binary: tests/test_oracle_pin_dft.py matrices 4-6 and 7-9)
+            prescale = 2.0 ** round(math.log2(float(C.Q[0]) / MSG_RATIO))
+            d_stc = math.pow(qdiff * 2.0 ** 30 / prescale, 1.0 / len(stc_groups)) if stock else 1.0
+            stc = ld.compute_dft_matrices(logn, logd, len(stc_groups), d_stc, False)
             self.cts_n1 = [ld.find_best_bsgs_split(list(M), 1 << logd, 16.0) for M in cts]
             self.stc_n1 = [ld.find_best_bsgs_split(list(M), 1 << logd, 16.0) for M in stc]
             self.cts = [{k: v.complex() for k, v in M.items()} for M in cts]
@@ -954,11 +962,17 @@ class Bootstrapper:
         C = self.C
         q0 = float(C.Q[0])
         prescale, sinescale, pscale = 2.0 ** round(math.log2(q0 / MSG_RATIO)), 2.0 ** round(math.log2(q0)), 2.0 ** 30
-        assert ct0.level == 0 and prescale >= ct0.scale
-        k = int(math.floor(prescale / ct0.scale + 0.5))
-        ct = C.mul_const_int(ct0, k); ct.scale = ct0.scale * k                      # ScaleUp(ct, round(prescale / scale))
-        ct = C.mod_raise(ct, LV_CTS_TOP)
         dbg = getattr(self, "debug", None)                                          # tests: intermediate ciphertexts by the reference's function names
+        if self.stock:                                                              # Bootstrapp: SetScale(ct, prescale) - MultByConst + Rescale down to level 0 -, no ScaleUp
+            ct = C.set_scale(ct0, prescale)
+            assert ct.level == 0
+            if dbg is not None:
+                dbg["SetScale"] = ct.copy()
+        else:
+            assert ct0.level == 0 and prescale >= ct0.scale
+            k = int(math.floor(prescale / ct0.scale + 0.5))
+            ct = C.mul_const_int(ct0, k); ct.scale = ct0.scale * k                  # ScaleUp(ct, round(prescale / scale))
+        ct = C.mod_raise(ct, LV_CTS_TOP)
         if dbg is not None:
             dbg["modUp"] = ct.copy()
         k = int(math.floor((sinescale / MSG_RATIO) / ct.scale + 0.5))
@@ -1002,8 +1016,20 @@ class Bootstrapper:
             c = Ct(c.rows, pscale)                                                  # ct.Scale = params.scale
             if dbg is not None:
                 dbg.setdefault("evaluateSine", []).append(c.copy())
-            c = C.rescale_to(C.mul_const_float(c, (q0 / sinescale) * (pscale / prescale)), pscale)
+            if not self.stock:                                                      # the fork's tail; the stock Bootstrapp hands the level-15 ciphertexts to SlotsToCoeffs
+                c = C.rescale_to(C.mul_const_float(c, (q0 / sinescale) * (pscale / prescale)), pscale)
             out.append(c)
+        return out
+
+    def bootstrapp(self, ct):
+        """ckks.(*Bootstrapper).Bootstrapp (stock; the baseline half of convReLU, test_BL.go:133) on parameter set [7]: level >= 0 in, level 14 at scale ~2^120 out
+        (three SlotsToCoeffs plaintext scales on top of 2^30: the caller's next plaintext product brings it back, test_BL.go:146-153)"""
+        assert self.stock and self.ls == 0
+        parts = self._ctos_fork(ct)
+        out = self.stoc(parts[0], parts[1])
+        dbg = getattr(self, "debug", None)
+        if dbg is not None:
+            dbg["Bootstrapp"] = out.copy()
         return out
 
     def stoc(self, ct_re, ct_im):
@@ -1014,6 +1040,18 @@ class Bootstrapper:
             ct = ct_re                                             # the (re | im) -> re + i im combination is inside stc[0]
         else:
             ct = C.add(ct_re, C.mul_by_i(ct_im))
+        if self.stock:
+            # ckks.SlotsToCoeffs inside the stock Bootstrapp (tests/golden/ref_flow_bl_5_1.json): MultByi + Add, then LinearTransform on the matrices' own levels
+            # 15, 15, 14 at plaintext scales sqrt(q15), sqrt(q15), 2^30, each followed by a Rescale(min = the scale before) that finds nothing to drop
+            dbg = getattr(self, "debug", None)
+            sc = math.sqrt(float(C.Q[LV_RELU_TOP]))
+            for M, n1, s_pt, L in zip(self.stc, self.stc_n1, (sc, sc, 2.0 ** 30), (LV_RELU_TOP, LV_RELU_TOP, LV_RELU_TOP - 1)):
+                ct = C.drop_to(ct, min(ct.level, L))
+                s_in = ct.scale
+                ct = C.rescale_to(C.linear_transform_qp(ct, M, s_pt, n1, slots=self.period), s_in)
+                if dbg is not None:
+                    dbg.setdefault("StoC_LinearTransform", []).append(ct.copy())
+            return ct
         ct = C.drop_to(ct, self.stc_top)
         G = self.stc
         if self.fork_flow:
@@ -1086,11 +1124,11 @@ def conv_relu_tail(C, btp, ct_conv, alpha, pow_, in_wid, kp_wid, stages=None):
 
 # ------------------------------------------------------------------ the baseline's Bootstrapp + ReLU (test_BL.go:113-168)
 def bl_bootstrapper(C):
-    """the stock Bootstrapp as restated in host/hconv_relu.cpp for parameter set [7] (newBootBL)"""
-    return Bootstrapper(C, stc_top=15, stc_scales=(2.0 ** 40, 2.0 ** 40), sine_out_scale=2.0 ** 55)
+    """the baseline's bootstrapper: stock NewBootstrapper on parameter set [7] (main.go:52-55, 476-479)"""
+    return Bootstrapper(C, stock=True)
 
 
-def bl_boot_relu(C, btp, ct_res, alpha, pow_, msg_ratio=16.0, stages=None):
+def bl_boot_relu(C, btp, ct_res, alpha, pow_, stages=None):
     """test_BL.go:113-168 (blBootReLU of host/hconv_relu.cpp): ct_res = the two level-1 slot-encoded convolution results;
     returns the two level-1, scale-2^30 ciphertexts holding ReLU of their real parts"""
     c = []
@@ -1099,16 +1137,14 @@ def bl_boot_relu(C, btp, ct_res, alpha, pow_, msg_ratio=16.0, stages=None):
         c.append(C.mul_by_i(t) if pos == 1 else t)
     ct = C.add(c[0], c[1])
     ct = Ct(ct.rows, ct.scale * 2.0 ** (pow_ + 2))
-    ct = C.set_scale(ct, 2.0 ** round(math.log2(float(C.Q[0]) / msg_ratio)))
-    assert ct.level == 0
-    halves = btp.ctos(ct)
-    ct_boot = btp.stoc(halves[0], halves[1])
+    ct_boot = btp.bootstrapp(ct)                                                        # SetScale to q0 / MessageRatio is Bootstrapp's first step
     if stages is not None:
         stages["boot"] = [ct_boot.copy()]
-    L = ct_boot.level
-    pl = C.encode_ntt(np.ones(C.n, dtype=np.complex128), L, 2.0 ** 30 * float(C.Q[L]) / ct_boot.scale)
-    ct_boot = C.rescale(C.mul_plain(ct_boot, pl, 2.0 ** 30 * float(C.Q[L]) / ct_boot.scale))
-    ct_boot.scale = 2.0 ** 30
+    L = ct_boot.level                                                                    # 14; test_BL.go:146-153: all-ones plaintext at 2^30 q14 q13 / scale, Mul, Rescale(params.Scale)
+    s_pl = 2.0 ** 30 * float(C.Q[14]) * float(C.Q[13]) / ct_boot.scale
+    pl = C.encode_ntt(np.ones(C.n, dtype=np.complex128), L, s_pl)
+    ct_boot = C.rescale_to(C.mul_plain(ct_boot, pl, s_pl), 2.0 ** 30)
+    assert ct_boot.level == 12
     ci = C.conjugate(ct_boot)
     res = [C.add(ct_boot, ci), C.mul_by_i(C.sub(ci, ct_boot))]
     out = []

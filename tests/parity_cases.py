@@ -647,6 +647,79 @@ def case_strconv_tail_sparse(make_ctx, log_sparse, in_wid, logN=16, seed=3):
     ctx.close()
 
 
+# ---------------------------------------------------------------- the encrypted ResNet as a whole (scope row 8f-3)
+RESNET_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_resnet_digests.json")
+
+
+class DeviceConvOracle:
+    """the conv oracle's interface with the ring work of evalConv_BN on the device: conv_then_pack (hc_conv_then_pack: loop A, the pack tree, the bias) and the
+    NTT / product of the monomial shifts through the C ABI; key generation, encoding and decryption stay on the host oracle (they are host code in the product too)"""
+
+    def __init__(self, O, ctx):
+        self.O, self.ctx, self._loaded, self._idx = O, ctx, set(), False
+
+    def __getattr__(self, name):
+        return getattr(self.O, name)
+
+    def ntt(self, mod, a):
+        return self.ctx.ntt(mod, a).reshape(np.shape(a))
+
+    def mul(self, mod, a, b):
+        return self.ctx.mul(mod, a, b)
+
+    def conv_then_pack(self, ct_in, ct_scale, pl_ker, ker_scale, idx_pt, evk, max_ob, norm, out_scale, bias=None):
+        for j in range(evk.shape[0]):                      # row j holds the key of galEl 2^(j+1) + 1 (conv.go:241-261)
+            if j not in self._loaded and evk[j].any():
+                self.ctx.evk_load((1 << (j + 1)) + 1, [evk[j][0], evk[j][1], evk[j][2], evk[j][3]])
+                self._loaded.add(j)
+        if not self._idx:
+            self.ctx.idx_load(None)
+            self._idx = True
+        return self.ctx.conv_then_pack(ct_in, ct_scale, pl_ker, ker_scale, max_ob, norm, out_scale, bias)
+
+
+def resnet_layer_digests(R):
+    """testResNet_crop_sparse (test.go:76-370) layer by layer on R (tests/oracle_resnet.ResNetOracle, oracle or device flavoured): the SHA-256 of the ciphertext every
+    conv-BN-ReLU layer hands on, and the decrypted class scores"""
+    net, C = R.net, R.C
+    ct = C.encrypt_coeffs(R.pack_input(net.image), 1, 2.0 ** 30, seed=5)
+    out = []
+    for kind, blk, w, a, b in net.layers:
+        ct = R.layer(ct, kind, blk, w, a, b, R.pow)
+        out.append(sha_ct(ct))
+    return out, [float(v) for v in R.final_fc(ct)]
+
+
+def case_resnet_network(make_ctx, depth, logN=16):
+    """the whole encrypted network on the device ABI - every layer's convolution (hc_conv_then_pack at max_ob 64 / 256 / 1024 with norm 4 / 8 / 16), sparse-slot bootstrapping,
+    ReLU, masks or the stride layers' ext_double_ctxt, SlotsToCoeffs - against the ORACLE network: the ciphertext after every layer must be the oracle's, bit for bit
+    (digests generated once in the build container by tests/golden/gen_resnet_digests.py: the oracle network takes an hour on one core; HCONV_TEST_FULL_ORACLE=1 re-runs it)"""
+    import oracle_ckks as ck
+    import oracle_resnet as orn
+    from oracle_lib import Oracle
+    net = orn.Net(logN, depth=depth)
+    Ro = orn.ResNetOracle(net)
+    want = None
+    if logN == 16 and os.path.exists(RESNET_FIXTURE) and not os.environ.get("HCONV_TEST_FULL_ORACLE"):
+        want = json.load(open(RESNET_FIXTURE))["depth"].get(str(depth))
+    if want is None:
+        d, sc = resnet_layer_digests(Ro)
+        want = {"layers": d, "scores": sc}
+    Co = Ro.C
+    ctx_boot = make_ctx(Co.Q, Co.P)
+    ctx_conv = make_ctx([Q0, Q1], [P0])
+    Cd = ck.Ckks(logN=logN, seed=Co.seed, h=192 if logN >= 14 else 64, backend=CkksDeviceBackend(ctx_boot), oracle=Co.O)
+    Cd.sk, Cd.keys = Co.sk, Co.keys
+    Rd = orn.ResNetOracle(net, Ckks=Cd, conv_oracle=DeviceConvOracle(Ro.Oc, ctx_conv))
+    got, scores = resnet_layer_digests(Rd)
+    for i, (g, w) in enumerate(zip(got, want["layers"])):
+        assert g == w, f"layer {i} ({net.layers[i][0]}, block {net.layers[i][1]}): the device network's ciphertext differs from the oracle's"
+    assert len(got) == len(want["layers"])
+    assert np.max(np.abs(np.array(scores) - np.array(want["scores"]))) == 0.0      # same ciphertext, same key: the same decryption
+    ctx_boot.close(); ctx_conv.close()
+    return scores
+
+
 def case_conv_relu_tail(make_ctx, logN=16, seed=3, min_bits=8.0):
     """the whole tail of evalConv_BNRelu_new (CtoS + sine, ReLU, mask, StoC) on the device ABI vs the oracle: every stage
     bit-identical, and the decrypted result close to max(x, 0) (reference binary: MED 11.5 bits on its data)"""

@@ -166,3 +166,18 @@ def test_keyswitch_hoisted():
     """one digit decomposition shared by several key switches (RotateHoisted), bit-identical to the plain key switch"""
     subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
     pc.case_keyswitch_hoisted(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), lambda Q, P: Oracle(q=Q, p=P))
+
+
+def test_free_into_a_foreign_context_is_refused(monkeypatch):
+    """cached allocations (HCONV_ASYNC_ALLOC=1): a block goes back to the context it came from; handing it to another context's hc_free is an error, not a silent
+    hipFree that leaves the owner's block table stale (the lifetime bug behind round 2's synchronising hc_free)"""
+    from optimal_conv_amd.abi import DevBuf
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    monkeypatch.setenv("HCONV_ASYNC_ALLOC", "1")
+    a, b = Context([Q0, Q1], [P0], lib_path=EMU_LIB), Context([Q0, Q1], [P0], lib_path=EMU_LIB)
+    buf = DevBuf(a, 1 << 16)
+    assert b.L.hc_free(b.h, buf.ptr) != 0 and b"not allocated by this context" in b.L.hc_last_error(b.h)
+    assert a.L.hc_free(a.h, buf.ptr) == 0
+    again = DevBuf(a, 1 << 16)                      # the parked block is handed out again
+    assert again.ptr.value == buf.ptr.value
+    again.free(); a.close(); b.close()

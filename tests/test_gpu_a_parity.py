@@ -313,6 +313,15 @@ def test_strconv_tail_sparse_on_gpu(log_sparse, in_wid):
     pc.case_strconv_tail_sparse(lambda Q, P: Context(Q, P), log_sparse, in_wid)
 
 
+@pytest.mark.parametrize("depth", [8] + ([20] if os.environ.get("HCONV_TEST_DEPTH20") else []))
+def test_resnet_network_on_gpu(depth):
+    """scope row 8f-3 as a whole: `resnet 3 <depth> 1 n false` (testResNet_crop_sparse, test.go:76-370) with every layer's ring work on the device ABI, against the
+    oracle network: the ciphertext after EVERY conv-BN-ReLU layer bit-identical, and the same class scores. Depth 8 has every layer geometry of depth 20 (three
+    block widths, both stride layers, log_sparse 1..4) in 7 layers; HCONV_TEST_DEPTH20=1 adds the 19-layer network the reference's Table 3 is quoted on"""
+    from optimal_conv_amd import Context
+    print("scores", pc.case_resnet_network(lambda Q, P: Context(Q, P), depth))
+
+
 def test_conv_1024_channels_sparse_tile_local_galois(env):
     """max_ob = 1024 at norm 16 (the resnet's 8x8 layers): Galois elements 2^7+1, 2^8+1 through the fused kernels vs the oracle"""
     pc.case_keyswitch(*env, gals=(129, 257, 33))
@@ -500,6 +509,20 @@ def test_sparse_ctos_vs_reference_trace_on_gpu():
         holder["ctx"] = Context(C.Q, C.P)
         return pc.CkksDeviceBackend(holder["ctx"])
     assert chain_replay.replay_sparse(backend) == 10
+    holder["ctx"].close()
+
+
+def test_baseline_bootstrapp_vs_reference_trace_on_gpu():
+    """round 3: the baseline half of convReLU - the stock ckks.(*Bootstrapper).Bootstrapp on parameter set [7] (test_BL.go:133) - with every residue operation through the
+    C ABI against the reference binary's digests on planted data (tests/golden/ref_trace_chain_bl_5_1.json, gotrace -flow-bl -chain): 18 checkpoints from SetScale
+    to the level-14 ciphertext Bootstrapp returns"""
+    from optimal_conv_amd import Context
+    import chain_replay
+    holder = {}
+    def backend(C):
+        holder["ctx"] = Context(C.Q, C.P)
+        return pc.CkksDeviceBackend(holder["ctx"])
+    assert chain_replay.replay_bl(backend) == 18
     holder["ctx"].close()
 
 

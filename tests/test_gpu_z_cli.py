@@ -131,6 +131,26 @@ def test_conv_relu_cli_replays_the_reference_chain(tmp_path):
         assert (lv, sc) == (want["level"], want["scale"]) and polys == want["polys"], f"{name}: the host chain differs from the reference binary"
 
 
+def test_conv_relu_cli_replays_the_reference_baseline_bootstrapp(tmp_path):
+    """The PRODUCT path against the reference binary on the BASELINE half of convReLU (round 3): with HCONV_CHAIN_REPLAY_BL=<seed> the CLI's blBootReLU runs the stock
+    Bootstrapp on the input and the switching keys `gotrace -flow-bl -chain` planted into /root/reference/test_run (tests/golden/ref_trace_chain_bl_5_1.json) and prints the
+    SHA-256 of the two ciphertexts evaluateSine returns and of the level-14 ciphertext Bootstrapp returns: they must be the binary's."""
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_trace_chain_bl_5_1.json")))
+    ev = [e for e in ref["events"] if "digests" in e]
+    sine = next(e for e in ev if e["fn"] == "evaluateSine")["digests"]
+    boot = next(e for e in ev if e["fn"] == "Bootstrapp")["digests"][0]
+    gen.write_case(str(tmp_path / "test_conv_data"), 5, 1, 0)
+    out = subprocess.run([CLI, "--test-mode", "convReLU", "5", "1", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HCONV_SEED="31", HCONV_CHAIN_REPLAY_BL=str(ref["seed"])))
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = {m.group(1): (int(m.group(2)), float(m.group(3)), m.group(4).split()) for m in re.finditer(r"^replay digest (\S+) level (\d+) scale (\S+) ((?:[0-9a-f]{64} ?)+)$", out.stdout, re.M)}
+    assert set(got) == {"sine0", "sine1", "bootstrapp"}, out.stdout[-2000:]
+    for name, want in (("sine0", sine[0]), ("sine1", sine[1]), ("bootstrapp", boot)):
+        lv, sc, polys = got[name]
+        assert (lv, sc) == (want["level"], want["scale"]) and polys == want["polys"], f"{name}: the host's baseline Bootstrapp differs from the reference binary"
+
+
 def test_conv_relu_cli_replays_the_reference_sparse_ctos(tmp_path):
     """The PRODUCT path against the reference binary on the SPARSE-slot bootstrapper (round 3): `gotrace -chain -logslots 13` made
     /root/reference/test_run build and call the bootstrapper the resnet uses as btp3 (log_sparse 2) on planted data inside a `convReLU 5 1 1`
@@ -176,6 +196,28 @@ def test_resnet_cli_depth8(tmp_path, cf100, wide):
     # random weights give class scores of ~0.1 separated by less than the accumulated ReLU-approximation error of 7 layers, so
     # for the 100-class head the check is closeness and correlation with the plain model, not the arg-max
     assert np.max(np.abs(got - want)) < 0.08 and np.corrcoef(got, want)[0, 1] > 0.8, (got, want)
+
+
+def test_resnet_cli_two_image_threads_cached_allocations(tmp_path):
+    """`resnet 3 8 1 2 false` with HCONV_IMAGE_THREADS=2 (two host threads, each with its own convolution and bootstrapper contexts on non-blocking streams, blocks
+    recycled from per-context caches: HCONV_ASYNC_ALLOC=1). hc_free no longer waits for the stream, so this is the run that fails if a block is freed while another
+    context still uses it, or into a context that does not own it: the scores must be those of the one-thread, plain-allocation run"""
+    import numpy as np
+    import golden.gen_resnet_csv as rgen
+    want = rgen.write_case(str(tmp_path), 3, 8, 2)
+    res = {}
+    for mode, env in (("plain", {}), ("cached", {"HCONV_IMAGE_THREADS": "2", "HCONV_ASYNC_ALLOC": "1"})):
+        out = subprocess.run([CLI, "--test-mode", "resnet", "3", "8", "1", "2", "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
+                             env=dict(os.environ, HCONV_SEED="11", **env))
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[mode] = [np.loadtxt(tmp_path / "Resnet_enc_results" / "results_crop_ker3_d8_wid1" / f"class_result_ker3_{i}.csv") for i in range(2)]
+    # image 0 is the first encryption of a context keyed by HCONV_SEED in both runs: identical; image 1 is thread 1's FIRST encryption but the one-thread run's SECOND,
+    # so its encryption randomness differs and the scores agree to the scheme's noise only
+    assert np.array_equal(res["plain"][0], res["cached"][0]), (res["plain"][0], res["cached"][0])
+    # (seven bootstrapped ReLU layers amplify a different noise sample to ~1e-2 in the scores: the bound is the one the depth-8 test holds against the plain model)
+    for mode in res:
+        assert np.max(np.abs(res[mode][1] - want[1][0])) < 0.08 and res[mode][1].argmax() == want[1][0].argmax(), (mode, res[mode][1], want[1][0])
+    assert np.max(np.abs(res["plain"][1] - res["cached"][1])) < 0.05, (res["plain"][1], res["cached"][1])
 
 
 def test_resnet_cli_depth20(tmp_path):

@@ -111,8 +111,9 @@ def test_baseline_bootstrapp_relu_small_ring():
     cts = [C.encrypt_slots(x[k] + 0j, 1, 2.0 ** 60, seed=30 + k) for k in range(2)]
     st = {}
     out = ck.bl_boot_relu(C, ck.bl_bootstrapper(C), cts, 0.0, 4.0, stages=st)
-    assert st["boot"][0].level == 13
+    assert st["boot"][0].level == 14 and st["boot"][0].scale == 1.3292279958004808e+36      # tests/golden/ref_flow_bl_5_1.json: what the binary's Bootstrapp returns
     packed = (x[0] + 1j * x[1]) / 32.0                       # (a + conj a) = 2 Re at a scale relabelled by 2^(pow+2) = 64
+    print("bootstrapping error", np.max(np.abs(C.decrypt_slots(st["boot"][0]) - packed)))
     assert np.max(np.abs(C.decrypt_slots(st["boot"][0]) - packed)) < 2e-4
     for k in range(2):
         assert out[k].level == 1 and out[k].scale == 2.0 ** 30
@@ -163,6 +164,50 @@ def test_chain_follows_the_reference_flow_level_for_level_and_scale_for_scale():
     assert (out.level, out.scale) == (1, 1073741823.9892578)         # what the reference hands to the next convolution
     # the reference rescales both halves' results one after the other where this chain finishes one half before the other: compare as multisets per stage
     assert sorted(got) == sorted(want), (len(got), len(want))
+
+
+def test_baseline_bootstrapp_follows_the_reference_flow_level_for_level_and_scale_for_scale():
+    """tests/golden/ref_flow_bl_5_1.json (gotrace -flow-bl over `convReLU 5 1 1`: the baseline half's stock ckks.(*Bootstrapper).Bootstrapp on parameter set [7], entry
+    to return): level and float64 scale after SetScale, modUp, each of the seven LinearTransforms, every Rescale outside the polynomial evaluator and both EvaluateCheby -
+    the oracle's stock flow on a small ring (same modulus chain, hence the same float64 scale arithmetic) passes through exactly the same values and returns at level 14, scale ~2^120"""
+    import json, os
+    import lattigo_poly
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_flow_bl_5_1.json")))["events"]
+    want = [(e["fn"], e["out"][0][0], e["out"][0][1]) for e in ref
+            if e["fn"] in ("modUp", "LinearTransform", "EvaluateCheby") or (e["fn"] == "Rescale" and e["depth"] <= 3) or (e["fn"] == "SetScale" and e["depth"] == 1)]
+    C = ck.Ckks(logN=10, Q=ck.Q_SET7, h=32)
+    got, depth = [], [0]
+    def wrap(obj, name, label):
+        f = getattr(obj, name)
+        def g(*a, **k):
+            depth[0] += 1
+            r = f(*a, **k)
+            depth[0] -= 1
+            if depth[0] == 0:
+                got.append((label, r.level, r.scale))
+            return r
+        setattr(obj, name, g)
+    for name, label in (("mod_raise", "modUp"), ("linear_transform_qp", "LinearTransform"), ("rescale_to", "Rescale"), ("set_scale", "SetScale")):
+        wrap(C, name, label)
+    orig = lattigo_poly.evaluate_cheby
+    def cheby(*a, **k):
+        depth[0] += 1
+        r = orig(*a, **k)
+        depth[0] -= 1
+        got.append(("EvaluateCheby", r.level, r.scale))
+        return r
+    lattigo_poly.evaluate_cheby = cheby
+    try:
+        x = np.random.default_rng(4).uniform(-1, 1, C.n) / 32.0
+        out = ck.bl_bootstrapper(C).bootstrapp(C.encrypt_slots(x + 0j, 1, 2.0 ** 66, seed=8))
+    finally:
+        lattigo_poly.evaluate_cheby = orig
+    first, last = ref[0], ref[0]
+    assert (out.level, out.scale) == (first["out"][0][0], first["out"][0][1]) == (14, 1.3292279958004808e+36)
+    # SetScale's own Rescale is logged by the binary at depth 2, the oracle's set_scale rescales inside: drop that one from the reference list
+    want.remove(("Rescale", 0, 7.378697629483821e+19))
+    assert sorted(got) == sorted(want), (sorted(got), sorted(want))
+    assert np.max(np.abs(C.decrypt_slots(out) - x)) < 1e-6
 
 
 def test_linear_transform_qp_equals_the_pinned_restatement(C):

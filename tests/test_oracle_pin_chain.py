@@ -21,3 +21,10 @@ def test_sparse_ctos_equals_the_reference_binary():
     on planted data (`gotrace -chain -logslots 13`): subSum, the sparse DFT matrices with their repacking, the packed (re | im) ciphertext through
     the sine - ten checkpoints from modUp to the ciphertext the function ends on"""
     assert chain_replay.replay_sparse() == 10
+
+
+@pytest.mark.slow
+def test_baseline_bootstrapp_equals_the_reference_binary():
+    """round 3: the baseline half of convReLU - the stock Bootstrapp on parameter set [7] - against the binary's digests on planted data (`gotrace -flow-bl -chain`):
+    SetScale, modUp, seven LinearTransforms, conjugation, CoeffsToSlots, both EvaluateCheby, evaluateSine, SlotsToCoeffs, the returned level-14 ciphertext"""
+    assert chain_replay.replay_bl() == 18
