@@ -539,22 +539,39 @@ struct Boot {
     // summed in QP and brought down ONCE, a rotation-0 diagonal multiplies the input itself after that division, the second component is
     // key-switched again without ModDown and permuted into QP accumulators, the first is permuted straight into the result; giant step 0 adds
     // its products to the same accumulators, which are brought down once. 2 ModDowns per giant step + 2 instead of 2 per baby step.
-    DCt linear_transform_qp(const DCt &ct, const LT &lt) {
+    // hoist_c1 / hoist_level: the reference's behaviour on a ciphertext ABOVE the matrix level (the stock Bootstrapp's last SlotsToCoeffs matrix: ciphertext level 15,
+    // matrix level 14). DecomposeNTT runs at the matrix level, but rotateHoistedNoModDown takes its level from the ciphertext (test_run @0x524d60), so the hoisted key
+    // switch runs one digit further than was decomposed and reads what the evaluator's decomposition pool still holds there: the last digit of the PREVIOUS
+    // LinearTransform's input. Harmless for the value (that digit's gadget factor vanishes modulo the limbs kept), but the residues depend on it; the same residues come
+    // out of ONE decomposition at the ciphertext's level of hoist_c1 = (c1's limbs up to the matrix level | the previous input's limbs above it), rows above the matrix
+    // level dropped afterwards (tests/oracle_ckks.py linear_transform_qp, pinned by ref_trace_chain_bl_5_1.json).
+    DCt linear_transform_qp(const DCt &ct, const LT &lt, const uint64_t *hoist_c1 = nullptr, int hoist_level = -1) {
         const int L = ct.level, nl = L + 1, np = (int)P.size(), nt = nl + np; const size_t zs = (size_t)nt * N;
         std::map<int, std::vector<int>> index; std::set<int> babies;
         for (auto &g : lt.giant) for (auto &b : g.second) { index[g.first / lt.n1].push_back(b.first); if (b.first) babies.insert(b.first); }
-        for (int b : babies) key(gal_rot(b), L, 1);                                 // key generation (if any) before a decomposition is taken
+        const int Lb = hoist_c1 ? hoist_level : L;                                  // the level the baby-step key switches run at
+        for (int b : babies) key(gal_rot(b), Lb, 1);                                // key generation (if any) before a decomposition is taken
         for (auto &g : lt.giant) if (g.first) key(gal_rot(g.first), L, 2);
         std::vector<uint64_t> pmod((size_t)nl), zeros((size_t)nl, 0);
         for (int l = 0; l < nl; l++) { uint64_t r = 1; for (uint64_t pj : P) r = mulmod(r, pj % Q[(size_t)l], Q[(size_t)l]); pmod[(size_t)l] = r; }
         auto pc0 = block(); HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), pmod.data(), pc0.get()));                       // P * c0
         std::map<int, std::shared_ptr<uint64_t>> rot;
         if (!babies.empty()) {
-            HCR(hc_keyswitch_decompose(hc, L, ct.p[1].get()));
-            auto acc = block_qp2();
+            const uint64_t *cx = hoist_c1 ? hoist_c1 : ct.p[1].get();
+            HCR(hc_keyswitch_decompose(hc, Lb, cx));
+            auto acc = block_qp2(), wide = hoist_c1 ? block_qp2() : std::shared_ptr<uint64_t>();
             for (int b : babies) {
                 const uint64_t gal = gal_rot(b);
-                HCR(hc_keyswitch_qp(hc, key(gal, L, 1), L, ct.p[1].get(), acc.get(), 1)); n_keyswitch++;
+                if (!hoist_c1) HCR(hc_keyswitch_qp(hc, key(gal, L, 1), L, cx, acc.get(), 1));
+                else {                                                                                                  // [2][Lb+1+np][N] -> rows 0..L and the P rows of each component
+                    HCR(hc_keyswitch_qp(hc, key(gal, Lb, 1), Lb, cx, wide.get(), 1));
+                    const size_t zw = (size_t)(Lb + 1 + np) * N;
+                    for (int k = 0; k < 2; k++) {
+                        HCR(hc_copy(hc, acc.get() + (size_t)k * zs, wide.get() + (size_t)k * zw, (size_t)nl * N * 8));
+                        HCR(hc_copy(hc, acc.get() + (size_t)k * zs + (size_t)nl * N, wide.get() + (size_t)k * zw + (size_t)(Lb + 1) * N, (size_t)np * N * 8));
+                    }
+                }
+                n_keyswitch++;
                 HCR(hc_lv_add(hc, L, acc.get(), pc0.get(), acc.get()));                                                  // the Q rows of the first component
                 auto r = block_qp2(); HCR(hc_permute(hc, gal, acc.get(), r.get(), 2 * nt));
                 rot[b] = r;
@@ -953,7 +970,18 @@ struct Boot {
         if (ls && im) panic("sparse SlotsToCoeffs takes one packed ciphertext");
         if (chain == 7 && ls == 0) {      // ckks.SlotsToCoeffs inside the stock Bootstrapp (ref_flow_bl_5_1.json): MultByi + Add, LinearTransform on the matrices' own levels 15, 15, 14, each followed by a Rescale(min = the scale before) that finds nothing to drop: level 14, scale ~2^120
             DCt ct = add(re, mul_by_i(*im));
-            for (auto &lt : S.stc) { if (ct.level > lt.level) ct = drop_to(ct, lt.level); const double s_in = ct.scale; ct = lt_rescale(linear_transform(ct, lt), s_in); }
+            std::shared_ptr<uint64_t> prev_c1;                                       // the second polynomial of the previous LinearTransform's input (see linear_transform_qp)
+            for (auto &lt : S.stc) {
+                const double s_in = ct.scale;
+                if (ct.level > lt.level) {
+                    if (!prev_c1) panic("SlotsToCoeffs: a matrix below the ciphertext's level must follow one at that level");
+                    const int Lh = ct.level, nk = lt.level + 1;
+                    auto y = block();                                                                            // limbs 0..matrix level of c1, the previous input's limbs above
+                    HCR(hc_copy(hc, y.get(), ct.p[1].get(), (size_t)nk * N * 8));
+                    HCR(hc_copy(hc, y.get() + (size_t)nk * N, prev_c1.get() + (size_t)nk * N, (size_t)(Lh + 1 - nk) * N * 8));
+                    ct = lt_rescale(linear_transform_qp(drop_to(ct, lt.level), lt, y.get(), Lh), s_in);
+                } else { prev_c1 = ct.p[1]; ct = lt_rescale(linear_transform(ct, lt), s_in); }
+            }
             return ct;
         }
         DCt ct = drop_to(ls ? re : add(re, mul_by_i(*im)), LV_STC_TOP);

@@ -113,3 +113,6 @@ python3 -c "import json,sys; d=json.load(open(\"trace_blop_3_0.json\")); d[\"eve
 Q7=$(python3 -c "import sys; sys.path.insert(0,'$REPO/tests'); import oracle_ckks as c; print(','.join(hex(q) for q in c.Q_SET7))")
 "$SCRATCH/gotrace" -flow-bl -chain -Q $Q7 -P $P -nq-full 28 -o trace_chain_bl_5_1.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_chain_bl.txt 2>&1
 python3 "$REPO/oracle/pin/mk_flow_fixture.py" "$REPO/tests/golden/ref_trace_chain_bl_5_1.json" trace_chain_bl_5_1.json
+# ... and the levels of the nested key switches of its seven LinearTransforms (the last one hoists at the ciphertext's level 15 over a level-14 decomposition)
+"$SCRATCH/gotrace" -lt 7 -keep-bl -Q $Q7 -P $P -nq-full 28 -o trace_lt_bl_7.json -- "$SCRATCH/test_run_scratch" convReLU 5 1 1 > log_lt_bl.txt 2>&1
+# (summarised into tests/golden/ref_trace_lt_bl_levels.json: per call the ciphertext level, the matrix header and the count of nested calls per level)

@@ -485,7 +485,7 @@ class Ckks:
             acc = inner if acc is None else self.add(acc, inner)
         return acc
 
-    def linear_transform_qp(self, ct, diags, pt_scale, n1=None, slots=None):
+    def linear_transform_qp(self, ct, diags, pt_scale, n1=None, slots=None, hoist=None):
         """ckks.(*evaluator).LinearTransform -> MultiplyByDiagMatrixBSGS exactly as the reference's fork computes it (tests/lattigo_lt.py is the
         same algorithm on the bare oracle, pinned against the binary in tests/test_oracle_pin_lt.py): baby-step rotations key-switched without
         the division by P on one digit decomposition, P*c0 added, products with the diagonals (encoded mod Q and mod P) summed in QP, ONE
@@ -505,7 +505,20 @@ class Ckks:
             Pbig *= p
         pc0 = be.lv_mul_const(c0, [Pbig % self.Q[l] for l in range(nl)])
         babies = sorted({i for js in index.values() for i in js if i})
-        accs = be.keyswitch_qp([self.key(self.gal_rot(i), L, "baby") for i in babies], c1) if babies else []
+        if hoist is None:
+            accs = be.keyswitch_qp([self.key(self.gal_rot(i), L, "baby") for i in babies], c1) if babies else []
+        else:
+            # The reference's LinearTransform on a ciphertext ABOVE the matrix level (the stock Bootstrapp's last SlotsToCoeffs matrix: ciphertext level 15, matrix
+            # level 14): DecomposeNTT runs at the matrix level, but rotateHoistedNoModDown takes ITS level from the ciphertext (test_run @0x524d60: level =
+            # len(ct0.Value[0].Coeffs) - 1), so KeyswitchHoistedNoModDown runs one digit further than was decomposed and reads what the evaluator's decomposition
+            # pool still holds there - the last digit of the PREVIOUS LinearTransform's input (limbs hoist[1]+1 .. of its c1). Harmless for the value (the key's
+            # gadget factor of that digit vanishes modulo the limbs kept; only e * digit / P of noise is added), but the residues depend on it. Equivalent: one
+            # decomposition at the ciphertext's level of Y = (c1's limbs up to the matrix level | the previous input's limbs above it); rows above the matrix
+            # level dropped afterwards.
+            Y, Lh = hoist
+            assert Y.shape[0] == Lh + 1 and Lh > L and np.array_equal(Y[:nl], c1)
+            full = be.keyswitch_qp([self.key(self.gal_rot(i), Lh, "baby") for i in babies], np.ascontiguousarray(Y)) if babies else []
+            accs = [np.concatenate([a[:, :nl], a[:, Lh + 1:]], axis=1) for a in full]
         self.counters["keyswitch"] += len(babies)
         rot = {}
         for i, acc in zip(babies, accs):
@@ -1045,10 +1058,15 @@ class Bootstrapper:
             # 15, 15, 14 at plaintext scales sqrt(q15), sqrt(q15), 2^30, each followed by a Rescale(min = the scale before) that finds nothing to drop
             dbg = getattr(self, "debug", None)
             sc = math.sqrt(float(C.Q[LV_RELU_TOP]))
+            prev_c1 = None
             for M, n1, s_pt, L in zip(self.stc, self.stc_n1, (sc, sc, 2.0 ** 30), (LV_RELU_TOP, LV_RELU_TOP, LV_RELU_TOP - 1)):
-                ct = C.drop_to(ct, min(ct.level, L))
+                hoist = None
+                if ct.level > L:                                    # see linear_transform_qp: the baby steps run at the ciphertext's level on a stale last digit
+                    hoist = (np.concatenate([ct.rows[1][: L + 1], prev_c1[L + 1: ct.level + 1]]), ct.level)
+                    ct = C.drop_to(ct, L)
+                prev_c1 = ct.rows[1] if hoist is None else prev_c1
                 s_in = ct.scale
-                ct = C.rescale_to(C.linear_transform_qp(ct, M, s_pt, n1, slots=self.period), s_in)
+                ct = C.rescale_to(C.linear_transform_qp(ct, M, s_pt, n1, slots=self.period, hoist=hoist), s_in)
                 if dbg is not None:
                     dbg.setdefault("StoC_LinearTransform", []).append(ct.copy())
             return ct
