@@ -113,6 +113,7 @@ struct hc_ctx {
     const void *hoist_cx = nullptr; int hoist_level = -1;   // the polynomial whose digit decomposition ws_mm currently holds
     long chunk_nodes = 64;
     long lanes = 1;               // internal concurrency of ONE conv_then_pack (power of two; 1 = single stream)
+    long lane_priority = 0;       // 1: the lanes' streams get descending priorities (lane 0 highest), so the lanes run staggered: a lane's small, latency-bound tree levels fill with the next lane's big ones
     std::vector<HcLane> lane;
     hipEvent_t ev_fork = nullptr;
     HcCplx *enc_roots = nullptr; int *enc_rot_group = nullptr;      // slot encoder tables (hc_encode_slots), built at first use
@@ -1298,7 +1299,13 @@ static int hc_conv_lanes(hc_ctx *c, const hc_ker *ker, int max_ob, int G, const 
     const int nloc = max_ob / G;
     if ((int)c->lane.size() < G) {
         size_t old = c->lane.size(); c->lane.resize((size_t)G);
-        for (size_t g = old; g < (size_t)G; g++) { HC_HIP(c, hipStreamCreate(&c->lane[g].stream)); HC_HIP(c, hipEventCreate(&c->lane[g].done)); }
+        int least = 0, greatest = 0;
+        if (c->lane_priority) HC_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));       // numerically lower = higher priority
+        for (size_t g = old; g < (size_t)G; g++) {
+            if (c->lane_priority) HC_HIP(c, hipStreamCreateWithPriority(&c->lane[g].stream, hipStreamDefault, std::min(least, greatest + (int)g)));
+            else HC_HIP(c, hipStreamCreate(&c->lane[g].stream));
+            HC_HIP(c, hipEventCreate(&c->lane[g].done));
+        }
     }
     if (!c->ev_fork) HC_HIP(c, hipEventCreate(&c->ev_fork));
     if (c->ws_gather_rows < (size_t)G * 2) {
@@ -1584,6 +1591,7 @@ extern "C" int hc_bl_post_ker_slots(hc_ctx *c, const double *max_ker_rs, int in_
 extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!c || !name) return HC_ERR_ARG;
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
+    if (!strcmp(name, "lane_priority")) { if (!c->lane.empty()) return hc_fail(c, HC_ERR_STATE, "lane_priority must be set before the first convolution on lanes"); c->lane_priority = value != 0; return HC_OK; }
     if (!strcmp(name, "lanes")) { if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
     if (!strcmp(name, "small_levels")) { if (value < 0) return hc_fail(c, HC_ERR_ARG, "small_levels must be >= 0"); c->small_levels = value; return HC_OK; }
     if (!strcmp(name, "peer_access")) { c->peer_access = value ? 1 : 0; return HC_OK; }
