@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="ciphertexts per hc_conv_then_pack_batch call (one launch set covers them all); 4 x 4 contexts measured best (8 x 2: -4.5 %, 8 x 3: -1 %)")
     ap.add_argument("--streams", type=int, default=4, help="contexts (HIP streams) per GPU, each with its own batch of resident ciphertexts")
     ap.add_argument("--batch-alt", type=int, default=0, help="experiment: odd-numbered contexts use this batch size instead (desynchronises the streams)")
-    ap.add_argument("--lanes", type=int, default=1, help="internal lanes of one conv (channels i mod G on their own streams)")
+    ap.add_argument("--lanes", type=int, default=1, help="internal lanes of ONE convolution (channels i mod G on their own streams; affects single_conv_ms only: batches of >= 2 ciphertexts do not use lanes)")
     ap.add_argument("--antiphase", type=int, default=0, help="two half-batches per context one phase apart (memory-bound kernels of one beside VALU-bound kernels of the other); 0 = one launch set per batch")
     ap.add_argument("--opt", action="append", default=[], help="extra context option name=value (hc_set_option), e.g. b5_merged=0; experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -112,7 +112,11 @@ struct hc_ctx {
     std::map<int, HcTw *> rescale_plan;                     // per level: qL^-1 mod q_i
     const void *hoist_cx = nullptr; int hoist_level = -1;   // the polynomial whose digit decomposition ws_mm currently holds
     long chunk_nodes = 64;
-    long lanes = 1;               // internal concurrency of ONE conv_then_pack (power of two; 1 = single stream)
+    long lanes = 1;               // internal concurrency of ONE convolution (hc_conv_then_pack, hc_conv_then_pack_batch with n = 1): a power of two, 1 = single stream (default).
+                                  // Measured on MI355X, `conv 3 3` alone (profiles/round3_lanes.txt): 2 lanes 1.60 -> 1.49 ms in a process with ONE context, but 1.50 -> 1.65 ms in
+                                  // bench.py's process with four contexts - the runtime maps all streams of a process onto 4 hardware queues, lanes that share a queue run one
+                                  // after the other, and kernels of different queues slow each other down (two 32-node b5m side by side: 134 + 141 us against 2 x 45 alone); 4 lanes
+                                  // 2.9 ms. So lanes stay an option.
     long lane_priority = 0;       // 1: the lanes' streams get descending priorities (lane 0 highest), so the lanes run staggered: a lane's small, latency-bound tree levels fill with the next lane's big ones
     std::vector<HcLane> lane;
     hipEvent_t ev_fork = nullptr;
@@ -1316,6 +1320,12 @@ static int hc_conv_lanes(hc_ctx *c, const hc_ker *ker, int max_ob, int G, const 
         c->ws_gather_rows = (size_t)G * 2;
     }
     HC_HIP(c, hipEventRecord(c->ev_fork, c->stream));          // ctc (and everything queued before) is ready
+    // The lanes' launches are RECORDED first and then issued round-robin, one launch per lane in turn. Issued lane after lane (round 2), the host needs ~8 us per launch
+    // and ~55 launches per lane: lane g + 1 was not even submitted before lane g was most of the way through its tree, so the lanes ran one after the other (kernel
+    // trace: 2.9 ms for one `conv 3 3` on 4 lanes against 1.6 ms on one). Round-robin, the G lanes' kernels of one step reach the device together and the small tree
+    // levels - a handful of workgroups, latency-bound - of G lanes overlap.
+    std::vector<std::vector<HcOp>> ops((size_t)G);
+    const bool record = !c->profile;                           // the per-kernel profile brackets every launch with events on the issuing stream: keep that mode sequential
     for (int g = 0; g < G; g++) {
         HcLane &L = c->lane[(size_t)g];
         if (L.cts_rows < (size_t)nloc * 2) {
@@ -1325,17 +1335,32 @@ static int hc_conv_lanes(hc_ctx *c, const hc_ker *ker, int max_ob, int G, const 
             HC_HIP(c, hcx_malloc(c, (void **)&L.cts, (size_t)nloc * 2 * HC_N * sizeof(u64)));
             L.cts_rows = (size_t)nloc * 2;
         }
-        int rc;
-        {
+        for (int attempt = 0;; attempt++) {
             HcLaneScope scope(c, &L);
-            rc = hipStreamWaitEvent(c->stream, c->ev_fork, 0) == hipSuccess ? HC_OK : hc_fail(c, HC_ERR_HIP, "hipStreamWaitEvent failed");
-            if (!rc) rc = hc_loopA_run_set(c, hc_ptrs1(ker->d), 1, g, G, nloc, L.cts, 0, true);
+            if (!record && hipStreamWaitEvent(c->stream, c->ev_fork, 0) != hipSuccess) return hc_fail(c, HC_ERR_HIP, "hipStreamWaitEvent failed");
+            // a workspace that grows while the sequence is being recorded leaves the launches recorded before it pointing at the freed block: record again (the
+            // workspaces only grow, so the second pass finds them large enough)
+            const u64 *tmp0 = c->ws_tmp, *cts20 = c->ws_cts2; const size_t tr0 = c->ws_tmp_rows, cr0 = c->ws_cts2_rows;
+            ops[(size_t)g].clear();
+            if (record) c->rec = &ops[(size_t)g];
+            int rc = hc_loopA_run_set(c, hc_ptrs1(ker->d), 1, g, G, nloc, L.cts, 0, true);
             if (!rc) rc = hc_pack_run(c, L.cts, 0, 1, nloc, nloc, nullptr, log2g);
-            if (!rc && hipMemcpyAsync(c->ws_gather + (size_t)g * 2 * HC_N, L.cts, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
-                rc = hc_fail(c, HC_ERR_HIP, "lane gather copy failed");
-            if (!rc && hipEventRecord(L.done, c->stream) != hipSuccess) rc = hc_fail(c, HC_ERR_HIP, "hipEventRecord failed");
+            c->rec = nullptr;
+            if (rc) return rc;
+            if (!record || (c->ws_tmp == tmp0 && c->ws_cts2 == cts20 && c->ws_tmp_rows == tr0 && c->ws_cts2_rows == cr0)) break;
+            if (attempt == 3) return hc_fail(c, HC_ERR_STATE, "hc_conv_lanes: the lane workspaces keep growing");
         }
-        if (rc) return rc;
+    }
+    if (record) {
+        size_t nmax = 0;
+        for (int g = 0; g < G; g++) { HC_HIP(c, hipStreamWaitEvent(c->lane[(size_t)g].stream, c->ev_fork, 0)); nmax = std::max(nmax, ops[(size_t)g].size()); }
+        for (size_t i = 0; i < nmax; i++)
+            for (int g = 0; g < G; g++) if (i < ops[(size_t)g].size()) HC_HIP(c, ops[(size_t)g][i].run(c->lane[(size_t)g].stream));
+    }
+    for (int g = 0; g < G; g++) {
+        HcLane &L = c->lane[(size_t)g];
+        HC_HIP(c, hipMemcpyAsync(c->ws_gather + (size_t)g * 2 * HC_N, L.cts, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, L.stream));
+        HC_HIP(c, hipEventRecord(L.done, L.stream));
     }
     for (int g = 0; g < G; g++) HC_HIP(c, hipStreamWaitEvent(c->stream, c->lane[(size_t)g].done, 0));
     const HcPtrs bp = hc_ptrs1(bias);
@@ -1433,17 +1458,22 @@ static int hc_conv_batch_antiphase(hc_ctx *c, int n, const HcPtrs &ct_in, const 
     HC_HIP(c, hipStreamWaitEvent(c->stream, L0.done, 0)); HC_HIP(c, hipStreamWaitEvent(c->stream, L1.done, 0));
     return HC_OK;
 }
+// lanes for ONE convolution (option "lanes"); only dense packing (norm 1) splits into lanes, and the per-kernel profile keeps one stream
+static int hc_lanes_for(const hc_ctx *c, int max_ob, int norm) {
+    const int G = c->lanes > 1 && !c->profile ? (int)c->lanes : 1;
+    return (G > 1 && norm == 1 && max_ob >= 2 * G) ? G : 1;
+}
 extern "C" int hc_conv_then_pack(hc_ctx *c, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
                                  int max_ob, int norm, double out_scale, const uint64_t *bias, uint64_t *ct_out, double *scale_out) {
     HC_ENTER(c);
     if (!ct_in || !ker || !ct_out || ker->max_ob < max_ob) return hc_fail(c, HC_ERR_ARG, "hc_conv_then_pack: bad arguments");
     u64 cst[2]; double target;
     HC_TRY(hc_loopA_consts(c, ct_scale, ker_scale, max_ob, norm, out_scale, cst, &target));
-    const int G = (int)c->lanes;
+    const int G = hc_lanes_for(c, max_ob, norm);
     // conv.go:274 multiplies the scale by real_cnum; conv.go:541 then demands out_scale and level 0
     const double final_scale = target * (double)(max_ob / norm);
     if (final_scale != out_scale) return hc_fail(c, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
-    if (G > 1 && norm == 1 && max_ob >= 2 * G) {
+    if (G > 1) {
         HC_TRY(hc_prepare_ctc(c, hc_ptrs1((const u64 *)ct_in), 1, cst));
         HC_TRY(hc_conv_lanes(c, ker, max_ob, G, (const u64 *)bias, (u64 *)ct_out));
     } else {
@@ -1469,7 +1499,11 @@ extern "C" int hc_conv_then_pack_batch(hc_ctx *c, int n, const uint64_t *const *
     HC_TRY(hc_loopA_consts(c, ct_scale, ker_scale, max_ob, norm, out_scale, cst, &target));
     const double final_scale = target * (double)(max_ob / norm);
     if (final_scale != out_scale) return hc_fail(c, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
-    if (n >= 2 && c->antiphase && !c->profile) HC_TRY(hc_conv_batch_antiphase(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
+    if (n == 1 && hc_lanes_for(c, max_ob, norm) > 1) {
+        HC_TRY(hc_prepare_ctc(c, pin, 1, cst));
+        HC_TRY(hc_conv_lanes(c, ker[0], max_ob, hc_lanes_for(c, max_ob, norm), pbias.p[0], outs[0]));
+    }
+    else if (n >= 2 && c->antiphase && !c->profile) HC_TRY(hc_conv_batch_antiphase(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
     else HC_TRY(hc_conv_batch_run(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
     if (scale_out) *scale_out = final_scale;
     return HC_OK;
@@ -1592,7 +1626,7 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!c || !name) return HC_ERR_ARG;
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
     if (!strcmp(name, "lane_priority")) { if (!c->lane.empty()) return hc_fail(c, HC_ERR_STATE, "lane_priority must be set before the first convolution on lanes"); c->lane_priority = value != 0; return HC_OK; }
-    if (!strcmp(name, "lanes")) { if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
+    if (!strcmp(name, "lanes")) { if (value == 0) value = 1; if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
     if (!strcmp(name, "small_levels")) { if (value < 0) return hc_fail(c, HC_ERR_ARG, "small_levels must be >= 0"); c->small_levels = value; return HC_OK; }
     if (!strcmp(name, "peer_access")) { c->peer_access = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "b5_merged")) { c->b5_merged = value ? 1 : 0; return HC_OK; }
