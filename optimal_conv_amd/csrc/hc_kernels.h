@@ -131,6 +131,17 @@ __device__ __forceinline__ void hc_gs_round_f64(double (&e)[16], const TW &tw, H
 //   hi-local (col = hi*16+tid), lo-local (col = tid*16+lo), linear (row k, col = t). The swizzle XORs the low
 //   4 column bits with bits 5..7 of the column and flips bits 3 and 4 on odd rows: bijective per row, and each of
 //   the three patterns spreads its 32 lanes over all 32 slots (derivation in DESIGN.md).
+// A rows pass exchanges data only inside the 16 lanes that share a row (hc_rows_lds keeps row rloc in words [256 rloc, 256 rloc + 256)), i.e. inside ONE wavefront, whose LDS
+// instructions execute in program order: the exchange needs no workgroup barrier, only that the compiler keeps the order (round 3; HC_ROWS_WAVE_SYNC=0 restores __syncthreads).
+// The CPU emulator runs the threads of a block as fibers one after the other, so there the wave-level synchronisation has to be a yield like any barrier.
+#ifndef HC_ROWS_WAVE_SYNC
+#define HC_ROWS_WAVE_SYNC 1
+#endif
+#if defined(HC_EMU) || !HC_ROWS_WAVE_SYNC
+#define HC_ROW_SYNC() __syncthreads()
+#else
+#define HC_ROW_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 __device__ __forceinline__ int hc_rows_lds(int rloc, int col) {
     return rloc * 256 + ((col & 0xF0) ^ ((rloc & 1) << 4)) + ((col & 15) ^ ((col >> 5) & 7) ^ ((rloc & 1) << 3));
 }
@@ -149,7 +160,7 @@ __device__ __forceinline__ void hc_rows_fwd(u64 (&e)[16], u64 *lds, const HcTwTa
     hc_ct_round<FM>(e, HcRowsTwA{T.rowsA + row * 16}, Q);
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) lds[hc_rows_lds(rloc, hi * 16 + tid)] = e[hi];
-    __syncthreads();
+    HC_ROW_SYNC();
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = lds[hc_rows_lds(rloc, tid * 16 + lo)];
     hc_ct_round<FM>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, Q);
@@ -159,7 +170,7 @@ __device__ __forceinline__ void hc_rows_inv(u64 (&e)[16], u64 *lds, const HcTwTa
     hc_gs_round<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, Q, T.ninv, T.ninv);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) lds[hc_rows_lds(rloc, tid * 16 + lo)] = e[lo];
-    __syncthreads();
+    HC_ROW_SYNC();
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = lds[hc_rows_lds(rloc, hi * 16 + tid)];
     hc_gs_round<false>(e, HcRowsTwA{T.rowsA + row * 16}, Q, T.ninv, T.ninv);
@@ -193,7 +204,7 @@ __device__ __forceinline__ void hc_rows_inv_f64(double (&e)[16], u64 *lds, const
     hc_gs_round_f64<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, m, T.ninv, T.ninv);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) lds[hc_rows_lds(rloc, tid * 16 + lo)] = hc_d2u(e[lo]);
-    __syncthreads();
+    HC_ROW_SYNC();
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = hc_u2d(lds[hc_rows_lds(rloc, hi * 16 + tid)]);
     hc_gs_round_f64<false>(e, HcRowsTwA{T.rowsA + row * 16}, m, T.ninv, T.ninv);
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon(const u64 *in, u64
     for (int hi = 0; hi < 16; hi++) e[hi] = in[pbase + (size_t)row * 256 + hi * 16 + tid];
     const HcQ Q = hc_q(q);
     hc_rows_fwd<FM>(e, lds, T, row, rloc, tid, Q);
-    __syncthreads();
+    HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
     for (int k = 0; k < 16; k++) out[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t] = hc_fwd_canon<FM>(e[k], Q, mu);
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv(const u64 *in, u64 *out,
 #pragma unroll
     for (int k = 0; k < 16; k++) e[k] = in[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t];
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
-    __syncthreads();
+    HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_inv(e, lds, T, row, rloc, tid, hc_q(q));
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[pbase + (size_t)row * 256 + hi * 16 + tid] = e[hi];
@@ -518,7 +529,7 @@ __global__ __launch_bounds__(HC_TPB, HC_A_WAVES) void hc_k_a1(HcLoopA A, HcTwTab
     }
     u64 *o = A.tmp + ((size_t)z * A.njobs + job) * 65536 + (size_t)row * 256;
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
-    __syncthreads();
+    HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     if (F64) {
         const HcF64Mod m{(double)A.m1.q, 1.0 / (double)A.m1.q};
         double f[16];
@@ -591,7 +602,7 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_a3(HcLoopA A, HcTwT
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) { const HcTw cw = c[kk * 256]; a0[kk] = hc_shoup4(a0[kk], cw.w, cw.ws, Q); }      // [0, 4q)
     hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, Q);
-    __syncthreads();
+    HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
@@ -648,7 +659,7 @@ __global__ __launch_bounds__(HC_TPB, HC_A_WAVES) void hc_k_b1(HcLoopB B, HcTwTab
         for (int kk = 0; kk < 16; kk++) tt[kk * 256] = e[kk];
     }
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
-    __syncthreads();
+    HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_inv(e, lds, T0inv, row, rloc, tid, Q);
     u64 *__restrict__ o = B.tmpC + (size_t)job * 65536 + (size_t)row * 256;
 #pragma unroll
@@ -692,7 +703,7 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b3(HcLoopB B, HcTwT
             const HcTw w = ev[lo * 256];
             e[lo] = hc_shoup4(cp[lo], w.w, w.ws, Q);
         }
-        __syncthreads();
+        HC_ROW_SYNC();             // row-local (the forward pass's / the previous k's reads of this row, then the inverse pass's writes): hc_k_b3 has no workgroup barrier left
         hc_rows_inv(e, lds, TPinv, row, rloc, tid, Q);
         u64 *o = B.tmpE + ((size_t)node * 2 + k) * 65536 + (size_t)row * 256;
 #pragma unroll
@@ -782,7 +793,7 @@ __global__ __launch_bounds__(HC_TPB, ROWLOCAL ? 5 : 3) void hc_k_b5(HcLoopB B, H
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
     hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, Q);
-    __syncthreads();
+    HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);          // e[kk] = n = NTT(ext * P^-1) at (row kk, column t)
     __syncthreads();
     if (ROWLOCAL) {
@@ -880,7 +891,7 @@ __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTw
         for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
         if (k == 0) __syncthreads();                      // the last gather of k = 1 is done before the transform writes LDS again
         hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, Q);
-        __syncthreads();
+        HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
         hc_rows_lo_to_lin(e, lds, t, rloc, tid);          // e[kk] = n_k at (row kk, column t)
         __syncthreads();
 #pragma unroll
@@ -984,17 +995,19 @@ template <bool ROWS, int D, bool SCALE_LAST> __device__ __forceinline__ void hc_
     } else { hc_s_bf_inv(e0, e2, wc, Q); hc_s_bf_inv(e1, e3, wc, Q); }
     lds[hc_s_addr<ROWS>(line, x0)] = e0; lds[hc_s_addr<ROWS>(line, x0 + D)] = e1; lds[hc_s_addr<ROWS>(line, x0 + G)] = e2; lds[hc_s_addr<ROWS>(line, x0 + G + D)] = e3;
 }
+// between the rounds of a ROWS pass a line belongs to ONE wavefront (line = t >> 6): wave-level order is enough (HC_ROW_SYNC); a cols line is spread over the four waves
+template <bool ROWS> __device__ __forceinline__ void hc_s_sync() { if (ROWS) { HC_ROW_SYNC(); } else __syncthreads(); }
 // whole passes over the tile in LDS with preloaded twiddles; every thread must call them; they end with a barrier (the tile is complete and visible)
 template <bool ROWS> __device__ __forceinline__ void hc_s_pass_fwd(u64 *lds, const HcTw (&w)[12], int line, int u, const HcQ &Q) {
-    hc_s_round_fwd<ROWS, 128>(lds, w[0], w[1], w[2], line, u, Q); __syncthreads();
-    hc_s_round_fwd<ROWS, 32>(lds, w[3], w[4], w[5], line, u, Q); __syncthreads();
-    hc_s_round_fwd<ROWS, 8>(lds, w[6], w[7], w[8], line, u, Q); __syncthreads();
+    hc_s_round_fwd<ROWS, 128>(lds, w[0], w[1], w[2], line, u, Q); hc_s_sync<ROWS>();
+    hc_s_round_fwd<ROWS, 32>(lds, w[3], w[4], w[5], line, u, Q); hc_s_sync<ROWS>();
+    hc_s_round_fwd<ROWS, 8>(lds, w[6], w[7], w[8], line, u, Q); hc_s_sync<ROWS>();
     hc_s_round_fwd<ROWS, 2>(lds, w[9], w[10], w[11], line, u, Q); __syncthreads();
 }
 template <bool ROWS, bool SCALE> __device__ __forceinline__ void hc_s_pass_inv(u64 *lds, const HcTwTab &T, const HcTw (&w)[12], int line, int u, const HcQ &Q) {
-    hc_s_round_inv<ROWS, 1, false>(lds, T, w[0], w[1], w[2], line, u, Q); __syncthreads();
-    hc_s_round_inv<ROWS, 4, false>(lds, T, w[3], w[4], w[5], line, u, Q); __syncthreads();
-    hc_s_round_inv<ROWS, 16, false>(lds, T, w[6], w[7], w[8], line, u, Q); __syncthreads();
+    hc_s_round_inv<ROWS, 1, false>(lds, T, w[0], w[1], w[2], line, u, Q); hc_s_sync<ROWS>();
+    hc_s_round_inv<ROWS, 4, false>(lds, T, w[3], w[4], w[5], line, u, Q); hc_s_sync<ROWS>();
+    hc_s_round_inv<ROWS, 16, false>(lds, T, w[6], w[7], w[8], line, u, Q); hc_s_sync<ROWS>();
     hc_s_round_inv<ROWS, 64, SCALE>(lds, T, w[9], w[10], w[11], line, u, Q); __syncthreads();
 }
 // thread -> (line, u): rows tiles: 64 consecutive threads per row; cols tiles: the column index is the fast one
@@ -1208,7 +1221,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, 
     for (int hi = 0; hi < 16; hi++) e[hi] = in[pbase + (size_t)row * 256 + hi * 16 + tid];
     const HcQ Q = hc_q(R.q);
     hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, Q);
-    __syncthreads();
+    HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
     for (int k = 0; k < 16; k++) out[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu);
@@ -1224,7 +1237,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *o
 #pragma unroll
     for (int k = 0; k < 16; k++) e[k] = in[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t];
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
-    __syncthreads();
+    HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_inv(e, lds, R.inv, row, rloc, tid, hc_q(R.q));
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[pbase + (size_t)row * 256 + hi * 16 + tid] = e[hi];
@@ -1321,7 +1334,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_mac(const u64 *evk, cons
             for (int h = 0; h < 16; h++) e[h] = in[h * 16 + tid];
             if (d) __syncthreads();                                                // the previous digit's exchange is done with the LDS
             hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, Q);
-            __syncthreads();
+            HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
             hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
             for (int k = 0; k < 16; k++) e[k] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu);
