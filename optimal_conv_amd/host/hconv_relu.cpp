@@ -884,6 +884,9 @@ struct Boot {
             if (g.first) key(gal_rot(g.first), lt.level, 2);
             for (auto &b : g.second) if (b.first) key(gal_rot(b.first), lt.level, 1);
         }
+        // a SlotsToCoeffs matrix below its predecessor's level (the stock Bootstrapp's last one) hoists its baby steps at the ciphertext's level (linear_transform_qp, hoist_c1)
+        for (size_t i = 1; i < S.stc.size(); i++) if (S.stc[i].level < S.stc[i - 1].level)
+            for (auto &g : S.stc[i].giant) for (auto &b : g.second) if (b.first) key(gal_rot(b.first), S.stc[i - 1].level, 1);
         for (int j = 0; j < ls; j++) key(gal_rot(ns << j), LV_CTS_TOP);       // SubSum
         if (ls) key(gal_rot(ns), LV_SINE_TOP);                                 // packing the imaginary half next to the real one
         if (dft_digests) fflush(dft_digests);
