@@ -1010,6 +1010,66 @@ template <bool ROWS, bool SCALE> __device__ __forceinline__ void hc_s_pass_inv(u
     hc_s_round_inv<ROWS, 16, false>(lds, T, w[6], w[7], w[8], line, u, Q); hc_s_sync<ROWS>();
     hc_s_round_inv<ROWS, 64, SCALE>(lds, T, w[9], w[10], w[11], line, u, Q); __syncthreads();
 }
+// ---- rows passes in REGISTERS with cross-lane exchanges (round 3): a 256-point line is the work of ONE wavefront (64 lanes x 4 residues), so the three regroupings between
+// the four radix-4 rounds are 4 x 4 transposes between the register index and a pair of lane bits - lane distances 32 / 16 (v_permlane32_swap, v_permlane16_swap: gfx950),
+// 8 / 4 (DPP row_ror:8, row_shr:4 / row_shl:4 with bank masks) and 2 / 1 (DPP quad_perm + select). No LDS, no barrier. hc_xswap<LB>(r0, r1) is one step of such a transpose:
+// the lanes whose bit LB is 0 hand r1 to their partner (lane ^ 2^LB) and receive its r0 into r1's place... precisely: lane(bit = 0).r1 <-> lane(bit = 1).r0.
+// (lane semantics of the five instructions probed on MI355X: tools/dpp_probe.hip). Under the CPU emulator the threads of a block are fibers: the exchange goes through a
+// static array with two yields.
+#ifndef HC_S_REG_PASSES
+#define HC_S_REG_PASSES 1
+#endif
+#if defined(HC_EMU)
+template <int LB> __device__ __forceinline__ void hc_xswap(u64 &r0, u64 &r1) {
+    __shared__ u64 xch[HC_STPB];
+    const int t = threadIdx.x; const bool hi = (t >> LB) & 1;
+    xch[t] = hi ? r0 : r1;
+    __syncthreads();
+    const u64 got = xch[t ^ (1 << LB)];
+    __syncthreads();
+    if (hi) r0 = got; else r1 = got;
+}
+#else
+template <int LB> __device__ __forceinline__ void hc_xswap32(u32 &a, u32 &b) {       // a = r0's dword, b = r1's dword
+    if (LB == 5) { auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = r[0]; b = r[1]; }
+    else if (LB == 4) { auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = r[0]; b = r[1]; }
+    else if (LB == 3) { const u32 a0 = a; a = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xF, 0xC, false); b = __builtin_amdgcn_update_dpp(b, a0, 0x128, 0xF, 0x3, false); }   // row_ror:8
+    else if (LB == 2) { const u32 a0 = a; a = __builtin_amdgcn_update_dpp(a, b, 0x114, 0xF, 0xA, false); b = __builtin_amdgcn_update_dpp(b, a0, 0x104, 0xF, 0x5, false); }   // row_shr:4 / row_shl:4
+    else {
+        const bool hi = (threadIdx.x >> LB) & 1;
+        const u32 give = hi ? a : b;
+        const u32 got = LB == 1 ? __builtin_amdgcn_mov_dpp(give, 0x4E, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(give, 0xB1, 0xF, 0xF, true);                              // quad_perm [2,3,0,1] / [1,0,3,2]
+        if (hi) a = got; else b = got;
+    }
+}
+template <int LB> __device__ __forceinline__ void hc_xswap(u64 &r0, u64 &r1) {
+    u32 a0 = (u32)r0, a1 = (u32)(r0 >> 32), b0 = (u32)r1, b1 = (u32)(r1 >> 32);
+    hc_xswap32<LB>(a0, b0); hc_xswap32<LB>(a1, b1);
+    r0 = ((u64)a1 << 32) | a0; r1 = ((u64)b1 << 32) | b0;
+}
+#endif
+// register index (2 bits) <-> lane bits (HB, HB - 1): e[j] of the lane with field m  <->  e[m] of the lane with field j
+template <int HB> __device__ __forceinline__ void hc_s_transpose(u64 (&e)[4]) { hc_xswap<HB>(e[0], e[2]); hc_xswap<HB>(e[1], e[3]); hc_xswap<HB - 1>(e[0], e[1]); hc_xswap<HB - 1>(e[2], e[3]); }
+// forward pass: in e[j] = element (lane + 64 j) of the line, out e[j] = element (4 lane + j); w = hc_s_tw_load_fwd(u = lane): the same thread <-> butterfly-group assignment as the LDS pass
+__device__ __forceinline__ void hc_s_pass_fwd_reg(u64 (&e)[4], const HcTw (&w)[12], const HcQ &Q) {
+    hc_s_bf_fwd(e[0], e[2], w[0], Q); hc_s_bf_fwd(e[1], e[3], w[0], Q); hc_s_bf_fwd(e[0], e[1], w[1], Q); hc_s_bf_fwd(e[2], e[3], w[2], Q);
+    hc_s_transpose<5>(e);
+    hc_s_bf_fwd(e[0], e[2], w[3], Q); hc_s_bf_fwd(e[1], e[3], w[3], Q); hc_s_bf_fwd(e[0], e[1], w[4], Q); hc_s_bf_fwd(e[2], e[3], w[5], Q);
+    hc_s_transpose<3>(e);
+    hc_s_bf_fwd(e[0], e[2], w[6], Q); hc_s_bf_fwd(e[1], e[3], w[6], Q); hc_s_bf_fwd(e[0], e[1], w[7], Q); hc_s_bf_fwd(e[2], e[3], w[8], Q);
+    hc_s_transpose<1>(e);
+    hc_s_bf_fwd(e[0], e[2], w[9], Q); hc_s_bf_fwd(e[1], e[3], w[9], Q); hc_s_bf_fwd(e[0], e[1], w[10], Q); hc_s_bf_fwd(e[2], e[3], w[11], Q);
+}
+// inverse pass (no N^-1: the rows passes never carry it): in e[j] = element (4 lane + j), out e[j] = element (lane + 64 j); w = hc_s_tw_load_inv(u = lane)
+__device__ __forceinline__ void hc_s_pass_inv_reg(u64 (&e)[4], const HcTw (&w)[12], const HcQ &Q) {
+    hc_s_bf_inv(e[0], e[1], w[0], Q); hc_s_bf_inv(e[2], e[3], w[1], Q); hc_s_bf_inv(e[0], e[2], w[2], Q); hc_s_bf_inv(e[1], e[3], w[2], Q);
+    hc_s_transpose<1>(e);
+    hc_s_bf_inv(e[0], e[1], w[3], Q); hc_s_bf_inv(e[2], e[3], w[4], Q); hc_s_bf_inv(e[0], e[2], w[5], Q); hc_s_bf_inv(e[1], e[3], w[5], Q);
+    hc_s_transpose<3>(e);
+    hc_s_bf_inv(e[0], e[1], w[6], Q); hc_s_bf_inv(e[2], e[3], w[7], Q); hc_s_bf_inv(e[0], e[2], w[8], Q); hc_s_bf_inv(e[1], e[3], w[8], Q);
+    hc_s_transpose<5>(e);
+    hc_s_bf_inv(e[0], e[1], w[9], Q); hc_s_bf_inv(e[2], e[3], w[10], Q); hc_s_bf_inv(e[0], e[2], w[11], Q); hc_s_bf_inv(e[1], e[3], w[11], Q);
+}
 // thread -> (line, u): rows tiles: 64 consecutive threads per row; cols tiles: the column index is the fast one
 #define HC_S_ROWS_MAP const int t = threadIdx.x, line = t >> 6, u = t & 63, grow = HC_TILE * 4 + line
 // cols tiles are 32 bytes wide: four neighbours share every 128-byte line, so the eight tiles an XCD serves (blockIdx.x mod 8 picks the XCD) are made NEIGHBOURS - two lines'
@@ -1028,6 +1088,19 @@ __global__ __launch_bounds__(HC_STPB) void hc_k_sb1(HcLoopB B, HcTwTab T0inv) {
     const HcTw *__restrict__ idx = B.idx + tile;
     const HcQ Q = hc_q(B.m0.q);
     HcTw w[12]; hc_s_tw_load_inv<true>(w, T0inv, grow, u);
+    u64 *__restrict__ o = B.tmpC + (size_t)job * 65536 + tile;
+#if HC_S_REG_PASSES
+    (void)lds;
+    u64 e[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = line * 256 + u * 4 + j; const HcTw I = idx[p];
+        e[j] = hc_fold(y1[p] + Q.q4 - hc_shoup4(x1[p], I.w, I.ws, Q), Q.nq4);            // t2.c1 (conv.go:288-289), lazy < 4q
+    }
+    hc_s_pass_inv_reg(e, w, Q);
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[line * 256 + j * 64 + u] = e[j];
+#else
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int p = k * 256 + t; const HcTw I = idx[p];
@@ -1035,9 +1108,9 @@ __global__ __launch_bounds__(HC_STPB) void hc_k_sb1(HcLoopB B, HcTwTab T0inv) {
     }
     __syncthreads();
     hc_s_pass_inv<true, false>(lds, T0inv, w, line, u, Q);
-    u64 *__restrict__ o = B.tmpC + (size_t)job * 65536 + tile;
 #pragma unroll
     for (int k = 0; k < 4; k++) o[k * 256 + t] = lds[k * 256 + t];
+#endif
 }
 // SB2: cols-inverse mod Q0 (with N^-1) -> canonical -> cols-forward mod P, in place on tmpC. grid = (64, batch*nodes); the tile is 256 rows x 4 columns
 __global__ __launch_bounds__(HC_STPB) void hc_k_sb2(HcLoopB B, HcTwTab T0inv, HcTwTab TPfwd) {
@@ -1068,12 +1141,33 @@ __global__ __launch_bounds__(HC_STPB) void hc_k_sb3(HcLoopB B, HcTwTab TPfwd, Hc
     const u64 *in = B.tmpC + (size_t)node * 65536 + tile;
     const HcQ Q = hc_q(B.mp.q);
     HcTw w[12]; hc_s_tw_load_fwd<true>(w, TPfwd, grow, u);
+    const HcTw *__restrict__ ev = B.evkP + (size_t)k * 65536;                    // lo-local coalesced order: natural (R, C = tid*16 + lo) -> ((R>>4)*16 + lo)*256 + (R&15)*16 + tid
+#if HC_S_REG_PASSES
+    {
+        (void)lds;
+        u64 e[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) e[j] = in[line * 256 + j * 64 + u];
+        hc_s_pass_fwd_reg(e, w, Q);
+        hc_s_tw_load_inv<true>(w, TPinv, grow, u);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int R = grow, C = u * 4 + j;
+            const HcTw kw = ev[((R >> 4) * 16 + (C & 15)) * 256 + (R & 15) * 16 + (C >> 4)];
+            e[j] = hc_shoup4(e[j], kw.w, kw.ws, Q);                                // < 4q for any 64-bit input: what the inverse pass takes
+        }
+        hc_s_pass_inv_reg(e, w, Q);
+        u64 *o = B.tmpE + ((size_t)node * 2 + k) * 65536 + tile;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[line * 256 + j * 64 + u] = e[j];
+        return;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < 4; j++) lds[j * 256 + t] = in[j * 256 + t];
     __syncthreads();
     hc_s_pass_fwd<true>(lds, w, line, u, Q);
     hc_s_tw_load_inv<true>(w, TPinv, grow, u);
-    const HcTw *__restrict__ ev = B.evkP + (size_t)k * 65536;                    // lo-local coalesced order: natural (R, C = tid*16 + lo) -> ((R>>4)*16 + lo)*256 + (R&15)*16 + tid
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int p = j * 256 + t, R = HC_TILE * 4 + (p >> 8), C = p & 255;
@@ -1127,19 +1221,32 @@ __global__ __launch_bounds__(HC_STPB) void hc_k_sb5(HcLoopB B, HcTwTab T0fwd, Hc
     u64 *__restrict__ o = (outs.p[z] != nullptr ? const_cast<u64 *>(outs.p[z]) + (size_t)k * 65536 : B.dst + (size_t)z * B.dst_stride + ((size_t)i * 2 + k) * 65536) + tile;
     const u64 *__restrict__ bias = (k == 0 && biases.p[z] != nullptr) ? biases.p[z] + tile : nullptr;
     HcTw w[12]; hc_s_tw_load_fwd<true>(w, T0fwd, grow, u);
+#if HC_S_REG_PASSES
+    u64 e[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) e[j] = in[line * 256 + j * 64 + u];
+    hc_s_pass_fwd_reg(e, w, Q);                                                                    // e[j] = n_k at (line, 4 u + j): the epilogue below is elementwise, any thread may hold any position
+#else
 #pragma unroll
     for (int j = 0; j < 4; j++) lds[j * 256 + t] = in[j * 256 + t];
     __syncthreads();
     hc_s_pass_fwd<true>(lds, w, line, u, Q);
+#endif
     u64 t1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
+#if HC_S_REG_PASSES
+        const int p = line * 256 + u * 4 + j;
+        const u64 nraw = e[j];
+#else
         const int p = j * 256 + t;
+        const u64 nraw = lds[p];
+#endif
         const HcTw I = idx[p], K = evk[p];
         const u64 y1 = ys[65536 + p], x1 = xs[65536 + p];
         const u64 T = hc_fold(y1 + Q.q4 - hc_shoup4(x1, I.w, I.ws, Q), Q.nq4);                    // t2.c1, the expression of hc_k_sb1 / hc_k_b1
         const u64 g = hc_canon4(hc_shoup4(T, K.w, K.ws, Q), Q);                                   // (key row / P) * t2.c1
-        const u64 n = hc_canon8(lds[p], Q);
+        const u64 n = hc_canon8(nraw, Q);
         u64 f;
         if (k == 0) {
             const u64 y0 = ys[p], m = hc_canon4(hc_shoup4(xs[p], I.w, I.ws, Q), Q);
@@ -1155,7 +1262,11 @@ __global__ __launch_bounds__(HC_STPB) void hc_k_sb5(HcLoopB B, HcTwTab T0fwd, Hc
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; j++) {
+#if HC_S_REG_PASSES
+        const int p = line * 256 + u * 4 + j;
+#else
         const int p = j * 256 + t;
+#endif
         const u32 srcidx = hc_perm_src((u32)(HC_TILE * 1024 + p), B.gal);
         o[p] = hc_addmod(t1[j], lds[srcidx & 1023], Q.q);                                          // row-local permutation: the source is in this 4-row tile
     }
