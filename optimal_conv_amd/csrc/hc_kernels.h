@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(HC_STPB) void hc_k_sb5(HcLoopB B, HcTwTab T0fwd, Hc
 #if HC_S_REG_PASSES
     u64 e[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) e[j] = in[line * 256 + j * 64 + u];
+    for (int j = 0; j < 4; j++) e[j] = hc_reduce64(in[line * 256 + j * 64 + u], B.m0.mu, Q);       // canonical whatever produced it: the full-tile b4 hands over in its free-running lazy range (option "s_mask")
     hc_s_pass_fwd_reg(e, w, Q);                                                                    // e[j] = n_k at (line, 4 u + j): the epilogue below is elementwise, any thread may hold any position
 #else
 #pragma unroll

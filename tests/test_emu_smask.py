@@ -1,11 +1,11 @@
-"""CPU check (kernel emulator) of the experimental option "s_mask": any mix of quarter-tile and full-tile kernels over the stages of a tree level gives the same bits (bit 4 needs bit 3: the full-tile b4 hands over in its free-running lazy range, which only b5m accepts)."""
+"""CPU check (kernel emulator) of the experimental option "s_mask": any mix of quarter-tile and full-tile kernels over the stages of a tree level gives the same bits."""
 import pytest
 
 import parity_cases as pc
 from test_emu_parity import env  # noqa: F401  (fixture)
 
 
-@pytest.mark.parametrize("mask", [31, 5, 10, 24])
+@pytest.mark.parametrize("mask", [31, 5, 10, 17])
 def test_conv_then_pack_with_quarter_tile_stages_on_big_levels(env, mask):
     ctx, O = env
     ctx.set_option("small_levels", 0)
