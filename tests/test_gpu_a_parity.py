@@ -313,11 +313,11 @@ def test_strconv_tail_sparse_on_gpu(log_sparse, in_wid):
     pc.case_strconv_tail_sparse(lambda Q, P: Context(Q, P), log_sparse, in_wid)
 
 
-@pytest.mark.parametrize("depth", [8] + ([20] if os.environ.get("HCONV_TEST_DEPTH20") else []))
+@pytest.mark.parametrize("depth", [20] + ([8] if os.environ.get("HCONV_TEST_DEPTH8") else []))
 def test_resnet_network_on_gpu(depth):
     """scope row 8f-3 as a whole: `resnet 3 <depth> 1 n false` (testResNet_crop_sparse, test.go:76-370) with every layer's ring work on the device ABI, against the
-    oracle network: the ciphertext after EVERY conv-BN-ReLU layer bit-identical, and the same class scores. Depth 8 has every layer geometry of depth 20 (three
-    block widths, both stride layers, log_sparse 1..4) in 7 layers; HCONV_TEST_DEPTH20=1 adds the 19-layer network the reference's Table 3 is quoted on"""
+    oracle network: the ciphertext after EVERY conv-BN-ReLU layer bit-identical, and the same class scores. Depth 20 (19 layers, ~2.5 min on MI355X) is BASELINE.md's
+    config 5; HCONV_TEST_DEPTH8=1 adds the 7-layer network (every layer geometry of depth 20 once: three block widths, both stride layers, log_sparse 1..4)"""
     from optimal_conv_amd import Context
     print("scores", pc.case_resnet_network(lambda Q, P: Context(Q, P), depth))
 
