@@ -320,7 +320,21 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
     hc_ctx *c = new hc_ctx();
     c->device = device; c->nq = nq; c->np = np;
     { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa ? (atoi(aa) == 2 ? 2 : (atoi(aa) ? 1 : 0)) : 0; }
-    if (hipSetDevice(device) != hipSuccess || (c->async_alloc ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipStreamCreate(&c->stream)) != hipSuccess) { delete c; return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: cannot create stream on device %d", device); }
+    // experiment (HCONV_CU_SPLIT=k or -k, measured in profiles/round3_lanes.txt): the i-th context of the process runs on the i mod k-th part of the CUs only - k > 0: whole XCDs
+    // (CU-mask bit b is CU b / 8 of XCD b mod 8), k < 0: every XCD, a 1/|k| share of its CUs - so that kernels of different contexts never share a CU
+    static int ctx_counter = 0;
+    const int cu_split = getenv("HCONV_CU_SPLIT") ? atoi(getenv("HCONV_CU_SPLIT")) : 0;
+    hipError_t se = hipSetDevice(device);
+#ifndef HC_EMU
+    if (se == hipSuccess && (cu_split > 1 || cu_split < -1)) {
+        const int k = cu_split > 0 ? cu_split : -cu_split, part = ctx_counter++ % k;
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < 256; b++) { const int xcd = b & 7, cu = b >> 3; const bool on = cu_split > 0 ? (xcd * k / 8 == part) : (cu % k == part); if (on) mask[b >> 5] |= 1u << (b & 31); }
+        se = hipExtStreamCreateWithCUMask(&c->stream, 8, mask);
+    } else
+#endif
+    if (se == hipSuccess) se = c->async_alloc ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipStreamCreate(&c->stream);
+    if (se != hipSuccess) { delete c; return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: cannot create stream on device %d", device); }
     hipEventCreate(&c->t0); hipEventCreate(&c->t1);
     c->mods.resize((size_t)(nq + np));
     for (int i = 0; i < nq + np; i++) {
