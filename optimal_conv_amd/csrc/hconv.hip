@@ -117,9 +117,6 @@ struct hc_ctx {
                                   // bench.py's process with four contexts - the runtime maps all streams of a process onto 4 hardware queues, lanes that share a queue run one
                                   // after the other, and kernels of different queues slow each other down (two 32-node b5m side by side: 134 + 141 us against 2 x 45 alone); 4 lanes
                                   // 2.9 ms. So lanes stay an option.
-    long mv_split = 0;            // experiment: k in 1..31 gives the memory-bound kernels of a batched convolution k/32 of every XCD's CUs and the VALU-bound ones the rest, on two CU-masked
-                                  // streams chained by events (hc_conv_batch_mvsplit); measured in profiles/round3_lanes.txt
-    hipStream_t mv_stream[2] = {nullptr, nullptr}; long mv_made = 0; std::vector<hipEvent_t> mv_ev; size_t mv_next = 0;
     long s_mask = 0;              // experiment: stages of the BIG tree levels that run on the quarter-tile kernels (bit i = stage i + 1); measured in profiles/round3_lanes.txt
     long lane_priority = 0;       // 1: the lanes' streams get descending priorities (lane 0 highest), so the lanes run staggered: a lane's small, latency-bound tree levels fill with the next lane's big ones
     std::vector<HcLane> lane;
@@ -323,19 +320,7 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
     hc_ctx *c = new hc_ctx();
     c->device = device; c->nq = nq; c->np = np;
     { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa ? (atoi(aa) == 2 ? 2 : (atoi(aa) ? 1 : 0)) : 0; }
-    // experiment (HCONV_CU_SPLIT=k or -k, measured in profiles/round3_lanes.txt): the i-th context of the process runs on the i mod k-th part of the CUs only - k > 0: whole XCDs
-    // (CU-mask bit b is CU b / 8 of XCD b mod 8), k < 0: every XCD, a 1/|k| share of its CUs - so that kernels of different contexts never share a CU
-    static int ctx_counter = 0;
-    const int cu_split = getenv("HCONV_CU_SPLIT") ? atoi(getenv("HCONV_CU_SPLIT")) : 0;
     hipError_t se = hipSetDevice(device);
-#ifndef HC_EMU
-    if (se == hipSuccess && (cu_split > 1 || cu_split < -1)) {
-        const int k = cu_split > 0 ? cu_split : -cu_split, part = ctx_counter++ % k;
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int b = 0; b < 256; b++) { const int xcd = b & 7, cu = b >> 3; const bool on = cu_split > 0 ? (xcd * k / 8 == part) : (cu % k == part); if (on) mask[b >> 5] |= 1u << (b & 31); }
-        se = hipExtStreamCreateWithCUMask(&c->stream, 8, mask);
-    } else
-#endif
     if (se == hipSuccess) se = c->async_alloc ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipStreamCreate(&c->stream);
     if (se != hipSuccess) { delete c; return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: cannot create stream on device %d", device); }
     hipEventCreate(&c->t0); hipEventCreate(&c->t1);
@@ -388,8 +373,6 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     for (auto &kv : c->evk) { F(kv.second.q_rows); F(kv.second.p_rows); }
     for (auto &kv : c->swk) F(kv.second.rows);
     F(c->idx_pairs); F(c->ws_cts); F(c->ws_cts2); F(c->ws_gather);
-    for (int i = 0; i < 2; i++) if (c->mv_stream[i]) { D(hipStreamSynchronize(c->mv_stream[i]), "hipStreamSynchronize"); D(hipStreamDestroy(c->mv_stream[i]), "hipStreamDestroy"); }
-    for (hipEvent_t e : c->mv_ev) D(hipEventDestroy(e), "hipEventDestroy");
     if (c->ev_fork) D(hipEventDestroy(c->ev_fork), "hipEventDestroy");
     if (c->ev_shard) D(hipEventDestroy(c->ev_shard), "hipEventDestroy");
     for (auto &L : c->lane) {
@@ -1487,52 +1470,6 @@ static int hc_conv_batch_antiphase(hc_ctx *c, int n, const HcPtrs &ct_in, const 
     HC_HIP(c, hipStreamWaitEvent(c->stream, L0.done, 0)); HC_HIP(c, hipStreamWaitEvent(c->stream, L1.done, 0));
     return HC_OK;
 }
-// Experiment (option "mv_split" = k): a batched convolution with its memory-bound kernels ('M': a1, a3, b1, b5, copies) on k/32 of the CUs of every XCD and its VALU-bound kernels ('V':
-// a2, b2, b3, b4) on the rest - two CU-masked streams, the recorded launch sequence issued in order with an event wherever the kind changes. With several contexts in flight the
-// two partitions are both busy: kernels of the two kinds run side by side WITHOUT sharing a CU (what co-scheduling on shared CUs could not do: profiles/round3_antiphase_trace.txt).
-static int hc_conv_batch_mvsplit(hc_ctx *c, int n, const HcPtrs &ct_in, const HcPtrs &kers, const HcPtrs &bias, bool any_bias, u64 *const *ct_out, int max_ob, int norm, const u64 cst[2]) {
-#ifdef HC_EMU
-    return hc_conv_batch_run(c, n, ct_in, kers, bias, any_bias, ct_out, max_ob, norm, cst);
-#else
-    if (c->mv_made != c->mv_split) {
-        for (int i = 0; i < 2; i++) if (c->mv_stream[i]) { HC_HIP(c, hipStreamSynchronize(c->mv_stream[i])); HC_HIP(c, hipStreamDestroy(c->mv_stream[i])); c->mv_stream[i] = nullptr; }
-        for (int i = 0; i < 2; i++) {
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int b = 0; b < 256; b++) { const bool m_side = (b >> 3) < (int)c->mv_split; if (m_side == (i == 0)) mask[b >> 5] |= 1u << (b & 31); }     // bit b: CU b / 8 of its 8-way group (probed: HCONV_CU_SPLIT)
-            HC_HIP(c, hipExtStreamCreateWithCUMask(&c->mv_stream[i], 8, mask));
-        }
-        c->mv_made = c->mv_split;
-    }
-    if (!c->ev_fork) HC_HIP(c, hipEventCreate(&c->ev_fork));
-    std::vector<HcOp> ops;
-    for (int attempt = 0;; attempt++) {           // as hc_conv_lanes: a workspace that grows during the recording invalidates it
-        const u64 *tmp0 = c->ws_tmp, *cts0 = c->ws_cts, *cts20 = c->ws_cts2, *ctc0 = (const u64 *)c->ws_ctc; const size_t r0 = c->ws_tmp_rows, r1 = c->ws_cts2_rows;
-        ops.clear(); c->rec = &ops;
-        const int rc = hc_conv_batch_run(c, n, ct_in, kers, bias, any_bias, ct_out, max_ob, norm, cst);
-        c->rec = nullptr;
-        if (rc) return rc;
-        if (c->ws_tmp == tmp0 && c->ws_cts == cts0 && c->ws_cts2 == cts20 && (const u64 *)c->ws_ctc == ctc0 && c->ws_tmp_rows == r0 && c->ws_cts2_rows == r1) break;
-        if (attempt == 3) return hc_fail(c, HC_ERR_STATE, "hc_conv_batch_mvsplit: the workspaces keep growing");
-    }
-    auto next_event = [&](hipEvent_t *e) -> hipError_t {
-        if (c->mv_ev.size() < 512) { hipEvent_t ev; hipError_t r = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (r != hipSuccess) return r; c->mv_ev.push_back(ev); *e = ev; return hipSuccess; }
-        *e = c->mv_ev[c->mv_next]; c->mv_next = (c->mv_next + 1) % c->mv_ev.size(); return hipSuccess;
-    };
-    HC_HIP(c, hipEventRecord(c->ev_fork, c->stream));
-    int cur = -1;
-    for (auto &op : ops) {
-        const int tgt = op.kind == 'V' ? 1 : 0;
-        if (tgt != cur) {
-            if (cur < 0) HC_HIP(c, hipStreamWaitEvent(c->mv_stream[tgt], c->ev_fork, 0));
-            else { hipEvent_t e; HC_HIP(c, next_event(&e)); HC_HIP(c, hipEventRecord(e, c->mv_stream[cur])); HC_HIP(c, hipStreamWaitEvent(c->mv_stream[tgt], e, 0)); }
-            cur = tgt;
-        }
-        HC_HIP(c, op.run(c->mv_stream[tgt]));
-    }
-    if (cur >= 0) { hipEvent_t e; HC_HIP(c, next_event(&e)); HC_HIP(c, hipEventRecord(e, c->mv_stream[cur])); HC_HIP(c, hipStreamWaitEvent(c->stream, e, 0)); }
-    return HC_OK;
-#endif
-}
 // lanes for ONE convolution (option "lanes"); only dense packing (norm 1) splits into lanes, and the per-kernel profile keeps one stream
 static int hc_lanes_for(const hc_ctx *c, int max_ob, int norm) {
     const int G = c->lanes > 1 && !c->profile ? (int)c->lanes : 1;
@@ -1578,7 +1515,6 @@ extern "C" int hc_conv_then_pack_batch(hc_ctx *c, int n, const uint64_t *const *
         HC_TRY(hc_prepare_ctc(c, pin, 1, cst));
         HC_TRY(hc_conv_lanes(c, ker[0], max_ob, hc_lanes_for(c, max_ob, norm), pbias.p[0], outs[0]));
     }
-    else if (c->mv_split > 0 && !c->profile) HC_TRY(hc_conv_batch_mvsplit(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
     else if (n >= 2 && c->antiphase && !c->profile) HC_TRY(hc_conv_batch_antiphase(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
     else HC_TRY(hc_conv_batch_run(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
     if (scale_out) *scale_out = final_scale;
@@ -1701,7 +1637,6 @@ extern "C" int hc_bl_post_ker_slots(hc_ctx *c, const double *max_ker_rs, int in_
 extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!c || !name) return HC_ERR_ARG;
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
-    if (!strcmp(name, "mv_split")) { if (value < 0 || value > 31) return hc_fail(c, HC_ERR_ARG, "mv_split is 0 (off) or the memory-bound kernels' share of the CUs in 32nds (1..31)"); c->mv_split = value; return HC_OK; }
     if (!strcmp(name, "s_mask")) { if (value < 0 || value > 31) return hc_fail(c, HC_ERR_ARG, "s_mask is a 5-bit mask"); c->s_mask = value; return HC_OK; }
     if (!strcmp(name, "lane_priority")) { if (!c->lane.empty()) return hc_fail(c, HC_ERR_STATE, "lane_priority must be set before the first convolution on lanes"); c->lane_priority = value != 0; return HC_OK; }
     if (!strcmp(name, "lanes")) { if (value == 0) value = 1; if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
