@@ -221,7 +221,8 @@ int hc_bl_post_ker_slots(hc_ctx *ctx, const double *max_ker_rs, int in_wid, int 
 
 /* ---- tuning / measurement ---- */
 int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes", "lanes" (streams ONE convolution is split over: a power of two, default 1 = none; measured: a gain only while the
-                                                                  process has few streams, see hconv.hip; "lane_priority" 1 gives them descending stream priorities), "small_levels", "profile", "ks_fused", "b5_merged" (A/B switch of the per-node b5 kernel),
+                                                                  process has few streams, see hconv.hip; "lane_priority" 1 gives them descending stream priorities), "small_levels" (tree levels of at most
+                                                                  this many nodes x ciphertexts run on the quarter-tile kernels: default 16, 0 = never), "s_mask" (experiment: those kernels per stage on the big levels too), "profile", "ks_fused", "b5_merged" (A/B switch of the per-node b5 kernel),
                                                                   "antiphase" (two half-batches one phase apart; measured no gain, default 0), "peer_access" (hc_conv_then_pack_sharded:
                                                                   0 = do not enable direct peer copies; default 1: enabled where hipDeviceCanAccessPeer allows, a failure to enable is an error) */
 /* HIP-event timing on the context's stream */
