@@ -712,7 +712,7 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b3(HcLoopB B, HcTwT
 }
 // KB4: cols-inverse mod P, exact basis extension P -> Q0 (ring.modUpExact, one P prime), cols-forward mod Q0.
 // grid = (2*batch*nodes, 16), in place on tmpE
-template <int FM, int SPLIT = 0>
+template <int FM>
 __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTwTab T0fwd) {
     __shared__ u64 lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
@@ -732,14 +732,6 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTw
         u64 r = hc_shoup4(yv, B.pinv.w, B.pinv.ws, Q);
         if (yv >= B.vthresh) r += Q.q - 1;
         e[hi] = r;
-    }
-    if (SPLIT) {
-        // round 3: only the FIRST radix-16 round of the cols-forward pass (row distances 128..16) runs here; the second (row distances 8..1, inside an aligned group of 16 rows =
-        // one rows tile, twiddles uniform per tile) is the first thing hc_k_b5m does on the tile it loads. This kernel is bound by the vector ALU, b5m by memory.
-        hc_ct_round<FM>(e, HcRowsTwA{T0fwd.colsA}, Q);
-#pragma unroll
-        for (int hi = 0; hi < 16; hi++) base[(size_t)(hi * 16 + tid) * 256] = e[hi];
-        return;
     }
     __syncthreads();
     hc_cols_fwd<FM>(e, lds, T0fwd, c, tid, Q);
@@ -877,7 +869,7 @@ __global__ __launch_bounds__(HC_TPB, ROWLOCAL ? 5 : 3) void hc_k_b5(HcLoopB B, H
 #ifndef HC_B5M_WAVES
 #define HC_B5M_WAVES 3
 #endif
-template <int FM, int SPLIT = 0>
+template <int FM>
 __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTwTab T0fwd, HcPtrs biases, HcPtrs outs) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
@@ -895,25 +887,9 @@ __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTw
 #pragma unroll HC_B5M_UNROLL
     for (int k = 1; k >= 0; k--) {
         const u64 *__restrict__ in = B.tmpE + ((size_t)zn * 2 + k) * 65536 + (size_t)row * 256;
-        if (SPLIT) {
-            // hc_k_b4<FM, 1> stopped after the first round of the cols-forward pass: its second round (row distances 8, 4, 2, 1: inside this tile's 16 rows, twiddles
-            // colsB[slot][tile] - uniform over the workgroup) runs here, on the tile loaded in linear order (thread t = column t of the 16 rows), then the rows pass
-            const u64 *__restrict__ lin = B.tmpE + ((size_t)zn * 2 + k) * 65536 + (size_t)HC_TILE * 4096 + t;
 #pragma unroll
-            for (int kk = 0; kk < 16; kk++) e[kk] = lin[kk * 256];
-            hc_ct_round<FM>(e, HcRowsTwB{T0fwd.colsB + HC_TILE}, Q);
-            if (k == 0) __syncthreads();                  // the last gather of k = 1 is done before LDS is written again
-#pragma unroll
-            for (int kk = 0; kk < 16; kk++) lds[hc_rows_lds(kk, t)] = e[kk];
-            __syncthreads();
-#pragma unroll
-            for (int hi = 0; hi < 16; hi++) e[hi] = lds[hc_rows_lds(rloc, hi * 16 + tid)];
-            HC_ROW_SYNC();                                // row-local: the reads above and the pass's writes below stay inside the 16 lanes of a row
-        } else {
-#pragma unroll
-            for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
-            if (k == 0) __syncthreads();                  // the last gather of k = 1 is done before the transform writes LDS again
-        }
+        for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
+        if (k == 0) __syncthreads();                      // the last gather of k = 1 is done before the transform writes LDS again
         hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, Q);
         HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
         hc_rows_lo_to_lin(e, lds, t, rloc, tid);          // e[kk] = n_k at (row kk, column t)

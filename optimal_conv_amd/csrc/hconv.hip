@@ -117,7 +117,6 @@ struct hc_ctx {
                                   // bench.py's process with four contexts - the runtime maps all streams of a process onto 4 hardware queues, lanes that share a queue run one
                                   // after the other, and kernels of different queues slow each other down (two 32-node b5m side by side: 134 + 141 us against 2 x 45 alone); 4 lanes
                                   // 2.9 ms. So lanes stay an option.
-    long b4_split = 1;            // the last round of b4's cols-forward pass inside b5m (hc_kernels.h: hc_k_b4<FM, 1>, hc_k_b5m<FM, 1>); 0 = the 8 + 8 split of rounds 1-2
     long s_mask = 0;              // experiment: stages of the BIG tree levels that run on the quarter-tile kernels (bit i = stage i + 1); measured in profiles/round3_lanes.txt
     long lane_priority = 0;       // 1: the lanes' streams get descending priorities (lane 0 highest), so the lanes run staggered: a lane's small, latency-bound tree levels fill with the next lane's big ones
     std::vector<HcLane> lane;
@@ -948,14 +947,10 @@ static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, size_t sstride, si
         else HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b2_colsinv_colsfwdP", hc_k_b2, g1, B, m0.inv, mp.fwd));
         if (sm & 4) HC_TRY(hc_launch<HC_STPB>(c, "b3_rowsfwdP_mac_rowsinvP", hc_k_sb3, s3, B, mp.fwd, mp.inv));
         else HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, g1, B, mp.fwd, mp.inv));
-        // round 3: with the merged b5 the last radix-16 round of b4's cols-forward pass runs inside b5m (b4 is bound by the vector ALU, b5m by memory; option "b4_split", default 1)
-        const bool split = c->b4_split && it->second.row256 && c->b5_merged && !(sm & 24);
         if (sm & 8) HC_TRY(hc_launch<HC_STPB>(c, "b4_colsinvP_modup_colsfwd", hc_k_sb4, s2, B, mp.inv, m0.fwd));
-        else if (split) HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "b4_colsinvP_modup_colsfwd", hc_k_b4<HC_FM_FREE, 1>, g2, B, mp.inv, m0.fwd) : hc_launch(c, "b4_colsinvP_modup_colsfwd", hc_k_b4<HC_FM_ALT, 1>, g2, B, mp.inv, m0.fwd));
         else HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, g2, B, mp.inv, m0.fwd));
         const HcPtrs pb = bias_last ? *bias_last : nobias, po = outs_last ? *outs_last : nobias;
         if (sm & 16) HC_TRY(hc_launch<HC_STPB>(c, "b5_rowsfwd_moddown_perm_add", hc_k_sb5, s2, B, m0.fwd, pb, po));
-        else if (split) HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5m<HC_FM_FREE, 1>, g1, B, m0.fwd, pb, po) : hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5m<HC_FM_ALT, 1>, g1, B, m0.fwd, pb, po));
         else if (it->second.row256 && c->b5_merged) HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5m, g1, B, m0.fwd, pb, po));
         else if (it->second.row256) HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_FREE, 1>, g2, B, m0.fwd, pb, po) : hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_ALT, 1>, g2, B, m0.fwd, pb, po));
         else HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_FREE, 0>, g2, B, m0.fwd, pb, po) : hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_ALT, 0>, g2, B, m0.fwd, pb, po));
@@ -1642,7 +1637,6 @@ extern "C" int hc_bl_post_ker_slots(hc_ctx *c, const double *max_ker_rs, int in_
 extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!c || !name) return HC_ERR_ARG;
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
-    if (!strcmp(name, "b4_split")) { c->b4_split = value != 0; return HC_OK; }
     if (!strcmp(name, "s_mask")) { if (value < 0 || value > 31) return hc_fail(c, HC_ERR_ARG, "s_mask is a 5-bit mask"); c->s_mask = value; return HC_OK; }
     if (!strcmp(name, "lane_priority")) { if (!c->lane.empty()) return hc_fail(c, HC_ERR_STATE, "lane_priority must be set before the first convolution on lanes"); c->lane_priority = value != 0; return HC_OK; }
     if (!strcmp(name, "lanes")) { if (value == 0) value = 1; if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
