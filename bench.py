@@ -87,9 +87,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="ciphertexts per hc_conv_then_pack_batch call (one launch set covers them all); 4 x 4 contexts measured best (8 x 2: -4.5 %, 8 x 3: -1 %)")
     ap.add_argument("--streams", type=int, default=4, help="contexts (HIP streams) per GPU, each with its own batch of resident ciphertexts")
     ap.add_argument("--batch-alt", type=int, default=0, help="experiment: odd-numbered contexts use this batch size instead (desynchronises the streams)")
-    ap.add_argument("--lanes", type=int, default=1, help="internal lanes of ONE convolution (channels i mod G on their own streams; affects single_conv_ms only: batches of >= 2 ciphertexts do not use lanes)")
-    ap.add_argument("--antiphase", type=int, default=0, help="two half-batches per context one phase apart (memory-bound kernels of one beside VALU-bound kernels of the other); 0 = one launch set per batch")
-    ap.add_argument("--opt", action="append", default=[], help="extra context option name=value (hc_set_option), e.g. b5_merged=0; experiments")
+    ap.add_argument("--opt", action="append", default=[], help="extra context option name=value (hc_set_option), e.g. small_levels=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -130,8 +128,6 @@ def main():
     for s_ in range(S):
         ctx = Context([Q0, Q1], [P0], device=device)            # raises if no GPU / no libhconv.so
         ctx.set_option("chunk_nodes", args.chunk)
-        ctx.set_option("lanes", args.lanes)
-        ctx.set_option("antiphase", args.antiphase)
         for kv in args.opt:
             ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         for gal, k4 in keys:
@@ -199,11 +195,12 @@ def main():
 
     # ONE convolution alone on an otherwise idle GPU (what the `conv` CLI does): latency, not throughput
     L0["ctx"].sync()
-    t1 = time.perf_counter()
-    for _ in range(10):
+    lone = []
+    for _ in range(10):       # HIP events around each lone convolution, the stream drained in between: a latency, nothing pipelines
+        ctx.timer_start()
         ctx.conv_then_pack_batch_dev(L0["in"][:1], 2.0 ** 30, L0["ker"][:1], 2.0 ** 30, B, 1, 2.0 ** 30, [L0["bias"]], L0["out"][:1])
-    L0["ctx"].sync()
-    single_ms = (time.perf_counter() - t1) / 10 * 1e3
+        lone.append(ctx.timer_stop())
+    single_ms = float(np.median(lone))
 
     if rank == 0:
         per_step = sum(len(L["in"]) for L in lanes)
@@ -228,7 +225,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"conv {args.ker_wid} {args.i_batch}", "ker_wid": args.ker_wid, "batch": B, "in_wid": W,
                        "logN": 16, "moduli": "ckks.DefaultBootstrapParams[6] Q0,Q1 + P=0x1fffffffffe00001",
-                       "convs_per_step_per_gpu": per_step, "ciphertexts_per_launch_set": NB, "contexts_per_gpu": S, "chunk_nodes": args.chunk, "lanes_per_conv": args.lanes},
+                       "convs_per_step_per_gpu": per_step, "ciphertexts_per_launch_set": NB, "contexts_per_gpu": S, "chunk_nodes": args.chunk},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_measured_with": traffic_how,
                          "unit_of_launch": "one conv_then_pack (its share of the batched launch set: all kernels of loop A and of the pack tree)",

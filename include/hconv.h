@@ -143,7 +143,7 @@ int hc_keyswitch_decompose(hc_ctx *ctx, int level, const uint64_t *cx);
  *                   the decomposition hc_keyswitch_decompose(level, cx) left): acc[2][level+1+np][N], canonical residues, NTT domain.
  *  hc_mod_down2     ring.(*FastBasisExtender).ModDownSplitNTTPQ (@4e4c40) on the two polynomials x[2][level+1+np][N] -> out0, out1 [level+1][N].
  *                   hc_keyswitch == hc_keyswitch_qp followed by hc_mod_down2, bit for bit. A decomposition held by hc_keyswitch_decompose
- *                   survives hc_mod_down2 / hc_keyswitch_qp(hoisted = 0) only at the SAME level; a call at another level drops it.
+ *                   survives hc_mod_down2 at the SAME level only (another level drops it); hc_keyswitch_qp(hoisted = 0) always re-decomposes and drops it.
  *  hc_qp_op2        out_k = a_k (op) b_k for k = 0, 1 over all level+1+np rows; op = HC_LV_MUL, HC_LV_ADD or HC_LV_MUL_ACC (out_k += a_k * b_k);
  *                   b1 == b0 for a plaintext operand. (hc_permute works on any rows, so it permutes QP polynomials as they are.) */
 int hc_keyswitch_qp(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *acc, int hoisted);
@@ -220,11 +220,9 @@ int hc_bl_post_ker_slots(hc_ctx *ctx, const double *max_ker_rs, int in_wid, int 
                          double *values_out);
 
 /* ---- tuning / measurement ---- */
-int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes", "lanes" (streams ONE convolution is split over: a power of two, default 1 = none; measured: a gain only while the
-                                                                  process has few streams, see hconv.hip; "lane_priority" 1 gives them descending stream priorities), "small_levels" (tree levels of at most
-                                                                  this many nodes x ciphertexts run on the quarter-tile kernels: default 16, 0 = never), "s_mask" (experiment: those kernels per stage on the big levels too), "profile", "ks_fused", "b5_merged" (A/B switch of the per-node b5 kernel),
-                                                                  "antiphase" (two half-batches one phase apart; measured no gain, default 0), "peer_access" (hc_conv_then_pack_sharded:
-                                                                  0 = do not enable direct peer copies; default 1: enabled where hipDeviceCanAccessPeer allows, a failure to enable is an error) */
+int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes" (jobs - channels / tree nodes summed over the batch - per kernel launch), "small_levels" (tree levels of at most
+                                                                  this many nodes x ciphertexts run on the quarter-tile kernels: default 16, 0 = never), "profile" (per-kernel HIP-event totals),
+                                                                  "peer_access" (hc_conv_then_pack_sharded: 0 = do not enable direct peer copies; default 1: enabled where hipDeviceCanAccessPeer allows) */
 /* HIP-event timing on the context's stream */
 int hc_timer_start(hc_ctx *ctx);
 int hc_timer_stop(hc_ctx *ctx, float *ms);

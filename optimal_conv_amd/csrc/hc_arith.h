@@ -103,31 +103,9 @@ HC_HD HcQ hc_q(u64 q) {
     HcQ Q; Q.q = q; Q.nq = hc_opaque_uniform(0 - q); Q.q4 = 4 * q; Q.nq4 = hc_opaque_uniform(0 - 4 * q); Q.nq2 = hc_opaque_uniform(0 - 2 * q);
     return Q;
 }
-#ifndef HC_MADCHAIN
-#define HC_MADCHAIN 0
-#endif
-// Round 3 experiment, OFF (measured slower): the low 64 bits of x*w + hi*nq as ONE chain of v_mad_u64_u32. The compiler narrows the four cross products (x0 w1, x1 w0,
-// h0 n1, h1 n0: only their low 32 bits count) to v_mul_lo_u32 + v_add3_u32 - six instructions; kept 64 bits wide by an empty asm after each step they become four
-// multiply-adds whose sum is shifted in by one v_lshl_add_u64: 11 four-cycle instructions per product instead of 13. But every chained multiply-add needs its 64-bit
-// addend in an aligned register pair: +2 v_mov_b32 and +1.5 s_nop per product, more live registers (b3: 128 VGPRs and 12 bytes of scratch). Same box, back to back:
-// 742 / 745 conv/s with the chain against 763 / 763 without (b3 0.221 vs 0.197 ms per conv, b5m 0.328 vs 0.309). Same value modulo 2^64 either way.
-HC_HD u64 hc_opaque64(u64 v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("" : "+v"(v));
-#endif
-    return v;
-}
-HC_HD u64 hc_shoup4(u64 x, u64 w, u64 wp, const HcQ &Q) {
-#if defined(__HIP_DEVICE_COMPILE__) && HC_MADCHAIN
-    const u64 hi = hc_mulhi_lo2(x, wp);
-    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), w0 = (u32)w, w1 = (u32)(w >> 32), h0 = (u32)hi, h1 = (u32)(hi >> 32), n0 = (u32)Q.nq, n1 = (u32)(Q.nq >> 32);
-    u64 t = (u64)x0 * w0; t = (u64)h0 * n0 + t;
-    u64 c = hc_opaque64((u64)x0 * w1); c = hc_opaque64((u64)x1 * w0 + c); c = hc_opaque64((u64)h0 * n1 + c); c = hc_opaque64((u64)h1 * n0 + c);
-    return t + (c << 32);
-#else
-    return x * w + hc_mulhi_lo2(x, wp) * Q.nq;
-#endif
-}
+// (Measured in round 3 and not kept: the cross terms as a chain of four v_mad_u64_u32 - 11 four-cycle instructions instead of 13, but aligned 64-bit addends cost
+// moves, s_nops and registers: 742-745 conv/s against 763. profiles/round3_lanes.txt.)
+HC_HD u64 hc_shoup4(u64 x, u64 w, u64 wp, const HcQ &Q) { return x * w + hc_mulhi_lo2(x, wp) * Q.nq; }
 // x < 2b with b <= 2^63 and nb = 2^64 - b: x - b if that is non-negative, else x (one 64-bit add, a sign test on the high word,
 // two selects: no carry chain). Result < b.
 HC_HD u64 hc_fold(u64 x, u64 nb) { const u64 t = x + nb; return (int)(u32)(t >> 32) < 0 ? x : t; }

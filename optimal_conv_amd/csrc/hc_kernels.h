@@ -748,15 +748,9 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTw
 // canonical; ALT mode has no such headroom and works on canonical terms.
 // Requires the permutation to stay inside the workgroup's 16-row tile (4096 consecutive coefficients): galEl = 2^j+1, j >= 5
 // (j >= 9 even stays inside one 256-coefficient row; j = 7, 8 are what the resnet's 8x8 layers, max_cnum 1024, add).
-// ROWLOCAL = 1 (galEl = 2^j + 1 with j >= 9: every pack tree up to 256 channels): the permutation stays inside a 256-coefficient row, so
-// the epilogue runs in batches of HC_B5_ROWS rows -- operands loaded, t1 and d formed, d through that row of LDS, gathered, stored -- and
-// nothing but the transform's 16 residues lives across the transform: <= 96 VGPRs, five workgroups per CU (round 2 held t1 and F, 64
-// VGPRs, across the transform: 138 VGPRs, three per CU, and its load / transform / store phases did not overlap).
-// ROWLOCAL = 0 (j = 5..8, the 1024-channel trees of the resnet's 8x8 layers): the gather reads the whole 16-row tile, so all of d is
-// formed before it.
-#ifndef HC_B5_ROWS
-#define HC_B5_ROWS 2
-#endif
+// This kernel serves the TILE-local permutations (j = 5..8: the 1024-channel trees of the resnet's 8x8 layers) and the L0 key-switch API:
+// the gather reads the whole 16-row tile, so all of d is formed before it. Row-local permutations (j >= 9: every pack tree up to 256
+// channels) run on hc_k_b5m below.
 template <int FM, int K0>
 __device__ __forceinline__ void hc_b5_terms(u64 Y, u64 T, HcTw K, u64 X, HcTw I, const HcQ &Q, u64 &t1, u64 &f) {
     const u64 q = Q.q;
@@ -772,8 +766,8 @@ __device__ __forceinline__ void hc_b5_terms(u64 Y, u64 T, HcTw K, u64 X, HcTw I,
         f = g;
     }
 }
-template <int FM, int ROWLOCAL>
-__global__ __launch_bounds__(HC_TPB, ROWLOCAL ? 5 : 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, HcPtrs biases, HcPtrs outs) {
+template <int FM>
+__global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, HcPtrs biases, HcPtrs outs) {
     __shared__ u64 lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
     const int job = HC_JOB, zn = job >> 1, k = job & 1, z = zn / B.nodes, node = zn - z * B.nodes, i = (B.n0 + node) * B.norm;
@@ -796,37 +790,7 @@ __global__ __launch_bounds__(HC_TPB, ROWLOCAL ? 5 : 3) void hc_k_b5(HcLoopB B, H
     HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);          // e[kk] = n = NTT(ext * P^-1) at (row kk, column t)
     __syncthreads();
-    if (ROWLOCAL) {
-#pragma unroll
-        for (int b = 0; b < 16; b += HC_B5_ROWS) {
-            u64 Y[HC_B5_ROWS], T[HC_B5_ROWS], X[HC_B5_ROWS], t1[HC_B5_ROWS], bs[HC_B5_ROWS]; HcTw K[HC_B5_ROWS], I[HC_B5_ROWS];
-#pragma unroll
-            for (int j = 0; j < HC_B5_ROWS; j++) {
-                const int off = (b + j) * 256;
-                Y[j] = yk[off]; K[j] = evk[off]; T[j] = tc1[off];
-                if (k == 0) { X[j] = xk[off]; I[j] = idx[off]; } else { X[j] = 0; I[j] = K[j]; }
-                bs[j] = bias != nullptr ? bias[off] : 0;
-            }
-#pragma unroll
-            for (int j = 0; j < HC_B5_ROWS; j++) {
-                const int kk = b + j;
-                u64 f;
-                if (k == 0) hc_b5_terms<FM, 1>(Y[j], T[j], K[j], X[j], I[j], Q, t1[j], f);
-                else hc_b5_terms<FM, 0>(Y[j], T[j], K[j], X[j], I[j], Q, t1[j], f);
-                if (FM == HC_FM_FREE) { t1[j] += bs[j]; f = f + HC_FREE_OFF * q - e[kk]; }                 // d < 81q
-                else { t1[j] = hc_addmod(t1[j], bs[j], q); f = hc_submod(f, hc_canon8(e[kk], Q), q); }
-                lds[hc_rows_lds(kk, t)] = f;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < HC_B5_ROWS; j++) {
-                const int kk = b + j;
-                const u32 srcidx = hc_perm_src((u32)((HC_TILE * 16 + kk) * 256 + t), B.gal);
-                const u64 d = lds[hc_rows_lds(kk, (int)(srcidx & 255))];                                   // the source is in the same row
-                o[kk * 256] = FM == HC_FM_FREE ? hc_reduce64(t1[j] + d, B.m0.mu, Q) : hc_addmod(t1[j], d, q);
-            }
-        }
-    } else {
+    {
         u64 t1[16];
 #pragma unroll
         for (int b = 0; b < 16; b += 4) {
@@ -863,6 +827,7 @@ __global__ __launch_bounds__(HC_TPB, ROWLOCAL ? 5 : 3) void hc_k_b5(HcLoopB B, H
 // per node: 0.5 written, 2 x 0.5 read, against 0.5 more for x1), and idx is read once per node. Per row batch of either polynomial:
 //   k = 1: m1 = I*x1 ; T = y1 - m1 ; t1 = y1 + m1 ; F = (a_Q/P)*T                      k = 0: m = I*x0 ; t1 = y0 + m ; F = y0 - m + (b_Q/P)*T
 //   d = F - n_k (n_k = rows-forward of the k-th extension, divided by P by b4) ; through the LDS row ; dst = reduce(t1 + perm(d)) (+ bias, k = 0)
+#define HC_B5_ROWS 2                  // rows per epilogue batch of hc_k_b5m
 #ifndef HC_B5M_UNROLL
 #define HC_B5M_UNROLL 2
 #endif
@@ -1419,46 +1384,6 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const 
         }
         a[j] = s;
     }
-}
-// The same inner product with the digits' second transform pass inside (the plain, non-hoisted key switch): `half` holds the digits
-// after the cols pass only ([beta][nt][N], what hc_k_cols_fwd_mm wrote); a workgroup owns a 16-row tile of limb T, and for every
-// digit runs the rows pass on its tile (or, on a digit's own limbs, takes the NTT-domain input cx as it is), canonicalises, and
-// accumulates both key components in registers. The transformed digits never travel to HBM and back: per key switch that is
-// 2 * beta * nt rows of traffic less, in a chain whose key switches are bandwidth-bound.
-// grid = (16, nt)
-__global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_mac(const u64 *evk, const u64 *cx, const u64 *half, u64 *acc, const HcRowMod *M, const HcMod *mods, int nl, int nq, int nt, int alpha, int beta) {
-    __shared__ u64 lds[HC_ROWS_LDS];
-    const int T = blockIdx.y, mod = T < nl ? T : nq + (T - nl);
-    const HcRowMod &R = M[mod]; const u64 q = R.q, qinv = mods[mod].qinv; const HcQ Q = hc_q(q);
-    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
-    const size_t lin = (size_t)T * 65536 + (size_t)blockIdx.x * 4096 + t;          // + k * 256: element (tile row k, column t)
-    u64 a0[16], a1[16], e[16];
-    for (int d = 0; d < beta; d++) {
-        const int lo = d * alpha, hi = lo + alpha < nl ? lo + alpha : nl;
-        const u64 *kb = evk + ((size_t)d * 2 * nt) * 65536 + lin, *ka = kb + (size_t)nt * 65536;
-        if (T >= lo && T < hi) {                                                   // block-uniform
-#pragma unroll
-            for (int k = 0; k < 16; k++) e[k] = cx[lin + k * 256];
-        } else {
-            const u64 *in = half + ((size_t)d * nt + T) * 65536 + (size_t)row * 256;
-#pragma unroll
-            for (int h = 0; h < 16; h++) e[h] = in[h * 16 + tid];
-            if (d) __syncthreads();                                                // the previous digit's exchange is done with the LDS
-            hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, Q);
-            HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
-            hc_rows_lo_to_lin(e, lds, t, rloc, tid);
-#pragma unroll
-            for (int k = 0; k < 16; k++) e[k] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu);
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const u64 p0 = hc_mont(e[k], kb[k * 256], q, qinv), p1 = hc_mont(e[k], ka[k * 256], q, qinv);
-            a0[k] = d == 0 ? p0 : hc_addmod(a0[k], p0, q);
-            a1[k] = d == 0 ? p1 : hc_addmod(a1[k], p1, q);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) { acc[lin + k * 256] = a0[k]; acc[(size_t)nt * 65536 + lin + k * 256] = a1[k]; }
 }
 // d_k[l] = (acc[k][l] - ext[k][l]) * P^-1 mod q_l for all limbs l and both k
 __global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_mm(const u64 *acc, size_t acc_zs, const u64 *ext, size_t ext_zs, u64 *d0, u64 *d1, const HcMod *mods, const HcTw *pinv) {

@@ -12,7 +12,6 @@
 #include <stdio.h>
 #include <string.h>
 
-#include <functional>
 #include <map>
 #include <utility>
 #include <string>
@@ -72,22 +71,6 @@ struct HcModHost {
 struct HcEvk { HcTw *q_rows; HcTw *p_rows; bool row_local; bool row256; };   // row_local: the permutation stays inside 4096-coefficient tiles; row256: even inside 256-coefficient rows   // [2][N] each, Shoup pairs: q_rows (key / P mod Q0) natural order; p_rows (key / N mod P) lo-local order
 struct HcSwk { u64 *rows = nullptr; int level = 0, beta = 0; };   // general switching key: [beta][2][level+1+np][N], stored form
 struct HcProfRec { std::string name; hipEvent_t a, b; };
-// An internal lane = its own HIP stream + workspaces: one convolution is split by output channel i mod G into G
-// independent sub-trees (the decomposition sharded.py uses across GPUs) that run concurrently on one GPU.
-struct HcLane {
-    hipStream_t stream = nullptr; hipEvent_t done = nullptr;
-    u64 *tmp = nullptr; size_t tmp_rows = 0;
-    u64 *cts = nullptr; size_t cts_rows = 0;
-    u64 *cts2 = nullptr; size_t cts2_rows = 0;
-    // a half-batch of hc_conv_then_pack_batch in anti-phase with the other half (hc_conv_batch_antiphase): its own loop-A outputs and c' pairs
-    u64 *bcts = nullptr; size_t bcts_rows = 0;
-    HcTw *ctc = nullptr; size_t ctc_cts = 0;
-    std::vector<hipEvent_t> step_ev; size_t step_next = 0;      // ring of events for the lock-step barriers between the two lanes
-};
-// One queued operation of a recorded launch sequence (hc_ctx::rec): kind 'V' = bound by the vector ALU (the cols kernels a2, b2, b4 and
-// b3), 'M' = bound by memory (a1, a3, b1, b5, copies). See hc_conv_batch_antiphase.
-struct HcOp { char kind; std::function<hipError_t(hipStream_t)> run; };
-
 struct hc_ctx {
     int device = 0, nq = 0, np = 0;
     hipStream_t stream = nullptr;
@@ -104,7 +87,6 @@ struct hc_ctx {
     struct CacheBlk { size_t n = 0; hipEvent_t ev = nullptr; bool pending = false; };
     std::map<char *, CacheBlk> cache_blk; std::map<size_t, std::vector<void *>> cache_free;      // HCONV_ASYNC_ALLOC=1: sizes of the blocks this context allocated; parked blocks by size
     int async_alloc = 0;                                    // HCONV_ASYNC_ALLOC=1: non-blocking stream + cached allocations (see hcx_malloc)
-    long ks_fused = 0;                                      // plain key switch with the digits' second transform pass inside the inner product (hc_k_rows_fwd_mac): measured 3 % slower per ResNet image (202 VGPRs, a serial loop over the digits), so off
     HcRowMod *d_rowmods = nullptr;                          // per modulus: both twiddle tables + q, mu (multi-modulus batched transforms)
     u64 *ws_mm = nullptr; size_t ws_mm_rows = 0;            // scratch of the batched key switch / rescale
     struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr; };
@@ -112,25 +94,14 @@ struct hc_ctx {
     std::map<int, HcTw *> rescale_plan;                     // per level: qL^-1 mod q_i
     const void *hoist_cx = nullptr; int hoist_level = -1;   // the polynomial whose digit decomposition ws_mm currently holds
     long chunk_nodes = 64;
-    long lanes = 1;               // internal concurrency of ONE convolution (hc_conv_then_pack, hc_conv_then_pack_batch with n = 1): a power of two, 1 = single stream (default).
-                                  // Measured on MI355X, `conv 3 3` alone (profiles/round3_lanes.txt): 2 lanes 1.60 -> 1.49 ms in a process with ONE context, but 1.50 -> 1.65 ms in
-                                  // bench.py's process with four contexts - the runtime maps all streams of a process onto 4 hardware queues, lanes that share a queue run one
-                                  // after the other, and kernels of different queues slow each other down (two 32-node b5m side by side: 134 + 141 us against 2 x 45 alone); 4 lanes
-                                  // 2.9 ms. So lanes stay an option.
-    long s_mask = 0;              // experiment: stages of the BIG tree levels that run on the quarter-tile kernels (bit i = stage i + 1); measured in profiles/round3_lanes.txt
-    long lane_priority = 0;       // 1: the lanes' streams get descending priorities (lane 0 highest), so the lanes run staggered: a lane's small, latency-bound tree levels fill with the next lane's big ones
-    std::vector<HcLane> lane;
     hipEvent_t ev_fork = nullptr;
     HcCplx *enc_roots = nullptr; int *enc_rot_group = nullptr;      // slot encoder tables (hc_encode_slots), built at first use
     hipEvent_t ev_shard = nullptr;     // hc_conv_then_pack_sharded: this device's partial ciphertext is complete / has been collected
     u64 *ws_gather = nullptr; size_t ws_gather_rows = 0;
-    std::vector<HcOp> *rec = nullptr;     // non-null: hc_launch / hc_copy_d2d append to it instead of enqueueing on the stream
     long small_levels = 16;               // pack-tree launches of at most this many nodes (summed over the batch) run on the 1024-thread S kernels; 0 = never
     long peer_access = 1;                 // hc_conv_then_pack_sharded: enable direct peer copies between distinct devices (0: leave the copies to hipMemcpyPeerAsync's staging)
+    unsigned peer_warned = 0;             // bit d: enabling peer access to device d failed and was reported once
     unsigned peer_enabled = 0;            // bit d: peer access from this context's device to device d was enabled by (or found enabled for) this context
-    long b5_merged = 1;                   // row-local pack levels: one b5 workgroup per (node, tile) for both polynomials (hc_k_b5m); 0 = two jobs (A/B switch)
-    long antiphase = 0;                   // hc_conv_then_pack_batch with n >= 2: two half-batches on two streams, memory-bound phases of one against VALU-bound phases of the other.
-                                          // OFF by default: measured no gain (profiles/round3_antiphase_trace.txt) -- co-resident kernels time-slice the CU's wave slots and the VALU pipe
     long profile = 0;
     std::vector<HcProfRec> prof;
     std::map<std::string, std::pair<double, long>> prof_acc;
@@ -213,16 +184,8 @@ struct HcScratch {
 static inline bool hc_fm_free(u64 q) { return q < (1ull << 57); }     // 74q < 2^64 (hc_ct_round)
 static inline bool hc_f64_ok(u64 q) { return q < (1ull << 49); }    // fp64 inverse transform (hc_arith.h): 4q < 2^51
 
-static char hc_op_kind(const char *name) {       // by kernel name: the measured bound of each kernel of the conv path
-    if ((name[0] == 'a' && name[1] == '2') || (name[0] == 'b' && (name[1] == '2' || name[1] == '3' || name[1] == '4'))) return 'V';
-    return 'M';
-}
 template <int TPB = HC_TPB, class K, class... Args>
 static int hc_launch(hc_ctx *c, const char *name, K kernel, dim3 grid, Args... args) {
-    if (c->rec) {
-        c->rec->push_back(HcOp{hc_op_kind(name), [=](hipStream_t st) -> hipError_t { hipLaunchKernelGGL(kernel, grid, dim3(TPB), 0, st, args...); return hipGetLastError(); }});
-        return HC_OK;
-    }
     hipEvent_t a = nullptr, b = nullptr;
     if (c->profile) { HC_HIP(c, hipEventCreate(&a)); HC_HIP(c, hipEventCreate(&b)); HC_HIP(c, hipEventRecord(a, c->stream)); }
     hipLaunchKernelGGL(kernel, grid, dim3(TPB), 0, c->stream, args...);
@@ -231,9 +194,8 @@ static int hc_launch(hc_ctx *c, const char *name, K kernel, dim3 grid, Args... a
     return HC_OK;
 }
 #define HC_TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
-// device-to-device copy on the context's stream (or into the recorded sequence)
+// device-to-device copy on the context's stream
 static int hc_copy_d2d(hc_ctx *c, void *dst, const void *src, size_t bytes) {
-    if (c->rec) { c->rec->push_back(HcOp{'M', [=](hipStream_t st) -> hipError_t { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st); }}); return HC_OK; }
     HC_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
     return HC_OK;
 }
@@ -375,13 +337,6 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     F(c->idx_pairs); F(c->ws_cts); F(c->ws_cts2); F(c->ws_gather);
     if (c->ev_fork) D(hipEventDestroy(c->ev_fork), "hipEventDestroy");
     if (c->ev_shard) D(hipEventDestroy(c->ev_shard), "hipEventDestroy");
-    for (auto &L : c->lane) {
-        if (L.stream) D(hipStreamSynchronize(L.stream), "hipStreamSynchronize");
-        F(L.tmp); F(L.cts); F(L.cts2); F(L.bcts); F(L.ctc);
-        for (hipEvent_t e : L.step_ev) D(hipEventDestroy(e), "hipEventDestroy");
-        if (L.done) D(hipEventDestroy(L.done), "hipEventDestroy");
-        if (L.stream) D(hipStreamDestroy(L.stream), "hipStreamDestroy");
-    }
     F(c->enc_roots); F(c->enc_rot_group);
     F(c->ws_ctc); F(c->ws_tmp); F(c->d_mods); F(c->d_rowmods); F(c->ws_mm);
     for (auto &kv : c->ks_plan) { F(kv.second.bx); F(kv.second.bxdown); F(kv.second.pinv); }
@@ -556,12 +511,11 @@ extern "C" int hc_lv_sub(hc_ctx *c, int level, const uint64_t *a, const uint64_t
 extern "C" int hc_lv_mul_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_MULC>(c, "hc_lv_mul_const", level, a, nullptr, out, consts); }
 extern "C" int hc_lv_add_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_ADDC>(c, "hc_lv_add_const", level, a, nullptr, out, consts); }
 // batched transforms over rows of different moduli (row y <-> modulus y < nl ? y : nq + y - nl); z operands zs words apart
-static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0, bool cols_only = false) {
+static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z));
     HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = z_alpha;
     const dim3 grid(16, (unsigned)rows, (unsigned)z); const size_t zt = (size_t)rows * HC_N;
     A.zs_in = zs_in; A.zs_out = zt; HC_TRY(hc_launch(c, "cols_fwd_mm", hc_k_cols_fwd_mm, grid, in, c->ws_tmp, A));
-    if (cols_only) return HC_OK;                                  // the caller's next kernel runs the rows pass itself, from ws_tmp ([z][rows][N])
     A.zs_in = zt; A.zs_out = zs_out; HC_TRY(hc_launch(c, "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
@@ -917,7 +871,7 @@ static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, size_t sstride, si
     HC_TRY(hc_ensure_tmp(c, (size_t)n * chunk * 4));
     HcLoopB B; HC_TRY(hc_fill_loopB(c, &B, src, dst, it->second, logStep, step, norm, galEl, n * chunk));
     B.src_stride = sstride; B.dst_stride = dstride;
-    if (it->second.row256 && c->b5_merged) B.tmpT = nullptr;      // hc_k_b5m recomputes t2.c1: b1 need not store it
+    if (it->second.row256) B.tmpT = nullptr;      // hc_k_b5m recomputes t2.c1: b1 need not store it
     HcPtrs nobias; memset(&nobias, 0, sizeof nobias);
     const HcModHost &m0 = c->mods[0], &mp = c->mods[(size_t)c->nq];
     for (int n0 = 0; n0 < nodes; n0 += chunk) {
@@ -937,23 +891,13 @@ static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, size_t sstride, si
             HC_TRY(hc_launch<HC_STPB>(c, "b5_rowsfwd_moddown_perm_add", hc_k_sb5, s2, B, m0.fwd, pb, po));
             continue;
         }
-        // experiment (option "s_mask", default 0): bit i puts stage i + 1 of a BIG level on the quarter-tile kernel too (same tmp layouts, same bits, twice the waves per SIMD)
-        const long sm = (it->second.row256 && c->b5_merged && !HC_JOB_FAST) ? c->s_mask : 0;
-        const dim3 s1(HC_STILES, (unsigned)(n * nn)), s2(HC_STILES, (unsigned)(2 * n * nn)), s3(HC_STILES, (unsigned)(n * nn), 2);
-        if (sm) B.tmpT = nullptr;
-        if (sm & 1) HC_TRY(hc_launch<HC_STPB>(c, "b1_node_rowsinv", hc_k_sb1, s1, B, m0.inv));
-        else HC_TRY(hc_launch(c, "b1_node_rowsinv", hc_k_b1, g1, B, m0.inv));
-        if (sm & 2) HC_TRY(hc_launch<HC_STPB>(c, "b2_colsinv_colsfwdP", hc_k_sb2, s1, B, m0.inv, mp.fwd));
-        else HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b2_colsinv_colsfwdP", hc_k_b2, g1, B, m0.inv, mp.fwd));
-        if (sm & 4) HC_TRY(hc_launch<HC_STPB>(c, "b3_rowsfwdP_mac_rowsinvP", hc_k_sb3, s3, B, mp.fwd, mp.inv));
-        else HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, g1, B, mp.fwd, mp.inv));
-        if (sm & 8) HC_TRY(hc_launch<HC_STPB>(c, "b4_colsinvP_modup_colsfwd", hc_k_sb4, s2, B, mp.inv, m0.fwd));
-        else HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, g2, B, mp.inv, m0.fwd));
+        HC_TRY(hc_launch(c, "b1_node_rowsinv", hc_k_b1, g1, B, m0.inv));
+        HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b2_colsinv_colsfwdP", hc_k_b2, g1, B, m0.inv, mp.fwd));
+        HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, g1, B, mp.fwd, mp.inv));
+        HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, g2, B, mp.inv, m0.fwd));
         const HcPtrs pb = bias_last ? *bias_last : nobias, po = outs_last ? *outs_last : nobias;
-        if (sm & 16) HC_TRY(hc_launch<HC_STPB>(c, "b5_rowsfwd_moddown_perm_add", hc_k_sb5, s2, B, m0.fwd, pb, po));
-        else if (it->second.row256 && c->b5_merged) HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5m, g1, B, m0.fwd, pb, po));
-        else if (it->second.row256) HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_FREE, 1>, g2, B, m0.fwd, pb, po) : hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_ALT, 1>, g2, B, m0.fwd, pb, po));
-        else HC_TRY(hc_fm_free(m0.m.q) ? hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_FREE, 0>, g2, B, m0.fwd, pb, po) : hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_ALT, 0>, g2, B, m0.fwd, pb, po));
+        if (it->second.row256) HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5m, g1, B, m0.fwd, pb, po));      // one workgroup per (node, tile), both polynomials
+        else HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, g2, B, m0.fwd, pb, po));                        // tile-local permutation (2^j + 1, j = 5..8)
     }
     return HC_OK;
 }
@@ -1038,8 +982,7 @@ static int hc_ks_common(hc_ctx *c, uint64_t galEl, const uint64_t *c0, const uin
             if (!rc) rc = HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, hc_grid(1), B, mp.fwd, mp.inv);
             if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, hc_grid(2), B, mp.inv, m0.fwd);
             HcPtrs nobias; memset(&nobias, 0, sizeof nobias);
-            if (!rc) rc = hc_fm_free(m0.m.q) ? hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_FREE, 0>, hc_grid(2), B, m0.fwd, nobias, nobias)
-                                             : hc_launch(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5<HC_FM_ALT, 0>, hc_grid(2), B, m0.fwd, nobias, nobias);
+            if (!rc) rc = HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, hc_grid(2), B, m0.fwd, nobias, nobias);
             HcTw z; z.w = z.ws = 0;      // node result = y + RotateGal(y): subtract y again
             if (!rc) rc = hc_launch(c, "ks_sub", hc_k_pointwise<HC_PW_SUB>, hc_pw_grid(2 * HC_N), (const u64 *)res, (const u64 *)y, res, (size_t)2 * HC_N, c->mods[0].m, z);
             if (!rc && (hipMemcpyAsync(o0, res, HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) != hipSuccess
@@ -1130,22 +1073,20 @@ static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
 }
 // phase 1 (rlwe.KeySwitcher.DecomposeNTT / ring.Decomposer.DecomposeAndSplit): digits[d][T] = the d-th digit of cx extended to limb
 // T (Q limbs 0..level, then the P limbs), NTT domain; a digit's own limbs are not written (phase 2 reads cx there)
-static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, u64 *coef, u64 *digits, bool half = false) {
+static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, u64 *coef, u64 *digits) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
     HC_TRY(hc_intt_mm(c, cx, coef, nl, nl, 1, 0, 0));                                                    // cxInvNTT, all limbs
     // every digit at once (blockIdx.z = digit): extension of the digit's residues to all other limbs, then their transforms
     HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(128, 4, (unsigned)beta), (const u64 *)coef, (size_t)HC_N, digits, (const HcBasisExt *)P->bx, nt, 0, 0, (size_t)alpha * HC_N, (size_t)nt * HC_N, alpha, nl));
-    // half: only the cols pass, into ws_tmp; hc_k_rows_fwd_mac finishes the transform inside the inner product (plain key switch)
-    return hc_ntt_mm(c, digits, digits, nt, nl, 0, 0, beta, (size_t)nt * HC_N, (size_t)nt * HC_N, alpha, half);
+    return hc_ntt_mm(c, digits, digits, nt, nl, 0, 0, beta, (size_t)nt * HC_N, (size_t)nt * HC_N, alpha);
 }
 static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1, uint64_t rot_gal, const u64 *rot_c0);
 // phase 2: inner product with the key (both components), then ModDownSplitNTTPQ
-static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const u64 *digits, u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1, bool half = false, uint64_t rot_gal = 0, const u64 *rot_c0 = nullptr) {
+static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const u64 *digits, u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1, uint64_t rot_gal = 0, const u64 *rot_c0 = nullptr) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = key.beta;
-    if (half) HC_TRY(hc_launch(c, "ks_rows_fwd_mac", hc_k_rows_fwd_mac, dim3(16, (unsigned)nt), (const u64 *)key.rows, cx, (const u64 *)c->ws_tmp, acc, (const HcRowMod *)c->d_rowmods, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta));
-    else HC_TRY(hc_launch(c, "ks_mac_all", hc_k_ks_mac_all, dim3(32, (unsigned)nt, 2), (const u64 *)key.rows, cx, digits, acc, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta));
+    HC_TRY(hc_launch(c, "ks_mac_all", hc_k_ks_mac_all, dim3(32, (unsigned)nt, 2), (const u64 *)key.rows, cx, digits, acc, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta));
     return hc_ks_moddown(c, level, acc, pc, ext, d0, d1, rot_gal, rot_c0);
 }
 // ring.(*FastBasisExtender).ModDownSplitNTTPQ for the two polynomials acc[2][nt][N] (basis Q_0..Q_level, P_0..P_(np-1), canonical, NTT):
@@ -1185,10 +1126,9 @@ extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_
     const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch", key_id, level, &key));
     if (!cx || !d0 || !d1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch: null");
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
-    const bool half = c->ks_fused != 0;
-    HC_TRY(hc_ks_decompose_into(c, level, cx, S.coef, S.digits, half));
+    HC_TRY(hc_ks_decompose_into(c, level, cx, S.coef, S.digits));
     c->hoist_cx = nullptr;                                   // the scratch no longer holds a hoisted decomposition
-    return hc_ks_apply_from(c, *key, level, cx, S.digits, S.acc, S.pc, S.ext, d0, d1, half);
+    return hc_ks_apply_from(c, *key, level, cx, S.digits, S.acc, S.pc, S.ext, d0, d1);
 }
 // Hoisted key switching (evaluator.RotateHoisted, conv.go:131; the baby steps of a linear transform): the decomposition of cx is
 // computed once and kept in the context; every hc_keyswitch_hoisted with the same (cx, level) then only does the inner product with
@@ -1222,10 +1162,10 @@ extern "C" int hc_keyswitch_rotate(hc_ctx *c, uint64_t key_id, uint64_t galEl, i
     if (hoisted) {
         if (c->hoist_cx != c1 || c->hoist_level != level) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch_rotate: no decomposition of this polynomial at level %d is held (call hc_keyswitch_decompose first)", level);
     } else {
-        HC_TRY(hc_ks_decompose_into(c, level, c1, S.coef, S.digits, false));
+        HC_TRY(hc_ks_decompose_into(c, level, c1, S.coef, S.digits));
         c->hoist_cx = nullptr;
     }
-    return hc_ks_apply_from(c, *key, level, c1, S.digits, S.acc, S.pc, S.ext, out0, out1, false, galEl, c0);
+    return hc_ks_apply_from(c, *key, level, c1, S.digits, S.acc, S.pc, S.ext, out0, out1, galEl, c0);
 }
 
 // ---- the key switch in two halves and arithmetic in the extended basis (Lattigo's MultiplyByDiagMatrixBSGS keeps the baby-step rotations,
@@ -1240,7 +1180,7 @@ extern "C" int hc_keyswitch_qp(hc_ctx *c, uint64_t key_id, int level, const uint
     if (hoisted) {
         if (c->hoist_cx != cx || c->hoist_level != level) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch_qp: no decomposition of this polynomial at level %d is held (call hc_keyswitch_decompose first)", level);
     } else {
-        HC_TRY(hc_ks_decompose_into(c, level, cx, S.coef, S.digits, false));
+        HC_TRY(hc_ks_decompose_into(c, level, cx, S.coef, S.digits));
         c->hoist_cx = nullptr;
     }
     const int alpha = c->np, nl = level + 1, nt = nl + alpha;
@@ -1298,89 +1238,6 @@ static int hc_loopA_consts(hc_ctx *c, double ct_scale, double ker_scale, int max
     *target = tgt;
     return HC_OK;
 }
-// RAII swap of the context's stream + workspaces with a lane's, so every helper above runs on that lane unchanged
-struct HcLaneScope {
-    hc_ctx *c; HcLane *L;
-    HcLaneScope(hc_ctx *c_, HcLane *L_) : c(c_), L(L_) { swap(); }
-    ~HcLaneScope() { swap(); }
-    void swap() { std::swap(c->stream, L->stream); std::swap(c->ws_tmp, L->tmp); std::swap(c->ws_tmp_rows, L->tmp_rows);
-                  std::swap(c->ws_cts2, L->cts2); std::swap(c->ws_cts2_rows, L->cts2_rows); }
-};
-// One convolution on G internal lanes: lane g computes the channels i = g (mod G) (loop A) and the tree levels with
-// step >= G over them (hc_pack_run with stride log2 G) on its own stream; the G partial ciphertexts are then packed by
-// the last log2 G levels on the main stream. Same arithmetic, same order per node => same bits as the single-lane run.
-static int hc_conv_lanes(hc_ctx *c, const hc_ker *ker, int max_ob, int G, const u64 *bias, u64 *ct_out) {
-    if (G & (G - 1)) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two");
-    int log2g = 0; while ((1 << log2g) < G) log2g++;
-    const int nloc = max_ob / G;
-    if ((int)c->lane.size() < G) {
-        size_t old = c->lane.size(); c->lane.resize((size_t)G);
-        int least = 0, greatest = 0;
-        if (c->lane_priority) HC_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));       // numerically lower = higher priority
-        for (size_t g = old; g < (size_t)G; g++) {
-            if (c->lane_priority) HC_HIP(c, hipStreamCreateWithPriority(&c->lane[g].stream, hipStreamDefault, std::min(least, greatest + (int)g)));
-            else HC_HIP(c, hipStreamCreate(&c->lane[g].stream));
-            HC_HIP(c, hipEventCreate(&c->lane[g].done));
-        }
-    }
-    if (!c->ev_fork) HC_HIP(c, hipEventCreate(&c->ev_fork));
-    if (c->ws_gather_rows < (size_t)G * 2) {
-        HC_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->ws_gather) HC_HIP(c, hcx_free(c, c->ws_gather));
-        c->ws_gather = nullptr; c->ws_gather_rows = 0;
-        HC_HIP(c, hcx_malloc(c, (void **)&c->ws_gather, (size_t)G * 2 * HC_N * sizeof(u64)));
-        c->ws_gather_rows = (size_t)G * 2;
-    }
-    HC_HIP(c, hipEventRecord(c->ev_fork, c->stream));          // ctc (and everything queued before) is ready
-    // The lanes' launches are RECORDED first and then issued round-robin, one launch per lane in turn. Issued lane after lane (round 2), the host needs ~8 us per launch
-    // and ~55 launches per lane: lane g + 1 was not even submitted before lane g was most of the way through its tree, so the lanes ran one after the other (kernel
-    // trace: 2.9 ms for one `conv 3 3` on 4 lanes against 1.6 ms on one). Round-robin, the G lanes' kernels of one step reach the device together and the small tree
-    // levels - a handful of workgroups, latency-bound - of G lanes overlap.
-    std::vector<std::vector<HcOp>> ops((size_t)G);
-    const bool record = !c->profile;                           // the per-kernel profile brackets every launch with events on the issuing stream: keep that mode sequential
-    for (int g = 0; g < G; g++) {
-        HcLane &L = c->lane[(size_t)g];
-        if (L.cts_rows < (size_t)nloc * 2) {
-            HC_HIP(c, hipStreamSynchronize(L.stream));
-            if (L.cts) HC_HIP(c, hcx_free(c, L.cts));
-            L.cts = nullptr; L.cts_rows = 0;
-            HC_HIP(c, hcx_malloc(c, (void **)&L.cts, (size_t)nloc * 2 * HC_N * sizeof(u64)));
-            L.cts_rows = (size_t)nloc * 2;
-        }
-        for (int attempt = 0;; attempt++) {
-            HcLaneScope scope(c, &L);
-            if (!record && hipStreamWaitEvent(c->stream, c->ev_fork, 0) != hipSuccess) return hc_fail(c, HC_ERR_HIP, "hipStreamWaitEvent failed");
-            // a workspace that grows while the sequence is being recorded leaves the launches recorded before it pointing at the freed block: record again (the
-            // workspaces only grow, so the second pass finds them large enough)
-            const u64 *tmp0 = c->ws_tmp, *cts20 = c->ws_cts2; const size_t tr0 = c->ws_tmp_rows, cr0 = c->ws_cts2_rows;
-            ops[(size_t)g].clear();
-            if (record) c->rec = &ops[(size_t)g];
-            int rc = hc_loopA_run_set(c, hc_ptrs1(ker->d), 1, g, G, nloc, L.cts, 0, true);
-            if (!rc) rc = hc_pack_run(c, L.cts, 0, 1, nloc, nloc, nullptr, log2g);
-            c->rec = nullptr;
-            if (rc) return rc;
-            if (!record || (c->ws_tmp == tmp0 && c->ws_cts2 == cts20 && c->ws_tmp_rows == tr0 && c->ws_cts2_rows == cr0)) break;
-            if (attempt == 3) return hc_fail(c, HC_ERR_STATE, "hc_conv_lanes: the lane workspaces keep growing");
-        }
-    }
-    if (record) {
-        size_t nmax = 0;
-        for (int g = 0; g < G; g++) { HC_HIP(c, hipStreamWaitEvent(c->lane[(size_t)g].stream, c->ev_fork, 0)); nmax = std::max(nmax, ops[(size_t)g].size()); }
-        for (size_t i = 0; i < nmax; i++)
-            for (int g = 0; g < G; g++) if (i < ops[(size_t)g].size()) HC_HIP(c, ops[(size_t)g][i].run(c->lane[(size_t)g].stream));
-    }
-    for (int g = 0; g < G; g++) {
-        HcLane &L = c->lane[(size_t)g];
-        HC_HIP(c, hipMemcpyAsync(c->ws_gather + (size_t)g * 2 * HC_N, L.cts, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, L.stream));
-        HC_HIP(c, hipEventRecord(L.done, L.stream));
-    }
-    for (int g = 0; g < G; g++) HC_HIP(c, hipStreamWaitEvent(c->stream, c->lane[(size_t)g].done, 0));
-    const HcPtrs bp = hc_ptrs1(bias);
-    HC_TRY(hc_pack_run(c, c->ws_gather, 0, 1, G, G, bias ? &bp : nullptr, 0));
-    HC_HIP(c, hipMemcpyAsync(ct_out, c->ws_gather, 2 * HC_N * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-    return HC_OK;
-}
-
 extern "C" int hc_conv_mult_phase(hc_ctx *c, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
                                   int max_ob, int norm, double out_scale, uint64_t *cts_out) {
     HC_ENTER(c);
@@ -1402,96 +1259,17 @@ static int hc_conv_batch_run(hc_ctx *c, int n, const HcPtrs &ct_in, const HcPtrs
     HcPtrs outs; memset(&outs, 0, sizeof outs); for (int z = 0; z < n; z++) outs.p[z] = ct_out[z];
     return hc_pack_run(c, c->ws_cts, cstride, n, max_ob, max_ob / norm, any_bias ? &bias : nullptr, 0, &outs);      // the root node writes ct_out itself
 }
-// ---- two half-batches in anti-phase ---------------------------------------------------------------------------------------------
-// The kernels of the conv are either bound by the vector ALU (the cols kernels a2, b2, b4 and b3: 77-86 % of the VALU pipe, little
-// memory traffic) or by memory (a1, a3, b1, b5: 3.6-4.5 TB/s, 40-47 % of the pipe); both resources are needed for about the same
-// total time, and a kernel of one kind leaves the other resource idle. hc_conv_then_pack_batch therefore runs
-// the two halves of its batch on two streams, ONE PHASE APART: each half's launch sequence is recorded (hc_ctx::rec) and cut into
-// phases of consecutive launches of one kind ( M: ctc a1 | V: a2 | M: a3 a1 | ... | M: a3 b1 | V: b2 b3 b4 | M: b5 b1 | ... ), the
-// second half starts one phase late, and after every phase the two streams wait for each other (two events per step). So at any time
-// a memory-bound phase of one half shares the CUs with a VALU-bound phase of the other. Same kernels on the same data in the same
-// per-ciphertext order: same bits. (Independent contexts on several streams get the same overlap only where their phases happen to
-// line up: +11 % in round 2; this is the deterministic form.)
-struct HcBatchLaneScope {
-    hc_ctx *c; HcLane *L;
-    HcBatchLaneScope(hc_ctx *c_, HcLane *L_) : c(c_), L(L_) { swap(); }
-    ~HcBatchLaneScope() { swap(); }
-    void swap() { std::swap(c->stream, L->stream); std::swap(c->ws_tmp, L->tmp); std::swap(c->ws_tmp_rows, L->tmp_rows);
-                  std::swap(c->ws_cts2, L->cts2); std::swap(c->ws_cts2_rows, L->cts2_rows);
-                  std::swap(c->ws_cts, L->bcts); std::swap(c->ws_cts_rows, L->bcts_rows); std::swap(c->ws_ctc, L->ctc); std::swap(c->ws_ctc_cts, L->ctc_cts); }
-};
-static int hc_lane_step_event(hc_ctx *c, HcLane &L, hipEvent_t *ev) {
-    if (L.step_ev.size() < 128) { hipEvent_t e; HC_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); L.step_ev.push_back(e); *ev = e; return HC_OK; }
-    *ev = L.step_ev[L.step_next]; L.step_next = (L.step_next + 1) % L.step_ev.size();     // 128 steps back: long complete
-    return HC_OK;
-}
-static int hc_conv_batch_antiphase(hc_ctx *c, int n, const HcPtrs &ct_in, const HcPtrs &kers, const HcPtrs &bias, bool any_bias, u64 *const *ct_out,
-                                   int max_ob, int norm, const u64 cst[2]) {
-    if (c->lane.size() < 2) {
-        size_t old = c->lane.size(); c->lane.resize(2);
-        for (size_t g = old; g < 2; g++) { HC_HIP(c, hipStreamCreate(&c->lane[g].stream)); HC_HIP(c, hipEventCreate(&c->lane[g].done)); }
-    }
-    if (!c->ev_fork) HC_HIP(c, hipEventCreate(&c->ev_fork));
-    HC_HIP(c, hipEventRecord(c->ev_fork, c->stream));            // whatever the caller queued before (uploads, the previous layer) comes first
-    const int nh[2] = {(n + 1) / 2, n / 2}, off[2] = {0, (n + 1) / 2};
-    std::vector<HcOp> ops[2];
-    for (int h = 0; h < 2; h++) {
-        HcPtrs pin, pker, pbias; memset(&pin, 0, sizeof pin); memset(&pker, 0, sizeof pker); memset(&pbias, 0, sizeof pbias);
-        for (int z = 0; z < nh[h]; z++) { pin.p[z] = ct_in.p[off[h] + z]; pker.p[z] = kers.p[off[h] + z]; pbias.p[z] = bias.p[off[h] + z]; }
-        HcBatchLaneScope scope(c, &c->lane[(size_t)h]);
-        HC_HIP(c, hipStreamWaitEvent(c->stream, c->ev_fork, 0));
-        // size the lane's temporaries for the whole sequence up front: a workspace that grew while the sequence is being recorded
-        // would leave the launches recorded before it pointing at the freed block
-        long ch = (c->chunk_nodes < 1 ? 1 : c->chunk_nodes) / nh[h]; if (ch < 1) ch = 1;
-        const long nch = max_ob / norm, cha = ch < nch ? ch : nch, chb = ch < (nch / 2 > 0 ? nch / 2 : 1) ? ch : (nch / 2 > 0 ? nch / 2 : 1);
-        const size_t rows_a = (size_t)nh[h] * (size_t)cha * 2, rows_b = (size_t)nh[h] * (size_t)chb * 4;
-        HC_TRY(hc_ensure_tmp(c, rows_a > rows_b ? rows_a : rows_b));
-        c->rec = &ops[h];
-        const int rc = hc_conv_batch_run(c, nh[h], pin, pker, pbias, any_bias, ct_out + off[h], max_ob, norm, cst);
-        c->rec = nullptr;
-        if (rc) return rc;
-    }
-    // phases = maximal runs of one kind
-    std::vector<std::pair<size_t, size_t>> ph[2];
-    for (int h = 0; h < 2; h++)
-        for (size_t i = 0; i < ops[h].size();) { size_t j = i; while (j < ops[h].size() && ops[h][j].kind == ops[h][i].kind) j++; ph[h].push_back({i, j}); i = j; }
-    const size_t steps = ph[0].size() > ph[1].size() + 1 ? ph[0].size() : ph[1].size() + 1;
-    HcLane &L0 = c->lane[0], &L1 = c->lane[1];
-    for (size_t s = 0; s < steps; s++) {
-        if (s < ph[0].size()) for (size_t i = ph[0][s].first; i < ph[0][s].second; i++) HC_HIP(c, ops[0][i].run(L0.stream));
-        if (s >= 1 && s - 1 < ph[1].size()) for (size_t i = ph[1][s - 1].first; i < ph[1][s - 1].second; i++) HC_HIP(c, ops[1][i].run(L1.stream));
-        if (s + 1 < steps) {         // lock step: neither lane starts its next phase before the other has finished this one
-            hipEvent_t e0, e1; HC_TRY(hc_lane_step_event(c, L0, &e0)); HC_TRY(hc_lane_step_event(c, L1, &e1));
-            HC_HIP(c, hipEventRecord(e0, L0.stream)); HC_HIP(c, hipEventRecord(e1, L1.stream));
-            HC_HIP(c, hipStreamWaitEvent(L0.stream, e1, 0)); HC_HIP(c, hipStreamWaitEvent(L1.stream, e0, 0));
-        }
-    }
-    HC_HIP(c, hipEventRecord(L0.done, L0.stream)); HC_HIP(c, hipEventRecord(L1.done, L1.stream));
-    HC_HIP(c, hipStreamWaitEvent(c->stream, L0.done, 0)); HC_HIP(c, hipStreamWaitEvent(c->stream, L1.done, 0));
-    return HC_OK;
-}
-// lanes for ONE convolution (option "lanes"); only dense packing (norm 1) splits into lanes, and the per-kernel profile keeps one stream
-static int hc_lanes_for(const hc_ctx *c, int max_ob, int norm) {
-    const int G = c->lanes > 1 && !c->profile ? (int)c->lanes : 1;
-    return (G > 1 && norm == 1 && max_ob >= 2 * G) ? G : 1;
-}
 extern "C" int hc_conv_then_pack(hc_ctx *c, const uint64_t *ct_in, double ct_scale, const hc_ker *ker, double ker_scale,
                                  int max_ob, int norm, double out_scale, const uint64_t *bias, uint64_t *ct_out, double *scale_out) {
     HC_ENTER(c);
     if (!ct_in || !ker || !ct_out || ker->max_ob < max_ob) return hc_fail(c, HC_ERR_ARG, "hc_conv_then_pack: bad arguments");
     u64 cst[2]; double target;
     HC_TRY(hc_loopA_consts(c, ct_scale, ker_scale, max_ob, norm, out_scale, cst, &target));
-    const int G = hc_lanes_for(c, max_ob, norm);
     // conv.go:274 multiplies the scale by real_cnum; conv.go:541 then demands out_scale and level 0
     const double final_scale = target * (double)(max_ob / norm);
     if (final_scale != out_scale) return hc_fail(c, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
-    if (G > 1) {
-        HC_TRY(hc_prepare_ctc(c, hc_ptrs1((const u64 *)ct_in), 1, cst));
-        HC_TRY(hc_conv_lanes(c, ker, max_ob, G, (const u64 *)bias, (u64 *)ct_out));
-    } else {
-        u64 *outs[1] = {(u64 *)ct_out};
-        HC_TRY(hc_conv_batch_run(c, 1, hc_ptrs1((const u64 *)ct_in), hc_ptrs1(ker->d), hc_ptrs1((const u64 *)bias), bias != nullptr, outs, max_ob, norm, cst));
-    }
+    u64 *outs[1] = {(u64 *)ct_out};
+    HC_TRY(hc_conv_batch_run(c, 1, hc_ptrs1((const u64 *)ct_in), hc_ptrs1(ker->d), hc_ptrs1((const u64 *)bias), bias != nullptr, outs, max_ob, norm, cst));
     if (scale_out) *scale_out = final_scale;
     return HC_OK;
 }
@@ -1511,12 +1289,7 @@ extern "C" int hc_conv_then_pack_batch(hc_ctx *c, int n, const uint64_t *const *
     HC_TRY(hc_loopA_consts(c, ct_scale, ker_scale, max_ob, norm, out_scale, cst, &target));
     const double final_scale = target * (double)(max_ob / norm);
     if (final_scale != out_scale) return hc_fail(c, HC_ERR_STATE, "LV or scale after conv then pack, inconsistent");
-    if (n == 1 && hc_lanes_for(c, max_ob, norm) > 1) {
-        HC_TRY(hc_prepare_ctc(c, pin, 1, cst));
-        HC_TRY(hc_conv_lanes(c, ker[0], max_ob, hc_lanes_for(c, max_ob, norm), pbias.p[0], outs[0]));
-    }
-    else if (n >= 2 && c->antiphase && !c->profile) HC_TRY(hc_conv_batch_antiphase(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
-    else HC_TRY(hc_conv_batch_run(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
+    HC_TRY(hc_conv_batch_run(c, n, pin, pker, pbias, any_bias, outs, max_ob, norm, cst));
     if (scale_out) *scale_out = final_scale;
     return HC_OK;
 }
@@ -1558,9 +1331,11 @@ extern "C" int hc_conv_then_pack_sharded(hc_ctx *const *ctxs, int G, const uint6
             if (can) {
                 HC_HIP(c0, hipSetDevice(c0->device));
                 const hipError_t pe = hipDeviceEnablePeerAccess(c->device, 0);
-                if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();               // a previous call (or another context of this process) did it
-                else if (pe != hipSuccess) return hc_fail(c0, HC_ERR_HIP, "hc_conv_then_pack_sharded: hipDeviceEnablePeerAccess(device %d -> %d): %s", c0->device, c->device, hipGetErrorString(pe));
-                c0->peer_enabled |= 1u << (unsigned)(c->device & 31);
+                if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) { if (pe != hipSuccess) (void)hipGetLastError(); c0->peer_enabled |= 1u << (unsigned)(c->device & 31); }
+                else {      // recoverable: hipMemcpyPeerAsync stages the copy itself without peer access (same bits, slower); say so once per device pair
+                    (void)hipGetLastError();
+                    if (!(c0->peer_warned & (1u << (unsigned)(c->device & 31)))) { fprintf(stderr, "libhconv: hipDeviceEnablePeerAccess(device %d -> %d): %s; peer copies will be staged\n", c0->device, c->device, hipGetErrorString(pe)); c0->peer_warned |= 1u << (unsigned)(c->device & 31); }
+                }
             }     // else: hipMemcpyPeerAsync stages through the host (slower, same bits)
         }
     }
@@ -1637,15 +1412,9 @@ extern "C" int hc_bl_post_ker_slots(hc_ctx *c, const double *max_ker_rs, int in_
 extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!c || !name) return HC_ERR_ARG;
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
-    if (!strcmp(name, "s_mask")) { if (value < 0 || value > 31) return hc_fail(c, HC_ERR_ARG, "s_mask is a 5-bit mask"); c->s_mask = value; return HC_OK; }
-    if (!strcmp(name, "lane_priority")) { if (!c->lane.empty()) return hc_fail(c, HC_ERR_STATE, "lane_priority must be set before the first convolution on lanes"); c->lane_priority = value != 0; return HC_OK; }
-    if (!strcmp(name, "lanes")) { if (value == 0) value = 1; if (value < 1 || (value & (value - 1)) || value > 16) return hc_fail(c, HC_ERR_ARG, "lanes must be a power of two in 1..16"); c->lanes = value; return HC_OK; }
     if (!strcmp(name, "small_levels")) { if (value < 0) return hc_fail(c, HC_ERR_ARG, "small_levels must be >= 0"); c->small_levels = value; return HC_OK; }
     if (!strcmp(name, "peer_access")) { c->peer_access = value ? 1 : 0; return HC_OK; }
-    if (!strcmp(name, "b5_merged")) { c->b5_merged = value ? 1 : 0; return HC_OK; }
-    if (!strcmp(name, "antiphase")) { c->antiphase = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
-    if (!strcmp(name, "ks_fused")) { c->ks_fused = value ? 1 : 0; return HC_OK; }      // plain key switch: rows pass inside the inner product (default off: measured slower)
     return hc_fail(c, HC_ERR_ARG, "unknown option %s", name);
 }
 extern "C" int hc_timer_start(hc_ctx *c) { HC_ENTER(c); HC_HIP(c, hipEventRecord(c->t0, c->stream)); return HC_OK; }

@@ -820,7 +820,6 @@ struct Boot {
         if (chain == 7) { LV_STC_TOP = 15; stc_scale_top = sqrt((double)Q[15]); stc_scale_last = 1073741824.0; lv_relin_lo = 2; }
         else { LV_STC_TOP = 3; stc_scale_top = sqrt((double)Q[3]); stc_scale_last = 1073741824.0; lv_relin_lo = LV_RELU_TOP - 11; }
         if (hc_ctx_create(&hc, LOGN, Q.data(), NQ, P.data(), (int)P.size(), device)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
-        if (getenv("HCONV_KS_FUSED")) HCR(hc_set_option(hc, "ks_fused", atoi(getenv("HCONV_KS_FUSED"))));     // A/B switch of the fused inner product
         const int nm = NQ + (int)P.size();
         { void *v = nullptr; HCR(hc_malloc(hc, (size_t)nm * N * 8, &v)); d_sk = (uint64_t *)v; }
         std::vector<uint64_t> h((size_t)N);

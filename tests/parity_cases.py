@@ -141,7 +141,7 @@ def load_tree_keys(ctx, seed, max_ob, norm=1):
     return evk_all
 
 
-def case_conv(ctx, O, max_ob, seed=0xBEEF, with_bias=True, chunk=None, norm=1, out_scale=2.0 ** 30, lanes=1):
+def case_conv(ctx, O, max_ob, seed=0xBEEF, with_bias=True, chunk=None, norm=1, out_scale=2.0 ** 30):
     """norm > 1 = the sparse packing of the reference's *_sparse kinds (only channels i % norm == 0 are live,
     conv.go:526, 286-287); out_scale = 2^43 is what evalConv_BNRelu_new asks of the same operator (eval.go:433)."""
     ct_in, ker = planted_conv_inputs(seed, max_ob)
@@ -151,9 +151,7 @@ def case_conv(ctx, O, max_ob, seed=0xBEEF, with_bias=True, chunk=None, norm=1, o
     bias = splitmix_rows(seed + 5, Q0, N) if with_bias else None
     if chunk is not None:
         ctx.set_option("chunk_nodes", chunk)
-    ctx.set_option("lanes", lanes)
     got, sc = ctx.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, max_ob, norm, out_scale, bias)
-    ctx.set_option("lanes", 1)
     want, wsc = O.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, idx, evk_all, max_ob, norm, out_scale, bias)
     assert sc == wsc == out_scale
     eq(got, want, f"conv_then_pack B={max_ob} norm={norm} out_scale={out_scale}")

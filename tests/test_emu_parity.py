@@ -84,12 +84,6 @@ def test_conv_sparse_norm_and_relu_scale(env, max_ob, norm, out_scale):
     pc.case_conv(*env, max_ob, norm=norm, out_scale=out_scale)
 
 
-@pytest.mark.parametrize("max_ob,lanes,chunk", [(8, 2, 32), (16, 4, 3), (16, 8, 32)])
-def test_conv_internal_lanes(env, max_ob, lanes, chunk):
-    """one convolution split over internal lanes (channels i mod G on their own streams) must give the same bits"""
-    pc.case_conv(*env, max_ob, lanes=lanes, chunk=chunk)
-
-
 @pytest.mark.parametrize("max_ob,n,chunk,shared", [(4, 3, 64, False), (8, 2, 3, True), (2, 5, 4, False)])
 def test_conv_batch(env, max_ob, n, chunk, shared):
     """hc_conv_then_pack_batch (n ciphertexts per launch set) == n separate convolutions == the oracle"""

@@ -192,12 +192,6 @@ def test_conv_sparse_norm_and_relu_scale(env, max_ob, norm, out_scale):
     pc.case_conv(*env, max_ob, norm=norm, out_scale=out_scale)
 
 
-@pytest.mark.parametrize("max_ob,lanes,chunk", [(16, 2, 32), (64, 4, 64), (256, 4, 64), (256, 8, 16), (256, 2, 256)])
-def test_conv_internal_lanes(env, max_ob, lanes, chunk):
-    """one convolution split over internal lanes (channels i mod G on their own HIP streams) vs the oracle"""
-    pc.case_conv(*env, max_ob, lanes=lanes, chunk=chunk)
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("max_ob,n,chunk,shared", [(4, 3, 64, False), (16, 8, 64, True), (64, 4, 48, False), (256, 4, 128, False), (256, 8, 512, True)])
 def test_conv_batch(env, max_ob, n, chunk, shared):
