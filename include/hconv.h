@@ -81,6 +81,18 @@ int hc_div_round_last2(hc_ctx *ctx, int level, const uint64_t *x0, const uint64_
 /* ring.PermuteNTTWithIndexLvl with ring.PermuteNTTIndex(galEl) (inside RotateGal, conv.go:291) */
 int hc_permute(hc_ctx *ctx, uint64_t galEl, const uint64_t *in, uint64_t *out, int count);
 
+/* ---- image batches of the leveled evaluator ----
+ * The images of a batch go through a layer with the same weights, masks, DFT matrices and switching keys (test.go:128 runs them one after
+ * another). hc_set_batch(n, poly_stride, qp_stride) makes every leveled entry point below (hc_lv_*, hc_rotate_finish, hc_keyswitch*, hc_mod_down2,
+ * hc_qp_*, hc_div_round_last / 2) act on n <= 8 independent ciphertexts in ONE set of launches: a device pointer designates the operand of image 0,
+ * image z's copy lies z * poly_stride words further (polynomials at a level: rows Q_0..Q_level) or z * qp_stride words further (extended-basis pairs
+ * [2][level+1+np][N]: acc of hc_keyswitch_qp, x of hc_mod_down2, the operands of hc_qp_op2 / hc_qp_permute2). Operands that are PLAINTEXTS are shared
+ * by all images and read once per launch: b of hc_lv_mul / hc_lv_mul_acc, b0 == b1 of hc_lv_op2 / hc_qp_op2 (multiplications), every constant vector;
+ * switching keys likewise (one fetch of a key row serves all images and both key components). Results are bit-identical to n separate calls.
+ * n = 1 (default) restores single-ciphertext behaviour; the L0 one-row primitives above, hc_permute and the L1 convolution (which has its own
+ * batch entry point) ignore the setting. A decomposition held by hc_keyswitch_decompose belongs to the batch it was taken under. */
+int hc_set_batch(hc_ctx *ctx, int n, size_t poly_stride_words, size_t qp_stride_words);
+
 /* ---- L0, leveled: a polynomial at `level` is (level+1) consecutive rows, row l modulo q_l (Lattigo's ring.Poly / ckks.Element
  * at that level). One call covers all limbs. These are what a general-level ckks.Evaluator binds for the convReLU chain
  * (eval.go:272-607): MulNew/MulRelin's tensor products, Add/Sub, MultByConst / MulByPow2, AddConst, and the bootstrapper's modUp. */
@@ -99,6 +111,10 @@ int hc_lv_op2(hc_ctx *ctx, int op, int level, const uint64_t *a0, const uint64_t
 /* evaluator.permuteNTT's tail after the key switch (RotateNew, RotateHoisted, ConjugateNew): out0 = Permute_galEl(d0 + c0),
  * out1 = Permute_galEl(d1) over limbs 0..level in one launch; same residues as hc_lv_add + two hc_permute calls */
 int hc_rotate_finish(hc_ctx *ctx, uint64_t galEl, int level, const uint64_t *d0, const uint64_t *d1, const uint64_t *c0, uint64_t *out0, uint64_t *out1);
+/* ring.PermuteNTTWithIndexLvl on a polynomial at `level` (rows 0..level) and on an extended-basis pair [2][level+1+np][N] (the same residues as
+ * hc_permute over those rows), for every image of the batch; in != out */
+int hc_lv_permute(hc_ctx *ctx, uint64_t galEl, int level, const uint64_t *in, uint64_t *out);
+int hc_qp_permute2(hc_ctx *ctx, uint64_t galEl, int level, const uint64_t *in, uint64_t *out);
 /* RotateNew / ConjugateNew / one rotation of RotateHoisted as a single call: key switch of c1 with key `key_id` (the key of galEl), + c0,
  * permutation of both polynomials, with the addition and the permutation inside ModDown's last pass. hoisted != 0: reuse the decomposition
  * left by hc_keyswitch_decompose(level, c1). Same residues as hc_keyswitch (or hc_keyswitch_hoisted) + hc_rotate_finish. */

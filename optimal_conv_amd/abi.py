@@ -34,6 +34,9 @@ SYMBOLS = {
     "hc_const_for": (C.c_uint64, [C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_double)]),
     "hc_div_round_last": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_lv_op2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_set_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t]),
+    "hc_lv_permute": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
+    "hc_qp_permute2": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_rotate_finish": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_keyswitch_rotate": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "hc_div_round_last2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -194,6 +197,10 @@ class Context:
 
     def sync(self):
         self._ck(self.L.hc_sync(self.h))
+
+    def set_batch(self, n, poly_stride=0, qp_stride=0):
+        """hc_set_batch: n images per launch of the leveled entry points, strides in words"""
+        self._ck(self.L.hc_set_batch(self.h, int(n), int(poly_stride), int(qp_stride)))
 
     def set_option(self, name, value):
         self._ck(self.L.hc_set_option(self.h, name.encode(), int(value)))

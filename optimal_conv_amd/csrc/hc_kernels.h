@@ -317,28 +317,47 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_pointwise(const u64 *a, const u64
 enum { HC_PW_ADDC = 6, HC_PW_MAC = 7 };    // MAC: out = out + a * b (the diagonal sums of a linear transform)
 struct HcLvConsts { HcTw c[32]; };      // per-limb constants of one call, passed by value (no host-device copy, no synchronisation)
 #define HC_ROW_IS_MOD 0x7fffffff
-template <int OP>
 // nlq / nqt: rows 0..nlq-1 belong to moduli 0..nlq-1, rows from nlq on to moduli nqt, nqt+1, ... (a polynomial in the extended basis
-// Q_0..Q_level, P_0..P_(np-1) of the key switch: nlq = level + 1, nqt = number of Q moduli of the context); nlq = HC_ROW_IS_MOD: row = modulus
-__global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const u64 *b, u64 *out, const HcMod *mods, HcLvConsts K, size_t as, size_t bs, size_t os, int nlq, int nqt) {
+// Q_0..Q_level, P_0..P_(np-1) of the key switch: nlq = level + 1, nqt = number of Q moduli of the context); nlq = HC_ROW_IS_MOD: row = modulus.
+// blockIdx.z = polynomial + npoly * image group; a group is `nin` images handled by ONE thread (operands ia / ib / io words apart per image):
+// nin > 1 is the form for a SHARED second operand (ib = 0: a plaintext - a mask, an encoded diagonal - multiplying every image of a batch), which is
+// then read, and brought to Montgomery form, once per coefficient whatever the number of images.
+#define HC_MAXIMG 8                   // images per batched launch of the leveled evaluator (hc_set_batch)
+template <int OP>
+__global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const u64 *b, u64 *out, const HcMod *mods, HcLvConsts K, size_t as, size_t bs, size_t os, int nlq, int nqt,
+                                                            int npoly, int nin, size_t ia, size_t ib, size_t io) {
     const int row = blockIdx.y, l = row < nlq ? row : nqt + (row - nlq); const HcMod m = mods[l]; const HcTw *csts = K.c;
     const size_t base = (size_t)row * 65536;
-    a += (size_t)blockIdx.z * as; b += (size_t)blockIdx.z * bs; out += (size_t)blockIdx.z * os;      // blockIdx.z = polynomial of a ciphertext (distances modulo 2^64)
+    const int zp = (int)blockIdx.z % npoly; const size_t img0 = (size_t)((int)blockIdx.z / npoly) * nin;
+    a += (size_t)zp * as + img0 * ia; b += (size_t)zp * bs + img0 * ib; out += (size_t)zp * os + img0 * io;      // distances in words, modulo 2^64
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
-        const u64 x = a[base + i]; u64 r;
-        if (OP == HC_PW_MUL) r = hc_mont(x, hc_mont(b[base + i], m.r2, m.q, m.qinv), m.q, m.qinv);
-        else if (OP == HC_PW_ADD) r = hc_addmod(x, b[base + i], m.q);
-        else if (OP == HC_PW_SUB) r = hc_submod(x, b[base + i], m.q);
-        else if (OP == HC_PW_MULC) r = hc_mul_shoup(x, csts[l].w, csts[l].ws, m.q);
-        else if (OP == HC_PW_MAC) r = hc_addmod(out[base + i], hc_mont(x, hc_mont(b[base + i], m.r2, m.q, m.qinv), m.q, m.qinv), m.q);
-        else r = hc_addmod(x, csts[l].w, m.q);
-        out[base + i] = r;
+        if (nin == 1) {
+            const u64 x = a[base + i]; u64 r;
+            if (OP == HC_PW_MUL) r = hc_mont(x, hc_mont(b[base + i], m.r2, m.q, m.qinv), m.q, m.qinv);
+            else if (OP == HC_PW_ADD) r = hc_addmod(x, b[base + i], m.q);
+            else if (OP == HC_PW_SUB) r = hc_submod(x, b[base + i], m.q);
+            else if (OP == HC_PW_MULC) r = hc_mul_shoup(x, csts[l].w, csts[l].ws, m.q);
+            else if (OP == HC_PW_MAC) r = hc_addmod(out[base + i], hc_mont(x, hc_mont(b[base + i], m.r2, m.q, m.qinv), m.q, m.qinv), m.q);
+            else r = hc_addmod(x, csts[l].w, m.q);
+            out[base + i] = r;
+        } else {                                                               // shared b (ib == 0), products only
+            const u64 y = hc_mont(b[base + i], m.r2, m.q, m.qinv);           // MForm, once
+            u64 x[HC_MAXIMG], o[HC_MAXIMG];
+#pragma unroll
+            for (int g = 0; g < HC_MAXIMG; g++) if (g < nin) { x[g] = a[(size_t)g * ia + base + i]; if (OP == HC_PW_MAC) o[g] = out[(size_t)g * io + base + i]; }
+#pragma unroll
+            for (int g = 0; g < HC_MAXIMG; g++) if (g < nin) {
+                const u64 pr = hc_mont(x[g], y, m.q, m.qinv);
+                out[(size_t)g * io + base + i] = OP == HC_PW_MAC ? hc_addmod(o[g], pr, m.q) : pr;
+            }
+        }
     }
 }
 // the tensor step of ckks.evaluator.mulRelin for all limbs: d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1 (canonical)
-__global__ __launch_bounds__(HC_TPB) void hc_k_lv_tensor(const u64 *a0, const u64 *a1, const u64 *b0, const u64 *b1, u64 *d0, u64 *d1, u64 *d2, const HcMod *mods) {
+// blockIdx.z = image of a batch (every operand `is` words further per image)
+__global__ __launch_bounds__(HC_TPB) void hc_k_lv_tensor(const u64 *a0, const u64 *a1, const u64 *b0, const u64 *b1, u64 *d0, u64 *d1, u64 *d2, const HcMod *mods, size_t is) {
     const int l = blockIdx.y; const HcMod m = mods[l];
-    const size_t base = (size_t)l * 65536;
+    const size_t base = (size_t)l * 65536 + (size_t)blockIdx.z * is;
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
         const u64 x0 = a0[base + i], x1 = a1[base + i];
         const u64 y0 = hc_mont(b0[base + i], m.r2, m.q, m.qinv), y1 = hc_mont(b1[base + i], m.r2, m.q, m.qinv);   // MForm, as mulRelin does
@@ -348,8 +367,10 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_lv_tensor(const u64 *a0, const u6
     }
 }
 // ckks.(*Bootstrapper).modUp for one polynomial: coefficient row t (canonical mod q0) -> centred lift reduced into limb blockIdx.y
-__global__ __launch_bounds__(HC_TPB) void hc_k_mod_raise(const u64 *t, u64 *out, const HcMod *mods) {
+// blockIdx.z = image of a batch: coefficient rows 65536 words apart, outputs `is` words apart
+__global__ __launch_bounds__(HC_TPB) void hc_k_mod_raise(const u64 *t, u64 *out, const HcMod *mods, size_t is) {
     const int l = blockIdx.y; const u64 q0 = mods[0].q, q = mods[l].q, mu = mods[l].mu;
+    t += (size_t)blockIdx.z * 65536; out += (size_t)blockIdx.z * is;
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
         const u64 x = t[i];
         u64 r;
@@ -461,11 +482,17 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_permute(const u64 *in, u64 *out, 
         out[i] = in[(i & ~(size_t)0xFFFF) + hc_perm_src((u32)(i & 0xFFFF), g)];
 }
 
+// the same permutation on `rows` consecutive rows of each image of a batch: grid = (64, rows, images), images `is` words apart
+__global__ __launch_bounds__(HC_TPB) void hc_k_permute_mm(const u64 *in, u64 *out, u32 g, size_t is) {
+    const size_t base = (size_t)blockIdx.z * is + (size_t)blockIdx.y * 65536;
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) out[base + i] = in[base + hc_perm_src((u32)i, g)];
+}
+
 // evaluator.permuteNTT's tail for all limbs of both polynomials in one launch: out0 = Permute_g(d0 + c0), out1 = Permute_g(d1)
-// (d = the key switch of c1). grid = (64, level + 1, 2)
-__global__ __launch_bounds__(HC_TPB) void hc_k_rotate_finish(const u64 *d0, const u64 *d1, const u64 *c0, u64 *o0, u64 *o1, const HcMod *mods, u32 g) {
-    const int l = blockIdx.y; const u64 q = mods[l].q; const size_t base = (size_t)l * 65536;
-    if (blockIdx.z == 0) {
+// (d = the key switch of c1). grid = (64, level + 1, 2 * images): blockIdx.z = polynomial + 2 * image, images `is` words apart
+__global__ __launch_bounds__(HC_TPB) void hc_k_rotate_finish(const u64 *d0, const u64 *d1, const u64 *c0, u64 *o0, u64 *o1, const HcMod *mods, u32 g, size_t is) {
+    const int l = blockIdx.y; const u64 q = mods[l].q; const size_t base = (size_t)l * 65536 + (size_t)(blockIdx.z >> 1) * is;
+    if ((blockIdx.z & 1) == 0) {
         for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) { const size_t s = base + hc_perm_src((u32)i, g); o0[base + i] = hc_addmod(d0[s], c0[s], q); }
     } else {
         for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) o1[base + i] = d1[base + hc_perm_src((u32)i, g)];
@@ -1264,20 +1291,24 @@ struct HcBasisExt {
 // Rows in [skip_lo, skip_hi) are left untouched (a digit's own limbs during decomposition). Forward transforms use the
 // HC_FM_ALT folding, which every accepted modulus admits; outputs are canonical, so results equal the per-limb kernels'.
 struct HcRowMod { HcTwTab fwd, inv; u64 q, mu; };
-struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; int z_alpha; };
+// blockIdx.z = operand + nz * image: `nz` operands zs_* words apart (the two polynomials of a ciphertext, the digits of a key switch), and the
+// images of a batch (hc_set_batch) is_* words apart
+struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; int z_alpha; int nz; size_t is_in, is_out; };
 // z_alpha > 0: operand z is digit z of a key switch and its own limbs [z*z_alpha, min((z+1)*z_alpha, nl)) are the rows to skip
-__device__ __forceinline__ bool hc_mm_skip(const HcMm &A, int y) {
-    if (A.z_alpha > 0) { const int lo = (int)blockIdx.z * A.z_alpha, hi = lo + A.z_alpha < A.nl ? lo + A.z_alpha : A.nl; return y >= lo && y < hi; }
+__device__ __forceinline__ bool hc_mm_skip(const HcMm &A, int y, int zi) {
+    if (A.z_alpha > 0) { const int lo = zi * A.z_alpha, hi = lo + A.z_alpha < A.nl ? lo + A.z_alpha : A.nl; return y >= lo && y < hi; }
     return y >= A.skip_lo && y < A.skip_hi;
 }
 __device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl ? y : A.nq + (y - A.nl); }
+#define HC_MM_PROLOGUE \
+    const int y = blockIdx.y, zi = (int)blockIdx.z % A.nz, img = (int)blockIdx.z / A.nz; if (hc_mm_skip(A, y, zi)) return; \
+    const HcRowMod &R = A.M[hc_mm_mod(A, y)]; \
+    in += (size_t)zi * A.zs_in + (size_t)img * A.is_in; out += (size_t)zi * A.zs_out + (size_t)img * A.is_out;
 __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_COLS_LDS];
-    const int y = blockIdx.y; if (hc_mm_skip(A, y)) return;
-    const HcRowMod &R = A.M[hc_mm_mod(A, y)];
+    HC_MM_PROLOGUE
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
-    in += (size_t)blockIdx.z * A.zs_in; out += (size_t)blockIdx.z * A.zs_out;
     u64 e[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[base + (size_t)(hi * 16 + tid) * 256];
@@ -1287,11 +1318,9 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd_mm(const u64 *in, u64 *o
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_ROWS_LDS];
-    const int y = blockIdx.y; if (hc_mm_skip(A, y)) return;
-    const HcRowMod &R = A.M[hc_mm_mod(A, y)];
+    HC_MM_PROLOGUE
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
     const size_t pbase = (size_t)y * 65536;
-    in += (size_t)blockIdx.z * A.zs_in; out += (size_t)blockIdx.z * A.zs_out;
     u64 e[16];
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = in[pbase + (size_t)row * 256 + hi * 16 + tid];
@@ -1304,11 +1333,9 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, 
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_ROWS_LDS];
-    const int y = blockIdx.y; if (hc_mm_skip(A, y)) return;
-    const HcRowMod &R = A.M[hc_mm_mod(A, y)];
+    HC_MM_PROLOGUE
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
     const size_t pbase = (size_t)y * 65536;
-    in += (size_t)blockIdx.z * A.zs_in; out += (size_t)blockIdx.z * A.zs_out;
     u64 e[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) e[k] = in[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t];
@@ -1320,11 +1347,9 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *o
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_cols_inv_canon_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_COLS_LDS];
-    const int y = blockIdx.y; if (hc_mm_skip(A, y)) return;
-    const HcRowMod &R = A.M[hc_mm_mod(A, y)];
+    HC_MM_PROLOGUE
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
-    in += (size_t)blockIdx.z * A.zs_in; out += (size_t)blockIdx.z * A.zs_out;
     u64 e[16];
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = in[base + (size_t)(tid * 16 + lo) * 256];
@@ -1336,10 +1361,13 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_inv_canon_mm(const u64 *in, 
 // fast basis extension into every target row of the batch: Bs[T] holds the constants for target row T (the source-side
 // constants s, inv, mu_s are the same in all of them). One thread owns a coefficient: y_i and the fp64 overflow count v are
 // computed once, then reused for the targets T = blockIdx.y, blockIdx.y + gridDim.y, ... (rows in [skip_lo, skip_hi) excepted).
-// z_alpha > 0: operand z is digit z (constants Bs + z*rows, own limbs [z*z_alpha, ..) skipped, nl = number of Q limbs)
-__global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend_mm(const u64 *src, size_t src_stride, u64 *dst, const HcBasisExt *Bs, int rows, int skip_lo, int skip_hi, size_t zs_src, size_t zs_dst, int z_alpha, int nl) {
-    src += (size_t)blockIdx.z * zs_src; dst += (size_t)blockIdx.z * zs_dst;
-    if (z_alpha > 0) { Bs += (size_t)blockIdx.z * rows; skip_lo = (int)blockIdx.z * z_alpha; skip_hi = skip_lo + z_alpha < nl ? skip_lo + z_alpha : nl; }
+// z_alpha > 0: operand z is digit z (constants Bs + z*rows, own limbs [z*z_alpha, ..) skipped, nl = number of Q limbs).
+// blockIdx.z = operand + nz * image (images is_src / is_dst words apart)
+__global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend_mm(const u64 *src, size_t src_stride, u64 *dst, const HcBasisExt *Bs, int rows, int skip_lo, int skip_hi, size_t zs_src, size_t zs_dst, int z_alpha, int nl,
+                                                               int nz, size_t is_src, size_t is_dst) {
+    const int zi = (int)blockIdx.z % nz, img = (int)blockIdx.z / nz;
+    src += (size_t)zi * zs_src + (size_t)img * is_src; dst += (size_t)zi * zs_dst + (size_t)img * is_dst;
+    if (z_alpha > 0) { Bs += (size_t)zi * rows; skip_lo = zi * z_alpha; skip_hi = skip_lo + z_alpha < nl ? skip_lo + z_alpha : nl; }
     const HcBasisExt &B0 = Bs[0];
     const int n = B0.n;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
@@ -1367,39 +1395,52 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend_mm(const u64 *src, s
         }
     }
 }
-// acc[k][T] (+)= evk[k][T] (*)_mont c2[T] for all limbs T and both key components k (blockIdx.z); a digit's own limbs
-// [lo,hi) read the NTT-domain input cx instead of the extended c2
-// the whole inner product in one launch: acc[k][T] = sum_d evk[d][k][T] (*)_mont c2_d[T], digits laid out [beta][nt][N]
-__global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const u64 *cx, const u64 *digits, u64 *acc, const HcMod *mods, int nl, int nq, int nt, int alpha, int beta) {
-    const int T = blockIdx.y, k = blockIdx.z;
+// The inner product of a key switch in one launch, BOTH key components and ALL images of a batch per thread:
+//   acc[img][k][T] = sum_d evk[d][k][T] (*)_mont c2_{img,d}[T]      (a digit's own limbs [lo, hi) read the NTT-domain input cx instead of the extension)
+// digits laid out [beta][nt][N] per image. A key element is read ONCE whatever the number of images, a digit element once for both
+// components: per coefficient beta * (2 + n) reads and 2 n writes (one image, one component per thread: beta * (2 + 2 n)).
+// grid = (64, nt); images cx_is / dg_is / acc_is words apart.
+__global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_is, const HcMod *mods,
+                                                          int nl, int nq, int nt, int alpha, int beta, int n) {
+    const int T = blockIdx.y;
     const HcMod m = mods[T < nl ? T : nq + (T - nl)];
-    u64 *a = acc + ((size_t)k * nt + T) * 65536;
+    const size_t rowT = (size_t)T * 65536, comp = (size_t)nt * 65536;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        u64 s = 0;
+        u64 s0[HC_MAXIMG], s1[HC_MAXIMG];
         for (int d = 0; d < beta; d++) {
             const int lo = d * alpha, hi = lo + alpha < nl ? lo + alpha : nl;
-            const u64 x = (T >= lo && T < hi) ? cx[(size_t)T * 65536 + j] : digits[((size_t)d * nt + T) * 65536 + j];
-            const u64 p = hc_mont(x, evk[(((size_t)d * 2 + k) * nt + T) * 65536 + j], m.q, m.qinv);
-            s = d == 0 ? p : hc_addmod(s, p, m.q);
+            const bool own = T >= lo && T < hi;
+            const u64 kb = evk[((size_t)d * 2 * nt) * 65536 + rowT + j], ka = evk[((size_t)d * 2 * nt) * 65536 + comp + rowT + j];
+            const u64 *xs = own ? cx + rowT + j : digits + ((size_t)d * nt) * 65536 + rowT + j; const size_t xis = own ? cx_is : dg_is;
+#pragma unroll
+            for (int g = 0; g < HC_MAXIMG; g++) if (g < n) {
+                const u64 x = xs[(size_t)g * xis];
+                const u64 p0 = hc_mont(x, kb, m.q, m.qinv), p1 = hc_mont(x, ka, m.q, m.qinv);
+                s0[g] = d == 0 ? p0 : hc_addmod(s0[g], p0, m.q);
+                s1[g] = d == 0 ? p1 : hc_addmod(s1[g], p1, m.q);
+            }
         }
-        a[j] = s;
+#pragma unroll
+        for (int g = 0; g < HC_MAXIMG; g++) if (g < n) { u64 *a = acc + (size_t)g * acc_is + rowT + j; a[0] = s0[g]; a[comp] = s1[g]; }
     }
 }
-// d_k[l] = (acc[k][l] - ext[k][l]) * P^-1 mod q_l for all limbs l and both k
-__global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_mm(const u64 *acc, size_t acc_zs, const u64 *ext, size_t ext_zs, u64 *d0, u64 *d1, const HcMod *mods, const HcTw *pinv) {
-    const int l = blockIdx.y, k = blockIdx.z; const u64 q = mods[l].q; const HcTw pi = pinv[l];
-    const u64 *a = acc + (size_t)k * acc_zs + (size_t)l * 65536, *x = ext + (size_t)k * ext_zs + (size_t)l * 65536;
-    u64 *o = (k ? d1 : d0) + (size_t)l * 65536;
+// d_k[l] = (acc[k][l] - ext[k][l]) * P^-1 mod q_l for all limbs l and both k; blockIdx.z = k + 2 * image (images acc_is / ext_is / d_is words apart)
+__global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_mm(const u64 *acc, size_t acc_zs, const u64 *ext, size_t ext_zs, u64 *d0, u64 *d1, const HcMod *mods, const HcTw *pinv,
+                                                             size_t acc_is, size_t ext_is, size_t d_is) {
+    const int l = blockIdx.y, k = blockIdx.z & 1; const size_t img = blockIdx.z >> 1; const u64 q = mods[l].q; const HcTw pi = pinv[l];
+    const u64 *a = acc + img * acc_is + (size_t)k * acc_zs + (size_t)l * 65536, *x = ext + img * ext_is + (size_t)k * ext_zs + (size_t)l * 65536;
+    u64 *o = (k ? d1 : d0) + img * d_is + (size_t)l * 65536;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
         o[j] = hc_mul_shoup(hc_submod(a[j], x[j], q), pi.w, pi.ws, q);
 }
 // ModDown's last step and evaluator.permuteNTT's tail in one pass (rotations: the key-switched polynomials never reach HBM unpermuted):
 //   out_0[l][i] = ((acc_0 - ext_0) * P^-1 + c0)[l][src(i)],  out_1[l][i] = ((acc_1 - ext_1) * P^-1)[l][src(i)],  src = PermuteNTTIndex(g)
-__global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_rotate_mm(const u64 *acc, size_t acc_zs, const u64 *ext, size_t ext_zs, const u64 *c0, u64 *o0, u64 *o1, const HcMod *mods, const HcTw *pinv, u32 g) {
-    const int l = blockIdx.y, k = blockIdx.z; const u64 q = mods[l].q; const HcTw pi = pinv[l];
+__global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_rotate_mm(const u64 *acc, size_t acc_zs, const u64 *ext, size_t ext_zs, const u64 *c0, u64 *o0, u64 *o1, const HcMod *mods, const HcTw *pinv, u32 g,
+                                                                    size_t acc_is, size_t ext_is, size_t d_is) {
+    const int l = blockIdx.y, k = blockIdx.z & 1; const size_t img = blockIdx.z >> 1; const u64 q = mods[l].q; const HcTw pi = pinv[l];
     const size_t base = (size_t)l * 65536;
-    const u64 *a = acc + (size_t)k * acc_zs + base, *x = ext + (size_t)k * ext_zs + base;
-    u64 *o = (k ? o1 : o0) + base;
+    const u64 *a = acc + img * acc_is + (size_t)k * acc_zs + base, *x = ext + img * ext_is + (size_t)k * ext_zs + base;
+    u64 *o = (k ? o1 : o0) + img * d_is + base; c0 += img * d_is;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
         const u32 s = hc_perm_src((u32)j, g);
         u64 r = hc_mul_shoup(hc_submod(a[s], x[s], q), pi.w, pi.ws, q);
@@ -1408,17 +1449,18 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_rotate_mm(const u64 *a
     }
 }
 // general-level DivRoundByLastModulusNTT, all lower limbs per launch: lift (v[i] from t) and finish (out[i] = (x[i]-u[i]) * qL^-1)
-// blockIdx.z = polynomial (a ciphertext's two polynomials in one launch; xs / os = distance between them in words, modulo 2^64)
+// blockIdx.z = polynomial + np * image (a ciphertext's two polynomials xs / os words apart, the images of a batch x_is / o_is; the scratch rows t, v are dense: [z][..])
 __global__ __launch_bounds__(HC_TPB) void hc_k_rescale_lift_mm(const u64 *t, u64 *v, const HcMod *mods, int level) {
     const int i = blockIdx.y; const u64 qL = mods[level].q, h = (qL - 1) >> 1, qi = mods[i].q, mu_i = mods[i].mu, neg_h = qi - (h % qi);
     t += (size_t)blockIdx.z * 65536; v += (size_t)blockIdx.z * level * 65536;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
         v[(size_t)i * 65536 + j] = hc_barrett64(hc_csub(t[j] + h, qL) + neg_h, qi, mu_i);
 }
-__global__ __launch_bounds__(HC_TPB) void hc_k_rescale_finish_mm(const u64 *x, size_t xs, const u64 *u, size_t us, u64 *out, size_t os, const HcMod *mods, const HcTw *qlinv) {
+__global__ __launch_bounds__(HC_TPB) void hc_k_rescale_finish_mm(const u64 *x, size_t xs, const u64 *u, size_t us, u64 *out, size_t os, const HcMod *mods, const HcTw *qlinv, int np, size_t x_is, size_t o_is) {
     const int i = blockIdx.y; const u64 q = mods[i].q; const HcTw w = qlinv[i];
     const size_t b = (size_t)i * 65536;
-    x += (size_t)blockIdx.z * xs; u += (size_t)blockIdx.z * us; out += (size_t)blockIdx.z * os;
+    const size_t zp = blockIdx.z % np, img = blockIdx.z / np;
+    x += zp * xs + img * x_is; u += (size_t)blockIdx.z * us; out += zp * os + img * o_is;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
         out[b + j] = hc_mul_shoup(hc_submod(x[b + j], u[b + j], q), w.w, w.ws, q);
 }

@@ -92,6 +92,7 @@ struct hc_ctx {
     struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr; };
     std::map<int, KsPlan> ks_plan;                          // per level: basis-extension constants of every (digit, target limb)
     std::map<int, HcTw *> rescale_plan;                     // per level: qL^-1 mod q_i
+    int nb = 1; size_t bs_poly = 0, bs_qp = 0;              // image batch of the leveled entry points (hc_set_batch): images, words between the images of a polynomial / of an extended-basis pair
     const void *hoist_cx = nullptr; int hoist_level = -1;   // the polynomial whose digit decomposition ws_mm currently holds
     long chunk_nodes = 64;
     hipEvent_t ev_fork = nullptr;
@@ -457,7 +458,27 @@ extern "C" int hc_rotate_finish(hc_ctx *c, uint64_t galEl, int level, const uint
     HC_ENTER(c);
     if (level < 0 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "hc_rotate_finish: level %d outside 0..%d", level, c->nq - 1);
     if (!d0 || !d1 || !c0 || !out0 || !out1 || out0 == d0 || out0 == c0 || out1 == d1 || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_rotate_finish: bad arguments (outputs must differ from inputs, galEl odd)");
-    return hc_launch(c, "rotate_finish", hc_k_rotate_finish, dim3(64, (unsigned)(level + 1), 2), (const u64 *)d0, (const u64 *)d1, (const u64 *)c0, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, (u32)(galEl & 0x1FFFF));
+    return hc_launch(c, "rotate_finish", hc_k_rotate_finish, dim3(64, (unsigned)(level + 1), 2u * (unsigned)c->nb), (const u64 *)d0, (const u64 *)d1, (const u64 *)c0, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, (u32)(galEl & 0x1FFFF), c->bs_poly);
+}
+// ring.PermuteNTTWithIndexLvl on a polynomial at `level` (rows 0..level) / on an extended-basis pair [2][level+1+np][N], for every image of the batch
+extern "C" int hc_lv_permute(hc_ctx *c, uint64_t galEl, int level, const uint64_t *in, uint64_t *out) {
+    HC_ENTER(c);
+    if (level < 0 || level >= c->nq || !in || !out || in == out || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_lv_permute: bad arguments (in/out must differ, galEl odd)");
+    return hc_launch(c, "permute", hc_k_permute_mm, dim3(64, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), c->bs_poly);
+}
+extern "C" int hc_qp_permute2(hc_ctx *c, uint64_t galEl, int level, const uint64_t *in, uint64_t *out) {
+    HC_ENTER(c);
+    if (level < 0 || level >= c->nq || c->np < 1 || !in || !out || in == out || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_qp_permute2: bad arguments (in/out must differ, galEl odd)");
+    return hc_launch(c, "permute", hc_k_permute_mm, dim3(64, 2u * (unsigned)(level + 1 + c->np), (unsigned)c->nb), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), c->bs_qp);
+}
+// Image batch of the leveled evaluator (include/hconv.h): n images per launch, the images of an operand stride words apart
+extern "C" int hc_set_batch(hc_ctx *c, int n, size_t poly_stride_words, size_t qp_stride_words) {
+    if (!c) return HC_ERR_ARG;
+    if (n < 1 || n > HC_MAXIMG) return hc_fail(c, HC_ERR_ARG, "hc_set_batch: n=%d outside 1..%d", n, HC_MAXIMG);
+    if (n > 1 && (poly_stride_words < (size_t)HC_N || (c->np > 0 && qp_stride_words < (size_t)HC_N))) return hc_fail(c, HC_ERR_ARG, "hc_set_batch: strides must cover at least one row");
+    if (n != c->nb || poly_stride_words != c->bs_poly) c->hoist_cx = nullptr;       // a held decomposition belongs to the batch it was taken under
+    c->nb = n; c->bs_poly = n > 1 ? poly_stride_words : 0; c->bs_qp = n > 1 ? qp_stride_words : 0;
+    return HC_OK;
 }
 
 // ---- leveled polynomials: rows 0..level <-> moduli 0..level (a ring.Poly at that level); one launch covers all limbs
@@ -466,9 +487,9 @@ static int hc_lv_check(hc_ctx *c, const char *fn, int level, const void *a, cons
     if (!a || !out) return hc_fail(c, HC_ERR_ARG, "%s: null", fn);
     return HC_OK;
 }
-static dim3 hc_lv_grid(int level) { return dim3(64, (unsigned)(level + 1)); }
+// b_shared: the second operand is a plaintext common to every image of the batch (read once per coefficient: one thread does all images)
 template <int OP>
-static int hc_lv_pw(hc_ctx *c, const char *fn, int level, const uint64_t *a, const uint64_t *b, uint64_t *out, const uint64_t *consts_host) {
+static int hc_lv_pw(hc_ctx *c, const char *fn, int level, const uint64_t *a, const uint64_t *b, uint64_t *out, const uint64_t *consts_host, bool b_shared = false) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, fn, level, a, out));
     if ((OP == HC_PW_MUL || OP == HC_PW_ADD || OP == HC_PW_SUB || OP == HC_PW_MAC) && !b) return hc_fail(c, HC_ERR_ARG, "%s: null", fn);
     HcLvConsts K; memset(&K, 0, sizeof K);
@@ -477,7 +498,9 @@ static int hc_lv_pw(hc_ctx *c, const char *fn, int level, const uint64_t *a, con
         if (level >= 32) return hc_fail(c, HC_ERR_UNSUPPORTED, "%s: more than 32 limbs", fn);
         for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[l] = h_pair(consts_host[l] % q, q); }
     }
-    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, hc_lv_grid(level), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, K, (size_t)0, (size_t)0, (size_t)0, HC_ROW_IS_MOD, 0);
+    const bool inthread = b_shared && c->nb > 1;
+    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(64, (unsigned)(level + 1), inthread ? 1u : (unsigned)c->nb), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, K, (size_t)0, (size_t)0, (size_t)0, HC_ROW_IS_MOD, 0,
+                     1, inthread ? c->nb : 1, c->bs_poly, b_shared ? (size_t)0 : c->bs_poly, c->bs_poly);
 }
 // the same operations on both polynomials of a ciphertext in one launch (they may live in separate allocations; b1 == b0 for a plaintext operand)
 template <int OP>
@@ -491,7 +514,9 @@ static int hc_lv_pw2(hc_ctx *c, const char *fn, int level, const u64 *a0, const 
         for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[l] = h_pair(consts_host[l] % q, q); }
     }
     const u64 *bb0 = b0 ? b0 : a0, *bb1 = b1 ? b1 : a1;
-    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(64, (unsigned)(level + 1), 2), a0, bb0, o0, (const HcMod *)c->d_mods, K, (size_t)(a1 - a0), (size_t)(bb1 - bb0), (size_t)(o1 - o0), HC_ROW_IS_MOD, 0);
+    const bool b_shared = (OP == HC_PW_MUL || OP == HC_PW_MAC) && b0 && b0 == b1, inthread = b_shared && c->nb > 1;      // one plaintext for both polynomials = one plaintext for every image
+    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(64, (unsigned)(level + 1), inthread ? 2u : 2u * (unsigned)c->nb), a0, bb0, o0, (const HcMod *)c->d_mods, K, (size_t)(a1 - a0), (size_t)(bb1 - bb0), (size_t)(o1 - o0), HC_ROW_IS_MOD, 0,
+                     2, inthread ? c->nb : 1, c->bs_poly, b_shared ? (size_t)0 : c->bs_poly, c->bs_poly);
 }
 extern "C" int hc_lv_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1, const uint64_t *consts) {
     HC_ENTER(c);
@@ -504,27 +529,27 @@ extern "C" int hc_lv_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const
     }
     return hc_fail(c, HC_ERR_ARG, "hc_lv_op2: unknown operation %d", op);
 }
-extern "C" int hc_lv_mul(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_MUL>(c, "hc_lv_mul", level, a, b, out, nullptr); }
-extern "C" int hc_lv_mul_acc(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *acc) { return hc_lv_pw<HC_PW_MAC>(c, "hc_lv_mul_acc", level, a, b, acc, nullptr); }
+extern "C" int hc_lv_mul(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_MUL>(c, "hc_lv_mul", level, a, b, out, nullptr, true); }
+extern "C" int hc_lv_mul_acc(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *acc) { return hc_lv_pw<HC_PW_MAC>(c, "hc_lv_mul_acc", level, a, b, acc, nullptr, true); }
 extern "C" int hc_lv_add(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_ADD>(c, "hc_lv_add", level, a, b, out, nullptr); }
 extern "C" int hc_lv_sub(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_SUB>(c, "hc_lv_sub", level, a, b, out, nullptr); }
 extern "C" int hc_lv_mul_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_MULC>(c, "hc_lv_mul_const", level, a, nullptr, out, consts); }
 extern "C" int hc_lv_add_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_ADDC>(c, "hc_lv_add_const", level, a, nullptr, out, consts); }
-// batched transforms over rows of different moduli (row y <-> modulus y < nl ? y : nq + y - nl); z operands zs words apart
-static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0) {
-    HC_TRY(hc_ensure_tmp(c, (size_t)rows * z));
-    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = z_alpha;
-    const dim3 grid(16, (unsigned)rows, (unsigned)z); const size_t zt = (size_t)rows * HC_N;
-    A.zs_in = zs_in; A.zs_out = zt; HC_TRY(hc_launch(c, "cols_fwd_mm", hc_k_cols_fwd_mm, grid, in, c->ws_tmp, A));
-    A.zs_in = zt; A.zs_out = zs_out; HC_TRY(hc_launch(c, "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
+// batched transforms over rows of different moduli (row y <-> modulus y < nl ? y : nq + y - nl); z operands zs words apart, n images is words apart
+static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0, int n = 1, size_t is_in = 0, size_t is_out = 0) {
+    HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
+    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = z_alpha; A.nz = z;
+    const dim3 grid(16, (unsigned)rows, (unsigned)(z * n)); const size_t zt = (size_t)rows * HC_N, it = zt * (size_t)z;
+    A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; HC_TRY(hc_launch(c, "cols_fwd_mm", hc_k_cols_fwd_mm, grid, in, c->ws_tmp, A));
+    A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out; HC_TRY(hc_launch(c, "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
-static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out, int skip_lo = 0, int skip_hi = 0) {
-    HC_TRY(hc_ensure_tmp(c, (size_t)rows * z));
-    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = 0;
-    const dim3 grid(16, (unsigned)rows, (unsigned)z); const size_t zt = (size_t)rows * HC_N;
-    A.zs_in = zs_in; A.zs_out = zt; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, in, c->ws_tmp, A));
-    A.zs_in = zt; A.zs_out = zs_out; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
+static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out, int skip_lo = 0, int skip_hi = 0, int n = 1, size_t is_in = 0, size_t is_out = 0) {
+    HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
+    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = 0; A.nz = z;
+    const dim3 grid(16, (unsigned)rows, (unsigned)(z * n)); const size_t zt = (size_t)rows * HC_N, it = zt * (size_t)z;
+    A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, in, c->ws_tmp, A));
+    A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
 static int hc_ensure_mm(hc_ctx *c, size_t rows) {
@@ -538,26 +563,25 @@ static int hc_ensure_mm(hc_ctx *c, size_t rows) {
 }
 extern "C" int hc_lv_ntt(hc_ctx *c, int level, const uint64_t *in, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_ntt", level, in, out));
-    return hc_ntt_mm(c, in, out, level + 1, level + 1, 0, 0, 1, 0, 0);
+    return hc_ntt_mm(c, in, out, level + 1, level + 1, 0, 0, 1, 0, 0, 0, c->nb, c->bs_poly, c->bs_poly);
 }
 extern "C" int hc_lv_intt(hc_ctx *c, int level, const uint64_t *in, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_intt", level, in, out));
-    return hc_intt_mm(c, in, out, level + 1, level + 1, 1, 0, 0);
+    return hc_intt_mm(c, in, out, level + 1, level + 1, 1, 0, 0, 0, 0, c->nb, c->bs_poly, c->bs_poly);
 }
 extern "C" int hc_lv_mul_tensor(hc_ctx *c, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *d0, uint64_t *d1, uint64_t *d2) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mul_tensor", level, a0, d0));
     if (!a1 || !b0 || !b1 || !d1 || !d2) return hc_fail(c, HC_ERR_ARG, "hc_lv_mul_tensor: null");
-    return hc_launch(c, "lv_tensor", hc_k_lv_tensor, hc_lv_grid(level), (const u64 *)a0, (const u64 *)a1, (const u64 *)b0, (const u64 *)b1, (u64 *)d0, (u64 *)d1, (u64 *)d2, (const HcMod *)c->d_mods);
+    return hc_launch(c, "lv_tensor", hc_k_lv_tensor, dim3(64, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)a0, (const u64 *)a1, (const u64 *)b0, (const u64 *)b1, (u64 *)d0, (u64 *)d1, (u64 *)d2, (const HcMod *)c->d_mods, c->bs_poly);
 }
 extern "C" int hc_lv_mod_raise(hc_ctx *c, int level, const uint64_t *in_q0, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mod_raise", level, in_q0, out));
     if ((const void *)in_q0 == (const void *)out) return hc_fail(c, HC_ERR_ARG, "hc_lv_mod_raise: in and out must differ");
-    u64 *t = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&t, HC_N * sizeof(u64)));
-    int rc = hc_intt(c, 0, in_q0, t, 1);
-    if (!rc) rc = hc_launch(c, "mod_raise", hc_k_mod_raise, hc_lv_grid(level), (const u64 *)t, (u64 *)out, (const HcMod *)c->d_mods);
-    if (!rc) rc = hc_lv_ntt(c, level, out, out);
-    hipStreamSynchronize(c->stream); hcx_free(c, t);
-    return rc;
+    HC_TRY(hc_ensure_mm(c, (size_t)c->nb)); c->hoist_cx = nullptr;
+    u64 *t = c->ws_mm;                                                                  // one coefficient row per image
+    HC_TRY(hc_intt_mm(c, in_q0, t, 1, 1, 1, 0, 0, 0, 0, c->nb, c->bs_poly, (size_t)HC_N));
+    HC_TRY(hc_launch(c, "mod_raise", hc_k_mod_raise, dim3(64, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)t, (u64 *)out, (const HcMod *)c->d_mods, c->bs_poly));
+    return hc_ntt_mm(c, out, out, level + 1, level + 1, 0, 0, 1, 0, 0, 0, c->nb, c->bs_poly, c->bs_poly);
 }
 
 // getConstAndScale + scaleUpExact of the reference's dependency: a float64 constant with a
@@ -658,15 +682,23 @@ static int hc_div_round_last_n(hc_ctx *c, int level, const u64 *x, size_t xs, u6
             HC_HIP(c, hcx_h2d(c, d, h.data(), h.size() * sizeof(HcTw)));
             it = c->rescale_plan.emplace(level, d).first;
         }
-        // np polynomials per launch (blockIdx.z): x, x + xs and out, out + os (distances in words, modulo 2^64)
-        HC_TRY(hc_ensure_mm(c, (size_t)np * (level + 1)));
+        // np polynomials of each of the nb images per launch (blockIdx.z): x, x + xs and out, out + os (distances in words, modulo 2^64); images bs_poly apart
+        const int nb = c->nb, nz = np * nb;
+        HC_TRY(hc_ensure_mm(c, (size_t)nz * (level + 1)));
         c->hoist_cx = nullptr;                                   // the scratch is shared with the key switch's decomposition
-        u64 *t = c->ws_mm, *v = c->ws_mm + (size_t)np * HC_N;
+        u64 *t = c->ws_mm, *v = c->ws_mm + (size_t)nz * HC_N;      // t[z][N], v[z][level][N], z = polynomial + np * image
         // InvNTT of the last limb of every polynomial: the multi-modulus kernels over rows 0..level with rows below `level` skipped
-        HC_TRY(hc_intt_mm(c, x, t - (size_t)level * HC_N, level + 1, level + 1, np, xs, (size_t)HC_N, 0, level));
-        HC_TRY(hc_launch(c, "rescale_lift_mm", hc_k_rescale_lift_mm, dim3(64, (unsigned)level, (unsigned)np), (const u64 *)t, v, (const HcMod *)c->d_mods, level));
-        HC_TRY(hc_ntt_mm(c, v, v, level, level, 0, 0, np, (size_t)level * HC_N, (size_t)level * HC_N));
-        return hc_launch(c, "rescale_finish_mm", hc_k_rescale_finish_mm, dim3(64, (unsigned)level, (unsigned)np), x, xs, (const u64 *)v, (size_t)level * HC_N, out, os, (const HcMod *)c->d_mods, (const HcTw *)it->second);
+        HC_TRY(hc_intt_mm(c, x, t - (size_t)level * HC_N, level + 1, level + 1, np, xs, (size_t)HC_N, 0, level, nb, c->bs_poly, (size_t)np * HC_N));
+        HC_TRY(hc_launch(c, "rescale_lift_mm", hc_k_rescale_lift_mm, dim3(64, (unsigned)level, (unsigned)nz), (const u64 *)t, v, (const HcMod *)c->d_mods, level));
+        HC_TRY(hc_ntt_mm(c, v, v, level, level, 0, 0, nz, (size_t)level * HC_N, (size_t)level * HC_N));
+        return hc_launch(c, "rescale_finish_mm", hc_k_rescale_finish_mm, dim3(64, (unsigned)level, (unsigned)nz), x, xs, (const u64 *)v, (size_t)level * HC_N, out, os, (const HcMod *)c->d_mods, (const HcTw *)it->second, np, c->bs_poly, c->bs_poly);
+    }
+    if (c->nb > 1) {           // level 1 in a batch: image by image through the fused level-1 path below (not on the batched chain's route: its rescales end at level 1)
+        const int nb = c->nb; const size_t bs = c->bs_poly; int rc = HC_OK;
+        c->nb = 1;
+        for (int g = 0; g < nb && !rc; g++) rc = hc_div_round_last_n(c, level, x + (size_t)g * bs, xs, out + (size_t)g * bs, os, np);
+        c->nb = nb;
+        return rc;
     }
     if (np != 1) { HC_TRY(hc_div_round_last_n(c, level, x, 0, out, 0, 1)); return hc_div_round_last_n(c, level, x + xs, 0, out + os, 0, 1); }
     // Build a "ciphertext" whose polynomial 0 is x (constants 1) and a kernel plaintext equal to 1 everywhere.
@@ -1071,48 +1103,55 @@ static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
     *out = &pit->second;
     return HC_OK;
 }
+// scratch of one key switch at `level` for the nb images of the batch, section-major: coef[img][nl] | digits[img][beta][nt] | acc[img][2][nt] | pc[img][2][alpha] | ext[img][2][nl]
+struct HcKsScratch { u64 *coef, *digits, *acc, *pc, *ext; size_t coef_is, digits_is, acc_is, pc_is, ext_is; };
+static int hc_ks_scratch(hc_ctx *c, int level, HcKsScratch *S) {
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha; const size_t nb = (size_t)c->nb;
+    S->coef_is = (size_t)nl * HC_N; S->digits_is = (size_t)beta * nt * HC_N; S->acc_is = (size_t)2 * nt * HC_N; S->pc_is = (size_t)2 * alpha * HC_N; S->ext_is = (size_t)2 * nl * HC_N;
+    HC_TRY(hc_ensure_mm(c, nb * ((size_t)nl + (size_t)beta * nt + 2 * nt + 2 * alpha + 2 * nl)));
+    S->coef = c->ws_mm; S->digits = S->coef + nb * S->coef_is; S->acc = S->digits + nb * S->digits_is; S->pc = S->acc + nb * S->acc_is; S->ext = S->pc + nb * S->pc_is;
+    return HC_OK;
+}
 // phase 1 (rlwe.KeySwitcher.DecomposeNTT / ring.Decomposer.DecomposeAndSplit): digits[d][T] = the d-th digit of cx extended to limb
 // T (Q limbs 0..level, then the P limbs), NTT domain; a digit's own limbs are not written (phase 2 reads cx there)
-static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, u64 *coef, u64 *digits) {
+static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, const HcKsScratch &S) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
-    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
-    HC_TRY(hc_intt_mm(c, cx, coef, nl, nl, 1, 0, 0));                                                    // cxInvNTT, all limbs
-    // every digit at once (blockIdx.z = digit): extension of the digit's residues to all other limbs, then their transforms
-    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(128, 4, (unsigned)beta), (const u64 *)coef, (size_t)HC_N, digits, (const HcBasisExt *)P->bx, nt, 0, 0, (size_t)alpha * HC_N, (size_t)nt * HC_N, alpha, nl));
-    return hc_ntt_mm(c, digits, digits, nt, nl, 0, 0, beta, (size_t)nt * HC_N, (size_t)nt * HC_N, alpha);
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha, nb = c->nb;
+    HC_TRY(hc_intt_mm(c, cx, S.coef, nl, nl, 1, 0, 0, 0, 0, nb, c->bs_poly, S.coef_is));                    // cxInvNTT, all limbs
+    // every digit of every image at once (blockIdx.z = digit + beta * image): extension of the digit's residues to all other limbs, then their transforms
+    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(128, 4, (unsigned)(beta * nb)), (const u64 *)S.coef, (size_t)HC_N, S.digits, (const HcBasisExt *)P->bx, nt, 0, 0, (size_t)alpha * HC_N, (size_t)nt * HC_N, alpha, nl,
+                     beta, S.coef_is, S.digits_is));
+    return hc_ntt_mm(c, S.digits, S.digits, nt, nl, 0, 0, beta, (size_t)nt * HC_N, (size_t)nt * HC_N, alpha, nb, S.digits_is, S.digits_is);
 }
-static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1, uint64_t rot_gal, const u64 *rot_c0);
-// phase 2: inner product with the key (both components), then ModDownSplitNTTPQ
-static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const u64 *digits, u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1, uint64_t rot_gal = 0, const u64 *rot_c0 = nullptr) {
-    const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
-    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = key.beta;
-    HC_TRY(hc_launch(c, "ks_mac_all", hc_k_ks_mac_all, dim3(32, (unsigned)nt, 2), (const u64 *)key.rows, cx, digits, acc, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta));
-    return hc_ks_moddown(c, level, acc, pc, ext, d0, d1, rot_gal, rot_c0);
-}
-// ring.(*FastBasisExtender).ModDownSplitNTTPQ for the two polynomials acc[2][nt][N] (basis Q_0..Q_level, P_0..P_(np-1), canonical, NTT):
-// InvNTT of the P limbs, {P} -> every Q limb, NTT, (acc - ext) * P^-1
-static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, u64 *pc, u64 *ext, u64 *d0, u64 *d1, uint64_t rot_gal, const u64 *rot_c0) {
-    const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
+// the inner product with both components of the key, all images: acc [img][2][nt][N], images acc_is words apart
+static int hc_ks_mac(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *acc, size_t acc_is) {
     const int alpha = c->np, nl = level + 1, nt = nl + alpha;
-    {   HcMm A; A.M = c->d_rowmods; A.nl = 0; A.nq = c->nq; A.skip_lo = A.skip_hi = 0; A.z_alpha = 0;  // rows y -> modulus nq + y
-        HC_TRY(hc_ensure_tmp(c, (size_t)2 * alpha));
-        const dim3 grid(16, (unsigned)alpha, 2); const size_t zt = (size_t)alpha * HC_N;
-        A.zs_in = (size_t)nt * HC_N; A.zs_out = zt; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, (const u64 *)(acc + (size_t)nl * HC_N), c->ws_tmp, A));
-        A.zs_in = zt; A.zs_out = zt; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, pc, A));
-    }
-    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4, 2), (const u64 *)pc, (size_t)HC_N, ext, (const HcBasisExt *)P->bxdown, nl, 0, 0, (size_t)alpha * HC_N, (size_t)nl * HC_N, 0, nl));
-    HC_TRY(hc_ntt_mm(c, ext, ext, nl, nl, 0, 0, 2, (size_t)nl * HC_N, (size_t)nl * HC_N));
-    if (rot_gal)     // a rotation: + c0 and the permutation ride in ModDown's last pass (d0, d1 = the rotated ciphertext)
-        return hc_launch(c, "ks_moddown_rotate_mm", hc_k_ks_moddown_rotate_mm, dim3(32, (unsigned)nl, 2), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)ext, (size_t)nl * HC_N, rot_c0, d0, d1, (const HcMod *)c->d_mods, (const HcTw *)P->pinv, (u32)(rot_gal & 0x1FFFF));
-    return hc_launch(c, "ks_moddown_mm", hc_k_ks_moddown_mm, dim3(32, (unsigned)nl, 2), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)ext, (size_t)nl * HC_N, d0, d1, (const HcMod *)c->d_mods, (const HcTw *)P->pinv);
+    return hc_launch(c, "ks_mac_all", hc_k_ks_mac_all, dim3(64, (unsigned)nt), (const u64 *)key.rows, cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, acc, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, key.beta, c->nb);
 }
-// scratch layout of one key switch at `level`: coef[nl] | digits[beta][nt] | acc[2][nt] | pc[2][alpha] | ext[2][nl]
-struct HcKsScratch { u64 *coef, *digits, *acc, *pc, *ext; };
-static int hc_ks_scratch(hc_ctx *c, int level, HcKsScratch *S) {
-    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
-    HC_TRY(hc_ensure_mm(c, (size_t)nl + (size_t)beta * nt + 2 * nt + 2 * alpha + 2 * nl));
-    S->coef = c->ws_mm; S->digits = S->coef + (size_t)nl * HC_N; S->acc = S->digits + (size_t)beta * nt * HC_N; S->pc = S->acc + (size_t)2 * nt * HC_N; S->ext = S->pc + (size_t)2 * alpha * HC_N;
-    return HC_OK;
+// ring.(*FastBasisExtender).ModDownSplitNTTPQ for the two polynomials acc[2][nt][N] of every image (basis Q_0..Q_level, P_0..P_(np-1), canonical, NTT):
+// InvNTT of the P limbs, {P} -> every Q limb, NTT, (acc - ext) * P^-1
+static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, size_t acc_is, const HcKsScratch &S, u64 *d0, u64 *d1, uint64_t rot_gal, const u64 *rot_c0) {
+    const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha, nb = c->nb;
+    {   HcMm A; A.M = c->d_rowmods; A.nl = 0; A.nq = c->nq; A.skip_lo = A.skip_hi = 0; A.z_alpha = 0; A.nz = 2;  // rows y -> modulus nq + y
+        HC_TRY(hc_ensure_tmp(c, (size_t)2 * alpha * nb));
+        const dim3 grid(16, (unsigned)alpha, 2u * (unsigned)nb); const size_t zt = (size_t)alpha * HC_N;
+        A.zs_in = (size_t)nt * HC_N; A.is_in = acc_is; A.zs_out = zt; A.is_out = 2 * zt; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, (const u64 *)(acc + (size_t)nl * HC_N), c->ws_tmp, A));
+        A.zs_in = zt; A.is_in = 2 * zt; A.zs_out = zt; A.is_out = S.pc_is; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, S.pc, A));
+    }
+    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4, 2u * (unsigned)nb), (const u64 *)S.pc, (size_t)HC_N, S.ext, (const HcBasisExt *)P->bxdown, nl, 0, 0, (size_t)alpha * HC_N, (size_t)nl * HC_N, 0, nl,
+                     2, S.pc_is, S.ext_is));
+    HC_TRY(hc_ntt_mm(c, S.ext, S.ext, nl, nl, 0, 0, 2, (size_t)nl * HC_N, (size_t)nl * HC_N, 0, nb, S.ext_is, S.ext_is));
+    if (rot_gal)     // a rotation: + c0 and the permutation ride in ModDown's last pass (d0, d1 = the rotated ciphertext)
+        return hc_launch(c, "ks_moddown_rotate_mm", hc_k_ks_moddown_rotate_mm, dim3(32, (unsigned)nl, 2u * (unsigned)nb), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)S.ext, (size_t)nl * HC_N, rot_c0, d0, d1, (const HcMod *)c->d_mods, (const HcTw *)P->pinv, (u32)(rot_gal & 0x1FFFF),
+                         acc_is, S.ext_is, c->bs_poly);
+    return hc_launch(c, "ks_moddown_mm", hc_k_ks_moddown_mm, dim3(32, (unsigned)nl, 2u * (unsigned)nb), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)S.ext, (size_t)nl * HC_N, d0, d1, (const HcMod *)c->d_mods, (const HcTw *)P->pinv,
+                     acc_is, S.ext_is, c->bs_poly);
+}
+// phase 2: inner product with the key (both components), then ModDownSplitNTTPQ
+static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *d0, u64 *d1, uint64_t rot_gal = 0, const u64 *rot_c0 = nullptr) {
+    HC_TRY(hc_ks_mac(c, key, level, cx, S, S.acc, S.acc_is));
+    return hc_ks_moddown(c, level, S.acc, S.acc_is, S, d0, d1, rot_gal, rot_c0);
 }
 static int hc_ks_find(hc_ctx *c, const char *fn, uint64_t key_id, int level, const HcSwk **key) {
     auto it = c->swk.find(key_id);
@@ -1126,9 +1165,9 @@ extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_
     const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch", key_id, level, &key));
     if (!cx || !d0 || !d1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch: null");
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
-    HC_TRY(hc_ks_decompose_into(c, level, cx, S.coef, S.digits));
+    HC_TRY(hc_ks_decompose_into(c, level, cx, S));
     c->hoist_cx = nullptr;                                   // the scratch no longer holds a hoisted decomposition
-    return hc_ks_apply_from(c, *key, level, cx, S.digits, S.acc, S.pc, S.ext, d0, d1);
+    return hc_ks_apply_from(c, *key, level, cx, S, d0, d1);
 }
 // Hoisted key switching (evaluator.RotateHoisted, conv.go:131; the baby steps of a linear transform): the decomposition of cx is
 // computed once and kept in the context; every hc_keyswitch_hoisted with the same (cx, level) then only does the inner product with
@@ -1138,7 +1177,7 @@ extern "C" int hc_keyswitch_decompose(hc_ctx *c, int level, const uint64_t *cx) 
     HC_ENTER(c);
     if (!cx || level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_decompose: bad arguments");
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
-    HC_TRY(hc_ks_decompose_into(c, level, cx, S.coef, S.digits));
+    HC_TRY(hc_ks_decompose_into(c, level, cx, S));
     c->hoist_cx = cx; c->hoist_level = level;
     return HC_OK;
 }
@@ -1148,7 +1187,7 @@ extern "C" int hc_keyswitch_hoisted(hc_ctx *c, uint64_t key_id, int level, const
     if (!cx || !d0 || !d1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_hoisted: null");
     if (c->hoist_cx != cx || c->hoist_level != level) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch_hoisted: no decomposition of this polynomial at level %d is held (call hc_keyswitch_decompose first)", level);
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
-    return hc_ks_apply_from(c, *key, level, cx, S.digits, S.acc, S.pc, S.ext, d0, d1);
+    return hc_ks_apply_from(c, *key, level, cx, S, d0, d1);
 }
 
 // evaluator.RotateNew / ConjugateNew (permuteNTT) as ONE call: key switch of c1 with the key of galEl, + c0, permutation of both polynomials;
@@ -1162,10 +1201,10 @@ extern "C" int hc_keyswitch_rotate(hc_ctx *c, uint64_t key_id, uint64_t galEl, i
     if (hoisted) {
         if (c->hoist_cx != c1 || c->hoist_level != level) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch_rotate: no decomposition of this polynomial at level %d is held (call hc_keyswitch_decompose first)", level);
     } else {
-        HC_TRY(hc_ks_decompose_into(c, level, c1, S.coef, S.digits));
+        HC_TRY(hc_ks_decompose_into(c, level, c1, S));
         c->hoist_cx = nullptr;
     }
-    return hc_ks_apply_from(c, *key, level, c1, S.digits, S.acc, S.pc, S.ext, out0, out1, galEl, c0);
+    return hc_ks_apply_from(c, *key, level, c1, S, out0, out1, galEl, c0);
 }
 
 // ---- the key switch in two halves and arithmetic in the extended basis (Lattigo's MultiplyByDiagMatrixBSGS keeps the baby-step rotations,
@@ -1180,11 +1219,10 @@ extern "C" int hc_keyswitch_qp(hc_ctx *c, uint64_t key_id, int level, const uint
     if (hoisted) {
         if (c->hoist_cx != cx || c->hoist_level != level) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch_qp: no decomposition of this polynomial at level %d is held (call hc_keyswitch_decompose first)", level);
     } else {
-        HC_TRY(hc_ks_decompose_into(c, level, cx, S.coef, S.digits));
+        HC_TRY(hc_ks_decompose_into(c, level, cx, S));
         c->hoist_cx = nullptr;
     }
-    const int alpha = c->np, nl = level + 1, nt = nl + alpha;
-    return hc_launch(c, "ks_mac_all", hc_k_ks_mac_all, dim3(32, (unsigned)nt, 2), (const u64 *)key->rows, cx, (const u64 *)S.digits, (u64 *)acc, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, key->beta);
+    return hc_ks_mac(c, *key, level, cx, S, (u64 *)acc, c->bs_qp);
 }
 // hc_mod_down2 = ring.(*FastBasisExtender).ModDownSplitNTTPQ on the two polynomials x[2][level+1+np][N] -> out0, out1 [level+1][N]. A hoisted
 // decomposition held by the context survives it when it was taken at this same level (any other level drops it).
@@ -1194,7 +1232,7 @@ extern "C" int hc_mod_down2(hc_ctx *c, int level, const uint64_t *x, uint64_t *o
     if (!x || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_mod_down2: null");
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
     if (level != c->hoist_level) c->hoist_cx = nullptr;      // the scratch layout depends on the level: pc / ext of another level overlap the held digits
-    return hc_ks_moddown(c, level, (const u64 *)x, S.pc, S.ext, (u64 *)out0, (u64 *)out1, 0, nullptr);
+    return hc_ks_moddown(c, level, (const u64 *)x, c->bs_qp, S, (u64 *)out0, (u64 *)out1, 0, nullptr);
 }
 // hc_qp_op2: out_k = a_k (op) b_k, k = 0, 1, over the level+1+np rows of the extended basis (op: HC_LV_MUL, HC_LV_ADD, HC_LV_MUL_ACC; b1 == b0
 // for a plaintext operand; products of two NTT residues as hc_lv_mul)
@@ -1203,12 +1241,14 @@ extern "C" int hc_qp_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const
     if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: level %d outside 0..%d or no special primes", level, c->nq - 1);
     if (!a0 || !a1 || !b0 || !b1 || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: null");
     HcLvConsts K; memset(&K, 0, sizeof K);
-    const dim3 grid(64, (unsigned)(level + 1 + c->np), 2);
     const size_t as = (size_t)(a1 - a0), bs = (size_t)(b1 - b0), os = (size_t)(out1 - out0);
+    const bool b_shared = b0 == b1 && op != HC_LV_ADD, inthread = b_shared && c->nb > 1;                                  // a plaintext (an encoded diagonal): one for every image
+    const dim3 grid(64, (unsigned)(level + 1 + c->np), inthread ? 2u : 2u * (unsigned)c->nb);
+    const int nin = inthread ? c->nb : 1; const size_t ia = c->bs_qp, ib = b_shared ? (size_t)0 : c->bs_qp, io = c->bs_qp;
     switch (op) {
-        case HC_LV_MUL: return hc_launch(c, "hc_qp_op2(mul)", hc_k_lv_pointwise<HC_PW_MUL>, grid, (const u64 *)a0, (const u64 *)b0, (u64 *)out0, (const HcMod *)c->d_mods, K, as, bs, os, level + 1, c->nq);
-        case HC_LV_ADD: return hc_launch(c, "hc_qp_op2(add)", hc_k_lv_pointwise<HC_PW_ADD>, grid, (const u64 *)a0, (const u64 *)b0, (u64 *)out0, (const HcMod *)c->d_mods, K, as, bs, os, level + 1, c->nq);
-        case HC_LV_MUL_ACC: return hc_launch(c, "hc_qp_op2(mul_acc)", hc_k_lv_pointwise<HC_PW_MAC>, grid, (const u64 *)a0, (const u64 *)b0, (u64 *)out0, (const HcMod *)c->d_mods, K, as, bs, os, level + 1, c->nq);
+        case HC_LV_MUL: return hc_launch(c, "hc_qp_op2(mul)", hc_k_lv_pointwise<HC_PW_MUL>, grid, (const u64 *)a0, (const u64 *)b0, (u64 *)out0, (const HcMod *)c->d_mods, K, as, bs, os, level + 1, c->nq, 2, nin, ia, ib, io);
+        case HC_LV_ADD: return hc_launch(c, "hc_qp_op2(add)", hc_k_lv_pointwise<HC_PW_ADD>, grid, (const u64 *)a0, (const u64 *)b0, (u64 *)out0, (const HcMod *)c->d_mods, K, as, bs, os, level + 1, c->nq, 2, nin, ia, ib, io);
+        case HC_LV_MUL_ACC: return hc_launch(c, "hc_qp_op2(mul_acc)", hc_k_lv_pointwise<HC_PW_MAC>, grid, (const u64 *)a0, (const u64 *)b0, (u64 *)out0, (const HcMod *)c->d_mods, K, as, bs, os, level + 1, c->nq, 2, nin, ia, ib, io);
     }
     return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: unknown operation %d", op);
 }

@@ -296,7 +296,7 @@ def case_prep_ker(ctx, O, k=3, i_batch=1, trace=None):
 # moduli of the reference's parameter sets beyond the conv path: [7]'s level-1 prime, two ~30-bit
 # ReLU-level primes, a 60-bit StC prime; P chain of the bootstrapping evaluator
 Q1_BL = 0x10000000006E0001
-Q_MIX = [Q0, Q1_BL, 0x3FFC0001, 0x40080001, 0x1000000000B00001]
+Q_MIX = [Q0, Q1_BL, 0x3FFC0001, 0x40080001, 0x1000000000B00001, 0x3FFFFE80001, 0x3FAC0001]
 P_CHAIN = [0x1FFFFFFFFFE00001, 0x1FFFFFFFFFC80001, 0x1FFFFFFFFFB40001, 0x1FFFFFFFFF500001, 0x1FFFFFFFFF420001]
 
 
@@ -383,6 +383,129 @@ def case_keyswitch_qp_mod_down(make_ctx, make_oracle, level=4, alpha=3, nkeys=2)
     gal = pow(5, 3, 2 * N)
     idx = O.permute_index(gal)
     eq(ctx.permute(gal, want[0][0]), np.stack([O.permute(idx, r) for r in want[0][0]]), "permute over QP rows")
+    ctx.close()
+
+
+def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
+    """hc_set_batch: every leveled entry point on n images per launch (operands `stride` words apart, plaintexts and keys shared) must give,
+    for every image, the bits of the same call on that image alone (which the other cases pin to the oracle). Strides are padded so that an
+    addressing slip lands in the padding, outputs start from a non-zero fill, and the images' inputs differ."""
+    import ctypes as C
+    Q, P = Q_MIX[: level + 2], P_CHAIN[:alpha]            # one modulus above the level: rows and moduli must not be confused
+    ctx = make_ctx(Q, P)
+    L = ctx.L
+    nl, nt, beta = level + 1, level + 1 + alpha, (level + 1 + alpha - 1) // alpha
+    PS, QS = (nl + 2) * N, (2 * nt + 3) * N
+    qp_mod = lambda t: Q[t] if t < nl else P[t - nl]
+    cnt = [0]
+
+    def rnd(q):
+        cnt[0] += 1
+        return splitmix_rows(seed + 31 * cnt[0], q, N)
+
+    def poly(rows=nl):           # n images x rows
+        return np.stack([np.stack([rnd(Q[l]) for l in range(rows)]) for _ in range(n)])
+
+    def qp():
+        return np.stack([np.stack([np.stack([rnd(qp_mod(t)) for t in range(nt)]) for _ in range(2)]) for _ in range(n)])
+
+    def put(arr, stride):        # (n, words...) -> one allocation, image z at z * stride
+        b = ctx.buf(np.full(n * stride, 0xDEADBEEFCAFE, dtype=np.uint64))
+        for z in range(n):
+            b.upload(arr[z].reshape(-1), z * stride)
+        return b
+
+    def get(b, stride, words):
+        full = b.download()
+        return np.stack([full[z * stride: z * stride + words] for z in range(n)])
+
+    def run(what, fn, ins, outs, init=None):
+        """ins: [(array, 'p'|'q'|'s')] per-image polynomials / QP pairs / shared plaintexts; outs: ['p'|'q', words]"""
+        st = {"p": PS, "q": QS, "s": 0}
+        ibufs = [(ctx.buf(a) if k == "s" else put(a, st[k]), st[k]) for a, k in ins]
+        res = []
+        for mode in ("single", "batch"):
+            obufs = [put(init[i] if init else np.full((n, w), 0x1234567, dtype=np.uint64), st[k]) for i, (k, w) in enumerate(outs)]
+            if mode == "single":
+                ctx.set_batch(1)
+                for z in range(n):
+                    fn(*[b.at(z * s_) for b, s_ in ibufs], *[o.at(z * st[k]) for o, (k, w) in zip(obufs, outs)])
+            else:
+                ctx.set_batch(n, PS, QS)
+                fn(*[b.ptr for b, s_ in ibufs], *[o.ptr for o in obufs])
+            ctx.sync()
+            res.append([get(o, st[k], w) for o, (k, w) in zip(obufs, outs)])
+            for o in obufs:
+                o.free()
+        ctx.set_batch(1)
+        for b, s_ in ibufs:
+            b.free()
+        for i in range(len(outs)):
+            eq(res[1][i], res[0][i], f"batched {what} (n={n}, level={level}) output {i}")
+        return res[0]
+
+    ck = ctx._ck
+    h = ctx.h
+    PW, QW = nl * N, 2 * nt * N
+    a, b = poly(), poly()
+    pt = np.stack([rnd(Q[l]) for l in range(nl)])
+    ptq = np.stack([rnd(qp_mod(t)) for t in range(nt)])
+    consts = (C.c_uint64 * nl)(*[int(rnd(Q[l])[0]) for l in range(nl)])
+    a1, b1 = poly(), poly()
+    run("lv_ntt", lambda x, o: ck(L.hc_lv_ntt(h, level, x, o)), [(a, "p")], [("p", PW)])
+    run("lv_intt", lambda x, o: ck(L.hc_lv_intt(h, level, x, o)), [(a, "p")], [("p", PW)])
+    run("lv_mul (plaintext)", lambda x, y, o: ck(L.hc_lv_mul(h, level, x, y, o)), [(a, "p"), (pt, "s")], [("p", PW)])
+    run("lv_mul_acc", lambda x, y, o: ck(L.hc_lv_mul_acc(h, level, x, y, o)), [(a, "p"), (pt, "s")], [("p", PW)], init=[b.reshape(n, -1)])
+    run("lv_add", lambda x, y, o: ck(L.hc_lv_add(h, level, x, y, o)), [(a, "p"), (b, "p")], [("p", PW)])
+    run("lv_sub", lambda x, y, o: ck(L.hc_lv_sub(h, level, x, y, o)), [(a, "p"), (b, "p")], [("p", PW)])
+    run("lv_mul_const", lambda x, o: ck(L.hc_lv_mul_const(h, level, x, consts, o)), [(a, "p")], [("p", PW)])
+    run("lv_add_const", lambda x, o: ck(L.hc_lv_add_const(h, level, x, consts, o)), [(a, "p")], [("p", PW)])
+    for op, nm in ((1, "add"), (2, "sub")):
+        run(f"lv_op2 {nm}", lambda x0, x1, y0, y1, o0, o1, op=op: ck(L.hc_lv_op2(h, op, level, x0, x1, y0, y1, o0, o1, None)), [(a, "p"), (a1, "p"), (b, "p"), (b1, "p")], [("p", PW), ("p", PW)])
+    run("lv_op2 mul_const", lambda x0, x1, o0, o1: ck(L.hc_lv_op2(h, 3, level, x0, x1, None, None, o0, o1, consts)), [(a, "p"), (a1, "p")], [("p", PW), ("p", PW)])
+    run("lv_op2 mul (plaintext)", lambda x0, x1, y, o0, o1: ck(L.hc_lv_op2(h, 0, level, x0, x1, y, y, o0, o1, None)), [(a, "p"), (a1, "p"), (pt, "s")], [("p", PW), ("p", PW)])
+    run("lv_op2 mul_acc (plaintext)", lambda x0, x1, y, o0, o1: ck(L.hc_lv_op2(h, 7, level, x0, x1, y, y, o0, o1, None)), [(a, "p"), (a1, "p"), (pt, "s")], [("p", PW), ("p", PW)],
+        init=[b.reshape(n, -1), b1.reshape(n, -1)])
+    run("lv_mul_tensor", lambda x0, x1, y0, y1, d0, d1, d2: ck(L.hc_lv_mul_tensor(h, level, x0, x1, y0, y1, d0, d1, d2)), [(a, "p"), (a1, "p"), (b, "p"), (b1, "p")], [("p", PW)] * 3)
+    run("lv_mod_raise", lambda x, o: ck(L.hc_lv_mod_raise(h, level, x, o)), [(poly(1), "p")], [("p", PW)])
+    gal = pow(5, 7, 2 * N)
+    run("lv_permute", lambda x, o: ck(L.hc_lv_permute(h, C.c_uint64(gal), level, x, o)), [(a, "p")], [("p", PW)])
+    run("rotate_finish", lambda d0, d1, c0, o0, o1: ck(L.hc_rotate_finish(h, C.c_uint64(gal), level, d0, d1, c0, o0, o1)), [(a, "p"), (a1, "p"), (b, "p")], [("p", PW), ("p", PW)])
+    for lv in (level, 2):
+        x0, x1 = poly(lv + 1), poly(lv + 1)
+        run(f"div_round_last2 level {lv}", lambda p0, p1, o0, o1, lv=lv: ck(L.hc_div_round_last2(h, lv, p0, p1, o0, o1)), [(x0, "p"), (x1, "p")], [("p", lv * N), ("p", lv * N)])
+        run(f"div_round_last level {lv}", lambda p0, o0, lv=lv: ck(L.hc_div_round_last(h, lv, p0, o0)), [(x0, "p")], [("p", lv * N)])
+    # key switching: two keys at `level`
+    for kid in range(2):
+        evk = np.empty((beta, 2, nt, N), dtype=np.uint64)
+        for d in range(beta):
+            for k in range(2):
+                for T in range(nt):
+                    evk[d, k, T] = splitmix_rows(seed + 9000 + 1000 * kid + ((d * 2 + k) * 16 + T), qp_mod(T), N)
+        ctx.swk_load(30 + kid, level, evk)
+    K0, K1 = C.c_uint64(30), C.c_uint64(31)
+    ks = run("keyswitch", lambda x, d0, d1: ck(L.hc_keyswitch(h, K0, level, x, d0, d1)), [(a, "p")], [("p", PW), ("p", PW)])
+
+    def hoisted(x, d0, d1, e0, e1):
+        ck(L.hc_keyswitch_decompose(h, level, x)); ck(L.hc_keyswitch_hoisted(h, K0, level, x, d0, d1)); ck(L.hc_keyswitch_hoisted(h, K1, level, x, e0, e1))
+    hs = run("keyswitch_decompose + hoisted x2", hoisted, [(a, "p")], [("p", PW)] * 4)
+    eq(hs[0], ks[0], "hoisted == plain key switch (d0)"); eq(hs[1], ks[1], "hoisted == plain key switch (d1)")
+    run("keyswitch_rotate", lambda c0, c1, o0, o1: ck(L.hc_keyswitch_rotate(h, K1, C.c_uint64(gal), level, c0, c1, o0, o1, 0)), [(a, "p"), (a1, "p")], [("p", PW), ("p", PW)])
+
+    def rot_hoisted(c0, c1, o0, o1):
+        ck(L.hc_keyswitch_decompose(h, level, c1)); ck(L.hc_keyswitch_rotate(h, K1, C.c_uint64(gal), level, c0, c1, o0, o1, 1))
+    run("keyswitch_rotate hoisted", rot_hoisted, [(a, "p"), (a1, "p")], [("p", PW), ("p", PW)])
+    acc = run("keyswitch_qp", lambda x, o: ck(L.hc_keyswitch_qp(h, K0, level, x, o, 0)), [(a, "p")], [("q", QW)])[0].reshape(n, 2, nt, N)
+
+    X = qp()
+    md = run("mod_down2", lambda x, o0, o1: ck(L.hc_mod_down2(h, level, x, o0, o1)), [(acc, "q")], [("p", PW), ("p", PW)])
+    eq(md[0], ks[0], "keyswitch_qp + mod_down2 == keyswitch (d0)"); eq(md[1], ks[1], "keyswitch_qp + mod_down2 == keyswitch (d1)")
+    off = nt * N * 8
+    at1 = lambda p_: C.c_void_p(p_.value + off)
+    run("qp_op2 mul (plaintext)", lambda x, y, o: ck(L.hc_qp_op2(h, 0, level, x, at1(x), y, y, o, at1(o))), [(X, "q"), (ptq, "s")], [("q", QW)])
+    run("qp_op2 mul_acc (plaintext)", lambda x, y, o: ck(L.hc_qp_op2(h, 7, level, x, at1(x), y, y, o, at1(o))), [(X, "q"), (ptq, "s")], [("q", QW)], init=[acc.reshape(n, -1)])
+    run("qp_op2 add", lambda x, y, o: ck(L.hc_qp_op2(h, 1, level, x, at1(x), y, at1(y), o, at1(o))), [(X, "q"), (acc, "q")], [("q", QW)])
+    run("qp_permute2", lambda x, o: ck(L.hc_qp_permute2(h, C.c_uint64(gal), level, x, o)), [(X, "q")], [("q", QW)])
     ctx.close()
 
 

@@ -162,6 +162,13 @@ def test_keyswitch_hoisted():
     pc.case_keyswitch_hoisted(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), lambda Q, P: Oracle(q=Q, p=P))
 
 
+@pytest.mark.parametrize("n,level,alpha", [(3, 4, 3), (2, 5, 2)])
+def test_batched_leveled_entry_points(n, level, alpha):
+    """hc_set_batch: n images per launch through every leveled entry point == n single-image calls, bit for bit"""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    pc.case_batched_leveled(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), n=n, level=level, alpha=alpha)
+
+
 def test_free_into_a_foreign_context_is_refused(monkeypatch):
     """cached allocations (HCONV_ASYNC_ALLOC=1): a block goes back to the context it came from; handing it to another context's hc_free is an error, not a silent
     hipFree that leaves the owner's block table stale (the lifetime bug behind round 2's synchronising hc_free)"""
