@@ -163,6 +163,10 @@ int hc_keyswitch_decompose(hc_ctx *ctx, int level, const uint64_t *cx);
  *  hc_qp_op2        out_k = a_k (op) b_k for k = 0, 1 over all level+1+np rows; op = HC_LV_MUL, HC_LV_ADD or HC_LV_MUL_ACC (out_k += a_k * b_k);
  *                   b1 == b0 for a plaintext operand. (hc_permute works on any rows, so it permutes QP polynomials as they are.) */
 int hc_keyswitch_qp(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *acc, int hoisted);
+/* one rotation of MultiplyByDiagMatrixBSGS as a single call (rotateHoistedNoModDown for a baby step: pc0 = P * c0; the giant step's SwitchKeysInPlaceNoModDown +
+ * permutation: pc0 = NULL): out[2][level+1+np][N] (+)= Permute_galEl( hc_keyswitch_qp(cx) + (pc0 on the Q rows of the first component) ); accumulate != 0 adds to
+ * what out holds. The same residues as hc_keyswitch_qp + hc_lv_add + hc_qp_permute2 (+ hc_qp_op2 HC_LV_ADD); out must not be the scratch of another call. */
+int hc_keyswitch_qp_rotate(hc_ctx *ctx, uint64_t key_id, uint64_t galEl, int level, const uint64_t *pc0, const uint64_t *cx, uint64_t *out, int hoisted, int accumulate);
 int hc_mod_down2(hc_ctx *ctx, int level, const uint64_t *x, uint64_t *out0, uint64_t *out1);
 int hc_qp_op2(hc_ctx *ctx, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1);
 int hc_keyswitch_hoisted(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1);

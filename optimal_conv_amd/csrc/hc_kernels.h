@@ -1448,6 +1448,22 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_rotate_mm(const u64 *a
         o[j] = r;
     }
 }
+// One rotation of a linear transform in the extended basis (rotateHoistedNoModDown / the giant step's SwitchKeysInPlaceNoModDown + permutation of
+// MultiplyByDiagMatrixBSGS): out[k][T][i] (+)= (acc[k][T] + [k == 0, T < nl] pc0[T])[src(i)], src = PermuteNTTIndex(g). acc = the inner product
+// [2][nt][N] per image, pc0 = P * c0 (nl rows; null: nothing added), accumulate: added to what out holds. grid = (32, nt, 2 * images)
+__global__ __launch_bounds__(HC_TPB) void hc_k_qp_rotate_finish(const u64 *acc, size_t acc_is, const u64 *pc0, size_t pc0_is, u64 *out, size_t out_is, const HcMod *mods, int nl, int nq, int nt, u32 g, int accumulate) {
+    const int T = blockIdx.y, k = blockIdx.z & 1; const size_t img = blockIdx.z >> 1; const u64 q = mods[T < nl ? T : nq + (T - nl)].q;
+    const size_t row = ((size_t)k * nt + T) * 65536;
+    const u64 *a = acc + img * acc_is + row, *p = (k == 0 && T < nl && pc0 != nullptr) ? pc0 + img * pc0_is + (size_t)T * 65536 : nullptr;
+    u64 *o = out + img * out_is + row;
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        const u32 s = hc_perm_src((u32)j, g);
+        u64 r = a[s];
+        if (p != nullptr) r = hc_addmod(r, p[s], q);
+        if (accumulate) r = hc_addmod(o[j], r, q);
+        o[j] = r;
+    }
+}
 // general-level DivRoundByLastModulusNTT, all lower limbs per launch: lift (v[i] from t) and finish (out[i] = (x[i]-u[i]) * qL^-1)
 // blockIdx.z = polynomial + np * image (a ciphertext's two polynomials xs / os words apart, the images of a batch x_is / o_is; the scratch rows t, v are dense: [z][..])
 __global__ __launch_bounds__(HC_TPB) void hc_k_rescale_lift_mm(const u64 *t, u64 *v, const HcMod *mods, int level) {

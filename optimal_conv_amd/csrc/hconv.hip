@@ -1224,6 +1224,24 @@ extern "C" int hc_keyswitch_qp(hc_ctx *c, uint64_t key_id, int level, const uint
     }
     return hc_ks_mac(c, *key, level, cx, S, (u64 *)acc, c->bs_qp);
 }
+// One rotation of MultiplyByDiagMatrixBSGS kept in the extended basis: hc_keyswitch_qp of cx with the key of galEl, + pc0 (P * c0; may be null) on the Q rows of the first
+// component, permutation by galEl of all 2 (level+1+np) rows into out (accumulate != 0: added to out) - the inner product lands in the context's scratch and
+// one pass applies the rest. The same residues as hc_keyswitch_qp + hc_lv_add + hc_qp_permute2 (+ hc_qp_op2 ADD).
+extern "C" int hc_keyswitch_qp_rotate(hc_ctx *c, uint64_t key_id, uint64_t galEl, int level, const uint64_t *pc0, const uint64_t *cx, uint64_t *out, int hoisted, int accumulate) {
+    HC_ENTER(c);
+    const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_qp_rotate", key_id, level, &key));
+    if (!cx || !out || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_qp_rotate: bad arguments (galEl odd)");
+    HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
+    if (hoisted) {
+        if (c->hoist_cx != cx || c->hoist_level != level) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch_qp_rotate: no decomposition of this polynomial at level %d is held (call hc_keyswitch_decompose first)", level);
+    } else {
+        HC_TRY(hc_ks_decompose_into(c, level, cx, S));
+        c->hoist_cx = nullptr;
+    }
+    HC_TRY(hc_ks_mac(c, *key, level, cx, S, S.acc, S.acc_is));
+    const int nl = level + 1, nt = nl + c->np;
+    return hc_launch(c, "qp_rotate_finish", hc_k_qp_rotate_finish, dim3(32, (unsigned)nt, 2u * (unsigned)c->nb), (const u64 *)S.acc, S.acc_is, (const u64 *)pc0, c->bs_poly, (u64 *)out, c->bs_qp, (const HcMod *)c->d_mods, nl, c->nq, nt, (u32)(galEl & 0x1FFFF), accumulate ? 1 : 0);
+}
 // hc_mod_down2 = ring.(*FastBasisExtender).ModDownSplitNTTPQ on the two polynomials x[2][level+1+np][N] -> out0, out1 [level+1][N]. A hoisted
 // decomposition held by the context survives it when it was taken at this same level (any other level drops it).
 extern "C" int hc_mod_down2(hc_ctx *c, int level, const uint64_t *x, uint64_t *out0, uint64_t *out1) {

@@ -169,7 +169,7 @@ Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, cons
         // four sparse ones its layers use (btp2..btp5 of main.go:480-500; log_sparse 1..4)
         const bool wide2 = kind == "Resnet_crop_sparse_wide2", wide3 = kind == "Resnet_crop_sparse_wide3";
         // wide2: layers at log_sparse 1, 2, 3, stride layers at 0 (full packing) and 1; wide3: layers at 0, 1, 2, both stride layers at 0
-        c->btp = kind == "Conv" ? newBoot(c->sk, c->seed, dev, {0}) : newBoot(c->sk, c->seed, dev, wide3 ? std::vector<int>{0, 1, 2} : (wide2 ? std::vector<int>{1, 0, 2, 3} : std::vector<int>{2, 1, 3, 4}));
+        c->btp = kind == "Conv" ? newBoot(c->sk, c->seed, dev, {0}, imageBatch()) : newBoot(c->sk, c->seed, dev, wide3 ? std::vector<int>{0, 1, 2} : (wide2 ? std::vector<int>{1, 0, 2, 3} : std::vector<int>{2, 1, 3, 4}), imageBatch());
         if (kind != "Conv") { bootPrepareCompress(c->btp, in_wids[0], kp_wids[1], (wide2 || wide3) ? 0 : 1); bootPrepareCompress(c->btp, in_wids[1], kp_wids[2], wide3 ? 0 : (wide2 ? 1 : 2)); }   // main.go:163-215
         printf("Done in %s \n", dur(start).c_str());
     }
@@ -489,6 +489,48 @@ Ciphertext evalConv_BN(Context *c, const Ciphertext &ct_input, const std::vector
     return ct_res;
 }
 
+// HCONV_IMAGE_BATCH (not a reference feature): the reference pushes images through a layer one after another (test.go:128); here up to 8 go through it as
+// one set of launches - hc_conv_then_pack_batch for the convolution, hc_set_batch for the bootstrapping chain - with weights, masks, matrices and keys read once
+int imageBatch() {
+    const char *e = getenv("HCONV_IMAGE_BATCH"); const int n = e ? atoi(e) : 1;
+    if (n < 1 || n > 8) panic("HCONV_IMAGE_BATCH must be 1..8");
+    return n;
+}
+// eval.go:224-263 for the images of a batch: prep_Ker and the bias plaintext once (they depend on the layer only), conv_then_pack + the bias add of all images as ONE launch set
+std::vector<Ciphertext> evalConv_BN_batch(Context *c, const std::vector<Ciphertext> &ct_inputs, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
+                                          const std::vector<double> &bn_b, int in_wid, int ker_wid, int real_ib, int real_ob, int norm, double out_scale, bool trans) {
+    const int n = (int)ct_inputs.size();
+    if (n == 1 || getenv("HCONV_OPWISE") || c->shards.size() > 1) {      // one image (the reference's own flow, with its two timers), or modes that exist per image only
+        std::vector<Ciphertext> r; for (const Ciphertext &ct : ct_inputs) r.push_back(evalConv_BN(c, ct, ker_in, bn_a, bn_b, in_wid, ker_wid, real_ib, real_ob, norm, out_scale, trans));
+        return r;
+    }
+    if (n < 1 || n > 16) panic("evalConv_BN_batch: 1..16 images");
+    const int max_batch = N / (in_wid * in_wid);
+    auto start = now();
+    KerPlain pl_ker = prep_Ker(c, ker_in, bn_a, in_wid, ker_wid, real_ib, real_ob, norm, c->ECD_LV, 0, trans);      // eval.go:231
+    std::vector<double> b_coeffs((size_t)N, 0.0);
+    for (size_t i = 0; i < bn_b.size(); i++) for (int j = 0; j < in_wid * in_wid; j++) b_coeffs[(size_t)(norm * (int)i + j * max_batch)] = bn_b[i];   // eval.go:233-238
+    Plaintext pl_bn_b; pl_bn_b.level = 0; pl_bn_b.Scale = out_scale;
+    pl_bn_b.d = dev_upload(c, EncodeCoeffs(b_coeffs, 0, out_scale));
+    HC(c->hc, hc_ntt(c->hc, 0, pl_bn_b.d, pl_bn_b.d, 1));                                                              // eval.go:242-243
+    HC(c->hc, hc_sync(c->hc));
+    printf("Plaintext (kernel) preparation, Done in %s \n", dur(start).c_str());                                      // eval.go:244
+    start = now();
+    std::vector<Ciphertext> res((size_t)n); std::vector<const uint64_t *> ins((size_t)n), bias((size_t)n, pl_bn_b.d); std::vector<const hc_ker *> kers((size_t)n, pl_ker.h); std::vector<uint64_t *> outs((size_t)n);
+    for (int z = 0; z < n; z++) {
+        if (ct_inputs[(size_t)z].Scale != ct_inputs[0].Scale || ct_inputs[(size_t)z].level != ct_inputs[0].level) panic("evalConv_BN_batch: the images of a batch share level and scale");
+        res[(size_t)z].d = dev_rows(c, 2); res[(size_t)z].level = 0; ins[(size_t)z] = ct_inputs[(size_t)z].d; outs[(size_t)z] = res[(size_t)z].d;
+    }
+    double sc = 0;
+    if (hc_conv_then_pack_batch(c->hc, n, ins.data(), ct_inputs[0].Scale, kers.data(), pl_ker.Scale, max_batch, norm, out_scale, bias.data(), outs.data(), &sc)) panic(std::string("hc_conv_then_pack_batch: ") + hc_last_error(c->hc));   // conv.go:541-543's panic included
+    HC(c->hc, hc_sync(c->hc));
+    for (int z = 0; z < n; z++) res[(size_t)z].Scale = sc;
+    printf("Conv (with BN) Done in %s  (%d images)\n", dur(start).c_str(), n);                                       // eval.go:260
+    hc_ker_free(c->hc, pl_ker.h);
+    HC(c->hc, hc_free(c->hc, pl_bn_b.d));
+    return res;
+}
+
 // ---------------------------------------------------------------- testConv_in (test.go:15-74)
 void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool boot) {
     const std::string kind = "Conv";
@@ -517,18 +559,32 @@ void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool
         if (boot) {                                                                                    // test.go:52-53, eval.go:272-607
             const double pow_ = 4.0, alpha = 0.0;                                                      // test.go:22
             const double out_scale = exp2(round(log2((double)MODQ[0]) - (pow_ + 8)));                  // eval.go:433
-            Ciphertext ct_conv = evalConv_BN(cont, ctxt_input, ker_in, bn_a, bn_b, in_wid, ker_wid, raw_in_batch, raw_out_batch, norm, out_scale, trans);
+            // HCONV_IMAGE_BATCH = n > 1 (not a reference feature): n independent encryptions of the input go through the layer as ONE set of launches
+            const int nimg = imageBatch();
+            std::vector<Ciphertext> ins{ctxt_input};
+            for (int z = 1; z < nimg; z++) ins.push_back(EncryptNew(cont, EncodeCoeffs(input, cont->ECD_LV, cont->scale), cont->ECD_LV, cont->scale));
+            std::vector<Ciphertext> ct_conv = evalConv_BN_batch(cont, ins, ker_in, bn_a, bn_b, in_wid, ker_wid, raw_in_batch, raw_out_batch, norm, out_scale, trans);
             HC(cont->hc, hc_sync(cont->hc));                                                           // hand-over to the bootstrapper's context (another stream)
-            BootCiphertext ct_res = evalConv_BNRelu_tail(cont->btp, "Conv", 0, ct_conv.d, ct_conv.Scale, alpha, pow_, in_wid, kp_wid);
+            std::vector<const uint64_t *> conv_d; for (const Ciphertext &ct : ct_conv) conv_d.push_back(ct.d);
+            auto layer = now();
+            std::vector<BootCiphertext> ct_res = evalConv_BNRelu_tail_batch(cont->btp, "Conv", 0, conv_d, ct_conv[0].Scale, alpha, pow_, in_wid, kp_wid);
+            if (nimg > 1) printf("Bootstrapping + ReLU of %d ciphertexts done in %s \n", nimg, dur(layer).c_str());
             start = now();
-            std::vector<double> cfs = bootDecryptDecodeCoeffs(cont->btp, ct_res);
+            std::vector<double> cfs = bootDecryptDecodeCoeffs(cont->btp, ct_res[0]);
             printf("Decryption Done in %s \n", dur(start).c_str());
             std::vector<double> test_out = post_process(cfs, raw_in_wid, in_wid);
             std::vector<double> real_out = readTxt(pre + "reluout" + suf, raw_in_wid * raw_in_wid * raw_in_batch);
             printDebugCfsPlain(test_out, real_out);
+            for (int z = 1; z < nimg; z++) {                                                           // the other encryptions decrypt to the same values up to the scheme's noise
+                std::vector<double> cz = post_process(bootDecryptDecodeCoeffs(cont->btp, ct_res[(size_t)z]), raw_in_wid, in_wid);
+                double mx = 0, mr = 0; for (size_t i = 0; i < cz.size(); i++) { mx = std::max(mx, fabs(cz[i] - test_out[i])); mr = std::max(mr, fabs(cz[i] - real_out[i])); }
+                printf("image %d of the batch: max |difference| to image 0 = %.3g, to the expected output = %.3g\n", z, mx, mr);
+            }
             long nk, nks; bootStats(cont->btp, &nk, &nks);
             if (getenv("HCONV_BOOT_STATS")) printf("boot stats: %ld switching keys generated, %ld key switches\n", nk, nks);
-            freeCt(cont, ctxt_input); freeCt(cont, ct_conv); freeBootCt(cont->btp, ct_res);
+            for (Ciphertext &ct : ins) freeCt(cont, ct);
+            for (Ciphertext &ct : ct_conv) freeCt(cont, ct);
+            for (BootCiphertext &ct : ct_res) freeBootCt(cont->btp, ct);
             continue;
         }
         Ciphertext ct_result = evalConv_BN(cont, ctxt_input, ker_in, bn_a, bn_b, in_wid, ker_wid, raw_in_batch, raw_out_batch, norm, (double)(1 << 30), trans);

@@ -106,11 +106,13 @@ Ciphertext evalConv_BN(Context *cont, const Ciphertext &ct_input, const std::vec
                        const std::vector<double> &bn_b, int in_wid, int ker_wid, int real_ib, int real_ob, int norm, double out_scale, bool trans);
 void testConv_in(int in_batch, int in_wid, int ker_wid, int total_test_num, bool boot);
 // ---- convReLU chain (hconv_relu.cpp; eval.go:272-607 for kind "Conv") ----
-Boot *newBoot(const std::vector<int64_t> &sk, const Seed256 &seed, int device, const std::vector<int> &log_sparse_sets);   // one "bootstrapper" per log_sparse
+Boot *newBoot(const std::vector<int64_t> &sk, const Seed256 &seed, int device, const std::vector<int> &log_sparse_sets, int image_batch = 1);   // one "bootstrapper" per log_sparse; image_batch: images per launch set of the tail (HCONV_IMAGE_BATCH)
 void freeBoot(Boot *);
 void bootPrepareCompress(Boot *B, int in_wid, int kp_wid, int log_sparse);   // rotation keys of a stride layer's ext_double_ctxt
 // everything after evalConv_BN: Scale *= 2^pow, BootstrappConv_CtoS, evalReLU + MulByPow2, keep_ctxt, BootstrappConv_StoC
 BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sparse, const uint64_t *ct_conv_dev, double ct_scale, double alpha, double pow, int in_wid, int kp_wid);
+// the same tail for the images of a batch (same layer, same weights) as ONE set of launches; at most the image_batch the bootstrapper was built with
+std::vector<BootCiphertext> evalConv_BNRelu_tail_batch(Boot *B, const std::string &kind, int log_sparse, const std::vector<const uint64_t *> &ct_conv_dev, double ct_scale, double alpha, double pow, int in_wid, int kp_wid);
 std::vector<double> bootDecryptDecodeCoeffs(Boot *B, const BootCiphertext &ct);
 void freeBootCt(Boot *B, BootCiphertext &ct);
 void bootStats(Boot *B, long *keys, long *keyswitches);
@@ -120,6 +122,13 @@ Boot *newBootBL(const std::vector<int64_t> &sk, const Seed256 &seed, int device)
 // ct_res0/1: level-1 results of the two baseline convolutions, device [2][2][N] over (Q0, Q1 of set [7]) at `scale`; out0/1 likewise at level 1
 void blBootReLU(Boot *B, const uint64_t *ct_res0, const uint64_t *ct_res1, double scale, double alpha, double pow, uint64_t *out0, uint64_t *out1, double *out_scale);
 // eval.go:272-607 for kinds "Conv", "Conv_sparse", "StrConv_sparse" (hconv_resnet.cpp); returns a level-1, scale-2^30 ciphertext
+// evalConv_BN / evalConv_BNRelu_new for the images of a batch: kernel plaintexts prepared once, hc_conv_then_pack_batch, the tail as one launch set
+std::vector<Ciphertext> evalConv_BN_batch(Context *cont, const std::vector<Ciphertext> &ct_inputs, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
+                                          const std::vector<double> &bn_b, int in_wid, int ker_wid, int real_ib, int real_ob, int norm, double out_scale, bool trans);
+std::vector<Ciphertext> evalConv_BNRelu_new_batch(Context *cont, const std::vector<Ciphertext> &ct_inputs, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
+                                                  const std::vector<double> &bn_b, double alpha, double pow, int in_wid, int kp_wid, int ker_wid, int real_ib, int real_ob,
+                                                  int norm, int log_sparse, const std::string &kind);
+int imageBatch();                                // HCONV_IMAGE_BATCH (1..8; default 1): images that go through a layer as one launch set
 Ciphertext evalConv_BNRelu_new(Context *cont, const Ciphertext &ct_input, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
                                const std::vector<double> &bn_b, double alpha, double pow, int in_wid, int kp_wid, int ker_wid, int real_ib, int real_ob,
                                int norm, int log_sparse, const std::string &kind);

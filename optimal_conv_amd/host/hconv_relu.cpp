@@ -88,20 +88,43 @@ struct Boot {
     long n_keyswitch = 0, n_keys = 0;
     std::map<std::string, DPt> pt_cache;                     // encoded 0/1 masks (keep_ctxt, ext_double_ctxt), by what defines them
 
-    // ---------------- memory
+    // ---------------- memory and the image batch
+    // HCONV_IMAGE_BATCH = nb_max > 1: every ciphertext object below stands for the ciphertexts of nb <= nb_max images going through the layer together (test.go:128 runs
+    // them one after another): a polynomial block holds nb_max x NQ rows, image z at z * NQ rows, an extended-basis block nb_max x 2 (NQ + NP) rows; hc_set_batch makes
+    // every leveled ABI call cover the nb images in one launch set (plaintexts - masks, diagonals, constants - and switching keys are shared and read once per launch).
+    int nb_max = 1, nb = 1;
+    size_t poly_stride() const { return (size_t)NQ * N; }
+    size_t qp_stride() const { return (size_t)2 * (NQ + P.size()) * N; }
+    void set_nb(int n) { if (n < 1 || n > nb_max) panic("image batch out of range"); nb = n; HCR(hc_set_batch(hc, n, poly_stride(), qp_stride())); }
+    struct Single {            // scope in which the ABI acts on ONE polynomial per call (encoding plaintexts, debugging)
+        Boot *b; int saved;
+        explicit Single(Boot *b_) : b(b_), saved(b_->nb) { if (saved != 1) b->set_nb(1); }
+        ~Single() { if (saved != 1) b->set_nb(saved); }
+    };
     std::shared_ptr<uint64_t> block() {
         uint64_t *d;
         if (!pool.empty()) { d = pool.back(); pool.pop_back(); }
-        else { void *v = nullptr; HCR(hc_malloc(hc, (size_t)NQ * N * 8, &v)); d = (uint64_t *)v; }
+        else { void *v = nullptr; HCR(hc_malloc(hc, (size_t)nb_max * NQ * N * 8, &v)); d = (uint64_t *)v; }
         return std::shared_ptr<uint64_t>(d, [this](uint64_t *x) { pool.push_back(x); });
     }
-    // two polynomials in the extended basis, [2][level+1+np][N] at the start of a 2 (NQ+NP)-row allocation (hc_keyswitch_qp / hc_mod_down2 layout)
+    std::vector<uint64_t *> pool1;
+    std::shared_ptr<uint64_t> block1() {               // one polynomial whatever the batch: plaintexts
+        uint64_t *d;
+        if (!pool1.empty()) { d = pool1.back(); pool1.pop_back(); }
+        else { void *v = nullptr; HCR(hc_malloc(hc, (size_t)NQ * N * 8, &v)); d = (uint64_t *)v; }
+        return std::shared_ptr<uint64_t>(d, [this](uint64_t *x) { pool1.push_back(x); });
+    }
+    // two polynomials in the extended basis, [2][level+1+np][N] at the start of a 2 (NQ+NP)-row allocation (hc_keyswitch_qp / hc_mod_down2 layout), per image
     std::vector<uint64_t *> pool_qp;
     std::shared_ptr<uint64_t> block_qp2() {
         uint64_t *d;
         if (!pool_qp.empty()) { d = pool_qp.back(); pool_qp.pop_back(); }
-        else { void *v = nullptr; HCR(hc_malloc(hc, (size_t)2 * (NQ + P.size()) * N * 8, &v)); d = (uint64_t *)v; }
+        else { void *v = nullptr; HCR(hc_malloc(hc, (size_t)nb_max * qp_stride() * 8, &v)); d = (uint64_t *)v; }
         return std::shared_ptr<uint64_t>(d, [this](uint64_t *x) { pool_qp.push_back(x); });
+    }
+    // rows [0, rows) of every image's polynomial: device-to-device copies between batched blocks
+    void copy_rows(uint64_t *dst, const uint64_t *src, size_t rows, size_t dst_off_rows = 0, size_t src_off_rows = 0) {
+        for (int z = 0; z < nb; z++) HCR(hc_copy(hc, dst + (size_t)z * poly_stride() + dst_off_rows * N, src + (size_t)z * poly_stride() + src_off_rows * N, rows * N * 8));
     }
     DCt new_ct(int level, int deg, double scale) { DCt c; c.deg = deg; c.level = level; c.scale = scale; for (int i = 0; i <= deg; i++) c.p[i] = block(); return c; }
     static DCt drop_to(const DCt &a, int level) { if (level > a.level) panic("drop_to: level above the ciphertext's"); DCt c = a; c.level = level; return c; }
@@ -203,7 +226,7 @@ struct Boot {
         if (a0.deg == 1 && b0.deg == 1) { HCR(hc_lv_op2(hc, HC_LV_ADD, L, a0.p[0].get(), a0.p[1].get(), b0.p[0].get(), b0.p[1].get(), r.p[0].get(), r.p[1].get(), nullptr)); return r; }   // both polynomials per launch
         for (int d = 0; d <= r.deg; d++) {
             if (d <= a0.deg && d <= b0.deg) HCR(hc_lv_add(hc, L, a0.p[d].get(), b0.p[d].get(), r.p[d].get()));
-            else HCR(hc_copy(hc, r.p[d].get(), (d <= a0.deg ? a0 : b0).p[d].get(), (size_t)(L + 1) * N * 8));
+            else copy_rows(r.p[d].get(), (d <= a0.deg ? a0 : b0).p[d].get(), (size_t)(L + 1));
         }
         return r;
     }
@@ -307,6 +330,7 @@ struct Boot {
     }
     // debugging aid (HCONV_DEBUG_BOOT): decrypt on the limbs 0, 1 (needs |message| * scale < Q0 Q1 / 2) and decode to slots
     std::vector<cplx> debug_slots(const DCt &a) {
+        Single one(this);                                          // image 0 of a batch
         const int L = std::min(a.level, 1); auto t = block();
         HCR(hc_lv_mul(hc, L, a.p[1].get(), d_sk, t.get())); HCR(hc_lv_add(hc, L, a.p[0].get(), t.get(), t.get())); HCR(hc_lv_intt(hc, L, t.get(), t.get()));
         std::vector<uint64_t> m((size_t)(L + 1) * N); HCR(hc_download(hc, m.data(), t.get(), m.size() * 8));
@@ -338,7 +362,8 @@ struct Boot {
     }
     DPt encode(const std::vector<cplx> &slots, int level, double scale) {
         std::vector<uint64_t> rows = enc.Encode(slots, scale, Q.data(), level + 1);
-        DPt pt; pt.level = level; pt.scale = scale; pt.p = block();
+        Single one(this);
+        DPt pt; pt.level = level; pt.scale = scale; pt.p = block1();
         HCR(hc_upload(hc, pt.p.get(), rows.data(), rows.size() * 8));
         HCR(hc_lv_ntt(hc, level, pt.p.get(), pt.p.get()));
         return pt;
@@ -355,6 +380,7 @@ struct Boot {
             auto it = sub_enc.find(lg + 1); if (it == sub_enc.end()) it = sub_enc.emplace(lg + 1, Encoder(lg + 1)).first;
             rows = enc.EncodeSparse(it->second, slots, scale, mods.data(), nl + np);
         }
+        Single one(this);
         DPt pt; pt.level = level; pt.scale = scale;
         { void *v = nullptr; HCR(hc_malloc(hc, rows.size() * 8, &v)); uint64_t *d = (uint64_t *)v; hc_ctx *h = hc; pt.p = std::shared_ptr<uint64_t>(d, [h](uint64_t *x) { hc_free(h, x); }); }
         HCR(hc_upload(hc, pt.p.get(), rows.data(), rows.size() * 8));
@@ -559,21 +585,24 @@ struct Boot {
         if (!babies.empty()) {
             const uint64_t *cx = hoist_c1 ? hoist_c1 : ct.p[1].get();
             HCR(hc_keyswitch_decompose(hc, Lb, cx));
-            auto acc = block_qp2(), wide = hoist_c1 ? block_qp2() : std::shared_ptr<uint64_t>();
+            auto wide = hoist_c1 ? block_qp2() : std::shared_ptr<uint64_t>();
+            if (hoist_c1 && nb != 1) panic("linear_transform_qp: the stale-digit hoisting of the stock Bootstrapp runs one image at a time");
             for (int b : babies) {
                 const uint64_t gal = gal_rot(b);
-                if (!hoist_c1) HCR(hc_keyswitch_qp(hc, key(gal, L, 1), L, cx, acc.get(), 1));
+                auto r = block_qp2();
+                if (!hoist_c1) HCR(hc_keyswitch_qp_rotate(hc, key(gal, L, 1), gal, L, pc0.get(), cx, r.get(), 1, 0));       // inner product, + P c0, permutation: one call
                 else {                                                                                                  // [2][Lb+1+np][N] -> rows 0..L and the P rows of each component
+                    auto acc = block_qp2();
                     HCR(hc_keyswitch_qp(hc, key(gal, Lb, 1), Lb, cx, wide.get(), 1));
                     const size_t zw = (size_t)(Lb + 1 + np) * N;
                     for (int k = 0; k < 2; k++) {
                         HCR(hc_copy(hc, acc.get() + (size_t)k * zs, wide.get() + (size_t)k * zw, (size_t)nl * N * 8));
                         HCR(hc_copy(hc, acc.get() + (size_t)k * zs + (size_t)nl * N, wide.get() + (size_t)k * zw + (size_t)(Lb + 1) * N, (size_t)np * N * 8));
                     }
+                    HCR(hc_lv_add(hc, L, acc.get(), pc0.get(), acc.get()));                                              // the Q rows of the first component
+                    HCR(hc_qp_permute2(hc, gal, L, acc.get(), r.get()));
                 }
                 n_keyswitch++;
-                HCR(hc_lv_add(hc, L, acc.get(), pc0.get(), acc.get()));                                                  // the Q rows of the first component
-                auto r = block_qp2(); HCR(hc_permute(hc, gal, acc.get(), r.get(), 2 * nt));
                 rot[b] = r;
             }
         }
@@ -593,11 +622,8 @@ struct Boot {
             if (haveA) HCR(hc_mod_down2(hc, L, A.get(), a0.get(), a1.get()));
             else { HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), zeros.data(), a0.get())); HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), zeros.data(), a1.get())); }
             if (row.count(0)) { const uint64_t *pt = row.at(0).p.get(); HCR(hc_lv_op2(hc, HC_LV_MUL_ACC, L, ct.p[0].get(), ct.p[1].get(), pt, pt, a0.get(), a1.get(), nullptr)); }
-            auto e = block_qp2();
-            HCR(hc_keyswitch_qp(hc, key(gal, L, 2), L, a1.get(), e.get(), 0)); n_keyswitch++;
-            { auto t = block(); HCR(hc_permute(hc, gal, a0.get(), t.get(), nl)); add_to_res(0, t); }
-            if (!haveB) { HCR(hc_permute(hc, gal, e.get(), B.get(), 2 * nt)); haveB = true; }
-            else { auto t = block_qp2(); HCR(hc_permute(hc, gal, e.get(), t.get(), 2 * nt)); HCR(hc_qp_op2(hc, HC_LV_ADD, L, B.get(), B.get() + zs, t.get(), t.get() + zs, B.get(), B.get() + zs)); }
+            { auto t = block(); HCR(hc_lv_permute(hc, gal, L, a0.get(), t.get())); add_to_res(0, t); }
+            HCR(hc_keyswitch_qp_rotate(hc, key(gal, L, 2), gal, L, nullptr, a1.get(), B.get(), 0, haveB ? 1 : 0)); n_keyswitch++; haveB = true;     // SwitchKeysInPlaceNoModDown, permuted into the accumulators
         }
         if (index.count(0)) for (int i : index[0]) if (i) {
             const uint64_t *pt = lt.giant.at(0).at(i).p.get(); uint64_t *r = rot[i].get();
@@ -828,7 +854,7 @@ struct Boot {
             for (int j = 0; j < N; j++) h[(size_t)j] = sk[(size_t)j] >= 0 ? (uint64_t)sk[(size_t)j] : q - (uint64_t)(-sk[(size_t)j]);
             HCR(hc_upload(hc, d_sk + (size_t)m * N, h.data(), (size_t)N * 8)); HCR(hc_ntt(hc, m, d_sk + (size_t)m * N, d_sk + (size_t)m * N, 1));
         }
-        mono_i = block();
+        mono_i = block1();
         { std::vector<uint64_t> m((size_t)NQ * N, 0); for (int l = 0; l < NQ; l++) m[(size_t)l * N + N / 2] = 1; HCR(hc_upload(hc, mono_i.get(), m.data(), m.size() * 8)); HCR(hc_lv_ntt(hc, NQ - 1, mono_i.get(), mono_i.get())); }
         // Chebyshev interpolant of cos(2 pi (K u - 1/4) / 2^r) on [-1,1]
         const int m = SIN_DEG + 1; sine.assign((size_t)m, 0.0);
@@ -979,8 +1005,8 @@ struct Boot {
                     if (!prev_c1) panic("SlotsToCoeffs: a matrix below the ciphertext's level must follow one at that level");
                     const int Lh = ct.level, nk = lt.level + 1;
                     auto y = block();                                                                            // limbs 0..matrix level of c1, the previous input's limbs above
-                    HCR(hc_copy(hc, y.get(), ct.p[1].get(), (size_t)nk * N * 8));
-                    HCR(hc_copy(hc, y.get() + (size_t)nk * N, prev_c1.get() + (size_t)nk * N, (size_t)(Lh + 1 - nk) * N * 8));
+                    copy_rows(y.get(), ct.p[1].get(), (size_t)nk);
+                    copy_rows(y.get(), prev_c1.get(), (size_t)(Lh + 1 - nk), (size_t)nk, (size_t)nk);
                     ct = lt_rescale(linear_transform_qp(drop_to(ct, lt.level), lt, y.get(), Lh), s_in);
                 } else { prev_c1 = ct.p[1]; ct = lt_rescale(linear_transform(ct, lt), s_in); }
             }
@@ -1095,8 +1121,9 @@ static DCt keep_ctxt(Boot *B, const DCt &ct, const std::vector<int> &idx, const 
 }
 
 // ---------------------------------------------------------------- public surface (hconv_host.hpp)
-Boot *newBoot(const std::vector<int64_t> &sk, const Seed256 &seed, int device, const std::vector<int> &log_sparse_sets) {
-    Boot *b = new Boot(); b->build(sk, seed, device);
+Boot *newBoot(const std::vector<int64_t> &sk, const Seed256 &seed, int device, const std::vector<int> &log_sparse_sets, int image_batch) {
+    if (image_batch < 1 || image_batch > 8) panic("image batch must be 1..8");
+    Boot *b = new Boot(); b->nb_max = image_batch; b->build(sk, seed, device);
     for (int ls : log_sparse_sets) b->set(ls);
     return b;
 }
@@ -1114,6 +1141,8 @@ void freeBoot(Boot *b) {
     b->pool.clear();
     for (uint64_t *blk : b->pool_qp) hc_free(b->hc, blk);
     b->pool_qp.clear();
+    for (uint64_t *blk : b->pool1) hc_free(b->hc, blk);
+    b->pool1.clear();
     if (b->d_sk) hc_free(b->hc, b->d_sk);
     hc_ctx_destroy(b->hc); delete b;      // the switching keys are owned by the context
 }
@@ -1131,37 +1160,48 @@ static void profile_dump(Boot *B, const char *label) {
     hc_profile_get(hc, nullptr, nullptr, nullptr);
 }
 
-// test mode (HCONV_CHAIN_REPLAY / HCONV_CHAIN_REPLAY_BL): SHA-256 of each polynomial's rows 0..level, as gotrace's emit_ct
-static void replay_digest_line(Boot *B, const char *what, const DCt &c) {
+// test mode (HCONV_CHAIN_REPLAY / HCONV_CHAIN_REPLAY_BL): SHA-256 of each polynomial's rows 0..level, as gotrace's emit_ct; one line per image of the
+// batch ("replay digest" for the first, "replay digest[z]" for image z > 0; `first_image` = the number of the batch's first image)
+static void replay_digest_line(Boot *B, const char *what, const DCt &c, int first_image = 0) {
     hc_ctx *hc = B->hc;
-    std::string line = std::string("replay digest ") + what + " level " + std::to_string(c.level);
-    char sc[40]; snprintf(sc, sizeof sc, " scale %.17g", c.scale); line += sc;
-    for (int d = 0; d <= c.deg; d++) { std::vector<uint64_t> rows((size_t)(c.level + 1) * N); HCR(hc_download(hc, rows.data(), c.p[d].get(), rows.size() * 8)); Sha256 h; h.update(rows.data(), rows.size() * 8); line += " " + h.hex(); }
-    printf("%s\n", line.c_str());
+    for (int z = 0; z < B->nb; z++) {
+        const int img = first_image + z;
+        std::string line = std::string("replay digest") + (img ? "[" + std::to_string(img) + "] " : " ") + what + " level " + std::to_string(c.level);
+        char sc[40]; snprintf(sc, sizeof sc, " scale %.17g", c.scale); line += sc;
+        for (int d = 0; d <= c.deg; d++) { std::vector<uint64_t> rows((size_t)(c.level + 1) * N); HCR(hc_download(hc, rows.data(), c.p[d].get() + (size_t)z * B->poly_stride(), rows.size() * 8)); Sha256 h; h.update(rows.data(), rows.size() * 8); line += " " + h.hex(); }
+        printf("%s\n", line.c_str());
+    }
 }
 // eval.go:437-565: everything after the convolution(s). ct_conv = the level-0 convolution result at out_scale
 // 2^(round(log2 Q0) - (pow+8)). kind "Conv" (log_sparse 0, two ciphertexts through sine/ReLU, keep_ctxt masks of gen_keep_vec),
 // "Conv_sparse" (one packed ciphertext, gen_keep_vec_sparse), "StrConv_sparse" (one packed ciphertext, ext_double_ctxt with
 // gen_comprs_sparse: kp_wid is then the NEXT block's raw width).
-BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sparse, const uint64_t *ct_conv_dev, double ct_scale, double alpha, double pow_, int in_wid, int kp_wid) {
+// The images of a batch (ct_conv_dev.size() <= the bootstrapper's HCONV_IMAGE_BATCH) go through the tail as ONE set of launches; results in the same order.
+std::vector<BootCiphertext> evalConv_BNRelu_tail_batch(Boot *B, const std::string &kind, int log_sparse, const std::vector<const uint64_t *> &ct_conv_dev, double ct_scale, double alpha, double pow_, int in_wid, int kp_wid) {
     hc_ctx *hc = B->hc;
     const bool stride = kind == "StrConv_sparse" || kind == "StrConv_sparse_full", sparse = kind == "Conv_sparse" || stride;
     if (!sparse && kind != "Conv") panic("No kind!");
     if (!sparse && log_sparse != 0) panic("No cases for log_sparse");
+    const int nimg = (int)ct_conv_dev.size();
+    if (nimg < 1 || nimg > B->nb_max) panic("evalConv_BNRelu_tail: more images than the bootstrapper's image batch (HCONV_IMAGE_BATCH)");
+    B->set_nb(nimg);
     DCt ct = B->new_ct(0, 1, ct_scale * pow(2.0, pow_));                                            // eval.go:437
-    for (int d = 0; d < 2; d++) HCR(hc_copy(hc, ct.p[d].get(), ct_conv_dev + (size_t)d * N, (size_t)N * 8));
-    // ct_conv_dev belongs to ANOTHER context (the convolution's): the copy above is queued on this context's stream, and the caller frees
-    // the source as soon as this function returns. Wait for the copy (the stream holds nothing else at this point) so that the hand-over
+    for (int z = 0; z < nimg; z++) for (int d = 0; d < 2; d++) HCR(hc_copy(hc, ct.p[d].get() + (size_t)z * B->poly_stride(), ct_conv_dev[(size_t)z] + (size_t)d * N, (size_t)N * 8));
+    // ct_conv_dev belongs to ANOTHER context (the convolution's): the copies above are queued on this context's stream, and the caller frees
+    // the sources as soon as this function returns. Wait for them (the stream holds nothing else at this point) so that the hand-over
     // does not depend on how the two contexts' streams happen to be scheduled (cached allocations recycle a freed block at once).
     HCR(hc_sync(hc));
-    auto replay_digest = [&](const char *what, const DCt &c) { replay_digest_line(B, what, c); };
-    if (B->replay_seed) {                                           // the input gotrace -chain plants at the entry of BootstrappConv_CtoS: SEED_OPIN(4000, 0, poly, limb 0)
+    // test mode: image z of the batch is image first_image + z of the replay; image 0 carries the input gotrace -chain plants at the entry of
+    // BootstrappConv_CtoS - SEED_OPIN(4000, 0, poly, limb 0) -, image i > 0 the same generator keyed seed + 0x1000003 i (keys are common)
+    const int first_image = B->replay_seed && testOnlyEnv("HCONV_REPLAY_IMAGE0") ? atoi(testOnlyEnv("HCONV_REPLAY_IMAGE0")) : 0;
+    auto replay_digest = [&](const char *what, const DCt &c) { replay_digest_line(B, what, c, first_image); };
+    if (B->replay_seed) {
         if (sparse) panic("HCONV_CHAIN_REPLAY covers the full-slot chain only");
         std::vector<uint64_t> row((size_t)N);
-        for (int k = 0; k < 2; k++) {
-            const uint64_t sd = B->replay_seed + ((6ull << 32) | (uint64_t)((((4000 * 2 + 0) * 4 + k) * 64) + 0));
+        for (int z = 0; z < nimg; z++) for (int k = 0; k < 2; k++) {
+            const uint64_t sd = B->replay_seed + 0x1000003ull * (uint64_t)(first_image + z) + ((6ull << 32) | (uint64_t)((((4000 * 2 + 0) * 4 + k) * 64) + 0));
             for (int j = 0; j < N; j++) row[(size_t)j] = Boot::splitmix_at(sd, (uint64_t)j) % B->Q[0];
-            HCR(hc_upload(hc, ct.p[k].get(), row.data(), (size_t)N * 8));
+            HCR(hc_upload(hc, ct.p[k].get() + (size_t)z * B->poly_stride(), row.data(), (size_t)N * 8));
         }
     }
     const bool prof = getenv("HCONV_PROFILE") && atoi(getenv("HCONV_PROFILE"));
@@ -1198,11 +1238,18 @@ BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sp
     printf("Boot (StoC) Done in %s \n", dur(start).c_str());
     if (B->replay_seed) replay_digest("final", res);
     if (prof) { profile_dump(B, (kind + " log_sparse " + std::to_string(log_sparse)).c_str()); HCR(hc_set_option(hc, "profile", 0)); }
-    BootCiphertext out; out.level = res.level; out.Scale = res.scale;
-    { void *v = nullptr; HCR(hc_malloc(hc, (size_t)2 * (res.level + 1) * N * 8, &v)); out.d = (uint64_t *)v; }
-    for (int d = 0; d < 2; d++) HCR(hc_copy(hc, out.d + (size_t)d * (res.level + 1) * N, res.p[d].get(), (size_t)(res.level + 1) * N * 8));
+    std::vector<BootCiphertext> outs((size_t)nimg);
+    for (int z = 0; z < nimg; z++) {
+        BootCiphertext &out = outs[(size_t)z]; out.level = res.level; out.Scale = res.scale;
+        { void *v = nullptr; HCR(hc_malloc(hc, (size_t)2 * (res.level + 1) * N * 8, &v)); out.d = (uint64_t *)v; }
+        for (int d = 0; d < 2; d++) HCR(hc_copy(hc, out.d + (size_t)d * (res.level + 1) * N, res.p[d].get() + (size_t)z * B->poly_stride(), (size_t)(res.level + 1) * N * 8));
+    }
     HCR(hc_sync(hc));
-    return out;
+    B->set_nb(1);
+    return outs;
+}
+BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sparse, const uint64_t *ct_conv_dev, double ct_scale, double alpha, double pow_, int in_wid, int kp_wid) {
+    return evalConv_BNRelu_tail_batch(B, kind, log_sparse, {ct_conv_dev}, ct_scale, alpha, pow_, in_wid, kp_wid)[0];
 }
 // ---------------------------------------------------------------- baseline: Bootstrapp + ReLU (test_BL.go:113-168)
 Boot *newBootBL(const std::vector<int64_t> &sk, const Seed256 &seed, int device) {

@@ -48,13 +48,15 @@ static void mul_monomial_l0(Context *c, Ciphertext &ct, int idx, bool negative) 
     HCX(c->hc, hc_free(c->hc, pt));
 }
 
-// eval.go:272-607 for the kinds the conv / convReLU / resnet command lines reach
-Ciphertext evalConv_BNRelu_new(Context *cont, const Ciphertext &ct_input, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
-                               const std::vector<double> &bn_b, double alpha, double pow_, int in_wid, int kp_wid, int ker_wid, int real_ib, int real_ob,
-                               int norm, int log_sparse, const std::string &kind) {
+// eval.go:272-607 for the kinds the conv / convReLU / resnet command lines reach, for the images of a batch (ct_inputs.size() <= HCONV_IMAGE_BATCH): every image
+// sees the operations of the reference's per-image flow, but a launch covers all of them (hc_conv_then_pack_batch; hc_set_batch inside the tail)
+std::vector<Ciphertext> evalConv_BNRelu_new_batch(Context *cont, const std::vector<Ciphertext> &ct_inputs, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
+                                                  const std::vector<double> &bn_b, double alpha, double pow_, int in_wid, int kp_wid, int ker_wid, int real_ib, int real_ob,
+                                                  int norm, int log_sparse, const std::string &kind) {
     if (!cont->btp) panic("evalConv_BNRelu_new needs a context built with boot = true");
+    const int nimg = (int)ct_inputs.size();
     const double out_scale = exp2(round(log2((double)PARAMS6_Q[0]) - (pow_ + 8)));                       // eval.go:433
-    Ciphertext ct_conv;
+    std::vector<Ciphertext> ct_conv;
     if (kind == "StrConv_sparse") {                                                                       // eval.go:335-392 (modify_ker, !full)
         std::vector<double> a0((size_t)real_ob / 2), a1((size_t)real_ob / 2), b0((size_t)real_ob / 2), b1((size_t)real_ob / 2);
         for (int i = 0; i < real_ob / 2; i++) { a0[(size_t)i] = bn_a[(size_t)(2 * i)]; a1[(size_t)i] = bn_a[(size_t)(2 * i + 1)]; b0[(size_t)i] = bn_b[(size_t)(2 * i)]; b1[(size_t)i] = bn_b[(size_t)(2 * i + 1)]; }
@@ -63,36 +65,47 @@ Ciphertext evalConv_BNRelu_new(Context *cont, const Ciphertext &ct_input, const 
             k0[(size_t)(k * real_ib * real_ob / 2 + (i * real_ob / 2 + j))] = ker_in[(size_t)(k * real_ib * real_ob + (i * real_ob + 2 * j))];
             k1[(size_t)(k * real_ib * real_ob / 2 + (i * real_ob / 2 + j))] = ker_in[(size_t)(k * real_ib * real_ob + (i * real_ob + 2 * j + 1))];
         }
-        Ciphertext r1 = evalConv_BN(cont, ct_input, k0, a0, b0, in_wid, ker_wid, real_ib, real_ob / 2, norm / 2, out_scale, false);
-        Ciphertext r2 = evalConv_BN(cont, ct_input, k1, a1, b1, in_wid, ker_wid, real_ib, real_ob / 2, norm / 2, out_scale, false);
-        mul_monomial_l0(cont, r2, norm / 4, false);                                                       // eval.go:361-367
-        for (int d = 0; d < 2; d++) HCX(cont->hc, hc_add(cont->hc, 0, r1.d + (size_t)d * N, r2.d + (size_t)d * N, r1.d + (size_t)d * N, 1));   // AddNew (369)
-        freeCt(cont, r2);
+        std::vector<Ciphertext> r1 = evalConv_BN_batch(cont, ct_inputs, k0, a0, b0, in_wid, ker_wid, real_ib, real_ob / 2, norm / 2, out_scale, false);
+        std::vector<Ciphertext> r2 = evalConv_BN_batch(cont, ct_inputs, k1, a1, b1, in_wid, ker_wid, real_ib, real_ob / 2, norm / 2, out_scale, false);
         const int max_batch = N / (in_wid * in_wid);
-        if ((in_wid - ker_wid / 2) % 2 == 0) mul_monomial_l0(cont, r1, N - max_batch * (in_wid + 1), true);                                      // eval.go:377-387
+        for (int z = 0; z < nimg; z++) {
+            mul_monomial_l0(cont, r2[(size_t)z], norm / 4, false);                                        // eval.go:361-367
+            for (int d = 0; d < 2; d++) HCX(cont->hc, hc_add(cont->hc, 0, r1[(size_t)z].d + (size_t)d * N, r2[(size_t)z].d + (size_t)d * N, r1[(size_t)z].d + (size_t)d * N, 1));   // AddNew (369)
+            freeCt(cont, r2[(size_t)z]);
+            if ((in_wid - ker_wid / 2) % 2 == 0) mul_monomial_l0(cont, r1[(size_t)z], N - max_batch * (in_wid + 1), true);                        // eval.go:377-387
+        }
         ct_conv = r1;
     } else if (kind == "StrConv_sparse_full") {                                                            // eval.go:389-412 (modify_ker, full): one convolution, then the offset monomial
-        ct_conv = evalConv_BN(cont, ct_input, ker_in, bn_a, bn_b, in_wid, ker_wid, real_ib, real_ob, norm, out_scale, false);
+        ct_conv = evalConv_BN_batch(cont, ct_inputs, ker_in, bn_a, bn_b, in_wid, ker_wid, real_ib, real_ob, norm, out_scale, false);
         const int max_batch = N / (in_wid * in_wid);
-        if ((in_wid - ker_wid / 2) % 2 == 0) mul_monomial_l0(cont, ct_conv, N - max_batch * (in_wid + 1), true);
+        if ((in_wid - ker_wid / 2) % 2 == 0) for (Ciphertext &c : ct_conv) mul_monomial_l0(cont, c, N - max_batch * (in_wid + 1), true);
     } else if (kind == "Conv_sparse" || kind == "Conv") {
-        ct_conv = evalConv_BN(cont, ct_input, ker_in, bn_a, bn_b, in_wid, ker_wid, real_ib, real_ob, norm, out_scale, false);                   // eval.go:433
+        ct_conv = evalConv_BN_batch(cont, ct_inputs, ker_in, bn_a, bn_b, in_wid, ker_wid, real_ib, real_ob, norm, out_scale, false);             // eval.go:433
     } else panic("No kind!");
     // hand-over to the bootstrapper's context (its own stream): everything queued on the convolution context - the stride layers end on a product and an addition that
     // nothing has waited for - must be complete before the other stream reads ct_conv
     HCX(cont->hc, hc_sync(cont->hc));
-    BootCiphertext r = evalConv_BNRelu_tail(cont->btp, kind, log_sparse, ct_conv.d, ct_conv.Scale, alpha, pow_, in_wid, kp_wid);
-    freeCt(cont, ct_conv);
-    // [2][2][N] over (Q0, Q1): what the next convolution reads. The result block belongs to the bootstrapper's context and goes back to it; the layer's output is a
-    // block of the convolution context (a block released into a context that did not allocate it would leave the owner's block table pointing at memory it no longer
-    // owns - the lifetime bug hc_free's stream synchronisation used to hide). The tail has synchronised its stream, so the copy sees the finished result.
-    Ciphertext out; out.level = r.level; out.Scale = r.Scale;
-    const size_t bytes = (size_t)2 * (r.level + 1) * N * 8;
-    { void *v = nullptr; HCX(cont->hc, hc_malloc(cont->hc, bytes, &v)); out.d = (uint64_t *)v; }
-    HCX(cont->hc, hc_copy(cont->hc, out.d, r.d, bytes));
+    std::vector<const uint64_t *> conv_d; for (const Ciphertext &c : ct_conv) conv_d.push_back(c.d);
+    std::vector<BootCiphertext> r = evalConv_BNRelu_tail_batch(cont->btp, kind, log_sparse, conv_d, ct_conv[0].Scale, alpha, pow_, in_wid, kp_wid);
+    for (Ciphertext &c : ct_conv) freeCt(cont, c);
+    // [2][2][N] over (Q0, Q1): what the next convolution reads. The result blocks belong to the bootstrapper's context and go back to it; the layer's outputs are
+    // blocks of the convolution context (a block released into a context that did not allocate it would leave the owner's block table pointing at memory it no longer
+    // owns - the lifetime bug hc_free's stream synchronisation used to hide). The tail has synchronised its stream, so the copies see the finished results.
+    std::vector<Ciphertext> outs((size_t)nimg);
+    for (int z = 0; z < nimg; z++) {
+        Ciphertext &out = outs[(size_t)z]; out.level = r[(size_t)z].level; out.Scale = r[(size_t)z].Scale;
+        const size_t bytes = (size_t)2 * (out.level + 1) * N * 8;
+        { void *v = nullptr; HCX(cont->hc, hc_malloc(cont->hc, bytes, &v)); out.d = (uint64_t *)v; }
+        HCX(cont->hc, hc_copy(cont->hc, out.d, r[(size_t)z].d, bytes));
+    }
     HCX(cont->hc, hc_sync(cont->hc));
-    freeBootCt(cont->btp, r);
-    return out;
+    for (BootCiphertext &b : r) freeBootCt(cont->btp, b);
+    return outs;
+}
+Ciphertext evalConv_BNRelu_new(Context *cont, const Ciphertext &ct_input, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
+                               const std::vector<double> &bn_b, double alpha, double pow_, int in_wid, int kp_wid, int ker_wid, int real_ib, int real_ob,
+                               int norm, int log_sparse, const std::string &kind) {
+    return evalConv_BNRelu_new_batch(cont, {ct_input}, ker_in, bn_a, bn_b, alpha, pow_, in_wid, kp_wid, ker_wid, real_ib, real_ob, norm, log_sparse, kind)[0];
 }
 
 // main.go:920-939
@@ -103,7 +116,8 @@ static std::vector<double> prt_mat_one_norm(const std::vector<double> &vec, int 
         if (j == sj && k == sk) {
             out.assign((size_t)(batch / norm), 0.0);
             for (size_t idx = 0; idx < out.size(); idx++) out[idx] = vec[i + (size_t)norm * idx];
-            for (double v : out) printf("%.10f ", v); printf("\n");
+            for (double v : out) printf("%.10f ", v);
+            printf("\n");
         }
         k++;
         if (k * k > mat_size) { k = 1; j++; }
@@ -152,41 +166,47 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
     // images of several streams overlap on the CUs (separate PROCESSES time-slice the device instead: tools/resnet_throughput.py).
     // Measured on MI355X, ResNet-20, 24 images, HCONV_ASYNC_ALLOC=1: 1 thread 4 704 images/hour, 2 threads 5 982, 3 threads 5 553,
     // 4 threads 5 340 (each image is ~60 000 kernel launches; the threads share the runtime's launch path).
-    const int n_threads = std::max(1, std::min(getenv("HCONV_IMAGE_THREADS") ? atoi(getenv("HCONV_IMAGE_THREADS")) : 1, end - st));
+    const int nbatch = imageBatch();
+    const int n_threads = std::max(1, std::min(getenv("HCONV_IMAGE_THREADS") ? atoi(getenv("HCONV_IMAGE_THREADS")) : 1, (end - st + nbatch - 1) / nbatch));
     if (n_threads > 1) setenv("HCONV_ASYNC_ALLOC", "1", 0);      // several contexts in one process: cached allocations on non-blocking streams, or every hipFree stalls all of them
     std::mutex mu; std::condition_variable cv; int ready = 0; std::chrono::steady_clock::time_point t_go;
     auto run_images = [&](int tix) {
     Context *cont;
     { std::lock_guard<std::mutex> g(mu); cont = newContext(logN, ker_wid, in_wids, raw_in_wids, true, kind_name); }      // one at a time: key generation prints and allocates
     { std::unique_lock<std::mutex> g(mu); if (++ready == n_threads) { t_go = now(); cv.notify_all(); } else cv.wait(g, [&] { return ready == n_threads; }); }
-    for (int iter = st + tix; iter < end; iter += n_threads) {
-        printf("Running  %d -th iter... ker size:  %d\n", iter, ker_wid);
-        std::vector<double> image = readTxt(img_dir + "test_image_" + std::to_string(iter) + ".csv", in_wids[0] * in_wids[0] * 3);
-        std::vector<double> input((size_t)N, 0.0); int k = 0;
-        for (int i = 0; i < in_wids[0]; i++) for (int j = 0; j < in_wids[0]; j++) for (int b = 0; b < 3; b++) {
-            if (i < raw_in_wids[0] && j < raw_in_wids[0]) input[(size_t)(i * in_wids[0] * max_batch[0] + j * max_batch[0] + b * norm[0])] = image[(size_t)k];   // sparse pack the input
-            k++;
+    // images go through the network in groups of HCONV_IMAGE_BATCH (every layer's launches cover the whole group); thread tix takes groups tix, tix + n_threads, ...
+    for (int g0 = st + tix * nbatch; g0 < end; g0 += n_threads * nbatch) {
+        const int nimg = std::min(nbatch, end - g0);
+        std::vector<Ciphertext> ct_layer;
+        auto enc_start = now();
+        for (int iter = g0; iter < g0 + nimg; iter++) {
+            printf("Running  %d -th iter... ker size:  %d\n", iter, ker_wid);
+            std::vector<double> image = readTxt(img_dir + "test_image_" + std::to_string(iter) + ".csv", in_wids[0] * in_wids[0] * 3);
+            std::vector<double> input((size_t)N, 0.0); int k = 0;
+            for (int i = 0; i < in_wids[0]; i++) for (int j = 0; j < in_wids[0]; j++) for (int b = 0; b < 3; b++) {
+                if (i < raw_in_wids[0] && j < raw_in_wids[0]) input[(size_t)(i * in_wids[0] * max_batch[0] + j * max_batch[0] + b * norm[0])] = image[(size_t)k];   // sparse pack the input
+                k++;
+            }
+            ct_layer.push_back(EncryptNew(cont, EncodeCoeffs(input, cont->ECD_LV, cont->scale), cont->ECD_LV, cont->scale));
         }
         printf("vec size:  %d\n", N); printf("input width:  [%d %d %d]\n", raw_in_wids[0], raw_in_wids[1], raw_in_wids[2]);
         printf("kernel width:  %d\n", ker_wid); printf("num batches:  [%d %d %d]\n", real_batch[0], real_batch[1], real_batch[2]);
-        auto enc_start = now();
-        Ciphertext ct_layer = EncryptNew(cont, EncodeCoeffs(input, cont->ECD_LV, cont->scale), cont->ECD_LV, cont->scale);
         printf("Encryption done in %s \n", dur(enc_start).c_str());
         double timings[6]; auto begin_start = now(), start = now();
-        auto step = [&](Ciphertext next) { freeCt(cont, ct_layer); ct_layer = next; };
+        auto step = [&](std::vector<Ciphertext> next) { for (Ciphertext &c : ct_layer) freeCt(cont, c); ct_layer = std::move(next); };
 
         double pow_ = init_pow;                                                                          // ResNet Block 1
         for (int i = 1; i <= num_blcs[0]; i++) {
             if (wide && i == 5) pow_ = mid_pow;                                                          // test.go:742-744
             // wide: 3 -> init_batch -> real_batch[0] over the first two layers (test.go:745-763); narrow: init_batch == real_batch[0]
             const int ib = i == 1 ? 3 : (wide && i == 2 ? init_batch : real_batch[0]), ob = wide && i == 1 ? init_batch : real_batch[0];
-            step(evalConv_BNRelu_new(cont, ct_layer, W(i - 1, "conv", ib * ob * ker_size), W(i - 1, "a", ob), W(i - 1, "b", ob),
-                                     alpha, pow_, in_wids[0], raw_in_wids[0], ker_wid, ib, ob, norm[0], log_sparse[0], "Conv_sparse"));
+            step(evalConv_BNRelu_new_batch(cont, ct_layer, W(i - 1, "conv", ib * ob * ker_size), W(i - 1, "a", ob), W(i - 1, "b", ob),
+                                           alpha, pow_, in_wids[0], raw_in_wids[0], ker_wid, ib, ob, norm[0], log_sparse[0], "Conv_sparse"));
             if (!wide) pow_ = mid_pow;
             printf("Block1, Layer  %d done!\n", i);
         }
         printf("Block1 done.\n"); timings[0] = secs(start); start = now();
-        if (!w3) step(evalConv_BNRelu_new(cont, ct_layer, W(num_blcs[0], "conv", real_batch[0] * real_batch[1] * ker_size), W(num_blcs[0], "a", real_batch[1]), W(num_blcs[0], "b", real_batch[1]),
+        if (!w3) step(evalConv_BNRelu_new_batch(cont, ct_layer, W(num_blcs[0], "conv", real_batch[0] * real_batch[1] * ker_size), W(num_blcs[0], "a", real_batch[1]), W(num_blcs[0], "b", real_batch[1]),
                                  alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], real_batch[1], norm[1], log_sparse[0] - 1, "StrConv_sparse"));           // test.go:200, 791
         else {                                                                                           // test.go:775-812: even / odd output channels as two full-packing stride layers, X^2 shift, add
             const std::vector<double> ker12 = W(num_blcs[0], "conv", real_batch[0] * real_batch[1] * ker_size), a12 = W(num_blcs[0], "a", real_batch[1]), b12 = W(num_blcs[0], "b", real_batch[1]);
@@ -196,50 +216,51 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
                 k1[(size_t)(k * real_batch[0] * ho + (i * ho + j))] = ker12[(size_t)(k * real_batch[0] * real_batch[1] + (i * real_batch[1] + 2 * j + 1))];
             }
             for (int i = 0; i < ho; i++) { a0[(size_t)i] = a12[(size_t)(2 * i)]; a1[(size_t)i] = a12[(size_t)(2 * i + 1)]; b0[(size_t)i] = b12[(size_t)(2 * i)]; b1[(size_t)i] = b12[(size_t)(2 * i + 1)]; }
-            Ciphertext r1 = evalConv_BNRelu_new(cont, ct_layer, k0, a0, b0, alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], ho, norm[0], 0, "StrConv_sparse_full");
-            Ciphertext r2 = evalConv_BNRelu_new(cont, ct_layer, k1, a1, b1, alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], ho, norm[0], 0, "StrConv_sparse_full");
+            std::vector<Ciphertext> r1 = evalConv_BNRelu_new_batch(cont, ct_layer, k0, a0, b0, alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], ho, norm[0], 0, "StrConv_sparse_full");
+            std::vector<Ciphertext> r2 = evalConv_BNRelu_new_batch(cont, ct_layer, k1, a1, b1, alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], ho, norm[0], 0, "StrConv_sparse_full");
             {   // MulNew(ct_result2, EncodeCoeffs(X^2 at scale 1)) at level 1, AddNew (test.go:804-811)
                 void *v = nullptr; HCX(cont->hc, hc_malloc(cont->hc, (size_t)2 * N * 8, &v)); uint64_t *pt = (uint64_t *)v;
                 std::vector<uint64_t> m((size_t)2 * N, 0); m[2] = 1; m[(size_t)N + 2] = 1;
                 HCX(cont->hc, hc_upload(cont->hc, pt, m.data(), m.size() * 8));
                 for (int l = 0; l < 2; l++) HCX(cont->hc, hc_ntt(cont->hc, l, pt + (size_t)l * N, pt + (size_t)l * N, 1));
-                for (int d = 0; d < 2; d++) for (int l = 0; l < 2; l++) {
-                    uint64_t *row2 = r2.d + ((size_t)d * 2 + l) * N, *row1 = r1.d + ((size_t)d * 2 + l) * N;
+                for (int z = 0; z < nimg; z++) for (int d = 0; d < 2; d++) for (int l = 0; l < 2; l++) {
+                    uint64_t *row2 = r2[(size_t)z].d + ((size_t)d * 2 + l) * N, *row1 = r1[(size_t)z].d + ((size_t)d * 2 + l) * N;
                     HCX(cont->hc, hc_mul(cont->hc, l, row2, pt + (size_t)l * N, row2, 1)); HCX(cont->hc, hc_add(cont->hc, l, row1, row2, row1, 1));
                 }
                 HCX(cont->hc, hc_free(cont->hc, pt));
             }
-            freeCt(cont, r2); step(r1);
+            for (Ciphertext &c : r2) freeCt(cont, c);
+            step(r1);
         }
         printf("Block1 to 2 done!\n"); timings[1] = secs(start); start = now();
         for (int i = 1; i <= num_blcs[1]; i++) {                                                         // ResNet Block 2
             if (wide && i == 5) pow_ = init_pow;                                                         // test.go:819-821
             const int w = num_blcs[0] + i;
-            step(evalConv_BNRelu_new(cont, ct_layer, W(w, "conv", real_batch[1] * real_batch[1] * ker_size), W(w, "a", real_batch[1]), W(w, "b", real_batch[1]),
-                                     alpha, pow_, in_wids[1], raw_in_wids[1], ker_wid, real_batch[1], real_batch[1], norm[1], log_sparse[1], "Conv_sparse"));
+            step(evalConv_BNRelu_new_batch(cont, ct_layer, W(w, "conv", real_batch[1] * real_batch[1] * ker_size), W(w, "a", real_batch[1]), W(w, "b", real_batch[1]),
+                                           alpha, pow_, in_wids[1], raw_in_wids[1], ker_wid, real_batch[1], real_batch[1], norm[1], log_sparse[1], "Conv_sparse"));
             printf("Block2, Layer  %d done!\n", i);
         }
         printf("Block2 done.\n"); timings[2] = secs(start); start = now();
         if (wide) pow_ = mid_pow;                                                                        // test.go:833
         { const int w = num_blcs[0] + num_blcs[1] + 1;
-          step(evalConv_BNRelu_new(cont, ct_layer, W(w, "conv", real_batch[1] * real_batch[2] * ker_size), W(w, "a", real_batch[2]), W(w, "b", real_batch[2]),
-                                   alpha, pow_, in_wids[1], raw_in_wids[2], ker_wid, real_batch[1], real_batch[2], norm[2], log_sparse[1] - 1, "StrConv_sparse")); }               // test.go:225, 838
+          step(evalConv_BNRelu_new_batch(cont, ct_layer, W(w, "conv", real_batch[1] * real_batch[2] * ker_size), W(w, "a", real_batch[2]), W(w, "b", real_batch[2]),
+                                         alpha, pow_, in_wids[1], raw_in_wids[2], ker_wid, real_batch[1], real_batch[2], norm[2], log_sparse[1] - 1, "StrConv_sparse")); }               // test.go:225, 838
         printf("Block2 to 3 done!\n"); timings[3] = secs(start); start = now();
         for (int i = 1; i <= num_blcs[2]; i++) {                                                         // ResNet Block 3
             const int w = num_blcs[0] + num_blcs[1] + i + 1;
             if (wide && i == 3) pow_ = init_pow;                                                         // test.go:845-850
             if (wide && i == 5) pow_ = mid_pow;
             if (i == num_blcs[2]) pow_ = final_pow;
-            step(evalConv_BNRelu_new(cont, ct_layer, W(w, "conv", real_batch[2] * real_batch[2] * ker_size), W(w, "a", real_batch[2]), W(w, "b", real_batch[2]),
-                                     alpha, pow_, in_wids[2], raw_in_wids[2], ker_wid, real_batch[2], real_batch[2], norm[2], log_sparse[2], "Conv_sparse"));
+            step(evalConv_BNRelu_new_batch(cont, ct_layer, W(w, "conv", real_batch[2] * real_batch[2] * ker_size), W(w, "a", real_batch[2]), W(w, "b", real_batch[2]),
+                                           alpha, pow_, in_wids[2], raw_in_wids[2], ker_wid, real_batch[2], real_batch[2], norm[2], log_sparse[2], "Conv_sparse"));
             printf("Block3, Layer  %d done!\n", i);
         }
         printf("Block3 done.\n"); timings[4] = secs(start); start = now();
 
         int ker_inf_wid = raw_in_wids[2]; if (ker_inf_wid % 2 == 0) ker_inf_wid++;                       // test.go:279-334: reduce_mean + FC
         std::vector<double> ker_inf = readTxt(weight_dir + "final-fckernel.csv", real_batch[2] * fc_out);
-        std::vector<double> bn_bf = readTxt(weight_dir + "final-fcbias.csv", fc_out), res_out;
-        Ciphertext ct_result, ct_result2;
+        std::vector<double> bn_bf = readTxt(weight_dir + "final-fcbias.csv", fc_out);
+        std::vector<Ciphertext> ct_result, ct_result2;
         if (cf100 && !wide) {                                                                            // test.go:287-315: two convolutions of fc_out/2 outputs (the wide driver keeps one: test.go:865-882)
             const int ho = fc_out / 2; const size_t tap = (size_t)real_batch[2] * ho;
             std::vector<double> k1((size_t)(ker_inf_wid * ker_inf_wid) * tap), k2(k1.size());
@@ -248,33 +269,37 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
                 k2[(size_t)(j * ho + i) + (size_t)b * tap] = ker_inf[(size_t)(j * fc_out + i + ho)];
             }
             std::vector<double> bn_af((size_t)ho, 1.0 / (double)(raw_in_wids[2] * raw_in_wids[2])), b1(bn_bf.begin(), bn_bf.begin() + ho), b2(bn_bf.begin() + ho, bn_bf.end());
-            ct_result = evalConv_BN(cont, ct_layer, k1, bn_af, b1, in_wids[2], ker_inf_wid, real_batch[2], ho, norm[2], (double)(1 << 30), false);
-            ct_result2 = evalConv_BN(cont, ct_layer, k2, bn_af, b2, in_wids[2], ker_inf_wid, real_batch[2], ho, norm[2], (double)(1 << 30), false);
+            ct_result = evalConv_BN_batch(cont, ct_layer, k1, bn_af, b1, in_wids[2], ker_inf_wid, real_batch[2], ho, norm[2], (double)(1 << 30), false);
+            ct_result2 = evalConv_BN_batch(cont, ct_layer, k2, bn_af, b2, in_wids[2], ker_inf_wid, real_batch[2], ho, norm[2], (double)(1 << 30), false);
         } else {                                                                                         // test.go:316-334
             std::vector<double> ker_inf_((size_t)(ker_inf_wid * ker_inf_wid * real_batch[2] * fc_out));
             for (size_t i = 0; i < ker_inf.size(); i++) for (int b = 0; b < ker_inf_wid * ker_inf_wid; b++) ker_inf_[i + (size_t)b * real_batch[2] * fc_out] = ker_inf[i];
             std::vector<double> bn_af((size_t)fc_out, 1.0 / (double)(raw_in_wids[2] * raw_in_wids[2]));
-            ct_result = evalConv_BN(cont, ct_layer, ker_inf_, bn_af, bn_bf, in_wids[2], ker_inf_wid, real_batch[2], fc_out, norm[2], (double)(1 << 30), false);
+            ct_result = evalConv_BN_batch(cont, ct_layer, ker_inf_, bn_af, bn_bf, in_wids[2], ker_inf_wid, real_batch[2], fc_out, norm[2], (double)(1 << 30), false);
         }
         printf("Final FC done.\n"); timings[5] = secs(start); start = now();
         printf("\n===============  DECRYPTION  ===============\n\n");
-        if (cf100 && !wide) {
-            std::vector<double> r1 = DecryptDecodeCoeffs(cont, ct_result), r2 = DecryptDecodeCoeffs(cont, ct_result2);
-            printf("Decryption Done in %s \n", dur(start).c_str());
-            std::vector<double> o1 = prt_mat_one_norm(r1, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1), o2 = prt_mat_one_norm(r2, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1);
-            res_out.assign(o1.begin(), o1.begin() + fc_out / 2); res_out.insert(res_out.end(), o2.begin(), o2.begin() + fc_out / 2);
-            freeCt(cont, ct_result2);
-        } else {
-            std::vector<double> res_tmp = DecryptDecodeCoeffs(cont, ct_result);
-            printf("Decryption Done in %s \n", dur(start).c_str());
-            res_out = prt_mat_one_norm(res_tmp, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1);
-            res_out.resize((size_t)fc_out);
+        for (int z = 0; z < nimg; z++) {
+            std::vector<double> res_out;
+            if (cf100 && !wide) {
+                std::vector<double> r1 = DecryptDecodeCoeffs(cont, ct_result[(size_t)z]), r2 = DecryptDecodeCoeffs(cont, ct_result2[(size_t)z]);
+                printf("Decryption Done in %s \n", dur(start).c_str());
+                std::vector<double> o1 = prt_mat_one_norm(r1, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1), o2 = prt_mat_one_norm(r2, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1);
+                res_out.assign(o1.begin(), o1.begin() + fc_out / 2); res_out.insert(res_out.end(), o2.begin(), o2.begin() + fc_out / 2);
+                freeCt(cont, ct_result2[(size_t)z]);
+            } else {
+                std::vector<double> res_tmp = DecryptDecodeCoeffs(cont, ct_result[(size_t)z]);
+                printf("Decryption Done in %s \n", dur(start).c_str());
+                res_out = prt_mat_one_norm(res_tmp, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1);
+                res_out.resize((size_t)fc_out);
+            }
+            printf("\n result:  ["); for (double v : res_out) printf("%.10f ", v);
+            printf("]\n");
+            writeTxt(out_dir + "class_result_" + ker_name + "_" + std::to_string(g0 + z) + ".csv", res_out);
+            freeCt(cont, ct_layer[(size_t)z]); freeCt(cont, ct_result[(size_t)z]);
         }
-        printf("\n result:  ["); for (double v : res_out) printf("%.10f ", v); printf("]\n");
-        writeTxt(out_dir + "class_result_" + ker_name + "_" + std::to_string(iter) + ".csv", res_out);
         printf("Blc1:  %g  sec\nBlc1->2:  %g  sec\nBlc2:  %g  sec\nBlc2->3:  %g  sec\nBlc3:  %g  sec\nFinal (reduce_mean & FC):  %g  sec\n", timings[0], timings[1], timings[2], timings[3], timings[4], timings[5]);
-        printf("Total done in %s \n", dur(begin_start).c_str());
-        freeCt(cont, ct_layer); freeCt(cont, ct_result);
+        printf("Total done in %s %s\n", dur(begin_start).c_str(), nimg > 1 ? ("(" + std::to_string(nimg) + " images)").c_str() : "");
     }
     { std::lock_guard<std::mutex> g(mu); freeContext(cont); }
     };

@@ -500,6 +500,22 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
     X = qp()
     md = run("mod_down2", lambda x, o0, o1: ck(L.hc_mod_down2(h, level, x, o0, o1)), [(acc, "q")], [("p", PW), ("p", PW)])
     eq(md[0], ks[0], "keyswitch_qp + mod_down2 == keyswitch (d0)"); eq(md[1], ks[1], "keyswitch_qp + mod_down2 == keyswitch (d1)")
+    def qp_rot_composed(c0p, x, o):          # hc_keyswitch_qp + add on the Q rows of component 0 + permutation, image by image (single mode only)
+        t = ctx.buf(nwords=2 * nt * N)
+        ck(L.hc_keyswitch_qp(h, K0, level, x, t.ptr, 0)); ck(L.hc_lv_add(h, level, t.ptr, c0p, t.ptr)); ck(L.hc_permute(h, C.c_uint64(gal), t.ptr, o, 2 * nt))
+        ctx.sync(); t.free()
+    qr = run("keyswitch_qp_rotate", lambda c0p, x, o: ck(L.hc_keyswitch_qp_rotate(h, K0, C.c_uint64(gal), level, c0p, x, o, 0, 0)), [(b, "p"), (a, "p")], [("q", QW)])
+    ctx.set_batch(1)
+    comp = []
+    for z in range(n):
+        bi, ai, oi = ctx.buf(b[z]), ctx.buf(a[z]), ctx.buf(nwords=2 * nt * N)
+        qp_rot_composed(bi.ptr, ai.ptr, oi.ptr); comp.append(oi.download())
+        bi.free(); ai.free(); oi.free()
+    eq(qr[0], np.stack(comp), "keyswitch_qp_rotate == keyswitch_qp + add + permute")
+
+    def qp_rot_acc(x, o):
+        ck(L.hc_keyswitch_decompose(h, level, x)); ck(L.hc_keyswitch_qp_rotate(h, K1, C.c_uint64(gal), level, None, x, o, 1, 1))
+    run("keyswitch_qp_rotate (hoisted, accumulate, no pc0)", qp_rot_acc, [(a1, "p")], [("q", QW)], init=[acc.reshape(n, -1)])
     off = nt * N * 8
     at1 = lambda p_: C.c_void_p(p_.value + off)
     run("qp_op2 mul (plaintext)", lambda x, y, o: ck(L.hc_qp_op2(h, 0, level, x, at1(x), y, y, o, at1(o))), [(X, "q"), (ptq, "s")], [("q", QW)])

@@ -593,3 +593,11 @@ def test_keyswitch_hoisted_on_gpu():
     from optimal_conv_amd import Context
     pc.case_keyswitch_hoisted(lambda Q, P: Context(Q, P), lambda Q, P: Oracle(q=Q, p=P))
     pc.case_keyswitch_hoisted(lambda Q, P: Context(Q, P), lambda Q, P: Oracle(q=Q, p=P), level=4, alpha=5, nkeys=2)
+
+
+@pytest.mark.parametrize("n,level,alpha", [(8, 5, 3), (3, 4, 5), (5, 2, 1)])
+def test_batched_leveled_entry_points_on_gpu(n, level, alpha):
+    """hc_set_batch: n images per launch through every leveled entry point (pointwise, transforms, rescale, the key switch whole / hoisted / in its QP halves, the fused
+    rotations of the linear transform) == n single-image calls, bit for bit; n = 8 is the widest batch, alpha = 5 the bootstrapping chain's digit size"""
+    from optimal_conv_amd import Context
+    pc.case_batched_leveled(lambda Q, P: Context(Q, P), n=n, level=level, alpha=alpha)

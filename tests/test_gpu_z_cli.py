@@ -131,6 +131,32 @@ def test_conv_relu_cli_replays_the_reference_chain(tmp_path):
         assert (lv, sc) == (want["level"], want["scale"]) and polys == want["polys"], f"{name}: the host chain differs from the reference binary"
 
 
+def test_conv_relu_cli_replays_the_reference_chain_in_an_image_batch(tmp_path):
+    """HCONV_IMAGE_BATCH=3: three ciphertexts go through the convReLU tail as ONE set of launches (hc_set_batch: every leveled ABI call covers the batch; masks,
+    diagonals and switching keys read once). Image 0 carries the input `gotrace -chain` planted into the reference binary and must end on the BINARY's digests;
+    images 1 and 2 carry other planted inputs, and image 2's digests must be those of a single-image run planted as image 2 (HCONV_REPLAY_IMAGE0=2)."""
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_trace_chain_5_1.json")))
+    ev = ref["events"]
+    ctos = next(e for e in ev if e["fn"] == "BootstrappConv_CtoS")["digests"]
+    final = [e for e in ev if e["fn"] == "Rescale" and "digests" in e][-1]["digests"][0]
+    gen.write_case(str(tmp_path / "test_conv_data"), 5, 1, 0)
+    pat = r"^replay digest(?:\[(\d+)\])? (\S+) level (\d+) scale (\S+) ((?:[0-9a-f]{64} ?)+)$"
+    runs = {}
+    for mode, extra in (("batch", {"HCONV_IMAGE_BATCH": "3"}), ("single2", {"HCONV_REPLAY_IMAGE0": "2"})):
+        out = subprocess.run([CLI, "--test-mode", "convReLU", "5", "1", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=900,
+                             env=dict(os.environ, HCONV_SEED="31", HCONV_CHAIN_REPLAY=str(ref["seed"]), HCONV_SKIP_BL="1", **extra))
+        assert out.returncode == 0, out.stderr[-2000:]
+        runs[mode] = {(int(m.group(1) or 0), m.group(2)): (int(m.group(3)), float(m.group(4)), m.group(5).split()) for m in re.finditer(pat, out.stdout, re.M)}
+    got = runs["batch"]
+    assert set(got) == {(z, name) for z in range(3) for name in ("ctos0", "ctos1", "final")}, sorted(got)
+    for name, want in (("ctos0", ctos[0]), ("ctos1", ctos[1]), ("final", final)):
+        lv, sc, polys = got[(0, name)]
+        assert (lv, sc) == (want["level"], want["scale"]) and polys == want["polys"], f"{name}: image 0 of the batch differs from the reference binary"
+        assert got[(2, name)] == runs["single2"][(2, name)], f"{name}: image 2 of the batch differs from the same image run alone"
+        assert got[(1, name)][2] != got[(0, name)][2] and got[(1, name)][2] != got[(2, name)][2]      # the images are different ciphertexts
+
+
 def test_conv_relu_cli_replays_the_reference_baseline_bootstrapp(tmp_path):
     """The PRODUCT path against the reference binary on the BASELINE half of convReLU (round 3): with HCONV_CHAIN_REPLAY_BL=<seed> the CLI's blBootReLU runs the stock
     Bootstrapp on the input and the switching keys `gotrace -flow-bl -chain` planted into /root/reference/test_run (tests/golden/ref_trace_chain_bl_5_1.json) and prints the
@@ -199,14 +225,14 @@ def test_resnet_cli_depth8(tmp_path, cf100, wide):
 
 
 def test_resnet_cli_two_image_threads_cached_allocations(tmp_path):
-    """`resnet 3 8 1 2 false` with HCONV_IMAGE_THREADS=2 (two host threads, each with its own convolution and bootstrapper contexts on non-blocking streams, blocks
+    """(also: the image batch, HCONV_IMAGE_BATCH=2, at the end) `resnet 3 8 1 2 false` with HCONV_IMAGE_THREADS=2 (two host threads, each with its own convolution and bootstrapper contexts on non-blocking streams, blocks
     recycled from per-context caches: HCONV_ASYNC_ALLOC=1). hc_free no longer waits for the stream, so this is the run that fails if a block is freed while another
     context still uses it, or into a context that does not own it: the scores must be those of the one-thread, plain-allocation run"""
     import numpy as np
     import golden.gen_resnet_csv as rgen
     want = rgen.write_case(str(tmp_path), 3, 8, 2)
     res = {}
-    for mode, env in (("plain", {}), ("cached", {"HCONV_IMAGE_THREADS": "2", "HCONV_ASYNC_ALLOC": "1"})):
+    for mode, env in (("plain", {}), ("cached", {"HCONV_IMAGE_THREADS": "2", "HCONV_ASYNC_ALLOC": "1"}), ("batch", {"HCONV_IMAGE_BATCH": "2"})):
         out = subprocess.run([CLI, "--test-mode", "resnet", "3", "8", "1", "2", "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
                              env=dict(os.environ, HCONV_SEED="11", **env))
         assert out.returncode == 0, out.stderr[-2000:]
@@ -218,6 +244,10 @@ def test_resnet_cli_two_image_threads_cached_allocations(tmp_path):
     for mode in res:
         assert np.max(np.abs(res[mode][1] - want[1][0])) < 0.08 and res[mode][1].argmax() == want[1][0].argmax(), (mode, res[mode][1], want[1][0])
     assert np.max(np.abs(res["plain"][1] - res["cached"][1])) < 0.05, (res["plain"][1], res["cached"][1])
+    # HCONV_IMAGE_BATCH=2: both images through every layer as one launch set (hc_conv_then_pack_batch, hc_set_batch). One thread, the same order of encryptions as the
+    # plain run, every image bit-identical to its single-image evaluation: the decrypted scores are EQUAL, not close
+    for i in range(2):
+        assert np.array_equal(res["plain"][i], res["batch"][i]), (i, res["plain"][i], res["batch"][i])
 
 
 def test_resnet_cli_depth20(tmp_path):
