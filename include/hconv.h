@@ -148,6 +148,12 @@ int hc_rotate_gal_l0(hc_ctx *ctx, uint64_t galEl, const uint64_t *c0, const uint
  * into every target limb, one accumulation of both key components): about 32 launches at level 27. */
 int hc_swk_load(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *rows_host);
 int hc_keyswitch(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1);
+/* HARNESS ONLY - not part of what a Lattigo host binds (it owns its keys and hands them over with hc_swk_load): rlwe.KeyGenerator.GenSwitchingKey on the device for
+ * the C++ test harness, restricted to the rows a level-`level` key switch reads. galEl odd: the rotation / conjugation key of galEl (s_out = sigma_{galEl^-1}(s));
+ * galEl = 0: the relinearisation key (s^2 -> s). sk_ntt: DEVICE rows [nq + np][N] = NTT(s) modulo every modulus of the context. seed8: 8 x 32 bits keying ChaCha20;
+ * uniform rows and the per-digit error (sigma 3.2, |e| <= 19) are functions of (seed, key_id, digit, limb, coefficient). The reference's keys are crypto/rand draws:
+ * nothing to reproduce but the RLWE relation b + a s_out - [own limbs] P s_in = e, which tests/ check. The key is stored as hc_swk_load would store it. */
+int hc_swk_generate(hc_ctx *ctx, uint64_t key_id, int level, uint64_t galEl, const uint64_t *sk_ntt, const uint32_t *seed8);
 /* Hoisted form (evaluator.RotateHoisted, conv.go:131; Lattigo's linear transforms): hc_keyswitch_decompose computes the digit
  * decomposition of cx once and keeps it in the context; each hc_keyswitch_hoisted(key, level, cx, ...) then only does the inner
  * product with its key and the ModDown. Bit-identical to hc_keyswitch. The decomposition is valid until the next hc_keyswitch /

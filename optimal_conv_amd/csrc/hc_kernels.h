@@ -1481,6 +1481,70 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rescale_finish_mm(const u64 *x, s
         out[b + j] = hc_mul_shoup(hc_submod(x[b + j], u[b + j], q), w.w, w.ws, q);
 }
 
+// ================================================================ switching-key generation on the device (harness: hc_swk_generate)
+// rlwe.KeyGenerator.GenSwitchingKey restricted to the rows a level-`level` key switch reads, for keys the HOST HARNESS needs (the reference draws its keys from
+// crypto/rand, so there is nothing to reproduce beyond the RLWE relation): per digit d and limb T (Q_0..Q_level, then the P limbs)
+//     a uniform mod q_T (sampled in the NTT domain) ;  b = NTT(e_d) - a * s_out + [T own limb of digit d] P * s_in ;  both stored in Montgomery form,
+// e_d one discrete Gaussian polynomial per digit (sigma 3.2, bound 6 sigma), s_out = sigma_g(s) read from NTT(s) through the NTT-domain permutation, s_in = s
+// (rotations / conjugation) or s^2 (relinearisation). All randomness is ChaCha20 (RFC 8439 block function, 64-bit counter) keyed by 256 bits from the host and
+// addressed by (key id, digit, limb | error tag, coefficient, attempt): deterministic in the seed, independent of launch geometry. Uniform residues by
+// rejection on ceil(log2 q) bits; the Gaussian by Box-Muller on two 53-bit uniforms.
+struct HcKeyGen { u32 key[8]; u32 id_lo, id_hi; u32 ginv; int relin; int nl, nq, nt, alpha, beta; };
+__device__ __forceinline__ u32 hc_rotl32(u32 x, int n) { return (x << n) | (x >> (32 - n)); }
+#define HC_CHACHA_QR(a, b, c, d) a += b; d = hc_rotl32(d ^ a, 16); c += d; b = hc_rotl32(b ^ c, 12); a += b; d = hc_rotl32(d ^ a, 8); c += d; b = hc_rotl32(b ^ c, 7);
+// one 64-byte block as eight 64-bit words; state words 12..15 = (c0, c1, n0, n1)
+__device__ __forceinline__ void hc_chacha_block(const u32 (&key)[8], u32 c0, u32 c1, u32 n0, u32 n1, u64 (&out)[8]) {
+    u32 x0 = 0x61707865, x1 = 0x3320646e, x2 = 0x79622d32, x3 = 0x6b206574, x4 = key[0], x5 = key[1], x6 = key[2], x7 = key[3], x8 = key[4], x9 = key[5], x10 = key[6], x11 = key[7],
+        x12 = c0, x13 = c1, x14 = n0, x15 = n1;
+    for (int i = 0; i < 10; i++) {
+        HC_CHACHA_QR(x0, x4, x8, x12) HC_CHACHA_QR(x1, x5, x9, x13) HC_CHACHA_QR(x2, x6, x10, x14) HC_CHACHA_QR(x3, x7, x11, x15)
+        HC_CHACHA_QR(x0, x5, x10, x15) HC_CHACHA_QR(x1, x6, x11, x12) HC_CHACHA_QR(x2, x7, x8, x13) HC_CHACHA_QR(x3, x4, x9, x14)
+    }
+    x0 += 0x61707865; x1 += 0x3320646e; x2 += 0x79622d32; x3 += 0x6b206574; x4 += key[0]; x5 += key[1]; x6 += key[2]; x7 += key[3]; x8 += key[4]; x9 += key[5]; x10 += key[6]; x11 += key[7];
+    x12 += c0; x13 += c1; x14 += n0; x15 += n1;
+    out[0] = x0 | ((u64)x1 << 32); out[1] = x2 | ((u64)x3 << 32); out[2] = x4 | ((u64)x5 << 32); out[3] = x6 | ((u64)x7 << 32);
+    out[4] = x8 | ((u64)x9 << 32); out[5] = x10 | ((u64)x11 << 32); out[6] = x12 | ((u64)x13 << 32); out[7] = x14 | ((u64)x15 << 32);
+}
+// rows: [beta][2][nt][N]; writes a (component 1, final values before the Montgomery factor) and e mod q_T (component 0, coefficient domain). grid = (64, nt, beta)
+__global__ __launch_bounds__(HC_TPB) void hc_k_swk_sample(u64 *rows, const HcMod *mods, HcKeyGen G) {
+    const int T = blockIdx.y, d = blockIdx.z; const u64 q = mods[T < G.nl ? T : G.nq + (T - G.nl)].q;
+    u64 *b_row = rows + (((size_t)d * 2 + 0) * G.nt + T) * 65536, *a_row = rows + (((size_t)d * 2 + 1) * G.nt + T) * 65536;
+    const int bits = 64 - __builtin_clzll(q); const u64 mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
+    for (u32 j = blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += gridDim.x * HC_TPB) {
+        u64 w[8]; u64 a = 0; bool found = false;
+        for (u32 attempt = 0; !found; attempt++) {                           // rejection: each word is accepted with probability q / 2^bits > 1/2
+            hc_chacha_block(G.key, j, attempt, G.id_lo, G.id_hi ^ ((u32)(d * 64 + T) << 8), w);
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (!found && (w[k] & mask) < q) { a = w[k] & mask; found = true; }
+        }
+        a_row[j] = a;
+        // the digit's error polynomial: the same stream for every limb T (tag 0xE0 in the nonce instead of the limb)
+        hc_chacha_block(G.key, j, 0, G.id_lo, G.id_hi ^ ((u32)(d * 64 + 63) << 8) ^ 0xE0000000u, w);
+        const double u1 = ((double)(w[0] >> 11) + 1.0) / 9007199254740993.0, u2 = (double)(w[1] >> 11) / 9007199254740992.0;
+        double g = sqrt(-2.0 * log(u1)) * 3.2 * cos(6.283185307179586 * u2);
+        if (fabs(g) > 19.2) g = 0;
+        const long e = (long)llrint(g);
+        b_row[j] = e >= 0 ? (u64)e : q - (u64)(-e);
+    }
+}
+// after the NTT of the e rows: b = e - a s_out (+ P s_in on the digit's own limbs), Montgomery form. sk_ntt: [nq + np][N] = NTT(s) per modulus. grid = (64, nt, beta)
+__global__ __launch_bounds__(HC_TPB) void hc_k_swk_finish(u64 *rows, const u64 *sk_ntt, const HcMod *mods, const HcTw *pmod, HcKeyGen G) {
+    const int T = blockIdx.y, d = blockIdx.z, mod = T < G.nl ? T : G.nq + (T - G.nl); const HcMod m = mods[mod];
+    u64 *b_row = rows + (((size_t)d * 2 + 0) * G.nt + T) * 65536, *a_row = rows + (((size_t)d * 2 + 1) * G.nt + T) * 65536;
+    const u64 *s = sk_ntt + (size_t)mod * 65536;
+    const bool own = T < G.nl && T >= d * G.alpha && T < (d + 1) * G.alpha;
+    for (u32 j = blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += gridDim.x * HC_TPB) {
+        const u64 a = a_row[j], sj = s[j], so = G.relin ? sj : s[hc_perm_src(j, G.ginv)];
+        const u64 am = hc_mont(a, m.r2, m.q, m.qinv);                                     // a in Montgomery form: the stored value, and mont(am, x) = a x
+        u64 b = hc_submod(b_row[j], hc_mont(am, so, m.q, m.qinv), m.q);
+        if (own) {
+            const u64 sin_ = G.relin ? hc_mont(hc_mont(sj, m.r2, m.q, m.qinv), sj, m.q, m.qinv) : sj;
+            b = hc_addmod(b, hc_mul_shoup(sin_, pmod[T].w, pmod[T].ws, m.q), m.q);
+        }
+        b_row[j] = hc_mont(b, m.r2, m.q, m.qinv); a_row[j] = am;
+    }
+}
+
 // ================================================================ slot encoder (ckks.Encoder.Encode / EncodeNTT, full slots)
 // Lattigo's "special" inverse FFT over the rotation group 5^j (encoder.go invfft; restated on the host in hconv_encoder.hpp and, for
 // the tests, in tests/oracle_bl.py): n = N/2 = 2^15 complex values, stages len = n .. 2 (distance len/2, large first), butterfly

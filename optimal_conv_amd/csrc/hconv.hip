@@ -1076,6 +1076,38 @@ extern "C" int hc_swk_load(hc_ctx *c, uint64_t key_id, int level, const uint64_t
     c->swk[key_id] = k;
     return HC_OK;
 }
+// Harness-side key generation on the device (include/hconv.h): one launch samples every row of the key, one batched transform takes the errors to the
+// NTT domain, one launch forms b and the stored (Montgomery) form. 3 + 2 launches per key instead of ~10 one-row launches and three uploads per (digit, limb).
+extern "C" int hc_swk_generate(hc_ctx *c, uint64_t key_id, int level, uint64_t galEl, const uint64_t *sk_ntt, const uint32_t *seed8) {
+    HC_ENTER(c);
+    if (!sk_ntt || !seed8 || level < 0 || level >= c->nq || c->np < 1 || c->np > 8 || (galEl && !(galEl & 1))) return hc_fail(c, HC_ERR_ARG, "hc_swk_generate: bad arguments");
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
+    if (beta > 63 || nt > 62) return hc_fail(c, HC_ERR_UNSUPPORTED, "hc_swk_generate: more than 62 limbs");
+    HcKeyGen G; memset(&G, 0, sizeof G);
+    memcpy(G.key, seed8, sizeof G.key); G.id_lo = (u32)key_id; G.id_hi = (u32)(key_id >> 32) & 0xFFu;
+    G.relin = galEl == 0; G.nl = nl; G.nq = c->nq; G.nt = nt; G.alpha = alpha; G.beta = beta;
+    if (galEl) { const u64 twoN = 2ull * HC_N; u64 ginv = 1, b = galEl % twoN; for (u64 e = twoN - 1; e; e >>= 1, b = (b * b) % twoN) if (e & 1) ginv = (ginv * b) % twoN; G.ginv = (u32)ginv; }
+    const size_t n = (size_t)beta * 2 * nt * HC_N;
+    HcScratch S(c);
+    HcSwk k; k.level = level; k.beta = beta;
+    HC_HIP(c, S.alloc(&k.rows, n * sizeof(u64)));
+    HcTw *pm = nullptr; HC_HIP(c, S.alloc(&pm, (size_t)nl * sizeof(HcTw)));
+    {   std::vector<HcTw> h((size_t)nl);
+        for (int l = 0; l < nl; l++) { const u64 q = c->mods[(size_t)l].m.q; u64 r = 1; for (int j = 0; j < alpha; j++) r = h_mulmod(r, c->mods[(size_t)(c->nq + j)].m.q % q, q); h[(size_t)l] = h_pair(r, q); }
+        HC_HIP(c, hcx_h2d(c, pm, h.data(), h.size() * sizeof(HcTw)));
+    }
+    const dim3 grid(64, (unsigned)nt, (unsigned)beta);
+    HC_TRY(hc_launch(c, "swk_sample", hc_k_swk_sample, grid, k.rows, (const HcMod *)c->d_mods, G));
+    c->hoist_cx = nullptr;
+    HC_TRY(hc_ntt_mm(c, k.rows, k.rows, nt, nl, 0, 0, beta, (size_t)2 * nt * HC_N, (size_t)2 * nt * HC_N));      // the e rows (component 0 of every digit), all limbs
+    HC_TRY(hc_launch(c, "swk_finish", hc_k_swk_finish, grid, k.rows, (const u64 *)sk_ntt, (const HcMod *)c->d_mods, (const HcTw *)pm, G));
+    HC_HIP(c, hipStreamSynchronize(c->stream));
+    S.keep(k.rows);
+    auto it = c->swk.find(key_id);
+    if (it != c->swk.end()) hcx_free(c, it->second.rows);
+    c->swk[key_id] = k;
+    return HC_OK;
+}
 // constants of every basis extension of a level, built once: digit d -> target limb T, and {P} -> Q limb l
 static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;

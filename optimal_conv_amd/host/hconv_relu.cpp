@@ -129,18 +129,8 @@ struct Boot {
     DCt new_ct(int level, int deg, double scale) { DCt c; c.deg = deg; c.level = level; c.scale = scale; for (int i = 0; i <= deg; i++) c.p[i] = block(); return c; }
     static DCt drop_to(const DCt &a, int level) { if (level > a.level) panic("drop_to: level above the ciphertext's"); DCt c = a; c.level = level; return c; }
 
-    // ---------------- sampling (harness only; the reference's randomness is crypto/rand and unseeded)
+    // ---------------- sampling (harness only; the reference's randomness is crypto/rand and unseeded): this stream keys the device's key generator
     uint64_t next() { return rng(); }
-    void uniform_rows(uint64_t q, uint64_t *out) { int bits = 64 - __builtin_clzll(q); uint64_t mask = bits == 64 ? ~0ull : ((1ull << bits) - 1); for (int j = 0; j < N; j++) { uint64_t r; do r = next() & mask; while (r >= q); out[j] = r; } }
-    void gaussian(std::vector<int64_t> &e) {
-        e.resize(N);
-        for (int j = 0; j < N; j += 2) {        // Box-Muller, sigma 3.2, bound 6 sigma
-            double u1 = ((double)(next() >> 11) + 1.0) / 9007199254740993.0, u2 = (double)(next() >> 11) / 9007199254740992.0;
-            double r = sqrt(-2.0 * log(u1)) * 3.2, a = r * cos(6.283185307179586 * u2), b = r * sin(6.283185307179586 * u2);
-            if (fabs(a) > 19.2) a = 0; if (fabs(b) > 19.2) b = 0;
-            e[(size_t)j] = (int64_t)llround(a); e[(size_t)j + 1] = (int64_t)llround(b);
-        }
-    }
     uint64_t modulus(int T, int nl) const { return T < nl ? Q[(size_t)T] : P[(size_t)(T - nl)]; }
     int modidx(int T, int nl) const { return T < nl ? T : NQ + (T - nl); }
 
@@ -174,48 +164,16 @@ struct Boot {
             key_ids[{ident, level}] = id; n_keys++;
             return id;
         }
-        // s_out: the key the result is under. Rotation/conjugation by gal: automorphism by gal^-1 of s; relinearisation: s.
-        std::vector<int64_t> sko(N, 0);
-        if (gal == 0) sko = sk;
-        else {
-            const uint64_t twoN = 2ull * N; uint64_t ginv = 1, b = gal % twoN;
-            for (uint64_t e = twoN - 1; e; e >>= 1, b = (b * b) % twoN) if (e & 1) ginv = (ginv * b) % twoN;
-            for (int i = 0; i < N; i++) { uint64_t t = ((uint64_t)i * ginv) % twoN; if (t < (uint64_t)N) sko[t] = sk[(size_t)i]; else sko[t - N] = -sk[(size_t)i]; }
-        }
-        const size_t rows = (size_t)beta * 2 * nt;
-        void *v = nullptr; HCR(hc_malloc(hc, (rows + 3) * N * 8, &v));
-        uint64_t *d = (uint64_t *)v, *t0 = d + rows * N, *t1 = t0 + N, *t2 = t1 + N;
-        std::vector<uint64_t> ha((size_t)N), he((size_t)N), hs((size_t)N);
-        std::vector<int64_t> e;
-        for (int dgt = 0; dgt < beta; dgt++) {
-            gaussian(e);
-            for (int T = 0; T < nt; T++) {
-                const uint64_t q = modulus(T, nl); const int mod = modidx(T, nl);
-                uint64_t *b_row = d + (((size_t)dgt * 2 + 0) * nt + T) * N, *a_row = d + (((size_t)dgt * 2 + 1) * nt + T) * N;
-                uniform_rows(q, ha.data());
-                for (int j = 0; j < N; j++) { he[(size_t)j] = e[(size_t)j] >= 0 ? (uint64_t)e[(size_t)j] : q - (uint64_t)(-e[(size_t)j]); hs[(size_t)j] = sko[(size_t)j] >= 0 ? (uint64_t)sko[(size_t)j] : q - (uint64_t)(-sko[(size_t)j]); }
-                HCR(hc_upload(hc, a_row, ha.data(), (size_t)N * 8)); HCR(hc_upload(hc, t0, he.data(), (size_t)N * 8)); HCR(hc_upload(hc, t1, hs.data(), (size_t)N * 8));
-                HCR(hc_ntt(hc, mod, t0, t0, 1)); HCR(hc_ntt(hc, mod, t1, t1, 1));                   // NTT(e), NTT(s_out)
-                HCR(hc_mul(hc, mod, a_row, t1, t1, 1)); HCR(hc_sub(hc, mod, t0, t1, b_row, 1));    // b = e - a*s_out
-                if (T < nl && T >= dgt * alpha && T < (dgt + 1) * alpha) {                        // + P * s_in on the digit's own limbs
-                    uint64_t pmod = 1; for (uint64_t pj : P) pmod = mulmod(pmod, pj % q, q);
-                    const uint64_t *s_row = d_sk + (size_t)mod * N;
-                    if (gal == 0) { HCR(hc_mul(hc, mod, s_row, s_row, t2, 1)); HCR(hc_mul_const(hc, mod, t2, pmod, t2, 1)); }
-                    else HCR(hc_mul_const(hc, mod, s_row, pmod, t2, 1));
-                    HCR(hc_add(hc, mod, b_row, t2, b_row, 1));
-                }
-                const uint64_t R = (uint64_t)((((u128)1) << 64) % q);                              // stored form: Montgomery
-                HCR(hc_mul_const(hc, mod, b_row, R, b_row, 1)); HCR(hc_mul_const(hc, mod, a_row, R, a_row, 1));
-            }
-        }
-        HCR(hc_sync(hc));
-        std::vector<uint64_t> host(rows * N); HCR(hc_download(hc, host.data(), d, host.size() * 8));
+        // rlwe.GenSwitchingKey on the device (hc_swk_generate: ChaCha20 rows keyed by this bootstrapper's own stream, one Gaussian error per digit, the NTT of all
+        // limbs in one batched launch): s_out = sigma_{gal^-1}(s) for a rotation / conjugation, s for relinearisation (gal = 0). Round 3 built every row on the
+        // host and pushed it through one-row launches: 17-28 s per context, now a fraction of a second.
+        if (!have_kg_seed) { for (int i = 0; i < 4; i++) { const uint64_t r = next(); kg_seed[2 * i] = (uint32_t)r; kg_seed[2 * i + 1] = (uint32_t)(r >> 32); } have_kg_seed = true; }
         const uint64_t id = 1 + key_ids.size();
-        HCR(hc_swk_load(hc, id, level, host.data()));
-        HCR(hc_free(hc, d));
+        HCR(hc_swk_generate(hc, id, level, gal, d_sk, kg_seed));
         key_ids[{ident, level}] = id; n_keys++;
         return id;
     }
+    uint32_t kg_seed[8]; bool have_kg_seed = false;
     uint64_t gal_rot(int k) const { const uint64_t twoN = 2ull * N; uint64_t e = (uint64_t)(int64_t)k & (twoN - 1), r = 1, b = 5; while (e) { if (e & 1) r = (r * b) % twoN; b = (b * b) % twoN; e >>= 1; } return r; }
 
     // ---------------- evaluator (ckks.Evaluator at any level)

@@ -525,6 +525,54 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
     ctx.close()
 
 
+def case_swk_generate(make_ctx, level=4, alpha=3, seed=0x5EED):
+    """hc_swk_generate (harness key generation on the device: ChaCha20 rows, one Gaussian error per digit, b = e - a s_out + P s_in on the digit's own limbs). There is
+    nothing of the reference to match (its keys are crypto/rand draws); what a key must do is switch: for a random polynomial cx, (d0, d1) = hc_keyswitch(cx) satisfies
+    d0 + d1 s_out = cx s_in + (small noise) modulo every limb, with s_out = sigma_{g^-1}(s), s_in = s for a rotation key and s_out = s, s_in = s^2 for relinearisation."""
+    import ctypes as C
+    Q, P = Q_MIX[: level + 2], P_CHAIN[:alpha]
+    ctx = make_ctx(Q, P)
+    mods = Q + P
+    rng = np.random.default_rng(seed)
+    sk = np.zeros(N, dtype=np.int64)
+    pos = rng.choice(N, 192, replace=False); sk[pos] = rng.choice([-1, 1], 192)
+    res = lambda v, q: np.where(v >= 0, v, v + q).astype(np.uint64)
+    sk_ntt = np.stack([ctx.ntt(m, res(sk, mods[m])).reshape(-1) for m in range(len(mods))])
+    d_sk = ctx.buf(sk_ntt)
+    seed8 = (C.c_uint32 * 8)(*[int(x) for x in rng.integers(0, 1 << 32, 8)])
+    nl = level + 1
+    for kid, gal in ((1, pow(5, 11, 2 * N)), (2, 2 * N - 1), (3, 0)):
+        ctx._ck(ctx.L.hc_swk_generate(ctx.h, C.c_uint64(kid), level, C.c_uint64(gal), d_sk.ptr, seed8))
+        cx = np.stack([splitmix_rows(seed + 100 * kid + l, Q[l], N) for l in range(nl)])
+        d0, d1 = ctx.keyswitch(kid, level, cx)
+        if gal:
+            ginv = pow(gal, -1, 2 * N); so = np.zeros(N, dtype=np.int64)
+            t = (np.arange(N, dtype=np.int64) * ginv) % (2 * N)
+            so[t % N] = np.where(t < N, sk, -sk)
+        noise = []
+        for l in range(nl):
+            q = Q[l]
+            s_l = sk_ntt[l]
+            sout = ctx.ntt(l, res(so, q)).reshape(-1) if gal else s_l
+            sin_ = s_l if gal else ctx.mul(l, s_l, s_l).reshape(-1)
+            r = ctx.sub(l, ctx.add(l, d0[l], ctx.mul(l, d1[l], sout)), ctx.mul(l, cx[l], sin_))
+            e = ctx.intt(l, r).reshape(-1).astype(np.int64)
+            e = np.where(e > q // 2, e - q, e)
+            noise.append(e)
+        for l in range(1, nl):
+            assert np.array_equal(noise[l], noise[0]), f"key {kid}: the switching noise differs between limbs 0 and {l}: not one small integer polynomial"
+        assert 0 < np.max(np.abs(noise[0])) < 1 << 22, f"key {kid} (galEl {gal}): switching noise {np.max(np.abs(noise[0]))} (expected a small non-zero polynomial)"
+    # deterministic in (seed, key id): the same call gives the same key, another id another key
+    cx = np.stack([splitmix_rows(seed + 7 + l, Q[l], N) for l in range(nl)])
+    a0 = ctx.keyswitch(1, level, cx)
+    ctx._ck(ctx.L.hc_swk_generate(ctx.h, C.c_uint64(1), level, C.c_uint64(pow(5, 11, 2 * N)), d_sk.ptr, seed8))
+    a1 = ctx.keyswitch(1, level, cx)
+    eq(np.stack(a0), np.stack(a1), "hc_swk_generate is deterministic in (seed, key id)")
+    ctx._ck(ctx.L.hc_swk_generate(ctx.h, C.c_uint64(9), level, C.c_uint64(pow(5, 11, 2 * N)), d_sk.ptr, seed8))
+    assert not np.array_equal(np.stack(ctx.keyswitch(9, level, cx)), np.stack(a0))
+    d_sk.free(); ctx.close()
+
+
 # ---------------------------------------------------------------- BL baseline (scope row 8f-2)
 class BLDevice:
     """oracle_bl.BLOracle's interface over the C ABI: the level-1 evaluator operations hconv_bl.cpp composes

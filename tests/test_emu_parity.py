@@ -169,6 +169,12 @@ def test_batched_leveled_entry_points(n, level, alpha):
     pc.case_batched_leveled(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), n=n, level=level, alpha=alpha)
 
 
+def test_swk_generate_switches_keys():
+    """harness key generation on the device: the generated keys satisfy the RLWE key-switching relation (rotation, conjugation, relinearisation)"""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    pc.case_swk_generate(lambda Q, P: Context(Q, P, lib_path=EMU_LIB))
+
+
 def test_free_into_a_foreign_context_is_refused(monkeypatch):
     """cached allocations (HCONV_ASYNC_ALLOC=1): a block goes back to the context it came from; handing it to another context's hc_free is an error, not a silent
     hipFree that leaves the owner's block table stale (the lifetime bug behind round 2's synchronising hc_free)"""

@@ -601,3 +601,11 @@ def test_batched_leveled_entry_points_on_gpu(n, level, alpha):
     rotations of the linear transform) == n single-image calls, bit for bit; n = 8 is the widest batch, alpha = 5 the bootstrapping chain's digit size"""
     from optimal_conv_amd import Context
     pc.case_batched_leveled(lambda Q, P: Context(Q, P), n=n, level=level, alpha=alpha)
+
+
+def test_swk_generate_switches_keys_on_gpu():
+    """harness key generation on the device (hc_swk_generate: ChaCha20 rows, per-digit Gaussian error, batched NTT): rotation, conjugation and relinearisation keys
+    satisfy d0 + d1 s_out = cx s_in + small noise on every limb, at the bootstrapping chain's digit size too"""
+    from optimal_conv_amd import Context
+    pc.case_swk_generate(lambda Q, P: Context(Q, P))
+    pc.case_swk_generate(lambda Q, P: Context(Q, P), level=5, alpha=5, seed=0xA11CE)
