@@ -41,13 +41,25 @@ def traffic_from_profiles(B):
     """HBM-side (L2 <-> fabric) bytes per conv from the committed rocprofv3 PMC passes (tools/gpu_r3_pmc.sh -> tools/pmc_traffic.py).
     PMC counters cannot be read from inside this process, so the figure is the one measured with the command recorded beside it
     (`measured_with`: contexts, ciphertexts per launch set, commit) and committed under profiles/. (None, None) when there is none."""
-    for name in (f"round3_traffic_conv_B{B}.json", f"traffic_conv_B{B}.json"):
+    for name in (f"round4_traffic_conv_B{B}.json", f"round3_traffic_conv_B{B}.json", f"traffic_conv_B{B}.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             return d["bytes_per_conv"], {"file": "profiles/" + name, **d.get("measured_with", {"note": d.get("method", "")})}
         except Exception:
             continue
     return None, None
+
+
+def valu_from_profiles():
+    """VALU side of the conv's roofline from the committed counter pass (tools/gpu_r4_pmc.sh -> tools/valu_floor.py): lane-instructions per conv, the counter-based busy
+    fraction of the VALU pipe, and the issue floor with every instruction class priced at its measured rate. None when there is no such profile."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "round4_conv33_valu.json")))
+        return {"lane_instr_per_conv": d["lane_instr_per_conv"], "busy_frac": d["busy_frac_counter"], "busy_frac_class_priced": d["busy_frac_priced"],
+                "issue_floor_ms": d["issue_floor_ms"], "issue_floor_ms_at_4_cycles_per_instr": d["issue_floor_ms_counter_4cyc"], "kernel_ms_per_conv_one_stream": d["kernel_ms_per_conv_one_stream"],
+                "clock_GHz": d["clock_GHz"], "measured_with": {"file": "profiles/round4_conv33_valu.json", "method": d["method"]}}
+    except Exception:
+        return None
 
 
 def synth_rows(rng, q, shape):
@@ -76,6 +88,185 @@ def cpu_baseline(B):
             "sample": f"1 full conv_then_pack+bias at B={B} (N=2^16) on the C oracle, {dt:.2f} s, host has {os.cpu_count()} cores"}
 
 
+CLI = os.path.join(ROOT, "optimal_conv_amd", "host", "conv")
+
+
+def _secs(tok):
+    import re
+    m = re.match(r"([0-9.e+-]+)(µs|ms|s)$", tok)
+    return float(m.group(1)) * {"µs": 1e-6, "ms": 1e-3, "s": 1.0}[m.group(2)]
+
+
+def _write_conv_csv(d, k, i_batch, iters):
+    """synthetic test_conv_data/*.csv in the reference's layout (test.go:37-40, 66-68): uniform inputs, kernel / sqrt(k^2 B), BN a in [0.5, 1.5], b in [-0.5, 0.5]"""
+    B, W = BATCHS[i_batch], WIDTHS[i_batch]
+    raw = W - k // 2
+    os.makedirs(d, exist_ok=True)
+    for it in range(iters):
+        rng = np.random.default_rng(1000 * k + 10 * i_batch + it)
+        parts = {"in": rng.uniform(-1, 1, raw * raw * B), "ker": rng.uniform(-1, 1, k * k * B * B) / np.sqrt(k * k * B), "bna": rng.uniform(0.5, 1.5, B), "bnb": rng.uniform(-0.5, 0.5, B)}
+        parts["out"] = parts["reluout"] = np.zeros(raw * raw * B)          # the printed precision is not what this run is for (tests/test_gpu_z_cli.py checks it)
+        for name, v in parts.items():
+            np.savetxt(os.path.join(d, f"test_conv{k}_batch_{B}_{name}_{it}.csv"), v, fmt="%.17g")
+
+
+def _write_resnet_csv(root, k, depth, n_images):
+    """random weights and images of the shapes `resnet k depth 1 n false` reads (test.go:78-80, 128, 171-183, 285, 329); the reference ships none (README.md:23)"""
+    blocks = {20: (7, 5, 5), 14: (5, 3, 3), 8: (3, 1, 1)}[depth]
+    ch = (16, 32, 64)
+    shapes = [(3, ch[0])] + [(ch[0], ch[0])] * (blocks[0] - 1) + [(ch[0], ch[1])] + [(ch[1], ch[1])] * blocks[1] + [(ch[1], ch[2])] + [(ch[2], ch[2])] * blocks[2]
+    tag = f"crop_ker{k}_d{depth}_wid1"
+    wdir, pdir = os.path.join(root, "Resnet_weights", "weights_" + tag), os.path.join(root, "Resnet_plain_data", tag)
+    os.makedirs(wdir, exist_ok=True); os.makedirs(pdir, exist_ok=True)
+    rng = np.random.default_rng(20)
+    for i, (ib, ob) in enumerate(shapes):
+        np.savetxt(os.path.join(wdir, f"w{i}-conv.csv"), rng.uniform(-1, 1, k * k * ib * ob) * 0.6 / np.sqrt(k * k * ib), fmt="%.17g")
+        np.savetxt(os.path.join(wdir, f"w{i}-a.csv"), rng.uniform(0.8, 1.2, ob), fmt="%.17g")
+        np.savetxt(os.path.join(wdir, f"w{i}-b.csv"), rng.uniform(-0.1, 0.1, ob), fmt="%.17g")
+    np.savetxt(os.path.join(wdir, "final-fckernel.csv"), rng.uniform(-1, 1, ch[2] * 10) / 8, fmt="%.17g")
+    np.savetxt(os.path.join(wdir, "final-fcbias.csv"), rng.uniform(-0.1, 0.1, 10), fmt="%.17g")
+    for it in range(n_images):
+        np.savetxt(os.path.join(pdir, f"test_image_{it}.csv"), np.random.default_rng(1000 + it).uniform(-1, 1, 32 * 32 * 3), fmt="%.17g")
+
+
+def chain_workloads(device, relu_batch, resnet_batch, resnet_images, relu=True):
+    """BASELINE configs 4 and 5 through the PRODUCT path - the C++ host CLI (optimal_conv_amd/host/conv) over libhconv.so - on synthetic CSVs, in the same run as the
+    headline: `convReLU 5 1` with HCONV_IMAGE_BATCH ciphertexts per launch set (per ciphertext-layer: convolution + BootstrappConv_CtoS + evalReLU + mask + SlotsToCoeffs)
+    and `resnet 3 20 1 n false` (images/hour). Timers are the CLI's own (the reference's: eval.go:463, 479, 565; test.go:361-367). Keys are fresh random ones."""
+    import re
+    import subprocess
+    import tempfile
+    if not os.path.exists(CLI):
+        import __graft_entry__
+        __graft_entry__.build()
+    out = {}
+    env = dict(os.environ, HCONV_SKIP_BL="1", HCONV_DEVICE=str(device), HCONV_ALG_BYTES="1")
+    env.pop("HCONV_SEED", None)
+    with tempfile.TemporaryDirectory(prefix="hconv_bench_") as work:
+        iters = 3
+        _write_conv_csv(os.path.join(work, "test_conv_data"), 5, 1, iters)
+        r = None if not relu else subprocess.run([CLI, "convReLU", "5", "1", str(iters)], cwd=work, capture_output=True, text=True, timeout=900, env=dict(env, HCONV_IMAGE_BATCH=str(relu_batch)))
+        if r is None:
+            pass
+        elif r.returncode == 0:
+            txt = r.stdout
+            conv = [_secs(t) for t in re.findall(r"^Conv \(with BN\) Done in (\S+) ", txt, re.M)]
+            ctos = [_secs(t) for t in re.findall(r"^Done in (\S+) $", txt, re.M) if not t.endswith("keys")]
+            relu = [_secs(t) for t in re.findall(r"ReLU Done in (\S+) ", txt, re.M)]
+            stoc = [_secs(t) for t in re.findall(r"^Boot \(StoC\) Done in (\S+) ", txt, re.M)]
+            alg = re.findall(r"^algorithmic traffic of the layer's tail: (\S+) GB per ciphertext \+ (\S+) GB shared", txt, re.M)
+            keys = re.search(r"^Generating bootstrapping keys\.\.\.\nDone in (\S+) ", txt, re.M)
+            if len(conv) == iters and len(relu) == iters and len(stoc) == iters and len(ctos) >= iters and alg:
+                ctos = ctos[-iters:]
+                layer = [conv[i] + ctos[i] + relu[i] + stoc[i] for i in range(1, iters)]          # the first iteration allocates the pools: warm-up
+                ms = 1e3 * float(np.mean(layer)) / relu_batch
+                ab = (float(alg[-1][0]) + float(alg[-1][1]) / relu_batch) * 1e9 + algorithmic_mib(16) * 2 ** 20
+                out["convReLU_5_1"] = {"ms_per_layer_per_ct": ms, "ciphertexts_per_launch_set": relu_batch, "layer_ms": 1e3 * float(np.mean(layer)),
+                                       "stages_ms_per_launch_set": {"conv": 1e3 * float(np.mean(conv[1:])), "ctos_sine": 1e3 * float(np.mean(ctos[1:])), "relu": 1e3 * float(np.mean(relu[1:])), "mask_stoc": 1e3 * float(np.mean(stoc[1:]))},
+                                       "algorithmic_bytes": ab, "algorithmic_bytes_note": "per ciphertext-layer: every evaluator operation reads its ciphertext operands and writes its result once (SURVEY 8d's convention), switching keys / diagonals / masks once per launch set (shared by the images), + the convolution's",
+                                       "frac": ab / (ms * 1e-3) / 8e12, "bootstrapping_keys_s": _secs(keys.group(1)) if keys else None,
+                                       "command": f"HCONV_IMAGE_BATCH={relu_batch} HCONV_SKIP_BL=1 conv convReLU 5 1 {iters}"}
+                tr = traffic_chain_from_profiles()
+                if tr:
+                    out["convReLU_5_1"].update(tr)
+            else:
+                out["convReLU_5_1"] = {"error": "could not parse the CLI output", "stdout_tail": txt[-400:]}
+        else:
+            out["convReLU_5_1"] = {"error": r.stderr[-400:]}
+        _write_resnet_csv(work, 3, 20, resnet_images)
+        r = subprocess.run([CLI, "resnet", "3", "20", "1", str(resnet_images), "false"], cwd=work, capture_output=True, text=True, timeout=1500, env=dict(env, HCONV_IMAGE_BATCH=str(resnet_batch)))
+        if r.returncode == 0:
+            tot = [(_secs(m.group(1)), int(m.group(2) or 1)) for m in re.finditer(r"^Total done in (\S+) (?:\((\d+) images\))?$", r.stdout, re.M)]
+            if len(tot) >= 2:
+                steady = tot[1:]          # the first group of images also generates the stride layers' keys on demand and allocates the pools
+                sec = sum(t for t, _ in steady); nim = sum(n for _, n in steady)
+                out["resnet20"] = {"images_per_hour": 3600.0 * nim / sec, "seconds_per_image": sec / nim, "images_per_launch_set": resnet_batch, "images_timed": nim,
+                                   "first_group_seconds": tot[0][0], "command": f"HCONV_IMAGE_BATCH={resnet_batch} conv resnet 3 20 1 {resnet_images} false", "data": "random weights and images of the reference's shapes"}
+            else:
+                out["resnet20"] = {"error": "fewer than two image groups", "stdout_tail": r.stdout[-400:]}
+        else:
+            out["resnet20"] = {"error": r.stderr[-400:]}
+    return out
+
+
+def traffic_chain_from_profiles():
+    """fabric bytes per convReLU ciphertext-layer from the committed rocprofv3 PMC passes (tools/gpu_relu_traffic.sh), with their provenance"""
+    for name in ("round4_traffic_convrelu_5_1.json",):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return {"traffic": d["bytes_per_ciphertext_layer"], "traffic_measured_with": {"file": "profiles/" + name, **d.get("measured_with", {})}}
+        except Exception:
+            continue
+    return None
+
+
+def sharded_conv_timing(rank, world, device, backend):
+    """ONE convolution `conv 7 3` (k = 7 only changes prep_Ker: the homomorphic work is that of B = 256) over the N GPUs of the node, both forms of SURVEY 8(e):
+    (a) one process per GPU, partial trees gathered over RCCL (optimal_conv_amd/sharded.py) - all ranks; (b) hc_conv_then_pack_sharded driven by rank 0 with one context
+    per device and peer copies (xGMI). Median of 5 after one warm-up each; rank 0 returns the figures."""
+    import torch
+    import torch.distributed as dist
+    from optimal_conv_amd import Context
+    from optimal_conv_amd.sharded import conv_then_pack_sharded, local_channels
+    B = 256
+    if B % world or world & (world - 1):
+        return {"skipped": f"world size {world} does not divide {B} as a power of two"}
+    rng = np.random.default_rng(0x7C0FFEE)           # the same data on every rank
+    ct_in = np.stack([np.stack([synth_rows(rng, Q0, N), synth_rows(rng, Q1, N)]) for _ in range(2)])
+    pl_ker = np.empty((B, 2, N), dtype=np.uint64)
+    pl_ker[:, 0] = synth_rows(rng, Q0, (B, N)); pl_ker[:, 1] = synth_rows(rng, Q1, (B, N))
+    keys, step, j = [], B // 2, 16 - ((B // 2).bit_length() - 1)
+    while step >= 1:
+        keys.append(((1 << j) + 1, [synth_rows(rng, Q0, N), synth_rows(rng, Q0, N), synth_rows(rng, P0, N), synth_rows(rng, P0, N)]))
+        step //= 2; j += 1
+    bias = synth_rows(rng, Q0, N)
+
+    def make(dev):
+        c = Context([Q0, Q1], [P0], device=dev)
+        for gal, k4 in keys:
+            c.evk_load(gal, k4)
+        c.idx_load(None)
+        return c
+    out = {"workload": "conv 7 3 (one convolution, B = 256, channels i mod N)", "n_gpus": world}
+    ctx = make(device)
+    kh = ctx.ker_load(pl_ker[local_channels(B, rank, world)])
+    cin, bb = ctx.buf(ct_in), ctx.buf(bias)
+    dev_s = f"cuda:{device}" if backend == "nccl" else "cpu"
+    times = []
+    for it in range(6):
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        conv_then_pack_sharded(ctx, cin, 2.0 ** 30, kh, 2.0 ** 30, B, 2.0 ** 30, bb, device=f"cuda:{device}")
+        dist.barrier()
+        times.append((time.perf_counter() - t0) * 1e3)
+    out["sharded_conv_ms_rccl_gather"] = float(np.median(times[1:]))
+    ctx.ker_free(kh); ctx.close()
+    dist.barrier()
+    if rank == 0:
+        try:
+            ctxs = [make(d) for d in range(world)]
+            khs = [c.ker_load(pl_ker) for c in ctxs]
+            ins = [c.buf(ct_in) for c in ctxs]
+            b0, o0 = ctxs[0].buf(bias), ctxs[0].buf(nwords=2 * N)
+            ts = []
+            for it in range(6):
+                for c in ctxs:
+                    c.sync()
+                t0 = time.perf_counter()
+                Context.conv_then_pack_sharded_dev(ctxs, ins, 2.0 ** 30, khs, 2.0 ** 30, B, 2.0 ** 30, b0, o0)
+                ctxs[0].sync()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            out["sharded_conv_ms"] = float(np.median(ts[1:]))
+            out["peer_access"] = "hipMemcpyPeerAsync between the devices' contexts; direct peer access enabled where hipDeviceCanAccessPeer allows (a failure to enable falls back to staged copies, reported on stderr)"
+            for c, k in zip(ctxs, khs):
+                c.ker_free(k); c.close()
+        except Exception as e:
+            out["sharded_conv_ms"] = None; out["sharded_conv_error"] = repr(e)
+    dist.barrier()
+    _ = dev_s
+    return out if rank == 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +280,10 @@ def main():
     ap.add_argument("--batch-alt", type=int, default=0, help="experiment: odd-numbered contexts use this batch size instead (desynchronises the streams)")
     ap.add_argument("--opt", action="append", default=[], help="extra context option name=value (hc_set_option), e.g. small_levels=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the convReLU 5 1 / resnet-20 figures (BASELINE configs 4, 5: the C++ host CLI, ~40 s)")
+    ap.add_argument("--relu-batch", type=int, default=4, help="HCONV_IMAGE_BATCH of the convReLU 5 1 workload")
+    ap.add_argument("--resnet-batch", type=int, default=8, help="HCONV_IMAGE_BATCH of the resnet-20 workload")
+    ap.add_argument("--resnet-images", type=int, default=24)
     args = ap.parse_args()
 
     import torch
@@ -208,6 +403,9 @@ def main():
         alg_bytes = algorithmic_mib(B) * 2 ** 20
         achieved = alg_bytes / (conv_ms_events * 1e-3) / 1e9
         traffic, traffic_how = traffic_from_profiles(B)
+        valu = valu_from_profiles() if B == 256 else None
+        # which roofline binds: the VALU issue floor (class-priced, measured instruction counts) against the HBM time of the algorithmic bytes, both per conv
+        bound = "valu" if (valu and valu["issue_floor_ms"] > alg_bytes / 8e12 * 1e3) else "hbm"
         mib = 2 ** 20
         loops = {}        # per-loop share of the roofline from the one-stream kernel profile above (SURVEY.md 8d splits the algorithmic bytes the same way)
         if kern:
@@ -226,21 +424,46 @@ def main():
             "config": {"workload": f"conv {args.ker_wid} {args.i_batch}", "ker_wid": args.ker_wid, "batch": B, "in_wid": W,
                        "logN": 16, "moduli": "ckks.DefaultBootstrapParams[6] Q0,Q1 + P=0x1fffffffffe00001",
                        "convs_per_step_per_gpu": per_step, "ciphertexts_per_launch_set": NB, "contexts_per_gpu": S, "chunk_nodes": args.chunk},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "roofline": {"bound": bound, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_measured_with": traffic_how,
                          "unit_of_launch": "one conv_then_pack (its share of the batched launch set: all kernels of loop A and of the pack tree)",
                          "algorithmic_bytes_per_conv": alg_bytes, "conv_ms_hip_events": conv_ms_events,
                          "dominant_kernel": dom, "kernels": kern,
                          "kernels_measured_with": {"contexts": 1, "ciphertexts_per_launch_set": NB, "note": "HIP events around every launch of one context, separate untimed pass"},
-                         "loops": loops, "single_conv_ms": single_ms},
+                         "loops": loops, "single_conv_ms": single_ms, "valu": valu},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
-        print(json.dumps(out), flush=True)
     for L in lanes:
         for k in L["ker"]:
             L["ctx"].ker_free(k)
         L["ctx"].close()
+    sharded = None
+    if world > 1:           # BASELINE config 3 beside the weak-scaling figure: ONE `conv 7 3` (B = 256) split i mod N over the N devices
+        try:
+            sharded = sharded_conv_timing(rank, world, device, backend)
+        except Exception as e:
+            sharded = {"error": repr(e)}
+    wl = None
+    if not args.no_workloads:       # after the headline's contexts are gone: the CLI builds its own (device memory is free again). N > 1: every rank classifies its own images
+        try:
+            wl = chain_workloads(device, args.relu_batch, args.resnet_batch, args.resnet_images, relu=(rank == 0))
+        except Exception as e:      # the headline line must not depend on the secondary workloads
+            wl = {"error": repr(e)}
+        if world > 1:               # every rank takes part whatever happened to its own run (inf = this rank has no figure)
+            spi = wl.get("resnet20", {}).get("seconds_per_image", float("inf")) if isinstance(wl, dict) else float("inf")
+            t = torch.tensor([spi], dtype=torch.float64, device=f"cuda:{device}" if backend == "nccl" else "cpu")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            if rank == 0 and "resnet20" in wl and np.isfinite(float(t.item())):
+                wl["resnet20"].update({"images_per_hour": world * 3600.0 / float(t.item()), "n_gpus": world, "note": "images sharded over the ranks (independent ciphertexts, no collective); slowest rank's time per image"})
+            elif rank == 0 and "resnet20" in wl:
+                wl["resnet20"]["note"] = "another rank produced no figure: this is rank 0's own rate"
+    if rank == 0:
+        if wl is not None:
+            out["workloads"] = wl
+        if sharded is not None:
+            out["sharded_conv"] = sharded
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -125,6 +125,11 @@ int hc_lv_mul_tensor(hc_ctx *ctx, int level, const uint64_t *a0, const uint64_t 
 /* consts_host: level+1 host integers, one per limb (reduced mod q_l by the callee) */
 int hc_lv_mul_const(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *consts_host, uint64_t *out);
 int hc_lv_add_const(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *consts_host, uint64_t *out);
+/* evaluatePolyFromPowerBasis' leaf (EvaluatePoly / EvaluateCheby: a MultByConst of every needed power and an Add chain, then AddConst) as ONE launch:
+ * out_k[l] = sum over t < nterms (<= 8) of consts[t][l] * a_t,k[l]  (+ addc[l] on k = 0), k = 0, 1, rows 0..level. a0, a1: HOST arrays of nterms device pointers (the two
+ * polynomials of each ciphertext); consts: HOST [nterms][level+1] integers, addc: HOST [level+1] or NULL (reduced by the callee). Exact modular sums: the same residues
+ * as hc_lv_op2(HC_LV_MUL_CONST) + hc_lv_op2(HC_LV_ADD) per term + hc_lv_add_const. Outputs may alias inputs element-wise (out_k == a_t,k). */
+int hc_lv_lincomb2(hc_ctx *ctx, int level, int nterms, const uint64_t *const *a0, const uint64_t *const *a1, const uint64_t *consts, const uint64_t *addc, uint64_t *out0, uint64_t *out1);
 /* test_run: ckks.(*Bootstrapper).modUp for one polynomial: in_q0 = NTT row mod q_0; out = level+1 NTT rows of the centred lift */
 int hc_lv_mod_raise(hc_ctx *ctx, int level, const uint64_t *in_q0, uint64_t *out);
 
@@ -148,12 +153,18 @@ int hc_rotate_gal_l0(hc_ctx *ctx, uint64_t galEl, const uint64_t *c0, const uint
  * into every target limb, one accumulation of both key components): about 32 launches at level 27. */
 int hc_swk_load(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *rows_host);
 int hc_keyswitch(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1);
+/* evaluator.Relinearize / MulRelin's tail as one call: out_k = a_k + (hc_keyswitch of cx)_k, k = 0, 1 (a = the degree-0 and degree-1 parts of the tensor product, cx = its
+ * degree-2 part); the addition rides in ModDown's last pass. The same residues as hc_keyswitch + hc_lv_op2(HC_LV_ADD). out_k may be a_k. */
+int hc_keyswitch_add(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, const uint64_t *a0, const uint64_t *a1, uint64_t *out0, uint64_t *out1);
 /* HARNESS ONLY - not part of what a Lattigo host binds (it owns its keys and hands them over with hc_swk_load): rlwe.KeyGenerator.GenSwitchingKey on the device for
  * the C++ test harness, restricted to the rows a level-`level` key switch reads. galEl odd: the rotation / conjugation key of galEl (s_out = sigma_{galEl^-1}(s));
  * galEl = 0: the relinearisation key (s^2 -> s). sk_ntt: DEVICE rows [nq + np][N] = NTT(s) modulo every modulus of the context. seed8: 8 x 32 bits keying ChaCha20;
  * uniform rows and the per-digit error (sigma 3.2, |e| <= 19) are functions of (seed, key_id, digit, limb, coefficient). The reference's keys are crypto/rand draws:
  * nothing to reproduce but the RLWE relation b + a s_out - [own limbs] P s_in = e, which tests/ check. The key is stored as hc_swk_load would store it. */
 int hc_swk_generate(hc_ctx *ctx, uint64_t key_id, int level, uint64_t galEl, const uint64_t *sk_ntt, const uint32_t *seed8);
+/* TEST HARNESS: the same key structure with the uniform rows of the test oracle's generator (counter-based splitmix64 of seed + 0x1000 + 64 digit + limb) and the
+ * per-digit errors e_host[beta][N] (signed 64-bit, HOST) supplied by the caller: lets the product host replay, bit for bit, a network the oracle evaluated under its keys */
+int hc_swk_generate_splitmix(hc_ctx *ctx, uint64_t key_id, int level, uint64_t galEl, const uint64_t *sk_ntt, uint64_t seed, const int64_t *e_host);
 /* Hoisted form (evaluator.RotateHoisted, conv.go:131; Lattigo's linear transforms): hc_keyswitch_decompose computes the digit
  * decomposition of cx once and keeps it in the context; each hc_keyswitch_hoisted(key, level, cx, ...) then only does the inner
  * product with its key and the ModDown. Bit-identical to hc_keyswitch. The decomposition is valid until the next hc_keyswitch /
@@ -176,6 +187,10 @@ int hc_keyswitch_qp_rotate(hc_ctx *ctx, uint64_t key_id, uint64_t galEl, int lev
 int hc_mod_down2(hc_ctx *ctx, int level, const uint64_t *x, uint64_t *out0, uint64_t *out1);
 int hc_qp_op2(hc_ctx *ctx, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1);
 int hc_keyswitch_hoisted(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1);
+/* the diagonal sum of one giant step of MultiplyByDiagMatrixBSGS in one launch: out[2][level+1+np][N] (+)= sum over t < nterms (<= 64) of a[t] (*) pt[t], a[t] =
+ * extended-basis pairs (the hoisted rotations), pt[t] = plaintexts [level+1+np][N] (the encoded diagonals); a, pt: HOST arrays of device pointers; accumulate != 0
+ * adds to what out holds. The same residues as nterms hc_qp_op2 calls (HC_LV_MUL, then HC_LV_MUL_ACC); out must not be one of the a[t]. */
+int hc_qp_mul_sum(hc_ctx *ctx, int level, int nterms, const uint64_t *const *a, const uint64_t *const *pt, uint64_t *out, int accumulate);
 
 /* ---- L1: the fused hot path ---- */
 /* pl_ker as prep_Ker leaves it (conv.go:510-515): HOST array [max_ob][2][N], level 1, NTT domain. */

@@ -45,9 +45,12 @@ SYMBOLS = {
     "hc_keyswitch_l0": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_rotate_gal_l0": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_swk_load": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, u64p]),
+    "hc_keyswitch_add": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_swk_generate_splitmix": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_int64)]),
     "hc_swk_generate": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32)]),
     "hc_keyswitch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_keyswitch_decompose": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "hc_qp_mul_sum": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_int]),
     "hc_keyswitch_hoisted": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_keyswitch_qp": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "hc_keyswitch_qp_rotate": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -62,6 +65,7 @@ SYMBOLS = {
     "hc_lv_mul_tensor": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 7),
     "hc_lv_mul_const": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_void_p]),
     "hc_lv_add_const": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_void_p]),
+    "hc_lv_lincomb2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u64p, u64p, C.c_void_p, C.c_void_p]),
     "hc_lv_mod_raise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_ker_load": (C.c_int, [C.c_void_p, u64p, C.c_int, C.POINTER(C.c_void_p)]),
     "hc_ker_load_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),

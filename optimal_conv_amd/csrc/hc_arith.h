@@ -99,6 +99,17 @@ HC_HD u64 hc_opaque_uniform(u64 v) {
 // per-kernel constants of one modulus (q must be uniform over the wave: every call site takes it from kernel arguments or from a
 // table indexed by blockIdx)
 struct HcQ { u64 q, nq, q4, nq4, nq2; };     // nq = 2^64 - q, q4 = 4q, nq4 = 2^64 - 4q, nq2 = 2^64 - 2q
+// the same constants for a modulus the compiler cannot prove wave-uniform (loaded inside a loop): kept opaque in vector registers
+HC_HD u64 hc_opaque_vector(u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("; constant kept opaque" : "+v"(v));
+#endif
+    return v;
+}
+HC_HD HcQ hc_qv(u64 q) {
+    HcQ Q; Q.q = q; Q.nq = hc_opaque_vector(0 - q); Q.q4 = 4 * q; Q.nq4 = hc_opaque_vector(0 - 4 * q); Q.nq2 = hc_opaque_vector(0 - 2 * q);
+    return Q;
+}
 HC_HD HcQ hc_q(u64 q) {
     HcQ Q; Q.q = q; Q.nq = hc_opaque_uniform(0 - q); Q.q4 = 4 * q; Q.nq4 = hc_opaque_uniform(0 - 4 * q); Q.nq2 = hc_opaque_uniform(0 - 2 * q);
     return Q;
@@ -122,6 +133,14 @@ HC_HD u64 hc_mont(u64 a, u64 b, u64 q, u64 qinv) {
     u64 lo = (u64)m, hi = (u64)(m >> 64);
     u64 h = hc_mulhi(lo * qinv, q);
     u64 r = hi - h;
+    return hi < h ? r + q : r;
+}
+// Montgomery reduction of an ACCUMULATED 128-bit sum T = sum a_d * b_d (Montgomery operands as hc_mont takes them): T * 2^-64 mod q, canonical. Needs T < q * 2^64
+// (seven products of residues below 2^61 at most): then (T >> 64) - mulhi(lo * qinv, q) lies in (-q, q), as in hc_mont. Equal to the modular sum of the hc_mont results.
+HC_HD u64 hc_mont_redc(u128 T, u64 q, u64 qinv) {
+    const u64 lo = (u64)T, hi = (u64)(T >> 64);
+    const u64 h = hc_mulhi(lo * qinv, q);
+    const u64 r = hi - h;
     return hi < h ? r + q : r;
 }
 HC_HD u64 hc_addmod(u64 a, u64 b, u64 q) { return hc_csub(a + b, q); }

@@ -353,6 +353,24 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const 
         }
     }
 }
+// A linear combination with integer coefficients of up to 8 ciphertexts, both polynomials, all limbs, every image of a batch in one launch: evaluatePolyFromPowerBasis'
+// leaf (a MultByConst per power of the basis and an Add chain, plus AddConst): out_k[l] = sum_t c[t][l] * a_t,k[l] (+ addc[l] on k = 0). The constants come in Montgomery
+// form (c * 2^64 mod q_l), the products are summed as 128-bit integers and reduced once (8 q^2 < q 2^64 needs q < 2^61: every accepted modulus): the residue of the
+// reference's term-by-term sum, with each operand read once and the result written once. grid = (64, level + 1, 2 * images)
+#define HC_MAXLIN 8
+struct HcLinPtrs { const u64 *a0[HC_MAXLIN], *a1[HC_MAXLIN]; };
+struct HcLinConsts { u64 c[HC_MAXLIN][32]; u64 addc[32]; };
+__global__ __launch_bounds__(HC_TPB) void hc_k_lv_lincomb(HcLinPtrs P, HcLinConsts K, int nterms, u64 *o0, u64 *o1, const HcMod *mods, size_t is) {
+    const int l = blockIdx.y, k = blockIdx.z & 1; const HcMod m = mods[l];
+    const size_t base = (size_t)l * 65536 + (size_t)(blockIdx.z >> 1) * is;
+    u64 *o = k ? o1 : o0; const u64 addc = k ? 0 : K.addc[l];
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
+        u128 T = 0;
+#pragma unroll
+        for (int t = 0; t < HC_MAXLIN; t++) if (t < nterms) T += (u128)(k ? P.a1[t] : P.a0[t])[base + i] * K.c[t][l];
+        o[base + i] = hc_addmod(hc_mont_redc(T, m.q, m.qinv), addc, m.q);
+    }
+}
 // the tensor step of ckks.evaluator.mulRelin for all limbs: d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1 (canonical)
 // blockIdx.z = image of a batch (every operand `is` words further per image)
 __global__ __launch_bounds__(HC_TPB) void hc_k_lv_tensor(const u64 *a0, const u64 *a1, const u64 *b0, const u64 *b1, u64 *d0, u64 *d1, u64 *d2, const HcMod *mods, size_t is) {
@@ -1272,15 +1290,7 @@ __global__ __launch_bounds__(HC_STPB) void hc_k_sb5(HcLoopB B, HcTwTab T0fwd, Hc
 // representatives) -> one target modulus t:
 //   y_i = x_i * (S/s_i)^-1 mod s_i ;  v = uint64(sum_i float64(y_i)/float64(s_i)) [fp64, limb order] ;
 //   out = sum_i y_i * (S/s_i mod t) - v * (S mod t)  mod t.      n == 1 degenerates to x mod t (the "copy" case).
-struct HcBasisExt {
-    int n;
-    u64 s[8];          // source moduli
-    HcTw inv[8];       // (S/s_i)^-1 mod s_i
-    HcTw hat[8];       // S/s_i mod t
-    HcTw smodt;        // S mod t
-    u64 t, mu_t;       // target modulus, floor(2^64/t)
-    u64 mu_s[8];       // floor(2^64/s_i)
-};
+
 // ring.DivRoundByLastModulusNTT, general level (the fused level-1 form is loop A's a2/a3): t = InvNTT_{qL}(x_L) (canonical);
 // lift:   v = ((t + h mod qL) + (q_i - h mod q_i)) mod q_i   with h = (qL-1)/2  -- the centred remainder, to be transformed mod q_i
 // finish: out_i = (x_i - NTT_{q_i}(v)) * qL^-1 mod q_i                                   (hc_k_rescale_{lift,finish}_mm below)
@@ -1290,10 +1300,65 @@ struct HcBasisExt {
 // (the Q limbs 0..nl-1 of a level, then the special primes), blockIdx.z selects one of several operands zs_* words apart.
 // Rows in [skip_lo, skip_hi) are left untouched (a digit's own limbs during decomposition). Forward transforms use the
 // HC_FM_ALT folding, which every accepted modulus admits; outputs are canonical, so results equal the per-limb kernels'.
+struct HcBasisExt {
+    int n;
+    u64 s[8];          // source moduli
+    HcTw inv[8];       // (S/s_i)^-1 mod s_i
+    HcTw hat[8];       // S/s_i mod t
+    HcTw smodt;        // S mod t
+    u64 t, mu_t;       // target modulus, floor(2^64/t)
+    u64 mu_s[8];       // floor(2^64/s_i)
+};
+// the target-side sum of the extension for the 16 elements (rows hi * 16 + tid of one column) a cols-pass thread owns: yv = that column of the y_i / v rows.
+// Four elements at a time: their (n + 1) x 4 operands are all requested before the first is used, so that the loads of a group overlap (element by element the
+// kernel waited one L2 round trip per element: 626 us per launch against 548 for the separate extension and cols pass it replaces)
+__device__ __forceinline__ void hc_basis_ext_tile(u64 (&e)[16], const u64 *yv, const HcBasisExt &B, int tid) {
+    const int n = B.n; const HcQ Q = hc_q(B.t);
+#pragma unroll
+    for (int g0 = 0; g0 < 16; g0 += 4) {
+        u64 y[4][9];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const u64 *p = yv + (size_t)((g0 + g) * 16 + tid) * 256;
+#pragma unroll
+            for (int i = 0; i < 9; i++) if (i <= n) y[g][i] = p[(size_t)i * 65536];                // rows y_0..y_(n-1), then v at row n
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            u64 v = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) if (i == n) v = y[g][i];
+            u64 r;
+            if (n == 1) r = hc_barrett64(y[g][0], B.t, B.mu_t);
+            else if (B.t < (1ull << 58)) {                                   // lazy sum: below 2^58 up to 8 terms and the offset stay under 36 t < 2^64 unreduced
+                u64 acc = Q.q4;
+#pragma unroll
+                for (int i = 0; i < 8; i++) if (i < n) acc += hc_shoup4(y[g][i], B.hat[i].w, B.hat[i].ws, Q);
+                r = hc_reduce64(acc - hc_shoup4(v, B.smodt.w, B.smodt.ws, Q), B.mu_t, Q);
+            } else {                                                         // the 60 / 61-bit limbs fold the running sum by 4t
+                u64 acc = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) if (i < n) acc = hc_fold(acc + hc_shoup4(y[g][i], B.hat[i].w, B.hat[i].ws, Q), Q.nq4);
+                r = hc_canon8(acc + Q.q4 - hc_shoup4(v, B.smodt.w, B.smodt.ws, Q), Q);
+            }
+            e[g0 + g] = r;
+        }
+    }
+}
 struct HcRowMod { HcTwTab fwd, inv; u64 q, mu; };
 // blockIdx.z = operand + nz * image: `nz` operands zs_* words apart (the two polynomials of a ciphertext, the digits of a key switch), and the
 // images of a batch (hc_set_batch) is_* words apart
-struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; int z_alpha; int nz; size_t is_in, is_out; };
+struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; int z_alpha; int nz; size_t is_in, is_out;
+              // fused prologue of the cols-forward pass / epilogue of the rows-forward pass (0 = none):
+              //  lift_level > 0  (cols_fwd): the input is NOT read from `in` rows: it is DivRoundByLastModulusNTT's centred remainder of t (one coefficient row per operand,
+              //                  `in` = t[z][N]) lifted into row y's modulus (hc_k_rescale_lift_mm's formula) - Rescale without the lift's pass over memory
+              //  epi_x != null   (rows_fwd): out = (x - NTT result) * epi_mul[y] (+ epi_add) instead of the NTT result: ModDown's (acc - ext) / P with an optional addend
+              //                  (relinearisation: d_k + key-switched part), or Rescale's (x - u) / q_L. x / add / out: operands epi_*_zs apart, images epi_*_is apart
+              //  ext_bs != null  (cols_fwd): the input is the fast basis extension of row y computed on the fly from the per-coefficient y_i / v rows hc_k_basis_yv left
+              //                  (`in` = yv[z][n_src + 1][N]): sum_i y_i (S/s_i mod t) - v (S mod t), constants ext_bs[(z_alpha ? zi * ext_rows : 0) + y] - the extended
+              //                  digits (or ModDown's extension of the P part) never exist in memory in the coefficient domain
+              int lift_level; const HcMod *mods; const HcBasisExt *ext_bs; int ext_rows;
+              const u64 *epi_x; size_t epi_x_zs, epi_x_is; const HcTw *epi_mul; const u64 *epi_add; size_t epi_add_zs, epi_add_is; };
 // z_alpha > 0: operand z is digit z of a key switch and its own limbs [z*z_alpha, min((z+1)*z_alpha, nl)) are the rows to skip
 __device__ __forceinline__ bool hc_mm_skip(const HcMm &A, int y, int zi) {
     if (A.z_alpha > 0) { const int lo = zi * A.z_alpha, hi = lo + A.z_alpha < A.nl ? lo + A.z_alpha : A.nl; return y >= lo && y < hi; }
@@ -1304,14 +1369,24 @@ __device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl
     const int y = blockIdx.y, zi = (int)blockIdx.z % A.nz, img = (int)blockIdx.z / A.nz; if (hc_mm_skip(A, y, zi)) return; \
     const HcRowMod &R = A.M[hc_mm_mod(A, y)]; \
     in += (size_t)zi * A.zs_in + (size_t)img * A.is_in; out += (size_t)zi * A.zs_out + (size_t)img * A.is_out;
+template <bool EXT>      // EXT: the instantiation whose input is the fused basis extension (more registers; the plain transforms keep five workgroups per CU)
 __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_COLS_LDS];
     HC_MM_PROLOGUE
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
     u64 e[16];
+    if (A.lift_level > 0) {                                                  // block-uniform
+        const u64 qL = A.mods[A.lift_level].q, h = (qL - 1) >> 1, qi = R.q, neg_h = qi - (h % qi);
+        const u64 *tt = in + blockIdx.x * 16 + c;                           // `in` = t[z][N] (zs_in = N, is_in = nz N): one coefficient row per operand
 #pragma unroll
-    for (int hi = 0; hi < 16; hi++) e[hi] = in[base + (size_t)(hi * 16 + tid) * 256];
+        for (int hi = 0; hi < 16; hi++) e[hi] = hc_barrett64(hc_csub(tt[(size_t)(hi * 16 + tid) * 256] + h, qL) + neg_h, qi, R.mu);
+    } else if (EXT) {
+        hc_basis_ext_tile(e, in + blockIdx.x * 16 + c, A.ext_bs[(A.z_alpha > 0 ? (size_t)zi * A.ext_rows : 0) + y], tid);
+    } else {
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) e[hi] = in[base + (size_t)(hi * 16 + tid) * 256];
+    }
     hc_cols_fwd<HC_FM_ALT>(e, lds, R.fwd, c, tid, hc_q(R.q));
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) out[base + (size_t)(tid * 16 + lo) * 256] = e[lo];
@@ -1328,8 +1403,21 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, 
     hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, Q);
     HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
+    const size_t lin = pbase + (size_t)(blockIdx.x * 16) * 256 + t;
+    if (A.epi_x != nullptr) {                                                // block-uniform
+        const u64 *x = A.epi_x + (size_t)zi * A.epi_x_zs + (size_t)img * A.epi_x_is + lin;
+        const u64 *ad = A.epi_add != nullptr ? A.epi_add + (size_t)zi * A.epi_add_zs + (size_t)img * A.epi_add_is + lin : nullptr;
+        const HcTw w = A.epi_mul[y];
 #pragma unroll
-    for (int k = 0; k < 16; k++) out[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu);
+        for (int k = 0; k < 16; k++) {
+            u64 r = hc_mul_shoup(hc_submod(x[k * 256], hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu), R.q), w.w, w.ws, R.q);
+            if (ad != nullptr) r = hc_addmod(r, ad[k * 256], R.q);
+            out[lin + k * 256] = r;
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[lin + k * 256] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu);
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_ROWS_LDS];
@@ -1358,41 +1446,25 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_inv_canon_mm(const u64 *in, 
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_canon4(e[hi], Q);
 }
-// fast basis extension into every target row of the batch: Bs[T] holds the constants for target row T (the source-side
-// constants s, inv, mu_s are the same in all of them). One thread owns a coefficient: y_i and the fp64 overflow count v are
-// computed once, then reused for the targets T = blockIdx.y, blockIdx.y + gridDim.y, ... (rows in [skip_lo, skip_hi) excepted).
-// z_alpha > 0: operand z is digit z (constants Bs + z*rows, own limbs [z*z_alpha, ..) skipped, nl = number of Q limbs).
-// blockIdx.z = operand + nz * image (images is_src / is_dst words apart)
-__global__ __launch_bounds__(HC_TPB) void hc_k_basis_extend_mm(const u64 *src, size_t src_stride, u64 *dst, const HcBasisExt *Bs, int rows, int skip_lo, int skip_hi, size_t zs_src, size_t zs_dst, int z_alpha, int nl,
-                                                               int nz, size_t is_src, size_t is_dst) {
-    const int zi = (int)blockIdx.z % nz, img = (int)blockIdx.z / nz;
-    src += (size_t)zi * zs_src + (size_t)img * is_src; dst += (size_t)zi * zs_dst + (size_t)img * is_dst;
-    if (z_alpha > 0) { Bs += (size_t)zi * rows; skip_lo = zi * z_alpha; skip_hi = skip_lo + z_alpha < nl ? skip_lo + z_alpha : nl; }
-    const HcBasisExt &B0 = Bs[0];
+// source side of the fast basis extension, once per coefficient: y_i = x_i (S/s_i)^-1 mod s_i for the n source limbs and the fp64 overflow count v = uint64(sum_i
+// float64(y_i) / float64(s_i)) (ring.reconstructRNS: the reference's expression, limb order) -> yv[z][yv_rows][N] (rows y_0..y_(n-1), then v). The target side - one lazy sum per
+// target limb - runs where the extension's forward transform reads its input (hc_k_cols_fwd_mm, HcMm::ext_bs). blockIdx.y = operand + nz * image. grid = (64, nz * images)
+__global__ __launch_bounds__(HC_TPB) void hc_k_basis_yv(const u64 *src, size_t src_stride, u64 *yv, int yv_rows, const HcBasisExt *Bs, int rows, size_t zs_src, int z_alpha, int nz, size_t is_src) {
+    const int zi = (int)blockIdx.y % nz, img = (int)blockIdx.y / nz;
+    src += (size_t)zi * zs_src + (size_t)img * is_src;
+    const HcBasisExt &B0 = Bs[z_alpha > 0 ? (size_t)zi * rows : 0];
     const int n = B0.n;
+    yv += (size_t)blockIdx.y * yv_rows * 65536;                               // [operand + nz * image][yv_rows][N]: rows y_0..y_(n-1), then v (a last, shorter digit leaves rows unused)
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        u64 y[8]; double vi = 0.0;
+        double vi = 0.0;
 #pragma unroll
         for (int i = 0; i < 8; i++) if (i < n) {
             const u64 x = hc_barrett64(src[(size_t)i * src_stride + j], B0.s[i], B0.mu_s[i]);
-            y[i] = n == 1 ? x : hc_mul_shoup(x, B0.inv[i].w, B0.inv[i].ws, B0.s[i]);
-            vi += (double)y[i] / (double)B0.s[i];
+            const u64 y = n == 1 ? x : hc_mul_shoup(x, B0.inv[i].w, B0.inv[i].ws, B0.s[i]);
+            vi += (double)y / (double)B0.s[i];
+            yv[(size_t)i * 65536 + j] = y;
         }
-        const u64 v = (u64)vi;
-        for (int T = blockIdx.y; T < rows; T += gridDim.y) {
-            if (T >= skip_lo && T < skip_hi) continue;
-            const HcBasisExt &B = Bs[T];
-            u64 r;
-            if (n == 1) r = hc_barrett64(y[0], B.t, B.mu_t);
-            else {
-                u64 acc = 0;
-#pragma unroll
-                // the Shoup product reduces ANY 64-bit multiplicand, so y_i (< s_i, possibly > t) needs no reduction modulo t of its own
-                for (int i = 0; i < 8; i++) if (i < n) acc = hc_addmod(acc, hc_mul_shoup(y[i], B.hat[i].w, B.hat[i].ws, B.t), B.t);
-                r = hc_submod(acc, hc_mul_shoup(v, B.smodt.w, B.smodt.ws, B.t), B.t);
-            }
-            dst[(size_t)T * 65536 + j] = r;
-        }
+        yv[(size_t)n * 65536 + j] = (u64)vi;
     }
 }
 // The inner product of a key switch in one launch, BOTH key components and ALL images of a batch per thread:
@@ -1406,32 +1478,31 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const 
     const HcMod m = mods[T < nl ? T : nq + (T - nl)];
     const size_t rowT = (size_t)T * 65536, comp = (size_t)nt * 65536;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        u64 s0[HC_MAXIMG], s1[HC_MAXIMG];
+        // the products of up to 6 digits are summed as 128-bit integers and reduced ONCE (6 q^2 < q 2^64 for q < 2^61): the same residue as the modular sum of the
+        // per-digit Montgomery products at less than half the instructions; a longer decomposition folds every 6 digits
+        u128 t0[HC_MAXIMG], t1[HC_MAXIMG]; u64 s0[HC_MAXIMG], s1[HC_MAXIMG];
         for (int d = 0; d < beta; d++) {
             const int lo = d * alpha, hi = lo + alpha < nl ? lo + alpha : nl;
             const bool own = T >= lo && T < hi;
             const u64 kb = evk[((size_t)d * 2 * nt) * 65536 + rowT + j], ka = evk[((size_t)d * 2 * nt) * 65536 + comp + rowT + j];
             const u64 *xs = own ? cx + rowT + j : digits + ((size_t)d * nt) * 65536 + rowT + j; const size_t xis = own ? cx_is : dg_is;
+            const int ph = d % 6;
 #pragma unroll
             for (int g = 0; g < HC_MAXIMG; g++) if (g < n) {
                 const u64 x = xs[(size_t)g * xis];
-                const u64 p0 = hc_mont(x, kb, m.q, m.qinv), p1 = hc_mont(x, ka, m.q, m.qinv);
-                s0[g] = d == 0 ? p0 : hc_addmod(s0[g], p0, m.q);
-                s1[g] = d == 0 ? p1 : hc_addmod(s1[g], p1, m.q);
+                const u128 p0 = (u128)x * kb, p1 = (u128)x * ka;
+                t0[g] = ph == 0 ? p0 : t0[g] + p0;
+                t1[g] = ph == 0 ? p1 : t1[g] + p1;
+                if (ph == 5 || d + 1 == beta) {
+                    const u64 r0 = hc_mont_redc(t0[g], m.q, m.qinv), r1 = hc_mont_redc(t1[g], m.q, m.qinv);
+                    s0[g] = d < 6 ? r0 : hc_addmod(s0[g], r0, m.q);
+                    s1[g] = d < 6 ? r1 : hc_addmod(s1[g], r1, m.q);
+                }
             }
         }
 #pragma unroll
         for (int g = 0; g < HC_MAXIMG; g++) if (g < n) { u64 *a = acc + (size_t)g * acc_is + rowT + j; a[0] = s0[g]; a[comp] = s1[g]; }
     }
-}
-// d_k[l] = (acc[k][l] - ext[k][l]) * P^-1 mod q_l for all limbs l and both k; blockIdx.z = k + 2 * image (images acc_is / ext_is / d_is words apart)
-__global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_mm(const u64 *acc, size_t acc_zs, const u64 *ext, size_t ext_zs, u64 *d0, u64 *d1, const HcMod *mods, const HcTw *pinv,
-                                                             size_t acc_is, size_t ext_is, size_t d_is) {
-    const int l = blockIdx.y, k = blockIdx.z & 1; const size_t img = blockIdx.z >> 1; const u64 q = mods[l].q; const HcTw pi = pinv[l];
-    const u64 *a = acc + img * acc_is + (size_t)k * acc_zs + (size_t)l * 65536, *x = ext + img * ext_is + (size_t)k * ext_zs + (size_t)l * 65536;
-    u64 *o = (k ? d1 : d0) + img * d_is + (size_t)l * 65536;
-    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
-        o[j] = hc_mul_shoup(hc_submod(a[j], x[j], q), pi.w, pi.ws, q);
 }
 // ModDown's last step and evaluator.permuteNTT's tail in one pass (rotations: the key-switched polynomials never reach HBM unpermuted):
 //   out_0[l][i] = ((acc_0 - ext_0) * P^-1 + c0)[l][src(i)],  out_1[l][i] = ((acc_1 - ext_1) * P^-1)[l][src(i)],  src = PermuteNTTIndex(g)
@@ -1464,23 +1535,35 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_qp_rotate_finish(const u64 *acc, 
         o[j] = r;
     }
 }
-// general-level DivRoundByLastModulusNTT, all lower limbs per launch: lift (v[i] from t) and finish (out[i] = (x[i]-u[i]) * qL^-1)
-// blockIdx.z = polynomial + np * image (a ciphertext's two polynomials xs / os words apart, the images of a batch x_is / o_is; the scratch rows t, v are dense: [z][..])
-__global__ __launch_bounds__(HC_TPB) void hc_k_rescale_lift_mm(const u64 *t, u64 *v, const HcMod *mods, int level) {
-    const int i = blockIdx.y; const u64 qL = mods[level].q, h = (qL - 1) >> 1, qi = mods[i].q, mu_i = mods[i].mu, neg_h = qi - (h % qi);
-    t += (size_t)blockIdx.z * 65536; v += (size_t)blockIdx.z * level * 65536;
-    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
-        v[(size_t)i * 65536 + j] = hc_barrett64(hc_csub(t[j] + h, qL) + neg_h, qi, mu_i);
+// The diagonal sum of one giant step of a linear transform (MultiplyByDiagMatrixBSGS: MulCoeffsMontgomery(AndAdd) of the hoisted rotations with the encoded
+// diagonals) in ONE launch: out[k][T] (+)= sum over t < nterms of a_t[k][T] (*) pt_t[T] over all 2 (level+1+np) rows of the extended basis, for every image of the
+// batch. a_t: extended-basis pairs (images a_is words apart), pt_t: plaintexts [nt][N] common to all images. Each diagonal element is read and brought to
+// Montgomery form once per coefficient and component; the products of up to 7 terms are summed as 128-bit integers and reduced once (7 q^2 < q 2^64): the residues
+// of the term-by-term sum at a third of the traffic (the accumulator is neither re-read nor re-written per term). grid = (64, nt, 2)
+#define HC_MAXTERMS 64
+struct HcTermPtrs { const u64 *a[HC_MAXTERMS]; const u64 *pt[HC_MAXTERMS]; };
+__global__ __launch_bounds__(HC_TPB) void hc_k_qp_mul_sum(HcTermPtrs P, int nterms, u64 *out, const HcMod *mods, int nlq, int nqt, int nt, int n, size_t a_is, size_t o_is, int accumulate) {
+    const int row = blockIdx.y, k = blockIdx.z; const HcMod m = mods[row < nlq ? row : nqt + (row - nlq)];
+    const size_t base = (size_t)row * 65536, comp = (size_t)k * nt * 65536;
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
+        u128 T[HC_MAXIMG]; u64 s[HC_MAXIMG];
+#pragma unroll
+        for (int g = 0; g < HC_MAXIMG; g++) s[g] = (accumulate && g < n) ? out[(size_t)g * o_is + comp + base + i] : 0;
+        for (int t = 0; t < nterms; t++) {
+            const u64 y = hc_mont(P.pt[t][base + i], m.r2, m.q, m.qinv);           // MForm, once for all images
+            const u64 *a = P.a[t] + comp + base + i;
+            const int ph = t % 7;
+#pragma unroll
+            for (int g = 0; g < HC_MAXIMG; g++) if (g < n) {
+                const u128 p = (u128)a[(size_t)g * a_is] * y;
+                T[g] = ph == 0 ? p : T[g] + p;
+                if (ph == 6 || t + 1 == nterms) s[g] = hc_addmod(s[g], hc_mont_redc(T[g], m.q, m.qinv), m.q);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < HC_MAXIMG; g++) if (g < n) out[(size_t)g * o_is + comp + base + i] = s[g];
+    }
 }
-__global__ __launch_bounds__(HC_TPB) void hc_k_rescale_finish_mm(const u64 *x, size_t xs, const u64 *u, size_t us, u64 *out, size_t os, const HcMod *mods, const HcTw *qlinv, int np, size_t x_is, size_t o_is) {
-    const int i = blockIdx.y; const u64 q = mods[i].q; const HcTw w = qlinv[i];
-    const size_t b = (size_t)i * 65536;
-    const size_t zp = blockIdx.z % np, img = blockIdx.z / np;
-    x += zp * xs + img * x_is; u += (size_t)blockIdx.z * us; out += zp * os + img * o_is;
-    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB)
-        out[b + j] = hc_mul_shoup(hc_submod(x[b + j], u[b + j], q), w.w, w.ws, q);
-}
-
 // ================================================================ switching-key generation on the device (harness: hc_swk_generate)
 // rlwe.KeyGenerator.GenSwitchingKey restricted to the rows a level-`level` key switch reads, for keys the HOST HARNESS needs (the reference draws its keys from
 // crypto/rand, so there is nothing to reproduce beyond the RLWE relation): per digit d and limb T (Q_0..Q_level, then the P limbs)
@@ -1489,7 +1572,8 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rescale_finish_mm(const u64 *x, s
 // (rotations / conjugation) or s^2 (relinearisation). All randomness is ChaCha20 (RFC 8439 block function, 64-bit counter) keyed by 256 bits from the host and
 // addressed by (key id, digit, limb | error tag, coefficient, attempt): deterministic in the seed, independent of launch geometry. Uniform residues by
 // rejection on ceil(log2 q) bits; the Gaussian by Box-Muller on two 53-bit uniforms.
-struct HcKeyGen { u32 key[8]; u32 id_lo, id_hi; u32 ginv; int relin; int nl, nq, nt, alpha, beta; };
+struct HcKeyGen { u32 key[8]; u32 id_lo, id_hi; u32 ginv; int relin; int nl, nq, nt, alpha, beta;
+                  int splitmix; u64 sm_seed; const long long *e_in; };      // test mode (hc_swk_generate_splitmix): a = splitmix64(sm_seed + 0x1000 + 64 d + T, j) mod q, e given
 __device__ __forceinline__ u32 hc_rotl32(u32 x, int n) { return (x << n) | (x >> (32 - n)); }
 #define HC_CHACHA_QR(a, b, c, d) a += b; d = hc_rotl32(d ^ a, 16); c += d; b = hc_rotl32(b ^ c, 12); a += b; d = hc_rotl32(d ^ a, 8); c += d; b = hc_rotl32(b ^ c, 7);
 // one 64-byte block as eight 64-bit words; state words 12..15 = (c0, c1, n0, n1)
@@ -1511,6 +1595,14 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_swk_sample(u64 *rows, const HcMod
     u64 *b_row = rows + (((size_t)d * 2 + 0) * G.nt + T) * 65536, *a_row = rows + (((size_t)d * 2 + 1) * G.nt + T) * 65536;
     const int bits = 64 - __builtin_clzll(q); const u64 mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
     for (u32 j = blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += gridDim.x * HC_TPB) {
+        if (G.splitmix) {                                                     // the test oracle's harness generator (oracle/oracle.c or_gen_swk): counter-based splitmix64 rows, the error handed over
+            u64 z = G.sm_seed + 0x1000 + (u64)(d * 64 + T) + ((u64)j + 1) * 0x9E3779B97F4A7C15ull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+            a_row[j] = z % q;
+            const long long e = G.e_in[(size_t)d * 65536 + j];
+            b_row[j] = e >= 0 ? (u64)e % q : q - ((u64)(-e) % q);
+            continue;
+        }
         u64 w[8]; u64 a = 0; bool found = false;
         for (u32 attempt = 0; !found; attempt++) {                           // rejection: each word is accepted with probability q / 2^bits > 1/2
             hc_chacha_block(G.key, j, attempt, G.id_lo, G.id_hi ^ ((u32)(d * 64 + T) << 8), w);

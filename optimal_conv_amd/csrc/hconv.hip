@@ -535,21 +535,32 @@ extern "C" int hc_lv_add(hc_ctx *c, int level, const uint64_t *a, const uint64_t
 extern "C" int hc_lv_sub(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_SUB>(c, "hc_lv_sub", level, a, b, out, nullptr); }
 extern "C" int hc_lv_mul_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_MULC>(c, "hc_lv_mul_const", level, a, nullptr, out, consts); }
 extern "C" int hc_lv_add_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_ADDC>(c, "hc_lv_add_const", level, a, nullptr, out, consts); }
-// batched transforms over rows of different moduli (row y <-> modulus y < nl ? y : nq + y - nl); z operands zs words apart, n images is words apart
-static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0, int n = 1, size_t is_in = 0, size_t is_out = 0) {
+// batched transforms over rows of different moduli (row y <-> modulus y < nl ? y : nq + y - nl); z operands zs words apart, n images is words apart.
+// fuse: optional prologue of the first pass (lift_level: Rescale's lift of t, see HcMm) and epilogue of the second (epi_x: (x - result) * epi_mul (+ epi_add))
+struct HcMmFuse { const HcBasisExt *ext_bs = nullptr; int ext_rows = 0; int lift_level = 0; const u64 *epi_x = nullptr; size_t epi_x_zs = 0, epi_x_is = 0; const HcTw *epi_mul = nullptr; const u64 *epi_add = nullptr; size_t epi_add_zs = 0, epi_add_is = 0; };
+static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0, int n = 1, size_t is_in = 0, size_t is_out = 0, const char *tag = "ntt",
+                     const HcMmFuse *fuse = nullptr) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
-    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = z_alpha; A.nz = z;
+    HcMm A; memset(&A, 0, sizeof A); A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = z_alpha; A.nz = z; A.mods = c->d_mods;
+    char n1[48], n2[48]; snprintf(n1, sizeof n1, "%s:cols_fwd_mm", tag); snprintf(n2, sizeof n2, "%s:rows_fwd_canon_mm", tag);
     const dim3 grid(16, (unsigned)rows, (unsigned)(z * n)); const size_t zt = (size_t)rows * HC_N, it = zt * (size_t)z;
-    A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; HC_TRY(hc_launch(c, "cols_fwd_mm", hc_k_cols_fwd_mm, grid, in, c->ws_tmp, A));
-    A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out; HC_TRY(hc_launch(c, "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
+    A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it;
+    if (fuse && fuse->lift_level > 0) { A.lift_level = fuse->lift_level; A.zs_in = (size_t)HC_N; A.is_in = (size_t)z * HC_N; }
+    if (fuse && fuse->ext_bs) { A.ext_bs = fuse->ext_bs; A.ext_rows = fuse->ext_rows; }
+    if (A.ext_bs) HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<true>, grid, in, c->ws_tmp, A));
+    else HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<false>, grid, in, c->ws_tmp, A));
+    A.lift_level = 0; A.ext_bs = nullptr; A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out;
+    if (fuse && fuse->epi_x) { A.epi_x = fuse->epi_x; A.epi_x_zs = fuse->epi_x_zs; A.epi_x_is = fuse->epi_x_is; A.epi_mul = fuse->epi_mul; A.epi_add = fuse->epi_add; A.epi_add_zs = fuse->epi_add_zs; A.epi_add_is = fuse->epi_add_is; }
+    HC_TRY(hc_launch(c, c->profile ? n2 : "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
-static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out, int skip_lo = 0, int skip_hi = 0, int n = 1, size_t is_in = 0, size_t is_out = 0) {
+static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out, int skip_lo = 0, int skip_hi = 0, int n = 1, size_t is_in = 0, size_t is_out = 0, const char *tag = "intt") {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
-    HcMm A; A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = 0; A.nz = z;
+    HcMm A; memset(&A, 0, sizeof A); A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = 0; A.nz = z;
+    char n1[48], n2[48]; snprintf(n1, sizeof n1, "%s:rows_inv_mm", tag); snprintf(n2, sizeof n2, "%s:cols_inv_canon_mm", tag);
     const dim3 grid(16, (unsigned)rows, (unsigned)(z * n)); const size_t zt = (size_t)rows * HC_N, it = zt * (size_t)z;
-    A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, in, c->ws_tmp, A));
-    A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
+    A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; HC_TRY(hc_launch(c, c->profile ? n1 : "rows_inv_mm", hc_k_rows_inv_mm, grid, in, c->ws_tmp, A));
+    A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out; HC_TRY(hc_launch(c, c->profile ? n2 : "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
 static int hc_ensure_mm(hc_ctx *c, size_t rows) {
@@ -573,6 +584,19 @@ extern "C" int hc_lv_mul_tensor(hc_ctx *c, int level, const uint64_t *a0, const 
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mul_tensor", level, a0, d0));
     if (!a1 || !b0 || !b1 || !d1 || !d2) return hc_fail(c, HC_ERR_ARG, "hc_lv_mul_tensor: null");
     return hc_launch(c, "lv_tensor", hc_k_lv_tensor, dim3(64, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)a0, (const u64 *)a1, (const u64 *)b0, (const u64 *)b1, (u64 *)d0, (u64 *)d1, (u64 *)d2, (const HcMod *)c->d_mods, c->bs_poly);
+}
+// evaluatePolyFromPowerBasis' leaf as one launch (hc_k_lv_lincomb): out_k = sum_t consts[t] a_t,k (+ addc on k = 0). consts: HOST [nterms][level+1], addc: HOST [level+1] or null
+extern "C" int hc_lv_lincomb2(hc_ctx *c, int level, int nterms, const uint64_t *const *a0, const uint64_t *const *a1, const uint64_t *consts, const uint64_t *addc, uint64_t *out0, uint64_t *out1) {
+    HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_lincomb2", level, a0, out0));
+    if (!a1 || !consts || !out1 || nterms < 1 || nterms > HC_MAXLIN || level >= 32) return hc_fail(c, HC_ERR_ARG, "hc_lv_lincomb2: bad arguments (1 <= nterms <= %d, at most 32 limbs)", HC_MAXLIN);
+    HcLinPtrs P; HcLinConsts K; memset(&P, 0, sizeof P); memset(&K, 0, sizeof K);
+    for (int t = 0; t < nterms; t++) {
+        if (!a0[t] || !a1[t]) return hc_fail(c, HC_ERR_ARG, "hc_lv_lincomb2: null term %d", t);
+        P.a0[t] = (const u64 *)a0[t]; P.a1[t] = (const u64 *)a1[t];
+        for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[t][l] = (u64)((((u128)(consts[(size_t)t * (level + 1) + l] % q)) << 64) % q); }
+    }
+    if (addc) for (int l = 0; l <= level; l++) K.addc[l] = addc[l] % c->mods[(size_t)l].m.q;
+    return hc_launch(c, "lv_lincomb", hc_k_lv_lincomb, dim3(64, (unsigned)(level + 1), 2u * (unsigned)c->nb), P, K, nterms, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, c->bs_poly);
 }
 extern "C" int hc_lv_mod_raise(hc_ctx *c, int level, const uint64_t *in_q0, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mod_raise", level, in_q0, out));
@@ -686,12 +710,13 @@ static int hc_div_round_last_n(hc_ctx *c, int level, const u64 *x, size_t xs, u6
         const int nb = c->nb, nz = np * nb;
         HC_TRY(hc_ensure_mm(c, (size_t)nz * (level + 1)));
         c->hoist_cx = nullptr;                                   // the scratch is shared with the key switch's decomposition
-        u64 *t = c->ws_mm, *v = c->ws_mm + (size_t)nz * HC_N;      // t[z][N], v[z][level][N], z = polynomial + np * image
+        u64 *t = c->ws_mm;                                         // t[z][N], z = polynomial + np * image
         // InvNTT of the last limb of every polynomial: the multi-modulus kernels over rows 0..level with rows below `level` skipped
-        HC_TRY(hc_intt_mm(c, x, t - (size_t)level * HC_N, level + 1, level + 1, np, xs, (size_t)HC_N, 0, level, nb, c->bs_poly, (size_t)np * HC_N));
-        HC_TRY(hc_launch(c, "rescale_lift_mm", hc_k_rescale_lift_mm, dim3(64, (unsigned)level, (unsigned)nz), (const u64 *)t, v, (const HcMod *)c->d_mods, level));
-        HC_TRY(hc_ntt_mm(c, v, v, level, level, 0, 0, nz, (size_t)level * HC_N, (size_t)level * HC_N));
-        return hc_launch(c, "rescale_finish_mm", hc_k_rescale_finish_mm, dim3(64, (unsigned)level, (unsigned)nz), x, xs, (const u64 *)v, (size_t)level * HC_N, out, os, (const HcMod *)c->d_mods, (const HcTw *)it->second, np, c->bs_poly, c->bs_poly);
+        HC_TRY(hc_intt_mm(c, x, t - (size_t)level * HC_N, level + 1, level + 1, np, xs, (size_t)HC_N, 0, level, nb, c->bs_poly, (size_t)np * HC_N, "rescale"));
+        // the lift of t into every lower modulus happens where the forward transform reads its input, (x - NTT(lift)) / q_L where it writes its output: two launches,
+        // x read once, the result written once (round 3: lift, two transform passes over a scratch, a finishing pass)
+        HcMmFuse F; F.lift_level = level; F.epi_x = x; F.epi_x_zs = xs; F.epi_x_is = c->bs_poly; F.epi_mul = it->second;
+        return hc_ntt_mm(c, t, out, level, level, 0, 0, np, (size_t)HC_N, os, 0, nb, (size_t)np * HC_N, c->bs_poly, "rescale", &F);
     }
     if (c->nb > 1) {           // level 1 in a batch: image by image through the fused level-1 path below (not on the batched chain's route: its rescales end at level 1)
         const int nb = c->nb; const size_t bs = c->bs_poly; int rc = HC_OK;
@@ -1078,13 +1103,13 @@ extern "C" int hc_swk_load(hc_ctx *c, uint64_t key_id, int level, const uint64_t
 }
 // Harness-side key generation on the device (include/hconv.h): one launch samples every row of the key, one batched transform takes the errors to the
 // NTT domain, one launch forms b and the stored (Montgomery) form. 3 + 2 launches per key instead of ~10 one-row launches and three uploads per (digit, limb).
-extern "C" int hc_swk_generate(hc_ctx *c, uint64_t key_id, int level, uint64_t galEl, const uint64_t *sk_ntt, const uint32_t *seed8) {
-    HC_ENTER(c);
-    if (!sk_ntt || !seed8 || level < 0 || level >= c->nq || c->np < 1 || c->np > 8 || (galEl && !(galEl & 1))) return hc_fail(c, HC_ERR_ARG, "hc_swk_generate: bad arguments");
+static int hc_swk_generate_impl(hc_ctx *c, uint64_t key_id, int level, uint64_t galEl, const uint64_t *sk_ntt, const uint32_t *seed8, bool splitmix, uint64_t sm_seed, const int64_t *e_host) {
+    if (!sk_ntt || level < 0 || level >= c->nq || c->np < 1 || c->np > 8 || (galEl && !(galEl & 1))) return hc_fail(c, HC_ERR_ARG, "hc_swk_generate: bad arguments");
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
     if (beta > 63 || nt > 62) return hc_fail(c, HC_ERR_UNSUPPORTED, "hc_swk_generate: more than 62 limbs");
     HcKeyGen G; memset(&G, 0, sizeof G);
-    memcpy(G.key, seed8, sizeof G.key); G.id_lo = (u32)key_id; G.id_hi = (u32)(key_id >> 32) & 0xFFu;
+    if (seed8) memcpy(G.key, seed8, sizeof G.key);
+    G.id_lo = (u32)key_id; G.id_hi = (u32)(key_id >> 32) & 0xFFu;
     G.relin = galEl == 0; G.nl = nl; G.nq = c->nq; G.nt = nt; G.alpha = alpha; G.beta = beta;
     if (galEl) { const u64 twoN = 2ull * HC_N; u64 ginv = 1, b = galEl % twoN; for (u64 e = twoN - 1; e; e >>= 1, b = (b * b) % twoN) if (e & 1) ginv = (ginv * b) % twoN; G.ginv = (u32)ginv; }
     const size_t n = (size_t)beta * 2 * nt * HC_N;
@@ -1095,6 +1120,11 @@ extern "C" int hc_swk_generate(hc_ctx *c, uint64_t key_id, int level, uint64_t g
     {   std::vector<HcTw> h((size_t)nl);
         for (int l = 0; l < nl; l++) { const u64 q = c->mods[(size_t)l].m.q; u64 r = 1; for (int j = 0; j < alpha; j++) r = h_mulmod(r, c->mods[(size_t)(c->nq + j)].m.q % q, q); h[(size_t)l] = h_pair(r, q); }
         HC_HIP(c, hcx_h2d(c, pm, h.data(), h.size() * sizeof(HcTw)));
+    }
+    if (splitmix) {
+        long long *de = nullptr; HC_HIP(c, S.alloc(&de, (size_t)beta * HC_N * sizeof(long long)));
+        HC_HIP(c, hcx_h2d(c, de, e_host, (size_t)beta * HC_N * sizeof(long long)));
+        G.splitmix = 1; G.sm_seed = sm_seed; G.e_in = de;
     }
     const dim3 grid(64, (unsigned)nt, (unsigned)beta);
     HC_TRY(hc_launch(c, "swk_sample", hc_k_swk_sample, grid, k.rows, (const HcMod *)c->d_mods, G));
@@ -1107,6 +1137,16 @@ extern "C" int hc_swk_generate(hc_ctx *c, uint64_t key_id, int level, uint64_t g
     if (it != c->swk.end()) hcx_free(c, it->second.rows);
     c->swk[key_id] = k;
     return HC_OK;
+}
+extern "C" int hc_swk_generate(hc_ctx *c, uint64_t key_id, int level, uint64_t galEl, const uint64_t *sk_ntt, const uint32_t *seed8) {
+    HC_ENTER(c); if (!seed8) return hc_fail(c, HC_ERR_ARG, "hc_swk_generate: null seed");
+    return hc_swk_generate_impl(c, key_id, level, galEl, sk_ntt, seed8, false, 0, nullptr);
+}
+// TEST harness: the key the test oracle's generator (oracle/oracle.c or_gen_swk) derives from `seed` - uniform rows = counter-based splitmix64, the per-digit errors
+// e_host[beta][N] (signed, drawn by the caller with the oracle's Box-Muller so that no device libm is involved) - for replaying the oracle's encrypted network in the product host
+extern "C" int hc_swk_generate_splitmix(hc_ctx *c, uint64_t key_id, int level, uint64_t galEl, const uint64_t *sk_ntt, uint64_t seed, const int64_t *e_host) {
+    HC_ENTER(c); if (!e_host) return hc_fail(c, HC_ERR_ARG, "hc_swk_generate_splitmix: null errors");
+    return hc_swk_generate_impl(c, key_id, level, galEl, sk_ntt, nullptr, true, seed, e_host);
 }
 // constants of every basis extension of a level, built once: digit d -> target limb T, and {P} -> Q limb l
 static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
@@ -1135,13 +1175,14 @@ static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
     *out = &pit->second;
     return HC_OK;
 }
-// scratch of one key switch at `level` for the nb images of the batch, section-major: coef[img][nl] | digits[img][beta][nt] | acc[img][2][nt] | pc[img][2][alpha] | ext[img][2][nl]
-struct HcKsScratch { u64 *coef, *digits, *acc, *pc, *ext; size_t coef_is, digits_is, acc_is, pc_is, ext_is; };
+// scratch of one key switch at `level` for the nb images of the batch, section-major: coef[img][nl] | digits[img][beta][nt] | acc[img][2][nt] | pc[img][2][alpha] | ext[img][2][nl] | yv[img][max(beta, 2)][alpha + 1]
+struct HcKsScratch { u64 *coef, *digits, *acc, *pc, *ext, *yv; size_t coef_is, digits_is, acc_is, pc_is, ext_is; };
 static int hc_ks_scratch(hc_ctx *c, int level, HcKsScratch *S) {
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha; const size_t nb = (size_t)c->nb;
     S->coef_is = (size_t)nl * HC_N; S->digits_is = (size_t)beta * nt * HC_N; S->acc_is = (size_t)2 * nt * HC_N; S->pc_is = (size_t)2 * alpha * HC_N; S->ext_is = (size_t)2 * nl * HC_N;
-    HC_TRY(hc_ensure_mm(c, nb * ((size_t)nl + (size_t)beta * nt + 2 * nt + 2 * alpha + 2 * nl)));
-    S->coef = c->ws_mm; S->digits = S->coef + nb * S->coef_is; S->acc = S->digits + nb * S->digits_is; S->pc = S->acc + nb * S->acc_is; S->ext = S->pc + nb * S->pc_is;
+    const size_t yv_rows = (size_t)(beta > 2 ? beta : 2) * (alpha + 1);                // y_i / v rows of the decomposition's digits, later of ModDown's two polynomials
+    HC_TRY(hc_ensure_mm(c, nb * ((size_t)nl + (size_t)beta * nt + 2 * nt + 2 * alpha + 2 * nl + yv_rows)));
+    S->coef = c->ws_mm; S->digits = S->coef + nb * S->coef_is; S->acc = S->digits + nb * S->digits_is; S->pc = S->acc + nb * S->acc_is; S->ext = S->pc + nb * S->pc_is; S->yv = S->ext + nb * S->ext_is;
     return HC_OK;
 }
 // phase 1 (rlwe.KeySwitcher.DecomposeNTT / ring.Decomposer.DecomposeAndSplit): digits[d][T] = the d-th digit of cx extended to limb
@@ -1149,11 +1190,13 @@ static int hc_ks_scratch(hc_ctx *c, int level, HcKsScratch *S) {
 static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, const HcKsScratch &S) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha, nb = c->nb;
-    HC_TRY(hc_intt_mm(c, cx, S.coef, nl, nl, 1, 0, 0, 0, 0, nb, c->bs_poly, S.coef_is));                    // cxInvNTT, all limbs
-    // every digit of every image at once (blockIdx.z = digit + beta * image): extension of the digit's residues to all other limbs, then their transforms
-    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(128, 4, (unsigned)(beta * nb)), (const u64 *)S.coef, (size_t)HC_N, S.digits, (const HcBasisExt *)P->bx, nt, 0, 0, (size_t)alpha * HC_N, (size_t)nt * HC_N, alpha, nl,
-                     beta, S.coef_is, S.digits_is));
-    return hc_ntt_mm(c, S.digits, S.digits, nt, nl, 0, 0, beta, (size_t)nt * HC_N, (size_t)nt * HC_N, alpha, nb, S.digits_is, S.digits_is);
+    HC_TRY(hc_intt_mm(c, cx, S.coef, nl, nl, 1, 0, 0, 0, 0, nb, c->bs_poly, S.coef_is, "decomp"));                    // cxInvNTT, all limbs
+    // source side of every digit's extension once per coefficient (y_i, v), then the target side inside the first pass of the digits' forward transforms (blockIdx.z =
+    // digit + beta * image): the extended digits are never written in the coefficient domain
+    const size_t yz = (size_t)(alpha + 1) * HC_N;
+    HC_TRY(hc_launch(c, "decomp:basis_yv", hc_k_basis_yv, dim3(64, (unsigned)(beta * nb)), (const u64 *)S.coef, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bx, nt, (size_t)alpha * HC_N, alpha, beta, S.coef_is));
+    HcMmFuse F; F.ext_bs = P->bx; F.ext_rows = nt;
+    return hc_ntt_mm(c, S.yv, S.digits, nt, nl, 0, 0, beta, yz, (size_t)nt * HC_N, alpha, nb, (size_t)beta * yz, S.digits_is, "decomp", &F);
 }
 // the inner product with both components of the key, all images: acc [img][2][nt][N], images acc_is words apart
 static int hc_ks_mac(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *acc, size_t acc_is) {
@@ -1162,28 +1205,32 @@ static int hc_ks_mac(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, cons
 }
 // ring.(*FastBasisExtender).ModDownSplitNTTPQ for the two polynomials acc[2][nt][N] of every image (basis Q_0..Q_level, P_0..P_(np-1), canonical, NTT):
 // InvNTT of the P limbs, {P} -> every Q limb, NTT, (acc - ext) * P^-1
-static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, size_t acc_is, const HcKsScratch &S, u64 *d0, u64 *d1, uint64_t rot_gal, const u64 *rot_c0) {
+static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, size_t acc_is, const HcKsScratch &S, u64 *d0, u64 *d1, uint64_t rot_gal, const u64 *rot_c0, const u64 *add0 = nullptr, const u64 *add1 = nullptr) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, nb = c->nb;
-    {   HcMm A; A.M = c->d_rowmods; A.nl = 0; A.nq = c->nq; A.skip_lo = A.skip_hi = 0; A.z_alpha = 0; A.nz = 2;  // rows y -> modulus nq + y
+    {   HcMm A; memset(&A, 0, sizeof A); A.M = c->d_rowmods; A.nl = 0; A.nq = c->nq; A.skip_lo = A.skip_hi = 0; A.z_alpha = 0; A.nz = 2;  // rows y -> modulus nq + y
         HC_TRY(hc_ensure_tmp(c, (size_t)2 * alpha * nb));
         const dim3 grid(16, (unsigned)alpha, 2u * (unsigned)nb); const size_t zt = (size_t)alpha * HC_N;
-        A.zs_in = (size_t)nt * HC_N; A.is_in = acc_is; A.zs_out = zt; A.is_out = 2 * zt; HC_TRY(hc_launch(c, "rows_inv_mm", hc_k_rows_inv_mm, grid, (const u64 *)(acc + (size_t)nl * HC_N), c->ws_tmp, A));
-        A.zs_in = zt; A.is_in = 2 * zt; A.zs_out = zt; A.is_out = S.pc_is; HC_TRY(hc_launch(c, "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, S.pc, A));
+        A.zs_in = (size_t)nt * HC_N; A.is_in = acc_is; A.zs_out = zt; A.is_out = 2 * zt; HC_TRY(hc_launch(c, "moddown:rows_inv_mm", hc_k_rows_inv_mm, grid, (const u64 *)(acc + (size_t)nl * HC_N), c->ws_tmp, A));
+        A.zs_in = zt; A.is_in = 2 * zt; A.zs_out = zt; A.is_out = S.pc_is; HC_TRY(hc_launch(c, "moddown:cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, S.pc, A));
     }
-    HC_TRY(hc_launch(c, "ks_basis_extend_mm", hc_k_basis_extend_mm, dim3(256, 4, 2u * (unsigned)nb), (const u64 *)S.pc, (size_t)HC_N, S.ext, (const HcBasisExt *)P->bxdown, nl, 0, 0, (size_t)alpha * HC_N, (size_t)nl * HC_N, 0, nl,
-                     2, S.pc_is, S.ext_is));
-    HC_TRY(hc_ntt_mm(c, S.ext, S.ext, nl, nl, 0, 0, 2, (size_t)nl * HC_N, (size_t)nl * HC_N, 0, nb, S.ext_is, S.ext_is));
-    if (rot_gal)     // a rotation: + c0 and the permutation ride in ModDown's last pass (d0, d1 = the rotated ciphertext)
+    const size_t yz = (size_t)(alpha + 1) * HC_N;
+    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(64, 2u * (unsigned)nb), (const u64 *)S.pc, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, (size_t)alpha * HC_N, 0, 2, S.pc_is));
+    HcMmFuse F; F.ext_bs = P->bxdown; F.ext_rows = nl;            // {P} -> every Q limb inside the forward transform's first pass
+    if (rot_gal) {   // a rotation: + c0 and the permutation ride in ModDown's last pass (d0, d1 = the rotated ciphertext)
+        HC_TRY(hc_ntt_mm(c, S.yv, S.ext, nl, nl, 0, 0, 2, yz, (size_t)nl * HC_N, 0, nb, 2 * yz, S.ext_is, "moddown", &F));
         return hc_launch(c, "ks_moddown_rotate_mm", hc_k_ks_moddown_rotate_mm, dim3(32, (unsigned)nl, 2u * (unsigned)nb), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)S.ext, (size_t)nl * HC_N, rot_c0, d0, d1, (const HcMod *)c->d_mods, (const HcTw *)P->pinv, (u32)(rot_gal & 0x1FFFF),
                          acc_is, S.ext_is, c->bs_poly);
-    return hc_launch(c, "ks_moddown_mm", hc_k_ks_moddown_mm, dim3(32, (unsigned)nl, 2u * (unsigned)nb), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)S.ext, (size_t)nl * HC_N, d0, d1, (const HcMod *)c->d_mods, (const HcTw *)P->pinv,
-                     acc_is, S.ext_is, c->bs_poly);
+    }
+    // (acc - NTT(ext)) / P, plus the addend if there is one (relinearisation: d_k + its key-switched part), in the epilogue of the extension's forward transform: d_k written once
+    F.epi_x = acc; F.epi_x_zs = (size_t)nt * HC_N; F.epi_x_is = acc_is; F.epi_mul = P->pinv;
+    if (add0) { F.epi_add = add0; F.epi_add_zs = (size_t)(add1 - add0); F.epi_add_is = c->bs_poly; }
+    return hc_ntt_mm(c, S.yv, d0, nl, nl, 0, 0, 2, yz, (size_t)(d1 - d0), 0, nb, 2 * yz, c->bs_poly, "moddown", &F);
 }
 // phase 2: inner product with the key (both components), then ModDownSplitNTTPQ
-static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *d0, u64 *d1, uint64_t rot_gal = 0, const u64 *rot_c0 = nullptr) {
+static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *d0, u64 *d1, uint64_t rot_gal = 0, const u64 *rot_c0 = nullptr, const u64 *add0 = nullptr, const u64 *add1 = nullptr) {
     HC_TRY(hc_ks_mac(c, key, level, cx, S, S.acc, S.acc_is));
-    return hc_ks_moddown(c, level, S.acc, S.acc_is, S, d0, d1, rot_gal, rot_c0);
+    return hc_ks_moddown(c, level, S.acc, S.acc_is, S, d0, d1, rot_gal, rot_c0, add0, add1);
 }
 static int hc_ks_find(hc_ctx *c, const char *fn, uint64_t key_id, int level, const HcSwk **key) {
     auto it = c->swk.find(key_id);
@@ -1200,6 +1247,16 @@ extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_
     HC_TRY(hc_ks_decompose_into(c, level, cx, S));
     c->hoist_cx = nullptr;                                   // the scratch no longer holds a hoisted decomposition
     return hc_ks_apply_from(c, *key, level, cx, S, d0, d1);
+}
+// evaluator.Relinearize's tail in the key switch: out_k = a_k + (key switch of cx)_k, the addition inside ModDown's last pass. out may be a (element-wise in place).
+extern "C" int hc_keyswitch_add(hc_ctx *c, uint64_t key_id, int level, const uint64_t *cx, const uint64_t *a0, const uint64_t *a1, uint64_t *out0, uint64_t *out1) {
+    HC_ENTER(c);
+    const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_add", key_id, level, &key));
+    if (!cx || !a0 || !a1 || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_add: null");
+    HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
+    HC_TRY(hc_ks_decompose_into(c, level, cx, S));
+    c->hoist_cx = nullptr;
+    return hc_ks_apply_from(c, *key, level, cx, S, (u64 *)out0, (u64 *)out1, 0, nullptr, (const u64 *)a0, (const u64 *)a1);
 }
 // Hoisted key switching (evaluator.RotateHoisted, conv.go:131; the baby steps of a linear transform): the decomposition of cx is
 // computed once and kept in the context; every hc_keyswitch_hoisted with the same (cx, level) then only does the inner product with
@@ -1301,6 +1358,17 @@ extern "C" int hc_qp_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const
         case HC_LV_MUL_ACC: return hc_launch(c, "hc_qp_op2(mul_acc)", hc_k_lv_pointwise<HC_PW_MAC>, grid, (const u64 *)a0, (const u64 *)b0, (u64 *)out0, (const HcMod *)c->d_mods, K, as, bs, os, level + 1, c->nq, 2, nin, ia, ib, io);
     }
     return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: unknown operation %d", op);
+}
+
+// hc_qp_mul_sum: out (+)= sum_t a_t (*) pt_t over the extended basis - the diagonal sum of a giant step in one launch (hc_k_qp_mul_sum)
+extern "C" int hc_qp_mul_sum(hc_ctx *c, int level, int nterms, const uint64_t *const *a, const uint64_t *const *pt, uint64_t *out, int accumulate) {
+    HC_ENTER(c);
+    if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum: level %d outside 0..%d or no special primes", level, c->nq - 1);
+    if (!a || !pt || !out || nterms < 1 || nterms > HC_MAXTERMS) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum: bad arguments (1 <= nterms <= %d)", HC_MAXTERMS);
+    HcTermPtrs P; memset(&P, 0, sizeof P);
+    for (int t = 0; t < nterms; t++) { if (!a[t] || !pt[t] || a[t] == out) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum: null or aliased term %d", t); P.a[t] = (const u64 *)a[t]; P.pt[t] = (const u64 *)pt[t]; }
+    const int nt = level + 1 + c->np;
+    return hc_launch(c, "qp_mul_sum", hc_k_qp_mul_sum, dim3(64, (unsigned)nt, 2), P, nterms, (u64 *)out, (const HcMod *)c->d_mods, level + 1, c->nq, nt, c->nb, c->bs_qp, c->bs_qp, accumulate ? 1 : 0);
 }
 
 // ------------------------------------------------------------------ L1

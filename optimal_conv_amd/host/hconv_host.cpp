@@ -82,6 +82,26 @@ static std::vector<uint64_t> gpu_ntt(Context *c, int mod, const std::vector<uint
     return out;
 }
 
+// ---------------------------------------------------------------- test mode: the oracle harness' deterministic generators (HCONV_RESNET_REPLAY)
+uint64_t resnetReplaySeed() { static const uint64_t v = testOnlyEnv("HCONV_RESNET_REPLAY") ? strtoull(testOnlyEnv("HCONV_RESNET_REPLAY"), nullptr, 0) : 0; return v; }
+namespace replay {
+uint64_t sm64(uint64_t seed, uint64_t i) { uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+void fill_seeded(uint64_t seed, uint64_t q, uint64_t *out) { for (int j = 0; j < N; j++) out[j] = sm64(seed, (uint64_t)j) % q; }
+void gauss(uint64_t seed, std::vector<int64_t> &e) {
+    e.resize(N);
+    for (int j = 0; j < N; j++) for (uint64_t k = 0;; k++) {
+        const double u1 = ((double)(sm64(seed, (uint64_t)j * 64 + 2 * k) >> 11) + 1.0) / 9007199254740993.0, u2 = (double)(sm64(seed, (uint64_t)j * 64 + 2 * k + 1) >> 11) / 9007199254740992.0;
+        const double g = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2) * 3.2;
+        if (fabs(g) <= 19.2) { e[(size_t)j] = (int64_t)llround(g); break; }
+    }
+}
+std::vector<int64_t> gen_sk(uint64_t seed, int h) {
+    std::vector<int64_t> sk((size_t)N, 0); uint64_t ctr = 0; int placed = 0;
+    while (placed < h) { const uint64_t r = sm64(seed, ctr++); const int pos = (int)(r % (uint64_t)N); if (!sk[(size_t)pos]) { sk[(size_t)pos] = (r >> 40) & 1 ? 1 : -1; placed++; } }
+    return sk;
+}
+}  // namespace replay
+
 // ---------------------------------------------------------------- sampling (harness only)
 static ChaChaRng &rng(Context *c) { return c->g; }      // one generator per context (image threads own their contexts)
 static std::vector<uint64_t> uniform_row(Context *c, uint64_t q) {
@@ -107,12 +127,13 @@ static void gen_and_load_galois_key(Context *c, uint64_t galEl) {
     for (uint64_t e = twoN - 1; e; e >>= 1, b = (b * b) % twoN) if (e & 1) ginv = (ginv * b) % twoN;
     std::vector<int64_t> sko(N, 0);
     for (int i = 0; i < N; i++) { uint64_t t = ((uint64_t)i * ginv) % twoN; if (t < (uint64_t)N) sko[t] = c->sk[i]; else sko[t - N] = -c->sk[i]; }
-    std::vector<int64_t> e = gaussian(c);
+    const uint64_t rs = resnetReplaySeed(); int jj = 0; while ((1ull << jj) + 1 < galEl) jj++;       // replay: or_gen_galois_key_l0(sk, 2^j + 1, seed 100 + j) of the oracle network
+    std::vector<int64_t> e; if (rs) replay::gauss((100 + (uint64_t)jj) ^ 0xE44E44ull, e); else e = gaussian(c);
     std::vector<uint64_t> rows[4];   // b_q, a_q, b_p, a_p
     const int mods[2] = {0, 2};
     for (int w = 0; w < 2; w++) {
         const int mod = mods[w]; const uint64_t q = MODQ[mod];
-        std::vector<uint64_t> a = uniform_row(c, q);
+        std::vector<uint64_t> a; if (rs) { a.resize(N); replay::fill_seeded(100 + (uint64_t)jj + 0x1000 + (uint64_t)w, q, a.data()); } else a = uniform_row(c, q);
         std::vector<uint64_t> both = signed_row(sko, q), en = signed_row(e, q);
         both.insert(both.end(), en.begin(), en.end());
         both = gpu_ntt(c, mod, both);
@@ -156,7 +177,8 @@ Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, cons
     }
     // kgen.GenKeyPairSparse(h = 192) (main.go:410)
     c->sk.assign(N, 0);
-    { auto &g = rng(c); int placed = 0; while (placed < 192) { uint64_t r = g(); int pos = (int)(r % N); if (!c->sk[pos]) { c->sk[pos] = (r >> 40) & 1 ? 1 : -1; placed++; } } }
+    if (resnetReplaySeed()) c->sk = replay::gen_sk(resnetReplaySeed(), 192);       // the oracle network's key: Ckks(seed).sk = or_gen_sk(seed, 192)
+    else { auto &g = rng(c); int placed = 0; while (placed < 192) { uint64_t r = g(); int pos = (int)(r % N); if (!c->sk[pos]) { c->sk[pos] = (r >> 40) & 1 ? 1 : -1; placed++; } } }
     for (int m = 0; m < 3; m++) c->sk_ntt[m] = gpu_ntt(c, m, signed_row(c->sk, MODQ[m]));
     printf("Num Rotations:  %d\n", c->num_rotations);                                                  // main.go:412
     // gen_idxNlogs (conv.go:241-261): idx[i] = NTT(X^(2^i)) on the device; Galois keys for 2^(i+1)+1, i < logN
@@ -254,11 +276,13 @@ std::vector<uint64_t> EncodeCoeffs(const std::vector<double> &coeffs, int level,
     return out;
 }
 Ciphertext EncryptNew(Context *c, const std::vector<uint64_t> &pt_rows, int level, double scale) {    // sk-encryption: c0 = -c1*s + e + m
-    std::vector<int64_t> e = gaussian(c);
+    const uint64_t rs = resnetReplaySeed() ? 5 + 1000 * c->replay_encryptions++ : 0;          // replay: or_encrypt(seed 5) for the first image, as resnet_layer_digests encrypts it
+    std::vector<int64_t> e; if (rs) replay::gauss(rs ^ 0xABCDEFull, e); else e = gaussian(c);
     std::vector<uint64_t> ct((size_t)2 * (level + 1) * N);
     for (int l = 0; l <= level; l++) {
         const uint64_t q = MODQ[l];
-        std::vector<uint64_t> c1 = uniform_row(c, q), t = signed_row(e, q);
+        std::vector<uint64_t> c1, t = signed_row(e, q);
+        if (rs) { c1.resize(N); replay::fill_seeded(rs + 0x2000 + (uint64_t)l, q, c1.data()); } else c1 = uniform_row(c, q);
         for (int j = 0; j < N; j++) t[(size_t)j] = addmod(t[(size_t)j], pt_rows[(size_t)l * N + (size_t)j] % q, q);
         t = gpu_ntt(c, l, t);
         for (int j = 0; j < N; j++) {

@@ -48,6 +48,16 @@ static const uint64_t PACK_P = 0x1fffffffffe00001ull;   // main.go:449
 // must never turn a deployment into key-less or predictable computation).
 bool &testMode();
 const char *testOnlyEnv(const char *name);              // getenv(name) under --test-mode; nullptr when unset; panic when set without the flag
+// HCONV_RESNET_REPLAY=<seed> (test mode): the secret key, every switching key and the input's encryption randomness are the counter-based splitmix64 draws of the
+// test oracle's harness generators (oracle/oracle.c or_gen_sk / or_gen_galois_key_l0 / or_gen_swk / or_encrypt, restated in hconv_host.cpp): the `resnet` run then
+// computes, bit for bit, the network tests/golden/gen_resnet_digests.py ran on the oracle, and prints a `replay digest layer i` line per layer (tests/test_gpu_z_cli.py)
+uint64_t resnetReplaySeed();                            // 0: off
+namespace replay {                                      // the oracle harness' generators (splitmix64, Box-Muller sigma 3.2 bound 6 sigma)
+uint64_t sm64(uint64_t seed, uint64_t i);
+void fill_seeded(uint64_t seed, uint64_t q, uint64_t *out);
+void gauss(uint64_t seed, std::vector<int64_t> &e);
+std::vector<int64_t> gen_sk(uint64_t seed, int h);
+}
 
 // Device-resident ciphertext / plaintext (ckks.Ciphertext{Value []*ring.Poly; Scale}, ckks.Plaintext)
 struct Ciphertext {
@@ -76,6 +86,7 @@ struct Context {
     int num_rotations = 0;
     Seed256 seed;                             // key of this context's generators (hconv_prng.hpp)
     ChaChaRng g;                              // this context's own generator: secret key, Galois keys, encryption randomness
+    uint64_t replay_encryptions = 0;          // HCONV_RESNET_REPLAY: encryptions so far (the i-th takes the oracle harness' seed 5 + 1000 i)
 };
 
 // ---- harness / reference-shaped API ----

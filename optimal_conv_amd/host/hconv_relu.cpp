@@ -59,6 +59,10 @@ struct DCt {
 };
 struct DPt { std::shared_ptr<uint64_t> p; int level = 0; double scale = 0; };
 
+struct Boot;
+static void profile_dump(Boot *B, const char *label);      // HCONV_PROFILE=1: per-kernel HIP-event totals since the last dump
+static bool profiling() { static const bool on = getenv("HCONV_PROFILE") && atoi(getenv("HCONV_PROFILE")); return on; }
+
 struct Boot {
     hc_ctx *hc = nullptr;
     std::vector<uint64_t> Q, P;
@@ -86,6 +90,11 @@ struct Boot {
     std::map<int, Encoder> sub_enc;                                    // encoders of the rings with fewer slots (sparse embedding), by log2 of their degree
     std::vector<double> sine;
     long n_keyswitch = 0, n_keys = 0;
+    // algorithmic traffic of what has been evaluated, in rows of N residues (SURVEY.md 8(d)'s convention carried to the chain: every evaluator operation reads its
+    // ciphertext operands once and writes its result once, temporaries stay on chip; switching keys, diagonals and masks are read once per operation and - being common
+    // to the images of a batch - once per launch set): alg_ct per ciphertext, alg_shared per launch set
+    double alg_ct = 0, alg_shared = 0;
+    int ks_rows(int L) const { const int a = (int)P.size(), nl = L + 1, nt = nl + a; return 2 * ((nl + a - 1) / a) * nt; }      // rows of one switching key at level L
     std::map<std::string, DPt> pt_cache;                     // encoded 0/1 masks (keep_ctxt, ext_double_ctxt), by what defines them
 
     // ---------------- memory and the image batch
@@ -164,6 +173,15 @@ struct Boot {
             key_ids[{ident, level}] = id; n_keys++;
             return id;
         }
+        if (resnetReplaySeed()) {            // test mode: or_gen_swk(sk, gal, level, 7000003 seed + 131 gal + level) of the oracle network (tests/oracle_ckks.py Ckks.key): the
+            const uint64_t seed = 7000003ull * resnetReplaySeed() + 131ull * gal + (uint64_t)level;      // oracle's errors drawn here, its splitmix rows and the arithmetic on the device
+            std::vector<int64_t> es((size_t)beta * N), e;
+            for (int dgt = 0; dgt < beta; dgt++) { replay::gauss(seed ^ (0xE44E44ull + (uint64_t)dgt * 7919), e); std::copy(e.begin(), e.end(), es.begin() + (long)dgt * N); }
+            const uint64_t id = 1 + key_ids.size();
+            HCR(hc_swk_generate_splitmix(hc, id, level, gal, d_sk, seed, es.data()));
+            key_ids[{ident, level}] = id; n_keys++;
+            return id;
+        }
         // rlwe.GenSwitchingKey on the device (hc_swk_generate: ChaCha20 rows keyed by this bootstrapper's own stream, one Gaussian error per digit, the NTT of all
         // limbs in one batched launch): s_out = sigma_{gal^-1}(s) for a rotation / conjugation, s for relinearisation (gal = 0). Round 3 built every row on the
         // host and pushed it through one-row launches: 17-28 s per context, now a fraction of a second.
@@ -181,6 +199,7 @@ struct Boot {
     DCt add(const DCt &a0, const DCt &b0) {
         const int L = std::min(a0.level, b0.level); same_scale(a0.scale, b0.scale);
         DCt r = new_ct(L, std::max(a0.deg, b0.deg), a0.scale);
+        alg_ct += 3.0 * (r.deg + 1) * (L + 1);
         if (a0.deg == 1 && b0.deg == 1) { HCR(hc_lv_op2(hc, HC_LV_ADD, L, a0.p[0].get(), a0.p[1].get(), b0.p[0].get(), b0.p[1].get(), r.p[0].get(), r.p[1].get(), nullptr)); return r; }   // both polynomials per launch
         for (int d = 0; d <= r.deg; d++) {
             if (d <= a0.deg && d <= b0.deg) HCR(hc_lv_add(hc, L, a0.p[d].get(), b0.p[d].get(), r.p[d].get()));
@@ -192,6 +211,7 @@ struct Boot {
         const int L = std::min(a0.level, b0.level); same_scale(a0.scale, b0.scale);
         if (a0.deg != b0.deg) panic("sub: degrees differ");
         DCt r = new_ct(L, a0.deg, a0.scale);
+        alg_ct += 3.0 * (r.deg + 1) * (L + 1);
         if (r.deg == 1) HCR(hc_lv_op2(hc, HC_LV_SUB, L, a0.p[0].get(), a0.p[1].get(), b0.p[0].get(), b0.p[1].get(), r.p[0].get(), r.p[1].get(), nullptr));
         else for (int d = 0; d <= r.deg; d++) HCR(hc_lv_sub(hc, L, a0.p[d].get(), b0.p[d].get(), r.p[d].get()));
         return r;
@@ -210,15 +230,32 @@ struct Boot {
     DCt mul_const_int(const DCt &a, double k_rounded_value) {      // k given as an integral double
         u128 mag; bool neg; split_int(k_rounded_value, &mag, &neg);
         std::vector<uint64_t> c = consts(mag, neg, a.level);
-        DCt r = new_ct(a.level, a.deg, a.scale);
+        DCt r = new_ct(a.level, a.deg, a.scale); alg_ct += 2.0 * (a.deg + 1) * (a.level + 1);
         if (a.deg == 1) HCR(hc_lv_op2(hc, HC_LV_MUL_CONST, a.level, a.p[0].get(), a.p[1].get(), nullptr, nullptr, r.p[0].get(), r.p[1].get(), c.data()));
         else for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul_const(hc, a.level, a.p[d].get(), c.data(), r.p[d].get()));
+        return r;
+    }
+    // sum_t k_t * a_t (+ c0) at `level` as ONE launch (hc_lv_lincomb2): what a leaf of the polynomial evaluators computes with a MultByConst per power and an Add chain.
+    // ks: integral doubles (as mul_const_int takes them); scale: the label of the result
+    DCt lincomb(const std::vector<DCt> &as, const std::vector<double> &ks, int level, double scale, bool with_c0 = false, double c0 = 0) {
+        const size_t nt_ = as.size();
+        if (nt_ < 1 || nt_ > 8 || ks.size() != nt_) panic("lincomb: 1..8 terms");
+        std::vector<uint64_t> cs(nt_ * (size_t)(level + 1)), cadd; std::vector<const uint64_t *> p0(nt_), p1(nt_);
+        for (size_t t = 0; t < nt_; t++) {
+            if (as[t].deg != 1 || as[t].level < level) panic("lincomb: degree-1 operands at or above the level");
+            u128 mag; bool neg; split_int(ks[t], &mag, &neg);
+            std::vector<uint64_t> c = consts(mag, neg, level); std::copy(c.begin(), c.end(), cs.begin() + (long)(t * (size_t)(level + 1)));
+            p0[t] = as[t].p[0].get(); p1[t] = as[t].p[1].get();
+        }
+        if (with_c0) { u128 mag; bool neg; split_int(c0, &mag, &neg); cadd = consts(mag, neg, level); }
+        DCt r = new_ct(level, 1, scale); alg_ct += (2.0 * (double)nt_ + 2.0) * (level + 1);
+        HCR(hc_lv_lincomb2(hc, level, (int)nt_, p0.data(), p1.data(), cs.data(), with_c0 ? cadd.data() : nullptr, r.p[0].get(), r.p[1].get()));
         return r;
     }
     DCt add_const_int(const DCt &a, double k_rounded_value) {
         u128 mag; bool neg; split_int(k_rounded_value, &mag, &neg);
         std::vector<uint64_t> c = consts(mag, neg, a.level);
-        DCt r = a; r.p[0] = block();
+        DCt r = a; r.p[0] = block(); alg_ct += 2.0 * (a.level + 1);
         HCR(hc_lv_add_const(hc, a.level, a.p[0].get(), c.data(), r.p[0].get()));
         return r;
     }
@@ -233,36 +270,35 @@ struct Boot {
     }
     DCt mul_plain(const DCt &a, const DPt &pt) {
         if (pt.level < a.level) panic("mul_plain: plaintext below the ciphertext's level");
-        DCt r = new_ct(a.level, a.deg, a.scale * pt.scale);
+        DCt r = new_ct(a.level, a.deg, a.scale * pt.scale); alg_ct += 2.0 * (a.deg + 1) * (a.level + 1); alg_shared += a.level + 1;
         if (a.deg == 1) HCR(hc_lv_op2(hc, HC_LV_MUL, a.level, a.p[0].get(), a.p[1].get(), pt.p.get(), pt.p.get(), r.p[0].get(), r.p[1].get(), nullptr));
         else for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul(hc, a.level, a.p[d].get(), pt.p.get(), r.p[d].get()));
         return r;
     }
     DCt mul_by_i(const DCt &a) {
-        DCt r = new_ct(a.level, a.deg, a.scale);
+        DCt r = new_ct(a.level, a.deg, a.scale); alg_ct += 2.0 * (a.deg + 1) * (a.level + 1); alg_shared += a.level + 1;
         if (a.deg == 1) HCR(hc_lv_op2(hc, HC_LV_MUL, a.level, a.p[0].get(), a.p[1].get(), mono_i.get(), mono_i.get(), r.p[0].get(), r.p[1].get(), nullptr));
         else for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul(hc, a.level, a.p[d].get(), mono_i.get(), r.p[d].get()));
         return r;
     }
     DCt mul_relin(const DCt &a, const DCt &b) {                   // evaluator.MulRelin: tensor, key switch of c2 with the rlk
         const int L = std::min(a.level, b.level);
-        DCt r = new_ct(L, 1, a.scale * b.scale);
-        auto d1 = block(), d2 = block(), t = block(), k = block();
+        DCt r = new_ct(L, 1, a.scale * b.scale); alg_ct += 6.0 * (L + 1); alg_shared += ks_rows(L);
+        auto d1 = block(), d2 = block();
         HCR(hc_lv_mul_tensor(hc, L, a.p[0].get(), a.p[1].get(), b.p[0].get(), b.p[1].get(), r.p[0].get(), d1.get(), d2.get()));
-        HCR(hc_keyswitch(hc, key(0, L), L, d2.get(), t.get(), k.get())); n_keyswitch++;
-        HCR(hc_lv_op2(hc, HC_LV_ADD, L, r.p[0].get(), d1.get(), t.get(), k.get(), r.p[0].get(), r.p[1].get(), nullptr));      // (d0 + ks0, d1 + ks1) in one launch
+        HCR(hc_keyswitch_add(hc, key(0, L), L, d2.get(), r.p[0].get(), d1.get(), r.p[0].get(), r.p[1].get())); n_keyswitch++;      // (d0 + ks0, d1 + ks1) inside ModDown's last pass
         return r;
     }
     DCt rescale(const DCt &a) {                                     // one DivRoundByLastModulusNTT
         if (a.level < 1) panic("rescale at level 0");
-        DCt r = new_ct(a.level - 1, a.deg, a.scale / (double)Q[(size_t)a.level]);
+        DCt r = new_ct(a.level - 1, a.deg, a.scale / (double)Q[(size_t)a.level]); alg_ct += (double)(a.deg + 1) * (2 * a.level + 1);
         if (a.deg == 1) HCR(hc_div_round_last2(hc, a.level, a.p[0].get(), a.p[1].get(), r.p[0].get(), r.p[1].get()));     // both polynomials per launch
         else for (int d = 0; d <= a.deg; d++) HCR(hc_div_round_last(hc, a.level, a.p[d].get(), r.p[d].get()));
         return r;
     }
     DCt galois(const DCt &a, uint64_t gal) {                       // evaluator.permuteNTT: key switch c1, + c0, permute both
         const int L = a.level;
-        DCt r = new_ct(L, 1, a.scale);
+        DCt r = new_ct(L, 1, a.scale); alg_ct += 4.0 * (L + 1); alg_shared += ks_rows(L);
         HCR(hc_keyswitch_rotate(hc, key(gal, L), gal, L, a.p[0].get(), a.p[1].get(), r.p[0].get(), r.p[1].get(), 0)); n_keyswitch++;   // + c0 and the permutation inside ModDown's last pass
         return r;
     }
@@ -270,7 +306,7 @@ struct Boot {
     DCt conjugate(const DCt &a) { return galois(a, 2ull * N - 1); }
     DCt mod_raise(const DCt &a, int level) {                        // ckks.(*Bootstrapper).modUp
         if (a.level != 0) panic("mod_raise expects a level-0 ciphertext");
-        DCt r = new_ct(level, 1, a.scale);
+        DCt r = new_ct(level, 1, a.scale); alg_ct += 2.0 + 2.0 * (level + 1);
         for (int d = 0; d < 2; d++) HCR(hc_lv_mod_raise(hc, level, a.p[d].get(), r.p[d].get()));
         return r;
     }
@@ -534,6 +570,9 @@ struct Boot {
         std::map<int, std::vector<int>> index; std::set<int> babies;
         for (auto &g : lt.giant) for (auto &b : g.second) { index[g.first / lt.n1].push_back(b.first); if (b.first) babies.insert(b.first); }
         const int Lb = hoist_c1 ? hoist_level : L;                                  // the level the baby-step key switches run at
+        alg_ct += 4.0 * nl;
+        for (auto &g : lt.giant) { if (g.first) alg_shared += ks_rows(L); alg_shared += (double)g.second.size() * nt; }
+        alg_shared += (double)babies.size() * ks_rows(Lb);
         for (int b : babies) key(gal_rot(b), Lb, 1);                                // key generation (if any) before a decomposition is taken
         for (auto &g : lt.giant) if (g.first) key(gal_rot(g.first), L, 2);
         std::vector<uint64_t> pmod((size_t)nl), zeros((size_t)nl, 0);
@@ -572,9 +611,9 @@ struct Boot {
             const int g = j * lt.n1; const uint64_t gal = gal_rot(g);
             const auto &row = lt.giant.at(g);
             auto A = block_qp2(); bool haveA = false;
-            for (int i : ix.second) if (i) {
-                const uint64_t *pt = row.at(i).p.get(); uint64_t *r = rot[i].get();
-                HCR(hc_qp_op2(hc, haveA ? HC_LV_MUL_ACC : HC_LV_MUL, L, r, r + zs, pt, pt, A.get(), A.get() + zs)); haveA = true;
+            {   std::vector<const uint64_t *> as, pts;                                         // the giant step's diagonal sum over its baby steps: one launch
+                for (int i : ix.second) if (i) { as.push_back(rot[i].get()); pts.push_back(row.at(i).p.get()); }
+                if (!as.empty()) { HCR(hc_qp_mul_sum(hc, L, (int)as.size(), as.data(), pts.data(), A.get(), 0)); haveA = true; }
             }
             auto a0 = block(), a1 = block();
             if (haveA) HCR(hc_mod_down2(hc, L, A.get(), a0.get(), a1.get()));
@@ -583,9 +622,10 @@ struct Boot {
             { auto t = block(); HCR(hc_lv_permute(hc, gal, L, a0.get(), t.get())); add_to_res(0, t); }
             HCR(hc_keyswitch_qp_rotate(hc, key(gal, L, 2), gal, L, nullptr, a1.get(), B.get(), 0, haveB ? 1 : 0)); n_keyswitch++; haveB = true;     // SwitchKeysInPlaceNoModDown, permuted into the accumulators
         }
-        if (index.count(0)) for (int i : index[0]) if (i) {
-            const uint64_t *pt = lt.giant.at(0).at(i).p.get(); uint64_t *r = rot[i].get();
-            HCR(hc_qp_op2(hc, haveB ? HC_LV_MUL_ACC : HC_LV_MUL, L, r, r + zs, pt, pt, B.get(), B.get() + zs)); haveB = true;
+        if (index.count(0)) {
+            std::vector<const uint64_t *> as, pts;
+            for (int i : index[0]) if (i) { as.push_back(rot[i].get()); pts.push_back(lt.giant.at(0).at(i).p.get()); }
+            if (!as.empty()) { HCR(hc_qp_mul_sum(hc, L, (int)as.size(), as.data(), pts.data(), B.get(), haveB ? 1 : 0)); haveB = true; }
         }
         if (haveB) { auto d0 = block(), d1 = block(); HCR(hc_mod_down2(hc, L, B.get(), d0.get(), d1.get())); add_to_res(0, d0); add_to_res(1, d1); }
         if (lt.giant.count(0) && lt.giant.at(0).count(0)) {
@@ -688,16 +728,14 @@ struct Boot {
     DCt lt_leaf(double target, const LPoly &p, std::map<int, DCt> &C, double sc) {
         if (p.degree() == 0) panic("EvaluatePoly: constant leaf (not produced by the sign polynomials)");
         const int lv = C[p.degree()].level; const double qi = (double)Q[(size_t)lv];
-        DCt res; bool have = false;
         if (fabs(p.c[0]) > 1e-14) panic("EvaluatePoly: constant term in a leaf (AddConst; not produced by the sign polynomials)");
+        std::vector<DCt> as; std::vector<double> ks;
         for (int key = p.degree(); key > 0; key--) if (fabs(p.c[(size_t)key]) > 1e-14) {
             const double const_scale = target * qi / C[key].scale;
-            DCt term = mul_const_int(drop_to(C[key], lv), trunc(p.c[(size_t)key] * const_scale));          // Go's int64(float64)
-            term.scale = target * qi;
-            res = have ? add(res, term) : term; have = true;
+            as.push_back(C[key]); ks.push_back(trunc(p.c[(size_t)key] * const_scale));                     // Go's int64(float64)
         }
-        if (!have) panic("EvaluatePoly: empty leaf");
-        return lt_rescale(res, sc);
+        if (as.empty()) panic("EvaluatePoly: empty leaf");
+        return lt_rescale(lincomb(as, ks, lv, target * qi), sc);                                           // MultByGaussianIntegerAndAdd per power: one launch
     }
     DCt lt_recurse(double target, int log_split, int log_degree, const LPoly &p, std::map<int, DCt> &C, double sc) {
         if (p.degree() < (1 << log_split)) {
@@ -736,16 +774,15 @@ struct Boot {
         const bool c0 = fabs(p.c[0]) > 1e-14;
         if (p.degree() == 0) { DCt z = mul_const_int(C[1], 0.0); z.scale = target; return c0 ? add_const(z, p.c[0]) : z; }
         const int lv = C[p.degree()].level; const double qi = (double)Q[(size_t)lv];
-        DCt res; bool have = false;
+        std::vector<DCt> as; std::vector<double> ks;
         for (int key = p.degree(); key > 0; key--) if (fabs(p.c[(size_t)key]) > 1e-14) {
             const double const_scale = target * qi / C[key].scale;
-            DCt term = mul_const_int(drop_to(C[key], lv), trunc(p.c[(size_t)key] * const_scale));          // Go's int64(float64)
-            term.scale = target * qi;
-            res = have ? add(res, term) : term; have = true;
+            as.push_back(C[key]); ks.push_back(trunc(p.c[(size_t)key] * const_scale));                     // Go's int64(float64)
         }
-        if (!have) { res = mul_const_int(drop_to(C[1], lv), 0.0); res.scale = target * qi; }
-        if (c0) res = add_const(res, p.c[0]);                // the reference adds it first; residues mod q do not depend on the order
-        return lt_rescale(res, sc);
+        if (as.empty()) { as.push_back(C[1]); ks.push_back(0.0); }
+        // the constant term (evaluator.AddConst: floor(|c * scale| + 0.5), sign restored) rides in the same launch; the reference adds it first, residues mod q do not depend on the order
+        const double k0 = floor(fabs(target * qi * p.c[0]) + 0.5) * (p.c[0] < 0 ? -1.0 : 1.0);
+        return lt_rescale(lincomb(as, ks, lv, target * qi, c0, k0), sc);
     }
     DCt lt_recurse_cheby(double target, int log_split, int log_degree, const LPoly &p, std::map<int, DCt> &C, double sc) {
         if (p.degree() < (1 << log_split)) {
@@ -906,6 +943,7 @@ struct Boot {
         for (int i = LOGN - 1 - ls; i < LOGN - 1; i++) ct = add(ct, rotate(ct, 1 << i));                   // subSum
         for (auto &lt : S.cts) { const double s_in = ct.scale; ct = lt_rescale(linear_transform(ct, lt), s_in); }
         if (ct.level != LV_SINE_TOP) panic("CoeffsToSlots ended at the wrong level");
+        if (profiling()) profile_dump(this, "modUp + CoeffsToSlots");
         DCt cc = conjugate(ct);
         DCt parts[2] = {add(ct, cc), mul_by_i(sub(cc, ct))};           // DivByi(ct - conj) = -i (ct - conj) = i (conj - ct): the same residues
         const int nparts = ls ? 1 : 2;
@@ -1108,7 +1146,7 @@ void freeBoot(Boot *b) {
 // HCONV_PROFILE=1: per-kernel HIP-event totals of one layer's tail (hc_set_option("profile")) on stderr; event records between
 // launches perturb the stream, so the printed wall times of such a run are not the ones to quote
 static void profile_dump(Boot *B, const char *label) {
-    hc_ctx *hc = B->hc; char names[8192];
+    hc_ctx *hc = B->hc; char names[8192]; HCR(hc_sync(hc));
     if (hc_profile_names(hc, names, sizeof names)) return;
     std::vector<std::pair<double, std::string>> rows; double tot = 0; long nl = 0;
     for (char *tok = strtok(names, ","); tok; tok = strtok(nullptr, ",")) { double ms = 0; long n = 0; hc_profile_get(hc, tok, &ms, &n); char b[160]; snprintf(b, sizeof b, "%-28s %6ld launches %8.3f ms %7.1f us/launch", tok, n, ms, n ? 1e3 * ms / (double)n : 0.0); rows.push_back({ms, b}); tot += ms; nl += n; }
@@ -1142,7 +1180,7 @@ std::vector<BootCiphertext> evalConv_BNRelu_tail_batch(Boot *B, const std::strin
     if (!sparse && log_sparse != 0) panic("No cases for log_sparse");
     const int nimg = (int)ct_conv_dev.size();
     if (nimg < 1 || nimg > B->nb_max) panic("evalConv_BNRelu_tail: more images than the bootstrapper's image batch (HCONV_IMAGE_BATCH)");
-    B->set_nb(nimg);
+    B->set_nb(nimg); B->alg_ct = B->alg_shared = 0;
     DCt ct = B->new_ct(0, 1, ct_scale * pow(2.0, pow_));                                            // eval.go:437
     for (int z = 0; z < nimg; z++) for (int d = 0; d < 2; d++) HCR(hc_copy(hc, ct.p[d].get() + (size_t)z * B->poly_stride(), ct_conv_dev[(size_t)z] + (size_t)d * N, (size_t)N * 8));
     // ct_conv_dev belongs to ANOTHER context (the convolution's): the copies above are queued on this context's stream, and the caller frees
@@ -1174,6 +1212,7 @@ std::vector<BootCiphertext> evalConv_BNRelu_tail_batch(Boot *B, const std::strin
     DCt boots[2]; const int iter = B->ctos(ct, ls_run, boots);                                         // eval.go:450-461
     HCR(hc_sync(hc));
     printf("Done in %s \n", dur(start).c_str());
+    if (prof) profile_dump(B, "sine");
     if (B->replay_seed) for (int ul = 0; ul < iter; ul++) replay_digest(ul ? "ctos1" : "ctos0", boots[ul]);
     if (rls) { printf("replay of the sparse-slot BootstrappConv_CtoS done (log_sparse %d)\n", ls_run); fflush(stdout); exit(0); }
     start = now();
@@ -1183,6 +1222,7 @@ std::vector<BootCiphertext> evalConv_BNRelu_tail_batch(Boot *B, const std::strin
     }
     HCR(hc_sync(hc));
     printf("ReLU Done in %s \n", dur(start).c_str());
+    if (prof) profile_dump(B, "ReLU");
     start = now();
     DCt keep[2];
     const std::string mk = std::to_string(in_wid) + "/" + std::to_string(kp_wid) + "/" + std::to_string(log_sparse);
@@ -1195,7 +1235,9 @@ std::vector<BootCiphertext> evalConv_BNRelu_tail_batch(Boot *B, const std::strin
     HCR(hc_sync(hc));
     printf("Boot (StoC) Done in %s \n", dur(start).c_str());
     if (B->replay_seed) replay_digest("final", res);
-    if (prof) { profile_dump(B, (kind + " log_sparse " + std::to_string(log_sparse)).c_str()); HCR(hc_set_option(hc, "profile", 0)); }
+    if (prof) { profile_dump(B, ("mask + SlotsToCoeffs; the layer was " + kind + " log_sparse " + std::to_string(log_sparse)).c_str()); HCR(hc_set_option(hc, "profile", 0)); }
+    if (getenv("HCONV_ALG_BYTES")) printf("algorithmic traffic of the layer's tail: %.6g GB per ciphertext + %.6g GB shared by the %d image%s of the launch set\n", B->alg_ct * N * 8 / 1e9, B->alg_shared * N * 8 / 1e9, nimg, nimg > 1 ? "s" : "");
+    B->alg_ct = B->alg_shared = 0;
     std::vector<BootCiphertext> outs((size_t)nimg);
     for (int z = 0; z < nimg; z++) {
         BootCiphertext &out = outs[(size_t)z]; out.level = res.level; out.Scale = res.scale;

@@ -26,6 +26,7 @@
 #include <thread>
 
 #include "hconv_host.hpp"
+#include "hconv_sha256.hpp"
 
 namespace hconv {
 
@@ -193,7 +194,17 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
         printf("kernel width:  %d\n", ker_wid); printf("num batches:  [%d %d %d]\n", real_batch[0], real_batch[1], real_batch[2]);
         printf("Encryption done in %s \n", dur(enc_start).c_str());
         double timings[6]; auto begin_start = now(), start = now();
-        auto step = [&](std::vector<Ciphertext> next) { for (Ciphertext &c : ct_layer) freeCt(cont, c); ct_layer = std::move(next); };
+        int layer_no = 0;
+        auto step = [&](std::vector<Ciphertext> next) {
+            for (Ciphertext &c : ct_layer) freeCt(cont, c);
+            ct_layer = std::move(next);
+            if (resnetReplaySeed()) for (size_t z = 0; z < ct_layer.size(); z++) {      // test mode: SHA-256 of the ciphertext the layer hands on ([2][level+1][N], as tests/parity_cases.py sha_ct)
+                std::vector<uint64_t> rows((size_t)2 * (ct_layer[z].level + 1) * N); HCX(cont->hc, hc_download(cont->hc, rows.data(), ct_layer[z].d, rows.size() * 8));
+                Sha256 h; h.update(rows.data(), rows.size() * 8);
+                printf("replay digest layer %d image %d level %d scale %.17g %s\n", layer_no, g0 + (int)z, ct_layer[z].level, ct_layer[z].Scale, h.hex().c_str());
+            }
+            layer_no++;
+        };
 
         double pow_ = init_pow;                                                                          // ResNet Block 1
         for (int i = 1; i <= num_blcs[0]; i++) {

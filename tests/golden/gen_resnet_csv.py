@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle_resnet as rn  # noqa: E402
 
 
-def write_case(root, ker_wid=3, depth=8, n_images=1, seed=0, cf100=False, wide=1):
+def write_case(root, ker_wid=3, depth=8, n_images=1, seed=0, cf100=False, wide=1, native_image=False):
+    """native_image: image 0 is the one rn.Net draws itself (what tests/golden/gen_resnet_digests.py encrypts), not default_rng(1000)'s"""
     net = rn.Net(16, ker_wid=ker_wid, depth=depth, seed=seed, fc_out=100 if cf100 else 10, wide=wide)
     tag = ("cf100_" if cf100 else "") + f"crop_ker{ker_wid}_d{depth}_wid{wide}"
     wdir, pdir = os.path.join(root, "Resnet_weights", "weights_" + tag), os.path.join(root, "Resnet_plain_data", tag)
@@ -27,7 +28,8 @@ def write_case(root, ker_wid=3, depth=8, n_images=1, seed=0, cf100=False, wide=1
     np.savetxt(os.path.join(wdir, "final-fcbias.csv"), net.fc_b, fmt="%.17g")
     scores = []
     for it in range(n_images):
-        net.image = np.random.default_rng(1000 + it).uniform(-1, 1, net.image.shape)
+        if not (native_image and it == 0):
+            net.image = np.random.default_rng(1000 + it).uniform(-1, 1, net.image.shape)
         W, raw = net.in_wids[0], net.raw[0]
         full = np.zeros((W, W, 3))
         full[:raw, :raw] = net.image

@@ -466,6 +466,33 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
     run("lv_op2 mul (plaintext)", lambda x0, x1, y, o0, o1: ck(L.hc_lv_op2(h, 0, level, x0, x1, y, y, o0, o1, None)), [(a, "p"), (a1, "p"), (pt, "s")], [("p", PW), ("p", PW)])
     run("lv_op2 mul_acc (plaintext)", lambda x0, x1, y, o0, o1: ck(L.hc_lv_op2(h, 7, level, x0, x1, y, y, o0, o1, None)), [(a, "p"), (a1, "p"), (pt, "s")], [("p", PW), ("p", PW)],
         init=[b.reshape(n, -1), b1.reshape(n, -1)])
+    # a leaf of evaluatePolyFromPowerBasis in one launch == the MultByConst / Add chain + AddConst
+    NL = 5
+    As = [(poly(), poly()) for _ in range(NL)]
+    cvals = np.array([[int(rnd(Q[l])[0]) for l in range(nl)] for _ in range(NL)], dtype=np.uint64)
+    addc = (C.c_uint64 * nl)(*[int(rnd(Q[l])[1]) for l in range(nl)])
+
+    def lincomb(*args):
+        a0s, a1s, o0, o1 = args[0:2 * NL:2], args[1:2 * NL:2], args[2 * NL], args[2 * NL + 1]
+        arr = C.c_void_p * NL
+        ck(L.hc_lv_lincomb2(h, level, NL, arr(*a0s), arr(*a1s), cvals.ctypes.data_as(C.POINTER(C.c_uint64)), addc, o0, o1))
+
+    lin_ins = [(x_, "p") for pair in As for x_ in pair]
+    got_lin = run("lv_lincomb2", lincomb, lin_ins, [("p", PW), ("p", PW)])
+    ctx.set_batch(1)
+    for z in range(n):                       # the chain, image by image
+        bufs = [ctx.buf(x_[z]) for pair in As for x_ in pair]; o0, o1 = ctx.buf(nwords=PW), ctx.buf(nwords=PW)
+        t0_, t1_ = ctx.buf(nwords=PW), ctx.buf(nwords=PW)
+        for t in range(NL):
+            ct_ = (C.c_uint64 * nl)(*[int(v) for v in cvals[t]])
+            if t == 0:
+                ck(L.hc_lv_op2(h, 3, level, bufs[0].ptr, bufs[1].ptr, None, None, o0.ptr, o1.ptr, ct_))
+            else:
+                ck(L.hc_lv_op2(h, 3, level, bufs[2 * t].ptr, bufs[2 * t + 1].ptr, None, None, t0_.ptr, t1_.ptr, ct_)); ck(L.hc_lv_op2(h, 1, level, o0.ptr, o1.ptr, t0_.ptr, t1_.ptr, o0.ptr, o1.ptr, None))
+        ck(L.hc_lv_add_const(h, level, o0.ptr, addc, o0.ptr))
+        eq(got_lin[0][z], o0.download(), f"lincomb2 == MultByConst / Add chain, image {z}, polynomial 0"); eq(got_lin[1][z], o1.download(), f"lincomb2 == chain, image {z}, polynomial 1")
+        for b_ in bufs + [o0, o1, t0_, t1_]:
+            b_.free()
     run("lv_mul_tensor", lambda x0, x1, y0, y1, d0, d1, d2: ck(L.hc_lv_mul_tensor(h, level, x0, x1, y0, y1, d0, d1, d2)), [(a, "p"), (a1, "p"), (b, "p"), (b1, "p")], [("p", PW)] * 3)
     run("lv_mod_raise", lambda x, o: ck(L.hc_lv_mod_raise(h, level, x, o)), [(poly(1), "p")], [("p", PW)])
     gal = pow(5, 7, 2 * N)
@@ -485,6 +512,12 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
         ctx.swk_load(30 + kid, level, evk)
     K0, K1 = C.c_uint64(30), C.c_uint64(31)
     ks = run("keyswitch", lambda x, d0, d1: ck(L.hc_keyswitch(h, K0, level, x, d0, d1)), [(a, "p")], [("p", PW), ("p", PW)])
+
+    ka = run("keyswitch_add", lambda x, p0, p1, o0, o1: ck(L.hc_keyswitch_add(h, K0, level, x, p0, p1, o0, o1)), [(a, "p"), (b, "p"), (b1, "p")], [("p", PW), ("p", PW)])
+    for z in range(n):
+        for k_, addend in ((0, b), (1, b1)):
+            want_ = np.stack([ctx.add(l, ks[k_][z].reshape(nl, N)[l], addend[z][l]).reshape(-1) for l in range(nl)]).reshape(-1)
+            eq(ka[k_][z], want_, f"keyswitch_add == keyswitch + add (image {z}, polynomial {k_})")
 
     def hoisted(x, d0, d1, e0, e1):
         ck(L.hc_keyswitch_decompose(h, level, x)); ck(L.hc_keyswitch_hoisted(h, K0, level, x, d0, d1)); ck(L.hc_keyswitch_hoisted(h, K1, level, x, e0, e1))
@@ -521,6 +554,24 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
     run("qp_op2 mul (plaintext)", lambda x, y, o: ck(L.hc_qp_op2(h, 0, level, x, at1(x), y, y, o, at1(o))), [(X, "q"), (ptq, "s")], [("q", QW)])
     run("qp_op2 mul_acc (plaintext)", lambda x, y, o: ck(L.hc_qp_op2(h, 7, level, x, at1(x), y, y, o, at1(o))), [(X, "q"), (ptq, "s")], [("q", QW)], init=[acc.reshape(n, -1)])
     run("qp_op2 add", lambda x, y, o: ck(L.hc_qp_op2(h, 1, level, x, at1(x), y, at1(y), o, at1(o))), [(X, "q"), (acc, "q")], [("q", QW)])
+    # the diagonal sum of a giant step in one launch == the chain of qp_op2 mul / mul_acc calls, for 9 terms (more than one 7-term fold) with and without accumulation
+    NT = 9
+    Xs = [qp() for _ in range(NT)]; pts = [np.stack([rnd(qp_mod(t)) for t in range(nt)]) for _ in range(NT)]
+
+    def mul_sum(*args, accumulate=0):
+        xs, ps, o = args[:NT], args[NT:2 * NT], args[2 * NT]
+        arr = C.c_void_p * NT
+        ck(L.hc_qp_mul_sum(h, level, NT, arr(*xs), arr(*ps), o, accumulate))
+
+    def mul_chain(*args, accumulate=0):
+        xs, ps, o = args[:NT], args[NT:2 * NT], args[2 * NT]
+        for t in range(NT):
+            ck(L.hc_qp_op2(h, 7 if (t or accumulate) else 0, level, xs[t], at1(xs[t]), ps[t], ps[t], o, at1(o)))
+    for accu in (0, 1):
+        ins = [(x_, "q") for x_ in Xs] + [(p_, "s") for p_ in pts]
+        got_sum = run(f"qp_mul_sum accumulate={accu}", lambda *a_, accu=accu: mul_sum(*a_, accumulate=accu), ins, [("q", QW)], init=[acc.reshape(n, -1)])
+        got_chain = run(f"qp_op2 chain accumulate={accu}", lambda *a_, accu=accu: mul_chain(*a_, accumulate=accu), ins, [("q", QW)], init=[acc.reshape(n, -1)])
+        eq(got_sum[0], got_chain[0], f"qp_mul_sum == the chain of qp_op2 products (accumulate={accu})")
     run("qp_permute2", lambda x, o: ck(L.hc_qp_permute2(h, C.c_uint64(gal), level, x, o)), [(X, "q")], [("q", QW)])
     ctx.close()
 
@@ -570,6 +621,52 @@ def case_swk_generate(make_ctx, level=4, alpha=3, seed=0x5EED):
     eq(np.stack(a0), np.stack(a1), "hc_swk_generate is deterministic in (seed, key id)")
     ctx._ck(ctx.L.hc_swk_generate(ctx.h, C.c_uint64(9), level, C.c_uint64(pow(5, 11, 2 * N)), d_sk.ptr, seed8))
     assert not np.array_equal(np.stack(ctx.keyswitch(9, level, cx)), np.stack(a0))
+    d_sk.free(); ctx.close()
+
+
+def oracle_gauss(seed, n):
+    """oracle/oracle.c gauss(): Box-Muller on counter-based splitmix64 draws, sigma 3.2, redrawn beyond 6 sigma; libm's log / cos through Python's math module"""
+    import math
+    M = (1 << 64) - 1
+
+    def sm64(i):
+        z = (seed + (i + 1) * 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+    e = np.empty(n, dtype=np.int64)
+    for j in range(n):
+        k = 0
+        while True:
+            u1 = ((sm64(j * 64 + 2 * k) >> 11) + 1.0) / 9007199254740993.0
+            u2 = (sm64(j * 64 + 2 * k + 1) >> 11) / 9007199254740992.0
+            g = math.sqrt(-2.0 * math.log(u1)) * math.cos(6.283185307179586 * u2) * 3.2
+            if abs(g) <= 19.2:
+                e[j] = int(math.floor(abs(g) + 0.5)) * (1 if g >= 0 else -1)      # llround: half away from zero
+                break
+            k += 1
+    return e
+
+
+def case_swk_generate_splitmix(make_ctx, make_oracle, level=3, alpha=2, seed=0x51ED):
+    """hc_swk_generate_splitmix (test harness: the oracle generator's splitmix rows on the device, its errors handed over) must give the key or_gen_swk gives: a key
+    switch with it equals the oracle's key switch with the oracle's key, bit for bit (rotation and relinearisation keys)"""
+    import ctypes as C
+    Q, P = Q_MIX[: level + 2], P_CHAIN[:alpha]
+    ctx, O = make_ctx(Q, P), make_oracle(Q, P)
+    mods = Q + P
+    sk = O.gen_sk(3, 64)
+    res = lambda v, q: np.where(v >= 0, v, v + q).astype(np.uint64)
+    d_sk = ctx.buf(np.stack([ctx.ntt(m, res(sk, mods[m])).reshape(-1) for m in range(len(mods))]))
+    nl, beta = level + 1, (level + 1 + alpha - 1) // alpha
+    for kid, gal in ((1, pow(5, 5, 2 * N)), (2, 0)):
+        es = np.concatenate([oracle_gauss(seed ^ (0xE44E44 + d * 7919), N) for d in range(beta)])
+        ctx._ck(ctx.L.hc_swk_generate_splitmix(ctx.h, C.c_uint64(kid), level, C.c_uint64(gal), d_sk.ptr, C.c_uint64(seed), es.ctypes.data_as(C.POINTER(C.c_int64))))
+        evk = O.gen_swk(sk, gal, level, seed)
+        cx = np.stack([splitmix_rows(seed + 50 * kid + l, Q[l], N) for l in range(nl)])
+        g0, g1 = ctx.keyswitch(kid, level, cx)
+        w0, w1 = O.keyswitch(level, cx, evk)
+        eq(g0, w0, f"key switch under the device-built oracle key (galEl {gal}), d0"); eq(g1, w1, f"key switch under the device-built oracle key (galEl {gal}), d1")
     d_sk.free(); ctx.close()
 
 

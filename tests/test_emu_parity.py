@@ -175,6 +175,12 @@ def test_swk_generate_switches_keys():
     pc.case_swk_generate(lambda Q, P: Context(Q, P, lib_path=EMU_LIB))
 
 
+def test_swk_generate_splitmix_equals_the_oracle_generator():
+    """test harness: the oracle's key generator reproduced on the device (for replaying the oracle's encrypted network in the product host)"""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    pc.case_swk_generate_splitmix(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), lambda Q, P: Oracle(q=Q, p=P))
+
+
 def test_free_into_a_foreign_context_is_refused(monkeypatch):
     """cached allocations (HCONV_ASYNC_ALLOC=1): a block goes back to the context it came from; handing it to another context's hc_free is an error, not a silent
     hipFree that leaves the owner's block table stale (the lifetime bug behind round 2's synchronising hc_free)"""

@@ -253,18 +253,27 @@ def test_resnet_cli_two_image_threads_cached_allocations(tmp_path):
 def test_resnet_cli_depth20(tmp_path):
     """BASELINE.md config 5 at its stated depth: `resnet 3 20 1 1 false` (testResNet_crop_sparse, test.go:76-370; CLI main.go:609-621),
     19 conv-BN-ReLU layers with bootstrapping + the FC layer on one ciphertext, synthetic weights in the reference's file layout
-    (the reference ships none, README.md:23). The encrypted class scores must follow the plain float model: same arg-max,
-    max |difference| < 0.05."""
+    (the reference ships none, README.md:23). Round 4: DIGEST grade. With HCONV_RESNET_REPLAY=1 the product host (C++ driver, its own composition of the
+    stride layers, the sparse bootstrappers, ext_double_ctxt) runs under the secret key, switching keys and encryption randomness of the test oracle's harness
+    generators, i.e. it evaluates the very network tests/golden/gen_resnet_digests.py evaluated on the CPU oracle (24 minutes there): the ciphertext after EVERY
+    layer must hash to the oracle's (tests/golden/oracle_resnet_digests.json), and the scores follow the plain model."""
+    import json
     import numpy as np
     import golden.gen_resnet_csv as rgen
-    (want, _), = rgen.write_case(str(tmp_path), 3, 20, 1)
+    (want, _), = rgen.write_case(str(tmp_path), 3, 20, 1, native_image=True)
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_resnet_digests.json")))["depth"]["20"]
     out = subprocess.run([CLI, "--test-mode", "resnet", "3", "20", "1", "1", "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
-                         env=dict(os.environ, HCONV_SEED="11"))
+                         env=dict(os.environ, HCONV_RESNET_REPLAY="1"))
     assert out.returncode == 0, out.stderr[-2000:]
     print(out.stdout[-1500:])
     for pat in (r"^Block1, Layer  7 done!$", r"^Block1 to 2 done!$", r"^Block2, Layer  5 done!$", r"^Block2 to 3 done!$", r"^Block3 done\.$", r"^Final FC done\.$", r"^Total done in \S+ $"):
         assert re.search(pat, out.stdout, re.M), pat
+    got_d = {int(m.group(1)): m.group(2) for m in re.finditer(r"^replay digest layer (\d+) image 0 level 1 scale \S+ ([0-9a-f]{64})$", out.stdout, re.M)}
+    assert sorted(got_d) == list(range(19)), sorted(got_d)
+    for i, w in enumerate(ref["layers"]):
+        assert got_d[i] == w, f"layer {i}: the product host's ciphertext differs from the oracle network's"
     got = np.loadtxt(tmp_path / "Resnet_enc_results" / "results_crop_ker3_d20_wid1" / "class_result_ker3_0.csv")
     assert got.shape == (10,)
+    assert np.max(np.abs(got - np.array(ref["scores"]))) < 1e-9, (got, ref["scores"])       # same ciphertext, same key: the oracle's decryption (float formatting aside)
     assert got.argmax() == want.argmax(), (got, want)
     assert np.max(np.abs(got - want)) < 0.05, (got, want)
