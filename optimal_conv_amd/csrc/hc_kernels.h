@@ -868,7 +868,8 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, H
 
 // KB5M: one workgroup per (node, tile) does BOTH polynomials, k = 1 first: grid = (batch*nodes, 16). Row-local permutations only
 // (galEl = 2^j + 1, j >= 9). Against two hc_k_b5 jobs: t2.c1 = y1 - I*x1 is recomputed from x1, y1 and idx in the k = 1 epilogue (the very
-// expression b1 fed into the key switch) and kept in registers for k = 0, so b1 does not write tmpT and nobody reads it (1.5 MiB less
+// expression b1 fed into the key switch) and - round 4 - once more in the k = 0 epilogue (x1, y1 come from L2 again; round 3 kept the 16 residues in registers across the
+// second transform: 168 VGPRs, 3 waves per SIMD; now 127 VGPRs, 4 waves, no scratch; measured +0.3 % conv/s, -1.5 % on a lone convolution: profiles/round4_conv33_b5m_ab.txt), so b1 does not write tmpT and nobody reads it (1.5 MiB less
 // per node: 0.5 written, 2 x 0.5 read, against 0.5 more for x1), and idx is read once per node. Per row batch of either polynomial:
 //   k = 1: m1 = I*x1 ; T = y1 - m1 ; t1 = y1 + m1 ; F = (a_Q/P)*T                      k = 0: m = I*x0 ; t1 = y0 + m ; F = y0 - m + (b_Q/P)*T
 //   d = F - n_k (n_k = rows-forward of the k-th extension, divided by P by b4) ; through the LDS row ; dst = reduce(t1 + perm(d)) (+ bias, k = 0)
@@ -876,8 +877,11 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, H
 #ifndef HC_B5M_UNROLL
 #define HC_B5M_UNROLL 2
 #endif
+#ifndef HC_B5M_RECOMPUTE
+#define HC_B5M_RECOMPUTE 1
+#endif
 #ifndef HC_B5M_WAVES
-#define HC_B5M_WAVES 3
+#define HC_B5M_WAVES 4                // with t2.c1 re-derived in the k = 0 epilogue the kernel fits 127 VGPRs without scratch: four workgroups per CU (round 3: 168 VGPRs, three)
 #endif
 template <int FM>
 __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTwTab T0fwd, HcPtrs biases, HcPtrs outs) {
@@ -893,7 +897,11 @@ __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTw
     const HcTw *__restrict__ evk = B.evkQ + tile;                                                                  // b_Q/P, then a_Q/P 65536 pairs on
     u64 *__restrict__ o = (outs.p[z] != nullptr ? const_cast<u64 *>(outs.p[z]) : B.dst + (size_t)z * B.dst_stride + (size_t)i * 2 * 65536) + tile;
     const u64 *__restrict__ bias = biases.p[z] != nullptr ? biases.p[z] + tile : nullptr;        // null except on the last node of the tree (eval.go:258)
+#if HC_B5M_RECOMPUTE
+    u64 e[16];
+#else
     u64 e[16], T[16];
+#endif
 #pragma unroll HC_B5M_UNROLL
     for (int k = 1; k >= 0; k--) {
         const u64 *__restrict__ in = B.tmpE + ((size_t)zn * 2 + k) * 65536 + (size_t)row * 256;
@@ -907,18 +915,31 @@ __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTw
 #pragma unroll
         for (int b = 0; b < 16; b += HC_B5_ROWS) {
             u64 Y[HC_B5_ROWS], X[HC_B5_ROWS], t1[HC_B5_ROWS], bs[HC_B5_ROWS]; HcTw K[HC_B5_ROWS], I[HC_B5_ROWS];
+#if HC_B5M_RECOMPUTE
+            u64 Y1[HC_B5_ROWS], X1[HC_B5_ROWS];
+#endif
 #pragma unroll
             for (int j = 0; j < HC_B5_ROWS; j++) {
                 const int off = (b + j) * 256;
                 Y[j] = ys[(size_t)k * 65536 + off]; X[j] = xs[(size_t)k * 65536 + off]; I[j] = idx[off]; K[j] = evk[(size_t)k * 65536 + off];
+#if HC_B5M_RECOMPUTE
+                if (k == 0) { Y1[j] = ys[(size_t)65536 + off]; X1[j] = xs[(size_t)65536 + off]; }
+#endif
                 bs[j] = (k == 0 && bias != nullptr) ? bias[off] : 0;
             }
 #pragma unroll
             for (int j = 0; j < HC_B5_ROWS; j++) {
                 const int kk = b + j;
                 u64 m = hc_shoup4(X[j], I[j].w, I[j].ws, Q), f;                                            // I * x_k, < 4q
+#if HC_B5M_RECOMPUTE
+                // t2.c1 (conv.go:288-289) as b1 formed it, lazy < 4q: formed where it is used, for k = 0 from x1 / y1 again (L2-hot: this workgroup read them a
+                // transform ago) - one more lazy product per element against 16 residues (32 VGPRs) carried across the second transform
+                const u64 Tk = k == 1 ? hc_fold(Y[j] + Q.q4 - m, Q.nq4) : hc_fold(Y1[j] + Q.q4 - hc_shoup4(X1[j], I[j].w, I[j].ws, Q), Q.nq4);
+#else
                 if (k == 1) T[kk] = hc_fold(Y[j] + Q.q4 - m, Q.nq4);                                       // t2.c1 (conv.go:288-289) as b1 formed it, lazy < 4q
-                u64 g = hc_shoup4(T[kk], K[j].w, K[j].ws, Q);                                              // (key row / P) * t2.c1, < 4q
+                const u64 Tk = T[kk];
+#endif
+                u64 g = hc_shoup4(Tk, K[j].w, K[j].ws, Q);                                                 // (key row / P) * t2.c1, < 4q
                 if (FM == HC_FM_FREE) {
                     t1[j] = Y[j] + m + bs[j];                                                              // conv.go:290 (+ bias), < 6q
                     f = (k == 0 ? Y[j] + Q.q4 - m + g : g) + HC_FREE_OFF * q - e[kk];                      // t2.c_k + (key switch)_k - n_k, < 81q
@@ -1349,6 +1370,8 @@ struct HcRowMod { HcTwTab fwd, inv; u64 q, mu; };
 // blockIdx.z = operand + nz * image: `nz` operands zs_* words apart (the two polynomials of a ciphertext, the digits of a key switch), and the
 // images of a batch (hc_set_batch) is_* words apart
 struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; int z_alpha; int nz; size_t is_in, is_out;
+              unsigned char rowlist[48];     // blockIdx.y -> row (rows a launch has nothing to do for are left out of the grid)
+
               // fused prologue of the cols-forward pass / epilogue of the rows-forward pass (0 = none):
               //  lift_level > 0  (cols_fwd): the input is NOT read from `in` rows: it is DivRoundByLastModulusNTT's centred remainder of t (one coefficient row per operand,
               //                  `in` = t[z][N]) lifted into row y's modulus (hc_k_rescale_lift_mm's formula) - Rescale without the lift's pass over memory
@@ -1366,10 +1389,13 @@ __device__ __forceinline__ bool hc_mm_skip(const HcMm &A, int y, int zi) {
 }
 __device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl ? y : A.nq + (y - A.nl); }
 #define HC_MM_PROLOGUE \
-    const int y = blockIdx.y, zi = (int)blockIdx.z % A.nz, img = (int)blockIdx.z / A.nz; if (hc_mm_skip(A, y, zi)) return; \
+    const int y = A.rowlist[blockIdx.y], zi = (int)blockIdx.z % A.nz, img = (int)blockIdx.z / A.nz; if (hc_mm_skip(A, y, zi)) return; \
     const HcRowMod &R = A.M[hc_mm_mod(A, y)]; \
     in += (size_t)zi * A.zs_in + (size_t)img * A.is_in; out += (size_t)zi * A.zs_out + (size_t)img * A.is_out;
-template <bool EXT>      // EXT: the instantiation whose input is the fused basis extension (more registers; the plain transforms keep five workgroups per CU)
+// (Round 4, measured and not kept - profiles/round4_chain_class_paths_ab.txt: butterflies per modulus class inside these kernels - 32-bit canonical arithmetic for the
+// chain's eleven ~30-bit limbs, the fold-free 64-bit form below 2^57 - as a block-uniform switch cost 108-132 VGPRs against 65-86 and only won the lost occupancy back;
+// as one launch per class they kept their registers but turned every pass into three short launches: 224 ms per 8-ciphertext layer against 203.)
+template <bool EXT>      // EXT: the input is the fused basis extension
 __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_COLS_LDS];
     HC_MM_PROLOGUE
@@ -1403,6 +1429,8 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, 
     hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, Q);
     HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
+#pragma unroll
+    for (int k = 0; k < 16; k++) e[k] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu);
     const size_t lin = pbase + (size_t)(blockIdx.x * 16) * 256 + t;
     if (A.epi_x != nullptr) {                                                // block-uniform
         const u64 *x = A.epi_x + (size_t)zi * A.epi_x_zs + (size_t)img * A.epi_x_is + lin;
@@ -1410,14 +1438,14 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, 
         const HcTw w = A.epi_mul[y];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            u64 r = hc_mul_shoup(hc_submod(x[k * 256], hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu), R.q), w.w, w.ws, R.q);
+            u64 r = hc_mul_shoup(hc_submod(x[k * 256], e[k], R.q), w.w, w.ws, R.q);
             if (ad != nullptr) r = hc_addmod(r, ad[k * 256], R.q);
             out[lin + k * 256] = r;
         }
         return;
     }
 #pragma unroll
-    for (int k = 0; k < 16; k++) out[lin + k * 256] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu);
+    for (int k = 0; k < 16; k++) out[lin + k * 256] = e[k];
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_ROWS_LDS];

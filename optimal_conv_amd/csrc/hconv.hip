@@ -543,7 +543,10 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
     HcMm A; memset(&A, 0, sizeof A); A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = z_alpha; A.nz = z; A.mods = c->d_mods;
     char n1[48], n2[48]; snprintf(n1, sizeof n1, "%s:cols_fwd_mm", tag); snprintf(n2, sizeof n2, "%s:rows_fwd_canon_mm", tag);
-    const dim3 grid(16, (unsigned)rows, (unsigned)(z * n)); const size_t zt = (size_t)rows * HC_N, it = zt * (size_t)z;
+    const size_t zt = (size_t)rows * HC_N, it = zt * (size_t)z;
+    if (rows > 48) return hc_fail(c, HC_ERR_UNSUPPORTED, "batched transform over more than 48 rows");
+    for (int y = 0; y < rows; y++) A.rowlist[y] = (unsigned char)y;
+    const dim3 grid(16, (unsigned)rows, (unsigned)(z * n));
     A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it;
     if (fuse && fuse->lift_level > 0) { A.lift_level = fuse->lift_level; A.zs_in = (size_t)HC_N; A.is_in = (size_t)z * HC_N; }
     if (fuse && fuse->ext_bs) { A.ext_bs = fuse->ext_bs; A.ext_rows = fuse->ext_rows; }
@@ -558,7 +561,11 @@ static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int 
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
     HcMm A; memset(&A, 0, sizeof A); A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = 0; A.nz = z;
     char n1[48], n2[48]; snprintf(n1, sizeof n1, "%s:rows_inv_mm", tag); snprintf(n2, sizeof n2, "%s:cols_inv_canon_mm", tag);
-    const dim3 grid(16, (unsigned)rows, (unsigned)(z * n)); const size_t zt = (size_t)rows * HC_N, it = zt * (size_t)z;
+    const size_t zt = (size_t)rows * HC_N, it = zt * (size_t)z;
+    if (rows > 48) return hc_fail(c, HC_ERR_UNSUPPORTED, "batched transform over more than 48 rows");
+    int cnt = 0;                                           // rows in [skip_lo, skip_hi) have nothing to do: not in the grid
+    for (int y = 0; y < rows; y++) if (!(y >= skip_lo && y < skip_hi)) A.rowlist[cnt++] = (unsigned char)y;
+    const dim3 grid(16, (unsigned)cnt, (unsigned)(z * n));
     A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; HC_TRY(hc_launch(c, c->profile ? n1 : "rows_inv_mm", hc_k_rows_inv_mm, grid, in, c->ws_tmp, A));
     A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out; HC_TRY(hc_launch(c, c->profile ? n2 : "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
@@ -1208,12 +1215,8 @@ static int hc_ks_mac(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, cons
 static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, size_t acc_is, const HcKsScratch &S, u64 *d0, u64 *d1, uint64_t rot_gal, const u64 *rot_c0, const u64 *add0 = nullptr, const u64 *add1 = nullptr) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, nb = c->nb;
-    {   HcMm A; memset(&A, 0, sizeof A); A.M = c->d_rowmods; A.nl = 0; A.nq = c->nq; A.skip_lo = A.skip_hi = 0; A.z_alpha = 0; A.nz = 2;  // rows y -> modulus nq + y
-        HC_TRY(hc_ensure_tmp(c, (size_t)2 * alpha * nb));
-        const dim3 grid(16, (unsigned)alpha, 2u * (unsigned)nb); const size_t zt = (size_t)alpha * HC_N;
-        A.zs_in = (size_t)nt * HC_N; A.is_in = acc_is; A.zs_out = zt; A.is_out = 2 * zt; HC_TRY(hc_launch(c, "moddown:rows_inv_mm", hc_k_rows_inv_mm, grid, (const u64 *)(acc + (size_t)nl * HC_N), c->ws_tmp, A));
-        A.zs_in = zt; A.is_in = 2 * zt; A.zs_out = zt; A.is_out = S.pc_is; HC_TRY(hc_launch(c, "moddown:cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, S.pc, A));
-    }
+    // InvNTT of the P rows of both components: rows y -> modulus nq + y (nl = 0)
+    HC_TRY(hc_intt_mm(c, acc + (size_t)nl * HC_N, S.pc, alpha, 0, 2, (size_t)nt * HC_N, (size_t)alpha * HC_N, 0, 0, nb, acc_is, S.pc_is, "moddown"));
     const size_t yz = (size_t)(alpha + 1) * HC_N;
     HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(64, 2u * (unsigned)nb), (const u64 *)S.pc, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, (size_t)alpha * HC_N, 0, 2, S.pc_is));
     HcMmFuse F; F.ext_bs = P->bxdown; F.ext_rows = nl;            // {P} -> every Q limb inside the forward transform's first pass

@@ -8,6 +8,7 @@ if [ -n "${PYTEST_K:-}" ]; then
   ( cd $R && timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -x -q -k "$PYTEST_K" > $O/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu.log )
   tail -6 $O/pytest_gpu.log
 fi
+[ -n "${LIBDIR:-}" ] && export LD_LIBRARY_PATH=$R/$LIBDIR:${LD_LIBRARY_PATH:-}      # another build of libhconv.so for the CLI (RUNPATH is searched after LD_LIBRARY_PATH)
 W=/tmp/r4chain; mkdir -p $W; cd $W
 PYTHONPATH=$R/tests python -c "import golden.gen_conv_csv as g; [g.write_case('test_conv_data',5,1,i) for i in range(2)]"
 for nb in ${RELU_BATCHES:-}; do
