@@ -237,6 +237,7 @@ def sharded_conv_timing(rank, world, device, backend):
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         conv_then_pack_sharded(ctx, cin, 2.0 ** 30, kh, 2.0 ** 30, B, 2.0 ** 30, bb, device=f"cuda:{device}")
+        ctx.sync()
         dist.barrier()
         times.append((time.perf_counter() - t0) * 1e3)
     out["sharded_conv_ms_rccl_gather"] = float(np.median(times[1:]))
@@ -244,7 +245,8 @@ def sharded_conv_timing(rank, world, device, backend):
     dist.barrier()
     if rank == 0:
         try:
-            ctxs = [make(d) for d in range(world)]
+            ndev = torch.cuda.device_count()
+            ctxs = [make(d % ndev) for d in range(world)]          # fewer devices than ranks (the one-GPU dry run): the contexts share devices
             khs = [c.ker_load(pl_ker) for c in ctxs]
             ins = [c.buf(ct_in) for c in ctxs]
             b0, o0 = ctxs[0].buf(bias), ctxs[0].buf(nwords=2 * N)
@@ -257,6 +259,7 @@ def sharded_conv_timing(rank, world, device, backend):
                 ctxs[0].sync()
                 ts.append((time.perf_counter() - t0) * 1e3)
             out["sharded_conv_ms"] = float(np.median(ts[1:]))
+            out["devices_used"] = min(world, ndev)
             out["peer_access"] = "hipMemcpyPeerAsync between the devices' contexts; direct peer access enabled where hipDeviceCanAccessPeer allows (a failure to enable falls back to staged copies, reported on stderr)"
             for c, k in zip(ctxs, khs):
                 c.ker_free(k); c.close()

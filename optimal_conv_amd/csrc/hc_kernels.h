@@ -868,8 +868,9 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, H
 
 // KB5M: one workgroup per (node, tile) does BOTH polynomials, k = 1 first: grid = (batch*nodes, 16). Row-local permutations only
 // (galEl = 2^j + 1, j >= 9). Against two hc_k_b5 jobs: t2.c1 = y1 - I*x1 is recomputed from x1, y1 and idx in the k = 1 epilogue (the very
-// expression b1 fed into the key switch) and - round 4 - once more in the k = 0 epilogue (x1, y1 come from L2 again; round 3 kept the 16 residues in registers across the
-// second transform: 168 VGPRs, 3 waves per SIMD; now 127 VGPRs, 4 waves, no scratch; measured +0.3 % conv/s, -1.5 % on a lone convolution: profiles/round4_conv33_b5m_ab.txt), so b1 does not write tmpT and nobody reads it (1.5 MiB less
+// expression b1 fed into the key switch) and kept in registers for k = 0 (168 VGPRs, 3 waves per SIMD). Round 4 measured the alternative the review asked for - t2.c1 re-derived in the k = 0
+// epilogue from x1 / y1: 127 VGPRs, 4 waves per SIMD, no scratch - at +0.3 % conv/s but +6 % fabric traffic (x1, y1 are not L2-hot a transform later: 563 MiB read per
+// launch against 428): not kept (profiles/round4_conv33_b5m_ab.txt, round4_conv33_counters_b5m_recompute.txt), so b1 does not write tmpT and nobody reads it (1.5 MiB less
 // per node: 0.5 written, 2 x 0.5 read, against 0.5 more for x1), and idx is read once per node. Per row batch of either polynomial:
 //   k = 1: m1 = I*x1 ; T = y1 - m1 ; t1 = y1 + m1 ; F = (a_Q/P)*T                      k = 0: m = I*x0 ; t1 = y0 + m ; F = y0 - m + (b_Q/P)*T
 //   d = F - n_k (n_k = rows-forward of the k-th extension, divided by P by b4) ; through the LDS row ; dst = reduce(t1 + perm(d)) (+ bias, k = 0)
@@ -877,11 +878,8 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, H
 #ifndef HC_B5M_UNROLL
 #define HC_B5M_UNROLL 2
 #endif
-#ifndef HC_B5M_RECOMPUTE
-#define HC_B5M_RECOMPUTE 1
-#endif
 #ifndef HC_B5M_WAVES
-#define HC_B5M_WAVES 4                // with t2.c1 re-derived in the k = 0 epilogue the kernel fits 127 VGPRs without scratch: four workgroups per CU (round 3: 168 VGPRs, three)
+#define HC_B5M_WAVES 3
 #endif
 template <int FM>
 __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTwTab T0fwd, HcPtrs biases, HcPtrs outs) {
@@ -897,11 +895,7 @@ __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTw
     const HcTw *__restrict__ evk = B.evkQ + tile;                                                                  // b_Q/P, then a_Q/P 65536 pairs on
     u64 *__restrict__ o = (outs.p[z] != nullptr ? const_cast<u64 *>(outs.p[z]) : B.dst + (size_t)z * B.dst_stride + (size_t)i * 2 * 65536) + tile;
     const u64 *__restrict__ bias = biases.p[z] != nullptr ? biases.p[z] + tile : nullptr;        // null except on the last node of the tree (eval.go:258)
-#if HC_B5M_RECOMPUTE
-    u64 e[16];
-#else
     u64 e[16], T[16];
-#endif
 #pragma unroll HC_B5M_UNROLL
     for (int k = 1; k >= 0; k--) {
         const u64 *__restrict__ in = B.tmpE + ((size_t)zn * 2 + k) * 65536 + (size_t)row * 256;
@@ -915,31 +909,18 @@ __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTw
 #pragma unroll
         for (int b = 0; b < 16; b += HC_B5_ROWS) {
             u64 Y[HC_B5_ROWS], X[HC_B5_ROWS], t1[HC_B5_ROWS], bs[HC_B5_ROWS]; HcTw K[HC_B5_ROWS], I[HC_B5_ROWS];
-#if HC_B5M_RECOMPUTE
-            u64 Y1[HC_B5_ROWS], X1[HC_B5_ROWS];
-#endif
 #pragma unroll
             for (int j = 0; j < HC_B5_ROWS; j++) {
                 const int off = (b + j) * 256;
                 Y[j] = ys[(size_t)k * 65536 + off]; X[j] = xs[(size_t)k * 65536 + off]; I[j] = idx[off]; K[j] = evk[(size_t)k * 65536 + off];
-#if HC_B5M_RECOMPUTE
-                if (k == 0) { Y1[j] = ys[(size_t)65536 + off]; X1[j] = xs[(size_t)65536 + off]; }
-#endif
                 bs[j] = (k == 0 && bias != nullptr) ? bias[off] : 0;
             }
 #pragma unroll
             for (int j = 0; j < HC_B5_ROWS; j++) {
                 const int kk = b + j;
                 u64 m = hc_shoup4(X[j], I[j].w, I[j].ws, Q), f;                                            // I * x_k, < 4q
-#if HC_B5M_RECOMPUTE
-                // t2.c1 (conv.go:288-289) as b1 formed it, lazy < 4q: formed where it is used, for k = 0 from x1 / y1 again (L2-hot: this workgroup read them a
-                // transform ago) - one more lazy product per element against 16 residues (32 VGPRs) carried across the second transform
-                const u64 Tk = k == 1 ? hc_fold(Y[j] + Q.q4 - m, Q.nq4) : hc_fold(Y1[j] + Q.q4 - hc_shoup4(X1[j], I[j].w, I[j].ws, Q), Q.nq4);
-#else
                 if (k == 1) T[kk] = hc_fold(Y[j] + Q.q4 - m, Q.nq4);                                       // t2.c1 (conv.go:288-289) as b1 formed it, lazy < 4q
-                const u64 Tk = T[kk];
-#endif
-                u64 g = hc_shoup4(Tk, K[j].w, K[j].ws, Q);                                                 // (key row / P) * t2.c1, < 4q
+                u64 g = hc_shoup4(T[kk], K[j].w, K[j].ws, Q);                                              // (key row / P) * t2.c1, < 4q
                 if (FM == HC_FM_FREE) {
                     t1[j] = Y[j] + m + bs[j];                                                              // conv.go:290 (+ bias), < 6q
                     f = (k == 0 ? Y[j] + Q.q4 - m + g : g) + HC_FREE_OFF * q - e[kk];                      // t2.c_k + (key switch)_k - n_k, < 81q
@@ -1333,19 +1314,22 @@ struct HcBasisExt {
 // the target-side sum of the extension for the 16 elements (rows hi * 16 + tid of one column) a cols-pass thread owns: yv = that column of the y_i / v rows.
 // Four elements at a time: their (n + 1) x 4 operands are all requested before the first is used, so that the loads of a group overlap (element by element the
 // kernel waited one L2 round trip per element: 626 us per launch against 548 for the separate extension and cols pass it replaces)
+#ifndef HC_EXT_GROUP
+#define HC_EXT_GROUP 4
+#endif
 __device__ __forceinline__ void hc_basis_ext_tile(u64 (&e)[16], const u64 *yv, const HcBasisExt &B, int tid) {
     const int n = B.n; const HcQ Q = hc_q(B.t);
 #pragma unroll
-    for (int g0 = 0; g0 < 16; g0 += 4) {
-        u64 y[4][9];
+    for (int g0 = 0; g0 < 16; g0 += HC_EXT_GROUP) {
+        u64 y[HC_EXT_GROUP][9];
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
+        for (int g = 0; g < HC_EXT_GROUP; g++) {
             const u64 *p = yv + (size_t)((g0 + g) * 16 + tid) * 256;
 #pragma unroll
             for (int i = 0; i < 9; i++) if (i <= n) y[g][i] = p[(size_t)i * 65536];                // rows y_0..y_(n-1), then v at row n
         }
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
+        for (int g = 0; g < HC_EXT_GROUP; g++) {
             u64 v = 0;
 #pragma unroll
             for (int i = 0; i < 9; i++) if (i == n) v = y[g][i];
@@ -1623,7 +1607,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_swk_sample(u64 *rows, const HcMod
     u64 *b_row = rows + (((size_t)d * 2 + 0) * G.nt + T) * 65536, *a_row = rows + (((size_t)d * 2 + 1) * G.nt + T) * 65536;
     const int bits = 64 - __builtin_clzll(q); const u64 mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
     for (u32 j = blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += gridDim.x * HC_TPB) {
-        if (G.splitmix) {                                                     // the test oracle's harness generator (oracle/oracle.c or_gen_swk): counter-based splitmix64 rows, the error handed over
+        if (G.splitmix) {                                                     // the test oracle's harness generator (or_gen_swk): counter-based splitmix64 rows, the error handed over
             u64 z = G.sm_seed + 0x1000 + (u64)(d * 64 + T) + ((u64)j + 1) * 0x9E3779B97F4A7C15ull;
             z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
             a_row[j] = z % q;

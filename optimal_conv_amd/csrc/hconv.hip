@@ -1149,7 +1149,7 @@ extern "C" int hc_swk_generate(hc_ctx *c, uint64_t key_id, int level, uint64_t g
     HC_ENTER(c); if (!seed8) return hc_fail(c, HC_ERR_ARG, "hc_swk_generate: null seed");
     return hc_swk_generate_impl(c, key_id, level, galEl, sk_ntt, seed8, false, 0, nullptr);
 }
-// TEST harness: the key the test oracle's generator (oracle/oracle.c or_gen_swk) derives from `seed` - uniform rows = counter-based splitmix64, the per-digit errors
+// TEST harness: the key the test oracle's generator (or_gen_swk) derives from `seed` - uniform rows = counter-based splitmix64, the per-digit errors
 // e_host[beta][N] (signed, drawn by the caller with the oracle's Box-Muller so that no device libm is involved) - for replaying the oracle's encrypted network in the product host
 extern "C" int hc_swk_generate_splitmix(hc_ctx *c, uint64_t key_id, int level, uint64_t galEl, const uint64_t *sk_ntt, uint64_t seed, const int64_t *e_host) {
     HC_ENTER(c); if (!e_host) return hc_fail(c, HC_ERR_ARG, "hc_swk_generate_splitmix: null errors");

@@ -49,7 +49,7 @@ static const uint64_t PACK_P = 0x1fffffffffe00001ull;   // main.go:449
 bool &testMode();
 const char *testOnlyEnv(const char *name);              // getenv(name) under --test-mode; nullptr when unset; panic when set without the flag
 // HCONV_RESNET_REPLAY=<seed> (test mode): the secret key, every switching key and the input's encryption randomness are the counter-based splitmix64 draws of the
-// test oracle's harness generators (oracle/oracle.c or_gen_sk / or_gen_galois_key_l0 / or_gen_swk / or_encrypt, restated in hconv_host.cpp): the `resnet` run then
+// test oracle's harness generators (or_gen_sk / or_gen_galois_key_l0 / or_gen_swk / or_encrypt, restated in hconv_host.cpp): the `resnet` run then
 // computes, bit for bit, the network tests/golden/gen_resnet_digests.py ran on the oracle, and prints a `replay digest layer i` line per layer (tests/test_gpu_z_cli.py)
 uint64_t resnetReplaySeed();                            // 0: off
 namespace replay {                                      // the oracle harness' generators (splitmix64, Box-Muller sigma 3.2 bound 6 sigma)

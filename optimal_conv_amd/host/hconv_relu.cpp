@@ -90,6 +90,7 @@ struct Boot {
     std::map<int, Encoder> sub_enc;                                    // encoders of the rings with fewer slots (sparse embedding), by log2 of their degree
     std::vector<double> sine;
     long n_keyswitch = 0, n_keys = 0;
+    bool parts_merged = false;                               // ctos_fork returned ONE ciphertext of 2 nb images (both halves): see merge2
     // algorithmic traffic of what has been evaluated, in rows of N residues (SURVEY.md 8(d)'s convention carried to the chain: every evaluator operation reads its
     // ciphertext operands once and writes its result once, temporaries stay on chip; switching keys, diagonals and masks are read once per operation and - being common
     // to the images of a batch - once per launch set): alg_ct per ciphertext, alg_shared per launch set
@@ -130,6 +131,28 @@ struct Boot {
         if (!pool_qp.empty()) { d = pool_qp.back(); pool_qp.pop_back(); }
         else { void *v = nullptr; HCR(hc_malloc(hc, (size_t)nb_max * qp_stride() * 8, &v)); d = (uint64_t *)v; }
         return std::shared_ptr<uint64_t>(d, [this](uint64_t *x) { pool_qp.push_back(x); });
+    }
+    // Full slots carry the two coefficient halves of every image as TWO ciphertexts through the sine and the ReLU (eval.go:462-477 loops over them). They see the same
+    // operations at the same levels, so with room for 2 nb images per block (merge_parts) they ride as ONE batch of 2 nb "images": image z of the second half sits at
+    // slot nb + z. The launches of the most expensive stages are then twice as wide for the same count - what HCONV_IMAGE_BATCH does across images, across the halves.
+    bool merge_parts = false;
+    DCt merge2(const DCt &a, const DCt &b) {              // called with nb = n: returns the 2n-image ciphertext and switches the batch to 2n
+        if (a.level != b.level || a.deg != 1 || b.deg != 1 || 2 * nb > nb_max) panic("merge2: halves differ or the blocks are too small");
+        DCt r = new_ct(a.level, 1, a.scale); const int n0 = nb;
+        for (int d = 0; d < 2; d++) for (int z = 0; z < n0; z++) {
+            HCR(hc_copy(hc, r.p[d].get() + (size_t)z * poly_stride(), a.p[d].get() + (size_t)z * poly_stride(), (size_t)(a.level + 1) * N * 8));
+            HCR(hc_copy(hc, r.p[d].get() + (size_t)(n0 + z) * poly_stride(), b.p[d].get() + (size_t)z * poly_stride(), (size_t)(a.level + 1) * N * 8));
+        }
+        set_nb(2 * n0);
+        return r;
+    }
+    void split2(const DCt &m, DCt out[2]) {               // called with nb = 2n: the two halves as n-image ciphertexts; the batch goes back to n
+        const int n0 = nb / 2; set_nb(n0);
+        for (int h = 0; h < 2; h++) {
+            out[h] = new_ct(m.level, 1, m.scale);
+            for (int d = 0; d < 2; d++) for (int z = 0; z < n0; z++)
+                HCR(hc_copy(hc, out[h].p[d].get() + (size_t)z * poly_stride(), m.p[d].get() + (size_t)(h * n0 + z) * poly_stride(), (size_t)(m.level + 1) * N * 8));
+        }
     }
     // rows [0, rows) of every image's polynomial: device-to-device copies between batched blocks
     void copy_rows(uint64_t *dst, const uint64_t *src, size_t rows, size_t dst_off_rows = 0, size_t src_off_rows = 0) {
@@ -767,8 +790,15 @@ struct Boot {
         const int a = (n + 1) / 2, b = n >> 1, c = a - b;
         lt_power_cheby(C, a, sc); lt_power_cheby(C, b, sc); if (c) lt_power_cheby(C, c, sc);
         DCt t = lt_rescale(mul_relin(C[a], C[b]), sc);
-        t = lt_add(t, t);
-        C[n] = c == 0 ? add_const(t, -1.0) : lt_sub(t, C[c]);
+        // 2 t - 1 (AddConst: floor(|scale| + 0.5)) or 2 t - C[c] (evaluateInPlace's Sub: the smaller-scale operand times uint64(ratio)) as ONE launch: the residues of Add(t, t)
+        // followed by AddConst / Sub, without their passes over the ciphertext
+        if (c == 0) C[n] = lincomb({t}, {2.0}, t.level, t.scale, true, -floor(fabs(t.scale) + 0.5));
+        else {
+            const DCt &u = C[c]; const int L = std::min(t.level, u.level);
+            double kt = 1, ku = 1, scale = t.scale;
+            if (t.scale > u.scale) ku = std::max(1.0, floor(t.scale / u.scale)); else if (u.scale > t.scale) { kt = std::max(1.0, floor(u.scale / t.scale)); scale = u.scale; }
+            C[n] = lincomb({t, u}, {2.0 * kt, -ku}, L, scale);
+        }
     }
     DCt lt_leaf_any(double target, const LPoly &p, std::map<int, DCt> &C, double sc) {       // evaluatePolyFromPowerBasis incl. the constant term
         const bool c0 = fabs(p.c[0]) > 1e-14;
@@ -952,7 +982,10 @@ struct Boot {
         for (int r = 0; r < SIN_DOUBLE; r++) target = sqrt(target * (double)Q[(size_t)(LV_RELU_TOP + 1 + r)]);
         const std::vector<double> coeffs(FORK_SINE_COEFFS, FORK_SINE_COEFFS + 63);
         const double scfac = (double)(1 << SIN_DOUBLE);
-        for (int h = 0; h < nparts; h++) {
+        const bool merged = nparts == 2 && merge_parts && 2 * nb <= nb_max && !stock;
+        if (merged) { parts[0] = merge2(parts[0], parts[1]); }        // both halves through the sine as one batch; split again by the caller after the ReLU (parts_merged)
+        parts_merged = merged;
+        for (int h = 0; h < (merged ? 1 : nparts); h++) {
             DCt c = parts[h]; c.scale = sinescale;
             c = add_const(c, -0.5 / (scfac * (2.0 * SIN_K / scfac)));
             c = eval_cheby_lattigo(c, coeffs, target, sinescale);
@@ -1119,7 +1152,10 @@ static DCt keep_ctxt(Boot *B, const DCt &ct, const std::vector<int> &idx, const 
 // ---------------------------------------------------------------- public surface (hconv_host.hpp)
 Boot *newBoot(const std::vector<int64_t> &sk, const Seed256 &seed, int device, const std::vector<int> &log_sparse_sets, int image_batch) {
     if (image_batch < 1 || image_batch > 8) panic("image batch must be 1..8");
-    Boot *b = new Boot(); b->nb_max = image_batch; b->build(sk, seed, device);
+    Boot *b = new Boot(); b->nb_max = image_batch;
+    // a full-slot bootstrapper (kind "Conv": two halves per image) gets blocks for twice the batch when that fits the library's 8 images per launch: merge2
+    if (std::find(log_sparse_sets.begin(), log_sparse_sets.end(), 0) != log_sparse_sets.end() && log_sparse_sets.size() == 1 && 2 * image_batch <= 8 && !(getenv("HCONV_NO_MERGE") && atoi(getenv("HCONV_NO_MERGE")))) { b->nb_max = 2 * image_batch; b->merge_parts = true; }
+    b->build(sk, seed, device);
     for (int ls : log_sparse_sets) b->set(ls);
     return b;
 }
@@ -1179,7 +1215,7 @@ std::vector<BootCiphertext> evalConv_BNRelu_tail_batch(Boot *B, const std::strin
     if (!sparse && kind != "Conv") panic("No kind!");
     if (!sparse && log_sparse != 0) panic("No cases for log_sparse");
     const int nimg = (int)ct_conv_dev.size();
-    if (nimg < 1 || nimg > B->nb_max) panic("evalConv_BNRelu_tail: more images than the bootstrapper's image batch (HCONV_IMAGE_BATCH)");
+    if (nimg < 1 || nimg > (B->merge_parts ? B->nb_max / 2 : B->nb_max)) panic("evalConv_BNRelu_tail: more images than the bootstrapper's image batch (HCONV_IMAGE_BATCH)");
     B->set_nb(nimg); B->alg_ct = B->alg_shared = 0;
     DCt ct = B->new_ct(0, 1, ct_scale * pow(2.0, pow_));                                            // eval.go:437
     for (int z = 0; z < nimg; z++) for (int d = 0; d < 2; d++) HCR(hc_copy(hc, ct.p[d].get() + (size_t)z * B->poly_stride(), ct_conv_dev[(size_t)z] + (size_t)d * N, (size_t)N * 8));
@@ -1213,13 +1249,18 @@ std::vector<BootCiphertext> evalConv_BNRelu_tail_batch(Boot *B, const std::strin
     HCR(hc_sync(hc));
     printf("Done in %s \n", dur(start).c_str());
     if (prof) profile_dump(B, "sine");
-    if (B->replay_seed) for (int ul = 0; ul < iter; ul++) replay_digest(ul ? "ctos1" : "ctos0", boots[ul]);
+    if (B->replay_seed) {
+        if (B->parts_merged) { DCt both = boots[0]; B->split2(both, boots); B->parts_merged = false; }      // test mode prints the halves: continue unmerged
+        for (int ul = 0; ul < iter; ul++) replay_digest(ul ? "ctos1" : "ctos0", boots[ul]);
+    }
     if (rls) { printf("replay of the sparse-slot BootstrappConv_CtoS done (log_sparse %d)\n", ls_run); fflush(stdout); exit(0); }
     start = now();
-    for (int ul = 0; ul < iter; ul++) {
+    for (int ul = 0; ul < (B->parts_merged ? 1 : iter); ul++) {
+        if (B->parts_merged) printf("Eval: ");                                                        // the reference's loop (eval.go:462-477) prints once per half: same line shape
         DCt r = evalReLU(B, boots[ul], alpha);                                                        // eval.go:473
         boots[ul] = B->mul_const_int(r, pow(2.0, pow_));                                              // MulByPow2 (eval.go:474)
     }
+    if (B->parts_merged) { DCt both = boots[0]; B->split2(both, boots); B->parts_merged = false; }    // the halves part again: their masks differ
     HCR(hc_sync(hc));
     printf("ReLU Done in %s \n", dur(start).c_str());
     if (prof) profile_dump(B, "ReLU");

@@ -24,6 +24,7 @@ python $R/tools/valu_floor.py combine $O $CONVS $O/valu.json | tee $O/valu.txt
 fi
 # (2) the chain
 NBC=${NBCHAIN:-4}; IT=2
+[ "${SKIP_CHAIN:-0}" = "1" ] && exit 0
 W2=/tmp/r4pmc_chain; mkdir -p $W2; cd $W2
 python - <<PY
 import sys; sys.path.insert(0, "$R")
@@ -53,7 +54,7 @@ res = {"bytes_per_ciphertext_layer": per, "bytes_per_layer_launch_set": per * nb
        "per_kernel_per_ciphertext_layer": {k: {"read": rd.get(k, 0) / layers / nb, "write": wr.get(k, 0) / layers / nb, "launches_per_layer": n.get(k, 0) / layers} for k in sorted(set(rd) | set(wr))},
        "measured_with": {"command": "HCONV_IMAGE_BATCH=%d HCONV_SKIP_BL=1 conv convReLU 5 1 %d" % (nb, layers), "ciphertexts_per_launch_set": nb, "layers_in_run": layers,
                          "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950); KiB units; the chain's kernels only (key generation, DFT-matrix encoding and the convolution excluded)"}}
-json.dump(res, open(O + "/traffic_convrelu_5_1.json", "w"), indent=1)
+json.dump(res, open(O + "/traffic_convrelu_5_1_n%d.json" % nb, "w"), indent=1)
 print("chain traffic per ciphertext-layer at n = %d: %.1f GB (read %.1f, write %.1f)" % (nb, per / 1e9, res["read_bytes_per_ciphertext_layer"] / 1e9, res["write_bytes_per_ciphertext_layer"] / 1e9))
 PY
 ls $O
