@@ -184,6 +184,10 @@ int hc_keyswitch_qp(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx,
  * permutation: pc0 = NULL): out[2][level+1+np][N] (+)= Permute_galEl( hc_keyswitch_qp(cx) + (pc0 on the Q rows of the first component) ); accumulate != 0 adds to
  * what out holds. The same residues as hc_keyswitch_qp + hc_lv_add + hc_qp_permute2 (+ hc_qp_op2 HC_LV_ADD); out must not be the scratch of another call. */
 int hc_keyswitch_qp_rotate(hc_ctx *ctx, uint64_t key_id, uint64_t galEl, int level, const uint64_t *pc0, const uint64_t *cx, uint64_t *out, int hoisted, int accumulate);
+/* all baby steps of a linear transform in one call: nrot hoisted rotations (key_ids[r], galEls[r]) of the decomposition hc_keyswitch_decompose(level, cx) holds, outs[r] as
+ * hc_keyswitch_qp_rotate(key_ids[r], galEls[r], level, pc0, cx, outs[r], 1, 0) leaves it. The inner products of several rotations share one pass over the digits.
+ * key_ids, galEls, outs: HOST arrays. */
+int hc_keyswitch_qp_rotate_many(hc_ctx *ctx, int nrot, const uint64_t *key_ids, const uint64_t *galEls, int level, const uint64_t *pc0, const uint64_t *cx, uint64_t *const *outs);
 int hc_mod_down2(hc_ctx *ctx, int level, const uint64_t *x, uint64_t *out0, uint64_t *out1);
 int hc_qp_op2(hc_ctx *ctx, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1);
 int hc_keyswitch_hoisted(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1);

@@ -1516,6 +1516,42 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const 
         for (int g = 0; g < HC_MAXIMG; g++) if (g < n) { u64 *a = acc + (size_t)g * acc_is + rowT + j; a[0] = s0[g]; a[comp] = s1[g]; }
     }
 }
+// The inner products of R hoisted rotations in ONE launch (the baby steps of a linear transform share one digit decomposition): a digit element is read once for the R keys
+// (hc_k_ks_mac_all re-reads all n x beta x nt digit rows per rotation - what bounds it). R x NB accumulator slots per component and thread (<= 16), plain Montgomery
+// accumulation (the kernel is bound by its loads). acc: [rotation][image][2][nt][N], rotations acc_rs words apart. grid = (64, nt)
+struct HcKeyPtrs { const u64 *k[8]; };
+template <int R, int NB>
+__global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_multi(HcKeyPtrs keys, int nrot, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_rs, size_t acc_is, const HcMod *mods,
+                                                            int nl, int nq, int nt, int alpha, int beta, int n) {
+    const int T = blockIdx.y;
+    const HcMod m = mods[T < nl ? T : nq + (T - nl)];
+    const size_t rowT = (size_t)T * 65536, comp = (size_t)nt * 65536;
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        u64 s0[R][NB], s1[R][NB];
+        for (int d = 0; d < beta; d++) {
+            const int lo = d * alpha, hi = lo + alpha < nl ? lo + alpha : nl;
+            const bool own = T >= lo && T < hi;
+            const u64 *xs = own ? cx + rowT + j : digits + ((size_t)d * nt) * 65536 + rowT + j; const size_t xis = own ? cx_is : dg_is;
+            u64 x[NB];
+#pragma unroll
+            for (int g = 0; g < NB; g++) if (g < n) x[g] = xs[(size_t)g * xis];
+#pragma unroll
+            for (int r = 0; r < R; r++) if (r < nrot) {
+                const u64 kb = keys.k[r][((size_t)d * 2 * nt) * 65536 + rowT + j], ka = keys.k[r][((size_t)d * 2 * nt) * 65536 + comp + rowT + j];
+#pragma unroll
+                for (int g = 0; g < NB; g++) if (g < n) {
+                    const u64 p0 = hc_mont(x[g], kb, m.q, m.qinv), p1 = hc_mont(x[g], ka, m.q, m.qinv);
+                    s0[r][g] = d == 0 ? p0 : hc_addmod(s0[r][g], p0, m.q);
+                    s1[r][g] = d == 0 ? p1 : hc_addmod(s1[r][g], p1, m.q);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) if (r < nrot)
+#pragma unroll
+            for (int g = 0; g < NB; g++) if (g < n) { u64 *a = acc + (size_t)r * acc_rs + (size_t)g * acc_is + rowT + j; a[0] = s0[r][g]; a[comp] = s1[r][g]; }
+    }
+}
 // ModDown's last step and evaluator.permuteNTT's tail in one pass (rotations: the key-switched polynomials never reach HBM unpermuted):
 //   out_0[l][i] = ((acc_0 - ext_0) * P^-1 + c0)[l][src(i)],  out_1[l][i] = ((acc_1 - ext_1) * P^-1)[l][src(i)],  src = PermuteNTTIndex(g)
 __global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_rotate_mm(const u64 *acc, size_t acc_zs, const u64 *ext, size_t ext_zs, const u64 *c0, u64 *o0, u64 *o1, const HcMod *mods, const HcTw *pinv, u32 g,

@@ -89,6 +89,7 @@ struct hc_ctx {
     int async_alloc = 0;                                    // HCONV_ASYNC_ALLOC=1: non-blocking stream + cached allocations (see hcx_malloc)
     HcRowMod *d_rowmods = nullptr;                          // per modulus: both twiddle tables + q, mu (multi-modulus batched transforms)
     u64 *ws_mm = nullptr; size_t ws_mm_rows = 0;            // scratch of the batched key switch / rescale
+    u64 *ws_accm = nullptr; size_t ws_accm_rows = 0;        // inner products of several hoisted rotations (hc_keyswitch_qp_rotate_many)
     struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr; };
     std::map<int, KsPlan> ks_plan;                          // per level: basis-extension constants of every (digit, target limb)
     std::map<int, HcTw *> rescale_plan;                     // per level: qL^-1 mod q_i
@@ -339,7 +340,7 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     if (c->ev_fork) D(hipEventDestroy(c->ev_fork), "hipEventDestroy");
     if (c->ev_shard) D(hipEventDestroy(c->ev_shard), "hipEventDestroy");
     F(c->enc_roots); F(c->enc_rot_group);
-    F(c->ws_ctc); F(c->ws_tmp); F(c->d_mods); F(c->d_rowmods); F(c->ws_mm);
+    F(c->ws_ctc); F(c->ws_tmp); F(c->d_mods); F(c->d_rowmods); F(c->ws_mm); F(c->ws_accm);
     for (auto &kv : c->ks_plan) { F(kv.second.bx); F(kv.second.bxdown); F(kv.second.pinv); }
     for (auto &kv : c->rescale_plan) F(kv.second);
     F(c->d_csts);
@@ -1333,6 +1334,42 @@ extern "C" int hc_keyswitch_qp_rotate(hc_ctx *c, uint64_t key_id, uint64_t galEl
     HC_TRY(hc_ks_mac(c, *key, level, cx, S, S.acc, S.acc_is));
     const int nl = level + 1, nt = nl + c->np;
     return hc_launch(c, "qp_rotate_finish", hc_k_qp_rotate_finish, dim3(32, (unsigned)nt, 2u * (unsigned)c->nb), (const u64 *)S.acc, S.acc_is, (const u64 *)pc0, c->bs_poly, (u64 *)out, c->bs_qp, (const HcMod *)c->d_mods, nl, c->nq, nt, (u32)(galEl & 0x1FFFF), accumulate ? 1 : 0);
+}
+// The baby steps of a linear transform as ONE call: nrot hoisted rotations of the decomposition hc_keyswitch_decompose(level, cx) left, each = hc_keyswitch_qp_rotate(key_ids[r],
+// galEls[r], level, pc0, cx, outs[r], 1, 0). The inner products of up to 16 / images rotations run in one launch (the digits - n x beta x nt rows - are read once for
+// all of them instead of once per rotation), then one finishing pass per rotation. Same residues as the single calls.
+extern "C" int hc_keyswitch_qp_rotate_many(hc_ctx *c, int nrot, const uint64_t *key_ids, const uint64_t *galEls, int level, const uint64_t *pc0, const uint64_t *cx, uint64_t *const *outs) {
+    HC_ENTER(c);
+    if (nrot < 1 || !key_ids || !galEls || !cx || !outs) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_qp_rotate_many: bad arguments");
+    if (c->hoist_cx != cx || c->hoist_level != level) return hc_fail(c, HC_ERR_STATE, "hc_keyswitch_qp_rotate_many: no decomposition of this polynomial at level %d is held (call hc_keyswitch_decompose first)", level);
+    HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha, nb = c->nb;
+    const int NB = nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8, R = NB == 8 ? 2 : NB == 4 ? 4 : 8;
+    const size_t acc_is = (size_t)2 * nt * HC_N, acc_rs = acc_is * (size_t)nb;
+    if (c->ws_accm_rows < (size_t)R * nb * 2 * nt) {
+        HC_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->ws_accm) HC_HIP(c, hcx_free(c, c->ws_accm));
+        c->ws_accm = nullptr; c->ws_accm_rows = 0;
+        HC_HIP(c, hcx_malloc(c, (void **)&c->ws_accm, (size_t)R * nb * 2 * nt * HC_N * sizeof(u64)));
+        c->ws_accm_rows = (size_t)R * nb * 2 * nt;
+    }
+    for (int r0 = 0; r0 < nrot; r0 += R) {
+        const int nr = nrot - r0 < R ? nrot - r0 : R;
+        HcKeyPtrs K; memset(&K, 0, sizeof K); int beta = 0;
+        for (int r = 0; r < nr; r++) {
+            const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_qp_rotate_many", key_ids[r0 + r], level, &key));
+            if (!(galEls[r0 + r] & 1) || !outs[r0 + r]) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_qp_rotate_many: rotation %d: galEl must be odd, out non-null", r0 + r);
+            K.k[r] = key->rows; beta = key->beta;
+        }
+        const dim3 grid(64, (unsigned)nt);
+#define HC_MAC_MULTI(RR, NN) hc_launch(c, "ks_mac_multi", hc_k_ks_mac_multi<RR, NN>, grid, K, nr, (const u64 *)cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, c->ws_accm, acc_rs, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta, nb)
+        if (NB == 8) HC_TRY(HC_MAC_MULTI(2, 8)); else if (NB == 4) HC_TRY(HC_MAC_MULTI(4, 4)); else if (NB == 2) HC_TRY(HC_MAC_MULTI(8, 2)); else HC_TRY(HC_MAC_MULTI(8, 1));
+#undef HC_MAC_MULTI
+        for (int r = 0; r < nr; r++)
+            HC_TRY(hc_launch(c, "qp_rotate_finish", hc_k_qp_rotate_finish, dim3(32, (unsigned)nt, 2u * (unsigned)nb), (const u64 *)(c->ws_accm + (size_t)r * acc_rs), acc_is, (const u64 *)pc0, c->bs_poly, (u64 *)outs[r0 + r], c->bs_qp,
+                             (const HcMod *)c->d_mods, nl, c->nq, nt, (u32)(galEls[r0 + r] & 0x1FFFF), 0));
+    }
+    return HC_OK;
 }
 // hc_mod_down2 = ring.(*FastBasisExtender).ModDownSplitNTTPQ on the two polynomials x[2][level+1+np][N] -> out0, out1 [level+1][N]. A hoisted
 // decomposition held by the context survives it when it was taken at this same level (any other level drops it).

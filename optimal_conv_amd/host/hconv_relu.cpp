@@ -607,11 +607,16 @@ struct Boot {
             HCR(hc_keyswitch_decompose(hc, Lb, cx));
             auto wide = hoist_c1 ? block_qp2() : std::shared_ptr<uint64_t>();
             if (hoist_c1 && nb != 1) panic("linear_transform_qp: the stale-digit hoisting of the stock Bootstrapp runs one image at a time");
-            for (int b : babies) {
+            if (!hoist_c1) {                                                                                            // all baby steps: inner products sharing the digit reads, + P c0, permutation
+                std::vector<uint64_t> ids, gals; std::vector<uint64_t *> outs;
+                for (int b : babies) { const uint64_t gal = gal_rot(b); auto r = block_qp2(); ids.push_back(key(gal, L, 1)); gals.push_back(gal); outs.push_back(r.get()); rot[b] = r; n_keyswitch++; }
+                static const bool one_by_one = getenv("HCONV_ROTATE_ONE_BY_ONE") != nullptr;
+                if (!one_by_one) HCR(hc_keyswitch_qp_rotate_many(hc, (int)ids.size(), ids.data(), gals.data(), L, pc0.get(), cx, outs.data()));
+                else for (size_t i = 0; i < ids.size(); i++) HCR(hc_keyswitch_qp_rotate(hc, ids[i], gals[i], L, pc0.get(), cx, outs[i], 1, 0));
+            } else for (int b : babies) {
                 const uint64_t gal = gal_rot(b);
                 auto r = block_qp2();
-                if (!hoist_c1) HCR(hc_keyswitch_qp_rotate(hc, key(gal, L, 1), gal, L, pc0.get(), cx, r.get(), 1, 0));       // inner product, + P c0, permutation: one call
-                else {                                                                                                  // [2][Lb+1+np][N] -> rows 0..L and the P rows of each component
+                {                                                                                                  // [2][Lb+1+np][N] -> rows 0..L and the P rows of each component
                     auto acc = block_qp2();
                     HCR(hc_keyswitch_qp(hc, key(gal, Lb, 1), Lb, cx, wide.get(), 1));
                     const size_t zw = (size_t)(Lb + 1 + np) * N;

@@ -546,6 +546,24 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
         bi.free(); ai.free(); oi.free()
     eq(qr[0], np.stack(comp), "keyswitch_qp_rotate == keyswitch_qp + add + permute")
 
+    # all baby steps in one call == the single hoisted rotations (5 rotations over two keys: more than one launch's worth at n >= 3)
+    rots = [(30, gal), (31, pow(5, 9, 2 * N)), (30, pow(5, 9, 2 * N)), (31, gal), (30, pow(5, 40, 2 * N))]
+
+    def rot_many(c0p, x, *outs):
+        ck(L.hc_keyswitch_decompose(h, level, x))
+        ids = (C.c_uint64 * len(rots))(*[r[0] for r in rots]); gs = (C.c_uint64 * len(rots))(*[r[1] for r in rots]); arr = (C.c_void_p * len(rots))(*outs)
+        ck(L.hc_keyswitch_qp_rotate_many(h, len(rots), ids, gs, level, c0p, x, arr))
+
+    def rot_single(c0p, x, *outs):
+        ck(L.hc_keyswitch_decompose(h, level, x))
+        for (kid_, g_), o_ in zip(rots, outs):
+            ck(L.hc_keyswitch_qp_rotate(h, C.c_uint64(kid_), C.c_uint64(g_), level, c0p, x, o_, 1, 0))
+    rm = run("keyswitch_qp_rotate_many", rot_many, [(b, "p"), (a, "p")], [("q", QW)] * len(rots))
+    rs_ = run("keyswitch_qp_rotate x5", rot_single, [(b, "p"), (a, "p")], [("q", QW)] * len(rots))
+    for i in range(len(rots)):
+        eq(rm[i], rs_[i], f"rotate_many == single hoisted rotations (rotation {i})")
+    eq(rm[0], qr[0], "rotate_many (hoisted) == the plain fused rotation")
+
     def qp_rot_acc(x, o):
         ck(L.hc_keyswitch_decompose(h, level, x)); ck(L.hc_keyswitch_qp_rotate(h, K1, C.c_uint64(gal), level, None, x, o, 1, 1))
     run("keyswitch_qp_rotate (hoisted, accumulate, no pc0)", qp_rot_acc, [(a1, "p")], [("q", QW)], init=[acc.reshape(n, -1)])
