@@ -156,6 +156,9 @@ int hc_keyswitch(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, ui
 /* evaluator.Relinearize / MulRelin's tail as one call: out_k = a_k + (hc_keyswitch of cx)_k, k = 0, 1 (a = the degree-0 and degree-1 parts of the tensor product, cx = its
  * degree-2 part); the addition rides in ModDown's last pass. The same residues as hc_keyswitch + hc_lv_op2(HC_LV_ADD). out_k may be a_k. */
 int hc_keyswitch_add(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, const uint64_t *a0, const uint64_t *a1, uint64_t *out0, uint64_t *out1);
+/* hc_keyswitch_add followed by ONE hc_div_round_last2 (evaluator.MulRelin + Rescale's first drop), as one call: out_k = Rescale(a_k + (key switch of cx)_k), level >= 2,
+ * out at level - 1. Same residues as the two calls; ModDown and the rescale share one forward transform per limb. */
+int hc_keyswitch_add_rescale(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, const uint64_t *a0, const uint64_t *a1, uint64_t *out0, uint64_t *out1);
 /* HARNESS ONLY - not part of what a Lattigo host binds (it owns its keys and hands them over with hc_swk_load): rlwe.KeyGenerator.GenSwitchingKey on the device for
  * the C++ test harness, restricted to the rows a level-`level` key switch reads. galEl odd: the rotation / conjugation key of galEl (s_out = sigma_{galEl^-1}(s));
  * galEl = 0: the relinearisation key (s^2 -> s). sk_ntt: DEVICE rows [nq + np][N] = NTT(s) modulo every modulus of the context. seed8: 8 x 32 bits keying ChaCha20;

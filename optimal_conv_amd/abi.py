@@ -46,6 +46,7 @@ SYMBOLS = {
     "hc_rotate_gal_l0": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_swk_load": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, u64p]),
     "hc_keyswitch_add": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_keyswitch_add_rescale": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_swk_generate_splitmix": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_int64)]),
     "hc_swk_generate": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32)]),
     "hc_keyswitch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1317,6 +1317,24 @@ struct HcBasisExt {
 #ifndef HC_EXT_GROUP
 #define HC_EXT_GROUP 4
 #endif
+// target side of the extension for one coefficient: y[0..n-1] = the y_i, y[n] = v
+__device__ __forceinline__ u64 hc_basis_ext_sum(const u64 (&y)[9], const HcBasisExt &B, const HcQ &Q) {
+    const int n = B.n;
+    u64 v = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) if (i == n) v = y[i];
+    if (n == 1) return hc_barrett64(y[0], B.t, B.mu_t);
+    if (B.t < (1ull << 58)) {                                          // lazy sum: below 2^58 up to 8 terms and the offset stay under 36 t < 2^64 unreduced
+        u64 acc = Q.q4;
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i < n) acc += hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q);
+        return hc_reduce64(acc - hc_shoup4(v, B.smodt.w, B.smodt.ws, Q), B.mu_t, Q);
+    }
+    u64 acc = 0;                                                       // the 60 / 61-bit limbs fold the running sum by 4t
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (i < n) acc = hc_fold(acc + hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q), Q.nq4);
+    return hc_canon8(acc + Q.q4 - hc_shoup4(v, B.smodt.w, B.smodt.ws, Q), Q);
+}
 __device__ __forceinline__ void hc_basis_ext_tile(u64 (&e)[16], const u64 *yv, const HcBasisExt &B, int tid) {
     const int n = B.n; const HcQ Q = hc_q(B.t);
 #pragma unroll
@@ -1329,25 +1347,7 @@ __device__ __forceinline__ void hc_basis_ext_tile(u64 (&e)[16], const u64 *yv, c
             for (int i = 0; i < 9; i++) if (i <= n) y[g][i] = p[(size_t)i * 65536];                // rows y_0..y_(n-1), then v at row n
         }
 #pragma unroll
-        for (int g = 0; g < HC_EXT_GROUP; g++) {
-            u64 v = 0;
-#pragma unroll
-            for (int i = 0; i < 9; i++) if (i == n) v = y[g][i];
-            u64 r;
-            if (n == 1) r = hc_barrett64(y[g][0], B.t, B.mu_t);
-            else if (B.t < (1ull << 58)) {                                   // lazy sum: below 2^58 up to 8 terms and the offset stay under 36 t < 2^64 unreduced
-                u64 acc = Q.q4;
-#pragma unroll
-                for (int i = 0; i < 8; i++) if (i < n) acc += hc_shoup4(y[g][i], B.hat[i].w, B.hat[i].ws, Q);
-                r = hc_reduce64(acc - hc_shoup4(v, B.smodt.w, B.smodt.ws, Q), B.mu_t, Q);
-            } else {                                                         // the 60 / 61-bit limbs fold the running sum by 4t
-                u64 acc = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) if (i < n) acc = hc_fold(acc + hc_shoup4(y[g][i], B.hat[i].w, B.hat[i].ws, Q), Q.nq4);
-                r = hc_canon8(acc + Q.q4 - hc_shoup4(v, B.smodt.w, B.smodt.ws, Q), Q);
-            }
-            e[g0 + g] = r;
-        }
+        for (int g = 0; g < HC_EXT_GROUP; g++) e[g0 + g] = hc_basis_ext_sum(y[g], B, Q);
     }
 }
 struct HcRowMod { HcTwTab fwd, inv; u64 q, mu; };
@@ -1364,8 +1364,12 @@ struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_
               //  ext_bs != null  (cols_fwd): the input is the fast basis extension of row y computed on the fly from the per-coefficient y_i / v rows hc_k_basis_yv left
               //                  (`in` = yv[z][n_src + 1][N]): sum_i y_i (S/s_i mod t) - v (S mod t), constants ext_bs[(z_alpha ? zi * ext_rows : 0) + y] - the extended
               //                  digits (or ModDown's extension of the P part) never exist in memory in the coefficient domain
+              //  ext_bs and lift_t (cols_fwd<2>): ModDown with the Rescale that follows it in ONE forward transform (NTT is linear): the input is ext_y + P * lift_y(t),
+              //                  t = the coefficient row of the last limb AFTER ModDown (lift_t[z][N]), lift_pmul[y] = P mod q_y; the matching epilogue is
+              //                  (x - result) * epi_mul[y] + epi_add * epi_add_mul[y] with epi_mul = (P q_L)^-1, epi_add_mul = q_L^-1
               int lift_level; const HcMod *mods; const HcBasisExt *ext_bs; int ext_rows;
-              const u64 *epi_x; size_t epi_x_zs, epi_x_is; const HcTw *epi_mul; const u64 *epi_add; size_t epi_add_zs, epi_add_is; };
+              const u64 *lift_t; size_t lift_t_zs, lift_t_is; const HcTw *lift_pmul;
+              const u64 *epi_x; size_t epi_x_zs, epi_x_is; const HcTw *epi_mul; const u64 *epi_add; size_t epi_add_zs, epi_add_is; const HcTw *epi_add_mul; };
 // z_alpha > 0: operand z is digit z of a key switch and its own limbs [z*z_alpha, min((z+1)*z_alpha, nl)) are the rows to skip
 __device__ __forceinline__ bool hc_mm_skip(const HcMm &A, int y, int zi) {
     if (A.z_alpha > 0) { const int lo = zi * A.z_alpha, hi = lo + A.z_alpha < A.nl ? lo + A.z_alpha : A.nl; return y >= lo && y < hi; }
@@ -1379,20 +1383,30 @@ __device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl
 // (Round 4, measured and not kept - profiles/round4_chain_class_paths_ab.txt: butterflies per modulus class inside these kernels - 32-bit canonical arithmetic for the
 // chain's eleven ~30-bit limbs, the fold-free 64-bit form below 2^57 - as a block-uniform switch cost 108-132 VGPRs against 65-86 and only won the lost occupancy back;
 // as one launch per class they kept their registers but turned every pass into three short launches: 224 ms per 8-ciphertext layer against 203.)
-template <bool EXT>      // EXT: the input is the fused basis extension
+template <int EXT>      // EXT 1: the input is the fused basis extension; 2: the extension plus P times Rescale's lift (ModDown and Rescale in one transform)
 __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_COLS_LDS];
     HC_MM_PROLOGUE
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
     u64 e[16];
-    if (A.lift_level > 0) {                                                  // block-uniform
+    if (EXT) {
+        hc_basis_ext_tile(e, in + blockIdx.x * 16 + c, A.ext_bs[(A.z_alpha > 0 ? (size_t)zi * A.ext_rows : 0) + y], tid);
+        if (EXT == 2) {
+            const u64 qL = A.mods[A.lift_level].q, h = (qL - 1) >> 1, qi = R.q, neg_h = qi - (h % qi);
+            const u64 *tt = A.lift_t + (size_t)zi * A.lift_t_zs + (size_t)img * A.lift_t_is + blockIdx.x * 16 + c;
+            const HcTw pm = A.lift_pmul[y];
+#pragma unroll
+            for (int hi = 0; hi < 16; hi++) {
+                const u64 r = hc_barrett64(hc_csub(tt[(size_t)(hi * 16 + tid) * 256] + h, qL) + neg_h, qi, R.mu);
+                e[hi] = hc_addmod(e[hi], hc_mul_shoup(r, pm.w, pm.ws, qi), qi);
+            }
+        }
+    } else if (A.lift_level > 0) {                                           // block-uniform
         const u64 qL = A.mods[A.lift_level].q, h = (qL - 1) >> 1, qi = R.q, neg_h = qi - (h % qi);
         const u64 *tt = in + blockIdx.x * 16 + c;                           // `in` = t[z][N] (zs_in = N, is_in = nz N): one coefficient row per operand
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) e[hi] = hc_barrett64(hc_csub(tt[(size_t)(hi * 16 + tid) * 256] + h, qL) + neg_h, qi, R.mu);
-    } else if (EXT) {
-        hc_basis_ext_tile(e, in + blockIdx.x * 16 + c, A.ext_bs[(A.z_alpha > 0 ? (size_t)zi * A.ext_rows : 0) + y], tid);
     } else {
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) e[hi] = in[base + (size_t)(hi * 16 + tid) * 256];
@@ -1423,7 +1437,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, 
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             u64 r = hc_mul_shoup(hc_submod(x[k * 256], e[k], R.q), w.w, w.ws, R.q);
-            if (ad != nullptr) r = hc_addmod(r, ad[k * 256], R.q);
+            if (ad != nullptr) r = hc_addmod(r, A.epi_add_mul != nullptr ? hc_mul_shoup(ad[k * 256], A.epi_add_mul[y].w, A.epi_add_mul[y].ws, R.q) : ad[k * 256], R.q);
             out[lin + k * 256] = r;
         }
         return;
@@ -1457,6 +1471,31 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_inv_canon_mm(const u64 *in, 
     hc_cols_inv(e, lds, R.inv, c, tid, Q);
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_canon4(e[hi], Q);
+}
+// ModDown fused with the Rescale behind it (hc_keyswitch_add_rescale), the last limb L. Rescale needs the coefficients of c_L = (acc_L - NTT(ext_L)) / P + add_L:
+// by linearity InvNTT(acc_L / P + add_L) - ext_L / P, ext_L being the coefficient-domain extension the y_i / v rows give. hc_k_mdrs_prep: acc_L <- acc_L / P + add_L in
+// place (NTT domain; row L of acc is scratch from here on); hc_k_mdrs_last: t = u - ext_L / P over the inverse transform u of that row (tu[z][t_rows][N], row 0).
+// blockIdx.y = component + 2 * image. grid = (64, 2 * images)
+__global__ __launch_bounds__(HC_TPB) void hc_k_mdrs_prep(u64 *acc, size_t acc_zs, size_t acc_is, const u64 *add, size_t add_zs, size_t add_is, int L, const HcTw *pinv, const HcMod *mods) {
+    const int zi = (int)blockIdx.y & 1, img = (int)blockIdx.y >> 1;
+    u64 *row = acc + (size_t)zi * acc_zs + (size_t)img * acc_is + (size_t)L * 65536;
+    const u64 *a = add != nullptr ? add + (size_t)zi * add_zs + (size_t)img * add_is + (size_t)L * 65536 : nullptr;
+    const u64 q = mods[L].q; const HcTw w = pinv[L];
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        u64 r = hc_mul_shoup(row[j], w.w, w.ws, q);
+        if (a != nullptr) r = hc_addmod(r, a[j], q);
+        row[j] = r;
+    }
+}
+__global__ __launch_bounds__(HC_TPB) void hc_k_mdrs_last(u64 *tu, int t_rows, const u64 *yv, int yv_rows, const HcBasisExt *Bs, int L, const HcTw *pinv) {
+    const HcBasisExt &B = Bs[L]; const int n = B.n; const HcQ Q = hc_q(B.t); const HcTw w = pinv[L];
+    tu += (size_t)blockIdx.y * t_rows * 65536; yv += (size_t)blockIdx.y * yv_rows * 65536;
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        u64 y[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) if (i <= n) y[i] = yv[(size_t)i * 65536 + j];
+        tu[j] = hc_submod(tu[j], hc_mul_shoup(hc_basis_ext_sum(y, B, Q), w.w, w.ws, B.t), B.t);
+    }
 }
 // source side of the fast basis extension, once per coefficient: y_i = x_i (S/s_i)^-1 mod s_i for the n source limbs and the fp64 overflow count v = uint64(sum_i
 // float64(y_i) / float64(s_i)) (ring.reconstructRNS: the reference's expression, limb order) -> yv[z][yv_rows][N] (rows y_0..y_(n-1), then v). The target side - one lazy sum per

@@ -90,7 +90,7 @@ struct hc_ctx {
     HcRowMod *d_rowmods = nullptr;                          // per modulus: both twiddle tables + q, mu (multi-modulus batched transforms)
     u64 *ws_mm = nullptr; size_t ws_mm_rows = 0;            // scratch of the batched key switch / rescale
     u64 *ws_accm = nullptr; size_t ws_accm_rows = 0;        // inner products of several hoisted rotations (hc_keyswitch_qp_rotate_many)
-    struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr; };
+    struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr, *pmod = nullptr, *pinv_qlinv = nullptr; };     // pmod: P mod q_i; pinv_qlinv: (P q_level)^-1 mod q_i, i < level
     std::map<int, KsPlan> ks_plan;                          // per level: basis-extension constants of every (digit, target limb)
     std::map<int, HcTw *> rescale_plan;                     // per level: qL^-1 mod q_i
     int nb = 1; size_t bs_poly = 0, bs_qp = 0;              // image batch of the leveled entry points (hc_set_batch): images, words between the images of a polynomial / of an extended-basis pair
@@ -341,7 +341,7 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
     if (c->ev_shard) D(hipEventDestroy(c->ev_shard), "hipEventDestroy");
     F(c->enc_roots); F(c->enc_rot_group);
     F(c->ws_ctc); F(c->ws_tmp); F(c->d_mods); F(c->d_rowmods); F(c->ws_mm); F(c->ws_accm);
-    for (auto &kv : c->ks_plan) { F(kv.second.bx); F(kv.second.bxdown); F(kv.second.pinv); }
+    for (auto &kv : c->ks_plan) { F(kv.second.bx); F(kv.second.bxdown); F(kv.second.pinv); F(kv.second.pmod); F(kv.second.pinv_qlinv); }
     for (auto &kv : c->rescale_plan) F(kv.second);
     F(c->d_csts);
     if (c->t0) D(hipEventDestroy(c->t0), "hipEventDestroy");
@@ -538,7 +538,8 @@ extern "C" int hc_lv_mul_const(hc_ctx *c, int level, const uint64_t *a, const ui
 extern "C" int hc_lv_add_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_ADDC>(c, "hc_lv_add_const", level, a, nullptr, out, consts); }
 // batched transforms over rows of different moduli (row y <-> modulus y < nl ? y : nq + y - nl); z operands zs words apart, n images is words apart.
 // fuse: optional prologue of the first pass (lift_level: Rescale's lift of t, see HcMm) and epilogue of the second (epi_x: (x - result) * epi_mul (+ epi_add))
-struct HcMmFuse { const HcBasisExt *ext_bs = nullptr; int ext_rows = 0; int lift_level = 0; const u64 *epi_x = nullptr; size_t epi_x_zs = 0, epi_x_is = 0; const HcTw *epi_mul = nullptr; const u64 *epi_add = nullptr; size_t epi_add_zs = 0, epi_add_is = 0; };
+struct HcMmFuse { const HcBasisExt *ext_bs = nullptr; int ext_rows = 0; int lift_level = 0; const u64 *epi_x = nullptr; size_t epi_x_zs = 0, epi_x_is = 0; const HcTw *epi_mul = nullptr; const u64 *epi_add = nullptr; size_t epi_add_zs = 0, epi_add_is = 0;
+                  const u64 *lift_t = nullptr; size_t lift_t_zs = 0, lift_t_is = 0; const HcTw *lift_pmul = nullptr, *epi_add_mul = nullptr; };      // lift_t: ModDown + Rescale in one transform (HcMm)
 static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0, int n = 1, size_t is_in = 0, size_t is_out = 0, const char *tag = "ntt",
                      const HcMmFuse *fuse = nullptr) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
@@ -549,12 +550,14 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
     for (int y = 0; y < rows; y++) A.rowlist[y] = (unsigned char)y;
     const dim3 grid(16, (unsigned)rows, (unsigned)(z * n));
     A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it;
-    if (fuse && fuse->lift_level > 0) { A.lift_level = fuse->lift_level; A.zs_in = (size_t)HC_N; A.is_in = (size_t)z * HC_N; }
+    if (fuse && fuse->lift_level > 0) { A.lift_level = fuse->lift_level; if (!fuse->lift_t) { A.zs_in = (size_t)HC_N; A.is_in = (size_t)z * HC_N; } }
     if (fuse && fuse->ext_bs) { A.ext_bs = fuse->ext_bs; A.ext_rows = fuse->ext_rows; }
-    if (A.ext_bs) HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<true>, grid, in, c->ws_tmp, A));
-    else HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<false>, grid, in, c->ws_tmp, A));
-    A.lift_level = 0; A.ext_bs = nullptr; A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out;
-    if (fuse && fuse->epi_x) { A.epi_x = fuse->epi_x; A.epi_x_zs = fuse->epi_x_zs; A.epi_x_is = fuse->epi_x_is; A.epi_mul = fuse->epi_mul; A.epi_add = fuse->epi_add; A.epi_add_zs = fuse->epi_add_zs; A.epi_add_is = fuse->epi_add_is; }
+    if (fuse && fuse->lift_t) { A.lift_t = fuse->lift_t; A.lift_t_zs = fuse->lift_t_zs; A.lift_t_is = fuse->lift_t_is; A.lift_pmul = fuse->lift_pmul; }
+    if (A.ext_bs && A.lift_t) HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<2>, grid, in, c->ws_tmp, A));
+    else if (A.ext_bs) HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<1>, grid, in, c->ws_tmp, A));
+    else HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<0>, grid, in, c->ws_tmp, A));
+    A.lift_level = 0; A.ext_bs = nullptr; A.lift_t = nullptr; A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out;
+    if (fuse && fuse->epi_x) { A.epi_x = fuse->epi_x; A.epi_x_zs = fuse->epi_x_zs; A.epi_x_is = fuse->epi_x_is; A.epi_mul = fuse->epi_mul; A.epi_add = fuse->epi_add; A.epi_add_zs = fuse->epi_add_zs; A.epi_add_is = fuse->epi_add_is; A.epi_add_mul = fuse->epi_add_mul; }
     HC_TRY(hc_launch(c, c->profile ? n2 : "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
@@ -698,6 +701,20 @@ static int hc_loopA_run(hc_ctx *c, const u64 *ker, int max_ob, int norm, u64 *ct
     return hc_loopA_run_set(c, hc_ptrs1(ker), 1, 0, norm, max_ob / norm, cts, 0, false);   // channels i % norm == 0 (conv.go:526)
 }
 
+// qL^-1 mod q_i, i < level, built once per level
+static int hc_rescale_plan(hc_ctx *c, int level, const HcTw **out) {
+    auto it = c->rescale_plan.find(level);
+    if (it == c->rescale_plan.end()) {
+        const u64 qL = c->mods[(size_t)level].m.q;
+        std::vector<HcTw> h((size_t)level);
+        for (int i = 0; i < level; i++) { const u64 q = c->mods[(size_t)i].m.q; h[(size_t)i] = h_pair(h_inv(qL % q, q), q); }
+        HcTw *d = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&d, h.size() * sizeof(HcTw)));
+        HC_HIP(c, hcx_h2d(c, d, h.data(), h.size() * sizeof(HcTw)));
+        it = c->rescale_plan.emplace(level, d).first;
+    }
+    *out = it->second;
+    return HC_OK;
+}
 // hc_div_round_last (level 1 only on this path): reuse loop A with ker = Montgomery one (c' (*) R = c')
 static int hc_div_round_last_n(hc_ctx *c, int level, const u64 *x, size_t xs, u64 *out, size_t os, int np) {
     if (level < 1 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "hc_div_round_last: level %d outside 1..%d", level, c->nq - 1);
@@ -705,15 +722,7 @@ static int hc_div_round_last_n(hc_ctx *c, int level, const u64 *x, size_t xs, u6
     if (level != 1) {
         // general level (the leveled evaluator of the convReLU chain): InvNTT of the last limb, centred lift into every lower
         // modulus, NTT there, subtract, multiply by qL^-1 -- six launches whatever the level. in == out is allowed.
-        const u64 qL = c->mods[(size_t)level].m.q;
-        auto it = c->rescale_plan.find(level);
-        if (it == c->rescale_plan.end()) {
-            std::vector<HcTw> h((size_t)level);
-            for (int i = 0; i < level; i++) { const u64 q = c->mods[(size_t)i].m.q; h[(size_t)i] = h_pair(h_inv(qL % q, q), q); }
-            HcTw *d = nullptr; HC_HIP(c, hcx_malloc(c, (void **)&d, h.size() * sizeof(HcTw)));
-            HC_HIP(c, hcx_h2d(c, d, h.data(), h.size() * sizeof(HcTw)));
-            it = c->rescale_plan.emplace(level, d).first;
-        }
+        const HcTw *qlinv; HC_TRY(hc_rescale_plan(c, level, &qlinv));
         // np polynomials of each of the nb images per launch (blockIdx.z): x, x + xs and out, out + os (distances in words, modulo 2^64); images bs_poly apart
         const int nb = c->nb, nz = np * nb;
         HC_TRY(hc_ensure_mm(c, (size_t)nz * (level + 1)));
@@ -723,7 +732,7 @@ static int hc_div_round_last_n(hc_ctx *c, int level, const u64 *x, size_t xs, u6
         HC_TRY(hc_intt_mm(c, x, t - (size_t)level * HC_N, level + 1, level + 1, np, xs, (size_t)HC_N, 0, level, nb, c->bs_poly, (size_t)np * HC_N, "rescale"));
         // the lift of t into every lower modulus happens where the forward transform reads its input, (x - NTT(lift)) / q_L where it writes its output: two launches,
         // x read once, the result written once (round 3: lift, two transform passes over a scratch, a finishing pass)
-        HcMmFuse F; F.lift_level = level; F.epi_x = x; F.epi_x_zs = xs; F.epi_x_is = c->bs_poly; F.epi_mul = it->second;
+        HcMmFuse F; F.lift_level = level; F.epi_x = x; F.epi_x_zs = xs; F.epi_x_is = c->bs_poly; F.epi_mul = qlinv;
         return hc_ntt_mm(c, t, out, level, level, 0, 0, np, (size_t)HC_N, os, 0, nb, (size_t)np * HC_N, c->bs_poly, "rescale", &F);
     }
     if (c->nb > 1) {           // level 1 in a batch: image by image through the fused level-1 path below (not on the batched chain's route: its rescales end at level 1)
@@ -1161,7 +1170,8 @@ static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
     auto pit = c->ks_plan.find(level);
     if (pit == c->ks_plan.end()) {
-        std::vector<HcBasisExt> hb((size_t)beta * nt), hd((size_t)nl); std::vector<HcTw> hp((size_t)nl);
+        std::vector<HcBasisExt> hb((size_t)beta * nt), hd((size_t)nl); std::vector<HcTw> hp((size_t)nl), hpm((size_t)nl), hpq((size_t)nl);
+        const u64 qL = c->mods[(size_t)level].m.q;
         auto modq = [&](int T) { return c->mods[(size_t)(T < nl ? T : c->nq + (T - nl))].m.q; };
         for (int d = 0; d < beta; d++) {
             const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl;
@@ -1172,24 +1182,27 @@ static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
         for (int l = 0; l < nl; l++) {
             const u64 q = c->mods[(size_t)l].m.q; u64 pmod = 1; for (u64 pj : psrc) pmod = h_mulmod(pmod, pj % q, q);
             hd[(size_t)l] = hc_make_bx(psrc, q); hp[(size_t)l] = h_pair(h_inv(pmod, q), q);
+            hpm[(size_t)l] = h_pair(pmod, q); hpq[(size_t)l] = l < level ? h_pair(h_inv(h_mulmod(pmod, qL % q, q), q), q) : h_pair(0, q);
         }
         hc_ctx::KsPlan P;
         HC_HIP(c, hcx_malloc(c, (void **)&P.bx, hb.size() * sizeof(HcBasisExt))); HC_HIP(c, hcx_malloc(c, (void **)&P.bxdown, hd.size() * sizeof(HcBasisExt))); HC_HIP(c, hcx_malloc(c, (void **)&P.pinv, hp.size() * sizeof(HcTw)));
         HC_HIP(c, hcx_h2d(c, P.bx, hb.data(), hb.size() * sizeof(HcBasisExt)));
         HC_HIP(c, hcx_h2d(c, P.bxdown, hd.data(), hd.size() * sizeof(HcBasisExt)));
         HC_HIP(c, hcx_h2d(c, P.pinv, hp.data(), hp.size() * sizeof(HcTw)));
+        HC_HIP(c, hcx_malloc(c, (void **)&P.pmod, hpm.size() * sizeof(HcTw))); HC_HIP(c, hcx_malloc(c, (void **)&P.pinv_qlinv, hpq.size() * sizeof(HcTw)));
+        HC_HIP(c, hcx_h2d(c, P.pmod, hpm.data(), hpm.size() * sizeof(HcTw))); HC_HIP(c, hcx_h2d(c, P.pinv_qlinv, hpq.data(), hpq.size() * sizeof(HcTw)));
         pit = c->ks_plan.emplace(level, P).first;
     }
     *out = &pit->second;
     return HC_OK;
 }
-// scratch of one key switch at `level` for the nb images of the batch, section-major: coef[img][nl] | digits[img][beta][nt] | acc[img][2][nt] | pc[img][2][alpha] | ext[img][2][nl] | yv[img][max(beta, 2)][alpha + 1]
+// scratch of one key switch at `level` for the nb images of the batch, section-major: coef[img][nl] | digits[img][beta][nt] | acc[img][2][nt] | pc[img][2][alpha + 1] | ext[img][2][nl] | yv[img][max(beta, 2)][alpha + 1]
 struct HcKsScratch { u64 *coef, *digits, *acc, *pc, *ext, *yv; size_t coef_is, digits_is, acc_is, pc_is, ext_is; };
 static int hc_ks_scratch(hc_ctx *c, int level, HcKsScratch *S) {
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha; const size_t nb = (size_t)c->nb;
-    S->coef_is = (size_t)nl * HC_N; S->digits_is = (size_t)beta * nt * HC_N; S->acc_is = (size_t)2 * nt * HC_N; S->pc_is = (size_t)2 * alpha * HC_N; S->ext_is = (size_t)2 * nl * HC_N;
+    S->coef_is = (size_t)nl * HC_N; S->digits_is = (size_t)beta * nt * HC_N; S->acc_is = (size_t)2 * nt * HC_N; S->pc_is = (size_t)2 * (alpha + 1) * HC_N; S->ext_is = (size_t)2 * nl * HC_N;
     const size_t yv_rows = (size_t)(beta > 2 ? beta : 2) * (alpha + 1);                // y_i / v rows of the decomposition's digits, later of ModDown's two polynomials
-    HC_TRY(hc_ensure_mm(c, nb * ((size_t)nl + (size_t)beta * nt + 2 * nt + 2 * alpha + 2 * nl + yv_rows)));
+    HC_TRY(hc_ensure_mm(c, nb * ((size_t)nl + (size_t)beta * nt + 2 * nt + 2 * (alpha + 1) + 2 * nl + yv_rows)));
     S->coef = c->ws_mm; S->digits = S->coef + nb * S->coef_is; S->acc = S->digits + nb * S->digits_is; S->pc = S->acc + nb * S->acc_is; S->ext = S->pc + nb * S->pc_is; S->yv = S->ext + nb * S->ext_is;
     return HC_OK;
 }
@@ -1231,6 +1244,26 @@ static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, size_t acc_is, co
     if (add0) { F.epi_add = add0; F.epi_add_zs = (size_t)(add1 - add0); F.epi_add_is = c->bs_poly; }
     return hc_ntt_mm(c, S.yv, d0, nl, nl, 0, 0, 2, yz, (size_t)(d1 - d0), 0, nb, 2 * yz, c->bs_poly, "moddown", &F);
 }
+// ModDownSplitNTTPQ and the DivRoundByLastModulusNTT behind it as ONE forward transform per limb (relinearisation followed by Rescale: most multiplications of the
+// sine and the ReLU polynomials): d_k = Rescale((acc_k - NTT(ext_k)) / P + add_k), level -> level - 1. Both steps subtract a forward transform from the same limb:
+// (x - NTT(ext)) / P + add - NTT(lift), all / q_L, = (x - NTT(ext + P lift)) / (P q_L) + add / q_L, exactly (modular arithmetic, canonical residues: the bits of the
+// two-step route). The lift needs the last limb's coefficients after ModDown: InvNTT(acc_L / P + add_L) - ext_L / P, the inverse transform riding with the P rows'.
+// acc's row `level` is overwritten.
+static int hc_ks_moddown_rescale(hc_ctx *c, int level, u64 *acc, size_t acc_is, const HcKsScratch &S, u64 *d0, u64 *d1, const u64 *add0, const u64 *add1) {
+    const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
+    const HcTw *qlinv; HC_TRY(hc_rescale_plan(c, level, &qlinv));
+    const int alpha = c->np, nl = level + 1, nt = nl + alpha, nb = c->nb;
+    const size_t tz = (size_t)(alpha + 1) * HC_N, yz = tz;
+    HC_TRY(hc_launch(c, "moddown:mdrs_prep", hc_k_mdrs_prep, dim3(64, 2u * (unsigned)nb), acc, (size_t)nt * HC_N, acc_is, add0, add0 ? (size_t)(add1 - add0) : (size_t)0, c->bs_poly, level, (const HcTw *)P->pinv, (const HcMod *)c->d_mods));
+    // InvNTT of row `level` and of the P rows of both components in one pair of launches: pc[z] = [u | the alpha P rows]
+    HC_TRY(hc_intt_mm(c, acc, S.pc - (size_t)level * HC_N, nt, nl, 2, (size_t)nt * HC_N, tz, 0, level, nb, acc_is, S.pc_is, "moddown"));
+    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(64, 2u * (unsigned)nb), (const u64 *)(S.pc + HC_N), (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, tz, 0, 2, S.pc_is));
+    HC_TRY(hc_launch(c, "moddown:mdrs_last", hc_k_mdrs_last, dim3(64, 2u * (unsigned)nb), S.pc, alpha + 1, (const u64 *)S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, level, (const HcTw *)P->pinv));
+    HcMmFuse F; F.ext_bs = P->bxdown; F.ext_rows = nl; F.lift_level = level; F.lift_t = S.pc; F.lift_t_zs = tz; F.lift_t_is = S.pc_is; F.lift_pmul = P->pmod;
+    F.epi_x = acc; F.epi_x_zs = (size_t)nt * HC_N; F.epi_x_is = acc_is; F.epi_mul = P->pinv_qlinv;
+    if (add0) { F.epi_add = add0; F.epi_add_zs = (size_t)(add1 - add0); F.epi_add_is = c->bs_poly; F.epi_add_mul = qlinv; }
+    return hc_ntt_mm(c, S.yv, d0, level, level, 0, 0, 2, yz, (size_t)(d1 - d0), 0, nb, 2 * yz, c->bs_poly, "moddown", &F);
+}
 // phase 2: inner product with the key (both components), then ModDownSplitNTTPQ
 static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *d0, u64 *d1, uint64_t rot_gal = 0, const u64 *rot_c0 = nullptr, const u64 *add0 = nullptr, const u64 *add1 = nullptr) {
     HC_TRY(hc_ks_mac(c, key, level, cx, S, S.acc, S.acc_is));
@@ -1261,6 +1294,19 @@ extern "C" int hc_keyswitch_add(hc_ctx *c, uint64_t key_id, int level, const uin
     HC_TRY(hc_ks_decompose_into(c, level, cx, S));
     c->hoist_cx = nullptr;
     return hc_ks_apply_from(c, *key, level, cx, S, (u64 *)out0, (u64 *)out1, 0, nullptr, (const u64 *)a0, (const u64 *)a1);
+}
+// hc_keyswitch_add followed by one hc_div_round_last2, as one call: out_k = Rescale(a_k + (key switch of cx)_k) at level - 1 (level >= 2). ModDown and the rescale share
+// one forward transform per limb (hc_ks_moddown_rescale); the residues are those of the two calls. out may be a.
+extern "C" int hc_keyswitch_add_rescale(hc_ctx *c, uint64_t key_id, int level, const uint64_t *cx, const uint64_t *a0, const uint64_t *a1, uint64_t *out0, uint64_t *out1) {
+    HC_ENTER(c);
+    const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_add_rescale", key_id, level, &key));
+    if (!cx || !a0 || !a1 || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_add_rescale: null");
+    if (level < 2) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_add_rescale: level %d: the fused rescale needs level >= 2 (use hc_keyswitch_add and hc_div_round_last2)", level);
+    HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
+    HC_TRY(hc_ks_decompose_into(c, level, cx, S));
+    c->hoist_cx = nullptr;
+    HC_TRY(hc_ks_mac(c, *key, level, cx, S, S.acc, S.acc_is));
+    return hc_ks_moddown_rescale(c, level, S.acc, S.acc_is, S, (u64 *)out0, (u64 *)out1, (const u64 *)a0, (const u64 *)a1);
 }
 // Hoisted key switching (evaluator.RotateHoisted, conv.go:131; the baby steps of a linear transform): the decomposition of cx is
 // computed once and kept in the context; every hc_keyswitch_hoisted with the same (cx, level) then only does the inner product with

@@ -312,6 +312,17 @@ struct Boot {
         HCR(hc_keyswitch_add(hc, key(0, L), L, d2.get(), r.p[0].get(), d1.get(), r.p[0].get(), r.p[1].get())); n_keyswitch++;      // (d0 + ks0, d1 + ks1) inside ModDown's last pass
         return r;
     }
+    // MulRelin followed by one Rescale: the key switch's ModDown and the rescale share one forward transform per limb (hc_keyswitch_add_rescale); the residues of the two steps
+    DCt mul_relin_rescale(const DCt &a, const DCt &b) {
+        const int L = std::min(a.level, b.level);
+        static const bool split = getenv("HCONV_NO_FUSED_RESCALE") != nullptr;
+        if (L < 2 || split) return rescale(mul_relin(a, b));
+        DCt r = new_ct(L - 1, 1, a.scale * b.scale / (double)Q[(size_t)L]); alg_ct += 6.0 * (L + 1) + 2.0 * (2 * L + 1); alg_shared += ks_rows(L);
+        auto d0 = block(), d1 = block(), d2 = block();
+        HCR(hc_lv_mul_tensor(hc, L, a.p[0].get(), a.p[1].get(), b.p[0].get(), b.p[1].get(), d0.get(), d1.get(), d2.get()));
+        HCR(hc_keyswitch_add_rescale(hc, key(0, L), L, d2.get(), d0.get(), d1.get(), r.p[0].get(), r.p[1].get())); n_keyswitch++;
+        return r;
+    }
     DCt rescale(const DCt &a) {                                     // one DivRoundByLastModulusNTT
         if (a.level < 1) panic("rescale at level 0");
         DCt r = new_ct(a.level - 1, a.deg, a.scale / (double)Q[(size_t)a.level]); alg_ct += (double)(a.deg + 1) * (2 * a.level + 1);
@@ -676,7 +687,7 @@ struct Boot {
             auto it = T.find(i); if (it != T.end()) return it->second;
             const int a = (i + 1) / 2, b = i / 2;
             DCt A = power(a), Bc = power(b);
-            DCt t = B->rescale(B->mul_relin(A, Bc));
+            DCt t = B->mul_relin_rescale(A, Bc);
             if (cheby) {
                 t = B->add(t, t);
                 const int c = a - b;
@@ -728,7 +739,7 @@ struct Boot {
             const int lq = plan_level(cq, log_split, lead), lmul = std::min(lq, Xg.level);
             DCt resq = rec(cq, log_split, lead, target * (double)B->Q[(size_t)lmul] / Xg.scale);
             if (resq.level != lq) panic("polynomial evaluation: planned level differs");
-            DCt prod = relabel(B->rescale(B->mul_relin(resq, Xg)), target);
+            DCt prod = relabel(B->mul_relin_rescale(resq, Xg), target);
             bool rnz = false; for (double v : cr) if (v != 0) rnz = true;
             if (rnz) prod = B->add(prod, rec(cr, log_split, false, target));
             return prod;
@@ -742,6 +753,11 @@ struct Boot {
     // ciphertext digest the reference binary produced for these polynomials (tests/test_oracle_pin_poly.py, gotrace -poly).
     struct LPoly { std::vector<double> c; int max_deg; bool lead; int degree() const { return (int)c.size() - 1; } };
     DCt lt_rescale(DCt a, double min_scale) { while (a.level > 0 && a.scale / (double)Q[(size_t)a.level] >= min_scale / 2) a = rescale(a); return a; }   // ckks Rescale's drop rule
+    DCt mul_relin_lt_rescale(const DCt &a, const DCt &b, double min_scale) {                          // lt_rescale(mul_relin(a, b)), the first drop inside the key switch
+        const int L = std::min(a.level, b.level);
+        if (L > 0 && a.scale * b.scale / (double)Q[(size_t)L] >= min_scale / 2) return lt_rescale(mul_relin_rescale(a, b), min_scale);
+        return mul_relin(a, b);
+    }
     DCt lt_add(const DCt &a, const DCt &b) {                           // evaluateInPlace: uint64(ratio) * the smaller-scale operand
         if (a.scale > b.scale) { const double k = floor(a.scale / b.scale); DCt bb = k > 1 ? mul_const_int(b, k) : b; bb.scale = a.scale; return add(a, bb); }
         if (b.scale > a.scale) { const double k = floor(b.scale / a.scale); DCt aa = k > 1 ? mul_const_int(a, k) : a; aa.scale = b.scale; return add(aa, b); }
@@ -751,7 +767,7 @@ struct Boot {
         if (C.count(n)) return;
         const int a = (n + 1) / 2, b = n >> 1;
         lt_power(C, a, sc); lt_power(C, b, sc);
-        C[n] = lt_rescale(mul_relin(C[a], C[b]), sc);
+        C[n] = mul_relin_lt_rescale(C[a], C[b], sc);
     }
     DCt lt_leaf(double target, const LPoly &p, std::map<int, DCt> &C, double sc) {
         if (p.degree() == 0) panic("EvaluatePoly: constant leaf (not produced by the sign polynomials)");
@@ -777,9 +793,8 @@ struct Boot {
         DCt res = lt_recurse(target * (double)Q[(size_t)level] / C[next_power].scale, log_split, log_degree, pq, C, sc);
         DCt tmp = lt_recurse(target, log_split, log_degree, pr, C, sc);
         if (res.level > tmp.level) res = drop_to(res, tmp.level + 1);                                     // DropLevel
-        res = mul_relin(res, C[next_power]);
-        if (res.level > tmp.level) { res = lt_rescale(res, sc); res = lt_add(res, tmp); }
-        else { res = lt_add(res, tmp); res = lt_rescale(res, sc); }
+        if (std::min(res.level, C[next_power].level) > tmp.level) { res = mul_relin_lt_rescale(res, C[next_power], sc); res = lt_add(res, tmp); }
+        else { res = mul_relin(res, C[next_power]); res = lt_add(res, tmp); res = lt_rescale(res, sc); }
         return res;
     }
     // ---- the Chebyshev basis of the same evaluator (EvaluateCheby @52d7c0: computePowerBasisCheby, splitCoeffsCheby, recurseCheby; the leaf is
@@ -794,7 +809,7 @@ struct Boot {
         if (C.count(n)) return;
         const int a = (n + 1) / 2, b = n >> 1, c = a - b;
         lt_power_cheby(C, a, sc); lt_power_cheby(C, b, sc); if (c) lt_power_cheby(C, c, sc);
-        DCt t = lt_rescale(mul_relin(C[a], C[b]), sc);
+        DCt t = mul_relin_lt_rescale(C[a], C[b], sc);
         // 2 t - 1 (AddConst: floor(|scale| + 0.5)) or 2 t - C[c] (evaluateInPlace's Sub: the smaller-scale operand times uint64(ratio)) as ONE launch: the residues of Add(t, t)
         // followed by AddConst / Sub, without their passes over the ciphertext
         if (c == 0) C[n] = lincomb({t}, {2.0}, t.level, t.scale, true, -floor(fabs(t.scale) + 0.5));
@@ -833,9 +848,8 @@ struct Boot {
         DCt res = lt_recurse_cheby(target * (double)Q[(size_t)level] / C[next_power].scale, log_split, log_degree, pq, C, sc);
         DCt tmp = lt_recurse_cheby(target, log_split, log_degree, pr, C, sc);
         if (res.level > tmp.level) res = drop_to(res, tmp.level + 1);
-        res = mul_relin(res, C[next_power]);
-        if (res.level > tmp.level) { res = lt_rescale(res, sc); res = lt_add(res, tmp); }
-        else { res = lt_add(res, tmp); res = lt_rescale(res, sc); }
+        if (std::min(res.level, C[next_power].level) > tmp.level) { res = mul_relin_lt_rescale(res, C[next_power], sc); res = lt_add(res, tmp); }
+        else { res = mul_relin(res, C[next_power]); res = lt_add(res, tmp); res = lt_rescale(res, sc); }
         return res;
     }
     DCt eval_cheby_lattigo(const DCt &ct, const std::vector<double> &coeffs, double target, double sc) {

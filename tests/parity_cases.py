@@ -519,6 +519,28 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
             want_ = np.stack([ctx.add(l, ks[k_][z].reshape(nl, N)[l], addend[z][l]).reshape(-1) for l in range(nl)]).reshape(-1)
             eq(ka[k_][z], want_, f"keyswitch_add == keyswitch + add (image {z}, polynomial {k_})")
 
+    # relinearisation and the Rescale behind it in one call == the two calls (ModDown and Rescale share one forward transform per limb)
+    def ks_add_then_rescale(x, p0, p1, o0, o1):
+        t0, t1 = ctx.buf(nwords=ctx_nb() * PS), ctx.buf(nwords=ctx_nb() * PS)
+        ck(L.hc_keyswitch_add(h, K0, level, x, p0, p1, t0.ptr, t1.ptr)); ck(L.hc_div_round_last2(h, level, t0.ptr, t1.ptr, o0, o1))
+        ctx.sync(); t0.free(); t1.free()
+    cur_nb = [1]
+    _sb = ctx.set_batch
+
+    def ctx_nb():
+        return cur_nb[0]
+
+    def set_batch_spy(nb_, *strides):
+        cur_nb[0] = nb_
+        return _sb(nb_, *strides)
+    ctx.set_batch = set_batch_spy
+    kr = run("keyswitch_add_rescale", lambda x, p0, p1, o0, o1: ck(L.hc_keyswitch_add_rescale(h, K0, level, x, p0, p1, o0, o1)), [(a, "p"), (b, "p"), (b1, "p")], [("p", level * N), ("p", level * N)])
+    kr2 = run("keyswitch_add + div_round_last2", ks_add_then_rescale, [(a, "p"), (b, "p"), (b1, "p")], [("p", level * N), ("p", level * N)])
+    ctx.set_batch = _sb
+    for k_ in range(2):
+        eq(kr[k_], kr2[k_], f"keyswitch_add_rescale == keyswitch_add + div_round_last2 (polynomial {k_})")
+        assert not (kr[k_] == 0x1234567).any(), "keyswitch_add_rescale left output words unwritten"
+
     def hoisted(x, d0, d1, e0, e1):
         ck(L.hc_keyswitch_decompose(h, level, x)); ck(L.hc_keyswitch_hoisted(h, K0, level, x, d0, d1)); ck(L.hc_keyswitch_hoisted(h, K1, level, x, e0, e1))
     hs = run("keyswitch_decompose + hoisted x2", hoisted, [(a, "p")], [("p", PW)] * 4)
