@@ -1354,6 +1354,7 @@ struct HcRowMod { HcTwTab fwd, inv; u64 q, mu; };
 // blockIdx.z = operand + nz * image: `nz` operands zs_* words apart (the two polynomials of a ciphertext, the digits of a key switch), and the
 // images of a batch (hc_set_batch) is_* words apart
 struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; int z_alpha; int nz; size_t is_in, is_out;
+              int xcd, nzn;                  // rows passes: XCD-aware 1-D grid over nzn = nz * images operands (HC_MM_PROLOGUE_ROWS)
               unsigned char rowlist[48];     // blockIdx.y -> row (rows a launch has nothing to do for are left out of the grid)
 
               // fused prologue of the cols-forward pass / epilogue of the rows-forward pass (0 = none):
@@ -1378,6 +1379,17 @@ __device__ __forceinline__ bool hc_mm_skip(const HcMm &A, int y, int zi) {
 __device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl ? y : A.nq + (y - A.nl); }
 #define HC_MM_PROLOGUE \
     const int y = A.rowlist[blockIdx.y], zi = (int)blockIdx.z % A.nz, img = (int)blockIdx.z / A.nz; if (hc_mm_skip(A, y, zi)) return; \
+    const HcRowMod &R = A.M[hc_mm_mod(A, y)]; \
+    in += (size_t)zi * A.zs_in + (size_t)img * A.is_in; out += (size_t)zi * A.zs_out + (size_t)img * A.is_out;
+// The rows passes read PER-ROW twiddles: 255 (w, w') pairs = 4 KB for every 2 KB row of data, the same for every operand and image of the launch. With the operand index in
+// blockIdx.z the workgroups sharing a twiddle slice were a whole (tiles x rows) sweep apart and, consecutive workgroup ids going round-robin over the 8 XCDs, on different L2s:
+// the tables came over the fabric once per operand (measured, rocprofv3 FETCH_SIZE: 1.1-1.9 MB fetched per 0.5 MB row written). A 1-D grid decoded as
+// id = xcd + 8 * (operand + nzn * group), (tile, row) = 8 * group + xcd, keeps all operands of one (tile, row) on ONE XCD, back to back: the slice is fetched once per launch.
+#define HC_MM_PROLOGUE_ROWS \
+    int bx, by_, bz_; \
+    if (A.xcd) { const unsigned id = blockIdx.x, rest = id >> 3, p = (rest / (unsigned)A.nzn) * 8 + (id & 7); bx = (int)(p & 15); by_ = (int)(p >> 4); bz_ = (int)(rest % (unsigned)A.nzn); } \
+    else { bx = (int)blockIdx.x; by_ = (int)blockIdx.y; bz_ = (int)blockIdx.z; } \
+    const int y = A.rowlist[by_], zi = bz_ % A.nz, img = bz_ / A.nz; if (hc_mm_skip(A, y, zi)) return; \
     const HcRowMod &R = A.M[hc_mm_mod(A, y)]; \
     in += (size_t)zi * A.zs_in + (size_t)img * A.is_in; out += (size_t)zi * A.zs_out + (size_t)img * A.is_out;
 // (Round 4, measured and not kept - profiles/round4_chain_class_paths_ab.txt: butterflies per modulus class inside these kernels - 32-bit canonical arithmetic for the
@@ -1417,8 +1429,8 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd_mm(const u64 *in, u64 *o
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_ROWS_LDS];
-    HC_MM_PROLOGUE
-    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
+    HC_MM_PROLOGUE_ROWS
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = bx * 16 + rloc;
     const size_t pbase = (size_t)y * 65536;
     u64 e[16];
 #pragma unroll
@@ -1429,7 +1441,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, 
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
     for (int k = 0; k < 16; k++) e[k] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu);
-    const size_t lin = pbase + (size_t)(blockIdx.x * 16) * 256 + t;
+    const size_t lin = pbase + (size_t)(bx * 16) * 256 + t;
     if (A.epi_x != nullptr) {                                                // block-uniform
         const u64 *x = A.epi_x + (size_t)zi * A.epi_x_zs + (size_t)img * A.epi_x_is + lin;
         const u64 *ad = A.epi_add != nullptr ? A.epi_add + (size_t)zi * A.epi_add_zs + (size_t)img * A.epi_add_is + lin : nullptr;
@@ -1447,12 +1459,12 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, 
 }
 __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ u64 lds[HC_ROWS_LDS];
-    HC_MM_PROLOGUE
-    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = blockIdx.x * 16 + rloc;
+    HC_MM_PROLOGUE_ROWS
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = bx * 16 + rloc;
     const size_t pbase = (size_t)y * 65536;
     u64 e[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) e[k] = in[pbase + (size_t)(blockIdx.x * 16 + k) * 256 + t];
+    for (int k = 0; k < 16; k++) e[k] = in[pbase + (size_t)(bx * 16 + k) * 256 + t];
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_inv(e, lds, R.inv, row, rloc, tid, hc_q(R.q));

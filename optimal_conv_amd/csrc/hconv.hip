@@ -102,6 +102,7 @@ struct hc_ctx {
     u64 *ws_gather = nullptr; size_t ws_gather_rows = 0;
     long small_levels = 16;               // pack-tree launches of at most this many nodes (summed over the batch) run on the 1024-thread S kernels; 0 = never
     long peer_access = 1;                 // hc_conv_then_pack_sharded: enable direct peer copies between distinct devices (0: leave the copies to hipMemcpyPeerAsync's staging)
+    int xcd_rows = getenv("HC_XCD_ROWS") ? atoi(getenv("HC_XCD_ROWS")) : 1;      // A/B switch of the XCD-aware rows-pass grid (HcMm::xcd)
     unsigned peer_warned = 0;             // bit d: enabling peer access to device d failed and was reported once
     unsigned peer_enabled = 0;            // bit d: peer access from this context's device to device d was enabled by (or found enabled for) this context
     long profile = 0;
@@ -558,7 +559,8 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
     else HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<0>, grid, in, c->ws_tmp, A));
     A.lift_level = 0; A.ext_bs = nullptr; A.lift_t = nullptr; A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out;
     if (fuse && fuse->epi_x) { A.epi_x = fuse->epi_x; A.epi_x_zs = fuse->epi_x_zs; A.epi_x_is = fuse->epi_x_is; A.epi_mul = fuse->epi_mul; A.epi_add = fuse->epi_add; A.epi_add_zs = fuse->epi_add_zs; A.epi_add_is = fuse->epi_add_is; A.epi_add_mul = fuse->epi_add_mul; }
-    HC_TRY(hc_launch(c, c->profile ? n2 : "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
+    A.xcd = c->xcd_rows; A.nzn = z * n;
+    HC_TRY(hc_launch(c, c->profile ? n2 : "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, A.xcd ? dim3(16u * (unsigned)rows * (unsigned)(z * n)) : grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
 static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out, int skip_lo = 0, int skip_hi = 0, int n = 1, size_t is_in = 0, size_t is_out = 0, const char *tag = "intt") {
@@ -570,7 +572,9 @@ static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int 
     int cnt = 0;                                           // rows in [skip_lo, skip_hi) have nothing to do: not in the grid
     for (int y = 0; y < rows; y++) if (!(y >= skip_lo && y < skip_hi)) A.rowlist[cnt++] = (unsigned char)y;
     const dim3 grid(16, (unsigned)cnt, (unsigned)(z * n));
-    A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; HC_TRY(hc_launch(c, c->profile ? n1 : "rows_inv_mm", hc_k_rows_inv_mm, grid, in, c->ws_tmp, A));
+    A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; A.xcd = c->xcd_rows; A.nzn = z * n;
+    HC_TRY(hc_launch(c, c->profile ? n1 : "rows_inv_mm", hc_k_rows_inv_mm, A.xcd ? dim3(16u * (unsigned)cnt * (unsigned)(z * n)) : grid, in, c->ws_tmp, A));
+    A.xcd = 0;
     A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out; HC_TRY(hc_launch(c, c->profile ? n2 : "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }

@@ -763,6 +763,20 @@ struct Boot {
         if (b.scale > a.scale) { const double k = floor(b.scale / a.scale); DCt aa = k > 1 ? mul_const_int(a, k) : a; aa.scale = b.scale; return add(aa, b); }
         return add(a, b);
     }
+    // lt_rescale(lt_add(mul_relin(a, b), tmp), sc) with the first drop inside the key switch: tmp (times evaluateInPlace's integer ratio) joins d0, d1 before the relinearisation
+    DCt mul_relin_add_lt_rescale(const DCt &a, const DCt &b, const DCt &tmp, double sc) {
+        const int L = std::min(a.level, b.level); const double ps = a.scale * b.scale;
+        static const bool split = getenv("HCONV_NO_FUSED_RESCALE") != nullptr;
+        if (split || L < 2 || tmp.level < L || tmp.deg != 1 || ps < tmp.scale || !(ps / (double)Q[(size_t)L] >= sc / 2)) return lt_rescale(lt_add(mul_relin(a, b), tmp), sc);
+        const double k = ps > tmp.scale ? floor(ps / tmp.scale) : 1.0;
+        const DCt bb = k > 1 ? mul_const_int(tmp, k) : tmp;
+        DCt r = new_ct(L - 1, 1, ps / (double)Q[(size_t)L]); alg_ct += 6.0 * (L + 1) + 6.0 * (L + 1) + 2.0 * (2 * L + 1); alg_shared += ks_rows(L);
+        auto d0 = block(), d1 = block(), d2 = block();
+        HCR(hc_lv_mul_tensor(hc, L, a.p[0].get(), a.p[1].get(), b.p[0].get(), b.p[1].get(), d0.get(), d1.get(), d2.get()));
+        HCR(hc_lv_op2(hc, HC_LV_ADD, L, d0.get(), d1.get(), bb.p[0].get(), bb.p[1].get(), d0.get(), d1.get(), nullptr));
+        HCR(hc_keyswitch_add_rescale(hc, key(0, L), L, d2.get(), d0.get(), d1.get(), r.p[0].get(), r.p[1].get())); n_keyswitch++;
+        return lt_rescale(r, sc);
+    }
     void lt_power(std::map<int, DCt> &C, int n, double sc) {
         if (C.count(n)) return;
         const int a = (n + 1) / 2, b = n >> 1;
@@ -794,7 +808,7 @@ struct Boot {
         DCt tmp = lt_recurse(target, log_split, log_degree, pr, C, sc);
         if (res.level > tmp.level) res = drop_to(res, tmp.level + 1);                                     // DropLevel
         if (std::min(res.level, C[next_power].level) > tmp.level) { res = mul_relin_lt_rescale(res, C[next_power], sc); res = lt_add(res, tmp); }
-        else { res = mul_relin(res, C[next_power]); res = lt_add(res, tmp); res = lt_rescale(res, sc); }
+        else res = mul_relin_add_lt_rescale(res, C[next_power], tmp, sc);
         return res;
     }
     // ---- the Chebyshev basis of the same evaluator (EvaluateCheby @52d7c0: computePowerBasisCheby, splitCoeffsCheby, recurseCheby; the leaf is
@@ -849,7 +863,7 @@ struct Boot {
         DCt tmp = lt_recurse_cheby(target, log_split, log_degree, pr, C, sc);
         if (res.level > tmp.level) res = drop_to(res, tmp.level + 1);
         if (std::min(res.level, C[next_power].level) > tmp.level) { res = mul_relin_lt_rescale(res, C[next_power], sc); res = lt_add(res, tmp); }
-        else { res = mul_relin(res, C[next_power]); res = lt_add(res, tmp); res = lt_rescale(res, sc); }
+        else res = mul_relin_add_lt_rescale(res, C[next_power], tmp, sc);
         return res;
     }
     DCt eval_cheby_lattigo(const DCt &ct, const std::vector<double> &coeffs, double target, double sc) {
