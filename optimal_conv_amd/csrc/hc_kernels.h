@@ -235,6 +235,74 @@ __device__ __forceinline__ void hc_rows_lo_to_lin(u64 (&e)[16], u64 *lds, int t,
     for (int k = 0; k < 16; k++) e[k] = lds[hc_rows_lds(k, t)];
 }
 
+// ---- the same exchanges through HALF the LDS (multi-modulus kernels of the chain): low words, then high words, over a 16 KiB tile of 4-byte words. 32 KiB per
+// 256-thread workgroup caps a CU at 5 workgroups = 5 wavefronts per SIMD; these kernels wait on memory two thirds of the time at VALU busy 0.4-0.5 (rocprofv3 SQ counters,
+// profiles/round4_chain_valu_table.txt), their 44-56 VGPRs would admit 8. The swizzles below are the 8-byte ones with one more row bit folded in: a ds_*_b32 is serviced
+// over 64 banks for all 64 lanes, and the four rows (rows passes) / four tids (cols passes) of a wavefront must land in four different 16-word groups.
+#ifndef HC_MM_LDS32
+#define HC_MM_LDS32 1
+#endif
+#ifndef HC_MM_WAVES
+#define HC_MM_WAVES 7                  // wavefronts per SIMD the multi-modulus transform kernels are compiled for (VGPR budget 512 / HC_MM_WAVES)
+#endif
+#ifndef HC_MM_WAVES_EXT
+#define HC_MM_WAVES_EXT 5              // the passes with the basis extension in their prologue: 96 VGPRs (a 80-register build spills 140 bytes and is slower)
+#endif
+// measured (convReLU 5 1 tail, 8 images, profiles/round4_chain_occupancy_ab.txt): 8-byte exchange / 5 waves 189.5 ms; 4-byte exchange at 6 / 6 waves 183.2, 7 / 5 waves 166.7,
+// 7 / 4 180.8, 8 / 6 193.0 (spills), 7 / 7 with two-element extension groups 169.6
+#if HC_MM_LDS32
+typedef u32 hc_mm_lds_t;
+#else
+typedef u64 hc_mm_lds_t;
+#endif
+__device__ __forceinline__ int hc_rows_lds32(int rloc, int col) {
+    return rloc * 256 + ((col & 0xF0) ^ ((rloc & 1) << 4) ^ ((rloc & 2) << 4)) + ((col & 15) ^ ((col >> 5) & 7) ^ ((rloc & 1) << 3));
+}
+__device__ __forceinline__ int hc_cols_lds32(int row, int c) { return ((row ^ ((row >> 4) & 3)) << 4) + c; }
+template <class WA, class RA, class SY>
+__device__ __forceinline__ void hc_xchg32(u64 (&e)[16], u32 *lds, WA wa, RA ra, SY sync) {
+    u32 lo[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) lds[wa(i)] = (u32)e[i];
+    sync();
+#pragma unroll
+    for (int i = 0; i < 16; i++) lo[i] = lds[ra(i)];
+    sync();                                                                  // every low word has been read before a high word lands on it
+#pragma unroll
+    for (int i = 0; i < 16; i++) lds[wa(i)] = (u32)(e[i] >> 32);
+    sync();
+#pragma unroll
+    for (int i = 0; i < 16; i++) e[i] = ((u64)lds[ra(i)] << 32) | lo[i];
+}
+template <int FM>
+__device__ __forceinline__ void hc_rows_fwd(u64 (&e)[16], u32 *lds, const HcTwTab &T, int row, int rloc, int tid, const HcQ &Q) {
+    hc_ct_round<FM>(e, HcRowsTwA{T.rowsA + row * 16}, Q);
+    hc_xchg32(e, lds, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [] { HC_ROW_SYNC(); });
+    hc_ct_round<FM>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, Q);
+}
+__device__ __forceinline__ void hc_rows_inv(u64 (&e)[16], u32 *lds, const HcTwTab &T, int row, int rloc, int tid, const HcQ &Q) {
+    hc_gs_round<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, Q, T.ninv, T.ninv);
+    hc_xchg32(e, lds, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [] { HC_ROW_SYNC(); });
+    hc_gs_round<false>(e, HcRowsTwA{T.rowsA + row * 16}, Q, T.ninv, T.ninv);
+}
+template <int FM>
+__device__ __forceinline__ void hc_cols_fwd(u64 (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, const HcQ &Q) {
+    hc_ct_round<FM>(e, HcRowsTwA{T.colsA}, Q);
+    hc_xchg32(e, lds, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [] { __syncthreads(); });
+    hc_ct_round<FM>(e, HcRowsTwB{T.colsB + tid}, Q);
+}
+__device__ __forceinline__ void hc_cols_inv(u64 (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, const HcQ &Q) {
+    hc_gs_round<false>(e, HcRowsTwB{T.colsB + tid}, Q, T.ninv, T.ninv);
+    hc_xchg32(e, lds, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [] { __syncthreads(); });
+    hc_gs_round<true>(e, HcRowsTwA{T.colsA}, Q, T.ninv, T.w_last_ninv);
+}
+__device__ __forceinline__ void hc_rows_lin_to_lo(u64 (&e)[16], u32 *lds, int t, int rloc, int tid) {
+    hc_xchg32(e, lds, [&](int k) { return hc_rows_lds32(k, t); }, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [] { __syncthreads(); });
+}
+__device__ __forceinline__ void hc_rows_lo_to_lin(u64 (&e)[16], u32 *lds, int t, int rloc, int tid) {
+    hc_xchg32(e, lds, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [&](int k) { return hc_rows_lds32(k, t); }, [] { __syncthreads(); });
+}
+
 // x mod q for x < 2^64 with mu = floor(2^64/q): result canonical
 __device__ __forceinline__ u64 hc_barrett64(u64 x, u64 q, u64 mu) {
     u64 r = x - hc_mulhi(x, mu) * q;   // in [0, 2q)
@@ -1396,8 +1464,8 @@ __device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl
 // chain's eleven ~30-bit limbs, the fold-free 64-bit form below 2^57 - as a block-uniform switch cost 108-132 VGPRs against 65-86 and only won the lost occupancy back;
 // as one launch per class they kept their registers but turned every pass into three short launches: 224 ms per 8-ciphertext layer against 203.)
 template <int EXT>      // EXT 1: the input is the fused basis extension; 2: the extension plus P times Rescale's lift (ModDown and Rescale in one transform)
-__global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd_mm(const u64 *in, u64 *out, HcMm A) {
-    __shared__ u64 lds[HC_COLS_LDS];
+__global__ __launch_bounds__(HC_TPB, EXT ? HC_MM_WAVES_EXT : HC_MM_WAVES) void hc_k_cols_fwd_mm(const u64 *in, u64 *out, HcMm A) {
+    __shared__ hc_mm_lds_t lds[HC_COLS_LDS];
     HC_MM_PROLOGUE
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
@@ -1427,8 +1495,8 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_cols_fwd_mm(const u64 *in, u64 *o
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) out[base + (size_t)(tid * 16 + lo) * 256] = e[lo];
 }
-__global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, u64 *out, HcMm A) {
-    __shared__ u64 lds[HC_ROWS_LDS];
+__global__ __launch_bounds__(HC_TPB, HC_MM_WAVES) void hc_k_rows_fwd_canon_mm(const u64 *in, u64 *out, HcMm A) {
+    __shared__ hc_mm_lds_t lds[HC_ROWS_LDS];
     HC_MM_PROLOGUE_ROWS
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = bx * 16 + rloc;
     const size_t pbase = (size_t)y * 65536;
@@ -1457,8 +1525,8 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_fwd_canon_mm(const u64 *in, 
 #pragma unroll
     for (int k = 0; k < 16; k++) out[lin + k * 256] = e[k];
 }
-__global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
-    __shared__ u64 lds[HC_ROWS_LDS];
+__global__ __launch_bounds__(HC_TPB, HC_MM_WAVES) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
+    __shared__ hc_mm_lds_t lds[HC_ROWS_LDS];
     HC_MM_PROLOGUE_ROWS
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = bx * 16 + rloc;
     const size_t pbase = (size_t)y * 65536;
@@ -1471,8 +1539,8 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rows_inv_mm(const u64 *in, u64 *o
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[pbase + (size_t)row * 256 + hi * 16 + tid] = e[hi];
 }
-__global__ __launch_bounds__(HC_TPB) void hc_k_cols_inv_canon_mm(const u64 *in, u64 *out, HcMm A) {
-    __shared__ u64 lds[HC_COLS_LDS];
+__global__ __launch_bounds__(HC_TPB, HC_MM_WAVES) void hc_k_cols_inv_canon_mm(const u64 *in, u64 *out, HcMm A) {
+    __shared__ hc_mm_lds_t lds[HC_COLS_LDS];
     HC_MM_PROLOGUE
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
