@@ -250,6 +250,17 @@ __device__ __forceinline__ void hc_rows_lo_to_lin(u64 (&e)[16], u64 *lds, int t,
 #endif
 // measured (convReLU 5 1 tail, 8 images, profiles/round4_chain_occupancy_ab.txt): 8-byte exchange / 5 waves 189.5 ms; 4-byte exchange at 6 / 6 waves 183.2, 7 / 5 waves 166.7,
 // 7 / 4 180.8, 8 / 6 193.0 (spills), 7 / 7 with two-element extension groups 169.6
+// The convolution's transform kernels (61-bit P, 82-126 VGPRs: occupancy is set by registers, not LDS): measured per kernel (profiles/round4_conv33_lds32_ab.txt), the
+// 4-byte exchange pays in the cols kernels a2, b2, b4 (-2..4 % each) and costs in the rows kernels a3, b3 (two exchanges each, +14 %), which keep the 8-byte one.
+#ifndef HC_CV_LDS32
+#define HC_CV_LDS32 1
+#endif
+#if HC_CV_LDS32
+typedef u32 hc_cvc_lds_t;
+#else
+typedef u64 hc_cvc_lds_t;
+#endif
+typedef u64 hc_cvr_lds_t;
 #if HC_MM_LDS32
 typedef u32 hc_mm_lds_t;
 #else
@@ -291,10 +302,31 @@ __device__ __forceinline__ void hc_cols_fwd(u64 (&e)[16], u32 *lds, const HcTwTa
     hc_xchg32(e, lds, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [] { __syncthreads(); });
     hc_ct_round<FM>(e, HcRowsTwB{T.colsB + tid}, Q);
 }
+template <bool SCALE = true>
 __device__ __forceinline__ void hc_cols_inv(u64 (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, const HcQ &Q) {
     hc_gs_round<false>(e, HcRowsTwB{T.colsB + tid}, Q, T.ninv, T.ninv);
     hc_xchg32(e, lds, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [] { __syncthreads(); });
-    hc_gs_round<true>(e, HcRowsTwA{T.colsA}, Q, T.ninv, T.w_last_ninv);
+    hc_gs_round<SCALE>(e, HcRowsTwA{T.colsA}, Q, T.ninv, T.w_last_ninv);
+}
+// fp64 forms: the doubles travel as their bit patterns
+template <class WA, class RA, class SY>
+__device__ __forceinline__ void hc_xchg32_f64(double (&f)[16], u32 *lds, WA wa, RA ra, SY sync) {
+    u64 b[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) b[i] = hc_d2u(f[i]);
+    hc_xchg32(b, lds, wa, ra, sync);
+#pragma unroll
+    for (int i = 0; i < 16; i++) f[i] = hc_u2d(b[i]);
+}
+__device__ __forceinline__ void hc_rows_inv_f64(double (&e)[16], u32 *lds, const HcTwTab &T, int row, int rloc, int tid, HcF64Mod m) {
+    hc_gs_round_f64<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, m, T.ninv, T.ninv);
+    hc_xchg32_f64(e, lds, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [] { HC_ROW_SYNC(); });
+    hc_gs_round_f64<false>(e, HcRowsTwA{T.rowsA + row * 16}, m, T.ninv, T.ninv);
+}
+__device__ __forceinline__ void hc_cols_inv_f64(double (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, HcF64Mod m) {
+    hc_gs_round_f64<false>(e, HcRowsTwB{T.colsB + tid}, m, T.ninv, T.ninv);
+    hc_xchg32_f64(e, lds, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [] { __syncthreads(); });
+    hc_gs_round_f64<true>(e, HcRowsTwA{T.colsA}, m, T.ninv, T.w_last_ninv);
 }
 __device__ __forceinline__ void hc_rows_lin_to_lo(u64 (&e)[16], u32 *lds, int t, int rloc, int tid) {
     hc_xchg32(e, lds, [&](int k) { return hc_rows_lds32(k, t); }, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [] { __syncthreads(); });
@@ -607,6 +639,28 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_rotate_finish(const u64 *d0, cons
 #define HC_NJOBS gridDim.y
 #endif
 #define HC_FREE_OFF 72                // FREE-mode forward outputs are below 70q (hc_ct_round): X + 72q - (such a value) stays positive
+// wavefronts per SIMD each transform kernel of the convolution is compiled for (its VGPR budget)
+#ifndef HC_W_A1
+#define HC_W_A1 4
+#endif
+#ifndef HC_W_A2
+#define HC_W_A2 4
+#endif
+#ifndef HC_W_A3
+#define HC_W_A3 4
+#endif
+#ifndef HC_W_B1
+#define HC_W_B1 4
+#endif
+#ifndef HC_W_B2
+#define HC_W_B2 1
+#endif
+#ifndef HC_W_B3
+#define HC_W_B3 4
+#endif
+#ifndef HC_W_B4
+#define HC_W_B4 1
+#endif
 struct HcLoopA {
     const HcTw *ctc;  // [2 polys][2 limbs][N]   ct_in times the integer constant (canonical) with its Shoup companion
     HcPtrs ker;       // per ciphertext: [max_ob][2 limbs][N] kernel plaintexts, plain NTT residues (what prep_Ker's pl_ker[i] holds)
@@ -626,8 +680,8 @@ struct HcLoopA {
 #define HC_A_WAVES 4          // a1 / a2 sit at 98 / 99 VGPRs; forcing five waves per SIMD spills 8 / 28 bytes per lane (+19 % fabric writes on a2) and measured no faster
 #endif
 template <int F64>
-__global__ __launch_bounds__(HC_TPB, HC_A_WAVES) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
-    __shared__ u64 lds[HC_ROWS_LDS];
+__global__ __launch_bounds__(HC_TPB, HC_W_A1) void hc_k_a1(HcLoopA A, HcTwTab T1inv) {
+    __shared__ hc_cvr_lds_t lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
     const int job = HC_JOB, p = job & 1, i = A.i0 + (job >> 1) * A.norm, z = blockIdx.z;
     const HcTw *__restrict__ c = A.ctc + ((size_t)z * 4 + (size_t)p * 2 + 1) * 65536;
@@ -659,8 +713,8 @@ __global__ __launch_bounds__(HC_TPB, HC_A_WAVES) void hc_k_a1(HcLoopA A, HcTwTab
 }
 // KA2: cols-inverse mod Q1, centred lift to Q0, cols-forward mod Q0, in place on tmp. grid = (jobs * batch, 16)
 template <int FM, int F64>
-__global__ __launch_bounds__(HC_TPB, HC_A_WAVES) void hc_k_a2(HcLoopA A, HcTwTab T1inv, HcTwTab T0fwd) {
-    __shared__ u64 lds[HC_COLS_LDS];
+__global__ __launch_bounds__(HC_TPB, HC_W_A2) void hc_k_a2(HcLoopA A, HcTwTab T1inv, HcTwTab T0fwd) {
+    __shared__ hc_cvc_lds_t lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     u64 *base = A.tmp + (size_t)HC_JOB * 65536 + HC_TILE * 16 + c;
     const HcQ Q0 = hc_q(A.m0.q);
@@ -698,8 +752,8 @@ __global__ __launch_bounds__(HC_TPB, HC_A_WAVES) void hc_k_a2(HcLoopA A, HcTwTab
 // a_0 = c'_p[0] (*) k_i[0] is formed first, in the linear layout the epilogue uses, so that every global load of
 // the kernel is issued before the transform starts and nothing stalls behind the stores at the end.
 template <int FM>
-__global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_a3(HcLoopA A, HcTwTab T0fwd) {
-    __shared__ u64 lds[HC_ROWS_LDS];
+__global__ __launch_bounds__(HC_TPB, HC_W_A3) void hc_k_a3(HcLoopA A, HcTwTab T0fwd) {
+    __shared__ hc_cvr_lds_t lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
     const int job = HC_JOB, p = job & 1, i = A.i0 + (job >> 1) * A.norm, z = blockIdx.z;
     const u64 *__restrict__ in = A.tmp + ((size_t)z * A.njobs + job) * 65536 + (size_t)row * 256;
@@ -749,8 +803,8 @@ struct HcLoopB {
 };
 // KB1: t2.c1 = y1 - I*x1 (kept in tmpT for KB5) and its rows-inverse (mod Q0). grid = (batch*nodes, 16). Everything else a node needs
 // from x and y (t1, t2.c0, the Q-part of the key switch) is formed in KB5 from src and tmpT.
-__global__ __launch_bounds__(HC_TPB, HC_A_WAVES) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
-    __shared__ u64 lds[HC_ROWS_LDS];
+__global__ __launch_bounds__(HC_TPB, HC_W_B1) void hc_k_b1(HcLoopB B, HcTwTab T0inv) {
+    __shared__ hc_cvr_lds_t lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
     const int job = HC_JOB, z = job / B.nodes, node = job - z * B.nodes, i = (B.n0 + node) * B.norm;
     const size_t tile = (size_t)HC_TILE * 4096 + t;
@@ -780,8 +834,8 @@ __global__ __launch_bounds__(HC_TPB, HC_A_WAVES) void hc_k_b1(HcLoopB B, HcTwTab
 }
 // KB2: cols-inverse mod Q0 (-> canonical c < Q0 < P), cols-forward mod P, in place on tmpC. grid = (batch*nodes, 16)
 template <int FMP>
-__global__ __launch_bounds__(HC_TPB) void hc_k_b2(HcLoopB B, HcTwTab T0inv, HcTwTab TPfwd) {
-    __shared__ u64 lds[HC_COLS_LDS];
+__global__ __launch_bounds__(HC_TPB, HC_W_B2) void hc_k_b2(HcLoopB B, HcTwTab T0inv, HcTwTab TPfwd) {
+    __shared__ hc_cvc_lds_t lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     u64 *base = B.tmpC + (size_t)HC_JOB * 65536 + HC_TILE * 16 + c;
     const HcQ Q0 = hc_q(B.m0.q), QP = hc_q(B.mp.q);
@@ -798,8 +852,8 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_b2(HcLoopB B, HcTwTab T0inv, HcTw
 }
 // KB3: rows-forward mod P, multiply by b_P and a_P, rows-inverse mod P of both. grid = (batch*nodes, 16)
 template <int FMP>
-__global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b3(HcLoopB B, HcTwTab TPfwd, HcTwTab TPinv) {
-    __shared__ u64 lds[HC_ROWS_LDS];
+__global__ __launch_bounds__(HC_TPB, HC_W_B3) void hc_k_b3(HcLoopB B, HcTwTab TPfwd, HcTwTab TPinv) {
+    __shared__ hc_cvr_lds_t lds[HC_ROWS_LDS];
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
     const int node = HC_JOB;
     const u64 *in = B.tmpC + (size_t)node * 65536 + (size_t)row * 256;
@@ -826,8 +880,8 @@ __global__ __launch_bounds__(HC_TPB, HC_MIN_WAVES) void hc_k_b3(HcLoopB B, HcTwT
 // KB4: cols-inverse mod P, exact basis extension P -> Q0 (ring.modUpExact, one P prime), cols-forward mod Q0.
 // grid = (2*batch*nodes, 16), in place on tmpE
 template <int FM>
-__global__ __launch_bounds__(HC_TPB) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTwTab T0fwd) {
-    __shared__ u64 lds[HC_COLS_LDS];
+__global__ __launch_bounds__(HC_TPB, HC_W_B4) void hc_k_b4(HcLoopB B, HcTwTab TPinv, HcTwTab T0fwd) {
+    __shared__ hc_cvc_lds_t lds[HC_COLS_LDS];
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     u64 *base = B.tmpE + (size_t)HC_JOB * 65536 + HC_TILE * 16 + c;
     const HcQ QP = hc_q(B.mp.q), Q = hc_q(B.m0.q);
