@@ -1657,15 +1657,18 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_yv(const u64 *src, size_t s
 // digits laid out [beta][nt][N] per image. A key element is read ONCE whatever the number of images, a digit element once for both
 // components: per coefficient beta * (2 + n) reads and 2 n writes (one image, one component per thread: beta * (2 + 2 n)).
 // grid = (64, nt); images cx_is / dg_is / acc_is words apart.
+// NB images per thread (blockIdx.z = image group): the 128-bit accumulators cost 8 VGPRs per image - 122 VGPRs (4 waves per SIMD) at 8 images per thread, whatever the batch
+template <int NB>
 __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_is, const HcMod *mods,
                                                           int nl, int nq, int nt, int alpha, int beta, int n) {
     const int T = blockIdx.y;
+    { const int g0 = (int)blockIdx.z * NB; cx += (size_t)g0 * cx_is; digits += (size_t)g0 * dg_is; acc += (size_t)g0 * acc_is; n = n - g0 < NB ? n - g0 : NB; }
     const HcMod m = mods[T < nl ? T : nq + (T - nl)];
     const size_t rowT = (size_t)T * 65536, comp = (size_t)nt * 65536;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
         // the products of up to 6 digits are summed as 128-bit integers and reduced ONCE (6 q^2 < q 2^64 for q < 2^61): the same residue as the modular sum of the
         // per-digit Montgomery products at less than half the instructions; a longer decomposition folds every 6 digits
-        u128 t0[HC_MAXIMG], t1[HC_MAXIMG]; u64 s0[HC_MAXIMG], s1[HC_MAXIMG];
+        u128 t0[NB], t1[NB]; u64 s0[NB], s1[NB];
         for (int d = 0; d < beta; d++) {
             const int lo = d * alpha, hi = lo + alpha < nl ? lo + alpha : nl;
             const bool own = T >= lo && T < hi;
@@ -1673,7 +1676,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const 
             const u64 *xs = own ? cx + rowT + j : digits + ((size_t)d * nt) * 65536 + rowT + j; const size_t xis = own ? cx_is : dg_is;
             const int ph = d % 6;
 #pragma unroll
-            for (int g = 0; g < HC_MAXIMG; g++) if (g < n) {
+            for (int g = 0; g < NB; g++) if (g < n) {
                 const u64 x = xs[(size_t)g * xis];
                 const u128 p0 = (u128)x * kb, p1 = (u128)x * ka;
                 t0[g] = ph == 0 ? p0 : t0[g] + p0;
@@ -1686,7 +1689,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const 
             }
         }
 #pragma unroll
-        for (int g = 0; g < HC_MAXIMG; g++) if (g < n) { u64 *a = acc + (size_t)g * acc_is + rowT + j; a[0] = s0[g]; a[comp] = s1[g]; }
+        for (int g = 0; g < NB; g++) if (g < n) { u64 *a = acc + (size_t)g * acc_is + rowT + j; a[0] = s0[g]; a[comp] = s1[g]; }
     }
 }
 // The inner products of R hoisted rotations in ONE launch (the baby steps of a linear transform share one digit decomposition): a digit element is read once for the R keys

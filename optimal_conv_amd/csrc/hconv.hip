@@ -1201,6 +1201,9 @@ static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
     return HC_OK;
 }
 // scratch of one key switch at `level` for the nb images of the batch, section-major: coef[img][nl] | digits[img][beta][nt] | acc[img][2][nt] | pc[img][2][alpha + 1] | ext[img][2][nl] | yv[img][max(beta, 2)][alpha + 1]
+#ifndef HC_MAC_NB
+#define HC_MAC_NB 4                  // images per thread of the key switch's inner product at batches above 2 (hc_k_ks_mac_all)
+#endif
 struct HcKsScratch { u64 *coef, *digits, *acc, *pc, *ext, *yv; size_t coef_is, digits_is, acc_is, pc_is, ext_is; };
 static int hc_ks_scratch(hc_ctx *c, int level, HcKsScratch *S) {
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha; const size_t nb = (size_t)c->nb;
@@ -1226,7 +1229,10 @@ static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, const HcKsS
 // the inner product with both components of the key, all images: acc [img][2][nt][N], images acc_is words apart
 static int hc_ks_mac(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *acc, size_t acc_is) {
     const int alpha = c->np, nl = level + 1, nt = nl + alpha;
-    return hc_launch(c, "ks_mac_all", hc_k_ks_mac_all, dim3(64, (unsigned)nt), (const u64 *)key.rows, cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, acc, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, key.beta, c->nb);
+    const int nb = c->nb, NB = nb <= 1 ? 1 : nb <= 2 ? 2 : HC_MAC_NB;                 // images per thread; more images = more image groups (blockIdx.z), each reading the key once
+#define HC_MAC_ALL(NN) hc_launch(c, "ks_mac_all", hc_k_ks_mac_all<NN>, dim3(64, (unsigned)nt, (unsigned)((nb + NN - 1) / NN)), (const u64 *)key.rows, cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, acc, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, key.beta, nb)
+    return NB == 1 ? HC_MAC_ALL(1) : NB == 2 ? HC_MAC_ALL(2) : NB == 4 ? HC_MAC_ALL(4) : HC_MAC_ALL(8);
+#undef HC_MAC_ALL
 }
 // ring.(*FastBasisExtender).ModDownSplitNTTPQ for the two polynomials acc[2][nt][N] of every image (basis Q_0..Q_level, P_0..P_(np-1), canonical, NTT):
 // InvNTT of the P limbs, {P} -> every Q limb, NTT, (acc - ext) * P^-1
