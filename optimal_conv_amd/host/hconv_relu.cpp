@@ -143,11 +143,12 @@ struct Boot {
             HCR(hc_copy(hc, r.p[d].get() + (size_t)z * poly_stride(), a.p[d].get() + (size_t)z * poly_stride(), (size_t)(a.level + 1) * N * 8));
             HCR(hc_copy(hc, r.p[d].get() + (size_t)(n0 + z) * poly_stride(), b.p[d].get() + (size_t)z * poly_stride(), (size_t)(a.level + 1) * N * 8));
         }
-        set_nb(2 * n0);
+        set_nb(2 * n0); alg_ct_at_merge = alg_ct;
         return r;
     }
+    double alg_ct_at_merge = 0;                            // the merged stretch works on TWO ciphertexts per image: its per-ciphertext byte count is doubled at split2
     void split2(const DCt &m, DCt out[2]) {               // called with nb = 2n: the two halves as n-image ciphertexts; the batch goes back to n
-        const int n0 = nb / 2; set_nb(n0);
+        const int n0 = nb / 2; set_nb(n0); alg_ct += alg_ct - alg_ct_at_merge;
         for (int h = 0; h < 2; h++) {
             out[h] = new_ct(m.level, 1, m.scale);
             for (int d = 0; d < 2; d++) for (int z = 0; z < n0; z++)
