@@ -192,6 +192,9 @@ int hc_keyswitch_qp_rotate(hc_ctx *ctx, uint64_t key_id, uint64_t galEl, int lev
  * key_ids, galEls, outs: HOST arrays. */
 int hc_keyswitch_qp_rotate_many(hc_ctx *ctx, int nrot, const uint64_t *key_ids, const uint64_t *galEls, int level, const uint64_t *pc0, const uint64_t *cx, uint64_t *const *outs);
 int hc_mod_down2(hc_ctx *ctx, int level, const uint64_t *x, uint64_t *out0, uint64_t *out1);
+/* hc_mod_down2, + a_k, and ONE hc_div_round_last2 as one call (the end of a linear transform): out_k = Rescale(ModDown(x)_k + a_k) at level - 1 (level >= 2); a0, a1 both
+ * NULL = no addend. Same residues as the three calls; row `level` of x is overwritten. */
+int hc_mod_down2_add_rescale(hc_ctx *ctx, int level, uint64_t *x, const uint64_t *a0, const uint64_t *a1, uint64_t *out0, uint64_t *out1);
 int hc_qp_op2(hc_ctx *ctx, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1);
 int hc_keyswitch_hoisted(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *d0, uint64_t *d1);
 /* the diagonal sum of one giant step of MultiplyByDiagMatrixBSGS in one launch: out[2][level+1+np][N] (+)= sum over t < nterms (<= 64) of a[t] (*) pt[t], a[t] =

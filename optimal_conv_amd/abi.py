@@ -56,6 +56,7 @@ SYMBOLS = {
     "hc_keyswitch_qp": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "hc_keyswitch_qp_rotate": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "hc_keyswitch_qp_rotate_many": (C.c_int, [C.c_void_p, C.c_int, u64p, u64p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "hc_mod_down2_add_rescale": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_mod_down2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_qp_op2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_lv_ntt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

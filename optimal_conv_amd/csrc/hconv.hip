@@ -102,7 +102,7 @@ struct hc_ctx {
     u64 *ws_gather = nullptr; size_t ws_gather_rows = 0;
     long small_levels = 16;               // pack-tree launches of at most this many nodes (summed over the batch) run on the 1024-thread S kernels; 0 = never
     long peer_access = 1;                 // hc_conv_then_pack_sharded: enable direct peer copies between distinct devices (0: leave the copies to hipMemcpyPeerAsync's staging)
-    int xcd_rows = getenv("HC_XCD_ROWS") ? atoi(getenv("HC_XCD_ROWS")) : 1;      // A/B switch of the XCD-aware rows-pass grid (HcMm::xcd)
+    int xcd_rows = 1;                     // XCD-aware 1-D grid of the rows passes (HcMm::xcd; 0 = the plain 3-D grid, kept for A/B builds)
     unsigned peer_warned = 0;             // bit d: enabling peer access to device d failed and was reported once
     unsigned peer_enabled = 0;            // bit d: peer access from this context's device to device d was enabled by (or found enabled for) this context
     long profile = 0;
@@ -1436,6 +1436,17 @@ extern "C" int hc_mod_down2(hc_ctx *c, int level, const uint64_t *x, uint64_t *o
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
     if (level != c->hoist_level) c->hoist_cx = nullptr;      // the scratch layout depends on the level: pc / ext of another level overlap the held digits
     return hc_ks_moddown(c, level, (const u64 *)x, c->bs_qp, S, (u64 *)out0, (u64 *)out1, 0, nullptr);
+}
+// hc_mod_down2 followed by + a_k and ONE hc_div_round_last2, as one call (the end of a linear transform: ModDown of the accumulators, the other terms, Rescale's first drop):
+// out_k = Rescale(ModDown(x)_k + a_k) at level - 1, level >= 2; a0 / a1 may be NULL (no addend; both or neither). One forward transform per limb (hc_ks_moddown_rescale); the
+// residues of the three calls. Row `level` of both components of x is overwritten.
+extern "C" int hc_mod_down2_add_rescale(hc_ctx *c, int level, uint64_t *x, const uint64_t *a0, const uint64_t *a1, uint64_t *out0, uint64_t *out1) {
+    HC_ENTER(c);
+    if (level < 2 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_mod_down2_add_rescale: level %d outside 2..%d or no special primes", level, c->nq - 1);
+    if (!x || !out0 || !out1 || (a0 == nullptr) != (a1 == nullptr)) return hc_fail(c, HC_ERR_ARG, "hc_mod_down2_add_rescale: null (the addends come as a pair)");
+    HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
+    if (level != c->hoist_level) c->hoist_cx = nullptr;
+    return hc_ks_moddown_rescale(c, level, (u64 *)x, c->bs_qp, S, (u64 *)out0, (u64 *)out1, (const u64 *)a0, (const u64 *)a1);
 }
 // hc_qp_op2: out_k = a_k (op) b_k, k = 0, 1, over the level+1+np rows of the extended basis (op: HC_LV_MUL, HC_LV_ADD, HC_LV_MUL_ACC; b1 == b0
 // for a plaintext operand; products of two NTT residues as hc_lv_mul)

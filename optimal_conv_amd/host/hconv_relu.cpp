@@ -600,7 +600,9 @@ struct Boot {
     // LinearTransform's input. Harmless for the value (that digit's gadget factor vanishes modulo the limbs kept), but the residues depend on it; the same residues come
     // out of ONE decomposition at the ciphertext's level of hoist_c1 = (c1's limbs up to the matrix level | the previous input's limbs above it), rows above the matrix
     // level dropped afterwards (tests/oracle_ckks.py linear_transform_qp, pinned by ref_trace_chain_bl_5_1.json).
-    DCt linear_transform_qp(const DCt &ct, const LT &lt, const uint64_t *hoist_c1 = nullptr, int hoist_level = -1) {
+    // fuse_min_scale > 0: the caller rescales next by ckks Rescale's drop rule with this minimum scale; when its first drop is due, it rides in the final ModDown
+    // (hc_mod_down2_add_rescale) and the result comes back one level down
+    DCt linear_transform_qp(const DCt &ct, const LT &lt, const uint64_t *hoist_c1 = nullptr, int hoist_level = -1, double fuse_min_scale = 0) {
         const int L = ct.level, nl = L + 1, np = (int)P.size(), nt = nl + np; const size_t zs = (size_t)nt * N;
         std::map<int, std::vector<int>> index; std::set<int> babies;
         for (auto &g : lt.giant) for (auto &b : g.second) { index[g.first / lt.n1].push_back(b.first); if (b.first) babies.insert(b.first); }
@@ -667,18 +669,29 @@ struct Boot {
             for (int i : index[0]) if (i) { as.push_back(rot[i].get()); pts.push_back(lt.giant.at(0).at(i).p.get()); }
             if (!as.empty()) { HCR(hc_qp_mul_sum(hc, L, (int)as.size(), as.data(), pts.data(), B.get(), haveB ? 1 : 0)); haveB = true; }
         }
-        if (haveB) { auto d0 = block(), d1 = block(); HCR(hc_mod_down2(hc, L, B.get(), d0.get(), d1.get())); add_to_res(0, d0); add_to_res(1, d1); }
-        if (lt.giant.count(0) && lt.giant.at(0).count(0)) {
+        static const bool split_rescale = getenv("HCONV_NO_FUSED_RESCALE") != nullptr;
+        const bool fuse = fuse_min_scale > 0 && haveB && L >= 2 && !split_rescale && res.scale / (double)Q[(size_t)L] >= fuse_min_scale / 2;
+        auto diag0 = [&]() {
+            if (!(lt.giant.count(0) && lt.giant.at(0).count(0))) return;
             const uint64_t *pt = lt.giant.at(0).at(0).p.get();
             if (have_res[0] && have_res[1]) HCR(hc_lv_op2(hc, HC_LV_MUL_ACC, L, ct.p[0].get(), ct.p[1].get(), pt, pt, res.p[0].get(), res.p[1].get(), nullptr));
             else for (int k = 0; k < 2; k++) { auto t = block(); HCR(hc_lv_mul(hc, L, ct.p[k].get(), pt, t.get())); add_to_res(k, t); }
+        };
+        if (fuse) {            // every other term first (modular sums commute), then ModDown(B) + them + the first drop of the caller's Rescale in one pass
+            diag0();
+            if (have_res[0] != have_res[1]) for (int k = 0; k < 2; k++) if (!have_res[k]) { auto z = block(); HCR(hc_lv_mul_const(hc, L, ct.p[k].get(), zeros.data(), z.get())); add_to_res(k, z); }
+            DCt out = new_ct(L - 1, 1, res.scale / (double)Q[(size_t)L]); alg_ct += 2.0 * (2 * L + 1);
+            HCR(hc_mod_down2_add_rescale(hc, L, B.get(), have_res[0] ? res.p[0].get() : nullptr, have_res[0] ? res.p[1].get() : nullptr, out.p[0].get(), out.p[1].get()));
+            return out;
         }
+        if (haveB) { auto d0 = block(), d1 = block(); HCR(hc_mod_down2(hc, L, B.get(), d0.get(), d1.get())); add_to_res(0, d0); add_to_res(1, d1); }
+        diag0();
         if (!have_res[0] || !have_res[1]) panic("linear_transform_qp: empty matrix");
         return res;
     }
-    DCt linear_transform(const DCt &ct, const LT &lt) {             // sum_k diag_k (.) rot_k(ct); no rescale
+    DCt linear_transform(const DCt &ct, const LT &lt, double fuse_min_scale = 0) {             // sum_k diag_k (.) rot_k(ct); no rescale (or its first drop: linear_transform_qp)
         if (ct.level != lt.level) panic("linear_transform: ciphertext level differs from the encoded matrix level");
-        return linear_transform_qp(ct, lt);
+        return linear_transform_qp(ct, lt, nullptr, -1, fuse_min_scale);
     }
 
     // ---------------- polynomial evaluation (tests/oracle_ckks.py: _power, _split, _plan_level, _eval_rec, eval_poly)
@@ -1005,7 +1018,7 @@ struct Boot {
         k = floor((sinescale / msg_ratio) / ct.scale + 0.5);
         { const double s0 = ct.scale; ct = mul_const_int(ct, k); ct.scale = s0 * k; }
         for (int i = LOGN - 1 - ls; i < LOGN - 1; i++) ct = add(ct, rotate(ct, 1 << i));                   // subSum
-        for (auto &lt : S.cts) { const double s_in = ct.scale; ct = lt_rescale(linear_transform(ct, lt), s_in); }
+        for (auto &lt : S.cts) { const double s_in = ct.scale; ct = lt_rescale(linear_transform(ct, lt, s_in), s_in); }
         if (ct.level != LV_SINE_TOP) panic("CoeffsToSlots ended at the wrong level");
         if (profiling()) profile_dump(this, "modUp + CoeffsToSlots");
         DCt cc = conjugate(ct);
@@ -1071,13 +1084,13 @@ struct Boot {
                     copy_rows(y.get(), ct.p[1].get(), (size_t)nk);
                     copy_rows(y.get(), prev_c1.get(), (size_t)(Lh + 1 - nk), (size_t)nk, (size_t)nk);
                     ct = lt_rescale(linear_transform_qp(drop_to(ct, lt.level), lt, y.get(), Lh), s_in);
-                } else { prev_c1 = ct.p[1]; ct = lt_rescale(linear_transform(ct, lt), s_in); }
+                } else { prev_c1 = ct.p[1]; ct = lt_rescale(linear_transform(ct, lt, s_in), s_in); }
             }
             return ct;
         }
         DCt ct = drop_to(ls ? re : add(re, mul_by_i(*im)), LV_STC_TOP);
         if (chain == 6) {        // ckks.SlotsToCoeffs as the fork runs it (sparse slots: one packed ciphertext, no MultByi + Add) (ref_flow_5_1.json): MultByi + Add, three LinearTransforms each followed by Rescale(min = the scale before), then eval.go:564's Rescale(2^30): level 3 -> 1
-            for (auto &lt : S.stc) { const double s_in = ct.scale; ct = lt_rescale(linear_transform(ct, lt), s_in); }
+            for (auto &lt : S.stc) { const double s_in = ct.scale; ct = lt_rescale(linear_transform(ct, lt, s_in), s_in); }
             return lt_rescale(ct, 1073741824.0);
         }
         for (size_t i = 0; i + 1 < S.stc.size(); i++) ct = linear_transform(ct, S.stc[i]);

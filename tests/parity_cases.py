@@ -541,6 +541,32 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
         eq(kr[k_], kr2[k_], f"keyswitch_add_rescale == keyswitch_add + div_round_last2 (polynomial {k_})")
         assert not (kr[k_] == 0x1234567).any(), "keyswitch_add_rescale left output words unwritten"
 
+    # the end of a linear transform in one call == ModDown, the additions, Rescale
+    xq = np.stack([np.stack([np.stack([rnd(qp_mod(t)) for t in range(nt)]) for _ in range(2)]).reshape(-1) for _ in range(n)])
+
+    def md_add_rescale_3(x, p0, p1, o0, o1):
+        t0, t1 = ctx.buf(nwords=ctx_nb() * PS), ctx.buf(nwords=ctx_nb() * PS)
+        ck(L.hc_mod_down2(h, level, x, t0.ptr, t1.ptr)); ck(L.hc_lv_op2(h, 1, level, t0.ptr, t1.ptr, p0, p1, t0.ptr, t1.ptr, None)); ck(L.hc_div_round_last2(h, level, t0.ptr, t1.ptr, o0, o1))
+        ctx.sync(); t0.free(); t1.free()
+
+    def md_rescale_2(x, o0, o1):
+        t0, t1 = ctx.buf(nwords=ctx_nb() * PS), ctx.buf(nwords=ctx_nb() * PS)
+        ck(L.hc_mod_down2(h, level, x, t0.ptr, t1.ptr)); ck(L.hc_div_round_last2(h, level, t0.ptr, t1.ptr, o0, o1))
+        ctx.sync(); t0.free(); t1.free()
+    ctx.set_batch = set_batch_spy
+    m3 = run("mod_down2 + add + div_round_last2", md_add_rescale_3, [(xq, "q"), (b, "p"), (b1, "p")], [("p", level * N), ("p", level * N)])
+    m2 = run("mod_down2 + div_round_last2", md_rescale_2, [(xq, "q")], [("p", level * N), ("p", level * N)])
+    def md_fused(x, p0, p1, o0, o1):                       # the call overwrites row `level` of x: work on a copy
+        t = ctx.buf(nwords=ctx_nb() * QS)
+        ck(L.hc_copy(h, t.ptr, x, ctx_nb() * QS * 8)); ck(L.hc_mod_down2_add_rescale(h, level, t.ptr, p0, p1, o0, o1))
+        ctx.sync(); t.free()
+    m1 = run("mod_down2_add_rescale", md_fused, [(xq, "q"), (b, "p"), (b1, "p")], [("p", level * N), ("p", level * N)])
+    m0 = run("mod_down2_add_rescale (no addend)", lambda x, o0, o1: md_fused(x, None, None, o0, o1), [(xq, "q")], [("p", level * N), ("p", level * N)])
+    ctx.set_batch = _sb
+    for k_ in range(2):
+        eq(m1[k_], m3[k_], f"mod_down2_add_rescale == mod_down2 + add + div_round_last2 (polynomial {k_})")
+        eq(m0[k_], m2[k_], f"mod_down2_add_rescale without addend == mod_down2 + div_round_last2 (polynomial {k_})")
+
     def hoisted(x, d0, d1, e0, e1):
         ck(L.hc_keyswitch_decompose(h, level, x)); ck(L.hc_keyswitch_hoisted(h, K0, level, x, d0, d1)); ck(L.hc_keyswitch_hoisted(h, K1, level, x, e0, e1))
     hs = run("keyswitch_decompose + hoisted x2", hoisted, [(a, "p")], [("p", PW)] * 4)
