@@ -996,7 +996,9 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, H
 // per node: 0.5 written, 2 x 0.5 read, against 0.5 more for x1), and idx is read once per node. Per row batch of either polynomial:
 //   k = 1: m1 = I*x1 ; T = y1 - m1 ; t1 = y1 + m1 ; F = (a_Q/P)*T                      k = 0: m = I*x0 ; t1 = y0 + m ; F = y0 - m + (b_Q/P)*T
 //   d = F - n_k (n_k = rows-forward of the k-th extension, divided by P by b4) ; through the LDS row ; dst = reduce(t1 + perm(d)) (+ bias, k = 0)
+#ifndef HC_B5_ROWS
 #define HC_B5_ROWS 2                  // rows per epilogue batch of hc_k_b5m
+#endif
 #ifndef HC_B5M_UNROLL
 #define HC_B5M_UNROLL 2
 #endif
