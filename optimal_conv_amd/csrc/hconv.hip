@@ -1409,14 +1409,15 @@ extern "C" int hc_keyswitch_qp_rotate_many(hc_ctx *c, int nrot, const uint64_t *
         HC_HIP(c, hcx_malloc(c, (void **)&c->ws_accm, (size_t)R * nb * 2 * nt * HC_N * sizeof(u64)));
         c->ws_accm_rows = (size_t)R * nb * 2 * nt;
     }
+    std::vector<const HcSwk *> keys((size_t)nrot);                           // every rotation is checked before the first launch: an error leaves nothing half done
+    for (int r = 0; r < nrot; r++) {
+        HC_TRY(hc_ks_find(c, "hc_keyswitch_qp_rotate_many", key_ids[r], level, &keys[(size_t)r]));
+        if (!(galEls[r] & 1) || !outs[r]) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_qp_rotate_many: rotation %d: galEl must be odd, out non-null", r);
+    }
     for (int r0 = 0; r0 < nrot; r0 += R) {
         const int nr = nrot - r0 < R ? nrot - r0 : R;
         HcKeyPtrs K; memset(&K, 0, sizeof K); int beta = 0;
-        for (int r = 0; r < nr; r++) {
-            const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_qp_rotate_many", key_ids[r0 + r], level, &key));
-            if (!(galEls[r0 + r] & 1) || !outs[r0 + r]) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_qp_rotate_many: rotation %d: galEl must be odd, out non-null", r0 + r);
-            K.k[r] = key->rows; beta = key->beta;
-        }
+        for (int r = 0; r < nr; r++) { K.k[r] = keys[(size_t)(r0 + r)]->rows; beta = keys[(size_t)(r0 + r)]->beta; }
         const dim3 grid(64, (unsigned)nt);
 #define HC_MAC_MULTI(RR, NN) hc_launch(c, "ks_mac_multi", hc_k_ks_mac_multi<RR, NN>, grid, K, nr, (const u64 *)cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, c->ws_accm, acc_rs, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta, nb)
         if (NB == 8) HC_TRY(HC_MAC_MULTI(2, 8)); else if (NB == 4) HC_TRY(HC_MAC_MULTI(4, 4)); else if (NB == 2) HC_TRY(HC_MAC_MULTI(8, 2)); else HC_TRY(HC_MAC_MULTI(8, 1));

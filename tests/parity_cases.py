@@ -611,6 +611,16 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
     for i in range(len(rots)):
         eq(rm[i], rs_[i], f"rotate_many == single hoisted rotations (rotation {i})")
     eq(rm[0], qr[0], "rotate_many (hoisted) == the plain fused rotation")
+    # error behaviour: no decomposition held -> refused before any launch; an unknown key among the rotations likewise
+    xa, xo = ctx.buf(a[0]), ctx.buf(nwords=2 * nt * N)
+    ids1 = (C.c_uint64 * 1)(30); gs1 = (C.c_uint64 * 1)(gal); arr1 = (C.c_void_p * 1)(xo.ptr)
+    ck(L.hc_keyswitch(h, K0, level, xa.ptr, xo.at(0), xo.at(PW)))                        # a plain key switch drops any held decomposition
+    assert L.hc_keyswitch_qp_rotate_many(h, 1, ids1, gs1, level, None, xa.ptr, arr1) != 0, "rotate_many without a held decomposition must fail"
+    ck(L.hc_keyswitch_decompose(h, level, xa.ptr))
+    bad = (C.c_uint64 * 1)(999)
+    assert L.hc_keyswitch_qp_rotate_many(h, 1, bad, gs1, level, None, xa.ptr, arr1) != 0, "rotate_many with an unknown key must fail"
+    assert L.hc_keyswitch_add_rescale(h, K0, 1, xa.ptr, xa.ptr, xa.ptr, xo.ptr, xo.ptr) != 0, "keyswitch_add_rescale below level 2 must fail"
+    ctx.sync(); xa.free(); xo.free()
 
     def qp_rot_acc(x, o):
         ck(L.hc_keyswitch_decompose(h, level, x)); ck(L.hc_keyswitch_qp_rotate(h, K1, C.c_uint64(gal), level, None, x, o, 1, 1))
