@@ -20,6 +20,24 @@
 #include "../../include/hconv.h"
 #include "hc_kernels.h"
 #include "hc_gomath.h"
+// workgroups per row of the streaming (grid-stride) kernels of the leveled evaluator and the key switch: a thread strides over 65536 / (256 x this) coefficients.
+// Measured on the convReLU 5 1 tail (profiles/round4_chain_occupancy_ab.txt, rounds 7-8): the inner products and the giant-step sums at 256 (one coefficient per thread)
+// and the rotation finishes at 128 take 2.3 % off a layer against 64 / 32; the pointwise kernels (HC_GX_LV) lose at 128 and at 256
+#ifndef HC_GX_LV
+#define HC_GX_LV 64
+#endif
+#ifndef HC_GX_ROT
+#define HC_GX_ROT 128
+#endif
+#ifndef HC_GX_QPMS
+#define HC_GX_QPMS 256
+#endif
+#ifndef HC_GX_MAC
+#define HC_GX_MAC 256
+#endif
+#ifndef HC_GX_MACM
+#define HC_GX_MACM 256
+#endif
 
 #define HC_N 65536
 #define HC_LOGN 16
@@ -460,18 +478,18 @@ extern "C" int hc_rotate_finish(hc_ctx *c, uint64_t galEl, int level, const uint
     HC_ENTER(c);
     if (level < 0 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "hc_rotate_finish: level %d outside 0..%d", level, c->nq - 1);
     if (!d0 || !d1 || !c0 || !out0 || !out1 || out0 == d0 || out0 == c0 || out1 == d1 || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_rotate_finish: bad arguments (outputs must differ from inputs, galEl odd)");
-    return hc_launch(c, "rotate_finish", hc_k_rotate_finish, dim3(64, (unsigned)(level + 1), 2u * (unsigned)c->nb), (const u64 *)d0, (const u64 *)d1, (const u64 *)c0, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, (u32)(galEl & 0x1FFFF), c->bs_poly);
+    return hc_launch(c, "rotate_finish", hc_k_rotate_finish, dim3(HC_GX_LV, (unsigned)(level + 1), 2u * (unsigned)c->nb), (const u64 *)d0, (const u64 *)d1, (const u64 *)c0, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, (u32)(galEl & 0x1FFFF), c->bs_poly);
 }
 // ring.PermuteNTTWithIndexLvl on a polynomial at `level` (rows 0..level) / on an extended-basis pair [2][level+1+np][N], for every image of the batch
 extern "C" int hc_lv_permute(hc_ctx *c, uint64_t galEl, int level, const uint64_t *in, uint64_t *out) {
     HC_ENTER(c);
     if (level < 0 || level >= c->nq || !in || !out || in == out || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_lv_permute: bad arguments (in/out must differ, galEl odd)");
-    return hc_launch(c, "permute", hc_k_permute_mm, dim3(64, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), c->bs_poly);
+    return hc_launch(c, "permute", hc_k_permute_mm, dim3(HC_GX_LV, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), c->bs_poly);
 }
 extern "C" int hc_qp_permute2(hc_ctx *c, uint64_t galEl, int level, const uint64_t *in, uint64_t *out) {
     HC_ENTER(c);
     if (level < 0 || level >= c->nq || c->np < 1 || !in || !out || in == out || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_qp_permute2: bad arguments (in/out must differ, galEl odd)");
-    return hc_launch(c, "permute", hc_k_permute_mm, dim3(64, 2u * (unsigned)(level + 1 + c->np), (unsigned)c->nb), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), c->bs_qp);
+    return hc_launch(c, "permute", hc_k_permute_mm, dim3(HC_GX_LV, 2u * (unsigned)(level + 1 + c->np), (unsigned)c->nb), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), c->bs_qp);
 }
 // Image batch of the leveled evaluator (include/hconv.h): n images per launch, the images of an operand stride words apart
 extern "C" int hc_set_batch(hc_ctx *c, int n, size_t poly_stride_words, size_t qp_stride_words) {
@@ -501,7 +519,7 @@ static int hc_lv_pw(hc_ctx *c, const char *fn, int level, const uint64_t *a, con
         for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[l] = h_pair(consts_host[l] % q, q); }
     }
     const bool inthread = b_shared && c->nb > 1;
-    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(64, (unsigned)(level + 1), inthread ? 1u : (unsigned)c->nb), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, K, (size_t)0, (size_t)0, (size_t)0, HC_ROW_IS_MOD, 0,
+    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(HC_GX_LV, (unsigned)(level + 1), inthread ? 1u : (unsigned)c->nb), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, K, (size_t)0, (size_t)0, (size_t)0, HC_ROW_IS_MOD, 0,
                      1, inthread ? c->nb : 1, c->bs_poly, b_shared ? (size_t)0 : c->bs_poly, c->bs_poly);
 }
 // the same operations on both polynomials of a ciphertext in one launch (they may live in separate allocations; b1 == b0 for a plaintext operand)
@@ -517,7 +535,7 @@ static int hc_lv_pw2(hc_ctx *c, const char *fn, int level, const u64 *a0, const 
     }
     const u64 *bb0 = b0 ? b0 : a0, *bb1 = b1 ? b1 : a1;
     const bool b_shared = (OP == HC_PW_MUL || OP == HC_PW_MAC) && b0 && b0 == b1, inthread = b_shared && c->nb > 1;      // one plaintext for both polynomials = one plaintext for every image
-    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(64, (unsigned)(level + 1), inthread ? 2u : 2u * (unsigned)c->nb), a0, bb0, o0, (const HcMod *)c->d_mods, K, (size_t)(a1 - a0), (size_t)(bb1 - bb0), (size_t)(o1 - o0), HC_ROW_IS_MOD, 0,
+    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(HC_GX_LV, (unsigned)(level + 1), inthread ? 2u : 2u * (unsigned)c->nb), a0, bb0, o0, (const HcMod *)c->d_mods, K, (size_t)(a1 - a0), (size_t)(bb1 - bb0), (size_t)(o1 - o0), HC_ROW_IS_MOD, 0,
                      2, inthread ? c->nb : 1, c->bs_poly, b_shared ? (size_t)0 : c->bs_poly, c->bs_poly);
 }
 extern "C" int hc_lv_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1, const uint64_t *consts) {
@@ -598,7 +616,7 @@ extern "C" int hc_lv_intt(hc_ctx *c, int level, const uint64_t *in, uint64_t *ou
 extern "C" int hc_lv_mul_tensor(hc_ctx *c, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *d0, uint64_t *d1, uint64_t *d2) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mul_tensor", level, a0, d0));
     if (!a1 || !b0 || !b1 || !d1 || !d2) return hc_fail(c, HC_ERR_ARG, "hc_lv_mul_tensor: null");
-    return hc_launch(c, "lv_tensor", hc_k_lv_tensor, dim3(64, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)a0, (const u64 *)a1, (const u64 *)b0, (const u64 *)b1, (u64 *)d0, (u64 *)d1, (u64 *)d2, (const HcMod *)c->d_mods, c->bs_poly);
+    return hc_launch(c, "lv_tensor", hc_k_lv_tensor, dim3(HC_GX_LV, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)a0, (const u64 *)a1, (const u64 *)b0, (const u64 *)b1, (u64 *)d0, (u64 *)d1, (u64 *)d2, (const HcMod *)c->d_mods, c->bs_poly);
 }
 // evaluatePolyFromPowerBasis' leaf as one launch (hc_k_lv_lincomb): out_k = sum_t consts[t] a_t,k (+ addc on k = 0). consts: HOST [nterms][level+1], addc: HOST [level+1] or null
 extern "C" int hc_lv_lincomb2(hc_ctx *c, int level, int nterms, const uint64_t *const *a0, const uint64_t *const *a1, const uint64_t *consts, const uint64_t *addc, uint64_t *out0, uint64_t *out1) {
@@ -611,7 +629,7 @@ extern "C" int hc_lv_lincomb2(hc_ctx *c, int level, int nterms, const uint64_t *
         for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[t][l] = (u64)((((u128)(consts[(size_t)t * (level + 1) + l] % q)) << 64) % q); }
     }
     if (addc) for (int l = 0; l <= level; l++) K.addc[l] = addc[l] % c->mods[(size_t)l].m.q;
-    return hc_launch(c, "lv_lincomb", hc_k_lv_lincomb, dim3(64, (unsigned)(level + 1), 2u * (unsigned)c->nb), P, K, nterms, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, c->bs_poly);
+    return hc_launch(c, "lv_lincomb", hc_k_lv_lincomb, dim3(HC_GX_LV, (unsigned)(level + 1), 2u * (unsigned)c->nb), P, K, nterms, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, c->bs_poly);
 }
 extern "C" int hc_lv_mod_raise(hc_ctx *c, int level, const uint64_t *in_q0, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mod_raise", level, in_q0, out));
@@ -619,7 +637,7 @@ extern "C" int hc_lv_mod_raise(hc_ctx *c, int level, const uint64_t *in_q0, uint
     HC_TRY(hc_ensure_mm(c, (size_t)c->nb)); c->hoist_cx = nullptr;
     u64 *t = c->ws_mm;                                                                  // one coefficient row per image
     HC_TRY(hc_intt_mm(c, in_q0, t, 1, 1, 1, 0, 0, 0, 0, c->nb, c->bs_poly, (size_t)HC_N));
-    HC_TRY(hc_launch(c, "mod_raise", hc_k_mod_raise, dim3(64, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)t, (u64 *)out, (const HcMod *)c->d_mods, c->bs_poly));
+    HC_TRY(hc_launch(c, "mod_raise", hc_k_mod_raise, dim3(HC_GX_LV, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)t, (u64 *)out, (const HcMod *)c->d_mods, c->bs_poly));
     return hc_ntt_mm(c, out, out, level + 1, level + 1, 0, 0, 1, 0, 0, 0, c->nb, c->bs_poly, c->bs_poly);
 }
 
@@ -1222,7 +1240,7 @@ static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, const HcKsS
     // source side of every digit's extension once per coefficient (y_i, v), then the target side inside the first pass of the digits' forward transforms (blockIdx.z =
     // digit + beta * image): the extended digits are never written in the coefficient domain
     const size_t yz = (size_t)(alpha + 1) * HC_N;
-    HC_TRY(hc_launch(c, "decomp:basis_yv", hc_k_basis_yv, dim3(64, (unsigned)(beta * nb)), (const u64 *)S.coef, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bx, nt, (size_t)alpha * HC_N, alpha, beta, S.coef_is));
+    HC_TRY(hc_launch(c, "decomp:basis_yv", hc_k_basis_yv, dim3(HC_GX_LV, (unsigned)(beta * nb)), (const u64 *)S.coef, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bx, nt, (size_t)alpha * HC_N, alpha, beta, S.coef_is));
     HcMmFuse F; F.ext_bs = P->bx; F.ext_rows = nt;
     return hc_ntt_mm(c, S.yv, S.digits, nt, nl, 0, 0, beta, yz, (size_t)nt * HC_N, alpha, nb, (size_t)beta * yz, S.digits_is, "decomp", &F);
 }
@@ -1230,7 +1248,7 @@ static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, const HcKsS
 static int hc_ks_mac(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *acc, size_t acc_is) {
     const int alpha = c->np, nl = level + 1, nt = nl + alpha;
     const int nb = c->nb, NB = nb <= 1 ? 1 : nb <= 2 ? 2 : HC_MAC_NB;                 // images per thread; more images = more image groups (blockIdx.z), each reading the key once
-#define HC_MAC_ALL(NN) hc_launch(c, "ks_mac_all", hc_k_ks_mac_all<NN>, dim3(64, (unsigned)nt, (unsigned)((nb + NN - 1) / NN)), (const u64 *)key.rows, cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, acc, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, key.beta, nb)
+#define HC_MAC_ALL(NN) hc_launch(c, "ks_mac_all", hc_k_ks_mac_all<NN>, dim3(HC_GX_MAC, (unsigned)nt, (unsigned)((nb + NN - 1) / NN)), (const u64 *)key.rows, cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, acc, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, key.beta, nb)
     return NB == 1 ? HC_MAC_ALL(1) : NB == 2 ? HC_MAC_ALL(2) : NB == 4 ? HC_MAC_ALL(4) : HC_MAC_ALL(8);
 #undef HC_MAC_ALL
 }
@@ -1242,11 +1260,11 @@ static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, size_t acc_is, co
     // InvNTT of the P rows of both components: rows y -> modulus nq + y (nl = 0)
     HC_TRY(hc_intt_mm(c, acc + (size_t)nl * HC_N, S.pc, alpha, 0, 2, (size_t)nt * HC_N, (size_t)alpha * HC_N, 0, 0, nb, acc_is, S.pc_is, "moddown"));
     const size_t yz = (size_t)(alpha + 1) * HC_N;
-    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(64, 2u * (unsigned)nb), (const u64 *)S.pc, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, (size_t)alpha * HC_N, 0, 2, S.pc_is));
+    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(HC_GX_LV, 2u * (unsigned)nb), (const u64 *)S.pc, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, (size_t)alpha * HC_N, 0, 2, S.pc_is));
     HcMmFuse F; F.ext_bs = P->bxdown; F.ext_rows = nl;            // {P} -> every Q limb inside the forward transform's first pass
     if (rot_gal) {   // a rotation: + c0 and the permutation ride in ModDown's last pass (d0, d1 = the rotated ciphertext)
         HC_TRY(hc_ntt_mm(c, S.yv, S.ext, nl, nl, 0, 0, 2, yz, (size_t)nl * HC_N, 0, nb, 2 * yz, S.ext_is, "moddown", &F));
-        return hc_launch(c, "ks_moddown_rotate_mm", hc_k_ks_moddown_rotate_mm, dim3(32, (unsigned)nl, 2u * (unsigned)nb), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)S.ext, (size_t)nl * HC_N, rot_c0, d0, d1, (const HcMod *)c->d_mods, (const HcTw *)P->pinv, (u32)(rot_gal & 0x1FFFF),
+        return hc_launch(c, "ks_moddown_rotate_mm", hc_k_ks_moddown_rotate_mm, dim3(HC_GX_ROT, (unsigned)nl, 2u * (unsigned)nb), (const u64 *)acc, (size_t)nt * HC_N, (const u64 *)S.ext, (size_t)nl * HC_N, rot_c0, d0, d1, (const HcMod *)c->d_mods, (const HcTw *)P->pinv, (u32)(rot_gal & 0x1FFFF),
                          acc_is, S.ext_is, c->bs_poly);
     }
     // (acc - NTT(ext)) / P, plus the addend if there is one (relinearisation: d_k + its key-switched part), in the epilogue of the extension's forward transform: d_k written once
@@ -1264,11 +1282,11 @@ static int hc_ks_moddown_rescale(hc_ctx *c, int level, u64 *acc, size_t acc_is, 
     const HcTw *qlinv; HC_TRY(hc_rescale_plan(c, level, &qlinv));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, nb = c->nb;
     const size_t tz = (size_t)(alpha + 1) * HC_N, yz = tz;
-    HC_TRY(hc_launch(c, "moddown:mdrs_prep", hc_k_mdrs_prep, dim3(64, 2u * (unsigned)nb), acc, (size_t)nt * HC_N, acc_is, add0, add0 ? (size_t)(add1 - add0) : (size_t)0, c->bs_poly, level, (const HcTw *)P->pinv, (const HcMod *)c->d_mods));
+    HC_TRY(hc_launch(c, "moddown:mdrs_prep", hc_k_mdrs_prep, dim3(HC_GX_LV, 2u * (unsigned)nb), acc, (size_t)nt * HC_N, acc_is, add0, add0 ? (size_t)(add1 - add0) : (size_t)0, c->bs_poly, level, (const HcTw *)P->pinv, (const HcMod *)c->d_mods));
     // InvNTT of row `level` and of the P rows of both components in one pair of launches: pc[z] = [u | the alpha P rows]
     HC_TRY(hc_intt_mm(c, acc, S.pc - (size_t)level * HC_N, nt, nl, 2, (size_t)nt * HC_N, tz, 0, level, nb, acc_is, S.pc_is, "moddown"));
-    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(64, 2u * (unsigned)nb), (const u64 *)(S.pc + HC_N), (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, tz, 0, 2, S.pc_is));
-    HC_TRY(hc_launch(c, "moddown:mdrs_last", hc_k_mdrs_last, dim3(64, 2u * (unsigned)nb), S.pc, alpha + 1, (const u64 *)S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, level, (const HcTw *)P->pinv));
+    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(HC_GX_LV, 2u * (unsigned)nb), (const u64 *)(S.pc + HC_N), (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, tz, 0, 2, S.pc_is));
+    HC_TRY(hc_launch(c, "moddown:mdrs_last", hc_k_mdrs_last, dim3(HC_GX_LV, 2u * (unsigned)nb), S.pc, alpha + 1, (const u64 *)S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, level, (const HcTw *)P->pinv));
     HcMmFuse F; F.ext_bs = P->bxdown; F.ext_rows = nl; F.lift_level = level; F.lift_t = S.pc; F.lift_t_zs = tz; F.lift_t_is = S.pc_is; F.lift_pmul = P->pmod;
     F.epi_x = acc; F.epi_x_zs = (size_t)nt * HC_N; F.epi_x_is = acc_is; F.epi_mul = P->pinv_qlinv;
     if (add0) { F.epi_add = add0; F.epi_add_zs = (size_t)(add1 - add0); F.epi_add_is = c->bs_poly; F.epi_add_mul = qlinv; }
@@ -1389,7 +1407,7 @@ extern "C" int hc_keyswitch_qp_rotate(hc_ctx *c, uint64_t key_id, uint64_t galEl
     }
     HC_TRY(hc_ks_mac(c, *key, level, cx, S, S.acc, S.acc_is));
     const int nl = level + 1, nt = nl + c->np;
-    return hc_launch(c, "qp_rotate_finish", hc_k_qp_rotate_finish, dim3(32, (unsigned)nt, 2u * (unsigned)c->nb), (const u64 *)S.acc, S.acc_is, (const u64 *)pc0, c->bs_poly, (u64 *)out, c->bs_qp, (const HcMod *)c->d_mods, nl, c->nq, nt, (u32)(galEl & 0x1FFFF), accumulate ? 1 : 0);
+    return hc_launch(c, "qp_rotate_finish", hc_k_qp_rotate_finish, dim3(HC_GX_ROT, (unsigned)nt, 2u * (unsigned)c->nb), (const u64 *)S.acc, S.acc_is, (const u64 *)pc0, c->bs_poly, (u64 *)out, c->bs_qp, (const HcMod *)c->d_mods, nl, c->nq, nt, (u32)(galEl & 0x1FFFF), accumulate ? 1 : 0);
 }
 // The baby steps of a linear transform as ONE call: nrot hoisted rotations of the decomposition hc_keyswitch_decompose(level, cx) left, each = hc_keyswitch_qp_rotate(key_ids[r],
 // galEls[r], level, pc0, cx, outs[r], 1, 0). The inner products of up to 16 / images rotations run in one launch (the digits - n x beta x nt rows - are read once for
@@ -1418,12 +1436,12 @@ extern "C" int hc_keyswitch_qp_rotate_many(hc_ctx *c, int nrot, const uint64_t *
         const int nr = nrot - r0 < R ? nrot - r0 : R;
         HcKeyPtrs K; memset(&K, 0, sizeof K); int beta = 0;
         for (int r = 0; r < nr; r++) { K.k[r] = keys[(size_t)(r0 + r)]->rows; beta = keys[(size_t)(r0 + r)]->beta; }
-        const dim3 grid(64, (unsigned)nt);
+        const dim3 grid(HC_GX_MACM, (unsigned)nt);
 #define HC_MAC_MULTI(RR, NN) hc_launch(c, "ks_mac_multi", hc_k_ks_mac_multi<RR, NN>, grid, K, nr, (const u64 *)cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, c->ws_accm, acc_rs, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta, nb)
         if (NB == 8) HC_TRY(HC_MAC_MULTI(2, 8)); else if (NB == 4) HC_TRY(HC_MAC_MULTI(4, 4)); else if (NB == 2) HC_TRY(HC_MAC_MULTI(8, 2)); else HC_TRY(HC_MAC_MULTI(8, 1));
 #undef HC_MAC_MULTI
         for (int r = 0; r < nr; r++)
-            HC_TRY(hc_launch(c, "qp_rotate_finish", hc_k_qp_rotate_finish, dim3(32, (unsigned)nt, 2u * (unsigned)nb), (const u64 *)(c->ws_accm + (size_t)r * acc_rs), acc_is, (const u64 *)pc0, c->bs_poly, (u64 *)outs[r0 + r], c->bs_qp,
+            HC_TRY(hc_launch(c, "qp_rotate_finish", hc_k_qp_rotate_finish, dim3(HC_GX_ROT, (unsigned)nt, 2u * (unsigned)nb), (const u64 *)(c->ws_accm + (size_t)r * acc_rs), acc_is, (const u64 *)pc0, c->bs_poly, (u64 *)outs[r0 + r], c->bs_qp,
                              (const HcMod *)c->d_mods, nl, c->nq, nt, (u32)(galEls[r0 + r] & 0x1FFFF), 0));
     }
     return HC_OK;
@@ -1458,7 +1476,7 @@ extern "C" int hc_qp_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const
     HcLvConsts K; memset(&K, 0, sizeof K);
     const size_t as = (size_t)(a1 - a0), bs = (size_t)(b1 - b0), os = (size_t)(out1 - out0);
     const bool b_shared = b0 == b1 && op != HC_LV_ADD, inthread = b_shared && c->nb > 1;                                  // a plaintext (an encoded diagonal): one for every image
-    const dim3 grid(64, (unsigned)(level + 1 + c->np), inthread ? 2u : 2u * (unsigned)c->nb);
+    const dim3 grid(HC_GX_LV, (unsigned)(level + 1 + c->np), inthread ? 2u : 2u * (unsigned)c->nb);
     const int nin = inthread ? c->nb : 1; const size_t ia = c->bs_qp, ib = b_shared ? (size_t)0 : c->bs_qp, io = c->bs_qp;
     switch (op) {
         case HC_LV_MUL: return hc_launch(c, "hc_qp_op2(mul)", hc_k_lv_pointwise<HC_PW_MUL>, grid, (const u64 *)a0, (const u64 *)b0, (u64 *)out0, (const HcMod *)c->d_mods, K, as, bs, os, level + 1, c->nq, 2, nin, ia, ib, io);
@@ -1476,7 +1494,7 @@ extern "C" int hc_qp_mul_sum(hc_ctx *c, int level, int nterms, const uint64_t *c
     HcTermPtrs P; memset(&P, 0, sizeof P);
     for (int t = 0; t < nterms; t++) { if (!a[t] || !pt[t] || a[t] == out) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum: null or aliased term %d", t); P.a[t] = (const u64 *)a[t]; P.pt[t] = (const u64 *)pt[t]; }
     const int nt = level + 1 + c->np;
-    return hc_launch(c, "qp_mul_sum", hc_k_qp_mul_sum, dim3(64, (unsigned)nt, 2), P, nterms, (u64 *)out, (const HcMod *)c->d_mods, level + 1, c->nq, nt, c->nb, c->bs_qp, c->bs_qp, accumulate ? 1 : 0);
+    return hc_launch(c, "qp_mul_sum", hc_k_qp_mul_sum, dim3(HC_GX_QPMS, (unsigned)nt, 2), P, nterms, (u64 *)out, (const HcMod *)c->d_mods, level + 1, c->nq, nt, c->nb, c->bs_qp, c->bs_qp, accumulate ? 1 : 0);
 }
 
 // ------------------------------------------------------------------ L1
