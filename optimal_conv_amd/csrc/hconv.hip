@@ -22,9 +22,22 @@
 #include "hc_gomath.h"
 // workgroups per row of the streaming (grid-stride) kernels of the leveled evaluator and the key switch: a thread strides over 65536 / (256 x this) coefficients.
 // Measured on the convReLU 5 1 tail (profiles/round4_chain_occupancy_ab.txt, rounds 7-8): the inner products and the giant-step sums at 256 (one coefficient per thread)
-// and the rotation finishes at 128 take 2.3 % off a layer against 64 / 32; the pointwise kernels (HC_GX_LV) lose at 128 and at 256
+// and the rotation finishes at 128 take 2.3 % off a layer against 64 / 32; per kernel (HIP-event profile): the extension's source side (basis_yv, mdrs) and the tensor product gain at 256, the polynomial leaves at
+// 128, the plain pointwise operations at 32 (at 256 they take twice as long: a workgroup's fixed cost against 256 coefficients of work)
 #ifndef HC_GX_LV
 #define HC_GX_LV 64
+#endif
+#ifndef HC_GX_PW
+#define HC_GX_PW 32
+#endif
+#ifndef HC_GX_YV
+#define HC_GX_YV 256
+#endif
+#ifndef HC_GX_TEN
+#define HC_GX_TEN 256
+#endif
+#ifndef HC_GX_LIN
+#define HC_GX_LIN 128
 #endif
 #ifndef HC_GX_ROT
 #define HC_GX_ROT 128
@@ -519,7 +532,7 @@ static int hc_lv_pw(hc_ctx *c, const char *fn, int level, const uint64_t *a, con
         for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[l] = h_pair(consts_host[l] % q, q); }
     }
     const bool inthread = b_shared && c->nb > 1;
-    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(HC_GX_LV, (unsigned)(level + 1), inthread ? 1u : (unsigned)c->nb), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, K, (size_t)0, (size_t)0, (size_t)0, HC_ROW_IS_MOD, 0,
+    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(HC_GX_PW, (unsigned)(level + 1), inthread ? 1u : (unsigned)c->nb), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, K, (size_t)0, (size_t)0, (size_t)0, HC_ROW_IS_MOD, 0,
                      1, inthread ? c->nb : 1, c->bs_poly, b_shared ? (size_t)0 : c->bs_poly, c->bs_poly);
 }
 // the same operations on both polynomials of a ciphertext in one launch (they may live in separate allocations; b1 == b0 for a plaintext operand)
@@ -535,7 +548,7 @@ static int hc_lv_pw2(hc_ctx *c, const char *fn, int level, const u64 *a0, const 
     }
     const u64 *bb0 = b0 ? b0 : a0, *bb1 = b1 ? b1 : a1;
     const bool b_shared = (OP == HC_PW_MUL || OP == HC_PW_MAC) && b0 && b0 == b1, inthread = b_shared && c->nb > 1;      // one plaintext for both polynomials = one plaintext for every image
-    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(HC_GX_LV, (unsigned)(level + 1), inthread ? 2u : 2u * (unsigned)c->nb), a0, bb0, o0, (const HcMod *)c->d_mods, K, (size_t)(a1 - a0), (size_t)(bb1 - bb0), (size_t)(o1 - o0), HC_ROW_IS_MOD, 0,
+    return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(HC_GX_PW, (unsigned)(level + 1), inthread ? 2u : 2u * (unsigned)c->nb), a0, bb0, o0, (const HcMod *)c->d_mods, K, (size_t)(a1 - a0), (size_t)(bb1 - bb0), (size_t)(o1 - o0), HC_ROW_IS_MOD, 0,
                      2, inthread ? c->nb : 1, c->bs_poly, b_shared ? (size_t)0 : c->bs_poly, c->bs_poly);
 }
 extern "C" int hc_lv_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1, const uint64_t *consts) {
@@ -616,7 +629,7 @@ extern "C" int hc_lv_intt(hc_ctx *c, int level, const uint64_t *in, uint64_t *ou
 extern "C" int hc_lv_mul_tensor(hc_ctx *c, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *d0, uint64_t *d1, uint64_t *d2) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mul_tensor", level, a0, d0));
     if (!a1 || !b0 || !b1 || !d1 || !d2) return hc_fail(c, HC_ERR_ARG, "hc_lv_mul_tensor: null");
-    return hc_launch(c, "lv_tensor", hc_k_lv_tensor, dim3(HC_GX_LV, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)a0, (const u64 *)a1, (const u64 *)b0, (const u64 *)b1, (u64 *)d0, (u64 *)d1, (u64 *)d2, (const HcMod *)c->d_mods, c->bs_poly);
+    return hc_launch(c, "lv_tensor", hc_k_lv_tensor, dim3(HC_GX_TEN, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)a0, (const u64 *)a1, (const u64 *)b0, (const u64 *)b1, (u64 *)d0, (u64 *)d1, (u64 *)d2, (const HcMod *)c->d_mods, c->bs_poly);
 }
 // evaluatePolyFromPowerBasis' leaf as one launch (hc_k_lv_lincomb): out_k = sum_t consts[t] a_t,k (+ addc on k = 0). consts: HOST [nterms][level+1], addc: HOST [level+1] or null
 extern "C" int hc_lv_lincomb2(hc_ctx *c, int level, int nterms, const uint64_t *const *a0, const uint64_t *const *a1, const uint64_t *consts, const uint64_t *addc, uint64_t *out0, uint64_t *out1) {
@@ -629,7 +642,7 @@ extern "C" int hc_lv_lincomb2(hc_ctx *c, int level, int nterms, const uint64_t *
         for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[t][l] = (u64)((((u128)(consts[(size_t)t * (level + 1) + l] % q)) << 64) % q); }
     }
     if (addc) for (int l = 0; l <= level; l++) K.addc[l] = addc[l] % c->mods[(size_t)l].m.q;
-    return hc_launch(c, "lv_lincomb", hc_k_lv_lincomb, dim3(HC_GX_LV, (unsigned)(level + 1), 2u * (unsigned)c->nb), P, K, nterms, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, c->bs_poly);
+    return hc_launch(c, "lv_lincomb", hc_k_lv_lincomb, dim3(HC_GX_LIN, (unsigned)(level + 1), 2u * (unsigned)c->nb), P, K, nterms, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, c->bs_poly);
 }
 extern "C" int hc_lv_mod_raise(hc_ctx *c, int level, const uint64_t *in_q0, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mod_raise", level, in_q0, out));
@@ -1240,7 +1253,7 @@ static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, const HcKsS
     // source side of every digit's extension once per coefficient (y_i, v), then the target side inside the first pass of the digits' forward transforms (blockIdx.z =
     // digit + beta * image): the extended digits are never written in the coefficient domain
     const size_t yz = (size_t)(alpha + 1) * HC_N;
-    HC_TRY(hc_launch(c, "decomp:basis_yv", hc_k_basis_yv, dim3(HC_GX_LV, (unsigned)(beta * nb)), (const u64 *)S.coef, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bx, nt, (size_t)alpha * HC_N, alpha, beta, S.coef_is));
+    HC_TRY(hc_launch(c, "decomp:basis_yv", hc_k_basis_yv, dim3(HC_GX_YV, (unsigned)(beta * nb)), (const u64 *)S.coef, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bx, nt, (size_t)alpha * HC_N, alpha, beta, S.coef_is));
     HcMmFuse F; F.ext_bs = P->bx; F.ext_rows = nt;
     return hc_ntt_mm(c, S.yv, S.digits, nt, nl, 0, 0, beta, yz, (size_t)nt * HC_N, alpha, nb, (size_t)beta * yz, S.digits_is, "decomp", &F);
 }
@@ -1260,7 +1273,7 @@ static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, size_t acc_is, co
     // InvNTT of the P rows of both components: rows y -> modulus nq + y (nl = 0)
     HC_TRY(hc_intt_mm(c, acc + (size_t)nl * HC_N, S.pc, alpha, 0, 2, (size_t)nt * HC_N, (size_t)alpha * HC_N, 0, 0, nb, acc_is, S.pc_is, "moddown"));
     const size_t yz = (size_t)(alpha + 1) * HC_N;
-    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(HC_GX_LV, 2u * (unsigned)nb), (const u64 *)S.pc, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, (size_t)alpha * HC_N, 0, 2, S.pc_is));
+    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(HC_GX_YV, 2u * (unsigned)nb), (const u64 *)S.pc, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, (size_t)alpha * HC_N, 0, 2, S.pc_is));
     HcMmFuse F; F.ext_bs = P->bxdown; F.ext_rows = nl;            // {P} -> every Q limb inside the forward transform's first pass
     if (rot_gal) {   // a rotation: + c0 and the permutation ride in ModDown's last pass (d0, d1 = the rotated ciphertext)
         HC_TRY(hc_ntt_mm(c, S.yv, S.ext, nl, nl, 0, 0, 2, yz, (size_t)nl * HC_N, 0, nb, 2 * yz, S.ext_is, "moddown", &F));
@@ -1282,11 +1295,11 @@ static int hc_ks_moddown_rescale(hc_ctx *c, int level, u64 *acc, size_t acc_is, 
     const HcTw *qlinv; HC_TRY(hc_rescale_plan(c, level, &qlinv));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, nb = c->nb;
     const size_t tz = (size_t)(alpha + 1) * HC_N, yz = tz;
-    HC_TRY(hc_launch(c, "moddown:mdrs_prep", hc_k_mdrs_prep, dim3(HC_GX_LV, 2u * (unsigned)nb), acc, (size_t)nt * HC_N, acc_is, add0, add0 ? (size_t)(add1 - add0) : (size_t)0, c->bs_poly, level, (const HcTw *)P->pinv, (const HcMod *)c->d_mods));
+    HC_TRY(hc_launch(c, "moddown:mdrs_prep", hc_k_mdrs_prep, dim3(HC_GX_YV, 2u * (unsigned)nb), acc, (size_t)nt * HC_N, acc_is, add0, add0 ? (size_t)(add1 - add0) : (size_t)0, c->bs_poly, level, (const HcTw *)P->pinv, (const HcMod *)c->d_mods));
     // InvNTT of row `level` and of the P rows of both components in one pair of launches: pc[z] = [u | the alpha P rows]
     HC_TRY(hc_intt_mm(c, acc, S.pc - (size_t)level * HC_N, nt, nl, 2, (size_t)nt * HC_N, tz, 0, level, nb, acc_is, S.pc_is, "moddown"));
-    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(HC_GX_LV, 2u * (unsigned)nb), (const u64 *)(S.pc + HC_N), (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, tz, 0, 2, S.pc_is));
-    HC_TRY(hc_launch(c, "moddown:mdrs_last", hc_k_mdrs_last, dim3(HC_GX_LV, 2u * (unsigned)nb), S.pc, alpha + 1, (const u64 *)S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, level, (const HcTw *)P->pinv));
+    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(HC_GX_YV, 2u * (unsigned)nb), (const u64 *)(S.pc + HC_N), (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, tz, 0, 2, S.pc_is));
+    HC_TRY(hc_launch(c, "moddown:mdrs_last", hc_k_mdrs_last, dim3(HC_GX_YV, 2u * (unsigned)nb), S.pc, alpha + 1, (const u64 *)S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, level, (const HcTw *)P->pinv));
     HcMmFuse F; F.ext_bs = P->bxdown; F.ext_rows = nl; F.lift_level = level; F.lift_t = S.pc; F.lift_t_zs = tz; F.lift_t_is = S.pc_is; F.lift_pmul = P->pmod;
     F.epi_x = acc; F.epi_x_zs = (size_t)nt * HC_N; F.epi_x_is = acc_is; F.epi_mul = P->pinv_qlinv;
     if (add0) { F.epi_add = add0; F.epi_add_zs = (size_t)(add1 - add0); F.epi_add_is = c->bs_poly; F.epi_add_mul = qlinv; }
@@ -1476,7 +1489,7 @@ extern "C" int hc_qp_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const
     HcLvConsts K; memset(&K, 0, sizeof K);
     const size_t as = (size_t)(a1 - a0), bs = (size_t)(b1 - b0), os = (size_t)(out1 - out0);
     const bool b_shared = b0 == b1 && op != HC_LV_ADD, inthread = b_shared && c->nb > 1;                                  // a plaintext (an encoded diagonal): one for every image
-    const dim3 grid(HC_GX_LV, (unsigned)(level + 1 + c->np), inthread ? 2u : 2u * (unsigned)c->nb);
+    const dim3 grid(HC_GX_PW, (unsigned)(level + 1 + c->np), inthread ? 2u : 2u * (unsigned)c->nb);
     const int nin = inthread ? c->nb : 1; const size_t ia = c->bs_qp, ib = b_shared ? (size_t)0 : c->bs_qp, io = c->bs_qp;
     switch (op) {
         case HC_LV_MUL: return hc_launch(c, "hc_qp_op2(mul)", hc_k_lv_pointwise<HC_PW_MUL>, grid, (const u64 *)a0, (const u64 *)b0, (u64 *)out0, (const HcMod *)c->d_mods, K, as, bs, os, level + 1, c->nq, 2, nin, ia, ib, io);
