@@ -201,6 +201,9 @@ int hc_keyswitch_hoisted(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t
  * extended-basis pairs (the hoisted rotations), pt[t] = plaintexts [level+1+np][N] (the encoded diagonals); a, pt: HOST arrays of device pointers; accumulate != 0
  * adds to what out holds. The same residues as nterms hc_qp_op2 calls (HC_LV_MUL, then HC_LV_MUL_ACC); out must not be one of the a[t]. */
 int hc_qp_mul_sum(hc_ctx *ctx, int level, int nterms, const uint64_t *const *a, const uint64_t *const *pt, uint64_t *out, int accumulate);
+/* two giant steps in one pass over the rotations: out_h (+)= sum_t a[t] (*) pt_h[t], h = 0, 1 (pt0[t] or pt1[t] NULL: that giant step has no diagonal for baby step t).
+ * Same residues as two hc_qp_mul_sum calls; the rotated ciphertexts are read once. a, pt0, pt1: HOST arrays of device pointers. */
+int hc_qp_mul_sum2(hc_ctx *ctx, int level, int nterms, const uint64_t *const *a, const uint64_t *const *pt0, const uint64_t *const *pt1, uint64_t *out0, uint64_t *out1, int accumulate0, int accumulate1);
 
 /* ---- L1: the fused hot path ---- */
 /* pl_ker as prep_Ker leaves it (conv.go:510-515): HOST array [max_ob][2][N], level 1, NTT domain. */

@@ -1510,6 +1510,23 @@ extern "C" int hc_qp_mul_sum(hc_ctx *c, int level, int nterms, const uint64_t *c
     return hc_launch(c, "qp_mul_sum", hc_k_qp_mul_sum, dim3(HC_GX_QPMS, (unsigned)nt, 2), P, nterms, (u64 *)out, (const HcMod *)c->d_mods, level + 1, c->nq, nt, c->nb, c->bs_qp, c->bs_qp, accumulate ? 1 : 0);
 }
 
+// two giant steps' sums from one pass over the rotations: out_h (+)= sum_t a[t] (*) pt_h[t], h = 0, 1; pt0[t] / pt1[t] may be NULL (that giant step has no diagonal for baby step
+// t; every t has at least one). The residues of two hc_qp_mul_sum calls.
+extern "C" int hc_qp_mul_sum2(hc_ctx *c, int level, int nterms, const uint64_t *const *a, const uint64_t *const *pt0, const uint64_t *const *pt1, uint64_t *out0, uint64_t *out1, int accumulate0, int accumulate1) {
+    HC_ENTER(c);
+    if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum2: level %d outside 0..%d or no special primes", level, c->nq - 1);
+    if (!a || !pt0 || !pt1 || !out0 || !out1 || out0 == out1 || nterms < 1 || nterms > HC_MAXTERMS) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum2: bad arguments (1 <= nterms <= %d, two different outputs)", HC_MAXTERMS);
+    HcTermPtrs2 P; memset(&P, 0, sizeof P);
+    for (int t = 0; t < nterms; t++) {
+        if (!a[t] || (!pt0[t] && !pt1[t]) || a[t] == out0 || a[t] == out1) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum2: null or aliased term %d", t);
+        P.a[t] = (const u64 *)a[t]; P.pt0[t] = (const u64 *)pt0[t]; P.pt1[t] = (const u64 *)pt1[t];
+    }
+    const int nt = level + 1 + c->np, nb = c->nb, NB = nb <= 1 ? 1 : nb <= 2 ? 2 : 4;
+#define HC_QPMS2(NN) hc_launch(c, "qp_mul_sum2", hc_k_qp_mul_sum2<NN>, dim3(HC_GX_QPMS, (unsigned)nt, 2u * (unsigned)((nb + NN - 1) / NN)), P, nterms, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, level + 1, c->nq, nt, nb, c->bs_qp, c->bs_qp, accumulate0 ? 1 : 0, accumulate1 ? 1 : 0)
+    return NB == 1 ? HC_QPMS2(1) : NB == 2 ? HC_QPMS2(2) : HC_QPMS2(4);
+#undef HC_QPMS2
+}
+
 // ------------------------------------------------------------------ L1
 static int hc_ensure_cts(hc_ctx *c, size_t rows) {
     if (c->ws_cts_rows >= rows) return HC_OK;

@@ -648,26 +648,44 @@ struct Boot {
         DCt res = new_ct(L, 1, ct.scale * lt.pt_scale); bool have_res[2] = {false, false};
         auto add_to_res = [&](int k, const std::shared_ptr<uint64_t> &x) { if (have_res[k]) HCR(hc_lv_add(hc, L, res.p[k].get(), x.get(), res.p[k].get())); else { res.p[k] = x; have_res[k] = true; } };
         auto B = block_qp2(); bool haveB = false;
+        // the diagonal sums of all giant steps first, TWO per pass over the rotations (hc_qp_mul_sum2: the rotated ciphertexts - the largest operands of a linear transform - are
+        // read once per pair instead of once per giant step); giant step 0's sum lands in the accumulators B, which the other giant steps' key switches then add to
+        // (modular sums commute: the residues of the reference's order)
+        struct Sum { uint64_t *out; std::map<int, const uint64_t *> pt; };
+        std::vector<Sum> sums; std::map<int, std::shared_ptr<uint64_t>> Aof;
+        if (index.count(0)) { Sum s0; s0.out = B.get(); for (int i : index[0]) if (i) s0.pt[i] = lt.giant.at(0).at(i).p.get(); if (!s0.pt.empty()) { sums.push_back(s0); haveB = true; } }
+        for (auto &ix : index) {
+            const int j = ix.first; if (j == 0) continue;
+            const auto &row = lt.giant.at(j * lt.n1);
+            Sum sj; for (int i : ix.second) if (i) sj.pt[i] = row.at(i).p.get();
+            if (!sj.pt.empty()) { Aof[j] = block_qp2(); sj.out = Aof[j].get(); sums.push_back(sj); }
+        }
+        static const bool one_by_one_sums = getenv("HCONV_SUMS_ONE_BY_ONE") != nullptr;
+        for (size_t u = 0; u < sums.size(); u += 2) {
+            if (u + 1 == sums.size() || one_by_one_sums) {
+                for (size_t v = u; v < std::min(u + 2, sums.size()); v++) {
+                    std::vector<const uint64_t *> as, pts; for (auto &kv : sums[v].pt) { as.push_back(rot[kv.first].get()); pts.push_back(kv.second); }
+                    HCR(hc_qp_mul_sum(hc, L, (int)as.size(), as.data(), pts.data(), sums[v].out, 0));
+                }
+                continue;
+            }
+            std::set<int> un; for (auto &kv : sums[u].pt) un.insert(kv.first); for (auto &kv : sums[u + 1].pt) un.insert(kv.first);
+            std::vector<const uint64_t *> as, p0, p1;
+            for (int i : un) { as.push_back(rot[i].get()); p0.push_back(sums[u].pt.count(i) ? sums[u].pt[i] : nullptr); p1.push_back(sums[u + 1].pt.count(i) ? sums[u + 1].pt[i] : nullptr); }
+            HCR(hc_qp_mul_sum2(hc, L, (int)as.size(), as.data(), p0.data(), p1.data(), sums[u].out, sums[u + 1].out, 0, 0));
+        }
         for (auto &ix : index) {
             const int j = ix.first; if (j == 0) continue;
             const int g = j * lt.n1; const uint64_t gal = gal_rot(g);
             const auto &row = lt.giant.at(g);
-            auto A = block_qp2(); bool haveA = false;
-            {   std::vector<const uint64_t *> as, pts;                                         // the giant step's diagonal sum over its baby steps: one launch
-                for (int i : ix.second) if (i) { as.push_back(rot[i].get()); pts.push_back(row.at(i).p.get()); }
-                if (!as.empty()) { HCR(hc_qp_mul_sum(hc, L, (int)as.size(), as.data(), pts.data(), A.get(), 0)); haveA = true; }
-            }
+            const bool haveA = Aof.count(j) != 0;
             auto a0 = block(), a1 = block();
-            if (haveA) HCR(hc_mod_down2(hc, L, A.get(), a0.get(), a1.get()));
+            if (haveA) HCR(hc_mod_down2(hc, L, Aof[j].get(), a0.get(), a1.get()));
             else { HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), zeros.data(), a0.get())); HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), zeros.data(), a1.get())); }
             if (row.count(0)) { const uint64_t *pt = row.at(0).p.get(); HCR(hc_lv_op2(hc, HC_LV_MUL_ACC, L, ct.p[0].get(), ct.p[1].get(), pt, pt, a0.get(), a1.get(), nullptr)); }
             { auto t = block(); HCR(hc_lv_permute(hc, gal, L, a0.get(), t.get())); add_to_res(0, t); }
             HCR(hc_keyswitch_qp_rotate(hc, key(gal, L, 2), gal, L, nullptr, a1.get(), B.get(), 0, haveB ? 1 : 0)); n_keyswitch++; haveB = true;     // SwitchKeysInPlaceNoModDown, permuted into the accumulators
-        }
-        if (index.count(0)) {
-            std::vector<const uint64_t *> as, pts;
-            for (int i : index[0]) if (i) { as.push_back(rot[i].get()); pts.push_back(lt.giant.at(0).at(i).p.get()); }
-            if (!as.empty()) { HCR(hc_qp_mul_sum(hc, L, (int)as.size(), as.data(), pts.data(), B.get(), haveB ? 1 : 0)); haveB = true; }
+            Aof.erase(j);
         }
         static const bool split_rescale = getenv("HCONV_NO_FUSED_RESCALE") != nullptr;
         const bool fuse = fuse_min_scale > 0 && haveB && L >= 2 && !split_rescale && res.scale / (double)Q[(size_t)L] >= fuse_min_scale / 2;

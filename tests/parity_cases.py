@@ -648,6 +648,25 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
         got_sum = run(f"qp_mul_sum accumulate={accu}", lambda *a_, accu=accu: mul_sum(*a_, accumulate=accu), ins, [("q", QW)], init=[acc.reshape(n, -1)])
         got_chain = run(f"qp_op2 chain accumulate={accu}", lambda *a_, accu=accu: mul_chain(*a_, accumulate=accu), ins, [("q", QW)], init=[acc.reshape(n, -1)])
         eq(got_sum[0], got_chain[0], f"qp_mul_sum == the chain of qp_op2 products (accumulate={accu})")
+    # two giant steps in one pass == two qp_mul_sum calls: giant step 0 takes terms 0..6 (into its accumulator), giant step 1 terms 2..8 (fresh): absent diagonals on both sides
+    pts2 = [np.stack([rnd(qp_mod(t)) for t in range(nt)]) for _ in range(NT)]
+    use0, use1 = list(range(0, 7)), list(range(2, 9))
+
+    def sum2(*args):
+        xs, p0, p1, o0, o1 = args[:NT], args[NT:2 * NT], args[2 * NT:3 * NT], args[3 * NT], args[3 * NT + 1]
+        arr = C.c_void_p * NT
+        ck(L.hc_qp_mul_sum2(h, level, NT, arr(*xs), arr(*[p0[t] if t in use0 else None for t in range(NT)]), arr(*[p1[t] if t in use1 else None for t in range(NT)]), o0, o1, 1, 0))
+
+    def sum1x2(*args):
+        xs, p0, p1, o0, o1 = args[:NT], args[NT:2 * NT], args[2 * NT:3 * NT], args[3 * NT], args[3 * NT + 1]
+        a7 = C.c_void_p * 7
+        ck(L.hc_qp_mul_sum(h, level, 7, a7(*[xs[t] for t in use0]), a7(*[p0[t] for t in use0]), o0, 1))
+        ck(L.hc_qp_mul_sum(h, level, 7, a7(*[xs[t] for t in use1]), a7(*[p1[t] for t in use1]), o1, 0))
+    ins2 = [(x_, "q") for x_ in Xs] + [(p_, "s") for p_ in pts] + [(p_, "s") for p_ in pts2]
+    g2 = run("qp_mul_sum2", sum2, ins2, [("q", QW), ("q", QW)], init=[acc.reshape(n, -1), acc.reshape(n, -1)])
+    g1 = run("qp_mul_sum x2", sum1x2, ins2, [("q", QW), ("q", QW)], init=[acc.reshape(n, -1), acc.reshape(n, -1)])
+    for k_ in range(2):
+        eq(g2[k_], g1[k_], f"qp_mul_sum2 == two qp_mul_sum calls (giant step {k_})")
     run("qp_permute2", lambda x, o: ck(L.hc_qp_permute2(h, C.c_uint64(gal), level, x, o)), [(X, "q")], [("q", QW)])
     ctx.close()
 
