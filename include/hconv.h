@@ -204,6 +204,8 @@ int hc_qp_mul_sum(hc_ctx *ctx, int level, int nterms, const uint64_t *const *a, 
 /* two giant steps in one pass over the rotations: out_h (+)= sum_t a[t] (*) pt_h[t], h = 0, 1 (pt0[t] or pt1[t] NULL: that giant step has no diagonal for baby step t).
  * Same residues as two hc_qp_mul_sum calls; the rotated ciphertexts are read once. a, pt0, pt1: HOST arrays of device pointers. */
 int hc_qp_mul_sum2(hc_ctx *ctx, int level, int nterms, const uint64_t *const *a, const uint64_t *const *pt0, const uint64_t *const *pt1, uint64_t *out0, uint64_t *out1, int accumulate0, int accumulate1);
+/* the same for ngiant <= 4 giant steps: out[h] (+)= sum_t a[t] (*) pt[h * nterms + t] (NULL entries: no diagonal), accumulate[h] per output. HOST arrays. */
+int hc_qp_mul_sum_many(hc_ctx *ctx, int level, int nterms, int ngiant, const uint64_t *const *a, const uint64_t *const *pt, uint64_t *const *out, const int *accumulate);
 
 /* ---- L1: the fused hot path ---- */
 /* pl_ker as prep_Ker leaves it (conv.go:510-515): HOST array [max_ob][2][N], level 1, NTT domain. */

@@ -1790,38 +1790,43 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_qp_mul_sum(HcTermPtrs P, int nter
         for (int g = 0; g < HC_MAXIMG; g++) if (g < n) out[(size_t)g * o_is + comp + base + i] = s[g];
     }
 }
-// TWO giant steps' sums from ONE read of the rotations: out_h (+)= sum_t a_t (*) pt_h,t, h = 0, 1, over the union of their baby steps (pt_h,t null where giant step h has no
-// diagonal for baby step t). hc_k_qp_mul_sum reads every rotated ciphertext once per giant step - 1.9 GB per launch at 8 images on the top level, not cache-resident, which is
-// what bounds it. NB images per thread (two 128-bit accumulators each), blockIdx.z = component + 2 * image group. grid = (gx, nt, 2 * groups)
-struct HcTermPtrs2 { const u64 *a[HC_MAXTERMS]; const u64 *pt0[HC_MAXTERMS]; const u64 *pt1[HC_MAXTERMS]; };
-template <int NB>
-__global__ __launch_bounds__(HC_TPB) void hc_k_qp_mul_sum2(HcTermPtrs2 P, int nterms, u64 *out0, u64 *out1, const HcMod *mods, int nlq, int nqt, int nt, int n, size_t a_is, size_t o_is, int acc0, int acc1) {
+// SEVERAL (G <= 4) giant steps' sums from ONE read of the rotations: out_h (+)= sum_t a_t (*) pt_h,t, h < G, over the union of their baby steps (pt_h,t null where giant step h
+// has no diagonal for baby step t). hc_k_qp_mul_sum reads every rotated ciphertext once per giant step - 1.9 GB per launch at 8 images on the top level, not cache-resident,
+// which is what bounds it. NB images per thread (G 128-bit accumulators each), blockIdx.z = component + 2 * image group. grid = (gx, nt, 2 * groups)
+#define HC_MAXGIANT 4
+struct HcTermPtrsG { const u64 *a[HC_MAXTERMS]; const u64 *pt[HC_MAXGIANT][HC_MAXTERMS]; u64 *out[HC_MAXGIANT]; int acc[HC_MAXGIANT]; };
+template <int G, int NB>
+__global__ __launch_bounds__(HC_TPB) void hc_k_qp_mul_sum_g(HcTermPtrsG P, int nterms, const HcMod *mods, int nlq, int nqt, int nt, int n, size_t a_is, size_t o_is) {
     const int row = blockIdx.y, k = blockIdx.z & 1, g0 = (int)(blockIdx.z >> 1) * NB; const HcMod m = mods[row < nlq ? row : nqt + (row - nlq)];
-    const size_t base = (size_t)row * 65536 + (size_t)k * nt * 65536;
+    const size_t prow = (size_t)row * 65536, base = prow + (size_t)k * nt * 65536;
     n = n - g0 < NB ? n - g0 : NB;
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
-        u128 T0[NB], T1[NB]; u64 s0[NB], s1[NB];
+        u128 T[G][NB]; u64 s[G][NB];
 #pragma unroll
-        for (int g = 0; g < NB; g++) {
-            s0[g] = (acc0 && g < n) ? out0[(size_t)(g0 + g) * o_is + base + i] : 0;
-            s1[g] = (acc1 && g < n) ? out1[(size_t)(g0 + g) * o_is + base + i] : 0;
-        }
+        for (int h = 0; h < G; h++)
+#pragma unroll
+            for (int g = 0; g < NB; g++) s[h][g] = (P.acc[h] && g < n) ? P.out[h][(size_t)(g0 + g) * o_is + base + i] : 0;
         for (int t = 0; t < nterms; t++) {
-            const bool h0 = P.pt0[t] != nullptr, h1 = P.pt1[t] != nullptr;                                       // uniform
-            const u64 y0 = h0 ? hc_mont(P.pt0[t][base - (size_t)k * nt * 65536 + i], m.r2, m.q, m.qinv) : 0, y1 = h1 ? hc_mont(P.pt1[t][base - (size_t)k * nt * 65536 + i], m.r2, m.q, m.qinv) : 0;
+            u64 y[G];
+#pragma unroll
+            for (int h = 0; h < G; h++) y[h] = P.pt[h][t] != nullptr ? hc_mont(P.pt[h][t][prow + i], m.r2, m.q, m.qinv) : 0;      // MForm, once for all images; 0 = no diagonal (uniform)
             const u64 *a = P.a[t] + (size_t)g0 * a_is + base + i;
             const int ph = t % 7;
 #pragma unroll
             for (int g = 0; g < NB; g++) if (g < n) {
                 const u64 x = a[(size_t)g * a_is];
-                if (ph == 0) { T0[g] = 0; T1[g] = 0; }
-                if (h0) T0[g] += (u128)x * y0;
-                if (h1) T1[g] += (u128)x * y1;
-                if (ph == 6 || t + 1 == nterms) { s0[g] = hc_addmod(s0[g], hc_mont_redc(T0[g], m.q, m.qinv), m.q); s1[g] = hc_addmod(s1[g], hc_mont_redc(T1[g], m.q, m.qinv), m.q); }
+#pragma unroll
+                for (int h = 0; h < G; h++) {
+                    if (ph == 0) T[h][g] = 0;
+                    if (P.pt[h][t] != nullptr) T[h][g] += (u128)x * y[h];
+                    if (ph == 6 || t + 1 == nterms) s[h][g] = hc_addmod(s[h][g], hc_mont_redc(T[h][g], m.q, m.qinv), m.q);
+                }
             }
         }
 #pragma unroll
-        for (int g = 0; g < NB; g++) if (g < n) { out0[(size_t)(g0 + g) * o_is + base + i] = s0[g]; out1[(size_t)(g0 + g) * o_is + base + i] = s1[g]; }
+        for (int h = 0; h < G; h++)
+#pragma unroll
+            for (int g = 0; g < NB; g++) if (g < n) P.out[h][(size_t)(g0 + g) * o_is + base + i] = s[h][g];
     }
 }
 // ================================================================ switching-key generation on the device (harness: hc_swk_generate)

@@ -1510,21 +1510,40 @@ extern "C" int hc_qp_mul_sum(hc_ctx *c, int level, int nterms, const uint64_t *c
     return hc_launch(c, "qp_mul_sum", hc_k_qp_mul_sum, dim3(HC_GX_QPMS, (unsigned)nt, 2), P, nterms, (u64 *)out, (const HcMod *)c->d_mods, level + 1, c->nq, nt, c->nb, c->bs_qp, c->bs_qp, accumulate ? 1 : 0);
 }
 
-// two giant steps' sums from one pass over the rotations: out_h (+)= sum_t a[t] (*) pt_h[t], h = 0, 1; pt0[t] / pt1[t] may be NULL (that giant step has no diagonal for baby step
-// t; every t has at least one). The residues of two hc_qp_mul_sum calls.
-extern "C" int hc_qp_mul_sum2(hc_ctx *c, int level, int nterms, const uint64_t *const *a, const uint64_t *const *pt0, const uint64_t *const *pt1, uint64_t *out0, uint64_t *out1, int accumulate0, int accumulate1) {
-    HC_ENTER(c);
-    if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum2: level %d outside 0..%d or no special primes", level, c->nq - 1);
-    if (!a || !pt0 || !pt1 || !out0 || !out1 || out0 == out1 || nterms < 1 || nterms > HC_MAXTERMS) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum2: bad arguments (1 <= nterms <= %d, two different outputs)", HC_MAXTERMS);
-    HcTermPtrs2 P; memset(&P, 0, sizeof P);
+// several giant steps' sums from one pass over the rotations: out[h] (+)= sum_t a[t] (*) pt[h * nterms + t], h < ngiant <= 4; a diagonal pointer may be NULL (giant step h has
+// no diagonal for baby step t; every t has at least one). The residues of ngiant hc_qp_mul_sum calls.
+static int hc_qp_mul_sum_g(hc_ctx *c, const char *fn, int level, int nterms, int ngiant, const uint64_t *const *a, const uint64_t *const *pt, uint64_t *const *out, const int *accumulate) {
+    if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "%s: level %d outside 0..%d or no special primes", fn, level, c->nq - 1);
+    if (!a || !pt || !out || !accumulate || ngiant < 1 || ngiant > HC_MAXGIANT || nterms < 1 || nterms > HC_MAXTERMS) return hc_fail(c, HC_ERR_ARG, "%s: bad arguments (1 <= nterms <= %d, 1 <= giant steps <= %d)", fn, HC_MAXTERMS, HC_MAXGIANT);
+    HcTermPtrsG P; memset(&P, 0, sizeof P);
+    for (int h = 0; h < ngiant; h++) {
+        if (!out[h]) return hc_fail(c, HC_ERR_ARG, "%s: null output %d", fn, h);
+        for (int h2 = 0; h2 < h; h2++) if (out[h2] == out[h]) return hc_fail(c, HC_ERR_ARG, "%s: outputs %d and %d are the same", fn, h2, h);
+        P.out[h] = (u64 *)out[h]; P.acc[h] = accumulate[h] ? 1 : 0;
+    }
     for (int t = 0; t < nterms; t++) {
-        if (!a[t] || (!pt0[t] && !pt1[t]) || a[t] == out0 || a[t] == out1) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum2: null or aliased term %d", t);
-        P.a[t] = (const u64 *)a[t]; P.pt0[t] = (const u64 *)pt0[t]; P.pt1[t] = (const u64 *)pt1[t];
+        bool any = false;
+        for (int h = 0; h < ngiant; h++) { P.pt[h][t] = (const u64 *)pt[(size_t)h * nterms + t]; any = any || P.pt[h][t]; if (a[t] == out[h]) return hc_fail(c, HC_ERR_ARG, "%s: term %d aliases output %d", fn, t, h); }
+        if (!a[t] || !any) return hc_fail(c, HC_ERR_ARG, "%s: term %d is null or has no diagonal", fn, t);
+        P.a[t] = (const u64 *)a[t];
     }
     const int nt = level + 1 + c->np, nb = c->nb, NB = nb <= 1 ? 1 : nb <= 2 ? 2 : 4;
-#define HC_QPMS2(NN) hc_launch(c, "qp_mul_sum2", hc_k_qp_mul_sum2<NN>, dim3(HC_GX_QPMS, (unsigned)nt, 2u * (unsigned)((nb + NN - 1) / NN)), P, nterms, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, level + 1, c->nq, nt, nb, c->bs_qp, c->bs_qp, accumulate0 ? 1 : 0, accumulate1 ? 1 : 0)
-    return NB == 1 ? HC_QPMS2(1) : NB == 2 ? HC_QPMS2(2) : HC_QPMS2(4);
-#undef HC_QPMS2
+#define HC_QPMSG(GG, NN) hc_launch(c, "qp_mul_sum_g", hc_k_qp_mul_sum_g<GG, NN>, dim3(HC_GX_QPMS, (unsigned)nt, 2u * (unsigned)((nb + NN - 1) / NN)), P, nterms, (const HcMod *)c->d_mods, level + 1, c->nq, nt, nb, c->bs_qp, c->bs_qp)
+#define HC_QPMSG_N(GG) (NB == 1 ? HC_QPMSG(GG, 1) : NB == 2 ? HC_QPMSG(GG, 2) : HC_QPMSG(GG, 4))
+    return ngiant == 1 ? HC_QPMSG_N(1) : ngiant == 2 ? HC_QPMSG_N(2) : ngiant == 3 ? HC_QPMSG_N(3) : HC_QPMSG_N(4);
+#undef HC_QPMSG_N
+#undef HC_QPMSG
+}
+extern "C" int hc_qp_mul_sum_many(hc_ctx *c, int level, int nterms, int ngiant, const uint64_t *const *a, const uint64_t *const *pt, uint64_t *const *out, const int *accumulate) {
+    HC_ENTER(c);
+    return hc_qp_mul_sum_g(c, "hc_qp_mul_sum_many", level, nterms, ngiant, a, pt, out, accumulate);
+}
+extern "C" int hc_qp_mul_sum2(hc_ctx *c, int level, int nterms, const uint64_t *const *a, const uint64_t *const *pt0, const uint64_t *const *pt1, uint64_t *out0, uint64_t *out1, int accumulate0, int accumulate1) {
+    HC_ENTER(c);
+    if (!pt0 || !pt1 || nterms < 1 || nterms > HC_MAXTERMS) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum2: bad arguments");
+    std::vector<const uint64_t *> pt((size_t)2 * nterms); for (int t = 0; t < nterms; t++) { pt[(size_t)t] = pt0[t]; pt[(size_t)nterms + t] = pt1[t]; }
+    uint64_t *outs[2] = {out0, out1}; const int acc[2] = {accumulate0, accumulate1};
+    return hc_qp_mul_sum_g(c, "hc_qp_mul_sum2", level, nterms, 2, a, pt.data(), outs, acc);
 }
 
 // ------------------------------------------------------------------ L1

@@ -648,8 +648,8 @@ struct Boot {
         DCt res = new_ct(L, 1, ct.scale * lt.pt_scale); bool have_res[2] = {false, false};
         auto add_to_res = [&](int k, const std::shared_ptr<uint64_t> &x) { if (have_res[k]) HCR(hc_lv_add(hc, L, res.p[k].get(), x.get(), res.p[k].get())); else { res.p[k] = x; have_res[k] = true; } };
         auto B = block_qp2(); bool haveB = false;
-        // the diagonal sums of all giant steps first, TWO per pass over the rotations (hc_qp_mul_sum2: the rotated ciphertexts - the largest operands of a linear transform - are
-        // read once per pair instead of once per giant step); giant step 0's sum lands in the accumulators B, which the other giant steps' key switches then add to
+        // the diagonal sums of all giant steps first, THREE per pass over the rotations (hc_qp_mul_sum_many, up to four: the rotated ciphertexts - the largest operands of a linear transform - are
+        // read once per group instead of once per giant step); giant step 0's sum lands in the accumulators B, which the other giant steps' key switches then add to
         // (modular sums commute: the residues of the reference's order)
         struct Sum { uint64_t *out; std::map<int, const uint64_t *> pt; };
         std::vector<Sum> sums; std::map<int, std::shared_ptr<uint64_t>> Aof;
@@ -660,19 +660,14 @@ struct Boot {
             Sum sj; for (int i : ix.second) if (i) sj.pt[i] = row.at(i).p.get();
             if (!sj.pt.empty()) { Aof[j] = block_qp2(); sj.out = Aof[j].get(); sums.push_back(sj); }
         }
-        static const bool one_by_one_sums = getenv("HCONV_SUMS_ONE_BY_ONE") != nullptr;
-        for (size_t u = 0; u < sums.size(); u += 2) {
-            if (u + 1 == sums.size() || one_by_one_sums) {
-                for (size_t v = u; v < std::min(u + 2, sums.size()); v++) {
-                    std::vector<const uint64_t *> as, pts; for (auto &kv : sums[v].pt) { as.push_back(rot[kv.first].get()); pts.push_back(kv.second); }
-                    HCR(hc_qp_mul_sum(hc, L, (int)as.size(), as.data(), pts.data(), sums[v].out, 0));
-                }
-                continue;
-            }
-            std::set<int> un; for (auto &kv : sums[u].pt) un.insert(kv.first); for (auto &kv : sums[u + 1].pt) un.insert(kv.first);
-            std::vector<const uint64_t *> as, p0, p1;
-            for (int i : un) { as.push_back(rot[i].get()); p0.push_back(sums[u].pt.count(i) ? sums[u].pt[i] : nullptr); p1.push_back(sums[u + 1].pt.count(i) ? sums[u + 1].pt[i] : nullptr); }
-            HCR(hc_qp_mul_sum2(hc, L, (int)as.size(), as.data(), p0.data(), p1.data(), sums[u].out, sums[u + 1].out, 0, 0));
+        static const int sums_per_pass = getenv("HCONV_SUMS_PER_PASS") ? std::max(1, std::min(4, atoi(getenv("HCONV_SUMS_PER_PASS")))) : 3;      // A/B switch; 1 = one pass per giant step. Measured (profiles/round4_chain_occupancy_ab.txt, round 12): 3 per pass
+        for (size_t u = 0; u < sums.size(); u += (size_t)sums_per_pass) {
+            const size_t ng = std::min((size_t)sums_per_pass, sums.size() - u);
+            std::set<int> un; for (size_t v = u; v < u + ng; v++) for (auto &kv : sums[v].pt) un.insert(kv.first);
+            std::vector<const uint64_t *> as, pts(ng * un.size(), nullptr); std::vector<uint64_t *> outs; std::vector<int> accs(ng, 0);
+            size_t t = 0; for (int i : un) { as.push_back(rot[i].get()); for (size_t v = 0; v < ng; v++) if (sums[u + v].pt.count(i)) pts[v * un.size() + t] = sums[u + v].pt[i]; t++; }
+            for (size_t v = 0; v < ng; v++) outs.push_back(sums[u + v].out);
+            HCR(hc_qp_mul_sum_many(hc, L, (int)as.size(), (int)ng, as.data(), pts.data(), outs.data(), accs.data()));
         }
         for (auto &ix : index) {
             const int j = ix.first; if (j == 0) continue;

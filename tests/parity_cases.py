@@ -667,6 +667,27 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
     g1 = run("qp_mul_sum x2", sum1x2, ins2, [("q", QW), ("q", QW)], init=[acc.reshape(n, -1), acc.reshape(n, -1)])
     for k_ in range(2):
         eq(g2[k_], g1[k_], f"qp_mul_sum2 == two qp_mul_sum calls (giant step {k_})")
+    # three giant steps per pass (hc_qp_mul_sum_many): term sets 0..6, 2..8 and {1, 4, 8}; the third accumulates
+    use2 = [1, 4, 8]
+    uses = [use0, use1, use2]
+    pts3 = [np.stack([rnd(qp_mod(t)) for t in range(nt)]) for _ in range(NT)]
+
+    def sum3(*args):
+        xs = args[:NT]; ps = [args[NT:2 * NT], args[2 * NT:3 * NT], args[3 * NT:4 * NT]]; outs = args[4 * NT:4 * NT + 3]
+        ck(L.hc_qp_mul_sum_many(h, level, NT, 3, (C.c_void_p * NT)(*xs), (C.c_void_p * (3 * NT))(*[ps[g_][t] if t in uses[g_] else None for g_ in range(3) for t in range(NT)]),
+                                (C.c_void_p * 3)(*outs), (C.c_int * 3)(1, 0, 1)))
+
+    def sum1x3(*args):
+        xs = args[:NT]; ps = [args[NT:2 * NT], args[2 * NT:3 * NT], args[3 * NT:4 * NT]]; outs = args[4 * NT:4 * NT + 3]
+        for g_, accu in ((0, 1), (1, 0), (2, 1)):
+            arr = C.c_void_p * len(uses[g_])
+            ck(L.hc_qp_mul_sum(h, level, len(uses[g_]), arr(*[xs[t] for t in uses[g_]]), arr(*[ps[g_][t] for t in uses[g_]]), outs[g_], accu))
+    ins3 = ins2 + [(p_, "s") for p_ in pts3]
+    init3 = [acc.reshape(n, -1)] * 3
+    g3 = run("qp_mul_sum_many (3 giant steps)", sum3, ins3, [("q", QW)] * 3, init=init3)
+    g1b = run("qp_mul_sum x3", sum1x3, ins3, [("q", QW)] * 3, init=init3)
+    for k_ in range(3):
+        eq(g3[k_], g1b[k_], f"qp_mul_sum_many == three qp_mul_sum calls (giant step {k_})")
     run("qp_permute2", lambda x, o: ck(L.hc_qp_permute2(h, C.c_uint64(gal), level, x, o)), [(X, "q")], [("q", QW)])
     ctx.close()
 
