@@ -20,6 +20,9 @@ int main(int argc, char **argv) {
     const int batchs[5] = {4, 16, 64, 256, 1024}, widths[5] = {128, 64, 32, 16, 8};   // main.go:578-579
     if (argc < 5) hconv::panic("runtime error: index out of range (usage: conv|convReLU <ker_wid> <i_batch> <num_tests>)");
     const std::string test_name = argv[1];
+    // The bootstrapping chains allocate and free a few buffers per evaluator operation, and hipFree drains the device every time: the chain commands run on cached
+    // allocations (hconv.hip hcx_malloc) unless HCONV_ASYNC_ALLOC=0 says otherwise - ResNet-20 at 8 images per launch set 2.12 -> 2.02 s per set (profiles/round4_cached_alloc_ab.txt)
+    if (test_name == "convReLU" || test_name == "resnet") setenv("HCONV_ASYNC_ALLOC", "1", 0);
     const int ker_wid = atoi(argv[2]), i_batch = atoi(argv[3]), num_tests = atoi(argv[4]);
     if (!(ker_wid == 3 || ker_wid == 5 || ker_wid == 7)) hconv::panic("Wrong kernel wid (not in 3,5,7)");
     bool boot = false;
