@@ -1694,62 +1694,6 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const 
         for (int g = 0; g < NB; g++) if (g < n) { u64 *a = acc + (size_t)g * acc_is + rowT + j; a[0] = s0[g]; a[comp] = s1[g]; }
     }
 }
-// The second pass of the digits' forward transforms and the inner product in ONE kernel (a key switch whose decomposition nobody else needs: relinearisation,
-// a lone rotation): the workgroup of (tile, target limb T, image) walks the beta digits - rows pass of digit d's tile in registers (or, on the digit's own limbs, the
-// NTT-domain input itself), canonical, times both key components, summed modulo q - and writes two accumulator tiles. The extended digits are never written: per relinearisation
-// n x beta x nt rows less to write and as many less to read (hc_k_rows_fwd_canon_mm + hc_k_ks_mac_all move them through HBM). Same residues: canonical digits, hc_mont products,
-// modular sums. tmp = the cols pass' output [image][digit][nt][N]; grid = 16 * nt * images workgroups, XCD-aware like HC_MM_PROLOGUE_ROWS (the images of one (tile, T) back to
-// back on one XCD: the key tiles and the per-row twiddles are fetched once per launch).
-#ifndef HC_FMAC_WAVES
-#define HC_FMAC_WAVES 4
-#endif
-#ifndef HC_FMAC_GROUP
-#define HC_FMAC_GROUP 4
-#endif
-struct HcFmac { const HcRowMod *M; const HcMod *mods; int nl, nq, nt, alpha, beta, nb; size_t tmp_zs, tmp_is; const u64 *cx; size_t cx_is; const u64 *evk; u64 *acc; size_t acc_is; };
-__global__ __launch_bounds__(HC_TPB, HC_FMAC_WAVES) void hc_k_rows_fwd_mac_mm(const u64 *tmp, HcFmac A) {
-    __shared__ hc_mm_lds_t lds[HC_ROWS_LDS];
-    const unsigned id = blockIdx.x, rest = id >> 3, pp = (rest / (unsigned)A.nb) * 8 + (id & 7);
-    const int bx = (int)(pp & 15), T = (int)(pp >> 4), img = (int)(rest % (unsigned)A.nb);
-    const int mi = T < A.nl ? T : A.nq + (T - A.nl);
-    const HcRowMod &R = A.M[mi]; const HcMod m = A.mods[mi];
-    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = bx * 16 + rloc;
-    const HcQ Q = hc_q(R.q);
-    const size_t lin = (size_t)T * 65536 + (size_t)(bx * 16) * 256 + t, comp = (size_t)A.nt * 65536;
-    u64 s0[16], s1[16];
-    for (int d = 0; d < A.beta; d++) {
-        const int lo = d * A.alpha, hi_ = lo + A.alpha < A.nl ? lo + A.alpha : A.nl;
-        u64 e[16];
-        if (T >= lo && T < hi_) {                                            // block-uniform: the digit's own limbs read the input
-            const u64 *x = A.cx + (size_t)img * A.cx_is + lin;
-#pragma unroll
-            for (int k = 0; k < 16; k++) e[k] = x[k * 256];
-        } else {
-            const u64 *in = tmp + (size_t)img * A.tmp_is + (size_t)d * A.tmp_zs + (size_t)T * 65536;
-#pragma unroll
-            for (int hi = 0; hi < 16; hi++) e[hi] = in[(size_t)row * 256 + hi * 16 + tid];
-            hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, Q);
-            HC_ROW_SYNC();
-            hc_rows_lo_to_lin(e, lds, t, rloc, tid);
-#pragma unroll
-            for (int k = 0; k < 16; k++) e[k] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu);
-            __syncthreads();                                                 // the tile is rewritten by the next digit
-        }
-        const u64 *kb = A.evk + ((size_t)d * 2 * A.nt) * 65536 + lin, *ka = kb + comp;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const u64 p0 = hc_mont(e[k], kb[k * 256], m.q, m.qinv), p1 = hc_mont(e[k], ka[k * 256], m.q, m.qinv);
-            s0[k] = d == 0 ? p0 : hc_addmod(s0[k], p0, m.q);
-            s1[k] = d == 0 ? p1 : hc_addmod(s1[k], p1, m.q);
-#if !defined(HC_EMU) && HC_FMAC_GROUP
-            if ((k + 1) % HC_FMAC_GROUP == 0) __builtin_amdgcn_sched_barrier(0);      // HC_FMAC_GROUP key pairs in flight at a time: all 32 hoisted to the top cost 64 VGPRs
-#endif
-        }
-    }
-    u64 *a = A.acc + (size_t)img * A.acc_is + lin;
-#pragma unroll
-    for (int k = 0; k < 16; k++) { a[k * 256] = s0[k]; a[comp + k * 256] = s1[k]; }
-}
 // The inner products of R hoisted rotations in ONE launch (the baby steps of a linear transform share one digit decomposition): a digit element is read once for the R keys
 // (hc_k_ks_mac_all re-reads all n x beta x nt digit rows per rotation - what bounds it). R x NB accumulator slots per component and thread (<= 16), plain Montgomery
 // accumulation (the kernel is bound by its loads). acc: [rotation][image][2][nt][N], rotations acc_rs words apart. grid = (64, nt)

@@ -133,7 +133,6 @@ struct hc_ctx {
     u64 *ws_gather = nullptr; size_t ws_gather_rows = 0;
     long small_levels = 16;               // pack-tree launches of at most this many nodes (summed over the batch) run on the 1024-thread S kernels; 0 = never
     long peer_access = 1;                 // hc_conv_then_pack_sharded: enable direct peer copies between distinct devices (0: leave the copies to hipMemcpyPeerAsync's staging)
-    int fused_mac = 0;                    // hc_k_rows_fwd_mac_mm: the digits' second transform pass and the inner product as one kernel where the decomposition is not kept (A/B; HCONV_FUSED_MAC)
     int xcd_rows = 1;                     // XCD-aware 1-D grid of the rows passes (HcMm::xcd; 0 = the plain 3-D grid, kept for A/B builds)
     unsigned peer_warned = 0;             // bit d: enabling peer access to device d failed and was reported once
     unsigned peer_enabled = 0;            // bit d: peer access from this context's device to device d was enabled by (or found enabled for) this context
@@ -316,7 +315,6 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
         return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: HIP device %d not available (%d devices) - this library has no CPU path", device, ndev);
     hc_ctx *c = new hc_ctx();
     c->device = device; c->nq = nq; c->np = np;
-    { const char *fm = getenv("HCONV_FUSED_MAC"); if (fm) c->fused_mac = atoi(fm) ? 1 : 0; }
     { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa ? (atoi(aa) == 2 ? 2 : (atoi(aa) ? 1 : 0)) : 0; }
     hipError_t se = hipSetDevice(device);
     if (se == hipSuccess) se = c->async_alloc ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipStreamCreate(&c->stream);
@@ -573,8 +571,7 @@ extern "C" int hc_lv_add_const(hc_ctx *c, int level, const uint64_t *a, const ui
 // batched transforms over rows of different moduli (row y <-> modulus y < nl ? y : nq + y - nl); z operands zs words apart, n images is words apart.
 // fuse: optional prologue of the first pass (lift_level: Rescale's lift of t, see HcMm) and epilogue of the second (epi_x: (x - result) * epi_mul (+ epi_add))
 struct HcMmFuse { const HcBasisExt *ext_bs = nullptr; int ext_rows = 0; int lift_level = 0; const u64 *epi_x = nullptr; size_t epi_x_zs = 0, epi_x_is = 0; const HcTw *epi_mul = nullptr; const u64 *epi_add = nullptr; size_t epi_add_zs = 0, epi_add_is = 0;
-                  const u64 *lift_t = nullptr; size_t lift_t_zs = 0, lift_t_is = 0; const HcTw *lift_pmul = nullptr, *epi_add_mul = nullptr;
-                  const HcFmac *mac = nullptr; };      // mac: the second pass is hc_k_rows_fwd_mac_mm (the transform's `out` is not written)      // lift_t: ModDown + Rescale in one transform (HcMm)
+                  const u64 *lift_t = nullptr; size_t lift_t_zs = 0, lift_t_is = 0; const HcTw *lift_pmul = nullptr, *epi_add_mul = nullptr; };      // lift_t: ModDown + Rescale in one transform (HcMm)
 static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0, int n = 1, size_t is_in = 0, size_t is_out = 0, const char *tag = "ntt",
                      const HcMmFuse *fuse = nullptr) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
@@ -593,10 +590,6 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
     else HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<0>, grid, in, c->ws_tmp, A));
     A.lift_level = 0; A.ext_bs = nullptr; A.lift_t = nullptr; A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out;
     if (fuse && fuse->epi_x) { A.epi_x = fuse->epi_x; A.epi_x_zs = fuse->epi_x_zs; A.epi_x_is = fuse->epi_x_is; A.epi_mul = fuse->epi_mul; A.epi_add = fuse->epi_add; A.epi_add_zs = fuse->epi_add_zs; A.epi_add_is = fuse->epi_add_is; A.epi_add_mul = fuse->epi_add_mul; }
-    if (fuse && fuse->mac) {
-        HcFmac F = *fuse->mac; F.M = c->d_rowmods; F.mods = c->d_mods; F.tmp_zs = zt; F.tmp_is = it;
-        return hc_launch(c, "decomp:rows_fwd_mac_mm", hc_k_rows_fwd_mac_mm, dim3(16u * (unsigned)rows * (unsigned)n), (const u64 *)c->ws_tmp, F);
-    }
     A.xcd = c->xcd_rows; A.nzn = z * n;
     HC_TRY(hc_launch(c, c->profile ? n2 : "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, A.xcd ? dim3(16u * (unsigned)rows * (unsigned)(z * n)) : grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
@@ -1253,7 +1246,7 @@ static int hc_ks_scratch(hc_ctx *c, int level, HcKsScratch *S) {
 }
 // phase 1 (rlwe.KeySwitcher.DecomposeNTT / ring.Decomposer.DecomposeAndSplit): digits[d][T] = the d-th digit of cx extended to limb
 // T (Q limbs 0..level, then the P limbs), NTT domain; a digit's own limbs are not written (phase 2 reads cx there)
-static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, const HcKsScratch &S, const HcFmac *mac = nullptr) {
+static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, const HcKsScratch &S) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha, nb = c->nb;
     HC_TRY(hc_intt_mm(c, cx, S.coef, nl, nl, 1, 0, 0, 0, 0, nb, c->bs_poly, S.coef_is, "decomp"));                    // cxInvNTT, all limbs
@@ -1261,21 +1254,8 @@ static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, const HcKsS
     // digit + beta * image): the extended digits are never written in the coefficient domain
     const size_t yz = (size_t)(alpha + 1) * HC_N;
     HC_TRY(hc_launch(c, "decomp:basis_yv", hc_k_basis_yv, dim3(HC_GX_YV, (unsigned)(beta * nb)), (const u64 *)S.coef, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bx, nt, (size_t)alpha * HC_N, alpha, beta, S.coef_is));
-    HcMmFuse F; F.ext_bs = P->bx; F.ext_rows = nt; F.mac = mac;
+    HcMmFuse F; F.ext_bs = P->bx; F.ext_rows = nt;
     return hc_ntt_mm(c, S.yv, S.digits, nt, nl, 0, 0, beta, yz, (size_t)nt * HC_N, alpha, nb, (size_t)beta * yz, S.digits_is, "decomp", &F);
-}
-// decomposition and inner product of a key switch that keeps no decomposition: acc [img][2][nt][N]. fused_mac: the digits' second transform pass and the inner
-// product in one kernel (the digits are not written)
-static int hc_ks_mac(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *acc, size_t acc_is);
-static int hc_ks_decompose_mac(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *acc, size_t acc_is) {
-    c->hoist_cx = nullptr;                                   // the scratch no longer holds a hoisted decomposition
-    const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
-    if (c->fused_mac && key.beta == beta) {
-        HcFmac M; memset(&M, 0, sizeof M); M.nl = nl; M.nq = c->nq; M.nt = nt; M.alpha = alpha; M.beta = beta; M.nb = c->nb; M.cx = cx; M.cx_is = c->bs_poly; M.evk = (const u64 *)key.rows; M.acc = acc; M.acc_is = acc_is;
-        return hc_ks_decompose_into(c, level, cx, S, &M);
-    }
-    HC_TRY(hc_ks_decompose_into(c, level, cx, S));
-    return hc_ks_mac(c, key, level, cx, S, acc, acc_is);
 }
 // the inner product with both components of the key, all images: acc [img][2][nt][N], images acc_is words apart
 static int hc_ks_mac(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *acc, size_t acc_is) {
@@ -1342,8 +1322,9 @@ extern "C" int hc_keyswitch(hc_ctx *c, uint64_t key_id, int level, const uint64_
     const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch", key_id, level, &key));
     if (!cx || !d0 || !d1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch: null");
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
-    HC_TRY(hc_ks_decompose_mac(c, *key, level, cx, S, S.acc, S.acc_is));
-    return hc_ks_moddown(c, level, S.acc, S.acc_is, S, d0, d1, 0, nullptr);
+    HC_TRY(hc_ks_decompose_into(c, level, cx, S));
+    c->hoist_cx = nullptr;                                   // the scratch no longer holds a hoisted decomposition
+    return hc_ks_apply_from(c, *key, level, cx, S, d0, d1);
 }
 // evaluator.Relinearize's tail in the key switch: out_k = a_k + (key switch of cx)_k, the addition inside ModDown's last pass. out may be a (element-wise in place).
 extern "C" int hc_keyswitch_add(hc_ctx *c, uint64_t key_id, int level, const uint64_t *cx, const uint64_t *a0, const uint64_t *a1, uint64_t *out0, uint64_t *out1) {
@@ -1351,8 +1332,9 @@ extern "C" int hc_keyswitch_add(hc_ctx *c, uint64_t key_id, int level, const uin
     const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_add", key_id, level, &key));
     if (!cx || !a0 || !a1 || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_add: null");
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
-    HC_TRY(hc_ks_decompose_mac(c, *key, level, cx, S, S.acc, S.acc_is));
-    return hc_ks_moddown(c, level, S.acc, S.acc_is, S, (u64 *)out0, (u64 *)out1, 0, nullptr, (const u64 *)a0, (const u64 *)a1);
+    HC_TRY(hc_ks_decompose_into(c, level, cx, S));
+    c->hoist_cx = nullptr;
+    return hc_ks_apply_from(c, *key, level, cx, S, (u64 *)out0, (u64 *)out1, 0, nullptr, (const u64 *)a0, (const u64 *)a1);
 }
 // hc_keyswitch_add followed by one hc_div_round_last2, as one call: out_k = Rescale(a_k + (key switch of cx)_k) at level - 1 (level >= 2). ModDown and the rescale share
 // one forward transform per limb (hc_ks_moddown_rescale); the residues are those of the two calls. out may be a.
@@ -1362,7 +1344,9 @@ extern "C" int hc_keyswitch_add_rescale(hc_ctx *c, uint64_t key_id, int level, c
     if (!cx || !a0 || !a1 || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_add_rescale: null");
     if (level < 2) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_add_rescale: level %d: the fused rescale needs level >= 2 (use hc_keyswitch_add and hc_div_round_last2)", level);
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
-    HC_TRY(hc_ks_decompose_mac(c, *key, level, cx, S, S.acc, S.acc_is));
+    HC_TRY(hc_ks_decompose_into(c, level, cx, S));
+    c->hoist_cx = nullptr;
+    HC_TRY(hc_ks_mac(c, *key, level, cx, S, S.acc, S.acc_is));
     return hc_ks_moddown_rescale(c, level, S.acc, S.acc_is, S, (u64 *)out0, (u64 *)out1, (const u64 *)a0, (const u64 *)a1);
 }
 // Hoisted key switching (evaluator.RotateHoisted, conv.go:131; the baby steps of a linear transform): the decomposition of cx is
@@ -1763,7 +1747,6 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
     if (!strcmp(name, "small_levels")) { if (value < 0) return hc_fail(c, HC_ERR_ARG, "small_levels must be >= 0"); c->small_levels = value; return HC_OK; }
     if (!strcmp(name, "peer_access")) { c->peer_access = value ? 1 : 0; return HC_OK; }
-    if (!strcmp(name, "fused_mac")) { c->fused_mac = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
     return hc_fail(c, HC_ERR_ARG, "unknown option %s", name);
 }
