@@ -1448,11 +1448,11 @@ __device__ __forceinline__ u64 hc_basis_ext_sum(const u64 (&y)[9], const HcBasis
 #pragma unroll
     for (int i = 0; i < 9; i++) if (i == n) v = y[i];
     if (n == 1) return hc_barrett64(y[0], B.t, B.mu_t);
-    if (B.t < (1ull << 58)) {                                          // lazy sum: below 2^58 up to 8 terms and the offset stay under 40 t < 2^64 unreduced
-        u64 acc = 2 * Q.q4;                                            // v <= n <= 8 (a count of overflows): v (S mod t) < 8 t as a plain 32 x 64-bit product, no reduction of its own
+    if (B.t < (1ull << 58)) {                                          // lazy sum: below 2^58 up to 8 terms and the offset stay under 36 t < 2^64 unreduced
+        u64 acc = Q.q4;
 #pragma unroll
         for (int i = 0; i < 8; i++) if (i < n) acc += hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q);
-        return hc_reduce64(acc - (u64)(u32)v * B.smodt.w, B.mu_t, Q);
+        return hc_reduce64(acc - hc_shoup4(v, B.smodt.w, B.smodt.ws, Q), B.mu_t, Q);
     }
     u64 acc = 0;                                                       // the 60 / 61-bit limbs fold the running sum by 4t
 #pragma unroll
