@@ -1434,7 +1434,6 @@ struct HcBasisExt {
     HcTw smodt;        // S mod t
     u64 t, mu_t;       // target modulus, floor(2^64/t)
     u64 mu_s[8];       // floor(2^64/s_i)
-    u32 hat31[8];      // (S/s_i mod t) * 2^31 mod t for a target below 2^31 (hc_basis_ext_sum30), else 0
 };
 // the target-side sum of the extension for the 16 elements (rows hi * 16 + tid of one column) a cols-pass thread owns: yv = that column of the y_i / v rows.
 // Four elements at a time: their (n + 1) x 4 operands are all requested before the first is used, so that the loads of a group overlap (element by element the
@@ -1551,105 +1550,6 @@ __global__ __launch_bounds__(HC_TPB, EXT ? HC_MM_WAVES_EXT : HC_MM_WAVES) void h
     hc_cols_fwd<HC_FM_ALT>(e, lds, R.fwd, c, tid, hc_q(R.q));
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) out[base + (size_t)(tid * 16 + lo) * 256] = e[lo];
-}
-// ---- the extension passes on the ~30-bit limbs (eleven of parameter set [6]'s 28: 11 of 26 target rows at the sine's levels), a kernel of their own launched over THOSE rows
-// (HcMm::rowlist) beside hc_k_cols_fwd_mm over the others - per-row instantiations, not a block-uniform switch inside one kernel (which costs both paths' registers: section 4b).
-// The extension passes are bound by VALU issue, and below 2^31 everything is a 32-bit product:
-//   target sum   y_i = y1 2^31 + y0 (y_i < 2^61): y_i (S/s_i) = y0 hat + y1 (hat 2^31 mod t) (mod t), two v_mad_u64_u32 per term into ONE unreduced 64-bit sum
-//                (n t (3 2^30) + 8 t < 2^64: hc_small_target checks it on the host), then one Barrett reduction: 4 instructions per term against 12;
-//   butterflies  Harvey's 32-bit lazy form on [0, 2t): T = Y w - hi32(Y w') t with w' = floor(w 2^32 / t) = the top word of the 64-bit companion (the same tables);
-//   exchange     one pass of 4-byte words.
-// Outputs in [0, 2t), as 8-byte words: what hc_k_rows_fwd_canon_mm accepts (< 8q) - canonical results, the same residues.
-#ifndef HC_MM_WAVES_S
-#define HC_MM_WAVES_S 6
-#endif
-#ifndef HC_EXT_GROUP_S
-#define HC_EXT_GROUP_S 4
-#endif
-__device__ __forceinline__ u32 hc_mulhi32(u32 a, u32 b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umulhi(a, b);
-#else
-    return (u32)(((u64)a * b) >> 32);
-#endif
-}
-template <class TW>
-__device__ __forceinline__ void hc_ct_round32(u32 (&e)[16], const TW &tw, u32 t, u32 t2) {
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const int half = 8 >> s;
-#pragma unroll
-        for (int g = 0; g < (1 << s); g++) {
-            const HcTw W = tw((1 << s) - 1 + g);
-            const u32 w = (u32)W.w, wp = (u32)(W.ws >> 32);
-#pragma unroll
-            for (int k = 0; k < half; k++) {
-                const int a = g * 2 * half + k, b = a + half;
-                const u32 X = e[a], Y = e[b];
-                const u32 T = Y * w - hc_mulhi32(Y, wp) * t;               // [0, 2t) for any 32-bit Y
-                const u32 d = t2 - T;
-                e[a] = X >= d ? X - d : X + T;                             // X + T - 2t if that is non-negative: [0, 2t), no 32-bit overflow (4t may exceed 2^32)
-                e[b] = X >= T ? X - T : X - T + t2;
-            }
-        }
-    }
-}
-__device__ __forceinline__ void hc_cols_fwd32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, u32 t) {
-    hc_ct_round32(e, HcRowsTwA{T.colsA}, t, 2 * t);
-#pragma unroll
-    for (int hi = 0; hi < 16; hi++) lds[hc_cols_lds32(hi * 16 + tid, c)] = e[hi];
-    __syncthreads();
-#pragma unroll
-    for (int lo = 0; lo < 16; lo++) e[lo] = lds[hc_cols_lds32(tid * 16 + lo, c)];
-    hc_ct_round32(e, HcRowsTwB{T.colsB + tid}, t, 2 * t);
-}
-__device__ __forceinline__ u32 hc_basis_ext_sum30(const u64 (&y)[9], const HcBasisExt &B, const HcQ &Q) {
-    const int n = B.n;
-    u64 v = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) if (i == n) v = y[i];
-    if (n == 1) return (u32)hc_barrett64(y[0], B.t, B.mu_t);
-    u64 acc = 8 * B.t;                                                     // v <= n <= 8: v (S mod t) < 8 t
-#pragma unroll
-    for (int i = 0; i < 8; i++) if (i < n) acc += (u64)((u32)y[i] & 0x7FFFFFFFu) * (u32)B.hat[i].w + (u64)(u32)(y[i] >> 31) * B.hat31[i];
-    return (u32)hc_reduce64(acc - (u64)(u32)v * (u32)B.smodt.w, B.mu_t, Q);
-}
-template <int EXT>
-__global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_S) void hc_k_cols_fwd_mm_s(const u64 *in, u64 *out, HcMm A) {
-    __shared__ u32 lds[HC_COLS_LDS];
-    HC_MM_PROLOGUE
-    const int t = threadIdx.x, c = t & 15, tid = t >> 4;
-    const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
-    const HcBasisExt &B = A.ext_bs[(A.z_alpha > 0 ? (size_t)zi * A.ext_rows : 0) + y];
-    const HcQ Q = hc_q(B.t);
-    const u64 *yv = in + blockIdx.x * 16 + c;
-    u32 e[16];
-#pragma unroll
-    for (int g0 = 0; g0 < 16; g0 += HC_EXT_GROUP_S) {
-        u64 yy[HC_EXT_GROUP_S][9];
-#pragma unroll
-        for (int g = 0; g < HC_EXT_GROUP_S; g++) {
-            const u64 *p = yv + (size_t)((g0 + g) * 16 + tid) * 256;
-#pragma unroll
-            for (int i = 0; i < 9; i++) if (i <= B.n) yy[g][i] = p[(size_t)i * 65536];
-        }
-#pragma unroll
-        for (int g = 0; g < HC_EXT_GROUP_S; g++) e[g0 + g] = hc_basis_ext_sum30(yy[g], B, Q);
-    }
-    const u32 qi = (u32)R.q;
-    if (EXT == 2) {
-        const u64 qL = A.mods[A.lift_level].q, h = (qL - 1) >> 1, neg_h = R.q - (h % R.q);
-        const u64 *tt = A.lift_t + (size_t)zi * A.lift_t_zs + (size_t)img * A.lift_t_is + blockIdx.x * 16 + c;
-        const HcTw pm = A.lift_pmul[y];
-#pragma unroll
-        for (int hi = 0; hi < 16; hi++) {
-            const u64 r = hc_barrett64(hc_csub(tt[(size_t)(hi * 16 + tid) * 256] + h, qL) + neg_h, R.q, R.mu);
-            e[hi] = (u32)hc_addmod((u64)e[hi], hc_mul_shoup(r, pm.w, pm.ws, R.q), R.q);
-        }
-    }
-    hc_cols_fwd32(e, lds, R.fwd, c, tid, qi);
-#pragma unroll
-    for (int lo = 0; lo < 16; lo++) out[base + (size_t)(tid * 16 + lo) * 256] = (u64)e[lo];
 }
 __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES) void hc_k_rows_fwd_canon_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ hc_mm_lds_t lds[HC_ROWS_LDS];

@@ -133,7 +133,6 @@ struct hc_ctx {
     u64 *ws_gather = nullptr; size_t ws_gather_rows = 0;
     long small_levels = 16;               // pack-tree launches of at most this many nodes (summed over the batch) run on the 1024-thread S kernels; 0 = never
     long peer_access = 1;                 // hc_conv_then_pack_sharded: enable direct peer copies between distinct devices (0: leave the copies to hipMemcpyPeerAsync's staging)
-    int small_rows = 1;                   // the extension passes' ~30-bit target rows on the 32-bit kernel (hc_k_cols_fwd_mm_s); 0 = one launch over all rows (A/B; HCONV_SMALL_ROWS)
     int xcd_rows = 1;                     // XCD-aware 1-D grid of the rows passes (HcMm::xcd; 0 = the plain 3-D grid, kept for A/B builds)
     unsigned peer_warned = 0;             // bit d: enabling peer access to device d failed and was reported once
     unsigned peer_enabled = 0;            // bit d: peer access from this context's device to device d was enabled by (or found enabled for) this context
@@ -316,7 +315,6 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
         return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: HIP device %d not available (%d devices) - this library has no CPU path", device, ndev);
     hc_ctx *c = new hc_ctx();
     c->device = device; c->nq = nq; c->np = np;
-    { const char *sr = getenv("HCONV_SMALL_ROWS"); if (sr) c->small_rows = atoi(sr) ? 1 : 0; }
     { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa ? (atoi(aa) == 2 ? 2 : (atoi(aa) ? 1 : 0)) : 0; }
     hipError_t se = hipSetDevice(device);
     if (se == hipSuccess) se = c->async_alloc ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipStreamCreate(&c->stream);
@@ -572,15 +570,13 @@ extern "C" int hc_lv_mul_const(hc_ctx *c, int level, const uint64_t *a, const ui
 extern "C" int hc_lv_add_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_ADDC>(c, "hc_lv_add_const", level, a, nullptr, out, consts); }
 // batched transforms over rows of different moduli (row y <-> modulus y < nl ? y : nq + y - nl); z operands zs words apart, n images is words apart.
 // fuse: optional prologue of the first pass (lift_level: Rescale's lift of t, see HcMm) and epilogue of the second (epi_x: (x - result) * epi_mul (+ epi_add))
-// a target limb the 32-bit extension pass (hc_k_cols_fwd_mm_s) may take: n unreduced terms y0 hat + y1 hat31 (y0 < 2^31, y1 < 2^30, hat < t) and the 8 t offset fit 64 bits
-static inline bool hc_small_target(u64 t, int n) { return t < (1ull << 31) && (u128)t * ((u128)n * 3 * (1ull << 30) + 8) < ((u128)1 << 64); }
 struct HcMmFuse { const HcBasisExt *ext_bs = nullptr; int ext_rows = 0; int lift_level = 0; const u64 *epi_x = nullptr; size_t epi_x_zs = 0, epi_x_is = 0; const HcTw *epi_mul = nullptr; const u64 *epi_add = nullptr; size_t epi_add_zs = 0, epi_add_is = 0;
                   const u64 *lift_t = nullptr; size_t lift_t_zs = 0, lift_t_is = 0; const HcTw *lift_pmul = nullptr, *epi_add_mul = nullptr; };      // lift_t: ModDown + Rescale in one transform (HcMm)
 static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0, int n = 1, size_t is_in = 0, size_t is_out = 0, const char *tag = "ntt",
                      const HcMmFuse *fuse = nullptr) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
     HcMm A; memset(&A, 0, sizeof A); A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = z_alpha; A.nz = z; A.mods = c->d_mods;
-    char n1[48], n1s[48], n2[48]; snprintf(n1, sizeof n1, "%s:cols_fwd_mm", tag); snprintf(n1s, sizeof n1s, "%s:cols_fwd_mm_s", tag); snprintf(n2, sizeof n2, "%s:rows_fwd_canon_mm", tag);
+    char n1[48], n2[48]; snprintf(n1, sizeof n1, "%s:cols_fwd_mm", tag); snprintf(n2, sizeof n2, "%s:rows_fwd_canon_mm", tag);
     const size_t zt = (size_t)rows * HC_N, it = zt * (size_t)z;
     if (rows > 48) return hc_fail(c, HC_ERR_UNSUPPORTED, "batched transform over more than 48 rows");
     for (int y = 0; y < rows; y++) A.rowlist[y] = (unsigned char)y;
@@ -589,18 +585,8 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
     if (fuse && fuse->lift_level > 0) { A.lift_level = fuse->lift_level; if (!fuse->lift_t) { A.zs_in = (size_t)HC_N; A.is_in = (size_t)z * HC_N; } }
     if (fuse && fuse->ext_bs) { A.ext_bs = fuse->ext_bs; A.ext_rows = fuse->ext_rows; }
     if (fuse && fuse->lift_t) { A.lift_t = fuse->lift_t; A.lift_t_zs = fuse->lift_t_zs; A.lift_t_is = fuse->lift_t_is; A.lift_pmul = fuse->lift_pmul; }
-    if (A.ext_bs) {
-        // the ~30-bit target limbs go through the 32-bit instantiation of the pass, as a launch of their own over those rows (hc_k_cols_fwd_mm_s)
-        HcMm As = A; int cg = 0, cs = 0;
-        for (int y = 0; y < rows; y++) {
-            const u64 t = c->mods[(size_t)(y < nl ? y : c->nq + (y - nl))].m.q;
-            if (c->small_rows && hc_small_target(t, c->np)) As.rowlist[cs++] = (unsigned char)y; else A.rowlist[cg++] = (unsigned char)y;
-        }
-        const dim3 gg(16, (unsigned)cg, (unsigned)(z * n)), gs(16, (unsigned)cs, (unsigned)(z * n));
-        if (A.lift_t) { if (cg) HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<2>, gg, in, c->ws_tmp, A)); if (cs) HC_TRY(hc_launch(c, c->profile ? n1s : "cols_fwd_mm_s", hc_k_cols_fwd_mm_s<2>, gs, in, c->ws_tmp, As)); }
-        else { if (cg) HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<1>, gg, in, c->ws_tmp, A)); if (cs) HC_TRY(hc_launch(c, c->profile ? n1s : "cols_fwd_mm_s", hc_k_cols_fwd_mm_s<1>, gs, in, c->ws_tmp, As)); }
-        for (int y = 0; y < rows; y++) A.rowlist[y] = (unsigned char)y;
-    }
+    if (A.ext_bs && A.lift_t) HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<2>, grid, in, c->ws_tmp, A));
+    else if (A.ext_bs) HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<1>, grid, in, c->ws_tmp, A));
     else HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<0>, grid, in, c->ws_tmp, A));
     A.lift_level = 0; A.ext_bs = nullptr; A.lift_t = nullptr; A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out;
     if (fuse && fuse->epi_x) { A.epi_x = fuse->epi_x; A.epi_x_zs = fuse->epi_x_zs; A.epi_x_is = fuse->epi_x_is; A.epi_mul = fuse->epi_mul; A.epi_add = fuse->epi_add; A.epi_add_zs = fuse->epi_add_zs; A.epi_add_is = fuse->epi_add_is; A.epi_add_mul = fuse->epi_add_mul; }
@@ -1148,7 +1134,6 @@ static HcBasisExt hc_make_bx(const std::vector<u64> &src, u64 t) {
         for (int j = 0; j < B.n; j++) if (j != i) { hat_si = h_mulmod(hat_si, src[(size_t)j] % si, si); hat_t = h_mulmod(hat_t, src[(size_t)j] % t, t); }
         B.inv[i] = h_pair(h_inv(hat_si, si), si);
         B.hat[i] = h_pair(hat_t, t);
-        B.hat31[i] = t < (1ull << 31) ? (u32)h_mulmod(hat_t, (1ull << 31) % t, t) : 0;
         smodt = h_mulmod(smodt, si % t, t);
     }
     B.smodt = h_pair(smodt, t);
@@ -1762,7 +1747,6 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
     if (!strcmp(name, "small_levels")) { if (value < 0) return hc_fail(c, HC_ERR_ARG, "small_levels must be >= 0"); c->small_levels = value; return HC_OK; }
     if (!strcmp(name, "peer_access")) { c->peer_access = value ? 1 : 0; return HC_OK; }
-    if (!strcmp(name, "small_rows")) { c->small_rows = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
     return hc_fail(c, HC_ERR_ARG, "unknown option %s", name);
 }
