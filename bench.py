@@ -441,6 +441,22 @@ def main():
         for k in L["ker"]:
             L["ctx"].ker_free(k)
         L["ctx"].close()
+    # The headline is measured. What follows are extras (the sharded conv 7 3 under N > 1, the chain workloads through the CLI): they must never cost the line. The N > 1 extras
+    # have only ever run as ranks sharing one GPU (no multi-GPU box in this pool), so a watchdog prints the headline alone if they do not come back (a collective that hangs, a
+    # peer copy that stalls) and ends the process; every rank carries it so that the launcher is not left waiting for a stuck rank.
+    import threading
+    emitted = threading.Lock()
+    def _give_up():
+        if not emitted.acquire(blocking=False):
+            return
+        if rank == 0:
+            out["extras"] = "timed out after %d s: headline only" % extras_timeout
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    extras_timeout = int(os.environ.get("HC_BENCH_EXTRAS_TIMEOUT", "420" if world > 1 else "900"))
+    watchdog = threading.Timer(extras_timeout, _give_up)
+    watchdog.daemon = True
+    watchdog.start()
     sharded = None
     if world > 1:           # BASELINE config 3 beside the weak-scaling figure: ONE `conv 7 3` (B = 256) split i mod N over the N devices
         try:
@@ -461,6 +477,9 @@ def main():
                 wl["resnet20"].update({"images_per_hour": world * 3600.0 / float(t.item()), "n_gpus": world, "note": "images sharded over the ranks (independent ciphertexts, no collective); slowest rank's time per image"})
             elif rank == 0 and "resnet20" in wl:
                 wl["resnet20"]["note"] = "another rank produced no figure: this is rank 0's own rate"
+    if not emitted.acquire(blocking=False):       # the watchdog is printing the headline: let it end the process
+        time.sleep(60)
+    watchdog.cancel()
     if rank == 0:
         if wl is not None:
             out["workloads"] = wl
