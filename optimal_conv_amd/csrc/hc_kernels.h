@@ -1609,8 +1609,8 @@ __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES) void hc_k_cols_inv_canon_mm(co
     for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_canon4(e[hi], Q);
 }
 // ModDown fused with the Rescale behind it (hc_keyswitch_add_rescale), the last limb L. Rescale needs the coefficients of c_L = (acc_L - NTT(ext_L)) / P + add_L:
-// by linearity InvNTT(acc_L / P + add_L) - ext_L / P, ext_L being the coefficient-domain extension the y_i / v rows give. hc_k_mdrs_prep: acc_L <- acc_L / P + add_L in
-// place (NTT domain; row L of acc is scratch from here on); hc_k_mdrs_last: t = u - ext_L / P over the inverse transform u of that row (tu[z][t_rows][N], row 0).
+// by linearity InvNTT(acc_L / P + add_L) - ext_L / P, ext_L being the coefficient-domain extension the y_i / v rows give. acc_L <- acc_L / P + add_L where the inner product writes that row (hc_k_ks_mac_all, HcMacPrep; hc_k_mdrs_prep for an acc that comes from elsewhere), in
+// place (NTT domain; row L of acc is scratch from here on); then t = u - ext_L / P over the inverse transform u of that row (row 0 of pc[z]), in the epilogue of the source-side kernel (hc_k_basis_yv<true>).
 // blockIdx.y = component + 2 * image. grid = (64, 2 * images)
 __global__ __launch_bounds__(HC_TPB) void hc_k_mdrs_prep(u64 *acc, size_t acc_zs, size_t acc_is, const u64 *add, size_t add_zs, size_t add_is, int L, const HcTw *pinv, const HcMod *mods) {
     const int zi = (int)blockIdx.y & 1, img = (int)blockIdx.y >> 1;
@@ -1623,35 +1623,33 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_mdrs_prep(u64 *acc, size_t acc_zs
         row[j] = r;
     }
 }
-__global__ __launch_bounds__(HC_TPB) void hc_k_mdrs_last(u64 *tu, int t_rows, const u64 *yv, int yv_rows, const HcBasisExt *Bs, int L, const HcTw *pinv) {
-    const HcBasisExt &B = Bs[L]; const int n = B.n; const HcQ Q = hc_q(B.t); const HcTw w = pinv[L];
-    tu += (size_t)blockIdx.y * t_rows * 65536; yv += (size_t)blockIdx.y * yv_rows * 65536;
-    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        u64 y[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) if (i <= n) y[i] = yv[(size_t)i * 65536 + j];
-        tu[j] = hc_submod(tu[j], hc_mul_shoup(hc_basis_ext_sum(y, B, Q), w.w, w.ws, B.t), B.t);
-    }
-}
-// source side of the fast basis extension, once per coefficient: y_i = x_i (S/s_i)^-1 mod s_i for the n source limbs and the fp64 overflow count v = uint64(sum_i
-// float64(y_i) / float64(s_i)) (ring.reconstructRNS: the reference's expression, limb order) -> yv[z][yv_rows][N] (rows y_0..y_(n-1), then v). The target side - one lazy sum per
-// target limb - runs where the extension's forward transform reads its input (hc_k_cols_fwd_mm, HcMm::ext_bs). blockIdx.y = operand + nz * image. grid = (64, nz * images)
-__global__ __launch_bounds__(HC_TPB) void hc_k_basis_yv(const u64 *src, size_t src_stride, u64 *yv, int yv_rows, const HcBasisExt *Bs, int rows, size_t zs_src, int z_alpha, int nz, size_t is_src) {
+// mdrs != null (ModDown fused with Rescale, hc_ks_moddown_rescale): the row BEFORE the n source rows holds u = InvNTT(acc_L / P + add_L); it becomes t = u - ext_L / P with ext_L the
+// extension of this very coefficient into limb L (constants *mdrs, P^-1 mod q_L = *mdrs_pinv) - hc_k_mdrs_last's work, here where the y_i / v are still in registers
+template <bool MDRS>
+__global__ __launch_bounds__(HC_TPB) void hc_k_basis_yv(const u64 *src, size_t src_stride, u64 *yv, int yv_rows, const HcBasisExt *Bs, int rows, size_t zs_src, int z_alpha, int nz, size_t is_src,
+                                                        const HcBasisExt *mdrs, const HcTw *mdrs_pinv) {
     const int zi = (int)blockIdx.y % nz, img = (int)blockIdx.y / nz;
     src += (size_t)zi * zs_src + (size_t)img * is_src;
     const HcBasisExt &B0 = Bs[z_alpha > 0 ? (size_t)zi * rows : 0];
     const int n = B0.n;
     yv += (size_t)blockIdx.y * yv_rows * 65536;                               // [operand + nz * image][yv_rows][N]: rows y_0..y_(n-1), then v (a last, shorter digit leaves rows unused)
+    const HcBasisExt &BL = MDRS ? *mdrs : B0; const HcQ QL = hc_q(BL.t); const HcTw wL = MDRS ? *mdrs_pinv : HcTw{0, 0};
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        double vi = 0.0;
+        double vi = 0.0; u64 yy[9];
 #pragma unroll
         for (int i = 0; i < 8; i++) if (i < n) {
             const u64 x = hc_barrett64(src[(size_t)i * src_stride + j], B0.s[i], B0.mu_s[i]);
             const u64 y = n == 1 ? x : hc_mul_shoup(x, B0.inv[i].w, B0.inv[i].ws, B0.s[i]);
             vi += (double)y / (double)B0.s[i];
-            yv[(size_t)i * 65536 + j] = y;
+            yv[(size_t)i * 65536 + j] = y; if (MDRS) yy[i] = y;
         }
         yv[(size_t)n * 65536 + j] = (u64)vi;
+        if (MDRS) {
+#pragma unroll
+            for (int i = 1; i < 9; i++) if (i == n) yy[i] = (u64)vi;
+            u64 *tu = const_cast<u64 *>(src) - src_stride + j;
+            *tu = hc_submod(*tu, hc_mul_shoup(hc_basis_ext_sum(yy, BL, QL), wL.w, wL.ws, BL.t), BL.t);
+        }
     }
 }
 // The inner product of a key switch in one launch, BOTH key components and ALL images of a batch per thread:
@@ -1660,10 +1658,16 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_yv(const u64 *src, size_t s
 // components: per coefficient beta * (2 + n) reads and 2 n writes (one image, one component per thread: beta * (2 + 2 n)).
 // grid = (64, nt); images cx_is / dg_is / acc_is words apart.
 // NB images per thread (blockIdx.z = image group): the 128-bit accumulators cost 8 VGPRs per image - 122 VGPRs (4 waves per SIMD) at 8 images per thread, whatever the batch
+// prep_pinv != null (a relinearisation whose ModDown is fused with the Rescale behind it, hc_ks_moddown_rescale): the last Q limb's row leaves as acc_L / P + add_L - the row
+// Rescale's lift is taken from - instead of acc_L (what hc_k_mdrs_prep did in a launch of its own); add: [k][row][N] components add_zs apart, images add_is apart, or null
+struct HcMacPrep { const HcTw *pinv; const u64 *add; size_t add_zs, add_is; };
 template <int NB>
 __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_is, const HcMod *mods,
-                                                          int nl, int nq, int nt, int alpha, int beta, int n) {
+                                                          int nl, int nq, int nt, int alpha, int beta, int n, HcMacPrep prep) {
     const int T = blockIdx.y;
+    const bool prepL = prep.pinv != nullptr && T == nl - 1;                  // block-uniform
+    const HcTw pw = prepL ? prep.pinv[T] : HcTw{0, 0};
+    if (prep.add != nullptr) prep.add += (size_t)blockIdx.z * NB * prep.add_is;
     { const int g0 = (int)blockIdx.z * NB; cx += (size_t)g0 * cx_is; digits += (size_t)g0 * dg_is; acc += (size_t)g0 * acc_is; n = n - g0 < NB ? n - g0 : NB; }
     const HcMod m = mods[T < nl ? T : nq + (T - nl)];
     const size_t rowT = (size_t)T * 65536, comp = (size_t)nt * 65536;
@@ -1691,7 +1695,14 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const 
             }
         }
 #pragma unroll
-        for (int g = 0; g < NB; g++) if (g < n) { u64 *a = acc + (size_t)g * acc_is + rowT + j; a[0] = s0[g]; a[comp] = s1[g]; }
+        for (int g = 0; g < NB; g++) if (g < n) {
+            u64 *a = acc + (size_t)g * acc_is + rowT + j;
+            if (prepL) {
+                u64 r0 = hc_mul_shoup(s0[g], pw.w, pw.ws, m.q), r1 = hc_mul_shoup(s1[g], pw.w, pw.ws, m.q);
+                if (prep.add != nullptr) { const u64 *ad = prep.add + (size_t)g * prep.add_is + rowT + j; r0 = hc_addmod(r0, ad[0], m.q); r1 = hc_addmod(r1, ad[prep.add_zs], m.q); }
+                a[0] = r0; a[comp] = r1;
+            } else { a[0] = s0[g]; a[comp] = s1[g]; }
+        }
     }
 }
 // The inner products of R hoisted rotations in ONE launch (the baby steps of a linear transform share one digit decomposition): a digit element is read once for the R keys

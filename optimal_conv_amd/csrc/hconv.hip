@@ -1253,15 +1253,16 @@ static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, const HcKsS
     // source side of every digit's extension once per coefficient (y_i, v), then the target side inside the first pass of the digits' forward transforms (blockIdx.z =
     // digit + beta * image): the extended digits are never written in the coefficient domain
     const size_t yz = (size_t)(alpha + 1) * HC_N;
-    HC_TRY(hc_launch(c, "decomp:basis_yv", hc_k_basis_yv, dim3(HC_GX_YV, (unsigned)(beta * nb)), (const u64 *)S.coef, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bx, nt, (size_t)alpha * HC_N, alpha, beta, S.coef_is));
+    HC_TRY(hc_launch(c, "decomp:basis_yv", hc_k_basis_yv<false>, dim3(HC_GX_YV, (unsigned)(beta * nb)), (const u64 *)S.coef, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bx, nt, (size_t)alpha * HC_N, alpha, beta, S.coef_is, (const HcBasisExt *)nullptr, (const HcTw *)nullptr));
     HcMmFuse F; F.ext_bs = P->bx; F.ext_rows = nt;
     return hc_ntt_mm(c, S.yv, S.digits, nt, nl, 0, 0, beta, yz, (size_t)nt * HC_N, alpha, nb, (size_t)beta * yz, S.digits_is, "decomp", &F);
 }
 // the inner product with both components of the key, all images: acc [img][2][nt][N], images acc_is words apart
-static int hc_ks_mac(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *acc, size_t acc_is) {
+static int hc_ks_mac(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *acc, size_t acc_is, const HcMacPrep *prep = nullptr) {
+    HcMacPrep PR; memset(&PR, 0, sizeof PR); if (prep) PR = *prep;
     const int alpha = c->np, nl = level + 1, nt = nl + alpha;
     const int nb = c->nb, NB = nb <= 1 ? 1 : nb <= 2 ? 2 : HC_MAC_NB;                 // images per thread; more images = more image groups (blockIdx.z), each reading the key once
-#define HC_MAC_ALL(NN) hc_launch(c, "ks_mac_all", hc_k_ks_mac_all<NN>, dim3(HC_GX_MAC, (unsigned)nt, (unsigned)((nb + NN - 1) / NN)), (const u64 *)key.rows, cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, acc, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, key.beta, nb)
+#define HC_MAC_ALL(NN) hc_launch(c, "ks_mac_all", hc_k_ks_mac_all<NN>, dim3(HC_GX_MAC, (unsigned)nt, (unsigned)((nb + NN - 1) / NN)), (const u64 *)key.rows, cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, acc, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, key.beta, nb, PR)
     return NB == 1 ? HC_MAC_ALL(1) : NB == 2 ? HC_MAC_ALL(2) : NB == 4 ? HC_MAC_ALL(4) : HC_MAC_ALL(8);
 #undef HC_MAC_ALL
 }
@@ -1273,7 +1274,7 @@ static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, size_t acc_is, co
     // InvNTT of the P rows of both components: rows y -> modulus nq + y (nl = 0)
     HC_TRY(hc_intt_mm(c, acc + (size_t)nl * HC_N, S.pc, alpha, 0, 2, (size_t)nt * HC_N, (size_t)alpha * HC_N, 0, 0, nb, acc_is, S.pc_is, "moddown"));
     const size_t yz = (size_t)(alpha + 1) * HC_N;
-    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(HC_GX_YV, 2u * (unsigned)nb), (const u64 *)S.pc, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, (size_t)alpha * HC_N, 0, 2, S.pc_is));
+    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv<false>, dim3(HC_GX_YV, 2u * (unsigned)nb), (const u64 *)S.pc, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, (size_t)alpha * HC_N, 0, 2, S.pc_is, (const HcBasisExt *)nullptr, (const HcTw *)nullptr));
     HcMmFuse F; F.ext_bs = P->bxdown; F.ext_rows = nl;            // {P} -> every Q limb inside the forward transform's first pass
     if (rot_gal) {   // a rotation: + c0 and the permutation ride in ModDown's last pass (d0, d1 = the rotated ciphertext)
         HC_TRY(hc_ntt_mm(c, S.yv, S.ext, nl, nl, 0, 0, 2, yz, (size_t)nl * HC_N, 0, nb, 2 * yz, S.ext_is, "moddown", &F));
@@ -1290,16 +1291,18 @@ static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, size_t acc_is, co
 // (x - NTT(ext)) / P + add - NTT(lift), all / q_L, = (x - NTT(ext + P lift)) / (P q_L) + add / q_L, exactly (modular arithmetic, canonical residues: the bits of the
 // two-step route). The lift needs the last limb's coefficients after ModDown: InvNTT(acc_L / P + add_L) - ext_L / P, the inverse transform riding with the P rows'.
 // acc's row `level` is overwritten.
-static int hc_ks_moddown_rescale(hc_ctx *c, int level, u64 *acc, size_t acc_is, const HcKsScratch &S, u64 *d0, u64 *d1, const u64 *add0, const u64 *add1) {
+static int hc_ks_moddown_rescale(hc_ctx *c, int level, u64 *acc, size_t acc_is, const HcKsScratch &S, u64 *d0, u64 *d1, const u64 *add0, const u64 *add1, bool prepped = false) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const HcTw *qlinv; HC_TRY(hc_rescale_plan(c, level, &qlinv));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, nb = c->nb;
     const size_t tz = (size_t)(alpha + 1) * HC_N, yz = tz;
+    if (!prepped)       // (the inner product of hc_keyswitch_add_rescale leaves row `level` as acc_L / P + add_L already: HcMacPrep)
     HC_TRY(hc_launch(c, "moddown:mdrs_prep", hc_k_mdrs_prep, dim3(HC_GX_YV, 2u * (unsigned)nb), acc, (size_t)nt * HC_N, acc_is, add0, add0 ? (size_t)(add1 - add0) : (size_t)0, c->bs_poly, level, (const HcTw *)P->pinv, (const HcMod *)c->d_mods));
     // InvNTT of row `level` and of the P rows of both components in one pair of launches: pc[z] = [u | the alpha P rows]
     HC_TRY(hc_intt_mm(c, acc, S.pc - (size_t)level * HC_N, nt, nl, 2, (size_t)nt * HC_N, tz, 0, level, nb, acc_is, S.pc_is, "moddown"));
-    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv, dim3(HC_GX_YV, 2u * (unsigned)nb), (const u64 *)(S.pc + HC_N), (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, tz, 0, 2, S.pc_is));
-    HC_TRY(hc_launch(c, "moddown:mdrs_last", hc_k_mdrs_last, dim3(HC_GX_YV, 2u * (unsigned)nb), S.pc, alpha + 1, (const u64 *)S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, level, (const HcTw *)P->pinv));
+    // source side of the P rows' extension and, with each coefficient's y_i / v still in registers, t = u - ext_L / P on the row before them (what hc_k_mdrs_last did in a launch of its own)
+    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv<true>, dim3(HC_GX_YV, 2u * (unsigned)nb), (const u64 *)(S.pc + HC_N), (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, tz, 0, 2, S.pc_is,
+                     (const HcBasisExt *)(P->bxdown + level), (const HcTw *)(P->pinv + level)));
     HcMmFuse F; F.ext_bs = P->bxdown; F.ext_rows = nl; F.lift_level = level; F.lift_t = S.pc; F.lift_t_zs = tz; F.lift_t_is = S.pc_is; F.lift_pmul = P->pmod;
     F.epi_x = acc; F.epi_x_zs = (size_t)nt * HC_N; F.epi_x_is = acc_is; F.epi_mul = P->pinv_qlinv;
     if (add0) { F.epi_add = add0; F.epi_add_zs = (size_t)(add1 - add0); F.epi_add_is = c->bs_poly; F.epi_add_mul = qlinv; }
@@ -1346,8 +1349,10 @@ extern "C" int hc_keyswitch_add_rescale(hc_ctx *c, uint64_t key_id, int level, c
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
     HC_TRY(hc_ks_decompose_into(c, level, cx, S));
     c->hoist_cx = nullptr;
-    HC_TRY(hc_ks_mac(c, *key, level, cx, S, S.acc, S.acc_is));
-    return hc_ks_moddown_rescale(c, level, S.acc, S.acc_is, S, (u64 *)out0, (u64 *)out1, (const u64 *)a0, (const u64 *)a1);
+    const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
+    HcMacPrep PR; PR.pinv = P->pinv; PR.add = (const u64 *)a0; PR.add_zs = (size_t)((const u64 *)a1 - (const u64 *)a0); PR.add_is = c->bs_poly;      // acc_L / P + add_L leaves the inner product (hc_ks_moddown_rescale's first step)
+    HC_TRY(hc_ks_mac(c, *key, level, cx, S, S.acc, S.acc_is, &PR));
+    return hc_ks_moddown_rescale(c, level, S.acc, S.acc_is, S, (u64 *)out0, (u64 *)out1, (const u64 *)a0, (const u64 *)a1, true);
 }
 // Hoisted key switching (evaluator.RotateHoisted, conv.go:131; the baby steps of a linear transform): the decomposition of cx is
 // computed once and kept in the context; every hc_keyswitch_hoisted with the same (cx, level) then only does the inner product with
