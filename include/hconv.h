@@ -90,7 +90,11 @@ int hc_permute(hc_ctx *ctx, uint64_t galEl, const uint64_t *in, uint64_t *out, i
  * by all images and read once per launch: b of hc_lv_mul / hc_lv_mul_acc, b0 == b1 of hc_lv_op2 / hc_qp_op2 (multiplications), every constant vector;
  * switching keys likewise (one fetch of a key row serves all images and both key components). Results are bit-identical to n separate calls.
  * n = 1 (default) restores single-ciphertext behaviour; the L0 one-row primitives above, hc_permute and the L1 convolution (which has its own
- * batch entry point) ignore the setting. A decomposition held by hc_keyswitch_decompose belongs to the batch it was taken under. */
+ * batch entry point) ignore the setting. A decomposition held by hc_keyswitch_decompose belongs to the batch it was taken under.
+ * The setting is context STATE (calls on one hc_ctx are serialised by the caller): a binding must hold it in a scope that restores n = 1 on every way out - INTEGRATION.md 3d
+ * (`Batched` with a deferred reset), `Context.batch()` in abi.py, `Boot::Batch` in the C++ host. Under n > 1 every entry point checks the strides against the footprint of its
+ * operands at the call's level - poly_stride >= (level+1) N, qp_stride >= 2 (level+1+np) N where it takes extended-basis pairs - and fails with HC_ERR_ARG otherwise (images
+ * that overlap would race inside one launch). */
 int hc_set_batch(hc_ctx *ctx, int n, size_t poly_stride_words, size_t qp_stride_words);
 
 /* ---- L0, leveled: a polynomial at `level` is (level+1) consecutive rows, row l modulo q_l (Lattigo's ring.Poly / ckks.Element

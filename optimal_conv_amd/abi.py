@@ -3,6 +3,7 @@
 The library is HIP-only: `load()` raises if libhconv.so has not been built (see __graft_entry__.build) and
 `Context()` raises if no GPU is visible. There is no CPU fallback anywhere in this package.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -212,6 +213,17 @@ class Context:
     def set_batch(self, n, poly_stride=0, qp_stride=0):
         """hc_set_batch: n images per launch of the leveled entry points, strides in words"""
         self._ck(self.L.hc_set_batch(self.h, int(n), int(poly_stride), int(qp_stride)))
+
+    @contextlib.contextmanager
+    def batch(self, n, poly_stride=0, qp_stride=0):
+        """Scope in which every leveled entry point covers n images per launch. The batch is a piece of context state on the C side (hc_set_batch); this guard is how a
+        binding should hold it: the context is back at ONE image per call on every way out of the block, exceptions included, so that a later call can never stride into
+        images it was not given (the Go shim of INTEGRATION.md 3d does the same with `defer`)."""
+        self.set_batch(n, poly_stride, qp_stride)
+        try:
+            yield self
+        finally:
+            self.L.hc_set_batch(self.h, 1, 0, 0)
 
     def set_option(self, name, value):
         self._ck(self.L.hc_set_option(self.h, name.encode(), int(value)))

@@ -99,17 +99,6 @@ HC_HD u64 hc_opaque_uniform(u64 v) {
 // per-kernel constants of one modulus (q must be uniform over the wave: every call site takes it from kernel arguments or from a
 // table indexed by blockIdx)
 struct HcQ { u64 q, nq, q4, nq4, nq2; };     // nq = 2^64 - q, q4 = 4q, nq4 = 2^64 - 4q, nq2 = 2^64 - 2q
-// the same constants for a modulus the compiler cannot prove wave-uniform (loaded inside a loop): kept opaque in vector registers
-HC_HD u64 hc_opaque_vector(u64 v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("; constant kept opaque" : "+v"(v));
-#endif
-    return v;
-}
-HC_HD HcQ hc_qv(u64 q) {
-    HcQ Q; Q.q = q; Q.nq = hc_opaque_vector(0 - q); Q.q4 = 4 * q; Q.nq4 = hc_opaque_vector(0 - 4 * q); Q.nq2 = hc_opaque_vector(0 - 2 * q);
-    return Q;
-}
 HC_HD HcQ hc_q(u64 q) {
     HcQ Q; Q.q = q; Q.nq = hc_opaque_uniform(0 - q); Q.q4 = 4 * q; Q.nq4 = hc_opaque_uniform(0 - 4 * q); Q.nq2 = hc_opaque_uniform(0 - 2 * q);
     return Q;

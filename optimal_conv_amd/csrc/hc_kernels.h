@@ -1005,6 +1005,9 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, H
 #ifndef HC_B5M_WAVES
 #define HC_B5M_WAVES 3
 #endif
+// `#pragma unroll MACRO` is not expanded in the second phase of `hipcc -save-temps` (the macro is gone from the preprocessed file): _Pragma is expanded by the preprocessor itself
+#define HC_PRAGMA_(x) _Pragma(#x)
+#define HC_UNROLL_N(n) HC_PRAGMA_(unroll n)
 template <int FM>
 __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTwTab T0fwd, HcPtrs biases, HcPtrs outs) {
     __shared__ u64 lds[HC_ROWS_LDS];
@@ -1020,7 +1023,7 @@ __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTw
     u64 *__restrict__ o = (outs.p[z] != nullptr ? const_cast<u64 *>(outs.p[z]) : B.dst + (size_t)z * B.dst_stride + (size_t)i * 2 * 65536) + tile;
     const u64 *__restrict__ bias = biases.p[z] != nullptr ? biases.p[z] + tile : nullptr;        // null except on the last node of the tree (eval.go:258)
     u64 e[16], T[16];
-#pragma unroll HC_B5M_UNROLL
+    HC_UNROLL_N(HC_B5M_UNROLL)
     for (int k = 1; k >= 0; k--) {
         const u64 *__restrict__ in = B.tmpE + ((size_t)zn * 2 + k) * 65536 + (size_t)row * 256;
 #pragma unroll

@@ -486,22 +486,33 @@ extern "C" int hc_permute(hc_ctx *c, uint64_t galEl, const uint64_t *in, uint64_
     return hc_launch(c, "permute", hc_k_permute, hc_pw_grid((size_t)count * HC_N), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), count);
 }
 
+// Under an image batch the images of an operand must not overlap: a stride below the operand's footprint at this level would let the blockIdx.z slices of a launch race
+// on shared rows (silent corruption), so it is an argument error. qp: the operand is an extended-basis pair [2][level+1+np][N].
+static int hc_batch_fits(hc_ctx *c, const char *fn, int level, bool qp) {
+    if (c->nb <= 1) return HC_OK;
+    if (c->bs_poly < (size_t)(level + 1) * HC_N) return hc_fail(c, HC_ERR_ARG, "%s: image stride %zu words is below the %d rows of a polynomial at level %d (hc_set_batch)", fn, c->bs_poly, level + 1, level);
+    if (qp && c->bs_qp < (size_t)2 * (size_t)(level + 1 + c->np) * HC_N) return hc_fail(c, HC_ERR_ARG, "%s: extended-basis image stride %zu words is below 2 x %d rows at level %d (hc_set_batch)", fn, c->bs_qp, level + 1 + c->np, level);
+    return HC_OK;
+}
 // evaluator.permuteNTT after the key switch (RotateNew / RotateHoisted / ConjugateNew): out0 = Permute(d0 + c0), out1 = Permute(d1), all limbs, one launch
 extern "C" int hc_rotate_finish(hc_ctx *c, uint64_t galEl, int level, const uint64_t *d0, const uint64_t *d1, const uint64_t *c0, uint64_t *out0, uint64_t *out1) {
     HC_ENTER(c);
     if (level < 0 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "hc_rotate_finish: level %d outside 0..%d", level, c->nq - 1);
     if (!d0 || !d1 || !c0 || !out0 || !out1 || out0 == d0 || out0 == c0 || out1 == d1 || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_rotate_finish: bad arguments (outputs must differ from inputs, galEl odd)");
+    HC_TRY(hc_batch_fits(c, "hc_rotate_finish", level, false));
     return hc_launch(c, "rotate_finish", hc_k_rotate_finish, dim3(HC_GX_LV, (unsigned)(level + 1), 2u * (unsigned)c->nb), (const u64 *)d0, (const u64 *)d1, (const u64 *)c0, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, (u32)(galEl & 0x1FFFF), c->bs_poly);
 }
 // ring.PermuteNTTWithIndexLvl on a polynomial at `level` (rows 0..level) / on an extended-basis pair [2][level+1+np][N], for every image of the batch
 extern "C" int hc_lv_permute(hc_ctx *c, uint64_t galEl, int level, const uint64_t *in, uint64_t *out) {
     HC_ENTER(c);
     if (level < 0 || level >= c->nq || !in || !out || in == out || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_lv_permute: bad arguments (in/out must differ, galEl odd)");
+    HC_TRY(hc_batch_fits(c, "hc_lv_permute", level, false));
     return hc_launch(c, "permute", hc_k_permute_mm, dim3(HC_GX_LV, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), c->bs_poly);
 }
 extern "C" int hc_qp_permute2(hc_ctx *c, uint64_t galEl, int level, const uint64_t *in, uint64_t *out) {
     HC_ENTER(c);
     if (level < 0 || level >= c->nq || c->np < 1 || !in || !out || in == out || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_qp_permute2: bad arguments (in/out must differ, galEl odd)");
+    HC_TRY(hc_batch_fits(c, "hc_qp_permute2", level, true));
     return hc_launch(c, "permute", hc_k_permute_mm, dim3(HC_GX_LV, 2u * (unsigned)(level + 1 + c->np), (unsigned)c->nb), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), c->bs_qp);
 }
 // Image batch of the leveled evaluator (include/hconv.h): n images per launch, the images of an operand stride words apart
@@ -509,7 +520,7 @@ extern "C" int hc_set_batch(hc_ctx *c, int n, size_t poly_stride_words, size_t q
     if (!c) return HC_ERR_ARG;
     if (n < 1 || n > HC_MAXIMG) return hc_fail(c, HC_ERR_ARG, "hc_set_batch: n=%d outside 1..%d", n, HC_MAXIMG);
     if (n > 1 && (poly_stride_words < (size_t)HC_N || (c->np > 0 && qp_stride_words < (size_t)HC_N))) return hc_fail(c, HC_ERR_ARG, "hc_set_batch: strides must cover at least one row");
-    if (n != c->nb || poly_stride_words != c->bs_poly) c->hoist_cx = nullptr;       // a held decomposition belongs to the batch it was taken under
+    if (n != c->nb || poly_stride_words != c->bs_poly || qp_stride_words != c->bs_qp) c->hoist_cx = nullptr;       // a held decomposition belongs to the batch it was taken under
     c->nb = n; c->bs_poly = n > 1 ? poly_stride_words : 0; c->bs_qp = n > 1 ? qp_stride_words : 0;
     return HC_OK;
 }
@@ -518,7 +529,7 @@ extern "C" int hc_set_batch(hc_ctx *c, int n, size_t poly_stride_words, size_t q
 static int hc_lv_check(hc_ctx *c, const char *fn, int level, const void *a, const void *out) {
     if (level < 0 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "%s: level %d outside 0..%d", fn, level, c->nq - 1);
     if (!a || !out) return hc_fail(c, HC_ERR_ARG, "%s: null", fn);
-    return HC_OK;
+    return hc_batch_fits(c, fn, level, false);
 }
 // b_shared: the second operand is a plaintext common to every image of the batch (read once per coefficient: one thread does all images)
 template <int OP>
@@ -754,6 +765,7 @@ static int hc_rescale_plan(hc_ctx *c, int level, const HcTw **out) {
 static int hc_div_round_last_n(hc_ctx *c, int level, const u64 *x, size_t xs, u64 *out, size_t os, int np) {
     if (level < 1 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "hc_div_round_last: level %d outside 1..%d", level, c->nq - 1);
     if (!x || !out) return hc_fail(c, HC_ERR_ARG, "hc_div_round_last: null");
+    HC_TRY(hc_batch_fits(c, "hc_div_round_last", level, false));
     if (level != 1) {
         // general level (the leveled evaluator of the convReLU chain): InvNTT of the last limb, centred lift into every lower
         // modulus, NTT there, subtract, multiply by qL^-1 -- six launches whatever the level. in == out is allowed.
@@ -1159,6 +1171,7 @@ static int hc_swk_generate_impl(hc_ctx *c, uint64_t key_id, int level, uint64_t 
     if (!sk_ntt || level < 0 || level >= c->nq || c->np < 1 || c->np > 8 || (galEl && !(galEl & 1))) return hc_fail(c, HC_ERR_ARG, "hc_swk_generate: bad arguments");
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
     if (beta > 63 || nt > 62) return hc_fail(c, HC_ERR_UNSUPPORTED, "hc_swk_generate: more than 62 limbs");
+    if (!splitmix && (key_id >> 40)) return hc_fail(c, HC_ERR_ARG, "hc_swk_generate: key id %llu does not fit the 40 bits of the ChaCha nonce that tell keys apart", (unsigned long long)key_id);
     HcKeyGen G; memset(&G, 0, sizeof G);
     if (seed8) memcpy(G.key, seed8, sizeof G.key);
     G.id_lo = (u32)key_id; G.id_hi = (u32)(key_id >> 32) & 0xFFu;
@@ -1313,7 +1326,8 @@ static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *c
     HC_TRY(hc_ks_mac(c, key, level, cx, S, S.acc, S.acc_is));
     return hc_ks_moddown(c, level, S.acc, S.acc_is, S, d0, d1, rot_gal, rot_c0, add0, add1);
 }
-static int hc_ks_find(hc_ctx *c, const char *fn, uint64_t key_id, int level, const HcSwk **key) {
+static int hc_ks_find(hc_ctx *c, const char *fn, uint64_t key_id, int level, const HcSwk **key, bool qp_operands = false) {
+    HC_TRY(hc_batch_fits(c, fn, level, qp_operands));
     auto it = c->swk.find(key_id);
     if (it == c->swk.end()) return hc_fail(c, HC_ERR_STATE, "%s: no switching key %llu loaded", fn, (unsigned long long)key_id);
     if (level != it->second.level) return hc_fail(c, HC_ERR_ARG, "%s: key %llu is loaded for level %d, not %d", fn, (unsigned long long)key_id, it->second.level, level);
@@ -1361,6 +1375,7 @@ extern "C" int hc_keyswitch_add_rescale(hc_ctx *c, uint64_t key_id, int level, c
 extern "C" int hc_keyswitch_decompose(hc_ctx *c, int level, const uint64_t *cx) {
     HC_ENTER(c);
     if (!cx || level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_decompose: bad arguments");
+    HC_TRY(hc_batch_fits(c, "hc_keyswitch_decompose", level, false));
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
     HC_TRY(hc_ks_decompose_into(c, level, cx, S));
     c->hoist_cx = cx; c->hoist_level = level;
@@ -1398,7 +1413,7 @@ extern "C" int hc_keyswitch_rotate(hc_ctx *c, uint64_t key_id, uint64_t galEl, i
 // hc_keyswitch_decompose(level, cx) left in the context): acc[2][level+1+np][N], rows Q_0..Q_level then P_0..P_(np-1), canonical, NTT.
 extern "C" int hc_keyswitch_qp(hc_ctx *c, uint64_t key_id, int level, const uint64_t *cx, uint64_t *acc, int hoisted) {
     HC_ENTER(c);
-    const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_qp", key_id, level, &key));
+    const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_qp", key_id, level, &key, true));
     if (!cx || !acc) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_qp: null");
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
     if (hoisted) {
@@ -1414,7 +1429,7 @@ extern "C" int hc_keyswitch_qp(hc_ctx *c, uint64_t key_id, int level, const uint
 // one pass applies the rest. The same residues as hc_keyswitch_qp + hc_lv_add + hc_qp_permute2 (+ hc_qp_op2 ADD).
 extern "C" int hc_keyswitch_qp_rotate(hc_ctx *c, uint64_t key_id, uint64_t galEl, int level, const uint64_t *pc0, const uint64_t *cx, uint64_t *out, int hoisted, int accumulate) {
     HC_ENTER(c);
-    const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_qp_rotate", key_id, level, &key));
+    const HcSwk *key; HC_TRY(hc_ks_find(c, "hc_keyswitch_qp_rotate", key_id, level, &key, true));
     if (!cx || !out || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_qp_rotate: bad arguments (galEl odd)");
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
     if (hoisted) {
@@ -1447,7 +1462,7 @@ extern "C" int hc_keyswitch_qp_rotate_many(hc_ctx *c, int nrot, const uint64_t *
     }
     std::vector<const HcSwk *> keys((size_t)nrot);                           // every rotation is checked before the first launch: an error leaves nothing half done
     for (int r = 0; r < nrot; r++) {
-        HC_TRY(hc_ks_find(c, "hc_keyswitch_qp_rotate_many", key_ids[r], level, &keys[(size_t)r]));
+        HC_TRY(hc_ks_find(c, "hc_keyswitch_qp_rotate_many", key_ids[r], level, &keys[(size_t)r], true));
         if (!(galEls[r] & 1) || !outs[r]) return hc_fail(c, HC_ERR_ARG, "hc_keyswitch_qp_rotate_many: rotation %d: galEl must be odd, out non-null", r);
     }
     for (int r0 = 0; r0 < nrot; r0 += R) {
@@ -1470,6 +1485,7 @@ extern "C" int hc_mod_down2(hc_ctx *c, int level, const uint64_t *x, uint64_t *o
     HC_ENTER(c);
     if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_mod_down2: level %d outside 0..%d or no special primes", level, c->nq - 1);
     if (!x || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_mod_down2: null");
+    HC_TRY(hc_batch_fits(c, "hc_mod_down2", level, true));
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
     if (level != c->hoist_level) c->hoist_cx = nullptr;      // the scratch layout depends on the level: pc / ext of another level overlap the held digits
     return hc_ks_moddown(c, level, (const u64 *)x, c->bs_qp, S, (u64 *)out0, (u64 *)out1, 0, nullptr);
@@ -1481,6 +1497,7 @@ extern "C" int hc_mod_down2_add_rescale(hc_ctx *c, int level, uint64_t *x, const
     HC_ENTER(c);
     if (level < 2 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_mod_down2_add_rescale: level %d outside 2..%d or no special primes", level, c->nq - 1);
     if (!x || !out0 || !out1 || (a0 == nullptr) != (a1 == nullptr)) return hc_fail(c, HC_ERR_ARG, "hc_mod_down2_add_rescale: null (the addends come as a pair)");
+    HC_TRY(hc_batch_fits(c, "hc_mod_down2_add_rescale", level, true));
     HcKsScratch S; HC_TRY(hc_ks_scratch(c, level, &S));
     if (level != c->hoist_level) c->hoist_cx = nullptr;
     return hc_ks_moddown_rescale(c, level, (u64 *)x, c->bs_qp, S, (u64 *)out0, (u64 *)out1, (const u64 *)a0, (const u64 *)a1);
@@ -1491,6 +1508,7 @@ extern "C" int hc_qp_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const
     HC_ENTER(c);
     if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: level %d outside 0..%d or no special primes", level, c->nq - 1);
     if (!a0 || !a1 || !b0 || !b1 || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: null");
+    HC_TRY(hc_batch_fits(c, "hc_qp_op2", level, true));
     HcLvConsts K; memset(&K, 0, sizeof K);
     const size_t as = (size_t)(a1 - a0), bs = (size_t)(b1 - b0), os = (size_t)(out1 - out0);
     const bool b_shared = b0 == b1 && op != HC_LV_ADD, inthread = b_shared && c->nb > 1;                                  // a plaintext (an encoded diagonal): one for every image
@@ -1509,6 +1527,7 @@ extern "C" int hc_qp_mul_sum(hc_ctx *c, int level, int nterms, const uint64_t *c
     HC_ENTER(c);
     if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum: level %d outside 0..%d or no special primes", level, c->nq - 1);
     if (!a || !pt || !out || nterms < 1 || nterms > HC_MAXTERMS) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum: bad arguments (1 <= nterms <= %d)", HC_MAXTERMS);
+    HC_TRY(hc_batch_fits(c, "hc_qp_mul_sum", level, true));
     HcTermPtrs P; memset(&P, 0, sizeof P);
     for (int t = 0; t < nterms; t++) { if (!a[t] || !pt[t] || a[t] == out) return hc_fail(c, HC_ERR_ARG, "hc_qp_mul_sum: null or aliased term %d", t); P.a[t] = (const u64 *)a[t]; P.pt[t] = (const u64 *)pt[t]; }
     const int nt = level + 1 + c->np;
@@ -1520,6 +1539,7 @@ extern "C" int hc_qp_mul_sum(hc_ctx *c, int level, int nterms, const uint64_t *c
 static int hc_qp_mul_sum_g(hc_ctx *c, const char *fn, int level, int nterms, int ngiant, const uint64_t *const *a, const uint64_t *const *pt, uint64_t *const *out, const int *accumulate) {
     if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "%s: level %d outside 0..%d or no special primes", fn, level, c->nq - 1);
     if (!a || !pt || !out || !accumulate || ngiant < 1 || ngiant > HC_MAXGIANT || nterms < 1 || nterms > HC_MAXTERMS) return hc_fail(c, HC_ERR_ARG, "%s: bad arguments (1 <= nterms <= %d, 1 <= giant steps <= %d)", fn, HC_MAXTERMS, HC_MAXGIANT);
+    HC_TRY(hc_batch_fits(c, fn, level, true));
     HcTermPtrsG P; memset(&P, 0, sizeof P);
     for (int h = 0; h < ngiant; h++) {
         if (!out[h]) return hc_fail(c, HC_ERR_ARG, "%s: null output %d", fn, h);

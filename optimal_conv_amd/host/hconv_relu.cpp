@@ -111,6 +111,12 @@ struct Boot {
         explicit Single(Boot *b_) : b(b_), saved(b_->nb) { if (saved != 1) b->set_nb(1); }
         ~Single() { if (saved != 1) b->set_nb(saved); }
     };
+    struct Batch {             // scope in which every leveled ABI call covers n images; the context is back at ONE image per call on every way out of the scope
+        Boot *b;
+        Batch(Boot *b_, int n) : b(b_) { b->set_nb(n); }
+        ~Batch() { b->nb = 1; hc_set_batch(b->hc, 1, 0, 0); }
+        Batch(const Batch &) = delete; Batch &operator=(const Batch &) = delete;
+    };
     std::shared_ptr<uint64_t> block() {
         uint64_t *d;
         if (!pool.empty()) { d = pool.back(); pool.pop_back(); }
@@ -1276,7 +1282,7 @@ std::vector<BootCiphertext> evalConv_BNRelu_tail_batch(Boot *B, const std::strin
     if (!sparse && log_sparse != 0) panic("No cases for log_sparse");
     const int nimg = (int)ct_conv_dev.size();
     if (nimg < 1 || nimg > (B->merge_parts ? B->nb_max / 2 : B->nb_max)) panic("evalConv_BNRelu_tail: more images than the bootstrapper's image batch (HCONV_IMAGE_BATCH)");
-    B->set_nb(nimg); B->alg_ct = B->alg_shared = 0;
+    Boot::Batch batch_scope(B, nimg); B->alg_ct = B->alg_shared = 0;                                  // hc_set_batch(nimg) here, hc_set_batch(1) wherever this function is left
     DCt ct = B->new_ct(0, 1, ct_scale * pow(2.0, pow_));                                            // eval.go:437
     for (int z = 0; z < nimg; z++) for (int d = 0; d < 2; d++) HCR(hc_copy(hc, ct.p[d].get() + (size_t)z * B->poly_stride(), ct_conv_dev[(size_t)z] + (size_t)d * N, (size_t)N * 8));
     // ct_conv_dev belongs to ANOTHER context (the convolution's): the copies above are queued on this context's stream, and the caller frees
@@ -1346,7 +1352,6 @@ std::vector<BootCiphertext> evalConv_BNRelu_tail_batch(Boot *B, const std::strin
         for (int d = 0; d < 2; d++) HCR(hc_copy(hc, out.d + (size_t)d * (res.level + 1) * N, res.p[d].get() + (size_t)z * B->poly_stride(), (size_t)(res.level + 1) * N * 8));
     }
     HCR(hc_sync(hc));
-    B->set_nb(1);
     return outs;
 }
 BootCiphertext evalConv_BNRelu_tail(Boot *B, const std::string &kind, int log_sparse, const uint64_t *ct_conv_dev, double ct_scale, double alpha, double pow_, int in_wid, int kp_wid) {

@@ -386,13 +386,17 @@ def case_keyswitch_qp_mod_down(make_ctx, make_oracle, level=4, alpha=3, nkeys=2)
     ctx.close()
 
 
-def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
+def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4, make_oracle=None, chain=None):
     """hc_set_batch: every leveled entry point on n images per launch (operands `stride` words apart, plaintexts and keys shared) must give,
     for every image, the bits of the same call on that image alone (which the other cases pin to the oracle). Strides are padded so that an
     addressing slip lands in the padding, outputs start from a non-zero fill, and the images' inputs differ."""
     import ctypes as C
-    Q, P = Q_MIX[: level + 2], P_CHAIN[:alpha]            # one modulus above the level: rows and moduli must not be confused
+    QC, PC = chain if chain is not None else (Q_MIX, P_CHAIN)      # chain = (Q, P) of a real parameter set: the shapes the bench times (level 27, alpha 5)
+    Q, P = list(QC[: level + 2]), list(PC[:alpha])        # one modulus above the level (where the chain has one): rows and moduli must not be confused
     ctx = make_ctx(Q, P)
+    O = make_oracle(Q, P) if make_oracle is not None else None     # oracle legs: every FUSED entry point against the CPU oracle, not only against its unfused composition
+    oimgs = sorted({0, n - 1})
+    omod = lambda t: t if t < level + 1 else len(Q) + (t - (level + 1))
     L = ctx.L
     nl, nt, beta = level + 1, level + 1 + alpha, (level + 1 + alpha - 1) // alpha
     PS, QS = (nl + 2) * N, (2 * nt + 3) * N
@@ -479,6 +483,18 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
 
     lin_ins = [(x_, "p") for pair in As for x_ in pair]
     got_lin = run("lv_lincomb2", lincomb, lin_ins, [("p", PW), ("p", PW)])
+    if O is not None:
+        for z in oimgs:
+            for k_ in range(2):
+                want_rows = []
+                for l in range(nl):
+                    acc_ = O.mul_scalar(l, As[0][k_][z][l], int(cvals[0][l]) % Q[l])
+                    for t in range(1, NL):
+                        acc_ = O.add(l, acc_, O.mul_scalar(l, As[t][k_][z][l], int(cvals[t][l]) % Q[l]))
+                    if k_ == 0:
+                        acc_ = O.add(l, acc_, np.full(N, int(addc[l]) % Q[l], dtype=np.uint64))
+                    want_rows.append(acc_)
+                eq(got_lin[k_][z], np.stack(want_rows).reshape(-1), f"lv_lincomb2 == oracle (image {z}, polynomial {k_})")
     ctx.set_batch(1)
     for z in range(n):                       # the chain, image by image
         bufs = [ctx.buf(x_[z]) for pair in As for x_ in pair]; o0, o1 = ctx.buf(nwords=PW), ctx.buf(nwords=PW)
@@ -503,13 +519,15 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
         run(f"div_round_last2 level {lv}", lambda p0, p1, o0, o1, lv=lv: ck(L.hc_div_round_last2(h, lv, p0, p1, o0, o1)), [(x0, "p"), (x1, "p")], [("p", lv * N), ("p", lv * N)])
         run(f"div_round_last level {lv}", lambda p0, o0, lv=lv: ck(L.hc_div_round_last(h, lv, p0, o0)), [(x0, "p")], [("p", lv * N)])
     # key switching: two keys at `level`
+    evks = {}
     for kid in range(2):
         evk = np.empty((beta, 2, nt, N), dtype=np.uint64)
         for d in range(beta):
             for k in range(2):
                 for T in range(nt):
-                    evk[d, k, T] = splitmix_rows(seed + 9000 + 1000 * kid + ((d * 2 + k) * 16 + T), qp_mod(T), N)
+                    evk[d, k, T] = splitmix_rows(seed + 9000 + 1000 * kid + ((d * 2 + k) * 64 + T), qp_mod(T), N)
         ctx.swk_load(30 + kid, level, evk)
+        evks[30 + kid] = evk
     K0, K1 = C.c_uint64(30), C.c_uint64(31)
     ks = run("keyswitch", lambda x, d0, d1: ck(L.hc_keyswitch(h, K0, level, x, d0, d1)), [(a, "p")], [("p", PW), ("p", PW)])
 
@@ -540,6 +558,12 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
     for k_ in range(2):
         eq(kr[k_], kr2[k_], f"keyswitch_add_rescale == keyswitch_add + div_round_last2 (polynomial {k_})")
         assert not (kr[k_] == 0x1234567).any(), "keyswitch_add_rescale left output words unwritten"
+    if O is not None:
+        for z in oimgs:
+            w = O.keyswitch(level, a[z], evks[30])
+            for k_, addend in ((0, b), (1, b1)):
+                summed = np.stack([O.add(l, w[k_][l], addend[z][l]) for l in range(nl)])
+                eq(kr[k_][z], O.div_round_last(level, summed).reshape(-1), f"keyswitch_add_rescale == oracle key switch + add + DivRoundByLastModulusNTT (image {z}, polynomial {k_})")
 
     # the end of a linear transform in one call == ModDown, the additions, Rescale
     xq = np.stack([np.stack([np.stack([rnd(qp_mod(t)) for t in range(nt)]) for _ in range(2)]).reshape(-1) for _ in range(n)])
@@ -566,6 +590,14 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
     for k_ in range(2):
         eq(m1[k_], m3[k_], f"mod_down2_add_rescale == mod_down2 + add + div_round_last2 (polynomial {k_})")
         eq(m0[k_], m2[k_], f"mod_down2_add_rescale without addend == mod_down2 + div_round_last2 (polynomial {k_})")
+    if O is not None:
+        for z in oimgs:
+            xz = xq[z].reshape(2, nt, N)
+            for k_, addend in ((0, b), (1, b1)):
+                down_ = O.mod_down(level, xz[k_])
+                summed = np.stack([O.add(l, down_[l], addend[z][l]) for l in range(nl)])
+                eq(m1[k_][z], O.div_round_last(level, summed).reshape(-1), f"mod_down2_add_rescale == oracle ModDown + add + DivRoundByLastModulusNTT (image {z}, polynomial {k_})")
+                eq(m0[k_][z], O.div_round_last(level, down_).reshape(-1), f"mod_down2_add_rescale (no addend) == oracle (image {z}, polynomial {k_})")
 
     def hoisted(x, d0, d1, e0, e1):
         ck(L.hc_keyswitch_decompose(h, level, x)); ck(L.hc_keyswitch_hoisted(h, K0, level, x, d0, d1)); ck(L.hc_keyswitch_hoisted(h, K1, level, x, e0, e1))
@@ -611,6 +643,16 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
     for i in range(len(rots)):
         eq(rm[i], rs_[i], f"rotate_many == single hoisted rotations (rotation {i})")
     eq(rm[0], qr[0], "rotate_many (hoisted) == the plain fused rotation")
+    if O is not None:
+        for z in oimgs:
+            accs_ = O.keyswitch_qp_hoisted(level, a[z], [evks[kid_] for kid_, g_ in rots])
+            for i, (kid_, g_) in enumerate(rots):
+                idx_ = O.permute_index(g_)
+                acc_ = accs_[i].copy()
+                for l in range(nl):
+                    acc_[0, l] = O.add(l, acc_[0, l], b[z][l])              # + P c0 on the Q rows of the first component (pc0 = b)
+                want_ = np.stack([np.stack([O.permute(idx_, acc_[k_, t]) for t in range(nt)]) for k_ in range(2)])
+                eq(rm[i][z], want_.reshape(-1), f"keyswitch_qp_rotate_many == oracle hoisted key switch + P c0 + permutation (image {z}, rotation {i})")
     # error behaviour: no decomposition held -> refused before any launch; an unknown key among the rotations likewise
     xa, xo = ctx.buf(a[0]), ctx.buf(nwords=2 * nt * N)
     ids1 = (C.c_uint64 * 1)(30); gs1 = (C.c_uint64 * 1)(gal); arr1 = (C.c_void_p * 1)(xo.ptr)
@@ -688,7 +730,48 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4):
     g1b = run("qp_mul_sum x3", sum1x3, ins3, [("q", QW)] * 3, init=init3)
     for k_ in range(3):
         eq(g3[k_], g1b[k_], f"qp_mul_sum_many == three qp_mul_sum calls (giant step {k_})")
+    if O is not None:
+        allp = [pts, pts2, pts3]
+        for z in oimgs:
+            for g_, accu in ((0, 1), (1, 0), (2, 1)):
+                want_ = np.empty((2, nt, N), dtype=np.uint64)
+                for k_ in range(2):
+                    for t_ in range(nt):
+                        m_ = omod(t_)
+                        r_ = acc[z, k_, t_] if accu else np.zeros(N, dtype=np.uint64)
+                        for u_ in uses[g_]:
+                            r_ = O.add(m_, r_, O.mul(m_, Xs[u_][z, k_, t_], allp[g_][u_][t_]))
+                        want_[k_, t_] = r_
+                eq(g3[g_][z], want_.reshape(-1), f"qp_mul_sum_many == oracle sum of products (image {z}, giant step {g_})")
+                if g_ < 2:
+                    eq(g2[g_][z], want_.reshape(-1), f"qp_mul_sum2 == oracle sum of products (image {z}, giant step {g_})")
     run("qp_permute2", lambda x, o: ck(L.hc_qp_permute2(h, C.c_uint64(gal), level, x, o)), [(X, "q")], [("q", QW)])
+    # the batch is held by a scope: whatever ends the scope - an exception inside it included - the next leveled call acts on ONE image again
+    xa, xb, xo = put(a, PS), put(b, PS), put(np.full((n, PW), 0x1234567, dtype=np.uint64), PS)
+    try:
+        with ctx.batch(n, PS, QS):
+            ck(L.hc_lv_add(h, level, xa.ptr, xb.ptr, xo.ptr))
+            raise RuntimeError("leaves the batch scope early")
+    except RuntimeError:
+        pass
+    ctx.sync()
+    full = get(xo, PS, PW)
+    xo.upload(np.full(n * PS, 0x1234567, dtype=np.uint64))
+    ck(L.hc_lv_add(h, level, xa.ptr, xb.ptr, xo.ptr)); ctx.sync()
+    after = get(xo, PS, PW)
+    eq(after[0], full[0], "after a batch scope ended by an exception: image 0 is computed as before")
+    assert n == 1 or (after[1:] == 0x1234567).all(), "a leveled call after a batch scope was left by an exception still strides over the images of the batch"
+    # strides below the operands' footprint make the images of a batch overlap: refused, nothing launched
+    if n > 1:
+        ctx.set_batch(n, nl * N - N, QS)
+        assert L.hc_lv_add(h, level, xa.ptr, xb.ptr, xo.ptr) != 0, "an image stride below (level+1) rows must be refused"
+        ctx.set_batch(n, PS, 2 * nt * N - N)
+        assert L.hc_qp_permute2(h, C.c_uint64(gal), level, xa.ptr, xo.ptr) != 0, "an extended-basis image stride below 2 (level+1+np) rows must be refused"
+        ck(L.hc_lv_add(h, level, xa.ptr, xb.ptr, xo.ptr))            # the polynomial stride is fine: the leveled call itself still runs
+        ctx.set_batch(1)
+    ctx.sync()
+    for b_ in (xa, xb, xo):
+        b_.free()
     ctx.close()
 
 

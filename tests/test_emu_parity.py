@@ -164,9 +164,10 @@ def test_keyswitch_hoisted():
 
 @pytest.mark.parametrize("n,level,alpha", [(3, 4, 3), (2, 5, 2)])
 def test_batched_leveled_entry_points(n, level, alpha):
-    """hc_set_batch: n images per launch through every leveled entry point == n single-image calls, bit for bit"""
+    """hc_set_batch: n images per launch through every leveled entry point == n single-image calls, bit for bit; every fused entry point also == the CPU oracle; a batch
+    scope left by an exception leaves the context at one image per call; image strides below an operand's footprint are refused"""
     subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
-    pc.case_batched_leveled(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), n=n, level=level, alpha=alpha)
+    pc.case_batched_leveled(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), n=n, level=level, alpha=alpha, make_oracle=lambda Q, P: Oracle(q=Q, p=P))
 
 
 def test_swk_generate_switches_keys():

@@ -595,12 +595,15 @@ def test_keyswitch_hoisted_on_gpu():
     pc.case_keyswitch_hoisted(lambda Q, P: Context(Q, P), lambda Q, P: Oracle(q=Q, p=P), level=4, alpha=5, nkeys=2)
 
 
-@pytest.mark.parametrize("n,level,alpha", [(8, 5, 3), (3, 4, 5), (5, 2, 1)])
-def test_batched_leveled_entry_points_on_gpu(n, level, alpha):
+@pytest.mark.parametrize("n,level,alpha,real_chain", [(8, 27, 5, True), (3, 4, 5, False), (5, 2, 1, False)])
+def test_batched_leveled_entry_points_on_gpu(n, level, alpha, real_chain):
     """hc_set_batch: n images per launch through every leveled entry point (pointwise, transforms, rescale, the key switch whole / hoisted / in its QP halves, the fused
-    rotations of the linear transform) == n single-image calls, bit for bit; n = 8 is the widest batch, alpha = 5 the bootstrapping chain's digit size"""
+    rotations of the linear transform) == n single-image calls, bit for bit, and every FUSED entry point == the CPU oracle (first and last image). (8, 27, 5) on
+    ckks.DefaultBootstrapParams[6] is the shape bench.py's chain workloads run at their top level: the widest batch, all 28 + 5 moduli, six digits, 1.7 GB of key-switch scratch."""
     from optimal_conv_amd import Context
-    pc.case_batched_leveled(lambda Q, P: Context(Q, P), n=n, level=level, alpha=alpha)
+    import oracle_ckks as oc
+    pc.case_batched_leveled(lambda Q, P: Context(Q, P), n=n, level=level, alpha=alpha, make_oracle=lambda Q, P: Oracle(q=Q, p=P),
+                            chain=(oc.Q_SET6, oc.P_SET6) if real_chain else None)
 
 
 def test_swk_generate_switches_keys_on_gpu():
