@@ -41,7 +41,7 @@ def traffic_from_profiles(B):
     """HBM-side (L2 <-> fabric) bytes per conv from the committed rocprofv3 PMC passes (tools/gpu_r3_pmc.sh -> tools/pmc_traffic.py).
     PMC counters cannot be read from inside this process, so the figure is the one measured with the command recorded beside it
     (`measured_with`: contexts, ciphertexts per launch set, commit) and committed under profiles/. (None, None) when there is none."""
-    for name in (f"round4_traffic_conv_B{B}.json", f"round3_traffic_conv_B{B}.json", f"traffic_conv_B{B}.json"):
+    for name in (f"round5_traffic_conv_B{B}.json", f"round4_traffic_conv_B{B}.json", f"round3_traffic_conv_B{B}.json", f"traffic_conv_B{B}.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             return d["bytes_per_conv"], {"file": "profiles/" + name, **d.get("measured_with", {"note": d.get("method", "")})}
@@ -54,10 +54,11 @@ def valu_from_profiles():
     """VALU side of the conv's roofline from the committed counter pass (tools/gpu_r4_pmc.sh -> tools/valu_floor.py): lane-instructions per conv, the counter-based busy
     fraction of the VALU pipe, and the issue floor with every instruction class priced at its measured rate. None when there is no such profile."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "round4_conv33_valu.json")))
+        name = "round5_conv33_valu.json" if os.path.exists(os.path.join(ROOT, "profiles", "round5_conv33_valu.json")) else "round4_conv33_valu.json"
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
         return {"lane_instr_per_conv": d["lane_instr_per_conv"], "busy_frac": d["busy_frac_counter"], "busy_frac_class_priced": d["busy_frac_priced"],
                 "issue_floor_ms": d["issue_floor_ms"], "issue_floor_ms_at_4_cycles_per_instr": d["issue_floor_ms_counter_4cyc"], "kernel_ms_per_conv_one_stream": d["kernel_ms_per_conv_one_stream"],
-                "clock_GHz": d["clock_GHz"], "measured_with": {"file": "profiles/round4_conv33_valu.json", "method": d["method"]}}
+                "clock_GHz": d["clock_GHz"], "measured_with": {"file": "profiles/" + name, "method": d["method"]}}
     except Exception:
         return None
 
@@ -161,14 +162,24 @@ def chain_workloads(device, relu_batch, resnet_batch, resnet_images, relu=True):
                 layer = [conv[i] + ctos[i] + relu[i] + stoc[i] for i in range(1, iters)]          # the first iteration allocates the pools: warm-up
                 ms = 1e3 * float(np.mean(layer)) / relu_batch
                 ab = (float(alg[-1][0]) + float(alg[-1][1]) / relu_batch) * 1e9 + algorithmic_mib(16) * 2 ** 20
-                out["convReLU_5_1"] = {"ms_per_layer_per_ct": ms, "ciphertexts_per_launch_set": relu_batch, "layer_ms": 1e3 * float(np.mean(layer)),
+                out["convReLU_5_1"] = {"ms_per_ct_layer_throughput": ms, "ms_per_layer_per_ct": ms, "ciphertexts_per_launch_set": relu_batch, "layer_ms": 1e3 * float(np.mean(layer)),
+                                       "layer_latency_ms": 1e3 * float(np.mean(layer)),
+                                       "figures_note": "ms_per_ct_layer_throughput = layer_latency_ms / ciphertexts_per_launch_set: a THROUGHPUT figure (the images of a batch share every launch); the latency a caller waits for a layer is layer_latency_ms, and ms_per_layer_n1 is one image alone (the reference's own flow); prep_Ker is outside the timers as in the reference (eval.go:244)",
                                        "stages_ms_per_launch_set": {"conv": 1e3 * float(np.mean(conv[1:])), "ctos_sine": 1e3 * float(np.mean(ctos[1:])), "relu": 1e3 * float(np.mean(relu[1:])), "mask_stoc": 1e3 * float(np.mean(stoc[1:]))},
-                                       "algorithmic_bytes": ab, "algorithmic_bytes_note": "per ciphertext-layer: every evaluator operation reads its ciphertext operands and writes its result once (SURVEY 8d's convention), switching keys / diagonals / masks once per launch set (shared by the images), + the convolution's",
+                                       "algorithmic_bytes": ab, "algorithmic_bytes_note": "per ciphertext-layer, counted PER EVALUATOR OPERATION: every operation reads its ciphertext operands and writes its result once (SURVEY 8d's convention), switching keys / diagonals / masks once per launch set (shared by the images), + the convolution's. A hybrid key switch cannot keep its beta x (level+1+alpha) digit rows on chip, so this convention is generous: frac is an UPPER reading of the fraction",
                                        "frac": ab / (ms * 1e-3) / 8e12, "bootstrapping_keys_s": _secs(keys.group(1)) if keys else None,
                                        "command": f"HCONV_IMAGE_BATCH={relu_batch} HCONV_SKIP_BL=1 conv convReLU 5 1 {iters}"}
                 tr = traffic_chain_from_profiles()
                 if tr:
                     out["convReLU_5_1"].update(tr)
+                if relu_batch != 1:          # one image alone: the latency of the reference's own per-image flow (eval.go:446-565's timers)
+                    r1 = subprocess.run([CLI, "convReLU", "5", "1", str(iters)], cwd=work, capture_output=True, text=True, timeout=900, env=dict(env, HCONV_IMAGE_BATCH="1"))
+                    if r1.returncode == 0:
+                        t1 = r1.stdout
+                        c1 = [_secs(t) for t in re.findall(r"^Conv \(with BN\) Done in (\S+) ", t1, re.M)]; b1 = [_secs(t) for t in re.findall(r"^Done in (\S+) $", t1, re.M) if not t.endswith("keys")][-iters:]
+                        l1 = [_secs(t) for t in re.findall(r"ReLU Done in (\S+) ", t1, re.M)]; s1 = [_secs(t) for t in re.findall(r"^Boot \(StoC\) Done in (\S+) ", t1, re.M)]
+                        if len(c1) == iters and len(b1) == iters and len(l1) == iters and len(s1) == iters:
+                            out["convReLU_5_1"]["ms_per_layer_n1"] = 1e3 * float(np.mean([c1[i] + b1[i] + l1[i] + s1[i] for i in range(1, iters)]))
             else:
                 out["convReLU_5_1"] = {"error": "could not parse the CLI output", "stdout_tail": txt[-400:]}
         else:
@@ -191,7 +202,7 @@ def chain_workloads(device, relu_batch, resnet_batch, resnet_images, relu=True):
 
 def traffic_chain_from_profiles():
     """fabric bytes per convReLU ciphertext-layer from the committed rocprofv3 PMC passes (tools/gpu_relu_traffic.sh), with their provenance"""
-    for name in ("round4_traffic_convrelu_5_1.json",):
+    for name in ("round5_traffic_convrelu_5_1.json", "round4_traffic_convrelu_5_1.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             return {"traffic": d["bytes_per_ciphertext_layer"], "traffic_measured_with": {"file": "profiles/" + name, **d.get("measured_with", {})}}
@@ -407,8 +418,11 @@ def main():
         achieved = alg_bytes / (conv_ms_events * 1e-3) / 1e9
         traffic, traffic_how = traffic_from_profiles(B)
         valu = valu_from_profiles() if B == 256 else None
-        # which roofline binds: the VALU issue floor (class-priced, measured instruction counts) against the HBM time of the algorithmic bytes, both per conv
-        bound = "valu" if (valu and valu["issue_floor_ms"] > alg_bytes / 8e12 * 1e3) else "hbm"
+        # `bound` names the roofline `achieved` / `peak` / `frac` are quoted against (HBM: the metric's roofline). The other roof - VALU issue, from measured
+        # instruction counts priced per class - is carried beside it as `valu_frac` = issue floor / achieved time per conv. Neither binds alone (issue at ~0.65, fabric at ~0.37
+        # of their ceilings): the kernels are latency / overlap bound, `state` says so.
+        bound = "hbm"
+        valu_frac = (valu["issue_floor_ms"] / conv_ms_events) if valu else None
         mib = 2 ** 20
         loops = {}        # per-loop share of the roofline from the one-stream kernel profile above (SURVEY.md 8d splits the algorithmic bytes the same way)
         if kern:
@@ -427,7 +441,8 @@ def main():
             "config": {"workload": f"conv {args.ker_wid} {args.i_batch}", "ker_wid": args.ker_wid, "batch": B, "in_wid": W,
                        "logN": 16, "moduli": "ckks.DefaultBootstrapParams[6] Q0,Q1 + P=0x1fffffffffe00001",
                        "convs_per_step_per_gpu": per_step, "ciphertexts_per_launch_set": NB, "contexts_per_gpu": S, "chunk_nodes": args.chunk},
-            "roofline": {"bound": bound, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "roofline": {"bound": bound, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "valu_frac": valu_frac,
+                         "state": "neither roof binds alone: VALU issue floor / achieved = valu_frac, fabric traffic / time well below the ~6.3 TB/s achievable - the kernels are latency / overlap bound (DESIGN.md 5)",
                          "traffic": traffic, "traffic_measured_with": traffic_how,
                          "unit_of_launch": "one conv_then_pack (its share of the batched launch set: all kernels of loop A and of the pack tree)",
                          "algorithmic_bytes_per_conv": alg_bytes, "conv_ms_hip_events": conv_ms_events,

@@ -150,8 +150,17 @@ __device__ __forceinline__ int hc_rows_lds(int rloc, int col) {
 //   a half-wave land in different 16-word halves in both patterns.
 __device__ __forceinline__ int hc_cols_lds(int row, int c) { return ((row ^ ((row >> 4) & 1)) << 4) + c; }
 
-struct HcRowsTwA { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return p[slot]; } };
-struct HcRowsTwB { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return p[slot * 16]; } };
+// Twiddle tables always live in device (global) memory. The multi-modulus kernels take their table pointers from a struct they load (HcRowMod), so the compiler only knows a
+// GENERIC pointer and emitted flat_load_dwordx4 for every twiddle - 30 per thread and pass - which count against lgkmcnt as well as vmcnt and so tie every twiddle fetch to
+// the LDS exchange waits. The explicit address space makes them global_load_dwordx4 (round 5; the convolution's kernels receive HcTwTab by value and always had global loads).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const HcTw __attribute__((address_space(1))) *HcTwGlobalPtr;
+#define HC_TW_LOAD(p, i) (*((HcTwGlobalPtr)(p) + (i)))
+#else
+#define HC_TW_LOAD(p, i) ((p)[i])
+#endif
+struct HcRowsTwA { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return HC_TW_LOAD(p, slot); } };
+struct HcRowsTwB { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return HC_TW_LOAD(p, slot * 16); } };
 
 // forward rows pass on registers: in  e[hi] = element (row, hi*16+tid)  [lazy < 4q]
 //                                 out e[lo] = element (row, tid*16+lo)  [lazy, bound per forward mode]
@@ -246,7 +255,7 @@ __device__ __forceinline__ void hc_rows_lo_to_lin(u64 (&e)[16], u64 *lds, int t,
 #define HC_MM_WAVES 7                  // wavefronts per SIMD the multi-modulus transform kernels are compiled for (VGPR budget 512 / HC_MM_WAVES)
 #endif
 #ifndef HC_MM_WAVES_EXT
-#define HC_MM_WAVES_EXT 5              // the passes with the basis extension in their prologue: 96 VGPRs (a 80-register build spills 140 bytes and is slower)
+#define HC_MM_WAVES_EXT 4              // the passes with the basis extension in their prologue: 120 VGPRs, no scratch (round 5: with the straight-line extension of full digits, hc_basis_ext_tile, 4 wavefronts beat 5 with 96 bytes of scratch: 18.85 vs 19.39 ms per ciphertext-layer; round 4's branchy form preferred 5 with 68 bytes of scratch)
 #endif
 // measured (convReLU 5 1 tail, 8 images, profiles/round4_chain_occupancy_ab.txt): 8-byte exchange / 5 waves 189.5 ms; 4-byte exchange at 6 / 6 waves 183.2, 7 / 5 waves 166.7,
 // 7 / 4 180.8, 8 / 6 193.0 (spills), 7 / 7 with two-element extension groups 169.6
@@ -1005,6 +1014,9 @@ __global__ __launch_bounds__(HC_TPB, 3) void hc_k_b5(HcLoopB B, HcTwTab T0fwd, H
 #ifndef HC_B5M_WAVES
 #define HC_B5M_WAVES 3
 #endif
+#ifndef HC_B5M_PIPE
+#define HC_B5M_PIPE 0
+#endif
 // `#pragma unroll MACRO` is not expanded in the second phase of `hipcc -save-temps` (the macro is gone from the preprocessed file): _Pragma is expanded by the preprocessor itself
 #define HC_PRAGMA_(x) _Pragma(#x)
 #define HC_UNROLL_N(n) HC_PRAGMA_(unroll n)
@@ -1023,6 +1035,66 @@ __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTw
     u64 *__restrict__ o = (outs.p[z] != nullptr ? const_cast<u64 *>(outs.p[z]) : B.dst + (size_t)z * B.dst_stride + (size_t)i * 2 * 65536) + tile;
     const u64 *__restrict__ bias = biases.p[z] != nullptr ? biases.p[z] + tile : nullptr;        // null except on the last node of the tree (eval.go:258)
     u64 e[16], T[16];
+#if HC_B5M_PIPE
+    // software-pipelined epilogue: the operands of row batch 0 are requested BEFORE the transform of the polynomial (their round trip hides behind the
+    // butterflies instead of following them), and every later batch is requested before the batch in front of it is worked on
+    HC_UNROLL_N(HC_B5M_UNROLL)
+    for (int k = 1; k >= 0; k--) {
+        const u64 *__restrict__ in = B.tmpE + ((size_t)zn * 2 + k) * 65536 + (size_t)row * 256;
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
+        u64 Yn[HC_B5_ROWS], Xn[HC_B5_ROWS], bn[HC_B5_ROWS]; HcTw Kn[HC_B5_ROWS], In[HC_B5_ROWS];
+#pragma unroll
+        for (int j = 0; j < HC_B5_ROWS; j++) {
+            const int off = j * 256;
+            Yn[j] = ys[(size_t)k * 65536 + off]; Xn[j] = xs[(size_t)k * 65536 + off]; In[j] = idx[off]; Kn[j] = evk[(size_t)k * 65536 + off];
+            bn[j] = (k == 0 && bias != nullptr) ? bias[off] : 0;
+        }
+        if (k == 0) __syncthreads();                      // the last gather of k = 1 is done before the transform writes LDS again
+        hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, Q);
+        HC_ROW_SYNC();
+        hc_rows_lo_to_lin(e, lds, t, rloc, tid);          // e[kk] = n_k at (row kk, column t)
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 16; b += HC_B5_ROWS) {
+            u64 Y[HC_B5_ROWS], X[HC_B5_ROWS], t1[HC_B5_ROWS], bs[HC_B5_ROWS]; HcTw K[HC_B5_ROWS], I[HC_B5_ROWS];
+#pragma unroll
+            for (int j = 0; j < HC_B5_ROWS; j++) { Y[j] = Yn[j]; X[j] = Xn[j]; I[j] = In[j]; K[j] = Kn[j]; bs[j] = bn[j]; }
+            if (b + HC_B5_ROWS < 16) {
+#pragma unroll
+                for (int j = 0; j < HC_B5_ROWS; j++) {
+                    const int off = (b + HC_B5_ROWS + j) * 256;
+                    Yn[j] = ys[(size_t)k * 65536 + off]; Xn[j] = xs[(size_t)k * 65536 + off]; In[j] = idx[off]; Kn[j] = evk[(size_t)k * 65536 + off];
+                    bn[j] = (k == 0 && bias != nullptr) ? bias[off] : 0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < HC_B5_ROWS; j++) {
+                const int kk = b + j;
+                u64 m = hc_shoup4(X[j], I[j].w, I[j].ws, Q), f;
+                if (k == 1) T[kk] = hc_fold(Y[j] + Q.q4 - m, Q.nq4);
+                u64 g = hc_shoup4(T[kk], K[j].w, K[j].ws, Q);
+                if (FM == HC_FM_FREE) {
+                    t1[j] = Y[j] + m + bs[j];
+                    f = (k == 0 ? Y[j] + Q.q4 - m + g : g) + HC_FREE_OFF * q - e[kk];
+                } else {
+                    m = hc_canon4(m, Q); g = hc_canon4(g, Q);
+                    t1[j] = hc_addmod(hc_addmod(Y[j], m, q), bs[j], q);
+                    f = hc_submod(k == 0 ? hc_addmod(hc_submod(Y[j], m, q), g, q) : g, hc_canon8(e[kk], Q), q);
+                }
+                lds[hc_rows_lds(kk, t)] = f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < HC_B5_ROWS; j++) {
+                const int kk = b + j;
+                const u32 srcidx = hc_perm_src((u32)((HC_TILE * 16 + kk) * 256 + t), B.gal);
+                const u64 d = lds[hc_rows_lds(kk, (int)(srcidx & 255))];
+                o[(size_t)k * 65536 + kk * 256] = FM == HC_FM_FREE ? hc_reduce64(t1[j] + d, B.m0.mu, Q) : hc_addmod(t1[j], d, q);
+            }
+        }
+    }
+#else
     HC_UNROLL_N(HC_B5M_UNROLL)
     for (int k = 1; k >= 0; k--) {
         const u64 *__restrict__ in = B.tmpE + ((size_t)zn * 2 + k) * 65536 + (size_t)row * 256;
@@ -1068,6 +1140,7 @@ __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTw
             }
         }
     }
+#endif
 }
 
 // ================================================================ loop B for SMALL tree levels (round 3)
@@ -1444,44 +1517,102 @@ struct HcBasisExt {
 #ifndef HC_EXT_GROUP
 #define HC_EXT_GROUP 4
 #endif
-// target side of the extension for one coefficient: y[0..n-1] = the y_i, y[n] = v
-__device__ __forceinline__ u64 hc_basis_ext_sum(const u64 (&y)[9], const HcBasisExt &B, const HcQ &Q) {
+#ifndef HC_EXT_FULL
+#define HC_EXT_FULL 1                  // a straight-line form of the extension for operands with exactly NS source limbs (hc_basis_ext_tile)
+#endif
+#ifndef HC_EXT_NS
+#define HC_EXT_NS 1                    // size the extension's operand registers by the context's number of special primes (0: by the tables' 8, the round-4 form)
+#endif
+// target side of the extension for one coefficient: y[0..n-1] = the y_i, y[n] = v. NS = the most source limbs the caller can have (the context's number of special primes:
+// a digit has at most alpha limbs, ModDown extends from the alpha P limbs): the operand array - (NS + 1) registers pairs per coefficient in flight - is sized by it, not by the
+// 8 the constant tables admit. With NS = 5 (the bootstrapping chain) four coefficients in flight hold 48 VGPRs of operands instead of 72: hc_k_cols_fwd_mm<1> / <2> compile for
+// their 5 wavefronts per SIMD without the 68 / 52 bytes of scratch per lane the 9-operand form spilled (round 4: -Rpass-analysis=kernel-resource-usage).
+template <int NS>
+__device__ __forceinline__ u64 hc_basis_ext_sum(const u64 (&y)[NS + 1], const HcBasisExt &B, const HcQ &Q) {
     const int n = B.n;
     u64 v = 0;
 #pragma unroll
-    for (int i = 0; i < 9; i++) if (i == n) v = y[i];
+    for (int i = 0; i <= NS; i++) if (i == n) v = y[i];
     if (n == 1) return hc_barrett64(y[0], B.t, B.mu_t);
     if (B.t < (1ull << 58)) {                                          // lazy sum: below 2^58 up to 8 terms and the offset stay under 36 t < 2^64 unreduced
         u64 acc = Q.q4;
 #pragma unroll
-        for (int i = 0; i < 8; i++) if (i < n) acc += hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q);
+        for (int i = 0; i < NS; i++) if (i < n) acc += hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q);
         return hc_reduce64(acc - hc_shoup4(v, B.smodt.w, B.smodt.ws, Q), B.mu_t, Q);
     }
     u64 acc = 0;                                                       // the 60 / 61-bit limbs fold the running sum by 4t
 #pragma unroll
-    for (int i = 0; i < 8; i++) if (i < n) acc = hc_fold(acc + hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q), Q.nq4);
+    for (int i = 0; i < NS; i++) if (i < n) acc = hc_fold(acc + hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q), Q.nq4);
     return hc_canon8(acc + Q.q4 - hc_shoup4(v, B.smodt.w, B.smodt.ws, Q), Q);
 }
+// the same with the source count known at compile time (n == NS: every full digit and ModDown's P -> Q extension): no per-operand conditions, the loads of a group are one
+// straight run
+template <int NS>
+__device__ __forceinline__ u64 hc_basis_ext_sum_full(const u64 (&y)[NS + 1], const HcBasisExt &B, const HcQ &Q) {
+    if (B.t < (1ull << 58)) {
+        u64 acc = Q.q4;
+#pragma unroll
+        for (int i = 0; i < NS; i++) acc += hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q);
+        return hc_reduce64(acc - hc_shoup4(y[NS], B.smodt.w, B.smodt.ws, Q), B.mu_t, Q);
+    }
+    u64 acc = 0;
+#pragma unroll
+    for (int i = 0; i < NS; i++) acc = hc_fold(acc + hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q), Q.nq4);
+    return hc_canon8(acc + Q.q4 - hc_shoup4(y[NS], B.smodt.w, B.smodt.ws, Q), Q);
+}
+template <int NS>
 __device__ __forceinline__ void hc_basis_ext_tile(u64 (&e)[16], const u64 *yv, const HcBasisExt &B, int tid) {
     const int n = B.n; const HcQ Q = hc_q(B.t);
+    if (HC_EXT_FULL && NS > 1 && n == NS) {                                  // block-uniform
+#pragma unroll
+        for (int g0 = 0; g0 < 16; g0 += HC_EXT_GROUP) {
+            u64 y[HC_EXT_GROUP][NS + 1];
+#pragma unroll
+            for (int g = 0; g < HC_EXT_GROUP; g++) {
+                const u64 *p = yv + (size_t)((g0 + g) * 16 + tid) * 256;
+#pragma unroll
+                for (int i = 0; i <= NS; i++) y[g][i] = p[(size_t)i * 65536];
+            }
+#pragma unroll
+            for (int g = 0; g < HC_EXT_GROUP; g++) e[g0 + g] = hc_basis_ext_sum_full<NS>(y[g], B, Q);
+        }
+        return;
+    }
 #pragma unroll
     for (int g0 = 0; g0 < 16; g0 += HC_EXT_GROUP) {
-        u64 y[HC_EXT_GROUP][9];
+        u64 y[HC_EXT_GROUP][NS + 1];
 #pragma unroll
         for (int g = 0; g < HC_EXT_GROUP; g++) {
             const u64 *p = yv + (size_t)((g0 + g) * 16 + tid) * 256;
 #pragma unroll
-            for (int i = 0; i < 9; i++) if (i <= n) y[g][i] = p[(size_t)i * 65536];                // rows y_0..y_(n-1), then v at row n
+            for (int i = 0; i <= NS; i++) if (i <= n) y[g][i] = p[(size_t)i * 65536];                // rows y_0..y_(n-1), then v at row n
         }
 #pragma unroll
-        for (int g = 0; g < HC_EXT_GROUP; g++) e[g0 + g] = hc_basis_ext_sum(y[g], B, Q);
+        for (int g = 0; g < HC_EXT_GROUP; g++) e[g0 + g] = hc_basis_ext_sum<NS>(y[g], B, Q);
     }
+}
+// ---- 4-byte rows (round 5). Eleven of the bootstrapping chain's 28 Q limbs are ~30-bit primes (levels 5-15 of ckks.DefaultBootstrapParams[6]); Lattigo stores every residue in
+// a uint64. Inside the library a row of such a limb is stored as N 4-byte words AT THE SAME ROW ADDRESS (the row pitch stays N 8-byte words, so no layout or stride changes
+// anywhere: the second half of the slot is simply never touched): the arrays that never leave the library - the seam between the two passes of every multi-modulus
+// transform (ws_tmp), the extended digits of a key switch, the switching keys - move half the bytes for those rows. Values a caller can see (ciphertexts, plaintexts, the
+// extended-basis accumulators) keep Lattigo's 8-byte representation. A lazy value must be brought below 2^32 first: below 2q for q < 2^31.
+#define HC_SMALL_Q(q) ((q) < (1ull << 31))
+__device__ __forceinline__ u64 hc_ld32(const u64 *row, size_t j) { return (u64)reinterpret_cast<const u32 *>(row)[j]; }
+__device__ __forceinline__ void hc_st32(u64 *row, size_t j, u64 v) { reinterpret_cast<u32 *>(row)[j] = (u32)v; }
+// One load form for a row of either width: an 8-byte load at the element pitch (4 or 8 bytes), masked. For a 4-byte row it straddles elements j and j + 1 (4-byte aligned:
+// a legal global_load_dwordx2; the last element reads 4 bytes into the unused half of the row's slot). Measured per kernel (profiles/round5_chain_kernel_ab.txt): in the
+// rows-forward pass this beats two copies of the body chosen per workgroup (which spill 88 bytes at its 72-register budget) and a condition around two load forms (for which
+// the compiler issues BOTH loads on every row); in the inner products and the cols-inverse pass the two-copies form wins.
+struct __attribute__((packed, aligned(4))) HcU64A4 { u64 v; };
+__device__ __forceinline__ u64 hc_ldp(const u64 *row, size_t j, bool row32) {
+    return reinterpret_cast<const HcU64A4 *>(reinterpret_cast<const char *>(row) + (j << (row32 ? 2 : 3)))->v & (row32 ? 0xFFFFFFFFull : ~0ull);
 }
 struct HcRowMod { HcTwTab fwd, inv; u64 q, mu; };
 // blockIdx.z = operand + nz * image: `nz` operands zs_* words apart (the two polynomials of a ciphertext, the digits of a key switch), and the
 // images of a batch (hc_set_batch) is_* words apart
 struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; int z_alpha; int nz; size_t is_in, is_out;
               int xcd, nzn;                  // rows passes: XCD-aware 1-D grid over nzn = nz * images operands (HC_MM_PROLOGUE_ROWS)
+              int pk_in, pk_out;             // the rows of `in` / `out` whose modulus is below 2^31 are stored as 4-byte words (hc_row32: library-internal arrays only)
               unsigned char rowlist[48];     // blockIdx.y -> row (rows a launch has nothing to do for are left out of the grid)
 
               // fused prologue of the cols-forward pass / epilogue of the rows-forward pass (0 = none):
@@ -1522,7 +1653,7 @@ __device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl
 // (Round 4, measured and not kept - profiles/round4_chain_class_paths_ab.txt: butterflies per modulus class inside these kernels - 32-bit canonical arithmetic for the
 // chain's eleven ~30-bit limbs, the fold-free 64-bit form below 2^57 - as a block-uniform switch cost 108-132 VGPRs against 65-86 and only won the lost occupancy back;
 // as one launch per class they kept their registers but turned every pass into three short launches: 224 ms per 8-ciphertext layer against 203.)
-template <int EXT>      // EXT 1: the input is the fused basis extension; 2: the extension plus P times Rescale's lift (ModDown and Rescale in one transform)
+template <int EXT, int NS = 8>      // EXT 1: the input is the fused basis extension; 2: the extension plus P times Rescale's lift (ModDown and Rescale in one transform); NS: most source limbs of the extension
 __global__ __launch_bounds__(HC_TPB, EXT ? HC_MM_WAVES_EXT : HC_MM_WAVES) void hc_k_cols_fwd_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ hc_mm_lds_t lds[HC_COLS_LDS];
     HC_MM_PROLOGUE
@@ -1530,7 +1661,7 @@ __global__ __launch_bounds__(HC_TPB, EXT ? HC_MM_WAVES_EXT : HC_MM_WAVES) void h
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
     u64 e[16];
     if (EXT) {
-        hc_basis_ext_tile(e, in + blockIdx.x * 16 + c, A.ext_bs[(A.z_alpha > 0 ? (size_t)zi * A.ext_rows : 0) + y], tid);
+        hc_basis_ext_tile<NS>(e, in + blockIdx.x * 16 + c, A.ext_bs[(A.z_alpha > 0 ? (size_t)zi * A.ext_rows : 0) + y], tid);
         if (EXT == 2) {
             const u64 qL = A.mods[A.lift_level].q, h = (qL - 1) >> 1, qi = R.q, neg_h = qi - (h % qi);
             const u64 *tt = A.lift_t + (size_t)zi * A.lift_t_zs + (size_t)img * A.lift_t_is + blockIdx.x * 16 + c;
@@ -1550,35 +1681,79 @@ __global__ __launch_bounds__(HC_TPB, EXT ? HC_MM_WAVES_EXT : HC_MM_WAVES) void h
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) e[hi] = in[base + (size_t)(hi * 16 + tid) * 256];
     }
-    hc_cols_fwd<HC_FM_ALT>(e, lds, R.fwd, c, tid, hc_q(R.q));
+    const HcQ Qf = hc_q(R.q);
+    hc_cols_fwd<HC_FM_ALT>(e, lds, R.fwd, c, tid, Qf);
+    if (A.pk_out && HC_SMALL_Q(R.q)) {                                        // block-uniform: the seam row as 4-byte words (lazy values < 8q -> < 2q < 2^32)
+#pragma unroll
+        for (int lo = 0; lo < 16; lo++) hc_st32(out + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(tid * 16 + lo) * 256, hc_fold(hc_fold(e[lo], Qf.nq4), Qf.nq2));
+        return;
+    }
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) out[base + (size_t)(tid * 16 + lo) * 256] = e[lo];
 }
-__global__ __launch_bounds__(HC_TPB, HC_MM_WAVES) void hc_k_rows_fwd_canon_mm(const u64 *in, u64 *out, HcMm A) {
+#ifndef HC_MM_WAVES_RF
+#define HC_MM_WAVES_RF 6                  // the rows-forward pass with its clustered epilogue loads: 80 VGPRs, no scratch (7 wavefronts: 72 VGPRs and 44 bytes of scratch; measured 18.38 vs 18.51 ms per ciphertext-layer)
+#endif
+__global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_RF) void hc_k_rows_fwd_canon_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ hc_mm_lds_t lds[HC_ROWS_LDS];
     HC_MM_PROLOGUE_ROWS
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = bx * 16 + rloc;
     const size_t pbase = (size_t)y * 65536;
     u64 e[16];
+    const u64 rq = R.q, rmu = R.mu;                                          // copies: R lives in global memory, and after the first store of the epilogue every R.q would be re-read (the stores may alias it)
+    const bool small = HC_SMALL_Q(rq);                                       // block-uniform
 #pragma unroll
-    for (int hi = 0; hi < 16; hi++) e[hi] = in[pbase + (size_t)row * 256 + hi * 16 + tid];
-    const HcQ Q = hc_q(R.q);
+    for (int hi = 0; hi < 16; hi++) e[hi] = hc_ldp(in + pbase, (size_t)row * 256 + hi * 16 + tid, A.pk_in && small);
+    const HcQ Q = hc_q(rq);
     hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, Q);
     HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
-    for (int k = 0; k < 16; k++) e[k] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, R.mu);
+    for (int k = 0; k < 16; k++) e[k] = hc_fwd_canon<HC_FM_ALT>(e[k], Q, rmu);
     const size_t lin = pbase + (size_t)(bx * 16) * 256 + t;
     if (A.epi_x != nullptr) {                                                // block-uniform
+        // (x - result) * c (+ addend [* c']): the operands of eight rows are requested together and the kind of epilogue is decided once, outside the loops. As one loop
+        // with the conditions inside it compiled to SIXTEEN dependent round trips per thread (load x, wait, load the addend, wait, store ...): the tail of every ModDown and
+        // Rescale waited on memory 16 times over
         const u64 *x = A.epi_x + (size_t)zi * A.epi_x_zs + (size_t)img * A.epi_x_is + lin;
-        const u64 *ad = A.epi_add != nullptr ? A.epi_add + (size_t)zi * A.epi_add_zs + (size_t)img * A.epi_add_is + lin : nullptr;
         const HcTw w = A.epi_mul[y];
+        if (A.epi_add == nullptr) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            u64 r = hc_mul_shoup(hc_submod(x[k * 256], e[k], R.q), w.w, w.ws, R.q);
-            if (ad != nullptr) r = hc_addmod(r, A.epi_add_mul != nullptr ? hc_mul_shoup(ad[k * 256], A.epi_add_mul[y].w, A.epi_add_mul[y].ws, R.q) : ad[k * 256], R.q);
-            out[lin + k * 256] = r;
+            for (int h = 0; h < 16; h += 8) {
+                u64 xv[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) xv[k] = x[(h + k) * 256];
+#pragma unroll
+                for (int k = 0; k < 8; k++) out[lin + (h + k) * 256] = hc_mul_shoup(hc_submod(xv[k], e[h + k], rq), w.w, w.ws, rq);
+            }
+            return;
         }
+        const u64 *ad = A.epi_add + (size_t)zi * A.epi_add_zs + (size_t)img * A.epi_add_is + lin;
+        if (A.epi_add_mul != nullptr) {
+            const HcTw wa = A.epi_add_mul[y];
+#pragma unroll
+            for (int h = 0; h < 16; h += 8) {
+                u64 xv[8], av[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { xv[k] = x[(h + k) * 256]; av[k] = ad[(h + k) * 256]; }
+#pragma unroll
+                for (int k = 0; k < 8; k++) out[lin + (h + k) * 256] = hc_addmod(hc_mul_shoup(hc_submod(xv[k], e[h + k], rq), w.w, w.ws, rq), hc_mul_shoup(av[k], wa.w, wa.ws, rq), rq);
+            }
+            return;
+        }
+#pragma unroll
+        for (int h = 0; h < 16; h += 8) {
+            u64 xv[8], av[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { xv[k] = x[(h + k) * 256]; av[k] = ad[(h + k) * 256]; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) out[lin + (h + k) * 256] = hc_addmod(hc_mul_shoup(hc_submod(xv[k], e[h + k], rq), w.w, w.ws, rq), av[k], rq);
+        }
+        return;
+    }
+    if (A.pk_out && small) {                                                 // the extended digits of a key switch: canonical residues below 2^31 as 4-byte words
+#pragma unroll
+        for (int k = 0; k < 16; k++) hc_st32(out + pbase, (size_t)(bx * 16 + k) * 256 + t, e[k]);
         return;
     }
 #pragma unroll
@@ -1594,22 +1769,33 @@ __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES) void hc_k_rows_inv_mm(const u6
     for (int k = 0; k < 16; k++) e[k] = in[pbase + (size_t)(bx * 16 + k) * 256 + t];
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
-    hc_rows_inv(e, lds, R.inv, row, rloc, tid, hc_q(R.q));
+    const HcQ Q = hc_q(R.q);
+    hc_rows_inv(e, lds, R.inv, row, rloc, tid, Q);
+    if (A.pk_out && HC_SMALL_Q(R.q)) {                                       // block-uniform: the seam row as 4-byte words (lazy values < 4q -> < 2q < 2^32)
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) hc_st32(out + pbase, (size_t)row * 256 + hi * 16 + tid, hc_fold(e[hi], Q.nq2));
+        return;
+    }
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[pbase + (size_t)row * 256 + hi * 16 + tid] = e[hi];
 }
-__global__ __launch_bounds__(HC_TPB, HC_MM_WAVES) void hc_k_cols_inv_canon_mm(const u64 *in, u64 *out, HcMm A) {
-    __shared__ hc_mm_lds_t lds[HC_COLS_LDS];
-    HC_MM_PROLOGUE
+template <bool IN32>
+__device__ __forceinline__ void hc_cols_inv_canon_mm_body(const u64 *in, u64 *out, hc_mm_lds_t *lds, const HcRowMod &R, int y) {
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
     u64 e[16];
 #pragma unroll
-    for (int lo = 0; lo < 16; lo++) e[lo] = in[base + (size_t)(tid * 16 + lo) * 256];
+    for (int lo = 0; lo < 16; lo++) e[lo] = IN32 ? hc_ld32(in + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(tid * 16 + lo) * 256) : in[base + (size_t)(tid * 16 + lo) * 256];
     const HcQ Q = hc_q(R.q);
     hc_cols_inv(e, lds, R.inv, c, tid, Q);
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_canon4(e[hi], Q);
+}
+__global__ __launch_bounds__(HC_TPB, HC_MM_WAVES) void hc_k_cols_inv_canon_mm(const u64 *in, u64 *out, HcMm A) {
+    __shared__ hc_mm_lds_t lds[HC_COLS_LDS];
+    HC_MM_PROLOGUE
+    if (A.pk_in && HC_SMALL_Q(R.q)) hc_cols_inv_canon_mm_body<true>(in, out, lds, R, y);          // block-uniform
+    else hc_cols_inv_canon_mm_body<false>(in, out, lds, R, y);
 }
 // ModDown fused with the Rescale behind it (hc_keyswitch_add_rescale), the last limb L. Rescale needs the coefficients of c_L = (acc_L - NTT(ext_L)) / P + add_L:
 // by linearity InvNTT(acc_L / P + add_L) - ext_L / P, ext_L being the coefficient-domain extension the y_i / v rows give. acc_L <- acc_L / P + add_L where the inner product writes that row (hc_k_ks_mac_all, HcMacPrep; hc_k_mdrs_prep for an acc that comes from elsewhere), in
@@ -1651,7 +1837,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_yv(const u64 *src, size_t s
 #pragma unroll
             for (int i = 1; i < 9; i++) if (i == n) yy[i] = (u64)vi;
             u64 *tu = const_cast<u64 *>(src) - src_stride + j;
-            *tu = hc_submod(*tu, hc_mul_shoup(hc_basis_ext_sum(yy, BL, QL), wL.w, wL.ws, BL.t), BL.t);
+            *tu = hc_submod(*tu, hc_mul_shoup(hc_basis_ext_sum<8>(yy, BL, QL), wL.w, wL.ws, BL.t), BL.t);
         }
     }
 }
@@ -1664,30 +1850,31 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_yv(const u64 *src, size_t s
 // prep_pinv != null (a relinearisation whose ModDown is fused with the Rescale behind it, hc_ks_moddown_rescale): the last Q limb's row leaves as acc_L / P + add_L - the row
 // Rescale's lift is taken from - instead of acc_L (what hc_k_mdrs_prep did in a launch of its own); add: [k][row][N] components add_zs apart, images add_is apart, or null
 struct HcMacPrep { const HcTw *pinv; const u64 *add; size_t add_zs, add_is; };
-template <int NB>
-__global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_is, const HcMod *mods,
-                                                          int nl, int nq, int nt, int alpha, int beta, int n, HcMacPrep prep) {
-    const int T = blockIdx.y;
-    const bool prepL = prep.pinv != nullptr && T == nl - 1;                  // block-uniform
-    const HcTw pw = prepL ? prep.pinv[T] : HcTw{0, 0};
-    if (prep.add != nullptr) prep.add += (size_t)blockIdx.z * NB * prep.add_is;
-    { const int g0 = (int)blockIdx.z * NB; cx += (size_t)g0 * cx_is; digits += (size_t)g0 * dg_is; acc += (size_t)g0 * acc_is; n = n - g0 < NB ? n - g0 : NB; }
-    const HcMod m = mods[T < nl ? T : nq + (T - nl)];
+// Per-digit form: the digits stay a loop (any count, few registers, 6-7 wavefronts per SIMD) but the 2 + NB loads of ONE digit are a straight run - typed at compile time
+// (P32), the image index clamped instead of tested - and only the own / foreign choice, which changes the operand's width, is a (uniform) branch.
+template <int NB, bool P32>
+__device__ __forceinline__ void hc_ks_mac_all_digit(const u64 *evk, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_is, const HcMod m, int T,
+                                                    int nl, int nt, int alpha, int beta, int n, const HcMacPrep &prep, bool prepL, HcTw pw) {
     const size_t rowT = (size_t)T * 65536, comp = (size_t)nt * 65536;
+    const int d_own = T < nl ? T / alpha : -1;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        // the products of up to 6 digits are summed as 128-bit integers and reduced ONCE (6 q^2 < q 2^64 for q < 2^61): the same residue as the modular sum of the
-        // per-digit Montgomery products at less than half the instructions; a longer decomposition folds every 6 digits
         u128 t0[NB], t1[NB]; u64 s0[NB], s1[NB];
         for (int d = 0; d < beta; d++) {
-            const int lo = d * alpha, hi = lo + alpha < nl ? lo + alpha : nl;
-            const bool own = T >= lo && T < hi;
-            const u64 kb = evk[((size_t)d * 2 * nt) * 65536 + rowT + j], ka = evk[((size_t)d * 2 * nt) * 65536 + comp + rowT + j];
-            const u64 *xs = own ? cx + rowT + j : digits + ((size_t)d * nt) * 65536 + rowT + j; const size_t xis = own ? cx_is : dg_is;
+            const u64 *krow = evk + ((size_t)d * 2 * nt) * 65536 + rowT;
+            const u64 kb = P32 ? hc_ld32(krow, j) : krow[j], ka = P32 ? hc_ld32(krow + comp, j) : krow[comp + j];
+            u64 x[NB];
+            if (d == d_own) {                                                 // uniform
+#pragma unroll
+                for (int g = 0; g < NB; g++) x[g] = cx[(size_t)(g < n ? g : n - 1) * cx_is + rowT + j];
+            } else {
+                const u64 *xrow = digits + ((size_t)d * nt) * 65536 + rowT;
+#pragma unroll
+                for (int g = 0; g < NB; g++) { const u64 *xg = xrow + (size_t)(g < n ? g : n - 1) * dg_is; x[g] = P32 ? hc_ld32(xg, j) : xg[j]; }
+            }
             const int ph = d % 6;
 #pragma unroll
-            for (int g = 0; g < NB; g++) if (g < n) {
-                const u64 x = xs[(size_t)g * xis];
-                const u128 p0 = (u128)x * kb, p1 = (u128)x * ka;
+            for (int g = 0; g < NB; g++) {
+                const u128 p0 = (u128)x[g] * kb, p1 = (u128)x[g] * ka;
                 t0[g] = ph == 0 ? p0 : t0[g] + p0;
                 t1[g] = ph == 0 ? p1 : t1[g] + p1;
                 if (ph == 5 || d + 1 == beta) {
@@ -1708,41 +1895,73 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_all(const u64 *evk, const 
         }
     }
 }
+#ifndef HC_MAC_WAVES
+#define HC_MAC_WAVES 1                 // minimum wavefronts per SIMD the inner products are compiled for (1 = no constraint: 89 VGPRs / 5 wavefronts at 4 images per thread)
+#endif
+#ifndef HC_MACM_WAVES
+#define HC_MACM_WAVES 1
+#endif
+template <int NB>
+__global__ __launch_bounds__(HC_TPB, HC_MAC_WAVES) void hc_k_ks_mac_all(const u64 *evk, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_is, const HcMod *mods,
+                                                          int nl, int nq, int nt, int alpha, int beta, int n, HcMacPrep prep, int pk) {
+    const int T = blockIdx.y;
+    const bool prepL = prep.pinv != nullptr && T == nl - 1;                  // block-uniform
+    const HcTw pw = prepL ? prep.pinv[T] : HcTw{0, 0};
+    if (prep.add != nullptr) prep.add += (size_t)blockIdx.z * NB * prep.add_is;
+    { const int g0 = (int)blockIdx.z * NB; cx += (size_t)g0 * cx_is; digits += (size_t)g0 * dg_is; acc += (size_t)g0 * acc_is; n = n - g0 < NB ? n - g0 : NB; }
+    const HcMod m = mods[T < nl ? T : nq + (T - nl)];
+    if (pk && HC_SMALL_Q(m.q)) hc_ks_mac_all_digit<NB, true>(evk, cx, cx_is, digits, dg_is, acc, acc_is, m, T, nl, nt, alpha, beta, n, prep, prepL, pw);          // block-uniform: this limb's digit and key rows are 4-byte words
+    else hc_ks_mac_all_digit<NB, false>(evk, cx, cx_is, digits, dg_is, acc, acc_is, m, T, nl, nt, alpha, beta, n, prep, prepL, pw);
+}
 // The inner products of R hoisted rotations in ONE launch (the baby steps of a linear transform share one digit decomposition): a digit element is read once for the R keys
 // (hc_k_ks_mac_all re-reads all n x beta x nt digit rows per rotation - what bounds it). R x NB accumulator slots per component and thread (<= 16), plain Montgomery
 // accumulation (the kernel is bound by its loads). acc: [rotation][image][2][nt][N], rotations acc_rs words apart. grid = (64, nt)
 struct HcKeyPtrs { const u64 *k[8]; };
-template <int R, int NB>
-__global__ __launch_bounds__(HC_TPB) void hc_k_ks_mac_multi(HcKeyPtrs keys, int nrot, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_rs, size_t acc_is, const HcMod *mods,
-                                                            int nl, int nq, int nt, int alpha, int beta, int n) {
-    const int T = blockIdx.y;
-    const HcMod m = mods[T < nl ? T : nq + (T - nl)];
+// per-digit form as hc_ks_mac_all_digit: the 2 R key words of a digit (all rotations) and its NB digit words are one run of loads
+template <int R, int NB, bool P32>
+__device__ __forceinline__ void hc_ks_mac_multi_digit(const HcKeyPtrs &keys, int nrot, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_rs, size_t acc_is, const HcMod m, int T,
+                                                      int nl, int nt, int alpha, int beta, int n) {
     const size_t rowT = (size_t)T * 65536, comp = (size_t)nt * 65536;
+    const int d_own = T < nl ? T / alpha : -1;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
         u64 s0[R][NB], s1[R][NB];
         for (int d = 0; d < beta; d++) {
-            const int lo = d * alpha, hi = lo + alpha < nl ? lo + alpha : nl;
-            const bool own = T >= lo && T < hi;
-            const u64 *xs = own ? cx + rowT + j : digits + ((size_t)d * nt) * 65536 + rowT + j; const size_t xis = own ? cx_is : dg_is;
-            u64 x[NB];
+            u64 x[NB], kb[R], ka[R];
 #pragma unroll
-            for (int g = 0; g < NB; g++) if (g < n) x[g] = xs[(size_t)g * xis];
+            for (int r = 0; r < R; r++) {                                     // the keys of every rotation for this digit: one run of loads (a rotation beyond nrot re-reads the last one's)
+                const u64 *krow = keys.k[r < nrot ? r : nrot - 1] + ((size_t)d * 2 * nt) * 65536 + rowT;
+                kb[r] = P32 ? hc_ld32(krow, j) : krow[j]; ka[r] = P32 ? hc_ld32(krow + comp, j) : krow[comp + j];
+            }
+            if (d == d_own) {                                                 // uniform
 #pragma unroll
-            for (int r = 0; r < R; r++) if (r < nrot) {
-                const u64 kb = keys.k[r][((size_t)d * 2 * nt) * 65536 + rowT + j], ka = keys.k[r][((size_t)d * 2 * nt) * 65536 + comp + rowT + j];
+                for (int g = 0; g < NB; g++) x[g] = cx[(size_t)(g < n ? g : n - 1) * cx_is + rowT + j];
+            } else {
+                const u64 *xrow = digits + ((size_t)d * nt) * 65536 + rowT;
 #pragma unroll
-                for (int g = 0; g < NB; g++) if (g < n) {
-                    const u64 p0 = hc_mont(x[g], kb, m.q, m.qinv), p1 = hc_mont(x[g], ka, m.q, m.qinv);
+                for (int g = 0; g < NB; g++) { const u64 *xg = xrow + (size_t)(g < n ? g : n - 1) * dg_is; x[g] = P32 ? hc_ld32(xg, j) : xg[j]; }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int g = 0; g < NB; g++) {
+                    const u64 p0 = hc_mont(x[g], kb[r], m.q, m.qinv), p1 = hc_mont(x[g], ka[r], m.q, m.qinv);
                     s0[r][g] = d == 0 ? p0 : hc_addmod(s0[r][g], p0, m.q);
                     s1[r][g] = d == 0 ? p1 : hc_addmod(s1[r][g], p1, m.q);
                 }
-            }
         }
 #pragma unroll
         for (int r = 0; r < R; r++) if (r < nrot)
 #pragma unroll
             for (int g = 0; g < NB; g++) if (g < n) { u64 *a = acc + (size_t)r * acc_rs + (size_t)g * acc_is + rowT + j; a[0] = s0[r][g]; a[comp] = s1[r][g]; }
     }
+}
+template <int R, int NB>
+__global__ __launch_bounds__(HC_TPB, HC_MACM_WAVES) void hc_k_ks_mac_multi(HcKeyPtrs keys, int nrot, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_rs, size_t acc_is, const HcMod *mods,
+                                                            int nl, int nq, int nt, int alpha, int beta, int n, int pk) {
+    const int T = blockIdx.y;
+    const HcMod m = mods[T < nl ? T : nq + (T - nl)];
+    if (pk && HC_SMALL_Q(m.q)) hc_ks_mac_multi_digit<R, NB, true>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n);          // block-uniform
+    else hc_ks_mac_multi_digit<R, NB, false>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n);
 }
 // ModDown's last step and evaluator.permuteNTT's tail in one pass (rotations: the key-switched polynomials never reach HBM unpermuted):
 //   out_0[l][i] = ((acc_0 - ext_0) * P^-1 + c0)[l][src(i)],  out_1[l][i] = ((acc_1 - ext_1) * P^-1)[l][src(i)],  src = PermuteNTTIndex(g)
@@ -1841,6 +2060,23 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_qp_mul_sum_g(HcTermPtrsG P, int n
         for (int h = 0; h < G; h++)
 #pragma unroll
             for (int g = 0; g < NB; g++) if (g < n) P.out[h][(size_t)(g0 + g) * o_is + base + i] = s[h][g];
+    }
+}
+// In-place conversion of rows to the 4-byte form (hc_ld32): one workgroup per row of the grid (blockIdx.x = row, `rows` rows `stride` words apart... consecutive), rows whose modulus
+// mods[modidx[row % period]] is at least 2^31 are left alone. A chunk of 4096 words is read by the whole workgroup before any of its 4-byte words is written: the words written
+// (bytes [16 KiB c, 16 KiB (c + 1))) lie in what chunks <= c have already read.
+__global__ __launch_bounds__(HC_TPB) void hc_k_pack32_rows(u64 *rows, const HcMod *mods, int nl, int nq, int nt) {
+    const int T = (int)(blockIdx.x % (unsigned)nt);
+    if (!HC_SMALL_Q(mods[T < nl ? T : nq + (T - nl)].q)) return;
+    u64 *row = rows + (size_t)blockIdx.x * 65536;
+    for (int c = 0; c < 16; c++) {
+        u64 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = row[(size_t)c * 4096 + i * 256 + threadIdx.x];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; i++) hc_st32(row, (size_t)c * 4096 + i * 256 + threadIdx.x, v[i]);
+        __syncthreads();
     }
 }
 // ================================================================ switching-key generation on the device (harness: hc_swk_generate)

@@ -134,6 +134,7 @@ struct hc_ctx {
     long small_levels = 16;               // pack-tree launches of at most this many nodes (summed over the batch) run on the 1024-thread S kernels; 0 = never
     long peer_access = 1;                 // hc_conv_then_pack_sharded: enable direct peer copies between distinct devices (0: leave the copies to hipMemcpyPeerAsync's staging)
     int xcd_rows = 1;                     // XCD-aware 1-D grid of the rows passes (HcMm::xcd; 0 = the plain 3-D grid, kept for A/B builds)
+    int pack32 = 1;                       // library-internal rows of moduli below 2^31 as 4-byte words (hc_kernels.h hc_ld32): transform seams, extended digits, switching keys. HCONV_PACK32=0 at hc_ctx_create turns it off (A/B)
     unsigned peer_warned = 0;             // bit d: enabling peer access to device d failed and was reported once
     unsigned peer_enabled = 0;            // bit d: peer access from this context's device to device d was enabled by (or found enabled for) this context
     long profile = 0;
@@ -315,6 +316,7 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
         return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: HIP device %d not available (%d devices) - this library has no CPU path", device, ndev);
     hc_ctx *c = new hc_ctx();
     c->device = device; c->nq = nq; c->np = np;
+    { const char *pk = getenv("HCONV_PACK32"); if (pk && *pk) c->pack32 = atoi(pk) ? 1 : 0; }
     { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa ? (atoi(aa) == 2 ? 2 : (atoi(aa) ? 1 : 0)) : 0; }
     hipError_t se = hipSetDevice(device);
     if (se == hipSuccess) se = c->async_alloc ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipStreamCreate(&c->stream);
@@ -582,7 +584,8 @@ extern "C" int hc_lv_add_const(hc_ctx *c, int level, const uint64_t *a, const ui
 // batched transforms over rows of different moduli (row y <-> modulus y < nl ? y : nq + y - nl); z operands zs words apart, n images is words apart.
 // fuse: optional prologue of the first pass (lift_level: Rescale's lift of t, see HcMm) and epilogue of the second (epi_x: (x - result) * epi_mul (+ epi_add))
 struct HcMmFuse { const HcBasisExt *ext_bs = nullptr; int ext_rows = 0; int lift_level = 0; const u64 *epi_x = nullptr; size_t epi_x_zs = 0, epi_x_is = 0; const HcTw *epi_mul = nullptr; const u64 *epi_add = nullptr; size_t epi_add_zs = 0, epi_add_is = 0;
-                  const u64 *lift_t = nullptr; size_t lift_t_zs = 0, lift_t_is = 0; const HcTw *lift_pmul = nullptr, *epi_add_mul = nullptr; };      // lift_t: ModDown + Rescale in one transform (HcMm)
+                  const u64 *lift_t = nullptr; size_t lift_t_zs = 0, lift_t_is = 0; const HcTw *lift_pmul = nullptr, *epi_add_mul = nullptr;      // lift_t: ModDown + Rescale in one transform (HcMm)
+                  bool out_packed = false; };      // out is a library-internal array read only by kernels that expect 4-byte rows for the small moduli (the digits of a key switch)
 static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0, int n = 1, size_t is_in = 0, size_t is_out = 0, const char *tag = "ntt",
                      const HcMmFuse *fuse = nullptr) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
@@ -596,10 +599,16 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
     if (fuse && fuse->lift_level > 0) { A.lift_level = fuse->lift_level; if (!fuse->lift_t) { A.zs_in = (size_t)HC_N; A.is_in = (size_t)z * HC_N; } }
     if (fuse && fuse->ext_bs) { A.ext_bs = fuse->ext_bs; A.ext_rows = fuse->ext_rows; }
     if (fuse && fuse->lift_t) { A.lift_t = fuse->lift_t; A.lift_t_zs = fuse->lift_t_zs; A.lift_t_is = fuse->lift_t_is; A.lift_pmul = fuse->lift_pmul; }
-    if (A.ext_bs && A.lift_t) HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<2>, grid, in, c->ws_tmp, A));
-    else if (A.ext_bs) HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<1>, grid, in, c->ws_tmp, A));
+    // the extension's operand registers are sized by the most source limbs a digit / ModDown can have: the context's number of special primes (hc_basis_ext_tile)
+#define HC_COLS_EXT(E) (!HC_EXT_NS ? hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 8>, grid, in, c->ws_tmp, A) : c->np <= 2 ? hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 2>, grid, in, c->ws_tmp, A) : c->np <= 5 ? hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 5>, grid, in, c->ws_tmp, A) \
+                        : hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 8>, grid, in, c->ws_tmp, A))
+    A.pk_out = c->pack32;                                                    // the seam between the two passes (ws_tmp) never leaves the library
+    if (A.ext_bs && A.lift_t) HC_TRY(HC_COLS_EXT(2));
+    else if (A.ext_bs) HC_TRY(HC_COLS_EXT(1));
     else HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<0>, grid, in, c->ws_tmp, A));
+#undef HC_COLS_EXT
     A.lift_level = 0; A.ext_bs = nullptr; A.lift_t = nullptr; A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out;
+    A.pk_in = c->pack32; A.pk_out = (c->pack32 && fuse && fuse->out_packed) ? 1 : 0;
     if (fuse && fuse->epi_x) { A.epi_x = fuse->epi_x; A.epi_x_zs = fuse->epi_x_zs; A.epi_x_is = fuse->epi_x_is; A.epi_mul = fuse->epi_mul; A.epi_add = fuse->epi_add; A.epi_add_zs = fuse->epi_add_zs; A.epi_add_is = fuse->epi_add_is; A.epi_add_mul = fuse->epi_add_mul; }
     A.xcd = c->xcd_rows; A.nzn = z * n;
     HC_TRY(hc_launch(c, c->profile ? n2 : "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, A.xcd ? dim3(16u * (unsigned)rows * (unsigned)(z * n)) : grid, (const u64 *)c->ws_tmp, out, A));
@@ -615,8 +624,9 @@ static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int 
     for (int y = 0; y < rows; y++) if (!(y >= skip_lo && y < skip_hi)) A.rowlist[cnt++] = (unsigned char)y;
     const dim3 grid(16, (unsigned)cnt, (unsigned)(z * n));
     A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; A.xcd = c->xcd_rows; A.nzn = z * n;
+    A.pk_out = c->pack32;                                                    // the seam (ws_tmp)
     HC_TRY(hc_launch(c, c->profile ? n1 : "rows_inv_mm", hc_k_rows_inv_mm, A.xcd ? dim3(16u * (unsigned)cnt * (unsigned)(z * n)) : grid, in, c->ws_tmp, A));
-    A.xcd = 0;
+    A.xcd = 0; A.pk_in = c->pack32; A.pk_out = 0;
     A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out; HC_TRY(hc_launch(c, c->profile ? n2 : "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
@@ -1159,6 +1169,7 @@ extern "C" int hc_swk_load(hc_ctx *c, uint64_t key_id, int level, const uint64_t
     HcSwk k; k.level = level; k.beta = beta;
     HC_HIP(c, hcx_malloc(c, (void **)&k.rows, n * sizeof(u64)));
     HC_HIP(c, hcx_h2d_async(c, k.rows, rows_host, n * sizeof(u64)));
+    if (c->pack32) HC_TRY(hc_launch(c, "pack32_rows", hc_k_pack32_rows, dim3((unsigned)(beta * 2 * nt)), k.rows, (const HcMod *)c->d_mods, level + 1, c->nq, nt));      // the rows of the ~30-bit limbs as 4-byte words (read by the inner products only)
     HC_HIP(c, hipStreamSynchronize(c->stream));
     auto it = c->swk.find(key_id);
     if (it != c->swk.end()) hcx_free(c, it->second.rows);
@@ -1196,6 +1207,7 @@ static int hc_swk_generate_impl(hc_ctx *c, uint64_t key_id, int level, uint64_t 
     c->hoist_cx = nullptr;
     HC_TRY(hc_ntt_mm(c, k.rows, k.rows, nt, nl, 0, 0, beta, (size_t)2 * nt * HC_N, (size_t)2 * nt * HC_N));      // the e rows (component 0 of every digit), all limbs
     HC_TRY(hc_launch(c, "swk_finish", hc_k_swk_finish, grid, k.rows, (const u64 *)sk_ntt, (const HcMod *)c->d_mods, (const HcTw *)pm, G));
+    if (c->pack32) HC_TRY(hc_launch(c, "pack32_rows", hc_k_pack32_rows, dim3((unsigned)(beta * 2 * nt)), k.rows, (const HcMod *)c->d_mods, nl, c->nq, nt));
     HC_HIP(c, hipStreamSynchronize(c->stream));
     S.keep(k.rows);
     auto it = c->swk.find(key_id);
@@ -1267,7 +1279,7 @@ static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, const HcKsS
     // digit + beta * image): the extended digits are never written in the coefficient domain
     const size_t yz = (size_t)(alpha + 1) * HC_N;
     HC_TRY(hc_launch(c, "decomp:basis_yv", hc_k_basis_yv<false>, dim3(HC_GX_YV, (unsigned)(beta * nb)), (const u64 *)S.coef, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bx, nt, (size_t)alpha * HC_N, alpha, beta, S.coef_is, (const HcBasisExt *)nullptr, (const HcTw *)nullptr));
-    HcMmFuse F; F.ext_bs = P->bx; F.ext_rows = nt;
+    HcMmFuse F; F.ext_bs = P->bx; F.ext_rows = nt; F.out_packed = true;            // the digits are read by the inner products only (hc_k_ks_mac_all / _multi)
     return hc_ntt_mm(c, S.yv, S.digits, nt, nl, 0, 0, beta, yz, (size_t)nt * HC_N, alpha, nb, (size_t)beta * yz, S.digits_is, "decomp", &F);
 }
 // the inner product with both components of the key, all images: acc [img][2][nt][N], images acc_is words apart
@@ -1275,7 +1287,7 @@ static int hc_ks_mac(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, cons
     HcMacPrep PR; memset(&PR, 0, sizeof PR); if (prep) PR = *prep;
     const int alpha = c->np, nl = level + 1, nt = nl + alpha;
     const int nb = c->nb, NB = nb <= 1 ? 1 : nb <= 2 ? 2 : HC_MAC_NB;                 // images per thread; more images = more image groups (blockIdx.z), each reading the key once
-#define HC_MAC_ALL(NN) hc_launch(c, "ks_mac_all", hc_k_ks_mac_all<NN>, dim3(HC_GX_MAC, (unsigned)nt, (unsigned)((nb + NN - 1) / NN)), (const u64 *)key.rows, cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, acc, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, key.beta, nb, PR)
+#define HC_MAC_ALL(NN) hc_launch(c, "ks_mac_all", hc_k_ks_mac_all<NN>, dim3(HC_GX_MAC, (unsigned)nt, (unsigned)((nb + NN - 1) / NN)), (const u64 *)key.rows, cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, acc, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, key.beta, nb, PR, c->pack32 ? 3 : 0)
     return NB == 1 ? HC_MAC_ALL(1) : NB == 2 ? HC_MAC_ALL(2) : NB == 4 ? HC_MAC_ALL(4) : HC_MAC_ALL(8);
 #undef HC_MAC_ALL
 }
@@ -1470,7 +1482,7 @@ extern "C" int hc_keyswitch_qp_rotate_many(hc_ctx *c, int nrot, const uint64_t *
         HcKeyPtrs K; memset(&K, 0, sizeof K); int beta = 0;
         for (int r = 0; r < nr; r++) { K.k[r] = keys[(size_t)(r0 + r)]->rows; beta = keys[(size_t)(r0 + r)]->beta; }
         const dim3 grid(HC_GX_MACM, (unsigned)nt);
-#define HC_MAC_MULTI(RR, NN) hc_launch(c, "ks_mac_multi", hc_k_ks_mac_multi<RR, NN>, grid, K, nr, (const u64 *)cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, c->ws_accm, acc_rs, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta, nb)
+#define HC_MAC_MULTI(RR, NN) hc_launch(c, "ks_mac_multi", hc_k_ks_mac_multi<RR, NN>, grid, K, nr, (const u64 *)cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, c->ws_accm, acc_rs, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta, nb, c->pack32 ? 3 : 0)
         if (NB == 8) HC_TRY(HC_MAC_MULTI(2, 8)); else if (NB == 4) HC_TRY(HC_MAC_MULTI(4, 4)); else if (NB == 2) HC_TRY(HC_MAC_MULTI(8, 2)); else HC_TRY(HC_MAC_MULTI(8, 1));
 #undef HC_MAC_MULTI
         for (int r = 0; r < nr; r++)

@@ -136,6 +136,7 @@ static void writeTxt(const std::string &name, const std::vector<double> &v) {
 // test.go:76-370 (wide_case 1) and test.go:638-912 testResNet_crop_sparse_wide (wide_case 2: twice the channels, first layer 3 -> 16
 // -> 32, first stride layer on full packing; wide_case 3: 48/96/192 channels, block 1 and both stride layers on full packing)
 void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug, bool cf100, int wide_case) {
+    if (const char *fi = testOnlyEnv("HCONV_RESNET_FIRST_IMAGE")) st = atoi(fi);      // test mode: images st .. end - 1 (one image of a batch run alone, for the batch == single digest test)
     (void)debug;
     if (wide_case < 1 || wide_case > 3) panic("wrong wide_case (2 nor 3)!");
     const bool wide = wide_case != 1;
@@ -188,6 +189,7 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
                 if (i < raw_in_wids[0] && j < raw_in_wids[0]) input[(size_t)(i * in_wids[0] * max_batch[0] + j * max_batch[0] + b * norm[0])] = image[(size_t)k];   // sparse pack the input
                 k++;
             }
+            if (resnetReplaySeed()) cont->replay_encryptions = iter;     // test mode: the encryption randomness of an image depends on its index only, not on which images ran before it in this process
             ct_layer.push_back(EncryptNew(cont, EncodeCoeffs(input, cont->ECD_LV, cont->scale), cont->ECD_LV, cont->scale));
         }
         printf("vec size:  %d\n", N); printf("input width:  [%d %d %d]\n", raw_in_wids[0], raw_in_wids[1], raw_in_wids[2]);

@@ -115,3 +115,27 @@ def test_bench_two_gpus_over_rccl(tmp_path):
     j2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
     assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["unit"] == "conv/s"
     assert 1.5 * j1["value"] < j2["value"] < 2.5 * j1["value"], (j1["value"], j2["value"])
+
+
+def test_bench_two_gloo_ranks_on_one_gpu_carries_configs_3_and_5(tmp_path):
+    """The N > 1 line of bench.py, as far as a one-GPU box can exercise it (no multi-GPU box exists in this pool: a dry run of the plumbing, not a measurement): two gloo
+    ranks share GPU 0. The ONE JSON line must carry the weak-scaling headline with n_gpus = 2 AND both multi-GPU configurations of BASELINE.json: config 3 - one `conv 7 3`
+    split i mod N over the ranks' contexts, both forms (`sharded_conv`) - and config 5 - every rank classifying its own ResNet-20 images, the whole-job rate from the
+    slowest rank (`workloads.resnet20.images_per_hour`, n_gpus = 2) - so that the first SCALE record the driver can take holds them."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HC_BENCH_BACKEND="gloo")
+    args = ["--steps", "2", "--warmup", "1", "--batch", "2", "--streams", "1", "--no-cpu-baseline", "--relu-batch", "2", "--resnet-batch", "2", "--resnet-images", "4"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 90),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env, capture_output=True, text=True, timeout=1200)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
+    lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["unit"] == "conv/s" and j["value"] > 0
+    assert "extras" not in j, j.get("extras")                                    # the watchdog did not have to cut the extras off
+    sc = j["sharded_conv"]
+    assert sc["n_gpus"] == 2 and sc["sharded_conv_ms"] > 0 and sc["sharded_conv_ms_rccl_gather"] > 0, sc
+    rn = j["workloads"]["resnet20"]
+    assert rn.get("n_gpus") == 2 and rn["images_per_hour"] > 0 and rn["images_per_launch_set"] == 2, rn
+    cr = j["workloads"]["convReLU_5_1"]
+    assert cr["ms_per_ct_layer_throughput"] > 0 and cr["layer_latency_ms"] >= cr["ms_per_ct_layer_throughput"] and cr.get("ms_per_layer_n1", 0) > 0, cr

@@ -251,6 +251,33 @@ def test_resnet_cli_two_image_threads_cached_allocations(tmp_path):
         assert np.array_equal(res["plain"][i], res["batch"][i]), (i, res["plain"][i], res["batch"][i])
 
 
+def test_resnet_cli_depth20_image_batch_of_8(tmp_path):
+    """The configuration bench.py's `resnet20` workload times: `resnet 3 20 1 8 false` with HCONV_IMAGE_BATCH=8 - eight images through every one of the 19 layers as ONE launch
+    set (hc_conv_then_pack_batch for the convolutions, hc_set_batch(8) for every bootstrapping tail). Digest grade, under HCONV_RESNET_REPLAY (the oracle harness' keys; an
+    image's encryption randomness depends on its index only): image 0's ciphertext after EVERY layer == tests/golden/oracle_resnet_digests.json (the CPU oracle's network), and
+    image 5's after every layer == the same image classified ALONE in a second process (HCONV_RESNET_FIRST_IMAGE=5, no batch): a batch member is the bits of its single run."""
+    import json
+    import golden.gen_resnet_csv as rgen
+    rgen.write_case(str(tmp_path), 3, 20, 8, native_image=True)
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_resnet_digests.json")))["depth"]["20"]
+    pat = r"^replay digest layer (\d+) image (\d+) level 1 scale \S+ ([0-9a-f]{64})$"
+    out = subprocess.run([CLI, "--test-mode", "resnet", "3", "20", "1", "8", "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
+                         env=dict(os.environ, HCONV_RESNET_REPLAY="1", HCONV_IMAGE_BATCH="8"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    batch = {(int(m.group(1)), int(m.group(2))): m.group(3) for m in re.finditer(pat, out.stdout, re.M)}
+    assert sorted(batch) == [(l, z) for l in range(19) for z in range(8)], sorted(batch)[:5]
+    for l, w in enumerate(ref["layers"]):
+        assert batch[(l, 0)] == w, f"layer {l}: image 0 of the batch of 8 differs from the oracle network's ciphertext"
+    assert len({batch[(18, z)] for z in range(8)}) == 8, "the eight images of the batch must end on eight different ciphertexts"
+    alone = subprocess.run([CLI, "--test-mode", "resnet", "3", "20", "1", "6", "false"], cwd=tmp_path, capture_output=True, text=True, timeout=1500,
+                           env=dict(os.environ, HCONV_RESNET_REPLAY="1", HCONV_RESNET_FIRST_IMAGE="5", HCONV_IMAGE_BATCH="1"))
+    assert alone.returncode == 0, alone.stderr[-2000:]
+    single = {(int(m.group(1)), int(m.group(2))): m.group(3) for m in re.finditer(pat, alone.stdout, re.M)}
+    assert sorted(single) == [(l, 5) for l in range(19)], sorted(single)[:5]
+    for l in range(19):
+        assert batch[(l, 5)] == single[(l, 5)], f"layer {l}: image 5 inside the batch of 8 differs from image 5 classified alone"
+
+
 def test_resnet_cli_depth20(tmp_path):
     """BASELINE.md config 5 at its stated depth: `resnet 3 20 1 1 false` (testResNet_crop_sparse, test.go:76-370; CLI main.go:609-621),
     19 conv-BN-ReLU layers with bootstrapping + the FC layer on one ciphertext, synthetic weights in the reference's file layout
