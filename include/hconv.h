@@ -279,10 +279,24 @@ int hc_lv_mul_sum(hc_ctx *ctx, int level, const uint64_t *const *cts, const uint
 int hc_bl_post_ker_slots(hc_ctx *ctx, const double *max_ker_rs, int in_wid, int ker_wid, int pad, int max_batch, int rot,
                          double *values_out);
 
+/* ---- 4-byte rows (round 5) ----
+ * Lattigo stores every residue in a uint64. Eleven of the 28 Q limbs of ckks.DefaultBootstrapParams[6] / [7] are ~30-bit primes, and every kernel of the bootstrapping chain is
+ * priced in bytes: option "pack32" lets rows of limbs below 2^31 be stored as N 4-byte words AT THE ROW'S ADDRESS (the row pitch stays N 8-byte words: no stride, size or
+ * pointer arithmetic of the caller changes; the second half of such a row's slot is simply unused).
+ *   1 (default): inside the library only - the seam between the two passes of every transform, the extended digits of a key switch, the switching keys. Invisible at this ABI.
+ *   2: ALSO in every LEVELED operand a caller hands in or gets back - the polynomials of hc_lv_*, hc_rotate_finish, hc_lv_permute, hc_keyswitch*, hc_div_round_last / 2 (general
+ *      level), the extended-basis pairs of hc_keyswitch_qp*, hc_mod_down2*, hc_qp_*, the plaintexts they multiply by, hc_encode_slots' output. hc_row_is32(ctx, mod) tells which
+ *      limbs that concerns; a caller converts at its own boundary only (what it uploads into / downloads from such rows: the C++ host's Boot::put_rows / get_rows; ciphertexts
+ *      enter and leave the chain at levels 0 / 1, whose limbs are large, so the hot path converts nothing). The L0 one-row primitives (hc_ntt ... hc_permute with an explicit
+ *      modulus or row count), the level-0/1 convolution path and hc_swk_generate's secret-key rows keep 8-byte rows. Same residues, bit for bit, in every setting.
+ *   0: off. Keys are stored per the setting in force when they are loaded: switch between 0 and 1 / 2 only on a context without keys (HC_ERR_STATE otherwise).
+ * HCONV_PACK32=0|1|2 in the environment sets the initial value at hc_ctx_create. */
+int hc_row_is32(hc_ctx *ctx, int mod);
 /* ---- tuning / measurement ---- */
 int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes" (jobs - channels / tree nodes summed over the batch - per kernel launch), "small_levels" (tree levels of at most
                                                                   this many nodes x ciphertexts run on the quarter-tile kernels: default 16, 0 = never), "profile" (per-kernel HIP-event totals),
-                                                                  "peer_access" (hc_conv_then_pack_sharded: 0 = do not enable direct peer copies; default 1: enabled where hipDeviceCanAccessPeer allows) */
+                                                                  "peer_access" (hc_conv_then_pack_sharded: 0 = do not enable direct peer copies; default 1: enabled where hipDeviceCanAccessPeer allows),
+                                                                  "pack32" (0 / 1 / 2: 4-byte rows, above) */
 /* HIP-event timing on the context's stream */
 int hc_timer_start(hc_ctx *ctx);
 int hc_timer_stop(hc_ctx *ctx, float *ms);

@@ -96,6 +96,7 @@ SYMBOLS = {
     "hc_pack_ctxts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "hc_pack_ctxts_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hc_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
+    "hc_row_is32": (C.c_int, [C.c_void_p, C.c_int]),
     "hc_timer_start": (C.c_int, [C.c_void_p]),
     "hc_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "hc_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]),

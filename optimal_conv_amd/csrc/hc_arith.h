@@ -142,4 +142,5 @@ struct HcMod {
     u64 r2;        // 2^128 mod q (to enter Montgomery form)
     u64 ninv, ninv_s;  // N^-1 mod q and its Shoup companion
     u64 mu;            // floor(2^64/q) (Barrett, 64-bit inputs)
+    u64 row32;         // != 0: the rows of this limb in LEVELED operands (polynomials, extended-basis pairs, plaintexts) are 4-byte words (context option pack32 = 2, limbs below 2^31)
 };

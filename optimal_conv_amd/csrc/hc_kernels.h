@@ -29,6 +29,29 @@
 
 struct __attribute__((aligned(16))) HcTw { u64 w, ws; };
 
+// ---- 4-byte rows (round 5). Eleven of the bootstrapping chain's 28 Q limbs are ~30-bit primes (levels 5-15 of ckks.DefaultBootstrapParams[6]); Lattigo stores every residue in
+// a uint64. Inside the library a row of such a limb is stored as N 4-byte words AT THE SAME ROW ADDRESS (the row pitch stays N 8-byte words, so no layout or stride changes
+// anywhere: the second half of the slot is simply never touched): the arrays that never leave the library - the seam between the two passes of every multi-modulus
+// transform (ws_tmp), the extended digits of a key switch, the switching keys - move half the bytes for those rows. Values a caller can see (ciphertexts, plaintexts, the
+// extended-basis accumulators) keep Lattigo's 8-byte representation. A lazy value must be brought below 2^32 first: below 2q for q < 2^31.
+#define HC_SMALL_Q(q) ((q) < (1ull << 31))
+// Row form chosen at compile time inside a kernel: the loops of a streaming kernel are written once as a generic lambda over HcBool<S32> and entered through HC_ROW_DISPATCH
+// (one uniform branch per workgroup, two copies of the loop; a run-time condition around the two load forms made the compiler issue both loads). HC_LD / HC_ST take the ROW's
+// base pointer (8-byte words) and the element index inside the row.
+template <bool B> struct HcBool { static constexpr bool value = B; };
+#define HC_LD(S32, rowptr, j) ((S32) ? hc_ld32(rowptr, j) : (rowptr)[j])
+#define HC_ST(S32, rowptr, j, v) do { if (S32) hc_st32(rowptr, j, v); else (rowptr)[j] = (v); } while (0)
+#define HC_ROW_DISPATCH(row32, body) do { if (row32) body(HcBool<true>{}); else body(HcBool<false>{}); } while (0)
+__device__ __forceinline__ u64 hc_ld32(const u64 *row, size_t j) { return (u64)reinterpret_cast<const u32 *>(row)[j]; }
+__device__ __forceinline__ void hc_st32(u64 *row, size_t j, u64 v) { reinterpret_cast<u32 *>(row)[j] = (u32)v; }
+// One load form for a row of either width: an 8-byte load at the element pitch (4 or 8 bytes), masked. For a 4-byte row it straddles elements j and j + 1 (4-byte aligned:
+// a legal global_load_dwordx2; the last element reads 4 bytes into the unused half of the row's slot). Measured per kernel (profiles/round5_chain_kernel_ab.txt): in the
+// rows-forward pass this beats two copies of the body chosen per workgroup (which spill 88 bytes at its 72-register budget) and a condition around two load forms (for which
+// the compiler issues BOTH loads on every row); in the inner products and the cols-inverse pass the two-copies form wins.
+struct __attribute__((packed, aligned(4))) HcU64A4 { u64 v; };
+__device__ __forceinline__ u64 hc_ldp(const u64 *row, size_t j, bool row32) {
+    return reinterpret_cast<const HcU64A4 *>(reinterpret_cast<const char *>(row) + (j << (row32 ? 2 : 3)))->v & (row32 ? 0xFFFFFFFFull : ~0ull);
+}
 // Twiddle tables of one (modulus, direction), device pointers.
 struct HcTwTab {
     const HcTw *rowsA;   // [256 rows][16 slots]          round on the high column bits (uniform per row)
@@ -439,28 +462,33 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const 
     const size_t base = (size_t)row * 65536;
     const int zp = (int)blockIdx.z % npoly; const size_t img0 = (size_t)((int)blockIdx.z / npoly) * nin;
     a += (size_t)zp * as + img0 * ia; b += (size_t)zp * bs + img0 * ib; out += (size_t)zp * os + img0 * io;      // distances in words, modulo 2^64
+    const u64 *ar = a + base, *br = b + base; u64 *outr = out + base;                 // row base pointers
+    auto body = [&](auto s32c) {
+    constexpr bool S32 = decltype(s32c)::value;
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
         if (nin == 1) {
-            const u64 x = a[base + i]; u64 r;
-            if (OP == HC_PW_MUL) r = hc_mont(x, hc_mont(b[base + i], m.r2, m.q, m.qinv), m.q, m.qinv);
-            else if (OP == HC_PW_ADD) r = hc_addmod(x, b[base + i], m.q);
-            else if (OP == HC_PW_SUB) r = hc_submod(x, b[base + i], m.q);
+            const u64 x = HC_LD(S32, ar, i); u64 r;
+            if (OP == HC_PW_MUL) r = hc_mont(x, hc_mont(HC_LD(S32, br, i), m.r2, m.q, m.qinv), m.q, m.qinv);
+            else if (OP == HC_PW_ADD) r = hc_addmod(x, HC_LD(S32, br, i), m.q);
+            else if (OP == HC_PW_SUB) r = hc_submod(x, HC_LD(S32, br, i), m.q);
             else if (OP == HC_PW_MULC) r = hc_mul_shoup(x, csts[l].w, csts[l].ws, m.q);
-            else if (OP == HC_PW_MAC) r = hc_addmod(out[base + i], hc_mont(x, hc_mont(b[base + i], m.r2, m.q, m.qinv), m.q, m.qinv), m.q);
+            else if (OP == HC_PW_MAC) r = hc_addmod(HC_LD(S32, outr, i), hc_mont(x, hc_mont(HC_LD(S32, br, i), m.r2, m.q, m.qinv), m.q, m.qinv), m.q);
             else r = hc_addmod(x, csts[l].w, m.q);
-            out[base + i] = r;
+            HC_ST(S32, outr, i, r);
         } else {                                                               // shared b (ib == 0), products only
-            const u64 y = hc_mont(b[base + i], m.r2, m.q, m.qinv);           // MForm, once
+            const u64 y = hc_mont(HC_LD(S32, br, i), m.r2, m.q, m.qinv);     // MForm, once
             u64 x[HC_MAXIMG], o[HC_MAXIMG];
 #pragma unroll
-            for (int g = 0; g < HC_MAXIMG; g++) if (g < nin) { x[g] = a[(size_t)g * ia + base + i]; if (OP == HC_PW_MAC) o[g] = out[(size_t)g * io + base + i]; }
+            for (int g = 0; g < HC_MAXIMG; g++) if (g < nin) { x[g] = HC_LD(S32, ar + (size_t)g * ia, i); if (OP == HC_PW_MAC) o[g] = HC_LD(S32, outr + (size_t)g * io, i); }
 #pragma unroll
             for (int g = 0; g < HC_MAXIMG; g++) if (g < nin) {
                 const u64 pr = hc_mont(x[g], y, m.q, m.qinv);
-                out[(size_t)g * io + base + i] = OP == HC_PW_MAC ? hc_addmod(o[g], pr, m.q) : pr;
+                HC_ST(S32, outr + (size_t)g * io, i, OP == HC_PW_MAC ? hc_addmod(o[g], pr, m.q) : pr);
             }
         }
     }
+    };
+    HC_ROW_DISPATCH(m.row32, body);
 }
 // A linear combination with integer coefficients of up to 8 ciphertexts, both polynomials, all limbs, every image of a batch in one launch: evaluatePolyFromPowerBasis'
 // leaf (a MultByConst per power of the basis and an Add chain, plus AddConst): out_k[l] = sum_t c[t][l] * a_t,k[l] (+ addc[l] on k = 0). The constants come in Montgomery
@@ -472,38 +500,46 @@ struct HcLinConsts { u64 c[HC_MAXLIN][32]; u64 addc[32]; };
 __global__ __launch_bounds__(HC_TPB) void hc_k_lv_lincomb(HcLinPtrs P, HcLinConsts K, int nterms, u64 *o0, u64 *o1, const HcMod *mods, size_t is) {
     const int l = blockIdx.y, k = blockIdx.z & 1; const HcMod m = mods[l];
     const size_t base = (size_t)l * 65536 + (size_t)(blockIdx.z >> 1) * is;
-    u64 *o = k ? o1 : o0; const u64 addc = k ? 0 : K.addc[l];
+    u64 *o = (k ? o1 : o0) + base; const u64 addc = k ? 0 : K.addc[l];
+    auto body = [&](auto s32c) {
+    constexpr bool S32 = decltype(s32c)::value;
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
         u128 T = 0;
 #pragma unroll
-        for (int t = 0; t < HC_MAXLIN; t++) if (t < nterms) T += (u128)(k ? P.a1[t] : P.a0[t])[base + i] * K.c[t][l];
-        o[base + i] = hc_addmod(hc_mont_redc(T, m.q, m.qinv), addc, m.q);
+        for (int t = 0; t < HC_MAXLIN; t++) if (t < nterms) T += (u128)HC_LD(S32, (k ? P.a1[t] : P.a0[t]) + base, i) * K.c[t][l];
+        HC_ST(S32, o, i, hc_addmod(hc_mont_redc(T, m.q, m.qinv), addc, m.q));
     }
+    };
+    HC_ROW_DISPATCH(m.row32, body);
 }
 // the tensor step of ckks.evaluator.mulRelin for all limbs: d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1 (canonical)
 // blockIdx.z = image of a batch (every operand `is` words further per image)
 __global__ __launch_bounds__(HC_TPB) void hc_k_lv_tensor(const u64 *a0, const u64 *a1, const u64 *b0, const u64 *b1, u64 *d0, u64 *d1, u64 *d2, const HcMod *mods, size_t is) {
     const int l = blockIdx.y; const HcMod m = mods[l];
     const size_t base = (size_t)l * 65536 + (size_t)blockIdx.z * is;
+    auto body = [&](auto s32c) {
+    constexpr bool S32 = decltype(s32c)::value;
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
-        const u64 x0 = a0[base + i], x1 = a1[base + i];
-        const u64 y0 = hc_mont(b0[base + i], m.r2, m.q, m.qinv), y1 = hc_mont(b1[base + i], m.r2, m.q, m.qinv);   // MForm, as mulRelin does
-        d0[base + i] = hc_mont(x0, y0, m.q, m.qinv);
-        d1[base + i] = hc_addmod(hc_mont(x0, y1, m.q, m.qinv), hc_mont(x1, y0, m.q, m.qinv), m.q);
-        d2[base + i] = hc_mont(x1, y1, m.q, m.qinv);
+        const u64 x0 = HC_LD(S32, a0 + base, i), x1 = HC_LD(S32, a1 + base, i);
+        const u64 y0 = hc_mont(HC_LD(S32, b0 + base, i), m.r2, m.q, m.qinv), y1 = hc_mont(HC_LD(S32, b1 + base, i), m.r2, m.q, m.qinv);   // MForm, as mulRelin does
+        HC_ST(S32, d0 + base, i, hc_mont(x0, y0, m.q, m.qinv));
+        HC_ST(S32, d1 + base, i, hc_addmod(hc_mont(x0, y1, m.q, m.qinv), hc_mont(x1, y0, m.q, m.qinv), m.q));
+        HC_ST(S32, d2 + base, i, hc_mont(x1, y1, m.q, m.qinv));
     }
+    };
+    HC_ROW_DISPATCH(m.row32, body);
 }
 // ckks.(*Bootstrapper).modUp for one polynomial: coefficient row t (canonical mod q0) -> centred lift reduced into limb blockIdx.y
 // blockIdx.z = image of a batch: coefficient rows 65536 words apart, outputs `is` words apart
 __global__ __launch_bounds__(HC_TPB) void hc_k_mod_raise(const u64 *t, u64 *out, const HcMod *mods, size_t is) {
-    const int l = blockIdx.y; const u64 q0 = mods[0].q, q = mods[l].q, mu = mods[l].mu;
-    t += (size_t)blockIdx.z * 65536; out += (size_t)blockIdx.z * is;
+    const int l = blockIdx.y; const u64 q0 = mods[0].q, q = mods[l].q, mu = mods[l].mu; const bool row32 = mods[l].row32 != 0;
+    t += (size_t)blockIdx.z * 65536; out += (size_t)blockIdx.z * is + (size_t)l * 65536;
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
         const u64 x = t[i];
         u64 r;
         if (x > (q0 >> 1)) { r = hc_barrett64(q0 - x, q, mu); r = r ? q - r : 0; }
         else r = hc_barrett64(x, q, mu);
-        out[(size_t)l * 65536 + i] = r;
+        if (row32) hc_st32(out, i, r); else out[i] = r;                       // (a store: nothing to speculate)
     }
 }
 // Shoup companion of a row of fixed multiplicands: ws = floor(w * 2^64 / q)
@@ -610,20 +646,30 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_permute(const u64 *in, u64 *out, 
 }
 
 // the same permutation on `rows` consecutive rows of each image of a batch: grid = (64, rows, images), images `is` words apart
-__global__ __launch_bounds__(HC_TPB) void hc_k_permute_mm(const u64 *in, u64 *out, u32 g, size_t is) {
+// rows [0, nl) and [nt, nt + nl) belong to limbs 0 .. nl - 1, the others to the special primes (a polynomial: nt = nl = rows; an extended-basis pair: nt = nl + np)
+__global__ __launch_bounds__(HC_TPB) void hc_k_permute_mm(const u64 *in, u64 *out, u32 g, size_t is, const HcMod *mods, int nl, int nq, int nt) {
     const size_t base = (size_t)blockIdx.z * is + (size_t)blockIdx.y * 65536;
-    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) out[base + i] = in[base + hc_perm_src((u32)i, g)];
+    const int T = (int)blockIdx.y % nt; const bool row32 = mods[T < nl ? T : nq + (T - nl)].row32 != 0;
+    auto body = [&](auto s32c) {
+    constexpr bool S32 = decltype(s32c)::value;
+    for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) HC_ST(S32, out + base, i, HC_LD(S32, in + base, hc_perm_src((u32)i, g)));
+    };
+    HC_ROW_DISPATCH(row32, body);
 }
 
 // evaluator.permuteNTT's tail for all limbs of both polynomials in one launch: out0 = Permute_g(d0 + c0), out1 = Permute_g(d1)
 // (d = the key switch of c1). grid = (64, level + 1, 2 * images): blockIdx.z = polynomial + 2 * image, images `is` words apart
 __global__ __launch_bounds__(HC_TPB) void hc_k_rotate_finish(const u64 *d0, const u64 *d1, const u64 *c0, u64 *o0, u64 *o1, const HcMod *mods, u32 g, size_t is) {
     const int l = blockIdx.y; const u64 q = mods[l].q; const size_t base = (size_t)l * 65536 + (size_t)(blockIdx.z >> 1) * is;
+    auto body = [&](auto s32c) {
+    constexpr bool S32 = decltype(s32c)::value;
     if ((blockIdx.z & 1) == 0) {
-        for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) { const size_t s = base + hc_perm_src((u32)i, g); o0[base + i] = hc_addmod(d0[s], c0[s], q); }
+        for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) { const size_t s = hc_perm_src((u32)i, g); HC_ST(S32, o0 + base, i, hc_addmod(HC_LD(S32, d0 + base, s), HC_LD(S32, c0 + base, s), q)); }
     } else {
-        for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) o1[base + i] = d1[base + hc_perm_src((u32)i, g)];
+        for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) HC_ST(S32, o1 + base, i, HC_LD(S32, d1 + base, hc_perm_src((u32)i, g)));
     }
+    };
+    HC_ROW_DISPATCH(mods[l].row32, body);
 }
 
 // ================================================================ loop A (conv.go:525-531), fused
@@ -1591,28 +1637,12 @@ __device__ __forceinline__ void hc_basis_ext_tile(u64 (&e)[16], const u64 *yv, c
         for (int g = 0; g < HC_EXT_GROUP; g++) e[g0 + g] = hc_basis_ext_sum<NS>(y[g], B, Q);
     }
 }
-// ---- 4-byte rows (round 5). Eleven of the bootstrapping chain's 28 Q limbs are ~30-bit primes (levels 5-15 of ckks.DefaultBootstrapParams[6]); Lattigo stores every residue in
-// a uint64. Inside the library a row of such a limb is stored as N 4-byte words AT THE SAME ROW ADDRESS (the row pitch stays N 8-byte words, so no layout or stride changes
-// anywhere: the second half of the slot is simply never touched): the arrays that never leave the library - the seam between the two passes of every multi-modulus
-// transform (ws_tmp), the extended digits of a key switch, the switching keys - move half the bytes for those rows. Values a caller can see (ciphertexts, plaintexts, the
-// extended-basis accumulators) keep Lattigo's 8-byte representation. A lazy value must be brought below 2^32 first: below 2q for q < 2^31.
-#define HC_SMALL_Q(q) ((q) < (1ull << 31))
-__device__ __forceinline__ u64 hc_ld32(const u64 *row, size_t j) { return (u64)reinterpret_cast<const u32 *>(row)[j]; }
-__device__ __forceinline__ void hc_st32(u64 *row, size_t j, u64 v) { reinterpret_cast<u32 *>(row)[j] = (u32)v; }
-// One load form for a row of either width: an 8-byte load at the element pitch (4 or 8 bytes), masked. For a 4-byte row it straddles elements j and j + 1 (4-byte aligned:
-// a legal global_load_dwordx2; the last element reads 4 bytes into the unused half of the row's slot). Measured per kernel (profiles/round5_chain_kernel_ab.txt): in the
-// rows-forward pass this beats two copies of the body chosen per workgroup (which spill 88 bytes at its 72-register budget) and a condition around two load forms (for which
-// the compiler issues BOTH loads on every row); in the inner products and the cols-inverse pass the two-copies form wins.
-struct __attribute__((packed, aligned(4))) HcU64A4 { u64 v; };
-__device__ __forceinline__ u64 hc_ldp(const u64 *row, size_t j, bool row32) {
-    return reinterpret_cast<const HcU64A4 *>(reinterpret_cast<const char *>(row) + (j << (row32 ? 2 : 3)))->v & (row32 ? 0xFFFFFFFFull : ~0ull);
-}
 struct HcRowMod { HcTwTab fwd, inv; u64 q, mu; };
 // blockIdx.z = operand + nz * image: `nz` operands zs_* words apart (the two polynomials of a ciphertext, the digits of a key switch), and the
 // images of a batch (hc_set_batch) is_* words apart
 struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; int z_alpha; int nz; size_t is_in, is_out;
               int xcd, nzn;                  // rows passes: XCD-aware 1-D grid over nzn = nz * images operands (HC_MM_PROLOGUE_ROWS)
-              int pk_in, pk_out;             // the rows of `in` / `out` whose modulus is below 2^31 are stored as 4-byte words (hc_row32: library-internal arrays only)
+              int pk_in, pk_out, pk_epi;     // the rows of `in` / `out` / the epilogue's operands (epi_x, epi_add and the result) whose modulus is below 2^31 are 4-byte words
               unsigned char rowlist[48];     // blockIdx.y -> row (rows a launch has nothing to do for are left out of the grid)
 
               // fused prologue of the cols-forward pass / epilogue of the rows-forward pass (0 = none):
@@ -1678,8 +1708,9 @@ __global__ __launch_bounds__(HC_TPB, EXT ? HC_MM_WAVES_EXT : HC_MM_WAVES) void h
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) e[hi] = hc_barrett64(hc_csub(tt[(size_t)(hi * 16 + tid) * 256] + h, qL) + neg_h, qi, R.mu);
     } else {
+        const bool in32 = A.pk_in && HC_SMALL_Q(R.q);                         // block-uniform (a caller's polynomial under pack32 = 2)
 #pragma unroll
-        for (int hi = 0; hi < 16; hi++) e[hi] = in[base + (size_t)(hi * 16 + tid) * 256];
+        for (int hi = 0; hi < 16; hi++) e[hi] = hc_ldp(in + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(hi * 16 + tid) * 256, in32);
     }
     const HcQ Qf = hc_q(R.q);
     hc_cols_fwd<HC_FM_ALT>(e, lds, R.fwd, c, tid, Qf);
@@ -1691,6 +1722,9 @@ __global__ __launch_bounds__(HC_TPB, EXT ? HC_MM_WAVES_EXT : HC_MM_WAVES) void h
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) out[base + (size_t)(tid * 16 + lo) * 256] = e[lo];
 }
+#ifndef HC_EPI_ROWS
+#define HC_EPI_ROWS 4                  // rows of the epilogue's operands requested together
+#endif
 #ifndef HC_MM_WAVES_RF
 #define HC_MM_WAVES_RF 6                  // the rows-forward pass with its clustered epilogue loads: 80 VGPRs, no scratch (7 wavefronts: 72 VGPRs and 44 bytes of scratch; measured 18.38 vs 18.51 ms per ciphertext-layer)
 #endif
@@ -1715,39 +1749,41 @@ __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_RF) void hc_k_rows_fwd_canon_mm
         // (x - result) * c (+ addend [* c']): the operands of eight rows are requested together and the kind of epilogue is decided once, outside the loops. As one loop
         // with the conditions inside it compiled to SIXTEEN dependent round trips per thread (load x, wait, load the addend, wait, store ...): the tail of every ModDown and
         // Rescale waited on memory 16 times over
-        const u64 *x = A.epi_x + (size_t)zi * A.epi_x_zs + (size_t)img * A.epi_x_is + lin;
+        const bool e32 = A.pk_epi && small;                                  // block-uniform: x, the addend and the result are rows of 4-byte words
+        const size_t lj = (size_t)(bx * 16) * 256 + t;                       // element index of (row bx * 16, column t) inside the limb's row
+        const u64 *x = A.epi_x + (size_t)zi * A.epi_x_zs + (size_t)img * A.epi_x_is + pbase;
+        u64 *orow = out + pbase;
         const HcTw w = A.epi_mul[y];
-        if (A.epi_add == nullptr) {
+        const u64 *ad = A.epi_add != nullptr ? A.epi_add + (size_t)zi * A.epi_add_zs + (size_t)img * A.epi_add_is + pbase : nullptr;
+        const bool scaled = A.epi_add_mul != nullptr;
+        const HcTw wa = scaled ? A.epi_add_mul[y] : HcTw{0, 0};
 #pragma unroll
-            for (int h = 0; h < 16; h += 8) {
-                u64 xv[8];
+        for (int h = 0; h < 16; h += HC_EPI_ROWS) {
+            u64 xv[HC_EPI_ROWS], av[HC_EPI_ROWS], r[HC_EPI_ROWS];
 #pragma unroll
-                for (int k = 0; k < 8; k++) xv[k] = x[(h + k) * 256];
+            for (int k = 0; k < HC_EPI_ROWS; k++) xv[k] = hc_ldp(x, lj + (size_t)(h + k) * 256, e32);
+            if (ad != nullptr) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) out[lin + (h + k) * 256] = hc_mul_shoup(hc_submod(xv[k], e[h + k], rq), w.w, w.ws, rq);
+                for (int k = 0; k < HC_EPI_ROWS; k++) av[k] = hc_ldp(ad, lj + (size_t)(h + k) * 256, e32);
             }
-            return;
-        }
-        const u64 *ad = A.epi_add + (size_t)zi * A.epi_add_zs + (size_t)img * A.epi_add_is + lin;
-        if (A.epi_add_mul != nullptr) {
-            const HcTw wa = A.epi_add_mul[y];
 #pragma unroll
-            for (int h = 0; h < 16; h += 8) {
-                u64 xv[8], av[8];
+            for (int k = 0; k < HC_EPI_ROWS; k++) r[k] = hc_mul_shoup(hc_submod(xv[k], e[h + k], rq), w.w, w.ws, rq);
+            if (ad != nullptr) {
+                if (scaled) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) { xv[k] = x[(h + k) * 256]; av[k] = ad[(h + k) * 256]; }
+                    for (int k = 0; k < HC_EPI_ROWS; k++) r[k] = hc_addmod(r[k], hc_mul_shoup(av[k], wa.w, wa.ws, rq), rq);
+                } else {
 #pragma unroll
-                for (int k = 0; k < 8; k++) out[lin + (h + k) * 256] = hc_addmod(hc_mul_shoup(hc_submod(xv[k], e[h + k], rq), w.w, w.ws, rq), hc_mul_shoup(av[k], wa.w, wa.ws, rq), rq);
+                    for (int k = 0; k < HC_EPI_ROWS; k++) r[k] = hc_addmod(r[k], av[k], rq);
+                }
             }
-            return;
-        }
+            if (e32) {
 #pragma unroll
-        for (int h = 0; h < 16; h += 8) {
-            u64 xv[8], av[8];
+                for (int k = 0; k < HC_EPI_ROWS; k++) hc_st32(orow, lj + (size_t)(h + k) * 256, r[k]);
+            } else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) { xv[k] = x[(h + k) * 256]; av[k] = ad[(h + k) * 256]; }
-#pragma unroll
-            for (int k = 0; k < 8; k++) out[lin + (h + k) * 256] = hc_addmod(hc_mul_shoup(hc_submod(xv[k], e[h + k], rq), w.w, w.ws, rq), av[k], rq);
+                for (int k = 0; k < HC_EPI_ROWS; k++) orow[lj + (size_t)(h + k) * 256] = r[k];
+            }
         }
         return;
     }
@@ -1759,14 +1795,18 @@ __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_RF) void hc_k_rows_fwd_canon_mm
 #pragma unroll
     for (int k = 0; k < 16; k++) out[lin + k * 256] = e[k];
 }
-__global__ __launch_bounds__(HC_TPB, HC_MM_WAVES) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
+#ifndef HC_MM_WAVES_INV
+#define HC_MM_WAVES_INV 6              // the inverse passes: 78-80 VGPRs without scratch (at 7 the typed / pitch row loads of round 5 spill 16-24 bytes)
+#endif
+__global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_INV) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ hc_mm_lds_t lds[HC_ROWS_LDS];
     HC_MM_PROLOGUE_ROWS
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = bx * 16 + rloc;
     const size_t pbase = (size_t)y * 65536;
     u64 e[16];
+    const bool in32 = A.pk_in && HC_SMALL_Q(R.q);                             // block-uniform (a caller's NTT-domain polynomial under pack32 = 2)
 #pragma unroll
-    for (int k = 0; k < 16; k++) e[k] = in[pbase + (size_t)(bx * 16 + k) * 256 + t];
+    for (int k = 0; k < 16; k++) e[k] = hc_ldp(in + pbase, (size_t)(bx * 16 + k) * 256 + t, in32);
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     const HcQ Q = hc_q(R.q);
@@ -1780,7 +1820,7 @@ __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES) void hc_k_rows_inv_mm(const u6
     for (int hi = 0; hi < 16; hi++) out[pbase + (size_t)row * 256 + hi * 16 + tid] = e[hi];
 }
 template <bool IN32>
-__device__ __forceinline__ void hc_cols_inv_canon_mm_body(const u64 *in, u64 *out, hc_mm_lds_t *lds, const HcRowMod &R, int y) {
+__device__ __forceinline__ void hc_cols_inv_canon_mm_body(const u64 *in, u64 *out, hc_mm_lds_t *lds, const HcRowMod &R, int y, bool out32) {
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
     u64 e[16];
@@ -1788,14 +1828,20 @@ __device__ __forceinline__ void hc_cols_inv_canon_mm_body(const u64 *in, u64 *ou
     for (int lo = 0; lo < 16; lo++) e[lo] = IN32 ? hc_ld32(in + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(tid * 16 + lo) * 256) : in[base + (size_t)(tid * 16 + lo) * 256];
     const HcQ Q = hc_q(R.q);
     hc_cols_inv(e, lds, R.inv, c, tid, Q);
+    if (out32) {                                                              // uniform: a caller's coefficient-domain polynomial under pack32 = 2 (hc_lv_intt)
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) hc_st32(out + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(hi * 16 + tid) * 256, hc_canon4(e[hi], Q));
+        return;
+    }
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_canon4(e[hi], Q);
 }
-__global__ __launch_bounds__(HC_TPB, HC_MM_WAVES) void hc_k_cols_inv_canon_mm(const u64 *in, u64 *out, HcMm A) {
+__global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_INV) void hc_k_cols_inv_canon_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ hc_mm_lds_t lds[HC_COLS_LDS];
     HC_MM_PROLOGUE
-    if (A.pk_in && HC_SMALL_Q(R.q)) hc_cols_inv_canon_mm_body<true>(in, out, lds, R, y);          // block-uniform
-    else hc_cols_inv_canon_mm_body<false>(in, out, lds, R, y);
+    const bool small = HC_SMALL_Q(R.q);
+    if (A.pk_in && small) hc_cols_inv_canon_mm_body<true>(in, out, lds, R, y, A.pk_out && small);          // block-uniform
+    else hc_cols_inv_canon_mm_body<false>(in, out, lds, R, y, A.pk_out && small);
 }
 // ModDown fused with the Rescale behind it (hc_keyswitch_add_rescale), the last limb L. Rescale needs the coefficients of c_L = (acc_L - NTT(ext_L)) / P + add_L:
 // by linearity InvNTT(acc_L / P + add_L) - ext_L / P, ext_L being the coefficient-domain extension the y_i / v rows give. acc_L <- acc_L / P + add_L where the inner product writes that row (hc_k_ks_mac_all, HcMacPrep; hc_k_mdrs_prep for an acc that comes from elsewhere), in
@@ -1806,11 +1852,15 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_mdrs_prep(u64 *acc, size_t acc_zs
     u64 *row = acc + (size_t)zi * acc_zs + (size_t)img * acc_is + (size_t)L * 65536;
     const u64 *a = add != nullptr ? add + (size_t)zi * add_zs + (size_t)img * add_is + (size_t)L * 65536 : nullptr;
     const u64 q = mods[L].q; const HcTw w = pinv[L];
+    auto body = [&](auto s32c) {
+    constexpr bool S32 = decltype(s32c)::value;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        u64 r = hc_mul_shoup(row[j], w.w, w.ws, q);
-        if (a != nullptr) r = hc_addmod(r, a[j], q);
-        row[j] = r;
+        u64 r = hc_mul_shoup(HC_LD(S32, row, j), w.w, w.ws, q);
+        if (a != nullptr) r = hc_addmod(r, HC_LD(S32, a, j), q);
+        HC_ST(S32, row, j, r);
     }
+    };
+    HC_ROW_DISPATCH(mods[L].row32, body);
 }
 // mdrs != null (ModDown fused with Rescale, hc_ks_moddown_rescale): the row BEFORE the n source rows holds u = InvNTT(acc_L / P + add_L); it becomes t = u - ext_L / P with ext_L the
 // extension of this very coefficient into limb L (constants *mdrs, P^-1 mod q_L = *mdrs_pinv) - hc_k_mdrs_last's work, here where the y_i / v are still in registers
@@ -1852,7 +1902,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_yv(const u64 *src, size_t s
 struct HcMacPrep { const HcTw *pinv; const u64 *add; size_t add_zs, add_is; };
 // Per-digit form: the digits stay a loop (any count, few registers, 6-7 wavefronts per SIMD) but the 2 + NB loads of ONE digit are a straight run - typed at compile time
 // (P32), the image index clamped instead of tested - and only the own / foreign choice, which changes the operand's width, is a (uniform) branch.
-template <int NB, bool P32>
+template <int NB, bool P32, bool U32>
 __device__ __forceinline__ void hc_ks_mac_all_digit(const u64 *evk, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_is, const HcMod m, int T,
                                                     int nl, int nt, int alpha, int beta, int n, const HcMacPrep &prep, bool prepL, HcTw pw) {
     const size_t rowT = (size_t)T * 65536, comp = (size_t)nt * 65536;
@@ -1865,7 +1915,7 @@ __device__ __forceinline__ void hc_ks_mac_all_digit(const u64 *evk, const u64 *c
             u64 x[NB];
             if (d == d_own) {                                                 // uniform
 #pragma unroll
-                for (int g = 0; g < NB; g++) x[g] = cx[(size_t)(g < n ? g : n - 1) * cx_is + rowT + j];
+                for (int g = 0; g < NB; g++) { const u64 *xg = cx + (size_t)(g < n ? g : n - 1) * cx_is + rowT; x[g] = U32 ? hc_ld32(xg, j) : xg[j]; }
             } else {
                 const u64 *xrow = digits + ((size_t)d * nt) * 65536 + rowT;
 #pragma unroll
@@ -1886,12 +1936,13 @@ __device__ __forceinline__ void hc_ks_mac_all_digit(const u64 *evk, const u64 *c
         }
 #pragma unroll
         for (int g = 0; g < NB; g++) if (g < n) {
-            u64 *a = acc + (size_t)g * acc_is + rowT + j;
+            u64 *a = acc + (size_t)g * acc_is + rowT;
+            u64 r0 = s0[g], r1 = s1[g];
             if (prepL) {
-                u64 r0 = hc_mul_shoup(s0[g], pw.w, pw.ws, m.q), r1 = hc_mul_shoup(s1[g], pw.w, pw.ws, m.q);
-                if (prep.add != nullptr) { const u64 *ad = prep.add + (size_t)g * prep.add_is + rowT + j; r0 = hc_addmod(r0, ad[0], m.q); r1 = hc_addmod(r1, ad[prep.add_zs], m.q); }
-                a[0] = r0; a[comp] = r1;
-            } else { a[0] = s0[g]; a[comp] = s1[g]; }
+                r0 = hc_mul_shoup(r0, pw.w, pw.ws, m.q); r1 = hc_mul_shoup(r1, pw.w, pw.ws, m.q);
+                if (prep.add != nullptr) { const u64 *ad = prep.add + (size_t)g * prep.add_is + rowT; r0 = hc_addmod(r0, HC_LD(U32, ad, j), m.q); r1 = hc_addmod(r1, HC_LD(U32, ad + prep.add_zs, j), m.q); }
+            }
+            HC_ST(U32, a, j, r0); HC_ST(U32, a + comp, j, r1);
         }
     }
 }
@@ -1910,15 +1961,17 @@ __global__ __launch_bounds__(HC_TPB, HC_MAC_WAVES) void hc_k_ks_mac_all(const u6
     if (prep.add != nullptr) prep.add += (size_t)blockIdx.z * NB * prep.add_is;
     { const int g0 = (int)blockIdx.z * NB; cx += (size_t)g0 * cx_is; digits += (size_t)g0 * dg_is; acc += (size_t)g0 * acc_is; n = n - g0 < NB ? n - g0 : NB; }
     const HcMod m = mods[T < nl ? T : nq + (T - nl)];
-    if (pk && HC_SMALL_Q(m.q)) hc_ks_mac_all_digit<NB, true>(evk, cx, cx_is, digits, dg_is, acc, acc_is, m, T, nl, nt, alpha, beta, n, prep, prepL, pw);          // block-uniform: this limb's digit and key rows are 4-byte words
-    else hc_ks_mac_all_digit<NB, false>(evk, cx, cx_is, digits, dg_is, acc, acc_is, m, T, nl, nt, alpha, beta, n, prep, prepL, pw);
+    const bool small = HC_SMALL_Q(m.q);                                      // block-uniform: this limb's digit and key rows (pk) / the caller's rows cx, acc, add (m.row32: pack32 = 2) are 4-byte words
+    if (pk && small && m.row32) hc_ks_mac_all_digit<NB, true, true>(evk, cx, cx_is, digits, dg_is, acc, acc_is, m, T, nl, nt, alpha, beta, n, prep, prepL, pw);
+    else if (pk && small) hc_ks_mac_all_digit<NB, true, false>(evk, cx, cx_is, digits, dg_is, acc, acc_is, m, T, nl, nt, alpha, beta, n, prep, prepL, pw);
+    else hc_ks_mac_all_digit<NB, false, false>(evk, cx, cx_is, digits, dg_is, acc, acc_is, m, T, nl, nt, alpha, beta, n, prep, prepL, pw);
 }
 // The inner products of R hoisted rotations in ONE launch (the baby steps of a linear transform share one digit decomposition): a digit element is read once for the R keys
 // (hc_k_ks_mac_all re-reads all n x beta x nt digit rows per rotation - what bounds it). R x NB accumulator slots per component and thread (<= 16), plain Montgomery
 // accumulation (the kernel is bound by its loads). acc: [rotation][image][2][nt][N], rotations acc_rs words apart. grid = (64, nt)
 struct HcKeyPtrs { const u64 *k[8]; };
 // per-digit form as hc_ks_mac_all_digit: the 2 R key words of a digit (all rotations) and its NB digit words are one run of loads
-template <int R, int NB, bool P32>
+template <int R, int NB, bool P32, bool U32>
 __device__ __forceinline__ void hc_ks_mac_multi_digit(const HcKeyPtrs &keys, int nrot, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_rs, size_t acc_is, const HcMod m, int T,
                                                       int nl, int nt, int alpha, int beta, int n) {
     const size_t rowT = (size_t)T * 65536, comp = (size_t)nt * 65536;
@@ -1934,7 +1987,7 @@ __device__ __forceinline__ void hc_ks_mac_multi_digit(const HcKeyPtrs &keys, int
             }
             if (d == d_own) {                                                 // uniform
 #pragma unroll
-                for (int g = 0; g < NB; g++) x[g] = cx[(size_t)(g < n ? g : n - 1) * cx_is + rowT + j];
+                for (int g = 0; g < NB; g++) { const u64 *xg = cx + (size_t)(g < n ? g : n - 1) * cx_is + rowT; x[g] = U32 ? hc_ld32(xg, j) : xg[j]; }
             } else {
                 const u64 *xrow = digits + ((size_t)d * nt) * 65536 + rowT;
 #pragma unroll
@@ -1952,7 +2005,7 @@ __device__ __forceinline__ void hc_ks_mac_multi_digit(const HcKeyPtrs &keys, int
 #pragma unroll
         for (int r = 0; r < R; r++) if (r < nrot)
 #pragma unroll
-            for (int g = 0; g < NB; g++) if (g < n) { u64 *a = acc + (size_t)r * acc_rs + (size_t)g * acc_is + rowT + j; a[0] = s0[r][g]; a[comp] = s1[r][g]; }
+            for (int g = 0; g < NB; g++) if (g < n) { u64 *a = acc + (size_t)r * acc_rs + (size_t)g * acc_is + rowT; HC_ST(U32, a, j, s0[r][g]); HC_ST(U32, a + comp, j, s1[r][g]); }
     }
 }
 template <int R, int NB>
@@ -1960,8 +2013,10 @@ __global__ __launch_bounds__(HC_TPB, HC_MACM_WAVES) void hc_k_ks_mac_multi(HcKey
                                                             int nl, int nq, int nt, int alpha, int beta, int n, int pk) {
     const int T = blockIdx.y;
     const HcMod m = mods[T < nl ? T : nq + (T - nl)];
-    if (pk && HC_SMALL_Q(m.q)) hc_ks_mac_multi_digit<R, NB, true>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n);          // block-uniform
-    else hc_ks_mac_multi_digit<R, NB, false>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n);
+    const bool small = HC_SMALL_Q(m.q);                                      // block-uniform
+    if (pk && small && m.row32) hc_ks_mac_multi_digit<R, NB, true, true>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n);
+    else if (pk && small) hc_ks_mac_multi_digit<R, NB, true, false>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n);
+    else hc_ks_mac_multi_digit<R, NB, false, false>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n);
 }
 // ModDown's last step and evaluator.permuteNTT's tail in one pass (rotations: the key-switched polynomials never reach HBM unpermuted):
 //   out_0[l][i] = ((acc_0 - ext_0) * P^-1 + c0)[l][src(i)],  out_1[l][i] = ((acc_1 - ext_1) * P^-1)[l][src(i)],  src = PermuteNTTIndex(g)
@@ -1970,29 +2025,37 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_ks_moddown_rotate_mm(const u64 *a
     const int l = blockIdx.y, k = blockIdx.z & 1; const size_t img = blockIdx.z >> 1; const u64 q = mods[l].q; const HcTw pi = pinv[l];
     const size_t base = (size_t)l * 65536;
     const u64 *a = acc + img * acc_is + (size_t)k * acc_zs + base, *x = ext + img * ext_is + (size_t)k * ext_zs + base;
-    u64 *o = (k ? o1 : o0) + img * d_is + base; c0 += img * d_is;
+    u64 *o = (k ? o1 : o0) + img * d_is + base; c0 += img * d_is + base;
+    auto body = [&](auto s32c) {
+    constexpr bool S32 = decltype(s32c)::value;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
         const u32 s = hc_perm_src((u32)j, g);
-        u64 r = hc_mul_shoup(hc_submod(a[s], x[s], q), pi.w, pi.ws, q);
-        if (k == 0) r = hc_addmod(r, c0[base + s], q);
-        o[j] = r;
+        u64 r = hc_mul_shoup(hc_submod(HC_LD(S32, a, s), HC_LD(S32, x, s), q), pi.w, pi.ws, q);
+        if (k == 0) r = hc_addmod(r, HC_LD(S32, c0, s), q);
+        HC_ST(S32, o, j, r);
     }
+    };
+    HC_ROW_DISPATCH(mods[l].row32, body);
 }
 // One rotation of a linear transform in the extended basis (rotateHoistedNoModDown / the giant step's SwitchKeysInPlaceNoModDown + permutation of
 // MultiplyByDiagMatrixBSGS): out[k][T][i] (+)= (acc[k][T] + [k == 0, T < nl] pc0[T])[src(i)], src = PermuteNTTIndex(g). acc = the inner product
 // [2][nt][N] per image, pc0 = P * c0 (nl rows; null: nothing added), accumulate: added to what out holds. grid = (32, nt, 2 * images)
 __global__ __launch_bounds__(HC_TPB) void hc_k_qp_rotate_finish(const u64 *acc, size_t acc_is, const u64 *pc0, size_t pc0_is, u64 *out, size_t out_is, const HcMod *mods, int nl, int nq, int nt, u32 g, int accumulate) {
-    const int T = blockIdx.y, k = blockIdx.z & 1; const size_t img = blockIdx.z >> 1; const u64 q = mods[T < nl ? T : nq + (T - nl)].q;
+    const int T = blockIdx.y, k = blockIdx.z & 1; const size_t img = blockIdx.z >> 1; const HcMod &mm = mods[T < nl ? T : nq + (T - nl)]; const u64 q = mm.q;
     const size_t row = ((size_t)k * nt + T) * 65536;
     const u64 *a = acc + img * acc_is + row, *p = (k == 0 && T < nl && pc0 != nullptr) ? pc0 + img * pc0_is + (size_t)T * 65536 : nullptr;
     u64 *o = out + img * out_is + row;
+    auto body = [&](auto s32c) {
+    constexpr bool S32 = decltype(s32c)::value;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
         const u32 s = hc_perm_src((u32)j, g);
-        u64 r = a[s];
-        if (p != nullptr) r = hc_addmod(r, p[s], q);
-        if (accumulate) r = hc_addmod(o[j], r, q);
-        o[j] = r;
+        u64 r = HC_LD(S32, a, s);
+        if (p != nullptr) r = hc_addmod(r, HC_LD(S32, p, s), q);
+        if (accumulate) r = hc_addmod(HC_LD(S32, o, j), r, q);
+        HC_ST(S32, o, j, r);
     }
+    };
+    HC_ROW_DISPATCH(mm.row32, body);
 }
 // The diagonal sum of one giant step of a linear transform (MultiplyByDiagMatrixBSGS: MulCoeffsMontgomery(AndAdd) of the hoisted rotations with the encoded
 // diagonals) in ONE launch: out[k][T] (+)= sum over t < nterms of a_t[k][T] (*) pt_t[T] over all 2 (level+1+np) rows of the extended basis, for every image of the
@@ -2004,24 +2067,28 @@ struct HcTermPtrs { const u64 *a[HC_MAXTERMS]; const u64 *pt[HC_MAXTERMS]; };
 __global__ __launch_bounds__(HC_TPB) void hc_k_qp_mul_sum(HcTermPtrs P, int nterms, u64 *out, const HcMod *mods, int nlq, int nqt, int nt, int n, size_t a_is, size_t o_is, int accumulate) {
     const int row = blockIdx.y, k = blockIdx.z; const HcMod m = mods[row < nlq ? row : nqt + (row - nlq)];
     const size_t base = (size_t)row * 65536, comp = (size_t)k * nt * 65536;
+    auto body = [&](auto s32c) {
+    constexpr bool S32 = decltype(s32c)::value;
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
         u128 T[HC_MAXIMG]; u64 s[HC_MAXIMG];
 #pragma unroll
-        for (int g = 0; g < HC_MAXIMG; g++) s[g] = (accumulate && g < n) ? out[(size_t)g * o_is + comp + base + i] : 0;
+        for (int g = 0; g < HC_MAXIMG; g++) s[g] = (accumulate && g < n) ? HC_LD(S32, out + (size_t)g * o_is + comp + base, i) : 0;
         for (int t = 0; t < nterms; t++) {
-            const u64 y = hc_mont(P.pt[t][base + i], m.r2, m.q, m.qinv);           // MForm, once for all images
-            const u64 *a = P.a[t] + comp + base + i;
+            const u64 y = hc_mont(HC_LD(S32, P.pt[t] + base, i), m.r2, m.q, m.qinv);           // MForm, once for all images
+            const u64 *a = P.a[t] + comp + base;
             const int ph = t % 7;
 #pragma unroll
             for (int g = 0; g < HC_MAXIMG; g++) if (g < n) {
-                const u128 p = (u128)a[(size_t)g * a_is] * y;
+                const u128 p = (u128)HC_LD(S32, a + (size_t)g * a_is, i) * y;
                 T[g] = ph == 0 ? p : T[g] + p;
                 if (ph == 6 || t + 1 == nterms) s[g] = hc_addmod(s[g], hc_mont_redc(T[g], m.q, m.qinv), m.q);
             }
         }
 #pragma unroll
-        for (int g = 0; g < HC_MAXIMG; g++) if (g < n) out[(size_t)g * o_is + comp + base + i] = s[g];
+        for (int g = 0; g < HC_MAXIMG; g++) if (g < n) HC_ST(S32, out + (size_t)g * o_is + comp + base, i, s[g]);
     }
+    };
+    HC_ROW_DISPATCH(m.row32, body);
 }
 // SEVERAL (G <= 4) giant steps' sums from ONE read of the rotations: out_h (+)= sum_t a_t (*) pt_h,t, h < G, over the union of their baby steps (pt_h,t null where giant step h
 // has no diagonal for baby step t). hc_k_qp_mul_sum reads every rotated ciphertext once per giant step - 1.9 GB per launch at 8 images on the top level, not cache-resident,
@@ -2033,21 +2100,23 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_qp_mul_sum_g(HcTermPtrsG P, int n
     const int row = blockIdx.y, k = blockIdx.z & 1, g0 = (int)(blockIdx.z >> 1) * NB; const HcMod m = mods[row < nlq ? row : nqt + (row - nlq)];
     const size_t prow = (size_t)row * 65536, base = prow + (size_t)k * nt * 65536;
     n = n - g0 < NB ? n - g0 : NB;
+    auto body = [&](auto s32c) {
+    constexpr bool S32 = decltype(s32c)::value;
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
         u128 T[G][NB]; u64 s[G][NB];
 #pragma unroll
         for (int h = 0; h < G; h++)
 #pragma unroll
-            for (int g = 0; g < NB; g++) s[h][g] = (P.acc[h] && g < n) ? P.out[h][(size_t)(g0 + g) * o_is + base + i] : 0;
+            for (int g = 0; g < NB; g++) s[h][g] = (P.acc[h] && g < n) ? HC_LD(S32, P.out[h] + (size_t)(g0 + g) * o_is + base, i) : 0;
         for (int t = 0; t < nterms; t++) {
             u64 y[G];
 #pragma unroll
-            for (int h = 0; h < G; h++) y[h] = P.pt[h][t] != nullptr ? hc_mont(P.pt[h][t][prow + i], m.r2, m.q, m.qinv) : 0;      // MForm, once for all images; 0 = no diagonal (uniform)
-            const u64 *a = P.a[t] + (size_t)g0 * a_is + base + i;
+            for (int h = 0; h < G; h++) y[h] = P.pt[h][t] != nullptr ? hc_mont(HC_LD(S32, P.pt[h][t] + prow, i), m.r2, m.q, m.qinv) : 0;      // MForm, once for all images; 0 = no diagonal (uniform)
+            const u64 *a = P.a[t] + (size_t)g0 * a_is + base;
             const int ph = t % 7;
 #pragma unroll
             for (int g = 0; g < NB; g++) if (g < n) {
-                const u64 x = a[(size_t)g * a_is];
+                const u64 x = HC_LD(S32, a + (size_t)g * a_is, i);
 #pragma unroll
                 for (int h = 0; h < G; h++) {
                     if (ph == 0) T[h][g] = 0;
@@ -2059,8 +2128,10 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_qp_mul_sum_g(HcTermPtrsG P, int n
 #pragma unroll
         for (int h = 0; h < G; h++)
 #pragma unroll
-            for (int g = 0; g < NB; g++) if (g < n) P.out[h][(size_t)(g0 + g) * o_is + base + i] = s[h][g];
+            for (int g = 0; g < NB; g++) if (g < n) HC_ST(S32, P.out[h] + (size_t)(g0 + g) * o_is + base, i, s[h][g]);
     }
+    };
+    HC_ROW_DISPATCH(m.row32, body);
 }
 // In-place conversion of rows to the 4-byte form (hc_ld32): one workgroup per row of the grid (blockIdx.x = row, `rows` rows `stride` words apart... consecutive), rows whose modulus
 // mods[modidx[row % period]] is at least 2^31 are left alone. A chunk of 4096 words is read by the whole workgroup before any of its 4-byte words is written: the words written
@@ -2222,7 +2293,8 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_slots_round(const HcCplx *w, u64 
                 int e2; const double mant = frexp(x + 0.5, &e2); const u64 mi = (u64)ldexp(mant, 53); r = mi % q;
                 for (int sft = 0; sft < e2 - 53; sft++) { r += r; if (r >= q) r -= q; }
             } else r = (u64)(x + 0.5) % q;
-            o[(size_t)l * 65536 + i] = neg ? q - r : r;          // q itself when r == 0, as scaleUpVecExact leaves it (the NTT maps it to the same row as 0)
+            const u64 vv = neg ? q - r : r;                     // q itself when r == 0, as scaleUpVecExact leaves it (the NTT maps it to the same row as 0)
+            if (mods[l].row32) hc_st32(o + (size_t)l * 65536, (size_t)i, vv); else o[(size_t)l * 65536 + i] = vv;
         }
     }
 }

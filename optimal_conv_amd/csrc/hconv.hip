@@ -134,7 +134,8 @@ struct hc_ctx {
     long small_levels = 16;               // pack-tree launches of at most this many nodes (summed over the batch) run on the 1024-thread S kernels; 0 = never
     long peer_access = 1;                 // hc_conv_then_pack_sharded: enable direct peer copies between distinct devices (0: leave the copies to hipMemcpyPeerAsync's staging)
     int xcd_rows = 1;                     // XCD-aware 1-D grid of the rows passes (HcMm::xcd; 0 = the plain 3-D grid, kept for A/B builds)
-    int pack32 = 1;                       // library-internal rows of moduli below 2^31 as 4-byte words (hc_kernels.h hc_ld32): transform seams, extended digits, switching keys. HCONV_PACK32=0 at hc_ctx_create turns it off (A/B)
+    int pack32 = 1;                       // 1: library-internal rows of moduli below 2^31 as 4-byte words (hc_kernels.h hc_ld32): transform seams, extended digits, switching keys. 2: the rows of the caller's leveled
+                                          // operands as well (include/hconv.h "4-byte rows"; option pack32 or HCONV_PACK32=2 at hc_ctx_create). 0: off (A/B)
     unsigned peer_warned = 0;             // bit d: enabling peer access to device d failed and was reported once
     unsigned peer_enabled = 0;            // bit d: peer access from this context's device to device d was enabled by (or found enabled for) this context
     long profile = 0;
@@ -316,7 +317,7 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
         return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: HIP device %d not available (%d devices) - this library has no CPU path", device, ndev);
     hc_ctx *c = new hc_ctx();
     c->device = device; c->nq = nq; c->np = np;
-    { const char *pk = getenv("HCONV_PACK32"); if (pk && *pk) c->pack32 = atoi(pk) ? 1 : 0; }
+    { const char *pk = getenv("HCONV_PACK32"); if (pk && *pk) { const int v = atoi(pk); c->pack32 = v <= 0 ? 0 : v >= 2 ? 2 : 1; } }
     { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa ? (atoi(aa) == 2 ? 2 : (atoi(aa) ? 1 : 0)) : 0; }
     hipError_t se = hipSetDevice(device);
     if (se == hipSuccess) se = c->async_alloc ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipStreamCreate(&c->stream);
@@ -337,6 +338,7 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
         mh.m.r2 = h_mulmod(r, r, qi);
         mh.m.ninv = h_inv(HC_N, qi); mh.m.ninv_s = h_shoup(mh.m.ninv, qi);
         mh.m.mu = (u64)((((u128)1) << 64) / qi);
+        mh.m.row32 = (c->pack32 == 2 && qi < (1ull << 31)) ? 1 : 0;
         u64 g = h_primitive_root(qi), power = (qi - 1) / (2ull * HC_N);
         mh.psi = h_powmod(g, power, qi); mh.psi_inv = h_powmod(g, (qi - 1) - power, qi);
         int rc = hc_build_tables(c, &mh, false); if (!rc) rc = hc_build_tables(c, &mh, true);
@@ -509,13 +511,13 @@ extern "C" int hc_lv_permute(hc_ctx *c, uint64_t galEl, int level, const uint64_
     HC_ENTER(c);
     if (level < 0 || level >= c->nq || !in || !out || in == out || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_lv_permute: bad arguments (in/out must differ, galEl odd)");
     HC_TRY(hc_batch_fits(c, "hc_lv_permute", level, false));
-    return hc_launch(c, "permute", hc_k_permute_mm, dim3(HC_GX_LV, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), c->bs_poly);
+    return hc_launch(c, "permute", hc_k_permute_mm, dim3(HC_GX_LV, (unsigned)(level + 1), (unsigned)c->nb), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), c->bs_poly, (const HcMod *)c->d_mods, level + 1, c->nq, level + 1);
 }
 extern "C" int hc_qp_permute2(hc_ctx *c, uint64_t galEl, int level, const uint64_t *in, uint64_t *out) {
     HC_ENTER(c);
     if (level < 0 || level >= c->nq || c->np < 1 || !in || !out || in == out || !(galEl & 1)) return hc_fail(c, HC_ERR_ARG, "hc_qp_permute2: bad arguments (in/out must differ, galEl odd)");
     HC_TRY(hc_batch_fits(c, "hc_qp_permute2", level, true));
-    return hc_launch(c, "permute", hc_k_permute_mm, dim3(HC_GX_LV, 2u * (unsigned)(level + 1 + c->np), (unsigned)c->nb), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), c->bs_qp);
+    return hc_launch(c, "permute", hc_k_permute_mm, dim3(HC_GX_LV, 2u * (unsigned)(level + 1 + c->np), (unsigned)c->nb), (const u64 *)in, (u64 *)out, (u32)(galEl & 0x1FFFF), c->bs_qp, (const HcMod *)c->d_mods, level + 1, c->nq, level + 1 + c->np);
 }
 // Image batch of the leveled evaluator (include/hconv.h): n images per launch, the images of an operand stride words apart
 extern "C" int hc_set_batch(hc_ctx *c, int n, size_t poly_stride_words, size_t qp_stride_words) {
@@ -585,7 +587,8 @@ extern "C" int hc_lv_add_const(hc_ctx *c, int level, const uint64_t *a, const ui
 // fuse: optional prologue of the first pass (lift_level: Rescale's lift of t, see HcMm) and epilogue of the second (epi_x: (x - result) * epi_mul (+ epi_add))
 struct HcMmFuse { const HcBasisExt *ext_bs = nullptr; int ext_rows = 0; int lift_level = 0; const u64 *epi_x = nullptr; size_t epi_x_zs = 0, epi_x_is = 0; const HcTw *epi_mul = nullptr; const u64 *epi_add = nullptr; size_t epi_add_zs = 0, epi_add_is = 0;
                   const u64 *lift_t = nullptr; size_t lift_t_zs = 0, lift_t_is = 0; const HcTw *lift_pmul = nullptr, *epi_add_mul = nullptr;      // lift_t: ModDown + Rescale in one transform (HcMm)
-                  bool out_packed = false; };      // out is a library-internal array read only by kernels that expect 4-byte rows for the small moduli (the digits of a key switch)
+                  bool out_packed = false;       // out is a library-internal array read only by kernels that expect 4-byte rows for the small moduli (the digits of a key switch)
+                  bool raw = false; };           // in / out are plain 8-byte rows whatever the context's pack32 (the rows of a switching key while it is being generated)
 static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int skip_lo, int skip_hi, int z, size_t zs_in, size_t zs_out, int z_alpha = 0, int n = 1, size_t is_in = 0, size_t is_out = 0, const char *tag = "ntt",
                      const HcMmFuse *fuse = nullptr) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
@@ -602,19 +605,21 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
     // the extension's operand registers are sized by the most source limbs a digit / ModDown can have: the context's number of special primes (hc_basis_ext_tile)
 #define HC_COLS_EXT(E) (!HC_EXT_NS ? hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 8>, grid, in, c->ws_tmp, A) : c->np <= 2 ? hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 2>, grid, in, c->ws_tmp, A) : c->np <= 5 ? hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 5>, grid, in, c->ws_tmp, A) \
                         : hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 8>, grid, in, c->ws_tmp, A))
-    A.pk_out = c->pack32;                                                    // the seam between the two passes (ws_tmp) never leaves the library
+    const bool user32 = c->pack32 == 2 && !(fuse && fuse->raw);              // pack32 = 2: the caller's polynomials (a plain input, the output, the epilogue's operands) carry 4-byte rows too
+    A.pk_in = user32; A.pk_out = c->pack32;                                  // the seam between the two passes (ws_tmp) never leaves the library
     if (A.ext_bs && A.lift_t) HC_TRY(HC_COLS_EXT(2));
     else if (A.ext_bs) HC_TRY(HC_COLS_EXT(1));
     else HC_TRY(hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<0>, grid, in, c->ws_tmp, A));
 #undef HC_COLS_EXT
     A.lift_level = 0; A.ext_bs = nullptr; A.lift_t = nullptr; A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out;
-    A.pk_in = c->pack32; A.pk_out = (c->pack32 && fuse && fuse->out_packed) ? 1 : 0;
+    A.pk_in = c->pack32; A.pk_out = ((c->pack32 && fuse && fuse->out_packed) || user32) ? 1 : 0; A.pk_epi = user32;
     if (fuse && fuse->epi_x) { A.epi_x = fuse->epi_x; A.epi_x_zs = fuse->epi_x_zs; A.epi_x_is = fuse->epi_x_is; A.epi_mul = fuse->epi_mul; A.epi_add = fuse->epi_add; A.epi_add_zs = fuse->epi_add_zs; A.epi_add_is = fuse->epi_add_is; A.epi_add_mul = fuse->epi_add_mul; }
     A.xcd = c->xcd_rows; A.nzn = z * n;
     HC_TRY(hc_launch(c, c->profile ? n2 : "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, A.xcd ? dim3(16u * (unsigned)rows * (unsigned)(z * n)) : grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
-static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out, int skip_lo = 0, int skip_hi = 0, int n = 1, size_t is_in = 0, size_t is_out = 0, const char *tag = "intt") {
+// out_user: out is a polynomial of the caller's (hc_lv_intt), not one of the library's coefficient-domain scratch arrays (which keep 8-byte rows under every pack32)
+static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out, int skip_lo = 0, int skip_hi = 0, int n = 1, size_t is_in = 0, size_t is_out = 0, const char *tag = "intt", bool out_user = false) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
     HcMm A; memset(&A, 0, sizeof A); A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = 0; A.nz = z;
     char n1[48], n2[48]; snprintf(n1, sizeof n1, "%s:rows_inv_mm", tag); snprintf(n2, sizeof n2, "%s:cols_inv_canon_mm", tag);
@@ -624,9 +629,9 @@ static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int 
     for (int y = 0; y < rows; y++) if (!(y >= skip_lo && y < skip_hi)) A.rowlist[cnt++] = (unsigned char)y;
     const dim3 grid(16, (unsigned)cnt, (unsigned)(z * n));
     A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; A.xcd = c->xcd_rows; A.nzn = z * n;
-    A.pk_out = c->pack32;                                                    // the seam (ws_tmp)
+    A.pk_in = c->pack32 == 2; A.pk_out = c->pack32;                          // the caller's NTT-domain rows; the seam (ws_tmp)
     HC_TRY(hc_launch(c, c->profile ? n1 : "rows_inv_mm", hc_k_rows_inv_mm, A.xcd ? dim3(16u * (unsigned)cnt * (unsigned)(z * n)) : grid, in, c->ws_tmp, A));
-    A.xcd = 0; A.pk_in = c->pack32; A.pk_out = 0;
+    A.xcd = 0; A.pk_in = c->pack32; A.pk_out = (c->pack32 == 2 && out_user) ? 1 : 0;
     A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out; HC_TRY(hc_launch(c, c->profile ? n2 : "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
@@ -645,7 +650,7 @@ extern "C" int hc_lv_ntt(hc_ctx *c, int level, const uint64_t *in, uint64_t *out
 }
 extern "C" int hc_lv_intt(hc_ctx *c, int level, const uint64_t *in, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_intt", level, in, out));
-    return hc_intt_mm(c, in, out, level + 1, level + 1, 1, 0, 0, 0, 0, c->nb, c->bs_poly, c->bs_poly);
+    return hc_intt_mm(c, in, out, level + 1, level + 1, 1, 0, 0, 0, 0, c->nb, c->bs_poly, c->bs_poly, "intt", true);
 }
 extern "C" int hc_lv_mul_tensor(hc_ctx *c, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *d0, uint64_t *d1, uint64_t *d2) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mul_tensor", level, a0, d0));
@@ -1205,7 +1210,8 @@ static int hc_swk_generate_impl(hc_ctx *c, uint64_t key_id, int level, uint64_t 
     const dim3 grid(64, (unsigned)nt, (unsigned)beta);
     HC_TRY(hc_launch(c, "swk_sample", hc_k_swk_sample, grid, k.rows, (const HcMod *)c->d_mods, G));
     c->hoist_cx = nullptr;
-    HC_TRY(hc_ntt_mm(c, k.rows, k.rows, nt, nl, 0, 0, beta, (size_t)2 * nt * HC_N, (size_t)2 * nt * HC_N));      // the e rows (component 0 of every digit), all limbs
+    { HcMmFuse Fraw; Fraw.raw = true;                                                                          // key rows are 8-byte words until hc_k_pack32_rows below
+      HC_TRY(hc_ntt_mm(c, k.rows, k.rows, nt, nl, 0, 0, beta, (size_t)2 * nt * HC_N, (size_t)2 * nt * HC_N, 0, 1, 0, 0, "ntt", &Fraw)); }      // the e rows (component 0 of every digit), all limbs
     HC_TRY(hc_launch(c, "swk_finish", hc_k_swk_finish, grid, k.rows, (const u64 *)sk_ntt, (const HcMod *)c->d_mods, (const HcTw *)pm, G));
     if (c->pack32) HC_TRY(hc_launch(c, "pack32_rows", hc_k_pack32_rows, dim3((unsigned)(beta * 2 * nt)), k.rows, (const HcMod *)c->d_mods, nl, c->nq, nt));
     HC_HIP(c, hipStreamSynchronize(c->stream));
@@ -1768,6 +1774,7 @@ extern "C" int hc_encode_slots(hc_ctx *c, double *values, int count, int level, 
 extern "C" int hc_lv_mul_sum(hc_ctx *c, int level, const uint64_t *const *cts, const uint64_t *pts, int ntaps, uint64_t *out) {
     HC_ENTER(c);
     if (!cts || !pts || !out || ntaps < 1 || ntaps > HC_MAXTAPS || level < 0 || level >= c->nq) return hc_fail(c, HC_ERR_ARG, "hc_lv_mul_sum: bad arguments (1 <= ntaps <= %d)", HC_MAXTAPS);
+    if (c->pack32 == 2) return hc_fail(c, HC_ERR_UNSUPPORTED, "hc_lv_mul_sum: the baseline's tap sum reads 8-byte rows only (option pack32 = 2 is for the bootstrapping chain's contexts)");
     HcTapPtrs T; memset(&T, 0, sizeof T);
     for (int t = 0; t < ntaps; t++) { if (!cts[t]) return hc_fail(c, HC_ERR_ARG, "hc_lv_mul_sum: null ciphertext %d", t); T.ct[t] = (const u64 *)cts[t]; }
     return hc_launch(c, "lv_mul_sum", hc_k_lv_mul_sum, dim3(64, (unsigned)(level + 1), 2), T, (const u64 *)pts, ntaps, level + 1, (u64 *)out, (const HcMod *)c->d_mods);
@@ -1779,12 +1786,25 @@ extern "C" int hc_bl_post_ker_slots(hc_ctx *c, const double *max_ker_rs, int in_
 }
 
 // ------------------------------------------------------------------ options / timing
+extern "C" int hc_row_is32(hc_ctx *c, int mod) {
+    if (!c || mod < 0 || mod >= c->nq + c->np) return 0;
+    return c->mods[(size_t)mod].m.row32 ? 1 : 0;
+}
 extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!c || !name) return HC_ERR_ARG;
     if (!strcmp(name, "chunk_nodes")) { if (value < 1) return hc_fail(c, HC_ERR_ARG, "chunk_nodes must be >= 1"); c->chunk_nodes = value; return HC_OK; }
     if (!strcmp(name, "small_levels")) { if (value < 0) return hc_fail(c, HC_ERR_ARG, "small_levels must be >= 0"); c->small_levels = value; return HC_OK; }
     if (!strcmp(name, "peer_access")) { c->peer_access = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
+    if (!strcmp(name, "pack32")) {          // 0 / 1 / 2 (include/hconv.h "4-byte rows"). Switching keys are stored per the setting in force when they are loaded or generated: 0 <-> 1, 2 only on a context without keys
+        if (value < 0 || value > 2) return hc_fail(c, HC_ERR_ARG, "pack32 must be 0, 1 or 2");
+        if (((value == 0) != (c->pack32 == 0)) && !c->swk.empty()) return hc_fail(c, HC_ERR_STATE, "pack32: switching keys are already stored in the other form");
+        HC_ENTER(c); HC_HIP(c, hipStreamSynchronize(c->stream));
+        c->pack32 = (int)value; c->hoist_cx = nullptr;
+        std::vector<HcMod> hm; for (auto &mh : c->mods) { mh.m.row32 = (value == 2 && mh.m.q < (1ull << 31)) ? 1 : 0; hm.push_back(mh.m); }
+        HC_HIP(c, hcx_h2d(c, c->d_mods, hm.data(), hm.size() * sizeof(HcMod)));
+        return HC_OK;
+    }
     return hc_fail(c, HC_ERR_ARG, "unknown option %s", name);
 }
 extern "C" int hc_timer_start(hc_ctx *c) { HC_ENTER(c); HC_HIP(c, hipEventRecord(c->t0, c->stream)); return HC_OK; }

@@ -106,6 +106,16 @@ struct Boot {
     size_t poly_stride() const { return (size_t)NQ * N; }
     size_t qp_stride() const { return (size_t)2 * (NQ + P.size()) * N; }
     void set_nb(int n) { if (n < 1 || n > nb_max) panic("image batch out of range"); nb = n; HCR(hc_set_batch(hc, n, poly_stride(), qp_stride())); }
+    // 4-byte rows (include/hconv.h, option pack32 = 2: the bootstrapping contexts run with it unless HCONV_PACK32 says otherwise): the rows of the ~30-bit limbs of every leveled
+    // operand on the device are N 4-byte words at the row's address. The host converts only where IT reads or writes such rows: rows[0 .. nl) <-> limbs 0 .. nl - 1 (rows beyond
+    // are special primes: large). Ciphertexts enter and leave the chain at levels 0 / 1 (large limbs), so the layers themselves convert nothing.
+    std::vector<char> row32;                                 // per limb: hc_row_is32
+    void pack_rows(std::vector<uint64_t> &rows, int nl) const {
+        for (int l = 0; l < nl && l < (int)row32.size(); l++) if (row32[(size_t)l]) { uint32_t *d = reinterpret_cast<uint32_t *>(&rows[(size_t)l * N]); for (int j = 0; j < N; j++) d[j] = (uint32_t)rows[(size_t)l * N + (size_t)j]; }
+    }
+    void unpack_rows(std::vector<uint64_t> &rows, int nl) const {
+        for (int l = 0; l < nl && l < (int)row32.size(); l++) if (row32[(size_t)l]) { const uint32_t *d = reinterpret_cast<const uint32_t *>(&rows[(size_t)l * N]); for (int j = N - 1; j >= 0; j--) rows[(size_t)l * N + (size_t)j] = d[j]; }
+    }
     struct Single {            // scope in which the ABI acts on ONE polynomial per call (encoding plaintexts, debugging)
         Boot *b; int saved;
         explicit Single(Boot *b_) : b(b_), saved(b_->nb) { if (saved != 1) b->set_nb(1); }
@@ -399,6 +409,7 @@ struct Boot {
         std::vector<uint64_t> rows = enc.Encode(slots, scale, Q.data(), level + 1);
         Single one(this);
         DPt pt; pt.level = level; pt.scale = scale; pt.p = block1();
+        pack_rows(rows, level + 1);
         HCR(hc_upload(hc, pt.p.get(), rows.data(), rows.size() * 8));
         HCR(hc_lv_ntt(hc, level, pt.p.get(), pt.p.get()));
         return pt;
@@ -418,6 +429,7 @@ struct Boot {
         Single one(this);
         DPt pt; pt.level = level; pt.scale = scale;
         { void *v = nullptr; HCR(hc_malloc(hc, rows.size() * 8, &v)); uint64_t *d = (uint64_t *)v; hc_ctx *h = hc; pt.p = std::shared_ptr<uint64_t>(d, [h](uint64_t *x) { hc_free(h, x); }); }
+        pack_rows(rows, nl);
         HCR(hc_upload(hc, pt.p.get(), rows.data(), rows.size() * 8));
         HCR(hc_lv_ntt(hc, level, pt.p.get(), pt.p.get()));
         for (int j = 0; j < np; j++) { uint64_t *r = pt.p.get() + (size_t)(nl + j) * N; HCR(hc_ntt(hc, NQ + j, r, r, 1)); }
@@ -578,6 +590,7 @@ struct Boot {
                 Sha256 hv; hv.update(rolled.data(), rolled.size() * sizeof(cplx));
                 std::vector<uint64_t> rows((size_t)(level + 1) * N), zero((size_t)N, 0);
                 HCR(hc_download(hc, rows.data(), lt.giant[g][b].p.get(), rows.size() * 8));
+                unpack_rows(rows, level + 1);
                 for (int l = 0; l <= level; l++) { const uint64_t q = Q[(size_t)l], r = (uint64_t)((((u128)1) << 64) % q); for (int j = 0; j < N; j++) rows[(size_t)l * N + j] = mulmod(rows[(size_t)l * N + j], r, q); }
                 Sha256 hq; hq.update(rows.data(), rows.size() * 8); hq.update(zero.data(), zero.size() * 8);
                 std::string mp = "";
@@ -937,6 +950,8 @@ struct Boot {
         if (chain == 7) { LV_STC_TOP = 15; stc_scale_top = sqrt((double)Q[15]); stc_scale_last = 1073741824.0; lv_relin_lo = 2; }
         else { LV_STC_TOP = 3; stc_scale_top = sqrt((double)Q[3]); stc_scale_last = 1073741824.0; lv_relin_lo = LV_RELU_TOP - 11; }
         if (hc_ctx_create(&hc, LOGN, Q.data(), NQ, P.data(), (int)P.size(), device)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
+        if (!getenv("HCONV_PACK32")) HCR(hc_set_option(hc, "pack32", 2));             // 4-byte rows for the ~30-bit limbs of every leveled operand (HCONV_PACK32=0 / 1: A/B against the 8-byte forms)
+        row32.assign((size_t)NQ, 0); for (int l = 0; l < NQ; l++) row32[(size_t)l] = (char)hc_row_is32(hc, l);
         const int nm = NQ + (int)P.size();
         { void *v = nullptr; HCR(hc_malloc(hc, (size_t)nm * N * 8, &v)); d_sk = (uint64_t *)v; }
         std::vector<uint64_t> h((size_t)N);
@@ -946,7 +961,7 @@ struct Boot {
             HCR(hc_upload(hc, d_sk + (size_t)m * N, h.data(), (size_t)N * 8)); HCR(hc_ntt(hc, m, d_sk + (size_t)m * N, d_sk + (size_t)m * N, 1));
         }
         mono_i = block1();
-        { std::vector<uint64_t> m((size_t)NQ * N, 0); for (int l = 0; l < NQ; l++) m[(size_t)l * N + N / 2] = 1; HCR(hc_upload(hc, mono_i.get(), m.data(), m.size() * 8)); HCR(hc_lv_ntt(hc, NQ - 1, mono_i.get(), mono_i.get())); }
+        { std::vector<uint64_t> m((size_t)NQ * N, 0); for (int l = 0; l < NQ; l++) m[(size_t)l * N + N / 2] = 1; pack_rows(m, NQ); HCR(hc_upload(hc, mono_i.get(), m.data(), m.size() * 8)); HCR(hc_lv_ntt(hc, NQ - 1, mono_i.get(), mono_i.get())); }
         // Chebyshev interpolant of cos(2 pi (K u - 1/4) / 2^r) on [-1,1]
         const int m = SIN_DEG + 1; sine.assign((size_t)m, 0.0);
         for (int j = 0; j < m; j++) {
@@ -1266,7 +1281,7 @@ static void replay_digest_line(Boot *B, const char *what, const DCt &c, int firs
         const int img = first_image + z;
         std::string line = std::string("replay digest") + (img ? "[" + std::to_string(img) + "] " : " ") + what + " level " + std::to_string(c.level);
         char sc[40]; snprintf(sc, sizeof sc, " scale %.17g", c.scale); line += sc;
-        for (int d = 0; d <= c.deg; d++) { std::vector<uint64_t> rows((size_t)(c.level + 1) * N); HCR(hc_download(hc, rows.data(), c.p[d].get() + (size_t)z * B->poly_stride(), rows.size() * 8)); Sha256 h; h.update(rows.data(), rows.size() * 8); line += " " + h.hex(); }
+        for (int d = 0; d <= c.deg; d++) { std::vector<uint64_t> rows((size_t)(c.level + 1) * N); HCR(hc_download(hc, rows.data(), c.p[d].get() + (size_t)z * B->poly_stride(), rows.size() * 8)); B->unpack_rows(rows, c.level + 1); Sha256 h; h.update(rows.data(), rows.size() * 8); line += " " + h.hex(); }
         printf("%s\n", line.c_str());
     }
 }
