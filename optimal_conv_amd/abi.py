@@ -228,6 +228,43 @@ class Context:
 
     def set_option(self, name, value):
         self._ck(self.L.hc_set_option(self.h, name.encode(), int(value)))
+        if name == "pack32":
+            self._row32 = None
+
+    # ---- 4-byte rows (include/hconv.h; option pack32 = 2): the numpy-in / numpy-out conveniences below convert at the boundary, as a binding must. `nl` = the Q rows per
+    # polynomial (rows nl .. per-1 of each group of `per` rows are special primes: large); row r of a group <-> limb r
+    def row32(self):
+        if getattr(self, "_row32", None) is None:
+            self._row32 = [bool(self.L.hc_row_is32(self.h, m)) for m in range(len(self.q))]
+        return self._row32
+
+    def pack_rows(self, arr, nl, per=None):
+        a = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, self.N).copy()
+        r32 = self.row32()
+        if not any(r32[:nl]):
+            return a.reshape(np.shape(arr))
+        per = per or nl
+        v = a.view(np.uint32).reshape(a.shape[0], 2 * self.N)
+        for r in range(a.shape[0]):
+            T = r % per
+            if T < nl and r32[T]:
+                low = (a[r] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+                v[r, : self.N] = low
+                v[r, self.N:] = 0xDEADBEEF          # the unused half of the slot: poisoned so that a kernel that reads 8-byte words there cannot pass
+        return a.reshape(np.shape(arr))
+
+    def unpack_rows(self, arr, nl, per=None):
+        a = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, self.N).copy()
+        r32 = self.row32()
+        if not any(r32[:nl]):
+            return a.reshape(np.shape(arr))
+        per = per or nl
+        v = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, self.N).view(np.uint32).reshape(a.shape[0], 2 * self.N)
+        for r in range(a.shape[0]):
+            T = r % per
+            if T < nl and r32[T]:
+                a[r] = v[r, : self.N].astype(np.uint64)
+        return a.reshape(np.shape(arr))
 
     # ---- L0, numpy in / numpy out convenience (each call uploads, runs, downloads) ----
     def _rows_op(self, fn, mod, *arrays, extra=()):
@@ -274,19 +311,19 @@ class Context:
 
     def div_round_last2(self, level, x0, x1):
         """both polynomials of a ciphertext in one set of launches (separate allocations, as the host side holds them)"""
-        srcs = [self.buf(np.ascontiguousarray(x, dtype=np.uint64).reshape(level + 1, self.N)) for x in (x0, x1)]
+        srcs = [self.buf(self.pack_rows(np.ascontiguousarray(x, dtype=np.uint64).reshape(level + 1, self.N), level + 1)) for x in (x0, x1)]
         dsts = [self.buf(nwords=level * self.N) for _ in range(2)]
         self._ck(self.L.hc_div_round_last2(self.h, level, srcs[0].ptr, srcs[1].ptr, dsts[0].ptr, dsts[1].ptr))
-        out = [d.download((level, self.N)) for d in dsts]
+        out = [self.unpack_rows(d.download((level, self.N)), level) for d in dsts]
         for b in srcs + dsts:
             b.free()
         return out
 
     def div_round_last(self, level, x):
-        x = np.ascontiguousarray(x, dtype=np.uint64).reshape(level + 1, self.N)
+        x = self.pack_rows(np.ascontiguousarray(x, dtype=np.uint64).reshape(level + 1, self.N), level + 1)
         src, dst = self.buf(x), self.buf(nwords=level * self.N)
         self._ck(self.L.hc_div_round_last(self.h, level, src.ptr, dst.ptr))
-        out = dst.download((level, self.N))
+        out = self.unpack_rows(dst.download((level, self.N)), level)
         src.free(); dst.free()
         return out
 
@@ -314,22 +351,22 @@ class Context:
         self._ck(self.L.hc_swk_load(self.h, C.c_uint64(key_id), level, _hp(rows.reshape(-1))))
 
     def keyswitch(self, key_id, level, cx):
-        cx = np.ascontiguousarray(cx, dtype=np.uint64).reshape(level + 1, self.N)
+        cx = self.pack_rows(np.ascontiguousarray(cx, dtype=np.uint64).reshape(level + 1, self.N), level + 1)
         src = self.buf(cx)
         d = self.buf(nwords=2 * (level + 1) * self.N)
         self._ck(self.L.hc_keyswitch(self.h, C.c_uint64(key_id), level, src.ptr, d.at(0), d.at((level + 1) * self.N)))
-        out = d.download((2, level + 1, self.N))
+        out = self.unpack_rows(d.download((2, level + 1, self.N)), level + 1)
         src.free(); d.free()
         return out[0], out[1]
 
     # ---- leveled polynomials: arrays of shape (level+1, N), row l modulo q_l
     def _lv(self, fn, level, *arrays, consts=None, out_rows=None):
         arrays = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, self.N) for a in arrays]
-        bufs = [self.buf(a) for a in arrays]
+        bufs = [self.buf(self.pack_rows(a, a.shape[0])) for a in arrays]
         out = self.buf(nwords=(out_rows or (level + 1)) * self.N)
         extra = () if consts is None else ((C.c_uint64 * (level + 1))(*[int(c) for c in consts]),)
         self._ck(fn(self.h, level, *[b.ptr for b in bufs], *extra, out.ptr))
-        res = out.download(((out_rows or (level + 1)), self.N))
+        res = self.unpack_rows(out.download(((out_rows or (level + 1)), self.N)), out_rows or (level + 1))
         for b in bufs + [out]:
             b.free()
         return res
@@ -340,39 +377,40 @@ class Context:
     def lv_add(self, level, a, b): return self._lv(self.L.hc_lv_add, level, a, b)
 
     def lv_mul_acc(self, level, a, b, acc):
-        A, B_, D = self.buf(np.ascontiguousarray(a, dtype=np.uint64)), self.buf(np.ascontiguousarray(b, dtype=np.uint64)), self.buf(np.ascontiguousarray(acc, dtype=np.uint64))
+        A, B_, D = [self.buf(self.pack_rows(np.ascontiguousarray(x, dtype=np.uint64).reshape(level + 1, self.N), level + 1)) for x in (a, b, acc)]
         self._ck(self.L.hc_lv_mul_acc(self.h, level, A.ptr, B_.ptr, D.ptr))
-        out = D.download((level + 1, self.N))
+        out = self.unpack_rows(D.download((level + 1, self.N)), level + 1)
         A.free(); B_.free(); D.free()
         return out
     def keyswitch_rotate(self, key_id, gal, level, c0, c1, hoisted=False):
-        b0, b1 = self.buf(np.ascontiguousarray(c0, dtype=np.uint64)), self.buf(np.ascontiguousarray(c1, dtype=np.uint64))
+        b0, b1 = [self.buf(self.pack_rows(np.ascontiguousarray(x, dtype=np.uint64).reshape(level + 1, self.N), level + 1)) for x in (c0, c1)]
         outs = [self.buf(nwords=(level + 1) * self.N) for _ in range(2)]
         if hoisted:
             self._ck(self.L.hc_keyswitch_decompose(self.h, level, b1.ptr))
         self._ck(self.L.hc_keyswitch_rotate(self.h, C.c_uint64(key_id), C.c_uint64(gal), level, b0.ptr, b1.ptr, outs[0].ptr, outs[1].ptr, 1 if hoisted else 0))
-        res = [o.download((level + 1, self.N)) for o in outs]
+        res = [self.unpack_rows(o.download((level + 1, self.N)), level + 1) for o in outs]
         for x in [b0, b1] + outs:
             x.free()
         return res
 
     def rotate_finish(self, gal, level, d0, d1, c0):
-        bufs = [self.buf(np.ascontiguousarray(x, dtype=np.uint64)) for x in (d0, d1, c0)]
+        bufs = [self.buf(self.pack_rows(np.ascontiguousarray(x, dtype=np.uint64).reshape(level + 1, self.N), level + 1)) for x in (d0, d1, c0)]
         outs = [self.buf(nwords=(level + 1) * self.N) for _ in range(2)]
         self._ck(self.L.hc_rotate_finish(self.h, C.c_uint64(gal), level, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, outs[0].ptr, outs[1].ptr))
-        res = [o.download((level + 1, self.N)) for o in outs]
+        res = [self.unpack_rows(o.download((level + 1, self.N)), level + 1) for o in outs]
         for x in bufs + outs:
             x.free()
         return res
 
     def lv_op2(self, op, level, a, b=None, out=None, consts=None, shared_b=False):
         """hc_lv_op2: a, b, out = (2, level+1, N) ciphertexts (b = (level+1, N) with shared_b: a plaintext operand); separate allocations per polynomial"""
-        A = [self.buf(np.ascontiguousarray(a[k], dtype=np.uint64)) for k in range(2)]
-        Bs = [] if b is None else ([self.buf(np.ascontiguousarray(b, dtype=np.uint64))] * 2 if shared_b else [self.buf(np.ascontiguousarray(b[k], dtype=np.uint64)) for k in range(2)])
-        O = [self.buf(np.ascontiguousarray(out[k], dtype=np.uint64)) if out is not None else self.buf(nwords=(level + 1) * self.N) for k in range(2)]
+        pk = lambda x: self.pack_rows(np.ascontiguousarray(x, dtype=np.uint64).reshape(level + 1, self.N), level + 1)
+        A = [self.buf(pk(a[k])) for k in range(2)]
+        Bs = [] if b is None else ([self.buf(pk(b))] * 2 if shared_b else [self.buf(pk(b[k])) for k in range(2)])
+        O = [self.buf(pk(out[k])) if out is not None else self.buf(nwords=(level + 1) * self.N) for k in range(2)]
         cs = (C.c_uint64 * (level + 1))(*[int(x) for x in consts]) if consts is not None else None
         self._ck(self.L.hc_lv_op2(self.h, op, level, A[0].ptr, A[1].ptr, Bs[0].ptr if Bs else None, Bs[1].ptr if Bs else None, O[0].ptr, O[1].ptr, cs))
-        res = np.stack([O[k].download((level + 1, self.N)) for k in range(2)])
+        res = np.stack([self.unpack_rows(O[k].download((level + 1, self.N)), level + 1) for k in range(2)])
         for x in A + O + (Bs[:1] if shared_b else Bs):
             x.free()
         return res
@@ -382,11 +420,11 @@ class Context:
     def lv_add_const(self, level, a, consts): return self._lv(self.L.hc_lv_add_const, level, a, consts=consts)
     def lv_mul_tensor(self, level, a, b):
         """a, b: (2, level+1, N) -> (d0, d1, d2)"""
-        A, B = self.buf(np.ascontiguousarray(a, dtype=np.uint64)), self.buf(np.ascontiguousarray(b, dtype=np.uint64))
+        A, B = [self.buf(self.pack_rows(np.ascontiguousarray(x, dtype=np.uint64).reshape(2, level + 1, self.N), level + 1)) for x in (a, b)]
         n = (level + 1) * self.N
         D = self.buf(nwords=3 * n)
         self._ck(self.L.hc_lv_mul_tensor(self.h, level, A.at(0), A.at(n), B.at(0), B.at(n), D.at(0), D.at(n), D.at(2 * n)))
-        out = D.download((3, level + 1, self.N))
+        out = self.unpack_rows(D.download((3, level + 1, self.N)), level + 1)
         A.free(); B.free(); D.free()
         return out[0], out[1], out[2]
 
@@ -395,7 +433,7 @@ class Context:
     # ---- the extended basis QP (rows Q_0..Q_level then P_0..P_(np-1)): the halves of the key switch and arithmetic between them
     def keyswitch_qp(self, key_ids, level, cx, hoisted=True):
         """SwitchKeysInPlaceNoModDown / KeyswitchHoistedNoModDown with every key in key_ids on one polynomial: [(2, level+1+np, N), ...]"""
-        cx = np.ascontiguousarray(cx, dtype=np.uint64).reshape(level + 1, self.N)
+        cx = self.pack_rows(np.ascontiguousarray(cx, dtype=np.uint64).reshape(level + 1, self.N), level + 1)
         nt = level + 1 + len(self.p)
         src, acc = self.buf(cx), self.buf(nwords=2 * nt * self.N)
         if hoisted:
@@ -403,42 +441,42 @@ class Context:
         outs = []
         for kid in key_ids:
             self._ck(self.L.hc_keyswitch_qp(self.h, C.c_uint64(kid), level, src.ptr, acc.ptr, 1 if hoisted else 0))
-            outs.append(acc.download((2, nt, self.N)).copy())
+            outs.append(self.unpack_rows(acc.download((2, nt, self.N)), level + 1, nt).copy())
         src.free(); acc.free()
         return outs
 
     def mod_down2(self, level, x):
         """ModDownSplitNTTPQ of the two polynomials x (2, level+1+np, N) -> (2, level+1, N)"""
         nt = level + 1 + len(self.p)
-        X = self.buf(np.ascontiguousarray(x, dtype=np.uint64).reshape(2, nt, self.N))
+        X = self.buf(self.pack_rows(np.ascontiguousarray(x, dtype=np.uint64).reshape(2, nt, self.N), level + 1, nt))
         O = self.buf(nwords=2 * (level + 1) * self.N)
         self._ck(self.L.hc_mod_down2(self.h, level, X.ptr, O.at(0), O.at((level + 1) * self.N)))
-        out = O.download((2, level + 1, self.N))
+        out = self.unpack_rows(O.download((2, level + 1, self.N)), level + 1)
         X.free(); O.free()
         return out
 
     def qp_op2(self, op, level, a, b, out=None, shared_b=False):
         """hc_qp_op2: a, out (2, nt, N); b (2, nt, N) or, with shared_b, one plaintext (nt, N)"""
         nt = level + 1 + len(self.p)
-        A = self.buf(np.ascontiguousarray(a, dtype=np.uint64).reshape(2, nt, self.N))
-        B_ = self.buf(np.ascontiguousarray(b, dtype=np.uint64))
-        O = self.buf(np.ascontiguousarray(out, dtype=np.uint64).reshape(2, nt, self.N)) if out is not None else self.buf(nwords=2 * nt * self.N)
+        A = self.buf(self.pack_rows(np.ascontiguousarray(a, dtype=np.uint64).reshape(2, nt, self.N), level + 1, nt))
+        B_ = self.buf(self.pack_rows(np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, nt, self.N), level + 1, nt))
+        O = self.buf(self.pack_rows(np.ascontiguousarray(out, dtype=np.uint64).reshape(2, nt, self.N), level + 1, nt)) if out is not None else self.buf(nwords=2 * nt * self.N)
         n = nt * self.N
         self._ck(self.L.hc_qp_op2(self.h, op, level, A.at(0), A.at(n), B_.at(0), B_.at(0 if shared_b else n), O.at(0), O.at(n)))
-        res = O.download((2, nt, self.N))
+        res = self.unpack_rows(O.download((2, nt, self.N)), level + 1, nt)
         A.free(); B_.free(); O.free()
         return res
 
     def keyswitch_hoisted(self, key_ids, level, cx):
         """one decomposition of cx, then the inner product + ModDown with every key in key_ids: [(d0, d1), ...]"""
-        cx = np.ascontiguousarray(cx, dtype=np.uint64).reshape(level + 1, self.N)
+        cx = self.pack_rows(np.ascontiguousarray(cx, dtype=np.uint64).reshape(level + 1, self.N), level + 1)
         src = self.buf(cx)
         d = self.buf(nwords=2 * (level + 1) * self.N)
         self._ck(self.L.hc_keyswitch_decompose(self.h, level, src.ptr))
         outs = []
         for kid in key_ids:
             self._ck(self.L.hc_keyswitch_hoisted(self.h, C.c_uint64(kid), level, src.ptr, d.at(0), d.at((level + 1) * self.N)))
-            o = d.download((2, level + 1, self.N))
+            o = self.unpack_rows(d.download((2, level + 1, self.N)), level + 1)
             outs.append((o[0].copy(), o[1].copy()))
         src.free(); d.free()
         return outs

@@ -177,11 +177,29 @@ __device__ __forceinline__ int hc_cols_lds(int row, int c) { return ((row ^ ((ro
 // GENERIC pointer and emitted flat_load_dwordx4 for every twiddle - 30 per thread and pass - which count against lgkmcnt as well as vmcnt and so tie every twiddle fetch to
 // the LDS exchange waits. The explicit address space makes them global_load_dwordx4 (round 5; the convolution's kernels receive HcTwTab by value and always had global loads).
 #if defined(__HIP_DEVICE_COMPILE__)
-typedef const HcTw __attribute__((address_space(1))) *HcTwGlobalPtr;
+typedef const HcTw __attribute__((address_space(4))) *HcTwGlobalPtr;
 #define HC_TW_LOAD(p, i) (*((HcTwGlobalPtr)(p) + (i)))
 #else
 #define HC_TW_LOAD(p, i) ((p)[i])
 #endif
+// Tables the kernels only read - twiddles, the per-modulus rows of HcRowMod, the extension's constants - are read through the CONSTANT address space: a load whose address is
+// uniform then goes through the scalar cache into SGPRs whatever else the kernel does. As global-memory loads they depend on the compiler proving that no store of the kernel
+// can reach them, and with the 32-bit and 64-bit bodies side by side (HC_S32) it stopped proving that for the second body: hc_k_cols_fwd_mm<1, 5> went from 267 s_load / 196
+// global_load to 30 / 596 - every constant fetched per lane into VGPRs - and lost 8 %. hc_const_copy: a table entry selected by blockIdx, copied into registers that way.
+template <class T>
+__device__ __forceinline__ T hc_const_copy(const T *p) {
+    T r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(T) % 8 == 0 && alignof(T) >= 8, "hc_const_copy: whole 8-byte words");
+    typedef const u64 __attribute__((address_space(4))) *W;                  // (word by word: a memcpy from the constant address space is lowered to vector loads)
+    const W src = (W)(const void *)p; u64 *dst = reinterpret_cast<u64 *>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 8; i++) dst[i] = src[i];
+#else
+    r = *p;
+#endif
+    return r;
+}
 struct HcRowsTwA { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return HC_TW_LOAD(p, slot); } };
 struct HcRowsTwB { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return HC_TW_LOAD(p, slot * 16); } };
 
@@ -278,7 +296,8 @@ __device__ __forceinline__ void hc_rows_lo_to_lin(u64 (&e)[16], u64 *lds, int t,
 #define HC_MM_WAVES 7                  // wavefronts per SIMD the multi-modulus transform kernels are compiled for (VGPR budget 512 / HC_MM_WAVES)
 #endif
 #ifndef HC_MM_WAVES_EXT
-#define HC_MM_WAVES_EXT 4              // the passes with the basis extension in their prologue: 120 VGPRs, no scratch (round 5: with the straight-line extension of full digits, hc_basis_ext_tile, 4 wavefronts beat 5 with 96 bytes of scratch: 18.85 vs 19.39 ms per ciphertext-layer; round 4's branchy form preferred 5 with 68 bytes of scratch)
+#define HC_MM_WAVES_EXT 5              // the passes with the basis extension in their prologue. Round 5, first half: the straight-line extension of full digits at 4 wavefronts (120 VGPRs) beat 5 with 96 bytes of scratch; since the tables' constants
+                                       // come through the constant address space into SGPRs (hc_const_copy) the kernels need 96-102 VGPRs: 5 wavefronts with 0 / 24 bytes of scratch, 16.93 vs 17.05 ms per ciphertext-layer
 #endif
 // measured (convReLU 5 1 tail, 8 images, profiles/round4_chain_occupancy_ab.txt): 8-byte exchange / 5 waves 189.5 ms; 4-byte exchange at 6 / 6 waves 183.2, 7 / 5 waves 166.7,
 // 7 / 4 180.8, 8 / 6 193.0 (spills), 7 / 7 with two-element extension groups 169.6
@@ -371,6 +390,101 @@ __device__ __forceinline__ void hc_rows_lo_to_lin(u64 (&e)[16], u32 *lds, int t,
 __device__ __forceinline__ u64 hc_barrett64(u64 x, u64 q, u64 mu) {
     u64 r = x - hc_mulhi(x, mu) * q;   // in [0, 2q)
     return hc_csub(r, q);
+}
+
+// ================================================================ 32-bit transforms for the limbs below 2^31 (round 5)
+// Eleven of the bootstrapping chain's 28 limbs are ~30-bit primes. Every instruction class these kernels are made of issues at one wave64 per 4 cycles whatever its width
+// (DESIGN.md section 5), so a butterfly costs its instruction count: 20-22 for the 64-bit lazy forms above, 12 for the canonical 32-bit form below - a Shoup product is
+// v_mul_hi_u32 + 2 v_mul_lo_u32 + a subtraction, every conditional correction is a subtraction and a v_min_u32 - and a thread's 16 residues take 16 registers, one LDS word
+// each (ONE exchange and barrier per pass instead of the two halves' three). The 32-bit companion of a table entry (w, w' = floor(w 2^64 / q)) is (low word of w, high word of
+// w'): floor(floor(w 2^64 / q) / 2^32) = floor(w 2^32 / q), so the 64-bit tables serve both forms. Everything is canonical, in and out: the same residues as the 64-bit
+// kernels, bit for bit. A workgroup takes this form as a WHOLE (its modulus is block-uniform): the 64-bit and 32-bit bodies share no live registers (round 4 switched per
+// butterfly inside one body and paid 108-132 VGPRs for 65-86: profiles/round4_chain_class_paths_ab.txt).
+#ifndef HC_S32
+#define HC_S32 1
+#endif
+struct HcTw32 { u32 w, ws; };
+__device__ __forceinline__ HcTw32 hc_tw32(const HcTw &t) { return HcTw32{(u32)t.w, (u32)(t.ws >> 32)}; }
+__device__ __forceinline__ u32 hc_umulhi32(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
+__device__ __forceinline__ u32 hc_min32(u32 a, u32 b) { return a < b ? a : b; }
+__device__ __forceinline__ u32 hc_csub32(u32 x, u32 q) { return hc_min32(x, x - q); }                         // [0,2q) -> [0,q): x - q wraps above x when x < q
+__device__ __forceinline__ u32 hc_add32(u32 a, u32 b, u32 q) { return hc_csub32(a + b, q); }                   // a, b < q < 2^31
+__device__ __forceinline__ u32 hc_sub32(u32 a, u32 b, u32 q) { const u32 d = a - b; return hc_min32(d, d + q); }   // a < b: d wraps to 2^32 - (b - a) and d + q to the residue
+__device__ __forceinline__ u32 hc_mul32(u32 y, HcTw32 w, u32 q) { return hc_csub32(y * w.w - hc_umulhi32(y, w.ws) * q, q); }     // ANY y < 2^32; w < q
+template <class TW>
+__device__ __forceinline__ void hc_ct_round32(u32 (&e)[16], const TW &tw, u32 q) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int g = 0; g < (1 << s); g++) {
+            const HcTw32 w = hc_tw32(tw((1 << s) - 1 + g));
+#pragma unroll
+            for (int k = 0; k < half; k++) {
+                const int a = g * 2 * half + k, b = a + half;
+                const u32 X = e[a], T = hc_mul32(e[b], w, q);
+                e[a] = hc_add32(X, T, q);
+                e[b] = hc_sub32(X, T, q);
+            }
+        }
+    }
+}
+template <bool LAST, class TW>
+__device__ __forceinline__ void hc_gs_round32(u32 (&e)[16], const TW &tw, u32 q, HcTw32 ninv, HcTw32 w_last) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int dist = 1 << s;
+#pragma unroll
+        for (int g = 0; g < (8 >> s); g++) {
+            HcTw32 w = hc_tw32(tw((8 >> s) - 1 + g));
+            if (LAST && s == 3) w = w_last;
+#pragma unroll
+            for (int k = 0; k < dist; k++) {
+                const int a = g * 2 * dist + k, b = a + dist;
+                const u32 X = e[a], Y = e[b], u = hc_add32(X, Y, q), d = hc_sub32(X, Y, q);
+                e[a] = (LAST && s == 3) ? hc_mul32(u, ninv, q) : u;
+                e[b] = hc_mul32(d, w, q);
+            }
+        }
+    }
+}
+template <class WA, class RA, class SY>
+__device__ __forceinline__ void hc_xchg1(u32 (&e)[16], u32 *lds, WA wa, RA ra, SY sync) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) lds[wa(i)] = e[i];
+    sync();
+#pragma unroll
+    for (int i = 0; i < 16; i++) e[i] = lds[ra(i)];
+}
+// the passes of hc_rows_fwd / hc_rows_inv / hc_cols_fwd / hc_cols_inv above on 32-bit residues: same element orders, same LDS address functions (4-byte words)
+__device__ __forceinline__ void hc_rows_fwd32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int row, int rloc, int tid, u32 q) {
+    hc_ct_round32(e, HcRowsTwA{T.rowsA + row * 16}, q);
+    hc_xchg1(e, lds, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [] { HC_ROW_SYNC(); });
+    hc_ct_round32(e, HcRowsTwB{T.rowsB + row * 256 + tid}, q);
+}
+__device__ __forceinline__ void hc_rows_inv32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int row, int rloc, int tid, u32 q) {
+    const HcTw32 ni = hc_tw32(T.ninv);
+    hc_gs_round32<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, q, ni, ni);
+    hc_xchg1(e, lds, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [] { HC_ROW_SYNC(); });
+    hc_gs_round32<false>(e, HcRowsTwA{T.rowsA + row * 16}, q, ni, ni);
+}
+__device__ __forceinline__ void hc_cols_fwd32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, u32 q) {
+    hc_ct_round32(e, HcRowsTwA{T.colsA}, q);
+    hc_xchg1(e, lds, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [] { __syncthreads(); });
+    hc_ct_round32(e, HcRowsTwB{T.colsB + tid}, q);
+}
+template <bool SCALE = true>
+__device__ __forceinline__ void hc_cols_inv32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, u32 q) {
+    const HcTw32 ni = hc_tw32(T.ninv);
+    hc_gs_round32<false>(e, HcRowsTwB{T.colsB + tid}, q, ni, ni);
+    hc_xchg1(e, lds, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [] { __syncthreads(); });
+    hc_gs_round32<SCALE>(e, HcRowsTwA{T.colsA}, q, ni, hc_tw32(T.w_last_ninv));
+}
+__device__ __forceinline__ void hc_rows_lin_to_lo32(u32 (&e)[16], u32 *lds, int t, int rloc, int tid) {
+    hc_xchg1(e, lds, [&](int k) { return hc_rows_lds32(k, t); }, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [] { __syncthreads(); });
+}
+__device__ __forceinline__ void hc_rows_lo_to_lin32(u32 (&e)[16], u32 *lds, int t, int rloc, int tid) {
+    hc_xchg1(e, lds, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [&](int k) { return hc_rows_lds32(k, t); }, [] { __syncthreads(); });
 }
 
 // ================================================================ standalone transforms (L0 API)
@@ -1580,31 +1694,34 @@ __device__ __forceinline__ u64 hc_basis_ext_sum(const u64 (&y)[NS + 1], const Hc
 #pragma unroll
     for (int i = 0; i <= NS; i++) if (i == n) v = y[i];
     if (n == 1) return hc_barrett64(y[0], B.t, B.mu_t);
-    if (B.t < (1ull << 58)) {                                          // lazy sum: below 2^58 up to 8 terms and the offset stay under 36 t < 2^64 unreduced
-        u64 acc = Q.q4;
+    // v <= n <= 8 is a small integer: v (S mod t) < 8t is formed as an exact 32 x 64-bit product (2-3 instructions against a lazy Shoup product's 12-14)
+    const u64 vs = (u64)(u32)v * B.smodt.w;
+    if (B.t < (1ull << 58)) {                                          // lazy sum: below 2^58 up to 8 terms and the offset stay under 40 t < 2^64 unreduced
+        u64 acc = 2 * Q.q4;
 #pragma unroll
         for (int i = 0; i < NS; i++) if (i < n) acc += hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q);
-        return hc_reduce64(acc - hc_shoup4(v, B.smodt.w, B.smodt.ws, Q), B.mu_t, Q);
+        return hc_reduce64(acc - vs, B.mu_t, Q);
     }
     u64 acc = 0;                                                       // the 60 / 61-bit limbs fold the running sum by 4t
 #pragma unroll
     for (int i = 0; i < NS; i++) if (i < n) acc = hc_fold(acc + hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q), Q.nq4);
-    return hc_canon8(acc + Q.q4 - hc_shoup4(v, B.smodt.w, B.smodt.ws, Q), Q);
+    return hc_canon8(acc + Q.q4 - hc_fold(vs, Q.nq4), Q);             // 8t < 2^64: vs folds to below 4t
 }
 // the same with the source count known at compile time (n == NS: every full digit and ModDown's P -> Q extension): no per-operand conditions, the loads of a group are one
 // straight run
 template <int NS>
 __device__ __forceinline__ u64 hc_basis_ext_sum_full(const u64 (&y)[NS + 1], const HcBasisExt &B, const HcQ &Q) {
+    const u64 vs = (u64)(u32)y[NS] * B.smodt.w;                          // v (S mod t) < 8t, exact (hc_basis_ext_sum)
     if (B.t < (1ull << 58)) {
-        u64 acc = Q.q4;
+        u64 acc = 2 * Q.q4;
 #pragma unroll
         for (int i = 0; i < NS; i++) acc += hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q);
-        return hc_reduce64(acc - hc_shoup4(y[NS], B.smodt.w, B.smodt.ws, Q), B.mu_t, Q);
+        return hc_reduce64(acc - vs, B.mu_t, Q);
     }
     u64 acc = 0;
 #pragma unroll
     for (int i = 0; i < NS; i++) acc = hc_fold(acc + hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q), Q.nq4);
-    return hc_canon8(acc + Q.q4 - hc_shoup4(y[NS], B.smodt.w, B.smodt.ws, Q), Q);
+    return hc_canon8(acc + Q.q4 - hc_fold(vs, Q.nq4), Q);
 }
 template <int NS>
 __device__ __forceinline__ void hc_basis_ext_tile(u64 (&e)[16], const u64 *yv, const HcBasisExt &B, int tid) {
@@ -1637,7 +1754,60 @@ __device__ __forceinline__ void hc_basis_ext_tile(u64 (&e)[16], const u64 *yv, c
         for (int g = 0; g < HC_EXT_GROUP; g++) e[g0 + g] = hc_basis_ext_sum<NS>(y[g], B, Q);
     }
 }
-struct HcRowMod { HcTwTab fwd, inv; u64 q, mu; };
+// The target side for a target limb below 2^31 (HC_S32): the constants h_i = S/s_i mod t are 31-bit words, so y_i h_i is formed from the two 32 x 32 -> 64-bit products of
+// y_i's halves (two v_mad_u64_u32 per term instead of a 64-bit lazy Shoup product's 12-14 instructions) and summed WITHOUT carry chains: the high halves' products (y_i < 2^61:
+// below 2^60 each) share one 64-bit accumulator, the low halves' (below 2^63 each) one per PAIR of terms; sum = H 2^32 + L with H = hi-sum + the pairs' upper words, L = the
+// pairs' lower words (34 bits). v (S mod t) comes off as 8t - v (S mod t) >= 0 (v <= n <= 8). Two 64-bit Barrett steps reduce H, then (H mod t) 2^32 + L. Canonical, hence the
+// same residue as hc_basis_ext_sum's. ONE straight-line form for every source count 2 <= n <= NS: the rows a short digit does not have are read as its v row again (an
+// in-bounds address, no per-operand condition) and meet a zero constant. (With hc_basis_ext_tile's per-operand conditions this body compiled to a load, a full wait and a
+// spill per operand: 208 bytes of scratch.)
+template <int NS>
+__device__ __forceinline__ u32 hc_basis_ext_sum32(const u64 (&y)[NS + 1], const u32 (&hat)[NS], u64 off, u32 smodt, u64 t, u64 mu_t) {
+    u64 H = 0, L = off - (u64)(u32)y[NS] * (u64)smodt;                       // L < 2^34
+#pragma unroll
+    for (int i = 0; i < NS; i += 2) {
+        u64 pair = 0;
+#pragma unroll
+        for (int k = i; k < i + 2 && k < NS; k++) {
+            H += (u64)(u32)(y[k] >> 32) * hat[k];
+            pair += (u64)(u32)y[k] * hat[k];
+        }
+        H += pair >> 32; L += (u64)(u32)pair;
+    }
+    const u64 r1 = hc_barrett64(H, t, mu_t);
+    return (u32)hc_barrett64((r1 << 32) + L, t, mu_t);
+}
+template <int NS>
+__device__ __forceinline__ void hc_basis_ext_tile32(u32 (&e)[16], const u64 *yv, const HcBasisExt &B, int tid) {
+    const int n = B.n;
+    const u64 t = B.t, mu_t = B.mu_t;
+    if (n == 1) {                                                            // block-uniform: the "copy" case, x mod t
+#pragma unroll
+        for (int g = 0; g < 16; g++) e[g] = (u32)hc_barrett64(yv[(size_t)(g * 16 + tid) * 256], t, mu_t);
+        return;
+    }
+    u32 hat[NS]; size_t roff[NS + 1];
+#pragma unroll
+    for (int i = 0; i < NS; i++) hat[i] = i < n ? (u32)B.hat[i].w : 0u;
+#pragma unroll
+    for (int i = 0; i <= NS; i++) roff[i] = (size_t)(i < n ? i : n) * 65536;
+    const u32 smodt = (u32)B.smodt.w; const u64 off = 8 * t;
+#pragma unroll
+    for (int g0 = 0; g0 < 16; g0 += HC_EXT_GROUP) {
+        u64 y[HC_EXT_GROUP][NS + 1];
+#pragma unroll
+        for (int g = 0; g < HC_EXT_GROUP; g++) {
+            const u64 *p = yv + (size_t)((g0 + g) * 16 + tid) * 256;
+#pragma unroll
+            for (int i = 0; i <= NS; i++) y[g][i] = p[roff[i]];
+        }
+#pragma unroll
+        for (int g = 0; g < HC_EXT_GROUP; g++) e[g0 + g] = hc_basis_ext_sum32<NS>(y[g], hat, off, smodt, t, mu_t);
+    }
+}
+struct HcRowMod { HcTwTab fwd, inv; u64 q, mu;
+                  u64 s32; };            // nonzero: the batched transforms take their 32-bit form (HC_S32) for rows of this modulus: q < 2^31 and option small32. (The kernels test
+                                         // HC_SMALL_Q(q) && s32: with a purely scalar condition - s32 alone, or a launch argument - around the two bodies the gfx950 backend of ROCm 7.2 dies, "illegal VGPR to SGPR copy")
 // blockIdx.z = operand + nz * image: `nz` operands zs_* words apart (the two polynomials of a ciphertext, the digits of a key switch), and the
 // images of a batch (hc_set_batch) is_* words apart
 struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; int z_alpha; int nz; size_t is_in, is_out;
@@ -1667,7 +1837,7 @@ __device__ __forceinline__ bool hc_mm_skip(const HcMm &A, int y, int zi) {
 __device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl ? y : A.nq + (y - A.nl); }
 #define HC_MM_PROLOGUE \
     const int y = A.rowlist[blockIdx.y], zi = (int)blockIdx.z % A.nz, img = (int)blockIdx.z / A.nz; if (hc_mm_skip(A, y, zi)) return; \
-    const HcRowMod &R = A.M[hc_mm_mod(A, y)]; \
+    const HcRowMod R = hc_const_copy(&A.M[hc_mm_mod(A, y)]); \
     in += (size_t)zi * A.zs_in + (size_t)img * A.is_in; out += (size_t)zi * A.zs_out + (size_t)img * A.is_out;
 // The rows passes read PER-ROW twiddles: 255 (w, w') pairs = 4 KB for every 2 KB row of data, the same for every operand and image of the launch. With the operand index in
 // blockIdx.z the workgroups sharing a twiddle slice were a whole (tiles x rows) sweep apart and, consecutive workgroup ids going round-robin over the 8 XCDs, on different L2s:
@@ -1678,20 +1848,57 @@ __device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl
     if (A.xcd) { const unsigned id = blockIdx.x, rest = id >> 3, p = (rest / (unsigned)A.nzn) * 8 + (id & 7); bx = (int)(p & 15); by_ = (int)(p >> 4); bz_ = (int)(rest % (unsigned)A.nzn); } \
     else { bx = (int)blockIdx.x; by_ = (int)blockIdx.y; bz_ = (int)blockIdx.z; } \
     const int y = A.rowlist[by_], zi = bz_ % A.nz, img = bz_ / A.nz; if (hc_mm_skip(A, y, zi)) return; \
-    const HcRowMod &R = A.M[hc_mm_mod(A, y)]; \
+    const HcRowMod R = hc_const_copy(&A.M[hc_mm_mod(A, y)]); \
     in += (size_t)zi * A.zs_in + (size_t)img * A.is_in; out += (size_t)zi * A.zs_out + (size_t)img * A.is_out;
 // (Round 4, measured and not kept - profiles/round4_chain_class_paths_ab.txt: butterflies per modulus class inside these kernels - 32-bit canonical arithmetic for the
 // chain's eleven ~30-bit limbs, the fold-free 64-bit form below 2^57 - as a block-uniform switch cost 108-132 VGPRs against 65-86 and only won the lost occupancy back;
 // as one launch per class they kept their registers but turned every pass into three short launches: 224 ms per 8-ciphertext layer against 203.)
-template <int EXT, int NS = 8>      // EXT 1: the input is the fused basis extension; 2: the extension plus P times Rescale's lift (ModDown and Rescale in one transform); NS: most source limbs of the extension
-__global__ __launch_bounds__(HC_TPB, EXT ? HC_MM_WAVES_EXT : HC_MM_WAVES) void hc_k_cols_fwd_mm(const u64 *in, u64 *out, HcMm A) {
-    __shared__ hc_mm_lds_t lds[HC_COLS_LDS];
-    HC_MM_PROLOGUE
+// hc_k_cols_fwd_mm for a row whose modulus is below 2^31: every prologue it has, 32-bit residues from there on
+template <int EXT, int NS>
+__device__ __forceinline__ void hc_cols_fwd_mm_small(const u64 *in, u64 *out, u32 *lds, const HcMm &A, const HcRowMod &R, int y, int zi, int img) {
+    const int t = threadIdx.x, c = t & 15, tid = t >> 4;
+    const u32 q = (u32)R.q;
+    u32 e[16];
+    if (EXT) {
+        hc_basis_ext_tile32<NS>(e, in + blockIdx.x * 16 + c, hc_const_copy(&A.ext_bs[(A.z_alpha > 0 ? (size_t)zi * A.ext_rows : 0) + y]), tid);
+        if (EXT == 2) {
+            const u64 qL = A.mods[A.lift_level].q, h = (qL - 1) >> 1, qi = R.q, neg_h = qi - hc_barrett64(h, qi, R.mu);
+            const u64 *tt = A.lift_t + (size_t)zi * A.lift_t_zs + (size_t)img * A.lift_t_is + blockIdx.x * 16 + c;
+            const HcTw32 pm = hc_tw32(A.lift_pmul[y]);
+#pragma unroll
+            for (int hi = 0; hi < 16; hi++) {
+                const u32 r = (u32)hc_barrett64(hc_csub(tt[(size_t)(hi * 16 + tid) * 256] + h, qL) + neg_h, qi, R.mu);
+                e[hi] = hc_add32(e[hi], hc_mul32(r, pm, q), q);
+            }
+        }
+    } else if (A.lift_level > 0) {                                           // block-uniform
+        const u64 qL = A.mods[A.lift_level].q, h = (qL - 1) >> 1, qi = R.q, neg_h = qi - hc_barrett64(h, qi, R.mu);
+        const u64 *tt = in + blockIdx.x * 16 + c;
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) e[hi] = (u32)hc_barrett64(hc_csub(tt[(size_t)(hi * 16 + tid) * 256] + h, qL) + neg_h, qi, R.mu);
+    } else if (A.pk_in) {                                                    // block-uniform (a caller's polynomial under pack32 = 2)
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) e[hi] = (u32)hc_ld32(in + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(hi * 16 + tid) * 256);
+    } else {
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) e[hi] = (u32)in[(size_t)y * 65536 + (size_t)(blockIdx.x * 16 + c) + (size_t)(hi * 16 + tid) * 256];
+    }
+    hc_cols_fwd32(e, lds, R.fwd, c, tid, q);
+    if (A.pk_out) {
+#pragma unroll
+        for (int lo = 0; lo < 16; lo++) hc_st32(out + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(tid * 16 + lo) * 256, e[lo]);
+        return;
+    }
+#pragma unroll
+    for (int lo = 0; lo < 16; lo++) out[(size_t)y * 65536 + (size_t)(blockIdx.x * 16 + c) + (size_t)(tid * 16 + lo) * 256] = e[lo];
+}
+template <int EXT, int NS>
+__device__ __forceinline__ void hc_cols_fwd_mm_big(const u64 *in, u64 *out, hc_mm_lds_t *lds, const HcMm &A, const HcRowMod &R, int y, int zi, int img) {
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
     u64 e[16];
     if (EXT) {
-        hc_basis_ext_tile<NS>(e, in + blockIdx.x * 16 + c, A.ext_bs[(A.z_alpha > 0 ? (size_t)zi * A.ext_rows : 0) + y], tid);
+        hc_basis_ext_tile<NS>(e, in + blockIdx.x * 16 + c, hc_const_copy(&A.ext_bs[(A.z_alpha > 0 ? (size_t)zi * A.ext_rows : 0) + y]), tid);
         if (EXT == 2) {
             const u64 qL = A.mods[A.lift_level].q, h = (qL - 1) >> 1, qi = R.q, neg_h = qi - (h % qi);
             const u64 *tt = A.lift_t + (size_t)zi * A.lift_t_zs + (size_t)img * A.lift_t_is + blockIdx.x * 16 + c;
@@ -1722,15 +1929,84 @@ __global__ __launch_bounds__(HC_TPB, EXT ? HC_MM_WAVES_EXT : HC_MM_WAVES) void h
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) out[base + (size_t)(tid * 16 + lo) * 256] = e[lo];
 }
+template <int EXT, int NS = 8>      // EXT 1: the input is the fused basis extension; 2: the extension plus P times Rescale's lift (ModDown and Rescale in one transform); NS: most source limbs of the extension
+__global__ __launch_bounds__(HC_TPB, EXT ? HC_MM_WAVES_EXT : HC_MM_WAVES) void hc_k_cols_fwd_mm(const u64 *in, u64 *out, HcMm A) {
+    __shared__ hc_mm_lds_t lds[HC_COLS_LDS];
+    HC_MM_PROLOGUE
+    if (HC_S32 && HC_SMALL_Q(R.q) && R.s32) hc_cols_fwd_mm_small<EXT, NS>(in, out, reinterpret_cast<u32 *>(lds), A, R, y, zi, img);       // block-uniform
+    else hc_cols_fwd_mm_big<EXT, NS>(in, out, lds, A, R, y, zi, img);
+}
 #ifndef HC_EPI_ROWS
 #define HC_EPI_ROWS 4                  // rows of the epilogue's operands requested together
 #endif
 #ifndef HC_MM_WAVES_RF
 #define HC_MM_WAVES_RF 6                  // the rows-forward pass with its clustered epilogue loads: 80 VGPRs, no scratch (7 wavefronts: 72 VGPRs and 44 bytes of scratch; measured 18.38 vs 18.51 ms per ciphertext-layer)
 #endif
+// hc_k_rows_fwd_canon_mm for a row whose modulus is below 2^31 (HC_S32): 32-bit residues through the pass and the epilogue
+__device__ __forceinline__ void hc_rows_fwd_canon_mm_small(const u64 *in, u64 *out, u32 *lds, const HcMm &A, const HcRowMod &R, int y, int zi, int img, int bx) {
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = bx * 16 + rloc;
+    const size_t pbase = (size_t)y * 65536;
+    const u32 q = (u32)R.q;
+    u32 e[16];
+    if (A.pk_in) {                                                           // block-uniform
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) e[hi] = (u32)hc_ld32(in + pbase, (size_t)row * 256 + hi * 16 + tid);
+    } else {
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) e[hi] = (u32)in[pbase + (size_t)row * 256 + hi * 16 + tid];
+    }
+    hc_rows_fwd32(e, lds, R.fwd, row, rloc, tid, q);
+    HC_ROW_SYNC();
+    hc_rows_lo_to_lin32(e, lds, t, rloc, tid);
+    const size_t lj = (size_t)(bx * 16) * 256 + t;                           // element index of (row bx * 16, column t) inside the limb's row
+    if (A.epi_x != nullptr) {                                                // block-uniform: (x - result) * c (+ addend [* c']), hc_k_rows_fwd_canon_mm's epilogue
+        const u64 *x = A.epi_x + (size_t)zi * A.epi_x_zs + (size_t)img * A.epi_x_is + pbase;
+        u64 *orow = out + pbase;
+        const HcTw32 w = hc_tw32(A.epi_mul[y]);
+        const u64 *ad = A.epi_add != nullptr ? A.epi_add + (size_t)zi * A.epi_add_zs + (size_t)img * A.epi_add_is + pbase : nullptr;
+        const bool scaled = A.epi_add_mul != nullptr;
+        const HcTw32 wa = scaled ? hc_tw32(A.epi_add_mul[y]) : HcTw32{0, 0};
+        auto body = [&](auto s32c) {
+            constexpr bool S32 = decltype(s32c)::value;
+#pragma unroll
+            for (int h = 0; h < 16; h += HC_EPI_ROWS) {
+                u32 xv[HC_EPI_ROWS], av[HC_EPI_ROWS], r[HC_EPI_ROWS];
+#pragma unroll
+                for (int k = 0; k < HC_EPI_ROWS; k++) xv[k] = (u32)HC_LD(S32, x, lj + (size_t)(h + k) * 256);
+                if (ad != nullptr) {
+#pragma unroll
+                    for (int k = 0; k < HC_EPI_ROWS; k++) av[k] = (u32)HC_LD(S32, ad, lj + (size_t)(h + k) * 256);
+                }
+#pragma unroll
+                for (int k = 0; k < HC_EPI_ROWS; k++) r[k] = hc_mul32(hc_sub32(xv[k], e[h + k], q), w, q);
+                if (ad != nullptr) {
+                    if (scaled) {
+#pragma unroll
+                        for (int k = 0; k < HC_EPI_ROWS; k++) r[k] = hc_add32(r[k], hc_mul32(av[k], wa, q), q);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < HC_EPI_ROWS; k++) r[k] = hc_add32(r[k], av[k], q);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < HC_EPI_ROWS; k++) HC_ST(S32, orow, lj + (size_t)(h + k) * 256, (u64)r[k]);
+            }
+        };
+        HC_ROW_DISPATCH(A.pk_epi, body);
+        return;
+    }
+    if (A.pk_out) {                                                          // the extended digits of a key switch, a caller's polynomial under pack32 = 2
+#pragma unroll
+        for (int k = 0; k < 16; k++) hc_st32(out + pbase, lj + (size_t)k * 256, e[k]);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[pbase + lj + (size_t)k * 256] = e[k];
+}
 __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_RF) void hc_k_rows_fwd_canon_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ hc_mm_lds_t lds[HC_ROWS_LDS];
     HC_MM_PROLOGUE_ROWS
+    if (HC_S32 && HC_SMALL_Q(R.q) && R.s32) { hc_rows_fwd_canon_mm_small(in, out, reinterpret_cast<u32 *>(lds), A, R, y, zi, img, bx); return; }       // block-uniform
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = bx * 16 + rloc;
     const size_t pbase = (size_t)y * 65536;
     u64 e[16];
@@ -1798,9 +2074,55 @@ __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_RF) void hc_k_rows_fwd_canon_mm
 #ifndef HC_MM_WAVES_INV
 #define HC_MM_WAVES_INV 6              // the inverse passes: 78-80 VGPRs without scratch (at 7 the typed / pitch row loads of round 5 spill 16-24 bytes)
 #endif
+// hc_k_rows_inv_mm / hc_k_cols_inv_canon_mm for a row whose modulus is below 2^31 (HC_S32)
+__device__ __forceinline__ void hc_rows_inv_mm_small(const u64 *in, u64 *out, u32 *lds, const HcMm &A, const HcRowMod &R, int y, int bx) {
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = bx * 16 + rloc;
+    const size_t pbase = (size_t)y * 65536;
+    const u32 q = (u32)R.q;
+    u32 e[16];
+    if (A.pk_in) {                                                           // block-uniform
+#pragma unroll
+        for (int k = 0; k < 16; k++) e[k] = (u32)hc_ld32(in + pbase, (size_t)(bx * 16 + k) * 256 + t);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) e[k] = (u32)in[pbase + (size_t)(bx * 16 + k) * 256 + t];
+    }
+    hc_rows_lin_to_lo32(e, lds, t, rloc, tid);
+    HC_ROW_SYNC();
+    hc_rows_inv32(e, lds, R.inv, row, rloc, tid, q);
+    if (A.pk_out) {
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) hc_st32(out + pbase, (size_t)row * 256 + hi * 16 + tid, e[hi]);
+        return;
+    }
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) out[pbase + (size_t)row * 256 + hi * 16 + tid] = e[hi];
+}
+__device__ __forceinline__ void hc_cols_inv_canon_mm_small(const u64 *in, u64 *out, u32 *lds, const HcMm &A, const HcRowMod &R, int y) {
+    const int t = threadIdx.x, c = t & 15, tid = t >> 4;
+    const size_t pbase = (size_t)y * 65536, col = (size_t)(blockIdx.x * 16 + c);
+    const u32 q = (u32)R.q;
+    u32 e[16];
+    if (A.pk_in) {                                                           // block-uniform
+#pragma unroll
+        for (int lo = 0; lo < 16; lo++) e[lo] = (u32)hc_ld32(in + pbase, col + (size_t)(tid * 16 + lo) * 256);
+    } else {
+#pragma unroll
+        for (int lo = 0; lo < 16; lo++) e[lo] = (u32)in[pbase + col + (size_t)(tid * 16 + lo) * 256];
+    }
+    hc_cols_inv32(e, lds, R.inv, c, tid, q);
+    if (A.pk_out) {
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) hc_st32(out + pbase, col + (size_t)(hi * 16 + tid) * 256, e[hi]);
+        return;
+    }
+#pragma unroll
+    for (int hi = 0; hi < 16; hi++) out[pbase + col + (size_t)(hi * 16 + tid) * 256] = e[hi];
+}
 __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_INV) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ hc_mm_lds_t lds[HC_ROWS_LDS];
     HC_MM_PROLOGUE_ROWS
+    if (HC_S32 && HC_SMALL_Q(R.q) && R.s32) { hc_rows_inv_mm_small(in, out, reinterpret_cast<u32 *>(lds), A, R, y, bx); return; }       // block-uniform
     const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = bx * 16 + rloc;
     const size_t pbase = (size_t)y * 65536;
     u64 e[16];
@@ -1840,7 +2162,8 @@ __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_INV) void hc_k_cols_inv_canon_m
     __shared__ hc_mm_lds_t lds[HC_COLS_LDS];
     HC_MM_PROLOGUE
     const bool small = HC_SMALL_Q(R.q);
-    if (A.pk_in && small) hc_cols_inv_canon_mm_body<true>(in, out, lds, R, y, A.pk_out && small);          // block-uniform
+    if (HC_S32 && small && R.s32) hc_cols_inv_canon_mm_small(in, out, reinterpret_cast<u32 *>(lds), A, R, y);      // block-uniform
+    else if (A.pk_in && small) hc_cols_inv_canon_mm_body<true>(in, out, lds, R, y, A.pk_out && small);
     else hc_cols_inv_canon_mm_body<false>(in, out, lds, R, y, A.pk_out && small);
 }
 // ModDown fused with the Rescale behind it (hc_keyswitch_add_rescale), the last limb L. Rescale needs the coefficients of c_L = (acc_L - NTT(ext_L)) / P + add_L:

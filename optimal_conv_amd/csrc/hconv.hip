@@ -136,6 +136,7 @@ struct hc_ctx {
     int xcd_rows = 1;                     // XCD-aware 1-D grid of the rows passes (HcMm::xcd; 0 = the plain 3-D grid, kept for A/B builds)
     int pack32 = 1;                       // 1: library-internal rows of moduli below 2^31 as 4-byte words (hc_kernels.h hc_ld32): transform seams, extended digits, switching keys. 2: the rows of the caller's leveled
                                           // operands as well (include/hconv.h "4-byte rows"; option pack32 or HCONV_PACK32=2 at hc_ctx_create). 0: off (A/B)
+    int small32 = 1;                      // the batched transform kernels take their 32-bit form for rows of a modulus below 2^31 (hc_kernels.h HC_S32; option small32 / HCONV_SMALL32=0 for A/B)
     unsigned peer_warned = 0;             // bit d: enabling peer access to device d failed and was reported once
     unsigned peer_enabled = 0;            // bit d: peer access from this context's device to device d was enabled by (or found enabled for) this context
     long profile = 0;
@@ -308,6 +309,12 @@ static int hc_build_tables(hc_ctx *c, HcModHost *mh, bool inverse) {
 extern "C" int hc_version(void) { return 1; }
 extern "C" const char *hc_last_error(const hc_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
+// the per-modulus table of the batched transforms (HcRowMod); again after option small32 changes
+static int hc_upload_rowmods(hc_ctx *c) {
+    std::vector<HcRowMod> hr;
+    for (auto &mh : c->mods) { HcRowMod r; r.fwd = mh.fwd; r.inv = mh.inv; r.q = mh.m.q; r.mu = mh.m.mu; r.s32 = (c->small32 && mh.m.q < (1ull << 31)) ? 1 : 0; hr.push_back(r); }
+    return hcx_h2d(c, c->d_rowmods, hr.data(), hr.size() * sizeof(HcRowMod)) == hipSuccess ? HC_OK : HC_ERR_HIP;
+}
 extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, const uint64_t *p, int np, int device) {
     if (!out || !q || nq < 1 || np < 0 || (np > 0 && !p)) return hc_fail(nullptr, HC_ERR_ARG, "hc_ctx_create: bad arguments");
     if (np > 8) return hc_fail(nullptr, HC_ERR_UNSUPPORTED, "hc_ctx_create: np=%d special primes; the key switch's basis-extension tables hold at most 8 (the reference's parameter sets use 1, 2 or 5)", np);
@@ -317,6 +324,7 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
         return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: HIP device %d not available (%d devices) - this library has no CPU path", device, ndev);
     hc_ctx *c = new hc_ctx();
     c->device = device; c->nq = nq; c->np = np;
+    { const char *sm = getenv("HCONV_SMALL32"); if (sm && *sm) c->small32 = atoi(sm) ? 1 : 0; }
     { const char *pk = getenv("HCONV_PACK32"); if (pk && *pk) { const int v = atoi(pk); c->pack32 = v <= 0 ? 0 : v >= 2 ? 2 : 1; } }
     { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa ? (atoi(aa) == 2 ? 2 : (atoi(aa) ? 1 : 0)) : 0; }
     hipError_t se = hipSetDevice(device);
@@ -349,10 +357,7 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
         if (hcx_malloc(c, (void **)&c->d_mods, hm.size() * sizeof(HcMod)) != hipSuccess || hcx_malloc(c, (void **)&c->d_csts, hm.size() * sizeof(HcTw)) != hipSuccess ||
             hcx_h2d(c, c->d_mods, hm.data(), hm.size() * sizeof(HcMod)) != hipSuccess) { g_create_err = "hc_ctx_create: device modulus table"; hc_ctx_destroy(c); return HC_ERR_HIP; }
     }
-    {   std::vector<HcRowMod> hr; for (auto &mh : c->mods) { HcRowMod r; r.fwd = mh.fwd; r.inv = mh.inv; r.q = mh.m.q; r.mu = mh.m.mu; hr.push_back(r); }
-        if (hcx_malloc(c, (void **)&c->d_rowmods, hr.size() * sizeof(HcRowMod)) != hipSuccess ||
-            hcx_h2d(c, c->d_rowmods, hr.data(), hr.size() * sizeof(HcRowMod)) != hipSuccess) { g_create_err = "hc_ctx_create: device table of transforms"; hc_ctx_destroy(c); return HC_ERR_HIP; }
-    }
+    if (hcx_malloc(c, (void **)&c->d_rowmods, c->mods.size() * sizeof(HcRowMod)) != hipSuccess || hc_upload_rowmods(c) != HC_OK) { g_create_err = "hc_ctx_create: device table of transforms"; hc_ctx_destroy(c); return HC_ERR_HIP; }
     *out = c;
     return HC_OK;
 }
@@ -1796,6 +1801,7 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!strcmp(name, "small_levels")) { if (value < 0) return hc_fail(c, HC_ERR_ARG, "small_levels must be >= 0"); c->small_levels = value; return HC_OK; }
     if (!strcmp(name, "peer_access")) { c->peer_access = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
+    if (!strcmp(name, "small32")) { c->small32 = value ? 1 : 0; HC_HIP(c, hipStreamSynchronize(c->stream)); return hc_upload_rowmods(c); }      // results do not depend on it (both forms leave canonical residues): A/B only
     if (!strcmp(name, "pack32")) {          // 0 / 1 / 2 (include/hconv.h "4-byte rows"). Switching keys are stored per the setting in force when they are loaded or generated: 0 <-> 1, 2 only on a context without keys
         if (value < 0 || value > 2) return hc_fail(c, HC_ERR_ARG, "pack32 must be 0, 1 or 2");
         if (((value == 0) != (c->pack32 == 0)) && !c->swk.empty()) return hc_fail(c, HC_ERR_STATE, "pack32: switching keys are already stored in the other form");

@@ -386,6 +386,66 @@ def case_keyswitch_qp_mod_down(make_ctx, make_oracle, level=4, alpha=3, nkeys=2)
     ctx.close()
 
 
+def case_leveled_rows(make_ctx, make_oracle, level=5, alpha=3, seed=0x4B17):
+    """Every numpy-in / numpy-out leveled entry point against the oracle's row functions, on a chain that mixes 60-bit and ~30-bit limbs (the bootstrapping chain's
+    shape). With option pack32 = 2 the binding packs the small limbs' rows to 4-byte words on upload (the other half of each slot poisoned) and widens them on download,
+    so the same residues must come back in either mode."""
+    Q, P = Q_MIX[: level + 1], P_CHAIN[:alpha]
+    ctx, O = make_ctx(Q, P), make_oracle(Q, P)
+    nl = level + 1
+    rnd = lambda s: np.stack([splitmix_rows(seed + 97 * s + l, Q[l], N) for l in range(nl)])
+    a, b, c = rnd(1), rnd(2), rnd(3)
+    rows = lambda fn, *xs: np.stack([np.asarray(fn(l, *[x[l] for x in xs])).reshape(-1) for l in range(nl)])
+    eq(ctx.lv_ntt(level, a), rows(O.ntt, a), "lv_ntt"); eq(ctx.lv_intt(level, a), rows(O.intt, a), "lv_intt")
+    eq(ctx.lv_intt(level, ctx.lv_ntt(level, a)), a, "lv_intt(lv_ntt(x)) == x")
+    eq(ctx.lv_mul(level, a, b), rows(O.mul, a, b), "lv_mul"); eq(ctx.lv_add(level, a, b), rows(O.add, a, b), "lv_add"); eq(ctx.lv_sub(level, a, b), rows(O.sub, a, b), "lv_sub")
+    eq(ctx.lv_mul_acc(level, a, b, c), rows(O.add, c, rows(O.mul, a, b)), "lv_mul_acc")
+    cs = [int(x) % Q[l] for l, x in enumerate(splitmix_rows(seed + 5, 1 << 61, nl))]
+    want = np.stack([np.asarray(O.mul_scalar(l, a[l], cs[l])).reshape(-1) for l in range(nl)])
+    eq(ctx.lv_mul_const(level, a, cs), want, "lv_mul_const")
+    want = np.stack([(a[l] + np.uint64(cs[l])) % np.uint64(Q[l]) for l in range(nl)])
+    eq(ctx.lv_add_const(level, a, cs), want, "lv_add_const")
+    eq(ctx.div_round_last(level, a), O.div_round_last(level, a), "div_round_last")
+    d = ctx.div_round_last2(level, a, b)
+    eq(d[0], O.div_round_last(level, a), "div_round_last2 [0]"); eq(d[1], O.div_round_last(level, b), "div_round_last2 [1]")
+    ct_a, ct_b = np.stack([a, b]), np.stack([c, rnd(4)])
+    t = ctx.lv_mul_tensor(level, ct_a, ct_b)
+    eq(t[0], rows(O.mul, ct_a[0], ct_b[0]), "tensor d0"); eq(t[2], rows(O.mul, ct_a[1], ct_b[1]), "tensor d2")
+    eq(t[1], rows(O.add, rows(O.mul, ct_a[0], ct_b[1]), rows(O.mul, ct_a[1], ct_b[0])), "tensor d1")
+    eq(ctx.lv_op2(0, level, ct_a, ct_b), np.stack([rows(O.mul, ct_a[k], ct_b[k]) for k in range(2)]), "op2 mul")
+    eq(ctx.lv_op2(0, level, ct_a, c, shared_b=True), np.stack([rows(O.mul, ct_a[k], c) for k in range(2)]), "op2 mul by a plaintext")
+    eq(ctx.lv_op2(1, level, ct_a, ct_b), np.stack([rows(O.add, ct_a[k], ct_b[k]) for k in range(2)]), "op2 add")
+    eq(ctx.lv_op2(2, level, ct_a, ct_b), np.stack([rows(O.sub, ct_a[k], ct_b[k]) for k in range(2)]), "op2 sub")
+    eq(ctx.lv_op2(7, level, ct_a, c, out=ct_b, shared_b=True), np.stack([rows(O.add, ct_b[k], rows(O.mul, ct_a[k], c)) for k in range(2)]), "op2 mul-acc")
+    # modUp of the bootstrapping: the centred lift of a q_0 row to every limb
+    x0 = a[0]
+    cf = np.asarray(O.intt(0, x0)).reshape(-1)
+    half = Q[0] >> 1
+    want = []
+    for l in range(nl):
+        lifted = np.where(cf > half, (cf % np.uint64(Q[l]) + np.uint64(Q[l]) - np.uint64(Q[0] % Q[l])) % np.uint64(Q[l]), cf % np.uint64(Q[l]))
+        want.append(np.asarray(O.ntt(l, lifted)).reshape(-1))
+    eq(ctx.lv_mod_raise(level, x0), np.stack(want), "lv_mod_raise")
+    # rotation: key switch + automorphism, fused and in two steps
+    beta, nt = (nl + alpha - 1) // alpha, nl + alpha
+    evk = np.empty((beta, 2, nt, N), dtype=np.uint64)
+    for dd in range(beta):
+        for k in range(2):
+            for T in range(nt):
+                evk[dd, k, T] = splitmix_rows(seed + 9000 + ((dd * 2 + k) * 16 + T), Q[T] if T <= level else P[T - nl], N)
+    gal = pow(5, 7, 2 * N)
+    ctx.swk_load(gal, level, evk)
+    w0, w1 = O.keyswitch(level, b, evk)
+    idx = O.permute_index(gal)
+    want0 = np.stack([O.permute(idx, r) for r in rows(O.add, w0, a)]); want1 = np.stack([O.permute(idx, r) for r in w1])
+    for hoisted in (False, True):
+        r0, r1 = ctx.keyswitch_rotate(gal, gal, level, a, b, hoisted=hoisted)
+        eq(r0, want0, f"keyswitch_rotate c0 hoisted={hoisted}"); eq(r1, want1, f"keyswitch_rotate c1 hoisted={hoisted}")
+    f0, f1 = ctx.rotate_finish(gal, level, w0, w1, a)
+    eq(f0, want0, "rotate_finish c0"); eq(f1, want1, "rotate_finish c1")
+    ctx.close()
+
+
 def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4, make_oracle=None, chain=None):
     """hc_set_batch: every leveled entry point on n images per launch (operands `stride` words apart, plaintexts and keys shared) must give,
     for every image, the bits of the same call on that image alone (which the other cases pin to the oracle). Strides are padded so that an

@@ -117,9 +117,10 @@ def test_bl_baseline_conv():
     pc.case_bl_conv(lambda Q, P: Context(Q, P, lib_path=EMU_LIB))
 
 
-def test_keyswitch_general_vs_reference_relu_trace():
+@pytest.mark.parametrize("rows4", [False, True], ids=["rows8", "rows4"])
+def test_keyswitch_general_vs_reference_relu_trace(rows4):
     """hc_keyswitch (28 Q + 5 P moduli loaded) vs the reference binary's digests for the bootstrapping chain's key
-    switches; the emulator replays the cheap low levels and one five-digit call, the GPU test replays all of them"""
+    switches; the emulator replays the cheap low levels and one five-digit call, the GPU test replays all of them. rows4: the chain's ~30-bit limbs held as 4-byte words"""
     import json
     from oracle_lib import sha_rows
     from test_oracle_pin_keyswitch import ks_inputs
@@ -127,6 +128,9 @@ def test_keyswitch_general_vs_reference_relu_trace():
     d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_trace_ks_relu_5_1.json")))
     Q, P = d["ks_Q"], d["ks_P"]
     ctx = Context(Q, P, lib_path=EMU_LIB)
+    if rows4:
+        ctx.set_option("pack32", 2)
+        assert sum(ctx.row32()) == 11
     for e in [d["events"][1]] + d["events"][-3:]:
         assert e["alpha"] == 5
         cx, evk = ks_inputs(d["seed"], e["call"], e["evk"], e["level"], Q, P, d["N"])
@@ -160,6 +164,34 @@ def test_keyswitch_hoisted():
     """one digit decomposition shared by several key switches (RotateHoisted), bit-identical to the plain key switch"""
     subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
     pc.case_keyswitch_hoisted(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), lambda Q, P: Oracle(q=Q, p=P))
+
+
+def _rows4(Q, P):
+    """a context whose leveled operands hold the ~30-bit limbs' rows as 4-byte words (include/hconv.h, option pack32 = 2: what the bootstrapping host enables)"""
+    ctx = Context(Q, P, lib_path=EMU_LIB)
+    ctx.set_option("pack32", 2)
+    assert any(ctx.row32()) and not all(ctx.row32())
+    return ctx
+
+
+@pytest.mark.parametrize("rows4", [False, True])
+def test_leveled_entry_points_row_by_row(rows4):
+    """every numpy-in / numpy-out leveled entry point against the oracle's row functions, with 8-byte rows and with 4-byte rows for the small limbs"""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    pc.case_leveled_rows(_rows4 if rows4 else (lambda Q, P: Context(Q, P, lib_path=EMU_LIB)), lambda Q, P: Oracle(q=Q, p=P))
+
+
+@pytest.mark.parametrize("case", ["general", "hoisted", "qp"])
+def test_key_switch_with_four_byte_rows(case):
+    """the key-switch cases above, unchanged, on a context in pack32 = 2: the binding converts at the boundary, the residues are the oracle's"""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    mo = lambda Q, P: Oracle(q=Q, p=P)
+    if case == "general":
+        pc.case_keyswitch_general(_rows4, mo, shapes=((3, 2), (4, 3), (4, 5)))
+    elif case == "hoisted":
+        pc.case_keyswitch_hoisted(_rows4, mo)
+    else:
+        pc.case_keyswitch_qp_mod_down(_rows4, mo)
 
 
 @pytest.mark.parametrize("n,level,alpha", [(3, 4, 3), (2, 5, 2)])

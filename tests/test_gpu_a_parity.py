@@ -227,10 +227,21 @@ def test_keyswitch_general_on_gpu():
 KS_TRACES = sorted(glob.glob(os.path.join(HERE, "golden", "ref_trace_ks_*.json")))
 
 
+def _rows4(Q, P):
+    """a context whose leveled operands hold the ~30-bit limbs' rows as 4-byte words (include/hconv.h, option pack32 = 2: what the bootstrapping host enables);
+    optimal_conv_amd.abi converts at the boundary, the upper half of each packed slot poisoned"""
+    from optimal_conv_amd import Context
+    ctx = Context(Q, P)
+    ctx.set_option("pack32", 2)
+    return ctx
+
+
+@pytest.mark.parametrize("rows4", [False, True], ids=["rows8", "rows4"])
 @pytest.mark.parametrize("path", KS_TRACES, ids=[os.path.basename(t) for t in KS_TRACES])
-def test_keyswitch_general_vs_reference_traces(path):
+def test_keyswitch_general_vs_reference_traces(path, rows4):
     """GPU vs the digests the reference binary produced for rlwe.SwitchKeysInPlace: the BL run's RotateNew (level 1, two
-    P primes) and one call per level of the convReLU bootstrapping chain (levels 4..23, five P primes, 1..5 digits)"""
+    P primes) and one call per level of the convReLU bootstrapping chain (levels 4..23, five P primes, 1..5 digits); with 8-byte rows and with 4-byte rows for the
+    chain's ~30-bit limbs"""
     from optimal_conv_amd import Context
     from test_oracle_pin_keyswitch import ks_inputs
     d = json.load(open(path))
@@ -239,7 +250,7 @@ def test_keyswitch_general_vs_reference_traces(path):
     for e in d["events"]:
         Pa = P[: e["alpha"]]
         if len(Pa) not in ctxs:
-            ctxs[len(Pa)] = Context(Q, Pa)
+            ctxs[len(Pa)] = _rows4(Q, Pa) if rows4 else Context(Q, Pa)
         ctx = ctxs[len(Pa)]
         cx, evk = ks_inputs(d["seed"], e["call"], e["evk"], e["level"], Q, Pa, d["N"])
         ctx.swk_load(1000 + e["call"], e["level"], evk)
@@ -593,6 +604,24 @@ def test_keyswitch_hoisted_on_gpu():
     from optimal_conv_amd import Context
     pc.case_keyswitch_hoisted(lambda Q, P: Context(Q, P), lambda Q, P: Oracle(q=Q, p=P))
     pc.case_keyswitch_hoisted(lambda Q, P: Context(Q, P), lambda Q, P: Oracle(q=Q, p=P), level=4, alpha=5, nkeys=2)
+
+
+@pytest.mark.parametrize("rows4", [False, True], ids=["rows8", "rows4"])
+def test_leveled_entry_points_row_by_row_on_gpu(rows4):
+    """every numpy-in / numpy-out leveled entry point against the oracle's row functions, with 8-byte rows and with 4-byte rows for the small limbs"""
+    from optimal_conv_amd import Context
+    mk = _rows4 if rows4 else (lambda Q, P: Context(Q, P))
+    pc.case_leveled_rows(mk, lambda Q, P: Oracle(q=Q, p=P))
+    pc.case_leveled_rows(mk, lambda Q, P: Oracle(q=Q, p=P), level=6, alpha=5, seed=0x77)
+
+
+def test_key_switch_with_four_byte_rows_on_gpu():
+    """the key-switch cases above, unchanged, on a context in pack32 = 2"""
+    mo = lambda Q, P: Oracle(q=Q, p=P)
+    pc.case_keyswitch_general(_rows4, mo, shapes=((3, 2), (4, 3), (4, 5)))
+    pc.case_keyswitch_hoisted(_rows4, mo, level=4, alpha=5, nkeys=2)
+    pc.case_keyswitch_qp_mod_down(_rows4, mo)
+    pc.case_keyswitch_qp_mod_down(_rows4, mo, level=4, alpha=5, nkeys=2)
 
 
 @pytest.mark.parametrize("n,level,alpha,real_chain", [(8, 27, 5, True), (3, 4, 5, False), (5, 2, 1, False)])
