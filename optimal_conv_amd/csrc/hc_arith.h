@@ -89,12 +89,8 @@ HC_HD u64 hc_mulhi_lo2(u64 x, u64 p) {
 // A kernel-uniform value the optimiser cannot see through: without it x*w + hi*(0 - q) is canonicalised back into x*w - hi*q.
 HC_HD u64 hc_opaque_uniform(u64 v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // (readfirstlane of a value the compiler knows to be uniform is folded away - it does not hide anything, the asm does; but where the compiler keeps such a value in a VGPR -
-    // a modulus that a sibling branch feeds to vector instructions - it is the legal way into the SGPR the constraint asks for: without it the gfx950 backend of ROCm 7.2
-    // stops with "illegal VGPR to SGPR copy")
-    const u64 u = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
     u64 r;
-    asm("; uniform constant kept opaque" : "=s"(r) : "0"(u));
+    asm("; uniform constant kept opaque" : "=s"(r) : "0"(v));      // (readfirstlane of a uniform value is folded away; this is not)
     return r;
 #else
     return v;

@@ -177,10 +177,13 @@ __device__ __forceinline__ int hc_cols_lds(int row, int c) { return ((row ^ ((ro
 // GENERIC pointer and emitted flat_load_dwordx4 for every twiddle - 30 per thread and pass - which count against lgkmcnt as well as vmcnt and so tie every twiddle fetch to
 // the LDS exchange waits. The explicit address space makes them global_load_dwordx4 (round 5; the convolution's kernels receive HcTwTab by value and always had global loads).
 #if defined(__HIP_DEVICE_COMPILE__)
-typedef const HcTw __attribute__((address_space(4))) *HcTwGlobalPtr;
+typedef const HcTw __attribute__((address_space(1))) *HcTwGlobalPtr;
+typedef const HcTw __attribute__((address_space(4))) *HcTwConstPtr;
 #define HC_TW_LOAD(p, i) (*((HcTwGlobalPtr)(p) + (i)))
+#define HC_TW_LOADK(p, i) (*((HcTwConstPtr)(p) + (i)))
 #else
 #define HC_TW_LOAD(p, i) ((p)[i])
+#define HC_TW_LOADK(p, i) ((p)[i])
 #endif
 // Tables the kernels only read - twiddles, the per-modulus rows of HcRowMod, the extension's constants - are read through the CONSTANT address space: a load whose address is
 // uniform then goes through the scalar cache into SGPRs whatever else the kernel does. As global-memory loads they depend on the compiler proving that no store of the kernel
@@ -200,73 +203,76 @@ __device__ __forceinline__ T hc_const_copy(const T *p) {
 #endif
     return r;
 }
-struct HcRowsTwA { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return HC_TW_LOAD(p, slot); } };
-struct HcRowsTwB { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { return HC_TW_LOAD(p, slot * 16); } };
+// KC: through the CONSTANT address space (the batched multi-modulus kernels, whose 32-bit and 64-bit bodies sit side by side: hc_const_copy). The convolution's kernels keep
+// global loads: as constant-memory loads their twiddle fetches may be hoisted anywhere, and hc_k_b3 / hc_k_b5m - two transforms each - then spill 430-530 bytes (-19 % conv/s)
+template <bool KC = false> struct HcRowsTwA { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { if (KC) return HC_TW_LOADK(p, slot); else return HC_TW_LOAD(p, slot); } };
+template <bool KC = false> struct HcRowsTwB { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { if (KC) return HC_TW_LOADK(p, slot * 16); else return HC_TW_LOAD(p, slot * 16); } };
 
 // forward rows pass on registers: in  e[hi] = element (row, hi*16+tid)  [lazy < 4q]
 //                                 out e[lo] = element (row, tid*16+lo)  [lazy, bound per forward mode]
-template <int FM>
+template <int FM, bool KC = false>
 __device__ __forceinline__ void hc_rows_fwd(u64 (&e)[16], u64 *lds, const HcTwTab &T, int row, int rloc, int tid, const HcQ &Q) {
-    hc_ct_round<FM>(e, HcRowsTwA{T.rowsA + row * 16}, Q);
+    hc_ct_round<FM>(e, HcRowsTwA<KC>{T.rowsA + row * 16}, Q);
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) lds[hc_rows_lds(rloc, hi * 16 + tid)] = e[hi];
     HC_ROW_SYNC();
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = lds[hc_rows_lds(rloc, tid * 16 + lo)];
-    hc_ct_round<FM>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, Q);
+    hc_ct_round<FM>(e, HcRowsTwB<KC>{T.rowsB + row * 256 + tid}, Q);
 }
 // inverse rows pass: in e[lo] = (row, tid*16+lo) [lazy < 4q]; out e[hi] = (row, hi*16+tid) [lazy < 4q]
+template <bool KC = false>
 __device__ __forceinline__ void hc_rows_inv(u64 (&e)[16], u64 *lds, const HcTwTab &T, int row, int rloc, int tid, const HcQ &Q) {
-    hc_gs_round<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, Q, T.ninv, T.ninv);
+    hc_gs_round<false>(e, HcRowsTwB<KC>{T.rowsB + row * 256 + tid}, Q, T.ninv, T.ninv);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) lds[hc_rows_lds(rloc, tid * 16 + lo)] = e[lo];
     HC_ROW_SYNC();
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = lds[hc_rows_lds(rloc, hi * 16 + tid)];
-    hc_gs_round<false>(e, HcRowsTwA{T.rowsA + row * 16}, Q, T.ninv, T.ninv);
+    hc_gs_round<false>(e, HcRowsTwA<KC>{T.rowsA + row * 16}, Q, T.ninv, T.ninv);
 }
 // forward cols pass: in e[hi] = (hi*16+tid, c); out e[lo] = (tid*16+lo, c) [lazy, bounds per forward mode]
-template <int FM>
+template <int FM, bool KC = false>
 __device__ __forceinline__ void hc_cols_fwd(u64 (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, const HcQ &Q) {
-    hc_ct_round<FM>(e, HcRowsTwA{T.colsA}, Q);
+    hc_ct_round<FM>(e, HcRowsTwA<KC>{T.colsA}, Q);
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) lds[hc_cols_lds(hi * 16 + tid, c)] = e[hi];
     __syncthreads();
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = lds[hc_cols_lds(tid * 16 + lo, c)];
-    hc_ct_round<FM>(e, HcRowsTwB{T.colsB + tid}, Q);
+    hc_ct_round<FM>(e, HcRowsTwB<KC>{T.colsB + tid}, Q);
 }
 // inverse cols pass incl. N^-1 (SCALE = false: without it, for callers that folded N^-1 into a fixed multiplicand upstream):
 // in e[lo] = (tid*16+lo, c) [lazy < 4q]; out e[hi] = (hi*16+tid, c) [lazy < 4q]
-template <bool SCALE = true>
+template <bool SCALE = true, bool KC = false>
 __device__ __forceinline__ void hc_cols_inv(u64 (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, const HcQ &Q) {
-    hc_gs_round<false>(e, HcRowsTwB{T.colsB + tid}, Q, T.ninv, T.ninv);
+    hc_gs_round<false>(e, HcRowsTwB<KC>{T.colsB + tid}, Q, T.ninv, T.ninv);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) lds[hc_cols_lds(tid * 16 + lo, c)] = e[lo];
     __syncthreads();
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = lds[hc_cols_lds(hi * 16 + tid, c)];
-    hc_gs_round<SCALE>(e, HcRowsTwA{T.colsA}, Q, T.ninv, T.w_last_ninv);
+    hc_gs_round<SCALE>(e, HcRowsTwA<KC>{T.colsA}, Q, T.ninv, T.w_last_ninv);
 }
 
 // fp64 forms of the two inverse passes (same data movement; LDS carries the doubles' bit patterns)
 __device__ __forceinline__ void hc_rows_inv_f64(double (&e)[16], u64 *lds, const HcTwTab &T, int row, int rloc, int tid, HcF64Mod m) {
-    hc_gs_round_f64<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, m, T.ninv, T.ninv);
+    hc_gs_round_f64<false>(e, HcRowsTwB<false>{T.rowsB + row * 256 + tid}, m, T.ninv, T.ninv);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) lds[hc_rows_lds(rloc, tid * 16 + lo)] = hc_d2u(e[lo]);
     HC_ROW_SYNC();
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = hc_u2d(lds[hc_rows_lds(rloc, hi * 16 + tid)]);
-    hc_gs_round_f64<false>(e, HcRowsTwA{T.rowsA + row * 16}, m, T.ninv, T.ninv);
+    hc_gs_round_f64<false>(e, HcRowsTwA<false>{T.rowsA + row * 16}, m, T.ninv, T.ninv);
 }
 __device__ __forceinline__ void hc_cols_inv_f64(double (&e)[16], u64 *lds, const HcTwTab &T, int c, int tid, HcF64Mod m) {
-    hc_gs_round_f64<false>(e, HcRowsTwB{T.colsB + tid}, m, T.ninv, T.ninv);
+    hc_gs_round_f64<false>(e, HcRowsTwB<false>{T.colsB + tid}, m, T.ninv, T.ninv);
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) lds[hc_cols_lds(tid * 16 + lo, c)] = hc_d2u(e[lo]);
     __syncthreads();
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = hc_u2d(lds[hc_cols_lds(hi * 16 + tid, c)]);
-    hc_gs_round_f64<true>(e, HcRowsTwA{T.colsA}, m, T.ninv, T.w_last_ninv);
+    hc_gs_round_f64<true>(e, HcRowsTwA<false>{T.colsA}, m, T.ninv, T.w_last_ninv);
 }
 
 // rows tile <-> "linear" order (thread t holds column t of the 16 rows; k = local row) through LDS
@@ -336,28 +342,29 @@ __device__ __forceinline__ void hc_xchg32(u64 (&e)[16], u32 *lds, WA wa, RA ra, 
 #pragma unroll
     for (int i = 0; i < 16; i++) e[i] = ((u64)lds[ra(i)] << 32) | lo[i];
 }
-template <int FM>
+template <int FM, bool KC = false>
 __device__ __forceinline__ void hc_rows_fwd(u64 (&e)[16], u32 *lds, const HcTwTab &T, int row, int rloc, int tid, const HcQ &Q) {
-    hc_ct_round<FM>(e, HcRowsTwA{T.rowsA + row * 16}, Q);
+    hc_ct_round<FM>(e, HcRowsTwA<KC>{T.rowsA + row * 16}, Q);
     hc_xchg32(e, lds, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [] { HC_ROW_SYNC(); });
-    hc_ct_round<FM>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, Q);
+    hc_ct_round<FM>(e, HcRowsTwB<KC>{T.rowsB + row * 256 + tid}, Q);
 }
+template <bool KC = false>
 __device__ __forceinline__ void hc_rows_inv(u64 (&e)[16], u32 *lds, const HcTwTab &T, int row, int rloc, int tid, const HcQ &Q) {
-    hc_gs_round<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, Q, T.ninv, T.ninv);
+    hc_gs_round<false>(e, HcRowsTwB<KC>{T.rowsB + row * 256 + tid}, Q, T.ninv, T.ninv);
     hc_xchg32(e, lds, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [] { HC_ROW_SYNC(); });
-    hc_gs_round<false>(e, HcRowsTwA{T.rowsA + row * 16}, Q, T.ninv, T.ninv);
+    hc_gs_round<false>(e, HcRowsTwA<KC>{T.rowsA + row * 16}, Q, T.ninv, T.ninv);
 }
-template <int FM>
+template <int FM, bool KC = false>
 __device__ __forceinline__ void hc_cols_fwd(u64 (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, const HcQ &Q) {
-    hc_ct_round<FM>(e, HcRowsTwA{T.colsA}, Q);
+    hc_ct_round<FM>(e, HcRowsTwA<KC>{T.colsA}, Q);
     hc_xchg32(e, lds, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [] { __syncthreads(); });
-    hc_ct_round<FM>(e, HcRowsTwB{T.colsB + tid}, Q);
+    hc_ct_round<FM>(e, HcRowsTwB<KC>{T.colsB + tid}, Q);
 }
-template <bool SCALE = true>
+template <bool SCALE = true, bool KC = false>
 __device__ __forceinline__ void hc_cols_inv(u64 (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, const HcQ &Q) {
-    hc_gs_round<false>(e, HcRowsTwB{T.colsB + tid}, Q, T.ninv, T.ninv);
+    hc_gs_round<false>(e, HcRowsTwB<KC>{T.colsB + tid}, Q, T.ninv, T.ninv);
     hc_xchg32(e, lds, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [] { __syncthreads(); });
-    hc_gs_round<SCALE>(e, HcRowsTwA{T.colsA}, Q, T.ninv, T.w_last_ninv);
+    hc_gs_round<SCALE>(e, HcRowsTwA<KC>{T.colsA}, Q, T.ninv, T.w_last_ninv);
 }
 // fp64 forms: the doubles travel as their bit patterns
 template <class WA, class RA, class SY>
@@ -370,14 +377,14 @@ __device__ __forceinline__ void hc_xchg32_f64(double (&f)[16], u32 *lds, WA wa, 
     for (int i = 0; i < 16; i++) f[i] = hc_u2d(b[i]);
 }
 __device__ __forceinline__ void hc_rows_inv_f64(double (&e)[16], u32 *lds, const HcTwTab &T, int row, int rloc, int tid, HcF64Mod m) {
-    hc_gs_round_f64<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, m, T.ninv, T.ninv);
+    hc_gs_round_f64<false>(e, HcRowsTwB<false>{T.rowsB + row * 256 + tid}, m, T.ninv, T.ninv);
     hc_xchg32_f64(e, lds, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [] { HC_ROW_SYNC(); });
-    hc_gs_round_f64<false>(e, HcRowsTwA{T.rowsA + row * 16}, m, T.ninv, T.ninv);
+    hc_gs_round_f64<false>(e, HcRowsTwA<false>{T.rowsA + row * 16}, m, T.ninv, T.ninv);
 }
 __device__ __forceinline__ void hc_cols_inv_f64(double (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, HcF64Mod m) {
-    hc_gs_round_f64<false>(e, HcRowsTwB{T.colsB + tid}, m, T.ninv, T.ninv);
+    hc_gs_round_f64<false>(e, HcRowsTwB<false>{T.colsB + tid}, m, T.ninv, T.ninv);
     hc_xchg32_f64(e, lds, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [] { __syncthreads(); });
-    hc_gs_round_f64<true>(e, HcRowsTwA{T.colsA}, m, T.ninv, T.w_last_ninv);
+    hc_gs_round_f64<true>(e, HcRowsTwA<false>{T.colsA}, m, T.ninv, T.w_last_ninv);
 }
 __device__ __forceinline__ void hc_rows_lin_to_lo(u64 (&e)[16], u32 *lds, int t, int rloc, int tid) {
     hc_xchg32(e, lds, [&](int k) { return hc_rows_lds32(k, t); }, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [] { __syncthreads(); });
@@ -458,27 +465,27 @@ __device__ __forceinline__ void hc_xchg1(u32 (&e)[16], u32 *lds, WA wa, RA ra, S
 }
 // the passes of hc_rows_fwd / hc_rows_inv / hc_cols_fwd / hc_cols_inv above on 32-bit residues: same element orders, same LDS address functions (4-byte words)
 __device__ __forceinline__ void hc_rows_fwd32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int row, int rloc, int tid, u32 q) {
-    hc_ct_round32(e, HcRowsTwA{T.rowsA + row * 16}, q);
+    hc_ct_round32(e, HcRowsTwA<true>{T.rowsA + row * 16}, q);
     hc_xchg1(e, lds, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [] { HC_ROW_SYNC(); });
-    hc_ct_round32(e, HcRowsTwB{T.rowsB + row * 256 + tid}, q);
+    hc_ct_round32(e, HcRowsTwB<true>{T.rowsB + row * 256 + tid}, q);
 }
 __device__ __forceinline__ void hc_rows_inv32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int row, int rloc, int tid, u32 q) {
     const HcTw32 ni = hc_tw32(T.ninv);
-    hc_gs_round32<false>(e, HcRowsTwB{T.rowsB + row * 256 + tid}, q, ni, ni);
+    hc_gs_round32<false>(e, HcRowsTwB<true>{T.rowsB + row * 256 + tid}, q, ni, ni);
     hc_xchg1(e, lds, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [] { HC_ROW_SYNC(); });
-    hc_gs_round32<false>(e, HcRowsTwA{T.rowsA + row * 16}, q, ni, ni);
+    hc_gs_round32<false>(e, HcRowsTwA<true>{T.rowsA + row * 16}, q, ni, ni);
 }
 __device__ __forceinline__ void hc_cols_fwd32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, u32 q) {
-    hc_ct_round32(e, HcRowsTwA{T.colsA}, q);
+    hc_ct_round32(e, HcRowsTwA<true>{T.colsA}, q);
     hc_xchg1(e, lds, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [] { __syncthreads(); });
-    hc_ct_round32(e, HcRowsTwB{T.colsB + tid}, q);
+    hc_ct_round32(e, HcRowsTwB<true>{T.colsB + tid}, q);
 }
 template <bool SCALE = true>
 __device__ __forceinline__ void hc_cols_inv32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, u32 q) {
     const HcTw32 ni = hc_tw32(T.ninv);
-    hc_gs_round32<false>(e, HcRowsTwB{T.colsB + tid}, q, ni, ni);
+    hc_gs_round32<false>(e, HcRowsTwB<true>{T.colsB + tid}, q, ni, ni);
     hc_xchg1(e, lds, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [] { __syncthreads(); });
-    hc_gs_round32<SCALE>(e, HcRowsTwA{T.colsA}, q, ni, hc_tw32(T.w_last_ninv));
+    hc_gs_round32<SCALE>(e, HcRowsTwA<true>{T.colsA}, q, ni, hc_tw32(T.w_last_ninv));
 }
 __device__ __forceinline__ void hc_rows_lin_to_lo32(u32 (&e)[16], u32 *lds, int t, int rloc, int tid) {
     hc_xchg1(e, lds, [&](int k) { return hc_rows_lds32(k, t); }, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [] { __syncthreads(); });
@@ -1920,7 +1927,7 @@ __device__ __forceinline__ void hc_cols_fwd_mm_big(const u64 *in, u64 *out, hc_m
         for (int hi = 0; hi < 16; hi++) e[hi] = hc_ldp(in + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(hi * 16 + tid) * 256, in32);
     }
     const HcQ Qf = hc_q(R.q);
-    hc_cols_fwd<HC_FM_ALT>(e, lds, R.fwd, c, tid, Qf);
+    hc_cols_fwd<HC_FM_ALT, true>(e, lds, R.fwd, c, tid, Qf);
     if (A.pk_out && HC_SMALL_Q(R.q)) {                                        // block-uniform: the seam row as 4-byte words (lazy values < 8q -> < 2q < 2^32)
 #pragma unroll
         for (int lo = 0; lo < 16; lo++) hc_st32(out + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(tid * 16 + lo) * 256, hc_fold(hc_fold(e[lo], Qf.nq4), Qf.nq2));
@@ -2015,7 +2022,7 @@ __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_RF) void hc_k_rows_fwd_canon_mm
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) e[hi] = hc_ldp(in + pbase, (size_t)row * 256 + hi * 16 + tid, A.pk_in && small);
     const HcQ Q = hc_q(rq);
-    hc_rows_fwd<HC_FM_ALT>(e, lds, R.fwd, row, rloc, tid, Q);
+    hc_rows_fwd<HC_FM_ALT, true>(e, lds, R.fwd, row, rloc, tid, Q);
     HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     hc_rows_lo_to_lin(e, lds, t, rloc, tid);
 #pragma unroll
@@ -2132,7 +2139,7 @@ __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_INV) void hc_k_rows_inv_mm(cons
     hc_rows_lin_to_lo(e, lds, t, rloc, tid);
     HC_ROW_SYNC();        // row-local: the reads before and the writes after stay inside the 16 lanes of a row
     const HcQ Q = hc_q(R.q);
-    hc_rows_inv(e, lds, R.inv, row, rloc, tid, Q);
+    hc_rows_inv<true>(e, lds, R.inv, row, rloc, tid, Q);
     if (A.pk_out && HC_SMALL_Q(R.q)) {                                       // block-uniform: the seam row as 4-byte words (lazy values < 4q -> < 2q < 2^32)
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) hc_st32(out + pbase, (size_t)row * 256 + hi * 16 + tid, hc_fold(e[hi], Q.nq2));
@@ -2149,7 +2156,7 @@ __device__ __forceinline__ void hc_cols_inv_canon_mm_body(const u64 *in, u64 *ou
 #pragma unroll
     for (int lo = 0; lo < 16; lo++) e[lo] = IN32 ? hc_ld32(in + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(tid * 16 + lo) * 256) : in[base + (size_t)(tid * 16 + lo) * 256];
     const HcQ Q = hc_q(R.q);
-    hc_cols_inv(e, lds, R.inv, c, tid, Q);
+    hc_cols_inv<true, true>(e, lds, R.inv, c, tid, Q);
     if (out32) {                                                              // uniform: a caller's coefficient-domain polynomial under pack32 = 2 (hc_lv_intt)
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) hc_st32(out + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(hi * 16 + tid) * 256, hc_canon4(e[hi], Q));
