@@ -62,6 +62,11 @@ struct HcTwTab {
     HcTw w_last_ninv;    // inverse colsA slot 0 multiplied by N^-1
 };
 
+// The same tables for a modulus below 2^31 as 8-byte entries (low word of w, high word of w' = floor(w 2^32 / q)): what the 32-bit form of the batched transforms reads
+// (HC_S32). Half the table bytes: a rows pass reads 4 KB of 16-byte twiddles per 2 KB (1 KB as 4-byte words) row of data.
+struct __attribute__((aligned(8))) HcTw32 { u32 w, ws; };
+struct HcTwTab32 { const HcTw32 *rowsA, *rowsB, *colsA, *colsB; };
+
 // ---------------------------------------------------------------- radix-16 rounds
 // Slot numbering: a 4-stage round has 1+2+4+8 twiddles; the stage with 2^s twiddles uses slots (2^s - 1 + g).
 // Forward rounds walk s = 0..3 (distance 8,4,2,1); inverse rounds walk distance 1,2,4,8 (s = 3..0).
@@ -410,7 +415,6 @@ __device__ __forceinline__ u64 hc_barrett64(u64 x, u64 q, u64 mu) {
 #ifndef HC_S32
 #define HC_S32 1
 #endif
-struct HcTw32 { u32 w, ws; };
 __device__ __forceinline__ HcTw32 hc_tw32(const HcTw &t) { return HcTw32{(u32)t.w, (u32)(t.ws >> 32)}; }
 __device__ __forceinline__ u32 hc_umulhi32(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
 __device__ __forceinline__ u32 hc_min32(u32 a, u32 b) { return a < b ? a : b; }
@@ -425,7 +429,7 @@ __device__ __forceinline__ void hc_ct_round32(u32 (&e)[16], const TW &tw, u32 q)
         const int half = 8 >> s;
 #pragma unroll
         for (int g = 0; g < (1 << s); g++) {
-            const HcTw32 w = hc_tw32(tw((1 << s) - 1 + g));
+            const HcTw32 w = tw((1 << s) - 1 + g);
 #pragma unroll
             for (int k = 0; k < half; k++) {
                 const int a = g * 2 * half + k, b = a + half;
@@ -443,7 +447,7 @@ __device__ __forceinline__ void hc_gs_round32(u32 (&e)[16], const TW &tw, u32 q,
         const int dist = 1 << s;
 #pragma unroll
         for (int g = 0; g < (8 >> s); g++) {
-            HcTw32 w = hc_tw32(tw((8 >> s) - 1 + g));
+            HcTw32 w = tw((8 >> s) - 1 + g);
             if (LAST && s == 3) w = w_last;
 #pragma unroll
             for (int k = 0; k < dist; k++) {
@@ -463,29 +467,35 @@ __device__ __forceinline__ void hc_xchg1(u32 (&e)[16], u32 *lds, WA wa, RA ra, S
 #pragma unroll
     for (int i = 0; i < 16; i++) e[i] = lds[ra(i)];
 }
-// the passes of hc_rows_fwd / hc_rows_inv / hc_cols_fwd / hc_cols_inv above on 32-bit residues: same element orders, same LDS address functions (4-byte words)
-__device__ __forceinline__ void hc_rows_fwd32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int row, int rloc, int tid, u32 q) {
-    hc_ct_round32(e, HcRowsTwA<true>{T.rowsA + row * 16}, q);
+// the passes of hc_rows_fwd / hc_rows_inv / hc_cols_fwd / hc_cols_inv above on 32-bit residues: same element orders, same LDS address functions (4-byte words); twiddles from the
+// 8-byte tables, through the constant address space
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HC_TW32_LOADK(p, i) (*((const HcTw32 __attribute__((address_space(4))) *)(p) + (i)))
+#else
+#define HC_TW32_LOADK(p, i) ((p)[i])
+#endif
+struct HcRowsTw32A { const HcTw32 *p; __device__ __forceinline__ HcTw32 operator()(int slot) const { return HC_TW32_LOADK(p, slot); } };
+struct HcRowsTw32B { const HcTw32 *p; __device__ __forceinline__ HcTw32 operator()(int slot) const { return HC_TW32_LOADK(p, slot * 16); } };
+__device__ __forceinline__ void hc_rows_fwd32(u32 (&e)[16], u32 *lds, const HcTwTab32 &T, int row, int rloc, int tid, u32 q) {
+    hc_ct_round32(e, HcRowsTw32A{T.rowsA + row * 16}, q);
     hc_xchg1(e, lds, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [] { HC_ROW_SYNC(); });
-    hc_ct_round32(e, HcRowsTwB<true>{T.rowsB + row * 256 + tid}, q);
+    hc_ct_round32(e, HcRowsTw32B{T.rowsB + row * 256 + tid}, q);
 }
-__device__ __forceinline__ void hc_rows_inv32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int row, int rloc, int tid, u32 q) {
-    const HcTw32 ni = hc_tw32(T.ninv);
-    hc_gs_round32<false>(e, HcRowsTwB<true>{T.rowsB + row * 256 + tid}, q, ni, ni);
+__device__ __forceinline__ void hc_rows_inv32(u32 (&e)[16], u32 *lds, const HcTwTab32 &T, HcTw32 ni, int row, int rloc, int tid, u32 q) {
+    hc_gs_round32<false>(e, HcRowsTw32B{T.rowsB + row * 256 + tid}, q, ni, ni);
     hc_xchg1(e, lds, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [] { HC_ROW_SYNC(); });
-    hc_gs_round32<false>(e, HcRowsTwA<true>{T.rowsA + row * 16}, q, ni, ni);
+    hc_gs_round32<false>(e, HcRowsTw32A{T.rowsA + row * 16}, q, ni, ni);
 }
-__device__ __forceinline__ void hc_cols_fwd32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, u32 q) {
-    hc_ct_round32(e, HcRowsTwA<true>{T.colsA}, q);
+__device__ __forceinline__ void hc_cols_fwd32(u32 (&e)[16], u32 *lds, const HcTwTab32 &T, int c, int tid, u32 q) {
+    hc_ct_round32(e, HcRowsTw32A{T.colsA}, q);
     hc_xchg1(e, lds, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [] { __syncthreads(); });
-    hc_ct_round32(e, HcRowsTwB<true>{T.colsB + tid}, q);
+    hc_ct_round32(e, HcRowsTw32B{T.colsB + tid}, q);
 }
 template <bool SCALE = true>
-__device__ __forceinline__ void hc_cols_inv32(u32 (&e)[16], u32 *lds, const HcTwTab &T, int c, int tid, u32 q) {
-    const HcTw32 ni = hc_tw32(T.ninv);
-    hc_gs_round32<false>(e, HcRowsTwB<true>{T.colsB + tid}, q, ni, ni);
+__device__ __forceinline__ void hc_cols_inv32(u32 (&e)[16], u32 *lds, const HcTwTab32 &T, HcTw32 ni, HcTw32 w_last_ninv, int c, int tid, u32 q) {
+    hc_gs_round32<false>(e, HcRowsTw32B{T.colsB + tid}, q, ni, ni);
     hc_xchg1(e, lds, [&](int lo) { return hc_cols_lds32(tid * 16 + lo, c); }, [&](int hi) { return hc_cols_lds32(hi * 16 + tid, c); }, [] { __syncthreads(); });
-    hc_gs_round32<SCALE>(e, HcRowsTwA<true>{T.colsA}, q, ni, hc_tw32(T.w_last_ninv));
+    hc_gs_round32<SCALE>(e, HcRowsTw32A{T.colsA}, q, ni, w_last_ninv);
 }
 __device__ __forceinline__ void hc_rows_lin_to_lo32(u32 (&e)[16], u32 *lds, int t, int rloc, int tid) {
     hc_xchg1(e, lds, [&](int k) { return hc_rows_lds32(k, t); }, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [] { __syncthreads(); });
@@ -1813,12 +1823,14 @@ __device__ __forceinline__ void hc_basis_ext_tile32(u32 (&e)[16], const u64 *yv,
     }
 }
 struct HcRowMod { HcTwTab fwd, inv; u64 q, mu;
+                  HcTwTab32 fwd32, inv32;   // moduli below 2^31 (null otherwise)
                   u64 s32; };            // nonzero: the batched transforms take their 32-bit form (HC_S32) for rows of this modulus: q < 2^31 and option small32. (The kernels test
                                          // HC_SMALL_Q(q) && s32: with a purely scalar condition - s32 alone, or a launch argument - around the two bodies the gfx950 backend of ROCm 7.2 dies, "illegal VGPR to SGPR copy")
 // blockIdx.z = operand + nz * image: `nz` operands zs_* words apart (the two polynomials of a ciphertext, the digits of a key switch), and the
 // images of a batch (hc_set_batch) is_* words apart
 struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; int z_alpha; int nz; size_t is_in, is_out;
               int xcd, nzn;                  // rows passes: XCD-aware 1-D grid over nzn = nz * images operands (HC_MM_PROLOGUE_ROWS)
+              int out_gap;                   // hc_k_cols_inv_canon_mm: > 0: row y of the output goes to row y + y / out_gap (one free row after every out_gap rows: the v row of a digit's y_i rows)
               int pk_in, pk_out, pk_epi;     // the rows of `in` / `out` / the epilogue's operands (epi_x, epi_add and the result) whose modulus is below 2^31 are 4-byte words
               unsigned char rowlist[48];     // blockIdx.y -> row (rows a launch has nothing to do for are left out of the grid)
 
@@ -1890,7 +1902,7 @@ __device__ __forceinline__ void hc_cols_fwd_mm_small(const u64 *in, u64 *out, u3
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) e[hi] = (u32)in[(size_t)y * 65536 + (size_t)(blockIdx.x * 16 + c) + (size_t)(hi * 16 + tid) * 256];
     }
-    hc_cols_fwd32(e, lds, R.fwd, c, tid, q);
+    hc_cols_fwd32(e, lds, R.fwd32, c, tid, q);
     if (A.pk_out) {
 #pragma unroll
         for (int lo = 0; lo < 16; lo++) hc_st32(out + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(tid * 16 + lo) * 256, e[lo]);
@@ -1962,7 +1974,7 @@ __device__ __forceinline__ void hc_rows_fwd_canon_mm_small(const u64 *in, u64 *o
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) e[hi] = (u32)in[pbase + (size_t)row * 256 + hi * 16 + tid];
     }
-    hc_rows_fwd32(e, lds, R.fwd, row, rloc, tid, q);
+    hc_rows_fwd32(e, lds, R.fwd32, row, rloc, tid, q);
     HC_ROW_SYNC();
     hc_rows_lo_to_lin32(e, lds, t, rloc, tid);
     const size_t lj = (size_t)(bx * 16) * 256 + t;                           // element index of (row bx * 16, column t) inside the limb's row
@@ -2096,7 +2108,7 @@ __device__ __forceinline__ void hc_rows_inv_mm_small(const u64 *in, u64 *out, u3
     }
     hc_rows_lin_to_lo32(e, lds, t, rloc, tid);
     HC_ROW_SYNC();
-    hc_rows_inv32(e, lds, R.inv, row, rloc, tid, q);
+    hc_rows_inv32(e, lds, R.inv32, hc_tw32(R.inv.ninv), row, rloc, tid, q);
     if (A.pk_out) {
 #pragma unroll
         for (int hi = 0; hi < 16; hi++) hc_st32(out + pbase, (size_t)row * 256 + hi * 16 + tid, e[hi]);
@@ -2105,7 +2117,7 @@ __device__ __forceinline__ void hc_rows_inv_mm_small(const u64 *in, u64 *out, u3
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[pbase + (size_t)row * 256 + hi * 16 + tid] = e[hi];
 }
-__device__ __forceinline__ void hc_cols_inv_canon_mm_small(const u64 *in, u64 *out, u32 *lds, const HcMm &A, const HcRowMod &R, int y) {
+__device__ __forceinline__ void hc_cols_inv_canon_mm_small(const u64 *in, u64 *out, u32 *lds, const HcMm &A, const HcRowMod &R, int y, int yo, const HcTw *scale) {
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t pbase = (size_t)y * 65536, col = (size_t)(blockIdx.x * 16 + c);
     const u32 q = (u32)R.q;
@@ -2117,14 +2129,20 @@ __device__ __forceinline__ void hc_cols_inv_canon_mm_small(const u64 *in, u64 *o
 #pragma unroll
         for (int lo = 0; lo < 16; lo++) e[lo] = (u32)in[pbase + col + (size_t)(tid * 16 + lo) * 256];
     }
-    hc_cols_inv32(e, lds, R.inv, c, tid, q);
+    hc_cols_inv32(e, lds, R.inv32, hc_tw32(R.inv.ninv), hc_tw32(R.inv.w_last_ninv), c, tid, q);
+    if (scale != nullptr) {                                                   // uniform: y_i = x_i (S/s_i)^-1 (hc_cols_inv_canon_mm_body)
+        const HcTw32 w = hc_tw32(HC_TW_LOADK(scale, 0));
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) e[hi] = hc_mul32(e[hi], w, q);
+    }
+    const size_t obase = (size_t)yo * 65536;
     if (A.pk_out) {
 #pragma unroll
-        for (int hi = 0; hi < 16; hi++) hc_st32(out + pbase, col + (size_t)(hi * 16 + tid) * 256, e[hi]);
+        for (int hi = 0; hi < 16; hi++) hc_st32(out + obase, col + (size_t)(hi * 16 + tid) * 256, e[hi]);
         return;
     }
 #pragma unroll
-    for (int hi = 0; hi < 16; hi++) out[pbase + col + (size_t)(hi * 16 + tid) * 256] = e[hi];
+    for (int hi = 0; hi < 16; hi++) out[obase + col + (size_t)(hi * 16 + tid) * 256] = e[hi];
 }
 __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_INV) void hc_k_rows_inv_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ hc_mm_lds_t lds[HC_ROWS_LDS];
@@ -2148,8 +2166,10 @@ __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_INV) void hc_k_rows_inv_mm(cons
 #pragma unroll
     for (int hi = 0; hi < 16; hi++) out[pbase + (size_t)row * 256 + hi * 16 + tid] = e[hi];
 }
+// scale != null: the coefficients leave multiplied by that constant of the row's modulus - the source side of the basis extension, y_i = x_i (S/s_i)^-1 mod s_i, taken here
+// where x_i is in registers instead of in a pass of its own over memory (hc_k_basis_v then only adds the v row); yo: the row of `out` the result goes to
 template <bool IN32>
-__device__ __forceinline__ void hc_cols_inv_canon_mm_body(const u64 *in, u64 *out, hc_mm_lds_t *lds, const HcRowMod &R, int y, bool out32) {
+__device__ __forceinline__ void hc_cols_inv_canon_mm_body(const u64 *in, u64 *out, hc_mm_lds_t *lds, const HcRowMod &R, int y, int yo, bool out32, const HcTw *scale) {
     const int t = threadIdx.x, c = t & 15, tid = t >> 4;
     const size_t base = (size_t)y * 65536 + blockIdx.x * 16 + c;
     u64 e[16];
@@ -2157,21 +2177,32 @@ __device__ __forceinline__ void hc_cols_inv_canon_mm_body(const u64 *in, u64 *ou
     for (int lo = 0; lo < 16; lo++) e[lo] = IN32 ? hc_ld32(in + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(tid * 16 + lo) * 256) : in[base + (size_t)(tid * 16 + lo) * 256];
     const HcQ Q = hc_q(R.q);
     hc_cols_inv<true, true>(e, lds, R.inv, c, tid, Q);
+    if (scale != nullptr) {                                                   // uniform
+        const HcTw w = HC_TW_LOADK(scale, 0);
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) e[hi] = hc_mul_shoup(e[hi], w.w, w.ws, R.q);
+    } else {
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) e[hi] = hc_canon4(e[hi], Q);
+    }
     if (out32) {                                                              // uniform: a caller's coefficient-domain polynomial under pack32 = 2 (hc_lv_intt)
 #pragma unroll
-        for (int hi = 0; hi < 16; hi++) hc_st32(out + (size_t)y * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(hi * 16 + tid) * 256, hc_canon4(e[hi], Q));
+        for (int hi = 0; hi < 16; hi++) hc_st32(out + (size_t)yo * 65536, (size_t)(blockIdx.x * 16 + c) + (size_t)(hi * 16 + tid) * 256, e[hi]);
         return;
     }
+    const size_t obase = (size_t)yo * 65536 + blockIdx.x * 16 + c;
 #pragma unroll
-    for (int hi = 0; hi < 16; hi++) out[base + (size_t)(hi * 16 + tid) * 256] = hc_canon4(e[hi], Q);
+    for (int hi = 0; hi < 16; hi++) out[obase + (size_t)(hi * 16 + tid) * 256] = e[hi];
 }
 __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_INV) void hc_k_cols_inv_canon_mm(const u64 *in, u64 *out, HcMm A) {
     __shared__ hc_mm_lds_t lds[HC_COLS_LDS];
     HC_MM_PROLOGUE
     const bool small = HC_SMALL_Q(R.q);
-    if (HC_S32 && small && R.s32) hc_cols_inv_canon_mm_small(in, out, reinterpret_cast<u32 *>(lds), A, R, y);      // block-uniform
-    else if (A.pk_in && small) hc_cols_inv_canon_mm_body<true>(in, out, lds, R, y, A.pk_out && small);
-    else hc_cols_inv_canon_mm_body<false>(in, out, lds, R, y, A.pk_out && small);
+    const int yo = A.out_gap > 0 ? y + y / A.out_gap : y;
+    const HcTw *scale = A.epi_mul != nullptr ? A.epi_mul + y : nullptr;
+    if (HC_S32 && small && R.s32) hc_cols_inv_canon_mm_small(in, out, reinterpret_cast<u32 *>(lds), A, R, y, yo, scale);      // block-uniform
+    else if (A.pk_in && small) hc_cols_inv_canon_mm_body<true>(in, out, lds, R, y, yo, A.pk_out && small, scale);
+    else hc_cols_inv_canon_mm_body<false>(in, out, lds, R, y, yo, A.pk_out && small, scale);
 }
 // ModDown fused with the Rescale behind it (hc_keyswitch_add_rescale), the last limb L. Rescale needs the coefficients of c_L = (acc_L - NTT(ext_L)) / P + add_L:
 // by linearity InvNTT(acc_L / P + add_L) - ext_L / P, ext_L being the coefficient-domain extension the y_i / v rows give. acc_L <- acc_L / P + add_L where the inner product writes that row (hc_k_ks_mac_all, HcMacPrep; hc_k_mdrs_prep for an acc that comes from elsewhere), in
@@ -2219,6 +2250,20 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_yv(const u64 *src, size_t s
             u64 *tu = const_cast<u64 *>(src) - src_stride + j;
             *tu = hc_submod(*tu, hc_mul_shoup(hc_basis_ext_sum<8>(yy, BL, QL), wL.w, wL.ws, BL.t), BL.t);
         }
+    }
+}
+// The v row alone, for y_i rows the inverse transform already left in place (hc_cols_inv_canon_mm_body's scale): v = uint64(sum_i float64(y_i) / float64(s_i)), limb order,
+// exactly hc_k_basis_yv's sum. yv: [operand + nz * image][yv_rows][N]; rows 0..n-1 are read, row n is written. grid = (HC_GX_YV, nz * images)
+__global__ __launch_bounds__(HC_TPB) void hc_k_basis_v(u64 *yv, int yv_rows, const HcBasisExt *Bs, int rows, int z_alpha, int nz) {
+    const int zi = (int)blockIdx.y % nz;
+    const HcBasisExt &B0 = Bs[z_alpha > 0 ? (size_t)zi * rows : 0];
+    const int n = B0.n;
+    yv += (size_t)blockIdx.y * yv_rows * 65536;
+    for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        double vi = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i < n) vi += (double)yv[(size_t)i * 65536 + j] / (double)B0.s[i];
+        yv[(size_t)n * 65536 + j] = (u64)vi;
     }
 }
 // The inner product of a key switch in one launch, BOTH key components and ALL images of a batch per thread:

@@ -96,6 +96,7 @@ struct HcModHost {
     HcMod m;
     u64 psi, psi_inv;
     HcTwTab fwd, inv;            // device tables
+    HcTwTab32 fwd32 = {nullptr, nullptr, nullptr, nullptr}, inv32 = {nullptr, nullptr, nullptr, nullptr};     // moduli below 2^31: the same tables as 8-byte entries (HC_S32)
     HcTwTab inv_f64;             // moduli below 2^49: the inverse tables as {w, w/q} doubles (fp64 inverse transform of loop A)
     std::vector<void *> allocs;
 };
@@ -121,7 +122,7 @@ struct hc_ctx {
     HcRowMod *d_rowmods = nullptr;                          // per modulus: both twiddle tables + q, mu (multi-modulus batched transforms)
     u64 *ws_mm = nullptr; size_t ws_mm_rows = 0;            // scratch of the batched key switch / rescale
     u64 *ws_accm = nullptr; size_t ws_accm_rows = 0;        // inner products of several hoisted rotations (hc_keyswitch_qp_rotate_many)
-    struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr, *pmod = nullptr, *pinv_qlinv = nullptr; };     // pmod: P mod q_i; pinv_qlinv: (P q_level)^-1 mod q_i, i < level
+    struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr, *pmod = nullptr, *pinv_qlinv = nullptr, *yinv = nullptr; };    // yinv[l]: (S/q_l)^-1 mod q_l, S = the product of the limbs of l's digit (the source side of the extension: hc_k_cols_inv_canon_mm's scale); entries nl..nl+alpha-1: the same for the P limbs (ModDown)     // pmod: P mod q_i; pinv_qlinv: (P q_level)^-1 mod q_i, i < level
     std::map<int, KsPlan> ks_plan;                          // per level: basis-extension constants of every (digit, target limb)
     std::map<int, HcTw *> rescale_plan;                     // per level: qL^-1 mod q_i
     int nb = 1; size_t bs_poly = 0, bs_qp = 0;              // image batch of the leveled entry points (hc_set_batch): images, words between the images of a polynomial / of an extended-basis pair
@@ -294,6 +295,13 @@ static int hc_build_tables(hc_ctx *c, HcModHost *mh, bool inverse) {
     T.ninv = h_pair(mh->m.ninv, q);
     T.w_last_ninv = h_pair(h_mulmod(pw[1], mh->m.ninv, q), q);
     if (inverse) mh->inv = T; else mh->fwd = T;
+    if (q < (1ull << 31)) {             // the 8-byte form for the 32-bit transform bodies: floor(floor(w 2^64 / q) / 2^32) = floor(w 2^32 / q)
+        auto narrow = [](const std::vector<HcTw> &v) { std::vector<HcTw32> o(v.size()); for (size_t i = 0; i < v.size(); i++) { o[i].w = (u32)v[i].w; o[i].ws = (u32)(v[i].ws >> 32); } return o; };
+        HcTwTab32 S;
+        HC_TRY(hc_dev_upload(c, mh, narrow(rowsA), &S.rowsA)); HC_TRY(hc_dev_upload(c, mh, narrow(rowsB), &S.rowsB));
+        HC_TRY(hc_dev_upload(c, mh, narrow(colsA), &S.colsA)); HC_TRY(hc_dev_upload(c, mh, narrow(colsB), &S.colsB));
+        if (inverse) mh->inv32 = S; else mh->fwd32 = S;
+    }
     if (inverse && hc_f64_ok(q)) {      // the same table as doubles: {w, w/q} (both exact inputs, one correctly rounded division)
         auto conv = [&](HcTw x) { HcTw y; y.w = hc_d2u((double)x.w); y.ws = hc_d2u((double)x.w / (double)q); return y; };
         for (auto *v : {&rowsA, &rowsB, &colsA, &colsB}) for (auto &x : *v) x = conv(x);
@@ -312,7 +320,7 @@ extern "C" const char *hc_last_error(const hc_ctx *c) { return c ? c->err.c_str(
 // the per-modulus table of the batched transforms (HcRowMod); again after option small32 changes
 static int hc_upload_rowmods(hc_ctx *c) {
     std::vector<HcRowMod> hr;
-    for (auto &mh : c->mods) { HcRowMod r; r.fwd = mh.fwd; r.inv = mh.inv; r.q = mh.m.q; r.mu = mh.m.mu; r.s32 = (c->small32 && mh.m.q < (1ull << 31)) ? 1 : 0; hr.push_back(r); }
+    for (auto &mh : c->mods) { HcRowMod r; r.fwd = mh.fwd; r.inv = mh.inv; r.fwd32 = mh.fwd32; r.inv32 = mh.inv32; r.q = mh.m.q; r.mu = mh.m.mu; r.s32 = (c->small32 && mh.m.q < (1ull << 31)) ? 1 : 0; hr.push_back(r); }
     return hcx_h2d(c, c->d_rowmods, hr.data(), hr.size() * sizeof(HcRowMod)) == hipSuccess ? HC_OK : HC_ERR_HIP;
 }
 extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, const uint64_t *p, int np, int device) {
@@ -624,7 +632,9 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
     return HC_OK;
 }
 // out_user: out is a polynomial of the caller's (hc_lv_intt), not one of the library's coefficient-domain scratch arrays (which keep 8-byte rows under every pack32)
-static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out, int skip_lo = 0, int skip_hi = 0, int n = 1, size_t is_in = 0, size_t is_out = 0, const char *tag = "intt", bool out_user = false) {
+// out_scale / out_gap: the result leaves as the y_i rows of a basis extension (HcMm::out_gap, hc_cols_inv_canon_mm_body)
+static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int z, size_t zs_in, size_t zs_out, int skip_lo = 0, int skip_hi = 0, int n = 1, size_t is_in = 0, size_t is_out = 0, const char *tag = "intt", bool out_user = false,
+                      const HcTw *out_scale = nullptr, int out_gap = 0) {
     HC_TRY(hc_ensure_tmp(c, (size_t)rows * z * n));
     HcMm A; memset(&A, 0, sizeof A); A.M = c->d_rowmods; A.nl = nl; A.nq = c->nq; A.skip_lo = skip_lo; A.skip_hi = skip_hi; A.z_alpha = 0; A.nz = z;
     char n1[48], n2[48]; snprintf(n1, sizeof n1, "%s:rows_inv_mm", tag); snprintf(n2, sizeof n2, "%s:cols_inv_canon_mm", tag);
@@ -636,7 +646,7 @@ static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int 
     A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; A.xcd = c->xcd_rows; A.nzn = z * n;
     A.pk_in = c->pack32 == 2; A.pk_out = c->pack32;                          // the caller's NTT-domain rows; the seam (ws_tmp)
     HC_TRY(hc_launch(c, c->profile ? n1 : "rows_inv_mm", hc_k_rows_inv_mm, A.xcd ? dim3(16u * (unsigned)cnt * (unsigned)(z * n)) : grid, in, c->ws_tmp, A));
-    A.xcd = 0; A.pk_in = c->pack32; A.pk_out = (c->pack32 == 2 && out_user) ? 1 : 0;
+    A.xcd = 0; A.pk_in = c->pack32; A.pk_out = (c->pack32 == 2 && out_user) ? 1 : 0; A.epi_mul = out_scale; A.out_gap = out_gap;
     A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out; HC_TRY(hc_launch(c, c->profile ? n2 : "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
@@ -1255,7 +1265,11 @@ static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
             hd[(size_t)l] = hc_make_bx(psrc, q); hp[(size_t)l] = h_pair(h_inv(pmod, q), q);
             hpm[(size_t)l] = h_pair(pmod, q); hpq[(size_t)l] = l < level ? h_pair(h_inv(h_mulmod(pmod, qL % q, q), q), q) : h_pair(0, q);
         }
+        std::vector<HcTw> hy((size_t)nt);
+        for (int l = 0; l < nl; l++) hy[(size_t)l] = hb[(size_t)(l / alpha) * nt].inv[l % alpha];
+        for (int j = 0; j < alpha; j++) hy[(size_t)(nl + j)] = hd[0].inv[j];
         hc_ctx::KsPlan P;
+        HC_HIP(c, hcx_malloc(c, (void **)&P.yinv, hy.size() * sizeof(HcTw))); HC_HIP(c, hcx_h2d(c, P.yinv, hy.data(), hy.size() * sizeof(HcTw)));
         HC_HIP(c, hcx_malloc(c, (void **)&P.bx, hb.size() * sizeof(HcBasisExt))); HC_HIP(c, hcx_malloc(c, (void **)&P.bxdown, hd.size() * sizeof(HcBasisExt))); HC_HIP(c, hcx_malloc(c, (void **)&P.pinv, hp.size() * sizeof(HcTw)));
         HC_HIP(c, hcx_h2d(c, P.bx, hb.data(), hb.size() * sizeof(HcBasisExt)));
         HC_HIP(c, hcx_h2d(c, P.bxdown, hd.data(), hd.size() * sizeof(HcBasisExt)));
@@ -1285,11 +1299,12 @@ static int hc_ks_scratch(hc_ctx *c, int level, HcKsScratch *S) {
 static int hc_ks_decompose_into(hc_ctx *c, int level, const u64 *cx, const HcKsScratch &S) {
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha, nb = c->nb;
-    HC_TRY(hc_intt_mm(c, cx, S.coef, nl, nl, 1, 0, 0, 0, 0, nb, c->bs_poly, S.coef_is, "decomp"));                    // cxInvNTT, all limbs
-    // source side of every digit's extension once per coefficient (y_i, v), then the target side inside the first pass of the digits' forward transforms (blockIdx.z =
-    // digit + beta * image): the extended digits are never written in the coefficient domain
+    // cxInvNTT, all limbs, leaving the source side of every digit's extension - y_i = x_i (S/s_i)^-1 mod s_i - where the digit's rows go ([digit + beta * image][alpha + 1][N]: limb l
+    // at row l + l / alpha); one pass over them adds the v rows; the target side is taken inside the first pass of the digits' forward transforms (blockIdx.z = digit + beta *
+    // image): neither the coefficients of cx nor the extended digits exist in memory in the coefficient domain
     const size_t yz = (size_t)(alpha + 1) * HC_N;
-    HC_TRY(hc_launch(c, "decomp:basis_yv", hc_k_basis_yv<false>, dim3(HC_GX_YV, (unsigned)(beta * nb)), (const u64 *)S.coef, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bx, nt, (size_t)alpha * HC_N, alpha, beta, S.coef_is, (const HcBasisExt *)nullptr, (const HcTw *)nullptr));
+    HC_TRY(hc_intt_mm(c, cx, S.yv, nl, nl, 1, 0, 0, 0, 0, nb, c->bs_poly, (size_t)beta * yz, "decomp", false, P->yinv, alpha));
+    HC_TRY(hc_launch(c, "decomp:basis_v", hc_k_basis_v, dim3(HC_GX_YV, (unsigned)(beta * nb)), S.yv, alpha + 1, (const HcBasisExt *)P->bx, nt, alpha, beta));
     HcMmFuse F; F.ext_bs = P->bx; F.ext_rows = nt; F.out_packed = true;            // the digits are read by the inner products only (hc_k_ks_mac_all / _multi)
     return hc_ntt_mm(c, S.yv, S.digits, nt, nl, 0, 0, beta, yz, (size_t)nt * HC_N, alpha, nb, (size_t)beta * yz, S.digits_is, "decomp", &F);
 }
@@ -1308,9 +1323,9 @@ static int hc_ks_moddown(hc_ctx *c, int level, const u64 *acc, size_t acc_is, co
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, nb = c->nb;
     // InvNTT of the P rows of both components: rows y -> modulus nq + y (nl = 0)
-    HC_TRY(hc_intt_mm(c, acc + (size_t)nl * HC_N, S.pc, alpha, 0, 2, (size_t)nt * HC_N, (size_t)alpha * HC_N, 0, 0, nb, acc_is, S.pc_is, "moddown"));
     const size_t yz = (size_t)(alpha + 1) * HC_N;
-    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv<false>, dim3(HC_GX_YV, 2u * (unsigned)nb), (const u64 *)S.pc, (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, (size_t)alpha * HC_N, 0, 2, S.pc_is, (const HcBasisExt *)nullptr, (const HcTw *)nullptr));
+    HC_TRY(hc_intt_mm(c, acc + (size_t)nl * HC_N, S.yv, alpha, 0, 2, (size_t)nt * HC_N, yz, 0, 0, nb, acc_is, 2 * yz, "moddown", false, P->yinv + nl, 0));      // as the y_i rows of the extension {P} -> Q (hc_ks_decompose_into)
+    HC_TRY(hc_launch(c, "moddown:basis_v", hc_k_basis_v, dim3(HC_GX_YV, 2u * (unsigned)nb), S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, 0, 2));
     HcMmFuse F; F.ext_bs = P->bxdown; F.ext_rows = nl;            // {P} -> every Q limb inside the forward transform's first pass
     if (rot_gal) {   // a rotation: + c0 and the permutation ride in ModDown's last pass (d0, d1 = the rotated ciphertext)
         HC_TRY(hc_ntt_mm(c, S.yv, S.ext, nl, nl, 0, 0, 2, yz, (size_t)nl * HC_N, 0, nb, 2 * yz, S.ext_is, "moddown", &F));
