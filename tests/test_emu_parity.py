@@ -181,6 +181,20 @@ def test_leveled_entry_points_row_by_row(rows4):
     pc.case_leveled_rows(_rows4 if rows4 else (lambda Q, P: Context(Q, P, lib_path=EMU_LIB)), lambda Q, P: Oracle(q=Q, p=P))
 
 
+def test_transform_bodies_64_bit_for_the_small_limbs():
+    """option small32 = 0: the ~30-bit limbs go through the 64-bit bodies of the batched transforms (the default sends them through the 32-bit bodies, which every other test
+    here exercises): the same residues as the oracle either way"""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+
+    def mk(Q, P):
+        ctx = Context(Q, P, lib_path=EMU_LIB)
+        ctx.set_option("small32", 0)
+        return ctx
+    mo = lambda Q, P: Oracle(q=Q, p=P)
+    pc.case_keyswitch_general(mk, mo, shapes=((3, 2), (4, 5)))
+    pc.case_leveled_rows(mk, mo)
+
+
 @pytest.mark.parametrize("case", ["general", "hoisted", "qp"])
 def test_key_switch_with_four_byte_rows(case):
     """the key-switch cases above, unchanged, on a context in pack32 = 2: the binding converts at the boundary, the residues are the oracle's"""

@@ -615,6 +615,20 @@ def test_leveled_entry_points_row_by_row_on_gpu(rows4):
     pc.case_leveled_rows(mk, lambda Q, P: Oracle(q=Q, p=P), level=6, alpha=5, seed=0x77)
 
 
+def test_transform_bodies_64_bit_for_the_small_limbs_on_gpu():
+    """option small32 = 0: the ~30-bit limbs through the 64-bit bodies of the batched transforms (default: the 32-bit bodies): the oracle's residues either way"""
+    from optimal_conv_amd import Context
+
+    def mk(Q, P):
+        ctx = Context(Q, P)
+        ctx.set_option("small32", 0)
+        return ctx
+    mo = lambda Q, P: Oracle(q=Q, p=P)
+    pc.case_keyswitch_general(mk, mo, shapes=((3, 2), (4, 3), (4, 5)))
+    pc.case_leveled_rows(mk, mo)
+    pc.case_keyswitch_qp_mod_down(mk, mo, level=4, alpha=5, nkeys=2)
+
+
 def test_key_switch_with_four_byte_rows_on_gpu():
     """the key-switch cases above, unchanged, on a context in pack32 = 2"""
     mo = lambda Q, P: Oracle(q=Q, p=P)
