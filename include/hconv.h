@@ -86,9 +86,11 @@ int hc_permute(hc_ctx *ctx, uint64_t galEl, const uint64_t *in, uint64_t *out, i
  * another). hc_set_batch(n, poly_stride, qp_stride) makes every leveled entry point below (hc_lv_*, hc_rotate_finish, hc_keyswitch*, hc_mod_down2,
  * hc_qp_*, hc_div_round_last / 2) act on n <= 8 independent ciphertexts in ONE set of launches: a device pointer designates the operand of image 0,
  * image z's copy lies z * poly_stride words further (polynomials at a level: rows Q_0..Q_level) or z * qp_stride words further (extended-basis pairs
- * [2][level+1+np][N]: acc of hc_keyswitch_qp, x of hc_mod_down2, the operands of hc_qp_op2 / hc_qp_permute2). Operands that are PLAINTEXTS are shared
- * by all images and read once per launch: b of hc_lv_mul / hc_lv_mul_acc, b0 == b1 of hc_lv_op2 / hc_qp_op2 (multiplications), every constant vector;
- * switching keys likewise (one fetch of a key row serves all images and both key components). Results are bit-identical to n separate calls.
+ * [2][level+1+np][N]: acc of hc_keyswitch_qp, x of hc_mod_down2, the operands of hc_qp_op2 / hc_qp_permute2). EVERY polynomial operand is per image. An operand that is
+ * ONE PLAINTEXT for all images (a mask, an encoded diagonal, the secret key of the test harness) is named as such by the entry point or operation: b of hc_lv_mul_plain /
+ * hc_lv_mul_acc_plain, b0 of HC_LV_MUL_PLAIN / HC_LV_MUL_ACC_PLAIN (hc_lv_op2, hc_qp_op2), the plaintexts of hc_qp_mul_sum*, every constant vector - it is read once per launch;
+ * switching keys likewise (one fetch of a key row serves all images and both key components). (Until round 5 hc_lv_mul always shared b and hc_lv_op2 inferred a plaintext
+ * from b0 == b1: a per-image second operand gave wrong residues for images above 0 without an error.) Results are bit-identical to n separate calls.
  * n = 1 (default) restores single-ciphertext behaviour; the L0 one-row primitives above, hc_permute and the L1 convolution (which has its own
  * batch entry point) ignore the setting. A decomposition held by hc_keyswitch_decompose belongs to the batch it was taken under.
  * The setting is context STATE (calls on one hc_ctx are serialised by the caller): a binding must hold it in a scope that restores n = 1 on every way out - INTEGRATION.md 3d
@@ -106,11 +108,15 @@ int hc_lv_mul(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint
 /* acc += a * b: one term of a linear transform's diagonal sum (MulNew by the encoded diagonal + Add, conv.go:168-171 and the
  * bootstrapper's matrices) in one pass */
 int hc_lv_mul_acc(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *acc);
+/* the same with b = ONE plaintext for every image of a batch (read once per coefficient); identical to the above at n = 1 */
+int hc_lv_mul_plain(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *pt, uint64_t *out);
+int hc_lv_mul_acc_plain(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *pt, uint64_t *acc);
 int hc_lv_add(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
 int hc_lv_sub(hc_ctx *ctx, int level, const uint64_t *a, const uint64_t *b, uint64_t *out);
 /* the pointwise operations above on BOTH polynomials of a ciphertext in one launch (out_k = a_k op b_k, k = 0, 1; the polynomials may live
- * in separate allocations; pass b1 = b0 for a plaintext operand; HC_LV_MUL_CONST takes `consts` and ignores b; HC_LV_MUL_ACC accumulates into out) */
-enum { HC_LV_MUL = 0, HC_LV_ADD = 1, HC_LV_SUB = 2, HC_LV_MUL_CONST = 3, HC_LV_MUL_ACC = 7 };
+ * in separate allocations; HC_LV_MUL_CONST takes `consts` and ignores b; HC_LV_MUL_ACC accumulates into out; HC_LV_MUL_PLAIN / HC_LV_MUL_ACC_PLAIN: b0 is ONE plaintext that
+ * multiplies both polynomials of every image, b1 must be NULL or b0) */
+enum { HC_LV_MUL = 0, HC_LV_ADD = 1, HC_LV_SUB = 2, HC_LV_MUL_CONST = 3, HC_LV_MUL_ACC = 7, HC_LV_MUL_PLAIN = 8, HC_LV_MUL_ACC_PLAIN = 9 };
 int hc_lv_op2(hc_ctx *ctx, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1, const uint64_t *consts);
 /* evaluator.permuteNTT's tail after the key switch (RotateNew, RotateHoisted, ConjugateNew): out0 = Permute_galEl(d0 + c0),
  * out1 = Permute_galEl(d1) over limbs 0..level in one launch; same residues as hc_lv_add + two hc_permute calls */
@@ -184,7 +190,7 @@ int hc_keyswitch_decompose(hc_ctx *ctx, int level, const uint64_t *cx);
  *  hc_mod_down2     ring.(*FastBasisExtender).ModDownSplitNTTPQ (@4e4c40) on the two polynomials x[2][level+1+np][N] -> out0, out1 [level+1][N].
  *                   hc_keyswitch == hc_keyswitch_qp followed by hc_mod_down2, bit for bit. A decomposition held by hc_keyswitch_decompose
  *                   survives hc_mod_down2 at the SAME level only (another level drops it); hc_keyswitch_qp(hoisted = 0) always re-decomposes and drops it.
- *  hc_qp_op2        out_k = a_k (op) b_k for k = 0, 1 over all level+1+np rows; op = HC_LV_MUL, HC_LV_ADD or HC_LV_MUL_ACC (out_k += a_k * b_k);
+ *  hc_qp_op2        out_k = a_k (op) b_k for k = 0, 1 over all level+1+np rows; op = HC_LV_MUL, HC_LV_ADD, HC_LV_MUL_ACC (out_k += a_k * b_k) or their _PLAIN forms (b0 = one plaintext);
  *                   b1 == b0 for a plaintext operand. (hc_permute works on any rows, so it permutes QP polynomials as they are.) */
 int hc_keyswitch_qp(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *acc, int hoisted);
 /* one rotation of MultiplyByDiagMatrixBSGS as a single call (rotateHoistedNoModDown for a baby step: pc0 = P * c0; the giant step's SwitchKeysInPlaceNoModDown +

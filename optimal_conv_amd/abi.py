@@ -66,6 +66,8 @@ SYMBOLS = {
     "hc_lv_intt": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_lv_mul": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_lv_mul_acc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_lv_mul_plain": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_lv_mul_acc_plain": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_lv_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_lv_sub": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_lv_mul_tensor": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 7),
@@ -403,13 +405,16 @@ class Context:
         return res
 
     def lv_op2(self, op, level, a, b=None, out=None, consts=None, shared_b=False):
-        """hc_lv_op2: a, b, out = (2, level+1, N) ciphertexts (b = (level+1, N) with shared_b: a plaintext operand); separate allocations per polynomial"""
+        """hc_lv_op2: a, b, out = (2, level+1, N) ciphertexts (b = (level+1, N) with shared_b: ONE plaintext - the operation becomes HC_LV_MUL_PLAIN / HC_LV_MUL_ACC_PLAIN);
+        separate allocations per polynomial"""
+        if shared_b:
+            op = {0: 8, 7: 9}[op]
         pk = lambda x: self.pack_rows(np.ascontiguousarray(x, dtype=np.uint64).reshape(level + 1, self.N), level + 1)
         A = [self.buf(pk(a[k])) for k in range(2)]
         Bs = [] if b is None else ([self.buf(pk(b))] * 2 if shared_b else [self.buf(pk(b[k])) for k in range(2)])
         O = [self.buf(pk(out[k])) if out is not None else self.buf(nwords=(level + 1) * self.N) for k in range(2)]
         cs = (C.c_uint64 * (level + 1))(*[int(x) for x in consts]) if consts is not None else None
-        self._ck(self.L.hc_lv_op2(self.h, op, level, A[0].ptr, A[1].ptr, Bs[0].ptr if Bs else None, Bs[1].ptr if Bs else None, O[0].ptr, O[1].ptr, cs))
+        self._ck(self.L.hc_lv_op2(self.h, op, level, A[0].ptr, A[1].ptr, Bs[0].ptr if Bs else None, (None if shared_b else Bs[1].ptr) if Bs else None, O[0].ptr, O[1].ptr, cs))
         res = np.stack([self.unpack_rows(O[k].download((level + 1, self.N)), level + 1) for k in range(2)])
         for x in A + O + (Bs[:1] if shared_b else Bs):
             x.free()
@@ -462,7 +467,7 @@ class Context:
         B_ = self.buf(self.pack_rows(np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, nt, self.N), level + 1, nt))
         O = self.buf(self.pack_rows(np.ascontiguousarray(out, dtype=np.uint64).reshape(2, nt, self.N), level + 1, nt)) if out is not None else self.buf(nwords=2 * nt * self.N)
         n = nt * self.N
-        self._ck(self.L.hc_qp_op2(self.h, op, level, A.at(0), A.at(n), B_.at(0), B_.at(0 if shared_b else n), O.at(0), O.at(n)))
+        self._ck(self.L.hc_qp_op2(self.h, {0: 8, 7: 9}[op] if shared_b else op, level, A.at(0), A.at(n), B_.at(0), None if shared_b else B_.at(n), O.at(0), O.at(n)))
         res = self.unpack_rows(O.download((2, nt, self.N)), level + 1, nt)
         A.free(); B_.free(); O.free()
         return res

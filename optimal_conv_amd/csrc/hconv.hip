@@ -565,8 +565,9 @@ static int hc_lv_pw(hc_ctx *c, const char *fn, int level, const uint64_t *a, con
 }
 // the same operations on both polynomials of a ciphertext in one launch (they may live in separate allocations; b1 == b0 for a plaintext operand)
 template <int OP>
-static int hc_lv_pw2(hc_ctx *c, const char *fn, int level, const u64 *a0, const u64 *a1, const u64 *b0, const u64 *b1, u64 *o0, u64 *o1, const uint64_t *consts_host) {
+static int hc_lv_pw2(hc_ctx *c, const char *fn, int level, const u64 *a0, const u64 *a1, const u64 *b0, const u64 *b1, u64 *o0, u64 *o1, const uint64_t *consts_host, bool plain = false) {
     HC_TRY(hc_lv_check(c, fn, level, a0, o0));
+    if (plain) { if (b1 && b1 != b0) return hc_fail(c, HC_ERR_ARG, "%s: a plaintext operand is ONE polynomial (b1 must be null or b0)", fn); b1 = b0; }
     if (!a1 || !o1 || ((OP == HC_PW_MUL || OP == HC_PW_ADD || OP == HC_PW_SUB || OP == HC_PW_MAC) && (!b0 || !b1))) return hc_fail(c, HC_ERR_ARG, "%s: null", fn);
     HcLvConsts K; memset(&K, 0, sizeof K);
     if (OP == HC_PW_MULC) {
@@ -575,7 +576,7 @@ static int hc_lv_pw2(hc_ctx *c, const char *fn, int level, const u64 *a0, const 
         for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[l] = h_pair(consts_host[l] % q, q); }
     }
     const u64 *bb0 = b0 ? b0 : a0, *bb1 = b1 ? b1 : a1;
-    const bool b_shared = (OP == HC_PW_MUL || OP == HC_PW_MAC) && b0 && b0 == b1, inthread = b_shared && c->nb > 1;      // one plaintext for both polynomials = one plaintext for every image
+    const bool b_shared = plain, inthread = b_shared && c->nb > 1;      // one plaintext for both polynomials and every image: said by the operation (HC_LV_MUL_PLAIN), not inferred from b0 == b1
     return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(HC_GX_PW, (unsigned)(level + 1), inthread ? 2u : 2u * (unsigned)c->nb), a0, bb0, o0, (const HcMod *)c->d_mods, K, (size_t)(a1 - a0), (size_t)(bb1 - bb0), (size_t)(o1 - o0), HC_ROW_IS_MOD, 0,
                      2, inthread ? c->nb : 1, c->bs_poly, b_shared ? (size_t)0 : c->bs_poly, c->bs_poly);
 }
@@ -587,11 +588,16 @@ extern "C" int hc_lv_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const
         case HC_LV_SUB: return hc_lv_pw2<HC_PW_SUB>(c, "hc_lv_op2(sub)", level, a0, a1, b0, b1, out0, out1, nullptr);
         case HC_LV_MUL_CONST: return hc_lv_pw2<HC_PW_MULC>(c, "hc_lv_op2(mul_const)", level, a0, a1, nullptr, nullptr, out0, out1, consts);
         case HC_LV_MUL_ACC: return hc_lv_pw2<HC_PW_MAC>(c, "hc_lv_op2(mul_acc)", level, a0, a1, b0, b1, out0, out1, nullptr);
+        case HC_LV_MUL_PLAIN: return hc_lv_pw2<HC_PW_MUL>(c, "hc_lv_op2(mul)", level, a0, a1, b0, b1, out0, out1, nullptr, true);
+        case HC_LV_MUL_ACC_PLAIN: return hc_lv_pw2<HC_PW_MAC>(c, "hc_lv_op2(mul_acc)", level, a0, a1, b0, b1, out0, out1, nullptr, true);
     }
     return hc_fail(c, HC_ERR_ARG, "hc_lv_op2: unknown operation %d", op);
 }
-extern "C" int hc_lv_mul(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_MUL>(c, "hc_lv_mul", level, a, b, out, nullptr, true); }
-extern "C" int hc_lv_mul_acc(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *acc) { return hc_lv_pw<HC_PW_MAC>(c, "hc_lv_mul_acc", level, a, b, acc, nullptr, true); }
+extern "C" int hc_lv_mul(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_MUL>(c, "hc_lv_mul", level, a, b, out, nullptr, false); }
+extern "C" int hc_lv_mul_acc(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *acc) { return hc_lv_pw<HC_PW_MAC>(c, "hc_lv_mul_acc", level, a, b, acc, nullptr, false); }
+// b = one plaintext for every image of a batch (include/hconv.h "image batches")
+extern "C" int hc_lv_mul_plain(hc_ctx *c, int level, const uint64_t *a, const uint64_t *pt, uint64_t *out) { return hc_lv_pw<HC_PW_MUL>(c, "hc_lv_mul", level, a, pt, out, nullptr, true); }
+extern "C" int hc_lv_mul_acc_plain(hc_ctx *c, int level, const uint64_t *a, const uint64_t *pt, uint64_t *acc) { return hc_lv_pw<HC_PW_MAC>(c, "hc_lv_mul_acc", level, a, pt, acc, nullptr, true); }
 extern "C" int hc_lv_add(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_ADD>(c, "hc_lv_add", level, a, b, out, nullptr); }
 extern "C" int hc_lv_sub(hc_ctx *c, int level, const uint64_t *a, const uint64_t *b, uint64_t *out) { return hc_lv_pw<HC_PW_SUB>(c, "hc_lv_sub", level, a, b, out, nullptr); }
 extern "C" int hc_lv_mul_const(hc_ctx *c, int level, const uint64_t *a, const uint64_t *consts, uint64_t *out) { return hc_lv_pw<HC_PW_MULC>(c, "hc_lv_mul_const", level, a, nullptr, out, consts); }
@@ -1545,11 +1551,13 @@ extern "C" int hc_mod_down2_add_rescale(hc_ctx *c, int level, uint64_t *x, const
 extern "C" int hc_qp_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const uint64_t *a1, const uint64_t *b0, const uint64_t *b1, uint64_t *out0, uint64_t *out1) {
     HC_ENTER(c);
     if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: level %d outside 0..%d or no special primes", level, c->nq - 1);
+    const bool plain = op == HC_LV_MUL_PLAIN || op == HC_LV_MUL_ACC_PLAIN;
+    if (plain) { if (b1 && b1 != b0) return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: a plaintext operand is ONE polynomial over the extended basis (b1 must be null or b0)"); b1 = b0; op = op == HC_LV_MUL_PLAIN ? HC_LV_MUL : HC_LV_MUL_ACC; }
     if (!a0 || !a1 || !b0 || !b1 || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: null");
     HC_TRY(hc_batch_fits(c, "hc_qp_op2", level, true));
     HcLvConsts K; memset(&K, 0, sizeof K);
     const size_t as = (size_t)(a1 - a0), bs = (size_t)(b1 - b0), os = (size_t)(out1 - out0);
-    const bool b_shared = b0 == b1 && op != HC_LV_ADD, inthread = b_shared && c->nb > 1;                                  // a plaintext (an encoded diagonal): one for every image
+    const bool b_shared = plain, inthread = b_shared && c->nb > 1;                                  // a plaintext (an encoded diagonal): one for every image, said by the operation
     const dim3 grid(HC_GX_PW, (unsigned)(level + 1 + c->np), inthread ? 2u : 2u * (unsigned)c->nb);
     const int nin = inthread ? c->nb : 1; const size_t ia = c->bs_qp, ib = b_shared ? (size_t)0 : c->bs_qp, io = c->bs_qp;
     switch (op) {

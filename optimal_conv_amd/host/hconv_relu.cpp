@@ -311,14 +311,14 @@ struct Boot {
     DCt mul_plain(const DCt &a, const DPt &pt) {
         if (pt.level < a.level) panic("mul_plain: plaintext below the ciphertext's level");
         DCt r = new_ct(a.level, a.deg, a.scale * pt.scale); alg_ct += 2.0 * (a.deg + 1) * (a.level + 1); alg_shared += a.level + 1;
-        if (a.deg == 1) HCR(hc_lv_op2(hc, HC_LV_MUL, a.level, a.p[0].get(), a.p[1].get(), pt.p.get(), pt.p.get(), r.p[0].get(), r.p[1].get(), nullptr));
-        else for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul(hc, a.level, a.p[d].get(), pt.p.get(), r.p[d].get()));
+        if (a.deg == 1) HCR(hc_lv_op2(hc, HC_LV_MUL_PLAIN, a.level, a.p[0].get(), a.p[1].get(), pt.p.get(), nullptr, r.p[0].get(), r.p[1].get(), nullptr));
+        else for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul_plain(hc, a.level, a.p[d].get(), pt.p.get(), r.p[d].get()));
         return r;
     }
     DCt mul_by_i(const DCt &a) {
         DCt r = new_ct(a.level, a.deg, a.scale); alg_ct += 2.0 * (a.deg + 1) * (a.level + 1); alg_shared += a.level + 1;
-        if (a.deg == 1) HCR(hc_lv_op2(hc, HC_LV_MUL, a.level, a.p[0].get(), a.p[1].get(), mono_i.get(), mono_i.get(), r.p[0].get(), r.p[1].get(), nullptr));
-        else for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul(hc, a.level, a.p[d].get(), mono_i.get(), r.p[d].get()));
+        if (a.deg == 1) HCR(hc_lv_op2(hc, HC_LV_MUL_PLAIN, a.level, a.p[0].get(), a.p[1].get(), mono_i.get(), nullptr, r.p[0].get(), r.p[1].get(), nullptr));
+        else for (int d = 0; d <= a.deg; d++) HCR(hc_lv_mul_plain(hc, a.level, a.p[d].get(), mono_i.get(), r.p[d].get()));
         return r;
     }
     DCt mul_relin(const DCt &a, const DCt &b) {                   // evaluator.MulRelin: tensor, key switch of c2 with the rlk
@@ -377,7 +377,7 @@ struct Boot {
     std::vector<cplx> debug_slots(const DCt &a) {
         Single one(this);                                          // image 0 of a batch
         const int L = std::min(a.level, 1); auto t = block();
-        HCR(hc_lv_mul(hc, L, a.p[1].get(), d_sk, t.get())); HCR(hc_lv_add(hc, L, a.p[0].get(), t.get(), t.get())); HCR(hc_lv_intt(hc, L, t.get(), t.get()));
+        HCR(hc_lv_mul_plain(hc, L, a.p[1].get(), d_sk, t.get())); HCR(hc_lv_add(hc, L, a.p[0].get(), t.get(), t.get())); HCR(hc_lv_intt(hc, L, t.get(), t.get()));
         std::vector<uint64_t> m((size_t)(L + 1) * N); HCR(hc_download(hc, m.data(), t.get(), m.size() * 8));
         std::vector<double> cf((size_t)N);
         if (L == 0) { const uint64_t q0 = Q[0]; for (int j = 0; j < N; j++) cf[(size_t)j] = (m[(size_t)j] > q0 / 2 ? -(double)(q0 - m[(size_t)j]) : (double)m[(size_t)j]) / a.scale; }
@@ -696,7 +696,7 @@ struct Boot {
             auto a0 = block(), a1 = block();
             if (haveA) HCR(hc_mod_down2(hc, L, Aof[j].get(), a0.get(), a1.get()));
             else { HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), zeros.data(), a0.get())); HCR(hc_lv_mul_const(hc, L, ct.p[0].get(), zeros.data(), a1.get())); }
-            if (row.count(0)) { const uint64_t *pt = row.at(0).p.get(); HCR(hc_lv_op2(hc, HC_LV_MUL_ACC, L, ct.p[0].get(), ct.p[1].get(), pt, pt, a0.get(), a1.get(), nullptr)); }
+            if (row.count(0)) { const uint64_t *pt = row.at(0).p.get(); HCR(hc_lv_op2(hc, HC_LV_MUL_ACC_PLAIN, L, ct.p[0].get(), ct.p[1].get(), pt, nullptr, a0.get(), a1.get(), nullptr)); }
             { auto t = block(); HCR(hc_lv_permute(hc, gal, L, a0.get(), t.get())); add_to_res(0, t); }
             HCR(hc_keyswitch_qp_rotate(hc, key(gal, L, 2), gal, L, nullptr, a1.get(), B.get(), 0, haveB ? 1 : 0)); n_keyswitch++; haveB = true;     // SwitchKeysInPlaceNoModDown, permuted into the accumulators
             Aof.erase(j);
@@ -706,8 +706,8 @@ struct Boot {
         auto diag0 = [&]() {
             if (!(lt.giant.count(0) && lt.giant.at(0).count(0))) return;
             const uint64_t *pt = lt.giant.at(0).at(0).p.get();
-            if (have_res[0] && have_res[1]) HCR(hc_lv_op2(hc, HC_LV_MUL_ACC, L, ct.p[0].get(), ct.p[1].get(), pt, pt, res.p[0].get(), res.p[1].get(), nullptr));
-            else for (int k = 0; k < 2; k++) { auto t = block(); HCR(hc_lv_mul(hc, L, ct.p[k].get(), pt, t.get())); add_to_res(k, t); }
+            if (have_res[0] && have_res[1]) HCR(hc_lv_op2(hc, HC_LV_MUL_ACC_PLAIN, L, ct.p[0].get(), ct.p[1].get(), pt, nullptr, res.p[0].get(), res.p[1].get(), nullptr));
+            else for (int k = 0; k < 2; k++) { auto t = block(); HCR(hc_lv_mul_plain(hc, L, ct.p[k].get(), pt, t.get())); add_to_res(k, t); }
         };
         if (fuse) {            // every other term first (modular sums commute), then ModDown(B) + them + the first drop of the caller's Rescale in one pass
             diag0();
@@ -1445,7 +1445,7 @@ std::vector<double> bootDecryptDecodeCoeffs(Boot *B, const BootCiphertext &ct) {
     hc_ctx *hc = B->hc;
     if (ct.level != 1) panic("bootDecryptDecodeCoeffs expects the level-1 result of the chain");
     void *v = nullptr; HCR(hc_malloc(hc, (size_t)2 * N * 8, &v)); uint64_t *t = (uint64_t *)v;
-    HCR(hc_lv_mul(hc, 1, ct.d + (size_t)2 * N, B->d_sk, t)); HCR(hc_lv_add(hc, 1, ct.d, t, t)); HCR(hc_lv_intt(hc, 1, t, t));
+    HCR(hc_lv_mul_plain(hc, 1, ct.d + (size_t)2 * N, B->d_sk, t)); HCR(hc_lv_add(hc, 1, ct.d, t, t)); HCR(hc_lv_intt(hc, 1, t, t));
     std::vector<uint64_t> m((size_t)2 * N); HCR(hc_download(hc, m.data(), t, m.size() * 8)); HCR(hc_free(hc, t));
     const uint64_t q0 = B->Q[0], q1 = B->Q[1]; uint64_t inv = 1; { uint64_t b = q0 % q1, e = q1 - 2; while (e) { if (e & 1) inv = mulmod(inv, b, q1); b = mulmod(b, b, q1); e >>= 1; } }
     const u128 QQ = (u128)q0 * q1; std::vector<double> cf((size_t)N);

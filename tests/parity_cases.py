@@ -518,8 +518,10 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4, make_ora
     a1, b1 = poly(), poly()
     run("lv_ntt", lambda x, o: ck(L.hc_lv_ntt(h, level, x, o)), [(a, "p")], [("p", PW)])
     run("lv_intt", lambda x, o: ck(L.hc_lv_intt(h, level, x, o)), [(a, "p")], [("p", PW)])
-    run("lv_mul (plaintext)", lambda x, y, o: ck(L.hc_lv_mul(h, level, x, y, o)), [(a, "p"), (pt, "s")], [("p", PW)])
-    run("lv_mul_acc", lambda x, y, o: ck(L.hc_lv_mul_acc(h, level, x, y, o)), [(a, "p"), (pt, "s")], [("p", PW)], init=[b.reshape(n, -1)])
+    run("lv_mul_plain", lambda x, y, o: ck(L.hc_lv_mul_plain(h, level, x, y, o)), [(a, "p"), (pt, "s")], [("p", PW)])
+    run("lv_mul_acc_plain", lambda x, y, o: ck(L.hc_lv_mul_acc_plain(h, level, x, y, o)), [(a, "p"), (pt, "s")], [("p", PW)], init=[b.reshape(n, -1)])
+    run("lv_mul (per image)", lambda x, y, o: ck(L.hc_lv_mul(h, level, x, y, o)), [(a, "p"), (b, "p")], [("p", PW)])
+    run("lv_mul_acc (per image)", lambda x, y, o: ck(L.hc_lv_mul_acc(h, level, x, y, o)), [(a, "p"), (b, "p")], [("p", PW)], init=[a1.reshape(n, -1)])
     run("lv_add", lambda x, y, o: ck(L.hc_lv_add(h, level, x, y, o)), [(a, "p"), (b, "p")], [("p", PW)])
     run("lv_sub", lambda x, y, o: ck(L.hc_lv_sub(h, level, x, y, o)), [(a, "p"), (b, "p")], [("p", PW)])
     run("lv_mul_const", lambda x, o: ck(L.hc_lv_mul_const(h, level, x, consts, o)), [(a, "p")], [("p", PW)])
@@ -527,8 +529,9 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4, make_ora
     for op, nm in ((1, "add"), (2, "sub")):
         run(f"lv_op2 {nm}", lambda x0, x1, y0, y1, o0, o1, op=op: ck(L.hc_lv_op2(h, op, level, x0, x1, y0, y1, o0, o1, None)), [(a, "p"), (a1, "p"), (b, "p"), (b1, "p")], [("p", PW), ("p", PW)])
     run("lv_op2 mul_const", lambda x0, x1, o0, o1: ck(L.hc_lv_op2(h, 3, level, x0, x1, None, None, o0, o1, consts)), [(a, "p"), (a1, "p")], [("p", PW), ("p", PW)])
-    run("lv_op2 mul (plaintext)", lambda x0, x1, y, o0, o1: ck(L.hc_lv_op2(h, 0, level, x0, x1, y, y, o0, o1, None)), [(a, "p"), (a1, "p"), (pt, "s")], [("p", PW), ("p", PW)])
-    run("lv_op2 mul_acc (plaintext)", lambda x0, x1, y, o0, o1: ck(L.hc_lv_op2(h, 7, level, x0, x1, y, y, o0, o1, None)), [(a, "p"), (a1, "p"), (pt, "s")], [("p", PW), ("p", PW)],
+    run("lv_op2 mul (plaintext)", lambda x0, x1, y, o0, o1: ck(L.hc_lv_op2(h, 8, level, x0, x1, y, None, o0, o1, None)), [(a, "p"), (a1, "p"), (pt, "s")], [("p", PW), ("p", PW)])
+    run("lv_op2 mul (one per-image polynomial for both)", lambda x0, x1, y, o0, o1: ck(L.hc_lv_op2(h, 0, level, x0, x1, y, y, o0, o1, None)), [(a, "p"), (a1, "p"), (b, "p")], [("p", PW), ("p", PW)])
+    run("lv_op2 mul_acc (plaintext)", lambda x0, x1, y, o0, o1: ck(L.hc_lv_op2(h, 9, level, x0, x1, y, None, o0, o1, None)), [(a, "p"), (a1, "p"), (pt, "s")], [("p", PW), ("p", PW)],
         init=[b.reshape(n, -1), b1.reshape(n, -1)])
     # a leaf of evaluatePolyFromPowerBasis in one launch == the MultByConst / Add chain + AddConst
     NL = 5
@@ -729,8 +732,8 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4, make_ora
     run("keyswitch_qp_rotate (hoisted, accumulate, no pc0)", qp_rot_acc, [(a1, "p")], [("q", QW)], init=[acc.reshape(n, -1)])
     off = nt * N * 8
     at1 = lambda p_: C.c_void_p(p_.value + off)
-    run("qp_op2 mul (plaintext)", lambda x, y, o: ck(L.hc_qp_op2(h, 0, level, x, at1(x), y, y, o, at1(o))), [(X, "q"), (ptq, "s")], [("q", QW)])
-    run("qp_op2 mul_acc (plaintext)", lambda x, y, o: ck(L.hc_qp_op2(h, 7, level, x, at1(x), y, y, o, at1(o))), [(X, "q"), (ptq, "s")], [("q", QW)], init=[acc.reshape(n, -1)])
+    run("qp_op2 mul (plaintext)", lambda x, y, o: ck(L.hc_qp_op2(h, 8, level, x, at1(x), y, None, o, at1(o))), [(X, "q"), (ptq, "s")], [("q", QW)])
+    run("qp_op2 mul_acc (plaintext)", lambda x, y, o: ck(L.hc_qp_op2(h, 9, level, x, at1(x), y, None, o, at1(o))), [(X, "q"), (ptq, "s")], [("q", QW)], init=[acc.reshape(n, -1)])
     run("qp_op2 add", lambda x, y, o: ck(L.hc_qp_op2(h, 1, level, x, at1(x), y, at1(y), o, at1(o))), [(X, "q"), (acc, "q")], [("q", QW)])
     # the diagonal sum of a giant step in one launch == the chain of qp_op2 mul / mul_acc calls, for 9 terms (more than one 7-term fold) with and without accumulation
     NT = 9
@@ -744,7 +747,7 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4, make_ora
     def mul_chain(*args, accumulate=0):
         xs, ps, o = args[:NT], args[NT:2 * NT], args[2 * NT]
         for t in range(NT):
-            ck(L.hc_qp_op2(h, 7 if (t or accumulate) else 0, level, xs[t], at1(xs[t]), ps[t], ps[t], o, at1(o)))
+            ck(L.hc_qp_op2(h, 9 if (t or accumulate) else 8, level, xs[t], at1(xs[t]), ps[t], None, o, at1(o)))
     for accu in (0, 1):
         ins = [(x_, "q") for x_ in Xs] + [(p_, "s") for p_ in pts]
         got_sum = run(f"qp_mul_sum accumulate={accu}", lambda *a_, accu=accu: mul_sum(*a_, accumulate=accu), ins, [("q", QW)], init=[acc.reshape(n, -1)])
