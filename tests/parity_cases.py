@@ -300,11 +300,13 @@ Q_MIX = [Q0, Q1_BL, 0x3FFC0001, 0x40080001, 0x1000000000B00001, 0x3FFFFE80001, 0
 P_CHAIN = [0x1FFFFFFFFFE00001, 0x1FFFFFFFFFC80001, 0x1FFFFFFFFFB40001, 0x1FFFFFFFFF500001, 0x1FFFFFFFFF420001]
 
 
-def case_keyswitch_general(make_ctx, make_oracle, shapes=((1, 2), (0, 1), (2, 2), (3, 2), (4, 3), (4, 5))):
+def case_keyswitch_general(make_ctx, make_oracle, shapes=((1, 2), (0, 1), (2, 2), (3, 2), (4, 3), (4, 5)), chain=None):
     """hc_keyswitch vs or_keyswitch for (level, alpha): single- and multi-limb digits, several digits, targets smaller
-    than sources (30-bit limbs), and the level-0/one-prime case that must also equal the fused path's key switch."""
+    than sources (30-bit limbs), and the level-0/one-prime case that must also equal the fused path's key switch.
+    chain = (Q, P): other moduli than the mixed test chain (e.g. the bootstrapping chain with two special primes: seven and more digits, where the inner product's 128-bit
+    sums are folded between digits)"""
     for level, alpha in shapes:
-        Q, P = Q_MIX[: level + 1], P_CHAIN[:alpha]
+        Q, P = (chain[0][: level + 1], chain[1][:alpha]) if chain else (Q_MIX[: level + 1], P_CHAIN[:alpha])
         ctx, O = make_ctx(Q, P), make_oracle(Q, P)
         beta = (level + 1 + alpha - 1) // alpha
         cx = np.stack([splitmix_rows(900 + 7 * level + l, Q[l], N) for l in range(level + 1)])
@@ -313,7 +315,7 @@ def case_keyswitch_general(make_ctx, make_oracle, shapes=((1, 2), (0, 1), (2, 2)
             for k in range(2):
                 for T in range(level + 1 + alpha):
                     q = Q[T] if T <= level else P[T - level - 1]
-                    evk[d, k, T] = splitmix_rows(5000 + ((d * 2 + k) * 16 + T) * 3 + alpha, q, N)
+                    evk[d, k, T] = splitmix_rows(5000 + ((d * 2 + k) * 64 + T) * 3 + alpha, q, N)
         ctx.swk_load(77, level, evk)
         g0, g1 = ctx.keyswitch(77, level, cx)
         w0, w1 = O.keyswitch(level, cx, evk)

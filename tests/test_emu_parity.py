@@ -181,6 +181,13 @@ def test_leveled_entry_points_row_by_row(rows4):
     pc.case_leveled_rows(_rows4 if rows4 else (lambda Q, P: Context(Q, P, lib_path=EMU_LIB)), lambda Q, P: Oracle(q=Q, p=P))
 
 
+def test_keyswitch_with_seven_and_nine_digits():
+    """the bootstrapping chain with TWO special primes: levels 13 and 16 decompose into 7 and 9 digits - more than the 6 after which hc_k_ks_mac_all folds its 128-bit sums"""
+    import oracle_ckks
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    pc.case_keyswitch_general(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), lambda Q, P: Oracle(q=Q, p=P), shapes=((13, 2), (16, 2)), chain=(list(oracle_ckks.Q_SET6), list(oracle_ckks.P_SET6)))
+
+
 def test_transform_bodies_64_bit_for_the_small_limbs():
     """option small32 = 0: the ~30-bit limbs go through the 64-bit bodies of the batched transforms (the default sends them through the 32-bit bodies, which every other test
     here exercises): the same residues as the oracle either way"""

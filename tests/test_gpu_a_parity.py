@@ -615,6 +615,14 @@ def test_leveled_entry_points_row_by_row_on_gpu(rows4):
     pc.case_leveled_rows(mk, lambda Q, P: Oracle(q=Q, p=P), level=6, alpha=5, seed=0x77)
 
 
+def test_keyswitch_with_seven_and_nine_digits_on_gpu():
+    """the bootstrapping chain with TWO special primes: levels 13 and 16 decompose into 7 and 9 digits - more than the 6 after which hc_k_ks_mac_all folds its 128-bit sums
+    (the chain itself, five special primes, never exceeds 6 digits)"""
+    import oracle_ckks
+    from optimal_conv_amd import Context
+    pc.case_keyswitch_general(lambda Q, P: Context(Q, P), lambda Q, P: Oracle(q=Q, p=P), shapes=((13, 2), (16, 2)), chain=(list(oracle_ckks.Q_SET6), list(oracle_ckks.P_SET6)))
+
+
 def test_transform_bodies_64_bit_for_the_small_limbs_on_gpu():
     """option small32 = 0: the ~30-bit limbs through the 64-bit bodies of the batched transforms (default: the 32-bit bodies): the oracle's residues either way"""
     from optimal_conv_amd import Context
