@@ -1824,8 +1824,8 @@ __device__ __forceinline__ void hc_basis_ext_tile32(u32 (&e)[16], const u64 *yv,
 }
 struct HcRowMod { HcTwTab fwd, inv; u64 q, mu;
                   HcTwTab32 fwd32, inv32;   // moduli below 2^31 (null otherwise)
-                  u64 s32; };            // nonzero: the batched transforms take their 32-bit form (HC_S32) for rows of this modulus: q < 2^31 and option small32. (The kernels test
-                                         // HC_SMALL_Q(q) && s32: with a purely scalar condition - s32 alone, or a launch argument - around the two bodies the gfx950 backend of ROCm 7.2 dies, "illegal VGPR to SGPR copy")
+                  u64 s32; };            // nonzero: the batched transforms take their 32-bit form (HC_S32) for rows of this modulus: q < 2^31 and option small32 (in the table the
+                                         // kernels read their moduli from, so that the option costs no launch argument; the kernels test HC_SMALL_Q(q) && s32)
 // blockIdx.z = operand + nz * image: `nz` operands zs_* words apart (the two polynomials of a ciphertext, the digits of a key switch), and the
 // images of a batch (hc_set_batch) is_* words apart
 struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_out; int z_alpha; int nz; size_t is_in, is_out;

@@ -300,11 +300,12 @@ def test_baseline_boot_relu_on_gpu():
     pc.case_bl_boot_relu(lambda Q, P: Context(Q, P))
 
 
-@pytest.mark.parametrize("log_sparse,in_wid", [(2, None), (2, 32), (3, 16), (4, 8), (1, 32)])
+@pytest.mark.parametrize("log_sparse,in_wid", [(2, 32), (3, 16), (4, 8), (1, 32)])
 def test_conv_relu_tail_sparse_on_gpu(log_sparse, in_wid):
     """scope row 8f-3: the "Conv_sparse" tail (sparse-slot bootstrapping of the ResNet layers) on the device ABI, every stage bit-identical
-    to the oracle at full size: the square log_sparse-2 case of round 2, and the geometries of `resnet 3 20 1 n false` (test.go:76-370:
-    log_sparse 2 / 3 / 4 on 32 / 16 / 8-wide images), plus log_sparse 1 (the bootstrapper of the first stride layer) on its 32-wide image"""
+    to the oracle at full size: the geometries of `resnet 3 20 1 n false` (test.go:76-370: log_sparse 2 / 3 / 4 on 32 / 16 / 8-wide images), plus log_sparse 1 (the
+    bootstrapper of the first stride layer) on its 32-wide image. (Round 2's square log_sparse-2 case on the default width ran here until round 5: the same bootstrapper as
+    (2, 32); dropped to keep `pytest -m gpu` under 15 minutes.)"""
     from optimal_conv_amd import Context
     print("median precision bits", pc.case_conv_relu_tail_sparse(lambda Q, P: Context(Q, P), log_sparse, in_wid=in_wid))
 
