@@ -302,7 +302,8 @@ int hc_row_is32(hc_ctx *ctx, int mod);
 int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes" (jobs - channels / tree nodes summed over the batch - per kernel launch), "small_levels" (tree levels of at most
                                                                   this many nodes x ciphertexts run on the quarter-tile kernels: default 16, 0 = never), "profile" (per-kernel HIP-event totals),
                                                                   "peer_access" (hc_conv_then_pack_sharded: 0 = do not enable direct peer copies; default 1: enabled where hipDeviceCanAccessPeer allows),
-                                                                  "pack32" (0 / 1 / 2: 4-byte rows, above), "small32" (default 1: rows of a modulus below 2^31 take the 32-bit body of the batched
+                                                                  "pack32" (0 / 1 / 2: 4-byte rows, above), "rot_fuse" (default 1: hc_keyswitch_qp_rotate_many stores every rotation's result already permuted and with P c0 added from inside the inner
+                                                                  product; 0: one pass per rotation over the accumulators - same residues, an A/B switch; HCONV_ROT_FUSE), "small32" (default 1: rows of a modulus below 2^31 take the 32-bit body of the batched
                                                                   transform kernels; 0: the 64-bit body for every row - the same residues either way, an A/B switch; HCONV_SMALL32 at hc_ctx_create) */
 /* HIP-event timing on the context's stream */
 int hc_timer_start(hc_ctx *ctx);

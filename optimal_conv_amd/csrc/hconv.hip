@@ -137,6 +137,7 @@ struct hc_ctx {
     int xcd_rows = 1;                     // XCD-aware 1-D grid of the rows passes (HcMm::xcd; 0 = the plain 3-D grid, kept for A/B builds)
     int pack32 = 1;                       // 1: library-internal rows of moduli below 2^31 as 4-byte words (hc_kernels.h hc_ld32): transform seams, extended digits, switching keys. 2: the rows of the caller's leveled
                                           // operands as well (include/hconv.h "4-byte rows"; option pack32 or HCONV_PACK32=2 at hc_ctx_create). 0: off (A/B)
+    int rot_fuse = 1;                     // hc_keyswitch_qp_rotate_many: the rotations' tails (+ P c0, permutation) in the inner product's stores (HcRotFin) instead of one hc_k_qp_rotate_finish per rotation (option rot_fuse / HCONV_ROT_FUSE=0 for A/B)
     int small32 = 1;                      // the batched transform kernels take their 32-bit form for rows of a modulus below 2^31 (hc_kernels.h HC_S32; option small32 / HCONV_SMALL32=0 for A/B)
     unsigned peer_warned = 0;             // bit d: enabling peer access to device d failed and was reported once
     unsigned peer_enabled = 0;            // bit d: peer access from this context's device to device d was enabled by (or found enabled for) this context
@@ -333,6 +334,7 @@ extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, 
     hc_ctx *c = new hc_ctx();
     c->device = device; c->nq = nq; c->np = np;
     { const char *sm = getenv("HCONV_SMALL32"); if (sm && *sm) c->small32 = atoi(sm) ? 1 : 0; }
+    { const char *rf = getenv("HCONV_ROT_FUSE"); if (rf && *rf) c->rot_fuse = atoi(rf) ? 1 : 0; }
     { const char *pk = getenv("HCONV_PACK32"); if (pk && *pk) { const int v = atoi(pk); c->pack32 = v <= 0 ? 0 : v >= 2 ? 2 : 1; } }
     { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa ? (atoi(aa) == 2 ? 2 : (atoi(aa) ? 1 : 0)) : 0; }
     hipError_t se = hipSetDevice(device);
@@ -1514,9 +1516,19 @@ extern "C" int hc_keyswitch_qp_rotate_many(hc_ctx *c, int nrot, const uint64_t *
         HcKeyPtrs K; memset(&K, 0, sizeof K); int beta = 0;
         for (int r = 0; r < nr; r++) { K.k[r] = keys[(size_t)(r0 + r)]->rows; beta = keys[(size_t)(r0 + r)]->beta; }
         const dim3 grid(HC_GX_MACM, (unsigned)nt);
-#define HC_MAC_MULTI(RR, NN) hc_launch(c, "ks_mac_multi", hc_k_ks_mac_multi<RR, NN>, grid, K, nr, (const u64 *)cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, c->ws_accm, acc_rs, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta, nb, c->pack32 ? 3 : 0)
+        HcRotFin F; memset(&F, 0, sizeof F);
+        if (c->rot_fuse) {             // out_r = Permute_g(acc_r + P c0): element j is stored where g sends it, i.e. at hc_perm_src(j, g^-1 mod 2N)
+            for (int r = 0; r < nr; r++) {
+                const u32 g = (u32)(galEls[r0 + r] & 0x1FFFF); u32 x = g;
+                for (int it = 0; it < 5; it++) x = (x * (2u - g * x)) & 0x1FFFFu;               // Newton: doubles the correct low bits (3 -> 6 -> 12 -> 24)
+                F.out[r] = (u64 *)outs[r0 + r]; F.ginv[r] = x;
+            }
+            F.pc0 = (const u64 *)pc0; F.pc0_is = c->bs_poly; F.out_is = c->bs_qp;
+        }
+#define HC_MAC_MULTI(RR, NN) hc_launch(c, "ks_mac_multi", hc_k_ks_mac_multi<RR, NN>, grid, K, nr, (const u64 *)cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, c->ws_accm, acc_rs, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta, nb, c->pack32 ? 3 : 0, F)
         if (NB == 8) HC_TRY(HC_MAC_MULTI(2, 8)); else if (NB == 4) HC_TRY(HC_MAC_MULTI(4, 4)); else if (NB == 2) HC_TRY(HC_MAC_MULTI(8, 2)); else HC_TRY(HC_MAC_MULTI(8, 1));
 #undef HC_MAC_MULTI
+        if (!c->rot_fuse)
         for (int r = 0; r < nr; r++)
             HC_TRY(hc_launch(c, "qp_rotate_finish", hc_k_qp_rotate_finish, dim3(HC_GX_ROT, (unsigned)nt, 2u * (unsigned)nb), (const u64 *)(c->ws_accm + (size_t)r * acc_rs), acc_is, (const u64 *)pc0, c->bs_poly, (u64 *)outs[r0 + r], c->bs_qp,
                              (const HcMod *)c->d_mods, nl, c->nq, nt, (u32)(galEls[r0 + r] & 0x1FFFF), 0));
@@ -1824,6 +1836,7 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!strcmp(name, "small_levels")) { if (value < 0) return hc_fail(c, HC_ERR_ARG, "small_levels must be >= 0"); c->small_levels = value; return HC_OK; }
     if (!strcmp(name, "peer_access")) { c->peer_access = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
+    if (!strcmp(name, "rot_fuse")) { c->rot_fuse = value ? 1 : 0; return HC_OK; }                  // same residues either way: A/B only
     if (!strcmp(name, "small32")) { c->small32 = value ? 1 : 0; HC_HIP(c, hipStreamSynchronize(c->stream)); return hc_upload_rowmods(c); }      // results do not depend on it (both forms leave canonical residues): A/B only
     if (!strcmp(name, "pack32")) {          // 0 / 1 / 2 (include/hconv.h "4-byte rows"). Switching keys are stored per the setting in force when they are loaded or generated: 0 <-> 1, 2 only on a context without keys
         if (value < 0 || value > 2) return hc_fail(c, HC_ERR_ARG, "pack32 must be 0, 1 or 2");

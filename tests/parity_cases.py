@@ -708,6 +708,11 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4, make_ora
     for i in range(len(rots)):
         eq(rm[i], rs_[i], f"rotate_many == single hoisted rotations (rotation {i})")
     eq(rm[0], qr[0], "rotate_many (hoisted) == the plain fused rotation")
+    ctx.set_option("rot_fuse", 0)              # the rotations' tails as one hc_k_qp_rotate_finish per rotation (default: inside the inner product's stores)
+    rm0 = run("keyswitch_qp_rotate_many, tails as launches of their own", rot_many, [(b, "p"), (a, "p")], [("q", QW)] * len(rots))
+    ctx.set_option("rot_fuse", 1)
+    for i in range(len(rots)):
+        eq(rm0[i], rm[i], f"rotate_many: tails fused into the inner product == separate (rotation {i})")
     if O is not None:
         for z in oimgs:
             accs_ = O.keyswitch_qp_hoisted(level, a[z], [evks[kid_] for kid_, g_ in rots])
