@@ -39,6 +39,10 @@ struct __attribute__((aligned(16))) HcTw { u64 w, ws; };
 // (one uniform branch per workgroup, two copies of the loop; a run-time condition around the two load forms made the compiler issue both loads). HC_LD / HC_ST take the ROW's
 // base pointer (8-byte words) and the element index inside the row.
 template <bool B> struct HcBool { static constexpr bool value = B; };
+template <int V> struct HcInt { static constexpr int value = V; };
+// a small block-uniform count as a compile-time constant of a generic lambda: the loads of a coefficient's n operands become one straight run instead of `if (i < n)` per operand
+#define HC_COUNT_DISPATCH(n, body) do { switch (n) { case 1: body(HcInt<1>{}); break; case 2: body(HcInt<2>{}); break; case 3: body(HcInt<3>{}); break; case 4: body(HcInt<4>{}); break; \
+    case 5: body(HcInt<5>{}); break; case 6: body(HcInt<6>{}); break; case 7: body(HcInt<7>{}); break; case 8: body(HcInt<8>{}); break; default: break; } } while (0)
 #define HC_LD(S32, rowptr, j) ((S32) ? hc_ld32(rowptr, j) : (rowptr)[j])
 #define HC_ST(S32, rowptr, j, v) do { if (S32) hc_st32(rowptr, j, v); else (rowptr)[j] = (v); } while (0)
 #define HC_ROW_DISPATCH(row32, body) do { if (row32) body(HcBool<true>{}); else body(HcBool<false>{}); } while (0)
@@ -628,6 +632,9 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_lv_pointwise(const u64 *a, const 
 #define HC_MAXLIN 8
 struct HcLinPtrs { const u64 *a0[HC_MAXLIN], *a1[HC_MAXLIN]; };
 struct HcLinConsts { u64 c[HC_MAXLIN][32]; u64 addc[32]; };
+// NT = the number of terms at compile time: the loads of a coefficient's terms are one straight run (with `if (t < nterms)` around each of them the compiler branched per term and
+// waited for one load at a time: the basis extension's story, section 4b)
+template <int NT>
 __global__ __launch_bounds__(HC_TPB) void hc_k_lv_lincomb(HcLinPtrs P, HcLinConsts K, int nterms, u64 *o0, u64 *o1, const HcMod *mods, size_t is) {
     const int l = blockIdx.y, k = blockIdx.z & 1; const HcMod m = mods[l];
     const size_t base = (size_t)l * 65536 + (size_t)(blockIdx.z >> 1) * is;
@@ -637,7 +644,7 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_lv_lincomb(HcLinPtrs P, HcLinCons
     for (size_t i = (size_t)blockIdx.x * HC_TPB + threadIdx.x; i < 65536; i += (size_t)gridDim.x * HC_TPB) {
         u128 T = 0;
 #pragma unroll
-        for (int t = 0; t < HC_MAXLIN; t++) if (t < nterms) T += (u128)HC_LD(S32, (k ? P.a1[t] : P.a0[t]) + base, i) * K.c[t][l];
+        for (int t = 0; t < NT; t++) T += (u128)HC_LD(S32, (k ? P.a1[t] : P.a0[t]) + base, i) * K.c[t][l];
         HC_ST(S32, o, i, hc_addmod(hc_mont_redc(T, m.q, m.qinv), addc, m.q));
     }
     };
@@ -2234,23 +2241,31 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_yv(const u64 *src, size_t s
     const int n = B0.n;
     yv += (size_t)blockIdx.y * yv_rows * 65536;                               // [operand + nz * image][yv_rows][N]: rows y_0..y_(n-1), then v (a last, shorter digit leaves rows unused)
     const HcBasisExt &BL = MDRS ? *mdrs : B0; const HcQ QL = hc_q(BL.t); const HcTw wL = MDRS ? *mdrs_pinv : HcTw{0, 0};
+    auto body = [&](auto nc) {                                               // NN = n at compile time: the n source words of a coefficient (and t's word) are requested together
+    constexpr int NN = decltype(nc)::value;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        double vi = 0.0; u64 yy[9];
+        double vi = 0.0; u64 yy[9], xs[NN];
 #pragma unroll
-        for (int i = 0; i < 8; i++) if (i < n) {
-            const u64 x = hc_barrett64(src[(size_t)i * src_stride + j], B0.s[i], B0.mu_s[i]);
-            const u64 y = n == 1 ? x : hc_mul_shoup(x, B0.inv[i].w, B0.inv[i].ws, B0.s[i]);
+        for (int i = 0; i < NN; i++) xs[i] = src[(size_t)i * src_stride + j];
+        u64 *tu = const_cast<u64 *>(src) - src_stride + j;
+        const u64 tu0 = MDRS ? *tu : 0;
+#pragma unroll
+        for (int i = 0; i < NN; i++) {
+            const u64 x = hc_barrett64(xs[i], B0.s[i], B0.mu_s[i]);
+            const u64 y = NN == 1 ? x : hc_mul_shoup(x, B0.inv[i].w, B0.inv[i].ws, B0.s[i]);
             vi += (double)y / (double)B0.s[i];
             yv[(size_t)i * 65536 + j] = y; if (MDRS) yy[i] = y;
         }
-        yv[(size_t)n * 65536 + j] = (u64)vi;
+        yv[(size_t)NN * 65536 + j] = (u64)vi;
         if (MDRS) {
 #pragma unroll
-            for (int i = 1; i < 9; i++) if (i == n) yy[i] = (u64)vi;
-            u64 *tu = const_cast<u64 *>(src) - src_stride + j;
-            *tu = hc_submod(*tu, hc_mul_shoup(hc_basis_ext_sum<8>(yy, BL, QL), wL.w, wL.ws, BL.t), BL.t);
+            for (int i = NN + 1; i < 9; i++) yy[i] = 0;
+            yy[NN] = (u64)vi;
+            *tu = hc_submod(tu0, hc_mul_shoup(hc_basis_ext_sum<8>(yy, BL, QL), wL.w, wL.ws, BL.t), BL.t);
         }
     }
+    };
+    HC_COUNT_DISPATCH(n, body);
 }
 // The v row alone, for y_i rows the inverse transform already left in place (hc_cols_inv_canon_mm_body's scale): v = uint64(sum_i float64(y_i) / float64(s_i)), limb order,
 // exactly hc_k_basis_yv's sum. yv: [operand + nz * image][yv_rows][N]; rows 0..n-1 are read, row n is written. grid = (HC_GX_YV, nz * images)
@@ -2259,12 +2274,19 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_v(u64 *yv, int yv_rows, con
     const HcBasisExt &B0 = Bs[z_alpha > 0 ? (size_t)zi * rows : 0];
     const int n = B0.n;
     yv += (size_t)blockIdx.y * yv_rows * 65536;
+    auto body = [&](auto nc) {                                               // NN = n at compile time: a coefficient's n words are requested together
+    constexpr int NN = decltype(nc)::value;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        u64 y[NN];
+#pragma unroll
+        for (int i = 0; i < NN; i++) y[i] = yv[(size_t)i * 65536 + j];
         double vi = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) if (i < n) vi += (double)yv[(size_t)i * 65536 + j] / (double)B0.s[i];
-        yv[(size_t)n * 65536 + j] = (u64)vi;
+        for (int i = 0; i < NN; i++) vi += (double)y[i] / (double)B0.s[i];
+        yv[(size_t)NN * 65536 + j] = (u64)vi;
     }
+    };
+    HC_COUNT_DISPATCH(n, body);
 }
 // The inner product of a key switch in one launch, BOTH key components and ALL images of a batch per thread:
 //   acc[img][k][T] = sum_d evk[d][k][T] (*)_mont c2_{img,d}[T]      (a digit's own limbs [lo, hi) read the NTT-domain input cx instead of the extension)
@@ -2507,17 +2529,24 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_qp_mul_sum_g(HcTermPtrsG P, int n
             for (int g = 0; g < NB; g++) s[h][g] = (P.acc[h] && g < n) ? HC_LD(S32, P.out[h] + (size_t)(g0 + g) * o_is + base, i) : 0;
         for (int t = 0; t < nterms; t++) {
             u64 y[G];
-#pragma unroll
-            for (int h = 0; h < G; h++) y[h] = P.pt[h][t] != nullptr ? hc_mont(HC_LD(S32, P.pt[h][t] + prow, i), m.r2, m.q, m.qinv) : 0;      // MForm, once for all images; 0 = no diagonal (uniform)
             const u64 *a = P.a[t] + (size_t)g0 * a_is + base;
+            // the G diagonals and NB images of a term as ONE run of loads: a missing diagonal reads the rotation's own row (a valid address) and counts as 0, an image beyond the
+            // batch re-reads the last one's element - no condition around a load
+            u64 yr[G], x[NB];
+#pragma unroll
+            for (int h = 0; h < G; h++) yr[h] = HC_LD(S32, P.pt[h][t] != nullptr ? P.pt[h][t] + prow : a, i);
+#pragma unroll
+            for (int g = 0; g < NB; g++) x[g] = HC_LD(S32, a + (size_t)(g < n ? g : n - 1) * a_is, i);
+#pragma unroll
+            for (int h = 0; h < G; h++) y[h] = P.pt[h][t] != nullptr ? hc_mont(yr[h], m.r2, m.q, m.qinv) : 0;      // MForm, once for all images; 0 = no diagonal (uniform)
             const int ph = t % 7;
 #pragma unroll
             for (int g = 0; g < NB; g++) if (g < n) {
-                const u64 x = HC_LD(S32, a + (size_t)g * a_is, i);
+                const u64 x_ = x[g];
 #pragma unroll
                 for (int h = 0; h < G; h++) {
                     if (ph == 0) T[h][g] = 0;
-                    if (P.pt[h][t] != nullptr) T[h][g] += (u128)x * y[h];
+                    if (P.pt[h][t] != nullptr) T[h][g] += (u128)x_ * y[h];
                     if (ph == 6 || t + 1 == nterms) s[h][g] = hc_addmod(s[h][g], hc_mont_redc(T[h][g], m.q, m.qinv), m.q);
                 }
             }

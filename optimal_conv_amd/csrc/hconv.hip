@@ -691,7 +691,10 @@ extern "C" int hc_lv_lincomb2(hc_ctx *c, int level, int nterms, const uint64_t *
         for (int l = 0; l <= level; l++) { const u64 q = c->mods[(size_t)l].m.q; K.c[t][l] = (u64)((((u128)(consts[(size_t)t * (level + 1) + l] % q)) << 64) % q); }
     }
     if (addc) for (int l = 0; l <= level; l++) K.addc[l] = addc[l] % c->mods[(size_t)l].m.q;
-    return hc_launch(c, "lv_lincomb", hc_k_lv_lincomb, dim3(HC_GX_LIN, (unsigned)(level + 1), 2u * (unsigned)c->nb), P, K, nterms, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, c->bs_poly);
+#define HC_LINCOMB(NT) case NT: return hc_launch(c, "lv_lincomb", hc_k_lv_lincomb<NT>, dim3(HC_GX_LIN, (unsigned)(level + 1), 2u * (unsigned)c->nb), P, K, nterms, (u64 *)out0, (u64 *)out1, (const HcMod *)c->d_mods, c->bs_poly)
+    switch (nterms) { HC_LINCOMB(1); HC_LINCOMB(2); HC_LINCOMB(3); HC_LINCOMB(4); HC_LINCOMB(5); HC_LINCOMB(6); HC_LINCOMB(7); HC_LINCOMB(8); }
+#undef HC_LINCOMB
+    return hc_fail(c, HC_ERR_ARG, "hc_lv_lincomb2: %d terms", nterms);
 }
 extern "C" int hc_lv_mod_raise(hc_ctx *c, int level, const uint64_t *in_q0, uint64_t *out) {
     HC_ENTER(c); HC_TRY(hc_lv_check(c, "hc_lv_mod_raise", level, in_q0, out));
