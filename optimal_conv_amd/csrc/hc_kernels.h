@@ -2370,10 +2370,10 @@ struct HcKeyPtrs { const u64 *k[8]; };
 // The tail of a hoisted rotation inside the inner product (round 5): rotation r's result leaves as out_r = Permute_g(acc_r + [P c0 on the Q rows of component 0]) - what
 // hc_k_qp_rotate_finish does in a pass of its own over the accumulators (read 2 nt rows, write 2 nt rows, per rotation) - by storing element j at the position the permutation sends
 // it to: hc_perm_src(., g^-1). An aligned block of 2^m indices maps onto an aligned block of 2^m indices (the low bits of g (2 r + 1) depend on the low bits of r only), so the
-// 64 lanes of a wavefront still fill whole 128-byte lines. out[0] == null: plain accumulators (acc), as before.
+// 64 lanes of a wavefront still fill whole 128-byte lines. (Kernel template parameter FIN; without it: plain accumulators (acc), as before.)
 struct HcRotFin { u64 *out[8]; u32 ginv[8]; const u64 *pc0; size_t pc0_is, out_is; };
 // per-digit form as hc_ks_mac_all_digit: the 2 R key words of a digit (all rotations) and its NB digit words are one run of loads
-template <int R, int NB, bool P32, bool U32>
+template <int R, int NB, bool P32, bool U32, bool FIN>
 __device__ __forceinline__ void hc_ks_mac_multi_digit(const HcKeyPtrs &keys, int nrot, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_rs, size_t acc_is, const HcMod m, int T,
                                                       int nl, int nt, int alpha, int beta, int n, const HcRotFin &F) {
     const size_t rowT = (size_t)T * 65536, comp = (size_t)nt * 65536;
@@ -2404,7 +2404,7 @@ __device__ __forceinline__ void hc_ks_mac_multi_digit(const HcKeyPtrs &keys, int
                     s1[r][g] = d == 0 ? p1 : hc_addmod(s1[r][g], p1, m.q);
                 }
         }
-        if (F.out[0] != nullptr) {                                            // uniform: the rotations' tails here (HcRotFin)
+        if (FIN) {                                                            // the rotations' tails here (HcRotFin); a compile-time choice: with both store forms in one kernel it ran out of SGPRs
             if (F.pc0 != nullptr && T < nl) {
 #pragma unroll
                 for (int g = 0; g < NB; g++) if (g < n) {
@@ -2427,15 +2427,15 @@ __device__ __forceinline__ void hc_ks_mac_multi_digit(const HcKeyPtrs &keys, int
             for (int g = 0; g < NB; g++) if (g < n) { u64 *a = acc + (size_t)r * acc_rs + (size_t)g * acc_is + rowT; HC_ST(U32, a, j, s0[r][g]); HC_ST(U32, a + comp, j, s1[r][g]); }
     }
 }
-template <int R, int NB>
+template <int R, int NB, bool FIN>
 __global__ __launch_bounds__(HC_TPB, HC_MACM_WAVES) void hc_k_ks_mac_multi(HcKeyPtrs keys, int nrot, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_rs, size_t acc_is, const HcMod *mods,
                                                             int nl, int nq, int nt, int alpha, int beta, int n, int pk, HcRotFin F) {
     const int T = blockIdx.y;
     const HcMod m = mods[T < nl ? T : nq + (T - nl)];
     const bool small = HC_SMALL_Q(m.q);                                      // block-uniform
-    if (pk && small && m.row32) hc_ks_mac_multi_digit<R, NB, true, true>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n, F);
-    else if (pk && small) hc_ks_mac_multi_digit<R, NB, true, false>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n, F);
-    else hc_ks_mac_multi_digit<R, NB, false, false>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n, F);
+    if (pk && small && m.row32) hc_ks_mac_multi_digit<R, NB, true, true, FIN>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n, F);
+    else if (pk && small) hc_ks_mac_multi_digit<R, NB, true, false, FIN>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n, F);
+    else hc_ks_mac_multi_digit<R, NB, false, false, FIN>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n, F);
 }
 // ModDown's last step and evaluator.permuteNTT's tail in one pass (rotations: the key-switched polynomials never reach HBM unpermuted):
 //   out_0[l][i] = ((acc_0 - ext_0) * P^-1 + c0)[l][src(i)],  out_1[l][i] = ((acc_1 - ext_1) * P^-1)[l][src(i)],  src = PermuteNTTIndex(g)
