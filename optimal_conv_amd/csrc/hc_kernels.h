@@ -2232,7 +2232,8 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_mdrs_prep(u64 *acc, size_t acc_zs
 }
 // mdrs != null (ModDown fused with Rescale, hc_ks_moddown_rescale): the row BEFORE the n source rows holds u = InvNTT(acc_L / P + add_L); it becomes t = u - ext_L / P with ext_L the
 // extension of this very coefficient into limb L (constants *mdrs, P^-1 mod q_L = *mdrs_pinv) - hc_k_mdrs_last's work, here where the y_i / v are still in registers
-template <bool MDRS>
+// PRE: the source rows already hold y_i (the inverse transform's `scale`, hc_cols_inv_canon_mm_body) and ARE rows 0..n-1 of yv: only v and t are written
+template <bool MDRS, bool PRE = false>
 __global__ __launch_bounds__(HC_TPB) void hc_k_basis_yv(const u64 *src, size_t src_stride, u64 *yv, int yv_rows, const HcBasisExt *Bs, int rows, size_t zs_src, int z_alpha, int nz, size_t is_src,
                                                         const HcBasisExt *mdrs, const HcTw *mdrs_pinv) {
     const int zi = (int)blockIdx.y % nz, img = (int)blockIdx.y / nz;
@@ -2251,10 +2252,11 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_yv(const u64 *src, size_t s
         const u64 tu0 = MDRS ? *tu : 0;
 #pragma unroll
         for (int i = 0; i < NN; i++) {
-            const u64 x = hc_barrett64(xs[i], B0.s[i], B0.mu_s[i]);
-            const u64 y = NN == 1 ? x : hc_mul_shoup(x, B0.inv[i].w, B0.inv[i].ws, B0.s[i]);
+            u64 y = xs[i];
+            if (!PRE) { const u64 x = hc_barrett64(xs[i], B0.s[i], B0.mu_s[i]); y = NN == 1 ? x : hc_mul_shoup(x, B0.inv[i].w, B0.inv[i].ws, B0.s[i]); }
             vi += (double)y / (double)B0.s[i];
-            yv[(size_t)i * 65536 + j] = y; if (MDRS) yy[i] = y;
+            if (!PRE) yv[(size_t)i * 65536 + j] = y;
+            if (MDRS) yy[i] = y;
         }
         yv[(size_t)NN * 65536 + j] = (u64)vi;
         if (MDRS) {

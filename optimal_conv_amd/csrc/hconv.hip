@@ -122,7 +122,7 @@ struct hc_ctx {
     HcRowMod *d_rowmods = nullptr;                          // per modulus: both twiddle tables + q, mu (multi-modulus batched transforms)
     u64 *ws_mm = nullptr; size_t ws_mm_rows = 0;            // scratch of the batched key switch / rescale
     u64 *ws_accm = nullptr; size_t ws_accm_rows = 0;        // inner products of several hoisted rotations (hc_keyswitch_qp_rotate_many)
-    struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr, *pmod = nullptr, *pinv_qlinv = nullptr, *yinv = nullptr; };    // yinv[l]: (S/q_l)^-1 mod q_l, S = the product of the limbs of l's digit (the source side of the extension: hc_k_cols_inv_canon_mm's scale); entries nl..nl+alpha-1: the same for the P limbs (ModDown)     // pmod: P mod q_i; pinv_qlinv: (P q_level)^-1 mod q_i, i < level
+    struct KsPlan { HcBasisExt *bx = nullptr, *bxdown = nullptr; HcTw *pinv = nullptr, *pmod = nullptr, *pinv_qlinv = nullptr, *yinv = nullptr, *yinv1 = nullptr; };    // yinv[l]: (S/q_l)^-1 mod q_l, S = the product of the limbs of l's digit (the source side of the extension: hc_k_cols_inv_canon_mm's scale); entries nl..nl+alpha-1: the same for the P limbs (ModDown)     // pmod: P mod q_i; pinv_qlinv: (P q_level)^-1 mod q_i, i < level
     std::map<int, KsPlan> ks_plan;                          // per level: basis-extension constants of every (digit, target limb)
     std::map<int, HcTw *> rescale_plan;                     // per level: qL^-1 mod q_i
     int nb = 1; size_t bs_poly = 0, bs_qp = 0;              // image batch of the leveled entry points (hc_set_batch): images, words between the images of a polynomial / of an extended-basis pair
@@ -1279,8 +1279,11 @@ static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
         std::vector<HcTw> hy((size_t)nt);
         for (int l = 0; l < nl; l++) hy[(size_t)l] = hb[(size_t)(l / alpha) * nt].inv[l % alpha];
         for (int j = 0; j < alpha; j++) hy[(size_t)(nl + j)] = hd[0].inv[j];
+        std::vector<HcTw> hy1(hy);                         // yinv1: 1 on the Q rows (ModDown fused with Rescale transforms row `level` beside the P rows: it leaves unscaled)
+        for (int l = 0; l < nl; l++) hy1[(size_t)l] = h_pair(1, c->mods[(size_t)l].m.q);
         hc_ctx::KsPlan P;
         HC_HIP(c, hcx_malloc(c, (void **)&P.yinv, hy.size() * sizeof(HcTw))); HC_HIP(c, hcx_h2d(c, P.yinv, hy.data(), hy.size() * sizeof(HcTw)));
+        HC_HIP(c, hcx_malloc(c, (void **)&P.yinv1, hy1.size() * sizeof(HcTw))); HC_HIP(c, hcx_h2d(c, P.yinv1, hy1.data(), hy1.size() * sizeof(HcTw)));
         HC_HIP(c, hcx_malloc(c, (void **)&P.bx, hb.size() * sizeof(HcBasisExt))); HC_HIP(c, hcx_malloc(c, (void **)&P.bxdown, hd.size() * sizeof(HcBasisExt))); HC_HIP(c, hcx_malloc(c, (void **)&P.pinv, hp.size() * sizeof(HcTw)));
         HC_HIP(c, hcx_h2d(c, P.bx, hb.data(), hb.size() * sizeof(HcBasisExt)));
         HC_HIP(c, hcx_h2d(c, P.bxdown, hd.data(), hd.size() * sizeof(HcBasisExt)));
@@ -1292,16 +1295,16 @@ static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
     *out = &pit->second;
     return HC_OK;
 }
-// scratch of one key switch at `level` for the nb images of the batch, section-major: coef[img][nl] | digits[img][beta][nt] | acc[img][2][nt] | pc[img][2][alpha + 1] | ext[img][2][nl] | yv[img][max(beta, 2)][alpha + 1]
+// scratch of one key switch at `level` for the nb images of the batch, section-major: coef[img][nl] | digits[img][beta][nt] | acc[img][2][nt] | pc[img][2][alpha + 2] | ext[img][2][nl] | yv[img][max(beta, 2)][alpha + 1]
 #ifndef HC_MAC_NB
 #define HC_MAC_NB 4                  // images per thread of the key switch's inner product at batches above 2 (hc_k_ks_mac_all)
 #endif
 struct HcKsScratch { u64 *coef, *digits, *acc, *pc, *ext, *yv; size_t coef_is, digits_is, acc_is, pc_is, ext_is; };
 static int hc_ks_scratch(hc_ctx *c, int level, HcKsScratch *S) {
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha; const size_t nb = (size_t)c->nb;
-    S->coef_is = (size_t)nl * HC_N; S->digits_is = (size_t)beta * nt * HC_N; S->acc_is = (size_t)2 * nt * HC_N; S->pc_is = (size_t)2 * (alpha + 1) * HC_N; S->ext_is = (size_t)2 * nl * HC_N;
+    S->coef_is = (size_t)nl * HC_N; S->digits_is = (size_t)beta * nt * HC_N; S->acc_is = (size_t)2 * nt * HC_N; S->pc_is = (size_t)2 * (alpha + 2) * HC_N; S->ext_is = (size_t)2 * nl * HC_N;
     const size_t yv_rows = (size_t)(beta > 2 ? beta : 2) * (alpha + 1);                // y_i / v rows of the decomposition's digits, later of ModDown's two polynomials
-    HC_TRY(hc_ensure_mm(c, nb * ((size_t)nl + (size_t)beta * nt + 2 * nt + 2 * (alpha + 1) + 2 * nl + yv_rows)));
+    HC_TRY(hc_ensure_mm(c, nb * ((size_t)nl + (size_t)beta * nt + 2 * nt + 2 * (alpha + 2) + 2 * nl + yv_rows)));
     S->coef = c->ws_mm; S->digits = S->coef + nb * S->coef_is; S->acc = S->digits + nb * S->digits_is; S->pc = S->acc + nb * S->acc_is; S->ext = S->pc + nb * S->pc_is; S->yv = S->ext + nb * S->ext_is;
     return HC_OK;
 }
@@ -1357,18 +1360,18 @@ static int hc_ks_moddown_rescale(hc_ctx *c, int level, u64 *acc, size_t acc_is, 
     const hc_ctx::KsPlan *P; HC_TRY(hc_ks_plan(c, level, &P));
     const HcTw *qlinv; HC_TRY(hc_rescale_plan(c, level, &qlinv));
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, nb = c->nb;
-    const size_t tz = (size_t)(alpha + 1) * HC_N, yz = tz;
+    const size_t tz = (size_t)(alpha + 2) * HC_N;            // pc[z] = [u -> t | y_0 .. y_(alpha-1) | v]: the extension reads its y_i / v rows where the inverse transform left them
     if (!prepped)       // (the inner product of hc_keyswitch_add_rescale leaves row `level` as acc_L / P + add_L already: HcMacPrep)
     HC_TRY(hc_launch(c, "moddown:mdrs_prep", hc_k_mdrs_prep, dim3(HC_GX_YV, 2u * (unsigned)nb), acc, (size_t)nt * HC_N, acc_is, add0, add0 ? (size_t)(add1 - add0) : (size_t)0, c->bs_poly, level, (const HcTw *)P->pinv, (const HcMod *)c->d_mods));
     // InvNTT of row `level` and of the P rows of both components in one pair of launches: pc[z] = [u | the alpha P rows]
-    HC_TRY(hc_intt_mm(c, acc, S.pc - (size_t)level * HC_N, nt, nl, 2, (size_t)nt * HC_N, tz, 0, level, nb, acc_is, S.pc_is, "moddown"));
-    // source side of the P rows' extension and, with each coefficient's y_i / v still in registers, t = u - ext_L / P on the row before them (what hc_k_mdrs_last did in a launch of its own)
-    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv<true>, dim3(HC_GX_YV, 2u * (unsigned)nb), (const u64 *)(S.pc + HC_N), (size_t)HC_N, S.yv, alpha + 1, (const HcBasisExt *)P->bxdown, nl, tz, 0, 2, S.pc_is,
+    HC_TRY(hc_intt_mm(c, acc, S.pc - (size_t)level * HC_N, nt, nl, 2, (size_t)nt * HC_N, tz, 0, level, nb, acc_is, S.pc_is, "moddown", false, P->yinv1, 0));       // the P rows leave as y_i (hc_ks_decompose_into), row `level` as it is
+    // v of the P rows' extension and, with each coefficient's y_i / v in registers, t = u - ext_L / P on the row before them (what hc_k_mdrs_last did in a launch of its own)
+    HC_TRY(hc_launch(c, "moddown:basis_yv", hc_k_basis_yv<true, true>, dim3(HC_GX_YV, 2u * (unsigned)nb), (const u64 *)(S.pc + HC_N), (size_t)HC_N, S.pc + HC_N, alpha + 2, (const HcBasisExt *)P->bxdown, nl, tz, 0, 2, S.pc_is,
                      (const HcBasisExt *)(P->bxdown + level), (const HcTw *)(P->pinv + level)));
     HcMmFuse F; F.ext_bs = P->bxdown; F.ext_rows = nl; F.lift_level = level; F.lift_t = S.pc; F.lift_t_zs = tz; F.lift_t_is = S.pc_is; F.lift_pmul = P->pmod;
     F.epi_x = acc; F.epi_x_zs = (size_t)nt * HC_N; F.epi_x_is = acc_is; F.epi_mul = P->pinv_qlinv;
     if (add0) { F.epi_add = add0; F.epi_add_zs = (size_t)(add1 - add0); F.epi_add_is = c->bs_poly; F.epi_add_mul = qlinv; }
-    return hc_ntt_mm(c, S.yv, d0, level, level, 0, 0, 2, yz, (size_t)(d1 - d0), 0, nb, 2 * yz, c->bs_poly, "moddown", &F);
+    return hc_ntt_mm(c, S.pc + HC_N, d0, level, level, 0, 0, 2, tz, (size_t)(d1 - d0), 0, nb, S.pc_is, c->bs_poly, "moddown", &F);
 }
 // phase 2: inner product with the key (both components), then ModDownSplitNTTPQ
 static int hc_ks_apply_from(hc_ctx *c, const HcSwk &key, int level, const u64 *cx, const HcKsScratch &S, u64 *d0, u64 *d1, uint64_t rot_gal = 0, const u64 *rot_c0 = nullptr, const u64 *add0 = nullptr, const u64 *add1 = nullptr) {
