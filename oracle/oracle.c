@@ -1,5 +1,5 @@
 /*
- * oracle.c — CPU restatement (plain C, single thread) of the reference's conv hot path. See oracle.h.
+ * oracle.c — CPU restatement (plain C; the hot path on a single thread, the general-level key switch's independent rows on OpenMP threads) of the reference's conv hot path. See oracle.h.
  * TEST INFRASTRUCTURE: never linked into or called by the product library.
  *
  * Citations: `file.go:a-b` = /root/reference/file.go; `lattigo:` = the pinned dependency
@@ -387,12 +387,17 @@ void or_keyswitch_decompose(const or_ctx *c, int level, const uint64_t *cx, uint
     const int beta = (nl + alpha - 1) / alpha;
     const size_t n = (size_t)N;
     uint64_t *coef = malloc(sizeof(uint64_t) * n * (size_t)nl);                   /* cxInvNTT */
-    uint64_t *tmp = malloc(sizeof(uint64_t) * n);
+    /* The rows of the general-level functions (this one, or_keyswitch_mac, or_mod_down) are independent and run on OpenMP threads when the library is built with -fopenmp
+     * (oracle/Makefile): the Python replays of the reference's bootstrapping chains spend their time here. The hot path's functions - what bench.py times as cpu_baseline -
+     * carry no pragma and stay on one thread. */
+#pragma omp parallel for schedule(dynamic)
     for (int l = 0; l < nl; l++) or_intt(c, l, cx + (size_t)l * n, coef + (size_t)l * n);
     for (int d = 0; d < beta; d++) {
         const int lo = d * alpha, hi = (d + 1) * alpha < nl ? (d + 1) * alpha : nl, nd = hi - lo;
         uint64_t src[16]; for (int i = 0; i < nd; i++) src[i] = c->m[lo + i].q;
+#pragma omp parallel for schedule(dynamic)
         for (int T = 0; T < nt; T++) {
+            uint64_t *tmp = malloc(sizeof(uint64_t) * n);
             const int mod = T < nl ? T : c->nq + (T - nl);                         /* ctx modulus index of target limb */
             const or_mod *m = &c->m[mod];
             uint64_t *c2 = digits + ((size_t)d * (size_t)nt + (size_t)T) * n;
@@ -408,16 +413,18 @@ void or_keyswitch_decompose(const or_ctx *c, int level, const uint64_t *cx, uint
                 }
                 or_ntt(c, mod, tmp, c2);
             }
+            free(tmp);
         }
     }
-    free(coef); free(tmp);
+    free(coef);
 }
 /* rlwe.(*KeySwitcher).KeyswitchHoistedNoModDown: the inner product of a decomposition with one key */
 void or_keyswitch_mac(const or_ctx *c, int level, const uint64_t *digits, const uint64_t *evk, uint64_t *acc) {
     const int N = c->N, alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
     const size_t n = (size_t)N;
     memset(acc, 0, sizeof(uint64_t) * n * (size_t)nt * 2);                        /* [k][limb][N] */
-    for (int d = 0; d < beta; d++) for (int T = 0; T < nt; T++) {
+#pragma omp parallel for schedule(dynamic)
+    for (int T = 0; T < nt; T++) for (int d = 0; d < beta; d++) {                 /* (modular sums: the order of the digits does not matter) */
         const or_mod *m = &c->m[T < nl ? T : c->nq + (T - nl)];
         const uint64_t *c2 = digits + ((size_t)d * (size_t)nt + (size_t)T) * n;
         for (int k = 0; k < 2; k++) {
@@ -438,9 +445,11 @@ void or_mod_down(const or_ctx *c, int level, const uint64_t *x_qp, uint64_t *out
     const int N = c->N, alpha = c->np, nl = level + 1;
     const size_t n = (size_t)N;
     uint64_t psrc[16]; for (int j = 0; j < alpha; j++) psrc[j] = c->m[c->nq + j].q;
-    uint64_t *pc = malloc(sizeof(uint64_t) * n * (size_t)alpha), *tmp = malloc(sizeof(uint64_t) * n);
+    uint64_t *pc = malloc(sizeof(uint64_t) * n * (size_t)alpha);
     for (int j = 0; j < alpha; j++) or_intt(c, c->nq + j, x_qp + (size_t)(nl + j) * n, pc + (size_t)j * n);
+#pragma omp parallel for schedule(dynamic)
     for (int l = 0; l < nl; l++) {
+        uint64_t *tmp = malloc(sizeof(uint64_t) * n);
         const or_mod *m = &c->m[l];
         uint64_t pinv = 1; for (int j = 0; j < alpha; j++) pinv = mulmod(pinv, psrc[j] % m->q, m->q);
         pinv = powmod(pinv, m->q - 2, m->q);
@@ -449,8 +458,9 @@ void or_mod_down(const or_ctx *c, int level, const uint64_t *x_qp, uint64_t *out
         or_ntt(c, l, tmp, tmp);
         const uint64_t *a = x_qp + (size_t)l * n;
         for (int j = 0; j < N; j++) out[(size_t)l * n + (size_t)j] = mulmod(submod(a[j] % m->q, tmp[j], m->q), pinv, m->q);
+        free(tmp);
     }
-    free(pc); free(tmp);
+    free(pc);
 }
 void or_keyswitch(const or_ctx *c, int level, const uint64_t *cx, const uint64_t *evk, uint64_t *d0, uint64_t *d1) {
     const size_t n = (size_t)c->N, nt = (size_t)(level + 1 + c->np);
