@@ -14,6 +14,11 @@ max-over-ranks reduction of the elapsed time.
 Prints ONE JSON line (rank 0). `roofline.achieved` = algorithmic bytes per conv ((5B-1+2.5*log2B+0.5)
 MiB) / average conv duration measured with HIP events on the library's own stream; `cpu_baseline` = the CPU
 oracle (a port of the reference's Go/Lattigo path, one thread) timed on this host on one full `conv 3 3`.
+
+The line validates itself (`parity_check`): the oracle runs on the SAME planted inputs as ciphertext 0 of context 0, and its output is compared word for word with what
+the last timed step left on the GPU (outputs are cleared before the timed region); the convReLU 5 1 workload's launch set runs once more on the input and keys that were
+planted into the reference binary and its SHA-256 digests are compared with the binary's (tests/golden/ref_trace_chain_5_1.json); under N > 1 the sharded convolution
+is compared with the oracle too. Any mismatch: the line is still printed, then the process exits with status 1.
 """
 import argparse
 import json
@@ -67,26 +72,36 @@ def synth_rows(rng, q, shape):
     return (rng.integers(0, 1 << 62, size=shape, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
 
 
-def cpu_baseline(B):
-    """Time the CPU oracle (test infrastructure, used here only as the baseline being reported, never as the
-    product) on one full conv_then_pack at the bench workload."""
+def oracle_conv(B, ct_in, pl_ker, keys, bias):
+    """One conv_then_pack + bias on the CPU oracle (test infrastructure: the checker and the reported baseline, never the product) on the given planted
+    data; returns (output residues (2, N), seconds). `keys` = [(galEl = 2^j + 1, [b_Q0, a_Q0, b_P, a_P])] as handed to hc_evk_load."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle
     O = Oracle()
-    rng = np.random.default_rng(0xC0FFEE)
-    ct_in = np.stack([np.stack([synth_rows(rng, Q0, N), synth_rows(rng, Q1, N)]) for _ in range(2)])
-    ker = np.empty((B, 2, N), dtype=np.uint64)
-    ker[:, 0] = synth_rows(rng, Q0, (B, N)); ker[:, 1] = synth_rows(rng, Q1, (B, N))
     evk = np.zeros((16, 4, N), dtype=np.uint64)
-    evk[:, 0] = synth_rows(rng, Q0, (16, N)); evk[:, 1] = synth_rows(rng, Q0, (16, N))
-    evk[:, 2] = synth_rows(rng, P0, (16, N)); evk[:, 3] = synth_rows(rng, P0, (16, N))
+    for gal, k4 in keys:
+        evk[(gal - 1).bit_length() - 2] = np.stack(k4)          # row j - 1 for galEl = 2^j + 1 (tests/parity_cases.py: load_tree_keys)
     idx = O.idx_plaintexts()
-    bias = synth_rows(rng, Q0, N)
     t0 = time.perf_counter()
-    O.conv_then_pack(ct_in, 2.0 ** 30, ker, 2.0 ** 30, idx, evk, B, 1, 2.0 ** 30, bias)
-    dt = time.perf_counter() - t0
+    want, _ = O.conv_then_pack(ct_in, 2.0 ** 30, pl_ker, 2.0 ** 30, idx, evk, B, 1, 2.0 ** 30, bias)
+    return want, time.perf_counter() - t0
+
+
+def cpu_baseline(B, dt):
     return {"value": 1.0 / dt, "unit": "conv/s", "cores": 1, "kind": "port",
-            "sample": f"1 full conv_then_pack+bias at B={B} (N=2^16) on the C oracle, {dt:.2f} s, host has {os.cpu_count()} cores"}
+            "sample": f"1 full conv_then_pack+bias at B={B} (N=2^16) on the C oracle, {dt:.2f} s, host has {os.cpu_count()} cores; the SAME planted inputs as ciphertext 0 of context 0 of the timed region (parity_check compares the two outputs word for word)"}
+
+
+def first_difference(got, want):
+    """'ok' or the first differing word of two residue arrays, as the record the driver keeps"""
+    got, want = np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)
+    if got.shape != want.shape:
+        return f"shape {got.shape} != {want.shape}"
+    bad = np.flatnonzero(got != want)
+    if bad.size == 0:
+        return "ok"
+    i = int(bad[0])
+    return f"{bad.size} of {got.size} words differ; first at word {i} (poly {i // N}, coefficient {i % N}): gpu {int(got[i])} != oracle {int(want[i])}"
 
 
 CLI = os.path.join(ROOT, "optimal_conv_amd", "host", "conv")
@@ -128,6 +143,33 @@ def _write_resnet_csv(root, k, depth, n_images):
     np.savetxt(os.path.join(wdir, "final-fcbias.csv"), rng.uniform(-0.1, 0.1, 10), fmt="%.17g")
     for it in range(n_images):
         np.savetxt(os.path.join(pdir, f"test_image_{it}.csv"), np.random.default_rng(1000 + it).uniform(-1, 1, 32 * 32 * 3), fmt="%.17g")
+
+
+def chain_replay_check(device, relu_batch, work):
+    """The convReLU 5 1 workload's launch set once more on PLANTED data: `conv --test-mode convReLU 5 1 1` with HCONV_CHAIN_REPLAY=<seed of tests/golden/ref_trace_chain_5_1.json>
+    and the timed HCONV_IMAGE_BATCH. Image 0 carries the input and the switching keys `gotrace -chain` planted into the reference binary; the CLI prints the SHA-256 of
+    BootstrappConv_CtoS' two results and of the ciphertext the layer hands on, and they must be the binary's (the fixture is data recorded from /root/reference/test_run;
+    nothing of the reference is read here). Returns {"ctos0": .., "ctos1": .., "final": .., "match": bool}."""
+    import re
+    import subprocess
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_trace_chain_5_1.json")))
+    ev = ref["events"]
+    ctos = next(e for e in ev if e["fn"] == "BootstrappConv_CtoS")["digests"]
+    final = [e for e in ev if e["fn"] == "Rescale" and "digests" in e][-1]["digests"][0]
+    env = dict(os.environ, HCONV_SKIP_BL="1", HCONV_DEVICE=str(device), HCONV_SEED="31", HCONV_CHAIN_REPLAY=str(ref["seed"]), HCONV_IMAGE_BATCH=str(relu_batch))
+    r = subprocess.run([CLI, "--test-mode", "convReLU", "5", "1", "1"], cwd=work, capture_output=True, text=True, timeout=900, env=env)
+    if r.returncode != 0:
+        return {"match": False, "error": r.stderr[-400:]}
+    pat = r"^replay digest(?:\[(\d+)\])? (\S+) level (\d+) scale (\S+) ((?:[0-9a-f]{64} ?)+)$"
+    got = {m.group(2): (int(m.group(3)), float(m.group(4)), m.group(5).split()) for m in re.finditer(pat, r.stdout, re.M) if int(m.group(1) or 0) == 0}
+    out = {"fixture": "tests/golden/ref_trace_chain_5_1.json (SHA-256 of the reference binary's ciphertexts on the planted input and keys)",
+           "command": f"HCONV_IMAGE_BATCH={relu_batch} HCONV_CHAIN_REPLAY={ref['seed']} conv --test-mode convReLU 5 1 1 (image 0 of the launch set)", "match": True}
+    for name, want in (("ctos0", ctos[0]), ("ctos1", ctos[1]), ("final", final)):
+        g = got.get(name)
+        ok = g is not None and (g[0], g[1]) == (want["level"], want["scale"]) and g[2] == want["polys"]
+        out[name] = {"level": g[0] if g else None, "sha256": g[2] if g else None, "equals_reference_binary": bool(ok)}
+        out["match"] = out["match"] and bool(ok)
+    return out
 
 
 def chain_workloads(device, relu_batch, resnet_batch, resnet_images, relu=True):
@@ -184,6 +226,11 @@ def chain_workloads(device, relu_batch, resnet_batch, resnet_images, relu=True):
                 out["convReLU_5_1"] = {"error": "could not parse the CLI output", "stdout_tail": txt[-400:]}
         else:
             out["convReLU_5_1"] = {"error": r.stderr[-400:]}
+        if relu:        # the timed launch set (same batch, same options) on the reference's planted data: digests against the binary's
+            try:
+                out["convReLU_5_1_replay"] = chain_replay_check(device, relu_batch, work)
+            except Exception as e:
+                out["convReLU_5_1_replay"] = {"match": False, "error": repr(e)}
         _write_resnet_csv(work, 3, 20, resnet_images)
         r = subprocess.run([CLI, "resnet", "3", "20", "1", str(resnet_images), "false"], cwd=work, capture_output=True, text=True, timeout=1500, env=dict(env, HCONV_IMAGE_BATCH=str(resnet_batch)))
         if r.returncode == 0:
@@ -247,11 +294,15 @@ def sharded_conv_timing(rank, world, device, backend):
     for it in range(6):
         dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        conv_then_pack_sharded(ctx, cin, 2.0 ** 30, kh, 2.0 ** 30, B, 2.0 ** 30, bb, device=f"cuda:{device}")
+        res, _ = conv_then_pack_sharded(ctx, cin, 2.0 ** 30, kh, 2.0 ** 30, B, 2.0 ** 30, bb, device=f"cuda:{device}")
         ctx.sync()
         dist.barrier()
         times.append((time.perf_counter() - t0) * 1e3)
     out["sharded_conv_ms_rccl_gather"] = float(np.median(times[1:]))
+    want = None
+    if rank == 0:           # the first record from a multi-GPU box is also a correctness record: the last timed sharded convolution against the CPU oracle, all 2N words
+        want, _ = oracle_conv(B, ct_in, pl_ker, keys, bias)
+        out["parity_sharded_conv_rccl_gather"] = first_difference(res.cpu().numpy().view(np.uint64).reshape(2, N), want)
     ctx.ker_free(kh); ctx.close()
     dist.barrier()
     if rank == 0:
@@ -270,12 +321,13 @@ def sharded_conv_timing(rank, world, device, backend):
                 ctxs[0].sync()
                 ts.append((time.perf_counter() - t0) * 1e3)
             out["sharded_conv_ms"] = float(np.median(ts[1:]))
+            out["parity_sharded_conv"] = first_difference(o0.download((2, N)), want)
             out["devices_used"] = min(world, ndev)
             out["peer_access"] = "hipMemcpyPeerAsync between the devices' contexts; direct peer access enabled where hipDeviceCanAccessPeer allows (a failure to enable falls back to staged copies, reported on stderr)"
             for c, k in zip(ctxs, khs):
                 c.ker_free(k); c.close()
         except Exception as e:
-            out["sharded_conv_ms"] = None; out["sharded_conv_error"] = repr(e)
+            out["sharded_conv_ms"] = None; out["sharded_conv_error"] = repr(e); out["parity_sharded_conv"] = "not run: " + repr(e)
     dist.barrier()
     _ = dev_s
     return out if rank == 0 else None
@@ -347,7 +399,7 @@ def main():
         L = {"ctx": ctx, "bias": ctx.buf(bias), "ker": [], "in": [], "out": []}
         for z in range(args.batch_alt if (args.batch_alt and s_ % 2) else NB):
             L["ker"].append(ctx.ker_load(np.roll(pl_ker, s_ * NB + z, axis=0)))
-            L["in"].append(ctx.buf(np.roll(ct_in, 17 * (s_ * NB + z) + 1, axis=2)))
+            L["in"].append(ctx.buf(np.roll(ct_in, 17 * (s_ * NB + z), axis=2)))          # ciphertext 0 of context 0 = the planted data itself: the oracle's input below
             L["out"].append(ctx.buf(nwords=2 * N))
         lanes.append(L)
     ctx = lanes[0]["ctx"]
@@ -375,6 +427,10 @@ def main():
     sync_all()
     for _ in range(args.warmup):
         one_step()
+    sync_all()
+    for L in lanes:         # every output is cleared before the timed region: what is compared with the oracle below was written by the timed steps
+        for o in L["out"]:
+            o.upload(np.zeros(2 * N, dtype=np.uint64))
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
@@ -388,6 +444,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}" if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    timed_out0 = lanes[0]["out"][0].download((2, N))         # ciphertext 0 of context 0 after the LAST timed step (the region above is closed)
+    timed_out_last = lanes[-1]["out"][-1].download((2, N))    # ... and the last ciphertext of the last context (a rolled copy of the same data: must differ from it, and is non-zero)
 
     # per-kernel HIP-event profile (separate untimed pass: event records between launches perturb the stream)
     counter[0] = 0
@@ -450,8 +509,19 @@ def main():
                          "kernels_measured_with": {"contexts": 1, "ciphertexts_per_launch_set": NB, "note": "HIP events around every launch of one context, separate untimed pass"},
                          "loops": loops, "single_conv_ms": single_ms, "valu": valu},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B)
+        # The record proves its own work: the oracle (2 s, one core) runs on the SAME planted inputs as ciphertext 0 of context 0 and its output is compared word for word with
+        # what the timed region left there (conv.go:522-546 + eval.go:258). A mismatch fails the process after the line is printed.
+        if not args.no_cpu_baseline:
+            want, dt = oracle_conv(B, ct_in, pl_ker, keys, bias)
+            verdict = first_difference(timed_out0, want)
+            if verdict == "ok" and per_step > 1 and (not timed_out_last.any() or np.array_equal(timed_out_last, timed_out0)):
+                verdict = "the last resident ciphertext's output is zero or a copy of ciphertext 0's: the timed steps did not write it"
+            out["parity_check"] = {f"conv_{args.ker_wid}_{args.i_batch}": verdict,
+                                   "what": f"GPU output of ciphertext 0 / context 0 after the last of the {args.steps} timed steps (outputs cleared before the timed region; B={B}, n={NB}, chunk={args.chunk}, {S} contexts) == the CPU oracle on the same planted inputs, all {2 * N} words"}
+            if world == 1:
+                out["cpu_baseline"] = cpu_baseline(B, dt)
+        else:
+            out["parity_check"] = {f"conv_{args.ker_wid}_{args.i_batch}": "skipped (--no-cpu-baseline)"}
     for L in lanes:
         for k in L["ker"]:
             L["ctx"].ker_free(k)
@@ -495,14 +565,27 @@ def main():
     if not emitted.acquire(blocking=False):       # the watchdog is printing the headline: let it end the process
         time.sleep(60)
     watchdog.cancel()
+    failed = False
     if rank == 0:
         if wl is not None:
             out["workloads"] = wl
+            rp = wl.pop("convReLU_5_1_replay", None) if isinstance(wl, dict) else None
+            if rp is not None:
+                out["parity_check"]["convReLU_5_1"] = "ok" if rp.get("match") else "MISMATCH"
+                out["parity_check"]["convReLU_5_1_digests"] = rp
         if sharded is not None:
             out["sharded_conv"] = sharded
+            for k_ in ("parity_sharded_conv", "parity_sharded_conv_rccl_gather"):
+                if isinstance(sharded, dict) and k_ in sharded:
+                    out["parity_check"][k_[len("parity_"):]] = sharded.pop(k_)
         print(json.dumps(out), flush=True)
+        failed = any(isinstance(v, str) and v != "ok" and not v.startswith(("skipped", "not run")) for k_, v in out["parity_check"].items() if k_ != "what")
+        if failed:
+            print("bench.py: PARITY CHECK FAILED: " + json.dumps({k: v for k, v in out["parity_check"].items() if isinstance(v, str) and k != "what"}), file=sys.stderr, flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    if failed:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -42,7 +42,7 @@ typedef struct hc_ker hc_ker; /* device-resident kernel plaintexts pl_ker[0..max
 #define HC_ERR_UNSUPPORTED 4
 
 /* ---- context: replaces ckks.NewEvaluator(params, evk) for the pack evaluator (conv.go:258, main.go:446-461) ----
- * q[0..nq): ciphertext moduli in level order; p[0..np): special primes. NTT tables are derived as
+ * q[0..nq): ciphertext moduli in level order; p[0..np): special primes, np <= 5 (HC_ERR_UNSUPPORTED beyond: the reference's parameter sets use 1, 2 or 5). NTT tables are derived as
  * ring.genNTTParams does (psi = g^((q-1)/2N), g from ring.primitiveRoot). device = HIP device ordinal. */
 int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, const uint64_t *p, int np, int device);
 void hc_ctx_destroy(hc_ctx *ctx);
@@ -175,9 +175,6 @@ int hc_keyswitch_add_rescale(hc_ctx *ctx, uint64_t key_id, int level, const uint
  * uniform rows and the per-digit error (sigma 3.2, |e| <= 19) are functions of (seed, key_id, digit, limb, coefficient). The reference's keys are crypto/rand draws:
  * nothing to reproduce but the RLWE relation b + a s_out - [own limbs] P s_in = e, which tests/ check. The key is stored as hc_swk_load would store it. */
 int hc_swk_generate(hc_ctx *ctx, uint64_t key_id, int level, uint64_t galEl, const uint64_t *sk_ntt, const uint32_t *seed8);
-/* TEST HARNESS: the same key structure with the uniform rows of the test oracle's generator (counter-based splitmix64 of seed + 0x1000 + 64 digit + limb) and the
- * per-digit errors e_host[beta][N] (signed 64-bit, HOST) supplied by the caller: lets the product host replay, bit for bit, a network the oracle evaluated under its keys */
-int hc_swk_generate_splitmix(hc_ctx *ctx, uint64_t key_id, int level, uint64_t galEl, const uint64_t *sk_ntt, uint64_t seed, const int64_t *e_host);
 /* Hoisted form (evaluator.RotateHoisted, conv.go:131; Lattigo's linear transforms): hc_keyswitch_decompose computes the digit
  * decomposition of cx once and keeps it in the context; each hc_keyswitch_hoisted(key, level, cx, ...) then only does the inner
  * product with its key and the ModDown. Bit-identical to hc_keyswitch. The decomposition is valid until the next hc_keyswitch /
@@ -191,7 +188,10 @@ int hc_keyswitch_decompose(hc_ctx *ctx, int level, const uint64_t *cx);
  *                   hc_keyswitch == hc_keyswitch_qp followed by hc_mod_down2, bit for bit. A decomposition held by hc_keyswitch_decompose
  *                   survives hc_mod_down2 at the SAME level only (another level drops it); hc_keyswitch_qp(hoisted = 0) always re-decomposes and drops it.
  *  hc_qp_op2        out_k = a_k (op) b_k for k = 0, 1 over all level+1+np rows; op = HC_LV_MUL, HC_LV_ADD, HC_LV_MUL_ACC (out_k += a_k * b_k) or their _PLAIN forms (b0 = one plaintext);
- *                   b1 == b0 for a plaintext operand. (hc_permute works on any rows, so it permutes QP polynomials as they are.) */
+ *                   a plaintext operand (an encoded diagonal) is ONE polynomial shared by both components and by every image of a batch: say so with HC_LV_MUL_PLAIN /
+ *                   HC_LV_MUL_ACC_PLAIN (b1 NULL or b0). HC_LV_MUL / HC_LV_MUL_ACC with b0 == b1 inside an image batch (hc_set_batch n > 1) is refused with HC_ERR_ARG since
+ *                   hc_version() 2: version 1 inferred "shared plaintext" from it, and a per-image operand would now be read past the plaintext's allocation.
+ *                   (hc_permute works on any rows, so it permutes QP polynomials as they are.) */
 int hc_keyswitch_qp(hc_ctx *ctx, uint64_t key_id, int level, const uint64_t *cx, uint64_t *acc, int hoisted);
 /* one rotation of MultiplyByDiagMatrixBSGS as a single call (rotateHoistedNoModDown for a baby step: pc0 = P * c0; the giant step's SwitchKeysInPlaceNoModDown +
  * permutation: pc0 = NULL): out[2][level+1+np][N] (+)= Permute_galEl( hc_keyswitch_qp(cx) + (pc0 on the Q rows of the first component) ); accumulate != 0 adds to
@@ -296,15 +296,18 @@ int hc_bl_post_ker_slots(hc_ctx *ctx, const double *max_ker_rs, int in_wid, int 
  *      enter and leave the chain at levels 0 / 1, whose limbs are large, so the hot path converts nothing). The L0 one-row primitives (hc_ntt ... hc_permute with an explicit
  *      modulus or row count), the level-0/1 convolution path and hc_swk_generate's secret-key rows keep 8-byte rows. Same residues, bit for bit, in every setting.
  *   0: off. Keys are stored per the setting in force when they are loaded: switch between 0 and 1 / 2 only on a context without keys (HC_ERR_STATE otherwise).
- * HCONV_PACK32=0|1|2 in the environment sets the initial value at hc_ctx_create. */
+ * Setting 2 never applies to limbs 0 and 1 (the convolution's level-0 / 1 entry points and the secret-key rows read them as 8-byte rows whatever their size).
+ * The library reads NO configuration from the environment (a cgo host would inherit its shell's): every switch is an hc_set_option; this repo's CLI translates
+ * HCONV_PACK32 / HCONV_SMALL32 / HCONV_ROT_FUSE / HCONV_ASYNC_ALLOC into those calls (host/hconv_host.cpp applyEnvOptions). */
 int hc_row_is32(hc_ctx *ctx, int mod);
 /* ---- tuning / measurement ---- */
 int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes" (jobs - channels / tree nodes summed over the batch - per kernel launch), "small_levels" (tree levels of at most
                                                                   this many nodes x ciphertexts run on the quarter-tile kernels: default 16, 0 = never), "profile" (per-kernel HIP-event totals),
                                                                   "peer_access" (hc_conv_then_pack_sharded: 0 = do not enable direct peer copies; default 1: enabled where hipDeviceCanAccessPeer allows),
                                                                   "pack32" (0 / 1 / 2: 4-byte rows, above), "rot_fuse" (default 1: hc_keyswitch_qp_rotate_many stores every rotation's result already permuted and with P c0 added from inside the inner
-                                                                  product; 0: one pass per rotation over the accumulators - same residues, an A/B switch; HCONV_ROT_FUSE), "small32" (default 1: rows of a modulus below 2^31 take the 32-bit body of the batched
-                                                                  transform kernels; 0: the 64-bit body for every row - the same residues either way, an A/B switch; HCONV_SMALL32 at hc_ctx_create) */
+                                                                  product; 0: one pass per rotation over the accumulators - same residues, an A/B switch), "small32" (default 1: rows of a modulus below 2^31 take the 32-bit body of the batched
+                                                                  transform kernels; 0: the 64-bit body for every row - the same residues either way, an A/B switch), "async_alloc" (0, default: hipMalloc / hipFree; 1: a non-blocking stream and a per-context cache of blocks, so that hc_free never
+                                                                  drains the device - for several contexts driven from several host threads; only right after hc_ctx_create, HC_ERR_STATE once the context owns memory) */
 /* HIP-event timing on the context's stream */
 int hc_timer_start(hc_ctx *ctx);
 int hc_timer_stop(hc_ctx *ctx, float *ms);

@@ -1327,6 +1327,155 @@ __global__ __launch_bounds__(HC_TPB, HC_B5M_WAVES) void hc_k_b5m(HcLoopB B, HcTw
 #endif
 }
 
+// ---------------------------------------------------------------- KB5M with a LOADER wavefront (round 6 probe)
+// hc_k_b5m's epilogue is sixteen dependent round trips per workgroup (load two rows' operands -> wait -> multiply -> barrier -> store; the ISA shows exactly that order), and
+// what a CU keeps in flight - at best one 24 KiB row batch per resident workgroup - is what its fabric rate comes to (3.5 TB/s of the ~6 achievable). Register prefetch cannot
+// decouple it (round 5: HC_B5M_PIPE, +0.3 %): one batch of lookahead is 0.2 us of arithmetic against a 2-3 us round trip, and more batches do not fit the register file.
+// Here a FIFTH wavefront does nothing but `global_load_lds_dwordx4` (LDS-DMA: no VGPR destination, its own vmcnt) the epilogue operands of BOTH polynomials - y_k, x_k, the
+// idx pair and the key pair of a row: 48 bytes per coefficient, 12 KiB = twelve 1 KiB wave-instructions per row - into a ring of HC_LD_RING one-row slots behind the 32 KiB
+// tile; the four transform wavefronts read their operands from LDS and wait on global memory only for the transform's own tile and twiddles. The ring runs across the two
+// polynomials: while the transform wavefronts are in the second transform the loader already holds the first rows of its epilogue. Barrier protocol (every wavefront executes
+// the same 3 + 16 / R barriers per polynomial, + 1 in front of k = 0): a slot is refilled after the barrier that follows its last read; before the barrier that precedes the
+// first read of a row the loader waits until that row has landed (vmcnt is in order: rows issued - rows needed, x 12 instructions). LDS: 32 + HC_LD_RING x 12 KiB = 80 KiB:
+// two workgroups per CU (ten wavefronts).
+#ifndef HC_B5M_LOADER
+#define HC_B5M_LOADER 0
+#endif
+#if HC_B5M_LOADER && !defined(HC_EMU)
+#ifndef HC_LD_RING
+#define HC_LD_RING 4                  // one-row slots (each 1536 u64 words: y 256, x 256, idx pairs 512, key pairs 512)
+#endif
+#ifndef HC_LD_AUX
+#define HC_LD_AUX 0                   // cache policy bits of the LDS-DMA loads (2 = nt)
+#endif
+#define HC_LD_SLOT 1536
+#define HC_LD_TPB (HC_TPB + 64)
+typedef const void __attribute__((address_space(1))) *HcGlobalVoidPtr;
+typedef void __attribute__((address_space(3))) *HcLdsVoidPtr;
+// s_waitcnt vmcnt(n) needs an immediate: the callers' loops are fully unrolled, so n is a constant by the time this switch is compiled and one case survives
+__device__ __forceinline__ void hc_wait_vmcnt(int n) {
+#define HC_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) { HC_VMC(0) HC_VMC(12) HC_VMC(24) HC_VMC(36) HC_VMC(48) HC_VMC(60) default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break; }
+#undef HC_VMC
+}
+// one row (k = polynomial, kk = row of the tile) of epilogue operands into slot `slot`: 12 wave-instructions of 1 KiB
+__device__ __forceinline__ void hc_ld_row(u64 *ring, int slot, const u64 *ys, const u64 *xs, const HcTw *idx, const HcTw *evk, int k, int kk, int lane) {
+    u64 *s = ring + slot * HC_LD_SLOT;
+    const u64 *y = ys + (size_t)k * 65536 + kk * 256 + lane * 2, *x = xs + (size_t)k * 65536 + kk * 256 + lane * 2;
+    const HcTw *I = idx + kk * 256 + lane, *K = evk + (size_t)k * 65536 + kk * 256 + lane;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        __builtin_amdgcn_global_load_lds((HcGlobalVoidPtr)(y + h * 128), (HcLdsVoidPtr)(s + h * 128), 16, 0, HC_LD_AUX);
+        __builtin_amdgcn_global_load_lds((HcGlobalVoidPtr)(x + h * 128), (HcLdsVoidPtr)(s + 256 + h * 128), 16, 0, HC_LD_AUX);
+    }
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        __builtin_amdgcn_global_load_lds((HcGlobalVoidPtr)(I + h * 64), (HcLdsVoidPtr)(s + 512 + h * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((HcGlobalVoidPtr)(K + h * 64), (HcLdsVoidPtr)(s + 1024 + h * 128), 16, 0, 0);
+    }
+}
+// rows are numbered 0..31 through both polynomials (k = 1 first): row g is (k = g < 16, kk = g & 15) and lives in slot g % HC_LD_RING
+__device__ __forceinline__ void hc_ld_rows(int g0, int g1, u64 *ring, const u64 *ys, const u64 *xs, const HcTw *idx, const HcTw *evk, int lane) {
+#pragma unroll
+    for (int g = g0; g < g1; g++)
+        if (g < 32) hc_ld_row(ring, g % HC_LD_RING, ys, xs, idx, evk, g < 16 ? 1 : 0, g & 15, lane);
+}
+constexpr int hc_ld_min(int a, int b) { return a < b ? a : b; }
+template <int FM>
+__global__ __launch_bounds__(HC_LD_TPB, 3) void hc_k_b5m_ld(HcLoopB B, HcTwTab T0fwd, HcPtrs biases, HcPtrs outs) {
+    __shared__ u64 lds[HC_ROWS_LDS + HC_LD_RING * HC_LD_SLOT];
+    u64 *ring = lds + HC_ROWS_LDS;
+    constexpr int R = HC_B5_ROWS, S = HC_LD_RING, NBAT = 16 / R;
+    static_assert(S >= 2 * R && S % R == 0 && (S - R) * 12 <= 60, "ring: at least two row batches, a whole number of them, and a vmcnt that fits its 6-bit field");
+    const int zn = HC_JOB, z = zn / B.nodes, node = zn - z * B.nodes, i = (B.n0 + node) * B.norm;
+    const size_t tile0 = (size_t)HC_TILE * 4096;
+    const u64 *__restrict__ ys0 = B.src + (size_t)z * B.src_stride + (size_t)i * 2 * 65536 + tile0;
+    const u64 *__restrict__ xs0 = B.src + (size_t)z * B.src_stride + (size_t)(i + B.step) * 2 * 65536 + tile0;
+    if (threadIdx.x >= HC_TPB) {
+        // ---- the loader wavefront
+        const int lane = threadIdx.x - HC_TPB;
+        const HcTw *idx0 = B.idx + tile0, *evk0 = B.evkQ + tile0;
+        hc_ld_rows(0, S, ring, ys0, xs0, idx0, evk0, lane);
+#pragma unroll
+        for (int k = 1; k >= 0; k--) {
+            const int gb0 = (1 - k) * NBAT;                                   // first row batch of this polynomial
+            if (k == 0) __builtin_amdgcn_s_barrier();                         // in front of the second transform
+            __builtin_amdgcn_s_barrier();                                     // inside hc_rows_lo_to_lin
+            hc_wait_vmcnt((hc_ld_min(gb0 * R + S, 32) - (gb0 + 1) * R) * 12); // the first row batch of this polynomial has landed (rows issued - rows needed)
+            __builtin_amdgcn_s_barrier();                                     // behind hc_rows_lo_to_lin: the epilogue starts
+#pragma unroll
+            for (int b = 0; b < NBAT; b++) {
+                // batch gb (rows gb R .. gb R + R - 1) is being read; rows up to gb R + S - 1 are issued. The next batch of the SAME polynomial must have landed before the
+                // barrier (the next polynomial's first batch is waited for above); behind the barrier the slots of batch gb are free: rows gb R + S .. go into them
+                const int gb = gb0 + b, left = hc_ld_min(gb * R + S, 32) - (gb + 2) * R;
+                if (b + 1 < NBAT) hc_wait_vmcnt(left < 0 ? 0 : left * 12);
+                __builtin_amdgcn_s_barrier();
+                hc_ld_rows(gb * R + S, gb * R + S + R, ring, ys0, xs0, idx0, evk0, lane);
+            }
+        }
+        return;
+    }
+    // ---- the four transform wavefronts: hc_k_b5m with the epilogue operands read from the ring
+    const int t = threadIdx.x, tid = t & 15, rloc = t >> 4, row = HC_TILE * 16 + rloc;
+    const HcQ Q = hc_q(B.m0.q);
+    const u64 q = Q.q;
+    u64 *__restrict__ o = (outs.p[z] != nullptr ? const_cast<u64 *>(outs.p[z]) : B.dst + (size_t)z * B.dst_stride + (size_t)i * 2 * 65536) + tile0 + t;
+    const u64 *__restrict__ bias = biases.p[z] != nullptr ? biases.p[z] + tile0 + t : nullptr;
+    u64 e[16], T[16];
+    HC_UNROLL_N(HC_B5M_UNROLL)
+    for (int k = 1; k >= 0; k--) {
+        const u64 *__restrict__ in = B.tmpE + ((size_t)zn * 2 + k) * 65536 + (size_t)row * 256;
+#pragma unroll
+        for (int hi = 0; hi < 16; hi++) e[hi] = in[hi * 16 + tid];
+        if (k == 0) __syncthreads();
+        hc_rows_fwd<FM>(e, lds, T0fwd, row, rloc, tid, Q);
+        HC_ROW_SYNC();
+        hc_rows_lo_to_lin(e, lds, t, rloc, tid);
+        __syncthreads();
+        // the bias (root node of a tree only) is the one global load left in the epilogue: a copy of the loop for it, so that the common copy never waits on vmcnt
+        // (a conditional load inside the loop made every batch wait for vmcnt(0), i.e. for the previous batch's stores as well)
+        auto epilogue = [&](auto HB) {
+            constexpr bool HASB = decltype(HB)::value;
+#pragma unroll
+            for (int b = 0; b < 16; b += R) {
+                u64 Y[R], X[R], t1[R], bs[R]; HcTw K[R], I[R];
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const u64 *s = ring + (((1 - k) * 16 + b + j) % S) * HC_LD_SLOT;
+                    Y[j] = s[t]; X[j] = s[256 + t]; I[j] = *reinterpret_cast<const HcTw *>(s + 512 + 2 * t); K[j] = *reinterpret_cast<const HcTw *>(s + 1024 + 2 * t);
+                    bs[j] = HASB ? bias[(b + j) * 256] : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const int kk = b + j;
+                    u64 m = hc_shoup4(X[j], I[j].w, I[j].ws, Q), f;
+                    if (k == 1) T[kk] = hc_fold(Y[j] + Q.q4 - m, Q.nq4);
+                    u64 g = hc_shoup4(T[kk], K[j].w, K[j].ws, Q);
+                    if (FM == HC_FM_FREE) {
+                        t1[j] = Y[j] + m + bs[j];
+                        f = (k == 0 ? Y[j] + Q.q4 - m + g : g) + HC_FREE_OFF * q - e[kk];
+                    } else {
+                        m = hc_canon4(m, Q); g = hc_canon4(g, Q);
+                        t1[j] = hc_addmod(hc_addmod(Y[j], m, q), bs[j], q);
+                        f = hc_submod(k == 0 ? hc_addmod(hc_submod(Y[j], m, q), g, q) : g, hc_canon8(e[kk], Q), q);
+                    }
+                    lds[hc_rows_lds(kk, t)] = f;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const int kk = b + j;
+                    const u32 srcidx = hc_perm_src((u32)((HC_TILE * 16 + kk) * 256 + t), B.gal);
+                    const u64 d = lds[hc_rows_lds(kk, (int)(srcidx & 255))];
+                    o[(size_t)k * 65536 + kk * 256] = FM == HC_FM_FREE ? hc_reduce64(t1[j] + d, B.m0.mu, Q) : hc_addmod(t1[j], d, q);
+                }
+            }
+        };
+        if (k == 0 && bias != nullptr) epilogue(HcBool<true>{}); else epilogue(HcBool<false>{});
+    }
+}
+#endif
+
 // ================================================================ loop B for SMALL tree levels (round 3)
 // The top levels of a pack tree have 1..16 nodes: 16..256 workgroups for 256 CUs, one wave per SIMD, and a level costs the LATENCY of five
 // kernels (77..105 us whatever the node count; 0.45 ms of a lone convolution's 1.76) - each thread of the kernels above walks 64..192 butterflies
@@ -1704,9 +1853,7 @@ struct HcBasisExt {
 #ifndef HC_EXT_FULL
 #define HC_EXT_FULL 1                  // a straight-line form of the extension for operands with exactly NS source limbs (hc_basis_ext_tile)
 #endif
-#ifndef HC_EXT_NS
-#define HC_EXT_NS 1                    // size the extension's operand registers by the context's number of special primes (0: by the tables' 8, the round-4 form)
-#endif
+#define HC_MAX_NP 5                    // most special primes of a context (hc_ctx_create refuses more): the extension's operand registers are sized by it (NS = 2 or HC_MAX_NP)
 // target side of the extension for one coefficient: y[0..n-1] = the y_i, y[n] = v. NS = the most source limbs the caller can have (the context's number of special primes:
 // a digit has at most alpha limbs, ModDown extends from the alpha P limbs): the operand array - (NS + 1) registers pairs per coefficient in flight - is sized by it, not by the
 // 8 the constant tables admit. With NS = 5 (the bootstrapping chain) four coefficients in flight hold 48 VGPRs of operands instead of 72: hc_k_cols_fwd_mm<1> / <2> compile for

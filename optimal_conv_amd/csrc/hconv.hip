@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/hconv.h"
+#include "../../include/hconv_test_hooks.h"
 #include "hc_kernels.h"
 #include "hc_gomath.h"
 // workgroups per row of the streaming (grid-stride) kernels of the leveled evaluator and the key switch: a thread strides over 65536 / (256 x this) coefficients.
@@ -118,7 +119,8 @@ struct hc_ctx {
     HcMod *d_mods = nullptr; HcTw *d_csts = nullptr;      // device copies: all moduli (Q then P); per-call constants of the leveled ops
     struct CacheBlk { size_t n = 0; hipEvent_t ev = nullptr; bool pending = false; };
     std::map<char *, CacheBlk> cache_blk; std::map<size_t, std::vector<void *>> cache_free;      // HCONV_ASYNC_ALLOC=1: sizes of the blocks this context allocated; parked blocks by size
-    int async_alloc = 0;                                    // HCONV_ASYNC_ALLOC=1: non-blocking stream + cached allocations (see hcx_malloc)
+    int async_alloc = 0;                                    // option async_alloc = 1: non-blocking stream + cached allocations (see hcx_malloc)
+    long allocs_live = 0;                                   // hc_malloc blocks not yet freed (the allocation mode may only change while there are none)
     HcRowMod *d_rowmods = nullptr;                          // per modulus: both twiddle tables + q, mu (multi-modulus batched transforms)
     u64 *ws_mm = nullptr; size_t ws_mm_rows = 0;            // scratch of the batched key switch / rescale
     u64 *ws_accm = nullptr; size_t ws_accm_rows = 0;        // inner products of several hoisted rotations (hc_keyswitch_qp_rotate_many)
@@ -136,7 +138,7 @@ struct hc_ctx {
     long peer_access = 1;                 // hc_conv_then_pack_sharded: enable direct peer copies between distinct devices (0: leave the copies to hipMemcpyPeerAsync's staging)
     int xcd_rows = 1;                     // XCD-aware 1-D grid of the rows passes (HcMm::xcd; 0 = the plain 3-D grid, kept for A/B builds)
     int pack32 = 1;                       // 1: library-internal rows of moduli below 2^31 as 4-byte words (hc_kernels.h hc_ld32): transform seams, extended digits, switching keys. 2: the rows of the caller's leveled
-                                          // operands as well (include/hconv.h "4-byte rows"; option pack32 or HCONV_PACK32=2 at hc_ctx_create). 0: off (A/B)
+                                          // operands as well (include/hconv.h "4-byte rows"; option pack32). 0: off (A/B)
     int rot_fuse = 1;                     // hc_keyswitch_qp_rotate_many: the rotations' tails (+ P c0, permutation) in the inner product's stores (HcRotFin) instead of one hc_k_qp_rotate_finish per rotation (option rot_fuse / HCONV_ROT_FUSE=0 for A/B)
     int small32 = 1;                      // the batched transform kernels take their 32-bit form for rows of a modulus below 2^31 (hc_kernels.h HC_S32; option small32 / HCONV_SMALL32=0 for A/B)
     unsigned peer_warned = 0;             // bit d: enabling peer access to device d failed and was reported once
@@ -161,7 +163,7 @@ static int hc_fail(hc_ctx *c, int code, const char *fmt, ...) {
 // forward lazy-reduction mode by modulus size (see HC_FM_* in hc_kernels.h): FREE needs 74q < 2^64 <=> q < 2^57 (hc_fm_free); ALT needs 8q < 2^64
 // Allocation: plain hipMalloc / hipFree by default. hipFree synchronises the whole device, which is harmless with one context but
 // serialises independent contexts driven from several host threads (a thread's free waits for every other thread's queued work).
-// HCONV_ASYNC_ALLOC=1 at context creation gives this context a non-blocking stream and a cache of its own hipMalloc blocks: hc_free
+// Option async_alloc = 1 (set right after hc_ctx_create) gives this context a non-blocking stream and a cache of its own hipMalloc blocks: hc_free
 // parks a block, the next request of the same size takes it — no hipFree, hence no device-wide synchronisation, in steady state
 // (a layer asks for the same sizes again and again). Reuse is safe because every use of a block is queued on this context's stream
 // (see hcx_h2d_async for the one host-side exception). ROCm 7.2's own stream-ordered allocator (hipMallocAsync / hipFreeAsync) was
@@ -315,7 +317,7 @@ static int hc_build_tables(hc_ctx *c, HcModHost *mh, bool inverse) {
     return HC_OK;
 }
 
-extern "C" int hc_version(void) { return 1; }
+extern "C" int hc_version(void) { return 2; }      // 2: a plaintext shared by the images of a batch is said by the operation (HC_LV_MUL_PLAIN), never inferred from b0 == b1
 extern "C" const char *hc_last_error(const hc_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 // the per-modulus table of the batched transforms (HcRowMod); again after option small32 changes
@@ -326,19 +328,19 @@ static int hc_upload_rowmods(hc_ctx *c) {
 }
 extern "C" int hc_ctx_create(hc_ctx **out, int logN, const uint64_t *q, int nq, const uint64_t *p, int np, int device) {
     if (!out || !q || nq < 1 || np < 0 || (np > 0 && !p)) return hc_fail(nullptr, HC_ERR_ARG, "hc_ctx_create: bad arguments");
-    if (np > 8) return hc_fail(nullptr, HC_ERR_UNSUPPORTED, "hc_ctx_create: np=%d special primes; the key switch's basis-extension tables hold at most 8 (the reference's parameter sets use 1, 2 or 5)", np);
+    // the basis extension's operand registers are sized by the special primes (hc_k_cols_fwd_mm<EXT, NS>, NS = 2 or 5): an NS = 8 build spills 208 bytes per lane and ran
+    // 30 % slower - refused rather than shipped as a silently slow path (the reference's parameter sets use 1, 2 or 5 special primes: SURVEY 8(a)-P)
+    if (np > HC_MAX_NP) return hc_fail(nullptr, HC_ERR_UNSUPPORTED, "hc_ctx_create: np=%d special primes; this build supports at most %d (the reference's parameter sets use 1, 2 or 5)", np, HC_MAX_NP);
     if (logN != HC_LOGN) return hc_fail(nullptr, HC_ERR_UNSUPPORTED, "hc_ctx_create: logN=%d (this build is specialised for logN=16, the only ring degree the reference CLI uses: main.go:578-579)", logN);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0)
         return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: HIP device %d not available (%d devices) - this library has no CPU path", device, ndev);
     hc_ctx *c = new hc_ctx();
     c->device = device; c->nq = nq; c->np = np;
-    { const char *sm = getenv("HCONV_SMALL32"); if (sm && *sm) c->small32 = atoi(sm) ? 1 : 0; }
-    { const char *rf = getenv("HCONV_ROT_FUSE"); if (rf && *rf) c->rot_fuse = atoi(rf) ? 1 : 0; }
-    { const char *pk = getenv("HCONV_PACK32"); if (pk && *pk) { const int v = atoi(pk); c->pack32 = v <= 0 ? 0 : v >= 2 ? 2 : 1; } }
-    { const char *aa = getenv("HCONV_ASYNC_ALLOC"); c->async_alloc = aa ? (atoi(aa) == 2 ? 2 : (atoi(aa) ? 1 : 0)) : 0; }
+    // no configuration from the environment: a cgo host would inherit whatever its shell had. Every switch is an hc_set_option (small32, rot_fuse, pack32, async_alloc);
+    // this repo's CLI translates its HCONV_* variables into those calls (host/hconv_host.cpp: applyEnvOptions)
     hipError_t se = hipSetDevice(device);
-    if (se == hipSuccess) se = c->async_alloc ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) : hipStreamCreate(&c->stream);
+    if (se == hipSuccess) se = hipStreamCreate(&c->stream);
     if (se != hipSuccess) { delete c; return hc_fail(nullptr, HC_ERR_HIP, "hc_ctx_create: cannot create stream on device %d", device); }
     hipEventCreate(&c->t0); hipEventCreate(&c->t1);
     c->mods.resize((size_t)(nq + np));
@@ -403,9 +405,9 @@ extern "C" void hc_ctx_destroy(hc_ctx *c) {
 }
 
 // ------------------------------------------------------------------ memory
-extern "C" int hc_malloc(hc_ctx *c, size_t bytes, void **dptr) { HC_ENTER(c); if (!dptr) return hc_fail(c, HC_ERR_ARG, "hc_malloc: null"); HC_HIP(c, hcx_malloc(c, dptr, bytes)); return HC_OK; }
-// hipFree drains the device by itself. With cached allocations (HCONV_ASYNC_ALLOC=1) the block is parked for reuse by THIS context, and
-// hc_free does not wait for the stream. Plain mode: hipFree drains the device itself. Cached mode (HCONV_ASYNC_ALLOC=1): the block is parked behind an event
+extern "C" int hc_malloc(hc_ctx *c, size_t bytes, void **dptr) { HC_ENTER(c); if (!dptr) return hc_fail(c, HC_ERR_ARG, "hc_malloc: null"); HC_HIP(c, hcx_malloc(c, dptr, bytes)); c->allocs_live++; return HC_OK; }
+// hipFree drains the device by itself. With cached allocations (option async_alloc = 1) the block is parked for reuse by THIS context, and
+// hc_free does not wait for the stream. Plain mode: hipFree drains the device itself. Cached mode (option async_alloc = 1): the block is parked behind an event
 // and handed out again only to work queued on this same stream (hcx_free / hcx_h2d_async). What the caller owes: a block is freed into the context that
 // allocated it, after every OTHER context that was handed the pointer has been waited for (hc_sync) - the resnet host does both at its two hand-overs
 // (hconv_resnet.cpp evalConv_BNRelu_new, hconv_relu.cpp evalConv_BNRelu_tail). Round 2 kept a stream synchronisation here because dropping it broke
@@ -415,6 +417,7 @@ extern "C" int hc_free(hc_ctx *c, void *dptr) {
     hipError_t e = hcx_free(c, dptr);
     if (e == hipErrorInvalidDevicePointer) return hc_fail(c, HC_ERR_ARG, "hc_free: %p was not allocated by this context (with cached allocations a block goes back to the context it came from)", dptr);
     HC_HIP(c, e);
+    if (dptr) c->allocs_live--;
     return HC_OK;
 }
 extern "C" int hc_upload(hc_ctx *c, void *dst, const void *src, size_t bytes) {
@@ -565,11 +568,15 @@ static int hc_lv_pw(hc_ctx *c, const char *fn, int level, const uint64_t *a, con
     return hc_launch(c, fn, hc_k_lv_pointwise<OP>, dim3(HC_GX_PW, (unsigned)(level + 1), inthread ? 1u : (unsigned)c->nb), (const u64 *)a, (const u64 *)(b ? b : a), (u64 *)out, (const HcMod *)c->d_mods, K, (size_t)0, (size_t)0, (size_t)0, HC_ROW_IS_MOD, 0,
                      1, inthread ? c->nb : 1, c->bs_poly, b_shared ? (size_t)0 : c->bs_poly, c->bs_poly);
 }
-// the same operations on both polynomials of a ciphertext in one launch (they may live in separate allocations; b1 == b0 for a plaintext operand)
+// the same operations on both polynomials of a ciphertext in one launch (they may live in separate allocations; ONE plaintext for both polynomials and every image is HC_LV_MUL_PLAIN / HC_LV_MUL_ACC_PLAIN with b1 null or b0)
 template <int OP>
 static int hc_lv_pw2(hc_ctx *c, const char *fn, int level, const u64 *a0, const u64 *a1, const u64 *b0, const u64 *b1, u64 *o0, u64 *o1, const uint64_t *consts_host, bool plain = false) {
     HC_TRY(hc_lv_check(c, fn, level, a0, o0));
     if (plain) { if (b1 && b1 != b0) return hc_fail(c, HC_ERR_ARG, "%s: a plaintext operand is ONE polynomial (b1 must be null or b0)", fn); b1 = b0; }
+    // hc_version() 1 inferred "one plaintext for every image" from b0 == b1; since version 2 the operation says it (HC_LV_MUL_PLAIN / HC_LV_MUL_ACC_PLAIN). A product whose two
+    // second operands are the same polynomial inside an image batch is almost certainly such a legacy call, and would read pt + z * stride past a one-polynomial allocation
+    else if ((OP == HC_PW_MUL || OP == HC_PW_MAC) && c->nb > 1 && b0 && b0 == b1)
+        return hc_fail(c, HC_ERR_ARG, "%s: b0 == b1 inside an image batch - a plaintext shared by the images is HC_LV_MUL_PLAIN / HC_LV_MUL_ACC_PLAIN (hc_version() >= 2)", fn);
     if (!a1 || !o1 || ((OP == HC_PW_MUL || OP == HC_PW_ADD || OP == HC_PW_SUB || OP == HC_PW_MAC) && (!b0 || !b1))) return hc_fail(c, HC_ERR_ARG, "%s: null", fn);
     HcLvConsts K; memset(&K, 0, sizeof K);
     if (OP == HC_PW_MULC) {
@@ -624,8 +631,7 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
     if (fuse && fuse->ext_bs) { A.ext_bs = fuse->ext_bs; A.ext_rows = fuse->ext_rows; }
     if (fuse && fuse->lift_t) { A.lift_t = fuse->lift_t; A.lift_t_zs = fuse->lift_t_zs; A.lift_t_is = fuse->lift_t_is; A.lift_pmul = fuse->lift_pmul; }
     // the extension's operand registers are sized by the most source limbs a digit / ModDown can have: the context's number of special primes (hc_basis_ext_tile)
-#define HC_COLS_EXT(E) (!HC_EXT_NS ? hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 8>, grid, in, c->ws_tmp, A) : c->np <= 2 ? hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 2>, grid, in, c->ws_tmp, A) : c->np <= 5 ? hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 5>, grid, in, c->ws_tmp, A) \
-                        : hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 8>, grid, in, c->ws_tmp, A))
+#define HC_COLS_EXT(E) (c->np <= 2 ? hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, 2>, grid, in, c->ws_tmp, A) : hc_launch(c, c->profile ? n1 : "cols_fwd_mm", hc_k_cols_fwd_mm<E, HC_MAX_NP>, grid, in, c->ws_tmp, A))
     const bool user32 = c->pack32 == 2 && !(fuse && fuse->raw);              // pack32 = 2: the caller's polynomials (a plain input, the output, the epilogue's operands) carry 4-byte rows too
     A.pk_in = user32; A.pk_out = c->pack32;                                  // the seam between the two passes (ws_tmp) never leaves the library
     if (A.ext_bs && A.lift_t) HC_TRY(HC_COLS_EXT(2));
@@ -1058,7 +1064,12 @@ static int hc_pack_level(hc_ctx *c, const u64 *src, u64 *dst, size_t sstride, si
         HC_TRY(HC_LAUNCH_FM(mp.m.q, c, "b3_rowsfwdP_mac_rowsinvP", hc_k_b3, g1, B, mp.fwd, mp.inv));
         HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b4_colsinvP_modup_colsfwd", hc_k_b4, g2, B, mp.inv, m0.fwd));
         const HcPtrs pb = bias_last ? *bias_last : nobias, po = outs_last ? *outs_last : nobias;
+#if HC_B5M_LOADER && !defined(HC_EMU)
+        if (it->second.row256) HC_TRY((hc_fm_free(m0.m.q) ? hc_launch<HC_LD_TPB>(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5m_ld<HC_FM_FREE>, g1, B, m0.fwd, pb, po)
+                                                          : hc_launch<HC_LD_TPB>(c, "b5_rowsfwd_moddown_perm_add", hc_k_b5m_ld<HC_FM_ALT>, g1, B, m0.fwd, pb, po)));   // + a loader wavefront
+#else
         if (it->second.row256) HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5m, g1, B, m0.fwd, pb, po));      // one workgroup per (node, tile), both polynomials
+#endif
         else HC_TRY(HC_LAUNCH_FM(m0.m.q, c, "b5_rowsfwd_moddown_perm_add", hc_k_b5, g2, B, m0.fwd, pb, po));                        // tile-local permutation (2^j + 1, j = 5..8)
     }
     return HC_OK;
@@ -1194,7 +1205,7 @@ static HcBasisExt hc_make_bx(const std::vector<u64> &src, u64 t) {
 }
 extern "C" int hc_swk_load(hc_ctx *c, uint64_t key_id, int level, const uint64_t *rows_host) {
     HC_ENTER(c);
-    if (!rows_host || level < 0 || level >= c->nq || c->np < 1 || c->np > 8) return hc_fail(c, HC_ERR_ARG, "hc_swk_load: bad arguments");
+    if (!rows_host || level < 0 || level >= c->nq || c->np < 1 || c->np > HC_MAX_NP) return hc_fail(c, HC_ERR_ARG, "hc_swk_load: bad arguments");
     const int nt = level + 1 + c->np, beta = (level + 1 + c->np - 1) / c->np;
     const size_t n = (size_t)beta * 2 * nt * HC_N;
     HcSwk k; k.level = level; k.beta = beta;
@@ -1210,7 +1221,7 @@ extern "C" int hc_swk_load(hc_ctx *c, uint64_t key_id, int level, const uint64_t
 // Harness-side key generation on the device (include/hconv.h): one launch samples every row of the key, one batched transform takes the errors to the
 // NTT domain, one launch forms b and the stored (Montgomery) form. 3 + 2 launches per key instead of ~10 one-row launches and three uploads per (digit, limb).
 static int hc_swk_generate_impl(hc_ctx *c, uint64_t key_id, int level, uint64_t galEl, const uint64_t *sk_ntt, const uint32_t *seed8, bool splitmix, uint64_t sm_seed, const int64_t *e_host) {
-    if (!sk_ntt || level < 0 || level >= c->nq || c->np < 1 || c->np > 8 || (galEl && !(galEl & 1))) return hc_fail(c, HC_ERR_ARG, "hc_swk_generate: bad arguments");
+    if (!sk_ntt || level < 0 || level >= c->nq || c->np < 1 || c->np > HC_MAX_NP || (galEl && !(galEl & 1))) return hc_fail(c, HC_ERR_ARG, "hc_swk_generate: bad arguments");
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha;
     if (beta > 63 || nt > 62) return hc_fail(c, HC_ERR_UNSUPPORTED, "hc_swk_generate: more than 62 limbs");
     if (!splitmix && (key_id >> 40)) return hc_fail(c, HC_ERR_ARG, "hc_swk_generate: key id %llu does not fit the 40 bits of the ChaCha nonce that tell keys apart", (unsigned long long)key_id);
@@ -1295,17 +1306,17 @@ static int hc_ks_plan(hc_ctx *c, int level, const hc_ctx::KsPlan **out) {
     *out = &pit->second;
     return HC_OK;
 }
-// scratch of one key switch at `level` for the nb images of the batch, section-major: coef[img][nl] | digits[img][beta][nt] | acc[img][2][nt] | pc[img][2][alpha + 2] | ext[img][2][nl] | yv[img][max(beta, 2)][alpha + 1]
+// scratch of one key switch at `level` for the nb images of the batch, section-major: digits[img][beta][nt] | acc[img][2][nt] | pc[img][2][alpha + 2] | ext[img][2][nl] | yv[img][max(beta, 2)][alpha + 1]
 #ifndef HC_MAC_NB
 #define HC_MAC_NB 4                  // images per thread of the key switch's inner product at batches above 2 (hc_k_ks_mac_all)
 #endif
-struct HcKsScratch { u64 *coef, *digits, *acc, *pc, *ext, *yv; size_t coef_is, digits_is, acc_is, pc_is, ext_is; };
+struct HcKsScratch { u64 *digits, *acc, *pc, *ext, *yv; size_t digits_is, acc_is, pc_is, ext_is; };
 static int hc_ks_scratch(hc_ctx *c, int level, HcKsScratch *S) {
     const int alpha = c->np, nl = level + 1, nt = nl + alpha, beta = (nl + alpha - 1) / alpha; const size_t nb = (size_t)c->nb;
-    S->coef_is = (size_t)nl * HC_N; S->digits_is = (size_t)beta * nt * HC_N; S->acc_is = (size_t)2 * nt * HC_N; S->pc_is = (size_t)2 * (alpha + 2) * HC_N; S->ext_is = (size_t)2 * nl * HC_N;
+    S->digits_is = (size_t)beta * nt * HC_N; S->acc_is = (size_t)2 * nt * HC_N; S->pc_is = (size_t)2 * (alpha + 2) * HC_N; S->ext_is = (size_t)2 * nl * HC_N;
     const size_t yv_rows = (size_t)(beta > 2 ? beta : 2) * (alpha + 1);                // y_i / v rows of the decomposition's digits, later of ModDown's two polynomials
-    HC_TRY(hc_ensure_mm(c, nb * ((size_t)nl + (size_t)beta * nt + 2 * nt + 2 * (alpha + 2) + 2 * nl + yv_rows)));
-    S->coef = c->ws_mm; S->digits = S->coef + nb * S->coef_is; S->acc = S->digits + nb * S->digits_is; S->pc = S->acc + nb * S->acc_is; S->ext = S->pc + nb * S->pc_is; S->yv = S->ext + nb * S->ext_is;
+    HC_TRY(hc_ensure_mm(c, nb * ((size_t)beta * nt + 2 * nt + 2 * (alpha + 2) + 2 * nl + yv_rows)));
+    S->digits = c->ws_mm; S->acc = S->digits + nb * S->digits_is; S->pc = S->acc + nb * S->acc_is; S->ext = S->pc + nb * S->pc_is; S->yv = S->ext + nb * S->ext_is;
     return HC_OK;
 }
 // phase 1 (rlwe.KeySwitcher.DecomposeNTT / ring.Decomposer.DecomposeAndSplit): digits[d][T] = the d-th digit of cx extended to limb
@@ -1571,6 +1582,8 @@ extern "C" int hc_qp_op2(hc_ctx *c, int op, int level, const uint64_t *a0, const
     if (level < 0 || level >= c->nq || c->np < 1) return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: level %d outside 0..%d or no special primes", level, c->nq - 1);
     const bool plain = op == HC_LV_MUL_PLAIN || op == HC_LV_MUL_ACC_PLAIN;
     if (plain) { if (b1 && b1 != b0) return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: a plaintext operand is ONE polynomial over the extended basis (b1 must be null or b0)"); b1 = b0; op = op == HC_LV_MUL_PLAIN ? HC_LV_MUL : HC_LV_MUL_ACC; }
+    else if ((op == HC_LV_MUL || op == HC_LV_MUL_ACC) && c->nb > 1 && b0 && b0 == b1)      // the legacy form of a shared plaintext (hc_lv_pw2)
+        return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: b0 == b1 inside an image batch - a plaintext shared by the images is HC_LV_MUL_PLAIN / HC_LV_MUL_ACC_PLAIN (hc_version() >= 2)");
     if (!a0 || !a1 || !b0 || !b1 || !out0 || !out1) return hc_fail(c, HC_ERR_ARG, "hc_qp_op2: null");
     HC_TRY(hc_batch_fits(c, "hc_qp_op2", level, true));
     HcLvConsts K; memset(&K, 0, sizeof K);
@@ -1843,13 +1856,30 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!strcmp(name, "peer_access")) { c->peer_access = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "rot_fuse")) { c->rot_fuse = value ? 1 : 0; return HC_OK; }                  // same residues either way: A/B only
-    if (!strcmp(name, "small32")) { c->small32 = value ? 1 : 0; HC_HIP(c, hipStreamSynchronize(c->stream)); return hc_upload_rowmods(c); }      // results do not depend on it (both forms leave canonical residues): A/B only
+    if (!strcmp(name, "small32")) { HC_ENTER(c); c->small32 = value ? 1 : 0; HC_HIP(c, hipStreamSynchronize(c->stream)); return hc_upload_rowmods(c); }      // results do not depend on it (both forms leave canonical residues): A/B only
+    if (!strcmp(name, "async_alloc")) {     // 0: hipMalloc / hipFree; 1: non-blocking stream + this context's cache of blocks (hcx_malloc); 2: diagnostic (ROCm's stream-ordered allocator)
+        if (value < 0 || value > 2) return hc_fail(c, HC_ERR_ARG, "async_alloc must be 0, 1 or 2");
+        if ((int)value == c->async_alloc) return HC_OK;
+        // the stream and the ownership of every block follow the mode: it can only change while the context owns nothing but its tables (right after hc_ctx_create)
+        if (c->allocs_live || !c->evk.empty() || !c->swk.empty() || c->idx_pairs || c->ws_cts || c->ws_tmp || c->ws_mm || c->ws_ctc || !c->cache_blk.empty())
+            return hc_fail(c, HC_ERR_STATE, "async_alloc: set it right after hc_ctx_create, before the context allocates");
+        HC_ENTER(c); HC_HIP(c, hipStreamSynchronize(c->stream));
+        hipStream_t ns = nullptr;
+        HC_HIP(c, value ? hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) : hipStreamCreate(&ns));
+        HC_HIP(c, hipStreamDestroy(c->stream));
+        c->stream = ns; c->async_alloc = (int)value;
+        return HC_OK;
+    }
     if (!strcmp(name, "pack32")) {          // 0 / 1 / 2 (include/hconv.h "4-byte rows"). Switching keys are stored per the setting in force when they are loaded or generated: 0 <-> 1, 2 only on a context without keys
         if (value < 0 || value > 2) return hc_fail(c, HC_ERR_ARG, "pack32 must be 0, 1 or 2");
         if (((value == 0) != (c->pack32 == 0)) && !c->swk.empty()) return hc_fail(c, HC_ERR_STATE, "pack32: switching keys are already stored in the other form");
         HC_ENTER(c); HC_HIP(c, hipStreamSynchronize(c->stream));
         c->pack32 = (int)value; c->hoist_cx = nullptr;
         std::vector<HcMod> hm; for (auto &mh : c->mods) { mh.m.row32 = (value == 2 && mh.m.q < (1ull << 31)) ? 1 : 0; hm.push_back(mh.m); }
+        // limbs 0 and 1 are what the convolution's entry points, hc_div_round_last_n's level-1 branch and hc_swk_generate's sk rows read as 8-byte rows
+        if (value == 2 && c->mods.size() > 1 && (hm[0].row32 || hm[1].row32)) {
+            for (size_t l = 0; l < 2; l++) { c->mods[l].m.row32 = 0; hm[l].row32 = 0; }
+        }
         HC_HIP(c, hcx_h2d(c, c->d_mods, hm.data(), hm.size() * sizeof(HcMod)));
         return HC_OK;
     }

@@ -36,7 +36,9 @@ int main(int argc, char **argv) {
         const int depth = atoi(argv[3]), wide_case = atoi(argv[4]), test_num = atoi(argv[5]);
         const bool cf100 = std::string(argv[6]) == "true" || std::string(argv[6]) == "1";
         if (wide_case < 1 || wide_case > 3) hconv::panic("Wrong wide case!");                              // main.go:628
-        hconv::testResNet_crop_sparse(0, test_num, ker_wid, depth, false, cf100, wide_case);
+        // BASELINE config 5 is `resnet 3 20 1 n false`; the wide networks and the CIFAR-100 head are outside the scope table and not built
+        if (wide_case != 1 || cf100) hconv::panic("resnet: wide_case 2 / 3 and cf100 = true are out of scope in this build (SURVEY.md section 2, row 14)");
+        hconv::testResNet_crop_sparse(0, test_num, ker_wid, depth, false);
         return 0;
     } else hconv::panic("wrong test type");
     if (i_batch < 0) hconv::panic("runtime error: index out of range");

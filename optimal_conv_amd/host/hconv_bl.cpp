@@ -243,6 +243,7 @@ static BLContext *bl_newContext(int logN, int ker_wid, int in_wid, bool boot) {
     c->seed = seedFromEnvironment(); c->g.reseed(c->seed, 0x424c);
     const int dev = getenv("HCONV_DEVICE") ? atoi(getenv("HCONV_DEVICE")) : 0;
     if (hc_ctx_create(&c->hc, LOGN, BLQ, 2, BLQ + 2, 2, dev)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
+    applyEnvOptions(c->hc);
     c->sk.assign(N, 0);
     { int placed = 0; while (placed < 192) { uint64_t r = c->g(); int pos = (int)(r % N); if (!c->sk[(size_t)pos]) { c->sk[(size_t)pos] = (r >> 40) & 1 ? 1 : -1; placed++; } } }
     for (int m = 0; m < 4; m++) c->sk_ntt[m] = bl_ntt(c, m, signed_row(c->sk, BLQ[m]));

@@ -156,9 +156,22 @@ static void gen_and_load_galois_key(Context *c, uint64_t galEl) {
 }
 
 // ---------------------------------------------------------------- newContext (main.go:44-462, kind "Conv")
+void applyEnvOptions(hc_ctx *hc, int pack32_default) {
+    auto opt = [&](const char *env, const char *name, long dflt) {
+        const char *v = getenv(env);
+        const long val = (v && *v) ? atol(v) : dflt;
+        if (val < 0) return;
+        if (hc_set_option(hc, name, val)) panic(std::string("hc_set_option(") + name + "): " + hc_last_error(hc));
+    };
+    opt("HCONV_ASYNC_ALLOC", "async_alloc", -1);      // first: the allocation mode can only change while the context owns nothing but its tables
+    opt("HCONV_SMALL32", "small32", -1);
+    opt("HCONV_ROT_FUSE", "rot_fuse", -1);
+    opt("HCONV_PACK32", "pack32", pack32_default);
+}
+
 Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, const std::vector<int> &kp_wids, bool boot, const std::string &kind) {
     (void)ker_wid;
-    if (kind != "Conv" && kind != "Resnet_crop_sparse" && kind != "Resnet_crop_sparse_wide2" && kind != "Resnet_crop_sparse_wide3") panic("Wrong kinds!");       // main.go:404 (the kinds the built command lines use)
+    if (kind != "Conv" && kind != "Resnet_crop_sparse") panic("Wrong kinds!");       // main.go:404 (the kinds the built command lines use)
     Context *c = new Context();
     double logqp = 0; for (uint64_t q : PARAMS6_Q) logqp += log2((double)q); for (uint64_t p : PARAMS6_P) logqp += log2((double)p);
     printf("CKKS parameters: logN = %d, logSlots = %d, h = %d, logQP = %d, levels = %d, scale= 2^%f, sigma = %f \n",
@@ -168,11 +181,12 @@ Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, cons
     int dev = getenv("HCONV_DEVICE") ? atoi(getenv("HCONV_DEVICE")) : 0;
     uint64_t q[2] = {MODQ[0], MODQ[1]}, p[1] = {PACK_P};
     if (hc_ctx_create(&c->hc, LOGN, q, 2, p, 1, dev)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
+    applyEnvOptions(c->hc);
     c->shards.push_back(c->hc);
     if (const char *ng = getenv("HCONV_GPUS")) {       // one convolution over G devices (contexts share devices when the box has fewer)
         const int G = atoi(ng); int ndev = 1; hc_device_count(&ndev);
         if (G < 1 || G > 16 || (G & (G - 1))) panic("HCONV_GPUS must be a power of two in 1..16");
-        for (int g = 1; g < G; g++) { hc_ctx *h = nullptr; if (hc_ctx_create(&h, LOGN, q, 2, p, 1, (dev + g) % ndev)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr)); c->shards.push_back(h); }
+        for (int g = 1; g < G; g++) { hc_ctx *h = nullptr; if (hc_ctx_create(&h, LOGN, q, 2, p, 1, (dev + g) % ndev)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr)); applyEnvOptions(h); c->shards.push_back(h); }
         if (G > 1) printf("Sharding every convolution over %d device contexts (%d device%s visible)\n", G, ndev, ndev == 1 ? "" : "s");
     }
     // kgen.GenKeyPairSparse(h = 192) (main.go:410)
@@ -189,10 +203,8 @@ Context *newContext(int logN, int ker_wid, const std::vector<int> &in_wids, cons
         auto start = now();
         // DFT matrices and every switching key, same secret key. "Conv": one full-slot bootstrapper; the resnet kind: the
         // four sparse ones its layers use (btp2..btp5 of main.go:480-500; log_sparse 1..4)
-        const bool wide2 = kind == "Resnet_crop_sparse_wide2", wide3 = kind == "Resnet_crop_sparse_wide3";
-        // wide2: layers at log_sparse 1, 2, 3, stride layers at 0 (full packing) and 1; wide3: layers at 0, 1, 2, both stride layers at 0
-        c->btp = kind == "Conv" ? newBoot(c->sk, c->seed, dev, {0}, imageBatch()) : newBoot(c->sk, c->seed, dev, wide3 ? std::vector<int>{0, 1, 2} : (wide2 ? std::vector<int>{1, 0, 2, 3} : std::vector<int>{2, 1, 3, 4}), imageBatch());
-        if (kind != "Conv") { bootPrepareCompress(c->btp, in_wids[0], kp_wids[1], (wide2 || wide3) ? 0 : 1); bootPrepareCompress(c->btp, in_wids[1], kp_wids[2], wide3 ? 0 : (wide2 ? 1 : 2)); }   // main.go:163-215
+        c->btp = kind == "Conv" ? newBoot(c->sk, c->seed, dev, {0}, imageBatch()) : newBoot(c->sk, c->seed, dev, std::vector<int>{2, 1, 3, 4}, imageBatch());
+        if (kind != "Conv") { bootPrepareCompress(c->btp, in_wids[0], kp_wids[1], 1); bootPrepareCompress(c->btp, in_wids[1], kp_wids[2], 2); }   // main.go:163-215
         printf("Done in %s \n", dur(start).c_str());
     }
     return c;

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/hconv.h"
+#include "../../include/hconv_test_hooks.h"      // --test-mode replays only (HCONV_RESNET_REPLAY)
 #include "hconv_prng.hpp"
 
 namespace hconv {
@@ -43,6 +44,10 @@ extern const std::vector<uint64_t> PARAMS6_P;      // bootstrapping key-switch p
 static const uint64_t PACK_P = 0x1fffffffffe00001ull;   // main.go:449
 
 [[noreturn]] void panic(const std::string &msg);        // Go's panic(): message to stderr, exit status 2
+// The library reads no configuration from the environment (include/hconv.h); this CLI does, and hands it over as options right after every hc_ctx_create:
+// HCONV_ASYNC_ALLOC (0 / 1 / 2), HCONV_SMALL32, HCONV_ROT_FUSE, HCONV_PACK32 (A/B switches; same residues in every setting). pack32_default: the value a context takes
+// when HCONV_PACK32 is unset (-1: the library's own default)
+void applyEnvOptions(hc_ctx *hc, int pack32_default = -1);
 // Test-only overrides (HCONV_SEED: deterministic keys; HCONV_CHAIN_REPLAY: planted keys and input) take effect only when the CLI was
 // started with --test-mode as its first argument; set in the environment WITHOUT that flag they end the process (an inherited variable
 // must never turn a deployment into key-less or predictable computation).
@@ -143,8 +148,8 @@ int imageBatch();                                // HCONV_IMAGE_BATCH (1..8; def
 Ciphertext evalConv_BNRelu_new(Context *cont, const Ciphertext &ct_input, const std::vector<double> &ker_in, const std::vector<double> &bn_a,
                                const std::vector<double> &bn_b, double alpha, double pow, int in_wid, int kp_wid, int ker_wid, int real_ib, int real_ob,
                                int norm, int log_sparse, const std::string &kind);
-// test.go:76-370 — `resnet ker depth 1 n cf100`
-void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug, bool cf100, int wide_case = 1);   // wide_case 2: test.go:638 testResNet_crop_sparse_wide
+// test.go:76-370 — `resnet ker depth 1 n false`
+void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug);
 // test_BL.go:16 — the slot-packed baseline the reference runs first (hconv_bl.cpp); boot = true adds Bootstrapp + ReLU (test_BL.go:113-168)
 void testConv_BL_in(int real_batch, int in_wid, int ker_wid, int total_test_num, bool boot);
 

@@ -950,7 +950,7 @@ struct Boot {
         if (chain == 7) { LV_STC_TOP = 15; stc_scale_top = sqrt((double)Q[15]); stc_scale_last = 1073741824.0; lv_relin_lo = 2; }
         else { LV_STC_TOP = 3; stc_scale_top = sqrt((double)Q[3]); stc_scale_last = 1073741824.0; lv_relin_lo = LV_RELU_TOP - 11; }
         if (hc_ctx_create(&hc, LOGN, Q.data(), NQ, P.data(), (int)P.size(), device)) panic(std::string("hc_ctx_create: ") + hc_last_error(nullptr));
-        if (!getenv("HCONV_PACK32")) HCR(hc_set_option(hc, "pack32", 2));             // 4-byte rows for the ~30-bit limbs of every leveled operand (HCONV_PACK32=0 / 1: A/B against the 8-byte forms)
+        applyEnvOptions(hc, 2);                                                        // pack32 = 2 unless HCONV_PACK32 says otherwise: 4-byte rows for the ~30-bit limbs of every leveled operand (HCONV_PACK32=0 / 1: A/B against the 8-byte forms)
         row32.assign((size_t)NQ, 0); for (int l = 0; l < NQ; l++) row32[(size_t)l] = (char)hc_row_is32(hc, l);
         const int nm = NQ + (int)P.size();
         { void *v = nullptr; HCR(hc_malloc(hc, (size_t)nm * N * 8, &v)); d_sk = (uint64_t *)v; }
@@ -1292,7 +1292,7 @@ static void replay_digest_line(Boot *B, const char *what, const DCt &c, int firs
 // The images of a batch (ct_conv_dev.size() <= the bootstrapper's HCONV_IMAGE_BATCH) go through the tail as ONE set of launches; results in the same order.
 std::vector<BootCiphertext> evalConv_BNRelu_tail_batch(Boot *B, const std::string &kind, int log_sparse, const std::vector<const uint64_t *> &ct_conv_dev, double ct_scale, double alpha, double pow_, int in_wid, int kp_wid) {
     hc_ctx *hc = B->hc;
-    const bool stride = kind == "StrConv_sparse" || kind == "StrConv_sparse_full", sparse = kind == "Conv_sparse" || stride;
+    const bool stride = kind == "StrConv_sparse", sparse = kind == "Conv_sparse" || stride;
     if (!sparse && kind != "Conv") panic("No kind!");
     if (!sparse && log_sparse != 0) panic("No cases for log_sparse");
     const int nimg = (int)ct_conv_dev.size();

@@ -1,4 +1,4 @@
-// hconv_resnet.cpp — `resnet <ker> <depth> <wide_case 1|2|3> <n> <cf100>` (scope row 8f-3): the reference's encrypted ResNet inference
+// hconv_resnet.cpp — `resnet <ker> <depth> 1 <n> false` (scope row 8f-3): the reference's encrypted ResNet inference
 // (test.go:76-370 testResNet_crop_sparse) on the MI355X engine, and the layer operator it is built from
 // (eval.go:272-607 evalConv_BNRelu_new for kinds "Conv_sparse" / "StrConv_sparse").
 //
@@ -76,10 +76,6 @@ std::vector<Ciphertext> evalConv_BNRelu_new_batch(Context *cont, const std::vect
             if ((in_wid - ker_wid / 2) % 2 == 0) mul_monomial_l0(cont, r1[(size_t)z], N - max_batch * (in_wid + 1), true);                        // eval.go:377-387
         }
         ct_conv = r1;
-    } else if (kind == "StrConv_sparse_full") {                                                            // eval.go:389-412 (modify_ker, full): one convolution, then the offset monomial
-        ct_conv = evalConv_BN_batch(cont, ct_inputs, ker_in, bn_a, bn_b, in_wid, ker_wid, real_ib, real_ob, norm, out_scale, false);
-        const int max_batch = N / (in_wid * in_wid);
-        if ((in_wid - ker_wid / 2) % 2 == 0) for (Ciphertext &c : ct_conv) mul_monomial_l0(cont, c, N - max_batch * (in_wid + 1), true);
     } else if (kind == "Conv_sparse" || kind == "Conv") {
         ct_conv = evalConv_BN_batch(cont, ct_inputs, ker_in, bn_a, bn_b, in_wid, ker_wid, real_ib, real_ob, norm, out_scale, false);             // eval.go:433
     } else panic("No kind!");
@@ -133,35 +129,25 @@ static void writeTxt(const std::string &name, const std::vector<double> &v) {
     for (double d : v) { snprintf(buf, sizeof buf, "%.17g\n", d); f << buf; }
 }
 
-// test.go:76-370 (wide_case 1) and test.go:638-912 testResNet_crop_sparse_wide (wide_case 2: twice the channels, first layer 3 -> 16
-// -> 32, first stride layer on full packing; wide_case 3: 48/96/192 channels, block 1 and both stride layers on full packing)
-void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug, bool cf100, int wide_case) {
+// test.go:76-370: `resnet ker depth 1 n false` (BASELINE config 5). The wide drivers (wide_case 2 / 3: testResNet_crop_sparse_wide, test.go:638-912) and the CIFAR-100 head
+// (cf100: two final convolutions, test.go:287-315) are SURVEY section 2 row 14 - out of scope - and were removed from this host in round 6 (they lived here in rounds 1-5).
+void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug) {
     if (const char *fi = testOnlyEnv("HCONV_RESNET_FIRST_IMAGE")) st = atoi(fi);      // test mode: images st .. end - 1 (one image of a batch run alone, for the batch == single digest test)
     (void)debug;
-    if (wide_case < 1 || wide_case > 3) panic("wrong wide_case (2 nor 3)!");
-    const bool wide = wide_case != 1;
-    const std::string ker_name = "ker" + std::to_string(ker_wid), tag = std::string(cf100 ? "cf100_" : "") + "crop_" + ker_name + "_d" + std::to_string(depth) + "_wid" + std::to_string(wide_case) + "/";
+    const std::string ker_name = "ker" + std::to_string(ker_wid), tag = "crop_" + ker_name + "_d" + std::to_string(depth) + "_wid1/";
     const std::string weight_dir = "Resnet_weights/weights_" + tag, out_dir = "Resnet_enc_results/results_" + tag, img_dir = "Resnet_plain_data/" + tag;
-    int fc_out = 10; double init_pow = 6.0, mid_pow = 6.0, final_pow = 6.0;
-    if (!wide) { if (cf100) { fc_out = 100; final_pow = ker_wid == 3 ? 7.0 : (ker_wid == 5 ? 6.0 : 5.0); init_pow = 5.0; mid_pow = 5.0; } }
-    else {                                                                                               // test.go:645-665
-        init_pow = mid_pow = final_pow = ker_wid == 5 ? 6.0 : 5.0;
-        if (cf100) { fc_out = 100; final_pow = 7.0; init_pow = 5.0; mid_pow = 5.0; if (ker_wid == 5 && depth == 8) { init_pow = 6.0; final_pow = 6.0; } }
-    }
+    const int fc_out = 10; const double init_pow = 6.0, mid_pow = 6.0, final_pow = 6.0;                  // test.go:84-89 (cifar10)
     int num_blcs[3];
     if (depth == 20) { num_blcs[0] = 7; num_blcs[1] = 5; num_blcs[2] = 5; } else if (depth == 14) { num_blcs[0] = 5; num_blcs[1] = 3; num_blcs[2] = 3; }
     else if (depth == 8) { num_blcs[0] = 3; num_blcs[1] = 1; num_blcs[2] = 1; } else panic("wrong depth (not in 8, 14, 20)!");
-    const int init_batch = 16;                                                                           // test.go:667
-    const int w3 = wide_case == 3;                                                                       // test.go:686-691: 48/96/192 channels, norm 1/2/4, block 1 on full packing
-    const int real_batch[3] = {w3 ? 48 : (wide ? 32 : 16), w3 ? 96 : (wide ? 64 : 32), w3 ? 192 : (wide ? 128 : 64)}, norm[3] = {w3 ? 1 : (wide ? 2 : 4), w3 ? 2 : (wide ? 4 : 8), w3 ? 4 : (wide ? 8 : 16)};
-    const int log_sparse[3] = {w3 ? 0 : (wide ? 1 : 2), w3 ? 1 : (wide ? 2 : 3), w3 ? 2 : (wide ? 3 : 4)};
+    const int real_batch[3] = {16, 32, 64}, norm[3] = {4, 8, 16}, log_sparse[3] = {2, 3, 4};           // test.go:107-112
     const int logN = 16; const double alpha = 0.0;
     const std::vector<int> in_wids = {32, 16, 8}, raw_in_wids = {32 - ker_wid / 2, 16 - ker_wid / 2, 8 - ker_wid / 2};
     const int ker_size = ker_wid * ker_wid;
     int max_batch[3]; for (int i = 0; i < 3; i++) max_batch[i] = (1 << logN) / (in_wids[(size_t)i] * in_wids[(size_t)i]);
     mkdir("Resnet_enc_results", 0755); mkdir(out_dir.c_str(), 0755);
     auto W = [&](int i, const char *what, int size) { return readTxt(weight_dir + "w" + std::to_string(i) + "-" + what + ".csv", size); };
-    const char *kind_name = w3 ? "Resnet_crop_sparse_wide3" : (wide ? "Resnet_crop_sparse_wide2" : "Resnet_crop_sparse");
+    const char *kind_name = "Resnet_crop_sparse";
 
     // HCONV_IMAGE_THREADS=K (not a reference feature): K host threads, each with its own context (keys, bootstrappers, stream),
     // classify disjoint shares of the images at the same time. A layer's launches are mostly far below one wave of workgroups, so the
@@ -210,59 +196,29 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
 
         double pow_ = init_pow;                                                                          // ResNet Block 1
         for (int i = 1; i <= num_blcs[0]; i++) {
-            if (wide && i == 5) pow_ = mid_pow;                                                          // test.go:742-744
-            // wide: 3 -> init_batch -> real_batch[0] over the first two layers (test.go:745-763); narrow: init_batch == real_batch[0]
-            const int ib = i == 1 ? 3 : (wide && i == 2 ? init_batch : real_batch[0]), ob = wide && i == 1 ? init_batch : real_batch[0];
+            const int ib = i == 1 ? 3 : real_batch[0], ob = real_batch[0];
             step(evalConv_BNRelu_new_batch(cont, ct_layer, W(i - 1, "conv", ib * ob * ker_size), W(i - 1, "a", ob), W(i - 1, "b", ob),
                                            alpha, pow_, in_wids[0], raw_in_wids[0], ker_wid, ib, ob, norm[0], log_sparse[0], "Conv_sparse"));
-            if (!wide) pow_ = mid_pow;
+            pow_ = mid_pow;
             printf("Block1, Layer  %d done!\n", i);
         }
         printf("Block1 done.\n"); timings[0] = secs(start); start = now();
-        if (!w3) step(evalConv_BNRelu_new_batch(cont, ct_layer, W(num_blcs[0], "conv", real_batch[0] * real_batch[1] * ker_size), W(num_blcs[0], "a", real_batch[1]), W(num_blcs[0], "b", real_batch[1]),
-                                 alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], real_batch[1], norm[1], log_sparse[0] - 1, "StrConv_sparse"));           // test.go:200, 791
-        else {                                                                                           // test.go:775-812: even / odd output channels as two full-packing stride layers, X^2 shift, add
-            const std::vector<double> ker12 = W(num_blcs[0], "conv", real_batch[0] * real_batch[1] * ker_size), a12 = W(num_blcs[0], "a", real_batch[1]), b12 = W(num_blcs[0], "b", real_batch[1]);
-            const int ho = real_batch[1] / 2; std::vector<double> k0(ker12.size() / 2), k1(ker12.size() / 2), a0((size_t)ho), a1((size_t)ho), b0((size_t)ho), b1((size_t)ho);
-            for (int k = 0; k < ker_size; k++) for (int i = 0; i < real_batch[0]; i++) for (int j = 0; j < ho; j++) {
-                k0[(size_t)(k * real_batch[0] * ho + (i * ho + j))] = ker12[(size_t)(k * real_batch[0] * real_batch[1] + (i * real_batch[1] + 2 * j))];
-                k1[(size_t)(k * real_batch[0] * ho + (i * ho + j))] = ker12[(size_t)(k * real_batch[0] * real_batch[1] + (i * real_batch[1] + 2 * j + 1))];
-            }
-            for (int i = 0; i < ho; i++) { a0[(size_t)i] = a12[(size_t)(2 * i)]; a1[(size_t)i] = a12[(size_t)(2 * i + 1)]; b0[(size_t)i] = b12[(size_t)(2 * i)]; b1[(size_t)i] = b12[(size_t)(2 * i + 1)]; }
-            std::vector<Ciphertext> r1 = evalConv_BNRelu_new_batch(cont, ct_layer, k0, a0, b0, alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], ho, norm[0], 0, "StrConv_sparse_full");
-            std::vector<Ciphertext> r2 = evalConv_BNRelu_new_batch(cont, ct_layer, k1, a1, b1, alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], ho, norm[0], 0, "StrConv_sparse_full");
-            {   // MulNew(ct_result2, EncodeCoeffs(X^2 at scale 1)) at level 1, AddNew (test.go:804-811)
-                void *v = nullptr; HCX(cont->hc, hc_malloc(cont->hc, (size_t)2 * N * 8, &v)); uint64_t *pt = (uint64_t *)v;
-                std::vector<uint64_t> m((size_t)2 * N, 0); m[2] = 1; m[(size_t)N + 2] = 1;
-                HCX(cont->hc, hc_upload(cont->hc, pt, m.data(), m.size() * 8));
-                for (int l = 0; l < 2; l++) HCX(cont->hc, hc_ntt(cont->hc, l, pt + (size_t)l * N, pt + (size_t)l * N, 1));
-                for (int z = 0; z < nimg; z++) for (int d = 0; d < 2; d++) for (int l = 0; l < 2; l++) {
-                    uint64_t *row2 = r2[(size_t)z].d + ((size_t)d * 2 + l) * N, *row1 = r1[(size_t)z].d + ((size_t)d * 2 + l) * N;
-                    HCX(cont->hc, hc_mul(cont->hc, l, row2, pt + (size_t)l * N, row2, 1)); HCX(cont->hc, hc_add(cont->hc, l, row1, row2, row1, 1));
-                }
-                HCX(cont->hc, hc_free(cont->hc, pt));
-            }
-            for (Ciphertext &c : r2) freeCt(cont, c);
-            step(r1);
-        }
+        step(evalConv_BNRelu_new_batch(cont, ct_layer, W(num_blcs[0], "conv", real_batch[0] * real_batch[1] * ker_size), W(num_blcs[0], "a", real_batch[1]), W(num_blcs[0], "b", real_batch[1]),
+                                       alpha, pow_, in_wids[0], raw_in_wids[1], ker_wid, real_batch[0], real_batch[1], norm[1], log_sparse[0] - 1, "StrConv_sparse"));           // test.go:200
         printf("Block1 to 2 done!\n"); timings[1] = secs(start); start = now();
         for (int i = 1; i <= num_blcs[1]; i++) {                                                         // ResNet Block 2
-            if (wide && i == 5) pow_ = init_pow;                                                         // test.go:819-821
             const int w = num_blcs[0] + i;
             step(evalConv_BNRelu_new_batch(cont, ct_layer, W(w, "conv", real_batch[1] * real_batch[1] * ker_size), W(w, "a", real_batch[1]), W(w, "b", real_batch[1]),
                                            alpha, pow_, in_wids[1], raw_in_wids[1], ker_wid, real_batch[1], real_batch[1], norm[1], log_sparse[1], "Conv_sparse"));
             printf("Block2, Layer  %d done!\n", i);
         }
         printf("Block2 done.\n"); timings[2] = secs(start); start = now();
-        if (wide) pow_ = mid_pow;                                                                        // test.go:833
         { const int w = num_blcs[0] + num_blcs[1] + 1;
           step(evalConv_BNRelu_new_batch(cont, ct_layer, W(w, "conv", real_batch[1] * real_batch[2] * ker_size), W(w, "a", real_batch[2]), W(w, "b", real_batch[2]),
-                                         alpha, pow_, in_wids[1], raw_in_wids[2], ker_wid, real_batch[1], real_batch[2], norm[2], log_sparse[1] - 1, "StrConv_sparse")); }               // test.go:225, 838
+                                         alpha, pow_, in_wids[1], raw_in_wids[2], ker_wid, real_batch[1], real_batch[2], norm[2], log_sparse[1] - 1, "StrConv_sparse")); }               // test.go:225
         printf("Block2 to 3 done!\n"); timings[3] = secs(start); start = now();
         for (int i = 1; i <= num_blcs[2]; i++) {                                                         // ResNet Block 3
             const int w = num_blcs[0] + num_blcs[1] + i + 1;
-            if (wide && i == 3) pow_ = init_pow;                                                         // test.go:845-850
-            if (wide && i == 5) pow_ = mid_pow;
             if (i == num_blcs[2]) pow_ = final_pow;
             step(evalConv_BNRelu_new_batch(cont, ct_layer, W(w, "conv", real_batch[2] * real_batch[2] * ker_size), W(w, "a", real_batch[2]), W(w, "b", real_batch[2]),
                                            alpha, pow_, in_wids[2], raw_in_wids[2], ker_wid, real_batch[2], real_batch[2], norm[2], log_sparse[2], "Conv_sparse"));
@@ -273,18 +229,8 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
         int ker_inf_wid = raw_in_wids[2]; if (ker_inf_wid % 2 == 0) ker_inf_wid++;                       // test.go:279-334: reduce_mean + FC
         std::vector<double> ker_inf = readTxt(weight_dir + "final-fckernel.csv", real_batch[2] * fc_out);
         std::vector<double> bn_bf = readTxt(weight_dir + "final-fcbias.csv", fc_out);
-        std::vector<Ciphertext> ct_result, ct_result2;
-        if (cf100 && !wide) {                                                                            // test.go:287-315: two convolutions of fc_out/2 outputs (the wide driver keeps one: test.go:865-882)
-            const int ho = fc_out / 2; const size_t tap = (size_t)real_batch[2] * ho;
-            std::vector<double> k1((size_t)(ker_inf_wid * ker_inf_wid) * tap), k2(k1.size());
-            for (int i = 0; i < ho; i++) for (int j = 0; j < real_batch[2]; j++) for (int b = 0; b < ker_inf_wid * ker_inf_wid; b++) {
-                k1[(size_t)(j * ho + i) + (size_t)b * tap] = ker_inf[(size_t)(j * fc_out + i)];
-                k2[(size_t)(j * ho + i) + (size_t)b * tap] = ker_inf[(size_t)(j * fc_out + i + ho)];
-            }
-            std::vector<double> bn_af((size_t)ho, 1.0 / (double)(raw_in_wids[2] * raw_in_wids[2])), b1(bn_bf.begin(), bn_bf.begin() + ho), b2(bn_bf.begin() + ho, bn_bf.end());
-            ct_result = evalConv_BN_batch(cont, ct_layer, k1, bn_af, b1, in_wids[2], ker_inf_wid, real_batch[2], ho, norm[2], (double)(1 << 30), false);
-            ct_result2 = evalConv_BN_batch(cont, ct_layer, k2, bn_af, b2, in_wids[2], ker_inf_wid, real_batch[2], ho, norm[2], (double)(1 << 30), false);
-        } else {                                                                                         // test.go:316-334
+        std::vector<Ciphertext> ct_result;
+        {                                                                                                // test.go:316-334
             std::vector<double> ker_inf_((size_t)(ker_inf_wid * ker_inf_wid * real_batch[2] * fc_out));
             for (size_t i = 0; i < ker_inf.size(); i++) for (int b = 0; b < ker_inf_wid * ker_inf_wid; b++) ker_inf_[i + (size_t)b * real_batch[2] * fc_out] = ker_inf[i];
             std::vector<double> bn_af((size_t)fc_out, 1.0 / (double)(raw_in_wids[2] * raw_in_wids[2]));
@@ -293,19 +239,10 @@ void testResNet_crop_sparse(int st, int end, int ker_wid, int depth, bool debug,
         printf("Final FC done.\n"); timings[5] = secs(start); start = now();
         printf("\n===============  DECRYPTION  ===============\n\n");
         for (int z = 0; z < nimg; z++) {
-            std::vector<double> res_out;
-            if (cf100 && !wide) {
-                std::vector<double> r1 = DecryptDecodeCoeffs(cont, ct_result[(size_t)z]), r2 = DecryptDecodeCoeffs(cont, ct_result2[(size_t)z]);
-                printf("Decryption Done in %s \n", dur(start).c_str());
-                std::vector<double> o1 = prt_mat_one_norm(r1, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1), o2 = prt_mat_one_norm(r2, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1);
-                res_out.assign(o1.begin(), o1.begin() + fc_out / 2); res_out.insert(res_out.end(), o2.begin(), o2.begin() + fc_out / 2);
-                freeCt(cont, ct_result2[(size_t)z]);
-            } else {
-                std::vector<double> res_tmp = DecryptDecodeCoeffs(cont, ct_result[(size_t)z]);
-                printf("Decryption Done in %s \n", dur(start).c_str());
-                res_out = prt_mat_one_norm(res_tmp, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1);
-                res_out.resize((size_t)fc_out);
-            }
+            std::vector<double> res_tmp = DecryptDecodeCoeffs(cont, ct_result[(size_t)z]);
+            printf("Decryption Done in %s \n", dur(start).c_str());
+            std::vector<double> res_out = prt_mat_one_norm(res_tmp, max_batch[2], norm[2], ker_inf_wid / 2 + 1, ker_inf_wid / 2 + 1);
+            res_out.resize((size_t)fc_out);
             printf("\n result:  ["); for (double v : res_out) printf("%.10f ", v);
             printf("]\n");
             writeTxt(out_dir + "class_result_" + ker_name + "_" + std::to_string(g0 + z) + ".csv", res_out);

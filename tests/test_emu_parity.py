@@ -9,8 +9,10 @@ import subprocess
 import pytest
 
 import parity_cases as pc
-from optimal_conv_amd import Context
+from optimal_conv_amd import Context, HconvError
 from oracle_lib import Oracle, P0, Q0, Q1
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_emu")
 EMU_LIB = os.path.join(EMU_DIR, "_build", "libhconv_emu.so")
@@ -235,16 +237,36 @@ def test_swk_generate_splitmix_equals_the_oracle_generator():
     pc.case_swk_generate_splitmix(lambda Q, P: Context(Q, P, lib_path=EMU_LIB), lambda Q, P: Oracle(q=Q, p=P))
 
 
-def test_free_into_a_foreign_context_is_refused(monkeypatch):
-    """cached allocations (HCONV_ASYNC_ALLOC=1): a block goes back to the context it came from; handing it to another context's hc_free is an error, not a silent
+def test_free_into_a_foreign_context_is_refused():
+    """cached allocations (option async_alloc = 1; the library itself reads no environment variable): a block goes back to the context it came from; handing it to another context's hc_free is an error, not a silent
     hipFree that leaves the owner's block table stale (the lifetime bug behind round 2's synchronising hc_free)"""
     from optimal_conv_amd.abi import DevBuf
     subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
-    monkeypatch.setenv("HCONV_ASYNC_ALLOC", "1")
     a, b = Context([Q0, Q1], [P0], lib_path=EMU_LIB), Context([Q0, Q1], [P0], lib_path=EMU_LIB)
+    a.set_option("async_alloc", 1); b.set_option("async_alloc", 1)
     buf = DevBuf(a, 1 << 16)
+    with pytest.raises(HconvError, match="right after hc_ctx_create"):       # the allocation mode follows the blocks: not while the context owns one
+        a.set_option("async_alloc", 0)
     assert b.L.hc_free(b.h, buf.ptr) != 0 and b"not allocated by this context" in b.L.hc_last_error(b.h)
     assert a.L.hc_free(a.h, buf.ptr) == 0
     again = DevBuf(a, 1 << 16)                      # the parked block is handed out again
     assert again.ptr.value == buf.ptr.value
     again.free(); a.close(); b.close()
+
+
+def test_the_library_reads_no_environment_and_refuses_more_than_five_special_primes(monkeypatch):
+    """hc_ctx_create takes nothing from the environment (a cgo host would inherit its shell's); np = 6..8 had a spilling, 30 % slower extension pass
+    and is refused (HC_ERR_UNSUPPORTED) instead of shipped; the source holds no getenv at all."""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+    src = open(os.path.join(ROOT, "optimal_conv_amd", "csrc", "hconv.hip")).read()
+    assert "getenv" not in src
+    for v in ("HCONV_PACK32", "HCONV_SMALL32", "HCONV_ROT_FUSE", "HCONV_ASYNC_ALLOC"):
+        monkeypatch.setenv(v, "0")
+    c = Context([0x3FFC0001, 0x40080001, 0x3FAC0001, pc.Q_MIX[4]], pc.P_CHAIN[:5], lib_path=EMU_LIB)
+    assert [int(c.L.hc_row_is32(c.h, l)) for l in range(4)] == [0, 0, 0, 0]    # HCONV_PACK32 in the environment changes nothing
+    c.set_option("pack32", 2)
+    assert [int(c.L.hc_row_is32(c.h, l)) for l in range(4)] == [0, 0, 1, 0]    # limbs 0 and 1 keep 8-byte rows whatever their size (the conv path, Rescale's level-1 branch, sk rows read them so)
+    c.close()
+    six = pc.P_CHAIN + [0x1FFFFFFFFF380001]
+    with pytest.raises(HconvError, match="at most 5"):
+        Context(pc.Q_MIX[:3], six, lib_path=EMU_LIB)

@@ -285,6 +285,17 @@ def test_ckks_leveled_ops_on_gpu():
     pc.case_ckks_ops(lambda Q, P: Context(Q, P))
 
 
+# HCONV_TEST_FULL=1 adds the long ABI-level replays whose claims the default suite also holds through the PRODUCT host (tests/test_gpu_z_cli.py: the chain replays against the
+# reference binary's digests, test_resnet_cli_depth20 / _image_batch_of_8 against the oracle network's 19 layer digests - every layer geometry: log_sparse 1..4, both stride
+# layers). Round 6: the default `pytest -m gpu` had grown to 829 s of the driver's 1 200 s limit; the full set last ran green on MI355X at the start of round 6
+# (profiles/round6_pytest_gpu_full_durations.txt).
+FULL = bool(os.environ.get("HCONV_TEST_FULL"))
+
+
+def _full_only(*params):
+    return [pytest.param(*p, marks=pytest.mark.skipif(not FULL, reason="HCONV_TEST_FULL=1: covered through the product host by default")) for p in params]
+
+
 def test_conv_relu_tail_on_gpu():
     """scope row 8f-1: CtoS + sine evaluation, the ReLU polynomials of conv.go:435-480, keep_ctxt mask, StoC on the device ABI:
     every stage bit-identical to the oracle, decrypted result within the precision the reference prints for convReLU"""
@@ -293,6 +304,7 @@ def test_conv_relu_tail_on_gpu():
     print("median precision bits", bits)
 
 
+@pytest.mark.skipif(not FULL, reason="HCONV_TEST_FULL=1 (74 s): the baseline's Bootstrapp is pinned to the reference binary by test_baseline_bootstrapp_vs_reference_trace_on_gpu and the CLI replay")
 def test_baseline_boot_relu_on_gpu():
     """the baseline half of convReLU (test_BL.go:113-168: imaginary packing, SetScale, stock Bootstrapp over parameter set [7], ReLU
     from level 12, SetScale) through the C ABI vs the oracle backend at full size: bootstrapped ciphertext and both results bit for bit"""
@@ -300,7 +312,7 @@ def test_baseline_boot_relu_on_gpu():
     pc.case_bl_boot_relu(lambda Q, P: Context(Q, P))
 
 
-@pytest.mark.parametrize("log_sparse,in_wid", [(2, 32), (3, 16), (4, 8), (1, 32)])
+@pytest.mark.parametrize("log_sparse,in_wid", [(4, 8), (1, 32)] + _full_only((2, 32), (3, 16)))
 def test_conv_relu_tail_sparse_on_gpu(log_sparse, in_wid):
     """scope row 8f-3: the "Conv_sparse" tail (sparse-slot bootstrapping of the ResNet layers) on the device ABI, every stage bit-identical
     to the oracle at full size: the geometries of `resnet 3 20 1 n false` (test.go:76-370: log_sparse 2 / 3 / 4 on 32 / 16 / 8-wide images), plus log_sparse 1 (the
@@ -310,7 +322,7 @@ def test_conv_relu_tail_sparse_on_gpu(log_sparse, in_wid):
     print("median precision bits", pc.case_conv_relu_tail_sparse(lambda Q, P: Context(Q, P), log_sparse, in_wid=in_wid))
 
 
-@pytest.mark.parametrize("log_sparse,in_wid", [(1, 32), (2, 16)])
+@pytest.mark.parametrize("log_sparse,in_wid", [(2, 16)] + _full_only((1, 32)))
 def test_strconv_tail_sparse_on_gpu(log_sparse, in_wid):
     """scope row 8f-3: the "StrConv_sparse" tail of the two stride layers of `resnet 3 20 1 n false` (eval.go:335-392 after the half
     convolutions are joined): bootstrapping with log_sparse 1 / 2, ReLU, ext_double_ctxt (conv.go:374-414) with the gen_comprs_sparse
@@ -319,7 +331,7 @@ def test_strconv_tail_sparse_on_gpu(log_sparse, in_wid):
     pc.case_strconv_tail_sparse(lambda Q, P: Context(Q, P), log_sparse, in_wid)
 
 
-@pytest.mark.parametrize("depth", [20] + ([8] if os.environ.get("HCONV_TEST_DEPTH8") else []))
+@pytest.mark.parametrize("depth", _full_only((20,)) + ([8] if os.environ.get("HCONV_TEST_DEPTH8") else []))
 def test_resnet_network_on_gpu(depth):
     """scope row 8f-3 as a whole: `resnet 3 <depth> 1 n false` (testResNet_crop_sparse, test.go:76-370) with every layer's ring work on the device ABI, against the
     oracle network: the ciphertext after EVERY conv-BN-ReLU layer bit-identical, and the same class scores. Depth 20 (19 layers, ~2.5 min on MI355X) is BASELINE.md's

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    text = open(os.path.join(ROOT, "include", "hconv.h")).read()
+    # include/hconv.h = what a Lattigo host binds; include/hconv_test_hooks.h = the one entry point that exists for this repository's replays
+    text = open(os.path.join(ROOT, "include", "hconv.h")).read() + open(os.path.join(ROOT, "include", "hconv_test_hooks.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(hc_[a-z0-9_]+)\s*\(", text)))
 
@@ -29,7 +30,7 @@ def test_hip_library_exports_every_declared_symbol():
         import __graft_entry__
         __graft_entry__.build()
     L = abi.load()                       # types every symbol; AttributeError on drift
-    assert L.hc_version() >= 1
+    assert L.hc_version() >= 2
 
 
 def test_no_cpu_fallback_without_gpu():
