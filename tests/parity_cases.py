@@ -532,7 +532,19 @@ def case_batched_leveled(make_ctx, n=3, level=4, alpha=3, seed=0xBA7C4, make_ora
         run(f"lv_op2 {nm}", lambda x0, x1, y0, y1, o0, o1, op=op: ck(L.hc_lv_op2(h, op, level, x0, x1, y0, y1, o0, o1, None)), [(a, "p"), (a1, "p"), (b, "p"), (b1, "p")], [("p", PW), ("p", PW)])
     run("lv_op2 mul_const", lambda x0, x1, o0, o1: ck(L.hc_lv_op2(h, 3, level, x0, x1, None, None, o0, o1, consts)), [(a, "p"), (a1, "p")], [("p", PW), ("p", PW)])
     run("lv_op2 mul (plaintext)", lambda x0, x1, y, o0, o1: ck(L.hc_lv_op2(h, 8, level, x0, x1, y, None, o0, o1, None)), [(a, "p"), (a1, "p"), (pt, "s")], [("p", PW), ("p", PW)])
-    run("lv_op2 mul (one per-image polynomial for both)", lambda x0, x1, y, o0, o1: ck(L.hc_lv_op2(h, 0, level, x0, x1, y, y, o0, o1, None)), [(a, "p"), (a1, "p"), (b, "p")], [("p", PW), ("p", PW)])
+    run("lv_op2 mul (per-image second operands)", lambda x0, x1, y0, y1, o0, o1: ck(L.hc_lv_op2(h, 0, level, x0, x1, y0, y1, o0, o1, None)), [(a, "p"), (a1, "p"), (b, "p"), (b1, "p")], [("p", PW), ("p", PW)])
+    # hc_version() 1 read "b0 == b1" as ONE plaintext for every image; since version 2 that is HC_LV_MUL_PLAIN, and the legacy form inside a batch is refused instead of read
+    # as a per-image operand past a one-polynomial allocation. Outside a batch b0 == b1 keeps its plain meaning.
+    if n > 1:
+        xa, xb, xo = put(a, PS), put(b, PS), put(np.zeros((n, PW), dtype=np.uint64), PS)
+        ctx.set_batch(n, PS, QS)
+        for opc in (0, 7):
+            assert L.hc_lv_op2(h, opc, level, xa.ptr, xa.ptr, xb.ptr, xb.ptr, xo.ptr, xo.ptr, None) == 1 and b"HC_LV_MUL_PLAIN" in L.hc_last_error(h)
+        ctx.set_batch(1)
+        ck(L.hc_lv_op2(h, 0, level, xa.ptr, xa.ptr, xb.ptr, xb.ptr, xo.ptr, xo.ptr, None))
+        ctx.sync()
+        for x in (xa, xb, xo):
+            x.free()
     run("lv_op2 mul_acc (plaintext)", lambda x0, x1, y, o0, o1: ck(L.hc_lv_op2(h, 9, level, x0, x1, y, None, o0, o1, None)), [(a, "p"), (a1, "p"), (pt, "s")], [("p", PW), ("p", PW)],
         init=[b.reshape(n, -1), b1.reshape(n, -1)])
     # a leaf of evaluatePolyFromPowerBasis in one launch == the MultByConst / Add chain + AddConst
