@@ -46,7 +46,7 @@ def traffic_from_profiles(B):
     """HBM-side (L2 <-> fabric) bytes per conv from the committed rocprofv3 PMC passes (tools/gpu_r3_pmc.sh -> tools/pmc_traffic.py).
     PMC counters cannot be read from inside this process, so the figure is the one measured with the command recorded beside it
     (`measured_with`: contexts, ciphertexts per launch set, commit) and committed under profiles/. (None, None) when there is none."""
-    for name in (f"round5_traffic_conv_B{B}.json", f"round4_traffic_conv_B{B}.json", f"round3_traffic_conv_B{B}.json", f"traffic_conv_B{B}.json"):
+    for name in (f"round6_traffic_conv_B{B}.json", f"round5_traffic_conv_B{B}.json", f"round4_traffic_conv_B{B}.json", f"round3_traffic_conv_B{B}.json", f"traffic_conv_B{B}.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             return d["bytes_per_conv"], {"file": "profiles/" + name, **d.get("measured_with", {"note": d.get("method", "")})}
@@ -59,7 +59,7 @@ def valu_from_profiles():
     """VALU side of the conv's roofline from the committed counter pass (tools/gpu_r4_pmc.sh -> tools/valu_floor.py): lane-instructions per conv, the counter-based busy
     fraction of the VALU pipe, and the issue floor with every instruction class priced at its measured rate. None when there is no such profile."""
     try:
-        name = "round5_conv33_valu.json" if os.path.exists(os.path.join(ROOT, "profiles", "round5_conv33_valu.json")) else "round4_conv33_valu.json"
+        name = next(n for n in ("round6_conv33_valu.json", "round5_conv33_valu.json", "round4_conv33_valu.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         return {"lane_instr_per_conv": d["lane_instr_per_conv"], "busy_frac": d["busy_frac_counter"], "busy_frac_class_priced": d["busy_frac_priced"],
                 "issue_floor_ms": d["issue_floor_ms"], "issue_floor_ms_at_4_cycles_per_instr": d["issue_floor_ms_counter_4cyc"], "kernel_ms_per_conv_one_stream": d["kernel_ms_per_conv_one_stream"],
@@ -214,6 +214,10 @@ def chain_workloads(device, relu_batch, resnet_batch, resnet_images, relu=True):
                 tr = traffic_chain_from_profiles()
                 if tr:
                     out["convReLU_5_1"].update(tr)
+                cv = chain_valu_from_profiles()
+                if cv:          # both roofs: issue floor / measured time beside the HBM fraction above
+                    out["convReLU_5_1"].update(cv)
+                    out["convReLU_5_1"]["valu_frac"] = cv["issue_floor_ms"] / ms
                 if relu_batch != 1:          # one image alone: the latency of the reference's own per-image flow (eval.go:446-565's timers)
                     r1 = subprocess.run([CLI, "convReLU", "5", "1", str(iters)], cwd=work, capture_output=True, text=True, timeout=900, env=dict(env, HCONV_IMAGE_BATCH="1"))
                     if r1.returncode == 0:
@@ -249,13 +253,24 @@ def chain_workloads(device, relu_batch, resnet_batch, resnet_images, relu=True):
 
 def traffic_chain_from_profiles():
     """fabric bytes per convReLU ciphertext-layer from the committed rocprofv3 PMC passes (tools/gpu_relu_traffic.sh), with their provenance"""
-    for name in ("round5_traffic_convrelu_5_1.json", "round4_traffic_convrelu_5_1.json"):
+    for name in ("round6_traffic_convrelu_5_1.json", "round5_traffic_convrelu_5_1.json", "round4_traffic_convrelu_5_1.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             return {"traffic": d["bytes_per_ciphertext_layer"], "traffic_measured_with": {"file": "profiles/" + name, **d.get("measured_with", {})}}
         except Exception:
             continue
     return None
+
+
+def chain_valu_from_profiles():
+    """the OTHER roof of the convReLU chain: lane-instructions and the VALU issue floor per ciphertext-layer from the committed per-kernel counter pass
+    (tools/gpu_r6_chain_counters.sh -> tools/chain_table.py -> profiles/round6_chain_valu.json; the layers' kernels only, set-up excluded)"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "round6_chain_valu.json")))
+        return {"issue_floor_ms": d["issue_floor_ms"], "lane_instr_per_ct_layer": d["lane_instr_per_ct_layer"], "kernel_ms_per_ct_layer_under_rocprof": d["kernel_ms_per_ct_layer"],
+                "valu_measured_with": {"file": "profiles/round6_chain_valu.json", "table": "profiles/round6_chain_counters.txt", "images_per_launch_set": d["images_per_launch_set"], "commit": d.get("commit"), "method": d["method"]}}
+    except Exception:
+        return None
 
 
 def sharded_conv_timing(rank, world, device, backend):

@@ -215,7 +215,10 @@ __device__ __forceinline__ T hc_const_copy(const T *p) {
 // KC: through the CONSTANT address space (the batched multi-modulus kernels, whose 32-bit and 64-bit bodies sit side by side: hc_const_copy). The convolution's kernels keep
 // global loads: as constant-memory loads their twiddle fetches may be hoisted anywhere, and hc_k_b3 / hc_k_b5m - two transforms each - then spill 430-530 bytes (-19 % conv/s)
 template <bool KC = false> struct HcRowsTwA { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { if (KC) return HC_TW_LOADK(p, slot); else return HC_TW_LOAD(p, slot); } };
-template <bool KC = false> struct HcRowsTwB { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { if (KC) return HC_TW_LOADK(p, slot * 16); else return HC_TW_LOAD(p, slot * 16); } };
+#ifndef HC_DBG_TWB_FIXED
+#define HC_DBG_TWB_FIXED 0          // timing probe only (WRONG residues): every per-thread twiddle of a rows pass is the slot-0 one - what the 60 KiB of per-thread twiddles per tile cost
+#endif
+template <bool KC = false> struct HcRowsTwB { const HcTw *p; __device__ __forceinline__ HcTw operator()(int slot) const { if (HC_DBG_TWB_FIXED) slot = 0; if (KC) return HC_TW_LOADK(p, slot * 16); else return HC_TW_LOAD(p, slot * 16); } };
 
 // forward rows pass on registers: in  e[hi] = element (row, hi*16+tid)  [lazy < 4q]
 //                                 out e[lo] = element (row, tid*16+lo)  [lazy, bound per forward mode]
@@ -479,7 +482,7 @@ __device__ __forceinline__ void hc_xchg1(u32 (&e)[16], u32 *lds, WA wa, RA ra, S
 #define HC_TW32_LOADK(p, i) ((p)[i])
 #endif
 struct HcRowsTw32A { const HcTw32 *p; __device__ __forceinline__ HcTw32 operator()(int slot) const { return HC_TW32_LOADK(p, slot); } };
-struct HcRowsTw32B { const HcTw32 *p; __device__ __forceinline__ HcTw32 operator()(int slot) const { return HC_TW32_LOADK(p, slot * 16); } };
+struct HcRowsTw32B { const HcTw32 *p; __device__ __forceinline__ HcTw32 operator()(int slot) const { if (HC_DBG_TWB_FIXED) slot = 0; return HC_TW32_LOADK(p, slot * 16); } };
 __device__ __forceinline__ void hc_rows_fwd32(u32 (&e)[16], u32 *lds, const HcTwTab32 &T, int row, int rloc, int tid, u32 q) {
     hc_ct_round32(e, HcRowsTw32A{T.rowsA + row * 16}, q);
     hc_xchg1(e, lds, [&](int hi) { return hc_rows_lds32(rloc, hi * 16 + tid); }, [&](int lo) { return hc_rows_lds32(rloc, tid * 16 + lo); }, [] { HC_ROW_SYNC(); });
@@ -1853,6 +1856,9 @@ struct HcBasisExt {
 #ifndef HC_EXT_FULL
 #define HC_EXT_FULL 1                  // a straight-line form of the extension for operands with exactly NS source limbs (hc_basis_ext_tile)
 #endif
+#ifndef HC_DBG_EXT_ONELOAD
+#define HC_DBG_EXT_ONELOAD 0          // timing probe only (WRONG residues): the extension reads ONE of a coefficient's n + 1 operand words - what its 6x re-read of the y rows costs
+#endif
 #define HC_MAX_NP 5                    // most special primes of a context (hc_ctx_create refuses more): the extension's operand registers are sized by it (NS = 2 or HC_MAX_NP)
 // target side of the extension for one coefficient: y[0..n-1] = the y_i, y[n] = v. NS = the most source limbs the caller can have (the context's number of special primes:
 // a digit has at most alpha limbs, ModDown extends from the alpha P limbs): the operand array - (NS + 1) registers pairs per coefficient in flight - is sized by it, not by the
@@ -1868,10 +1874,12 @@ __device__ __forceinline__ u64 hc_basis_ext_sum(const u64 (&y)[NS + 1], const Hc
     // v <= n <= 8 is a small integer: v (S mod t) < 8t is formed as an exact 32 x 64-bit product (2-3 instructions against a lazy Shoup product's 12-14)
     const u64 vs = (u64)(u32)v * B.smodt.w;
     if (B.t < (1ull << 58)) {                                          // lazy sum: below 2^58 up to 8 terms and the offset stay under 40 t < 2^64 unreduced
-        u64 acc = 2 * Q.q4;
+        // sum_i hc_shoup4(y_i, w_i, w'_i) = sum_i y_i w_i + (sum_i hi_i) (2^64 - t) modulo 2^64 - and the sum is below 2^64, so this IS the sum: ONE product by the negated
+        // modulus for all terms instead of one per term (round 6: the extension is VALU-bound; 4-5 instructions less per term, the same 64-bit value)
+        u64 acc = 2 * Q.q4, hi = 0;
 #pragma unroll
-        for (int i = 0; i < NS; i++) if (i < n) acc += hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q);
-        return hc_reduce64(acc - vs, B.mu_t, Q);
+        for (int i = 0; i < NS; i++) if (i < n) { acc += y[i] * B.hat[i].w; hi += hc_mulhi_lo2(y[i], B.hat[i].ws); }
+        return hc_reduce64(acc + hi * Q.nq - vs, B.mu_t, Q);
     }
     u64 acc = 0;                                                       // the 60 / 61-bit limbs fold the running sum by 4t
 #pragma unroll
@@ -1884,10 +1892,10 @@ template <int NS>
 __device__ __forceinline__ u64 hc_basis_ext_sum_full(const u64 (&y)[NS + 1], const HcBasisExt &B, const HcQ &Q) {
     const u64 vs = (u64)(u32)y[NS] * B.smodt.w;                          // v (S mod t) < 8t, exact (hc_basis_ext_sum)
     if (B.t < (1ull << 58)) {
-        u64 acc = 2 * Q.q4;
+        u64 acc = 2 * Q.q4, hi = 0;                                      // one product by 2^64 - t for the sum of the quotient estimates (hc_basis_ext_sum)
 #pragma unroll
-        for (int i = 0; i < NS; i++) acc += hc_shoup4(y[i], B.hat[i].w, B.hat[i].ws, Q);
-        return hc_reduce64(acc - vs, B.mu_t, Q);
+        for (int i = 0; i < NS; i++) { acc += y[i] * B.hat[i].w; hi += hc_mulhi_lo2(y[i], B.hat[i].ws); }
+        return hc_reduce64(acc + hi * Q.nq - vs, B.mu_t, Q);
     }
     u64 acc = 0;
 #pragma unroll
@@ -1905,7 +1913,7 @@ __device__ __forceinline__ void hc_basis_ext_tile(u64 (&e)[16], const u64 *yv, c
             for (int g = 0; g < HC_EXT_GROUP; g++) {
                 const u64 *p = yv + (size_t)((g0 + g) * 16 + tid) * 256;
 #pragma unroll
-                for (int i = 0; i <= NS; i++) y[g][i] = p[(size_t)i * 65536];
+                for (int i = 0; i <= NS; i++) y[g][i] = p[(size_t)(HC_DBG_EXT_ONELOAD ? 0 : i) * 65536];
             }
 #pragma unroll
             for (int g = 0; g < HC_EXT_GROUP; g++) e[g0 + g] = hc_basis_ext_sum_full<NS>(y[g], B, Q);
@@ -1970,7 +1978,7 @@ __device__ __forceinline__ void hc_basis_ext_tile32(u32 (&e)[16], const u64 *yv,
         for (int g = 0; g < HC_EXT_GROUP; g++) {
             const u64 *p = yv + (size_t)((g0 + g) * 16 + tid) * 256;
 #pragma unroll
-            for (int i = 0; i <= NS; i++) y[g][i] = p[roff[i]];
+            for (int i = 0; i <= NS; i++) y[g][i] = p[HC_DBG_EXT_ONELOAD ? 0 : roff[i]];
         }
 #pragma unroll
         for (int g = 0; g < HC_EXT_GROUP; g++) e[g0 + g] = hc_basis_ext_sum32<NS>(y[g], hat, off, smodt, t, mu_t);
@@ -2446,6 +2454,21 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_basis_v(u64 *yv, int yv_rows, con
 // prep_pinv != null (a relinearisation whose ModDown is fused with the Rescale behind it, hc_ks_moddown_rescale): the last Q limb's row leaves as acc_L / P + add_L - the row
 // Rescale's lift is taken from - instead of acc_L (what hc_k_mdrs_prep did in a launch of its own); add: [k][row][N] components add_zs apart, images add_is apart, or null
 struct HcMacPrep { const HcTw *pinv; const u64 *add; size_t add_zs, add_is; };
+// Accumulators of the inner products (round 6). 8-byte rows: the key is in Montgomery form, products are summed as 128-bit integers and reduced once per PER = 6 digits
+// (hc_mont_redc: 6 q^2 < q 2^64). 4-byte rows (a limb below 2^31 under pack32): hc_k_pack32_rows leaves the key rows as PLAIN residues, digit and key words are 32-bit, a
+// product is ONE v_mad_u64_u32 into a 64-bit sum (PER = 4 products of residues below 2^31 stay below 2^64) and a short Barrett step closes it - 1.5 instructions per
+// product against the 25 of a Montgomery product on zero-extended words (hc_k_ks_mac_multi was VALU-bound at 0.86 of the pipe: profiles/round6_chain_counters_before.txt).
+template <bool P32> struct HcMacAcc;
+template <> struct HcMacAcc<false> {
+    static constexpr int PER = 6; u128 v;
+    __device__ __forceinline__ void mac(bool first, u64 x, u64 k) { const u128 p = (u128)x * k; v = first ? p : v + p; }
+    __device__ __forceinline__ u64 reduce(const HcMod &m) const { return hc_mont_redc(v, m.q, m.qinv); }
+};
+template <> struct HcMacAcc<true> {
+    static constexpr int PER = 4; u64 v;
+    __device__ __forceinline__ void mac(bool first, u64 x, u64 k) { const u64 p = (u64)(u32)x * (u64)(u32)k; v = first ? p : v + p; }
+    __device__ __forceinline__ u64 reduce(const HcMod &m) const { return hc_barrett64(v, m.q, m.mu); }
+};
 // Per-digit form: the digits stay a loop (any count, few registers, 6-7 wavefronts per SIMD) but the 2 + NB loads of ONE digit are a straight run - typed at compile time
 // (P32), the image index clamped instead of tested - and only the own / foreign choice, which changes the operand's width, is a (uniform) branch.
 template <int NB, bool P32, bool U32>
@@ -2453,8 +2476,9 @@ __device__ __forceinline__ void hc_ks_mac_all_digit(const u64 *evk, const u64 *c
                                                     int nl, int nt, int alpha, int beta, int n, const HcMacPrep &prep, bool prepL, HcTw pw) {
     const size_t rowT = (size_t)T * 65536, comp = (size_t)nt * 65536;
     const int d_own = T < nl ? T / alpha : -1;
+    constexpr int PER = HcMacAcc<P32>::PER;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
-        u128 t0[NB], t1[NB]; u64 s0[NB], s1[NB];
+        HcMacAcc<P32> t0[NB], t1[NB]; u64 s0[NB], s1[NB];
         for (int d = 0; d < beta; d++) {
             const u64 *krow = evk + ((size_t)d * 2 * nt) * 65536 + rowT;
             const u64 kb = P32 ? hc_ld32(krow, j) : krow[j], ka = P32 ? hc_ld32(krow + comp, j) : krow[comp + j];
@@ -2467,16 +2491,14 @@ __device__ __forceinline__ void hc_ks_mac_all_digit(const u64 *evk, const u64 *c
 #pragma unroll
                 for (int g = 0; g < NB; g++) { const u64 *xg = xrow + (size_t)(g < n ? g : n - 1) * dg_is; x[g] = P32 ? hc_ld32(xg, j) : xg[j]; }
             }
-            const int ph = d % 6;
+            const int ph = d % PER;
 #pragma unroll
             for (int g = 0; g < NB; g++) {
-                const u128 p0 = (u128)x[g] * kb, p1 = (u128)x[g] * ka;
-                t0[g] = ph == 0 ? p0 : t0[g] + p0;
-                t1[g] = ph == 0 ? p1 : t1[g] + p1;
-                if (ph == 5 || d + 1 == beta) {
-                    const u64 r0 = hc_mont_redc(t0[g], m.q, m.qinv), r1 = hc_mont_redc(t1[g], m.q, m.qinv);
-                    s0[g] = d < 6 ? r0 : hc_addmod(s0[g], r0, m.q);
-                    s1[g] = d < 6 ? r1 : hc_addmod(s1[g], r1, m.q);
+                t0[g].mac(ph == 0, x[g], kb); t1[g].mac(ph == 0, x[g], ka);
+                if (ph == PER - 1 || d + 1 == beta) {
+                    const u64 r0 = t0[g].reduce(m), r1 = t1[g].reduce(m);
+                    s0[g] = d < PER ? r0 : hc_addmod(s0[g], r0, m.q);
+                    s1[g] = d < PER ? r1 : hc_addmod(s1[g], r1, m.q);
                 }
             }
         }
@@ -2496,7 +2518,7 @@ __device__ __forceinline__ void hc_ks_mac_all_digit(const u64 *evk, const u64 *c
 #define HC_MAC_WAVES 1                 // minimum wavefronts per SIMD the inner products are compiled for (1 = no constraint: 89 VGPRs / 5 wavefronts at 4 images per thread)
 #endif
 #ifndef HC_MACM_WAVES
-#define HC_MACM_WAVES 1
+#define HC_MACM_WAVES 2                // the 128-bit accumulators of 4 rotations x 4 images take 128 VGPRs
 #endif
 template <int NB>
 __global__ __launch_bounds__(HC_TPB, HC_MAC_WAVES) void hc_k_ks_mac_all(const u64 *evk, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_is, const HcMod *mods,
@@ -2521,13 +2543,18 @@ struct HcKeyPtrs { const u64 *k[8]; };
 // it to: hc_perm_src(., g^-1). An aligned block of 2^m indices maps onto an aligned block of 2^m indices (the low bits of g (2 r + 1) depend on the low bits of r only), so the
 // 64 lanes of a wavefront still fill whole 128-byte lines. (Kernel template parameter FIN; without it: plain accumulators (acc), as before.)
 struct HcRotFin { u64 *out[8]; u32 ginv[8]; const u64 *pc0; size_t pc0_is, out_is; };
-// per-digit form as hc_ks_mac_all_digit: the 2 R key words of a digit (all rotations) and its NB digit words are one run of loads
-template <int R, int NB, bool P32, bool U32, bool FIN>
+// per-digit form as hc_ks_mac_all_digit: the 2 R key words of a digit (all rotations) and its NB digit words are one run of loads. Round 6: lazy sums instead of one
+// Montgomery product and one modular addition per term (35 instructions per product on 8-byte rows, 25 on 4-byte ones; the kernel ran at 0.86 of the VALU pipe): 128-bit
+// accumulators on 8-byte rows (14.5 per product; R x NB x 2 of them: 128 VGPRs - compiled for two wavefronts per SIMD, every thread keeps 2 R + NB loads in flight), 64-bit
+// ones on 4-byte rows (1.5 per product). LONG (block-uniform): more digits than one accumulator takes (PER) - the running canonical sums s exist only then.
+template <int R, int NB, bool P32, bool U32, bool FIN, bool LONG, bool LAZY>
 __device__ __forceinline__ void hc_ks_mac_multi_digit(const HcKeyPtrs &keys, int nrot, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_rs, size_t acc_is, const HcMod m, int T,
                                                       int nl, int nt, int alpha, int beta, int n, const HcRotFin &F) {
     const size_t rowT = (size_t)T * 65536, comp = (size_t)nt * 65536;
     const int d_own = T < nl ? T / alpha : -1;
+    constexpr int PER = HcMacAcc<P32>::PER;
     for (size_t j = (size_t)blockIdx.x * HC_TPB + threadIdx.x; j < 65536; j += (size_t)gridDim.x * HC_TPB) {
+        HcMacAcc<P32> t0[R][NB], t1[R][NB];
         u64 s0[R][NB], s1[R][NB];
         for (int d = 0; d < beta; d++) {
             u64 x[NB], kb[R], ka[R];
@@ -2544,14 +2571,30 @@ __device__ __forceinline__ void hc_ks_mac_multi_digit(const HcKeyPtrs &keys, int
 #pragma unroll
                 for (int g = 0; g < NB; g++) { const u64 *xg = xrow + (size_t)(g < n ? g : n - 1) * dg_is; x[g] = P32 ? hc_ld32(xg, j) : xg[j]; }
             }
+            const int ph = LONG ? d % PER : d;
 #pragma unroll
             for (int r = 0; r < R; r++)
 #pragma unroll
                 for (int g = 0; g < NB; g++) {
-                    const u64 p0 = hc_mont(x[g], kb[r], m.q, m.qinv), p1 = hc_mont(x[g], ka[r], m.q, m.qinv);
-                    s0[r][g] = d == 0 ? p0 : hc_addmod(s0[r][g], p0, m.q);
-                    s1[r][g] = d == 0 ? p1 : hc_addmod(s1[r][g], p1, m.q);
+                    if constexpr (!P32 && (LONG || !LAZY)) {                             // more than 6 digits on 8-byte rows (no parameter set of the reference): one Montgomery product per term - 128-bit sums AND running sums do not fit the register file
+                        const u64 p0 = hc_mont(x[g], kb[r], m.q, m.qinv), p1 = hc_mont(x[g], ka[r], m.q, m.qinv);
+                        s0[r][g] = d == 0 ? p0 : hc_addmod(s0[r][g], p0, m.q);
+                        s1[r][g] = d == 0 ? p1 : hc_addmod(s1[r][g], p1, m.q);
+                    } else {
+                        t0[r][g].mac(ph == 0, x[g], kb[r]); t1[r][g].mac(ph == 0, x[g], ka[r]);
+                        if (LONG && (ph == PER - 1 || d + 1 == beta)) {
+                            const u64 r0 = t0[r][g].reduce(m), r1 = t1[r][g].reduce(m);
+                            s0[r][g] = d < PER ? r0 : hc_addmod(s0[r][g], r0, m.q);
+                            s1[r][g] = d < PER ? r1 : hc_addmod(s1[r][g], r1, m.q);
+                        }
+                    }
                 }
+        }
+        if constexpr (!LONG && (P32 || LAZY)) {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int g = 0; g < NB; g++) { s0[r][g] = t0[r][g].reduce(m); s1[r][g] = t1[r][g].reduce(m); }
         }
         if (FIN) {                                                            // the rotations' tails here (HcRotFin); a compile-time choice: with both store forms in one kernel it ran out of SGPRs
             if (F.pc0 != nullptr && T < nl) {
@@ -2576,15 +2619,20 @@ __device__ __forceinline__ void hc_ks_mac_multi_digit(const HcKeyPtrs &keys, int
             for (int g = 0; g < NB; g++) if (g < n) { u64 *a = acc + (size_t)r * acc_rs + (size_t)g * acc_is + rowT; HC_ST(U32, a, j, s0[r][g]); HC_ST(U32, a + comp, j, s1[r][g]); }
     }
 }
-template <int R, int NB, bool FIN>
-__global__ __launch_bounds__(HC_TPB, HC_MACM_WAVES) void hc_k_ks_mac_multi(HcKeyPtrs keys, int nrot, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_rs, size_t acc_is, const HcMod *mods,
+// LAZY (host: three digits or more): 128-bit sums on the 8-byte rows, two wavefronts per SIMD. With one or two digits (SlotsToCoeffs: levels 3 and 2) the products are few and
+// the launch is short: one Montgomery product per term in a third of the registers measured faster there (46.5 against 53.8 us per launch)
+template <int R, int NB, bool FIN, bool LAZY>
+__global__ __launch_bounds__(HC_TPB, LAZY ? HC_MACM_WAVES : 1) void hc_k_ks_mac_multi(HcKeyPtrs keys, int nrot, const u64 *cx, size_t cx_is, const u64 *digits, size_t dg_is, u64 *acc, size_t acc_rs, size_t acc_is, const HcMod *mods,
                                                             int nl, int nq, int nt, int alpha, int beta, int n, int pk, HcRotFin F) {
     const int T = blockIdx.y;
     const HcMod m = mods[T < nl ? T : nq + (T - nl)];
     const bool small = HC_SMALL_Q(m.q);                                      // block-uniform
-    if (pk && small && m.row32) hc_ks_mac_multi_digit<R, NB, true, true, FIN>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n, F);
-    else if (pk && small) hc_ks_mac_multi_digit<R, NB, true, false, FIN>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n, F);
-    else hc_ks_mac_multi_digit<R, NB, false, false, FIN>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n, F);
+#define HC_MACM_GO(P32, U32) do { if (beta > HcMacAcc<P32>::PER) hc_ks_mac_multi_digit<R, NB, P32, U32, FIN, true, LAZY>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n, F); \
+                                 else hc_ks_mac_multi_digit<R, NB, P32, U32, FIN, false, LAZY>(keys, nrot, cx, cx_is, digits, dg_is, acc, acc_rs, acc_is, m, T, nl, nt, alpha, beta, n, F); } while (0)
+    if (pk && small && m.row32) HC_MACM_GO(true, true);
+    else if (pk && small) HC_MACM_GO(true, false);
+    else HC_MACM_GO(false, false);
+#undef HC_MACM_GO
 }
 // ModDown's last step and evaluator.permuteNTT's tail in one pass (rotations: the key-switched polynomials never reach HBM unpermuted):
 //   out_0[l][i] = ((acc_0 - ext_0) * P^-1 + c0)[l][src(i)],  out_1[l][i] = ((acc_1 - ext_1) * P^-1)[l][src(i)],  src = PermuteNTTIndex(g)
@@ -2711,14 +2759,17 @@ __global__ __launch_bounds__(HC_TPB) void hc_k_qp_mul_sum_g(HcTermPtrsG P, int n
 // In-place conversion of rows to the 4-byte form (hc_ld32): one workgroup per row of the grid (blockIdx.x = row, `rows` rows `stride` words apart... consecutive), rows whose modulus
 // mods[modidx[row % period]] is at least 2^31 are left alone. A chunk of 4096 words is read by the whole workgroup before any of its 4-byte words is written: the words written
 // (bytes [16 KiB c, 16 KiB (c + 1))) lie in what chunks <= c have already read.
+// Round 6: the rows are switching-key rows in Lattigo's stored (Montgomery) form k 2^64 mod q; the packed words are the PLAIN residues k (one hc_mont_redc at load time), so
+// that the inner products of a small limb are bare 32 x 32 -> 64-bit multiply-adds (HcMacAcc<true>).
 __global__ __launch_bounds__(HC_TPB) void hc_k_pack32_rows(u64 *rows, const HcMod *mods, int nl, int nq, int nt) {
     const int T = (int)(blockIdx.x % (unsigned)nt);
-    if (!HC_SMALL_Q(mods[T < nl ? T : nq + (T - nl)].q)) return;
+    const HcMod m = mods[T < nl ? T : nq + (T - nl)];
+    if (!HC_SMALL_Q(m.q)) return;
     u64 *row = rows + (size_t)blockIdx.x * 65536;
     for (int c = 0; c < 16; c++) {
         u64 v[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = row[(size_t)c * 4096 + i * 256 + threadIdx.x];
+        for (int i = 0; i < 16; i++) v[i] = hc_mont_redc((u128)row[(size_t)c * 4096 + i * 256 + threadIdx.x], m.q, m.qinv);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 16; i++) hc_st32(row, (size_t)c * 4096 + i * 256 + threadIdx.x, v[i]);

@@ -1542,7 +1542,7 @@ extern "C" int hc_keyswitch_qp_rotate_many(hc_ctx *c, int nrot, const uint64_t *
             }
             F.pc0 = (const u64 *)pc0; F.pc0_is = c->bs_poly; F.out_is = c->bs_qp;
         }
-#define HC_MAC_MULTI(RR, NN) hc_launch(c, "ks_mac_multi", c->rot_fuse ? hc_k_ks_mac_multi<RR, NN, true> : hc_k_ks_mac_multi<RR, NN, false>, grid, K, nr, (const u64 *)cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, c->ws_accm, acc_rs, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta, nb, c->pack32 ? 3 : 0, F)
+#define HC_MAC_MULTI(RR, NN) hc_launch(c, "ks_mac_multi", beta >= 3 ? (c->rot_fuse ? hc_k_ks_mac_multi<RR, NN, true, true> : hc_k_ks_mac_multi<RR, NN, false, true>) : (c->rot_fuse ? hc_k_ks_mac_multi<RR, NN, true, false> : hc_k_ks_mac_multi<RR, NN, false, false>), grid, K, nr, (const u64 *)cx, c->bs_poly, (const u64 *)S.digits, S.digits_is, c->ws_accm, acc_rs, acc_is, (const HcMod *)c->d_mods, nl, c->nq, nt, alpha, beta, nb, c->pack32 ? 3 : 0, F)
         if (NB == 8) HC_TRY(HC_MAC_MULTI(2, 8)); else if (NB == 4) HC_TRY(HC_MAC_MULTI(4, 4)); else if (NB == 2) HC_TRY(HC_MAC_MULTI(8, 2)); else HC_TRY(HC_MAC_MULTI(8, 1));
 #undef HC_MAC_MULTI
         if (!c->rot_fuse)

@@ -72,6 +72,12 @@ for r in rows:
 ms = 1e3 * tot_t / layers
 print("sum of chain kernel time: %.2f ms per ciphertext-layer; VALU issue floor %.2f ms (valu_frac of the kernel time %.3f); fabric %.2f GB per ciphertext-layer = %.2f TB/s" %
       (ms, 1e3 * tot_floor / layers, tot_floor / tot_t, (tot_rd + tot_wr) / layers / 1e9, (tot_rd + tot_wr) / tot_t / 1e12))
+per_kernel = {r[0]: {"read": r[12] * 1e9, "write": r[13] * 1e9, "launches_per_layer_launch_set": r[1] / IT, "ms_per_ct_layer": r[3]} for r in rows}
+json.dump({"bytes_per_ciphertext_layer": (tot_rd + tot_wr) / layers, "read_bytes_per_ciphertext_layer": tot_rd / layers, "write_bytes_per_ciphertext_layer": tot_wr / layers,
+           "per_kernel_per_ciphertext_layer": per_kernel,
+           "measured_with": {"command": "HCONV_IMAGE_BATCH=%d HCONV_SKIP_BL=1 conv convReLU 5 1 %d under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes)" % (NB, IT),
+                             "images_per_launch_set": NB, "method": "FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, KiB units; the LAYERS' dispatches only (from the first hc_k_ctc_pairs on; harness kernels excluded): rounds 4-5 counted the set-up transforms (key generation, DFT diagonals) in"}},
+          open(O + "/traffic_convrelu_5_1.json", "w"), indent=1)
 json.dump({"issue_floor_ms": 1e3 * tot_floor / layers, "lane_instr_per_ct_layer": tot_lane / layers, "kernel_ms_per_ct_layer": ms, "valu_busy_of_kernel_time": tot_floor / tot_t,
            "fabric_bytes_per_ct_layer": (tot_rd + tot_wr) / layers, "images_per_launch_set": NB, "layers_in_run": IT,
            "method": "tools/gpu_r6_chain_counters.sh: rocprofv3 --kernel-trace --pmc passes over `conv convReLU 5 1 2`; issue floor = sum over the layer's kernels of 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x clock), clock from GRBM_GUI_ACTIVE; harness kernels (key generation, encoding) excluded"},
