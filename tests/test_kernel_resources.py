@@ -17,8 +17,8 @@ NO_SCRATCH = ["hc_k_a1", "hc_k_a2", "hc_k_a3", "hc_k_b1", "hc_k_b2", "hc_k_b3", 
               "hc_k_cols_inv_canon_mm", "hc_k_cols_fwd_mmILi0E", "hc_k_cols_fwd_mmILi1ELi2E", "hc_k_cols_fwd_mmILi2ELi2E", "hc_k_cols_fwd_mmILi2ELi5E", "hc_k_ks_mac", "hc_k_qp_mul_sum",
               "hc_k_lv_", "hc_k_basis_yv"]
 # hc_k_cols_fwd_mm<1, 5> at five wavefronts keeps 12 bytes of scratch in its rarely taken generic-digit path (measured faster than four wavefronts without: profiles/LEDGER.md)
-# hc_k_ks_mac_multi<8, 2, false, true>: the rot_fuse = 0 A/B form (not the default) at one or two images per launch set keeps 68 bytes beside its 128-bit sums
-SMALL_SCRATCH = {"hc_k_cols_fwd_mmILi1ELi5E": 16, "hc_k_ks_mac_multiILi8ELi2ELb0ELb1E": 72}
+# hc_k_ks_mac_multi<8, 2, false, *>: the rot_fuse = 0 A/B form (not the default) at two images per launch set keeps 68 bytes (eight key pointers and eight accumulator pointers: scalar registers)
+SMALL_SCRATCH = {"hc_k_cols_fwd_mmILi1ELi5E": 16, "hc_k_ks_mac_multiILi8ELi2ELb0E": 72}
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
