@@ -1994,7 +1994,9 @@ struct HcMm { const HcRowMod *M; int nl, nq, skip_lo, skip_hi; size_t zs_in, zs_
               int xcd, nzn;                  // rows passes: XCD-aware 1-D grid over nzn = nz * images operands (HC_MM_PROLOGUE_ROWS)
               int out_gap;                   // hc_k_cols_inv_canon_mm: > 0: row y of the output goes to row y + y / out_gap (one free row after every out_gap rows: the v row of a digit's y_i rows)
               int pk_in, pk_out, pk_epi;     // the rows of `in` / `out` / the epilogue's operands (epi_x, epi_add and the result) whose modulus is below 2^31 are 4-byte words
-              unsigned char rowlist[48];     // blockIdx.y -> row (rows a launch has nothing to do for are left out of the grid)
+              int gap_lo, gap_len;           // blockIdx.y -> row: y + (y >= gap_lo ? gap_len : 0) - the rows [gap_lo, gap_lo + gap_len) a launch has nothing to do for are left out of the
+                                             // grid. (Arithmetic since round 6: as a 48-byte table in the kernel arguments the lookup was a vector load and a full wait in front of every
+                                             // workgroup's first load: -1.1 % per ciphertext-layer at 4 images per launch set, -2.3 % at one.)
 
               // fused prologue of the cols-forward pass / epilogue of the rows-forward pass (0 = none):
               //  lift_level > 0  (cols_fwd): the input is NOT read from `in` rows: it is DivRoundByLastModulusNTT's centred remainder of t (one coefficient row per operand,
@@ -2017,7 +2019,7 @@ __device__ __forceinline__ bool hc_mm_skip(const HcMm &A, int y, int zi) {
 }
 __device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl ? y : A.nq + (y - A.nl); }
 #define HC_MM_PROLOGUE \
-    const int y = A.rowlist[blockIdx.y], zi = (int)blockIdx.z % A.nz, img = (int)blockIdx.z / A.nz; if (hc_mm_skip(A, y, zi)) return; \
+    const int y = (int)blockIdx.y + ((int)blockIdx.y >= A.gap_lo ? A.gap_len : 0), zi = (int)blockIdx.z % A.nz, img = (int)blockIdx.z / A.nz; if (hc_mm_skip(A, y, zi)) return; \
     const HcRowMod R = hc_const_copy(&A.M[hc_mm_mod(A, y)]); \
     in += (size_t)zi * A.zs_in + (size_t)img * A.is_in; out += (size_t)zi * A.zs_out + (size_t)img * A.is_out;
 // The rows passes read PER-ROW twiddles: 255 (w, w') pairs = 4 KB for every 2 KB row of data, the same for every operand and image of the launch. With the operand index in
@@ -2028,7 +2030,7 @@ __device__ __forceinline__ int hc_mm_mod(const HcMm &A, int y) { return y < A.nl
     int bx, by_, bz_; \
     if (A.xcd) { const unsigned id = blockIdx.x, rest = id >> 3, p = (rest / (unsigned)A.nzn) * 8 + (id & 7); bx = (int)(p & 15); by_ = (int)(p >> 4); bz_ = (int)(rest % (unsigned)A.nzn); } \
     else { bx = (int)blockIdx.x; by_ = (int)blockIdx.y; bz_ = (int)blockIdx.z; } \
-    const int y = A.rowlist[by_], zi = bz_ % A.nz, img = bz_ / A.nz; if (hc_mm_skip(A, y, zi)) return; \
+    const int y = by_ + (by_ >= A.gap_lo ? A.gap_len : 0), zi = bz_ % A.nz, img = bz_ / A.nz; if (hc_mm_skip(A, y, zi)) return; \
     const HcRowMod R = hc_const_copy(&A.M[hc_mm_mod(A, y)]); \
     in += (size_t)zi * A.zs_in + (size_t)img * A.is_in; out += (size_t)zi * A.zs_out + (size_t)img * A.is_out;
 // (Round 4, measured and not kept - profiles/round4_chain_class_paths_ab.txt: butterflies per modulus class inside these kernels - 32-bit canonical arithmetic for the

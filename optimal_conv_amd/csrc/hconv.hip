@@ -624,7 +624,7 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
     char n1[48], n2[48]; snprintf(n1, sizeof n1, "%s:cols_fwd_mm", tag); snprintf(n2, sizeof n2, "%s:rows_fwd_canon_mm", tag);
     const size_t zt = (size_t)rows * HC_N, it = zt * (size_t)z;
     if (rows > 48) return hc_fail(c, HC_ERR_UNSUPPORTED, "batched transform over more than 48 rows");
-    for (int y = 0; y < rows; y++) A.rowlist[y] = (unsigned char)y;
+    A.gap_lo = rows; A.gap_len = 0;                                          // every row is in the grid
     const dim3 grid(16, (unsigned)rows, (unsigned)(z * n));
     A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it;
     if (fuse && fuse->lift_level > 0) { A.lift_level = fuse->lift_level; if (!fuse->lift_t) { A.zs_in = (size_t)HC_N; A.is_in = (size_t)z * HC_N; } }
@@ -654,8 +654,10 @@ static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int 
     char n1[48], n2[48]; snprintf(n1, sizeof n1, "%s:rows_inv_mm", tag); snprintf(n2, sizeof n2, "%s:cols_inv_canon_mm", tag);
     const size_t zt = (size_t)rows * HC_N, it = zt * (size_t)z;
     if (rows > 48) return hc_fail(c, HC_ERR_UNSUPPORTED, "batched transform over more than 48 rows");
-    int cnt = 0;                                           // rows in [skip_lo, skip_hi) have nothing to do: not in the grid
-    for (int y = 0; y < rows; y++) if (!(y >= skip_lo && y < skip_hi)) A.rowlist[cnt++] = (unsigned char)y;
+    // rows in [skip_lo, skip_hi) have nothing to do: not in the grid
+    const int s_lo = skip_lo < 0 ? 0 : (skip_lo > rows ? rows : skip_lo), s_hi = skip_hi < s_lo ? s_lo : (skip_hi > rows ? rows : skip_hi);
+    const int cnt = rows - (s_hi - s_lo);
+    A.gap_lo = s_lo; A.gap_len = s_hi - s_lo;
     const dim3 grid(16, (unsigned)cnt, (unsigned)(z * n));
     A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; A.xcd = c->xcd_rows; A.nzn = z * n;
     A.pk_in = c->pack32 == 2; A.pk_out = c->pack32;                          // the caller's NTT-domain rows; the seam (ws_tmp)
