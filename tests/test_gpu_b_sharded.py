@@ -139,3 +139,24 @@ def test_bench_two_gloo_ranks_on_one_gpu_carries_configs_3_and_5(tmp_path):
     assert rn.get("n_gpus") == 2 and rn["images_per_hour"] > 0 and rn["images_per_launch_set"] == 2, rn
     cr = j["workloads"]["convReLU_5_1"]
     assert cr["ms_per_ct_layer_throughput"] > 0 and cr["layer_latency_ms"] >= cr["ms_per_ct_layer_throughput"] and cr.get("ms_per_layer_n1", 0) > 0, cr
+    # the first record from a multi-GPU box is also a correctness record (round 6): both sharded forms against the CPU oracle, the chain against the reference binary's digests
+    pk = j["parity_check"]
+    assert pk["sharded_conv"] == "ok" and pk["sharded_conv_rccl_gather"] == "ok" and pk["convReLU_5_1"] == "ok", pk
+
+
+def test_bench_line_validates_itself_on_gpu():
+    """the one record the driver takes carries its own proof. bench.py (N = 1, the driver's flags but fewer steps) feeds ciphertext 0 of context 0 the planted
+    inputs the oracle gets, clears every output before the timed region, and compares all 131 072 words of what the LAST timed step left with the oracle's; the convReLU 5 1
+    launch set (4 images) runs once more on the input and keys planted into the reference binary and must print the binary's three SHA-256 digests. rc = 0 only if both hold."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--resnet-images", "16"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    pk = j["parity_check"]
+    assert pk["conv_3_3"] == "ok" and pk["convReLU_5_1"] == "ok", pk
+    d = pk["convReLU_5_1_digests"]
+    assert d["match"] and all(d[k]["equals_reference_binary"] and len(d[k]["sha256"]) == 2 for k in ("ctos0", "ctos1", "final")), d
+    assert "B=256, n=4, chunk=512, 4 contexts" in pk["what"]                         # the timed configuration itself
+    assert j["cpu_baseline"]["kind"] == "port" and "SAME planted inputs" in j["cpu_baseline"]["sample"]
+    cr = j["workloads"]["convReLU_5_1"]
+    assert 0 < cr["valu_frac"] < 1 and cr["issue_floor_ms"] > 0 and cr["lane_instr_per_ct_layer"] > 0, {k: cr.get(k) for k in ("valu_frac", "issue_floor_ms")}

@@ -20,3 +20,6 @@ PYTHONPATH=$R/tests python -c "import golden.gen_resnet_csv as g; g.write_case('
 HCONV_IMAGE_BATCH=8 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/resnet_stats -o run -- $R/optimal_conv_amd/host/conv resnet 3 20 1 16 false > $O/resnet_stats.log 2>&1
 grep -E "^Total done|images done" $O/resnet_stats.log | tail -4
 ls $O
+# gpurun pulls at most 64 MiB back: the raw per-dispatch CSVs (hundreds of MB) have been reduced to the tables above
+find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
+du -sh $O
