@@ -197,12 +197,9 @@ def test_conv_relu_cli_replays_the_reference_sparse_ctos(tmp_path):
     assert (lv, sc) == (want["level"], want["scale"]) and polys == want["polys"], "the host's sparse BootstrappConv_CtoS differs from the reference binary"
 
 
-# wide_case 2 / 3 (testResNet_crop_sparse_wide) and the CIFAR-100 head are outside SURVEY.md section 8's rows (section 2 row 14): they run only
-# with HCONV_TEST_WIDE=1, so that the default -m gpu run spends its minutes on the in-scope rows
-_WIDE = pytest.mark.skipif(not os.environ.get("HCONV_TEST_WIDE"), reason="out-of-scope resnet variants: set HCONV_TEST_WIDE=1")
-
-
-@pytest.mark.parametrize("cf100,wide", [(False, 1), pytest.param(True, 1, marks=_WIDE), pytest.param(False, 2, marks=_WIDE), pytest.param(False, 3, marks=_WIDE)])
+# wide_case 2 / 3 (testResNet_crop_sparse_wide) and the CIFAR-100 head are outside SURVEY.md section 8's rows (section 2 row 14): removed from the host in round 6; the CLI refuses
+# them (tests/test_host_cpu.py::test_resnet_cli_refuses_the_out_of_scope_variants)
+@pytest.mark.parametrize("cf100,wide", [(False, 1)])
 def test_resnet_cli_depth8(tmp_path, cf100, wide):
     """`resnet 3 8 1 1 false` (scope row 8f-3; the reference's depth-8 variant of BASELINE.md config 5): encrypted inference with
     synthetic weights in the reference's file layout; the class scores must follow the plain float model of the same network"""

@@ -75,3 +75,18 @@ def test_oracle_end_to_end_semantics(k, i_batch, min_bits):
     err = np.abs(out - gen.plain_conv(x, ker, bna, bnb).reshape(-1))
     prec = -np.log2(np.maximum(err, 2.0 ** -40))
     assert np.median(prec) >= min_bits, f"median precision {np.median(prec):.1f} bits"
+
+
+def test_resnet_cli_refuses_the_out_of_scope_variants(tmp_path):
+    """the wide networks (wide_case 2 / 3) and the CIFAR-100 head are out of scope; the product CLI says so and exits like a Go panic (status 2) before it
+    touches a device, instead of carrying code nobody asked for."""
+    import subprocess
+    cli = os.path.join(ROOT, "optimal_conv_amd", "host", "conv")
+    if not os.path.exists(cli):
+        import __graft_entry__
+        __graft_entry__.build()
+    for argv in (["resnet", "3", "20", "2", "1", "false"], ["resnet", "3", "20", "3", "1", "false"], ["resnet", "3", "20", "1", "1", "true"]):
+        r = subprocess.run([cli] + argv, cwd=tmp_path, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 2 and "out of scope" in r.stderr, (argv, r.returncode, r.stderr[-300:])
+    r = subprocess.run([cli, "resnet", "3", "20", "4", "1", "false"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "Wrong wide case!" in r.stderr                       # main.go:628
