@@ -2368,6 +2368,103 @@ __global__ __launch_bounds__(HC_TPB, HC_MM_WAVES_INV) void hc_k_cols_inv_canon_m
     else if (A.pk_in && small) hc_cols_inv_canon_mm_body<true>(in, out, lds, R, y, yo, A.pk_out && small, scale);
     else hc_cols_inv_canon_mm_body<false>(in, out, lds, R, y, yo, A.pk_out && small, scale);
 }
+// ---- the two batched inverse passes on QUARTER tiles (round 6): for launches of a few hundred workgroups. A key switch's ModDown transforms alpha rows per polynomial, a Rescale one
+// row: 80-1 300 workgroups of the kernels above - at most one round on 256 CUs - whose duration is what ONE workgroup takes (13-16 us at one image per launch set, where 560 such
+// launches are 4 of a layer's 23 ms). As for the small levels of the pack tree (hc_k_sb1..5), a quarter of the tile per workgroup - 4 rows x 256 (rows pass: in registers, cross-lane
+// exchanges, no LDS, no barrier) or 256 rows x 4 columns (cols pass: four radix-4 rounds in 8 KiB of LDS) - is four residues per thread instead of sixteen and four times the
+// workgroups. One 64-bit body for every modulus (the 64-bit tables exist for the ~30-bit limbs too); same seam layout, every stored value canonical (or the seam's lazy < 4q / < 2q):
+// the same residues as the 16-row kernels, which a launch may be given to instead (option small_mm_wgs).
+__global__ __launch_bounds__(HC_STPB) void hc_k_rows_inv_mm_s(const u64 *in, u64 *out, HcMm A) {
+    HC_MM_PROLOGUE
+    const int t = threadIdx.x, line = t >> 6, u = t & 63, grow = (int)blockIdx.x * 4 + line;
+    const HcQ Q = hc_q(R.q);
+    const bool small = HC_SMALL_Q(R.q), in32 = A.pk_in && small;            // block-uniform
+    HcTw w[12]; hc_s_tw_load_inv<true>(w, R.inv, grow, u);
+    const size_t pbase = (size_t)y * 65536, p0 = (size_t)grow * 256 + 4 * u;
+    u64 e[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) e[j] = hc_ldp(in + pbase, p0 + j, in32);
+    hc_s_pass_inv_reg(e, w, Q);                                              // e[j] = element (grow, u + 64 j), lazy < 4q
+    if (A.pk_out && small) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) hc_st32(out + pbase, (size_t)grow * 256 + j * 64 + u, hc_fold(e[j], Q.nq2));
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) out[pbase + (size_t)grow * 256 + j * 64 + u] = e[j];
+}
+__global__ __launch_bounds__(HC_STPB) void hc_k_cols_inv_canon_mm_s(const u64 *in, u64 *out, HcMm A) {
+    __shared__ u64 lds[HC_S_LDS];
+    HC_MM_PROLOGUE
+    const int t = threadIdx.x, line = t & 3, u = t >> 2, col = HC_S_CTILE * 4 + line;
+    const HcQ Q = hc_q(R.q);
+    const bool small = HC_SMALL_Q(R.q), in32 = A.pk_in && small, out32 = A.pk_out && small;      // block-uniform
+    const int yo = A.out_gap > 0 ? y + y / A.out_gap : y;
+    HcTw w[12]; hc_s_tw_load_inv<false>(w, R.inv, 0, u);
+    const size_t pbase = (size_t)y * 65536;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int r = k * 64 + u; lds[r * 4 + line] = hc_ldp(in + pbase, (size_t)r * 256 + col, in32); }
+    __syncthreads();
+    hc_s_pass_inv<false, true>(lds, R.inv, w, line, u, Q);                   // incl. N^-1; lazy < 4q, natural order
+    const size_t obase = (size_t)yo * 65536;
+    HcTw sc{0, 0};
+    const bool scaled = A.epi_mul != nullptr;                                // y_i = x_i (S/s_i)^-1 (hc_cols_inv_canon_mm_body)
+    if (scaled) sc = HC_TW_LOADK(A.epi_mul + y, 0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int r = k * 64 + u;
+        const u64 v = lds[r * 4 + line], o = scaled ? hc_mul_shoup(v, sc.w, sc.ws, R.q) : hc_canon4(v, Q);
+        if (out32) hc_st32(out + obase, (size_t)r * 256 + col, o); else out[obase + (size_t)r * 256 + col] = o;
+    }
+}
+// the second forward pass on quarter tiles (as the two inverse passes above): rows pass in registers, canonical, then hc_k_rows_fwd_canon_mm's epilogue - (x - result) c (+ addend [c']) -
+// element by element (a thread holds four consecutive coefficients of its row). Same seam, same residues.
+__global__ __launch_bounds__(HC_STPB) void hc_k_rows_fwd_canon_mm_s(const u64 *in, u64 *out, HcMm A) {
+    HC_MM_PROLOGUE
+    const int t = threadIdx.x, line = t >> 6, u = t & 63, grow = (int)blockIdx.x * 4 + line;
+    const u64 rq = R.q;
+    const HcQ Q = hc_q(rq);
+    const bool small = HC_SMALL_Q(rq);                                       // block-uniform
+    HcTw w[12]; hc_s_tw_load_fwd<true>(w, R.fwd, grow, u);
+    const size_t pbase = (size_t)y * 65536, rbase = (size_t)grow * 256;
+    u64 e[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) e[j] = hc_ldp(in + pbase, rbase + j * 64 + u, A.pk_in && small);
+    hc_s_pass_fwd_reg(e, w, Q);                                              // e[j] = element (grow, 4 u + j), lazy < 8q
+#pragma unroll
+    for (int j = 0; j < 4; j++) e[j] = hc_canon8(e[j], Q);
+    const size_t lj = rbase + 4 * u;
+    if (A.epi_x != nullptr) {                                                // block-uniform
+        const bool e32 = A.pk_epi && small;
+        const u64 *x = A.epi_x + (size_t)zi * A.epi_x_zs + (size_t)img * A.epi_x_is + pbase;
+        u64 *orow = out + pbase;
+        const HcTw wm = A.epi_mul[y];
+        const u64 *ad = A.epi_add != nullptr ? A.epi_add + (size_t)zi * A.epi_add_zs + (size_t)img * A.epi_add_is + pbase : nullptr;
+        const bool scaled = A.epi_add_mul != nullptr;
+        const HcTw wa = scaled ? A.epi_add_mul[y] : HcTw{0, 0};
+        u64 xv[4], av[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; j++) xv[j] = hc_ldp(x, lj + j, e32);
+        if (ad != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) av[j] = hc_ldp(ad, lj + j, e32);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            u64 r = hc_mul_shoup(hc_submod(xv[j], e[j], rq), wm.w, wm.ws, rq);
+            if (ad != nullptr) r = hc_addmod(r, scaled ? hc_mul_shoup(av[j], wa.w, wa.ws, rq) : av[j], rq);
+            if (e32) hc_st32(orow, lj + j, r); else orow[lj + j] = r;
+        }
+        return;
+    }
+    if (A.pk_out && small) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) hc_st32(out + pbase, lj + j, e[j]);
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) out[pbase + lj + j] = e[j];
+}
 // ModDown fused with the Rescale behind it (hc_keyswitch_add_rescale), the last limb L. Rescale needs the coefficients of c_L = (acc_L - NTT(ext_L)) / P + add_L:
 // by linearity InvNTT(acc_L / P + add_L) - ext_L / P, ext_L being the coefficient-domain extension the y_i / v rows give. acc_L <- acc_L / P + add_L where the inner product writes that row (hc_k_ks_mac_all, HcMacPrep; hc_k_mdrs_prep for an acc that comes from elsewhere), in
 // place (NTT domain; row L of acc is scratch from here on); then t = u - ext_L / P over the inverse transform u of that row (row 0 of pc[z]), in the epilogue of the source-side kernel (hc_k_basis_yv<true>).

@@ -120,6 +120,7 @@ struct hc_ctx {
     struct CacheBlk { size_t n = 0; hipEvent_t ev = nullptr; bool pending = false; };
     std::map<char *, CacheBlk> cache_blk; std::map<size_t, std::vector<void *>> cache_free;      // HCONV_ASYNC_ALLOC=1: sizes of the blocks this context allocated; parked blocks by size
     int async_alloc = 0;                                    // option async_alloc = 1: non-blocking stream + cached allocations (see hcx_malloc)
+    long small_mm_wgs = 1024;                               // option small_mm_wgs: a batched inverse pass / second forward pass of at most this many 16-row workgroups runs on quarter tiles (0: never); measured 512 .. 32 768: profiles/round6_chain_probes.txt
     long allocs_live = 0;                                   // hc_malloc blocks not yet freed (the allocation mode may only change while there are none)
     HcRowMod *d_rowmods = nullptr;                          // per modulus: both twiddle tables + q, mu (multi-modulus batched transforms)
     u64 *ws_mm = nullptr; size_t ws_mm_rows = 0;            // scratch of the batched key switch / rescale
@@ -642,6 +643,8 @@ static int hc_ntt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int s
     A.pk_in = c->pack32; A.pk_out = ((c->pack32 && fuse && fuse->out_packed) || user32) ? 1 : 0; A.pk_epi = user32;
     if (fuse && fuse->epi_x) { A.epi_x = fuse->epi_x; A.epi_x_zs = fuse->epi_x_zs; A.epi_x_is = fuse->epi_x_is; A.epi_mul = fuse->epi_mul; A.epi_add = fuse->epi_add; A.epi_add_zs = fuse->epi_add_zs; A.epi_add_is = fuse->epi_add_is; A.epi_add_mul = fuse->epi_add_mul; }
     A.xcd = c->xcd_rows; A.nzn = z * n;
+    // a second pass of at most about a round of 16-row workgroups: on quarter tiles (hc_k_rows_fwd_canon_mm_s)
+    if ((long)16 * rows * z * n <= c->small_mm_wgs) { A.xcd = 0; HC_TRY(hc_launch<HC_STPB>(c, c->profile ? n2 : "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm_s, dim3(HC_STILES, (unsigned)rows, (unsigned)(z * n)), (const u64 *)c->ws_tmp, out, A)); return HC_OK; }
     HC_TRY(hc_launch(c, c->profile ? n2 : "rows_fwd_canon_mm", hc_k_rows_fwd_canon_mm, A.xcd ? dim3(16u * (unsigned)rows * (unsigned)(z * n)) : grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
@@ -661,9 +664,15 @@ static int hc_intt_mm(hc_ctx *c, const u64 *in, u64 *out, int rows, int nl, int 
     const dim3 grid(16, (unsigned)cnt, (unsigned)(z * n));
     A.zs_in = zs_in; A.is_in = is_in; A.zs_out = zt; A.is_out = it; A.xcd = c->xcd_rows; A.nzn = z * n;
     A.pk_in = c->pack32 == 2; A.pk_out = c->pack32;                          // the caller's NTT-domain rows; the seam (ws_tmp)
-    HC_TRY(hc_launch(c, c->profile ? n1 : "rows_inv_mm", hc_k_rows_inv_mm, A.xcd ? dim3(16u * (unsigned)cnt * (unsigned)(z * n)) : grid, in, c->ws_tmp, A));
+    // a launch of a few hundred workgroups costs what ONE workgroup takes: quarter tiles (four residues per thread, four times the workgroups) then
+    const bool quarter = (long)16 * cnt * z * n <= c->small_mm_wgs;
+    const dim3 sgrid(HC_STILES, (unsigned)cnt, (unsigned)(z * n));
+    if (quarter) { A.xcd = 0; HC_TRY(hc_launch<HC_STPB>(c, c->profile ? n1 : "rows_inv_mm", hc_k_rows_inv_mm_s, sgrid, in, c->ws_tmp, A)); }
+    else HC_TRY(hc_launch(c, c->profile ? n1 : "rows_inv_mm", hc_k_rows_inv_mm, A.xcd ? dim3(16u * (unsigned)cnt * (unsigned)(z * n)) : grid, in, c->ws_tmp, A));
     A.xcd = 0; A.pk_in = c->pack32; A.pk_out = (c->pack32 == 2 && out_user) ? 1 : 0; A.epi_mul = out_scale; A.out_gap = out_gap;
-    A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out; HC_TRY(hc_launch(c, c->profile ? n2 : "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
+    A.zs_in = zt; A.is_in = it; A.zs_out = zs_out; A.is_out = is_out;
+    if (quarter) HC_TRY(hc_launch<HC_STPB>(c, c->profile ? n2 : "cols_inv_canon_mm", hc_k_cols_inv_canon_mm_s, sgrid, (const u64 *)c->ws_tmp, out, A));
+    else HC_TRY(hc_launch(c, c->profile ? n2 : "cols_inv_canon_mm", hc_k_cols_inv_canon_mm, grid, (const u64 *)c->ws_tmp, out, A));
     return HC_OK;
 }
 static int hc_ensure_mm(hc_ctx *c, size_t rows) {
@@ -1857,6 +1866,7 @@ extern "C" int hc_set_option(hc_ctx *c, const char *name, long value) {
     if (!strcmp(name, "small_levels")) { if (value < 0) return hc_fail(c, HC_ERR_ARG, "small_levels must be >= 0"); c->small_levels = value; return HC_OK; }
     if (!strcmp(name, "peer_access")) { c->peer_access = value ? 1 : 0; return HC_OK; }
     if (!strcmp(name, "profile")) { hc_prof_flush(c); c->profile = value ? 1 : 0; return HC_OK; }
+    if (!strcmp(name, "small_mm_wgs")) { if (value < 0) return hc_fail(c, HC_ERR_ARG, "small_mm_wgs must be >= 0"); c->small_mm_wgs = value; return HC_OK; }      // same residues either way
     if (!strcmp(name, "rot_fuse")) { c->rot_fuse = value ? 1 : 0; return HC_OK; }                  // same residues either way: A/B only
     if (!strcmp(name, "small32")) { HC_ENTER(c); c->small32 = value ? 1 : 0; HC_HIP(c, hipStreamSynchronize(c->stream)); return hc_upload_rowmods(c); }      // results do not depend on it (both forms leave canonical residues): A/B only
     if (!strcmp(name, "async_alloc")) {     // 0: hipMalloc / hipFree; 1: non-blocking stream + this context's cache of blocks (hcx_malloc); 2: diagnostic (ROCm's stream-ordered allocator)

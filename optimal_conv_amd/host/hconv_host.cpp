@@ -166,6 +166,7 @@ void applyEnvOptions(hc_ctx *hc, int pack32_default) {
     opt("HCONV_ASYNC_ALLOC", "async_alloc", -1);      // first: the allocation mode can only change while the context owns nothing but its tables
     opt("HCONV_SMALL32", "small32", -1);
     opt("HCONV_ROT_FUSE", "rot_fuse", -1);
+    opt("HCONV_SMALL_MM_WGS", "small_mm_wgs", -1);    // A/B: 16-row workgroups per pass up to which the batched inverse transforms run on quarter tiles (0: never)
     opt("HCONV_PACK32", "pack32", pack32_default);
 }
 

@@ -204,6 +204,26 @@ def test_transform_bodies_64_bit_for_the_small_limbs():
     pc.case_leveled_rows(mk, mo)
 
 
+@pytest.mark.parametrize("wgs", [0, 1 << 30], ids=["16-row kernels only", "quarter tiles always"])
+def test_batched_transforms_on_quarter_tiles_or_not(wgs):
+    """option small_mm_wgs (round 6): a batched inverse pass / second forward pass of few workgroups runs on quarter tiles (hc_k_*_mm_s: four residues per thread). The default
+    (1 024 workgroups) puts most launches of the small test shapes on them; here every launch takes ONE of the two forms - the oracle's residues either way, in both row formats."""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+
+    def mk(Q, P, pack=1):
+        ctx = Context(Q, P, lib_path=EMU_LIB)
+        ctx.set_option("small_mm_wgs", wgs)
+        return ctx
+    mo = lambda Q, P: Oracle(q=Q, p=P)
+    pc.case_keyswitch_general(mk, mo, shapes=((3, 2), (4, 5)))
+    pc.case_leveled_rows(mk, mo)
+
+    def mk2(Q, P):
+        ctx = mk(Q, P); ctx.set_option("pack32", 2)
+        return ctx
+    pc.case_keyswitch_general(mk2, mo, shapes=((4, 3),))
+
+
 @pytest.mark.parametrize("case", ["general", "hoisted", "qp"])
 def test_key_switch_with_four_byte_rows(case):
     """the key-switch cases above, unchanged, on a context in pack32 = 2: the binding converts at the boundary, the residues are the oracle's"""

@@ -650,6 +650,27 @@ def test_transform_bodies_64_bit_for_the_small_limbs_on_gpu():
     pc.case_keyswitch_qp_mod_down(mk, mo, level=4, alpha=5, nkeys=2)
 
 
+@pytest.mark.parametrize("wgs", [0, 1 << 30], ids=["16-row kernels only", "quarter tiles always"])
+def test_batched_transforms_on_quarter_tiles_or_not_on_gpu(wgs):
+    """option small_mm_wgs (round 6): every batched inverse pass / second forward pass on the 16-row kernels, or every one on the quarter-tile kernels (hc_k_*_mm_s; the default
+    picks by launch size): the oracle's residues either way - key switches of one to five digits, every leveled entry point row by row, ModDown in the extended basis, 4-byte rows"""
+    from optimal_conv_amd import Context
+
+    def mk(Q, P):
+        ctx = Context(Q, P)
+        ctx.set_option("small_mm_wgs", wgs)
+        return ctx
+    mo = lambda Q, P: Oracle(q=Q, p=P)
+    pc.case_keyswitch_general(mk, mo, shapes=((3, 2), (4, 3), (4, 5)))
+    pc.case_leveled_rows(mk, mo)
+    pc.case_keyswitch_qp_mod_down(mk, mo, level=4, alpha=5, nkeys=2)
+
+    def mk2(Q, P):
+        ctx = mk(Q, P); ctx.set_option("pack32", 2)
+        return ctx
+    pc.case_keyswitch_general(mk2, mo, shapes=((4, 3),))
+
+
 def test_key_switch_with_four_byte_rows_on_gpu():
     """the key-switch cases above, unchanged, on a context in pack32 = 2"""
     mo = lambda Q, P: Oracle(q=Q, p=P)
