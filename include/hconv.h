@@ -306,7 +306,8 @@ int hc_set_option(hc_ctx *ctx, const char *name, long value); /* "chunk_nodes" (
                                                                   "peer_access" (hc_conv_then_pack_sharded: 0 = do not enable direct peer copies; default 1: enabled where hipDeviceCanAccessPeer allows),
                                                                   "pack32" (0 / 1 / 2: 4-byte rows, above), "rot_fuse" (default 1: hc_keyswitch_qp_rotate_many stores every rotation's result already permuted and with P c0 added from inside the inner
                                                                   product; 0: one pass per rotation over the accumulators - same residues, an A/B switch), "small32" (default 1: rows of a modulus below 2^31 take the 32-bit body of the batched
-                                                                  transform kernels; 0: the 64-bit body for every row - the same residues either way, an A/B switch), "async_alloc" (0, default: hipMalloc / hipFree; 1: a non-blocking stream and a per-context cache of blocks, so that hc_free never
+                                                                  transform kernels; 0: the 64-bit body for every row - the same residues either way, an A/B switch), "small_mm_wgs" (default 1024: a batched inverse pass / second forward pass of at most this many 16-row workgroups runs on quarter tiles - four residues per thread, four times the
+                                                                  workgroups: such a launch costs one workgroup's latency; 0: never - the same residues either way), "async_alloc" (0, default: hipMalloc / hipFree; 1: a non-blocking stream and a per-context cache of blocks, so that hc_free never
                                                                   drains the device - for several contexts driven from several host threads; only right after hc_ctx_create, HC_ERR_STATE once the context owns memory) */
 /* HIP-event timing on the context's stream */
 int hc_timer_start(hc_ctx *ctx);
