@@ -302,6 +302,15 @@ void or_div_round_last_ntt(const or_ctx *c, int level, const uint64_t *x, uint64
     free(t); free(u); free(v);
 }
 
+/* the OpenMP team of the general-level key switch's row loops (test infrastructure only; bench.py's cpu_baseline times or_conv_then_pack, which is single-threaded).
+ * Set by the loader (tests/oracle_lib.py) through this call, NOT through OMP_NUM_THREADS: an environment variable would be inherited by every subprocess a test starts. */
+#ifdef _OPENMP
+#include <omp.h>
+void or_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+void or_set_threads(int n) { (void)n; }
+#endif
+
 /* ---------- key switching (lattigo rlwe.(*KeySwitcher).SwitchKeysInPlace[NoModDown], DecomposeSingleNTT,
  * ring.(*Decomposer).DecomposeAndSplit, ring.(*FastBasisExtender).ModDownSplitNTTPQ, ring.modUpExact;
  * test_run @0x4fdd40, @0x4fe660, @0x4fe260, @0x4e6400, @0x4e4c40, @0x4e5700) ---------- */

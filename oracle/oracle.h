@@ -137,6 +137,8 @@ void or_decrypt_decode_l0(const or_ctx *, const int64_t *sk_coeffs, const uint64
 /* counter-based splitmix64 residues (shared with oracle/pin/gotrace.c and the tests) */
 void or_fill_seeded(uint64_t seed, uint64_t q, int n, uint64_t *out);
 
+/* threads of the oracle's OpenMP row loops (default: the runtime's); see oracle.c */
+void or_set_threads(int n);
 #ifdef __cplusplus
 }
 #endif

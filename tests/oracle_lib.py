@@ -41,8 +41,10 @@ def lib():
     if _lib is None:
         # the oracle's general-level key switch runs its independent rows on OpenMP threads (oracle/Makefile): at most 16 of them - a GPU box has 256 cores and the multi-process
         # tests load this library once per rank
-        os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
         L = C.CDLL(build())
+        L.or_set_threads.argtypes = [C.c_int]
+        if "OMP_NUM_THREADS" not in os.environ:          # through the library, not the environment: subprocesses of a test (CLI runs, torch.distributed ranks) must not inherit it
+            L.or_set_threads(min(16, os.cpu_count() or 1))
         L.or_ctx_new.restype = C.c_void_p
         L.or_ctx_new.argtypes = [C.c_int, u64p, C.c_int, u64p, C.c_int]
         L.or_ctx_free.argtypes = [C.c_void_p]

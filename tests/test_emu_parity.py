@@ -224,6 +224,19 @@ def test_batched_transforms_on_quarter_tiles_or_not(wgs):
     pc.case_keyswitch_general(mk2, mo, shapes=((4, 3),))
 
 
+def test_key_switch_with_unpacked_rows():
+    """option pack32 = 0 (advertised, untested): keys and digits stay 8-byte words in Montgomery form, the inner products take their generic path (pk = 0)"""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, EMU_LIB])
+
+    def mk(Q, P):
+        ctx = Context(Q, P, lib_path=EMU_LIB)
+        ctx.set_option("pack32", 0)
+        return ctx
+    mo = lambda Q, P: Oracle(q=Q, p=P)
+    pc.case_keyswitch_general(mk, mo, shapes=((3, 2), (4, 5)))
+    pc.case_keyswitch_hoisted(mk, mo)
+
+
 @pytest.mark.parametrize("case", ["general", "hoisted", "qp"])
 def test_key_switch_with_four_byte_rows(case):
     """the key-switch cases above, unchanged, on a context in pack32 = 2: the binding converts at the boundary, the residues are the oracle's"""

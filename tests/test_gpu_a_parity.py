@@ -671,6 +671,20 @@ def test_batched_transforms_on_quarter_tiles_or_not_on_gpu(wgs):
     pc.case_keyswitch_general(mk2, mo, shapes=((4, 3),))
 
 
+def test_key_switch_with_unpacked_rows_on_gpu():
+    """option pack32 = 0 (advertised, untested): 8-byte Montgomery key rows and digits, the inner products' generic path"""
+    from optimal_conv_amd import Context
+
+    def mk(Q, P):
+        ctx = Context(Q, P)
+        ctx.set_option("pack32", 0)
+        return ctx
+    mo = lambda Q, P: Oracle(q=Q, p=P)
+    pc.case_keyswitch_general(mk, mo, shapes=((3, 2), (4, 3), (4, 5)))
+    pc.case_keyswitch_hoisted(mk, mo)
+    pc.case_keyswitch_qp_mod_down(mk, mo, level=4, alpha=5, nkeys=2)
+
+
 def test_key_switch_with_four_byte_rows_on_gpu():
     """the key-switch cases above, unchanged, on a context in pack32 = 2"""
     mo = lambda Q, P: Oracle(q=Q, p=P)
