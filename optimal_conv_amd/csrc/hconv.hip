@@ -120,7 +120,12 @@ struct hc_ctx {
     struct CacheBlk { size_t n = 0; hipEvent_t ev = nullptr; bool pending = false; };
     std::map<char *, CacheBlk> cache_blk; std::map<size_t, std::vector<void *>> cache_free;      // HCONV_ASYNC_ALLOC=1: sizes of the blocks this context allocated; parked blocks by size
     int async_alloc = 0;                                    // option async_alloc = 1: non-blocking stream + cached allocations (see hcx_malloc)
+#ifdef HC_EMU
+    long small_mm_wgs = 0;                                  // the CPU emulator pays per fiber switch, and the quarter-tile rows passes exchange through 24 of them: the emulated suites run the 16-row
+                                                            // kernels unless a test asks (tests/test_emu_parity.py::test_batched_transforms_on_quarter_tiles_or_not forces each form)
+#else
     long small_mm_wgs = 1024;                               // option small_mm_wgs: a batched inverse pass / second forward pass of at most this many 16-row workgroups runs on quarter tiles (0: never); measured 512 .. 32 768: profiles/round6_chain_probes.txt
+#endif
     long allocs_live = 0;                                   // hc_malloc blocks not yet freed (the allocation mode may only change while there are none)
     HcRowMod *d_rowmods = nullptr;                          // per modulus: both twiddle tables + q, mu (multi-modulus batched transforms)
     u64 *ws_mm = nullptr; size_t ws_mm_rows = 0;            // scratch of the batched key switch / rescale
